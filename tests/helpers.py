@@ -1,0 +1,37 @@
+"""Shared test helpers: named model configs, seeded state-dicts and inputs (same recipes as tools/gen_golden.py)."""
+import numpy as np
+import torch
+
+from deepfilternet_amd.config import ModelParams
+from deepfilternet_amd.state_dict import random_state_dict
+from oracle import libdf_oracle as L
+
+
+def named_params(name: str) -> ModelParams:
+    if name == "defaults":
+        return ModelParams.defaults()
+    if name == "df3":
+        return ModelParams.deepfilternet3()
+    if name == "pf32":
+        p = ModelParams.defaults()
+        p.mask_pf, p.df_lookahead, p.conv_lookahead = True, 1, 1
+        p.df_gru_skip, p.df_pathway_kernel_size_t, p.conv_ch = "identity", 3, 32
+        return p
+    raise KeyError(name)
+
+
+GOLDEN_SEEDS = {"defaults": 0, "df3": 1, "pf32": 2}
+
+
+def widths_for(p: ModelParams) -> np.ndarray:
+    return L.erb_fb_widths(p.sr, p.fft_size, p.nb_erb, p.min_nb_freqs)
+
+
+def torch_sd(p: ModelParams, seed: int):
+    sd = random_state_dict(p, seed, widths=widths_for(p))
+    return {k: torch.as_tensor(v) for k, v in sd.items()}
+
+
+def rms(a):
+    a = np.asarray(a)
+    return float(np.sqrt(np.mean(np.abs(a) ** 2)))
