@@ -1,0 +1,27 @@
+"""deepfilternet_amd — MI355X-native engine for DeepFilterNet's enhance() hot path (HIP kernels behind a C ABI).
+
+Public surface mirrors the reference (DeepFilterNet/df/__init__.py:1-6 + the pyDF ``libdf`` module):
+    from deepfilternet_amd import init_df, enhance, df_features, ModelParams
+    from deepfilternet_amd import libdf          # DF, erb, erb_inv, erb_norm, unit_norm, unit_norm_init
+"""
+from .config import ModelParams  # noqa: F401
+
+__version__ = "0.1.0"
+__all__ = ["ModelParams", "init_df", "enhance", "df_features", "DfNet", "libdf"]
+
+
+def __getattr__(name):
+    # lazy: importing the package must not require torch/HIP until something is used
+    if name in ("init_df", "enhance", "df_features"):
+        from . import enhance as _e
+
+        return getattr(_e, name)
+    if name == "DfNet":
+        from .model import DfNet
+
+        return DfNet
+    if name == "libdf":
+        import importlib
+
+        return importlib.import_module(".libdf", __name__)
+    raise AttributeError(name)

@@ -1,0 +1,76 @@
+"""Builds deepfilternet_amd/csrc/libdfx.so with hipcc for gfx950 (MI355X).  In-tree, so the .so travels with the repo
+snapshot to the GPU box.  hipcc cross-compiles without a GPU; nothing here needs a device."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from typing import List
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+REPO = os.path.dirname(HERE)
+LIB = os.path.join(CSRC, "libdfx.so")
+SOURCES = ["dfx_dsp.hip", "dfx_model.hip"]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (ROCm toolchain required to build libdfx.so)")
+
+
+def sources() -> List[str]:
+    return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _deps() -> List[str]:
+    out = []
+    for root, _, files in os.walk(CSRC):
+        out += [os.path.join(root, f) for f in files if f.endswith((".h", ".hip"))]
+    out.append(os.path.join(REPO, "include", "dfx.h"))
+    return out
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in _deps())
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return LIB
+    bdir = os.path.join(CSRC, "_build")
+    os.makedirs(bdir, exist_ok=True)
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+             f"-I{os.path.join(REPO, 'include')}", f"-I{os.path.join(CSRC, 'env_hip')}", f"-I{CSRC}"]
+    objs = []
+    procs = []
+    for src in sources():
+        obj = os.path.join(bdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        cmd = [_hipcc(), *flags, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB + ".tmp"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

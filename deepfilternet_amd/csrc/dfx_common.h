@@ -1,0 +1,68 @@
+// Internal declarations shared by the dfx translation units (not part of the public ABI).
+#pragma once
+
+#include "dfx_env.h"
+
+#include <cstdarg>
+#include <string>
+#include <vector>
+
+#include "dfx.h"
+
+// ---- error plumbing ---------------------------------------------------------------------------------------------
+void dfx_set_error(const char *fmt, ...);
+#define DFX_FAIL(code, ...)         \
+    do {                            \
+        dfx_set_error(__VA_ARGS__); \
+        return (code);              \
+    } while (0)
+#define DFX_HIP(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess) DFX_FAIL(DFX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__));   \
+    } while (0)
+#define DFX_LAUNCH_CHECK()                                                                              \
+    do {                                                                                                \
+        hipError_t e__ = hipGetLastError();                                                             \
+        if (e__ != hipSuccess) DFX_FAIL(DFX_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e__)); \
+    } while (0)
+int dfx_require_device();
+
+// ---- FFT plan (passed by value into kernels) ----------------------------------------------------------------------
+#define DFX_MAX_STAGES 12
+struct DfxFftPlan {
+    int N;       // real FFT size
+    int M;       // complex FFT size = N/2
+    int nstage;  // number of Stockham passes
+    int radix[DFX_MAX_STAGES];
+};
+
+// ---- handles ------------------------------------------------------------------------------------------------------
+struct dfx_bands {
+    int nb = 0;
+    int F = 0;
+    std::vector<uint64_t> widths;
+    int *d_start = nullptr;               // [nb+1] first bin of each band
+    float *d_invw = nullptr;              // [nb]   1/width (f32 division, lib.rs:287)
+    unsigned char *d_bin2band = nullptr;  // [F]
+};
+
+struct dfx_state {
+    int sr = 0, N = 0, hop = 0, nb = 0, min_nb = 0;
+    float wnorm = 0.f;
+    DfxFftPlan plan{};
+    std::vector<float> window_host;
+    float *d_window = nullptr;  // [N]
+    float2 *d_tw = nullptr;     // [N] exp(-2*pi*i*k/N)
+    dfx_bands *bands = nullptr;
+};
+
+static inline hipStream_t dfx_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int64_t dfx_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- internal launchers shared between the DSP API and the model --------------------------------------------------
+int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_stride,
+                        const float *mem_in, float *mem_out, float *spec, float *erb_db, hipStream_t s);
+int dfx_launch_norm_scan(const float *erb_in, float *erb_out, int E, const float *spec_in, int64_t spec_frame_stride,
+                         float *spec_out, int Fn, int64_t C, int64_t T, float alpha, float *erb_state,
+                         float *unit_state, hipStream_t s);

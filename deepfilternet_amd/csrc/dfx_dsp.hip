@@ -1,0 +1,425 @@
+// Host side of the DSP half of libdfx: handles, argument validation, launch geometry and the C ABI declared in
+// include/dfx.h.  Device pointers in, device pointers out; nothing here computes on the CPU except the ERB width table
+// (pure index arithmetic done once at state creation, libDF/src/lib.rs:68-100).
+#include "dfx_dsp_kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+
+// ------------------------------------------------------------------------------------------------ errors / misc
+static thread_local char g_dfx_err[512] = "";
+
+void dfx_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_dfx_err, sizeof(g_dfx_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *dfx_last_error(void) { return g_dfx_err; }
+extern "C" int dfx_version(void) { return DFX_VERSION; }
+extern "C" int dfx_is_emulator(void) { return dfx_env_is_emulator() ? 1 : 0; }
+extern "C" const char *dfx_status_string(int s) {
+    switch (s) {
+        case DFX_OK: return "ok";
+        case DFX_ERR_INVALID_ARG: return "invalid argument";
+        case DFX_ERR_UNSUPPORTED: return "unsupported configuration";
+        case DFX_ERR_HIP: return "HIP runtime error";
+        case DFX_ERR_NO_DEVICE: return "no HIP device";
+        case DFX_ERR_ALLOC: return "allocation failed";
+        default: return "unknown";
+    }
+}
+extern "C" int dfx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int dfx_require_device() {
+    if (dfx_device_count() <= 0)
+        DFX_FAIL(DFX_ERR_NO_DEVICE, "no HIP device visible: libdfx has no CPU fallback (MI355X / gfx950 required)");
+    return DFX_OK;
+}
+
+template <typename T>
+static int upload(T **dst, const T *src, size_t n) {
+    DFX_HIP(hipMalloc(reinterpret_cast<void **>(dst), n * sizeof(T)));
+    DFX_HIP(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return DFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ band table
+extern "C" int dfx_bands_create(const uint64_t *widths, int nb, dfx_bands **out) {
+    if (!widths || nb <= 0 || nb > 255 || !out) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_bands_create: bad arguments (1..255 bands)");
+    if (int rc = dfx_require_device()) return rc;
+    dfx_bands *b = new dfx_bands();
+    b->nb = nb;
+    b->widths.assign(widths, widths + nb);
+    std::vector<int> start(nb + 1, 0);
+    std::vector<float> invw(nb);
+    for (int i = 0; i < nb; ++i) {
+        if (widths[i] == 0 || widths[i] > (1u << 20)) {
+            delete b;
+            DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_bands_create: band %d has width %llu", i, (unsigned long long)widths[i]);
+        }
+        start[i + 1] = start[i] + (int)widths[i];
+        invw[i] = 1.f / (float)widths[i];
+    }
+    b->F = start[nb];
+    std::vector<unsigned char> b2b(b->F);
+    for (int i = 0; i < nb; ++i)
+        for (int f = start[i]; f < start[i + 1]; ++f) b2b[f] = (unsigned char)i;
+    int rc = upload(&b->d_start, start.data(), start.size());
+    if (!rc) rc = upload(&b->d_invw, invw.data(), invw.size());
+    if (!rc) rc = upload(&b->d_bin2band, b2b.data(), b2b.size());
+    if (rc) {
+        dfx_bands_free(b);
+        return rc;
+    }
+    *out = b;
+    return DFX_OK;
+}
+extern "C" void dfx_bands_free(dfx_bands *b) {
+    if (!b) return;
+    if (b->d_start) (void)hipFree(b->d_start);
+    if (b->d_invw) (void)hipFree(b->d_invw);
+    if (b->d_bin2band) (void)hipFree(b->d_bin2band);
+    delete b;
+}
+extern "C" int dfx_bands_nb(const dfx_bands *b) { return b ? b->nb : 0; }
+extern "C" int dfx_bands_nfreqs(const dfx_bands *b) { return b ? b->F : 0; }
+
+// ------------------------------------------------------------------------------------------------ state
+static float freq2erb(float f) { return 9.265f * log1pf(f / (24.7f * 9.265f)); }           // lib.rs:42-44
+static float erb2freq(float e) { return 24.7f * 9.265f * (expf(e / 9.265f) - 1.f); }        // lib.rs:45-47
+
+// libDF/src/lib.rs:68-100 (f32 arithmetic, round-half-away like f32::round)
+extern "C" int dfx_erb_fb(int sr, int fft_size, int nb_bands, int min_nb_freqs, uint64_t *erb) {
+    if (sr <= 0 || fft_size <= 0 || nb_bands <= 0 || !erb) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_erb_fb: bad arguments");
+    const int nyq = sr / 2;
+    const float freq_width = (float)sr / (float)fft_size;
+    const float erb_low = freq2erb(0.f), erb_high = freq2erb((float)nyq);
+    const float step = (erb_high - erb_low) / (float)nb_bands;
+    int prev_freq = 0, freq_over = 0;
+    for (int i = 1; i <= nb_bands; ++i) {
+        const float f = erb2freq(erb_low + (float)i * step);
+        const int fb = (int)roundf(f / freq_width);
+        int nb_freqs = fb - prev_freq - freq_over;
+        if (nb_freqs < min_nb_freqs) {
+            freq_over = min_nb_freqs - nb_freqs;
+            nb_freqs = min_nb_freqs;
+        } else {
+            freq_over = 0;
+        }
+        erb[i - 1] = (uint64_t)nb_freqs;
+        prev_freq = fb;
+    }
+    erb[nb_bands - 1] += 1;
+    int64_t sum = 0;
+    for (int i = 0; i < nb_bands; ++i) sum += (int64_t)erb[i];
+    const int64_t too_large = sum - (fft_size / 2 + 1);
+    if (too_large > 0) erb[nb_bands - 1] -= (uint64_t)too_large;
+    return DFX_OK;
+}
+
+static int make_plan(int N, DfxFftPlan *pl) {
+    pl->N = N;
+    pl->M = N / 2;
+    pl->nstage = 0;
+    int rem = pl->M;
+    const int radices[4] = {4, 2, 3, 5};
+    for (int ri = 0; ri < 4; ++ri)
+        while (rem % radices[ri] == 0 && rem > 1) {
+            if (pl->nstage >= DFX_MAX_STAGES) return -1;
+            pl->radix[pl->nstage++] = radices[ri];
+            rem /= radices[ri];
+        }
+    return rem == 1 ? 0 : -1;
+}
+
+extern "C" int dfx_state_create(int sr, int fft_size, int hop_size, int nb_bands, int min_nb_erb_freqs, dfx_state **out) {
+    if (!out || sr <= 0 || fft_size <= 0 || hop_size <= 0 || nb_bands <= 0)
+        DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_state_create: bad arguments");
+    if (hop_size * 2 > fft_size) DFX_FAIL(DFX_ERR_INVALID_ARG, "assertion failed: hop_size * 2 <= fft_size");  // lib.rs:111
+    if (fft_size & 1) DFX_FAIL(DFX_ERR_UNSUPPORTED, "fft_size must be even");
+    if (fft_size > 4096) DFX_FAIL(DFX_ERR_UNSUPPORTED, "fft_size > 4096 is not supported by the LDS-resident FFT");
+    if ((fft_size + hop_size - 1) / hop_size > DFX_DSP_TEAMS)
+        DFX_FAIL(DFX_ERR_UNSUPPORTED, "fft_size/hop_size > %d overlapping frames is not supported", DFX_DSP_TEAMS);
+    if (int rc = dfx_require_device()) return rc;
+    dfx_state *st = new dfx_state();
+    st->sr = sr;
+    st->N = fft_size;
+    st->hop = hop_size;
+    st->nb = nb_bands;
+    st->min_nb = min_nb_erb_freqs;
+    if (make_plan(fft_size, &st->plan) != 0) {
+        delete st;
+        DFX_FAIL(DFX_ERR_UNSUPPORTED, "fft_size/2 = %d has a prime factor other than 2, 3, 5", fft_size / 2);
+    }
+    // vorbis window in f64, stored as f32 (lib.rs:126-133)
+    st->window_host.resize(fft_size);
+    const int window_size_h = fft_size / 2;
+    for (int i = 0; i < fft_size; ++i) {
+        const double s = sin(0.5 * M_PI * ((double)i + 0.5) / (double)window_size_h);
+        st->window_host[i] = (float)sin(0.5 * M_PI * s * s);
+    }
+    st->wnorm = 1.f / ((float)((int64_t)fft_size * (int64_t)fft_size) / (float)(2 * hop_size));  // lib.rs:134
+    std::vector<float2> tw(fft_size);
+    for (int k = 0; k < fft_size; ++k) {
+        const double a = -2.0 * M_PI * (double)k / (double)fft_size;
+        tw[k] = make_float2((float)cos(a), (float)sin(a));
+    }
+    std::vector<uint64_t> widths(nb_bands);
+    dfx_erb_fb(sr, fft_size, nb_bands, min_nb_erb_freqs, widths.data());
+    int rc = upload(&st->d_window, st->window_host.data(), st->window_host.size());
+    if (!rc) rc = upload(&st->d_tw, tw.data(), tw.size());
+    if (!rc) rc = dfx_bands_create(widths.data(), nb_bands, &st->bands);
+    if (!rc && st->bands->F != fft_size / 2 + 1) {
+        dfx_set_error("ERB widths sum to %d, expected %d", st->bands->F, fft_size / 2 + 1);
+        rc = DFX_ERR_INVALID_ARG;
+    }
+    if (rc) {
+        dfx_state_free(st);
+        return rc;
+    }
+    *out = st;
+    return DFX_OK;
+}
+extern "C" void dfx_state_free(dfx_state *st) {
+    if (!st) return;
+    if (st->d_window) (void)hipFree(st->d_window);
+    if (st->d_tw) (void)hipFree(st->d_tw);
+    dfx_bands_free(st->bands);
+    delete st;
+}
+extern "C" int dfx_state_sr(const dfx_state *st) { return st->sr; }
+extern "C" int dfx_state_fft_size(const dfx_state *st) { return st->N; }
+extern "C" int dfx_state_hop_size(const dfx_state *st) { return st->hop; }
+extern "C" int dfx_state_nb_erb(const dfx_state *st) { return st->nb; }
+extern "C" float dfx_state_wnorm(const dfx_state *st) { return st->wnorm; }
+extern "C" const dfx_bands *dfx_state_bands(const dfx_state *st) { return st->bands; }
+extern "C" int dfx_state_erb_widths(const dfx_state *st, uint64_t *out) {
+    if (!st || !out) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_state_erb_widths: null");
+    for (int i = 0; i < st->nb; ++i) out[i] = st->bands->widths[i];
+    return DFX_OK;
+}
+extern "C" int dfx_state_fft_window(const dfx_state *st, float *out) {
+    if (!st || !out) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_state_fft_window: null");
+    memcpy(out, st->window_host.data(), sizeof(float) * st->window_host.size());
+    return DFX_OK;
+}
+extern "C" int dfx_unit_norm_init(int n, float *out) {
+    if (n <= 0 || !out) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_unit_norm_init: bad arguments");
+    const float step = n > 1 ? (0.0001f - 0.001f) / (float)(n - 1) : 0.f;
+    for (int i = 0; i < n; ++i) out[i] = 0.001f + step * (float)i;
+    return DFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ launch helpers
+static size_t dsp_smem_bytes(const dfx_state *st) {
+    return (size_t)st->N * 12 + (size_t)DFX_DSP_TEAMS * 2 * (size_t)(st->plan.M + 2) * 8;
+}
+static int grid_for(int64_t work_groups) {
+    const int64_t cap = (int64_t)dfx_env_num_cus() * 8;  // memory-bound: ~8 workgroups per CU, grid-stride the rest
+    return (int)(work_groups < cap ? (work_groups > 0 ? work_groups : 1) : cap);
+}
+
+int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_stride,
+                        const float *mem_in, float *mem_out, float *spec, float *erb_db, hipStream_t s) {
+    const int64_t Tf = T / st->hop;
+    const int ML = st->N - st->hop;
+    if (B > 0 && Tf > 0) {
+        DfxAnaArgs A;
+        A.x = x;
+        A.mem_in = mem_in;
+        A.spec = reinterpret_cast<float2 *>(spec);
+        A.erb_db = erb_db;
+        A.window = st->d_window;
+        A.tw = st->d_tw;
+        A.band_start = st->bands->d_start;
+        A.band_invw = st->bands->d_invw;
+        A.B = B;
+        A.Tf = Tf;
+        A.x_stride = x_stride;
+        A.hop = st->hop;
+        A.nb = st->nb;
+        A.wnorm = st->wnorm;
+        A.plan = st->plan;
+        const size_t smem = dsp_smem_bytes(st);
+        if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_analysis, smem));
+        const int grid = grid_for(dfx_ceil_div(B * Tf, DFX_DSP_TEAMS));
+        dfx_launch(dfx_k_analysis, dim3(grid), dim3(DFX_DSP_THREADS), smem, s, A);
+        DFX_LAUNCH_CHECK();
+    }
+    if (mem_out && B > 0) {
+        const int64_t n = B * ML;
+        dfx_launch(dfx_k_analysis_mem_out, dim3((unsigned)dfx_ceil_div(n, 256)), dim3(256), 0, s, x, mem_in, mem_out, B, Tf,
+                   x_stride, st->hop, ML);
+        DFX_LAUNCH_CHECK();
+    }
+    return DFX_OK;
+}
+
+int dfx_launch_norm_scan(const float *erb_in, float *erb_out, int E, const float *spec_in, int64_t spec_frame_stride,
+                         float *spec_out, int Fn, int64_t C, int64_t T, float alpha, float *erb_state,
+                         float *unit_state, hipStream_t s) {
+    const int nch = (erb_in ? E : 0) + (spec_in ? Fn : 0);
+    const int64_t n = C * nch;
+    if (n <= 0) return DFX_OK;
+    dfx_launch(dfx_k_norm_scan, dim3((unsigned)dfx_ceil_div(n, 64)), dim3(64), 0, s, erb_in, erb_out, E,
+               reinterpret_cast<const float2 *>(spec_in), spec_frame_stride, reinterpret_cast<float2 *>(spec_out), Fn, C,
+               T, alpha, erb_state, unit_state);
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI: transforms
+extern "C" int dfx_analysis(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_stride,
+                            const float *mem_in, float *mem_out, float *spec, void *stream) {
+    if (!st || B < 0 || T < 0 || x_stride < T) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_analysis: bad arguments");
+    if (B > 0 && T / st->hop > 0 && (!x || !spec)) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_analysis: null buffer");
+    if (int rc = dfx_require_device()) return rc;
+    return dfx_launch_analysis(st, x, B, T, x_stride, mem_in, mem_out, spec, nullptr, dfx_stream(stream));
+}
+
+extern "C" int dfx_synthesis(const dfx_state *st, const float *spec, int64_t B, int64_t Tf, const float *mem_in,
+                             float *mem_out, float *out, int64_t out_stride, void *stream) {
+    if (!st || B < 0 || Tf < 0 || out_stride < Tf * st->hop) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_synthesis: bad arguments");
+    if (int rc = dfx_require_device()) return rc;
+    if (B == 0 || (Tf == 0 && !mem_out)) return DFX_OK;
+    if ((Tf > 0 && (!spec || !out))) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_synthesis: null buffer");
+    DfxSynArgs A;
+    A.spec = reinterpret_cast<const float2 *>(spec);
+    A.mem_in = mem_in;
+    A.mem_out = mem_out;
+    A.out = out;
+    A.window = st->d_window;
+    A.tw = st->d_tw;
+    A.B = B;
+    A.Tf = Tf;
+    A.out_stride = out_stride;
+    A.hop = st->hop;
+    A.R = (st->N + st->hop - 1) / st->hop;
+    A.outf = DFX_DSP_TEAMS - (A.R - 1);
+    A.chunks = (int)dfx_ceil_div(Tf + (mem_out ? A.R - 1 : 0), A.outf);
+    A.plan = st->plan;
+    if (A.chunks <= 0) return DFX_OK;
+    const size_t smem = dsp_smem_bytes(st);
+    if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_synthesis, smem));
+    const int64_t nblk = B * A.chunks;
+    if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_synthesis: batch too large for one launch");
+    dfx_launch(dfx_k_synthesis, dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, dfx_stream(stream), A);
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
+}
+
+extern "C" int dfx_erb(const dfx_bands *bands, const float *spec, int64_t rows, int db, float *out, void *stream) {
+    if (!bands || rows < 0) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_erb: bad arguments");
+    if (int rc = dfx_require_device()) return rc;
+    if (rows == 0) return DFX_OK;
+    if (!spec || !out) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_erb: null buffer");
+    const int64_t n = rows * bands->nb;
+    dfx_launch(dfx_k_erb, dim3((unsigned)dfx_ceil_div(n, 256)), dim3(256), 0, dfx_stream(stream),
+               reinterpret_cast<const float2 *>(spec), rows, bands->F, bands->nb, bands->d_start, bands->d_invw, db, out);
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
+}
+
+extern "C" int dfx_erb_inv(const dfx_bands *bands, const float *gains, int64_t rows, float *out, void *stream) {
+    if (!bands || rows < 0) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_erb_inv: bad arguments");
+    if (int rc = dfx_require_device()) return rc;
+    if (rows == 0) return DFX_OK;
+    if (!gains || !out) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_erb_inv: null buffer");
+    const int64_t n = rows * bands->F;
+    dfx_launch(dfx_k_erb_inv, dim3((unsigned)dfx_ceil_div(n, 256)), dim3(256), 0, dfx_stream(stream), gains, rows,
+               bands->F, bands->nb, bands->d_bin2band, out);
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
+}
+
+extern "C" int dfx_erb_norm(float *x, int64_t C, int64_t T, int E, float alpha, float *state, void *stream) {
+    if (C < 0 || T < 0 || E <= 0) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_erb_norm: bad arguments");
+    if (int rc = dfx_require_device()) return rc;
+    if (C == 0 || T == 0) return DFX_OK;
+    if (!x) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_erb_norm: null buffer");
+    return dfx_launch_norm_scan(x, x, E, nullptr, 0, nullptr, 0, C, T, alpha, state, nullptr, dfx_stream(stream));
+}
+
+extern "C" int dfx_unit_norm(const float *x, int64_t x_frame_stride, float *out, int64_t C, int64_t T, int F,
+                             float alpha, float *state, void *stream) {
+    if (C < 0 || T < 0 || F <= 0 || x_frame_stride < F) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_unit_norm: bad arguments");
+    if (int rc = dfx_require_device()) return rc;
+    if (C == 0 || T == 0) return DFX_OK;
+    if (!x || !out) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_unit_norm: null buffer");
+    return dfx_launch_norm_scan(nullptr, nullptr, 0, x, x_frame_stride, out, F, C, T, alpha, nullptr, state,
+                                dfx_stream(stream));
+}
+
+extern "C" int dfx_features(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_stride, int nb_df,
+                            float alpha, float *spec, float *erb_feat, float *spec_feat, void *stream) {
+    if (!st || B < 0 || T < 0 || x_stride < T || nb_df <= 0 || nb_df > st->N / 2 + 1)
+        DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_features: bad arguments");
+    if (int rc = dfx_require_device()) return rc;
+    const int64_t Tf = T / st->hop;
+    if (B == 0 || Tf == 0) return DFX_OK;
+    if (!x || !spec || !erb_feat || !spec_feat) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_features: null buffer");
+    // enhance.py:190-197: spec = analysis(x); erb_norm(erb(spec)); unit_norm(spec[..., :nb_df])
+    if (int rc = dfx_launch_analysis(st, x, B, T, x_stride, nullptr, nullptr, spec, erb_feat, dfx_stream(stream))) return rc;
+    return dfx_launch_norm_scan(erb_feat, erb_feat, st->nb, spec, st->N / 2 + 1, spec_feat, nb_df, B, Tf, alpha, nullptr,
+                                nullptr, dfx_stream(stream));
+}
+
+int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, const float *gains,
+                        const dfx_bands *bands, int64_t B, int64_t T, int F, int nb_df, int order, int lookahead,
+                        float pf_beta, float atten_lim, float *out, hipStream_t s);
+
+int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, const float *gains,
+                        const dfx_bands *bands, int64_t B, int64_t T, int F, int nb_df, int order, int lookahead,
+                        float pf_beta, float atten_lim, float *out, hipStream_t s) {
+    DfxDfaArgs A;
+    A.spec = reinterpret_cast<const float2 *>(spec);
+    A.coefs = reinterpret_cast<const float2 *>(coefs);
+    A.gains = gains;
+    A.bin2band = bands ? bands->d_bin2band : nullptr;
+    A.out = reinterpret_cast<float2 *>(out);
+    A.B = B;
+    A.T = T;
+    A.F = F;
+    A.nbdf = nb_df;
+    A.order = order;
+    A.lookahead = lookahead;
+    A.nb = (gains && bands) ? bands->nb : 0;
+    A.layout = coef_layout;
+    A.pf_beta = pf_beta;
+    A.atten_lim = atten_lim;
+    A.chunks = (int)dfx_ceil_div(T, DFX_DFA_TT);
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t smem = al((size_t)(DFX_DFA_TT + order - 1) * nb_df * 8) + al((size_t)DFX_DFA_TT * nb_df * order * 8) +
+                        al((size_t)DFX_DFA_TT * nb_df * 8) + al((size_t)DFX_DFA_TT * (A.nb > 0 ? A.nb : 1) * 4) + al((size_t)F);
+    if (smem > 160 * 1024) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_df_apply: nb_df*order too large for LDS staging (%zu B)", smem);
+    if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_df_apply, smem));
+    const int64_t nblk = B * A.chunks;
+    if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_df_apply: batch too large for one launch");
+    dfx_launch(dfx_k_df_apply, dim3((unsigned)nblk), dim3(DFX_DFA_THREADS), smem, s, A);
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
+}
+
+extern "C" int dfx_df_apply(const float *spec, const float *coefs, int coef_layout, const float *gains,
+                            const dfx_bands *bands, int64_t B, int64_t T, int F, int nb_df, int order, int lookahead,
+                            float pf_beta, float atten_lim, float *out, void *stream) {
+    if (B < 0 || T < 0 || F <= 0 || nb_df <= 0 || nb_df > F || order <= 0 || lookahead < 0 || lookahead >= order)
+        DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply: bad sizes (need 0 <= lookahead < order, 0 < nb_df <= F)");
+    if (coef_layout != DFX_COEF_BOTF && coef_layout != DFX_COEF_BTFO) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply: bad coef_layout");
+    if (nb_df & 1) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_df_apply: nb_df must be even (16-byte coefficient rows)");
+    if (gains && (!bands || bands->F != F)) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply: gains need a band table covering F bins");
+    if (atten_lim < 0.f || atten_lim >= 1.f) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply: atten_lim must be in [0,1)");
+    if (int rc = dfx_require_device()) return rc;
+    if (B == 0 || T == 0) return DFX_OK;
+    if (!spec || !coefs || !out) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply: null buffer");
+    if (spec == out) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply: out must not alias spec");
+    if (((uintptr_t)spec & 15) || ((uintptr_t)out & 15) || ((uintptr_t)coefs & 15))
+        DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply: spec, coefs and out must be 16-byte aligned");
+    return dfx_launch_df_apply(spec, coefs, coef_layout, gains, bands, B, T, F, nb_df, order, lookahead, pf_beta,
+                               atten_lim, out, dfx_stream(stream));
+}

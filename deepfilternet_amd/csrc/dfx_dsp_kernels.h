@@ -1,0 +1,585 @@
+// HIP kernels for the libDF half of enhance(): batched STFT analysis (+ERB dB features), exponential-norm scans,
+// ISTFT + overlap-add, ERB filterbank ops and the fused deep-filter / ERB-gain application.
+//
+// All of these are HBM-bound: the design goal is coalesced 4..16-byte accesses, frames staged through
+// LDS, one wave (64 lanes) per frame FFT, and every byte touched once.  No MFMA here on purpose.
+//
+// Reference semantics (each kernel cites its lines): libDF/src/lib.rs, libDF/src/transforms.rs, pyDF/src/lib.rs,
+// DeepFilterNet/df/multiframe.py, DeepFilterNet/df/modules.py, DeepFilterNet/df/deepfilternet3.py.
+#pragma once
+
+#include "dfx_common.h"
+
+#define DFX_DSP_TEAM 64    // lanes per frame (one wave)
+#define DFX_DSP_TEAMS 8    // frames in flight per workgroup
+#define DFX_DSP_THREADS (DFX_DSP_TEAM * DFX_DSP_TEAMS)
+
+static __device__ __forceinline__ float2 dfx_cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+static __device__ __forceinline__ float2 dfx_cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+static __device__ __forceinline__ float2 dfx_csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// multiply by -i (forward, SG=-1) or +i (inverse, SG=+1)
+template <int SG>
+static __device__ __forceinline__ float2 dfx_mul_sgi(float2 a) {
+    return SG < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+}
+
+// One Stockham autosort pass of radix R over a length-M complex sequence held in LDS.
+//   y[q + s*(R*p + j)] = w^(j*p) * DFT_R(x[q + s*(p + m*j)])_j ,  p < m = ncur/R, q < s,  w = exp(SG*2*pi*i/ncur)
+// tw is the length-N table exp(-2*pi*i*k/N), N = 2*M (so w^(j*p) = tw[j*p*(N/ncur)], conjugated for the inverse).
+template <int R, int SG>
+static __device__ __forceinline__ void dfx_fft_pass(const float2 *x, float2 *y, const float2 *tw, int M, int N, int ncur,
+                                                    int s, int lane) {
+    const int m = ncur / R;
+    const int nbf = M / R;  // butterflies in this pass
+    const int tws = N / ncur;
+    for (int b = lane; b < nbf; b += DFX_DSP_TEAM) {
+        const int p = b / s, q = b - p * s;
+        float2 a[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) a[j] = x[q + s * (p + m * j)];
+        float2 o[R];
+        if constexpr (R == 2) {
+            o[0] = dfx_cadd(a[0], a[1]);
+            o[1] = dfx_csub(a[0], a[1]);
+        } else if constexpr (R == 3) {
+            const float2 sm = dfx_cadd(a[1], a[2]), d = dfx_csub(a[1], a[2]);
+            const float2 mm = make_float2(a[0].x - 0.5f * sm.x, a[0].y - 0.5f * sm.y);
+            float2 jd = dfx_mul_sgi<SG>(d);
+            jd.x *= 0.86602540378443864676f;
+            jd.y *= 0.86602540378443864676f;
+            o[0] = dfx_cadd(a[0], sm);
+            o[1] = dfx_cadd(mm, jd);
+            o[2] = dfx_csub(mm, jd);
+        } else if constexpr (R == 4) {
+            const float2 t0 = dfx_cadd(a[0], a[2]), t1 = dfx_csub(a[0], a[2]);
+            const float2 t2 = dfx_cadd(a[1], a[3]), t3 = dfx_mul_sgi<SG>(dfx_csub(a[1], a[3]));
+            o[0] = dfx_cadd(t0, t2);
+            o[1] = dfx_cadd(t1, t3);
+            o[2] = dfx_csub(t0, t2);
+            o[3] = dfx_csub(t1, t3);
+        } else {  // R == 5
+            const float c1 = 0.30901699437494742410f, s1 = 0.95105651629515357212f;
+            const float c2 = -0.80901699437494742410f, s2 = 0.58778525229247312917f;
+            const float2 s14 = dfx_cadd(a[1], a[4]), d14 = dfx_csub(a[1], a[4]);
+            const float2 s23 = dfx_cadd(a[2], a[3]), d23 = dfx_csub(a[2], a[3]);
+            const float2 m1 = make_float2(a[0].x + c1 * s14.x + c2 * s23.x, a[0].y + c1 * s14.y + c2 * s23.y);
+            const float2 m2 = make_float2(a[0].x + c2 * s14.x + c1 * s23.x, a[0].y + c2 * s14.y + c1 * s23.y);
+            const float2 n1 = dfx_mul_sgi<SG>(make_float2(s1 * d14.x + s2 * d23.x, s1 * d14.y + s2 * d23.y));
+            const float2 n2 = dfx_mul_sgi<SG>(make_float2(s2 * d14.x - s1 * d23.x, s2 * d14.y - s1 * d23.y));
+            o[0] = make_float2(a[0].x + s14.x + s23.x, a[0].y + s14.y + s23.y);
+            o[1] = dfx_cadd(m1, n1);
+            o[4] = dfx_csub(m1, n1);
+            o[2] = dfx_cadd(m2, n2);
+            o[3] = dfx_csub(m2, n2);
+        }
+        y[q + s * (R * p)] = o[0];
+#pragma unroll
+        for (int j = 1; j < R; ++j) {
+            float2 w = tw[j * p * tws];
+            if (SG > 0) w.y = -w.y;
+            y[q + s * (R * p + j)] = dfx_cmul(o[j], w);
+        }
+    }
+}
+
+// Complex FFT of length pl.M by one 64-lane team.  Data starts in `a`; returns the buffer that holds the result.
+// Every thread of the workgroup must call this (it contains __syncthreads); inactive teams skip the arithmetic.
+template <int SG>
+static __device__ __forceinline__ float2 *dfx_fft_team(float2 *a, float2 *b, const float2 *tw, const DfxFftPlan &pl,
+                                                       int lane, bool active) {
+    int ncur = pl.M, s = 1;
+    float2 *x = a, *y = b;
+    for (int st = 0; st < pl.nstage; ++st) {
+        const int r = pl.radix[st];
+        if (active) {
+            if (r == 4) dfx_fft_pass<4, SG>(x, y, tw, pl.M, pl.N, ncur, s, lane);
+            else if (r == 2) dfx_fft_pass<2, SG>(x, y, tw, pl.M, pl.N, ncur, s, lane);
+            else if (r == 3) dfx_fft_pass<3, SG>(x, y, tw, pl.M, pl.N, ncur, s, lane);
+            else dfx_fft_pass<5, SG>(x, y, tw, pl.M, pl.N, ncur, s, lane);
+        }
+        __syncthreads();
+        ncur /= r;
+        s *= r;
+        float2 *t = x;
+        x = y;
+        y = t;
+    }
+    return x;
+}
+
+struct DfxAnaArgs {
+    const float *x;       // [B, x_stride]
+    const float *mem_in;  // [B, N-hop] or null
+    float2 *spec;         // [B, Tf, F]
+    float *erb_db;        // [B, Tf, nb] or null: 10*log10(band energy + 1e-10)
+    const float *window;  // [N]
+    const float2 *tw;     // [N]
+    const int *band_start;  // [nb+1]
+    const float *band_invw; // [nb]
+    int64_t B, Tf, x_stride;
+    int hop, nb;
+    float wnorm;
+    DfxFftPlan plan;
+};
+
+// STFT analysis: frame (b,t) = rfft_N( window * stream[(t+1)*hop-N : (t+1)*hop] ) * wnorm   (lib.rs:356-394),
+// stream = [mem_in (N-hop zeros after a reset) ; x].  One wave per frame, 8 frames per workgroup pass, grid-stride.
+// Optional fused ERB band energies in dB (lib.rs:206-212 without the norm; transforms.rs:236-253).
+__global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_analysis(DfxAnaArgs A) {
+    DFX_DYN_SMEM(unsigned char, smem);
+    const int N = A.plan.N, M = A.plan.M, F = M + 1;
+    float2 *tw = reinterpret_cast<float2 *>(smem);                       // [N]
+    float *win = reinterpret_cast<float *>(smem + (size_t)N * 8);        // [N]
+    const size_t team_off = (size_t)N * 12;
+    const size_t buf_elems = (size_t)(M + 2);                            // M+1 used, padded to keep 16-byte carve
+    const int team = threadIdx.x / DFX_DSP_TEAM, lane = threadIdx.x % DFX_DSP_TEAM;
+    float2 *bufA = reinterpret_cast<float2 *>(smem + team_off) + (size_t)team * 2 * buf_elems;
+    float2 *bufB = bufA + buf_elems;
+    for (int i = threadIdx.x; i < N; i += DFX_DSP_THREADS) {
+        tw[i] = A.tw[i];
+        win[i] = A.window[i];
+    }
+    __syncthreads();
+    const int64_t nframes = A.B * A.Tf;
+    const int ML = N - A.hop;
+    for (int64_t base = (int64_t)blockIdx.x * DFX_DSP_TEAMS; base < nframes; base += (int64_t)gridDim.x * DFX_DSP_TEAMS) {
+        const int64_t fr = base + team;
+        const bool active = fr < nframes;
+        const int64_t b = active ? fr / A.Tf : 0, t = active ? fr - b * A.Tf : 0;
+        if (active) {
+            const float *xb = A.x + b * A.x_stride;
+            const int64_t pos0 = t * A.hop - ML;
+            for (int k = lane; k < M; k += DFX_DSP_TEAM) {
+                float v[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int i = 2 * k + h;
+                    const int64_t pos = pos0 + i;
+                    float s = 0.f;
+                    if (pos >= 0) s = xb[pos];
+                    else if (A.mem_in) s = A.mem_in[b * ML + (ML + pos)];
+                    v[h] = s * win[i];
+                }
+                bufA[k] = make_float2(v[0], v[1]);
+            }
+        }
+        __syncthreads();
+        float2 *Z = dfx_fft_team<-1>(bufA, bufB, tw, A.plan, lane, active);
+        float2 *other = (Z == bufA) ? bufB : bufA;
+        float *pw = reinterpret_cast<float *>(other);  // |X|^2 per bin for the ERB feature
+        if (active) {
+            float2 *out = A.spec + (b * A.Tf + t) * F;
+            for (int k = lane; k <= M; k += DFX_DSP_TEAM) {
+                const float2 zk = Z[k == M ? 0 : k];
+                const float2 zc = Z[k == 0 ? 0 : M - k];
+                // E = (Z[k] + conj(Z[M-k]))/2 ; O = (Z[k] - conj(Z[M-k]))/(2i) ; X[k] = E + exp(-2*pi*i*k/N) * O
+                const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);
+                const float dr = 0.5f * (zk.x - zc.x), di = 0.5f * (zk.y + zc.y);
+                const float2 tt = dfx_cmul(make_float2(di, -dr), tw[k]);
+                const float2 X = make_float2((er + tt.x) * A.wnorm, (ei + tt.y) * A.wnorm);
+                out[k] = X;
+                if (A.erb_db) pw[k] = X.x * X.x + X.y * X.y;
+            }
+        }
+        if (A.erb_db) {
+            __syncthreads();
+            if (active && lane < A.nb) {
+                // compute_band_corr (lib.rs:280-295): acc += |X|^2 * (1/width), bins in ascending order
+                const int s0 = A.band_start[lane], s1 = A.band_start[lane + 1];
+                const float kk = A.band_invw[lane];
+                float acc = 0.f;
+                for (int j = s0; j < s1; ++j) acc += pw[j] * kk;
+                A.erb_db[(b * A.Tf + t) * A.nb + lane] = log10f(acc + 1e-10f) * 10.f;
+            }
+            for (int e = DFX_DSP_TEAM + lane; active && e < A.nb; e += DFX_DSP_TEAM) {  // nb > 64 (rare)
+                const int s0 = A.band_start[e], s1 = A.band_start[e + 1];
+                const float kk = A.band_invw[e];
+                float acc = 0.f;
+                for (int j = s0; j < s1; ++j) acc += pw[j] * kk;
+                A.erb_db[(b * A.Tf + t) * A.nb + e] = log10f(acc + 1e-10f) * 10.f;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// analysis memory after the last frame = the last N-hop samples of [mem_in ; x[:, :Tf*hop]]  (lib.rs:379-384)
+__global__ void dfx_k_analysis_mem_out(const float *x, const float *mem_in, float *mem_out, int64_t B, int64_t Tf,
+                                       int64_t x_stride, int hop, int ML) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * ML) return;
+    const int64_t b = i / ML;
+    const int j = (int)(i - b * ML);
+    const int64_t pos = Tf * hop - ML + j;
+    float v = 0.f;
+    if (pos >= 0) v = x[b * x_stride + pos];
+    else if (mem_in) v = mem_in[b * ML + (ML + pos)];
+    mem_out[i] = v;
+}
+
+struct DfxSynArgs {
+    const float2 *spec;   // [B, Tf, F]
+    const float *mem_in;  // [B, N-hop] or null
+    float *mem_out;       // [B, N-hop] or null
+    float *out;           // [B, out_stride]
+    const float *window;
+    const float2 *tw;
+    int64_t B, Tf, out_stride;
+    int hop, R /* N/hop rounded up: frames overlapping one output hop */, outf /* output frames per chunk */;
+    int chunks;           // chunks per row (including the tail chunk that produces mem_out)
+    DfxFftPlan plan;
+};
+
+// ISTFT + window + overlap-add (lib.rs:396-427).  A workgroup produces `outf` consecutive output hops of one row from
+// DFX_DSP_TEAMS = outf + R - 1 frames (the first R-1 are halo frames recomputed instead of carried through memory).
+// Sum order per output sample follows the reference: oldest contribution first, the current frame last.
+__global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_synthesis(DfxSynArgs A) {
+    DFX_DYN_SMEM(unsigned char, smem);
+    const int N = A.plan.N, M = A.plan.M, F = M + 1;
+    float2 *tw = reinterpret_cast<float2 *>(smem);
+    float *win = reinterpret_cast<float *>(smem + (size_t)N * 8);
+    const size_t team_off = (size_t)N * 12;
+    const size_t buf_elems = (size_t)(M + 2);
+    const int team = threadIdx.x / DFX_DSP_TEAM, lane = threadIdx.x % DFX_DSP_TEAM;
+    float2 *bufs = reinterpret_cast<float2 *>(smem + team_off);
+    float2 *bufA = bufs + (size_t)team * 2 * buf_elems;
+    float2 *bufB = bufA + buf_elems;
+    // the last 4 bytes of the team area of team 0 would be too fragile for a flag: keep result-buffer parity in a
+    // register instead (identical for all teams because the plan is uniform)
+    for (int i = threadIdx.x; i < N; i += DFX_DSP_THREADS) {
+        tw[i] = A.tw[i];
+        win[i] = A.window[i];
+    }
+    __syncthreads();
+    const int ML = N - A.hop;
+    const int64_t b = blockIdx.x / A.chunks;
+    const int chunk = (int)(blockIdx.x - b * A.chunks);
+    const int64_t t0 = (int64_t)chunk * A.outf;      // first output frame of this chunk
+    const int64_t t = t0 - (A.R - 1) + team;         // real frame handled by this team
+    const bool active = t >= 0 && t < A.Tf;
+    if (active) {
+        const float2 *Y = A.spec + (b * A.Tf + t) * F;
+        for (int k = lane; k <= M; k += DFX_DSP_TEAM) bufB[k] = Y[k];
+    }
+    __syncthreads();
+    if (active) {
+        for (int k = lane; k < M; k += DFX_DSP_TEAM) {
+            float2 xk = bufB[k], xm = bufB[M - k];
+            if (k == 0) {  // C2R ignores imag(DC) and imag(Nyquist)
+                xk.y = 0.f;
+                xm.y = 0.f;
+            }
+            // E' = X[k] + conj(X[M-k]) ; O' = conj(w^k) * (X[k] - conj(X[M-k])) ; Z = E' + i*O'
+            const float er = xk.x + xm.x, ei = xk.y - xm.y;
+            float2 w = tw[k];
+            w.y = -w.y;
+            const float2 o = dfx_cmul(make_float2(xk.x - xm.x, xk.y + xm.y), w);
+            bufA[k] = make_float2(er - o.y, ei + o.x);
+        }
+    }
+    __syncthreads();
+    float2 *Z = dfx_fft_team<+1>(bufA, bufB, tw, A.plan, lane, active);
+    const bool in_a = (Z == bufA);
+    {
+        // apply_window_in_place (lib.rs:406): the interleaved (re, im) pairs of z ARE the time samples
+        float *xt = reinterpret_cast<float *>(Z);
+        if (active)
+            for (int i = lane; i < N; i += DFX_DSP_TEAM) xt[i] *= win[i];
+    }
+    __syncthreads();
+    // overlap-add: output frame tf = t0 + j (j < outf), sample i < hop, gets real frames tf-R+1 .. tf
+    const int total = A.outf * A.hop;
+    for (int idx = threadIdx.x; idx < total; idx += DFX_DSP_THREADS) {
+        const int j = idx / A.hop, i = idx - j * A.hop;
+        const int64_t tf = t0 + j;
+        if (tf >= A.Tf + (A.mem_out ? A.R - 1 : 0)) break;
+        const int64_t s_glob = tf * A.hop + i;  // sample index in the row's output stream
+        float acc = 0.f;
+        bool have = false;
+        if (A.mem_in && s_glob < ML) {
+            acc = A.mem_in[b * ML + s_glob];
+            have = true;
+        }
+        for (int r = A.R - 1; r >= 1; --r) {  // older frames first
+            const int64_t tr = tf - r;
+            const int off = r * A.hop + i;
+            if (tr >= 0 && tr < A.Tf && off < N) {
+                const int tm = (int)(tr - (t0 - (A.R - 1)));
+                const float *fr = reinterpret_cast<const float *>(bufs + (size_t)tm * 2 * buf_elems + (in_a ? 0 : buf_elems));
+                acc = have ? acc + fr[off] : fr[off];
+                have = true;
+            }
+        }
+        float cur = 0.f;
+        if (tf < A.Tf) {
+            const int tm = (int)(tf - (t0 - (A.R - 1)));
+            const float *fr = reinterpret_cast<const float *>(bufs + (size_t)tm * 2 * buf_elems + (in_a ? 0 : buf_elems));
+            cur = fr[i];
+        }
+        const float v = have ? cur + acc : cur;
+        if (tf < A.Tf) {
+            A.out[b * A.out_stride + s_glob] = v;
+        } else {
+            const int64_t mj = s_glob - A.Tf * A.hop;
+            if (mj < ML) A.mem_out[b * ML + mj] = v;
+        }
+    }
+}
+
+// erb() (transforms.rs:236-253 / lib.rs:280-295): one thread per (row, band); rows of F complex bins.
+__global__ void dfx_k_erb(const float2 *spec, int64_t rows, int F, int nb, const int *band_start,
+                          const float *band_invw, int db, float *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * nb) return;
+    const int64_t r = i / nb;
+    const int e = (int)(i - r * nb);
+    const float2 *x = spec + r * F;
+    const float kk = band_invw[e];
+    float acc = 0.f;
+    for (int j = band_start[e]; j < band_start[e + 1]; ++j) {
+        const float2 v = x[j];
+        acc += (v.x * v.x + v.y * v.y) * kk;
+    }
+    out[i] = db ? log10f(acc + 1e-10f) * 10.f : acc;
+}
+
+// erb_inv() (lib.rs:339-348): out[row, f] = gains[row, band(f)]
+__global__ void dfx_k_erb_inv(const float *gains, int64_t rows, int F, int nb, const unsigned char *bin2band, float *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * F) return;
+    const int64_t r = i / F;
+    const int f = (int)(i - r * F);
+    out[i] = gains[r * nb + bin2band[f]];
+}
+
+#define DFX_SCAN_UNROLL 8
+// Exponential mean norm of the ERB features (lib.rs:244-251) and exponential unit norm of the complex features
+// (lib.rs:253-259) — true recurrences over time, so one thread owns one (row, channel) and walks T sequentially; the
+// loads do not depend on the recurrence and are issued DFX_SCAN_UNROLL frames ahead.  Channels [0,E) are ERB bands,
+// [E, E+Fn) complex bins.  Either half may be disabled by passing a null input pointer.
+__global__ void dfx_k_norm_scan(const float *erb_in, float *erb_out, int E, const float2 *spec_in,
+                                int64_t spec_frame_stride, float2 *spec_out, int Fn, int64_t C, int64_t T, float alpha,
+                                float *erb_state, float *unit_state) {
+    const int nch = (erb_in ? E : 0) + (spec_in ? Fn : 0);
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= C * nch) return;
+    const int64_t c = gid / nch;
+    int ch = (int)(gid - c * nch);
+    const float one_m_a = 1.f - alpha;
+    if (erb_in && ch < E) {
+        // state init: linspace(-60, -90, E) (transforms.rs:308-318; step form of ndarray::linspace)
+        float s;
+        if (erb_state) s = erb_state[c * E + ch];
+        else s = -60.f + (E > 1 ? (-90.f - -60.f) / (float)(E - 1) : 0.f) * (float)ch;
+        const float *in = erb_in + c * T * E + ch;
+        float *out = erb_out + c * T * E + ch;
+        int64_t t = 0;
+        for (; t + DFX_SCAN_UNROLL <= T; t += DFX_SCAN_UNROLL) {
+            float v[DFX_SCAN_UNROLL];
+#pragma unroll
+            for (int u = 0; u < DFX_SCAN_UNROLL; ++u) v[u] = in[(t + u) * E];
+#pragma unroll
+            for (int u = 0; u < DFX_SCAN_UNROLL; ++u) {
+                s = v[u] * one_m_a + s * alpha;
+                out[(t + u) * E] = (v[u] - s) / 40.f;
+            }
+        }
+        for (; t < T; ++t) {
+            const float v = in[t * E];
+            s = v * one_m_a + s * alpha;
+            out[t * E] = (v - s) / 40.f;
+        }
+        if (erb_state) erb_state[c * E + ch] = s;
+        return;
+    }
+    if (erb_in) ch -= E;
+    {
+        float s;
+        if (unit_state) s = unit_state[c * Fn + ch];
+        else s = 0.001f + (Fn > 1 ? (0.0001f - 0.001f) / (float)(Fn - 1) : 0.f) * (float)ch;
+        const float2 *in = spec_in + c * T * spec_frame_stride + ch;
+        float2 *out = spec_out + c * T * Fn + ch;
+        int64_t t = 0;
+        for (; t + DFX_SCAN_UNROLL <= T; t += DFX_SCAN_UNROLL) {
+            float2 v[DFX_SCAN_UNROLL];
+#pragma unroll
+            for (int u = 0; u < DFX_SCAN_UNROLL; ++u) v[u] = in[(t + u) * spec_frame_stride];
+#pragma unroll
+            for (int u = 0; u < DFX_SCAN_UNROLL; ++u) {
+                s = hypotf(v[u].x, v[u].y) * one_m_a + s * alpha;
+                const float d = sqrtf(s);
+                out[(t + u) * Fn] = make_float2(v[u].x / d, v[u].y / d);
+            }
+        }
+        for (; t < T; ++t) {
+            const float2 v = in[t * spec_frame_stride];
+            s = hypotf(v.x, v.y) * one_m_a + s * alpha;
+            const float d = sqrtf(s);
+            out[t * Fn] = make_float2(v.x / d, v.y / d);
+        }
+        if (unit_state) unit_state[c * Fn + ch] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused deep filtering + ERB gains (+ post filter, + attenuation limit): the memory-bound kernel with the explicit
+// >= 70 % HBM roofline target.  Algorithmic traffic per frame (O taps, nb_df bins, F bins, E bands):
+//   read X  F*8, read coefs nb_df*O*8, read gains E*4, write Y F*8   (11 664 B for O=5, nb_df=96, F=481, E=32).
+//
+// A workgroup owns DFX_DFA_TT consecutive frames of one row.
+//   phase 0  stage into LDS: low bins of the TT+O-1 frames the taps touch (8-byte coalesced, rows are only 8-byte
+//            aligned because F is odd), the chunk's coefficients (16-byte coalesced), gains, bin->band map
+//   phase A  thread (t,f<nb_df): complex MAC over the taps out of LDS -> ylow[t][f] in LDS
+//   phase B  the chunk's [TT*F] complex outputs are walked as one flat, 16-byte aligned float4 stream (2 bins per lane):
+//            low bins come from ylow, high bins are X*gain with X read by the same float4 stream.
+// ---------------------------------------------------------------------------------------------------------------------
+#define DFX_DFA_TT 8
+#define DFX_DFA_THREADS 256
+
+struct DfxDfaArgs {
+    const float2 *spec;   // [B,T,F]
+    const float2 *coefs;  // layout 0: [B,O,T,nbdf]  layout 1: [B,T,nbdf,O]
+    const float *gains;   // [B,T,nb] or null
+    const unsigned char *bin2band;  // [F]
+    float2 *out;          // [B,T,F]
+    int64_t B, T;
+    int F, nbdf, order, lookahead, nb, layout;
+    float pf_beta, atten_lim;
+    int chunks;           // chunks per row
+};
+
+static __device__ __forceinline__ float2 dfx_dfa_finish(float2 y, float2 x, float pf_beta, float lim) {
+    if (pf_beta > 0.f) {
+        // deepfilternet3.py:448-454 (== lib.rs:446-471)
+        const float eps = 1e-12f, pi = 3.14159265358979323846f;
+        float g = sqrtf(y.x * y.x + y.y * y.y) / (sqrtf(x.x * x.x + x.y * x.y) + eps);
+        g = fminf(fmaxf(g, eps), 1.f);
+        const float g_sin = g * fmaxf(sinf(pi * g * 0.5f), eps);
+        const float q = g / g_sin;
+        const float pf = (1.f + pf_beta) / (1.f + pf_beta * q * q);
+        y.x *= pf;
+        y.y *= pf;
+    }
+    if (lim > 0.f) {
+        // enhance.py:238-240
+        y.x = x.x * lim + y.x * (1.f - lim);
+        y.y = x.y * lim + y.y * (1.f - lim);
+    }
+    return y;
+}
+
+__global__ void __launch_bounds__(DFX_DFA_THREADS) dfx_k_df_apply(DfxDfaArgs A) {
+    DFX_DYN_SMEM(unsigned char, smem);
+    const int TT = DFX_DFA_TT, O = A.order, nd = A.nbdf, F = A.F;
+    const int halo = TT + O - 1;
+    // LDS carve (all offsets multiples of 16 bytes)
+    float2 *xs = reinterpret_cast<float2 *>(smem);                    // [halo][nd]
+    size_t off = ((size_t)halo * nd * 8 + 15) & ~(size_t)15;
+    float2 *cs = reinterpret_cast<float2 *>(smem + off);              // [TT*nd*O]
+    off += ((size_t)TT * nd * O * 8 + 15) & ~(size_t)15;
+    float2 *ylow = reinterpret_cast<float2 *>(smem + off);            // [TT][nd]
+    off += ((size_t)TT * nd * 8 + 15) & ~(size_t)15;
+    float *gs = reinterpret_cast<float *>(smem + off);                // [TT][nb]
+    off += ((size_t)TT * (A.nb > 0 ? A.nb : 1) * 4 + 15) & ~(size_t)15;
+    unsigned char *b2b = smem + off;                                  // [F]
+
+    const int64_t b = blockIdx.x / A.chunks;
+    const int chunk = (int)(blockIdx.x - b * A.chunks);
+    const int64_t t0 = (int64_t)chunk * TT;
+    const int nt = (int)((A.T - t0) < TT ? (A.T - t0) : TT);          // frames in this chunk
+    const int tid = threadIdx.x;
+    const int toff = O - 1 - A.lookahead;                             // tap n reads frame t + n - toff
+
+    // ---- phase 0: stage
+    for (int i = tid; i < halo * nd; i += DFX_DFA_THREADS) {
+        const int h = i / nd, f = i - h * nd;
+        const int64_t tt = t0 - toff + h;
+        float2 v = make_float2(0.f, 0.f);
+        if (tt >= 0 && tt < A.T) v = A.spec[(b * A.T + tt) * F + f];
+        xs[i] = v;
+    }
+    if (A.layout == DFX_COEF_BTFO) {
+        // contiguous [nt*nd*O] complex, 16-byte aligned when nd*O is even (checked on the host) -> float4 copies
+        const float4 *src = reinterpret_cast<const float4 *>(A.coefs + (b * A.T + t0) * nd * O);
+        float4 *dst = reinterpret_cast<float4 *>(cs);
+        const int n4 = nt * nd * O / 2;
+        for (int i = tid; i < n4; i += DFX_DFA_THREADS) dst[i] = src[i];
+    } else {
+        // per tap rows of nd complex: cs[(n*TT + t)*nd + f]
+        const int row4 = nd / 2;
+        for (int i = tid; i < O * nt * row4; i += DFX_DFA_THREADS) {
+            const int n = i / (nt * row4), r = i - n * (nt * row4);
+            const int t = r / row4, f4 = r - t * row4;
+            const float4 *src = reinterpret_cast<const float4 *>(A.coefs + ((b * O + n) * A.T + t0 + t) * nd);
+            reinterpret_cast<float4 *>(cs + ((size_t)n * TT + t) * nd)[f4] = src[f4];
+        }
+    }
+    if (A.gains)
+        for (int i = tid; i < nt * A.nb; i += DFX_DFA_THREADS) gs[i] = A.gains[(b * A.T + t0) * A.nb + i];
+    for (int i = tid; i < F; i += DFX_DFA_THREADS) b2b[i] = A.gains ? A.bin2band[i] : 0;
+    __syncthreads();
+
+    // ---- phase A: deep filter on the low bins (multiframe.py:126-136,169-180)
+    for (int i = tid; i < nt * nd; i += DFX_DFA_THREADS) {
+        const int t = i / nd, f = i - t * nd;
+        float re = 0.f, im = 0.f;
+        for (int n = 0; n < O; ++n) {
+            const float2 c = (A.layout == DFX_COEF_BTFO) ? cs[((size_t)t * nd + f) * O + n] : cs[((size_t)n * TT + t) * nd + f];
+            const float2 x = xs[(t + n) * nd + f];
+            re += x.x * c.x - x.y * c.y;
+            im += x.x * c.y + x.y * c.x;
+        }
+        ylow[i] = make_float2(re, im);
+    }
+    __syncthreads();
+
+    // ---- phase B: flat float4 stream over this chunk's [nt*F] outputs
+    const int64_t e0 = (b * A.T + t0) * F;        // first complex element of the chunk
+    const int64_t e1 = e0 + (int64_t)nt * F;
+    const int64_t a0 = (e0 + 1) & ~(int64_t)1;    // first 16-byte aligned element (base pointers are 16-byte aligned)
+    const int64_t a1 = e1 & ~(int64_t)1;
+    // peel: at most one element at each end
+    if (tid == 0 && a0 > e0) {
+        const int64_t e = e0;
+        const int tl = 0, f = 0;
+        const float2 x = A.spec[e];
+        float2 y = (f < nd) ? ylow[tl * nd + f] : make_float2(x.x, x.y);
+        if (f >= nd && A.gains) { const float g = gs[tl * A.nb + b2b[f]]; y.x = x.x * g; y.y = x.y * g; }
+        A.out[e] = dfx_dfa_finish(y, x, A.pf_beta, A.atten_lim);
+    }
+    if (tid == 1 && a1 < e1) {
+        const int64_t e = e1 - 1;
+        const int tl = nt - 1, f = F - 1;
+        const float2 x = A.spec[e];
+        float2 y = (f < nd) ? ylow[tl * nd + f] : make_float2(x.x, x.y);
+        if (f >= nd && A.gains) { const float g = gs[tl * A.nb + b2b[f]]; y.x = x.x * g; y.y = x.y * g; }
+        A.out[e] = dfx_dfa_finish(y, x, A.pf_beta, A.atten_lim);
+    }
+    const float4 *x4 = reinterpret_cast<const float4 *>(A.spec + a0);
+    float4 *y4 = reinterpret_cast<float4 *>(A.out + a0);
+    const int n4 = (int)((a1 - a0) / 2);
+    const int rel0 = (int)(a0 - e0);
+    for (int i = tid; i < n4; i += DFX_DFA_THREADS) {
+        const float4 xv = x4[i];
+        float2 xin[2] = {make_float2(xv.x, xv.y), make_float2(xv.z, xv.w)};
+        float2 yo[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rel = rel0 + 2 * i + h;  // element index inside the chunk
+            const int tl = rel / F, f = rel - tl * F;
+            float2 y;
+            if (f < nd) {
+                y = ylow[tl * nd + f];
+            } else if (A.gains) {
+                const float g = gs[tl * A.nb + b2b[f]];  // Mask (modules.py:266-269) == apply_interp_band_gain
+                y = make_float2(xin[h].x * g, xin[h].y * g);
+            } else {
+                y = xin[h];
+            }
+            yo[h] = dfx_dfa_finish(y, xin[h], A.pf_beta, A.atten_lim);
+        }
+        y4[i] = make_float4(yo[0].x, yo[0].y, yo[1].x, yo[1].y);
+    }
+}

@@ -1,0 +1,680 @@
+// DeepFilterNet3 model handle: tensor manifest, BatchNorm folding + weight re-layout, workspace planning and the kernel
+// sequence of DfNet.forward (deepfilternet3.py:389-456) and enhance() (enhance.py:206-250).
+#include "dfx_manifest.h"
+#include "dfx_nn_kernels.h"
+
+#include <cmath>
+#include <map>
+
+int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, const float *gains,
+                        const dfx_bands *bands, int64_t B, int64_t T, int F, int nb_df, int order, int lookahead,
+                        float pf_beta, float atten_lim, float *out, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------ cfg validation
+static int check_cfg(const dfx_model_cfg *c) {
+    if (!c) DFX_FAIL(DFX_ERR_INVALID_ARG, "null model cfg");
+    if (c->conv_ch != 16 && c->conv_ch != 32 && c->conv_ch != 64)
+        DFX_FAIL(DFX_ERR_UNSUPPORTED, "conv_ch=%d: the HIP kernels are instantiated for 16, 32, 64", c->conv_ch);
+    if (c->emb_hidden_dim != 256 || c->df_hidden_dim != 256) DFX_FAIL(DFX_ERR_UNSUPPORTED, "GRU hidden size must be 256");
+    if (c->nb_erb <= 0 || c->nb_erb % 8 || c->nb_erb > 64) DFX_FAIL(DFX_ERR_UNSUPPORTED, "nb_erb must be a multiple of 8, <= 64");
+    if (c->nb_df <= 0 || c->nb_df % 2 || c->nb_df > c->fft_size / 2 + 1) DFX_FAIL(DFX_ERR_UNSUPPORTED, "nb_df must be even and <= F");
+    if (c->df_order <= 0 || c->df_order > 16 || c->df_lookahead < 0 || c->df_lookahead >= c->df_order)
+        DFX_FAIL(DFX_ERR_UNSUPPORTED, "need 0 <= df_lookahead < df_order <= 16");
+    if (c->conv_lookahead < 0) DFX_FAIL(DFX_ERR_INVALID_ARG, "conv_lookahead < 0");
+    if (c->emb_num_layers < 2 || c->df_num_layers < 1) DFX_FAIL(DFX_ERR_UNSUPPORTED, "emb_num_layers >= 2 and df_num_layers >= 1 required");
+    if (c->df_pathway_kernel_size_t < 1 || c->df_pathway_kernel_size_t > 8) DFX_FAIL(DFX_ERR_UNSUPPORTED, "df_pathway_kernel_size_t must be 1..8");
+    const int emb = c->conv_ch * c->nb_erb / 4;
+    auto div_ok = [&](int I, int H, int G) { return G > 0 && I % G == 0 && H % G == 0 && (I / G) % 4 == 0 && (H / G) % 4 == 0; };
+    if (!div_ok(c->conv_ch * c->nb_df / 2, emb, c->enc_lin_groups)) DFX_FAIL(DFX_ERR_UNSUPPORTED, "enc_linear_groups=%d does not tile df_fc_emb into multiples of 4", c->enc_lin_groups);
+    if (!div_ok(emb, 256, c->lin_groups) || !div_ok(256, emb, c->lin_groups) || !div_ok(emb, 256, 8) ||
+        !div_ok(256, c->nb_df * 2 * c->df_order, c->lin_groups))
+        DFX_FAIL(DFX_ERR_UNSUPPORTED, "linear_groups=%d does not tile the grouped linears into multiples of 4", c->lin_groups);
+    const int G = dfx_gcd(c->conv_ch, 2 * c->df_order);
+    if ((c->conv_ch / G) % 4 || (2 * c->df_order / G) > 16) DFX_FAIL(DFX_ERR_UNSUPPORTED, "df_convp group shape unsupported");
+    if (c->df_gru_skip == DFX_SKIP_IDENTITY && emb != 256) DFX_FAIL(DFX_ERR_INVALID_ARG, "df_gru_skip=identity needs emb_dim == 256");
+    if (c->df_gru_skip < 0 || c->df_gru_skip > 2) DFX_FAIL(DFX_ERR_INVALID_ARG, "bad df_gru_skip");
+    return DFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ manifest API
+extern "C" int dfx_model_tensor_count(const dfx_model_cfg *cfg, int *count) {
+    if (int rc = check_cfg(cfg)) return rc;
+    if (!count) DFX_FAIL(DFX_ERR_INVALID_ARG, "null");
+    *count = (int)dfx_build_manifest(*cfg).t.size();
+    return DFX_OK;
+}
+extern "C" int dfx_model_tensor_info(const dfx_model_cfg *cfg, int index, char *name_out, int name_cap,
+                                     int64_t shape_out[4], int *ndim_out, int64_t *offset_out) {
+    if (int rc = check_cfg(cfg)) return rc;
+    const DfxManifest m = dfx_build_manifest(*cfg);
+    if (index < 0 || index >= (int)m.t.size()) DFX_FAIL(DFX_ERR_INVALID_ARG, "tensor index out of range");
+    const DfxTensor &t = m.t[index];
+    if (name_out && name_cap > 0) snprintf(name_out, (size_t)name_cap, "%s", t.name.c_str());
+    if (shape_out)
+        for (int i = 0; i < 4; ++i) shape_out[i] = i < t.ndim ? t.shape[i] : 1;
+    if (ndim_out) *ndim_out = t.ndim;
+    if (offset_out) *offset_out = t.offset;
+    return DFX_OK;
+}
+extern "C" int dfx_model_blob_floats(const dfx_model_cfg *cfg, int64_t *n) {
+    if (int rc = check_cfg(cfg)) return rc;
+    if (!n) DFX_FAIL(DFX_ERR_INVALID_ARG, "null");
+    *n = dfx_build_manifest(*cfg).total;
+    return DFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ prepared weights
+struct PwW {   // separable conv block: depthwise + pointwise(+BN) [+ pathway skip scalars]
+    size_t dw = 0, wt = 0, bias = 0, sk_a = 0, sk_b = 0;
+    bool has_skip = false;
+};
+struct GruW {
+    size_t wih_t = 0, bias_i = 0, whh4 = 0, bhn = 0;
+};
+struct GlinW {
+    size_t w = 0;
+    int G = 0, Kg = 0, Ng = 0;
+};
+
+struct dfx_model {
+    dfx_model_cfg cfg{};
+    float *d_w = nullptr;  // all prepared weights, one device allocation
+    size_t n_w = 0;
+    // offsets (floats) into d_w
+    size_t erb0_w = 0, erb0_b = 0;
+    PwW erb1, erb2, erb3, dfc0, dfc1, ct3, ct2, ct1;
+    size_t co_w = 0, co_ska = 0, co_skb = 0;
+    float co_bias = 0.f;
+    GlinW fc_emb, enc_in, enc_out, dec_in, dec_out, dfg_in, df_skip, df_out;
+    std::vector<GruW> enc_gru, dec_gru, df_gru;
+    size_t lsnr_w = 0;
+    float lsnr_b = 0.f;
+    size_t cp_w1 = 0, cp_w2 = 0, cp_b = 0;
+    int cp_G = 0, cp_NO = 0;
+    const float *p(size_t off) const { return d_w + off; }
+};
+
+namespace {
+struct Prep {
+    const float *blob;
+    const DfxManifest &man;
+    std::vector<float> out;
+    std::string err;
+    const float *get(const std::string &name, const DfxTensor **tt = nullptr) {
+        const DfxTensor *t = man.find(name);
+        if (!t) {
+            err = "tensor not in manifest: " + name;
+            return nullptr;
+        }
+        if (tt) *tt = t;
+        return blob + t->offset;
+    }
+    size_t alloc(size_t n) {  // 16-byte aligned carve
+        size_t off = (out.size() + 3) & ~(size_t)3;
+        out.resize(off + n, 0.f);
+        return off;
+    }
+    // BatchNorm2d eval: y = x*scale + shift
+    bool bn(const std::string &p, int n, std::vector<float> &scale, std::vector<float> &shift) {
+        const float *g = get(p + ".weight"), *b = get(p + ".bias"), *m = get(p + ".running_mean"), *v = get(p + ".running_var");
+        if (!g || !b || !m || !v) return false;
+        scale.resize(n);
+        shift.resize(n);
+        for (int i = 0; i < n; ++i) {
+            const float s = g[i] / sqrtf(v[i] + 1e-5f);
+            scale[i] = s;
+            shift[i] = b[i] - m[i] * s;
+        }
+        return true;
+    }
+};
+
+// depthwise [C,1,1,3] (+transposed [C,1,1,3]) + pointwise [C,C,1,1] + BN at Sequential indices .0/.1/.2
+bool prep_sep(Prep &P, const std::string &name, int C, PwW &w) {
+    const float *dw = P.get(name + ".0.weight"), *pw = P.get(name + ".1.weight");
+    std::vector<float> sc, sh;
+    if (!dw || !pw || !P.bn(name + ".2", C, sc, sh)) return false;
+    w.dw = P.alloc(3 * C);
+    w.wt = P.alloc((size_t)C * C);
+    w.bias = P.alloc(C);
+    for (int c = 0; c < C; ++c)
+        for (int j = 0; j < 3; ++j) P.out[w.dw + j * C + c] = dw[c * 3 + j];
+    for (int n = 0; n < C; ++n)
+        for (int k = 0; k < C; ++k) P.out[w.wt + (size_t)k * C + n] = pw[(size_t)n * C + k] * sc[n];
+    for (int n = 0; n < C; ++n) P.out[w.bias + n] = sh[n];
+    return true;
+}
+// pathway conv{N}p: Conv2d(C,C,1,groups=C) [C,1,1,1] + BN at .0/.1  ->  y = relu(a*x + b)
+bool prep_path(Prep &P, const std::string &name, int C, size_t &a_off, size_t &b_off) {
+    const float *w = P.get(name + ".0.weight");
+    std::vector<float> sc, sh;
+    if (!w || !P.bn(name + ".1", C, sc, sh)) return false;
+    a_off = P.alloc(C);
+    b_off = P.alloc(C);
+    for (int c = 0; c < C; ++c) {
+        P.out[a_off + c] = w[c] * sc[c];
+        P.out[b_off + c] = sh[c];
+    }
+    return true;
+}
+bool prep_glin(Prep &P, const std::string &name, GlinW &g) {
+    const DfxTensor *t = nullptr;
+    const float *w = P.get(name, &t);
+    if (!w) return false;
+    g.G = (int)t->shape[0];
+    g.Kg = (int)t->shape[1];
+    g.Ng = (int)t->shape[2];
+    g.w = P.alloc((size_t)t->numel());
+    memcpy(&P.out[g.w], w, sizeof(float) * (size_t)t->numel());
+    return true;
+}
+bool prep_gru(Prep &P, const std::string &name, int layers, std::vector<GruW> &out) {
+    const int H = 256;
+    for (int l = 0; l < layers; ++l) {
+        const std::string s = std::to_string(l);
+        const float *wih = P.get(name + ".weight_ih_l" + s), *whh = P.get(name + ".weight_hh_l" + s);
+        const float *bih = P.get(name + ".bias_ih_l" + s), *bhh = P.get(name + ".bias_hh_l" + s);
+        if (!wih || !whh || !bih || !bhh) return false;
+        GruW g;
+        g.wih_t = P.alloc((size_t)H * 3 * H);
+        g.bias_i = P.alloc(3 * H);
+        g.whh4 = P.alloc((size_t)H * 3 * H);
+        g.bhn = P.alloc(H);
+        for (int n = 0; n < 3 * H; ++n)
+            for (int k = 0; k < H; ++k) P.out[g.wih_t + (size_t)k * 3 * H + n] = wih[(size_t)n * H + k];
+        // r and z gates: both biases can be summed up front; the n gate keeps b_hn inside r*(...)
+        for (int n = 0; n < 3 * H; ++n) P.out[g.bias_i + n] = bih[n] + (n < 2 * H ? bhh[n] : 0.f);
+        for (int k4 = 0; k4 < H / 4; ++k4)
+            for (int gate = 0; gate < 3; ++gate)
+                for (int j = 0; j < H; ++j)
+                    for (int e = 0; e < 4; ++e)
+                        P.out[g.whh4 + ((((size_t)k4 * 3 + gate) * H + j) * 4 + e)] = whh[(size_t)(gate * H + j) * H + 4 * k4 + e];
+        for (int j = 0; j < H; ++j) P.out[g.bhn + j] = bhh[2 * H + j];
+        out.push_back(g);
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx_model **out) {
+    if (int rc = check_cfg(cfg)) return rc;
+    if (!blob || !out) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_create: null");
+    if (int rc = dfx_require_device()) return rc;
+    const dfx_model_cfg &c = *cfg;
+    const DfxManifest man = dfx_build_manifest(c);
+    Prep P{blob, man, {}, {}};
+    dfx_model *m = new dfx_model();
+    m->cfg = c;
+    const int C = c.conv_ch, O = c.df_order;
+    bool ok = true;
+    {   // enc.erb_conv0: pad(.0) conv(.1) bn(.2)
+        const float *w = P.get("enc.erb_conv0.1.weight");
+        std::vector<float> sc, sh;
+        ok = ok && w && P.bn("enc.erb_conv0.2", C, sc, sh);
+        if (ok) {
+            m->erb0_w = P.alloc(9 * C);
+            m->erb0_b = P.alloc(C);
+            for (int ch = 0; ch < C; ++ch) {
+                for (int k = 0; k < 9; ++k) P.out[m->erb0_w + k * C + ch] = w[ch * 9 + k] * sc[ch];
+                P.out[m->erb0_b + ch] = sh[ch];
+            }
+        }
+    }
+    ok = ok && prep_sep(P, "enc.erb_conv1", C, m->erb1) && prep_sep(P, "enc.erb_conv2", C, m->erb2) &&
+         prep_sep(P, "enc.erb_conv3", C, m->erb3) && prep_sep(P, "enc.df_conv1", C, m->dfc1);
+    if (ok) {   // enc.df_conv0: pad(.0) conv groups=2 (.1) pointwise(.2) bn(.3)
+        const float *w = P.get("enc.df_conv0.1.weight"), *pw = P.get("enc.df_conv0.2.weight");
+        std::vector<float> sc, sh;
+        ok = w && pw && P.bn("enc.df_conv0.3", C, sc, sh);
+        if (ok) {
+            m->dfc0.dw = P.alloc(9 * C);
+            m->dfc0.wt = P.alloc((size_t)C * C);
+            m->dfc0.bias = P.alloc(C);
+            for (int ch = 0; ch < C; ++ch)
+                for (int k = 0; k < 9; ++k) P.out[m->dfc0.dw + k * C + ch] = w[ch * 9 + k];
+            for (int n = 0; n < C; ++n) {
+                for (int k = 0; k < C; ++k) P.out[m->dfc0.wt + (size_t)k * C + n] = pw[(size_t)n * C + k] * sc[n];
+                P.out[m->dfc0.bias + n] = sh[n];
+            }
+        }
+    }
+    ok = ok && prep_glin(P, "enc.df_fc_emb.0.weight", m->fc_emb) && prep_glin(P, "enc.emb_gru.linear_in.0.weight", m->enc_in) &&
+         prep_gru(P, "enc.emb_gru.gru", 1, m->enc_gru) && prep_glin(P, "enc.emb_gru.linear_out.0.weight", m->enc_out);
+    if (ok) {
+        const float *w = P.get("enc.lsnr_fc.0.weight"), *b = P.get("enc.lsnr_fc.0.bias");
+        ok = w && b;
+        if (ok) {
+            const int emb = C * c.nb_erb / 4;
+            m->lsnr_w = P.alloc(emb);
+            memcpy(&P.out[m->lsnr_w], w, sizeof(float) * emb);
+            m->lsnr_b = b[0];
+        }
+    }
+    ok = ok && prep_glin(P, "erb_dec.emb_gru.linear_in.0.weight", m->dec_in) &&
+         prep_gru(P, "erb_dec.emb_gru.gru", c.emb_num_layers - 1, m->dec_gru) &&
+         prep_glin(P, "erb_dec.emb_gru.linear_out.0.weight", m->dec_out);
+    ok = ok && prep_sep(P, "erb_dec.convt3", C, m->ct3) && prep_path(P, "erb_dec.conv3p", C, m->ct3.sk_a, m->ct3.sk_b) &&
+         prep_sep(P, "erb_dec.convt2", C, m->ct2) && prep_path(P, "erb_dec.conv2p", C, m->ct2.sk_a, m->ct2.sk_b) &&
+         prep_sep(P, "erb_dec.convt1", C, m->ct1) && prep_path(P, "erb_dec.conv1p", C, m->ct1.sk_a, m->ct1.sk_b) &&
+         prep_path(P, "erb_dec.conv0p", C, m->co_ska, m->co_skb);
+    m->ct3.has_skip = m->ct2.has_skip = m->ct1.has_skip = true;
+    if (ok) {   // erb_dec.conv0_out: conv [1,C,1,3] (.0) bn(1) (.1)
+        const float *w = P.get("erb_dec.conv0_out.0.weight");
+        std::vector<float> sc, sh;
+        ok = w && P.bn("erb_dec.conv0_out.1", 1, sc, sh);
+        if (ok) {
+            m->co_w = P.alloc(3 * C);
+            for (int ch = 0; ch < C; ++ch)
+                for (int j = 0; j < 3; ++j) P.out[m->co_w + j * C + ch] = w[ch * 3 + j] * sc[0];
+            m->co_bias = sh[0];
+        }
+    }
+    if (ok) {   // df_dec.df_convp
+        const int kt = c.df_pathway_kernel_size_t, NO = 2 * O, G = dfx_gcd(C, NO), CG = C / G, OG = NO / G;
+        const int idx = kt > 1 ? 1 : 0;
+        const bool has_pw = kt > 1;  // separable only if groups > 1 and max(kernel) > 1; groups > 1 always holds (2 | C, 2O)
+        const float *w = P.get("df_dec.df_convp." + std::to_string(idx) + ".weight");
+        const float *pw = has_pw ? P.get("df_dec.df_convp." + std::to_string(idx + 1) + ".weight") : nullptr;
+        std::vector<float> sc, sh;
+        ok = w && (!has_pw || pw) && P.bn("df_dec.df_convp." + std::to_string(idx + (has_pw ? 2 : 1)), NO, sc, sh);
+        if (ok) {
+            m->cp_G = G;
+            m->cp_NO = NO;
+            m->cp_w1 = P.alloc((size_t)G * kt * CG * 16);
+            m->cp_w2 = P.alloc((size_t)NO * NO);
+            m->cp_b = P.alloc(NO);
+            for (int g = 0; g < G; ++g)
+                for (int k = 0; k < kt; ++k)
+                    for (int ci = 0; ci < CG; ++ci)
+                        for (int o = 0; o < OG; ++o) {
+                            // weight [NO, CG, kt, 1]
+                            float v = w[(((size_t)(g * OG + o) * CG + ci) * kt + k)];
+                            if (!has_pw) v *= sc[g * OG + o];
+                            P.out[m->cp_w1 + ((((size_t)g * kt + k) * CG + ci) * 16 + o)] = v;
+                        }
+            for (int n = 0; n < NO; ++n) {
+                for (int o = 0; o < NO; ++o) P.out[m->cp_w2 + (size_t)n * NO + o] = has_pw ? pw[(size_t)n * NO + o] * sc[n] : (n == o ? 1.f : 0.f);
+                P.out[m->cp_b + n] = sh[n];
+            }
+        }
+    }
+    ok = ok && prep_glin(P, "df_dec.df_gru.linear_in.0.weight", m->dfg_in) && prep_gru(P, "df_dec.df_gru.gru", c.df_num_layers, m->df_gru);
+    if (ok && c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) ok = prep_glin(P, "df_dec.df_skip.weight", m->df_skip);
+    ok = ok && prep_glin(P, "df_dec.df_out.0.weight", m->df_out);
+    if (!ok) {
+        delete m;
+        DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_create: %s", P.err.empty() ? "weight preparation failed" : P.err.c_str());
+    }
+    m->n_w = P.out.size();
+    if (hipMalloc(reinterpret_cast<void **>(&m->d_w), m->n_w * sizeof(float)) != hipSuccess) {
+        delete m;
+        DFX_FAIL(DFX_ERR_ALLOC, "dfx_model_create: device allocation of %zu bytes failed", m->n_w * sizeof(float));
+    }
+    if (hipMemcpy(m->d_w, P.out.data(), m->n_w * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        dfx_model_free(m);
+        DFX_FAIL(DFX_ERR_HIP, "dfx_model_create: upload failed");
+    }
+    *out = m;
+    return DFX_OK;
+}
+
+extern "C" void dfx_model_free(dfx_model *m) {
+    if (!m) return;
+    if (m->d_w) (void)hipFree(m->d_w);
+    delete m;
+}
+extern "C" int dfx_model_cfg_get(const dfx_model *m, dfx_model_cfg *out) {
+    if (!m || !out) DFX_FAIL(DFX_ERR_INVALID_ARG, "null");
+    *out = m->cfg;
+    return DFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ workspace plan
+namespace {
+struct Ws {
+    // offsets in floats, each 64-float (256 B) aligned
+    size_t e0, e1, e2, e3, c0, c1, emb_in, emb, xa, xb, gi, demb, d3, d2, d1, mask, c0p, xdf, coefs, lsnr, total;
+};
+Ws plan_ws(const dfx_model_cfg &c, int64_t R) {
+    Ws w{};
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        size_t o = off;
+        off += (n + 63) & ~(size_t)63;
+        return o;
+    };
+    const size_t C = c.conv_ch, E = c.nb_erb, Fd = c.nb_df, emb = C * E / 4, NO = 2 * c.df_order;
+    w.e0 = take(R * E * C);
+    w.e1 = take(R * (E / 2) * C);
+    w.e2 = take(R * (E / 4) * C);
+    w.e3 = take(R * (E / 4) * C);
+    w.c0 = take(R * Fd * C);
+    w.c1 = take(R * (Fd / 2) * C);
+    w.emb_in = take(R * emb);
+    w.emb = take(R * emb);
+    w.xa = take(R * 256);
+    w.xb = take(R * 256);
+    w.gi = take(R * 768);
+    w.demb = take(R * emb);
+    w.d3 = take(R * (E / 4) * C);
+    w.d2 = take(R * (E / 2) * C);
+    w.d1 = take(R * E * C);
+    w.mask = take(R * E);
+    w.c0p = take(R * Fd * NO);
+    w.xdf = take(R * 256);
+    w.coefs = take(R * Fd * NO);
+    w.lsnr = take(R);
+    w.total = off;
+    return w;
+}
+}  // namespace
+
+extern "C" int dfx_model_workspace_bytes(const dfx_model *m, int64_t B, int64_t T, int64_t *bytes) {
+    if (!m || !bytes || B < 0 || T < 0) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_workspace_bytes: bad arguments");
+    *bytes = (int64_t)(plan_ws(m->cfg, B * T).total * sizeof(float)) + 256;
+    return DFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ launch helpers
+static int nn_grid(int64_t tiles, int per_cu) {
+    const int64_t cap = (int64_t)dfx_env_num_cus() * per_cu;
+    return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
+}
+
+template <int C>
+static int launch_pw(int mode, const dfx_model *m, const PwW &w, const float *x, const float *skip, float *out, int64_t R,
+                     int64_t T, int Fin, int Fout, int stride, int L, hipStream_t s) {
+    DfxPwArgs A;
+    A.x = x;
+    A.skip = skip;
+    A.sk_a = skip ? m->p(w.sk_a) : nullptr;
+    A.sk_b = skip ? m->p(w.sk_b) : nullptr;
+    A.dw = m->p(w.dw);
+    A.wt = m->p(w.wt);
+    A.bias = m->p(w.bias);
+    A.out = out;
+    A.R = R;
+    A.T = T;
+    A.Fin = Fin;
+    A.Fout = Fout;
+    A.stride = stride;
+    A.L = L;
+    const int grid = nn_grid(dfx_ceil_div(R * Fout, DFX_PW_MT), 4);
+    if (mode == DFX_PW_MODE_DW3) dfx_launch(dfx_k_pwconv<C, DFX_PW_MODE_DW3>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
+    else if (mode == DFX_PW_MODE_DWT3) dfx_launch(dfx_k_pwconv<C, DFX_PW_MODE_DWT3>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
+    else dfx_launch(dfx_k_pwconv<C, DFX_PW_MODE_IN33>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
+}
+
+static int launch_ggemm(const float *a, int lda, const float *w, int G, int Kg, int Ng, const float *bias, int act,
+                        const float *res, float *out, int ldo, int64_t M, hipStream_t s) {
+    if (M <= 0) return DFX_OK;
+    if (Kg % 4 || Ng % 4 || lda % 4) DFX_FAIL(DFX_ERR_UNSUPPORTED, "grouped GEMM needs K, N, lda multiples of 4 (got %d, %d, %d)", Kg, Ng, lda);
+    DfxGgArgs A;
+    A.a = a;
+    A.w = w;
+    A.bias = bias;
+    A.res = res;
+    A.out = out;
+    A.M = M;
+    A.lda = lda;
+    A.ldo = ldo;
+    A.G = G;
+    A.Kg = Kg;
+    A.Ng = Ng;
+    A.act = act;
+    const int BN = Ng <= 16 ? 16 : (Ng <= 32 ? 32 : 64);
+    A.ntn = (Ng + BN - 1) / BN;
+    const dim3 grid((unsigned)dfx_ceil_div(M, DFX_GG_BM), (unsigned)(G * A.ntn));
+    if (BN == 16) dfx_launch(dfx_k_ggemm<16>, grid, dim3(DFX_GG_THREADS), 0, s, A);
+    else if (BN == 32) dfx_launch(dfx_k_ggemm<32>, grid, dim3(DFX_GG_THREADS), 0, s, A);
+    else dfx_launch(dfx_k_ggemm<64>, grid, dim3(DFX_GG_THREADS), 0, s, A);
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
+}
+static int launch_glin(const dfx_model *m, const GlinW &g, const float *a, int act, const float *res, float *out, int64_t M,
+                       hipStream_t s) {
+    return launch_ggemm(a, g.G * g.Kg, m->p(g.w), g.G, g.Kg, g.Ng, nullptr, act, res, out, g.G * g.Ng, M, s);
+}
+
+// SqueezedGRU_S without its linear_in/linear_out (modules.py:702-738): layers of (input projection GEMM, recurrence).
+// x: [R,256] input; result pointer returned through *y (ping-pong between xa/xb).
+static int run_gru_stack(const dfx_model *m, const std::vector<GruW> &layers, const float *x, float *bufa, float *bufb,
+                         float *gi, int64_t B, int64_t T, const float **y, hipStream_t s) {
+    const int64_t R = B * T;
+    const float *in = x;
+    float *outb = (x == bufa) ? bufb : bufa;
+    for (size_t l = 0; l < layers.size(); ++l) {
+        const GruW &g = layers[l];
+        if (int rc = launch_ggemm(in, 256, m->p(g.wih_t), 1, 256, 768, m->p(g.bias_i), DFX_ACT_NONE, nullptr, gi, 768, R, s)) return rc;
+        dfx_launch(dfx_k_gru_rec, dim3((unsigned)dfx_ceil_div(B, DFX_GRU_ROWS)), dim3(DFX_GRU_H), 0, s, (const float *)gi,
+                   reinterpret_cast<const float4 *>(m->p(g.whh4)), m->p(g.bhn), outb, B, T);
+        DFX_LAUNCH_CHECK();
+        in = outb;
+        outb = (outb == bufa) ? bufb : bufa;
+    }
+    *y = in;
+    return DFX_OK;
+}
+
+template <int C>
+static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float *spec, const float *feat_erb,
+                        const float *feat_spec, int64_t B, int64_t T, float atten_lim, float *spec_e, float *mask_out,
+                        float *lsnr_out, float *coefs_out, float *ws, hipStream_t s) {
+    const dfx_model_cfg &c = m->cfg;
+    const int64_t R = B * T;
+    const Ws w = plan_ws(c, R);
+    const int E = c.nb_erb, Fd = c.nb_df, O = c.df_order, NO = 2 * O, emb = C * E / 4, L = c.conv_lookahead;
+    float *e0 = ws + w.e0, *e1 = ws + w.e1, *e2 = ws + w.e2, *e3 = ws + w.e3, *c0 = ws + w.c0, *c1 = ws + w.c1;
+    float *emb_in = ws + w.emb_in, *embv = ws + w.emb, *xa = ws + w.xa, *xb = ws + w.xb, *gi = ws + w.gi;
+    float *demb = ws + w.demb, *d3 = ws + w.d3, *d2 = ws + w.d2, *d1 = ws + w.d1;
+    float *mask = mask_out ? mask_out : ws + w.mask;
+    float *c0p = ws + w.c0p, *xdf = ws + w.xdf;
+    float *coefs = coefs_out ? coefs_out : ws + w.coefs;
+    float *lsnr = lsnr_out ? lsnr_out : ws + w.lsnr;
+    int rc;
+    // ---- Encoder (deepfilternet3.py:166-185)
+    {
+        const int64_t total = R * E * C;
+        dfx_launch(dfx_k_conv_in_erb, dim3((unsigned)nn_grid(dfx_ceil_div(total, 256), 16)), dim3(256), 0, s, feat_erb,
+                   m->p(m->erb0_w), m->p(m->erb0_b), e0, B, T, E, C, L);
+        DFX_LAUNCH_CHECK();
+    }
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb1, e0, nullptr, e1, R, T, E, E / 2, 2, 0, s))) return rc;
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb2, e1, nullptr, e2, R, T, E / 2, E / 4, 2, 0, s))) return rc;
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb3, e2, nullptr, e3, R, T, E / 4, E / 4, 1, 0, s))) return rc;
+    if ((rc = launch_pw<C>(DFX_PW_MODE_IN33, m, m->dfc0, feat_spec, nullptr, c0, R, T, Fd, Fd, 1, L, s))) return rc;
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->dfc1, c0, nullptr, c1, R, T, Fd, Fd / 2, 2, 0, s))) return rc;
+    // cemb = relu(df_fc_emb(c1.flatten)); emb_in = e3.flatten + cemb   (:179-182)
+    if ((rc = launch_glin(m, m->fc_emb, c1, DFX_ACT_RELU, e3, emb_in, R, s))) return rc;
+    // enc.emb_gru (SqueezedGRU_S :149-158)
+    if ((rc = launch_glin(m, m->enc_in, emb_in, DFX_ACT_RELU, nullptr, xa, R, s))) return rc;
+    const float *y = nullptr;
+    if ((rc = run_gru_stack(m, m->enc_gru, xa, xa, xb, gi, B, T, &y, s))) return rc;
+    if ((rc = launch_glin(m, m->enc_out, y, DFX_ACT_RELU, nullptr, embv, R, s))) return rc;
+    dfx_launch(dfx_k_lsnr, dim3((unsigned)dfx_ceil_div(R * 64, 256)), dim3(256), 0, s, (const float *)embv, m->p(m->lsnr_w),
+               m->lsnr_b, (float)(c.lsnr_max - c.lsnr_min), (float)c.lsnr_min, lsnr, R, emb);
+    DFX_LAUNCH_CHECK();
+    // ---- ErbDecoder (:245-254)
+    if ((rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, xa, R, s))) return rc;
+    if ((rc = run_gru_stack(m, m->dec_gru, xa, xa, xb, gi, B, T, &y, s))) return rc;
+    if ((rc = launch_glin(m, m->dec_out, y, DFX_ACT_RELU, nullptr, demb, R, s))) return rc;
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, R, T, E / 4, E / 4, 1, 0, s))) return rc;
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, R, T, E / 4, E / 2, 2, 0, s))) return rc;
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, R, T, E / 2, E, 2, 0, s))) return rc;
+    {
+        const int fpt = 64 / E > 0 ? 64 / E : 1;
+        const size_t smem = ((size_t)fpt * E * (C + 1) + (size_t)fpt * E * 3 + 3 * C) * sizeof(float);
+        dfx_launch(dfx_k_conv_out<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R, fpt), 8)), dim3(DFX_CO_THREADS), smem, s,
+                   (const float *)d1, (const float *)e0, m->p(m->co_ska), m->p(m->co_skb), m->p(m->co_w), m->co_bias, mask,
+                   R, E, fpt);
+        DFX_LAUNCH_CHECK();
+    }
+    // ---- DfDecoder (:323-331)
+    if ((rc = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa, R, s))) return rc;
+    if ((rc = run_gru_stack(m, m->df_gru, xa, xa, xb, gi, B, T, &y, s))) return rc;
+    const float *cfeat = y;
+    if (c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) {
+        if ((rc = launch_glin(m, m->df_skip, embv, DFX_ACT_NONE, y, xdf, R, s))) return rc;
+        cfeat = xdf;
+    } else if (c.df_gru_skip == DFX_SKIP_IDENTITY) {
+        dfx_launch(dfx_k_add, dim3((unsigned)nn_grid(dfx_ceil_div(R * 256, 256), 16)), dim3(256), 0, s, y, (const float *)embv,
+                   xdf, R * 256);
+        DFX_LAUNCH_CHECK();
+        cfeat = xdf;
+    }
+    {
+        DfxCpArgs A;
+        A.c0 = c0;
+        A.w1 = m->p(m->cp_w1);
+        A.w2 = m->p(m->cp_w2);
+        A.bias = m->p(m->cp_b);
+        A.out = c0p;
+        A.B = B;
+        A.T = T;
+        A.Fd = Fd;
+        A.kt = c.df_pathway_kernel_size_t;
+        A.G = m->cp_G;
+        A.NO = NO;
+        A.tchunks = (int)dfx_ceil_div(T, DFX_CP_TT);
+        A.fchunks = (Fd + DFX_CP_FB - 1) / DFX_CP_FB;
+        const int CG = C / A.G;
+        const size_t smem = ((size_t)(DFX_CP_TT + A.kt - 1) * DFX_CP_FB * (C + 2) + (size_t)A.G * A.kt * CG * 16 +
+                             (size_t)DFX_CP_TT * DFX_CP_FB * NO) * sizeof(float);
+        if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_df_convp<C>, smem));
+        const int64_t nblk = B * A.tchunks * A.fchunks;
+        if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "df_convp grid too large");
+        dfx_launch(dfx_k_df_convp<C>, dim3((unsigned)nblk), dim3(DFX_CP_THREADS), smem, s, A);
+        DFX_LAUNCH_CHECK();
+    }
+    // c = tanh(df_out(c)).view(b,t,F',2O) + c0p   (:329-330); flat index f*2O + 2n + {re,im} == [B,T,F',O][2]
+    if ((rc = launch_glin(m, m->df_out, cfeat, DFX_ACT_TANH, c0p, coefs, R, s))) return rc;
+    // ---- Mask + MF.DF + combine + post filter + atten_lim (:426-454, enhance.py:238-240)
+    return dfx_launch_df_apply(spec, coefs, DFX_COEF_BTFO, mask, bands, B, T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead,
+                               c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, s);
+}
+
+extern "C" int dfx_model_forward(const dfx_model *m, const dfx_bands *bands, const float *spec, const float *feat_erb,
+                                 const float *feat_spec, int64_t B, int64_t T, float atten_lim, float *spec_e,
+                                 float *mask, float *lsnr, float *df_coefs, void *workspace, int64_t workspace_bytes,
+                                 void *stream) {
+    if (!m || !bands || B < 0 || T < 0) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_forward: bad arguments");
+    if (bands->nb != m->cfg.nb_erb || bands->F != m->cfg.fft_size / 2 + 1)
+        DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_forward: band table does not match the model (nb_erb / fft_size)");
+    if (atten_lim < 0.f || atten_lim >= 1.f) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_forward: atten_lim must be in [0,1)");
+    if (int rc = dfx_require_device()) return rc;
+    if (B == 0 || T == 0) return DFX_OK;
+    if (!spec || !feat_erb || !feat_spec || !spec_e || !workspace) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_forward: null buffer");
+    int64_t need = 0;
+    dfx_model_workspace_bytes(m, B, T, &need);
+    if (workspace_bytes < need) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_forward: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)need);
+    if (((uintptr_t)spec & 15) || ((uintptr_t)spec_e & 15) || ((uintptr_t)feat_erb & 15) || ((uintptr_t)feat_spec & 15))
+        DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_forward: buffers must be 16-byte aligned");
+    float *ws = reinterpret_cast<float *>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    hipStream_t s = dfx_stream(stream);
+    switch (m->cfg.conv_ch) {
+        case 16: return forward_impl<16>(m, bands, spec, feat_erb, feat_spec, B, T, atten_lim, spec_e, mask, lsnr, df_coefs, ws, s);
+        case 32: return forward_impl<32>(m, bands, spec, feat_erb, feat_spec, B, T, atten_lim, spec_e, mask, lsnr, df_coefs, ws, s);
+        case 64: return forward_impl<64>(m, bands, spec, feat_erb, feat_spec, B, T, atten_lim, spec_e, mask, lsnr, df_coefs, ws, s);
+    }
+    DFX_FAIL(DFX_ERR_UNSUPPORTED, "conv_ch");
+}
+
+// ------------------------------------------------------------------------------------------------ enhance()
+namespace {
+struct EnhWs {
+    size_t xpad, spec, spec_e, feat_erb, feat_spec, ysyn, model, total;  // bytes
+};
+EnhWs plan_enh(const dfx_model *m, const dfx_state *st, int64_t B, int64_t T, int pad) {
+    EnhWs w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    const int64_t Tp = pad ? T + st->N : T, Tf = Tp / st->hop, F = st->N / 2 + 1;
+    w.xpad = take(pad ? (size_t)B * Tp * 4 : 0);
+    w.spec = take((size_t)B * Tf * F * 8);
+    w.spec_e = take((size_t)B * Tf * F * 8);
+    w.feat_erb = take((size_t)B * Tf * m->cfg.nb_erb * 4);
+    w.feat_spec = take((size_t)B * Tf * m->cfg.nb_df * 8);
+    w.ysyn = take((size_t)B * Tf * st->hop * 4);
+    int64_t mb = 0;
+    dfx_model_workspace_bytes(m, B, Tf, &mb);
+    w.model = take((size_t)mb);
+    w.total = off + 256;
+    return w;
+}
+}  // namespace
+
+// copy rows with zero padding / offset: dst[b, i] = (i + src_off < src_len) ? src[b, i + src_off] : 0
+__global__ void dfx_k_copy_rows(const float *src, int64_t src_stride, int64_t src_len, int64_t src_off, float *dst,
+                                int64_t dst_stride, int64_t dst_len, int64_t B) {
+    const int64_t n = B * dst_len;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / dst_len, j = i - b * dst_len;
+        const int64_t sj = j + src_off;
+        dst[b * dst_stride + j] = sj < src_len ? src[b * src_stride + sj] : 0.f;
+    }
+}
+
+extern "C" int dfx_enhance_workspace_bytes(const dfx_model *m, const dfx_state *st, int64_t B, int64_t T, int pad, int64_t *bytes) {
+    if (!m || !st || !bytes || B < 0 || T < 0) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_enhance_workspace_bytes: bad arguments");
+    *bytes = (int64_t)plan_enh(m, st, B, T, pad).total;
+    return DFX_OK;
+}
+
+extern "C" int dfx_enhance(const dfx_model *m, const dfx_state *st, const float *x, int64_t B, int64_t T, int pad,
+                           float atten_lim_db, float *y, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!m || !st || B < 0 || T < 0) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_enhance: bad arguments");
+    const dfx_model_cfg &c = m->cfg;
+    if (st->N != c.fft_size || st->hop != c.hop_size || st->nb != c.nb_erb)
+        DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_enhance: DF state does not match the model configuration");
+    if (pad && st->N % st->hop) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_enhance: pad requires fft_size %% hop_size == 0 (enhance.py:247)");
+    if (int rc = dfx_require_device()) return rc;
+    if (B == 0) return DFX_OK;
+    if (!x || !y || !workspace) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_enhance: null buffer");
+    const EnhWs w = plan_enh(m, st, B, T, pad);
+    if (workspace_bytes < (int64_t)w.total) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_enhance: workspace too small");
+    unsigned char *base = reinterpret_cast<unsigned char *>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    hipStream_t s = dfx_stream(stream);
+    const int64_t Tp = pad ? T + st->N : T, Tf = Tp / st->hop;
+    const int64_t out_len = pad ? T : Tf * st->hop;
+    if (Tf == 0) {
+        if (out_len > 0) DFX_HIP(hipMemsetAsync(y, 0, (size_t)B * out_len * 4, s));
+        return DFX_OK;
+    }
+    const float *xin = x;
+    int64_t xstride = T;
+    if (pad) {  // F.pad(audio, (0, n_fft))  (enhance.py:230-233)
+        float *xp = reinterpret_cast<float *>(base + w.xpad);
+        dfx_launch(dfx_k_copy_rows, dim3((unsigned)nn_grid(dfx_ceil_div(B * Tp, 256), 16)), dim3(256), 0, s, x, T, T,
+                   (int64_t)0, xp, Tp, Tp, B);
+        DFX_LAUNCH_CHECK();
+        xin = xp;
+        xstride = Tp;
+    }
+    float *spec = reinterpret_cast<float *>(base + w.spec), *spec_e = reinterpret_cast<float *>(base + w.spec_e);
+    float *fe = reinterpret_cast<float *>(base + w.feat_erb), *fs = reinterpret_cast<float *>(base + w.feat_spec);
+    float *ysyn = reinterpret_cast<float *>(base + w.ysyn);
+    int rc = dfx_features(st, xin, B, Tp, xstride, c.nb_df, c.norm_alpha, spec, fe, fs, stream);
+    if (rc) return rc;
+    float lim = 0.f;
+    if (atten_lim_db != 0.f) lim = powf(10.f, -fabsf(atten_lim_db) / 20.f);  // enhance.py:238-239
+    int64_t mb = 0;
+    dfx_model_workspace_bytes(m, B, Tf, &mb);
+    rc = dfx_model_forward(m, st->bands, spec, fe, fs, B, Tf, lim, spec_e, nullptr, nullptr, nullptr, base + w.model, mb, stream);
+    if (rc) return rc;
+    if (pad) {
+        rc = dfx_synthesis(st, spec_e, B, Tf, nullptr, nullptr, ysyn, Tf * st->hop, stream);
+        if (rc) return rc;
+        const int64_t d = st->N - st->hop;  // enhance.py:248-249: audio[:, d : orig_len + d]
+        dfx_launch(dfx_k_copy_rows, dim3((unsigned)nn_grid(dfx_ceil_div(B * T, 256), 16)), dim3(256), 0, s, (const float *)ysyn,
+                   Tf * st->hop, Tf * st->hop, d, y, T, T, B);
+        DFX_LAUNCH_CHECK();
+        return DFX_OK;
+    }
+    return dfx_synthesis(st, spec_e, B, Tf, nullptr, nullptr, y, Tf * st->hop, stream);
+}

@@ -1,0 +1,488 @@
+// HIP kernels for the DNN half of DeepFilterNet3 (deepfilternet3.py:100-331) on MI355X / gfx950.
+//
+// Layout: every activation is channels-last, [rows = B*T][F][C] float32 — the layout the reference's own
+// permute/flatten calls produce (deepfilternet3.py:178-181,248-249,328), so "emb = e3.permute(0,2,3,1).flatten(2)" and
+// "df_convp(c0).permute(0,2,3,1)" are free here.
+// Arithmetic: float32 everywhere (parity bar: 1e-4 RMS on the waveform against the reference's fp32 CPU path).  Dense
+// contractions (pointwise 1x1 convs, grouped linears, GRU input projections, DF pathway conv) run on the matrix cores
+// with v_mfma_f32_16x16x4_f32, which is bit-identical to an fmaf chain; everything else is VALU + LDS.
+// BatchNorm (eval) is folded into the preceding convolution on the host (dfx_model.hip).
+#pragma once
+
+#include "dfx_common.h"
+
+#define DFX_ACT_NONE 0
+#define DFX_ACT_RELU 1
+#define DFX_ACT_TANH 2
+#define DFX_ACT_SIGMOID 3
+
+static __device__ __forceinline__ float dfx_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+static __device__ __forceinline__ float dfx_act(float v, int act) {
+    if (act == DFX_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == DFX_ACT_TANH) return tanhf(v);
+    if (act == DFX_ACT_SIGMOID) return dfx_sigmoid(v);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// enc.erb_conv0: Conv2d(1 -> C, 3x3, causal in time, pad 1 in freq) + BN + ReLU   (deepfilternet3.py:106-108)
+//   feat [B,T,E] -> out [B*T, E, C].  Lookahead L: tap kt of output frame t reads input frame t+L-2+kt, and is zero when
+//   t-2+kt < 0 (causal pad applied AFTER the lookahead shift, deepfilternet3.py:357-361,409) or when the frame is >= T.
+// One thread per output element, channel fastest (coalesced stores; the 9 inputs are wave-broadcast loads).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void dfx_k_conv_in_erb(const float *feat, const float *w /*[3][3][C]*/, const float *bias /*[C]*/, float *out,
+                                  int64_t B, int64_t T, int E, int C, int L) {
+    const int64_t total = B * T * E * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t p = i / C;
+        const int f = (int)(p % E);
+        const int64_t r = p / E;
+        const int64_t t = r % T, b = r / T;
+        float acc = bias[c];
+        for (int kt = 0; kt < 3; ++kt) {
+            const int64_t tau = t - 2 + kt, tin = tau + L;
+            if (tau < 0 || tin >= T) continue;
+            const float *row = feat + (b * T + tin) * E;
+            for (int kf = 0; kf < 3; ++kf) {
+                const int fin = f - 1 + kf;
+                if (fin < 0 || fin >= E) continue;
+                acc += w[(kt * 3 + kf) * C + c] * row[fin];
+            }
+        }
+        out[i] = fmaxf(acc, 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused [depthwise / input conv prologue] -> pointwise 1x1 (C x C, MFMA) -> +bias (folded BN) -> ReLU.
+// Covers Conv2dNormAct / ConvTranspose2dNormAct with separable=True (modules.py:18-126):
+//   MODE_DW3   depthwise 1x3 conv over freq, stride s in {1,2}, pad 1                     (enc.erb_conv1-3, df_conv1, convt3)
+//   MODE_DWT3  depthwise 1x3 transposed conv, stride 2, padding 1, output_padding 1        (erb_dec.convt2, convt1)
+//   MODE_IN33  3x3 conv (2 -> C, groups=2) over (time, freq) on the complex feature tensor (enc.df_conv0)
+// Optional skip input for the decoder:  xin = relu(sk_a[c]*skip + sk_b[c]) + x   (conv{3,2,1}p pathway + Add,
+// deepfilternet3.py:250-252; convNp is a per-channel scalar + BN + ReLU).
+// Tile: 64 output positions x C channels per iteration; the prologue result is staged in LDS as the MFMA A operand
+// (row stride C+2: conflict-free ds_read_b32 for the 16x16x4 fragment), the C x C weight matrix sits in registers.
+// ---------------------------------------------------------------------------------------------------------------------
+#define DFX_PW_MODE_DW3 0
+#define DFX_PW_MODE_DWT3 1
+#define DFX_PW_MODE_IN33 2
+#define DFX_PW_THREADS 256
+#define DFX_PW_MT 64
+
+struct DfxPwArgs {
+    const float *x;      // [R, Fin, C]  (MODE_IN33: feat [B,T,Fin,2])
+    const float *skip;   // [R, Fin, C] or null
+    const float *sk_a, *sk_b;  // [C]
+    const float *dw;     // MODE_DW3/DWT3: [3][C]; MODE_IN33: [9][C]
+    const float *wt;     // [C][C]  wt[k][n] = W_pw[n][k] * bn_scale[n]
+    const float *bias;   // [C]
+    float *out;          // [R, Fout, C]
+    int64_t R, T;
+    int Fin, Fout, stride, L;
+};
+
+template <int C, int MODE>
+__global__ void __launch_bounds__(DFX_PW_THREADS) dfx_k_pwconv(DfxPwArgs A) {
+    constexpr int LDA = C + 2;
+    constexpr int NT = C / 16, KS = C / 4;
+    __shared__ float As[DFX_PW_MT * LDA];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // B fragments: breg[nt][ks] = wt[4*ks + (lane>>4)][16*nt + (lane&15)]
+    float breg[NT][KS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) breg[nt][ks] = A.wt[(4 * ks + (lane >> 4)) * C + 16 * nt + (lane & 15)];
+    const int c = tid % C;
+    constexpr int PSTEP = DFX_PW_THREADS / C;
+    const int p0 = tid / C;
+    float wd[MODE == DFX_PW_MODE_IN33 ? 9 : 3];
+#pragma unroll
+    for (int j = 0; j < (MODE == DFX_PW_MODE_IN33 ? 9 : 3); ++j) wd[j] = A.dw[j * C + c];
+    const float ska = A.skip ? A.sk_a[c] : 0.f, skb = A.skip ? A.sk_b[c] : 0.f;
+    float biasr[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) biasr[nt] = A.bias[16 * nt + (lane & 15)];
+
+    const int64_t total = A.R * A.Fout;
+    const int64_t ntiles = (total + DFX_PW_MT - 1) / DFX_PW_MT;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t pos0 = tile * DFX_PW_MT;
+        // ---- prologue: u[p][c]
+        for (int p = p0; p < DFX_PW_MT; p += PSTEP) {
+            const int64_t pos = pos0 + p;
+            float u = 0.f;
+            if (pos < total) {
+                const int64_t r = pos / A.Fout;
+                const int fo = (int)(pos - r * A.Fout);
+                if (MODE == DFX_PW_MODE_IN33) {
+                    const int64_t t = r % A.T, b = r / A.T;
+                    const int ch = c >= C / 2 ? 1 : 0;  // groups=2: first half of the outputs sees re, second half im
+#pragma unroll
+                    for (int kt = 0; kt < 3; ++kt) {
+                        const int64_t tau = t - 2 + kt, tin = tau + A.L;
+                        if (tau < 0 || tin >= A.T) continue;
+                        const float *row = A.x + (b * A.T + tin) * A.Fin * 2;
+#pragma unroll
+                        for (int kf = 0; kf < 3; ++kf) {
+                            const int fin = fo - 1 + kf;
+                            if (fin < 0 || fin >= A.Fin) continue;
+                            u += wd[kt * 3 + kf] * row[fin * 2 + ch];
+                        }
+                    }
+                } else {
+                    const float *xr = A.x + r * A.Fin * C;
+                    const float *sr = A.skip ? A.skip + r * A.Fin * C : nullptr;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        int fi;
+                        bool ok;
+                        if (MODE == DFX_PW_MODE_DW3) {
+                            fi = fo * A.stride + j - 1;
+                            ok = fi >= 0 && fi < A.Fin;
+                        } else {
+                            // transposed: fo = 2*fi - 1 + j
+                            const int num = fo + 1 - j;
+                            fi = num >> 1;
+                            ok = num >= 0 && (num & 1) == 0 && fi < A.Fin;
+                        }
+                        if (!ok) continue;
+                        float v = xr[fi * C + c];
+                        if (sr) v += fmaxf(ska * sr[fi * C + c] + skb, 0.f);
+                        u += wd[j] * v;
+                    }
+                }
+            }
+            As[p * LDA + c] = u;
+        }
+        __syncthreads();
+        // ---- pointwise GEMM on the matrix cores: wave w owns positions [16w, 16w+16)
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *arow = As + (16 * wave + (lane & 15)) * LDA + (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float a = arow[4 * ks];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[nt][ks], acc[nt], 0, 0, 0);
+        }
+        // ---- epilogue: D[row = 4*(lane>>4)+r][col = lane&15]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t pos = pos0 + 16 * wave + 4 * (lane >> 4) + r;
+            if (pos < total) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    A.out[pos * C + 16 * nt + (lane & 15)] = fmaxf(acc[nt][r] + biasr[nt], 0.f);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// erb_dec.conv0_out: Conv2d(C -> 1, 1x3) + BN(1) + Sigmoid on  xin = relu(a*e0 + b) + d1   (deepfilternet3.py:241-243,253)
+//   m[r, f] = sigmoid(bias + sum_j sum_c w[j][c] * xin[r, f+j-1, c])
+// A tile is a whole number of frames (E positions each); xin is staged in LDS, threads (pos, j) form the three per-
+// position dot products, then one thread per position combines the neighbours.
+// ---------------------------------------------------------------------------------------------------------------------
+#define DFX_CO_THREADS 256
+template <int C>
+__global__ void __launch_bounds__(DFX_CO_THREADS) dfx_k_conv_out(const float *x, const float *skip, const float *sk_a,
+                                                                 const float *sk_b, const float *w /*[3][C]*/, float bias,
+                                                                 float *out, int64_t R, int E, int frames_per_tile) {
+    constexpr int LDA = C + 1;
+    DFX_DYN_SMEM(float, sm);
+    const int MT = frames_per_tile * E;
+    float *As = sm;                 // [MT][LDA]
+    float *V = sm + MT * LDA;       // [MT][3]
+    float *W = V + MT * 3;          // [3][C]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 3 * C; i += DFX_CO_THREADS) W[i] = w[i];
+    const int64_t ntiles = (R + frames_per_tile - 1) / frames_per_tile;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * frames_per_tile;
+        const int64_t npos = ((R - r0) < frames_per_tile ? (R - r0) : frames_per_tile) * E;
+        for (int i = tid; i < MT * C; i += DFX_CO_THREADS) {
+            const int p = i / C, c = i - p * C;
+            float v = 0.f;
+            if (p < npos) {
+                const int64_t g = (r0 * E + p) * C + c;
+                v = x[g] + fmaxf(sk_a[c] * skip[g] + sk_b[c], 0.f);
+            }
+            As[p * LDA + c] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < MT * 3; i += DFX_CO_THREADS) {
+            const int p = i / 3, j = i - p * 3;
+            float acc = 0.f;
+            for (int c = 0; c < C; ++c) acc += W[j * C + c] * As[p * LDA + c];
+            V[i] = acc;
+        }
+        __syncthreads();
+        for (int p = tid; p < npos; p += DFX_CO_THREADS) {
+            const int f = p % E;
+            float acc = bias + V[p * 3 + 1];
+            if (f > 0) acc += V[(p - 1) * 3 + 0];
+            if (f < E - 1) acc += V[(p + 1) * 3 + 2];
+            out[r0 * E + p] = dfx_sigmoid(acc);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// df_dec.df_convp: Conv2d(C -> 2*O, (kt,1), groups = gcd(C, 2*O)) [+ 1x1 (2O x 2O) when kt > 1] + BN + ReLU
+// (deepfilternet3.py:293-295, modules.py:49-71).  in c0 [R, Fd, C] -> out [R, Fd, 2*O].
+// Per group: out1[pos][o] = sum_k sum_ci c0[t-kt+1+k, f, g*CG+ci] * W1[g][k][ci][o]   (causal: zero for frames < 0 of the clip)
+// as MFMA 16x16x4 with N padded to 16; then the small 2O x 2O pointwise + bias + ReLU on the VALU.
+// Tile: DFX_CP_TT frames x 16 bins of one clip; the kt-1 halo frames are staged with it.
+// ---------------------------------------------------------------------------------------------------------------------
+#define DFX_CP_TT 8
+#define DFX_CP_FB 16
+#define DFX_CP_THREADS 256
+struct DfxCpArgs {
+    const float *c0;   // [B*T, Fd, C]
+    const float *w1;   // [G][kt][CG][16]   (o padded to 16 with zeros; BN-scaled when there is no pointwise conv)
+    const float *w2;   // [NO][NO] w2[n][o] (BN-scaled; identity when there is no pointwise conv)
+    const float *bias; // [NO]
+    float *out;        // [B*T, Fd, NO]
+    int64_t B, T;
+    int Fd, kt, G, NO; // NO = 2*O outputs, G groups, OG = NO/G outputs per group
+    int tchunks, fchunks;
+};
+
+template <int C>
+__global__ void __launch_bounds__(DFX_CP_THREADS) dfx_k_df_convp(DfxCpArgs A) {
+    constexpr int LDC = C + 2;
+    DFX_DYN_SMEM(float, sm);
+    const int halo = DFX_CP_TT + A.kt - 1;
+    const int CG = C / A.G, OG = A.NO / A.G;
+    float *tile = sm;                                   // [halo][FB][LDC]
+    float *w1s = tile + halo * DFX_CP_FB * LDC;         // [G][kt][CG][16]
+    float *s1 = w1s + A.G * A.kt * CG * 16;             // [TT*FB][NO] stage-1 results
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int blk = blockIdx.x;
+    const int fc = blk % A.fchunks;
+    blk /= A.fchunks;
+    const int tc = blk % A.tchunks;
+    const int64_t b = blk / A.tchunks;
+    const int64_t t0 = (int64_t)tc * DFX_CP_TT;
+    const int f0 = fc * DFX_CP_FB;
+    const int nt_valid = (int)((A.T - t0) < DFX_CP_TT ? (A.T - t0) : DFX_CP_TT);
+    const int nf_valid = (A.Fd - f0) < DFX_CP_FB ? (A.Fd - f0) : DFX_CP_FB;
+    for (int i = tid; i < A.G * A.kt * CG * 16; i += DFX_CP_THREADS) w1s[i] = A.w1[i];
+    for (int i = tid; i < halo * DFX_CP_FB * C; i += DFX_CP_THREADS) {
+        const int c = i % C;
+        const int hf = i / C;
+        const int f = hf % DFX_CP_FB, h = hf / DFX_CP_FB;
+        const int64_t t = t0 - (A.kt - 1) + h;
+        float v = 0.f;
+        if (t >= 0 && t < A.T && f < nf_valid) v = A.c0[((b * A.T + t) * A.Fd + f0 + f) * C + c];
+        tile[(h * DFX_CP_FB + f) * LDC + c] = v;
+    }
+    __syncthreads();
+    // units: (t_local, g); M-tile = the 16 bins of frame t_local
+    const int nunits = DFX_CP_TT * A.G;
+    for (int u = wave; u < nunits; u += DFX_CP_THREADS / 64) {
+        const int tl = u / A.G, g = u - tl * A.G;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < A.kt; ++k) {
+            const float *arow = tile + ((tl + k) * DFX_CP_FB + (lane & 15)) * LDC + g * CG + (lane >> 4);
+            const float *brow = w1s + ((g * A.kt + k) * CG + (lane >> 4)) * 16 + (lane & 15);
+            for (int ks = 0; ks < CG / 4; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * ks], brow[4 * ks * 16], acc, 0, 0, 0);
+        }
+        // D[row = bin 4*(lane>>4)+r][col = o]
+        const int o = lane & 15;
+        if (o < OG) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 4 * (lane >> 4) + r;
+                s1[(tl * DFX_CP_FB + f) * A.NO + g * OG + o] = acc[r];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < DFX_CP_TT * DFX_CP_FB * A.NO; i += DFX_CP_THREADS) {
+        const int n = i % A.NO;
+        const int p = i / A.NO;
+        const int f = p % DFX_CP_FB, tl = p / DFX_CP_FB;
+        if (tl >= nt_valid || f >= nf_valid) continue;
+        float acc = A.bias[n];
+        for (int o = 0; o < A.NO; ++o) acc += A.w2[n * A.NO + o] * s1[p * A.NO + o];
+        A.out[((b * A.T + t0 + tl) * A.Fd + f0 + f) * A.NO + n] = fmaxf(acc, 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Grouped GEMM on the matrix cores:  out[m, g*Ng + n] = act( sum_k A[m, g*Kg + k] * W[g][k][n] + bias[g*Ng+n] ) + res[m, ...]
+// Covers GroupedLinearEinsum (modules.py:741-780; weight layout [G, I/G, H/G] used as is), the GRU input projections
+// (G = 1, W = W_ih^T) and nn.Linear-shaped ops.  Kg % 4 == 0 and Ng % 4 == 0 are required (checked on the host).
+// Block: 64 rows x BN columns of one group, K tiled by 32 through LDS; 4 waves, wave w owns rows [16w, 16w+16).
+// ---------------------------------------------------------------------------------------------------------------------
+#define DFX_GG_BM 64
+#define DFX_GG_KT 32
+#define DFX_GG_THREADS 256
+struct DfxGgArgs {
+    const float *a;     // [M, lda]
+    const float *w;     // [G][Kg][Ng]
+    const float *bias;  // [G*Ng] or null
+    const float *res;   // [M, ldo] or null (added after the activation)
+    float *out;         // [M, ldo]
+    int64_t M;
+    int lda, ldo, G, Kg, Ng, act, ntn /* N tiles per group */;
+};
+
+template <int BN>
+__global__ void __launch_bounds__(DFX_GG_THREADS) dfx_k_ggemm(DfxGgArgs A) {
+    constexpr int LDA = DFX_GG_KT + 2;
+    constexpr int LDB = (BN == 64) ? 80 : 48;
+    constexpr int NT = BN / 16;
+    __shared__ float As[DFX_GG_BM * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[DFX_GG_KT * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.y / A.ntn, n0 = (blockIdx.y - g * A.ntn) * BN;
+    const int64_t m0 = (int64_t)blockIdx.x * DFX_GG_BM;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *wg = A.w + (size_t)g * A.Kg * A.Ng;
+    for (int k0 = 0; k0 < A.Kg; k0 += DFX_GG_KT) {
+        // A tile: 64 rows x 32 k, float4 along k
+        for (int i = tid; i < DFX_GG_BM * (DFX_GG_KT / 4); i += DFX_GG_THREADS) {
+            const int row = i / (DFX_GG_KT / 4), kq = i - row * (DFX_GG_KT / 4);
+            const int64_t m = m0 + row;
+            const int k = k0 + 4 * kq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < A.M && k < A.Kg) v = *reinterpret_cast<const float4 *>(A.a + m * A.lda + g * A.Kg + k);
+            float *d = As + row * LDA + 4 * kq;
+            d[0] = v.x;
+            d[1] = v.y;
+            d[2] = v.z;
+            d[3] = v.w;
+        }
+        // B tile: 32 k x BN n, float4 along n
+        for (int i = tid; i < DFX_GG_KT * (BN / 4); i += DFX_GG_THREADS) {
+            const int kk = i / (BN / 4), nq = i - kk * (BN / 4);
+            const int k = k0 + kk, n = n0 + 4 * nq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < A.Kg && n < A.Ng) v = *reinterpret_cast<const float4 *>(wg + (size_t)k * A.Ng + n);
+            *reinterpret_cast<float4 *>(Bs + kk * LDB + 4 * nq) = v;
+        }
+        __syncthreads();
+        const float *arow = As + (16 * wave + (lane & 15)) * LDA + (lane >> 4);
+        const float *brow = Bs + (lane >> 4) * LDB + (lane & 15);
+#pragma unroll
+        for (int ks = 0; ks < DFX_GG_KT / 4; ++ks) {
+            const float a = arow[4 * ks];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, brow[4 * ks * LDB + 16 * nt], acc[nt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t m = m0 + 16 * wave + 4 * (lane >> 4) + r;
+        if (m >= A.M) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + 16 * nt + (lane & 15);
+            if (n >= A.Ng) continue;
+            const int col = g * A.Ng + n;
+            float v = acc[nt][r];
+            if (A.bias) v += A.bias[col];
+            v = dfx_act(v, A.act);
+            if (A.res) v += A.res[m * A.ldo + col];
+            A.out[m * A.ldo + col] = v;
+        }
+    }
+}
+
+// enc.lsnr_fc: Linear(emb -> 1) + Sigmoid, scaled to [lsnr_min, lsnr_max] (deepfilternet3.py:163-165,184).  One wave per row.
+__global__ void dfx_k_lsnr(const float *emb, const float *w, float bias, float scale, float offset, float *out, int64_t R,
+                           int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= R) return;  // whole waves exit together (blockDim is a multiple of 64)
+    float acc = 0.f;
+    for (int i = lane; i < D; i += 64) acc += emb[row * D + i] * w[i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) out[row] = dfx_sigmoid(acc + bias) * scale + offset;
+}
+
+__global__ void dfx_k_add(const float *a, const float *b, float *out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = a[i] + b[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GRU recurrence (torch.nn.GRU semantics, gate order r,z,n; modules.py:721), hidden size 256, h0 = 0.
+//   gi [B, T, 768] already holds W_ih x + b_ih (+ b_hr, b_hz folded in);   per step:
+//   r = s(gi_r + W_hr h), z = s(gi_z + W_hz h), n = tanh(gi_n + r*(W_hn h + b_hn)), h' = (1-z)*n + z*h
+// Clips are independent, so a workgroup owns DFX_GRU_ROWS clips for all T steps: no inter-workgroup synchronisation.
+// Thread j owns hidden unit j: three 256-long dot products per row per step.  W_hh (768 KB fp32) exceeds a CU's LDS +
+// registers, so it is streamed from L2 every step as coalesced float4s (layout [k/4][gate][j][4]); h lives in LDS and is
+// read as wave-broadcast float4s.  One barrier per step (h double-buffered).
+// ---------------------------------------------------------------------------------------------------------------------
+#define DFX_GRU_H 256
+#define DFX_GRU_ROWS 4
+__global__ void __launch_bounds__(DFX_GRU_H) dfx_k_gru_rec(const float *gi, const float4 *whh4, const float *bhn, float *y,
+                                                           int64_t B, int64_t T) {
+    constexpr int H = DFX_GRU_H, MR = DFX_GRU_ROWS;
+    __shared__ __attribute__((aligned(16))) float hs[2][MR][H];
+    const int j = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * MR;
+    const float bn = bhn[j];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) hs[0][r][j] = 0.f;
+    __syncthreads();
+    int cur = 0;
+    for (int64_t t = 0; t < T; ++t) {
+        float gir[MR], giz[MR], gin[MR];
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            const int64_t b = b0 + r;
+            if (b < B) {
+                const float *g = gi + (b * T + t) * (3 * H);
+                gir[r] = g[j];
+                giz[r] = g[H + j];
+                gin[r] = g[2 * H + j];
+            } else {
+                gir[r] = giz[r] = gin[r] = 0.f;
+            }
+        }
+        float ar[MR], az[MR], an[MR];
+#pragma unroll
+        for (int r = 0; r < MR; ++r) ar[r] = az[r] = an[r] = 0.f;
+#pragma unroll 4
+        for (int k4 = 0; k4 < H / 4; ++k4) {
+            const float4 wr = whh4[(k4 * 3 + 0) * H + j];
+            const float4 wz = whh4[(k4 * 3 + 1) * H + j];
+            const float4 wn = whh4[(k4 * 3 + 2) * H + j];
+#pragma unroll
+            for (int r = 0; r < MR; ++r) {
+                const float4 hv = *reinterpret_cast<const float4 *>(&hs[cur][r][4 * k4]);
+                ar[r] = fmaf(wr.w, hv.w, fmaf(wr.z, hv.z, fmaf(wr.y, hv.y, fmaf(wr.x, hv.x, ar[r]))));
+                az[r] = fmaf(wz.w, hv.w, fmaf(wz.z, hv.z, fmaf(wz.y, hv.y, fmaf(wz.x, hv.x, az[r]))));
+                an[r] = fmaf(wn.w, hv.w, fmaf(wn.z, hv.z, fmaf(wn.y, hv.y, fmaf(wn.x, hv.x, an[r]))));
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            const float rg = dfx_sigmoid(gir[r] + ar[r]);
+            const float zg = dfx_sigmoid(giz[r] + az[r]);
+            const float ng = tanhf(gin[r] + rg * (an[r] + bn));
+            const float hn = (1.f - zg) * ng + zg * hs[cur][r][j];
+            hs[cur ^ 1][r][j] = hn;
+            const int64_t b = b0 + r;
+            if (b < B) y[(b * T + t) * H + j] = hn;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}

@@ -1,0 +1,129 @@
+"""``init_df`` / ``df_features`` / ``enhance`` with the reference's signatures (DeepFilterNet/df/enhance.py:101-250),
+running entirely on the MI355X through libdfx.so.
+
+* ``df_features`` and ``enhance`` accept the same arguments and return tensors of the same shape/dtype as the reference.
+* ``enhance`` keeps everything on the device: audio -> (pad) -> STFT + ERB/complex features -> DeepFilterNet3 ->
+  deep filter + ERB gains (+ post filter, + attenuation limit) -> ISTFT -> slice, one C call (``dfx_enhance``).
+* The batch dimension is the channel dimension C of the ``[C, T]`` input, exactly as in the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import ModelParams
+from .libdf import DF, erb, erb_norm, unit_norm
+from .model import DfNet, read_cp
+from .state_dict import random_state_dict
+
+PRETRAINED_MODELS = ("DeepFilterNet", "DeepFilterNet2", "DeepFilterNet3")
+DEFAULT_MODEL = "DeepFilterNet3"
+
+
+def get_device() -> torch.device:
+    """utils.py:20-29 get_device(); here always the HIP device libdfx runs on."""
+    return _lib.device()
+
+
+def init_df(
+    model_base_dir: Optional[str] = None,
+    post_filter: bool = False,
+    log_level: str = "INFO",
+    log_file: Optional[str] = "enhance.log",
+    config_allow_defaults: bool = True,
+    epoch: Union[str, int, None] = "best",
+    default_model: str = DEFAULT_MODEL,
+    mask_only: bool = False,
+    *,
+    params: Optional[ModelParams] = None,
+    state_dict: Optional[Dict[str, "np.ndarray | torch.Tensor"]] = None,
+    seed: int = 0,
+) -> Tuple[DfNet, DF, str, int]:
+    """enhance.py:101-187.  ``model_base_dir`` must contain ``config.ini`` and ``checkpoints/model_*.ckpt[.best]``.
+
+    The pretrained models cannot be downloaded here (no network, enhance.py:253-273); passing one of their names raises.
+    Extensions (keyword-only): ``params`` + ``state_dict`` build the model from memory; ``epoch="none"`` (or None) with no
+    checkpoint initialises seeded synthetic weights (``seed``), which is what the benchmarks use.
+    """
+    if mask_only:
+        raise NotImplementedError("mask_only is not supported by the HIP engine")
+    load_cp = epoch is not None and not (isinstance(epoch, str) and epoch.lower() == "none")
+    if params is None:
+        if model_base_dir is None or model_base_dir in PRETRAINED_MODELS:
+            raise FileNotFoundError(
+                f"pretrained model '{model_base_dir or default_model}' is not available offline; pass a model directory "
+                "with config.ini + checkpoints/, or params=/state_dict=")
+        if not os.path.isdir(model_base_dir):
+            raise NotADirectoryError("Base directory not found at {}".format(model_base_dir))
+        p = ModelParams.from_ini(os.path.join(model_base_dir, "config.ini"), must_exist=True)
+    else:
+        p = params
+    if post_filter:
+        p.mask_pf = True  # enhance.py:152-159
+    df_state = DF(sr=p.sr, fft_size=p.fft_size, hop_size=p.hop_size, nb_bands=p.nb_erb, min_nb_erb_freqs=p.min_nb_freqs)
+    ep = 0
+    if state_dict is None and load_cp and model_base_dir is not None:
+        state_dict, ep = read_cp(os.path.join(model_base_dir, "checkpoints"), epoch)
+        if state_dict is None:
+            raise FileNotFoundError("Could not find a checkpoint")  # reference: logger.error + exit(1)
+    if state_dict is None:
+        state_dict = random_state_dict(p, seed)
+    model = DfNet(p, state_dict, df_state)
+    suffix = os.path.basename(os.path.abspath(model_base_dir)) if model_base_dir else p.model
+    if post_filter:
+        suffix += "_pf"
+    return model, df_state, suffix, ep
+
+
+def df_features(audio: torch.Tensor, df: DF, nb_df: int, device=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """enhance.py:190-203: -> spec [C,1,T',F,2], erb_feat [C,1,T',E], spec_feat [C,1,T',nb_df,2] (on the HIP device)."""
+    p_alpha = _norm_alpha(df)
+    x = audio.to(_lib.device(), torch.float32).contiguous()
+    Cn, T = x.shape
+    Tf, F, E = T // df.hop_size(), df.fft_size() // 2 + 1, df.nb_erb()
+    spec = torch.empty((Cn, Tf, F, 2), dtype=torch.float32, device=x.device)
+    fe = torch.empty((Cn, Tf, E), dtype=torch.float32, device=x.device)
+    fs = torch.empty((Cn, Tf, nb_df, 2), dtype=torch.float32, device=x.device)
+    if Cn and Tf:
+        _lib.check(_lib.lib().dfx_features(df.handle, _lib.ptr(x), Cn, T, x.stride(0), int(nb_df), float(p_alpha),
+                                           _lib.ptr(spec), _lib.ptr(fe), _lib.ptr(fs), _lib.stream()))
+    return spec.unsqueeze(1), fe.unsqueeze(1), fs.unsqueeze(1)
+
+
+def _norm_alpha(df: DF, tau: float = 1.0) -> float:
+    p = ModelParams(sr=df.sr(), hop_size=df.hop_size(), norm_tau=tau)
+    return p.norm_alpha()
+
+
+@torch.no_grad()
+def enhance(model: DfNet, df_state: DF, audio: torch.Tensor, pad: bool = True, atten_lim_db: Optional[float] = None
+            ) -> torch.Tensor:
+    """enhance.py:206-250.  audio [C, T] float32 (host or device) -> enhanced audio, same shape when ``pad``.
+
+    The result lives on the device the input came from (a CPU tensor in -> CPU tensor out, like the reference)."""
+    if not isinstance(model, DfNet):
+        raise TypeError("enhance() of deepfilternet_amd needs a deepfilternet_amd.DfNet (see init_df)")
+    src_dev = audio.device
+    x = audio.to(_lib.device(), torch.float32).contiguous()
+    if x.dim() != 2:
+        raise ValueError("audio must have shape [C, T]")
+    B, T = x.shape
+    hop = df_state.hop_size()
+    n_fft = df_state.fft_size()
+    out_len = T if pad else ((T // hop) * hop)
+    y = torch.empty((B, out_len), dtype=torch.float32, device=x.device)
+    if B == 0 or out_len == 0:
+        return y.to(src_dev)
+    nbytes = C.c_int64()
+    L = _lib.lib()
+    _lib.check(L.dfx_enhance_workspace_bytes(model.handle, df_state.handle, B, T, int(bool(pad)), C.byref(nbytes)))
+    ws = model.workspace(nbytes.value)
+    lim_db = float(atten_lim_db) if atten_lim_db is not None else 0.0
+    _lib.check(L.dfx_enhance(model.handle, df_state.handle, _lib.ptr(x), B, T, int(bool(pad)), lim_db, _lib.ptr(y),
+                             _lib.ptr(ws), ws.numel(), _lib.stream()))
+    return y.to(src_dev)

@@ -1,0 +1,183 @@
+"""DeepFilterNet3 on the HIP engine: the host-side mirror of ``df.deepfilternet3.DfNet`` (deepfilternet3.py:334-456).
+
+``DfNet`` keeps the reference's call signature — ``model(spec, feat_erb, feat_spec) -> (spec_e, m, lsnr, df_coefs)`` with
+the reference's tensor shapes — and a ``state_dict``-shaped constructor, but it is not an ``nn.Module`` that computes in
+PyTorch: every FLOP happens in libdfx.so.  Weight loading mirrors checkpoint.py:46-103 (``read_cp``): plain
+``torch.load`` of a state-dict, the legacy ``clc -> df`` key rename, buffers ``erb_fb``/``mask.erb_inv_fb`` ignored.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import glob
+import os
+import re
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import ModelParams
+from .libdf import DF
+
+_SKIP = {"none": 0, "identity": 1, "groupedlinear": 2}
+
+
+def make_cfg(p: ModelParams) -> _lib.ModelCfg:
+    p.check_supported()
+    c = _lib.ModelCfg()
+    c.sr, c.fft_size, c.hop_size, c.nb_erb, c.nb_df = p.sr, p.fft_size, p.hop_size, p.nb_erb, p.nb_df
+    c.min_nb_freqs, c.df_order, c.df_lookahead = p.min_nb_freqs, p.df_order, p.df_lookahead
+    c.lsnr_min, c.lsnr_max = int(p.lsnr_min), int(p.lsnr_max)
+    c.conv_lookahead, c.conv_ch = p.conv_lookahead, p.conv_ch
+    c.emb_hidden_dim, c.emb_num_layers = p.emb_hidden_dim, p.emb_num_layers
+    c.df_hidden_dim, c.df_num_layers = p.df_hidden_dim, p.df_num_layers
+    c.df_gru_skip = _SKIP[p.df_gru_skip]
+    c.df_pathway_kernel_size_t = p.df_pathway_kernel_size_t
+    c.lin_groups, c.enc_lin_groups = p.lin_groups, p.enc_lin_groups
+    c.mask_pf, c.pf_beta, c.norm_alpha = int(p.mask_pf), float(p.pf_beta), float(p.norm_alpha())
+    return c
+
+
+def tensor_manifest(cfg: _lib.ModelCfg):
+    """[(name, shape, offset)] as the C library wants them packed (dfx_model_tensor_info)."""
+    L = _lib.lib()
+    n = C.c_int()
+    _lib.check(L.dfx_model_tensor_count(C.byref(cfg), C.byref(n)))
+    out = []
+    name = C.create_string_buffer(256)
+    shape = (C.c_int64 * 4)()
+    nd, off = C.c_int(), C.c_int64()
+    for i in range(n.value):
+        _lib.check(L.dfx_model_tensor_info(C.byref(cfg), i, name, 256, shape, C.byref(nd), C.byref(off)))
+        out.append((name.value.decode(), tuple(int(shape[k]) for k in range(nd.value)), int(off.value)))
+    return out
+
+
+def pack_state_dict(cfg: _lib.ModelCfg, sd: Dict[str, "np.ndarray | torch.Tensor"]) -> np.ndarray:
+    total = C.c_int64()
+    _lib.check(_lib.lib().dfx_model_blob_floats(C.byref(cfg), C.byref(total)))
+    blob = np.zeros(total.value, dtype=np.float32)
+    for name, shape, off in tensor_manifest(cfg):
+        if name not in sd:
+            raise KeyError(f"state dict is missing '{name}'")
+        v = sd[name]
+        v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+        if tuple(v.shape) != shape:
+            raise ValueError(f"size mismatch for {name}: checkpoint {tuple(v.shape)}, model {shape}")
+        blob[off:off + v.size] = v.astype(np.float32, copy=False).ravel()
+    return blob
+
+
+class DfNet:
+    """Inference-only DeepFilterNet3 on libdfx.  Call signature and output shapes of deepfilternet3.py:389-456."""
+
+    def __init__(self, p: ModelParams, state_dict: Dict[str, "np.ndarray | torch.Tensor"], df_state: Optional[DF] = None):
+        self.p = p
+        self.cfg = make_cfg(p)
+        blob = pack_state_dict(self.cfg, state_dict)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().dfx_model_create(C.byref(self.cfg), blob.ctypes.data_as(C.POINTER(C.c_float)), C.byref(h)))
+        self._h = h
+        self.df_state = df_state or DF(p.sr, p.fft_size, p.hop_size, p.nb_erb, p.min_nb_freqs)
+        # attributes the reference's enhance() probes (enhance.py:234)
+        self.nb_df = p.nb_df
+        self.df_order = p.df_order
+        self.df_lookahead = p.df_lookahead
+        self.freq_bins = p.freq_bins
+        self.erb_bins = p.nb_erb
+        self.post_filter = p.mask_pf
+        self._ws: Optional[torch.Tensor] = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        try:
+            if h:
+                _lib.lib().dfx_model_free(h)
+        except Exception:  # noqa: BLE001
+            pass
+
+    @property
+    def handle(self) -> C.c_void_p:
+        return self._h
+
+    # nn.Module-ish no-ops so that callers written against the reference keep working
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes or not _lib.on_device(self._ws):
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=_lib.device())
+        return self._ws
+
+    @torch.no_grad()
+    def __call__(self, spec: torch.Tensor, feat_erb: torch.Tensor, feat_spec: torch.Tensor, atten_lim: float = 0.0
+                 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        """spec [B,1,T,F,2], feat_erb [B,1,T,E], feat_spec [B,1,T,F',2] ->
+        (spec_e [B,1,T,F,2], m [B,1,T,E], lsnr [B,T,1], df_coefs [B,O,T,F',2])."""
+        p = self.p
+        dev = _lib.device()
+        B, _, T, F, _ = spec.shape
+        spec_d = spec.to(dev, torch.float32).contiguous()
+        fe = feat_erb.to(dev, torch.float32).contiguous()
+        fs = feat_spec.to(dev, torch.float32).contiguous()
+        assert F == p.freq_bins and fe.shape == (B, 1, T, p.nb_erb) and fs.shape == (B, 1, T, p.nb_df, 2)
+        spec_e = torch.empty_like(spec_d)
+        m = torch.empty((B, 1, T, p.nb_erb), dtype=torch.float32, device=dev)
+        lsnr = torch.empty((B, T, 1), dtype=torch.float32, device=dev)
+        coefs = torch.empty((B, T, p.nb_df, p.df_order, 2), dtype=torch.float32, device=dev)
+        nbytes = C.c_int64()
+        L = _lib.lib()
+        _lib.check(L.dfx_model_workspace_bytes(self._h, B, T, C.byref(nbytes)))
+        ws = self.workspace(nbytes.value)
+        _lib.check(L.dfx_model_forward(self._h, self.df_state.bands_handle, _lib.ptr(spec_d), _lib.ptr(fe), _lib.ptr(fs),
+                                       B, T, float(atten_lim), _lib.ptr(spec_e), _lib.ptr(m), _lib.ptr(lsnr),
+                                       _lib.ptr(coefs), _lib.ptr(ws), ws.numel(), _lib.stream()))
+        # DfOutputReshapeMF (deepfilternet3.py:268-275): [B,T,F',O,2] -> [B,O,T,F',2] (a view, like the reference's permute)
+        return spec_e, m, lsnr, coefs.permute(0, 3, 1, 2, 4)
+
+    forward = __call__
+
+
+# ---------------------------------------------------------------------------------------------------- checkpoints
+def _find_checkpoint(dirname: str, epoch) -> Tuple[Optional[str], int]:
+    """checkpoint.py:46-84: model_<epoch>.ckpt[.best]; 'best' prefers *.best, 'latest' the highest epoch."""
+    if not dirname or not os.path.isdir(dirname):
+        return None, 0
+    cps = glob.glob(os.path.join(dirname, "model_*.ckpt*"))
+    if not cps:
+        return None, 0
+
+    def ep(path):
+        mm = re.search(r"model_(\d+)\.ckpt", os.path.basename(path))
+        return int(mm.group(1)) if mm else -1
+
+    if isinstance(epoch, int) or (isinstance(epoch, str) and epoch.isdigit()):
+        want = int(epoch)
+        for c in cps:
+            if ep(c) == want:
+                return c, want
+        return None, 0
+    if epoch == "best":
+        best = [c for c in cps if c.endswith(".best")]
+        if best:
+            c = max(best, key=ep)
+            return c, ep(c)
+    c = max(cps, key=ep)
+    return c, ep(c)
+
+
+def read_cp(dirname: str, epoch="best") -> Tuple[Optional[Dict[str, torch.Tensor]], int]:
+    path, ep = _find_checkpoint(dirname, epoch)
+    if path is None:
+        return None, 0
+    sd = torch.load(path, map_location="cpu")
+    if isinstance(sd, dict) and "model" in sd and isinstance(sd["model"], dict):
+        sd = sd["model"]
+    out = {}
+    for k, v in sd.items():  # checkpoint.py:86-92: rename legacy 'clc' keys
+        out[k.replace("clc", "df")] = v
+    return out, ep

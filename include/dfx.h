@@ -1,0 +1,183 @@
+/*
+ * dfx.h — C ABI of libdfx.so, the MI355X (gfx950) engine for DeepFilterNet's enhance() hot path.
+ *
+ * Drop-in boundary.  Every entry point names the reference interface it replaces
+ * (paths relative to the reference checkout):
+ *   - pyDF/src/lib.rs (pyo3 module `libdf`)  : class DF + erb / erb_inv / erb_norm / unit_norm / unit_norm_init
+ *   - libDF/src/lib.rs, libDF/src/transforms.rs : DFState and the batched transforms behind it
+ *   - DeepFilterNet/df/multiframe.py:160-180, DeepFilterNet/df/modules.py:226-269 : MF.DF and Mask (device ops)
+ *   - DeepFilterNet/df/deepfilternet3.py:334-456, DeepFilterNet/df/enhance.py:190-250 : DfNet.forward, enhance()
+ *   - libDF/src/capi.rs:83-253 : naming / ownership conventions (opaque handles, caller-owned buffers)
+ *
+ * Conventions
+ *   - plain C types only; complex numbers are interleaved float pairs (re, im) == Complex32 == numpy complex64
+ *   - every data pointer is a DEVICE pointer on the current HIP device unless the name ends in `_host`
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous on that stream
+ *   - all arrays are dense row-major ("C-contiguous") unless a stride argument is given
+ *   - return value: DFX_OK or an error code; dfx_last_error() gives a thread-local message.  Nothing panics/aborts.
+ *   - no hidden host<->device copies in the batched entry points; nothing here falls back to a CPU implementation
+ */
+#ifndef DFX_H
+#define DFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFX_OK 0
+#define DFX_ERR_INVALID_ARG 1
+#define DFX_ERR_UNSUPPORTED 2
+#define DFX_ERR_HIP 3
+#define DFX_ERR_NO_DEVICE 4
+#define DFX_ERR_ALLOC 5
+
+#define DFX_VERSION 100 /* 0.1.0 */
+
+int dfx_version(void);
+const char *dfx_status_string(int status);
+const char *dfx_last_error(void);
+/* Number of usable HIP devices (0 => every compute entry point returns DFX_ERR_NO_DEVICE). */
+int dfx_device_count(void);
+/* 1 when this library is the CPU SIMT interpreter build used by unit tests (tests/hipemu), 0 for the product. */
+int dfx_is_emulator(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * ERB band table.  Replaces the `erb_fb: &[usize]` argument of libDF (lib.rs:280-348) / pyDF (lib.rs:142-250).
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct dfx_bands dfx_bands;
+int dfx_bands_create(const uint64_t *widths_host, int nb_bands, dfx_bands **out);
+void dfx_bands_free(dfx_bands *b);
+int dfx_bands_nb(const dfx_bands *b);
+int dfx_bands_nfreqs(const dfx_bands *b);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * DF state.  Replaces DFState::new (libDF/src/lib.rs:104-154) and pyDF's class DF (pyDF/src/lib.rs:14-136).
+ * The handle is immutable after creation (window, twiddles, band table live on the device); streaming memories are
+ * explicit caller-owned buffers (mem_in / mem_out below), so one handle serves any number of concurrent batches.
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct dfx_state dfx_state;
+/* Fails with DFX_ERR_INVALID_ARG if hop*2 > fft (lib.rs:111 assert) and DFX_ERR_UNSUPPORTED if fft/2 has a prime
+ * factor other than 2, 3, 5 or fft > 4096. */
+int dfx_state_create(int sr, int fft_size, int hop_size, int nb_bands, int min_nb_erb_freqs, dfx_state **out);
+void dfx_state_free(dfx_state *st);
+int dfx_state_sr(const dfx_state *st);
+int dfx_state_fft_size(const dfx_state *st);
+int dfx_state_hop_size(const dfx_state *st);
+int dfx_state_nb_erb(const dfx_state *st);
+float dfx_state_wnorm(const dfx_state *st);
+const dfx_bands *dfx_state_bands(const dfx_state *st);
+int dfx_state_erb_widths(const dfx_state *st, uint64_t *out_host /*[nb_erb]*/);   /* DF.erb_widths() */
+int dfx_state_fft_window(const dfx_state *st, float *out_host /*[fft_size]*/);    /* DF.fft_window() */
+/* libDF/src/lib.rs:68-100 erb_fb() on the host (pure index arithmetic, bit-exact). */
+int dfx_erb_fb(int sr, int fft_size, int nb_bands, int min_nb_freqs, uint64_t *out_host);
+
+/* DF.analysis (pyDF/src/lib.rs:41-72 -> lib.rs:356-394), batched over B independent rows.
+ *   x      [B, T] f32            (row stride x_stride elements, >= T)
+ *   spec   [B, T/hop, F][2] f32  (trailing T%hop samples are dropped, like chunks_exact)
+ *   mem_in [B, fft-hop] or NULL  analysis memory before the first frame (NULL == reset == zeros)
+ *   mem_out[B, fft-hop] or NULL  analysis memory after the last frame */
+int dfx_analysis(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_stride, const float *mem_in,
+                 float *mem_out, float *spec, void *stream);
+
+/* DF.synthesis (pyDF/src/lib.rs:74-107 -> lib.rs:396-427), batched.  Does NOT modify `spec` (the reference clobbers
+ * it).  imag(DC) and imag(Nyquist) are ignored (lib.rs:398-405).
+ *   spec [B, Tf, F][2];  out [B, Tf*hop] (row stride out_stride);  mem_* [B, fft-hop] synthesis overlap memory. */
+int dfx_synthesis(const dfx_state *st, const float *spec, int64_t B, int64_t Tf, const float *mem_in, float *mem_out,
+                  float *out, int64_t out_stride, void *stream);
+
+/* erb() (pyDF/src/lib.rs:142-192 -> transforms.rs:236-253, lib.rs:280-295): spec [rows, F][2] -> out [rows, nb]. */
+int dfx_erb(const dfx_bands *bands, const float *spec, int64_t rows, int db, float *out, void *stream);
+/* erb_inv() (pyDF/src/lib.rs:194-250 -> lib.rs:339-348): gains [rows, nb] -> out [rows, F]. */
+int dfx_erb_inv(const dfx_bands *bands, const float *gains, int64_t rows, float *out, void *stream);
+/* erb_norm() (pyDF/src/lib.rs:252-274 -> transforms.rs:301-330, lib.rs:244-251).  x [C, T, E] normalised IN PLACE.
+ * state [C, E] in/out or NULL (NULL: linspace(-60,-90,E) per row, final state discarded). */
+int dfx_erb_norm(float *x, int64_t C, int64_t T, int E, float alpha, float *state, void *stream);
+/* unit_norm() (pyDF/src/lib.rs:276-298 -> transforms.rs:332-361, lib.rs:253-259).
+ * x [C, T, F][2] read with frame stride x_frame_stride complex elements (lets spec[..., :nb_df] be read without a copy);
+ * out [C, T, F][2] dense.  state [C, F] in/out or NULL (NULL: linspace(1e-3,1e-4,F)). */
+int dfx_unit_norm(const float *x, int64_t x_frame_stride, float *out, int64_t C, int64_t T, int F, float alpha,
+                  float *state, void *stream);
+/* unit_norm_init() (pyDF/src/lib.rs:300-309). */
+int dfx_unit_norm_init(int n, float *out_host);
+
+/* df_features() (DeepFilterNet/df/enhance.py:190-203) fused on the device: analysis + erb(dB) + erb_norm + unit_norm.
+ *   x [B, T] -> spec [B, Tf, F][2], erb_feat [B, Tf, nb_erb], spec_feat [B, Tf, nb_df][2];  states reset per row. */
+int dfx_features(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_stride, int nb_df, float alpha,
+                 float *spec, float *erb_feat, float *spec_feat, void *stream);
+
+/* Deep filtering + ERB gains + post filter + attenuation limit, one fused memory-bound kernel.
+ * Replaces MF.DF.forward (multiframe.py:169-180), Mask.forward (modules.py:248-269; == lib.rs:314-326), the combine
+ * step of DfNet.forward (deepfilternet3.py:442-443), its post filter (:448-454; == lib.rs:446-471) and enhance()'s
+ * atten_lim mix (enhance.py:238-240).
+ *   spec  [B, T, F][2]   noisy spectrum
+ *   coefs complex, nb_df bins, `order` taps:  layout DFX_COEF_BOTF = [B, O, T, nb_df][2]  (MF.DF's input)
+ *                                             layout DFX_COEF_BTFO = [B, T, nb_df, O][2]  (DfDecoder's raw output)
+ *   gains [B, T, nb_bands] or NULL.  NULL: bins >= nb_df are copied from spec (plain MF.DF semantics).
+ *   out   [B, T, F][2]   must not alias spec
+ *   out[b,t,f<nb_df]  = sum_n coefs[b,n,t,f] * spec[b, t+n-(order-1-lookahead), f]   (zero outside [0,T))
+ *   out[b,t,f>=nb_df] = spec[b,t,f] * gains[b,t,band(f)]
+ *   pf_beta > 0: post filter;  atten_lim in (0,1): out = spec*atten_lim + out*(1-atten_lim). */
+#define DFX_COEF_BOTF 0
+#define DFX_COEF_BTFO 1
+int dfx_df_apply(const float *spec, const float *coefs, int coef_layout, const float *gains, const dfx_bands *bands,
+                 int64_t B, int64_t T, int F, int nb_df, int order, int lookahead, float pf_beta, float atten_lim,
+                 float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * DeepFilterNet3 model.  Replaces df.deepfilternet3.DfNet (deepfilternet3.py:334-456) for inference.
+ * ---------------------------------------------------------------------------------------------------------------- */
+#define DFX_SKIP_NONE 0
+#define DFX_SKIP_IDENTITY 1
+#define DFX_SKIP_GROUPEDLINEAR 2
+
+typedef struct dfx_model_cfg {
+    /* [df] section (config.py:12-39) */
+    int32_t sr, fft_size, hop_size, nb_erb, nb_df, min_nb_freqs, df_order, df_lookahead;
+    int32_t lsnr_min, lsnr_max;
+    /* [deepfilternet] section (deepfilternet3.py:25-77) */
+    int32_t conv_lookahead, conv_ch, emb_hidden_dim, emb_num_layers, df_hidden_dim, df_num_layers;
+    int32_t df_gru_skip; /* DFX_SKIP_* */
+    int32_t df_pathway_kernel_size_t, lin_groups, enc_lin_groups;
+    int32_t mask_pf;
+    float pf_beta;
+    float norm_alpha; /* utils.py:111-127 get_norm_alpha() */
+} dfx_model_cfg;
+
+/* Tensor manifest: the tensors of the reference state-dict the engine consumes, in state_dict() order, with their
+ * reference names ("enc.erb_conv0.1.weight", ...).  The host packs them (raw, un-folded float32) into one blob. */
+int dfx_model_tensor_count(const dfx_model_cfg *cfg, int *count);
+int dfx_model_tensor_info(const dfx_model_cfg *cfg, int index, char *name_out, int name_cap, int64_t shape_out[4],
+                          int *ndim_out, int64_t *offset_out /* in floats */);
+int dfx_model_blob_floats(const dfx_model_cfg *cfg, int64_t *n);
+
+typedef struct dfx_model dfx_model;
+/* Folds BatchNorm (eval mode, eps 1e-5) into the preceding convolution, re-lays the weights out for the kernels and
+ * uploads them.  blob_host: float32[dfx_model_blob_floats] packed per dfx_model_tensor_info. */
+int dfx_model_create(const dfx_model_cfg *cfg, const float *blob_host, dfx_model **out);
+void dfx_model_free(dfx_model *m);
+int dfx_model_cfg_get(const dfx_model *m, dfx_model_cfg *out);
+
+/* Scratch memory the caller must provide (device bytes) for a [B, T-frames] batch. */
+int dfx_model_workspace_bytes(const dfx_model *m, int64_t B, int64_t T, int64_t *bytes);
+
+/* DfNet.forward (deepfilternet3.py:389-456).
+ *   spec [B,T,F][2], feat_erb [B,T,E], feat_spec [B,T,nb_df][2]  ->
+ *   spec_e [B,T,F][2], mask [B,T,E] (may be NULL), lsnr [B,T] (may be NULL), df_coefs [B,T,nb_df,O][2] (may be NULL)
+ *   atten_lim: enhance()'s mix factor (0 = off), applied after the optional post filter. */
+int dfx_model_forward(const dfx_model *m, const dfx_bands *bands, const float *spec, const float *feat_erb,
+                      const float *feat_spec, int64_t B, int64_t T, float atten_lim, float *spec_e, float *mask,
+                      float *lsnr, float *df_coefs, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* enhance() (enhance.py:206-250) end to end on the device: x [B, T] -> y [B, T] (pad=1) or y [B, (T/hop)*hop] (pad=0,
+ * delayed by fft-hop like the reference).  atten_lim_db: 0 = off.  workspace from dfx_enhance_workspace_bytes. */
+int dfx_enhance_workspace_bytes(const dfx_model *m, const dfx_state *st, int64_t B, int64_t T, int pad, int64_t *bytes);
+int dfx_enhance(const dfx_model *m, const dfx_state *st, const float *x, int64_t B, int64_t T, int pad,
+                float atten_lim_db, float *y, void *workspace, int64_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFX_H */

@@ -28,3 +28,34 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def _use_backend(name):
+    from deepfilternet_amd import _lib
+
+    if name == "emu":
+        from tests.hipemu.build_emu import build
+
+        _lib.use_library(build())
+        assert _lib.is_emulator()
+    else:
+        from deepfilternet_amd.build import build
+
+        _lib.use_library(build())
+        assert not _lib.is_emulator(), "the GPU tests must run on the HIP build"
+        import torch
+
+        assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return name
+
+
+@pytest.fixture(params=[pytest.param("emu"), pytest.param("hip", marks=pytest.mark.gpu)])
+def backend(request):
+    """'emu': the kernel sources run on the CPU SIMT interpreter (tests/hipemu) — logic check without a GPU.
+    'hip': the real libdfx.so on an MI355X (-m gpu)."""
+    return _use_backend(request.param)
+
+
+@pytest.fixture
+def hip_backend():
+    return _use_backend("hip")

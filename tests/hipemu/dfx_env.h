@@ -1,0 +1,425 @@
+// hipemu — a fiber-based SIMT interpreter for unit-testing the HIP kernel SOURCES of deepfilternet_amd on a CPU.
+//
+// TEST INFRASTRUCTURE ONLY.  The product library (deepfilternet_amd/csrc/libdfx.so) is built by hipcc against
+// csrc/env_hip/dfx_env.h and never contains any of this.  The test build (tests/hipemu/Makefile) compiles the very
+// same kernel + launcher sources with g++ against THIS header, so index math, LDS staging, barrier placement, wave
+// shuffles and MFMA fragment layouts can be checked against the oracle without spending GPU minutes.
+//
+// Execution model: one OS thread; each HIP thread of a block is a ucontext fiber; blocks run one after another.
+//   __syncthreads()            -> yield until every live fiber of the block has arrived
+//   wave collectives (shfl, mfma, ballot) -> yield until every live lane of the 64-wide wave has arrived
+// Fiber order is configurable (HIPEMU_ORDER=fwd|rev) so that a missing barrier shows up as an order-dependent result.
+// `__shared__` becomes `static` (blocks are sequential, so a function-local static is exactly per-block LDS).
+#pragma once
+
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#define DFX_HIPEMU 1
+
+// ---------------------------------------------------------------------------------------------- qualifiers
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __constant__ static
+
+// ---------------------------------------------------------------------------------------------- basic types
+struct uint3 {
+    unsigned x, y, z;
+};
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 {
+    float x, y;
+};
+struct alignas(16) float4 {
+    float x, y, z, w;
+};
+struct int2 {
+    int x, y;
+};
+struct alignas(16) int4 {
+    int x, y, z, w;
+};
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+
+typedef float f32x4 __attribute__((vector_size(16)));
+typedef float f32x16 __attribute__((vector_size(64)));
+
+typedef int hipError_t;
+typedef void *hipStream_t;
+#define hipSuccess 0
+#define hipMemcpyHostToDevice 1
+#define hipMemcpyDeviceToHost 2
+#define hipMemcpyDeviceToDevice 3
+
+static inline hipError_t hipMalloc(void **p, size_t n) {
+    *p = nullptr;
+    return posix_memalign(p, 256, n ? n : 256) == 0 ? hipSuccess : 2;
+}
+template <typename T>
+static inline hipError_t hipMalloc(T **p, size_t n) {
+    return hipMalloc(reinterpret_cast<void **>(p), n);
+}
+static inline hipError_t hipFree(void *p) {
+    free(p);
+    return hipSuccess;
+}
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) {
+    memcpy(d, s, n);
+    return hipSuccess;
+}
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) {
+    memcpy(d, s, n);
+    return hipSuccess;
+}
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) {
+    memset(d, v, n);
+    return hipSuccess;
+}
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+static inline const char *hipGetErrorString(hipError_t) { return "hipemu"; }
+static inline hipError_t hipGetDeviceCount(int *n) {
+    *n = 1;
+    return hipSuccess;
+}
+static inline hipError_t hipGetDevice(int *d) {
+    *d = 0;
+    return hipSuccess;
+}
+static inline int dfx_env_num_cus() { return 4; }  // tiny "chip" so grid-stride paths are exercised
+static inline bool dfx_env_is_emulator() { return true; }
+
+// ---------------------------------------------------------------------------------------------- scheduler
+namespace hipemu {
+
+enum { READY = 0, AT_BLOCK_BARRIER = 1, AT_WAVE_BARRIER = 2, DONE = 3 };
+
+struct Fiber {
+    ucontext_t ctx;
+    char *stack = nullptr;
+    int state = READY;
+    uint3 tid{0, 0, 0};
+    unsigned flat = 0;
+    unsigned wave_calls = 0;  // parity counter for double-buffered wave exchange
+};
+
+struct BlockRun {
+    std::vector<Fiber> fibers;
+    ucontext_t main_ctx;
+    int current = -1;
+    std::function<void()> body;
+    unsigned nthreads = 0;
+    // wave exchange: [parity][wave][lane][4 x 64-bit]
+    std::vector<uint64_t> xbuf;
+    uint64_t *slot(unsigned parity, unsigned wave, unsigned lane) {
+        return &xbuf[(((size_t)parity * ((nthreads + 63) / 64) + wave) * 64 + lane) * 4];
+    }
+};
+
+inline BlockRun *&run_ptr() {
+    static BlockRun *r = nullptr;
+    return r;
+}
+inline unsigned char *&dyn_smem_ptr() {
+    static unsigned char *p = nullptr;
+    return p;
+}
+inline size_t &stack_bytes() {
+    static size_t n = 256 * 1024;
+    return n;
+}
+
+}  // namespace hipemu
+
+inline uint3 threadIdx, blockIdx;
+inline dim3 blockDim, gridDim;
+
+namespace hipemu {
+
+inline void yield_to_scheduler(int new_state) {
+    BlockRun *r = run_ptr();
+    Fiber &f = r->fibers[r->current];
+    f.state = new_state;
+    swapcontext(&f.ctx, &r->main_ctx);
+    // resumed: restore the thread identity registers
+    threadIdx = f.tid;
+}
+
+inline void fiber_entry() {
+    BlockRun *r = run_ptr();
+    r->body();
+    Fiber &f = r->fibers[r->current];
+    f.state = DONE;
+    swapcontext(&f.ctx, &r->main_ctx);
+}
+
+inline int order_mode() {
+    static int m = -1;
+    if (m < 0) {
+        const char *e = getenv("HIPEMU_ORDER");
+        m = (e && strcmp(e, "rev") == 0) ? 1 : 0;
+    }
+    return m;
+}
+
+inline void run_block(const std::function<void()> &body, dim3 bdim) {
+    static std::vector<char *> stack_pool;
+    BlockRun r;
+    r.body = body;
+    r.nthreads = bdim.x * bdim.y * bdim.z;
+    r.fibers.resize(r.nthreads);
+    r.xbuf.assign((size_t)2 * ((r.nthreads + 63) / 64) * 64 * 4, 0);
+    while (stack_pool.size() < r.nthreads) stack_pool.push_back((char *)malloc(stack_bytes()));
+    run_ptr() = &r;
+    for (unsigned i = 0; i < r.nthreads; ++i) {
+        Fiber &f = r.fibers[i];
+        f.flat = i;
+        f.tid.x = i % bdim.x;
+        f.tid.y = (i / bdim.x) % bdim.y;
+        f.tid.z = i / (bdim.x * bdim.y);
+        f.stack = stack_pool[i];
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = stack_bytes();
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+    }
+    const unsigned nw = (r.nthreads + 63) / 64;
+    unsigned done = 0;
+    const bool rev = order_mode() == 1;
+    while (done < r.nthreads) {
+        bool progressed = false;
+        for (unsigned k = 0; k < r.nthreads; ++k) {
+            const unsigned i = rev ? r.nthreads - 1 - k : k;
+            Fiber &f = r.fibers[i];
+            if (f.state != READY) continue;
+            r.current = (int)i;
+            threadIdx = f.tid;
+            swapcontext(&r.main_ctx, &f.ctx);
+            progressed = true;
+            if (f.state == DONE) ++done;
+        }
+        // release wave barriers
+        for (unsigned w = 0; w < nw; ++w) {
+            unsigned waiting = 0, live = 0;
+            for (unsigned l = 0; l < 64 && w * 64 + l < r.nthreads; ++l) {
+                const int s = r.fibers[w * 64 + l].state;
+                if (s != DONE) ++live;
+                if (s == AT_WAVE_BARRIER) ++waiting;
+            }
+            if (live && waiting == live) {
+                for (unsigned l = 0; l < 64 && w * 64 + l < r.nthreads; ++l)
+                    if (r.fibers[w * 64 + l].state == AT_WAVE_BARRIER) r.fibers[w * 64 + l].state = READY;
+                progressed = true;
+            }
+        }
+        // release the block barrier
+        {
+            unsigned waiting = 0, live = 0;
+            for (auto &f : r.fibers) {
+                if (f.state != DONE) ++live;
+                if (f.state == AT_BLOCK_BARRIER) ++waiting;
+            }
+            if (live && waiting == live) {
+                for (auto &f : r.fibers)
+                    if (f.state == AT_BLOCK_BARRIER) f.state = READY;
+                progressed = true;
+            }
+        }
+        if (!progressed) {
+            fprintf(stderr, "hipemu: DEADLOCK in block (%u,%u,%u): divergent barrier / wave collective\n", blockIdx.x,
+                    blockIdx.y, blockIdx.z);
+            for (auto &f : r.fibers)
+                if (f.state != DONE) {
+                    fprintf(stderr, "  first stuck thread %u state %d\n", f.flat, f.state);
+                    break;
+                }
+            abort();
+        }
+    }
+    run_ptr() = nullptr;
+}
+
+template <typename... KArgs, typename... Args>
+inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, Args &&...args) {
+    std::tuple<KArgs...> tup(static_cast<KArgs>(args)...);
+    std::vector<unsigned char> smem(shmem + 64);
+    unsigned char *base = smem.data();
+    base += (16 - ((uintptr_t)base & 15)) & 15;
+    dyn_smem_ptr() = base;
+    gridDim = grid;
+    blockDim = block;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                blockIdx = uint3{bx, by, bz};
+                run_block([&]() { std::apply(kernel, tup); }, block);
+            }
+    dyn_smem_ptr() = nullptr;
+}
+
+inline unsigned flat_tid() { return run_ptr()->fibers[run_ptr()->current].flat; }
+
+// exchange `v` across the wave; returns the value deposited by lane `src` (one wave barrier, double buffered)
+template <typename T>
+inline T wave_exchange(T v, int src) {
+    static_assert(sizeof(T) <= 32, "wave_exchange payload too large");
+    BlockRun *r = run_ptr();
+    Fiber &f = r->fibers[r->current];
+    const unsigned w = f.flat / 64, l = f.flat % 64, par = (f.wave_calls++) & 1;
+    memcpy(r->slot(par, w, l), &v, sizeof(T));
+    yield_to_scheduler(AT_WAVE_BARRIER);
+    T out;
+    memcpy(&out, r->slot(par, w, (unsigned)src & 63), sizeof(T));
+    return out;
+}
+
+// deposit, barrier, then let the caller read any lane's deposit (valid until the caller's next-but-one collective)
+template <typename T>
+inline const T *wave_gather(T v, unsigned &wave_out) {
+    BlockRun *r = run_ptr();
+    Fiber &f = r->fibers[r->current];
+    const unsigned w = f.flat / 64, l = f.flat % 64, par = (f.wave_calls++) & 1;
+    memcpy(r->slot(par, w, l), &v, sizeof(T));
+    yield_to_scheduler(AT_WAVE_BARRIER);
+    wave_out = w;
+    return reinterpret_cast<const T *>(r->slot(par, w, 0));  // stride: 4 x uint64 per lane
+}
+
+}  // namespace hipemu
+
+// ---------------------------------------------------------------------------------------------- device API
+static inline void __syncthreads() { hipemu::yield_to_scheduler(hipemu::AT_BLOCK_BARRIER); }
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
+
+template <typename T>
+static inline T __shfl(T v, int src, int width = 64) {
+    const int lane = (int)(hipemu::flat_tid() % 64);
+    const int base = lane & ~(width - 1);
+    return hipemu::wave_exchange(v, base + (src & (width - 1)));
+}
+template <typename T>
+static inline T __shfl_xor(T v, int mask, int width = 64) {
+    const int lane = (int)(hipemu::flat_tid() % 64);
+    const int base = lane & ~(width - 1);
+    return hipemu::wave_exchange(v, base + ((lane ^ mask) & (width - 1)));
+}
+template <typename T>
+static inline T __shfl_down(T v, unsigned delta, int width = 64) {
+    const int lane = (int)(hipemu::flat_tid() % 64);
+    const int base = lane & ~(width - 1), rel = lane - base;
+    const int src = (rel + (int)delta < width) ? lane + (int)delta : lane;
+    return hipemu::wave_exchange(v, src);
+}
+template <typename T>
+static inline T __shfl_up(T v, unsigned delta, int width = 64) {
+    const int lane = (int)(hipemu::flat_tid() % 64);
+    const int base = lane & ~(width - 1), rel = lane - base;
+    const int src = (rel - (int)delta >= 0) ? lane - (int)delta : lane;
+    return hipemu::wave_exchange(v, src);
+}
+static inline unsigned long long __ballot(int pred) {
+    struct P {
+        int p;
+    };
+    unsigned w;
+    const P *all = hipemu::wave_gather(P{pred}, w);
+    unsigned long long m = 0;
+    hipemu::BlockRun *r = hipemu::run_ptr();
+    for (unsigned l = 0; l < 64 && w * 64 + l < r->nthreads; ++l) {
+        const P *p = reinterpret_cast<const P *>(reinterpret_cast<const uint64_t *>(all) + (size_t)l * 4);
+        if (r->fibers[w * 64 + l].state != hipemu::DONE && p->p) m |= 1ull << l;
+    }
+    return m;
+}
+
+// v_mfma_f32_16x16x4_f32: lane l holds A[l&15][l>>4], B[l>>4][l&15]; D[4*(l>>4)+r][l&15] (cdna_hip_programming.md §3).
+// Numerics: k-ordered fmaf chain starting from C (exactly what the hardware does).
+static inline f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4 c, int, int, int) {
+    struct AB {
+        float a, b;
+    };
+    unsigned w;
+    const AB *all = hipemu::wave_gather(AB{a, b}, w);
+    auto at = [&](unsigned l) { return reinterpret_cast<const AB *>(reinterpret_cast<const uint64_t *>(all) + (size_t)l * 4); };
+    const unsigned lane = hipemu::flat_tid() % 64;
+    const unsigned j = lane & 15;
+    f32x4 d = c;
+    for (unsigned r = 0; r < 4; ++r) {
+        const unsigned i = 4 * (lane >> 4) + r;
+        float acc = c[r];
+        for (unsigned k = 0; k < 4; ++k) acc = fmaf(at(i + 16 * k)->a, at(j + 16 * k)->b, acc);
+        d[r] = acc;
+    }
+    return d;
+}
+
+// v_mfma_f32_32x32x2_f32: lane l holds A[l&31][l>>5], B[l>>5][l&31]; D[(r&3)+8*(r>>2)+4*(l>>5)][l&31].
+static inline f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16 c, int, int, int) {
+    struct AB {
+        float a, b;
+    };
+    unsigned w;
+    const AB *all = hipemu::wave_gather(AB{a, b}, w);
+    auto at = [&](unsigned l) { return reinterpret_cast<const AB *>(reinterpret_cast<const uint64_t *>(all) + (size_t)l * 4); };
+    const unsigned lane = hipemu::flat_tid() % 64;
+    const unsigned j = lane & 31;
+    f32x16 d = c;
+    for (unsigned r = 0; r < 16; ++r) {
+        const unsigned i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = c[r];
+        for (unsigned k = 0; k < 2; ++k) acc = fmaf(at(i + 32 * k)->a, at(j + 32 * k)->b, acc);
+        d[r] = acc;
+    }
+    return d;
+}
+
+static inline float atomicAdd(float *p, float v) {
+    float o = *p;
+    *p = o + v;
+    return o;
+}
+static inline int atomicAdd(int *p, int v) {
+    int o = *p;
+    *p = o + v;
+    return o;
+}
+static inline unsigned atomicAdd(unsigned *p, unsigned v) {
+    unsigned o = *p;
+    *p = o + v;
+    return o;
+}
+
+// fast-math helpers: the product maps these to the hardware approximations, the interpreter to libm
+static inline float dfx_fast_exp(float x) { return expf(x); }
+static inline float dfx_fast_rcp(float x) { return 1.0f / x; }
+static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
+
+#define DFX_DYN_SMEM(T, name) T *name = reinterpret_cast<T *>(hipemu::dyn_smem_ptr())
+
+template <typename... KArgs, typename... Args>
+static inline void dfx_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t, Args &&...args) {
+    hipemu::launch(kernel, grid, block, shmem, std::forward<Args>(args)...);
+}
+static inline hipError_t dfx_env_set_max_dyn_smem(const void *, size_t) { return hipSuccess; }

@@ -1,0 +1,72 @@
+"""The product library: builds with hipcc for gfx950, loads without a GPU and exports every symbol include/dfx.h
+declares.  No compute call is made here (there is no GPU in CI); without a device the entry points must refuse loudly
+instead of falling back to anything."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(REPO, "include", "dfx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dfx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_binding_table_covers_header():
+    from deepfilternet_amd import _lib
+
+    assert sorted(_lib.SIGNATURES) == header_symbols()
+
+
+def test_hip_library_builds_and_exports_all_symbols():
+    from deepfilternet_amd.build import build
+
+    path = build()
+    lib = C.CDLL(path)
+    for name in header_symbols():
+        assert hasattr(lib, name), name
+    lib.dfx_is_emulator.restype = C.c_int
+    assert lib.dfx_is_emulator() == 0
+    out = os.popen(f"/opt/rocm/lib/llvm/bin/llvm-readelf --notes {path} 2>/dev/null | grep -c gfx950").read().strip()
+    assert out == "" or int(out) >= 0  # informational; the offload arch is checked below when the tool is present
+    arch = os.popen(f"strings {path} | grep -m1 -o 'amdgcn-amd-amdhsa--gfx950'").read().strip()
+    assert arch == "amdgcn-amd-amdhsa--gfx950"
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")
+def test_no_device_means_loud_failure_not_fallback():
+    from deepfilternet_amd.build import build
+
+    lib = C.CDLL(build())
+    lib.dfx_last_error.restype = C.c_char_p
+    h = C.c_void_p()
+    rc = lib.dfx_state_create(48000, 960, 480, 32, 2, C.byref(h))
+    assert rc == 4 and b"no CPU fallback" in lib.dfx_last_error()  # DFX_ERR_NO_DEVICE
+    w = (C.c_uint64 * 2)(3, 4)
+    assert lib.dfx_bands_create(w, 2, C.byref(h)) == 4
+    # the pure index arithmetic helper works anywhere and is bit-exact with the oracle
+    from oracle import libdf_oracle as L
+
+    out = np.zeros(32, np.uint64)
+    assert lib.dfx_erb_fb(48000, 960, 32, 2, out.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
+    assert out.tolist() == L.erb_fb_widths(48000, 960, 32, 2).tolist()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")
+def test_python_layer_raises_without_gpu():
+    from deepfilternet_amd import _lib
+    from deepfilternet_amd.build import build
+
+    _lib.use_library(build())
+    with pytest.raises(RuntimeError, match="no CPU fallback|no HIP device"):
+        _lib.device()
+    from deepfilternet_amd import libdf
+
+    with pytest.raises(RuntimeError):
+        libdf.DF(48000, 960, 480, 32, 2)
