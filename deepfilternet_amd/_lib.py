@@ -81,6 +81,11 @@ SIGNATURES = {
     "dfx_model_forward": (_i, [_vp, _vp, _fp, _fp, _fp, _i64, _i64, _f, _fp, _fp, _fp, _fp, _fp, _i64, _vp]),
     "dfx_enhance_workspace_bytes": (_i, [_vp, _vp, _i64, _i64, _i, C.POINTER(_i64)]),
     "dfx_enhance": (_i, [_vp, _vp, _fp, _i64, _i64, _i, _f, _fp, _fp, _i64, _vp]),
+    "dfx_prof_kernel_count": (_i, []),
+    "dfx_prof_kernel_name": (C.c_char_p, [_i]),
+    "dfx_prof_enable": (_i, [C.c_uint32]),
+    "dfx_prof_reset": (_i, []),
+    "dfx_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(_i64)]),
 }
 
 _LIB: Optional[C.CDLL] = None
@@ -148,6 +153,42 @@ def stream() -> C.c_void_p:
     if is_emulator():
         return C.c_void_p(0)
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def kernel_ids() -> dict:
+    """{kernel name: id} of the kernels dfx_prof_* can time."""
+    L = lib()
+    return {L.dfx_prof_kernel_name(i).decode(): i for i in range(L.dfx_prof_kernel_count())}
+
+
+def prof_enable(names=None) -> None:
+    """Time the named kernels (None/empty = off, "all" = every kernel) with hipEvents on their launch stream."""
+    ids = kernel_ids()
+    if not names:
+        mask = 0
+    elif names == "all":
+        mask = (1 << len(ids)) - 1
+    else:
+        mask = 0
+        for n in names:
+            mask |= 1 << ids[n]
+    check(lib().dfx_prof_enable(mask))
+
+
+def prof_reset() -> None:
+    check(lib().dfx_prof_reset())
+
+
+def prof_read() -> dict:
+    """{kernel name: (total_ms, launches)} since the last reset (synchronises the recorded events)."""
+    L = lib()
+    out = {}
+    for n, i in kernel_ids().items():
+        ms, cnt = C.c_double(), C.c_int64()
+        check(L.dfx_prof_read(i, C.byref(ms), C.byref(cnt)))
+        if cnt.value:
+            out[n] = (ms.value, cnt.value)
+    return out
 
 
 def check(rc: int) -> None:

@@ -60,6 +60,28 @@ struct dfx_state {
 static inline hipStream_t dfx_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int64_t dfx_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---- per-kernel timing (dfx_prof_* in dfx.h): hipEvents recorded on the launch stream around a kernel launch ------
+enum DfxKernelId {
+    DFX_K_ANALYSIS = 0, DFX_K_ANALYSIS_MEM, DFX_K_NORM_SCAN, DFX_K_SYNTHESIS, DFX_K_ERB, DFX_K_ERB_INV, DFX_K_DF_APPLY,
+    DFX_K_CONV_IN_ERB, DFX_K_PWCONV, DFX_K_CONV_OUT, DFX_K_DF_CONVP, DFX_K_GGEMM, DFX_K_GRU_REC, DFX_K_LSNR, DFX_K_ADD,
+    DFX_K_COPY_ROWS, DFX_K_COUNT
+};
+bool dfx_prof_on(int kernel_id);
+void dfx_prof_begin(int kernel_id, hipStream_t s);
+void dfx_prof_end(int kernel_id, hipStream_t s);
+// RAII: put one in the scope of a dfx_launch() call
+struct DfxKScope {
+    int id;
+    hipStream_t s;
+    bool on;
+    DfxKScope(int id_, hipStream_t s_) : id(id_), s(s_), on(dfx_prof_on(id_)) {
+        if (on) dfx_prof_begin(id, s);
+    }
+    ~DfxKScope() {
+        if (on) dfx_prof_end(id, s);
+    }
+};
+
 // ---- internal launchers shared between the DSP API and the model --------------------------------------------------
 int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_stride,
                         const float *mem_in, float *mem_out, float *spec, float *erb_db, hipStream_t s);

@@ -41,6 +41,84 @@ int dfx_require_device() {
     return DFX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ kernel timing
+namespace {
+struct ProfPair {
+    int id;
+    hipEvent_t a, b;
+};
+struct Prof {
+    uint32_t mask = 0;
+    std::vector<ProfPair> pending;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t cur = nullptr;
+    double total_ms[DFX_K_COUNT] = {0};
+    int64_t launches[DFX_K_COUNT] = {0};
+    hipEvent_t get() {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void drain() {
+        for (auto &p : pending) {
+            float ms = 0.f;
+            (void)hipEventSynchronize(p.b);
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+                total_ms[p.id] += ms;
+                launches[p.id] += 1;
+            }
+            pool.push_back(p.a);
+            pool.push_back(p.b);
+        }
+        pending.clear();
+    }
+};
+Prof g_prof;
+const char *const g_kernel_names[DFX_K_COUNT] = {
+    "dfx_k_analysis", "dfx_k_analysis_mem_out", "dfx_k_norm_scan", "dfx_k_synthesis", "dfx_k_erb", "dfx_k_erb_inv",
+    "dfx_k_df_apply", "dfx_k_conv_in_erb", "dfx_k_pwconv", "dfx_k_conv_out", "dfx_k_df_convp", "dfx_k_ggemm",
+    "dfx_k_gru_rec", "dfx_k_lsnr", "dfx_k_add", "dfx_k_copy_rows"};
+}  // namespace
+
+bool dfx_prof_on(int id) { return g_prof.mask != 0 && id >= 0 && id < DFX_K_COUNT && ((g_prof.mask >> id) & 1u); }
+void dfx_prof_begin(int, hipStream_t s) {
+    g_prof.cur = g_prof.get();
+    (void)hipEventRecord(g_prof.cur, s);
+}
+void dfx_prof_end(int id, hipStream_t s) {
+    hipEvent_t b = g_prof.get();
+    (void)hipEventRecord(b, s);
+    g_prof.pending.push_back(ProfPair{id, g_prof.cur, b});
+    g_prof.cur = nullptr;
+}
+extern "C" int dfx_prof_kernel_count(void) { return DFX_K_COUNT; }
+extern "C" const char *dfx_prof_kernel_name(int id) { return (id >= 0 && id < DFX_K_COUNT) ? g_kernel_names[id] : ""; }
+extern "C" int dfx_prof_enable(uint32_t mask) {
+    g_prof.drain();
+    g_prof.mask = mask;
+    return DFX_OK;
+}
+extern "C" int dfx_prof_reset(void) {
+    g_prof.drain();
+    for (int i = 0; i < DFX_K_COUNT; ++i) {
+        g_prof.total_ms[i] = 0;
+        g_prof.launches[i] = 0;
+    }
+    return DFX_OK;
+}
+extern "C" int dfx_prof_read(int id, double *total_ms, int64_t *launches) {
+    if (id < 0 || id >= DFX_K_COUNT) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_prof_read: bad kernel id");
+    g_prof.drain();
+    if (total_ms) *total_ms = g_prof.total_ms[id];
+    if (launches) *launches = g_prof.launches[id];
+    return DFX_OK;
+}
+
 template <typename T>
 static int upload(T **dst, const T *src, size_t n) {
     DFX_HIP(hipMalloc(reinterpret_cast<void **>(dst), n * sizeof(T)));
@@ -248,11 +326,13 @@ int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t 
         const size_t smem = dsp_smem_bytes(st);
         if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_analysis, smem));
         const int grid = grid_for(dfx_ceil_div(B * Tf, DFX_DSP_TEAMS));
+        DfxKScope ks(DFX_K_ANALYSIS, s);
         dfx_launch(dfx_k_analysis, dim3(grid), dim3(DFX_DSP_THREADS), smem, s, A);
         DFX_LAUNCH_CHECK();
     }
     if (mem_out && B > 0) {
         const int64_t n = B * ML;
+        DfxKScope ks(DFX_K_ANALYSIS_MEM, s);
         dfx_launch(dfx_k_analysis_mem_out, dim3((unsigned)dfx_ceil_div(n, 256)), dim3(256), 0, s, x, mem_in, mem_out, B, Tf,
                    x_stride, st->hop, ML);
         DFX_LAUNCH_CHECK();
@@ -266,6 +346,7 @@ int dfx_launch_norm_scan(const float *erb_in, float *erb_out, int E, const float
     const int nch = (erb_in ? E : 0) + (spec_in ? Fn : 0);
     const int64_t n = C * nch;
     if (n <= 0) return DFX_OK;
+    DfxKScope ks(DFX_K_NORM_SCAN, s);
     dfx_launch(dfx_k_norm_scan, dim3((unsigned)dfx_ceil_div(n, 64)), dim3(64), 0, s, erb_in, erb_out, E,
                reinterpret_cast<const float2 *>(spec_in), spec_frame_stride, reinterpret_cast<float2 *>(spec_out), Fn, C,
                T, alpha, erb_state, unit_state);
@@ -308,6 +389,7 @@ extern "C" int dfx_synthesis(const dfx_state *st, const float *spec, int64_t B, 
     if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_synthesis, smem));
     const int64_t nblk = B * A.chunks;
     if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_synthesis: batch too large for one launch");
+    DfxKScope ks(DFX_K_SYNTHESIS, dfx_stream(stream));
     dfx_launch(dfx_k_synthesis, dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, dfx_stream(stream), A);
     DFX_LAUNCH_CHECK();
     return DFX_OK;
@@ -319,6 +401,7 @@ extern "C" int dfx_erb(const dfx_bands *bands, const float *spec, int64_t rows, 
     if (rows == 0) return DFX_OK;
     if (!spec || !out) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_erb: null buffer");
     const int64_t n = rows * bands->nb;
+    DfxKScope ks(DFX_K_ERB, dfx_stream(stream));
     dfx_launch(dfx_k_erb, dim3((unsigned)dfx_ceil_div(n, 256)), dim3(256), 0, dfx_stream(stream),
                reinterpret_cast<const float2 *>(spec), rows, bands->F, bands->nb, bands->d_start, bands->d_invw, db, out);
     DFX_LAUNCH_CHECK();
@@ -331,6 +414,7 @@ extern "C" int dfx_erb_inv(const dfx_bands *bands, const float *gains, int64_t r
     if (rows == 0) return DFX_OK;
     if (!gains || !out) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_erb_inv: null buffer");
     const int64_t n = rows * bands->F;
+    DfxKScope ks(DFX_K_ERB_INV, dfx_stream(stream));
     dfx_launch(dfx_k_erb_inv, dim3((unsigned)dfx_ceil_div(n, 256)), dim3(256), 0, dfx_stream(stream), gains, rows,
                bands->F, bands->nb, bands->d_bin2band, out);
     DFX_LAUNCH_CHECK();
@@ -400,6 +484,7 @@ int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, 
     if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_df_apply, smem));
     const int64_t nblk = B * A.chunks;
     if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_df_apply: batch too large for one launch");
+    DfxKScope ks(DFX_K_DF_APPLY, s);
     dfx_launch(dfx_k_df_apply, dim3((unsigned)nblk), dim3(DFX_DFA_THREADS), smem, s, A);
     DFX_LAUNCH_CHECK();
     return DFX_OK;

@@ -400,6 +400,7 @@ static int launch_pw(int mode, const dfx_model *m, const PwW &w, const float *x,
     A.stride = stride;
     A.L = L;
     const int grid = nn_grid(dfx_ceil_div(R * Fout, DFX_PW_MT), 4);
+    DfxKScope ks(DFX_K_PWCONV, s);
     if (mode == DFX_PW_MODE_DW3) dfx_launch(dfx_k_pwconv<C, DFX_PW_MODE_DW3>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
     else if (mode == DFX_PW_MODE_DWT3) dfx_launch(dfx_k_pwconv<C, DFX_PW_MODE_DWT3>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
     else dfx_launch(dfx_k_pwconv<C, DFX_PW_MODE_IN33>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
@@ -427,6 +428,7 @@ static int launch_ggemm(const float *a, int lda, const float *w, int G, int Kg, 
     const int BN = Ng <= 16 ? 16 : (Ng <= 32 ? 32 : 64);
     A.ntn = (Ng + BN - 1) / BN;
     const dim3 grid((unsigned)dfx_ceil_div(M, DFX_GG_BM), (unsigned)(G * A.ntn));
+    DfxKScope ks(DFX_K_GGEMM, s);
     if (BN == 16) dfx_launch(dfx_k_ggemm<16>, grid, dim3(DFX_GG_THREADS), 0, s, A);
     else if (BN == 32) dfx_launch(dfx_k_ggemm<32>, grid, dim3(DFX_GG_THREADS), 0, s, A);
     else dfx_launch(dfx_k_ggemm<64>, grid, dim3(DFX_GG_THREADS), 0, s, A);
@@ -448,6 +450,7 @@ static int run_gru_stack(const dfx_model *m, const std::vector<GruW> &layers, co
     for (size_t l = 0; l < layers.size(); ++l) {
         const GruW &g = layers[l];
         if (int rc = launch_ggemm(in, 256, m->p(g.wih_t), 1, 256, 768, m->p(g.bias_i), DFX_ACT_NONE, nullptr, gi, 768, R, s)) return rc;
+        DfxKScope ks(DFX_K_GRU_REC, s);
         dfx_launch(dfx_k_gru_rec, dim3((unsigned)dfx_ceil_div(B, DFX_GRU_ROWS)), dim3(DFX_GRU_H), 0, s, (const float *)gi,
                    reinterpret_cast<const float4 *>(m->p(g.whh4)), m->p(g.bhn), outb, B, T);
         DFX_LAUNCH_CHECK();
@@ -477,6 +480,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     // ---- Encoder (deepfilternet3.py:166-185)
     {
         const int64_t total = R * E * C;
+        DfxKScope ks(DFX_K_CONV_IN_ERB, s);
         dfx_launch(dfx_k_conv_in_erb, dim3((unsigned)nn_grid(dfx_ceil_div(total, 256), 16)), dim3(256), 0, s, feat_erb,
                    m->p(m->erb0_w), m->p(m->erb0_b), e0, B, T, E, C, L);
         DFX_LAUNCH_CHECK();
@@ -493,8 +497,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     const float *y = nullptr;
     if ((rc = run_gru_stack(m, m->enc_gru, xa, xa, xb, gi, B, T, &y, s))) return rc;
     if ((rc = launch_glin(m, m->enc_out, y, DFX_ACT_RELU, nullptr, embv, R, s))) return rc;
-    dfx_launch(dfx_k_lsnr, dim3((unsigned)dfx_ceil_div(R * 64, 256)), dim3(256), 0, s, (const float *)embv, m->p(m->lsnr_w),
-               m->lsnr_b, (float)(c.lsnr_max - c.lsnr_min), (float)c.lsnr_min, lsnr, R, emb);
+    {
+        DfxKScope ks(DFX_K_LSNR, s);
+        dfx_launch(dfx_k_lsnr, dim3((unsigned)dfx_ceil_div(R * 64, 256)), dim3(256), 0, s, (const float *)embv, m->p(m->lsnr_w),
+                   m->lsnr_b, (float)(c.lsnr_max - c.lsnr_min), (float)c.lsnr_min, lsnr, R, emb);
+    }
     DFX_LAUNCH_CHECK();
     // ---- ErbDecoder (:245-254)
     if ((rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, xa, R, s))) return rc;
@@ -506,6 +513,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     {
         const int fpt = 64 / E > 0 ? 64 / E : 1;
         const size_t smem = ((size_t)fpt * E * (C + 1) + (size_t)fpt * E * 3 + 3 * C) * sizeof(float);
+        DfxKScope ks(DFX_K_CONV_OUT, s);
         dfx_launch(dfx_k_conv_out<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R, fpt), 8)), dim3(DFX_CO_THREADS), smem, s,
                    (const float *)d1, (const float *)e0, m->p(m->co_ska), m->p(m->co_skb), m->p(m->co_w), m->co_bias, mask,
                    R, E, fpt);
@@ -519,6 +527,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         if ((rc = launch_glin(m, m->df_skip, embv, DFX_ACT_NONE, y, xdf, R, s))) return rc;
         cfeat = xdf;
     } else if (c.df_gru_skip == DFX_SKIP_IDENTITY) {
+        DfxKScope ks(DFX_K_ADD, s);
         dfx_launch(dfx_k_add, dim3((unsigned)nn_grid(dfx_ceil_div(R * 256, 256), 16)), dim3(256), 0, s, y, (const float *)embv,
                    xdf, R * 256);
         DFX_LAUNCH_CHECK();
@@ -545,6 +554,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_df_convp<C>, smem));
         const int64_t nblk = B * A.tchunks * A.fchunks;
         if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "df_convp grid too large");
+        DfxKScope ks(DFX_K_DF_CONVP, s);
         dfx_launch(dfx_k_df_convp<C>, dim3((unsigned)nblk), dim3(DFX_CP_THREADS), smem, s, A);
         DFX_LAUNCH_CHECK();
     }
@@ -650,6 +660,7 @@ extern "C" int dfx_enhance(const dfx_model *m, const dfx_state *st, const float 
     int64_t xstride = T;
     if (pad) {  // F.pad(audio, (0, n_fft))  (enhance.py:230-233)
         float *xp = reinterpret_cast<float *>(base + w.xpad);
+        DfxKScope ks(DFX_K_COPY_ROWS, s);
         dfx_launch(dfx_k_copy_rows, dim3((unsigned)nn_grid(dfx_ceil_div(B * Tp, 256), 16)), dim3(256), 0, s, x, T, T,
                    (int64_t)0, xp, Tp, Tp, B);
         DFX_LAUNCH_CHECK();
@@ -671,6 +682,7 @@ extern "C" int dfx_enhance(const dfx_model *m, const dfx_state *st, const float 
         rc = dfx_synthesis(st, spec_e, B, Tf, nullptr, nullptr, ysyn, Tf * st->hop, stream);
         if (rc) return rc;
         const int64_t d = st->N - st->hop;  // enhance.py:248-249: audio[:, d : orig_len + d]
+        DfxKScope ks(DFX_K_COPY_ROWS, s);
         dfx_launch(dfx_k_copy_rows, dim3((unsigned)nn_grid(dfx_ceil_div(B * T, 256), 16)), dim3(256), 0, s, (const float *)ysyn,
                    Tf * st->hop, Tf * st->hop, d, y, T, T, B);
         DFX_LAUNCH_CHECK();

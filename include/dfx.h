@@ -177,6 +177,18 @@ int dfx_enhance_workspace_bytes(const dfx_model *m, const dfx_state *st, int64_t
 int dfx_enhance(const dfx_model *m, const dfx_state *st, const float *x, int64_t B, int64_t T, int pad,
                 float atten_lim_db, float *y, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Per-kernel timing (measurement aid, no reference counterpart; the reference only logs wall-clock RTF,
+ * DeepFilterNet/df/enhance.py:77-87).  When a kernel's bit is set in `kernel_mask`, every launch of it is bracketed by
+ * two hipEvents recorded on the stream the kernel is launched on.  dfx_prof_read() synchronises the pending events and
+ * returns the accumulated device time and launch count since the last reset.  Mask 0 (default) = no events at all.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int dfx_prof_kernel_count(void);
+const char *dfx_prof_kernel_name(int kernel_id);
+int dfx_prof_enable(uint32_t kernel_mask);
+int dfx_prof_reset(void);
+int dfx_prof_read(int kernel_id, double *total_ms, int64_t *launches);
+
 #ifdef __cplusplus
 }
 #endif
