@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_analysis(DfxAnaArgs A) 
                 const float2 tt = dfx_cmul(make_float2(di, -dr), tw[k]);
                 const float2 X = make_float2((er + tt.x) * A.wnorm, (ei + tt.y) * A.wnorm);
                 out[k] = X;
-                if (A.erb_db) pw[k] = X.x * X.x + X.y * X.y;
+                if (A.erb_db) pw[k] = __fadd_rn(__fmul_rn(X.x, X.x), __fmul_rn(X.y, X.y));
             }
         }
         if (A.erb_db) {
@@ -190,14 +190,14 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_analysis(DfxAnaArgs A) 
                 const int s0 = A.band_start[lane], s1 = A.band_start[lane + 1];
                 const float kk = A.band_invw[lane];
                 float acc = 0.f;
-                for (int j = s0; j < s1; ++j) acc += pw[j] * kk;
+                for (int j = s0; j < s1; ++j) acc = __fadd_rn(acc, __fmul_rn(pw[j], kk));
                 A.erb_db[(b * A.Tf + t) * A.nb + lane] = log10f(acc + 1e-10f) * 10.f;
             }
             for (int e = DFX_DSP_TEAM + lane; active && e < A.nb; e += DFX_DSP_TEAM) {  // nb > 64 (rare)
                 const int s0 = A.band_start[e], s1 = A.band_start[e + 1];
                 const float kk = A.band_invw[e];
                 float acc = 0.f;
-                for (int j = s0; j < s1; ++j) acc += pw[j] * kk;
+                for (int j = s0; j < s1; ++j) acc = __fadd_rn(acc, __fmul_rn(pw[j], kk));
                 A.erb_db[(b * A.Tf + t) * A.nb + e] = log10f(acc + 1e-10f) * 10.f;
             }
         }
@@ -331,6 +331,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_synthesis(DfxSynArgs A)
 // erb() (transforms.rs:236-253 / lib.rs:280-295): one thread per (row, band); rows of F complex bins.
 __global__ void dfx_k_erb(const float2 *spec, int64_t rows, int F, int nb, const int *band_start,
                           const float *band_invw, int db, float *out) {
+#pragma clang fp contract(off)  // lib.rs:280-295 evaluates |x|^2 * k and the running sum as separate f32 operations
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * nb) return;
     const int64_t r = i / nb;
@@ -362,6 +363,7 @@ __global__ void dfx_k_erb_inv(const float *gains, int64_t rows, int F, int nb, c
 __global__ void dfx_k_norm_scan(const float *erb_in, float *erb_out, int E, const float2 *spec_in,
                                 int64_t spec_frame_stride, float2 *spec_out, int Fn, int64_t C, int64_t T, float alpha,
                                 float *erb_state, float *unit_state) {
+#pragma clang fp contract(off)  // the Rust reference never fuses x*(1-a) + s*a into an FMA (lib.rs:244-259)
     const int nch = (erb_in ? E : 0) + (spec_in ? Fn : 0);
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= C * nch) return;

@@ -450,9 +450,11 @@ static int run_gru_stack(const dfx_model *m, const std::vector<GruW> &layers, co
     for (size_t l = 0; l < layers.size(); ++l) {
         const GruW &g = layers[l];
         if (int rc = launch_ggemm(in, 256, m->p(g.wih_t), 1, 256, 768, m->p(g.bias_i), DFX_ACT_NONE, nullptr, gi, 768, R, s)) return rc;
+        DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_rec, DFX_GRU_SMEM));
         DfxKScope ks(DFX_K_GRU_REC, s);
-        dfx_launch(dfx_k_gru_rec, dim3((unsigned)dfx_ceil_div(B, DFX_GRU_ROWS)), dim3(DFX_GRU_H), 0, s, (const float *)gi,
-                   reinterpret_cast<const float4 *>(m->p(g.whh4)), m->p(g.bhn), outb, B, T);
+        dfx_launch(dfx_k_gru_rec, dim3((unsigned)dfx_ceil_div(B, DFX_GRU_ROWS)), dim3(DFX_GRU_THREADS), DFX_GRU_SMEM, s,
+                   (const float *)gi, reinterpret_cast<const float4 *>(m->p(g.whh4)), m->p(g.bhn), (const float *)nullptr,
+                   (float *)nullptr, outb, B, T);
         DFX_LAUNCH_CHECK();
         in = outb;
         outb = (outb == bufa) ? bufb : bufa;

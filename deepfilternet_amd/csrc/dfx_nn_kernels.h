@@ -421,68 +421,136 @@ __global__ void dfx_k_add(const float *a, const float *b, float *out, int64_t n)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// GRU recurrence (torch.nn.GRU semantics, gate order r,z,n; modules.py:721), hidden size 256, h0 = 0.
+// GRU recurrence (torch.nn.GRU semantics, gate order r,z,n; modules.py:721), hidden size 256.
 //   gi [B, T, 768] already holds W_ih x + b_ih (+ b_hr, b_hz folded in);   per step:
 //   r = s(gi_r + W_hr h), z = s(gi_z + W_hz h), n = tanh(gi_n + r*(W_hn h + b_hn)), h' = (1-z)*n + z*h
-// Clips are independent, so a workgroup owns DFX_GRU_ROWS clips for all T steps: no inter-workgroup synchronisation.
-// Thread j owns hidden unit j: three 256-long dot products per row per step.  W_hh (768 KB fp32) exceeds a CU's LDS +
-// registers, so it is streamed from L2 every step as coalesced float4s (layout [k/4][gate][j][4]); h lives in LDS and is
-// read as wave-broadcast float4s.  One barrier per step (h double-buffered).
+// Clips are independent, so a workgroup owns DFX_GRU_ROWS = 2 clips for all T steps: no inter-workgroup synchronisation,
+// B/2 workgroups (128 CUs at batch 256).  The step is a latency chain of T*layers = 5010 iterations, so the design goal is
+// the shortest possible step.  W_hh (768 KB fp32) exceeds what one CU can hold (512 KB of VGPRs + 160 KB LDS), so it is
+// split three ways per thread and only the remainder is re-read from L2 every step:
+//   512 threads; thread (j = tid>>1, kh = tid&1) owns hidden unit j for the 32 k4-blocks {2*i + kh} (a k4-block = 4
+//   consecutive k of the three gates = 12 floats).  Blocks [0,KR) live in VGPRs for the whole kernel (168 registers),
+//   blocks [KR,KR+KL) in LDS (144 KB), the last KS blocks are streamed from L2 through a two-deep register ring that is
+//   refilled across the step boundary (the weights do not depend on t).  h lives in LDS (double buffered, one barrier per
+//   step) and is read as wave-broadcast float4s; the two k-halves of a unit are adjacent lanes and are combined with
+//   one DPP shuffle per accumulator; lane kh then finishes row kh (gates, h', store).
+// Per step and CU: 288 KB from L2, 1536 FMA wave-instructions per SIMD, 1 barrier.
 // ---------------------------------------------------------------------------------------------------------------------
 #define DFX_GRU_H 256
-#define DFX_GRU_ROWS 4
-__global__ void __launch_bounds__(DFX_GRU_H) dfx_k_gru_rec(const float *gi, const float4 *whh4, const float *bhn, float *y,
-                                                           int64_t B, int64_t T) {
-    constexpr int H = DFX_GRU_H, MR = DFX_GRU_ROWS;
-    __shared__ __attribute__((aligned(16))) float hs[2][MR][H];
-    const int j = threadIdx.x;
+#define DFX_GRU_ROWS 2
+#define DFX_GRU_THREADS 512
+#define DFX_GRU_KR 14
+#define DFX_GRU_KL 6
+#define DFX_GRU_KS (32 - DFX_GRU_KR - DFX_GRU_KL)
+#define DFX_GRU_SMEM ((size_t)DFX_GRU_KL * 3 * DFX_GRU_THREADS * 16 + (size_t)2 * DFX_GRU_ROWS * DFX_GRU_H * 4)
+
+__global__ void __launch_bounds__(DFX_GRU_THREADS, 2) dfx_k_gru_rec(const float *gi, const float4 *__restrict__ whh4,
+                                                                    const float *bhn, const float *h_in, float *h_out,
+                                                                    float *y, int64_t B, int64_t T) {
+    constexpr int H = DFX_GRU_H, MR = DFX_GRU_ROWS, KR = DFX_GRU_KR, KL = DFX_GRU_KL, KS = DFX_GRU_KS, NT = DFX_GRU_THREADS;
+    static_assert(KS >= 2 && KS % 2 == 0 && MR == 2, "ring of two single-block buffers, lane pair = row pair");
+    DFX_DYN_SMEM(unsigned char, smraw);
+    float4 *wl = reinterpret_cast<float4 *>(smraw);                            // [KL][3][NT]
+    float *hs = reinterpret_cast<float *>(smraw + (size_t)KL * 3 * NT * 16);   // [2][MR][H]
+    const int tid = threadIdx.x, j = tid >> 1, kh = tid & 1;
     const int64_t b0 = (int64_t)blockIdx.x * MR;
-    const float bn = bhn[j];
+    // float4 index of this thread's k4-block i, gate g inside whh4 ([k4][gate][j] float4, k4 = 2*i + kh)
+#define DFX_GRU_WIDX(i, g) (((2 * (i) + kh) * 3 + (g)) * H + j)
+    float4 wr[KR][3];
 #pragma unroll
-    for (int r = 0; r < MR; ++r) hs[0][r][j] = 0.f;
+    for (int k = 0; k < KR; ++k)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) wr[k][g] = whh4[DFX_GRU_WIDX(k, g)];
+    for (int k = 0; k < KL; ++k)
+        for (int g = 0; g < 3; ++g) wl[(k * 3 + g) * NT + tid] = whh4[DFX_GRU_WIDX(KR + k, g)];
+    const float bn = bhn[j];
+    const bool valid = b0 + kh < B;
+    const int64_t brow = valid ? b0 + kh : B - 1;
+    hs[kh * H + j] = h_in ? h_in[brow * H + j] : 0.f;
     __syncthreads();
     int cur = 0;
+    const float4 *ws = whh4 + DFX_GRU_WIDX(KR + KL, 0);  // streamed block s, gate g: ws[(s*6 + g)*H]
+    const float *gp = gi + brow * T * (3 * H) + j;
+    float *yp = y + brow * T * H + j;
+    float gr = 0.f, gz = 0.f, gn = 0.f;
+    if (T > 0) {
+        gr = gp[0];
+        gz = gp[H];
+        gn = gp[2 * H];
+    }
+    float4 sA[3], sB[3];
+#define DFX_GRU_ISSUE(BUF, S) \
+    _Pragma("unroll") for (int g = 0; g < 3; ++g) BUF[g] = wst[((S) * 6 + g) * H];
+#define DFX_GRU_BLOCK(W0, W1, W2, I)                                                                       \
+    _Pragma("unroll") for (int r = 0; r < MR; ++r) {                                                       \
+        const float4 hv = *reinterpret_cast<const float4 *>(hc + r * H + 4 * (2 * (I) + kh));            \
+        ar[r] = fmaf(W0.w, hv.w, fmaf(W0.z, hv.z, fmaf(W0.y, hv.y, fmaf(W0.x, hv.x, ar[r]))));           \
+        az[r] = fmaf(W1.w, hv.w, fmaf(W1.z, hv.z, fmaf(W1.y, hv.y, fmaf(W1.x, hv.x, az[r]))));           \
+        an[r] = fmaf(W2.w, hv.w, fmaf(W2.z, hv.z, fmaf(W2.y, hv.y, fmaf(W2.x, hv.x, an[r]))));           \
+    }
+    {
+        const float4 *wst = ws;
+        DFX_GRU_ISSUE(sA, 0)
+    }
     for (int64_t t = 0; t < T; ++t) {
-        float gir[MR], giz[MR], gin[MR];
-#pragma unroll
-        for (int r = 0; r < MR; ++r) {
-            const int64_t b = b0 + r;
-            if (b < B) {
-                const float *g = gi + (b * T + t) * (3 * H);
-                gir[r] = g[j];
-                giz[r] = g[H + j];
-                gin[r] = g[2 * H + j];
-            } else {
-                gir[r] = giz[r] = gin[r] = 0.f;
-            }
-        }
         float ar[MR], az[MR], an[MR];
 #pragma unroll
         for (int r = 0; r < MR; ++r) ar[r] = az[r] = an[r] = 0.f;
-#pragma unroll 4
-        for (int k4 = 0; k4 < H / 4; ++k4) {
-            const float4 wr = whh4[(k4 * 3 + 0) * H + j];
-            const float4 wz = whh4[(k4 * 3 + 1) * H + j];
-            const float4 wn = whh4[(k4 * 3 + 2) * H + j];
+        const float *hc = hs + cur * MR * H;
+        int zoff = 0;
+        DFX_OPAQUE(zoff);  // an opaque zero: keeps the streamed weight loads inside the time loop (they are loop invariant)
+        const float4 *wst = ws + zoff;
+        // next step's input projection (independent of the recurrence)
+        const int64_t tn = t + 1 < T ? t + 1 : t;
+        const float ngr = gp[tn * 3 * H], ngz = gp[tn * 3 * H + H], ngn = gp[tn * 3 * H + 2 * H];
+        DFX_GRU_ISSUE(sB, 1)
+        DFX_SCHED_BARRIER();
 #pragma unroll
-            for (int r = 0; r < MR; ++r) {
-                const float4 hv = *reinterpret_cast<const float4 *>(&hs[cur][r][4 * k4]);
-                ar[r] = fmaf(wr.w, hv.w, fmaf(wr.z, hv.z, fmaf(wr.y, hv.y, fmaf(wr.x, hv.x, ar[r]))));
-                az[r] = fmaf(wz.w, hv.w, fmaf(wz.z, hv.z, fmaf(wz.y, hv.y, fmaf(wz.x, hv.x, az[r]))));
-                an[r] = fmaf(wn.w, hv.w, fmaf(wn.z, hv.z, fmaf(wn.y, hv.y, fmaf(wn.x, hv.x, an[r]))));
+        for (int k = 0; k < KR; ++k) { DFX_GRU_BLOCK(wr[k][0], wr[k][1], wr[k][2], k) }
+        constexpr int per = (KL + KS - 1) / KS;  // LDS-resident blocks interleaved per streamed block
+#pragma unroll
+        for (int s = 0; s < KS; s += 2) {
+            DFX_SCHED_BARRIER();
+            DFX_GRU_BLOCK(sA[0], sA[1], sA[2], KR + KL + s)
+            DFX_SCHED_BARRIER();
+            if (s + 2 < KS) { DFX_GRU_ISSUE(sA, s + 2) } else { DFX_GRU_ISSUE(sA, 0) }  // wraps into the next step
+#pragma unroll
+            for (int k = s * per; k < (s + 1) * per && k < KL; ++k) {
+                const float4 w0 = wl[(k * 3 + 0) * NT + tid], w1 = wl[(k * 3 + 1) * NT + tid], w2 = wl[(k * 3 + 2) * NT + tid];
+                DFX_GRU_BLOCK(w0, w1, w2, KR + k)
+            }
+            DFX_SCHED_BARRIER();
+            DFX_GRU_BLOCK(sB[0], sB[1], sB[2], KR + KL + s + 1)
+            DFX_SCHED_BARRIER();
+            if (s + 3 < KS) { DFX_GRU_ISSUE(sB, s + 3) }
+#pragma unroll
+            for (int k = (s + 1) * per; k < (s + 2) * per && k < KL; ++k) {
+                const float4 w0 = wl[(k * 3 + 0) * NT + tid], w1 = wl[(k * 3 + 1) * NT + tid], w2 = wl[(k * 3 + 2) * NT + tid];
+                DFX_GRU_BLOCK(w0, w1, w2, KR + k)
             }
         }
+        // combine the two k-halves of each unit (adjacent lanes), then lane kh finishes row kh
 #pragma unroll
         for (int r = 0; r < MR; ++r) {
-            const float rg = dfx_sigmoid(gir[r] + ar[r]);
-            const float zg = dfx_sigmoid(giz[r] + az[r]);
-            const float ng = tanhf(gin[r] + rg * (an[r] + bn));
-            const float hn = (1.f - zg) * ng + zg * hs[cur][r][j];
-            hs[cur ^ 1][r][j] = hn;
-            const int64_t b = b0 + r;
-            if (b < B) y[(b * T + t) * H + j] = hn;
+            ar[r] += __shfl_xor(ar[r], 1);
+            az[r] += __shfl_xor(az[r], 1);
+            an[r] += __shfl_xor(an[r], 1);
         }
+        const float sr = kh ? ar[1] : ar[0], sz = kh ? az[1] : az[0], sn = kh ? an[1] : an[0];
+        const float rg = dfx_sigmoid(gr + sr);
+        const float zg = dfx_sigmoid(gz + sz);
+        const float ng = tanhf(gn + rg * (sn + bn));
+        const float hn = (1.f - zg) * ng + zg * hc[kh * H + j];
+        hs[(cur ^ 1) * MR * H + kh * H + j] = hn;
+        if (valid) yp[t * H] = hn;
+        gr = ngr;
+        gz = ngz;
+        gn = ngn;
         __syncthreads();
         cur ^= 1;
     }
+    if (h_out && valid) h_out[brow * H + j] = hs[cur * MR * H + kh * H + j];
+#undef DFX_GRU_WIDX
+#undef DFX_GRU_ISSUE
+#undef DFX_GRU_BLOCK
 }

@@ -41,5 +41,9 @@ static inline hipError_t dfx_env_set_max_dyn_smem(const void *func, size_t bytes
     return hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// compiler fences used by the hand-scheduled kernels
+#define DFX_OPAQUE(x) asm volatile("" : "+v"(x))
+#define DFX_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+
 static __device__ __forceinline__ float dfx_fast_exp(float x) { return __expf(x); }
 static __device__ __forceinline__ float dfx_fast_rcp(float x) { return __frcp_rn(x); }

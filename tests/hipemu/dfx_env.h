@@ -426,8 +426,12 @@ static inline unsigned atomicAdd(unsigned *p, unsigned v) {
 // fast-math helpers: the product maps these to the hardware approximations, the interpreter to libm
 static inline float dfx_fast_exp(float x) { return expf(x); }
 static inline float dfx_fast_rcp(float x) { return 1.0f / x; }
+static inline float __fadd_rn(float a, float b) { return a + b; }  // the emulator is built with -ffp-contract=off
+static inline float __fmul_rn(float a, float b) { return a * b; }
 static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
 
+#define DFX_OPAQUE(x) asm volatile("" : "+r"(x))
+#define DFX_SCHED_BARRIER() ((void)0)
 #define DFX_DYN_SMEM(T, name) T *name = reinterpret_cast<T *>(hipemu::dyn_smem_ptr())
 
 template <typename... KArgs, typename... Args>
