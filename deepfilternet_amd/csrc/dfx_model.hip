@@ -89,7 +89,9 @@ struct dfx_model {
     std::vector<GruW> enc_gru, dec_gru, df_gru;
     size_t lsnr_w = 0;
     float lsnr_b = 0.f;
-    size_t cp_w1 = 0, cp_w2 = 0, cp_b = 0;
+    size_t cp_w1 = 0, cp_w2 = 0, cp_b = 0;   // df_convp, tiled form (kt > 5)
+    size_t cp_weff = 0, cp_b16 = 0;          // df_convp, folded sliding-window form (kt <= 5)
+    size_t cin_weff = 0, cin_b = 0;          // enc.df_conv0 folded into a dense 3x3 conv 2 -> C
     int cp_G = 0, cp_NO = 0;
     const float *p(size_t off) const { return d_w + off; }
 };
@@ -222,19 +224,21 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
     }
     ok = ok && prep_sep(P, "enc.erb_conv1", C, m->erb1) && prep_sep(P, "enc.erb_conv2", C, m->erb2) &&
          prep_sep(P, "enc.erb_conv3", C, m->erb3) && prep_sep(P, "enc.df_conv1", C, m->dfc1);
-    if (ok) {   // enc.df_conv0: pad(.0) conv groups=2 (.1) pointwise(.2) bn(.3)
+    if (ok) {   // enc.df_conv0: pad(.0) conv groups=2 (.1) pointwise(.2) bn(.3), folded into one dense conv (K = 18 -> 20)
         const float *w = P.get("enc.df_conv0.1.weight"), *pw = P.get("enc.df_conv0.2.weight");
         std::vector<float> sc, sh;
         ok = w && pw && P.bn("enc.df_conv0.3", C, sc, sh);
         if (ok) {
-            m->dfc0.dw = P.alloc(9 * C);
-            m->dfc0.wt = P.alloc((size_t)C * C);
-            m->dfc0.bias = P.alloc(C);
-            for (int ch = 0; ch < C; ++ch)
-                for (int k = 0; k < 9; ++k) P.out[m->dfc0.dw + k * C + ch] = w[ch * 9 + k];
+            m->cin_weff = P.alloc((size_t)20 * C);
+            m->cin_b = P.alloc(C);
             for (int n = 0; n < C; ++n) {
-                for (int k = 0; k < C; ++k) P.out[m->dfc0.wt + (size_t)k * C + n] = pw[(size_t)n * C + k] * sc[n];
-                P.out[m->dfc0.bias + n] = sh[n];
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int ch = 0; ch < 2; ++ch) {
+                        double acc = 0.0;  // groups=2: output channel c of the 3x3 conv sees input ch = c / (C/2)
+                        for (int c = ch * (C / 2); c < (ch + 1) * (C / 2); ++c) acc += (double)pw[(size_t)n * C + c] * (double)w[c * 9 + tap];
+                        P.out[m->cin_weff + (size_t)(tap * 2 + ch) * C + n] = (float)(acc * (double)sc[n]);
+                    }
+                P.out[m->cin_b + n] = sh[n];
             }
         }
     }
@@ -296,6 +300,22 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
                 for (int o = 0; o < NO; ++o) P.out[m->cp_w2 + (size_t)n * NO + o] = has_pw ? pw[(size_t)n * NO + o] * sc[n] : (n == o ? 1.f : 0.f);
                 P.out[m->cp_b + n] = sh[n];
             }
+            // folded form: W_eff[k][c][n] = scale[n] * sum_o PW[n][o] * W1[o][c - group(o)*CG][k]   (PW = identity if absent)
+            m->cp_weff = P.alloc((size_t)kt * C * 16);
+            m->cp_b16 = P.alloc(16);
+            for (int k = 0; k < kt; ++k)
+                for (int ch = 0; ch < C; ++ch) {
+                    const int g = ch / CG, ci = ch - g * CG;
+                    for (int n = 0; n < NO; ++n) {
+                        double acc = 0.0;
+                        for (int o = g * OG; o < (g + 1) * OG; ++o) {
+                            const double p2 = has_pw ? (double)pw[(size_t)n * NO + o] : (n == o ? 1.0 : 0.0);
+                            acc += p2 * (double)w[((size_t)o * CG + ci) * kt + k];
+                        }
+                        P.out[m->cp_weff + ((size_t)k * C + ch) * 16 + n] = (float)(acc * (double)sc[n]);
+                    }
+                }
+            for (int n = 0; n < NO; ++n) P.out[m->cp_b16 + n] = sh[n];
         }
     }
     ok = ok && prep_glin(P, "df_dec.df_gru.linear_in.0.weight", m->dfg_in) && prep_gru(P, "df_dec.df_gru.gru", c.df_num_layers, m->df_gru);
@@ -383,7 +403,7 @@ static int nn_grid(int64_t tiles, int per_cu) {
 
 template <int C>
 static int launch_pw(int mode, const dfx_model *m, const PwW &w, const float *x, const float *skip, float *out, int64_t R,
-                     int64_t T, int Fin, int Fout, int stride, int L, hipStream_t s) {
+                     int Fin, int Fout, int stride, hipStream_t s) {
     DfxPwArgs A;
     A.x = x;
     A.skip = skip;
@@ -394,16 +414,47 @@ static int launch_pw(int mode, const dfx_model *m, const PwW &w, const float *x,
     A.bias = m->p(w.bias);
     A.out = out;
     A.R = R;
-    A.T = T;
     A.Fin = Fin;
     A.Fout = Fout;
     A.stride = stride;
-    A.L = L;
-    const int grid = nn_grid(dfx_ceil_div(R * Fout, DFX_PW_MT), 4);
+    const int grid = nn_grid(dfx_ceil_div(R * Fout, 64), 8);
     DfxKScope ks(DFX_K_PWCONV, s);
-    if (mode == DFX_PW_MODE_DW3) dfx_launch(dfx_k_pwconv<C, DFX_PW_MODE_DW3>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
-    else if (mode == DFX_PW_MODE_DWT3) dfx_launch(dfx_k_pwconv<C, DFX_PW_MODE_DWT3>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
-    else dfx_launch(dfx_k_pwconv<C, DFX_PW_MODE_IN33>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
+    if (mode == DFX_PW_MODE_DW3) {
+        if (skip) dfx_launch(dfx_k_pwconv<C, DFX_PW_MODE_DW3, true>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
+        else dfx_launch(dfx_k_pwconv<C, DFX_PW_MODE_DW3, false>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
+    } else {
+        if (skip) dfx_launch(dfx_k_pwconv<C, DFX_PW_MODE_DWT3, true>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
+        else dfx_launch(dfx_k_pwconv<C, DFX_PW_MODE_DWT3, false>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
+    }
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
+}
+
+template <int C, int KT>
+static int launch_convp2(const dfx_model *m, const float *c0, float *out, int64_t B, int64_t T, int Fd, int NO, hipStream_t s) {
+    DfxCp2Args A;
+    A.c0 = c0;
+    A.weff = m->p(m->cp_weff);
+    A.bias = m->p(m->cp_b16);
+    A.out = out;
+    A.B = B;
+    A.T = T;
+    A.Fd = Fd;
+    A.NO = NO;
+    A.nfb = (Fd + 15) / 16;
+    // enough independent wave-runs to fill the chip (each run re-reads KT-1 halo frames): target >= 8 waves per SIMD-slot
+    const int64_t want = (int64_t)dfx_env_num_cus() * 4 * 8;
+    int64_t nseg = dfx_ceil_div(want, B * A.nfb);
+    const int64_t max_seg = dfx_ceil_div(T, (int64_t)8 * KT);
+    if (nseg > max_seg) nseg = max_seg;
+    if (nseg < 1) nseg = 1;
+    int64_t tseg = dfx_ceil_div(dfx_ceil_div(T, nseg), (int64_t)KT) * KT;
+    A.tseg = (int)tseg;
+    A.nseg = (int)dfx_ceil_div(T, tseg);
+    const int64_t nruns = B * A.nfb * A.nseg;
+    const int grid = nn_grid(dfx_ceil_div(nruns, 4), 8);
+    DfxKScope ks(DFX_K_DF_CONVP, s);
+    dfx_launch(dfx_k_df_convp2<C, KT>, dim3(grid), dim3(256), 0, s, A);
     DFX_LAUNCH_CHECK();
     return DFX_OK;
 }
@@ -481,17 +532,30 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     int rc;
     // ---- Encoder (deepfilternet3.py:166-185)
     {
-        const int64_t total = R * E * C;
+        const int64_t total = R * E * (C / 4);
         DfxKScope ks(DFX_K_CONV_IN_ERB, s);
         dfx_launch(dfx_k_conv_in_erb, dim3((unsigned)nn_grid(dfx_ceil_div(total, 256), 16)), dim3(256), 0, s, feat_erb,
                    m->p(m->erb0_w), m->p(m->erb0_b), e0, B, T, E, C, L);
         DFX_LAUNCH_CHECK();
     }
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb1, e0, nullptr, e1, R, T, E, E / 2, 2, 0, s))) return rc;
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb2, e1, nullptr, e2, R, T, E / 2, E / 4, 2, 0, s))) return rc;
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb3, e2, nullptr, e3, R, T, E / 4, E / 4, 1, 0, s))) return rc;
-    if ((rc = launch_pw<C>(DFX_PW_MODE_IN33, m, m->dfc0, feat_spec, nullptr, c0, R, T, Fd, Fd, 1, L, s))) return rc;
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->dfc1, c0, nullptr, c1, R, T, Fd, Fd / 2, 2, 0, s))) return rc;
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb1, e0, nullptr, e1, R, E, E / 2, 2, s))) return rc;
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb2, e1, nullptr, e2, R, E / 2, E / 4, 2, s))) return rc;
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb3, e2, nullptr, e3, R, E / 4, E / 4, 1, s))) return rc;
+    {
+        DfxCinArgs A;
+        A.feat = feat_spec;
+        A.weff = m->p(m->cin_weff);
+        A.bias = m->p(m->cin_b);
+        A.out = c0;
+        A.B = B;
+        A.T = T;
+        A.Fin = Fd;
+        A.L = L;
+        DfxKScope ks(DFX_K_CONV_IN_DF, s);
+        dfx_launch(dfx_k_conv_in_df<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R * Fd, 64), 8)), dim3(DFX_PW_THREADS), 0, s, A);
+        DFX_LAUNCH_CHECK();
+    }
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->dfc1, c0, nullptr, c1, R, Fd, Fd / 2, 2, s))) return rc;
     // cemb = relu(df_fc_emb(c1.flatten)); emb_in = e3.flatten + cemb   (:179-182)
     if ((rc = launch_glin(m, m->fc_emb, c1, DFX_ACT_RELU, e3, emb_in, R, s))) return rc;
     // enc.emb_gru (SqueezedGRU_S :149-158)
@@ -509,9 +573,9 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     if ((rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, xa, R, s))) return rc;
     if ((rc = run_gru_stack(m, m->dec_gru, xa, xa, xb, gi, B, T, &y, s))) return rc;
     if ((rc = launch_glin(m, m->dec_out, y, DFX_ACT_RELU, nullptr, demb, R, s))) return rc;
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, R, T, E / 4, E / 4, 1, 0, s))) return rc;
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, R, T, E / 4, E / 2, 2, 0, s))) return rc;
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, R, T, E / 2, E, 2, 0, s))) return rc;
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, R, E / 4, E / 4, 1, s))) return rc;
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, R, E / 4, E / 2, 2, s))) return rc;
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, R, E / 2, E, 2, s))) return rc;
     {
         const int fpt = 64 / E > 0 ? 64 / E : 1;
         const size_t smem = ((size_t)fpt * E * (C + 1) + (size_t)fpt * E * 3 + 3 * C) * sizeof(float);
@@ -535,7 +599,16 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         DFX_LAUNCH_CHECK();
         cfeat = xdf;
     }
-    {
+    if (c.df_pathway_kernel_size_t <= 5) {
+        switch (c.df_pathway_kernel_size_t) {
+            case 1: rc = launch_convp2<C, 1>(m, c0, c0p, B, T, Fd, NO, s); break;
+            case 2: rc = launch_convp2<C, 2>(m, c0, c0p, B, T, Fd, NO, s); break;
+            case 3: rc = launch_convp2<C, 3>(m, c0, c0p, B, T, Fd, NO, s); break;
+            case 4: rc = launch_convp2<C, 4>(m, c0, c0p, B, T, Fd, NO, s); break;
+            default: rc = launch_convp2<C, 5>(m, c0, c0p, B, T, Fd, NO, s); break;
+        }
+        if (rc) return rc;
+    } else {
         DfxCpArgs A;
         A.c0 = c0;
         A.w1 = m->p(m->cp_w1);

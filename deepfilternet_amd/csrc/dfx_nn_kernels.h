@@ -11,6 +11,8 @@
 
 #include "dfx_common.h"
 
+#include <type_traits>
+
 #define DFX_ACT_NONE 0
 #define DFX_ACT_RELU 1
 #define DFX_ACT_TANH 2
@@ -24,162 +26,240 @@ static __device__ __forceinline__ float dfx_act(float v, int act) {
     return v;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// enc.erb_conv0: Conv2d(1 -> C, 3x3, causal in time, pad 1 in freq) + BN + ReLU   (deepfilternet3.py:106-108)
-//   feat [B,T,E] -> out [B*T, E, C].  Lookahead L: tap kt of output frame t reads input frame t+L-2+kt, and is zero when
-//   t-2+kt < 0 (causal pad applied AFTER the lookahead shift, deepfilternet3.py:357-361,409) or when the frame is >= T.
-// One thread per output element, channel fastest (coalesced stores; the 9 inputs are wave-broadcast loads).
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ void dfx_k_conv_in_erb(const float *feat, const float *w /*[3][3][C]*/, const float *bias /*[C]*/, float *out,
-                                  int64_t B, int64_t T, int E, int C, int L) {
-    const int64_t total = B * T * E * C;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const int64_t p = i / C;
-        const int f = (int)(p % E);
-        const int64_t r = p / E;
-        const int64_t t = r % T, b = r / T;
-        float acc = bias[c];
-        for (int kt = 0; kt < 3; ++kt) {
-            const int64_t tau = t - 2 + kt, tin = tau + L;
-            if (tau < 0 || tin >= T) continue;
-            const float *row = feat + (b * T + tin) * E;
-            for (int kf = 0; kf < 3; ++kf) {
-                const int fin = f - 1 + kf;
-                if (fin < 0 || fin >= E) continue;
-                acc += w[(kt * 3 + kf) * C + c] * row[fin];
-            }
-        }
-        out[i] = fmaxf(acc, 0.f);
+// compile-time loop (the fully unrolled bodies index register arrays with constants only)
+template <int I, int N, typename F>
+static __device__ __forceinline__ void dfx_static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        dfx_static_for<I + 1, N>(f);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Fused [depthwise / input conv prologue] -> pointwise 1x1 (C x C, MFMA) -> +bias (folded BN) -> ReLU.
+// enc.erb_conv0: Conv2d(1 -> C, 3x3, causal in time, pad 1 in freq) + BN + ReLU   (deepfilternet3.py:106-108)
+//   feat [B,T,E] -> out [B*T, E, C].  Lookahead L: tap kt of output frame t reads input frame t+L-2+kt, and is zero when
+//   t-2+kt < 0 (causal pad applied AFTER the lookahead shift, deepfilternet3.py:357-361,409) or when the frame is >= T.
+// One thread per (position, 4 channels): 16-byte coalesced stores (the kernel is bound by the 4*E*C bytes it writes per
+// frame); a thread keeps its 9x4 weights in registers (its channel quad is fixed across the grid-stride loop); the 9
+// inputs of a position are L1-broadcast loads shared by the C/4 threads of that position.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dfx_k_conv_in_erb(const float *feat, const float *w /*[3][3][C]*/,
+                                                         const float *bias /*[C]*/, float *out, int64_t B, int64_t T, int E,
+                                                         int C, int L) {
+    const int C4 = C >> 2;
+    const int64_t total = B * T * E * C4;
+    const int64_t gid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4 = (int)(gid0 % C4);  // invariant: the grid stride is a multiple of C4 (C4 divides 256)
+    float4 wv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[k] = reinterpret_cast<const float4 *>(w)[k * C4 + c4];
+    const float4 bv = reinterpret_cast<const float4 *>(bias)[c4];
+    for (int64_t i = gid0; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / C4;
+        const int f = (int)(p % E);
+        const int64_t r = p / E;
+        const int64_t t = r % T, b = r / T;
+        float4 acc = bv;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+            const int64_t tau = t - 2 + kt, tin = tau + L;
+            if (tau < 0 || tin >= T) continue;
+            const float *row = feat + (b * T + tin) * E;
+#pragma unroll
+            for (int kf = 0; kf < 3; ++kf) {
+                const int fin = f - 1 + kf;
+                if (fin < 0 || fin >= E) continue;
+                const float x = row[fin];
+                const float4 ww = wv[kt * 3 + kf];
+                acc.x += ww.x * x;
+                acc.y += ww.y * x;
+                acc.z += ww.z * x;
+                acc.w += ww.w * x;
+            }
+        }
+        reinterpret_cast<float4 *>(out)[i] = make_float4(fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused [depthwise 1x3 prologue] -> pointwise 1x1 (C x C, MFMA) -> +bias (folded BN) -> ReLU, entirely in registers.
 // Covers Conv2dNormAct / ConvTranspose2dNormAct with separable=True (modules.py:18-126):
 //   MODE_DW3   depthwise 1x3 conv over freq, stride s in {1,2}, pad 1                     (enc.erb_conv1-3, df_conv1, convt3)
 //   MODE_DWT3  depthwise 1x3 transposed conv, stride 2, padding 1, output_padding 1        (erb_dec.convt2, convt1)
-//   MODE_IN33  3x3 conv (2 -> C, groups=2) over (time, freq) on the complex feature tensor (enc.df_conv0)
 // Optional skip input for the decoder:  xin = relu(sk_a[c]*skip + sk_b[c]) + x   (conv{3,2,1}p pathway + Add,
 // deepfilternet3.py:250-252; convNp is a per-channel scalar + BN + ReLU).
-// Tile: 64 output positions x C channels per iteration; the prologue result is staged in LDS as the MFMA A operand
-// (row stride C+2: conflict-free ds_read_b32 for the 16x16x4 fragment), the C x C weight matrix sits in registers.
+//
+// A wave owns 16 output positions at a time; there is no LDS staging and no workgroup barrier in the loop.  The GEMM is
+// computed transposed, out^T[n][pos] = sum_c W[n][c] * u[c][pos], on v_mfma_f32_16x16x4_f32 with
+//   A = W   (lane l: row n = l&15, the persistent weight fragment, C*C/64 registers)
+//   B = u   (lane l: column pos = l&15, k = l>>4)
+// and the contraction index is enumerated so that k-step ks, k = q (q = l>>4) is channel (C/4)*q + ks: lane (pos, q) then
+// needs exactly the C/4 CONSECUTIVE channels [(C/4)q, (C/4)(q+1)) of its position, which it loads straight from HBM as
+// float4s, runs the 3-tap depthwise conv on in registers and feeds to the matrix core.  D comes back as 4 consecutive
+// output channels per lane -> float4 stores.  Per 16 positions: 3*C/16 float4 loads per lane, (C/4)*(C/16) MFMAs.
 // ---------------------------------------------------------------------------------------------------------------------
 #define DFX_PW_MODE_DW3 0
 #define DFX_PW_MODE_DWT3 1
-#define DFX_PW_MODE_IN33 2
 #define DFX_PW_THREADS 256
-#define DFX_PW_MT 64
 
 struct DfxPwArgs {
-    const float *x;      // [R, Fin, C]  (MODE_IN33: feat [B,T,Fin,2])
+    const float *x;      // [R, Fin, C]
     const float *skip;   // [R, Fin, C] or null
     const float *sk_a, *sk_b;  // [C]
-    const float *dw;     // MODE_DW3/DWT3: [3][C]; MODE_IN33: [9][C]
+    const float *dw;     // [3][C]
     const float *wt;     // [C][C]  wt[k][n] = W_pw[n][k] * bn_scale[n]
     const float *bias;   // [C]
     float *out;          // [R, Fout, C]
-    int64_t R, T;
-    int Fin, Fout, stride, L;
+    int64_t R;
+    int Fin, Fout, stride;
 };
 
-template <int C, int MODE>
+template <int C, int MODE, bool SKIP>
 __global__ void __launch_bounds__(DFX_PW_THREADS) dfx_k_pwconv(DfxPwArgs A) {
-    constexpr int LDA = C + 2;
-    constexpr int NT = C / 16, KS = C / 4;
-    __shared__ float As[DFX_PW_MT * LDA];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // B fragments: breg[nt][ks] = wt[4*ks + (lane>>4)][16*nt + (lane&15)]
-    float breg[NT][KS];
+    constexpr int CPL = C / 4;   // channels per lane == MFMA k-steps
+    constexpr int NT = C / 16;   // 16-wide output channel tiles
+    constexpr int V4 = CPL / 4;  // float4s per lane and tap
+    __shared__ float4 dws[3 * C / 4];
+    __shared__ float4 sks[2 * C / 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
+    for (int i = tid; i < 3 * C / 4; i += DFX_PW_THREADS) dws[i] = reinterpret_cast<const float4 *>(A.dw)[i];
+    if (SKIP)
+        for (int i = tid; i < C / 4; i += DFX_PW_THREADS) {
+            sks[i] = reinterpret_cast<const float4 *>(A.sk_a)[i];
+            sks[C / 4 + i] = reinterpret_cast<const float4 *>(A.sk_b)[i];
+        }
+    float areg[NT][CPL];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) breg[nt][ks] = A.wt[(4 * ks + (lane >> 4)) * C + 16 * nt + (lane & 15)];
-    const int c = tid % C;
-    constexpr int PSTEP = DFX_PW_THREADS / C;
-    const int p0 = tid / C;
-    float wd[MODE == DFX_PW_MODE_IN33 ? 9 : 3];
+        for (int ks = 0; ks < CPL; ++ks) areg[nt][ks] = A.wt[(CPL * q + ks) * C + 16 * nt + jl];
+    float4 biasr[NT];
 #pragma unroll
-    for (int j = 0; j < (MODE == DFX_PW_MODE_IN33 ? 9 : 3); ++j) wd[j] = A.dw[j * C + c];
-    const float ska = A.skip ? A.sk_a[c] : 0.f, skb = A.skip ? A.sk_b[c] : 0.f;
-    float biasr[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) biasr[nt] = A.bias[16 * nt + (lane & 15)];
-
+    for (int nt = 0; nt < NT; ++nt) biasr[nt] = reinterpret_cast<const float4 *>(A.bias)[4 * nt + q];
+    __syncthreads();
     const int64_t total = A.R * A.Fout;
-    const int64_t ntiles = (total + DFX_PW_MT - 1) / DFX_PW_MT;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t pos0 = tile * DFX_PW_MT;
-        // ---- prologue: u[p][c]
-        for (int p = p0; p < DFX_PW_MT; p += PSTEP) {
-            const int64_t pos = pos0 + p;
-            float u = 0.f;
-            if (pos < total) {
-                const int64_t r = pos / A.Fout;
-                const int fo = (int)(pos - r * A.Fout);
-                if (MODE == DFX_PW_MODE_IN33) {
-                    const int64_t t = r % A.T, b = r / A.T;
-                    const int ch = c >= C / 2 ? 1 : 0;  // groups=2: first half of the outputs sees re, second half im
+    const int64_t ntiles = (total + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t pos = tile * 16 + jl;
+        const bool valid = pos < total;
+        const int64_t r = pos / A.Fout;
+        const int fo = (int)(pos - r * A.Fout);
+        float u[CPL];
 #pragma unroll
-                    for (int kt = 0; kt < 3; ++kt) {
-                        const int64_t tau = t - 2 + kt, tin = tau + A.L;
-                        if (tau < 0 || tin >= A.T) continue;
-                        const float *row = A.x + (b * A.T + tin) * A.Fin * 2;
+        for (int i = 0; i < CPL; ++i) u[i] = 0.f;
 #pragma unroll
-                        for (int kf = 0; kf < 3; ++kf) {
-                            const int fin = fo - 1 + kf;
-                            if (fin < 0 || fin >= A.Fin) continue;
-                            u += wd[kt * 3 + kf] * row[fin * 2 + ch];
-                        }
+        for (int j = 0; j < 3; ++j) {
+            int fi;
+            bool ok;
+            if (MODE == DFX_PW_MODE_DW3) {
+                fi = fo * A.stride + j - 1;
+                ok = fi >= 0 && fi < A.Fin;
+            } else {  // transposed: fo = 2*fi - 1 + j
+                const int num = fo + 1 - j;
+                fi = num >> 1;
+                ok = num >= 0 && (num & 1) == 0 && fi < A.Fin;
+            }
+            if (valid && ok) {
+                const int64_t off = (r * A.Fin + fi) * C + CPL * q;
+                const float4 *xp = reinterpret_cast<const float4 *>(A.x + off);
+                const float4 *sp = reinterpret_cast<const float4 *>(A.skip + (SKIP ? off : 0));
+#pragma unroll
+                for (int v = 0; v < V4; ++v) {
+                    float4 xv = xp[v];
+                    if (SKIP) {
+                        const float4 sv = sp[v], a = sks[V4 * q + v], bb = sks[C / 4 + V4 * q + v];
+                        xv.x += fmaxf(a.x * sv.x + bb.x, 0.f);
+                        xv.y += fmaxf(a.y * sv.y + bb.y, 0.f);
+                        xv.z += fmaxf(a.z * sv.z + bb.z, 0.f);
+                        xv.w += fmaxf(a.w * sv.w + bb.w, 0.f);
                     }
-                } else {
-                    const float *xr = A.x + r * A.Fin * C;
-                    const float *sr = A.skip ? A.skip + r * A.Fin * C : nullptr;
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        int fi;
-                        bool ok;
-                        if (MODE == DFX_PW_MODE_DW3) {
-                            fi = fo * A.stride + j - 1;
-                            ok = fi >= 0 && fi < A.Fin;
-                        } else {
-                            // transposed: fo = 2*fi - 1 + j
-                            const int num = fo + 1 - j;
-                            fi = num >> 1;
-                            ok = num >= 0 && (num & 1) == 0 && fi < A.Fin;
-                        }
-                        if (!ok) continue;
-                        float v = xr[fi * C + c];
-                        if (sr) v += fmaxf(ska * sr[fi * C + c] + skb, 0.f);
-                        u += wd[j] * v;
-                    }
+                    const float4 w = dws[j * (C / 4) + V4 * q + v];
+                    u[4 * v + 0] += w.x * xv.x;
+                    u[4 * v + 1] += w.y * xv.y;
+                    u[4 * v + 2] += w.z * xv.z;
+                    u[4 * v + 3] += w.w * xv.w;
                 }
             }
-            As[p * LDA + c] = u;
         }
-        __syncthreads();
-        // ---- pointwise GEMM on the matrix cores: wave w owns positions [16w, 16w+16)
         f32x4 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float *arow = As + (16 * wave + (lane & 15)) * LDA + (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < CPL; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[nt][ks], u[ks], acc[nt], 0, 0, 0);
+        if (valid) {
+            float4 *op = reinterpret_cast<float4 *>(A.out + pos * C + 4 * q);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                op[4 * nt] = make_float4(fmaxf(acc[nt][0] + biasr[nt].x, 0.f), fmaxf(acc[nt][1] + biasr[nt].y, 0.f),
+                                         fmaxf(acc[nt][2] + biasr[nt].z, 0.f), fmaxf(acc[nt][3] + biasr[nt].w, 0.f));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// enc.df_conv0: pad t(2,0) -> Conv2d(2 -> C, 3x3, groups=2) -> Conv2d(C -> C, 1x1) -> BN -> ReLU (deepfilternet3.py:115-117).
+// There is no nonlinearity between the grouped 3x3 conv and the pointwise conv (modules.py:49-71), so the host folds them
+// (and the BN scale) into ONE dense 3x3 conv 2 -> C:  W_eff[n][(kt,kf,ch)] = sum_{c in group ch} W_pw[n][c] * W_dw[c][kt][kf],
+// i.e. a GEMM with K = 18 (padded to 20) instead of K = C.  out^T[n][pos] = sum_k W_eff[n][k] * im2col[k][pos] on the
+// matrix core (same operand roles as dfx_k_pwconv); the B operand is gathered straight from feat_spec [B,T,Fin,2] with
+// the lookahead shift L and the causal/border zeros.  The kernel is bound by its 4*Fin*C-byte-per-frame store.
+// ---------------------------------------------------------------------------------------------------------------------
+struct DfxCinArgs {
+    const float *feat;  // [B, T, Fin, 2]
+    const float *weff;  // [20][C]  weff[k][n], k = (kt*3 + kf)*2 + ch, rows 18..19 zero
+    const float *bias;  // [C]
+    float *out;         // [B*T, Fin, C]
+    int64_t B, T;
+    int Fin, L;
+};
+
+template <int C>
+__global__ void __launch_bounds__(DFX_PW_THREADS) dfx_k_conv_in_df(DfxCinArgs A) {
+    constexpr int NT = C / 16, KS = 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
+    float areg[NT][KS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) areg[nt][ks] = A.weff[(4 * ks + q) * C + 16 * nt + jl];
+    float4 biasr[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) biasr[nt] = reinterpret_cast<const float4 *>(A.bias)[4 * nt + q];
+    const int64_t total = A.B * A.T * A.Fin;
+    const int64_t ntiles = (total + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t pos = tile * 16 + jl;
+        const bool valid = pos < total;
+        const int64_t r = pos / A.Fin;
+        const int fo = (int)(pos - r * A.Fin);
+        const int64_t b = r / A.T, t = r - b * A.T;
+        float bv[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const float a = arow[4 * ks];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[nt][ks], acc[nt], 0, 0, 0);
+            const int k = 4 * ks + q, tap = k >> 1, ch = k & 1, kt = tap / 3, kf = tap - 3 * kt;
+            const int64_t tau = t - 2 + kt, tin = tau + A.L;
+            const int fin = fo - 1 + kf;
+            float v = 0.f;
+            if (valid && k < 18 && tau >= 0 && tin < A.T && fin >= 0 && fin < A.Fin)
+                v = A.feat[((b * A.T + tin) * A.Fin + fin) * 2 + ch];
+            bv[ks] = v;
         }
-        // ---- epilogue: D[row = 4*(lane>>4)+r][col = lane&15]
+        f32x4 acc[NT];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t pos = pos0 + 16 * wave + 4 * (lane >> 4) + r;
-            if (pos < total) {
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    A.out[pos * C + 16 * nt + (lane & 15)] = fmaxf(acc[nt][r] + biasr[nt], 0.f);
-            }
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[nt][ks], bv[ks], acc[nt], 0, 0, 0);
+        if (valid) {
+            float4 *op = reinterpret_cast<float4 *>(A.out + pos * C + 4 * q);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                op[4 * nt] = make_float4(fmaxf(acc[nt][0] + biasr[nt].x, 0.f), fmaxf(acc[nt][1] + biasr[nt].y, 0.f),
+                                         fmaxf(acc[nt][2] + biasr[nt].z, 0.f), fmaxf(acc[nt][3] + biasr[nt].w, 0.f));
         }
-        __syncthreads();
     }
 }
 
@@ -315,6 +395,93 @@ __global__ void __launch_bounds__(DFX_CP_THREADS) dfx_k_df_convp(DfxCpArgs A) {
         float acc = A.bias[n];
         for (int o = 0; o < A.NO; ++o) acc += A.w2[n * A.NO + o] * s1[p * A.NO + o];
         A.out[((b * A.T + t0 + tl) * A.Fd + f0 + f) * A.NO + n] = fmaxf(acc, 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// df_dec.df_convp, sliding-window form (used for kt <= 5).  The grouped (kt,1) conv, the optional 2O x 2O pointwise conv and
+// the BN scale are folded on the host into one dense causal conv  out[pos][n] = relu(b[n] + sum_{k<kt} sum_c W_eff[k][c][n] *
+// c0[t-kt+1+k][f][c])  (no nonlinearity sits between them, modules.py:49-71): a GEMM with K = kt*C, N = 2O padded to 16.
+// A wave owns 16 frequency bins of one clip and walks a segment of frames: the kt-frame window of c0 lives in registers as
+// the MFMA B operand (lane (bin, q) holds channels [(C/4)q, (C/4)(q+1)) of each frame), so every c0 element is read from
+// HBM exactly once (plus kt-1 halo frames per segment), and W_eff is the persistent A fragment (kt*C/4 registers).
+// ---------------------------------------------------------------------------------------------------------------------
+struct DfxCp2Args {
+    const float *c0;    // [B*T, Fd, C]
+    const float *weff;  // [kt][C][16]  weff[(k*C + c)*16 + n], n >= NO zero
+    const float *bias;  // [16]
+    float *out;         // [B*T, Fd, NO]
+    int64_t B, T;
+    int Fd, NO, nfb, nseg, tseg;  // nfb = ceil(Fd/16) bin blocks, nseg segments of tseg frames (tseg % kt == 0)
+};
+
+template <int C, int KT>
+__global__ void __launch_bounds__(256) dfx_k_df_convp2(DfxCp2Args A) {
+    constexpr int CPL = C / 4, V4 = CPL / 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
+    float areg[KT][CPL];
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+        for (int ks = 0; ks < CPL; ++ks) areg[k][ks] = A.weff[((size_t)(k * C + CPL * q + ks)) * 16 + jl];
+    float biasr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) biasr[r] = A.bias[4 * q + r];
+    const int64_t nruns = A.B * A.nfb * A.nseg;
+    for (int64_t run = (int64_t)blockIdx.x * 4 + wave; run < nruns; run += (int64_t)gridDim.x * 4) {
+        const int seg = (int)(run % A.nseg);
+        const int64_t rest = run / A.nseg;
+        const int fb = (int)(rest % A.nfb);
+        const int64_t b = rest / A.nfb;
+        const int f = fb * 16 + jl;
+        const bool fvalid = f < A.Fd;
+        const int64_t t0 = (int64_t)seg * A.tseg;
+        const int64_t t1 = (t0 + A.tseg < A.T) ? t0 + A.tseg : A.T;
+        float win[KT][CPL];
+        auto load_frame = [&](float *dst, int64_t tau) {
+            if (fvalid && tau >= 0) {
+                const float4 *p = reinterpret_cast<const float4 *>(A.c0 + ((b * A.T + tau) * A.Fd + f) * C + CPL * q);
+#pragma unroll
+                for (int v = 0; v < V4; ++v) {
+                    const float4 x = p[v];
+                    dst[4 * v + 0] = x.x;
+                    dst[4 * v + 1] = x.y;
+                    dst[4 * v + 2] = x.z;
+                    dst[4 * v + 3] = x.w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) dst[i] = 0.f;
+            }
+        };
+        // frame tau lives in slot (tau - t0) mod KT; preload the kt-1 frames before the segment
+        dfx_static_for<1, KT>([&](auto sc) {
+            constexpr int sl = decltype(sc)::value;
+            load_frame(win[sl], t0 - KT + sl);
+        });
+        for (int64_t tb = t0; tb < t1; tb += KT) {
+            dfx_static_for<0, KT>([&](auto pc) {
+                constexpr int ph = decltype(pc)::value;
+                const int64_t t = tb + ph;
+                if (t < t1) {  // wave-uniform
+                    load_frame(win[ph], t);
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                    dfx_static_for<0, KT>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        constexpr int sl = (ph + 1 + k) % KT;  // tap k reads frame t - (KT-1) + k
+#pragma unroll
+                        for (int ks = 0; ks < CPL; ++ks)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[k][ks], win[sl][ks], acc, 0, 0, 0);
+                    });
+                    if (fvalid) {
+                        float *op = A.out + ((b * A.T + t) * A.Fd + f) * A.NO + 4 * q;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (4 * q + r < A.NO) op[r] = fmaxf(acc[r] + biasr[r], 0.f);
+                    }
+                }
+            });
+        }
     }
 }
 
