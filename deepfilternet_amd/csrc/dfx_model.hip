@@ -93,6 +93,10 @@ struct dfx_model {
     size_t cp_weff = 0, cp_b16 = 0;          // df_convp, folded sliding-window form (kt <= 5)
     size_t cin_weff = 0, cin_b = 0;          // enc.df_conv0 folded into a dense 3x3 conv 2 -> C
     int cp_G = 0, cp_NO = 0;
+    // intra-forward concurrency: two auxiliary streams + fork/join events (created once; one forward at a time per handle)
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool concurrent = false;
     const float *p(size_t off) const { return d_w + off; }
 };
 
@@ -334,12 +338,29 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         dfx_model_free(m);
         DFX_FAIL(DFX_ERR_HIP, "dfx_model_create: upload failed");
     }
+    {   // independent branches of the forward pass run on two auxiliary streams (DFX_STREAMS=0 keeps everything serial)
+        const char *e = getenv("DFX_STREAMS");
+        m->concurrent = !(e && e[0] == '0');
+        if (m->concurrent) {
+            bool good = true;
+            for (int i = 0; i < 2; ++i) good = good && hipStreamCreateWithFlags(&m->aux[i], hipStreamNonBlocking) == hipSuccess;
+            for (int i = 0; i < 8; ++i) good = good && hipEventCreateWithFlags(&m->ev[i], hipEventDisableTiming) == hipSuccess;
+            if (!good) {
+                dfx_model_free(m);
+                DFX_FAIL(DFX_ERR_HIP, "dfx_model_create: could not create the auxiliary streams/events");
+            }
+        }
+    }
     *out = m;
     return DFX_OK;
 }
 
 extern "C" void dfx_model_free(dfx_model *m) {
     if (!m) return;
+    for (int i = 0; i < 2; ++i)
+        if (m->aux[i]) (void)hipStreamDestroy(m->aux[i]);
+    for (int i = 0; i < 8; ++i)
+        if (m->ev[i]) (void)hipEventDestroy(m->ev[i]);
     if (m->d_w) (void)hipFree(m->d_w);
     delete m;
 }
@@ -353,7 +374,7 @@ extern "C" int dfx_model_cfg_get(const dfx_model *m, dfx_model_cfg *out) {
 namespace {
 struct Ws {
     // offsets in floats, each 64-float (256 B) aligned
-    size_t e0, e1, e2, e3, c0, c1, emb_in, emb, xa, xb, gi, demb, d3, d2, d1, mask, c0p, xdf, coefs, lsnr, total;
+    size_t e0, e1, e2, e3, c0, c1, emb_in, emb, xa, xb, gi, xa2, xb2, gi2, demb, d3, d2, d1, mask, c0p, xdf, coefs, lsnr, total;
 };
 Ws plan_ws(const dfx_model_cfg &c, int64_t R) {
     Ws w{};
@@ -375,6 +396,9 @@ Ws plan_ws(const dfx_model_cfg &c, int64_t R) {
     w.xa = take(R * 256);
     w.xb = take(R * 256);
     w.gi = take(R * 768);
+    w.xa2 = take(R * 256);  // the DF decoder's GRU stack runs concurrently with the ERB decoder's
+    w.xb2 = take(R * 256);
+    w.gi2 = take(R * 768);
     w.demb = take(R * emb);
     w.d3 = take(R * (E / 4) * C);
     w.d2 = take(R * (E / 2) * C);
@@ -529,18 +553,25 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     float *c0p = ws + w.c0p, *xdf = ws + w.xdf;
     float *coefs = coefs_out ? coefs_out : ws + w.coefs;
     float *lsnr = lsnr_out ? lsnr_out : ws + w.lsnr;
+    float *xa2 = ws + w.xa2, *xb2 = ws + w.xb2, *gi2 = ws + w.gi2;
     int rc;
-    // ---- Encoder (deepfilternet3.py:166-185)
-    {
-        const int64_t total = R * E * (C / 4);
-        DfxKScope ks(DFX_K_CONV_IN_ERB, s);
-        dfx_launch(dfx_k_conv_in_erb, dim3((unsigned)nn_grid(dfx_ceil_div(total, 256), 16)), dim3(256), 0, s, feat_erb,
-                   m->p(m->erb0_w), m->p(m->erb0_b), e0, B, T, E, C, L);
-        DFX_LAUNCH_CHECK();
-    }
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb1, e0, nullptr, e1, R, E, E / 2, 2, s))) return rc;
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb2, e1, nullptr, e2, R, E / 2, E / 4, 2, s))) return rc;
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb3, e2, nullptr, e3, R, E / 4, E / 4, 1, s))) return rc;
+    // Stream plan (s = caller's stream, x1/x2 = auxiliary; all joins are events, the host never blocks):
+    //   s : e0..e3 ----------------(join c1)-- fc_emb, enc GRU, emb, lsnr --+-- ERB decoder: GRU stack, convt3..conv0_out --(join coefs)-- df_apply
+    //   x1: c0 -+- c1 ------------------------------------------------------+-- DF decoder: GRU stack, skip, (join c0p) df_out -> coefs
+    //   x2:     +- df_convp -> c0p
+    const bool par = m->concurrent;
+    hipStream_t x1 = par ? m->aux[0] : s, x2 = par ? m->aux[1] : s;
+    auto signal = [&](int e, hipStream_t from) -> int {
+        if (par) DFX_HIP(hipEventRecord(m->ev[e], from));
+        return DFX_OK;
+    };
+    auto wait = [&](int e, hipStream_t on) -> int {
+        if (par) DFX_HIP(hipStreamWaitEvent(on, m->ev[e], 0));
+        return DFX_OK;
+    };
+    enum { EV_START = 0, EV_C0, EV_C1, EV_C0P, EV_EMB, EV_COEFS };
+    if ((rc = signal(EV_START, s)) || (rc = wait(EV_START, x1))) return rc;
+    // ---- Encoder, DF branch on x1 (deepfilternet3.py:176-179)
     {
         DfxCinArgs A;
         A.feat = feat_spec;
@@ -551,61 +582,21 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         A.T = T;
         A.Fin = Fd;
         A.L = L;
-        DfxKScope ks(DFX_K_CONV_IN_DF, s);
-        dfx_launch(dfx_k_conv_in_df<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R * Fd, 64), 8)), dim3(DFX_PW_THREADS), 0, s, A);
+        DfxKScope ks(DFX_K_CONV_IN_DF, x1);
+        dfx_launch(dfx_k_conv_in_df<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R * Fd, 64), 8)), dim3(DFX_PW_THREADS), 0, x1, A);
         DFX_LAUNCH_CHECK();
     }
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->dfc1, c0, nullptr, c1, R, Fd, Fd / 2, 2, s))) return rc;
-    // cemb = relu(df_fc_emb(c1.flatten)); emb_in = e3.flatten + cemb   (:179-182)
-    if ((rc = launch_glin(m, m->fc_emb, c1, DFX_ACT_RELU, e3, emb_in, R, s))) return rc;
-    // enc.emb_gru (SqueezedGRU_S :149-158)
-    if ((rc = launch_glin(m, m->enc_in, emb_in, DFX_ACT_RELU, nullptr, xa, R, s))) return rc;
-    const float *y = nullptr;
-    if ((rc = run_gru_stack(m, m->enc_gru, xa, xa, xb, gi, B, T, &y, s))) return rc;
-    if ((rc = launch_glin(m, m->enc_out, y, DFX_ACT_RELU, nullptr, embv, R, s))) return rc;
-    {
-        DfxKScope ks(DFX_K_LSNR, s);
-        dfx_launch(dfx_k_lsnr, dim3((unsigned)dfx_ceil_div(R * 64, 256)), dim3(256), 0, s, (const float *)embv, m->p(m->lsnr_w),
-                   m->lsnr_b, (float)(c.lsnr_max - c.lsnr_min), (float)c.lsnr_min, lsnr, R, emb);
-    }
-    DFX_LAUNCH_CHECK();
-    // ---- ErbDecoder (:245-254)
-    if ((rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, xa, R, s))) return rc;
-    if ((rc = run_gru_stack(m, m->dec_gru, xa, xa, xb, gi, B, T, &y, s))) return rc;
-    if ((rc = launch_glin(m, m->dec_out, y, DFX_ACT_RELU, nullptr, demb, R, s))) return rc;
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, R, E / 4, E / 4, 1, s))) return rc;
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, R, E / 4, E / 2, 2, s))) return rc;
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, R, E / 2, E, 2, s))) return rc;
-    {
-        const int fpt = 64 / E > 0 ? 64 / E : 1;
-        const size_t smem = ((size_t)fpt * E * (C + 1) + (size_t)fpt * E * 3 + 3 * C) * sizeof(float);
-        DfxKScope ks(DFX_K_CONV_OUT, s);
-        dfx_launch(dfx_k_conv_out<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R, fpt), 8)), dim3(DFX_CO_THREADS), smem, s,
-                   (const float *)d1, (const float *)e0, m->p(m->co_ska), m->p(m->co_skb), m->p(m->co_w), m->co_bias, mask,
-                   R, E, fpt);
-        DFX_LAUNCH_CHECK();
-    }
-    // ---- DfDecoder (:323-331)
-    if ((rc = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa, R, s))) return rc;
-    if ((rc = run_gru_stack(m, m->df_gru, xa, xa, xb, gi, B, T, &y, s))) return rc;
-    const float *cfeat = y;
-    if (c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) {
-        if ((rc = launch_glin(m, m->df_skip, embv, DFX_ACT_NONE, y, xdf, R, s))) return rc;
-        cfeat = xdf;
-    } else if (c.df_gru_skip == DFX_SKIP_IDENTITY) {
-        DfxKScope ks(DFX_K_ADD, s);
-        dfx_launch(dfx_k_add, dim3((unsigned)nn_grid(dfx_ceil_div(R * 256, 256), 16)), dim3(256), 0, s, y, (const float *)embv,
-                   xdf, R * 256);
-        DFX_LAUNCH_CHECK();
-        cfeat = xdf;
-    }
+    if ((rc = signal(EV_C0, x1)) || (rc = wait(EV_C0, x2))) return rc;
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->dfc1, c0, nullptr, c1, R, Fd, Fd / 2, 2, x1))) return rc;
+    if ((rc = signal(EV_C1, x1))) return rc;
+    // ---- df_dec.df_convp on x2 (only needs c0; :328)
     if (c.df_pathway_kernel_size_t <= 5) {
         switch (c.df_pathway_kernel_size_t) {
-            case 1: rc = launch_convp2<C, 1>(m, c0, c0p, B, T, Fd, NO, s); break;
-            case 2: rc = launch_convp2<C, 2>(m, c0, c0p, B, T, Fd, NO, s); break;
-            case 3: rc = launch_convp2<C, 3>(m, c0, c0p, B, T, Fd, NO, s); break;
-            case 4: rc = launch_convp2<C, 4>(m, c0, c0p, B, T, Fd, NO, s); break;
-            default: rc = launch_convp2<C, 5>(m, c0, c0p, B, T, Fd, NO, s); break;
+            case 1: rc = launch_convp2<C, 1>(m, c0, c0p, B, T, Fd, NO, x2); break;
+            case 2: rc = launch_convp2<C, 2>(m, c0, c0p, B, T, Fd, NO, x2); break;
+            case 3: rc = launch_convp2<C, 3>(m, c0, c0p, B, T, Fd, NO, x2); break;
+            case 4: rc = launch_convp2<C, 4>(m, c0, c0p, B, T, Fd, NO, x2); break;
+            default: rc = launch_convp2<C, 5>(m, c0, c0p, B, T, Fd, NO, x2); break;
         }
         if (rc) return rc;
     } else {
@@ -629,12 +620,75 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_df_convp<C>, smem));
         const int64_t nblk = B * A.tchunks * A.fchunks;
         if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "df_convp grid too large");
-        DfxKScope ks(DFX_K_DF_CONVP, s);
-        dfx_launch(dfx_k_df_convp<C>, dim3((unsigned)nblk), dim3(DFX_CP_THREADS), smem, s, A);
+        DfxKScope ks(DFX_K_DF_CONVP, x2);
+        dfx_launch(dfx_k_df_convp<C>, dim3((unsigned)nblk), dim3(DFX_CP_THREADS), smem, x2, A);
         DFX_LAUNCH_CHECK();
     }
-    // c = tanh(df_out(c)).view(b,t,F',2O) + c0p   (:329-330); flat index f*2O + 2n + {re,im} == [B,T,F',O][2]
-    if ((rc = launch_glin(m, m->df_out, cfeat, DFX_ACT_TANH, c0p, coefs, R, s))) return rc;
+    if ((rc = signal(EV_C0P, x2))) return rc;
+    // ---- Encoder, ERB branch on s (:168-171)
+    {
+        const int64_t total = R * E * (C / 4);
+        DfxKScope ks(DFX_K_CONV_IN_ERB, s);
+        dfx_launch(dfx_k_conv_in_erb, dim3((unsigned)nn_grid(dfx_ceil_div(total, 256), 16)), dim3(256), 0, s, feat_erb,
+                   m->p(m->erb0_w), m->p(m->erb0_b), e0, B, T, E, C, L);
+        DFX_LAUNCH_CHECK();
+    }
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb1, e0, nullptr, e1, R, E, E / 2, 2, s))) return rc;
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb2, e1, nullptr, e2, R, E / 2, E / 4, 2, s))) return rc;
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb3, e2, nullptr, e3, R, E / 4, E / 4, 1, s))) return rc;
+    if ((rc = wait(EV_C1, s))) return rc;
+    // cemb = relu(df_fc_emb(c1.flatten)); emb_in = e3.flatten + cemb   (:179-182)
+    if ((rc = launch_glin(m, m->fc_emb, c1, DFX_ACT_RELU, e3, emb_in, R, s))) return rc;
+    // enc.emb_gru (SqueezedGRU_S :149-158)
+    if ((rc = launch_glin(m, m->enc_in, emb_in, DFX_ACT_RELU, nullptr, xa, R, s))) return rc;
+    const float *y = nullptr;
+    if ((rc = run_gru_stack(m, m->enc_gru, xa, xa, xb, gi, B, T, &y, s))) return rc;
+    if ((rc = launch_glin(m, m->enc_out, y, DFX_ACT_RELU, nullptr, embv, R, s))) return rc;
+    if ((rc = signal(EV_EMB, s)) || (rc = wait(EV_EMB, x1))) return rc;
+    {
+        DfxKScope ks(DFX_K_LSNR, s);
+        dfx_launch(dfx_k_lsnr, dim3((unsigned)dfx_ceil_div(R * 64, 256)), dim3(256), 0, s, (const float *)embv, m->p(m->lsnr_w),
+                   m->lsnr_b, (float)(c.lsnr_max - c.lsnr_min), (float)c.lsnr_min, lsnr, R, emb);
+    }
+    DFX_LAUNCH_CHECK();
+    // ---- DfDecoder on x1 (:323-331)
+    {
+        const float *y2 = nullptr;
+        if ((rc = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, R, x1))) return rc;
+        if ((rc = run_gru_stack(m, m->df_gru, xa2, xa2, xb2, gi2, B, T, &y2, x1))) return rc;
+        const float *cfeat = y2;
+        if (c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) {
+            if ((rc = launch_glin(m, m->df_skip, embv, DFX_ACT_NONE, y2, xdf, R, x1))) return rc;
+            cfeat = xdf;
+        } else if (c.df_gru_skip == DFX_SKIP_IDENTITY) {
+            DfxKScope ks(DFX_K_ADD, x1);
+            dfx_launch(dfx_k_add, dim3((unsigned)nn_grid(dfx_ceil_div(R * 256, 256), 16)), dim3(256), 0, x1, y2, (const float *)embv,
+                       xdf, R * 256);
+            DFX_LAUNCH_CHECK();
+            cfeat = xdf;
+        }
+        if ((rc = wait(EV_C0P, x1))) return rc;
+        // c = tanh(df_out(c)).view(b,t,F',2O) + c0p   (:329-330); flat index f*2O + 2n + {re,im} == [B,T,F',O][2]
+        if ((rc = launch_glin(m, m->df_out, cfeat, DFX_ACT_TANH, c0p, coefs, R, x1))) return rc;
+        if ((rc = signal(EV_COEFS, x1))) return rc;
+    }
+    // ---- ErbDecoder on s (:245-254)
+    if ((rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, xa, R, s))) return rc;
+    if ((rc = run_gru_stack(m, m->dec_gru, xa, xa, xb, gi, B, T, &y, s))) return rc;
+    if ((rc = launch_glin(m, m->dec_out, y, DFX_ACT_RELU, nullptr, demb, R, s))) return rc;
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, R, E / 4, E / 4, 1, s))) return rc;
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, R, E / 4, E / 2, 2, s))) return rc;
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, R, E / 2, E, 2, s))) return rc;
+    {
+        const int fpt = 64 / E > 0 ? 64 / E : 1;
+        const size_t smem = ((size_t)fpt * E * (C + 1) + (size_t)fpt * E * 3 + 3 * C) * sizeof(float);
+        DfxKScope ks(DFX_K_CONV_OUT, s);
+        dfx_launch(dfx_k_conv_out<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R, fpt), 8)), dim3(DFX_CO_THREADS), smem, s,
+                   (const float *)d1, (const float *)e0, m->p(m->co_ska), m->p(m->co_skb), m->p(m->co_w), m->co_bias, mask,
+                   R, E, fpt);
+        DFX_LAUNCH_CHECK();
+    }
+    if ((rc = wait(EV_COEFS, s))) return rc;
     // ---- Mask + MF.DF + combine + post filter + atten_lim (:426-454, enhance.py:238-240)
     return dfx_launch_df_apply(spec, coefs, DFX_COEF_BTFO, mask, bands, B, T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead,
                                c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, s);

@@ -100,6 +100,18 @@ static inline hipError_t hipEventCreate(hipEvent_t *e) {
     return hipSuccess;
 }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+#define hipEventDisableTiming 2
+#define hipStreamNonBlocking 1
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) {
+    *e = nullptr;
+    return hipSuccess;
+}
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) {
+    *s = nullptr;
+    return hipSuccess;
+}
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) {
