@@ -473,19 +473,23 @@ int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, 
     A.order = order;
     A.lookahead = lookahead;
     A.nb = (gains && bands) ? bands->nb : 0;
-    A.layout = coef_layout;
+    if (!(gains && bands)) A.gains = nullptr;
+    const int64_t nd = nb_df, O = order;
+    if (coef_layout == DFX_COEF_BOTF) {         // [B,O,T,nd]
+        A.cs_b = O * T * nd, A.cs_n = T * nd, A.cs_t = nd, A.cs_f = 1;
+    } else if (coef_layout == DFX_COEF_BTFO) {  // [B,T,nd,O]
+        A.cs_b = T * nd * O, A.cs_t = nd * O, A.cs_f = O, A.cs_n = 1;
+    } else {                                    // DFX_COEF_BTOF [B,T,O,nd]
+        A.cs_b = T * O * nd, A.cs_t = O * nd, A.cs_n = nd, A.cs_f = 1;
+    }
     A.pf_beta = pf_beta;
     A.atten_lim = atten_lim;
-    A.chunks = (int)dfx_ceil_div(T, DFX_DFA_TT);
-    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
-    const size_t smem = al((size_t)(DFX_DFA_TT + order - 1) * nb_df * 8) + al((size_t)DFX_DFA_TT * nb_df * order * 8) +
-                        al((size_t)DFX_DFA_TT * nb_df * 8) + al((size_t)DFX_DFA_TT * (A.nb > 0 ? A.nb : 1) * 4) + al((size_t)F);
-    if (smem > 160 * 1024) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_df_apply: nb_df*order too large for LDS staging (%zu B)", smem);
-    if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_df_apply, smem));
-    const int64_t nblk = B * A.chunks;
+    A.chunks = (int)dfx_ceil_div(T, DFX_DFA_ROWS);
+    if (T * (int64_t)F > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_df_apply: T*F exceeds 2^31 elements per clip");
+    const int64_t nblk = dfx_ceil_div(B, 8) * 8 * A.chunks;
     if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_df_apply: batch too large for one launch");
     DfxKScope ks(DFX_K_DF_APPLY, s);
-    dfx_launch(dfx_k_df_apply, dim3((unsigned)nblk), dim3(DFX_DFA_THREADS), smem, s, A);
+    dfx_launch(dfx_k_df_apply, dim3((unsigned)nblk), dim3(DFX_DFA_THREADS), 0, s, A);
     DFX_LAUNCH_CHECK();
     return DFX_OK;
 }
@@ -495,16 +499,16 @@ extern "C" int dfx_df_apply(const float *spec, const float *coefs, int coef_layo
                             float pf_beta, float atten_lim, float *out, void *stream) {
     if (B < 0 || T < 0 || F <= 0 || nb_df <= 0 || nb_df > F || order <= 0 || lookahead < 0 || lookahead >= order)
         DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply: bad sizes (need 0 <= lookahead < order, 0 < nb_df <= F)");
-    if (coef_layout != DFX_COEF_BOTF && coef_layout != DFX_COEF_BTFO) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply: bad coef_layout");
-    if (nb_df & 1) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_df_apply: nb_df must be even (16-byte coefficient rows)");
+    if (coef_layout != DFX_COEF_BOTF && coef_layout != DFX_COEF_BTFO && coef_layout != DFX_COEF_BTOF)
+        DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply: bad coef_layout");
     if (gains && (!bands || bands->F != F)) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply: gains need a band table covering F bins");
     if (atten_lim < 0.f || atten_lim >= 1.f) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply: atten_lim must be in [0,1)");
     if (int rc = dfx_require_device()) return rc;
     if (B == 0 || T == 0) return DFX_OK;
     if (!spec || !coefs || !out) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply: null buffer");
     if (spec == out) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply: out must not alias spec");
-    if (((uintptr_t)spec & 15) || ((uintptr_t)out & 15) || ((uintptr_t)coefs & 15))
-        DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply: spec, coefs and out must be 16-byte aligned");
+    if (((uintptr_t)spec & 15) || ((uintptr_t)out & 15) || ((uintptr_t)coefs & 7))
+        DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply: spec and out must be 16-byte aligned, coefs 8-byte aligned");
     return dfx_launch_df_apply(spec, coefs, coef_layout, gains, bands, B, T, F, nb_df, order, lookahead, pf_beta,
                                atten_lim, out, dfx_stream(stream));
 }

@@ -430,26 +430,30 @@ __global__ void dfx_k_norm_scan(const float *erb_in, float *erb_out, int E, cons
 // >= 70 % HBM roofline target.  Algorithmic traffic per frame (O taps, nb_df bins, F bins, E bands):
 //   read X  F*8, read coefs nb_df*O*8, read gains E*4, write Y F*8   (11 664 B for O=5, nb_df=96, F=481, E=32).
 //
-// A workgroup owns DFX_DFA_TT consecutive frames of one row.
-//   phase 0  stage into LDS: low bins of the TT+O-1 frames the taps touch (8-byte coalesced, rows are only 8-byte
-//            aligned because F is odd), the chunk's coefficients (16-byte coalesced), gains, bin->band map
-//   phase A  thread (t,f<nb_df): complex MAC over the taps out of LDS -> ylow[t][f] in LDS
-//   phase B  the chunk's [TT*F] complex outputs are walked as one flat, 16-byte aligned float4 stream (2 bins per lane):
-//            low bins come from ylow, high bins are X*gain with X read by the same float4 stream.
+// Pure streaming design, no LDS, no barrier: a workgroup owns DFX_DFA_ROWS consecutive frames of one clip and walks
+// their [rows*F] complex values as ONE flat 16-byte stream (F is odd, so frame rows are only 8-byte aligned: the flat view
+// keeps every global access of the dominant streams a coalesced float4; at most one element is peeled at each end).
+//   lane i: float4 = bins (f, f+1) of a frame (or the last bin of one frame and the first of the next)
+//     f >= nb_df : y = x * gain[band(f)]                    (Mask, modules.py:266-269 == lib.rs:314-326)
+//     f <  nb_df : y = sum_n C[n][f] * X[t+n-(O-1-la)][f]   (MF.DF, multiframe.py:126-136,169-180) with the taps and the
+//                  coefficients loaded directly (8-byte loads; with the tap-major layouts consecutive lanes read consecutive
+//                  coefficients, and the tap rows of X are L2 hits: the clip -> XCD mapping keeps a clip on one L2)
+// The coefficient layout is described by four strides (complex elements): BOTF, BTFO and the engine's own BTOF.
 // ---------------------------------------------------------------------------------------------------------------------
-#define DFX_DFA_TT 8
+#define DFX_DFA_ROWS 16
 #define DFX_DFA_THREADS 256
 
 struct DfxDfaArgs {
     const float2 *spec;   // [B,T,F]
-    const float2 *coefs;  // layout 0: [B,O,T,nbdf]  layout 1: [B,T,nbdf,O]
+    const float2 *coefs;  // element (b,t,n,f) at b*cs_b + t*cs_t + n*cs_n + f*cs_f
     const float *gains;   // [B,T,nb] or null
     const unsigned char *bin2band;  // [F]
     float2 *out;          // [B,T,F]
     int64_t B, T;
-    int F, nbdf, order, lookahead, nb, layout;
+    int64_t cs_b, cs_t, cs_n, cs_f;
+    int F, nbdf, order, lookahead, nb;
     float pf_beta, atten_lim;
-    int chunks;           // chunks per row
+    int chunks;           // row chunks per clip
 };
 
 static __device__ __forceinline__ float2 dfx_dfa_finish(float2 y, float2 x, float pf_beta, float lim) {
@@ -472,116 +476,75 @@ static __device__ __forceinline__ float2 dfx_dfa_finish(float2 y, float2 x, floa
     return y;
 }
 
-__global__ void __launch_bounds__(DFX_DFA_THREADS) dfx_k_df_apply(DfxDfaArgs A) {
-    DFX_DYN_SMEM(unsigned char, smem);
-    const int TT = DFX_DFA_TT, O = A.order, nd = A.nbdf, F = A.F;
-    const int halo = TT + O - 1;
-    // LDS carve (all offsets multiples of 16 bytes)
-    float2 *xs = reinterpret_cast<float2 *>(smem);                    // [halo][nd]
-    size_t off = ((size_t)halo * nd * 8 + 15) & ~(size_t)15;
-    float2 *cs = reinterpret_cast<float2 *>(smem + off);              // [TT*nd*O]
-    off += ((size_t)TT * nd * O * 8 + 15) & ~(size_t)15;
-    float2 *ylow = reinterpret_cast<float2 *>(smem + off);            // [TT][nd]
-    off += ((size_t)TT * nd * 8 + 15) & ~(size_t)15;
-    float *gs = reinterpret_cast<float *>(smem + off);                // [TT][nb]
-    off += ((size_t)TT * (A.nb > 0 ? A.nb : 1) * 4 + 15) & ~(size_t)15;
-    unsigned char *b2b = smem + off;                                  // [F]
-
-    const int64_t b = blockIdx.x / A.chunks;
-    const int chunk = (int)(blockIdx.x - b * A.chunks);
-    const int64_t t0 = (int64_t)chunk * TT;
-    const int nt = (int)((A.T - t0) < TT ? (A.T - t0) : TT);          // frames in this chunk
-    const int tid = threadIdx.x;
-    const int toff = O - 1 - A.lookahead;                             // tap n reads frame t + n - toff
-
-    // ---- phase 0: stage
-    for (int i = tid; i < halo * nd; i += DFX_DFA_THREADS) {
-        const int h = i / nd, f = i - h * nd;
-        const int64_t tt = t0 - toff + h;
-        float2 v = make_float2(0.f, 0.f);
-        if (tt >= 0 && tt < A.T) v = A.spec[(b * A.T + tt) * F + f];
-        xs[i] = v;
-    }
-    if (A.layout == DFX_COEF_BTFO) {
-        // contiguous [nt*nd*O] complex, 16-byte aligned when nd*O is even (checked on the host) -> float4 copies
-        const float4 *src = reinterpret_cast<const float4 *>(A.coefs + (b * A.T + t0) * nd * O);
-        float4 *dst = reinterpret_cast<float4 *>(cs);
-        const int n4 = nt * nd * O / 2;
-        for (int i = tid; i < n4; i += DFX_DFA_THREADS) dst[i] = src[i];
-    } else {
-        // per tap rows of nd complex: cs[(n*TT + t)*nd + f]
-        const int row4 = nd / 2;
-        for (int i = tid; i < O * nt * row4; i += DFX_DFA_THREADS) {
-            const int n = i / (nt * row4), r = i - n * (nt * row4);
-            const int t = r / row4, f4 = r - t * row4;
-            const float4 *src = reinterpret_cast<const float4 *>(A.coefs + ((b * O + n) * A.T + t0 + t) * nd);
-            reinterpret_cast<float4 *>(cs + ((size_t)n * TT + t) * nd)[f4] = src[f4];
-        }
-    }
-    if (A.gains)
-        for (int i = tid; i < nt * A.nb; i += DFX_DFA_THREADS) gs[i] = A.gains[(b * A.T + t0) * A.nb + i];
-    for (int i = tid; i < F; i += DFX_DFA_THREADS) b2b[i] = A.gains ? A.bin2band[i] : 0;
-    __syncthreads();
-
-    // ---- phase A: deep filter on the low bins (multiframe.py:126-136,169-180)
-    for (int i = tid; i < nt * nd; i += DFX_DFA_THREADS) {
-        const int t = i / nd, f = i - t * nd;
+// one output bin: frame t (row index inside the clip), bin f, x = spec[b,t,f]
+static __device__ __forceinline__ float2 dfx_dfa_bin(const DfxDfaArgs &A, const float2 *spec_b, const float2 *coef_b,
+                                                     const float *gains_b, int t, int f, float2 x) {
+    float2 y;
+    if (f < A.nbdf) {
         float re = 0.f, im = 0.f;
-        for (int n = 0; n < O; ++n) {
-            const float2 c = (A.layout == DFX_COEF_BTFO) ? cs[((size_t)t * nd + f) * O + n] : cs[((size_t)n * TT + t) * nd + f];
-            const float2 x = xs[(t + n) * nd + f];
-            re += x.x * c.x - x.y * c.y;
-            im += x.x * c.y + x.y * c.x;
+        const int toff = A.order - 1 - A.lookahead;  // tap n reads frame t + n - toff
+        const float2 *cp = coef_b + (int64_t)t * A.cs_t + (int64_t)f * A.cs_f;
+        for (int n = 0; n < A.order; ++n) {
+            const int tt = t + n - toff;
+            if (tt >= 0 && tt < A.T) {
+                const float2 c = cp[(int64_t)n * A.cs_n];
+                const float2 xx = spec_b[(int64_t)tt * A.F + f];
+                re += xx.x * c.x - xx.y * c.y;
+                im += xx.x * c.y + xx.y * c.x;
+            }
         }
-        ylow[i] = make_float2(re, im);
+        y = make_float2(re, im);
+    } else if (gains_b) {
+        const float g = gains_b[(int64_t)t * A.nb + A.bin2band[f]];
+        y = make_float2(x.x * g, x.y * g);
+    } else {
+        y = x;
     }
-    __syncthreads();
+    return dfx_dfa_finish(y, x, A.pf_beta, A.atten_lim);
+}
 
-    // ---- phase B: flat float4 stream over this chunk's [nt*F] outputs
-    const int64_t e0 = (b * A.T + t0) * F;        // first complex element of the chunk
-    const int64_t e1 = e0 + (int64_t)nt * F;
-    const int64_t a0 = (e0 + 1) & ~(int64_t)1;    // first 16-byte aligned element (base pointers are 16-byte aligned)
-    const int64_t a1 = e1 & ~(int64_t)1;
-    // peel: at most one element at each end
+__global__ void __launch_bounds__(DFX_DFA_THREADS) dfx_k_df_apply(DfxDfaArgs A) {
+    // blocks that share blockIdx.x % 8 (one XCD, one L2) work on the same clips: the tap rows re-read by the deep filter
+    // were streamed through that L2 by a neighbouring block a moment ago (placement is a speed hint only)
+    const int64_t id = blockIdx.x;
+    const int xcd = (int)(id & 7);
+    const int64_t j = id >> 3;
+    const int chunk = (int)(j % A.chunks);
+    const int64_t b = (j / A.chunks) * 8 + xcd;
+    if (b >= A.B) return;
+    const int F = A.F;
+    const int t0 = chunk * DFX_DFA_ROWS;
+    const int nt = (A.T - t0) < DFX_DFA_ROWS ? (int)(A.T - t0) : DFX_DFA_ROWS;
+    const float2 *spec_b = A.spec + b * A.T * F;
+    float2 *out_b = A.out + b * A.T * F;
+    const float2 *coef_b = A.coefs + b * A.cs_b;
+    const float *gains_b = A.gains ? A.gains + b * A.T * A.nb : nullptr;
+    const int tid = threadIdx.x;
+    // element range of this chunk inside the clip, and its 16-byte aligned interior (absolute parity decides)
+    const int e0 = t0 * F, e1 = e0 + nt * F;
+    const int par = (int)((b * A.T * F) & 1);           // parity of the clip's first element in the whole array
+    const int a0 = e0 + ((e0 + par) & 1), a1 = e1 - ((e1 + par) & 1);
     if (tid == 0 && a0 > e0) {
-        const int64_t e = e0;
-        const int tl = 0, f = 0;
-        const float2 x = A.spec[e];
-        float2 y = (f < nd) ? ylow[tl * nd + f] : make_float2(x.x, x.y);
-        if (f >= nd && A.gains) { const float g = gs[tl * A.nb + b2b[f]]; y.x = x.x * g; y.y = x.y * g; }
-        A.out[e] = dfx_dfa_finish(y, x, A.pf_beta, A.atten_lim);
+        const int t = e0 / F, f = e0 - t * F;
+        out_b[e0] = dfx_dfa_bin(A, spec_b, coef_b, gains_b, t, f, spec_b[e0]);
     }
     if (tid == 1 && a1 < e1) {
-        const int64_t e = e1 - 1;
-        const int tl = nt - 1, f = F - 1;
-        const float2 x = A.spec[e];
-        float2 y = (f < nd) ? ylow[tl * nd + f] : make_float2(x.x, x.y);
-        if (f >= nd && A.gains) { const float g = gs[tl * A.nb + b2b[f]]; y.x = x.x * g; y.y = x.y * g; }
-        A.out[e] = dfx_dfa_finish(y, x, A.pf_beta, A.atten_lim);
+        const int e = e1 - 1, t = e / F, f = e - t * F;
+        out_b[e] = dfx_dfa_bin(A, spec_b, coef_b, gains_b, t, f, spec_b[e]);
     }
-    const float4 *x4 = reinterpret_cast<const float4 *>(A.spec + a0);
-    float4 *y4 = reinterpret_cast<float4 *>(A.out + a0);
-    const int n4 = (int)((a1 - a0) / 2);
-    const int rel0 = (int)(a0 - e0);
+    const float4 *x4 = reinterpret_cast<const float4 *>(spec_b + a0);
+    float4 *y4 = reinterpret_cast<float4 *>(out_b + a0);
+    const int n4 = (a1 - a0) >> 1;
     for (int i = tid; i < n4; i += DFX_DFA_THREADS) {
         const float4 xv = x4[i];
-        float2 xin[2] = {make_float2(xv.x, xv.y), make_float2(xv.z, xv.w)};
-        float2 yo[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int rel = rel0 + 2 * i + h;  // element index inside the chunk
-            const int tl = rel / F, f = rel - tl * F;
-            float2 y;
-            if (f < nd) {
-                y = ylow[tl * nd + f];
-            } else if (A.gains) {
-                const float g = gs[tl * A.nb + b2b[f]];  // Mask (modules.py:266-269) == apply_interp_band_gain
-                y = make_float2(xin[h].x * g, xin[h].y * g);
-            } else {
-                y = xin[h];
-            }
-            yo[h] = dfx_dfa_finish(y, xin[h], A.pf_beta, A.atten_lim);
+        const int e = a0 + 2 * i;
+        int t = e / F, f = e - t * F;
+        const float2 ya = dfx_dfa_bin(A, spec_b, coef_b, gains_b, t, f, make_float2(xv.x, xv.y));
+        if (++f == F) {
+            f = 0;
+            ++t;
         }
-        y4[i] = make_float4(yo[0].x, yo[0].y, yo[1].x, yo[1].y);
+        const float2 yb = dfx_dfa_bin(A, spec_b, coef_b, gains_b, t, f, make_float2(xv.z, xv.w));
+        y4[i] = make_float4(ya.x, ya.y, yb.x, yb.y);
     }
 }

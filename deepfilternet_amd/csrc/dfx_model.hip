@@ -484,7 +484,7 @@ static int launch_convp2(const dfx_model *m, const float *c0, float *out, int64_
 }
 
 static int launch_ggemm(const float *a, int lda, const float *w, int G, int Kg, int Ng, const float *bias, int act,
-                        const float *res, float *out, int ldo, int64_t M, hipStream_t s) {
+                        const float *res, float *out, int ldo, int64_t M, hipStream_t s, int perm_inner = 0, int perm_F = 0) {
     if (M <= 0) return DFX_OK;
     if (Kg % 4 || Ng % 4 || lda % 4) DFX_FAIL(DFX_ERR_UNSUPPORTED, "grouped GEMM needs K, N, lda multiples of 4 (got %d, %d, %d)", Kg, Ng, lda);
     DfxGgArgs A;
@@ -500,6 +500,8 @@ static int launch_ggemm(const float *a, int lda, const float *w, int G, int Kg, 
     A.Kg = Kg;
     A.Ng = Ng;
     A.act = act;
+    A.perm_inner = perm_inner;
+    A.perm_F = perm_F;
     const int BN = Ng <= 16 ? 16 : (Ng <= 32 ? 32 : 64);
     A.ntn = (Ng + BN - 1) / BN;
     const dim3 grid((unsigned)dfx_ceil_div(M, DFX_GG_BM), (unsigned)(G * A.ntn));
@@ -668,8 +670,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             cfeat = xdf;
         }
         if ((rc = wait(EV_C0P, x1))) return rc;
-        // c = tanh(df_out(c)).view(b,t,F',2O) + c0p   (:329-330); flat index f*2O + 2n + {re,im} == [B,T,F',O][2]
-        if ((rc = launch_glin(m, m->df_out, cfeat, DFX_ACT_TANH, c0p, coefs, R, x1))) return rc;
+        // c = tanh(df_out(c)).view(b,t,F',2O) + c0p   (:329-330); the reference's flat index f*2O + 2n + {re,im} is stored
+        // tap-major, [B,T,O,F'][2] (DFX_COEF_BTOF), so the deep-filter kernel reads coefficients coalesced over f
+        if ((rc = launch_ggemm(cfeat, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg, m->df_out.Ng,
+                               nullptr, DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, R, x1, NO, Fd)))
+            return rc;
         if ((rc = signal(EV_COEFS, x1))) return rc;
     }
     // ---- ErbDecoder on s (:245-254)
@@ -690,7 +695,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     }
     if ((rc = wait(EV_COEFS, s))) return rc;
     // ---- Mask + MF.DF + combine + post filter + atten_lim (:426-454, enhance.py:238-240)
-    return dfx_launch_df_apply(spec, coefs, DFX_COEF_BTFO, mask, bands, B, T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead,
+    return dfx_launch_df_apply(spec, coefs, DFX_COEF_BTOF, mask, bands, B, T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead,
                                c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, s);
 }
 

@@ -41,6 +41,9 @@ def test_matches_reference_mf_df_golden(backend, O_, la, golden_dir):
     # same coefficients in the DfDecoder layout [B,T,F',O]
     out2 = run_df_apply(sc, np.ascontiguousarray(cc.transpose(0, 2, 3, 1)), 1, None, None, 96, O_, la)
     assert np.array_equal(out, out2)
+    # and in the engine's own tap-major layout [B,T,O,F'] (DFX_COEF_BTOF)
+    out3 = run_df_apply(sc, np.ascontiguousarray(cc.transpose(0, 2, 1, 3)), 2, None, None, 96, O_, la)
+    assert np.array_equal(out, out3)
 
 
 def test_mask_matches_reference_golden(backend, golden_dir):
@@ -62,6 +65,8 @@ def test_mask_matches_reference_golden(backend, golden_dir):
     (1, 1, 481, 96, 5, 2, 0.0, 0.25),      # single frame + attenuation limit
     (2, 9, 97, 32, 10, 3, 0.02, 0.5),      # other sizes, order 10
     (2, 5, 64, 64, 3, 1, 0.0, 0.0),        # even F, nb_df == F
+    (3, 37, 481, 95, 5, 2, 0.0, 0.0),      # odd T*F (odd clips start 8-byte aligned only), odd nb_df, 3 row chunks
+    (9, 17, 33, 7, 2, 0, 0.0, 0.0),        # more clips than one XCD group, tiny rows
 ])
 def test_fused_matches_oracle(backend, B, T, F, nd, O_, la, pf, lim):
     rng = np.random.default_rng(B * 100 + T)
@@ -90,5 +95,7 @@ def test_argument_errors(backend):
     coefs = np.zeros((1, 4, 96, 5), np.complex64)
     with pytest.raises(_lib.DfxError, match="lookahead"):
         run_df_apply(spec, coefs, 1, None, None, 96, 5, 5)
-    with pytest.raises(_lib.DfxError, match="nb_df must be even"):
-        run_df_apply(spec, np.zeros((1, 4, 95, 5), np.complex64), 1, None, None, 95, 5, 0)
+    with pytest.raises(_lib.DfxError, match="coef_layout"):
+        run_df_apply(spec, coefs, 3, None, None, 96, 5, 0)
+    with pytest.raises(_lib.DfxError, match="nb_df"):
+        run_df_apply(spec, np.zeros((1, 4, 482, 5), np.complex64), 1, None, None, 482, 5, 0)

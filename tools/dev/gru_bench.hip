@@ -268,6 +268,107 @@ __global__ void __launch_bounds__(512, 2) gru3(const float *gi, const float4 *__
     }
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ float fsig(float x) { return __frcp_rn(1.f + __expf(-x)); }
+// 256 threads = 4 waves; wave w owns hidden units [64w, 64w+64) (lane = unit), 4 rows per block via v_mfma_f32_4x4x1_16B_f32
+// weights: whh4 [k4][gate][unit] float4 (4 consecutive k). k4 blocks [0,KR) registers, [KR,KR+KL) LDS, rest streamed (ring D).
+template <int KR, int KL, int D>
+__global__ void __launch_bounds__(256, 1) gru5(const float *gi, const float4 *__restrict__ whh4, const float *bhn, float *y, int64_t B, int64_t T) {
+    constexpr int KS = 64 - KR - KL, MR = 4, R = KR + KL;
+    static_assert(KS % D == 0, "");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    float4 *wl = reinterpret_cast<float4 *>(smraw);                          // [KL][3][256]
+    float *hs = reinterpret_cast<float *>(smraw + (size_t)KL * 3 * 256 * 16);  // [2][MR][H]
+    const int tid = threadIdx.x, lane = tid & 63, row = lane & 3;
+    const int u = tid;  // hidden unit
+    const int64_t b0 = (int64_t)blockIdx.x * MR;
+    float4 wr[KR][3];
+#pragma unroll
+    for (int k = 0; k < KR; ++k)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) wr[k][g] = whh4[(k * 3 + g) * H + u];
+    for (int k = 0; k < KL; ++k)
+        for (int g = 0; g < 3; ++g) wl[(k * 3 + g) * H + u] = whh4[((KR + k) * 3 + g) * H + u];
+    const float bn = bhn[u];
+    for (int i = tid; i < MR * H; i += 256) hs[i] = 0.f;
+    __syncthreads();
+    int cur = 0;
+    const float4 *ws = whh4 + (size_t)R * 3 * H + u;
+    float g_r[MR], g_z[MR], g_n[MR];
+    const float *gp[MR];
+    float *yp[MR];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+        const int64_t b = (b0 + r < B) ? b0 + r : B - 1;
+        gp[r] = gi + b * T * (3 * H) + u;
+        yp[r] = y + b * T * H + u;
+        g_r[r] = gp[r][0]; g_z[r] = gp[r][H]; g_n[r] = gp[r][2 * H];
+    }
+    float4 ring[D][3];
+#define ISSUE5(SLOT, S) { _Pragma("unroll") for (int g = 0; g < 3; ++g) ring[SLOT][g] = wst[((S) * 3 + g) * H]; }
+    // one k4 block: 4 k's x 3 gates = 12 MFMAs; A = h[row = lane&3][k]
+#define BLOCK5(W0, W1, W2, K4) {                                                                   \
+        const float4 hv = *reinterpret_cast<const float4 *>(hc + row * H + 4 * (K4));              \
+        ar = __builtin_amdgcn_mfma_f32_4x4x1f32(hv.x, W0.x, ar, 0, 0, 0);                          \
+        az = __builtin_amdgcn_mfma_f32_4x4x1f32(hv.x, W1.x, az, 0, 0, 0);                          \
+        an = __builtin_amdgcn_mfma_f32_4x4x1f32(hv.x, W2.x, an, 0, 0, 0);                          \
+        ar = __builtin_amdgcn_mfma_f32_4x4x1f32(hv.y, W0.y, ar, 0, 0, 0);                          \
+        az = __builtin_amdgcn_mfma_f32_4x4x1f32(hv.y, W1.y, az, 0, 0, 0);                          \
+        an = __builtin_amdgcn_mfma_f32_4x4x1f32(hv.y, W2.y, an, 0, 0, 0);                          \
+        ar = __builtin_amdgcn_mfma_f32_4x4x1f32(hv.z, W0.z, ar, 0, 0, 0);                          \
+        az = __builtin_amdgcn_mfma_f32_4x4x1f32(hv.z, W1.z, az, 0, 0, 0);                          \
+        an = __builtin_amdgcn_mfma_f32_4x4x1f32(hv.z, W2.z, an, 0, 0, 0);                          \
+        ar = __builtin_amdgcn_mfma_f32_4x4x1f32(hv.w, W0.w, ar, 0, 0, 0);                          \
+        az = __builtin_amdgcn_mfma_f32_4x4x1f32(hv.w, W1.w, az, 0, 0, 0);                          \
+        an = __builtin_amdgcn_mfma_f32_4x4x1f32(hv.w, W2.w, an, 0, 0, 0); }
+    {
+        const float4 *wst = ws;
+#pragma unroll
+        for (int d = 0; d < D; ++d) ISSUE5(d, d)
+    }
+    for (int64_t t = 0; t < T; ++t) {
+        f32x4 ar = {0, 0, 0, 0}, az = {0, 0, 0, 0}, an = {0, 0, 0, 0};
+        const float *hc = hs + cur * MR * H;
+        int zoff = 0;
+        DFX_OPAQUE(zoff);
+        const float4 *wst = ws + zoff;
+        const int64_t tn = t + 1 < T ? t + 1 : t;
+        float n_r[MR], n_z[MR], n_n[MR];
+#pragma unroll
+        for (int r = 0; r < MR; ++r) { n_r[r] = gp[r][tn * 3 * H]; n_z[r] = gp[r][tn * 3 * H + H]; n_n[r] = gp[r][tn * 3 * H + 2 * H]; }
+        static_for<0, KS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            static_for<s * R / KS, (s + 1) * R / KS>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (k < KR) { BLOCK5(wr[k][0], wr[k][1], wr[k][2], k) }
+                else {
+                    const float4 w0 = wl[((k - KR) * 3 + 0) * H + u], w1 = wl[((k - KR) * 3 + 1) * H + u], w2 = wl[((k - KR) * 3 + 2) * H + u];
+                    BLOCK5(w0, w1, w2, k)
+                }
+            });
+            DFX_SCHED_BARRIER();
+            BLOCK5(ring[s % D][0], ring[s % D][1], ring[s % D][2], R + s)
+            DFX_SCHED_BARRIER();
+            ISSUE5(s % D, (s + D) % KS)
+            DFX_SCHED_BARRIER();
+        });
+        // lane = unit; acc[r] = row r
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            const float rg = fsig(g_r[r] + ar[r]);
+            const float zg = fsig(g_z[r] + az[r]);
+            const float pre = g_n[r] + rg * (an[r] + bn);
+            const float ng = 2.f * fsig(2.f * pre) - 1.f;
+            const float hn = (1.f - zg) * ng + zg * hc[r * H + u];
+            hs[(cur ^ 1) * MR * H + r * H + u] = hn;
+            if (b0 + r < B) yp[r][t * H] = hn;
+            g_r[r] = n_r[r]; g_z[r] = n_z[r]; g_n[r] = n_n[r];
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
 template <int MR, int KR, int KL, int PK, int MODE>
@@ -322,6 +423,29 @@ static void run3(const char *name, const float *gi, const float4 *w, const float
     printf("v3 %-25s MR=%d KR=%d KL=%d D=%d MODE=%d grid=%d  %.3f ms  %.3f us/step  maxerr=%g\n", name, MR, KR, KL, D, MODE, grid, best, best * 1e3 / T, err);
 }
 
+template <int KR, int KL, int D>
+static void run5(const char *name, const float *gi, const float4 *w, const float *bhn, float *y, int64_t B, int64_t T, const float *yref_host, std::vector<float> &ybuf) {
+    const size_t smem = (size_t)KL * 3 * 256 * 16 + (size_t)2 * 4 * H * 4;
+    CK(hipFuncSetAttribute((const void *)gru5<KR, KL, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    const int grid = (int)((B + 3) / 4);
+    float best = 1e30f;
+    for (int it = 0; it < 3; ++it) {
+        CK(hipEventRecord(a, 0));
+        hipLaunchKernelGGL((gru5<KR, KL, D>), dim3(grid), dim3(256), smem, 0, gi, w, bhn, y, B, T);
+        CK(hipEventRecord(b, 0));
+        CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) best = ms;
+    }
+    CK(hipGetLastError());
+    CK(hipMemcpy(ybuf.data(), y, ybuf.size() * 4, hipMemcpyDeviceToHost));
+    double err = 0;
+    for (size_t i = 0; i < ybuf.size(); ++i) err = fmax(err, fabs((double)ybuf[i] - yref_host[i]));
+    printf("v5 mfma4x4x1 %-12s KR=%d KL=%d D=%d grid=%d  %.3f ms  %.3f us/step  maxerr=%g\n", name, KR, KL, D, grid, best, best * 1e3 / T, err);
+}
+
 int main(int argc, char **argv) {
     const int64_t B = argc > 1 ? atoll(argv[1]) : 256, T = argc > 2 ? atoll(argv[2]) : 1002;
     std::vector<float> hgi((size_t)B * T * 768), hw((size_t)768 * 256), hb(256);
@@ -368,25 +492,12 @@ int main(int argc, char **argv) {
     }
     std::vector<float> yref_full = ybuf;
     const float *yr = yref_full.data();
-    run<2, 14, 6, 1, 0>("pk", gi, w4, bhn, y, B, T, yr, ybuf);
-    run<2, 14, 6, 0, 2>("stream-only", gi, w4, bhn, y, B, T, yr, ybuf);
-    run<2, 12, 6, 1, 0>("pk KR12", gi, w4, bhn, y, B, T, yr, ybuf);
-    run<4, 12, 6, 1, 0>("pk MR4 KR12", gi, w4, bhn, y, B, T, yr, ybuf);
-    run<4, 10, 6, 1, 0>("pk MR4 KR10", gi, w4, bhn, y, B, T, yr, ybuf);
-    run3<4, 10, 6, 4, 0>("full", gi, w4, bhn, y, B, T, yr, ybuf);
-    run3<4, 10, 6, 4, 1>("nostream", gi, w4, bhn, y, B, T, yr, ybuf);
-    run3<4, 10, 6, 4, 2>("streamonly", gi, w4, bhn, y, B, T, yr, ybuf);
-    run3<4, 10, 6, 2, 0>("full", gi, w4, bhn, y, B, T, yr, ybuf);
     run3<4, 12, 6, 2, 0>("full", gi, w4, bhn, y, B, T, yr, ybuf);
-    run3<4, 11, 5, 4, 0>("full", gi, w4, bhn, y, B, T, yr, ybuf);
-    run3<4, 8, 6, 6, 0>("full", gi, w4, bhn, y, B, T, yr, ybuf);
-    run3<4, 8, 6, 6, 2>("streamonly", gi, w4, bhn, y, B, T, yr, ybuf);
-    run3<2, 10, 6, 4, 0>("full", gi, w4, bhn, y, B, T, yr, ybuf);
     run3<2, 14, 6, 2, 0>("full", gi, w4, bhn, y, B, T, yr, ybuf);
-    run3<2, 14, 6, 3, 0>("full", gi, w4, bhn, y, B, T, yr, ybuf);
-    run3<2, 14, 6, 4, 0>("full", gi, w4, bhn, y, B, T, yr, ybuf);
-    run3<2, 12, 6, 7, 0>("full", gi, w4, bhn, y, B, T, yr, ybuf);
-    run3<2, 8, 6, 6, 2>("streamonly", gi, w4, bhn, y, B, T, yr, ybuf);
-    run3<2, 2, 6, 8, 2>("streamonly", gi, w4, bhn, y, B, T, yr, ybuf);
+    run5<30, 12, 2>("", gi, w4, bhn, y, B, T, yr, ybuf);
+    run5<28, 12, 4>("", gi, w4, bhn, y, B, T, yr, ybuf);
+    run5<24, 12, 4>("", gi, w4, bhn, y, B, T, yr, ybuf);
+    run5<24, 12, 7>("", gi, w4, bhn, y, B, T, yr, ybuf);
+    run5<20, 12, 8>("", gi, w4, bhn, y, B, T, yr, ybuf);
     return 0;
 }
