@@ -484,12 +484,27 @@ int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, 
     }
     A.pf_beta = pf_beta;
     A.atten_lim = atten_lim;
-    A.chunks = (int)dfx_ceil_div(T, DFX_DFA_ROWS);
+    static int rows_sel = 0;
+    if (!rows_sel) {
+        const char *e = getenv("DFX_DFA_ROWS");
+        rows_sel = (e && atoi(e) == 32) ? 32 : DFX_DFA_ROWS;
+    }
+    const int ROWS = rows_sel;
+    A.chunks = (int)dfx_ceil_div(T, ROWS);
     if (T * (int64_t)F > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_df_apply: T*F exceeds 2^31 elements per clip");
     const int64_t nblk = dfx_ceil_div(B, 8) * 8 * A.chunks;
     if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_df_apply: batch too large for one launch");
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t smem = al((size_t)(ROWS + order - 1) * nb_df * 8) + al((size_t)ROWS * (A.nb > 0 ? A.nb : 1) * 4) + al((size_t)F);
+    if (smem > 160 * 1024) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_df_apply: nb_df*order too large for LDS staging (%zu B)", smem);
     DfxKScope ks(DFX_K_DF_APPLY, s);
-    dfx_launch(dfx_k_df_apply, dim3((unsigned)nblk), dim3(DFX_DFA_THREADS), 0, s, A);
+    if (ROWS == 32) {
+        if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_df_apply<32>, smem));
+        dfx_launch(dfx_k_df_apply<32>, dim3((unsigned)nblk), dim3(DFX_DFA_THREADS), smem, s, A);
+    } else {
+        if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_df_apply<16>, smem));
+        dfx_launch(dfx_k_df_apply<16>, dim3((unsigned)nblk), dim3(DFX_DFA_THREADS), smem, s, A);
+    }
     DFX_LAUNCH_CHECK();
     return DFX_OK;
 }

@@ -440,7 +440,7 @@ __global__ void dfx_k_norm_scan(const float *erb_in, float *erb_out, int E, cons
 //                  coefficients, and the tap rows of X are L2 hits: the clip -> XCD mapping keeps a clip on one L2)
 // The coefficient layout is described by four strides (complex elements): BOTF, BTFO and the engine's own BTOF.
 // ---------------------------------------------------------------------------------------------------------------------
-#define DFX_DFA_ROWS 16
+#define DFX_DFA_ROWS 16  // default rows per workgroup (DFX_DFA_ROWS=32 in the environment selects the 32-row instantiation)
 #define DFX_DFA_THREADS 256
 
 struct DfxDfaArgs {
@@ -476,26 +476,25 @@ static __device__ __forceinline__ float2 dfx_dfa_finish(float2 y, float2 x, floa
     return y;
 }
 
-// one output bin: frame t (row index inside the clip), bin f, x = spec[b,t,f]
-static __device__ __forceinline__ float2 dfx_dfa_bin(const DfxDfaArgs &A, const float2 *spec_b, const float2 *coef_b,
-                                                     const float *gains_b, int t, int f, float2 x) {
+// one output bin of frame t (row index inside the clip), bin f, x = spec[b,t,f].  xs: the low bins [0,nbdf) of frames
+// t0-toff .. of this chunk staged in LDS (zeros outside the clip); gs / b2b: the chunk's gains and the bin->band map in LDS.
+static __device__ __forceinline__ float2 dfx_dfa_bin(const DfxDfaArgs &A, const float2 *xs, const float *gs,
+                                                     const unsigned char *b2b, const float2 *coef_b, int t0, int t, int f,
+                                                     float2 x) {
     float2 y;
     if (f < A.nbdf) {
         float re = 0.f, im = 0.f;
-        const int toff = A.order - 1 - A.lookahead;  // tap n reads frame t + n - toff
         const float2 *cp = coef_b + (int64_t)t * A.cs_t + (int64_t)f * A.cs_f;
+        const float2 *xp = xs + (t - t0) * A.nbdf + f;  // tap n reads frame t + n - toff == staged row (t - t0) + n
         for (int n = 0; n < A.order; ++n) {
-            const int tt = t + n - toff;
-            if (tt >= 0 && tt < A.T) {
-                const float2 c = cp[(int64_t)n * A.cs_n];
-                const float2 xx = spec_b[(int64_t)tt * A.F + f];
-                re += xx.x * c.x - xx.y * c.y;
-                im += xx.x * c.y + xx.y * c.x;
-            }
+            const float2 c = cp[(int64_t)n * A.cs_n];
+            const float2 xx = xp[n * A.nbdf];
+            re += xx.x * c.x - xx.y * c.y;
+            im += xx.x * c.y + xx.y * c.x;
         }
         y = make_float2(re, im);
-    } else if (gains_b) {
-        const float g = gains_b[(int64_t)t * A.nb + A.bin2band[f]];
+    } else if (gs) {
+        const float g = gs[(t - t0) * A.nb + b2b[f]];
         y = make_float2(x.x * g, x.y * g);
     } else {
         y = x;
@@ -503,48 +502,98 @@ static __device__ __forceinline__ float2 dfx_dfa_bin(const DfxDfaArgs &A, const 
     return dfx_dfa_finish(y, x, A.pf_beta, A.atten_lim);
 }
 
+template <int ROWS>
 __global__ void __launch_bounds__(DFX_DFA_THREADS) dfx_k_df_apply(DfxDfaArgs A) {
-    // blocks that share blockIdx.x % 8 (one XCD, one L2) work on the same clips: the tap rows re-read by the deep filter
-    // were streamed through that L2 by a neighbouring block a moment ago (placement is a speed hint only)
+    DFX_DYN_SMEM(unsigned char, smem);
+    // blocks that share blockIdx.x % 8 (one XCD, one L2) work on the same clips (placement is a speed hint only)
     const int64_t id = blockIdx.x;
     const int xcd = (int)(id & 7);
     const int64_t j = id >> 3;
     const int chunk = (int)(j % A.chunks);
     const int64_t b = (j / A.chunks) * 8 + xcd;
     if (b >= A.B) return;
-    const int F = A.F;
-    const int t0 = chunk * DFX_DFA_ROWS;
-    const int nt = (A.T - t0) < DFX_DFA_ROWS ? (int)(A.T - t0) : DFX_DFA_ROWS;
+    const int F = A.F, nd = A.nbdf;
+    const int t0 = chunk * ROWS;
+    const int nt = (A.T - t0) < ROWS ? (int)(A.T - t0) : ROWS;
+    const int halo = ROWS + A.order - 1;
+    float2 *xs = reinterpret_cast<float2 *>(smem);                                   // [halo][nd]
+    size_t off = ((size_t)halo * nd * 8 + 15) & ~(size_t)15;
+    float *gs = reinterpret_cast<float *>(smem + off);                               // [ROWS][nb]
+    off += ((size_t)ROWS * (A.nb > 0 ? A.nb : 1) * 4 + 15) & ~(size_t)15;
+    unsigned char *b2b = smem + off;                                                 // [F]
     const float2 *spec_b = A.spec + b * A.T * F;
     float2 *out_b = A.out + b * A.T * F;
     const float2 *coef_b = A.coefs + b * A.cs_b;
-    const float *gains_b = A.gains ? A.gains + b * A.T * A.nb : nullptr;
     const int tid = threadIdx.x;
-    // element range of this chunk inside the clip, and its 16-byte aligned interior (absolute parity decides)
-    const int e0 = t0 * F, e1 = e0 + nt * F;
-    const int par = (int)((b * A.T * F) & 1);           // parity of the clip's first element in the whole array
-    const int a0 = e0 + ((e0 + par) & 1), a1 = e1 - ((e1 + par) & 1);
-    if (tid == 0 && a0 > e0) {
-        const int t = e0 / F, f = e0 - t * F;
-        out_b[e0] = dfx_dfa_bin(A, spec_b, coef_b, gains_b, t, f, spec_b[e0]);
+    // ---- stage the deep filter's input window: every low bin of the chunk (+ order-1 halo frames) is read from HBM once
+    const int toff = A.order - 1 - A.lookahead;
+    for (int i = tid; i < halo * nd; i += DFX_DFA_THREADS) {
+        const int h = i / nd, f = i - h * nd;
+        const int tt = t0 - toff + h;
+        float2 v = make_float2(0.f, 0.f);
+        if (tt >= 0 && tt < A.T) v = spec_b[(int64_t)tt * F + f];
+        xs[i] = v;
     }
-    if (tid == 1 && a1 < e1) {
-        const int e = e1 - 1, t = e / F, f = e - t * F;
-        out_b[e] = dfx_dfa_bin(A, spec_b, coef_b, gains_b, t, f, spec_b[e]);
+    if (A.gains) {
+        const float *gp = A.gains + (b * A.T + t0) * A.nb;
+        for (int i = tid; i < nt * A.nb; i += DFX_DFA_THREADS) gs[i] = gp[i];
+        for (int i = tid; i < F; i += DFX_DFA_THREADS) b2b[i] = A.bin2band[i];
+    } else {
+        gs = nullptr;
+    }
+    __syncthreads();
+    // ---- flat stream over the chunk's [nt*F] bins: a head and a tail of < 32 bins are peeled so that the float4 body
+    // starts and ends on 256-byte boundaries (every wave-wide access then covers whole cache lines)
+    const int e0 = t0 * F, e1 = e0 + nt * F;
+    const int mis = (int)((reinterpret_cast<uintptr_t>(spec_b + e0) >> 3) & 31);   // bins past a 256-byte boundary
+    int a0 = e0 + ((32 - mis) & 31);
+    if (a0 > e1) a0 = e1;
+    const int a1 = a0 + ((e1 - a0) & ~31);
+    for (int e = e0 + tid; e < a0; e += DFX_DFA_THREADS) {
+        const int t = e / F, f = e - t * F;
+        const float2 x = (f < nd) ? xs[(t - t0 + toff) * nd + f] : spec_b[e];
+        out_b[e] = dfx_dfa_bin(A, xs, gs, b2b, coef_b, t0, t, f, x);
+    }
+    for (int e = a1 + tid; e < e1; e += DFX_DFA_THREADS) {
+        const int t = e / F, f = e - t * F;
+        const float2 x = (f < nd) ? xs[(t - t0 + toff) * nd + f] : spec_b[e];
+        out_b[e] = dfx_dfa_bin(A, xs, gs, b2b, coef_b, t0, t, f, x);
     }
     const float4 *x4 = reinterpret_cast<const float4 *>(spec_b + a0);
     float4 *y4 = reinterpret_cast<float4 *>(out_b + a0);
     const int n4 = (a1 - a0) >> 1;
-    for (int i = tid; i < n4; i += DFX_DFA_THREADS) {
-        const float4 xv = x4[i];
-        const int e = a0 + 2 * i;
-        int t = e / F, f = e - t * F;
-        const float2 ya = dfx_dfa_bin(A, spec_b, coef_b, gains_b, t, f, make_float2(xv.x, xv.y));
-        if (++f == F) {
-            f = 0;
-            ++t;
+    // two float4s per iteration: both loads are issued before either is used
+    for (int i = tid; i < n4; i += 2 * DFX_DFA_THREADS) {
+        const int i2 = i + DFX_DFA_THREADS;
+        const bool has2 = i2 < n4;
+        int tt[2], ff[2], tt2[2], ff2[2];
+        bool lds[2];
+        float4 xv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = a0 + 2 * (u ? i2 : i);
+            tt[u] = e / F;
+            ff[u] = e - tt[u] * F;
+            tt2[u] = tt[u];
+            ff2[u] = ff[u] + 1;
+            if (ff2[u] == F) {
+                ff2[u] = 0;
+                ++tt2[u];
+            }
+            lds[u] = ff2[u] < nd && ff[u] < nd && ff2[u] != 0;  // both bins belong to the deep filter: inputs are in LDS
         }
-        const float2 yb = dfx_dfa_bin(A, spec_b, coef_b, gains_b, t, f, make_float2(xv.z, xv.w));
-        y4[i] = make_float4(ya.x, ya.y, yb.x, yb.y);
+        if (!lds[0]) xv[0] = x4[i];
+        if (has2 && !lds[1]) xv[1] = x4[i2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !has2) break;
+            if (lds[u]) {
+                const float2 xa = xs[(tt[u] - t0 + toff) * nd + ff[u]], xb = xs[(tt[u] - t0 + toff) * nd + ff2[u]];
+                xv[u] = make_float4(xa.x, xa.y, xb.x, xb.y);
+            }
+            const float2 ya = dfx_dfa_bin(A, xs, gs, b2b, coef_b, t0, tt[u], ff[u], make_float2(xv[u].x, xv[u].y));
+            const float2 yb = dfx_dfa_bin(A, xs, gs, b2b, coef_b, t0, tt2[u], ff2[u], make_float2(xv[u].z, xv[u].w));
+            y4[u ? i2 : i] = make_float4(ya.x, ya.y, yb.x, yb.y);
+        }
     }
 }

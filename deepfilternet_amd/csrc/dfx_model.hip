@@ -484,7 +484,8 @@ static int launch_convp2(const dfx_model *m, const float *c0, float *out, int64_
 }
 
 static int launch_ggemm(const float *a, int lda, const float *w, int G, int Kg, int Ng, const float *bias, int act,
-                        const float *res, float *out, int ldo, int64_t M, hipStream_t s, int perm_inner = 0, int perm_F = 0) {
+                        const float *res, float *out, int ldo, int64_t M, hipStream_t s, int perm_inner = 0, int perm_F = 0,
+                        int64_t perm_T = 1) {
     if (M <= 0) return DFX_OK;
     if (Kg % 4 || Ng % 4 || lda % 4) DFX_FAIL(DFX_ERR_UNSUPPORTED, "grouped GEMM needs K, N, lda multiples of 4 (got %d, %d, %d)", Kg, Ng, lda);
     DfxGgArgs A;
@@ -502,6 +503,7 @@ static int launch_ggemm(const float *a, int lda, const float *w, int G, int Kg, 
     A.act = act;
     A.perm_inner = perm_inner;
     A.perm_F = perm_F;
+    A.perm_T = perm_T;
     const int BN = Ng <= 16 ? 16 : (Ng <= 32 ? 32 : 64);
     A.ntn = (Ng + BN - 1) / BN;
     const dim3 grid((unsigned)dfx_ceil_div(M, DFX_GG_BM), (unsigned)(G * A.ntn));
@@ -671,9 +673,10 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         }
         if ((rc = wait(EV_C0P, x1))) return rc;
         // c = tanh(df_out(c)).view(b,t,F',2O) + c0p   (:329-330); the reference's flat index f*2O + 2n + {re,im} is stored
-        // tap-major, [B,T,O,F'][2] (DFX_COEF_BTOF), so the deep-filter kernel reads coefficients coalesced over f
+        // tap-major, [B,O,T,F'][2] (DFX_COEF_BOTF == the reference's DfOutputReshapeMF layout), so the deep-filter kernel
+        // reads coefficients coalesced over f
         if ((rc = launch_ggemm(cfeat, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg, m->df_out.Ng,
-                               nullptr, DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, R, x1, NO, Fd)))
+                               nullptr, DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, R, x1, NO, Fd, T)))
             return rc;
         if ((rc = signal(EV_COEFS, x1))) return rc;
     }
@@ -695,7 +698,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     }
     if ((rc = wait(EV_COEFS, s))) return rc;
     // ---- Mask + MF.DF + combine + post filter + atten_lim (:426-454, enhance.py:238-240)
-    return dfx_launch_df_apply(spec, coefs, DFX_COEF_BTOF, mask, bands, B, T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead,
+    return dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead,
                                c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, s);
 }
 

@@ -329,7 +329,7 @@ struct DfxCpArgs {
     const float *w1;   // [G][kt][CG][16]   (o padded to 16 with zeros; BN-scaled when there is no pointwise conv)
     const float *w2;   // [NO][NO] w2[n][o] (BN-scaled; identity when there is no pointwise conv)
     const float *bias; // [NO]
-    float *out;        // [B*T, NO/2, Fd, 2]  (tap-major, DFX_COEF_BTOF)
+    float *out;        // [B, NO/2, T, Fd, 2]  (tap-major, DFX_COEF_BOTF)
     int64_t B, T;
     int Fd, kt, G, NO; // NO = 2*O outputs, G groups, OG = NO/G outputs per group
     int tchunks, fchunks;
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(DFX_CP_THREADS) dfx_k_df_convp(DfxCpArgs A) {
         if (tl >= nt_valid || f >= nf_valid) continue;
         float acc = A.bias[n];
         for (int o = 0; o < A.NO; ++o) acc += A.w2[n * A.NO + o] * s1[p * A.NO + o];
-        A.out[(((b * A.T + t0 + tl) * (A.NO / 2) + (n >> 1)) * A.Fd + f0 + f) * 2 + (n & 1)] = fmaxf(acc, 0.f);  // BTOF
+        A.out[(((b * (A.NO / 2) + (n >> 1)) * A.T + t0 + tl) * A.Fd + f0 + f) * 2 + (n & 1)] = fmaxf(acc, 0.f);  // BOTF
     }
 }
 
@@ -410,7 +410,7 @@ struct DfxCp2Args {
     const float *c0;    // [B*T, Fd, C]
     const float *weff;  // [kt][C][16]  weff[(k*C + c)*16 + n], n >= NO zero
     const float *bias;  // [16]
-    float *out;         // [B*T, NO/2, Fd, 2]  (tap-major, DFX_COEF_BTOF)
+    float *out;         // [B, NO/2, T, Fd, 2]  (tap-major, DFX_COEF_BOTF)
     int64_t B, T;
     int Fd, NO, nfb, nseg, tseg;  // nfb = ceil(Fd/16) bin blocks, nseg segments of tseg frames (tseg % kt == 0)
 };
@@ -474,12 +474,12 @@ __global__ void __launch_bounds__(256) dfx_k_df_convp2(DfxCp2Args A) {
                             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[k][ks], win[sl][ks], acc, 0, 0, 0);
                     });
                     if (fvalid) {
-                        // output channel 4q + r = 2*tap + {re,im}; stored tap-major: [row][tap][f][2] (DFX_COEF_BTOF)
-                        float *op = A.out + ((b * A.T + t) * (A.NO / 2) * A.Fd + f) * 2;
+                        // output channel 4q + r = 2*tap + {re,im}; stored tap-major: [b][tap][t][f][2] (DFX_COEF_BOTF)
+                        float *op = A.out + ((b * (A.NO / 2) * A.T + t) * A.Fd + f) * 2;
 #pragma unroll
                         for (int h = 0; h < 2; ++h)
                             if (4 * q + 2 * h < A.NO)
-                                *reinterpret_cast<float2 *>(op + (int64_t)(2 * q + h) * A.Fd * 2) =
+                                *reinterpret_cast<float2 *>(op + (int64_t)(2 * q + h) * A.T * A.Fd * 2) =
                                     make_float2(fmaxf(acc[2 * h] + biasr[2 * h], 0.f), fmaxf(acc[2 * h + 1] + biasr[2 * h + 1], 0.f));
                     }
                 }
@@ -505,7 +505,8 @@ struct DfxGgArgs {
     float *out;         // [M, ldo]
     int64_t M;
     int lda, ldo, G, Kg, Ng, act, ntn /* N tiles per group */;
-    int perm_inner, perm_F;  // > 0: output column j = f*inner + i is stored at (i/2 * perm_F + f)*2 + (i&1)  ([F][O][2] -> [O][F][2])
+    int perm_inner, perm_F;  // > 0: output column j = f*inner + i of row m = b*perm_T + t is stored tap-major, [B][inner/2][T][F][2]
+    int64_t perm_T;          //      (DFX_COEF_BOTF, the reference's DfOutputReshapeMF layout); out/res are then addressed without ldo
 };
 
 template <int BN>
@@ -568,12 +569,14 @@ __global__ void __launch_bounds__(DFX_GG_THREADS) dfx_k_ggemm(DfxGgArgs A) {
             float v = acc[nt][r];
             if (A.bias) v += A.bias[col];
             v = dfx_act(v, A.act);
+            int64_t idx = m * A.ldo + col;
             if (A.perm_inner > 0) {
                 const int f = col / A.perm_inner, i = col - f * A.perm_inner;
-                col = ((i >> 1) * A.perm_F + f) * 2 + (i & 1);
+                const int64_t b = m / A.perm_T, t = m - b * A.perm_T;
+                idx = (((b * (A.perm_inner >> 1) + (i >> 1)) * A.perm_T + t) * A.perm_F + f) * 2 + (i & 1);
             }
-            if (A.res) v += A.res[m * A.ldo + col];
-            A.out[m * A.ldo + col] = v;
+            if (A.res) v += A.res[idx];
+            A.out[idx] = v;
         }
     }
 }

@@ -128,7 +128,7 @@ class DfNet:
         spec_e = torch.empty_like(spec_d)
         m = torch.empty((B, 1, T, p.nb_erb), dtype=torch.float32, device=dev)
         lsnr = torch.empty((B, T, 1), dtype=torch.float32, device=dev)
-        coefs = torch.empty((B, T, p.df_order, p.nb_df, 2), dtype=torch.float32, device=dev)  # DFX_COEF_BTOF
+        coefs = torch.empty((B, p.df_order, T, p.nb_df, 2), dtype=torch.float32, device=dev)  # DFX_COEF_BOTF
         nbytes = C.c_int64()
         L = _lib.lib()
         _lib.check(L.dfx_model_workspace_bytes(self._h, B, T, C.byref(nbytes)))
@@ -136,8 +136,8 @@ class DfNet:
         _lib.check(L.dfx_model_forward(self._h, self.df_state.bands_handle, _lib.ptr(spec_d), _lib.ptr(fe), _lib.ptr(fs),
                                        B, T, float(atten_lim), _lib.ptr(spec_e), _lib.ptr(m), _lib.ptr(lsnr),
                                        _lib.ptr(coefs), _lib.ptr(ws), ws.numel(), _lib.stream()))
-        # DfOutputReshapeMF (deepfilternet3.py:268-275) yields [B,O,T,F',2]; the engine stores [B,T,O,F',2] -> a view
-        return spec_e, m, lsnr, coefs.permute(0, 2, 1, 3, 4)
+        # the engine writes the coefficients directly in DfOutputReshapeMF's layout [B,O,T,F',2] (deepfilternet3.py:268-275)
+        return spec_e, m, lsnr, coefs
 
     forward = __call__
 

@@ -115,7 +115,7 @@ int dfx_features(const dfx_state *st, const float *x, int64_t B, int64_t T, int6
  *   spec  [B, T, F][2]   noisy spectrum
  *   coefs complex, nb_df bins, `order` taps:  layout DFX_COEF_BOTF = [B, O, T, nb_df][2]  (MF.DF's input)
  *                                             layout DFX_COEF_BTFO = [B, T, nb_df, O][2]  (DfDecoder's raw output)
- *                                             layout DFX_COEF_BTOF = [B, T, O, nb_df][2]  (this engine's DfDecoder output)
+ *                                             layout DFX_COEF_BTOF = [B, T, O, nb_df][2]
  *   gains [B, T, nb_bands] or NULL.  NULL: bins >= nb_df are copied from spec (plain MF.DF semantics).
  *   out   [B, T, F][2]   must not alias spec
  *   out[b,t,f<nb_df]  = sum_n coefs[b,n,t,f] * spec[b, t+n-(order-1-lookahead), f]   (zero outside [0,T))
@@ -123,7 +123,7 @@ int dfx_features(const dfx_state *st, const float *x, int64_t B, int64_t T, int6
  *   pf_beta > 0: post filter;  atten_lim in (0,1): out = spec*atten_lim + out*(1-atten_lim). */
 #define DFX_COEF_BOTF 0
 #define DFX_COEF_BTFO 1
-#define DFX_COEF_BTOF 2 /* [B, T, O, nb_df][2]: what dfx_model_forward produces (tap-major inside a frame) */
+#define DFX_COEF_BTOF 2 /* [B, T, O, nb_df][2] */
 int dfx_df_apply(const float *spec, const float *coefs, int coef_layout, const float *gains, const dfx_bands *bands,
                  int64_t B, int64_t T, int F, int nb_df, int order, int lookahead, float pf_beta, float atten_lim,
                  float *out, void *stream);
@@ -167,8 +167,8 @@ int dfx_model_workspace_bytes(const dfx_model *m, int64_t B, int64_t T, int64_t 
 
 /* DfNet.forward (deepfilternet3.py:389-456).
  *   spec [B,T,F][2], feat_erb [B,T,E], feat_spec [B,T,nb_df][2]  ->
- *   spec_e [B,T,F][2], mask [B,T,E] (may be NULL), lsnr [B,T] (may be NULL), df_coefs [B,T,O,nb_df][2] (may be NULL;
- *   DFX_COEF_BTOF: the reference's [B,O,T,nb_df,2] is its permute(0,2,1,3,4))
+ *   spec_e [B,T,F][2], mask [B,T,E] (may be NULL), lsnr [B,T] (may be NULL), df_coefs [B,O,T,nb_df][2] (may be NULL;
+ *   DFX_COEF_BOTF == the reference's DfOutputReshapeMF layout, deepfilternet3.py:268-275)
  *   atten_lim: enhance()'s mix factor (0 = off), applied after the optional post filter. */
 int dfx_model_forward(const dfx_model *m, const dfx_bands *bands, const float *spec, const float *feat_erb,
                       const float *feat_spec, int64_t B, int64_t T, float atten_lim, float *spec_e, float *mask,
