@@ -8,7 +8,7 @@ One "step" = one enhance() over one batch of B synthetic noisy 48 kHz clips alre
 owns its own B clips, no data-path collective; the finished waveforms are gathered to rank 0 over RCCL, overlapped with
 the next step).  Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline      the north-star DF-apply kernel (fused deep filter + ERB gains): algorithmic bytes / hipEvent-timed launch
-  kernels       hipEvent-timed per-kernel breakdown of one extra (untimed) step
+  kernels       hipEvent-timed per-kernel breakdown of one extra (untimed) step with the stream-level concurrency off
   cpu_baseline  the CPU oracle (oracle/, a port of the reference path) timed on this host on a bounded sample
 """
 from __future__ import annotations
@@ -186,11 +186,13 @@ def main() -> None:
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4), "launches": dfa_n}
 
-    # ---- per-kernel breakdown of one extra, untimed step
+    # ---- per-kernel breakdown of one extra, untimed step, branches serialised so that kernel times do not overlap
     _lib.prof_reset()
     _lib.prof_enable("all")
+    model.set_streams(False)
     enhance(model, df_state, x)
     torch.cuda.synchronize()
+    model.set_streams(True)
     kern = {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in sorted(_lib.prof_read().items(), key=lambda kv: -kv[1][0])}
     _lib.prof_enable(None)
 

@@ -341,7 +341,7 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
     {   // independent branches of the forward pass run on two auxiliary streams (DFX_STREAMS=0 keeps everything serial)
         const char *e = getenv("DFX_STREAMS");
         m->concurrent = !(e && e[0] == '0');
-        if (m->concurrent) {
+        {
             bool good = true;
             for (int i = 0; i < 2; ++i) good = good && hipStreamCreateWithFlags(&m->aux[i], hipStreamNonBlocking) == hipSuccess;
             for (int i = 0; i < 8; ++i) good = good && hipEventCreateWithFlags(&m->ev[i], hipEventDisableTiming) == hipSuccess;
@@ -363,6 +363,11 @@ extern "C" void dfx_model_free(dfx_model *m) {
         if (m->ev[i]) (void)hipEventDestroy(m->ev[i]);
     if (m->d_w) (void)hipFree(m->d_w);
     delete m;
+}
+extern "C" int dfx_model_set_streams(dfx_model *m, int enable) {
+    if (!m) DFX_FAIL(DFX_ERR_INVALID_ARG, "null");
+    m->concurrent = enable != 0 && m->aux[0] != nullptr;
+    return DFX_OK;
 }
 extern "C" int dfx_model_cfg_get(const dfx_model *m, dfx_model_cfg *out) {
     if (!m || !out) DFX_FAIL(DFX_ERR_INVALID_ARG, "null");
@@ -506,7 +511,9 @@ static int launch_ggemm(const float *a, int lda, const float *w, int G, int Kg, 
     A.perm_T = perm_T;
     const int BN = Ng <= 16 ? 16 : (Ng <= 32 ? 32 : 64);
     A.ntn = (Ng + BN - 1) / BN;
-    const dim3 grid((unsigned)dfx_ceil_div(M, DFX_GG_BM), (unsigned)(G * A.ntn));
+    const int64_t nblk = dfx_ceil_div(dfx_ceil_div(M, DFX_GG_BM), 8) * 8 * (int64_t)(G * A.ntn);
+    if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "grouped GEMM grid too large");
+    const dim3 grid((unsigned)nblk);
     DfxKScope ks(DFX_K_GGEMM, s);
     if (BN == 16) dfx_launch(dfx_k_ggemm<16>, grid, dim3(DFX_GG_THREADS), 0, s, A);
     else if (BN == 32) dfx_launch(dfx_k_ggemm<32>, grid, dim3(DFX_GG_THREADS), 0, s, A);

@@ -93,10 +93,11 @@ __global__ void __launch_bounds__(256) dfx_k_conv_in_erb(const float *feat, cons
 // computed transposed, out^T[n][pos] = sum_c W[n][c] * u[c][pos], on v_mfma_f32_16x16x4_f32 with
 //   A = W   (lane l: row n = l&15, the persistent weight fragment, C*C/64 registers)
 //   B = u   (lane l: column pos = l&15, k = l>>4)
-// and the contraction index is enumerated so that k-step ks, k = q (q = l>>4) is channel (C/4)*q + ks: lane (pos, q) then
-// needs exactly the C/4 CONSECUTIVE channels [(C/4)q, (C/4)(q+1)) of its position, which it loads straight from HBM as
-// float4s, runs the 3-tap depthwise conv on in registers and feeds to the matrix core.  D comes back as 4 consecutive
-// output channels per lane -> float4 stores.  Per 16 positions: 3*C/16 float4 loads per lane, (C/4)*(C/16) MFMAs.
+// and the contraction index is enumerated so that k-step ks = 4*i + r, k = q (q = l>>4) is channel 16*i + 4*q + r: lane
+// (pos, q) then owns the float4s {16*i + 4*q .. +3 : i < C/16} of its position, i.e. for every i the four q-lanes of a
+// position read 64 contiguous bytes.  The lane loads them straight from HBM, runs the 3-tap depthwise conv on them in
+// registers and feeds the matrix core.  D comes back as 4 consecutive output channels per lane -> float4 stores.
+// Per 16 positions: 3*C/16 float4 loads per lane, (C/4)*(C/16) MFMAs.
 // ---------------------------------------------------------------------------------------------------------------------
 #define DFX_PW_MODE_DW3 0
 #define DFX_PW_MODE_DWT3 1
@@ -132,7 +133,7 @@ __global__ void __launch_bounds__(DFX_PW_THREADS) dfx_k_pwconv(DfxPwArgs A) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int ks = 0; ks < CPL; ++ks) areg[nt][ks] = A.wt[(CPL * q + ks) * C + 16 * nt + jl];
+        for (int ks = 0; ks < CPL; ++ks) areg[nt][ks] = A.wt[(16 * (ks >> 2) + 4 * q + (ks & 3)) * C + 16 * nt + jl];
     float4 biasr[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) biasr[nt] = reinterpret_cast<const float4 *>(A.bias)[4 * nt + q];
@@ -160,20 +161,20 @@ __global__ void __launch_bounds__(DFX_PW_THREADS) dfx_k_pwconv(DfxPwArgs A) {
                 ok = num >= 0 && (num & 1) == 0 && fi < A.Fin;
             }
             if (valid && ok) {
-                const int64_t off = (r * A.Fin + fi) * C + CPL * q;
+                const int64_t off = (r * A.Fin + fi) * C + 4 * q;
                 const float4 *xp = reinterpret_cast<const float4 *>(A.x + off);
                 const float4 *sp = reinterpret_cast<const float4 *>(A.skip + (SKIP ? off : 0));
 #pragma unroll
-                for (int v = 0; v < V4; ++v) {
-                    float4 xv = xp[v];
+                for (int v = 0; v < V4; ++v) {  // float4 v of this lane = channels 16*v + 4*q .. +3
+                    float4 xv = xp[4 * v];
                     if (SKIP) {
-                        const float4 sv = sp[v], a = sks[V4 * q + v], bb = sks[C / 4 + V4 * q + v];
+                        const float4 sv = sp[4 * v], a = sks[4 * v + q], bb = sks[C / 4 + 4 * v + q];
                         xv.x += fmaxf(a.x * sv.x + bb.x, 0.f);
                         xv.y += fmaxf(a.y * sv.y + bb.y, 0.f);
                         xv.z += fmaxf(a.z * sv.z + bb.z, 0.f);
                         xv.w += fmaxf(a.w * sv.w + bb.w, 0.f);
                     }
-                    const float4 w = dws[j * (C / 4) + V4 * q + v];
+                    const float4 w = dws[j * (C / 4) + 4 * v + q];
                     u[4 * v + 0] += w.x * xv.x;
                     u[4 * v + 1] += w.y * xv.y;
                     u[4 * v + 2] += w.z * xv.z;
@@ -403,7 +404,7 @@ __global__ void __launch_bounds__(DFX_CP_THREADS) dfx_k_df_convp(DfxCpArgs A) {
 // the BN scale are folded on the host into one dense causal conv  out[pos][n] = relu(b[n] + sum_{k<kt} sum_c W_eff[k][c][n] *
 // c0[t-kt+1+k][f][c])  (no nonlinearity sits between them, modules.py:49-71): a GEMM with K = kt*C, N = 2O padded to 16.
 // A wave owns 16 frequency bins of one clip and walks a segment of frames: the kt-frame window of c0 lives in registers as
-// the MFMA B operand (lane (bin, q) holds channels [(C/4)q, (C/4)(q+1)) of each frame), so every c0 element is read from
+// the MFMA B operand (lane (bin, q) holds channels {16i + 4q .. +3} of each frame), so every c0 element is read from
 // HBM exactly once (plus kt-1 halo frames per segment), and W_eff is the persistent A fragment (kt*C/4 registers).
 // ---------------------------------------------------------------------------------------------------------------------
 struct DfxCp2Args {
@@ -423,7 +424,7 @@ __global__ void __launch_bounds__(256) dfx_k_df_convp2(DfxCp2Args A) {
 #pragma unroll
     for (int k = 0; k < KT; ++k)
 #pragma unroll
-        for (int ks = 0; ks < CPL; ++ks) areg[k][ks] = A.weff[((size_t)(k * C + CPL * q + ks)) * 16 + jl];
+        for (int ks = 0; ks < CPL; ++ks) areg[k][ks] = A.weff[((size_t)(k * C + 16 * (ks >> 2) + 4 * q + (ks & 3))) * 16 + jl];
     float biasr[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) biasr[r] = A.bias[4 * q + r];
@@ -440,10 +441,10 @@ __global__ void __launch_bounds__(256) dfx_k_df_convp2(DfxCp2Args A) {
         float win[KT][CPL];
         auto load_frame = [&](float *dst, int64_t tau) {
             if (fvalid && tau >= 0) {
-                const float4 *p = reinterpret_cast<const float4 *>(A.c0 + ((b * A.T + tau) * A.Fd + f) * C + CPL * q);
+                const float4 *p = reinterpret_cast<const float4 *>(A.c0 + ((b * A.T + tau) * A.Fd + f) * C + 4 * q);
 #pragma unroll
-                for (int v = 0; v < V4; ++v) {
-                    const float4 x = p[v];
+                for (int v = 0; v < V4; ++v) {  // float4 v of this lane = channels 16*v + 4*q .. +3 (k-steps 4v .. 4v+3)
+                    const float4 x = p[4 * v];
                     dst[4 * v + 0] = x.x;
                     dst[4 * v + 1] = x.y;
                     dst[4 * v + 2] = x.z;
@@ -517,8 +518,15 @@ __global__ void __launch_bounds__(DFX_GG_THREADS) dfx_k_ggemm(DfxGgArgs A) {
     __shared__ float As[DFX_GG_BM * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[DFX_GG_KT * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.y / A.ntn, n0 = (blockIdx.y - g * A.ntn) * BN;
-    const int64_t m0 = (int64_t)blockIdx.x * DFX_GG_BM;
+    // 1-D grid, XCD-aware: the G*ntn column tiles of one row tile are consecutive blocks of ONE XCD (id % 8), so the row
+    // tile of A is served by that L2 after its first read and partially written output lines are merged there
+    const int ncol = A.G * A.ntn;
+    const int64_t jj = (int64_t)blockIdx.x >> 3;
+    const int64_t mt = (jj / ncol) * 8 + (blockIdx.x & 7);
+    const int yt = (int)(jj % ncol);
+    const int64_t m0 = mt * DFX_GG_BM;
+    if (m0 >= A.M) return;
+    const int g = yt / A.ntn, n0 = (yt - g * A.ntn) * BN;
     f32x4 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -101,6 +101,10 @@ class DfNet:
     def handle(self) -> C.c_void_p:
         return self._h
 
+    def set_streams(self, enable: bool) -> None:
+        """Run the independent branches of the forward pass on internal HIP streams (default) or serially."""
+        _lib.check(_lib.lib().dfx_model_set_streams(self._h, int(bool(enable))))
+
     # nn.Module-ish no-ops so that callers written against the reference keep working
     def eval(self):
         return self

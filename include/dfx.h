@@ -161,6 +161,10 @@ typedef struct dfx_model dfx_model;
 int dfx_model_create(const dfx_model_cfg *cfg, const float *blob_host, dfx_model **out);
 void dfx_model_free(dfx_model *m);
 int dfx_model_cfg_get(const dfx_model *m, dfx_model_cfg *out);
+/* The forward pass runs its independent branches (ERB encoder/decoder | DF encoder/decoder | df_convp) on internal
+ * streams, forked from and joined to the caller's stream with events.  enable = 0 serialises everything on the caller's
+ * stream (useful for per-kernel timing).  Default: enabled (environment DFX_STREAMS=0 disables at creation). */
+int dfx_model_set_streams(dfx_model *m, int enable);
 
 /* Scratch memory the caller must provide (device bytes) for a [B, T-frames] batch. */
 int dfx_model_workspace_bytes(const dfx_model *m, int64_t B, int64_t T, int64_t *bytes);
