@@ -110,21 +110,19 @@ def main() -> None:
     x = synth_audio(B, T, 100 + rank, dev)
 
     gather = world > 1 and not args.no_gather
-    ybuf = [None, None]
-    glist = None
-    if gather and rank == 0:
-        glist = [[torch.empty((B, T), dtype=torch.float32, device=dev) for _ in range(world)] for _ in range(2)]
-    pending = [None, None]
+    from deepfilternet_amd.distributed import enhance_sharded
+
+    pending = [None, None]  # the gather of step i overlaps step i+1 (RCCL runs on its own stream)
 
     def step(i: int):
         k = i & 1
-        if pending[k] is not None:  # the gather that still reads ybuf[k]
+        if pending[k] is not None:
             pending[k].wait()
             pending[k] = None
-        ybuf[k] = enhance(model, df_state, x)
         if gather:
-            pending[k] = dist.gather(ybuf[k], glist[k] if rank == 0 else None, dst=0, async_op=True)
-        return ybuf[k]
+            pending[k] = enhance_sharded(model, df_state, x, presharded=True, counts=[B] * world, gather=True, dst=0)
+            return pending[k].local
+        return enhance(model, df_state, x)
 
     def drain():
         for k in (0, 1):

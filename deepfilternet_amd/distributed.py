@@ -1,0 +1,84 @@
+"""Multi-GPU sharding of ``enhance()``: clips are independent (STFT memories, norm states and GRU h0 are
+per clip, BatchNorm is in eval mode), so the batch is split across the ranks of one node — one process per GPU — with NO
+collective on the data path.  The only exchange is the optional final gather of the finished waveforms over RCCL/xGMI
+(``torch.distributed`` backend "nccl" on ROCm; "gloo" in the CPU tests), which ``enhance_sharded`` issues asynchronously so
+that it overlaps the next batch.
+
+The reference has no distributed code at all; this module is the engine's addition above the drop-in
+boundary and keeps ``enhance``'s argument meaning: ``audio`` is the full ``[C, T]`` batch (or this rank's slice).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous slice [lo, hi) of ``n`` clips owned by ``rank``: sizes differ by at most one, lower ranks get the extra."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world: {rank}/{world}")
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class GatherHandle:
+    """Result of ``enhance_sharded(..., gather=True)``: ``wait()`` returns the full ``[C, T]`` batch on ``dst`` (None elsewhere)."""
+
+    def __init__(self, work, parts: Optional[List[torch.Tensor]], sizes: List[int], local: torch.Tensor):
+        self._work, self._parts, self._sizes, self.local = work, parts, sizes, local
+
+    def wait(self) -> Optional[torch.Tensor]:
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        if self._parts is None:
+            return None
+        return torch.cat([p[:n] for p, n in zip(self._parts, self._sizes)], dim=0)
+
+
+def enhance_sharded(model, df_state, audio: torch.Tensor, pad: bool = True, atten_lim_db: Optional[float] = None, *,
+                    group=None, presharded: bool = False, counts: Optional[List[int]] = None, gather: bool = True,
+                    dst: int = 0, enhance_fn=None):
+    """Enhance this rank's clips of ``audio`` and (optionally) gather every rank's output to ``dst``.
+
+    audio       full batch ``[C, T]`` (every rank passes the same tensor; only its own slice is touched) or, with
+                ``presharded=True``, this rank's slice only.
+    counts      with ``presharded``: clips held by every rank, if known (saves the size exchange, which synchronises the host).
+    gather      True: returns a :class:`GatherHandle` (asynchronous ``dist.gather``); False: returns the local output.
+    enhance_fn  defaults to :func:`deepfilternet_amd.enhance.enhance` (hook for tests).
+    """
+    if enhance_fn is None:
+        from .enhance import enhance as enhance_fn
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    sizes: Optional[List[int]] = None
+    if presharded:
+        mine = audio
+        if counts is not None:
+            if len(counts) != world or counts[rank] != audio.shape[0]:
+                raise ValueError("counts must list every rank's number of clips")
+            sizes = [int(c) for c in counts]
+    else:
+        lo, hi = shard_range(audio.shape[0], rank, world)
+        mine = audio[lo:hi]
+        sizes = [b - a for a, b in (shard_range(audio.shape[0], r, world) for r in range(world))]
+    y = enhance_fn(model, df_state, mine, pad=pad, atten_lim_db=atten_lim_db)
+    if not gather or world == 1:
+        return GatherHandle(None, [y], [y.shape[0]], y) if gather else y
+    if sizes is None:  # ranks may hold different numbers of clips: exchange the counts first (tiny; blocks the host once)
+        sizes_t = torch.zeros(world, dtype=torch.int64)
+        sizes_t[rank] = y.shape[0]
+        dev_sizes = sizes_t.to(y.device) if dist.get_backend(group) == "nccl" else sizes_t
+        dist.all_reduce(dev_sizes, group=group)
+        sizes = [int(v) for v in dev_sizes.cpu().tolist()]
+    nmax = max(sizes)
+    send = y
+    if y.shape[0] < nmax:  # gather needs equal shapes: pad the short ranks (at most one clip)
+        send = torch.zeros((nmax,) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
+        send[: y.shape[0]] = y
+    parts = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    work = dist.gather(send.contiguous(), parts, dst=dst, group=group, async_op=True)
+    return GatherHandle(work, parts, sizes, y)
