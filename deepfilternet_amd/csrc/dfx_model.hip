@@ -521,6 +521,31 @@ static int launch_ggemm(const float *a, int lda, const float *w, int G, int Kg, 
     DFX_LAUNCH_CHECK();
     return DFX_OK;
 }
+// GRU input projection [M,256] x [256,N] + bias on the weight-stationary kernel (N % 128 == 0), else the generic GEMM
+static int launch_proj(const float *a, const float *w, const float *bias, float *out, int64_t M, int N, hipStream_t s) {
+    if (M <= 0) return DFX_OK;
+    if (N % DFX_PJ_BN) return launch_ggemm(a, 256, w, 1, 256, N, bias, DFX_ACT_NONE, nullptr, out, N, M, s);
+    DfxPjArgs A;
+    A.a = a;
+    A.w = w;
+    A.bias = bias;
+    A.out = out;
+    A.M = M;
+    A.N = N;
+    A.ncol = N / DFX_PJ_BN;
+    const int64_t max_groups = dfx_ceil_div(dfx_ceil_div(M, 16), 4);
+    int64_t rg = dfx_env_num_cus() / A.ncol;  // one workgroup per CU (147 KB of LDS each)
+    if (rg < 1) rg = 1;
+    if (rg > max_groups) rg = max_groups;
+    A.rgroups = (int)rg;
+    const int64_t nblk = dfx_ceil_div(rg, 8) * 8 * A.ncol;
+    DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_proj256, DFX_PJ_SMEM));
+    DfxKScope ks(DFX_K_PROJ, s);
+    dfx_launch(dfx_k_proj256, dim3((unsigned)nblk), dim3(256), DFX_PJ_SMEM, s, A);
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
+}
+
 static int launch_glin(const dfx_model *m, const GlinW &g, const float *a, int act, const float *res, float *out, int64_t M,
                        hipStream_t s) {
     return launch_ggemm(a, g.G * g.Kg, m->p(g.w), g.G, g.Kg, g.Ng, nullptr, act, res, out, g.G * g.Ng, M, s);
@@ -535,7 +560,7 @@ static int run_gru_stack(const dfx_model *m, const std::vector<GruW> &layers, co
     float *outb = (x == bufa) ? bufb : bufa;
     for (size_t l = 0; l < layers.size(); ++l) {
         const GruW &g = layers[l];
-        if (int rc = launch_ggemm(in, 256, m->p(g.wih_t), 1, 256, 768, m->p(g.bias_i), DFX_ACT_NONE, nullptr, gi, 768, R, s)) return rc;
+        if (int rc = launch_proj(in, m->p(g.wih_t), m->p(g.bias_i), gi, R, 768, s)) return rc;
         DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_rec, DFX_GRU_SMEM));
         DfxKScope ks(DFX_K_GRU_REC, s);
         dfx_launch(dfx_k_gru_rec, dim3((unsigned)dfx_ceil_div(B, DFX_GRU_ROWS)), dim3(DFX_GRU_THREADS), DFX_GRU_SMEM, s,

@@ -589,6 +589,95 @@ __global__ void __launch_bounds__(DFX_GG_THREADS) dfx_k_ggemm(DfxGgArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Dense projection with a weight-stationary LDS tile:  out[m, n] = sum_k a[m, k] * w[k, n] + bias[n]   (K = 256).
+// Used for the GRU input projections W_ih x + b (5 launches of [B*T, 256] x [256, 768] — 60 % of all GEMM flops).
+// A persistent workgroup keeps its 256 x 128 column tile of W in LDS for its whole life (147 KB, 1 workgroup per CU) and
+// streams row tiles past it: no per-tile barrier, activations never touch LDS.  Computed transposed like dfx_k_pwconv:
+//   A operand = W^T fragment read from LDS (lane (n, q): W[64q + ks][n], bank-conflict free with a 144-float row stride),
+//   B operand = x: lane (row, q) holds the 64 contiguous K values [64q, 64q+64) of its row, loaded as float4s from HBM,
+//   D = 4 consecutive output columns per lane -> float4 stores.  The next row tile is prefetched during the 512 MFMAs.
+// Grid: (N/128) column tiles x row groups, the column tiles of one row group on one XCD (its rows are L2 hits 5 of 6 times).
+// ---------------------------------------------------------------------------------------------------------------------
+#define DFX_PJ_K 256
+#define DFX_PJ_BN 128
+#define DFX_PJ_LDW (DFX_PJ_BN + 16)
+#define DFX_PJ_SMEM ((size_t)DFX_PJ_K * DFX_PJ_LDW * 4)
+struct DfxPjArgs {
+    const float *a;     // [M, 256]
+    const float *w;     // [256][N]
+    const float *bias;  // [N]
+    float *out;         // [M, N]
+    int64_t M;
+    int N, ncol, rgroups;  // ncol = N/128 column tiles, rgroups = row groups (grid = 8 * ceil(rgroups/8) * ncol)
+};
+
+__global__ void __launch_bounds__(256, 1) dfx_k_proj256(DfxPjArgs A) {
+    constexpr int K = DFX_PJ_K, BN = DFX_PJ_BN, LDW = DFX_PJ_LDW, NT = BN / 16;
+    DFX_DYN_SMEM(float, wl);  // [(ks*4 + q)][LDW]: row (ks, q) holds W[64q + ks][n0 .. n0+128)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
+    const int64_t jj = (int64_t)blockIdx.x >> 3;
+    const int64_t rg = (jj / A.ncol) * 8 + (blockIdx.x & 7);
+    const int ct = (int)(jj % A.ncol);
+    if (rg >= A.rgroups) return;
+    const int n0 = ct * BN;
+    for (int i = tid; i < K * (BN / 4); i += 256) {
+        const int k = i / (BN / 4), n4 = i - k * (BN / 4);
+        const float4 v = *reinterpret_cast<const float4 *>(A.w + (size_t)k * A.N + n0 + 4 * n4);
+        *reinterpret_cast<float4 *>(wl + ((k & 63) * 4 + (k >> 6)) * LDW + 4 * n4) = v;
+    }
+    float4 biasr[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) biasr[nt] = reinterpret_cast<const float4 *>(A.bias + n0)[4 * nt + q];
+    __syncthreads();
+    const int64_t ntiles = (A.M + 15) / 16;  // 16-row tiles; a wave takes tiles rg*4 + wave, + rgroups*4, ...
+    const int64_t tstride = (int64_t)A.rgroups * 4;
+    int64_t tile = rg * 4 + wave;
+    float4 xn[16];
+    auto load_tile = [&](int64_t tl) {
+        const int64_t m = tl * 16 + jl;
+        if (tl < ntiles && m < A.M) {
+            const float4 *p = reinterpret_cast<const float4 *>(A.a + m * K + 64 * q);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) xn[v] = p[v];
+        } else {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) xn[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    load_tile(tile);
+    const float *wfrag = wl + q * LDW + jl;  // + (ks*4)*LDW + 16*nt
+    for (; tile < ntiles; tile += tstride) {
+        float x[64];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            x[4 * v + 0] = xn[v].x;
+            x[4 * v + 1] = xn[v].y;
+            x[4 * v + 2] = xn[v].z;
+            x[4 * v + 3] = xn[v].w;
+        }
+        load_tile(tile + tstride);  // prefetch: lands while the matrix core works on this tile
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 64; ++ks) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[ks * 4 * LDW + 16 * nt], x[ks], acc[nt], 0, 0, 0);
+            if ((ks & 1) == 1) DFX_SCHED_BARRIER();  // keep the scheduler from hoisting all 512 LDS fragment reads
+        }
+        const int64_t m = tile * 16 + jl;
+        if (m < A.M) {
+            float4 *op = reinterpret_cast<float4 *>(A.out + m * A.N + n0 + 4 * q);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                op[4 * nt] = make_float4(acc[nt][0] + biasr[nt].x, acc[nt][1] + biasr[nt].y, acc[nt][2] + biasr[nt].z,
+                                         acc[nt][3] + biasr[nt].w);
+        }
+    }
+}
+
 // enc.lsnr_fc: Linear(emb -> 1) + Sigmoid, scaled to [lsnr_min, lsnr_max] (deepfilternet3.py:163-165,184).  One wave per row.
 __global__ void dfx_k_lsnr(const float *emb, const float *w, float bias, float scale, float offset, float *out, int64_t R,
                            int D) {
