@@ -612,7 +612,10 @@ struct DfxPjArgs {
     int N, ncol, rgroups;  // ncol = N/128 column tiles, rgroups = row groups (grid = 8 * ceil(rgroups/8) * ncol)
 };
 
-__global__ void __launch_bounds__(256, 1) dfx_k_proj256(DfxPjArgs A) {
+// MODE (dev ablations, tools/dev/proj_bench.hip): 0 = product; 1 = no activation loads; 2 = no LDS fragment re-reads
+#define DFX_PJ_THREADS 512  // 8 waves: two per SIMD (a single wave cannot keep the fp32 matrix pipe busy, measured 38-50 %)
+template <int MODE>
+__global__ void __launch_bounds__(DFX_PJ_THREADS, 2) dfx_k_proj256(DfxPjArgs A) {
     constexpr int K = DFX_PJ_K, BN = DFX_PJ_BN, LDW = DFX_PJ_LDW, NT = BN / 16;
     DFX_DYN_SMEM(float, wl);  // [(ks*4 + q)][LDW]: row (ks, q) holds W[64q + ks][n0 .. n0+128)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
@@ -621,60 +624,70 @@ __global__ void __launch_bounds__(256, 1) dfx_k_proj256(DfxPjArgs A) {
     const int ct = (int)(jj % A.ncol);
     if (rg >= A.rgroups) return;
     const int n0 = ct * BN;
-    for (int i = tid; i < K * (BN / 4); i += 256) {
+    for (int i = tid; i < K * (BN / 4); i += DFX_PJ_THREADS) {
         const int k = i / (BN / 4), n4 = i - k * (BN / 4);
         const float4 v = *reinterpret_cast<const float4 *>(A.w + (size_t)k * A.N + n0 + 4 * n4);
         *reinterpret_cast<float4 *>(wl + ((k & 63) * 4 + (k >> 6)) * LDW + 4 * n4) = v;
     }
-    float4 biasr[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) biasr[nt] = reinterpret_cast<const float4 *>(A.bias + n0)[4 * nt + q];
     __syncthreads();
-    const int64_t ntiles = (A.M + 15) / 16;  // 16-row tiles; a wave takes tiles rg*4 + wave, + rgroups*4, ...
-    const int64_t tstride = (int64_t)A.rgroups * 4;
-    int64_t tile = rg * 4 + wave;
-    float4 xn[16];
-    auto load_tile = [&](int64_t tl) {
+    constexpr int NW = DFX_PJ_THREADS / 64;
+    const int64_t ntiles = (A.M + 15) / 16;  // 16-row tiles; a wave takes tiles rg*NW + wave, + rgroups*NW, ...
+    const int64_t tstride = (int64_t)A.rgroups * NW;
+    const float *wfrag = wl + q * LDW + jl;  // + (ks*4)*LDW + 16*nt
+    const float4 *bias4 = reinterpret_cast<const float4 *>(A.bias + n0) + q;
+    auto load_tile = [&](float4 *dst, int64_t tl) {
         const int64_t m = tl * 16 + jl;
-        if (tl < ntiles && m < A.M) {
+        if (MODE != 1 && tl < ntiles && m < A.M) {
             const float4 *p = reinterpret_cast<const float4 *>(A.a + m * K + 64 * q);
 #pragma unroll
-            for (int v = 0; v < 16; ++v) xn[v] = p[v];
+            for (int v = 0; v < 16; ++v) dst[v] = p[v];
         } else {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) xn[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int v = 0; v < 16; ++v) dst[v] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    load_tile(tile);
-    const float *wfrag = wl + q * LDW + jl;  // + (ks*4)*LDW + 16*nt
-    for (; tile < ntiles; tile += tstride) {
-        float x[64];
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            x[4 * v + 0] = xn[v].x;
-            x[4 * v + 1] = xn[v].y;
-            x[4 * v + 2] = xn[v].z;
-            x[4 * v + 3] = xn[v].w;
-        }
-        load_tile(tile + tstride);  // prefetch: lands while the matrix core works on this tile
+    // one 16-row tile: 64 k-steps x NT MFMAs; the W^T fragments of k-step ks+1 are read from LDS while k-step ks computes
+    auto do_tile = [&](const float4 *xv, int64_t tl) {
         f32x4 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float fa[2][NT];
 #pragma unroll
-        for (int ks = 0; ks < 64; ++ks) {
+        for (int nt = 0; nt < NT; ++nt) fa[0][nt] = wfrag[16 * nt];
+        dfx_static_for<0, 64>([&](auto kc) {
+            constexpr int ks = decltype(kc)::value;
+            if constexpr (ks + 1 < 64 && MODE != 2) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[ks * 4 * LDW + 16 * nt], x[ks], acc[nt], 0, 0, 0);
-            if ((ks & 1) == 1) DFX_SCHED_BARRIER();  // keep the scheduler from hoisting all 512 LDS fragment reads
-        }
-        const int64_t m = tile * 16 + jl;
+                for (int nt = 0; nt < NT; ++nt) fa[(ks + 1) & 1][nt] = wfrag[(ks + 1) * 4 * LDW + 16 * nt];
+            }
+            const float4 x4 = xv[ks >> 2];
+            const float xk = (ks & 3) == 0 ? x4.x : (ks & 3) == 1 ? x4.y : (ks & 3) == 2 ? x4.z : x4.w;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[MODE == 2 ? 0 : (ks & 1)][nt], xk, acc[nt], 0, 0, 0);
+            DFX_SCHED_BARRIER();
+        });
+        const int64_t m = tl * 16 + jl;
         if (m < A.M) {
             float4 *op = reinterpret_cast<float4 *>(A.out + m * A.N + n0 + 4 * q);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                op[4 * nt] = make_float4(acc[nt][0] + biasr[nt].x, acc[nt][1] + biasr[nt].y, acc[nt][2] + biasr[nt].z,
-                                         acc[nt][3] + biasr[nt].w);
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 bz = bias4[4 * nt];
+                op[4 * nt] = make_float4(acc[nt][0] + bz.x, acc[nt][1] + bz.y, acc[nt][2] + bz.z, acc[nt][3] + bz.w);
+            }
         }
+    };
+    // two register buffers: the next tile's rows are in flight while the matrix core works on the current one
+    float4 xa[16], xb[16];
+    int64_t tile = rg * NW + wave;
+    load_tile(xa, tile);
+    while (tile < ntiles) {
+        load_tile(xb, tile + tstride);
+        do_tile(xa, tile);
+        tile += tstride;
+        if (tile >= ntiles) break;
+        load_tile(xa, tile + tstride);
+        do_tile(xb, tile);
+        tile += tstride;
     }
 }
 
