@@ -70,6 +70,8 @@ struct PwW {   // separable conv block: depthwise + pointwise(+BN) [+ pathway sk
 };
 struct GruW {
     size_t wih_t = 0, bias_i = 0, whh4 = 0, bhn = 0;
+    size_t wih_h3 = 0;      // W_ih as pre-scaled f16 hi/lo MFMA fragments (dfx_k_proj256_h3)
+    float wih_unscale = 1.f;
 };
 struct GlinW {
     size_t w = 0;
@@ -97,6 +99,7 @@ struct dfx_model {
     hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool concurrent = false;
+    bool exact_fp32 = false;  // DFX_EXACT_FP32=1: keep the dense contractions on the exact fp32 MFMA path
     const float *p(size_t off) const { return d_w + off; }
 };
 
@@ -196,6 +199,36 @@ bool prep_gru(Prep &P, const std::string &name, int layers, std::vector<GruW> &o
                     for (int e = 0; e < 4; ++e)
                         P.out[g.whh4 + ((((size_t)k4 * 3 + gate) * H + j) * 4 + e)] = whh[(size_t)(gate * H + j) * H + 4 * k4 + e];
         for (int j = 0; j < H; ++j) P.out[g.bhn + j] = bhh[2 * H + j];
+        {   // fp16-split fragments of W[k][n] = wih[n][k]: [n/64][kc][ct][hi,lo][lane][8], scaled by 2^e so that lo is a normal f16
+            float mx = 0.f;
+            for (size_t i = 0; i < (size_t)3 * H * H; ++i) mx = fmaxf(mx, fabsf(wih[i]));
+            int e = 0;
+            if (mx > 0.f) {
+                int ex;
+                frexpf(mx, &ex);          // mx = f * 2^ex, f in [0.5, 1)
+                e = 14 - ex;              // scaled magnitude < 2^14
+                if (e > 24) e = 24;
+                if (e < -14) e = -14;
+            }
+            const float sc = ldexpf(1.f, e);
+            g.wih_unscale = ldexpf(1.f, -e);
+            const size_t nh = (size_t)3 * H * H * 2;  // halves
+            g.wih_h3 = P.alloc(nh / 2);
+            uint16_t *dst = reinterpret_cast<uint16_t *>(&P.out[g.wih_h3]);
+            for (int ch = 0; ch < 3 * H / 64; ++ch)
+                for (int kc = 0; kc < 8; ++kc)
+                    for (int ct = 0; ct < 4; ++ct)
+                        for (int l = 0; l < 64; ++l)
+                            for (int i = 0; i < 8; ++i) {
+                                const int n = ch * 64 + ct * 16 + (l & 15), k = 32 * kc + 8 * (l >> 4) + i;
+                                const float w = wih[(size_t)n * H + k] * sc;
+                                const uint16_t hb = dfx_f32_to_f16_bits(w);
+                                const uint16_t lb = dfx_f32_to_f16_bits(w - dfx_f16_bits_to_f32(hb));
+                                const size_t frag = (((size_t)ch * 8 + kc) * 4 + ct) * 2;
+                                dst[((frag + 0) * 64 + l) * 8 + i] = hb;
+                                dst[((frag + 1) * 64 + l) * 8 + i] = lb;
+                            }
+        }
         out.push_back(g);
     }
     return true;
@@ -341,6 +374,8 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
     {   // independent branches of the forward pass run on two auxiliary streams (DFX_STREAMS=0 keeps everything serial)
         const char *e = getenv("DFX_STREAMS");
         m->concurrent = !(e && e[0] == '0');
+        const char *x = getenv("DFX_EXACT_FP32");
+        m->exact_fp32 = x && x[0] == '1';
         {
             bool good = true;
             for (int i = 0; i < 2; ++i) good = good && hipStreamCreateWithFlags(&m->aux[i], hipStreamNonBlocking) == hipSuccess;
@@ -548,6 +583,26 @@ static int launch_proj(const float *a, const float *w, const float *bias, float 
     return DFX_OK;
 }
 
+// GRU input projection on the fp16-split matrix path (K = 256, N % 64 == 0)
+static int launch_proj_h3(const dfx_model *m, const GruW &g, const float *a, float *out, int64_t M, int N, hipStream_t s) {
+    if (M <= 0) return DFX_OK;
+    DfxPhArgs A;
+    A.a = a;
+    A.wf = reinterpret_cast<const dfx_h8 *>(m->p(g.wih_h3));
+    A.bias = m->p(g.bias_i);
+    A.out = out;
+    A.M = M;
+    A.N = N;
+    A.unscale = g.wih_unscale;
+    const int64_t nblk = dfx_ceil_div(M, DFX_PH_BM);
+    if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "projection grid too large");
+    DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_proj256_h3, DFX_PH_SMEM));
+    DfxKScope ks(DFX_K_PROJ, s);
+    dfx_launch(dfx_k_proj256_h3, dim3((unsigned)nblk), dim3(DFX_PH_THREADS), DFX_PH_SMEM, s, A);
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
+}
+
 static int launch_glin(const dfx_model *m, const GlinW &g, const float *a, int act, const float *res, float *out, int64_t M,
                        hipStream_t s) {
     return launch_ggemm(a, g.G * g.Kg, m->p(g.w), g.G, g.Kg, g.Ng, nullptr, act, res, out, g.G * g.Ng, M, s);
@@ -562,7 +617,11 @@ static int run_gru_stack(const dfx_model *m, const std::vector<GruW> &layers, co
     float *outb = (x == bufa) ? bufb : bufa;
     for (size_t l = 0; l < layers.size(); ++l) {
         const GruW &g = layers[l];
-        if (int rc = launch_proj(in, m->p(g.wih_t), m->p(g.bias_i), gi, R, 768, s)) return rc;
+        if (m->exact_fp32) {
+            if (int rc = launch_proj(in, m->p(g.wih_t), m->p(g.bias_i), gi, R, 768, s)) return rc;
+        } else {
+            if (int rc = launch_proj_h3(m, g, in, gi, R, 768, s)) return rc;
+        }
         DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_rec, DFX_GRU_SMEM));
         DfxKScope ks(DFX_K_GRU_REC, s);
         dfx_launch(dfx_k_gru_rec, dim3((unsigned)dfx_ceil_div(B, DFX_GRU_ROWS)), dim3(DFX_GRU_THREADS), DFX_GRU_SMEM, s,

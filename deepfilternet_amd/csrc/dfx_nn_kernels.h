@@ -691,6 +691,89 @@ __global__ void __launch_bounds__(DFX_PJ_THREADS, 2) dfx_k_proj256(DfxPjArgs A) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Dense projection on the fp16-split matrix path ("fp16x3"):  out[m, n] = sum_k a[m, k] * w[k, n] + bias[n], K = 256.
+// Every fp32 operand is split exactly-enough into two halves (hi = f16(x), lo = f16(x - hi): 22 mantissa bits; the weights
+// are pre-scaled by a power of two so that lo stays out of the f16 subnormals) and the product is formed as
+// lo*hi + hi*lo + hi*hi on v_mfma_f32_16x16x32_f16 with fp32 accumulation: ~2^-21 relative to the fp32 result (the waveform
+// parity bar is 1e-4 RMS; measured end to end: unchanged to 1e-7) at 16/3 x the fp32 MFMA rate, which turns the GRU input
+// projections from MFMA-bound (50 GMAC each) into HBM-bound (1.05 GB each).
+// Workgroup = 128 rows (8 waves x 16 rows) x all N columns: `a` is read from HBM once; W streams from L2 through a
+// double-buffered 64 KB LDS stage per 64-column chunk, already in fragment order (one 16-byte ds_read per fragment and lane).
+// Transposed roles as in dfx_k_pwconv: A operand = W^T fragment, B operand = activations, D = 4 consecutive columns per lane.
+// ---------------------------------------------------------------------------------------------------------------------
+#define DFX_PH_THREADS 512
+#define DFX_PH_BM 128
+#define DFX_PH_NC 64
+#define DFX_PH_CHUNK_H8 (8 * 4 * 2 * 64)                 /* dfx_h8 per column chunk: [kc][ct][hi,lo][lane] */
+#define DFX_PH_SMEM ((size_t)2 * DFX_PH_CHUNK_H8 * 16)
+struct DfxPhArgs {
+    const float *a;      // [M, 256]
+    const dfx_h8 *wf;    // [N/64][8][4][2][64] fragment-ordered, pre-scaled f16 hi/lo of W[k][n]
+    const float *bias;   // [N]
+    float *out;          // [M, N]
+    int64_t M;
+    int N;
+    float unscale;       // 1 / weight scale (a power of two)
+};
+
+__global__ void __launch_bounds__(DFX_PH_THREADS, 2) dfx_k_proj256_h3(DfxPhArgs A) {
+    DFX_DYN_SMEM(dfx_h8, ws);  // [2][DFX_PH_CHUNK_H8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
+    const int nchunks = A.N / DFX_PH_NC;
+    const int64_t m = (int64_t)blockIdx.x * DFX_PH_BM + 16 * wave + jl;
+    constexpr int PER_T = DFX_PH_CHUNK_H8 / DFX_PH_THREADS;  // 8 x 16 bytes per thread and chunk
+    // stage chunk 0
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) ws[i * DFX_PH_THREADS + tid] = A.wf[i * DFX_PH_THREADS + tid];
+    // this lane's B operands: row m, k = 32*kc + 8*q .. +7
+    dfx_h8 xh[8], xl[8];
+    {
+        const bool ok = m < A.M;
+        const float4 *p = reinterpret_cast<const float4 *>(A.a + (ok ? m : 0) * 256 + 8 * q);
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            float x[8];
+            const float4 u = ok ? p[8 * kc] : make_float4(0.f, 0.f, 0.f, 0.f), v = ok ? p[8 * kc + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+            x[0] = u.x, x[1] = u.y, x[2] = u.z, x[3] = u.w, x[4] = v.x, x[5] = v.y, x[6] = v.z, x[7] = v.w;
+            dfx_split8(x, xh[kc], xl[kc]);
+        }
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const dfx_h8 *wc = ws + (size_t)(c & 1) * DFX_PH_CHUNK_H8;
+        dfx_h8 pre[PER_T];
+        if (c + 1 < nchunks) {
+            const dfx_h8 *src = A.wf + (size_t)(c + 1) * DFX_PH_CHUNK_H8;
+#pragma unroll
+            for (int i = 0; i < PER_T; ++i) pre[i] = src[i * DFX_PH_THREADS + tid];
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                const dfx_h8 whi = wc[((kc * 4 + ct) * 2 + 0) * 64 + lane], wlo = wc[((kc * 4 + ct) * 2 + 1) * 64 + lane];
+                acc = dfx_mfma_16x16x32_f16(wlo, xh[kc], acc);
+                acc = dfx_mfma_16x16x32_f16(whi, xl[kc], acc);
+                acc = dfx_mfma_16x16x32_f16(whi, xh[kc], acc);
+            }
+            if (m < A.M) {
+                const int n = c * DFX_PH_NC + 16 * ct + 4 * q;
+                const float4 bz = *reinterpret_cast<const float4 *>(A.bias + n);
+                *reinterpret_cast<float4 *>(A.out + m * A.N + n) =
+                    make_float4(acc[0] * A.unscale + bz.x, acc[1] * A.unscale + bz.y, acc[2] * A.unscale + bz.z, acc[3] * A.unscale + bz.w);
+            }
+        }
+        if (c + 1 < nchunks) {
+            dfx_h8 *dst = ws + (size_t)((c + 1) & 1) * DFX_PH_CHUNK_H8;
+#pragma unroll
+            for (int i = 0; i < PER_T; ++i) dst[i * DFX_PH_THREADS + tid] = pre[i];
+        }
+        __syncthreads();
+    }
+}
+
 // enc.lsnr_fc: Linear(emb -> 1) + Sigmoid, scaled to [lsnr_min, lsnr_max] (deepfilternet3.py:163-165,184).  One wave per row.
 __global__ void dfx_k_lsnr(const float *emb, const float *w, float bias, float scale, float offset, float *out, int64_t R,
                            int D) {

@@ -41,6 +41,34 @@ static inline hipError_t dfx_env_set_max_dyn_smem(const void *func, size_t bytes
     return hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// ---- fp16 split ("fp16x3") MFMA helpers: x = hi + lo with hi = f16(x), lo = f16(x - hi) carries 22 mantissa bits; the three
+// products hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 (fp32 accumulate, f16 x f16 products are exact in fp32)
+// reproduce an fp32 dot product to ~2^-21 relative at 16/3 x the fp32 MFMA rate.
+typedef _Float16 dfx_h8 __attribute__((ext_vector_type(8)));
+static __device__ __host__ __forceinline__ uint16_t dfx_f32_to_f16_bits(float x) {
+    const _Float16 h = (_Float16)x;  // round to nearest even
+    uint16_t b;
+    __builtin_memcpy(&b, &h, 2);
+    return b;
+}
+static __device__ __host__ __forceinline__ float dfx_f16_bits_to_f32(uint16_t b) {
+    _Float16 h;
+    __builtin_memcpy(&h, &b, 2);
+    return (float)h;
+}
+static __device__ __forceinline__ void dfx_split8(const float *x, dfx_h8 &hi, dfx_h8 &lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const _Float16 h = (_Float16)x[i];
+        hi[i] = h;
+        lo[i] = (_Float16)(x[i] - (float)h);
+    }
+}
+// D[i][j] += sum_k A[i][k] B[k][j]; lane l: A row i = l&15, B col j = l&15, both hold k = 8*(l>>4) .. +7; D: col = l&15, row = 4*(l>>4)+r
+static __device__ __forceinline__ f32x4 dfx_mfma_16x16x32_f16(dfx_h8 a, dfx_h8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
 // compiler fences used by the hand-scheduled kernels
 #define DFX_OPAQUE(x) asm volatile("" : "+v"(x))
 #define DFX_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)

@@ -25,7 +25,7 @@ def build(force: bool = False) -> str:
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in _deps()):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    flags = ["-O2", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+    flags = ["-O2", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mf16c", "-Wall", "-Wno-unused-function",
              "-Wno-unknown-pragmas", "-Wno-attributes", f"-I{os.path.join(REPO, 'include')}", f"-I{HERE}", f"-I{CSRC}"]
     objs, procs = [], []
     for s in SOURCES:

@@ -12,6 +12,7 @@
 // `__shared__` becomes `static` (blocks are sequential, so a function-local static is exactly per-block LDS).
 #pragma once
 
+#include <immintrin.h>
 #include <ucontext.h>
 
 #include <cmath>
@@ -433,6 +434,52 @@ static inline unsigned atomicAdd(unsigned *p, unsigned v) {
     unsigned o = *p;
     *p = o + v;
     return o;
+}
+
+// ---- fp16 helpers (the interpreter build uses the F16C conversions; same round-to-nearest-even as the GPU)
+struct alignas(16) dfx_h8 {
+    uint16_t v[8];
+    struct Ref {
+        uint16_t *p;
+        Ref &operator=(float f) {
+            *p = _cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+            return *this;
+        }
+        operator float() const { return _cvtsh_ss(*p); }
+    };
+    Ref operator[](int i) { return Ref{&v[i]}; }
+    float operator[](int i) const { return _cvtsh_ss(v[i]); }
+};
+static inline uint16_t dfx_f32_to_f16_bits(float x) { return _cvtss_sh(x, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC); }
+static inline float dfx_f16_bits_to_f32(uint16_t b) { return _cvtsh_ss(b); }
+static inline void dfx_split8(const float *x, dfx_h8 &hi, dfx_h8 &lo) {
+    for (int i = 0; i < 8; ++i) {
+        const uint16_t h = dfx_f32_to_f16_bits(x[i]);
+        hi.v[i] = h;
+        lo.v[i] = dfx_f32_to_f16_bits(x[i] - dfx_f16_bits_to_f32(h));
+    }
+}
+// v_mfma_f32_16x16x32_f16: lane l holds A[i = l&15][k = 8*(l>>4)+0..7] and B[k = 8*(l>>4)+0..7][j = l&15];
+// D[4*(l>>4)+r][l&15].  Products are exact in fp32; the accumulation order inside the instruction is unspecified (k ascending here).
+static inline f32x4 dfx_mfma_16x16x32_f16(dfx_h8 a, dfx_h8 b, f32x4 c) {
+    struct AB {
+        dfx_h8 a, b;
+    };
+    static_assert(sizeof(AB) == 32, "wave_gather slot is 32 bytes");
+    unsigned w;
+    const AB *all = hipemu::wave_gather(AB{a, b}, w);
+    auto at = [&](unsigned l) { return reinterpret_cast<const AB *>(reinterpret_cast<const uint64_t *>(all) + (size_t)l * 4); };
+    const unsigned lane = hipemu::flat_tid() % 64;
+    const unsigned j = lane & 15;
+    f32x4 d = c;
+    for (unsigned r = 0; r < 4; ++r) {
+        const unsigned i = 4 * (lane >> 4) + r;
+        float acc = c[r];
+        for (unsigned kg = 0; kg < 4; ++kg)
+            for (unsigned e = 0; e < 8; ++e) acc += dfx_f16_bits_to_f32(at(i + 16 * kg)->a.v[e]) * dfx_f16_bits_to_f32(at(j + 16 * kg)->b.v[e]);
+        d[r] = acc;
+    }
+    return d;
 }
 
 // fast-math helpers: the product maps these to the hardware approximations, the interpreter to libm
