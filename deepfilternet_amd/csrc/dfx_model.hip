@@ -72,6 +72,8 @@ struct GruW {
     size_t wih_t = 0, bias_i = 0, whh4 = 0, bhn = 0;
     size_t wih_h3 = 0;      // W_ih as pre-scaled f16 hi/lo MFMA fragments (dfx_k_proj256_h3)
     float wih_unscale = 1.f;
+    size_t whh_h3 = 0;      // W_hh as pre-scaled f16 hi/lo MFMA fragments (dfx_k_gru_rec_h3)
+    float whh_unscale = 1.f;
 };
 struct GlinW {
     size_t w = 0;
@@ -228,6 +230,36 @@ bool prep_gru(Prep &P, const std::string &name, int layers, std::vector<GruW> &o
                                 dst[((frag + 0) * 64 + l) * 8 + i] = hb;
                                 dst[((frag + 1) * 64 + l) * 8 + i] = lb;
                             }
+        }
+        {   // W_hh fragments for dfx_k_gru_rec_h3: [wave][f = kc*12 + gate*4 + s][hi,lo][lane][8]
+            float mx = 0.f;
+            for (size_t i = 0; i < (size_t)3 * H * H; ++i) mx = fmaxf(mx, fabsf(whh[i]));
+            int e = 0;
+            if (mx > 0.f) {
+                int ex;
+                frexpf(mx, &ex);
+                e = 14 - ex;
+                if (e > 24) e = 24;
+                if (e < -14) e = -14;
+            }
+            const float sc = ldexpf(1.f, e);
+            g.whh_unscale = ldexpf(1.f, -e);
+            g.whh_h3 = P.alloc((size_t)3 * H * H);  // 2 halves per weight
+            uint16_t *dst = reinterpret_cast<uint16_t *>(&P.out[g.whh_h3]);
+            for (int w = 0; w < 4; ++w)
+                for (int kc = 0; kc < 8; ++kc)
+                    for (int gate = 0; gate < 3; ++gate)
+                        for (int sub = 0; sub < 4; ++sub)
+                            for (int l = 0; l < 64; ++l)
+                                for (int i = 0; i < 8; ++i) {
+                                    const int unit = 64 * w + 16 * sub + (l & 15), k = 32 * kc + 8 * (l >> 4) + i;
+                                    const float v = whh[(size_t)(gate * H + unit) * H + k] * sc;
+                                    const uint16_t hb = dfx_f32_to_f16_bits(v);
+                                    const uint16_t lb = dfx_f32_to_f16_bits(v - dfx_f16_bits_to_f32(hb));
+                                    const size_t frag = ((size_t)w * DFX_GH_NF + kc * 12 + gate * 4 + sub) * 2;
+                                    dst[((frag + 0) * 64 + l) * 8 + i] = hb;
+                                    dst[((frag + 1) * 64 + l) * 8 + i] = lb;
+                                }
         }
         out.push_back(g);
     }
@@ -622,12 +654,29 @@ static int run_gru_stack(const dfx_model *m, const std::vector<GruW> &layers, co
         } else {
             if (int rc = launch_proj_h3(m, g, in, gi, R, 768, s)) return rc;
         }
-        DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_rec, DFX_GRU_SMEM));
-        DfxKScope ks(DFX_K_GRU_REC, s);
-        dfx_launch(dfx_k_gru_rec, dim3((unsigned)dfx_ceil_div(B, DFX_GRU_ROWS)), dim3(DFX_GRU_THREADS), DFX_GRU_SMEM, s,
-                   (const float *)gi, reinterpret_cast<const float4 *>(m->p(g.whh4)), m->p(g.bhn), (const float *)nullptr,
-                   (float *)nullptr, outb, B, T);
-        DFX_LAUNCH_CHECK();
+        if (m->exact_fp32) {
+            DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_rec, DFX_GRU_SMEM));
+            DfxKScope ks(DFX_K_GRU_REC, s);
+            dfx_launch(dfx_k_gru_rec, dim3((unsigned)dfx_ceil_div(B, DFX_GRU_ROWS)), dim3(DFX_GRU_THREADS), DFX_GRU_SMEM, s,
+                       (const float *)gi, reinterpret_cast<const float4 *>(m->p(g.whh4)), m->p(g.bhn), (const float *)nullptr,
+                       (float *)nullptr, outb, B, T);
+            DFX_LAUNCH_CHECK();
+        } else {
+            DfxGhArgs A;
+            A.gi = gi;
+            A.whf = reinterpret_cast<const dfx_h8 *>(m->p(g.whh_h3));
+            A.bhn = m->p(g.bhn);
+            A.h_in = nullptr;
+            A.h_out = nullptr;
+            A.y = outb;
+            A.B = B;
+            A.T = T;
+            A.unscale = g.whh_unscale;
+            DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_rec_h3, DFX_GH_SMEM));
+            DfxKScope ks(DFX_K_GRU_REC, s);
+            dfx_launch(dfx_k_gru_rec_h3, dim3((unsigned)dfx_ceil_div(B, DFX_GH_ROWS)), dim3(DFX_GH_THREADS), DFX_GH_SMEM, s, A);
+            DFX_LAUNCH_CHECK();
+        }
         in = outb;
         outb = (outb == bufa) ? bufb : bufa;
     }

@@ -925,3 +925,205 @@ __global__ void __launch_bounds__(DFX_GRU_THREADS, 2) dfx_k_gru_rec(const float 
 #undef DFX_GRU_ISSUE
 #undef DFX_GRU_BLOCK
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GRU recurrence on the fp16-split matrix path (default; DFX_EXACT_FP32=1 selects dfx_k_gru_rec above).
+// The per-step product h[16 rows, 256] x W_hh^T[256, 768] runs on v_mfma_f32_16x16x32_f16 as lo*hi + hi*lo + hi*hi
+// (see dfx_k_proj256_h3 for the numerics), which makes 16 clips per workgroup as cheap per step as 2 were on the VALU:
+// a layer needs B/16 workgroups (16 CUs at batch 256 instead of 128) and the chain is bound by the W_hh bytes that do
+// not fit on the CU, not by arithmetic.
+//   256 threads = 4 waves; wave w owns hidden units [64w, 64w+64) for all three gates = 12 MFMA tiles (gate g, sub-tile s).
+//   Transposed roles: A operand = W_hh fragment (lane (unit, kgrp): 8 consecutive k), B operand = h fragment (lane (row,
+//   kgrp)) read from an f16 hi/lo copy of h in LDS (row stride 528 B: conflict-free ds_read_b128); D[unit][row] leaves
+//   each lane with ONE clip and 4 consecutive units per tile -> float4 gi loads / y stores, and the lane keeps its 16
+//   h values in fp32 registers across steps (no fp32 h in LDS).
+//   The 96 fragment pairs (hi, lo: 2 KB per pair and wave) a wave consumes per step, in kc-major order, live in three
+//   places fixed at compile time: FR pairs in VGPRs, FL pairs in LDS, the rest streamed from L2 through a D-slot register
+//   ring that is refilled right after use and wraps into the next step (the weights do not depend on t).
+// ---------------------------------------------------------------------------------------------------------------------
+#define DFX_GH_ROWS 16
+#define DFX_GH_THREADS 256
+#define DFX_GH_FR 33
+#define DFX_GH_FL 15
+#define DFX_GH_NF 96
+#define DFX_GH_FS (DFX_GH_NF - DFX_GH_FR - DFX_GH_FL)
+#define DFX_GH_D 4
+#define DFX_GH_HROW 264  /* halves per row of the f16 copy of h (256 + 8 pad) */
+#define DFX_GH_SMEM_W ((size_t)DFX_GH_FL * 4 * 2 * 64 * 16)
+#define DFX_GH_SMEM (DFX_GH_SMEM_W + (size_t)2 * 2 * DFX_GH_ROWS * DFX_GH_HROW * 2)
+
+struct DfxGhSched {
+    int cls[DFX_GH_NF];   // 0 = register, 1 = LDS, 2 = streamed
+    int idx[DFX_GH_NF];   // index inside its class
+    int spos[DFX_GH_FS];  // fragment position of streamed fragment i
+};
+// uniform interleave: the resident fragments consumed between two streamed ones cover the stream's latency
+static constexpr DfxGhSched dfx_gh_make_sched() {
+    DfxGhSched sc{};
+    constexpr int R = DFX_GH_FR + DFX_GH_FL, FS = DFX_GH_FS;
+    int p = 0, nres = 0;
+    for (int st = 0; st < FS; ++st) {
+        const int hi = (st + 1) * R / FS;
+        for (; nres < hi; ++nres, ++p) {
+            // spread the LDS-resident fragments evenly among the register-resident ones
+            const bool lds = ((nres + 1) * DFX_GH_FL / R) != (nres * DFX_GH_FL / R);
+            sc.cls[p] = lds ? 1 : 0;
+            sc.idx[p] = lds ? nres * DFX_GH_FL / R : nres - (nres * DFX_GH_FL / R + (lds ? 0 : 0));
+        }
+        sc.cls[p] = 2;
+        sc.idx[p] = st;
+        sc.spos[st] = p;
+        ++p;
+    }
+    // renumber the register class densely
+    int nr = 0;
+    for (int i = 0; i < DFX_GH_NF; ++i)
+        if (sc.cls[i] == 0) sc.idx[i] = nr++;
+    return sc;
+}
+
+struct DfxGhArgs {
+    const float *gi;      // [B, T, 768]
+    const dfx_h8 *whf;    // [4 waves][96 fragments][hi, lo][64 lanes], pre-scaled
+    const float *bhn;     // [256]
+    const float *h_in;    // [B, 256] or null
+    float *h_out;         // [B, 256] or null
+    float *y;             // [B, T, 256]
+    int64_t B, T;
+    float unscale;
+};
+
+__global__ void __launch_bounds__(DFX_GH_THREADS, 1) dfx_k_gru_rec_h3(DfxGhArgs A) {
+    constexpr int H = 256, FR = DFX_GH_FR, FS = DFX_GH_FS, NF = DFX_GH_NF, D = DFX_GH_D, HROW = DFX_GH_HROW;
+    static_assert(FS % D == 0 && FS >= D, "ring slots must line up across the step boundary");
+    constexpr DfxGhSched SC = dfx_gh_make_sched();
+    DFX_DYN_SMEM(unsigned char, smraw);
+    dfx_h8 *wl = reinterpret_cast<dfx_h8 *>(smraw);                           // [FL][wave][hi,lo][lane]
+    uint16_t *h16 = reinterpret_cast<uint16_t *>(smraw + DFX_GH_SMEM_W);      // [buf][hi,lo][16][HROW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
+    const int64_t b0 = (int64_t)blockIdx.x * DFX_GH_ROWS;
+    const bool valid = b0 + jl < A.B;
+    const int64_t brow = valid ? b0 + jl : A.B - 1;
+    const dfx_h8 *wg = A.whf + (size_t)wave * NF * 2 * 64 + lane;  // fragment f, part p: wg[(f*2 + p)*64]
+    // ---- resident fragments
+    dfx_h8 wr[FR][2];
+    dfx_static_for<0, NF>([&](auto fc) {
+        constexpr int f = decltype(fc)::value;
+        if constexpr (SC.cls[f] == 0) {
+            wr[SC.idx[f]][0] = wg[(f * 2 + 0) * 64];
+            wr[SC.idx[f]][1] = wg[(f * 2 + 1) * 64];
+        } else if constexpr (SC.cls[f] == 1) {
+            wl[((SC.idx[f] * 4 + wave) * 2 + 0) * 64 + lane] = wg[(f * 2 + 0) * 64];
+            wl[((SC.idx[f] * 4 + wave) * 2 + 1) * 64 + lane] = wg[(f * 2 + 1) * 64];
+        }
+    });
+    // ---- state: this lane owns clip jl, units 64*wave + 16*s + 4*q + r
+    float hp[4][4];
+    float4 bn[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int u0 = 64 * wave + 16 * s + 4 * q;
+        bn[s] = *reinterpret_cast<const float4 *>(A.bhn + u0);
+        float4 h0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (A.h_in) h0 = *reinterpret_cast<const float4 *>(A.h_in + brow * H + u0);
+        hp[s][0] = h0.x, hp[s][1] = h0.y, hp[s][2] = h0.z, hp[s][3] = h0.w;
+    }
+    auto put_h16 = [&](int buf, int s) {  // f16 hi/lo of hp[s][0..3] -> LDS (8 bytes each)
+        uint16_t hh[4], hl[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            hh[r] = dfx_f32_to_f16_bits(hp[s][r]);
+            hl[r] = dfx_f32_to_f16_bits(hp[s][r] - dfx_f16_bits_to_f32(hh[r]));
+        }
+        const int col = 64 * wave + 16 * s + 4 * q;
+        uint16_t *ph = h16 + ((size_t)(buf * 2 + 0) * DFX_GH_ROWS + jl) * HROW + col;
+        uint16_t *pl = h16 + ((size_t)(buf * 2 + 1) * DFX_GH_ROWS + jl) * HROW + col;
+        *reinterpret_cast<uint2 *>(ph) = make_uint2((uint32_t)hh[0] | ((uint32_t)hh[1] << 16), (uint32_t)hh[2] | ((uint32_t)hh[3] << 16));
+        *reinterpret_cast<uint2 *>(pl) = make_uint2((uint32_t)hl[0] | ((uint32_t)hl[1] << 16), (uint32_t)hl[2] | ((uint32_t)hl[3] << 16));
+    };
+#pragma unroll
+    for (int s = 0; s < 4; ++s) put_h16(0, s);
+    __syncthreads();
+    // ---- streamed ring
+    dfx_h8 ring[D][2];
+    dfx_static_for<0, D>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        ring[d][0] = wg[(SC.spos[d] * 2 + 0) * 64];
+        ring[d][1] = wg[(SC.spos[d] * 2 + 1) * 64];
+    });
+    const float *gp = A.gi + brow * A.T * (3 * H) + 64 * wave + 4 * q;
+    float *yp = A.y + brow * A.T * H + 64 * wave + 4 * q;
+    int cur = 0;
+    for (int64_t t = 0; t < A.T; ++t) {
+        int zoff = 0;
+        DFX_OPAQUE(zoff);  // keeps the (loop-invariant) streamed weight loads inside the time loop
+        const dfx_h8 *wst = wg + zoff;
+        // this step's input projection: 3 gates x 4 sub-tiles, lands during the matrix phase
+        float4 gv[3][4];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) gv[g][s] = *reinterpret_cast<const float4 *>(gp + t * (3 * H) + g * H + 16 * s);
+        const uint16_t *hb = h16 + (size_t)(cur * 2) * DFX_GH_ROWS * HROW + (size_t)jl * HROW + 8 * q;
+        f32x4 acc[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dfx_h8 bh[2], bl[2];
+        bh[0] = *reinterpret_cast<const dfx_h8 *>(hb);
+        bl[0] = *reinterpret_cast<const dfx_h8 *>(hb + (size_t)DFX_GH_ROWS * HROW);
+        dfx_static_for<0, NF>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            constexpr int kc = f / 12, tile = f % 12;
+            if constexpr (tile == 6 && kc + 1 < 8) {  // next k-chunk of h, half a chunk ahead
+                bh[(kc + 1) & 1] = *reinterpret_cast<const dfx_h8 *>(hb + 32 * (kc + 1));
+                bl[(kc + 1) & 1] = *reinterpret_cast<const dfx_h8 *>(hb + (size_t)DFX_GH_ROWS * HROW + 32 * (kc + 1));
+            }
+            dfx_h8 whi, wlo;
+            if constexpr (SC.cls[f] == 0) {
+                whi = wr[SC.idx[f]][0];
+                wlo = wr[SC.idx[f]][1];
+            } else if constexpr (SC.cls[f] == 1) {
+                whi = wl[((SC.idx[f] * 4 + wave) * 2 + 0) * 64 + lane];
+                wlo = wl[((SC.idx[f] * 4 + wave) * 2 + 1) * 64 + lane];
+            } else {
+                whi = ring[SC.idx[f] % D][0];
+                wlo = ring[SC.idx[f] % D][1];
+            }
+            acc[tile] = dfx_mfma_16x16x32_f16(wlo, bh[kc & 1], acc[tile]);
+            acc[tile] = dfx_mfma_16x16x32_f16(whi, bl[kc & 1], acc[tile]);
+            acc[tile] = dfx_mfma_16x16x32_f16(whi, bh[kc & 1], acc[tile]);
+            if constexpr (SC.cls[f] == 2) {
+                constexpr int nxt = SC.spos[(SC.idx[f] + D) % FS];  // wraps into the next step
+                DFX_SCHED_BARRIER();
+                ring[SC.idx[f] % D][0] = wst[(nxt * 2 + 0) * 64];
+                ring[SC.idx[f] % D][1] = wst[(nxt * 2 + 1) * 64];
+                DFX_SCHED_BARRIER();
+            }
+        });
+        // ---- gates, new state (lane: clip jl, units 64w + 16s + 4q + r)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float gr[4] = {gv[0][s].x, gv[0][s].y, gv[0][s].z, gv[0][s].w};
+            const float gz[4] = {gv[1][s].x, gv[1][s].y, gv[1][s].z, gv[1][s].w};
+            const float gn[4] = {gv[2][s].x, gv[2][s].y, gv[2][s].z, gv[2][s].w};
+            const float bb[4] = {bn[s].x, bn[s].y, bn[s].z, bn[s].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float rg = dfx_fast_rcp(1.f + dfx_fast_exp(-(gr[r] + acc[0 + s][r] * A.unscale)));
+                const float zg = dfx_fast_rcp(1.f + dfx_fast_exp(-(gz[r] + acc[4 + s][r] * A.unscale)));
+                const float pre = gn[r] + rg * (acc[8 + s][r] * A.unscale + bb[r]);
+                const float ng = 2.f * dfx_fast_rcp(1.f + dfx_fast_exp(-2.f * pre)) - 1.f;
+                hp[s][r] = (1.f - zg) * ng + zg * hp[s][r];
+            }
+            if (valid) *reinterpret_cast<float4 *>(yp + t * H + 16 * s) = make_float4(hp[s][0], hp[s][1], hp[s][2], hp[s][3]);
+            put_h16(cur ^ 1, s);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (A.h_out && valid) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            *reinterpret_cast<float4 *>(A.h_out + brow * H + 64 * wave + 16 * s + 4 * q) = make_float4(hp[s][0], hp[s][1], hp[s][2], hp[s][3]);
+    }
+}

@@ -56,6 +56,10 @@ struct int2 {
 struct alignas(16) int4 {
     int x, y, z, w;
 };
+struct uint2 {
+    unsigned x, y;
+};
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline int2 make_int2(int x, int y) { return int2{x, y}; }
