@@ -80,6 +80,15 @@ struct GlinW {
     int G = 0, Kg = 0, Ng = 0;
 };
 
+#define DFX_MAX_LANES 4
+#define DFX_LANE_EVENTS 10
+struct DfxLane {
+    hipStream_t main = nullptr;
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t ev[DFX_LANE_EVENTS] = {};
+};
+enum { EV_START = 0, EV_C0, EV_C1, EV_C0P, EV_EMB, EV_COEFS, EV_FRONT, EV_DONE };
+
 struct dfx_model {
     dfx_model_cfg cfg{};
     float *d_w = nullptr;  // all prepared weights, one device allocation
@@ -97,10 +106,14 @@ struct dfx_model {
     size_t cp_weff = 0, cp_b16 = 0;          // df_convp, folded sliding-window form (kt <= 5)
     size_t cin_weff = 0, cin_b = 0;          // enc.df_conv0 folded into a dense 3x3 conv 2 -> C
     int cp_G = 0, cp_NO = 0;
-    // intra-forward concurrency: two auxiliary streams + fork/join events (created once; one forward at a time per handle)
-    hipStream_t aux[2] = {nullptr, nullptr};
-    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // concurrency (created once; one forward / enhance at a time per handle):
+    //   a lane = the streams of one batch chunk: `main` (only used when dfx_enhance pipelines chunks; otherwise the caller's
+    //   stream plays that role) + two auxiliary streams for the independent branches of the forward pass + fork/join events
+    DfxLane lanes[DFX_MAX_LANES];
+    hipEvent_t ev_fork = nullptr;
     bool concurrent = false;
+    bool have_streams = false;
+    int max_chunks = DFX_MAX_LANES;
     bool exact_fp32 = false;  // DFX_EXACT_FP32=1: keep the dense contractions on the exact fp32 MFMA path
     const float *p(size_t off) const { return d_w + off; }
 };
@@ -231,7 +244,7 @@ bool prep_gru(Prep &P, const std::string &name, int layers, std::vector<GruW> &o
                                 dst[((frag + 1) * 64 + l) * 8 + i] = lb;
                             }
         }
-        {   // W_hh fragments for dfx_k_gru_rec_h3: [wave][f = kc*12 + gate*4 + s][hi,lo][lane][8]
+        {   // W_hh fragments for dfx_k_gru_rec_h3: [16-unit tile][k-chunk][gate][hi,lo][lane][8]
             float mx = 0.f;
             for (size_t i = 0; i < (size_t)3 * H * H; ++i) mx = fmaxf(mx, fabsf(whh[i]));
             int e = 0;
@@ -246,20 +259,19 @@ bool prep_gru(Prep &P, const std::string &name, int layers, std::vector<GruW> &o
             g.whh_unscale = ldexpf(1.f, -e);
             g.whh_h3 = P.alloc((size_t)3 * H * H);  // 2 halves per weight
             uint16_t *dst = reinterpret_cast<uint16_t *>(&P.out[g.whh_h3]);
-            for (int w = 0; w < 4; ++w)
+            for (int ut = 0; ut < 16; ++ut)          // 16-unit tile
                 for (int kc = 0; kc < 8; ++kc)
                     for (int gate = 0; gate < 3; ++gate)
-                        for (int sub = 0; sub < 4; ++sub)
-                            for (int l = 0; l < 64; ++l)
-                                for (int i = 0; i < 8; ++i) {
-                                    const int unit = 64 * w + 16 * sub + (l & 15), k = 32 * kc + 8 * (l >> 4) + i;
-                                    const float v = whh[(size_t)(gate * H + unit) * H + k] * sc;
-                                    const uint16_t hb = dfx_f32_to_f16_bits(v);
-                                    const uint16_t lb = dfx_f32_to_f16_bits(v - dfx_f16_bits_to_f32(hb));
-                                    const size_t frag = ((size_t)w * DFX_GH_NF + kc * 12 + gate * 4 + sub) * 2;
-                                    dst[((frag + 0) * 64 + l) * 8 + i] = hb;
-                                    dst[((frag + 1) * 64 + l) * 8 + i] = lb;
-                                }
+                        for (int l = 0; l < 64; ++l)
+                            for (int i = 0; i < 8; ++i) {
+                                const int unit = 16 * ut + (l & 15), k = 32 * kc + 8 * (l >> 4) + i;
+                                const float v = whh[(size_t)(gate * H + unit) * H + k] * sc;
+                                const uint16_t hb = dfx_f32_to_f16_bits(v);
+                                const uint16_t lb = dfx_f32_to_f16_bits(v - dfx_f16_bits_to_f32(hb));
+                                const size_t frag = (((size_t)ut * 8 + kc) * 3 + gate) * 2;
+                                dst[((frag + 0) * 64 + l) * 8 + i] = hb;
+                                dst[((frag + 1) * 64 + l) * 8 + i] = lb;
+                            }
         }
         out.push_back(g);
     }
@@ -408,14 +420,21 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         m->concurrent = !(e && e[0] == '0');
         const char *x = getenv("DFX_EXACT_FP32");
         m->exact_fp32 = x && x[0] == '1';
+        const char *nc = getenv("DFX_CHUNKS");
+        if (nc && atoi(nc) >= 1) m->max_chunks = atoi(nc) < DFX_MAX_LANES ? atoi(nc) : DFX_MAX_LANES;
         {
-            bool good = true;
-            for (int i = 0; i < 2; ++i) good = good && hipStreamCreateWithFlags(&m->aux[i], hipStreamNonBlocking) == hipSuccess;
-            for (int i = 0; i < 8; ++i) good = good && hipEventCreateWithFlags(&m->ev[i], hipEventDisableTiming) == hipSuccess;
+            bool good = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) == hipSuccess;
+            for (int l = 0; l < DFX_MAX_LANES; ++l) {
+                DfxLane &ln = m->lanes[l];
+                good = good && hipStreamCreateWithFlags(&ln.main, hipStreamNonBlocking) == hipSuccess;
+                for (int i = 0; i < 2; ++i) good = good && hipStreamCreateWithFlags(&ln.aux[i], hipStreamNonBlocking) == hipSuccess;
+                for (int i = 0; i < DFX_LANE_EVENTS; ++i) good = good && hipEventCreateWithFlags(&ln.ev[i], hipEventDisableTiming) == hipSuccess;
+            }
             if (!good) {
                 dfx_model_free(m);
                 DFX_FAIL(DFX_ERR_HIP, "dfx_model_create: could not create the auxiliary streams/events");
             }
+            m->have_streams = true;
         }
     }
     *out = m;
@@ -424,16 +443,21 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
 
 extern "C" void dfx_model_free(dfx_model *m) {
     if (!m) return;
-    for (int i = 0; i < 2; ++i)
-        if (m->aux[i]) (void)hipStreamDestroy(m->aux[i]);
-    for (int i = 0; i < 8; ++i)
-        if (m->ev[i]) (void)hipEventDestroy(m->ev[i]);
+    for (int l = 0; l < DFX_MAX_LANES; ++l) {
+        DfxLane &ln = m->lanes[l];
+        if (ln.main) (void)hipStreamDestroy(ln.main);
+        for (int i = 0; i < 2; ++i)
+            if (ln.aux[i]) (void)hipStreamDestroy(ln.aux[i]);
+        for (int i = 0; i < DFX_LANE_EVENTS; ++i)
+            if (ln.ev[i]) (void)hipEventDestroy(ln.ev[i]);
+    }
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->d_w) (void)hipFree(m->d_w);
     delete m;
 }
 extern "C" int dfx_model_set_streams(dfx_model *m, int enable) {
     if (!m) DFX_FAIL(DFX_ERR_INVALID_ARG, "null");
-    m->concurrent = enable != 0 && m->aux[0] != nullptr;
+    m->concurrent = enable != 0 && m->have_streams;
     return DFX_OK;
 }
 extern "C" int dfx_model_cfg_get(const dfx_model *m, dfx_model_cfg *out) {
@@ -687,7 +711,7 @@ static int run_gru_stack(const dfx_model *m, const std::vector<GruW> &layers, co
 template <int C>
 static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float *spec, const float *feat_erb,
                         const float *feat_spec, int64_t B, int64_t T, float atten_lim, float *spec_e, float *mask_out,
-                        float *lsnr_out, float *coefs_out, float *ws, hipStream_t s) {
+                        float *lsnr_out, float *coefs_out, float *ws, hipStream_t s, const DfxLane *ln, bool signal_front) {
     const dfx_model_cfg &c = m->cfg;
     const int64_t R = B * T;
     const Ws w = plan_ws(c, R);
@@ -706,16 +730,15 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     //   x1: c0 -+- c1 ------------------------------------------------------+-- DF decoder: GRU stack, skip, (join c0p) df_out -> coefs
     //   x2:     +- df_convp -> c0p
     const bool par = m->concurrent;
-    hipStream_t x1 = par ? m->aux[0] : s, x2 = par ? m->aux[1] : s;
+    hipStream_t x1 = par ? ln->aux[0] : s, x2 = par ? ln->aux[1] : s;
     auto signal = [&](int e, hipStream_t from) -> int {
-        if (par) DFX_HIP(hipEventRecord(m->ev[e], from));
+        if (par) DFX_HIP(hipEventRecord(ln->ev[e], from));
         return DFX_OK;
     };
     auto wait = [&](int e, hipStream_t on) -> int {
-        if (par) DFX_HIP(hipStreamWaitEvent(on, m->ev[e], 0));
+        if (par) DFX_HIP(hipStreamWaitEvent(on, ln->ev[e], 0));
         return DFX_OK;
     };
-    enum { EV_START = 0, EV_C0, EV_C1, EV_C0P, EV_EMB, EV_COEFS };
     if ((rc = signal(EV_START, s)) || (rc = wait(EV_START, x1))) return rc;
     // ---- Encoder, DF branch on x1 (deepfilternet3.py:176-179)
     {
@@ -787,6 +810,9 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     if ((rc = launch_glin(m, m->fc_emb, c1, DFX_ACT_RELU, e3, emb_in, R, s))) return rc;
     // enc.emb_gru (SqueezedGRU_S :149-158)
     if ((rc = launch_glin(m, m->enc_in, emb_in, DFX_ACT_RELU, nullptr, xa, R, s))) return rc;
+    // the chip-filling front of this chunk is enqueued: the next chunk of a pipelined dfx_enhance may start its own front
+    // (it then overlaps this chunk's GRU chain, which occupies only a few CUs)
+    if (signal_front && (rc = signal(EV_FRONT, s))) return rc;
     const float *y = nullptr;
     if ((rc = run_gru_stack(m, m->enc_gru, xa, xa, xb, gi, B, T, &y, s))) return rc;
     if ((rc = launch_glin(m, m->enc_out, y, DFX_ACT_RELU, nullptr, embv, R, s))) return rc;
@@ -844,10 +870,10 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                                c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, s);
 }
 
-extern "C" int dfx_model_forward(const dfx_model *m, const dfx_bands *bands, const float *spec, const float *feat_erb,
-                                 const float *feat_spec, int64_t B, int64_t T, float atten_lim, float *spec_e,
-                                 float *mask, float *lsnr, float *df_coefs, void *workspace, int64_t workspace_bytes,
-                                 void *stream) {
+static int model_forward_lane(const dfx_model *m, const dfx_bands *bands, const float *spec, const float *feat_erb,
+                              const float *feat_spec, int64_t B, int64_t T, float atten_lim, float *spec_e, float *mask,
+                              float *lsnr, float *df_coefs, void *workspace, int64_t workspace_bytes, void *stream,
+                              const DfxLane *ln, bool signal_front) {
     if (!m || !bands || B < 0 || T < 0) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_forward: bad arguments");
     if (bands->nb != m->cfg.nb_erb || bands->F != m->cfg.fft_size / 2 + 1)
         DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_forward: band table does not match the model (nb_erb / fft_size)");
@@ -863,11 +889,20 @@ extern "C" int dfx_model_forward(const dfx_model *m, const dfx_bands *bands, con
     float *ws = reinterpret_cast<float *>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     hipStream_t s = dfx_stream(stream);
     switch (m->cfg.conv_ch) {
-        case 16: return forward_impl<16>(m, bands, spec, feat_erb, feat_spec, B, T, atten_lim, spec_e, mask, lsnr, df_coefs, ws, s);
-        case 32: return forward_impl<32>(m, bands, spec, feat_erb, feat_spec, B, T, atten_lim, spec_e, mask, lsnr, df_coefs, ws, s);
-        case 64: return forward_impl<64>(m, bands, spec, feat_erb, feat_spec, B, T, atten_lim, spec_e, mask, lsnr, df_coefs, ws, s);
+        case 16: return forward_impl<16>(m, bands, spec, feat_erb, feat_spec, B, T, atten_lim, spec_e, mask, lsnr, df_coefs, ws, s, ln, signal_front);
+        case 32: return forward_impl<32>(m, bands, spec, feat_erb, feat_spec, B, T, atten_lim, spec_e, mask, lsnr, df_coefs, ws, s, ln, signal_front);
+        case 64: return forward_impl<64>(m, bands, spec, feat_erb, feat_spec, B, T, atten_lim, spec_e, mask, lsnr, df_coefs, ws, s, ln, signal_front);
     }
     DFX_FAIL(DFX_ERR_UNSUPPORTED, "conv_ch");
+}
+
+extern "C" int dfx_model_forward(const dfx_model *m, const dfx_bands *bands, const float *spec, const float *feat_erb,
+                                 const float *feat_spec, int64_t B, int64_t T, float atten_lim, float *spec_e,
+                                 float *mask, float *lsnr, float *df_coefs, void *workspace, int64_t workspace_bytes,
+                                 void *stream) {
+    if (!m) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_forward: bad arguments");
+    return model_forward_lane(m, bands, spec, feat_erb, feat_spec, B, T, atten_lim, spec_e, mask, lsnr, df_coefs, workspace,
+                              workspace_bytes, stream, &m->lanes[0], false);
 }
 
 // ------------------------------------------------------------------------------------------------ enhance()
@@ -909,32 +944,52 @@ __global__ void dfx_k_copy_rows(const float *src, int64_t src_stride, int64_t sr
     }
 }
 
+// Batch-chunk pipelining: the GRU chain of a chunk is a long latency chain on a handful of CUs, so dfx_enhance splits the
+// batch into up to DFX_MAX_LANES chunks (multiples of the 16 clips a GRU workgroup owns), each with its own streams; the
+// chip-filling "front" (features, encoder convolutions) of chunk c+1 is released when chunk c has enqueued its front, and
+// then overlaps chunk c's GRU chain; the tails overlap likewise.  Chunks are independent clips, so results do not change.
+static int enh_chunks(const dfx_model *m, int64_t B, int64_t *sizes) {
+    int nc = 1;
+    if (m->concurrent && m->max_chunks > 1) {
+        const int64_t groups = dfx_ceil_div(B, 16);
+        nc = (int)(groups / 2 < m->max_chunks ? groups / 2 : m->max_chunks);  // at least 32 clips per chunk
+        if (nc < 1) nc = 1;
+    }
+    const int64_t groups = dfx_ceil_div(B, 16);
+    int64_t done = 0;
+    for (int c = 0; c < nc; ++c) {
+        int64_t g = groups / nc + (c < groups % nc ? 1 : 0);
+        int64_t n = g * 16;
+        if (done + n > B) n = B - done;
+        sizes[c] = n;
+        done += n;
+    }
+    return nc;
+}
+
 extern "C" int dfx_enhance_workspace_bytes(const dfx_model *m, const dfx_state *st, int64_t B, int64_t T, int pad, int64_t *bytes) {
     if (!m || !st || !bytes || B < 0 || T < 0) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_enhance_workspace_bytes: bad arguments");
-    *bytes = (int64_t)plan_enh(m, st, B, T, pad).total;
+    // sized for the finest chunking the handle may use, so toggling dfx_model_set_streams never needs a bigger workspace
+    int64_t sizes[DFX_MAX_LANES];
+    int64_t total = (int64_t)plan_enh(m, st, B, T, pad).total;
+    if (m->max_chunks > 1 && m->have_streams) {
+        const bool was = m->concurrent;
+        const_cast<dfx_model *>(m)->concurrent = true;
+        const int nc = enh_chunks(m, B, sizes);
+        const_cast<dfx_model *>(m)->concurrent = was;
+        int64_t sum = 0;
+        for (int c = 0; c < nc; ++c) sum += (int64_t)plan_enh(m, st, sizes[c], T, pad).total;
+        if (sum > total) total = sum;
+    }
+    *bytes = total;
     return DFX_OK;
 }
 
-extern "C" int dfx_enhance(const dfx_model *m, const dfx_state *st, const float *x, int64_t B, int64_t T, int pad,
-                           float atten_lim_db, float *y, void *workspace, int64_t workspace_bytes, void *stream) {
-    if (!m || !st || B < 0 || T < 0) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_enhance: bad arguments");
+static int enhance_chunk(const dfx_model *m, const dfx_state *st, const float *x, int64_t B, int64_t T, int pad, float lim,
+                         float *y, unsigned char *base, hipStream_t s, const DfxLane *ln, bool signal_front) {
     const dfx_model_cfg &c = m->cfg;
-    if (st->N != c.fft_size || st->hop != c.hop_size || st->nb != c.nb_erb)
-        DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_enhance: DF state does not match the model configuration");
-    if (pad && st->N % st->hop) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_enhance: pad requires fft_size %% hop_size == 0 (enhance.py:247)");
-    if (int rc = dfx_require_device()) return rc;
-    if (B == 0) return DFX_OK;
-    if (!x || !y || !workspace) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_enhance: null buffer");
     const EnhWs w = plan_enh(m, st, B, T, pad);
-    if (workspace_bytes < (int64_t)w.total) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_enhance: workspace too small");
-    unsigned char *base = reinterpret_cast<unsigned char *>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    hipStream_t s = dfx_stream(stream);
     const int64_t Tp = pad ? T + st->N : T, Tf = Tp / st->hop;
-    const int64_t out_len = pad ? T : Tf * st->hop;
-    if (Tf == 0) {
-        if (out_len > 0) DFX_HIP(hipMemsetAsync(y, 0, (size_t)B * out_len * 4, s));
-        return DFX_OK;
-    }
     const float *xin = x;
     int64_t xstride = T;
     if (pad) {  // F.pad(audio, (0, n_fft))  (enhance.py:230-233)
@@ -949,16 +1004,15 @@ extern "C" int dfx_enhance(const dfx_model *m, const dfx_state *st, const float 
     float *spec = reinterpret_cast<float *>(base + w.spec), *spec_e = reinterpret_cast<float *>(base + w.spec_e);
     float *fe = reinterpret_cast<float *>(base + w.feat_erb), *fs = reinterpret_cast<float *>(base + w.feat_spec);
     float *ysyn = reinterpret_cast<float *>(base + w.ysyn);
-    int rc = dfx_features(st, xin, B, Tp, xstride, c.nb_df, c.norm_alpha, spec, fe, fs, stream);
+    int rc = dfx_features(st, xin, B, Tp, xstride, c.nb_df, c.norm_alpha, spec, fe, fs, (void *)s);
     if (rc) return rc;
-    float lim = 0.f;
-    if (atten_lim_db != 0.f) lim = powf(10.f, -fabsf(atten_lim_db) / 20.f);  // enhance.py:238-239
     int64_t mb = 0;
     dfx_model_workspace_bytes(m, B, Tf, &mb);
-    rc = dfx_model_forward(m, st->bands, spec, fe, fs, B, Tf, lim, spec_e, nullptr, nullptr, nullptr, base + w.model, mb, stream);
+    rc = model_forward_lane(m, st->bands, spec, fe, fs, B, Tf, lim, spec_e, nullptr, nullptr, nullptr, base + w.model, mb,
+                            (void *)s, ln, signal_front);
     if (rc) return rc;
     if (pad) {
-        rc = dfx_synthesis(st, spec_e, B, Tf, nullptr, nullptr, ysyn, Tf * st->hop, stream);
+        rc = dfx_synthesis(st, spec_e, B, Tf, nullptr, nullptr, ysyn, Tf * st->hop, (void *)s);
         if (rc) return rc;
         const int64_t d = st->N - st->hop;  // enhance.py:248-249: audio[:, d : orig_len + d]
         DfxKScope ks(DFX_K_COPY_ROWS, s);
@@ -967,5 +1021,47 @@ extern "C" int dfx_enhance(const dfx_model *m, const dfx_state *st, const float 
         DFX_LAUNCH_CHECK();
         return DFX_OK;
     }
-    return dfx_synthesis(st, spec_e, B, Tf, nullptr, nullptr, y, Tf * st->hop, stream);
+    return dfx_synthesis(st, spec_e, B, Tf, nullptr, nullptr, y, Tf * st->hop, (void *)s);
+}
+
+extern "C" int dfx_enhance(const dfx_model *m, const dfx_state *st, const float *x, int64_t B, int64_t T, int pad,
+                           float atten_lim_db, float *y, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!m || !st || B < 0 || T < 0) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_enhance: bad arguments");
+    const dfx_model_cfg &c = m->cfg;
+    if (st->N != c.fft_size || st->hop != c.hop_size || st->nb != c.nb_erb)
+        DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_enhance: DF state does not match the model configuration");
+    if (pad && st->N % st->hop) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_enhance: pad requires fft_size %% hop_size == 0 (enhance.py:247)");
+    if (int rc = dfx_require_device()) return rc;
+    if (B == 0) return DFX_OK;
+    if (!x || !y || !workspace) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_enhance: null buffer");
+    int64_t sizes[DFX_MAX_LANES];
+    const int nc = enh_chunks(m, B, sizes);
+    int64_t need = 0;
+    for (int i = 0; i < nc; ++i) need += (int64_t)plan_enh(m, st, sizes[i], T, pad).total;
+    if (workspace_bytes < need) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_enhance: workspace too small");
+    unsigned char *base = reinterpret_cast<unsigned char *>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    hipStream_t s = dfx_stream(stream);
+    const int64_t Tp = pad ? T + st->N : T, Tf = Tp / st->hop;
+    const int64_t out_len = pad ? T : Tf * st->hop;
+    if (Tf == 0) {
+        if (out_len > 0) DFX_HIP(hipMemsetAsync(y, 0, (size_t)B * out_len * 4, s));
+        return DFX_OK;
+    }
+    float lim = 0.f;
+    if (atten_lim_db != 0.f) lim = powf(10.f, -fabsf(atten_lim_db) / 20.f);  // enhance.py:238-239
+    if (nc == 1) return enhance_chunk(m, st, x, B, T, pad, lim, y, base, s, &m->lanes[0], false);
+    // ---- pipelined chunks: fork from the caller's stream, stagger the fronts, join back
+    DFX_HIP(hipEventRecord(m->ev_fork, s));
+    int64_t row = 0;
+    for (int i = 0; i < nc; ++i) {
+        const DfxLane *ln = &m->lanes[i];
+        DFX_HIP(hipStreamWaitEvent(ln->main, m->ev_fork, 0));
+        if (i > 0) DFX_HIP(hipStreamWaitEvent(ln->main, m->lanes[i - 1].ev[EV_FRONT], 0));
+        if (int rc = enhance_chunk(m, st, x + row * T, sizes[i], T, pad, lim, y + row * out_len, base, ln->main, ln, true)) return rc;
+        DFX_HIP(hipEventRecord(ln->ev[EV_DONE], ln->main));
+        base += (plan_enh(m, st, sizes[i], T, pad).total + 255) & ~(size_t)255;
+        row += sizes[i];
+    }
+    for (int i = 0; i < nc; ++i) DFX_HIP(hipStreamWaitEvent(s, m->lanes[i].ev[EV_DONE], 0));
+    return DFX_OK;
 }

@@ -942,14 +942,28 @@ __global__ void __launch_bounds__(DFX_GRU_THREADS, 2) dfx_k_gru_rec(const float 
 //   ring that is refilled right after use and wraps into the next step (the weights do not depend on t).
 // ---------------------------------------------------------------------------------------------------------------------
 #define DFX_GH_ROWS 16
-#define DFX_GH_THREADS 256
-#define DFX_GH_FR 33
-#define DFX_GH_FL 15
-#define DFX_GH_NF 96
+#ifndef DFX_GH_ABLATE
+#define DFX_GH_ABLATE 0  /* dev ablations (tools/dev/gru_h3_bench.hip): 1 no stream refill, 2 no gi loads, 4 no matrix ops, 8 no gate math */
+#endif
+#ifndef DFX_GH_NW
+#define DFX_GH_NW 4      /* waves per workgroup: 4 (one per SIMD, 512 registers each) or 8 */
+#endif
+#define DFX_GH_THREADS (64 * DFX_GH_NW)
+#define DFX_GH_NS (16 / DFX_GH_NW)          /* 16-unit sub-tiles per gate and wave */
+#define DFX_GH_TILES (3 * DFX_GH_NS)        /* accumulator tiles per wave */
+#define DFX_GH_NF (8 * DFX_GH_TILES)        /* fragment pairs a wave consumes per step (8 k-chunks) */
+#ifndef DFX_GH_FR
+#define DFX_GH_FR 33     /* pairs per wave resident in registers */
+#endif
+#ifndef DFX_GH_FL
+#define DFX_GH_FL 15     /* pairs per wave resident in LDS */
+#endif
 #define DFX_GH_FS (DFX_GH_NF - DFX_GH_FR - DFX_GH_FL)
-#define DFX_GH_D 4
+#ifndef DFX_GH_D
+#define DFX_GH_D 4       /* ring slots for the streamed pairs */
+#endif
 #define DFX_GH_HROW 264  /* halves per row of the f16 copy of h (256 + 8 pad) */
-#define DFX_GH_SMEM_W ((size_t)DFX_GH_FL * 4 * 2 * 64 * 16)
+#define DFX_GH_SMEM_W ((size_t)DFX_GH_FL * DFX_GH_NW * 2 * 64 * 16)
 #define DFX_GH_SMEM (DFX_GH_SMEM_W + (size_t)2 * 2 * DFX_GH_ROWS * DFX_GH_HROW * 2)
 
 struct DfxGhSched {
@@ -984,7 +998,7 @@ static constexpr DfxGhSched dfx_gh_make_sched() {
 
 struct DfxGhArgs {
     const float *gi;      // [B, T, 768]
-    const dfx_h8 *whf;    // [4 waves][96 fragments][hi, lo][64 lanes], pre-scaled
+    const dfx_h8 *whf;    // [16 unit tiles][8 k-chunks][3 gates][hi, lo][64 lanes], pre-scaled (layout independent of NW)
     const float *bhn;     // [256]
     const float *h_in;    // [B, 256] or null
     float *h_out;         // [B, 256] or null
@@ -993,8 +1007,9 @@ struct DfxGhArgs {
     float unscale;
 };
 
-__global__ void __launch_bounds__(DFX_GH_THREADS, 1) dfx_k_gru_rec_h3(DfxGhArgs A) {
+__global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_rec_h3(DfxGhArgs A) {
     constexpr int H = 256, FR = DFX_GH_FR, FS = DFX_GH_FS, NF = DFX_GH_NF, D = DFX_GH_D, HROW = DFX_GH_HROW;
+    constexpr int NW = DFX_GH_NW, NS = DFX_GH_NS, TILES = DFX_GH_TILES, UW = 16 * NS;  // UW = units per wave
     static_assert(FS % D == 0 && FS >= D, "ring slots must line up across the step boundary");
     constexpr DfxGhSched SC = dfx_gh_make_sched();
     DFX_DYN_SMEM(unsigned char, smraw);
@@ -1004,25 +1019,27 @@ __global__ void __launch_bounds__(DFX_GH_THREADS, 1) dfx_k_gru_rec_h3(DfxGhArgs 
     const int64_t b0 = (int64_t)blockIdx.x * DFX_GH_ROWS;
     const bool valid = b0 + jl < A.B;
     const int64_t brow = valid ? b0 + jl : A.B - 1;
-    const dfx_h8 *wg = A.whf + (size_t)wave * NF * 2 * 64 + lane;  // fragment f, part p: wg[(f*2 + p)*64]
+    // fragment f = kc*TILES + gate*NS + s of this wave is global pair ((unit tile = wave*NS + s)*8 + kc)*3 + gate
+    const dfx_h8 *wg = A.whf + lane;
+#define DFX_GH_GIDX(f) (((((size_t)wave * NS + ((f) % TILES) % NS) * 8 + (f) / TILES) * 3 + ((f) % TILES) / NS) * 2 * 64)
     // ---- resident fragments
     dfx_h8 wr[FR][2];
     dfx_static_for<0, NF>([&](auto fc) {
         constexpr int f = decltype(fc)::value;
         if constexpr (SC.cls[f] == 0) {
-            wr[SC.idx[f]][0] = wg[(f * 2 + 0) * 64];
-            wr[SC.idx[f]][1] = wg[(f * 2 + 1) * 64];
+            wr[SC.idx[f]][0] = wg[DFX_GH_GIDX(f)];
+            wr[SC.idx[f]][1] = wg[DFX_GH_GIDX(f) + 64];
         } else if constexpr (SC.cls[f] == 1) {
-            wl[((SC.idx[f] * 4 + wave) * 2 + 0) * 64 + lane] = wg[(f * 2 + 0) * 64];
-            wl[((SC.idx[f] * 4 + wave) * 2 + 1) * 64 + lane] = wg[(f * 2 + 1) * 64];
+            wl[((SC.idx[f] * NW + wave) * 2 + 0) * 64 + lane] = wg[DFX_GH_GIDX(f)];
+            wl[((SC.idx[f] * NW + wave) * 2 + 1) * 64 + lane] = wg[DFX_GH_GIDX(f) + 64];
         }
     });
     // ---- state: this lane owns clip jl, units 64*wave + 16*s + 4*q + r
-    float hp[4][4];
-    float4 bn[4];
+    float hp[NS][4];
+    float4 bn[NS];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int u0 = 64 * wave + 16 * s + 4 * q;
+    for (int s = 0; s < NS; ++s) {
+        const int u0 = UW * wave + 16 * s + 4 * q;
         bn[s] = *reinterpret_cast<const float4 *>(A.bhn + u0);
         float4 h0 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (A.h_in) h0 = *reinterpret_cast<const float4 *>(A.h_in + brow * H + u0);
@@ -1035,85 +1052,112 @@ __global__ void __launch_bounds__(DFX_GH_THREADS, 1) dfx_k_gru_rec_h3(DfxGhArgs 
             hh[r] = dfx_f32_to_f16_bits(hp[s][r]);
             hl[r] = dfx_f32_to_f16_bits(hp[s][r] - dfx_f16_bits_to_f32(hh[r]));
         }
-        const int col = 64 * wave + 16 * s + 4 * q;
+        const int col = UW * wave + 16 * s + 4 * q;
         uint16_t *ph = h16 + ((size_t)(buf * 2 + 0) * DFX_GH_ROWS + jl) * HROW + col;
         uint16_t *pl = h16 + ((size_t)(buf * 2 + 1) * DFX_GH_ROWS + jl) * HROW + col;
         *reinterpret_cast<uint2 *>(ph) = make_uint2((uint32_t)hh[0] | ((uint32_t)hh[1] << 16), (uint32_t)hh[2] | ((uint32_t)hh[3] << 16));
         *reinterpret_cast<uint2 *>(pl) = make_uint2((uint32_t)hl[0] | ((uint32_t)hl[1] << 16), (uint32_t)hl[2] | ((uint32_t)hl[3] << 16));
     };
 #pragma unroll
-    for (int s = 0; s < 4; ++s) put_h16(0, s);
+    for (int s = 0; s < NS; ++s) put_h16(0, s);
     __syncthreads();
     // ---- streamed ring
     dfx_h8 ring[D][2];
     dfx_static_for<0, D>([&](auto dc) {
         constexpr int d = decltype(dc)::value;
-        ring[d][0] = wg[(SC.spos[d] * 2 + 0) * 64];
-        ring[d][1] = wg[(SC.spos[d] * 2 + 1) * 64];
+        ring[d][0] = wg[DFX_GH_GIDX(SC.spos[d])];
+        ring[d][1] = wg[DFX_GH_GIDX(SC.spos[d]) + 64];
     });
-    const float *gp = A.gi + brow * A.T * (3 * H) + 64 * wave + 4 * q;
-    float *yp = A.y + brow * A.T * H + 64 * wave + 4 * q;
+    const float *gp = A.gi + brow * A.T * (3 * H) + UW * wave + 4 * q;
+    float *yp = A.y + brow * A.T * H + UW * wave + 4 * q;
     int cur = 0;
+    // the input projection of a step (3 gates x 4 sub-tiles per lane) is loaded one step ahead: each sub-tile's registers are
+    // refilled for step t+1 as soon as the gate math of step t has consumed them, so the loads land during the matrix phase
+    float4 gv[3][NS];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            gv[g][s] = (A.T > 0 && !(DFX_GH_ABLATE & 2)) ? *reinterpret_cast<const float4 *>(gp + g * H + 16 * s) : make_float4(0.1f, 0.2f, 0.3f, 0.4f);
     for (int64_t t = 0; t < A.T; ++t) {
         int zoff = 0;
         DFX_OPAQUE(zoff);  // keeps the (loop-invariant) streamed weight loads inside the time loop
         const dfx_h8 *wst = wg + zoff;
-        // this step's input projection: 3 gates x 4 sub-tiles, lands during the matrix phase
-        float4 gv[3][4];
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) gv[g][s] = *reinterpret_cast<const float4 *>(gp + t * (3 * H) + g * H + 16 * s);
+        const int64_t tn = t + 1 < A.T ? t + 1 : t;
         const uint16_t *hb = h16 + (size_t)(cur * 2) * DFX_GH_ROWS * HROW + (size_t)jl * HROW + 8 * q;
-        f32x4 acc[12];
+        f32x4 acc[TILES];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < TILES; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         dfx_h8 bh[2], bl[2];
         bh[0] = *reinterpret_cast<const dfx_h8 *>(hb);
         bl[0] = *reinterpret_cast<const dfx_h8 *>(hb + (size_t)DFX_GH_ROWS * HROW);
-        dfx_static_for<0, NF>([&](auto fc) {
-            constexpr int f = decltype(fc)::value;
-            constexpr int kc = f / 12, tile = f % 12;
-            if constexpr (tile == 6 && kc + 1 < 8) {  // next k-chunk of h, half a chunk ahead
+        // three fragments (= three different accumulator tiles of one k-chunk) per group: the 9 MFMAs are issued so that
+        // consecutive ones never touch the same accumulator (a dependent 16x16x32 MFMA would wait for its predecessor)
+        dfx_static_for<0, NF / 3>([&](auto gc) {
+            constexpr int f0 = 3 * decltype(gc)::value;
+            constexpr int kc = f0 / TILES, tile0 = f0 % TILES;
+            if constexpr (tile0 == (TILES / 6) * 3 && kc + 1 < 8) {  // next k-chunk of h, half a chunk ahead
                 bh[(kc + 1) & 1] = *reinterpret_cast<const dfx_h8 *>(hb + 32 * (kc + 1));
                 bl[(kc + 1) & 1] = *reinterpret_cast<const dfx_h8 *>(hb + (size_t)DFX_GH_ROWS * HROW + 32 * (kc + 1));
             }
-            dfx_h8 whi, wlo;
-            if constexpr (SC.cls[f] == 0) {
-                whi = wr[SC.idx[f]][0];
-                wlo = wr[SC.idx[f]][1];
-            } else if constexpr (SC.cls[f] == 1) {
-                whi = wl[((SC.idx[f] * 4 + wave) * 2 + 0) * 64 + lane];
-                wlo = wl[((SC.idx[f] * 4 + wave) * 2 + 1) * 64 + lane];
-            } else {
-                whi = ring[SC.idx[f] % D][0];
-                wlo = ring[SC.idx[f] % D][1];
-            }
-            acc[tile] = dfx_mfma_16x16x32_f16(wlo, bh[kc & 1], acc[tile]);
-            acc[tile] = dfx_mfma_16x16x32_f16(whi, bl[kc & 1], acc[tile]);
-            acc[tile] = dfx_mfma_16x16x32_f16(whi, bh[kc & 1], acc[tile]);
-            if constexpr (SC.cls[f] == 2) {
-                constexpr int nxt = SC.spos[(SC.idx[f] + D) % FS];  // wraps into the next step
-                DFX_SCHED_BARRIER();
-                ring[SC.idx[f] % D][0] = wst[(nxt * 2 + 0) * 64];
-                ring[SC.idx[f] % D][1] = wst[(nxt * 2 + 1) * 64];
-                DFX_SCHED_BARRIER();
-            }
-        });
-        // ---- gates, new state (lane: clip jl, units 64w + 16s + 4q + r)
+            dfx_h8 whi[3], wlo[3];
+            dfx_static_for<0, 3>([&](auto ic) {
+                constexpr int i = decltype(ic)::value, f = f0 + i;
+                if constexpr (SC.cls[f] == 0) {
+                    whi[i] = wr[SC.idx[f]][0];
+                    wlo[i] = wr[SC.idx[f]][1];
+                } else if constexpr (SC.cls[f] == 1) {
+                    whi[i] = wl[((SC.idx[f] * NW + wave) * 2 + 0) * 64 + lane];
+                    wlo[i] = wl[((SC.idx[f] * NW + wave) * 2 + 1) * 64 + lane];
+                } else {
+                    whi[i] = ring[SC.idx[f] % D][0];
+                    wlo[i] = ring[SC.idx[f] % D][1];
+                }
+            });
+            if (!(DFX_GH_ABLATE & 4)) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+                for (int i = 0; i < 3; ++i) acc[tile0 + i] = dfx_mfma_16x16x32_f16(wlo[i], bh[kc & 1], acc[tile0 + i]);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[tile0 + i] = dfx_mfma_16x16x32_f16(whi[i], bl[kc & 1], acc[tile0 + i]);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[tile0 + i] = dfx_mfma_16x16x32_f16(whi[i], bh[kc & 1], acc[tile0 + i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[tile0 + i][0] += (float)whi[i][0] + (float)wlo[i][1] + (float)bh[kc & 1][0] + (float)bl[kc & 1][0];
+            }
+            DFX_SCHED_BARRIER();
+            dfx_static_for<0, 3>([&](auto ic) {
+                constexpr int f = f0 + decltype(ic)::value;
+                if constexpr (SC.cls[f] == 2 && !(DFX_GH_ABLATE & 1)) {
+                    constexpr int nxt = SC.spos[(SC.idx[f] + D) % FS];  // wraps into the next step
+                    ring[SC.idx[f] % D][0] = wst[DFX_GH_GIDX(nxt)];
+                    ring[SC.idx[f] % D][1] = wst[DFX_GH_GIDX(nxt) + 64];
+                }
+            });
+            DFX_SCHED_BARRIER();
+        });
+        // ---- gates, new state (lane: clip jl, units UW*w + 16s + 4q + r)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
             const float gr[4] = {gv[0][s].x, gv[0][s].y, gv[0][s].z, gv[0][s].w};
             const float gz[4] = {gv[1][s].x, gv[1][s].y, gv[1][s].z, gv[1][s].w};
             const float gn[4] = {gv[2][s].x, gv[2][s].y, gv[2][s].z, gv[2][s].w};
             const float bb[4] = {bn[s].x, bn[s].y, bn[s].z, bn[s].w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float rg = dfx_fast_rcp(1.f + dfx_fast_exp(-(gr[r] + acc[0 + s][r] * A.unscale)));
-                const float zg = dfx_fast_rcp(1.f + dfx_fast_exp(-(gz[r] + acc[4 + s][r] * A.unscale)));
-                const float pre = gn[r] + rg * (acc[8 + s][r] * A.unscale + bb[r]);
+                if (DFX_GH_ABLATE & 8) {
+                    hp[s][r] = 0.5f * hp[s][r] + 1e-3f * (gr[r] + gz[r] + gn[r] + bb[r] + acc[s][r] + acc[NS + s][r] + acc[2 * NS + s][r]);
+                    continue;
+                }
+                const float rg = dfx_fast_rcp(1.f + dfx_fast_exp(-(gr[r] + acc[0 * NS + s][r] * A.unscale)));
+                const float zg = dfx_fast_rcp(1.f + dfx_fast_exp(-(gz[r] + acc[1 * NS + s][r] * A.unscale)));
+                const float pre = gn[r] + rg * (acc[2 * NS + s][r] * A.unscale + bb[r]);
                 const float ng = 2.f * dfx_fast_rcp(1.f + dfx_fast_exp(-2.f * pre)) - 1.f;
                 hp[s][r] = (1.f - zg) * ng + zg * hp[s][r];
+            }
+            if (!(DFX_GH_ABLATE & 2)) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) gv[g][s] = *reinterpret_cast<const float4 *>(gp + tn * (3 * H) + g * H + 16 * s);
             }
             if (valid) *reinterpret_cast<float4 *>(yp + t * H + 16 * s) = make_float4(hp[s][0], hp[s][1], hp[s][2], hp[s][3]);
             put_h16(cur ^ 1, s);
@@ -1123,7 +1167,8 @@ __global__ void __launch_bounds__(DFX_GH_THREADS, 1) dfx_k_gru_rec_h3(DfxGhArgs 
     }
     if (A.h_out && valid) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            *reinterpret_cast<float4 *>(A.h_out + brow * H + 64 * wave + 16 * s + 4 * q) = make_float4(hp[s][0], hp[s][1], hp[s][2], hp[s][3]);
+        for (int s = 0; s < NS; ++s)
+            *reinterpret_cast<float4 *>(A.h_out + brow * H + UW * wave + 16 * s + 4 * q) = make_float4(hp[s][0], hp[s][1], hp[s][2], hp[s][3]);
     }
 }
+#undef DFX_GH_GIDX
