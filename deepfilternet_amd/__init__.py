@@ -4,7 +4,13 @@ Public surface mirrors the reference (DeepFilterNet/df/__init__.py:1-6 + the pyD
     from deepfilternet_amd import init_df, enhance, df_features, ModelParams
     from deepfilternet_amd import libdf          # DF, erb, erb_inv, erb_norm, unit_norm, unit_norm_init
 """
-from .config import ModelParams  # noqa: F401
+import os as _os
+
+# every GRU layer / branch of the forward pass runs on its own HIP stream; ROCm multiplexes streams onto 4 hardware queues
+# unless told otherwise, which serialises them again (must be set before the HIP runtime initialises)
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+from .config import ModelParams  # noqa: F401,E402
 
 __version__ = "0.1.0"
 __all__ = ["ModelParams", "init_df", "enhance", "df_features", "DfNet", "libdf"]

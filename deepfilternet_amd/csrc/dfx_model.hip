@@ -81,13 +81,17 @@ struct GlinW {
 };
 
 #define DFX_MAX_LANES 4
-#define DFX_LANE_EVENTS 10
+#define DFX_LANE_EVENTS 12
+#define DFX_MAX_GRU_LAYERS 8   /* all GRU layers of the three stacks */
+#define DFX_MAX_TCHUNKS 8      /* time chunks of the layer-pipelined GRU phase */
 struct DfxLane {
     hipStream_t main = nullptr;
     hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t ev[DFX_LANE_EVENTS] = {};
+    hipStream_t gs[DFX_MAX_GRU_LAYERS] = {};                      // one stream per GRU layer
+    hipEvent_t gev[DFX_MAX_GRU_LAYERS][DFX_MAX_TCHUNKS] = {};     // layer l has produced time chunk k
 };
-enum { EV_START = 0, EV_C0, EV_C1, EV_C0P, EV_EMB, EV_COEFS, EV_FRONT, EV_DONE };
+enum { EV_START = 0, EV_C0, EV_C1, EV_C0P, EV_EMB, EV_COEFS, EV_FRONT, EV_DONE, EV_XA, EV_MASK, EV_LSNR };
 
 struct dfx_model {
     dfx_model_cfg cfg{};
@@ -113,7 +117,9 @@ struct dfx_model {
     hipEvent_t ev_fork = nullptr;
     bool concurrent = false;
     bool have_streams = false;
-    int max_chunks = DFX_MAX_LANES;
+    int max_chunks = 1;       // batch chunks pipelined by dfx_enhance (DFX_CHUNKS; measured: no gain over time-chunk pipelining)
+    int tchunks = 6;          // time chunks of the layer-pipelined GRU phase (DFX_TCHUNKS)
+    int tchunk_min = 32;      // shortest chunk worth a launch (frames)
     bool exact_fp32 = false;  // DFX_EXACT_FP32=1: keep the dense contractions on the exact fp32 MFMA path
     const float *p(size_t off) const { return d_w + off; }
 };
@@ -420,6 +426,8 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         m->concurrent = !(e && e[0] == '0');
         const char *x = getenv("DFX_EXACT_FP32");
         m->exact_fp32 = x && x[0] == '1';
+        const char *tc = getenv("DFX_TCHUNKS");
+        if (tc && atoi(tc) >= 1) m->tchunks = atoi(tc) < DFX_MAX_TCHUNKS ? atoi(tc) : DFX_MAX_TCHUNKS;
         const char *nc = getenv("DFX_CHUNKS");
         if (nc && atoi(nc) >= 1) m->max_chunks = atoi(nc) < DFX_MAX_LANES ? atoi(nc) : DFX_MAX_LANES;
         {
@@ -429,6 +437,10 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
                 good = good && hipStreamCreateWithFlags(&ln.main, hipStreamNonBlocking) == hipSuccess;
                 for (int i = 0; i < 2; ++i) good = good && hipStreamCreateWithFlags(&ln.aux[i], hipStreamNonBlocking) == hipSuccess;
                 for (int i = 0; i < DFX_LANE_EVENTS; ++i) good = good && hipEventCreateWithFlags(&ln.ev[i], hipEventDisableTiming) == hipSuccess;
+                for (int i = 0; i < DFX_MAX_GRU_LAYERS; ++i) {
+                    good = good && hipStreamCreateWithFlags(&ln.gs[i], hipStreamNonBlocking) == hipSuccess;
+                    for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) good = good && hipEventCreateWithFlags(&ln.gev[i][k], hipEventDisableTiming) == hipSuccess;
+                }
             }
             if (!good) {
                 dfx_model_free(m);
@@ -450,6 +462,11 @@ extern "C" void dfx_model_free(dfx_model *m) {
             if (ln.aux[i]) (void)hipStreamDestroy(ln.aux[i]);
         for (int i = 0; i < DFX_LANE_EVENTS; ++i)
             if (ln.ev[i]) (void)hipEventDestroy(ln.ev[i]);
+        for (int i = 0; i < DFX_MAX_GRU_LAYERS; ++i) {
+            if (ln.gs[i]) (void)hipStreamDestroy(ln.gs[i]);
+            for (int k = 0; k < DFX_MAX_TCHUNKS; ++k)
+                if (ln.gev[i][k]) (void)hipEventDestroy(ln.gev[i][k]);
+        }
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->d_w) (void)hipFree(m->d_w);
@@ -458,6 +475,13 @@ extern "C" void dfx_model_free(dfx_model *m) {
 extern "C" int dfx_model_set_streams(dfx_model *m, int enable) {
     if (!m) DFX_FAIL(DFX_ERR_INVALID_ARG, "null");
     m->concurrent = enable != 0 && m->have_streams;
+    return DFX_OK;
+}
+extern "C" int dfx_model_set_pipeline(dfx_model *m, int time_chunks, int min_chunk_frames, int batch_chunks) {
+    if (!m || time_chunks < 1 || min_chunk_frames < 1 || batch_chunks < 1) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_set_pipeline: bad arguments");
+    m->tchunks = time_chunks < DFX_MAX_TCHUNKS ? time_chunks : DFX_MAX_TCHUNKS;
+    m->tchunk_min = min_chunk_frames;
+    m->max_chunks = batch_chunks < DFX_MAX_LANES ? batch_chunks : DFX_MAX_LANES;
     return DFX_OK;
 }
 extern "C" int dfx_model_cfg_get(const dfx_model *m, dfx_model_cfg *out) {
@@ -471,8 +495,9 @@ namespace {
 struct Ws {
     // offsets in floats, each 64-float (256 B) aligned
     size_t e0, e1, e2, e3, c0, c1, emb_in, emb, xa, xb, gi, xa2, xb2, gi2, demb, d3, d2, d1, mask, c0p, xdf, coefs, lsnr, total;
+    size_t pgi[DFX_MAX_GRU_LAYERS], py[DFX_MAX_GRU_LAYERS], ph[DFX_MAX_GRU_LAYERS];  // layer-pipelined GRU phase: gi, y, h state per layer
 };
-Ws plan_ws(const dfx_model_cfg &c, int64_t R) {
+Ws plan_ws(const dfx_model_cfg &c, int64_t R, int64_t B = 0) {
     Ws w{};
     size_t off = 0;
     auto take = [&](size_t n) {
@@ -504,6 +529,13 @@ Ws plan_ws(const dfx_model_cfg &c, int64_t R) {
     w.xdf = take(R * 256);
     w.coefs = take(R * Fd * NO);
     w.lsnr = take(R);
+    const int nlayers = 1 + (c.emb_num_layers - 1) + c.df_num_layers;
+    for (int l = 0; l < DFX_MAX_GRU_LAYERS; ++l) {
+        const bool used = l < nlayers;
+        w.pgi[l] = take(used ? R * 768 : 0);
+        w.py[l] = take(used ? R * 256 : 0);
+        w.ph[l] = take(used ? (B > 0 ? B : R) * 256 : 0);
+    }
     w.total = off;
     return w;
 }
@@ -511,7 +543,7 @@ Ws plan_ws(const dfx_model_cfg &c, int64_t R) {
 
 extern "C" int dfx_model_workspace_bytes(const dfx_model *m, int64_t B, int64_t T, int64_t *bytes) {
     if (!m || !bytes || B < 0 || T < 0) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_workspace_bytes: bad arguments");
-    *bytes = (int64_t)(plan_ws(m->cfg, B * T).total * sizeof(float)) + 256;
+    *bytes = (int64_t)(plan_ws(m->cfg, B * T, B).total * sizeof(float)) + 256;
     return DFX_OK;
 }
 
@@ -581,7 +613,7 @@ static int launch_convp2(const dfx_model *m, const float *c0, float *out, int64_
 
 static int launch_ggemm(const float *a, int lda, const float *w, int G, int Kg, int Ng, const float *bias, int act,
                         const float *res, float *out, int ldo, int64_t M, hipStream_t s, int perm_inner = 0, int perm_F = 0,
-                        int64_t perm_T = 1) {
+                        int64_t perm_T = 1, DfxRowMap rm = DfxRowMap{0, 0, 0}) {
     if (M <= 0) return DFX_OK;
     if (Kg % 4 || Ng % 4 || lda % 4) DFX_FAIL(DFX_ERR_UNSUPPORTED, "grouped GEMM needs K, N, lda multiples of 4 (got %d, %d, %d)", Kg, Ng, lda);
     DfxGgArgs A;
@@ -600,6 +632,7 @@ static int launch_ggemm(const float *a, int lda, const float *w, int G, int Kg, 
     A.perm_inner = perm_inner;
     A.perm_F = perm_F;
     A.perm_T = perm_T;
+    A.rm = rm;
     const int BN = Ng <= 16 ? 16 : (Ng <= 32 ? 32 : 64);
     A.ntn = (Ng + BN - 1) / BN;
     const int64_t nblk = dfx_ceil_div(dfx_ceil_div(M, DFX_GG_BM), 8) * 8 * (int64_t)(G * A.ntn);
@@ -640,7 +673,8 @@ static int launch_proj(const float *a, const float *w, const float *bias, float 
 }
 
 // GRU input projection on the fp16-split matrix path (K = 256, N % 64 == 0)
-static int launch_proj_h3(const dfx_model *m, const GruW &g, const float *a, float *out, int64_t M, int N, hipStream_t s) {
+static int launch_proj_h3(const dfx_model *m, const GruW &g, const float *a, float *out, int64_t M, int N, hipStream_t s,
+                          DfxRowMap rm = DfxRowMap{0, 0, 0}) {
     if (M <= 0) return DFX_OK;
     DfxPhArgs A;
     A.a = a;
@@ -650,6 +684,7 @@ static int launch_proj_h3(const dfx_model *m, const GruW &g, const float *a, flo
     A.M = M;
     A.N = N;
     A.unscale = g.wih_unscale;
+    A.rm = rm;
     const int64_t nblk = dfx_ceil_div(M, DFX_PH_BM);
     if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "projection grid too large");
     DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_proj256_h3, DFX_PH_SMEM));
@@ -660,8 +695,29 @@ static int launch_proj_h3(const dfx_model *m, const GruW &g, const float *a, flo
 }
 
 static int launch_glin(const dfx_model *m, const GlinW &g, const float *a, int act, const float *res, float *out, int64_t M,
-                       hipStream_t s) {
-    return launch_ggemm(a, g.G * g.Kg, m->p(g.w), g.G, g.Kg, g.Ng, nullptr, act, res, out, g.G * g.Ng, M, s);
+                       hipStream_t s, DfxRowMap rm = DfxRowMap{0, 0, 0}) {
+    return launch_ggemm(a, g.G * g.Kg, m->p(g.w), g.G, g.Kg, g.Ng, nullptr, act, res, out, g.G * g.Ng, M, s, 0, 0, 1, rm);
+}
+
+static int launch_gru_h3(const dfx_model *m, const GruW &g, const float *gi, float *y, const float *h_in, float *h_out,
+                         int64_t B, int64_t T, int64_t t0, int64_t t1, hipStream_t s) {
+    DfxGhArgs A;
+    A.gi = gi;
+    A.whf = reinterpret_cast<const dfx_h8 *>(m->p(g.whh_h3));
+    A.bhn = m->p(g.bhn);
+    A.h_in = h_in;
+    A.h_out = h_out;
+    A.y = y;
+    A.B = B;
+    A.T = T;
+    A.t0 = t0;
+    A.t1 = t1;
+    A.unscale = g.whh_unscale;
+    DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_rec_h3, DFX_GH_SMEM));
+    DfxKScope ks(DFX_K_GRU_REC, s);
+    dfx_launch(dfx_k_gru_rec_h3, dim3((unsigned)dfx_ceil_div(B, DFX_GH_ROWS)), dim3(DFX_GH_THREADS), DFX_GH_SMEM, s, A);
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
 }
 
 // SqueezedGRU_S without its linear_in/linear_out (modules.py:702-738): layers of (input projection GEMM, recurrence).
@@ -686,20 +742,7 @@ static int run_gru_stack(const dfx_model *m, const std::vector<GruW> &layers, co
                        (float *)nullptr, outb, B, T);
             DFX_LAUNCH_CHECK();
         } else {
-            DfxGhArgs A;
-            A.gi = gi;
-            A.whf = reinterpret_cast<const dfx_h8 *>(m->p(g.whh_h3));
-            A.bhn = m->p(g.bhn);
-            A.h_in = nullptr;
-            A.h_out = nullptr;
-            A.y = outb;
-            A.B = B;
-            A.T = T;
-            A.unscale = g.whh_unscale;
-            DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_rec_h3, DFX_GH_SMEM));
-            DfxKScope ks(DFX_K_GRU_REC, s);
-            dfx_launch(dfx_k_gru_rec_h3, dim3((unsigned)dfx_ceil_div(B, DFX_GH_ROWS)), dim3(DFX_GH_THREADS), DFX_GH_SMEM, s, A);
-            DFX_LAUNCH_CHECK();
+            if (int rc = launch_gru_h3(m, g, gi, outb, nullptr, nullptr, B, T, 0, T, s)) return rc;
         }
         in = outb;
         outb = (outb == bufa) ? bufb : bufa;
@@ -714,7 +757,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                         float *lsnr_out, float *coefs_out, float *ws, hipStream_t s, const DfxLane *ln, bool signal_front) {
     const dfx_model_cfg &c = m->cfg;
     const int64_t R = B * T;
-    const Ws w = plan_ws(c, R);
+    const Ws w = plan_ws(c, R, B);
     const int E = c.nb_erb, Fd = c.nb_df, O = c.df_order, NO = 2 * O, emb = C * E / 4, L = c.conv_lookahead;
     float *e0 = ws + w.e0, *e1 = ws + w.e1, *e2 = ws + w.e2, *e3 = ws + w.e3, *c0 = ws + w.c0, *c1 = ws + w.c1;
     float *emb_in = ws + w.emb_in, *embv = ws + w.emb, *xa = ws + w.xa, *xb = ws + w.xb, *gi = ws + w.gi;
@@ -813,56 +856,174 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     // the chip-filling front of this chunk is enqueued: the next chunk of a pipelined dfx_enhance may start its own front
     // (it then overlaps this chunk's GRU chain, which occupies only a few CUs)
     if (signal_front && (rc = signal(EV_FRONT, s))) return rc;
-    const float *y = nullptr;
-    if ((rc = run_gru_stack(m, m->enc_gru, xa, xa, xb, gi, B, T, &y, s))) return rc;
-    if ((rc = launch_glin(m, m->enc_out, y, DFX_ACT_RELU, nullptr, embv, R, s))) return rc;
-    if ((rc = signal(EV_EMB, s)) || (rc = wait(EV_EMB, x1))) return rc;
-    {
-        DfxKScope ks(DFX_K_LSNR, s);
-        dfx_launch(dfx_k_lsnr, dim3((unsigned)dfx_ceil_div(R * 64, 256)), dim3(256), 0, s, (const float *)embv, m->p(m->lsnr_w),
-                   m->lsnr_b, (float)(c.lsnr_max - c.lsnr_min), (float)c.lsnr_min, lsnr, R, emb);
-    }
-    DFX_LAUNCH_CHECK();
-    // ---- DfDecoder on x1 (:323-331)
-    {
-        const float *y2 = nullptr;
-        if ((rc = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, R, x1))) return rc;
-        if ((rc = run_gru_stack(m, m->df_gru, xa2, xa2, xb2, gi2, B, T, &y2, x1))) return rc;
-        const float *cfeat = y2;
-        if (c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) {
-            if ((rc = launch_glin(m, m->df_skip, embv, DFX_ACT_NONE, y2, xdf, R, x1))) return rc;
-            cfeat = xdf;
-        } else if (c.df_gru_skip == DFX_SKIP_IDENTITY) {
-            DfxKScope ks(DFX_K_ADD, x1);
-            dfx_launch(dfx_k_add, dim3((unsigned)nn_grid(dfx_ceil_div(R * 256, 256), 16)), dim3(256), 0, x1, y2, (const float *)embv,
-                       xdf, R * 256);
-            DFX_LAUNCH_CHECK();
-            cfeat = xdf;
+    // ---- GRU phase.  Layer-pipelined over time chunks when the fp16-split kernels are in use: every GRU layer has its own
+    // stream; layer l may run chunk k as soon as layer l-1 has produced chunk k (event), so the three-layer chain
+    // enc -> dec1 -> dec2 (and enc -> df1 -> df2) costs T*(1 + 2/K) steps instead of 3T.  Each layer-kernel occupies B/16
+    // CUs; the per-chunk projections and grouped linears address their rows through a DfxRowMap.
+    int K = m->tchunks;
+    if (T / K < m->tchunk_min) K = (int)(T / m->tchunk_min);
+    const int nenc = (int)m->enc_gru.size(), ndec = (int)m->dec_gru.size(), ndf = (int)m->df_gru.size();
+    const bool pipe = par && !m->exact_fp32 && K > 1 && nenc == 1 && 1 + ndec + ndf <= DFX_MAX_GRU_LAYERS;
+    if (!pipe) {
+        const float *y = nullptr;
+        if ((rc = run_gru_stack(m, m->enc_gru, xa, xa, xb, gi, B, T, &y, s))) return rc;
+        if ((rc = launch_glin(m, m->enc_out, y, DFX_ACT_RELU, nullptr, embv, R, s))) return rc;
+        if ((rc = signal(EV_EMB, s)) || (rc = wait(EV_EMB, x1))) return rc;
+        {
+            DfxKScope ks(DFX_K_LSNR, s);
+            dfx_launch(dfx_k_lsnr, dim3((unsigned)dfx_ceil_div(R * 64, 256)), dim3(256), 0, s, (const float *)embv, m->p(m->lsnr_w),
+                       m->lsnr_b, (float)(c.lsnr_max - c.lsnr_min), (float)c.lsnr_min, lsnr, R, emb);
         }
-        if ((rc = wait(EV_C0P, x1))) return rc;
-        // c = tanh(df_out(c)).view(b,t,F',2O) + c0p   (:329-330); the reference's flat index f*2O + 2n + {re,im} is stored
-        // tap-major, [B,O,T,F'][2] (DFX_COEF_BOTF == the reference's DfOutputReshapeMF layout), so the deep-filter kernel
-        // reads coefficients coalesced over f
-        if ((rc = launch_ggemm(cfeat, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg, m->df_out.Ng,
-                               nullptr, DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, R, x1, NO, Fd, T)))
-            return rc;
-        if ((rc = signal(EV_COEFS, x1))) return rc;
-    }
-    // ---- ErbDecoder on s (:245-254)
-    if ((rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, xa, R, s))) return rc;
-    if ((rc = run_gru_stack(m, m->dec_gru, xa, xa, xb, gi, B, T, &y, s))) return rc;
-    if ((rc = launch_glin(m, m->dec_out, y, DFX_ACT_RELU, nullptr, demb, R, s))) return rc;
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, R, E / 4, E / 4, 1, s))) return rc;
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, R, E / 4, E / 2, 2, s))) return rc;
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, R, E / 2, E, 2, s))) return rc;
-    {
-        const int fpt = 64 / E > 0 ? 64 / E : 1;
-        const size_t smem = ((size_t)fpt * E * (C + 1) + (size_t)fpt * E * 3 + 3 * C) * sizeof(float);
-        DfxKScope ks(DFX_K_CONV_OUT, s);
-        dfx_launch(dfx_k_conv_out<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R, fpt), 8)), dim3(DFX_CO_THREADS), smem, s,
-                   (const float *)d1, (const float *)e0, m->p(m->co_ska), m->p(m->co_skb), m->p(m->co_w), m->co_bias, mask,
-                   R, E, fpt);
         DFX_LAUNCH_CHECK();
+        // ---- DfDecoder on x1 (:323-331)
+        {
+            const float *y2 = nullptr;
+            if ((rc = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, R, x1))) return rc;
+            if ((rc = run_gru_stack(m, m->df_gru, xa2, xa2, xb2, gi2, B, T, &y2, x1))) return rc;
+            const float *cfeat = y2;
+            if (c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) {
+                if ((rc = launch_glin(m, m->df_skip, embv, DFX_ACT_NONE, y2, xdf, R, x1))) return rc;
+                cfeat = xdf;
+            } else if (c.df_gru_skip == DFX_SKIP_IDENTITY) {
+                DfxKScope ks(DFX_K_ADD, x1);
+                dfx_launch(dfx_k_add, dim3((unsigned)nn_grid(dfx_ceil_div(R * 256, 256), 16)), dim3(256), 0, x1, y2, (const float *)embv,
+                           xdf, R * 256);
+                DFX_LAUNCH_CHECK();
+                cfeat = xdf;
+            }
+            if ((rc = wait(EV_C0P, x1))) return rc;
+            // c = tanh(df_out(c)).view(b,t,F',2O) + c0p   (:329-330); the reference's flat index f*2O + 2n + {re,im} is stored
+            // tap-major, [B,O,T,F'][2] (DFX_COEF_BOTF == the reference's DfOutputReshapeMF layout), so the deep-filter kernel
+            // reads coefficients coalesced over f
+            if ((rc = launch_ggemm(cfeat, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg, m->df_out.Ng,
+                                   nullptr, DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, R, x1, NO, Fd, T)))
+                return rc;
+            if ((rc = signal(EV_COEFS, x1))) return rc;
+        }
+        // ---- ErbDecoder on s (:245-254)
+        if ((rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, xa, R, s))) return rc;
+        if ((rc = run_gru_stack(m, m->dec_gru, xa, xa, xb, gi, B, T, &y, s))) return rc;
+        if ((rc = launch_glin(m, m->dec_out, y, DFX_ACT_RELU, nullptr, demb, R, s))) return rc;
+        if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, R, E / 4, E / 4, 1, s))) return rc;
+        if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, R, E / 4, E / 2, 2, s))) return rc;
+        if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, R, E / 2, E, 2, s))) return rc;
+        {
+            const int fpt = 64 / E > 0 ? 64 / E : 1;
+            const size_t smem = ((size_t)fpt * E * (C + 1) + (size_t)fpt * E * 3 + 3 * C) * sizeof(float);
+            DfxKScope ks(DFX_K_CONV_OUT, s);
+            dfx_launch(dfx_k_conv_out<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R, fpt), 8)), dim3(DFX_CO_THREADS), smem, s,
+                       (const float *)d1, (const float *)e0, m->p(m->co_ska), m->p(m->co_skb), m->p(m->co_w), m->co_bias, mask,
+                       R, E, fpt);
+            DFX_LAUNCH_CHECK();
+        }
+    } else {
+        auto tb = [&](int k) { return (int64_t)k * T / K; };
+        auto rmk = [&](int k) { return DfxRowMap{T, tb(k + 1) - tb(k), tb(k)}; };
+        auto Mk = [&](int k) { return B * (tb(k + 1) - tb(k)); };
+        auto gwait = [&](int l, int k, hipStream_t on) -> int {
+            DFX_HIP(hipStreamWaitEvent(on, ln->gev[l][k], 0));
+            return DFX_OK;
+        };
+        auto gsig = [&](int l, int k, hipStream_t from) -> int {
+            DFX_HIP(hipEventRecord(ln->gev[l][k], from));
+            return DFX_OK;
+        };
+        // one GRU layer on one time chunk: input projection (rows of the chunk) + recurrence over [tb(k), tb(k+1))
+        auto layer_chunk = [&](const GruW &g, int l, int k, const float *xin, hipStream_t st) -> int {
+            float *gil = ws + w.pgi[l], *yl = ws + w.py[l], *hl = ws + w.ph[l];
+            if (int r2 = launch_proj_h3(m, g, xin, gil, Mk(k), 768, st, rmk(k))) return r2;
+            return launch_gru_h3(m, g, gil, yl, k == 0 ? nullptr : hl, hl, B, T, tb(k), tb(k + 1), st);
+        };
+        if ((rc = signal(EV_XA, s))) return rc;
+        // ---- encoder GRU on s: x = xa, then emb = relu(linear_out(y)) per chunk
+        for (int k = 0; k < K; ++k) {
+            if ((rc = layer_chunk(m->enc_gru[0], 0, k, xa, s))) return rc;
+            if ((rc = launch_glin(m, m->enc_out, ws + w.py[0], DFX_ACT_RELU, nullptr, embv, Mk(k), s, rmk(k)))) return rc;
+            if ((rc = gsig(0, k, s))) return rc;
+        }
+        {
+            DfxKScope ks(DFX_K_LSNR, s);
+            dfx_launch(dfx_k_lsnr, dim3((unsigned)dfx_ceil_div(R * 64, 256)), dim3(256), 0, s, (const float *)embv, m->p(m->lsnr_w),
+                       m->lsnr_b, (float)(c.lsnr_max - c.lsnr_min), (float)c.lsnr_min, lsnr, R, emb);
+        }
+        DFX_LAUNCH_CHECK();
+        // ---- ERB decoder stack: layers 1 .. ndec
+        for (int j = 0; j < ndec; ++j) {
+            const int l = 1 + j;
+            hipStream_t st = ln->gs[l];
+            DFX_HIP(hipStreamWaitEvent(st, ln->ev[EV_XA], 0));
+            for (int k = 0; k < K; ++k) {
+                if ((rc = gwait(l - 1, k, st))) return rc;
+                const float *xin = ws + w.py[l - 1];
+                if (j == 0) {  // linear_in on the encoder embedding
+                    if ((rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, xb, Mk(k), st, rmk(k)))) return rc;
+                    xin = xb;
+                }
+                if ((rc = layer_chunk(m->dec_gru[j], l, k, xin, st))) return rc;
+                if (j == ndec - 1) {
+                    if ((rc = launch_glin(m, m->dec_out, ws + w.py[l], DFX_ACT_RELU, nullptr, demb, Mk(k), st, rmk(k)))) return rc;
+                } else if ((rc = gsig(l, k, st))) return rc;
+            }
+            if (j == ndec - 1) {  // the convolutional half of the ERB decoder follows on this stream
+                if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, R, E / 4, E / 4, 1, st))) return rc;
+                if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, R, E / 4, E / 2, 2, st))) return rc;
+                if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, R, E / 2, E, 2, st))) return rc;
+                const int fpt = 64 / E > 0 ? 64 / E : 1;
+                const size_t smem = ((size_t)fpt * E * (C + 1) + (size_t)fpt * E * 3 + 3 * C) * sizeof(float);
+                {
+                    DfxKScope ks(DFX_K_CONV_OUT, st);
+                    dfx_launch(dfx_k_conv_out<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R, fpt), 8)), dim3(DFX_CO_THREADS), smem, st,
+                               (const float *)d1, (const float *)e0, m->p(m->co_ska), m->p(m->co_skb), m->p(m->co_w), m->co_bias,
+                               mask, R, E, fpt);
+                }
+                DFX_LAUNCH_CHECK();
+                if ((rc = signal(EV_MASK, st))) return rc;
+            }
+        }
+        // ---- DF decoder stack: layers 1+ndec .. ndec+ndf
+        for (int j = 0; j < ndf; ++j) {
+            const int l = 1 + ndec + j;
+            hipStream_t st = ln->gs[l];
+            DFX_HIP(hipStreamWaitEvent(st, ln->ev[EV_XA], 0));
+            if (j == ndf - 1 && (rc = wait(EV_C0P, st))) return rc;
+            for (int k = 0; k < K; ++k) {
+                if ((rc = gwait(j == 0 ? 0 : l - 1, k, st))) return rc;
+                const float *xin = ws + w.py[l - 1];
+                if (j == 0) {
+                    if ((rc = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, Mk(k), st, rmk(k)))) return rc;
+                    xin = xa2;
+                }
+                if ((rc = layer_chunk(m->df_gru[j], l, k, xin, st))) return rc;
+                if (j < ndf - 1) {
+                    if ((rc = gsig(l, k, st))) return rc;
+                } else if (c.df_gru_skip != DFX_SKIP_IDENTITY) {  // skip + df_out on this chunk's rows
+                    const float *cfeat = ws + w.py[l];
+                    if (c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) {
+                        if ((rc = launch_glin(m, m->df_skip, embv, DFX_ACT_NONE, ws + w.py[l], xdf, Mk(k), st, rmk(k)))) return rc;
+                        cfeat = xdf;
+                    }
+                    if ((rc = launch_ggemm(cfeat, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg,
+                                           m->df_out.Ng, nullptr, DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, Mk(k), st, NO, Fd,
+                                           T, rmk(k))))
+                        return rc;
+                }
+            }
+            if (j == ndf - 1) {
+                if (c.df_gru_skip == DFX_SKIP_IDENTITY) {
+                    {
+                        DfxKScope ks(DFX_K_ADD, st);
+                        dfx_launch(dfx_k_add, dim3((unsigned)nn_grid(dfx_ceil_div(R * 256, 256), 16)), dim3(256), 0, st,
+                                   (const float *)(ws + w.py[l]), (const float *)embv, xdf, R * 256);
+                    }
+                    DFX_LAUNCH_CHECK();
+                    if ((rc = launch_ggemm(xdf, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg, m->df_out.Ng,
+                                           nullptr, DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, R, st, NO, Fd, T)))
+                        return rc;
+                }
+                if ((rc = signal(EV_COEFS, st))) return rc;
+            }
+        }
+        if ((rc = wait(EV_MASK, s))) return rc;
     }
     if ((rc = wait(EV_COEFS, s))) return rc;
     // ---- Mask + MF.DF + combine + post filter + atten_lim (:426-454, enhance.py:238-240)

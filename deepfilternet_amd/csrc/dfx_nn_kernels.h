@@ -489,6 +489,17 @@ __global__ void __launch_bounds__(256) dfx_k_df_convp2(DfxCp2Args A) {
     }
 }
 
+// Row map for time-chunked launches: logical row m of a chunk of Tk frames starting at frame t0 (all B clips) is physical
+// row (m / Tk) * T + t0 + m % Tk of the [B*T, ...] activation arrays.  Tk == 0: identity.
+struct DfxRowMap {
+    int64_t T, Tk, t0;
+};
+static __device__ __forceinline__ int64_t dfx_row(const DfxRowMap &rm, int64_t m) {
+    if (rm.Tk == 0) return m;
+    const int64_t b = m / rm.Tk;
+    return b * rm.T + rm.t0 + (m - b * rm.Tk);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Grouped GEMM on the matrix cores:  out[m, g*Ng + n] = act( sum_k A[m, g*Kg + k] * W[g][k][n] + bias[g*Ng+n] ) + res[m, ...]
 // Covers GroupedLinearEinsum (modules.py:741-780; weight layout [G, I/G, H/G] used as is), the GRU input projections
@@ -508,6 +519,7 @@ struct DfxGgArgs {
     int lda, ldo, G, Kg, Ng, act, ntn /* N tiles per group */;
     int perm_inner, perm_F;  // > 0: output column j = f*inner + i of row m = b*perm_T + t is stored tap-major, [B][inner/2][T][F][2]
     int64_t perm_T;          //      (DFX_COEF_BOTF, the reference's DfOutputReshapeMF layout); out/res are then addressed without ldo
+    DfxRowMap rm;            // logical row -> physical row of a, out, res (time-chunked launches)
 };
 
 template <int BN>
@@ -538,7 +550,7 @@ __global__ void __launch_bounds__(DFX_GG_THREADS) dfx_k_ggemm(DfxGgArgs A) {
             const int64_t m = m0 + row;
             const int k = k0 + 4 * kq;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < A.M && k < A.Kg) v = *reinterpret_cast<const float4 *>(A.a + m * A.lda + g * A.Kg + k);
+            if (m < A.M && k < A.Kg) v = *reinterpret_cast<const float4 *>(A.a + dfx_row(A.rm, m) * A.lda + g * A.Kg + k);
             float *d = As + row * LDA + 4 * kq;
             d[0] = v.x;
             d[1] = v.y;
@@ -567,8 +579,9 @@ __global__ void __launch_bounds__(DFX_GG_THREADS) dfx_k_ggemm(DfxGgArgs A) {
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int64_t m = m0 + 16 * wave + 4 * (lane >> 4) + r;
-        if (m >= A.M) continue;
+        const int64_t ml = m0 + 16 * wave + 4 * (lane >> 4) + r;
+        if (ml >= A.M) continue;
+        const int64_t m = dfx_row(A.rm, ml);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int n = n0 + 16 * nt + (lane & 15);
@@ -715,13 +728,16 @@ struct DfxPhArgs {
     int64_t M;
     int N;
     float unscale;       // 1 / weight scale (a power of two)
+    DfxRowMap rm;        // logical row -> physical row of a and out
 };
 
 __global__ void __launch_bounds__(DFX_PH_THREADS, 2) dfx_k_proj256_h3(DfxPhArgs A) {
     DFX_DYN_SMEM(dfx_h8, ws);  // [2][DFX_PH_CHUNK_H8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
     const int nchunks = A.N / DFX_PH_NC;
-    const int64_t m = (int64_t)blockIdx.x * DFX_PH_BM + 16 * wave + jl;
+    const int64_t ml = (int64_t)blockIdx.x * DFX_PH_BM + 16 * wave + jl;
+    const bool ok = ml < A.M;
+    const int64_t m = ok ? dfx_row(A.rm, ml) : 0;
     constexpr int PER_T = DFX_PH_CHUNK_H8 / DFX_PH_THREADS;  // 8 x 16 bytes per thread and chunk
     // stage chunk 0
 #pragma unroll
@@ -729,8 +745,7 @@ __global__ void __launch_bounds__(DFX_PH_THREADS, 2) dfx_k_proj256_h3(DfxPhArgs 
     // this lane's B operands: row m, k = 32*kc + 8*q .. +7
     dfx_h8 xh[8], xl[8];
     {
-        const bool ok = m < A.M;
-        const float4 *p = reinterpret_cast<const float4 *>(A.a + (ok ? m : 0) * 256 + 8 * q);
+        const float4 *p = reinterpret_cast<const float4 *>(A.a + m * 256 + 8 * q);
 #pragma unroll
         for (int kc = 0; kc < 8; ++kc) {
             float x[8];
@@ -758,7 +773,7 @@ __global__ void __launch_bounds__(DFX_PH_THREADS, 2) dfx_k_proj256_h3(DfxPhArgs 
                 acc = dfx_mfma_16x16x32_f16(whi, xl[kc], acc);
                 acc = dfx_mfma_16x16x32_f16(whi, xh[kc], acc);
             }
-            if (m < A.M) {
+            if (ok) {
                 const int n = c * DFX_PH_NC + 16 * ct + 4 * q;
                 const float4 bz = *reinterpret_cast<const float4 *>(A.bias + n);
                 *reinterpret_cast<float4 *>(A.out + m * A.N + n) =
@@ -1004,6 +1019,7 @@ struct DfxGhArgs {
     float *h_out;         // [B, 256] or null
     float *y;             // [B, T, 256]
     int64_t B, T;
+    int64_t t0, t1;       // steps [t0, t1) of the T frames (time-chunked launches carry h through h_in / h_out)
     float unscale;
 };
 
@@ -1078,12 +1094,12 @@ __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_rec_h
     for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int s = 0; s < NS; ++s)
-            gv[g][s] = (A.T > 0 && !(DFX_GH_ABLATE & 2)) ? *reinterpret_cast<const float4 *>(gp + g * H + 16 * s) : make_float4(0.1f, 0.2f, 0.3f, 0.4f);
-    for (int64_t t = 0; t < A.T; ++t) {
+            gv[g][s] = (A.t1 > A.t0 && !(DFX_GH_ABLATE & 2)) ? *reinterpret_cast<const float4 *>(gp + A.t0 * (3 * H) + g * H + 16 * s) : make_float4(0.1f, 0.2f, 0.3f, 0.4f);
+    for (int64_t t = A.t0; t < A.t1; ++t) {
         int zoff = 0;
         DFX_OPAQUE(zoff);  // keeps the (loop-invariant) streamed weight loads inside the time loop
         const dfx_h8 *wst = wg + zoff;
-        const int64_t tn = t + 1 < A.T ? t + 1 : t;
+        const int64_t tn = t + 1 < A.t1 ? t + 1 : t;
         const uint16_t *hb = h16 + (size_t)(cur * 2) * DFX_GH_ROWS * HROW + (size_t)jl * HROW + 8 * q;
         f32x4 acc[TILES];
 #pragma unroll

@@ -105,6 +105,10 @@ class DfNet:
         """Run the independent branches of the forward pass on internal HIP streams (default) or serially."""
         _lib.check(_lib.lib().dfx_model_set_streams(self._h, int(bool(enable))))
 
+    def set_pipeline(self, time_chunks: int = 6, min_chunk_frames: int = 32, batch_chunks: int = 1) -> None:
+        """Time-chunk / batch-chunk pipelining knobs of the GRU phase (see dfx_model_set_pipeline in include/dfx.h)."""
+        _lib.check(_lib.lib().dfx_model_set_pipeline(self._h, int(time_chunks), int(min_chunk_frames), int(batch_chunks)))
+
     # nn.Module-ish no-ops so that callers written against the reference keep working
     def eval(self):
         return self

@@ -165,6 +165,13 @@ int dfx_model_cfg_get(const dfx_model *m, dfx_model_cfg *out);
  * streams, forked from and joined to the caller's stream with events.  enable = 0 serialises everything on the caller's
  * stream (useful for per-kernel timing).  Default: enabled (environment DFX_STREAMS=0 disables at creation). */
 int dfx_model_set_streams(dfx_model *m, int enable);
+/* Pipelining knobs (defaults 6, 32, 1; environment DFX_TCHUNKS / DFX_CHUNKS at creation):
+ *   time_chunks      the GRU phase is cut into this many time chunks and every GRU layer runs on its own stream, chunk k of
+ *                    layer l starting when layer l-1 has produced chunk k (chain = T*(1 + 2/K) steps instead of 3T);
+ *   min_chunk_frames shortest chunk worth a launch;
+ *   batch_chunks     dfx_enhance additionally pipelines this many batch chunks (multiples of 16 clips) on separate stream sets.
+ * The streams need their own hardware queues: export GPU_MAX_HW_QUEUES=16 (ROCm maps streams onto 4 queues by default). */
+int dfx_model_set_pipeline(dfx_model *m, int time_chunks, int min_chunk_frames, int batch_chunks);
 
 /* Scratch memory the caller must provide (device bytes) for a [B, T-frames] batch. */
 int dfx_model_workspace_bytes(const dfx_model *m, int64_t B, int64_t T, int64_t *bytes);
