@@ -85,7 +85,8 @@ static __device__ __forceinline__ void dfx_fft_pass(const float2 *x, float2 *y, 
 }
 
 // Complex FFT of length pl.M by one 64-lane team.  Data starts in `a`; returns the buffer that holds the result.
-// Every thread of the workgroup must call this (it contains __syncthreads); inactive teams skip the arithmetic.
+// A team is exactly one wave, so the passes only need a wave-level barrier (DFX_WAVE_SYNC): the 8 teams of a workgroup run
+// their FFTs independently instead of meeting at a workgroup barrier after every pass.
 template <int SG>
 static __device__ __forceinline__ float2 *dfx_fft_team(float2 *a, float2 *b, const float2 *tw, const DfxFftPlan &pl,
                                                        int lane, bool active) {
@@ -99,7 +100,7 @@ static __device__ __forceinline__ float2 *dfx_fft_team(float2 *a, float2 *b, con
             else if (r == 3) dfx_fft_pass<3, SG>(x, y, tw, pl.M, pl.N, ncur, s, lane);
             else dfx_fft_pass<5, SG>(x, y, tw, pl.M, pl.N, ncur, s, lane);
         }
-        __syncthreads();
+        DFX_WAVE_SYNC();
         ncur /= r;
         s *= r;
         float2 *t = x;
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_analysis(DfxAnaArgs A) 
                 bufA[k] = make_float2(v[0], v[1]);
             }
         }
-        __syncthreads();
+        DFX_WAVE_SYNC();
         float2 *Z = dfx_fft_team<-1>(bufA, bufB, tw, A.plan, lane, active);
         float2 *other = (Z == bufA) ? bufB : bufA;
         float *pw = reinterpret_cast<float *>(other);  // |X|^2 per bin for the ERB feature
@@ -184,7 +185,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_analysis(DfxAnaArgs A) 
             }
         }
         if (A.erb_db) {
-            __syncthreads();
+            DFX_WAVE_SYNC();
             if (active && lane < A.nb) {
                 // compute_band_corr (lib.rs:280-295): acc += |X|^2 * (1/width), bins in ascending order
                 const int s0 = A.band_start[lane], s1 = A.band_start[lane + 1];
@@ -201,7 +202,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_analysis(DfxAnaArgs A) 
                 A.erb_db[(b * A.Tf + t) * A.nb + e] = log10f(acc + 1e-10f) * 10.f;
             }
         }
-        __syncthreads();
+        DFX_WAVE_SYNC();
     }
 }
 
@@ -263,7 +264,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_synthesis(DfxSynArgs A)
         const float2 *Y = A.spec + (b * A.Tf + t) * F;
         for (int k = lane; k <= M; k += DFX_DSP_TEAM) bufB[k] = Y[k];
     }
-    __syncthreads();
+    DFX_WAVE_SYNC();
     if (active) {
         for (int k = lane; k < M; k += DFX_DSP_TEAM) {
             float2 xk = bufB[k], xm = bufB[M - k];
@@ -279,7 +280,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_synthesis(DfxSynArgs A)
             bufA[k] = make_float2(er - o.y, ei + o.x);
         }
     }
-    __syncthreads();
+    DFX_WAVE_SYNC();
     float2 *Z = dfx_fft_team<+1>(bufA, bufB, tw, A.plan, lane, active);
     const bool in_a = (Z == bufA);
     {

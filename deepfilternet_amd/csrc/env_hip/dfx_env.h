@@ -72,6 +72,14 @@ static __device__ __forceinline__ f32x4 dfx_mfma_16x16x32_f16(dfx_h8 a, dfx_h8 b
 // compiler fences used by the hand-scheduled kernels
 #define DFX_OPAQUE(x) asm volatile("" : "+v"(x))
 #define DFX_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// barrier + LDS visibility among the 64 lanes of ONE wave (LDS operations of a wave complete in order; the fences only pin the
+// compiler's ordering) — costs nothing compared with s_barrier across the workgroup
+#define DFX_WAVE_SYNC()                                          \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+    } while (0)
 
 static __device__ __forceinline__ float dfx_fast_exp(float x) { return __expf(x); }
 static __device__ __forceinline__ float dfx_fast_rcp(float x) { return __frcp_rn(x); }
