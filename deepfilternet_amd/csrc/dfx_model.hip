@@ -88,8 +88,12 @@ struct DfxLane {
     hipStream_t main = nullptr;
     hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t ev[DFX_LANE_EVENTS] = {};
-    hipStream_t gs[DFX_MAX_GRU_LAYERS] = {};                      // one stream per GRU layer
+    hipStream_t gs[DFX_MAX_GRU_LAYERS] = {};                      // recurrence stream of GRU layer l
+    hipStream_t ps[DFX_MAX_GRU_LAYERS] = {};                      // preparation stream of GRU layer l (linear_in, projection)
+    hipStream_t ts[2] = {};                                       // tails of the ERB / DF decoder
     hipEvent_t gev[DFX_MAX_GRU_LAYERS][DFX_MAX_TCHUNKS] = {};     // layer l has produced time chunk k
+    hipEvent_t pev[DFX_MAX_GRU_LAYERS][DFX_MAX_TCHUNKS] = {};     // gi of layer l, chunk k is ready
+    hipEvent_t eev[DFX_MAX_TCHUNKS] = {};                         // emb chunk k is ready
 };
 enum { EV_START = 0, EV_C0, EV_C1, EV_C0P, EV_EMB, EV_COEFS, EV_FRONT, EV_DONE, EV_XA, EV_MASK, EV_LSNR };
 
@@ -438,9 +442,17 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
                 for (int i = 0; i < 2; ++i) good = good && hipStreamCreateWithFlags(&ln.aux[i], hipStreamNonBlocking) == hipSuccess;
                 for (int i = 0; i < DFX_LANE_EVENTS; ++i) good = good && hipEventCreateWithFlags(&ln.ev[i], hipEventDisableTiming) == hipSuccess;
                 for (int i = 0; i < DFX_MAX_GRU_LAYERS; ++i) {
-                    good = good && hipStreamCreateWithFlags(&ln.gs[i], hipStreamNonBlocking) == hipSuccess;
-                    for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) good = good && hipEventCreateWithFlags(&ln.gev[i][k], hipEventDisableTiming) == hipSuccess;
+                    if (l == 0) {  // the layer-pipelined GRU phase runs on lane 0 only (keeps the number of live streams near the 16 hardware queues)
+                        good = good && hipStreamCreateWithFlags(&ln.gs[i], hipStreamNonBlocking) == hipSuccess;
+                        good = good && hipStreamCreateWithFlags(&ln.ps[i], hipStreamNonBlocking) == hipSuccess;
+                    }
+                    for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) {
+                        good = good && hipEventCreateWithFlags(&ln.gev[i][k], hipEventDisableTiming) == hipSuccess;
+                        good = good && hipEventCreateWithFlags(&ln.pev[i][k], hipEventDisableTiming) == hipSuccess;
+                    }
                 }
+                for (int i = 0; i < 2 && l == 0; ++i) good = good && hipStreamCreateWithFlags(&ln.ts[i], hipStreamNonBlocking) == hipSuccess;
+                for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) good = good && hipEventCreateWithFlags(&ln.eev[k], hipEventDisableTiming) == hipSuccess;
             }
             if (!good) {
                 dfx_model_free(m);
@@ -464,9 +476,16 @@ extern "C" void dfx_model_free(dfx_model *m) {
             if (ln.ev[i]) (void)hipEventDestroy(ln.ev[i]);
         for (int i = 0; i < DFX_MAX_GRU_LAYERS; ++i) {
             if (ln.gs[i]) (void)hipStreamDestroy(ln.gs[i]);
-            for (int k = 0; k < DFX_MAX_TCHUNKS; ++k)
+            if (ln.ps[i]) (void)hipStreamDestroy(ln.ps[i]);
+            for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) {
                 if (ln.gev[i][k]) (void)hipEventDestroy(ln.gev[i][k]);
+                if (ln.pev[i][k]) (void)hipEventDestroy(ln.pev[i][k]);
+            }
         }
+        for (int i = 0; i < 2; ++i)
+            if (ln.ts[i]) (void)hipStreamDestroy(ln.ts[i]);
+        for (int k = 0; k < DFX_MAX_TCHUNKS; ++k)
+            if (ln.eev[k]) (void)hipEventDestroy(ln.eev[k]);
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->d_w) (void)hipFree(m->d_w);
@@ -863,7 +882,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     int K = m->tchunks;
     if (T / K < m->tchunk_min) K = (int)(T / m->tchunk_min);
     const int nenc = (int)m->enc_gru.size(), ndec = (int)m->dec_gru.size(), ndf = (int)m->df_gru.size();
-    const bool pipe = par && !m->exact_fp32 && K > 1 && nenc == 1 && 1 + ndec + ndf <= DFX_MAX_GRU_LAYERS;
+    const bool pipe = par && !m->exact_fp32 && K > 1 && nenc == 1 && 1 + ndec + ndf <= DFX_MAX_GRU_LAYERS && ln == &m->lanes[0];
     if (!pipe) {
         const float *y = nullptr;
         if ((rc = run_gru_stack(m, m->enc_gru, xa, xa, xb, gi, B, T, &y, s))) return rc;
@@ -920,83 +939,102 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         auto tb = [&](int k) { return (int64_t)k * T / K; };
         auto rmk = [&](int k) { return DfxRowMap{T, tb(k + 1) - tb(k), tb(k)}; };
         auto Mk = [&](int k) { return B * (tb(k + 1) - tb(k)); };
-        auto gwait = [&](int l, int k, hipStream_t on) -> int {
-            DFX_HIP(hipStreamWaitEvent(on, ln->gev[l][k], 0));
+        auto ewait = [&](hipEvent_t e, hipStream_t on) -> int {
+            DFX_HIP(hipStreamWaitEvent(on, e, 0));
             return DFX_OK;
         };
-        auto gsig = [&](int l, int k, hipStream_t from) -> int {
-            DFX_HIP(hipEventRecord(ln->gev[l][k], from));
+        auto esig = [&](hipEvent_t e, hipStream_t from) -> int {
+            DFX_HIP(hipEventRecord(e, from));
             return DFX_OK;
         };
-        // one GRU layer on one time chunk: input projection (rows of the chunk) + recurrence over [tb(k), tb(k+1))
-        auto layer_chunk = [&](const GruW &g, int l, int k, const float *xin, hipStream_t st) -> int {
-            float *gil = ws + w.pgi[l], *yl = ws + w.py[l], *hl = ws + w.ph[l];
-            if (int r2 = launch_proj_h3(m, g, xin, gil, Mk(k), 768, st, rmk(k))) return r2;
-            return launch_gru_h3(m, g, gil, yl, k == 0 ? nullptr : hl, hl, B, T, tb(k), tb(k + 1), st);
+        // Per layer l two streams: ps[l] prepares chunk k (linear_in of a stack's first layer + the input projection) as soon
+        // as its input rows exist and signals pev[l][k]; gs[l] runs nothing but the recurrences, chunk after chunk, and
+        // signals gev[l][k].  Two tail streams consume the last layers' chunks (linear_out / skip / df_out) and then run the
+        // rest of their decoder.  The latency chain is therefore K+2 recurrence chunks and nothing else.
+        const int nl = 1 + ndec + ndf;
+        auto proj_chunk = [&](const GruW &g, int l, int k, const float *xin, hipStream_t st) -> int {
+            return launch_proj_h3(m, g, xin, ws + w.pgi[l], Mk(k), 768, st, rmk(k));
+        };
+        auto gru_chunk = [&](const GruW &g, int l, int k, hipStream_t st) -> int {
+            float *hl = ws + w.ph[l];
+            return launch_gru_h3(m, g, ws + w.pgi[l], ws + w.py[l], k == 0 ? nullptr : hl, hl, B, T, tb(k), tb(k + 1), st);
         };
         if ((rc = signal(EV_XA, s))) return rc;
-        // ---- encoder GRU on s: x = xa, then emb = relu(linear_out(y)) per chunk
+        for (int l = 0; l < nl; ++l) {
+            if (l > 0 && (rc = wait(EV_XA, ln->gs[l]))) return rc;
+            if ((rc = wait(EV_XA, ln->ps[l]))) return rc;
+        }
+        if ((rc = wait(EV_XA, ln->ts[0])) || (rc = wait(EV_XA, ln->ts[1]))) return rc;
+        // ---- layer 0 = encoder GRU: prep on ps[0] (x = xa is complete), recurrence on s
         for (int k = 0; k < K; ++k) {
-            if ((rc = layer_chunk(m->enc_gru[0], 0, k, xa, s))) return rc;
-            if ((rc = launch_glin(m, m->enc_out, ws + w.py[0], DFX_ACT_RELU, nullptr, embv, Mk(k), s, rmk(k)))) return rc;
-            if ((rc = gsig(0, k, s))) return rc;
+            if ((rc = proj_chunk(m->enc_gru[0], 0, k, xa, ln->ps[0])) || (rc = esig(ln->pev[0][k], ln->ps[0]))) return rc;
         }
-        {
-            DfxKScope ks(DFX_K_LSNR, s);
-            dfx_launch(dfx_k_lsnr, dim3((unsigned)dfx_ceil_div(R * 64, 256)), dim3(256), 0, s, (const float *)embv, m->p(m->lsnr_w),
-                       m->lsnr_b, (float)(c.lsnr_max - c.lsnr_min), (float)c.lsnr_min, lsnr, R, emb);
+        for (int k = 0; k < K; ++k) {
+            if ((rc = ewait(ln->pev[0][k], s)) || (rc = gru_chunk(m->enc_gru[0], 0, k, s)) || (rc = esig(ln->gev[0][k], s))) return rc;
         }
-        DFX_LAUNCH_CHECK();
-        // ---- ERB decoder stack: layers 1 .. ndec
+        // ---- ERB decoder stack (layers 1..ndec); its first prep stream also produces emb = relu(linear_out(y_enc)) per chunk
         for (int j = 0; j < ndec; ++j) {
             const int l = 1 + j;
-            hipStream_t st = ln->gs[l];
-            DFX_HIP(hipStreamWaitEvent(st, ln->ev[EV_XA], 0));
+            hipStream_t pst = ln->ps[l], gst = ln->gs[l];
             for (int k = 0; k < K; ++k) {
-                if ((rc = gwait(l - 1, k, st))) return rc;
-                const float *xin = ws + w.py[l - 1];
-                if (j == 0) {  // linear_in on the encoder embedding
-                    if ((rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, xb, Mk(k), st, rmk(k)))) return rc;
-                    xin = xb;
-                }
-                if ((rc = layer_chunk(m->dec_gru[j], l, k, xin, st))) return rc;
-                if (j == ndec - 1) {
-                    if ((rc = launch_glin(m, m->dec_out, ws + w.py[l], DFX_ACT_RELU, nullptr, demb, Mk(k), st, rmk(k)))) return rc;
-                } else if ((rc = gsig(l, k, st))) return rc;
-            }
-            if (j == ndec - 1) {  // the convolutional half of the ERB decoder follows on this stream
-                if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, R, E / 4, E / 4, 1, st))) return rc;
-                if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, R, E / 4, E / 2, 2, st))) return rc;
-                if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, R, E / 2, E, 2, st))) return rc;
-                const int fpt = 64 / E > 0 ? 64 / E : 1;
-                const size_t smem = ((size_t)fpt * E * (C + 1) + (size_t)fpt * E * 3 + 3 * C) * sizeof(float);
-                {
-                    DfxKScope ks(DFX_K_CONV_OUT, st);
-                    dfx_launch(dfx_k_conv_out<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R, fpt), 8)), dim3(DFX_CO_THREADS), smem, st,
-                               (const float *)d1, (const float *)e0, m->p(m->co_ska), m->p(m->co_skb), m->p(m->co_w), m->co_bias,
-                               mask, R, E, fpt);
-                }
-                DFX_LAUNCH_CHECK();
-                if ((rc = signal(EV_MASK, st))) return rc;
-            }
-        }
-        // ---- DF decoder stack: layers 1+ndec .. ndec+ndf
-        for (int j = 0; j < ndf; ++j) {
-            const int l = 1 + ndec + j;
-            hipStream_t st = ln->gs[l];
-            DFX_HIP(hipStreamWaitEvent(st, ln->ev[EV_XA], 0));
-            if (j == ndf - 1 && (rc = wait(EV_C0P, st))) return rc;
-            for (int k = 0; k < K; ++k) {
-                if ((rc = gwait(j == 0 ? 0 : l - 1, k, st))) return rc;
+                if ((rc = ewait(ln->gev[l - 1][k], pst))) return rc;
                 const float *xin = ws + w.py[l - 1];
                 if (j == 0) {
-                    if ((rc = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, Mk(k), st, rmk(k)))) return rc;
-                    xin = xa2;
+                    if ((rc = launch_glin(m, m->enc_out, ws + w.py[0], DFX_ACT_RELU, nullptr, embv, Mk(k), pst, rmk(k)))) return rc;
+                    if ((rc = esig(ln->eev[k], pst))) return rc;  // emb chunk k exists (the DF stack waits for it)
+                    if ((rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, xb, Mk(k), pst, rmk(k)))) return rc;
+                    xin = xb;
                 }
-                if ((rc = layer_chunk(m->df_gru[j], l, k, xin, st))) return rc;
-                if (j < ndf - 1) {
-                    if ((rc = gsig(l, k, st))) return rc;
-                } else if (c.df_gru_skip != DFX_SKIP_IDENTITY) {  // skip + df_out on this chunk's rows
+                if ((rc = proj_chunk(m->dec_gru[j], l, k, xin, pst)) || (rc = esig(ln->pev[l][k], pst))) return rc;
+            }
+            for (int k = 0; k < K; ++k) {
+                if ((rc = ewait(ln->pev[l][k], gst)) || (rc = gru_chunk(m->dec_gru[j], l, k, gst)) || (rc = esig(ln->gev[l][k], gst))) return rc;
+            }
+        }
+        {   // ERB tail: linear_out per chunk, then the convolutional half of the decoder (:250-253)
+            hipStream_t st = ln->ts[0];
+            for (int k = 0; k < K; ++k) {
+                if ((rc = ewait(ln->gev[ndec][k], st))) return rc;
+                if ((rc = launch_glin(m, m->dec_out, ws + w.py[ndec], DFX_ACT_RELU, nullptr, demb, Mk(k), st, rmk(k)))) return rc;
+            }
+            if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, R, E / 4, E / 4, 1, st))) return rc;
+            if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, R, E / 4, E / 2, 2, st))) return rc;
+            if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, R, E / 2, E, 2, st))) return rc;
+            const int fpt = 64 / E > 0 ? 64 / E : 1;
+            const size_t smem = ((size_t)fpt * E * (C + 1) + (size_t)fpt * E * 3 + 3 * C) * sizeof(float);
+            {
+                DfxKScope ks(DFX_K_CONV_OUT, st);
+                dfx_launch(dfx_k_conv_out<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R, fpt), 8)), dim3(DFX_CO_THREADS), smem, st,
+                           (const float *)d1, (const float *)e0, m->p(m->co_ska), m->p(m->co_skb), m->p(m->co_w), m->co_bias, mask,
+                           R, E, fpt);
+            }
+            DFX_LAUNCH_CHECK();
+            if ((rc = signal(EV_MASK, st))) return rc;
+        }
+        // ---- DF decoder stack (layers 1+ndec ..)
+        for (int j = 0; j < ndf; ++j) {
+            const int l = 1 + ndec + j;
+            hipStream_t pst = ln->ps[l], gst = ln->gs[l];
+            for (int k = 0; k < K; ++k) {
+                const float *xin = ws + w.py[l - 1];
+                if (j == 0) {
+                    if ((rc = ewait(ln->eev[k], pst))) return rc;
+                    if ((rc = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, Mk(k), pst, rmk(k)))) return rc;
+                    xin = xa2;
+                } else if ((rc = ewait(ln->gev[l - 1][k], pst))) return rc;
+                if ((rc = proj_chunk(m->df_gru[j], l, k, xin, pst)) || (rc = esig(ln->pev[l][k], pst))) return rc;
+            }
+            for (int k = 0; k < K; ++k) {
+                if ((rc = ewait(ln->pev[l][k], gst)) || (rc = gru_chunk(m->df_gru[j], l, k, gst)) || (rc = esig(ln->gev[l][k], gst))) return rc;
+            }
+        }
+        {   // DF tail: skip + df_out (+ c0p) per chunk (:324-330)
+            hipStream_t st = ln->ts[1];
+            const int l = ndec + ndf;
+            if ((rc = wait(EV_C0P, st))) return rc;
+            if (c.df_gru_skip != DFX_SKIP_IDENTITY) {
+                for (int k = 0; k < K; ++k) {
+                    if ((rc = ewait(ln->gev[l][k], st))) return rc;
                     const float *cfeat = ws + w.py[l];
                     if (c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) {
                         if ((rc = launch_glin(m, m->df_skip, embv, DFX_ACT_NONE, ws + w.py[l], xdf, Mk(k), st, rmk(k)))) return rc;
@@ -1007,22 +1045,28 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                                            T, rmk(k))))
                         return rc;
                 }
-            }
-            if (j == ndf - 1) {
-                if (c.df_gru_skip == DFX_SKIP_IDENTITY) {
-                    {
-                        DfxKScope ks(DFX_K_ADD, st);
-                        dfx_launch(dfx_k_add, dim3((unsigned)nn_grid(dfx_ceil_div(R * 256, 256), 16)), dim3(256), 0, st,
-                                   (const float *)(ws + w.py[l]), (const float *)embv, xdf, R * 256);
-                    }
-                    DFX_LAUNCH_CHECK();
-                    if ((rc = launch_ggemm(xdf, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg, m->df_out.Ng,
-                                           nullptr, DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, R, st, NO, Fd, T)))
-                        return rc;
+            } else {
+                if ((rc = ewait(ln->gev[l][K - 1], st))) return rc;
+                {
+                    DfxKScope ks(DFX_K_ADD, st);
+                    dfx_launch(dfx_k_add, dim3((unsigned)nn_grid(dfx_ceil_div(R * 256, 256), 16)), dim3(256), 0, st,
+                               (const float *)(ws + w.py[l]), (const float *)embv, xdf, R * 256);
                 }
-                if ((rc = signal(EV_COEFS, st))) return rc;
+                DFX_LAUNCH_CHECK();
+                if ((rc = launch_ggemm(xdf, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg, m->df_out.Ng,
+                                       nullptr, DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, R, st, NO, Fd, T)))
+                    return rc;
             }
+            if ((rc = signal(EV_COEFS, st))) return rc;
         }
+        // ---- lsnr on the caller's stream once the whole embedding exists (:163-165,184)
+        if ((rc = ewait(ln->eev[K - 1], s))) return rc;
+        {
+            DfxKScope ks(DFX_K_LSNR, s);
+            dfx_launch(dfx_k_lsnr, dim3((unsigned)dfx_ceil_div(R * 64, 256)), dim3(256), 0, s, (const float *)embv, m->p(m->lsnr_w),
+                       m->lsnr_b, (float)(c.lsnr_max - c.lsnr_min), (float)c.lsnr_min, lsnr, R, emb);
+        }
+        DFX_LAUNCH_CHECK();
         if ((rc = wait(EV_MASK, s))) return rc;
     }
     if ((rc = wait(EV_COEFS, s))) return rc;
