@@ -289,6 +289,28 @@ bool prep_gru(Prep &P, const std::string &name, int layers, std::vector<GruW> &o
 }
 }  // namespace
 
+static bool dfx_create_lane(dfx_model *m, int l) {
+    DfxLane &ln = m->lanes[l];
+    if (ln.main) return true;
+    bool good = hipStreamCreateWithFlags(&ln.main, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2; ++i) good = good && hipStreamCreateWithFlags(&ln.aux[i], hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < DFX_LANE_EVENTS; ++i) good = good && hipEventCreateWithFlags(&ln.ev[i], hipEventDisableTiming) == hipSuccess;
+    if (l == 0) {  // the layer-pipelined GRU phase runs on lane 0 only
+        const int nl = 1 + (m->cfg.emb_num_layers - 1) + m->cfg.df_num_layers;
+        for (int i = 0; i < nl && i < DFX_MAX_GRU_LAYERS; ++i) {
+            if (i > 0) good = good && hipStreamCreateWithFlags(&ln.gs[i], hipStreamNonBlocking) == hipSuccess;  // layer 0 recurs on the caller's stream
+            good = good && hipStreamCreateWithFlags(&ln.ps[i], hipStreamNonBlocking) == hipSuccess;
+            for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) {
+                good = good && hipEventCreateWithFlags(&ln.gev[i][k], hipEventDisableTiming) == hipSuccess;
+                good = good && hipEventCreateWithFlags(&ln.pev[i][k], hipEventDisableTiming) == hipSuccess;
+            }
+        }
+        for (int i = 0; i < 2; ++i) good = good && hipStreamCreateWithFlags(&ln.ts[i], hipStreamNonBlocking) == hipSuccess;
+        for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) good = good && hipEventCreateWithFlags(&ln.eev[k], hipEventDisableTiming) == hipSuccess;
+    }
+    return good;
+}
+
 extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx_model **out) {
     if (int rc = check_cfg(cfg)) return rc;
     if (!blob || !out) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_create: null");
@@ -435,25 +457,12 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         const char *nc = getenv("DFX_CHUNKS");
         if (nc && atoi(nc) >= 1) m->max_chunks = atoi(nc) < DFX_MAX_LANES ? atoi(nc) : DFX_MAX_LANES;
         {
+            // Streams are created sparingly: ROCm multiplexes them onto GPU_MAX_HW_QUEUES hardware queues and two live streams
+            // that share a queue serialise each other.  Lane 0 gets exactly the streams its model needs; lanes 1.. (batch-chunk
+            // pipelining, off by default) are created on demand by dfx_model_set_pipeline.
             bool good = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) == hipSuccess;
-            for (int l = 0; l < DFX_MAX_LANES; ++l) {
-                DfxLane &ln = m->lanes[l];
-                good = good && hipStreamCreateWithFlags(&ln.main, hipStreamNonBlocking) == hipSuccess;
-                for (int i = 0; i < 2; ++i) good = good && hipStreamCreateWithFlags(&ln.aux[i], hipStreamNonBlocking) == hipSuccess;
-                for (int i = 0; i < DFX_LANE_EVENTS; ++i) good = good && hipEventCreateWithFlags(&ln.ev[i], hipEventDisableTiming) == hipSuccess;
-                for (int i = 0; i < DFX_MAX_GRU_LAYERS; ++i) {
-                    if (l == 0) {  // the layer-pipelined GRU phase runs on lane 0 only (keeps the number of live streams near the 16 hardware queues)
-                        good = good && hipStreamCreateWithFlags(&ln.gs[i], hipStreamNonBlocking) == hipSuccess;
-                        good = good && hipStreamCreateWithFlags(&ln.ps[i], hipStreamNonBlocking) == hipSuccess;
-                    }
-                    for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) {
-                        good = good && hipEventCreateWithFlags(&ln.gev[i][k], hipEventDisableTiming) == hipSuccess;
-                        good = good && hipEventCreateWithFlags(&ln.pev[i][k], hipEventDisableTiming) == hipSuccess;
-                    }
-                }
-                for (int i = 0; i < 2 && l == 0; ++i) good = good && hipStreamCreateWithFlags(&ln.ts[i], hipStreamNonBlocking) == hipSuccess;
-                for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) good = good && hipEventCreateWithFlags(&ln.eev[k], hipEventDisableTiming) == hipSuccess;
-            }
+            good = good && dfx_create_lane(m, 0);
+            for (int l = 1; l < m->max_chunks && good; ++l) good = dfx_create_lane(m, l);
             if (!good) {
                 dfx_model_free(m);
                 DFX_FAIL(DFX_ERR_HIP, "dfx_model_create: could not create the auxiliary streams/events");
@@ -501,6 +510,8 @@ extern "C" int dfx_model_set_pipeline(dfx_model *m, int time_chunks, int min_chu
     m->tchunks = time_chunks < DFX_MAX_TCHUNKS ? time_chunks : DFX_MAX_TCHUNKS;
     m->tchunk_min = min_chunk_frames;
     m->max_chunks = batch_chunks < DFX_MAX_LANES ? batch_chunks : DFX_MAX_LANES;
+    for (int l = 1; l < m->max_chunks && m->have_streams; ++l)
+        if (!dfx_create_lane(m, l)) DFX_FAIL(DFX_ERR_HIP, "dfx_model_set_pipeline: could not create the streams of lane %d", l);
     return DFX_OK;
 }
 extern "C" int dfx_model_cfg_get(const dfx_model *m, dfx_model_cfg *out) {
