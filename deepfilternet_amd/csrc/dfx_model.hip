@@ -585,7 +585,7 @@ static int nn_grid(int64_t tiles, int per_cu) {
 
 template <int C>
 static int launch_pw(int mode, const dfx_model *m, const PwW &w, const float *x, const float *skip, float *out, int64_t R,
-                     int Fin, int Fout, int stride, hipStream_t s) {
+                     int Fin, int Fout, int stride, hipStream_t s, DfxRowMap rm = DfxRowMap{0, 0, 0}) {
     DfxPwArgs A;
     A.x = x;
     A.skip = skip;
@@ -599,6 +599,7 @@ static int launch_pw(int mode, const dfx_model *m, const PwW &w, const float *x,
     A.Fin = Fin;
     A.Fout = Fout;
     A.stride = stride;
+    A.rm = rm;
     const int grid = nn_grid(dfx_ceil_div(R * Fout, 64), 8);
     DfxKScope ks(DFX_K_PWCONV, s);
     if (mode == DFX_PW_MODE_DW3) {
@@ -943,7 +944,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             DfxKScope ks(DFX_K_CONV_OUT, s);
             dfx_launch(dfx_k_conv_out<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R, fpt), 8)), dim3(DFX_CO_THREADS), smem, s,
                        (const float *)d1, (const float *)e0, m->p(m->co_ska), m->p(m->co_skb), m->p(m->co_w), m->co_bias, mask,
-                       R, E, fpt);
+                       R, E, fpt, DfxRowMap{0, 0, 0});
             DFX_LAUNCH_CHECK();
         }
     } else {
@@ -1002,24 +1003,27 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 if ((rc = ewait(ln->pev[l][k], gst)) || (rc = gru_chunk(m->dec_gru[j], l, k, gst)) || (rc = esig(ln->gev[l][k], gst))) return rc;
             }
         }
-        {   // ERB tail: linear_out per chunk, then the convolutional half of the decoder (:250-253)
+        {   // ERB tail: per time chunk linear_out and the convolutional half of the decoder (:250-253; all of it is per frame),
+            // so it runs beside the GRU chain (which leaves most CUs idle) instead of after it
             hipStream_t st = ln->ts[0];
-            for (int k = 0; k < K; ++k) {
-                if ((rc = ewait(ln->gev[ndec][k], st))) return rc;
-                if ((rc = launch_glin(m, m->dec_out, ws + w.py[ndec], DFX_ACT_RELU, nullptr, demb, Mk(k), st, rmk(k)))) return rc;
-            }
-            if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, R, E / 4, E / 4, 1, st))) return rc;
-            if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, R, E / 4, E / 2, 2, st))) return rc;
-            if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, R, E / 2, E, 2, st))) return rc;
             const int fpt = 64 / E > 0 ? 64 / E : 1;
             const size_t smem = ((size_t)fpt * E * (C + 1) + (size_t)fpt * E * 3 + 3 * C) * sizeof(float);
-            {
-                DfxKScope ks(DFX_K_CONV_OUT, st);
-                dfx_launch(dfx_k_conv_out<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R, fpt), 8)), dim3(DFX_CO_THREADS), smem, st,
-                           (const float *)d1, (const float *)e0, m->p(m->co_ska), m->p(m->co_skb), m->p(m->co_w), m->co_bias, mask,
-                           R, E, fpt);
+            for (int k = 0; k < K; ++k) {
+                const int64_t Rk = Mk(k);
+                const DfxRowMap rm = rmk(k);
+                if ((rc = ewait(ln->gev[ndec][k], st))) return rc;
+                if ((rc = launch_glin(m, m->dec_out, ws + w.py[ndec], DFX_ACT_RELU, nullptr, demb, Rk, st, rm))) return rc;
+                if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, Rk, E / 4, E / 4, 1, st, rm))) return rc;
+                if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, Rk, E / 4, E / 2, 2, st, rm))) return rc;
+                if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, Rk, E / 2, E, 2, st, rm))) return rc;
+                {
+                    DfxKScope ks(DFX_K_CONV_OUT, st);
+                    dfx_launch(dfx_k_conv_out<C>, dim3((unsigned)nn_grid(dfx_ceil_div(Rk, fpt), 8)), dim3(DFX_CO_THREADS), smem, st,
+                               (const float *)d1, (const float *)e0, m->p(m->co_ska), m->p(m->co_skb), m->p(m->co_w), m->co_bias, mask,
+                               Rk, E, fpt, rm);
+                }
+                DFX_LAUNCH_CHECK();
             }
-            DFX_LAUNCH_CHECK();
             if ((rc = signal(EV_MASK, st))) return rc;
         }
         // ---- DF decoder stack (layers 1+ndec ..)

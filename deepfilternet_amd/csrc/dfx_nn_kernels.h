@@ -35,6 +35,17 @@ static __device__ __forceinline__ void dfx_static_for(F &&f) {
     }
 }
 
+// Row map for time-chunked launches: logical row m of a chunk of Tk frames starting at frame t0 (all B clips) is physical
+// row (m / Tk) * T + t0 + m % Tk of the [B*T, ...] activation arrays.  Tk == 0: identity.
+struct DfxRowMap {
+    int64_t T, Tk, t0;
+};
+static __device__ __forceinline__ int64_t dfx_row(const DfxRowMap &rm, int64_t m) {
+    if (rm.Tk == 0) return m;
+    const int64_t b = m / rm.Tk;
+    return b * rm.T + rm.t0 + (m - b * rm.Tk);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // enc.erb_conv0: Conv2d(1 -> C, 3x3, causal in time, pad 1 in freq) + BN + ReLU   (deepfilternet3.py:106-108)
 //   feat [B,T,E] -> out [B*T, E, C].  Lookahead L: tap kt of output frame t reads input frame t+L-2+kt, and is zero when
@@ -111,8 +122,9 @@ struct DfxPwArgs {
     const float *wt;     // [C][C]  wt[k][n] = W_pw[n][k] * bn_scale[n]
     const float *bias;   // [C]
     float *out;          // [R, Fout, C]
-    int64_t R;
+    int64_t R;          // logical rows (frames) of this launch
     int Fin, Fout, stride;
+    DfxRowMap rm;       // logical row -> physical row of x, skip and out (time-chunked launches)
 };
 
 template <int C, int MODE, bool SKIP>
@@ -143,8 +155,9 @@ __global__ void __launch_bounds__(DFX_PW_THREADS) dfx_k_pwconv(DfxPwArgs A) {
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
         const int64_t pos = tile * 16 + jl;
         const bool valid = pos < total;
-        const int64_t r = pos / A.Fout;
-        const int fo = (int)(pos - r * A.Fout);
+        const int64_t rl = pos / A.Fout;
+        const int fo = (int)(pos - rl * A.Fout);
+        const int64_t r = dfx_row(A.rm, valid ? rl : 0);
         float u[CPL];
 #pragma unroll
         for (int i = 0; i < CPL; ++i) u[i] = 0.f;
@@ -190,7 +203,7 @@ __global__ void __launch_bounds__(DFX_PW_THREADS) dfx_k_pwconv(DfxPwArgs A) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[nt][ks], u[ks], acc[nt], 0, 0, 0);
         if (valid) {
-            float4 *op = reinterpret_cast<float4 *>(A.out + pos * C + 4 * q);
+            float4 *op = reinterpret_cast<float4 *>(A.out + (r * A.Fout + fo) * C + 4 * q);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 op[4 * nt] = make_float4(fmaxf(acc[nt][0] + biasr[nt].x, 0.f), fmaxf(acc[nt][1] + biasr[nt].y, 0.f),
@@ -274,7 +287,7 @@ __global__ void __launch_bounds__(DFX_PW_THREADS) dfx_k_conv_in_df(DfxCinArgs A)
 template <int C>
 __global__ void __launch_bounds__(DFX_CO_THREADS) dfx_k_conv_out(const float *x, const float *skip, const float *sk_a,
                                                                  const float *sk_b, const float *w /*[3][C]*/, float bias,
-                                                                 float *out, int64_t R, int E, int frames_per_tile) {
+                                                                 float *out, int64_t R, int E, int frames_per_tile, DfxRowMap rm) {
     constexpr int LDA = C + 1;
     DFX_DYN_SMEM(float, sm);
     const int MT = frames_per_tile * E;
@@ -291,7 +304,7 @@ __global__ void __launch_bounds__(DFX_CO_THREADS) dfx_k_conv_out(const float *x,
             const int p = i / C, c = i - p * C;
             float v = 0.f;
             if (p < npos) {
-                const int64_t g = (r0 * E + p) * C + c;
+                const int64_t g = (dfx_row(rm, r0 + p / E) * E + p % E) * C + c;
                 v = x[g] + fmaxf(sk_a[c] * skip[g] + sk_b[c], 0.f);
             }
             As[p * LDA + c] = v;
@@ -309,7 +322,7 @@ __global__ void __launch_bounds__(DFX_CO_THREADS) dfx_k_conv_out(const float *x,
             float acc = bias + V[p * 3 + 1];
             if (f > 0) acc += V[(p - 1) * 3 + 0];
             if (f < E - 1) acc += V[(p + 1) * 3 + 2];
-            out[r0 * E + p] = dfx_sigmoid(acc);
+            out[dfx_row(rm, r0 + p / E) * E + f] = dfx_sigmoid(acc);
         }
         __syncthreads();
     }
@@ -487,17 +500,6 @@ __global__ void __launch_bounds__(256) dfx_k_df_convp2(DfxCp2Args A) {
             });
         }
     }
-}
-
-// Row map for time-chunked launches: logical row m of a chunk of Tk frames starting at frame t0 (all B clips) is physical
-// row (m / Tk) * T + t0 + m % Tk of the [B*T, ...] activation arrays.  Tk == 0: identity.
-struct DfxRowMap {
-    int64_t T, Tk, t0;
-};
-static __device__ __forceinline__ int64_t dfx_row(const DfxRowMap &rm, int64_t m) {
-    if (rm.Tk == 0) return m;
-    const int64_t b = m / rm.Tk;
-    return b * rm.T + rm.t0 + (m - b * rm.Tk);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
