@@ -156,6 +156,7 @@ def main() -> None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(y).all()
+    model.check()  # raises if a workgroup pair of the two-CU GRU kernel ever timed out (results would be invalid)
 
     if rank != 0:
         if dist is not None:

@@ -125,6 +125,9 @@ struct dfx_model {
     int tchunks = 6;          // time chunks of the layer-pipelined GRU phase (DFX_TCHUNKS)
     int tchunk_min = 32;      // shortest chunk worth a launch (frames)
     bool exact_fp32 = false;  // DFX_EXACT_FP32=1: keep the dense contractions on the exact fp32 MFMA path
+    bool gru_x2 = true;       // two-CU GRU recurrence with on-chip weights (DFX_GRU_X2=0: single-CU kernel with an L2 weight stream)
+    unsigned int *d_err = nullptr;      // device word: a bounded spin of the two-CU GRU kernel timed out
+    mutable unsigned int epoch = 0;     // tags the h exchange of one forward pass
     const float *p(size_t off) const { return d_w + off; }
 };
 
@@ -452,6 +455,12 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         m->concurrent = !(e && e[0] == '0');
         const char *x = getenv("DFX_EXACT_FP32");
         m->exact_fp32 = x && x[0] == '1';
+        const char *g2 = getenv("DFX_GRU_X2");
+        m->gru_x2 = !(g2 && g2[0] == '0') && !dfx_env_is_emulator();
+        if (hipMalloc(reinterpret_cast<void **>(&m->d_err), 256) != hipSuccess || hipMemset(m->d_err, 0, 256) != hipSuccess) {
+            dfx_model_free(m);
+            DFX_FAIL(DFX_ERR_ALLOC, "dfx_model_create: device allocation failed");
+        }
         const char *tc = getenv("DFX_TCHUNKS");
         if (tc && atoi(tc) >= 1) m->tchunks = atoi(tc) < DFX_MAX_TCHUNKS ? atoi(tc) : DFX_MAX_TCHUNKS;
         const char *nc = getenv("DFX_CHUNKS");
@@ -497,6 +506,7 @@ extern "C" void dfx_model_free(dfx_model *m) {
             if (ln.eev[k]) (void)hipEventDestroy(ln.eev[k]);
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->d_err) (void)hipFree(m->d_err);
     if (m->d_w) (void)hipFree(m->d_w);
     delete m;
 }
@@ -514,6 +524,16 @@ extern "C" int dfx_model_set_pipeline(dfx_model *m, int time_chunks, int min_chu
         if (!dfx_create_lane(m, l)) DFX_FAIL(DFX_ERR_HIP, "dfx_model_set_pipeline: could not create the streams of lane %d", l);
     return DFX_OK;
 }
+extern "C" int dfx_model_check(const dfx_model *m) {
+    if (!m) DFX_FAIL(DFX_ERR_INVALID_ARG, "null");
+    unsigned int e = 0;
+    DFX_HIP(hipMemcpy(&e, m->d_err, sizeof(e), hipMemcpyDeviceToHost));  // synchronises with the device
+    if (e) {
+        (void)hipMemset(m->d_err, 0, sizeof(e));
+        DFX_FAIL(DFX_ERR_HIP, "dfx: a workgroup pair of the two-CU GRU kernel timed out waiting for its partner; the last results are invalid");
+    }
+    return DFX_OK;
+}
 extern "C" int dfx_model_cfg_get(const dfx_model *m, dfx_model_cfg *out) {
     if (!m || !out) DFX_FAIL(DFX_ERR_INVALID_ARG, "null");
     *out = m->cfg;
@@ -526,6 +546,7 @@ struct Ws {
     // offsets in floats, each 64-float (256 B) aligned
     size_t e0, e1, e2, e3, c0, c1, emb_in, emb, xa, xb, gi, xa2, xb2, gi2, demb, d3, d2, d1, mask, c0p, xdf, coefs, lsnr, total;
     size_t pgi[DFX_MAX_GRU_LAYERS], py[DFX_MAX_GRU_LAYERS], ph[DFX_MAX_GRU_LAYERS];  // layer-pipelined GRU phase: gi, y, h state per layer
+    size_t pxb, pxb_floats;   // h exchange buffers of the two-CU GRU kernel: [layer][group][2][2][16][128] granules of 8 bytes
 };
 Ws plan_ws(const dfx_model_cfg &c, int64_t R, int64_t B = 0) {
     Ws w{};
@@ -565,6 +586,11 @@ Ws plan_ws(const dfx_model_cfg &c, int64_t R, int64_t B = 0) {
         w.pgi[l] = take(used ? R * 768 : 0);
         w.py[l] = take(used ? R * 256 : 0);
         w.ph[l] = take(used ? (B > 0 ? B : R) * 256 : 0);
+    }
+    {
+        const size_t groups = ((B > 0 ? (size_t)B : (size_t)R) + 15) / 16;
+        w.pxb_floats = (size_t)DFX_MAX_GRU_LAYERS * groups * 2 * 2 * 16 * 128 * 2;  // 8-byte granules as float pairs
+        w.pxb = take(w.pxb_floats);
     }
     w.total = off;
     return w;
@@ -729,6 +755,33 @@ static int launch_glin(const dfx_model *m, const GlinW &g, const float *a, int a
                        hipStream_t s, DfxRowMap rm = DfxRowMap{0, 0, 0}) {
     return launch_ggemm(a, g.G * g.Kg, m->p(g.w), g.G, g.Kg, g.Ng, nullptr, act, res, out, g.G * g.Ng, M, s, 0, 0, 1, rm);
 }
+
+#ifndef DFX_HIPEMU
+static int launch_gru_h3x2(const dfx_model *m, const GruW &g, const float *gi, float *y, const float *h_in, float *h_out,
+                           int64_t B, int64_t T, int64_t t0, int64_t t1, unsigned long long *xbuf, hipStream_t s) {
+    DfxG2Args A;
+    A.gi = gi;
+    A.whf = reinterpret_cast<const dfx_h8 *>(m->p(g.whh_h3));
+    A.bhn = m->p(g.bhn);
+    A.h_in = h_in;
+    A.h_out = h_out;
+    A.y = y;
+    A.xbuf = xbuf;
+    A.err = m->d_err;
+    A.B = B;
+    A.T = T;
+    A.t0 = t0;
+    A.t1 = t1;
+    A.groups = (int)dfx_ceil_div(B, 16);
+    A.epoch = m->epoch & 0xFFFu;
+    A.unscale = g.whh_unscale;
+    DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_rec_h3x2, DFX_G2_SMEM));
+    DfxKScope ks(DFX_K_GRU_REC, s);
+    dfx_launch(dfx_k_gru_rec_h3x2, dim3((unsigned)(dfx_ceil_div(A.groups, 8) * 8 * 2)), dim3(256), DFX_G2_SMEM, s, A);
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
+}
+#endif
 
 static int launch_gru_h3(const dfx_model *m, const GruW &g, const float *gi, float *y, const float *h_in, float *h_out,
                          int64_t B, int64_t T, int64_t t0, int64_t t1, hipStream_t s) {
@@ -964,13 +1017,26 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // signals gev[l][k].  Two tail streams consume the last layers' chunks (linear_out / skip / df_out) and then run the
         // rest of their decoder.  The latency chain is therefore K+2 recurrence chunks and nothing else.
         const int nl = 1 + ndec + ndf;
+        (void)nl;
         auto proj_chunk = [&](const GruW &g, int l, int k, const float *xin, hipStream_t st) -> int {
             return launch_proj_h3(m, g, xin, ws + w.pgi[l], Mk(k), 768, st, rmk(k));
         };
+        // two-CU recurrence (weights fully on chip) when all workgroup pairs of all concurrent layers fit on the chip
+        const bool use_x2 = m->gru_x2 && 2 * dfx_ceil_div(B, 16) * nl <= dfx_env_num_cus();
         auto gru_chunk = [&](const GruW &g, int l, int k, hipStream_t st) -> int {
             float *hl = ws + w.ph[l];
+#ifndef DFX_HIPEMU
+            if (use_x2) {
+                unsigned long long *xb2 = reinterpret_cast<unsigned long long *>(ws + w.pxb) + (size_t)l * dfx_ceil_div(B, 16) * 2 * 2 * 16 * 128;
+                return launch_gru_h3x2(m, g, ws + w.pgi[l], ws + w.py[l], k == 0 ? nullptr : hl, hl, B, T, tb(k), tb(k + 1), xb2, st);
+            }
+#endif
             return launch_gru_h3(m, g, ws + w.pgi[l], ws + w.py[l], k == 0 ? nullptr : hl, hl, B, T, tb(k), tb(k + 1), st);
         };
+        if (use_x2) {  // fresh tags for this pass (a stale granule of an earlier pass can then never match)
+            ++m->epoch;
+            DFX_HIP(hipMemsetAsync(ws + w.pxb, 0, (size_t)nl * dfx_ceil_div(B, 16) * 2 * 2 * 16 * 128 * 8, s));
+        }
         if ((rc = signal(EV_XA, s))) return rc;
         for (int l = 0; l < nl; ++l) {
             if (l > 0 && (rc = wait(EV_XA, ln->gs[l]))) return rc;

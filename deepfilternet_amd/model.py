@@ -109,6 +109,10 @@ class DfNet:
         """Time-chunk / batch-chunk pipelining knobs of the GRU phase (see dfx_model_set_pipeline in include/dfx.h)."""
         _lib.check(_lib.lib().dfx_model_set_pipeline(self._h, int(time_chunks), int(min_chunk_frames), int(batch_chunks)))
 
+    def check(self) -> None:
+        """Synchronise and raise if the two-CU GRU kernel ever hit a spin timeout (see dfx_model_check)."""
+        _lib.check(_lib.lib().dfx_model_check(self._h))
+
     # nn.Module-ish no-ops so that callers written against the reference keep working
     def eval(self):
         return self

@@ -172,6 +172,9 @@ int dfx_model_set_streams(dfx_model *m, int enable);
  *   batch_chunks     dfx_enhance additionally pipelines this many batch chunks (multiples of 16 clips) on separate stream sets.
  * The streams need their own hardware queues: export GPU_MAX_HW_QUEUES=16 (ROCm maps streams onto 4 queues by default). */
 int dfx_model_set_pipeline(dfx_model *m, int time_chunks, int min_chunk_frames, int batch_chunks);
+/* Synchronises with the device and reports DFX_ERR_HIP if a workgroup pair of the two-CU GRU kernel ever timed out waiting for
+ * its partner (bounded spins: the engine never hangs; results of that pass are invalid).  DFX_OK otherwise. */
+int dfx_model_check(const dfx_model *m);
 
 /* Scratch memory the caller must provide (device bytes) for a [B, T-frames] batch. */
 int dfx_model_workspace_bytes(const dfx_model *m, int64_t B, int64_t T, int64_t *bytes);
