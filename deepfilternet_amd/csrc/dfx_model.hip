@@ -125,7 +125,8 @@ struct dfx_model {
     int tchunks = 6;          // time chunks of the layer-pipelined GRU phase (DFX_TCHUNKS)
     int tchunk_min = 32;      // shortest chunk worth a launch (frames)
     bool exact_fp32 = false;  // DFX_EXACT_FP32=1: keep the dense contractions on the exact fp32 MFMA path
-    bool gru_x2 = true;       // two-CU GRU recurrence with on-chip weights (DFX_GRU_X2=0: single-CU kernel with an L2 weight stream)
+    bool gru_x2 = false;      // DFX_GRU_X2=1: two-CU GRU recurrence (weights fully on chip, h halves exchanged every step);
+                              // measured slower than the single-CU kernel (6.6 vs 5.2 us/step): the exchange costs ~4 us
     unsigned int *d_err = nullptr;      // device word: a bounded spin of the two-CU GRU kernel timed out
     mutable unsigned int epoch = 0;     // tags the h exchange of one forward pass
     const float *p(size_t off) const { return d_w + off; }
@@ -456,7 +457,7 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         const char *x = getenv("DFX_EXACT_FP32");
         m->exact_fp32 = x && x[0] == '1';
         const char *g2 = getenv("DFX_GRU_X2");
-        m->gru_x2 = !(g2 && g2[0] == '0') && !dfx_env_is_emulator();
+        m->gru_x2 = g2 && g2[0] == '1' && !dfx_env_is_emulator();
         if (hipMalloc(reinterpret_cast<void **>(&m->d_err), 256) != hipSuccess || hipMemset(m->d_err, 0, 256) != hipSuccess) {
             dfx_model_free(m);
             DFX_FAIL(DFX_ERR_ALLOC, "dfx_model_create: device allocation failed");

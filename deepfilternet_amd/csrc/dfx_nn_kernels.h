@@ -1197,6 +1197,8 @@ __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_rec_h
 // 128 hidden units (all three gates).  Half of W_hh is 384 KB as f16 hi/lo: it fits on one CU (33 fragment pairs per wave in
 // VGPRs + 15 in LDS), so nothing is streamed from L2 any more and the step no longer depends on what else is thrashing the
 // L2 (measured: the single-CU kernel goes from 5.2 to 8 us/step when projections / convolutions run beside it).
+// EXPERIMENTAL, off by default (DFX_GRU_X2=1): correct (GPU parity tests pass with it), but the per-step exchange costs ~4 us on
+// MI355X — 6.6 us/step alone, 9.8 us with five layers running — so the single-CU kernel wins (profiles/r01_gru_x2.log).
 // Price: the two workgroups exchange their halves of h every step through global memory.  Protocol (MI355X_MICROARCH.md,
 // "handoff-1to1", data-tagged granules): every h value travels as ONE naturally aligned 8-byte {f16 hi | f16 lo << 16, tag}
 // written with a single relaxed agent-scope (sc1) store; the consumer polls the granules themselves with relaxed agent-scope
