@@ -125,6 +125,7 @@ struct dfx_model {
     int tchunks = 6;          // time chunks of the layer-pipelined GRU phase (DFX_TCHUNKS)
     int tchunk_min = 32;      // shortest chunk worth a launch (frames)
     bool exact_fp32 = false;  // DFX_EXACT_FP32=1: keep the dense contractions on the exact fp32 MFMA path
+    bool convp_late = true;   // DFX_CONVP_EARLY=1 starts df_convp right after c0 instead of after the front
     bool gru_x2 = false;      // DFX_GRU_X2=1: two-CU GRU recurrence (weights fully on chip, h halves exchanged every step);
                               // measured slower than the single-CU kernel (6.6 vs 5.2 us/step): the exchange costs ~4 us
     unsigned int *d_err = nullptr;      // device word: a bounded spin of the two-CU GRU kernel timed out
@@ -456,6 +457,8 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         m->concurrent = !(e && e[0] == '0');
         const char *x = getenv("DFX_EXACT_FP32");
         m->exact_fp32 = x && x[0] == '1';
+        const char *ce = getenv("DFX_CONVP_EARLY");
+        m->convp_late = !(ce && ce[0] == '1');
         const char *g2 = getenv("DFX_GRU_X2");
         m->gru_x2 = g2 && g2[0] == '1' && !dfx_env_is_emulator();
         if (hipMalloc(reinterpret_cast<void **>(&m->d_err), 256) != hipSuccess || hipMemset(m->d_err, 0, 256) != hipSuccess) {
@@ -886,42 +889,48 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     if ((rc = signal(EV_C0, x1)) || (rc = wait(EV_C0, x2))) return rc;
     if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->dfc1, c0, nullptr, c1, R, Fd, Fd / 2, 2, x1))) return rc;
     if ((rc = signal(EV_C1, x1))) return rc;
-    // ---- df_dec.df_convp on x2 (only needs c0; :328)
-    if (c.df_pathway_kernel_size_t <= 5) {
-        switch (c.df_pathway_kernel_size_t) {
-            case 1: rc = launch_convp2<C, 1>(m, c0, c0p, B, T, Fd, NO, x2); break;
-            case 2: rc = launch_convp2<C, 2>(m, c0, c0p, B, T, Fd, NO, x2); break;
-            case 3: rc = launch_convp2<C, 3>(m, c0, c0p, B, T, Fd, NO, x2); break;
-            case 4: rc = launch_convp2<C, 4>(m, c0, c0p, B, T, Fd, NO, x2); break;
-            default: rc = launch_convp2<C, 5>(m, c0, c0p, B, T, Fd, NO, x2); break;
+    auto run_convp = [&]() -> int {
+        // ---- df_dec.df_convp on x2 (only needs c0; :328)
+        if (c.df_pathway_kernel_size_t <= 5) {
+            switch (c.df_pathway_kernel_size_t) {
+                case 1: rc = launch_convp2<C, 1>(m, c0, c0p, B, T, Fd, NO, x2); break;
+                case 2: rc = launch_convp2<C, 2>(m, c0, c0p, B, T, Fd, NO, x2); break;
+                case 3: rc = launch_convp2<C, 3>(m, c0, c0p, B, T, Fd, NO, x2); break;
+                case 4: rc = launch_convp2<C, 4>(m, c0, c0p, B, T, Fd, NO, x2); break;
+                default: rc = launch_convp2<C, 5>(m, c0, c0p, B, T, Fd, NO, x2); break;
+            }
+            if (rc) return rc;
+        } else {
+            DfxCpArgs A;
+            A.c0 = c0;
+            A.w1 = m->p(m->cp_w1);
+            A.w2 = m->p(m->cp_w2);
+            A.bias = m->p(m->cp_b);
+            A.out = c0p;
+            A.B = B;
+            A.T = T;
+            A.Fd = Fd;
+            A.kt = c.df_pathway_kernel_size_t;
+            A.G = m->cp_G;
+            A.NO = NO;
+            A.tchunks = (int)dfx_ceil_div(T, DFX_CP_TT);
+            A.fchunks = (Fd + DFX_CP_FB - 1) / DFX_CP_FB;
+            const int CG = C / A.G;
+            const size_t smem = ((size_t)(DFX_CP_TT + A.kt - 1) * DFX_CP_FB * (C + 2) + (size_t)A.G * A.kt * CG * 16 +
+                                 (size_t)DFX_CP_TT * DFX_CP_FB * NO) * sizeof(float);
+            if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_df_convp<C>, smem));
+            const int64_t nblk = B * A.tchunks * A.fchunks;
+            if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "df_convp grid too large");
+            DfxKScope ks(DFX_K_DF_CONVP, x2);
+            dfx_launch(dfx_k_df_convp<C>, dim3((unsigned)nblk), dim3(DFX_CP_THREADS), smem, x2, A);
+            DFX_LAUNCH_CHECK();
         }
-        if (rc) return rc;
-    } else {
-        DfxCpArgs A;
-        A.c0 = c0;
-        A.w1 = m->p(m->cp_w1);
-        A.w2 = m->p(m->cp_w2);
-        A.bias = m->p(m->cp_b);
-        A.out = c0p;
-        A.B = B;
-        A.T = T;
-        A.Fd = Fd;
-        A.kt = c.df_pathway_kernel_size_t;
-        A.G = m->cp_G;
-        A.NO = NO;
-        A.tchunks = (int)dfx_ceil_div(T, DFX_CP_TT);
-        A.fchunks = (Fd + DFX_CP_FB - 1) / DFX_CP_FB;
-        const int CG = C / A.G;
-        const size_t smem = ((size_t)(DFX_CP_TT + A.kt - 1) * DFX_CP_FB * (C + 2) + (size_t)A.G * A.kt * CG * 16 +
-                             (size_t)DFX_CP_TT * DFX_CP_FB * NO) * sizeof(float);
-        if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_df_convp<C>, smem));
-        const int64_t nblk = B * A.tchunks * A.fchunks;
-        if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "df_convp grid too large");
-        DfxKScope ks(DFX_K_DF_CONVP, x2);
-        dfx_launch(dfx_k_df_convp<C>, dim3((unsigned)nblk), dim3(DFX_CP_THREADS), smem, x2, A);
-        DFX_LAUNCH_CHECK();
-    }
-    if ((rc = signal(EV_C0P, x2))) return rc;
+        if ((rc = signal(EV_C0P, x2))) return rc;
+        return DFX_OK;
+    };
+    // the pathway conv only has to finish before df_out: by default it is released after the (HBM-bound) front so that it does not
+    // compete with the encoder for bandwidth and runs during the GRU phase instead (DFX_CONVP_EARLY=1: right after c0)
+    if (!m->convp_late && (rc = run_convp())) return rc;
     // ---- Encoder, ERB branch on s (:168-171)
     {
         const int64_t total = R * E * (C / 4);
@@ -941,6 +950,9 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     // the chip-filling front of this chunk is enqueued: the next chunk of a pipelined dfx_enhance may start its own front
     // (it then overlaps this chunk's GRU chain, which occupies only a few CUs)
     if (signal_front && (rc = signal(EV_FRONT, s))) return rc;
+    if (m->convp_late) {
+        if ((rc = signal(EV_LSNR, s)) || (rc = wait(EV_LSNR, x2)) || (rc = run_convp())) return rc;
+    }
     // ---- GRU phase.  Layer-pipelined over time chunks when the fp16-split kernels are in use: every GRU layer has its own
     // stream; layer l may run chunk k as soon as layer l-1 has produced chunk k (event), so the three-layer chain
     // enc -> dec1 -> dec2 (and enc -> df1 -> df2) costs T*(1 + 2/K) steps instead of 3T.  Each layer-kernel occupies B/16
