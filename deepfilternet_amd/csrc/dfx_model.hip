@@ -113,6 +113,9 @@ struct dfx_model {
     size_t cp_w1 = 0, cp_w2 = 0, cp_b = 0;   // df_convp, tiled form (kt > 5)
     size_t cp_weff = 0, cp_b16 = 0;          // df_convp, folded sliding-window form (kt <= 5)
     size_t cin_weff = 0, cin_b = 0;          // enc.df_conv0 folded into a dense 3x3 conv 2 -> C
+    // fp16-split MFMA fragments of the fused DF-encoder kernels (conv_ch % 32 == 0, kt <= 5): df_conv0, df_conv1 pointwise, df_convp
+    size_t c0_h3 = 0, dfc1_h3 = 0, cp_h3 = 0;
+    float c0_unscale = 1.f, dfc1_unscale = 1.f, cp_unscale = 1.f;
     int cp_G = 0, cp_NO = 0;
     // concurrency (created once; one forward / enhance at a time per handle):
     //   a lane = the streams of one batch chunk: `main` (only used when dfx_enhance pipelines chunks; otherwise the caller's
@@ -195,6 +198,37 @@ bool prep_path(Prep &P, const std::string &name, int C, size_t &a_off, size_t &b
         P.out[b_off + c] = sh[c];
     }
     return true;
+}
+// fp16-split MFMA A fragments: nfrag fragments of [hi, lo][64 lanes][8 halves]; val(frag, lane, i) is the fp32 weight of that slot.
+// All values are scaled by one power of two so that the largest is just below 2^14 (lo parts stay normal f16); *unscale undoes it.
+template <typename F>
+size_t pack_h3(Prep &P, int nfrag, F val, float *unscale) {
+    float mx = 0.f;
+    for (int fr = 0; fr < nfrag; ++fr)
+        for (int l = 0; l < 64; ++l)
+            for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(val(fr, l, i)));
+    int e = 0;
+    if (mx > 0.f) {
+        int ex;
+        frexpf(mx, &ex);
+        e = 14 - ex;
+        if (e > 24) e = 24;
+        if (e < -14) e = -14;
+    }
+    const float sc = ldexpf(1.f, e);
+    *unscale = ldexpf(1.f, -e);
+    const size_t off = P.alloc((size_t)nfrag * 2 * 64 * 8 / 2);
+    uint16_t *dst = reinterpret_cast<uint16_t *>(&P.out[off]);
+    for (int fr = 0; fr < nfrag; ++fr)
+        for (int l = 0; l < 64; ++l)
+            for (int i = 0; i < 8; ++i) {
+                const float w = val(fr, l, i) * sc;
+                const uint16_t hb = dfx_f32_to_f16_bits(w);
+                const uint16_t lb = dfx_f32_to_f16_bits(w - dfx_f16_bits_to_f32(hb));
+                dst[(((size_t)fr * 2 + 0) * 64 + l) * 8 + i] = hb;
+                dst[(((size_t)fr * 2 + 1) * 64 + l) * 8 + i] = lb;
+            }
+    return off;
 }
 bool prep_glin(Prep &P, const std::string &name, GlinW &g) {
     const DfxTensor *t = nullptr;
@@ -434,6 +468,26 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
                     }
                 }
             for (int n = 0; n < NO; ++n) P.out[m->cp_b16 + n] = sh[n];
+            if (C % 32 == 0) {  // fragments of the fused fp16-split DF-encoder kernels (dfx_k_df_conv01_h3, dfx_k_df_convp_h3)
+                const int KC = C / 32;
+                // channel a lane (q = l>>4) feeds as element i of k-chunk kc after dfx_c0_tile
+                auto chan = [](int kc, int l, int i) { const int e = 8 * kc + i; return 16 * (e >> 2) + 4 * (l >> 4) + (e & 3); };
+                const size_t cin = m->cin_weff, wt1 = m->dfc1.wt, cpw = m->cp_weff;
+                // P.out may reallocate inside pack_h3 (alloc): read through offsets, never through cached pointers
+                std::vector<float> src(P.out.begin(), P.out.end());
+                m->c0_h3 = pack_h3(P, C / 16, [&](int nt, int l, int i) {
+                    const int k = 8 * (l >> 4) + i;
+                    return k < 18 ? src[cin + (size_t)k * C + 16 * nt + (l & 15)] : 0.f;
+                }, &m->c0_unscale);
+                m->dfc1_h3 = pack_h3(P, (C / 16) * KC, [&](int fr, int l, int i) {
+                    const int nt = fr / KC, kc = fr % KC;
+                    return src[wt1 + (size_t)chan(kc, l, i) * C + 16 * nt + (l & 15)];
+                }, &m->dfc1_unscale);
+                m->cp_h3 = pack_h3(P, kt * KC, [&](int fr, int l, int i) {
+                    const int k = fr / KC, kc = fr % KC;
+                    return src[cpw + ((size_t)k * C + chan(kc, l, i)) * 16 + (l & 15)];
+                }, &m->cp_unscale);
+            }
         }
     }
     ok = ok && prep_glin(P, "df_dec.df_gru.linear_in.0.weight", m->dfg_in) && prep_gru(P, "df_dec.df_gru.gru", c.df_num_layers, m->df_gru);
@@ -552,6 +606,13 @@ struct Ws {
     size_t pgi[DFX_MAX_GRU_LAYERS], py[DFX_MAX_GRU_LAYERS], ph[DFX_MAX_GRU_LAYERS];  // layer-pipelined GRU phase: gi, y, h state per layer
     size_t pxb, pxb_floats;   // h exchange buffers of the two-CU GRU kernel: [layer][group][2][2][16][128] granules of 8 bytes
 };
+// df_conv0's output is recomputed by its consumers instead of being stored when the pathway conv has the sliding-window kernel
+// (kt <= 5).  DFX_FUSE_C0=0 restores the materialised c0 (dfx_k_conv_in_df -> dfx_k_pwconv / dfx_k_df_convp2) for A/B runs.
+static bool dfx_fuse_c0(const dfx_model_cfg &c) {
+    static const bool off = [] { const char *e = getenv("DFX_FUSE_C0"); return e && e[0] == '0'; }();
+    return !off && c.df_pathway_kernel_size_t <= 5;
+}
+
 Ws plan_ws(const dfx_model_cfg &c, int64_t R, int64_t B = 0) {
     Ws w{};
     size_t off = 0;
@@ -565,7 +626,7 @@ Ws plan_ws(const dfx_model_cfg &c, int64_t R, int64_t B = 0) {
     w.e1 = take(R * (E / 2) * C);
     w.e2 = take(R * (E / 4) * C);
     w.e3 = take(R * (E / 4) * C);
-    w.c0 = take(R * Fd * C);
+    w.c0 = dfx_fuse_c0(c) ? 0 : take(R * Fd * C);  // only materialised by the unfused DF-encoder path
     w.c1 = take(R * (Fd / 2) * C);
     w.emb_in = take(R * emb);
     w.emb = take(R * emb);
@@ -644,9 +705,14 @@ static int launch_pw(int mode, const dfx_model *m, const PwW &w, const float *x,
 }
 
 template <int C, int KT>
-static int launch_convp2(const dfx_model *m, const float *c0, float *out, int64_t B, int64_t T, int Fd, int NO, hipStream_t s) {
+static int launch_convp2(const dfx_model *m, const float *c0, const float *feat_spec, float *out, int64_t B, int64_t T, int Fd,
+                         int NO, hipStream_t s) {
     DfxCp2Args A;
     A.c0 = c0;
+    A.feat = feat_spec;  // non-null: df_conv0 is recomputed on the fly, c0 is not read
+    A.weff0 = m->p(m->cin_weff);
+    A.bias0 = m->p(m->cin_b);
+    A.L = m->cfg.conv_lookahead;
     A.weff = m->p(m->cp_weff);
     A.bias = m->p(m->cp_b16);
     A.out = out;
@@ -667,7 +733,101 @@ static int launch_convp2(const dfx_model *m, const float *c0, float *out, int64_
     const int64_t nruns = B * A.nfb * A.nseg;
     const int grid = nn_grid(dfx_ceil_div(nruns, 4), 8);
     DfxKScope ks(DFX_K_DF_CONVP, s);
-    dfx_launch(dfx_k_df_convp2<C, KT>, dim3(grid), dim3(256), 0, s, A);
+    if (feat_spec) dfx_launch(dfx_k_df_convp2<C, KT, true>, dim3(grid), dim3(256), 0, s, A);
+    else dfx_launch(dfx_k_df_convp2<C, KT, false>, dim3(grid), dim3(256), 0, s, A);
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
+}
+
+template <int C, int KT>
+static int launch_convp_h3(const dfx_model *m, const float *feat_spec, float *out, int64_t B, int64_t T, int Fd, int NO,
+                           hipStream_t s) {
+    if constexpr (C % 32 != 0) {
+        DFX_FAIL(DFX_ERR_UNSUPPORTED, "fp16-split df_convp needs conv_ch %% 32 == 0");
+    } else {
+        DfxCphArgs A;
+        A.feat = feat_spec;
+        A.w0f = reinterpret_cast<const dfx_h8 *>(m->p(m->c0_h3));
+        A.bias0 = m->p(m->cin_b);
+        A.wf = reinterpret_cast<const dfx_h8 *>(m->p(m->cp_h3));
+        A.bias = m->p(m->cp_b16);
+        A.out = out;
+        A.B = B;
+        A.T = T;
+        A.Fd = Fd;
+        A.NO = NO;
+        A.L = m->cfg.conv_lookahead;
+        A.unscale0 = m->c0_unscale;
+        A.unscale = m->cp_unscale;
+        A.nfb = (Fd + 15) / 16;
+        const int64_t want = (int64_t)dfx_env_num_cus() * 4 * 4;  // two resident waves per SIMD, two rounds
+        int64_t nseg = dfx_ceil_div(want, B * A.nfb);
+        const int64_t max_seg = dfx_ceil_div(T, (int64_t)8 * KT);
+        if (nseg > max_seg) nseg = max_seg;
+        if (nseg < 1) nseg = 1;
+        const int64_t tseg = dfx_ceil_div(dfx_ceil_div(T, nseg), (int64_t)KT) * KT;
+        A.tseg = (int)tseg;
+        A.nseg = (int)dfx_ceil_div(T, tseg);
+        const int64_t nruns = B * A.nfb * A.nseg;
+        const int grid = nn_grid(dfx_ceil_div(nruns, 4), 2);
+        DfxKScope ks(DFX_K_DF_CONVP, s);
+        dfx_launch((dfx_k_df_convp_h3<C, KT>), dim3(grid), dim3(256), 0, s, A);
+        DFX_LAUNCH_CHECK();
+        return DFX_OK;
+    }
+}
+
+template <int C>
+static int launch_conv01_h3(const dfx_model *m, const PwW &w, const float *feat_spec, float *out, int64_t B, int64_t T, int Fin,
+                            int Fout, int stride, hipStream_t s) {
+    if constexpr (C % 32 != 0) {
+        DFX_FAIL(DFX_ERR_UNSUPPORTED, "fp16-split df_conv1 needs conv_ch %% 32 == 0");
+    } else {
+        DfxC01hArgs A;
+        A.feat = feat_spec;
+        A.w0f = reinterpret_cast<const dfx_h8 *>(m->p(m->c0_h3));
+        A.bias0 = m->p(m->cin_b);
+        A.dw = m->p(w.dw);
+        A.wpf = reinterpret_cast<const dfx_h8 *>(m->p(m->dfc1_h3));
+        A.bias = m->p(w.bias);
+        A.out = out;
+        A.B = B;
+        A.T = T;
+        A.Fin = Fin;
+        A.Fout = Fout;
+        A.stride = stride;
+        A.L = m->cfg.conv_lookahead;
+        A.unscale0 = m->c0_unscale;
+        A.unscale = m->dfc1_unscale;
+        const int grid = nn_grid(dfx_ceil_div(B * T * Fout, 64), 2);
+        DfxKScope ks(DFX_K_PWCONV, s);
+        dfx_launch(dfx_k_df_conv01_h3<C>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
+        DFX_LAUNCH_CHECK();
+        return DFX_OK;
+    }
+}
+
+// enc.df_conv0 -> enc.df_conv1 without the c0 round trip (dfx_k_df_conv01)
+template <int C>
+static int launch_conv01(const dfx_model *m, const PwW &w, const float *feat_spec, float *out, int64_t B, int64_t T, int Fin,
+                         int Fout, int stride, hipStream_t s) {
+    DfxC01Args A;
+    A.feat = feat_spec;
+    A.weff0 = m->p(m->cin_weff);
+    A.bias0 = m->p(m->cin_b);
+    A.dw = m->p(w.dw);
+    A.wt = m->p(w.wt);
+    A.bias = m->p(w.bias);
+    A.out = out;
+    A.B = B;
+    A.T = T;
+    A.Fin = Fin;
+    A.Fout = Fout;
+    A.stride = stride;
+    A.L = m->cfg.conv_lookahead;
+    const int grid = nn_grid(dfx_ceil_div(B * T * Fout, 64), 8);
+    DfxKScope ks(DFX_K_PWCONV, s);
+    dfx_launch(dfx_k_df_conv01<C>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
     DFX_LAUNCH_CHECK();
     return DFX_OK;
 }
@@ -871,8 +1031,17 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         return DFX_OK;
     };
     if ((rc = signal(EV_START, s)) || (rc = wait(EV_START, x1))) return rc;
-    // ---- Encoder, DF branch on x1 (deepfilternet3.py:176-179)
-    {
+    // ---- Encoder, DF branch on x1 (deepfilternet3.py:176-179).  By default c0 = df_conv0(feat_spec) never exists in HBM: its two
+    // consumers (df_conv1 here, df_convp below) recompute the tiles they need from feat_spec on the matrix core.
+    const bool fuse_c0 = dfx_fuse_c0(c);
+    const float *cp_feat = fuse_c0 ? feat_spec : nullptr;
+    const bool fuse_h3 = fuse_c0 && !m->exact_fp32 && C % 32 == 0 && m->cp_h3;  // fp16-split matrix ops (default)
+    if (fuse_c0) {
+        if ((rc = signal(EV_C0, x1)) || (rc = wait(EV_C0, x2))) return rc;  // df_convp only needs feat_spec
+        if (fuse_h3) rc = launch_conv01_h3<C>(m, m->dfc1, feat_spec, c1, B, T, Fd, Fd / 2, 2, x1);
+        else rc = launch_conv01<C>(m, m->dfc1, feat_spec, c1, B, T, Fd, Fd / 2, 2, x1);
+        if (rc) return rc;
+    } else {
         DfxCinArgs A;
         A.feat = feat_spec;
         A.weff = m->p(m->cin_weff);
@@ -885,19 +1054,28 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         DfxKScope ks(DFX_K_CONV_IN_DF, x1);
         dfx_launch(dfx_k_conv_in_df<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R * Fd, 64), 8)), dim3(DFX_PW_THREADS), 0, x1, A);
         DFX_LAUNCH_CHECK();
+        if ((rc = signal(EV_C0, x1)) || (rc = wait(EV_C0, x2))) return rc;
+        if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->dfc1, c0, nullptr, c1, R, Fd, Fd / 2, 2, x1))) return rc;
     }
-    if ((rc = signal(EV_C0, x1)) || (rc = wait(EV_C0, x2))) return rc;
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->dfc1, c0, nullptr, c1, R, Fd, Fd / 2, 2, x1))) return rc;
     if ((rc = signal(EV_C1, x1))) return rc;
     auto run_convp = [&]() -> int {
         // ---- df_dec.df_convp on x2 (only needs c0; :328)
-        if (c.df_pathway_kernel_size_t <= 5) {
+        if (fuse_h3) {
             switch (c.df_pathway_kernel_size_t) {
-                case 1: rc = launch_convp2<C, 1>(m, c0, c0p, B, T, Fd, NO, x2); break;
-                case 2: rc = launch_convp2<C, 2>(m, c0, c0p, B, T, Fd, NO, x2); break;
-                case 3: rc = launch_convp2<C, 3>(m, c0, c0p, B, T, Fd, NO, x2); break;
-                case 4: rc = launch_convp2<C, 4>(m, c0, c0p, B, T, Fd, NO, x2); break;
-                default: rc = launch_convp2<C, 5>(m, c0, c0p, B, T, Fd, NO, x2); break;
+                case 1: rc = launch_convp_h3<C, 1>(m, feat_spec, c0p, B, T, Fd, NO, x2); break;
+                case 2: rc = launch_convp_h3<C, 2>(m, feat_spec, c0p, B, T, Fd, NO, x2); break;
+                case 3: rc = launch_convp_h3<C, 3>(m, feat_spec, c0p, B, T, Fd, NO, x2); break;
+                case 4: rc = launch_convp_h3<C, 4>(m, feat_spec, c0p, B, T, Fd, NO, x2); break;
+                default: rc = launch_convp_h3<C, 5>(m, feat_spec, c0p, B, T, Fd, NO, x2); break;
+            }
+            if (rc) return rc;
+        } else if (c.df_pathway_kernel_size_t <= 5) {
+            switch (c.df_pathway_kernel_size_t) {
+                case 1: rc = launch_convp2<C, 1>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2); break;
+                case 2: rc = launch_convp2<C, 2>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2); break;
+                case 3: rc = launch_convp2<C, 3>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2); break;
+                case 4: rc = launch_convp2<C, 4>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2); break;
+                default: rc = launch_convp2<C, 5>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2); break;
             }
             if (rc) return rc;
         } else {

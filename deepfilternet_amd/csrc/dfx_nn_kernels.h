@@ -278,6 +278,396 @@ __global__ void __launch_bounds__(DFX_PW_THREADS) dfx_k_conv_in_df(DfxCinArgs A)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// enc.df_conv0 computed on the fly (no c0 tensor in HBM).  c0 [B,T,Fd,C] is the largest activation of the network (4*Fd*C bytes
+// per frame, written once and read by df_conv1 and df_convp), yet every element is only a K = 18 dot product of feat_spec, so its
+// two consumers recompute the tiles they need on the matrix core instead:
+//   dfx_c0_patch  gathers the im2col column of one (frame, bin) position as the MFMA B operand (k = 4*ks + q), exactly like
+//                 dfx_k_conv_in_df;
+//   dfx_c0_tile   runs the C/16 x 5 MFMAs and applies bias + ReLU.  The D fragment gives lane (pos, q) the channels
+//                 {16*i + 4*q + r}: element [4*i + r] of the result.  That is directly a valid B operand for the next GEMM when the
+//                 consumer enumerates its contraction index as k-step ks <-> channel 16*(ks>>2) + 4*q + (ks&3) (the weights are
+//                 read in that order), so the chained GEMMs never leave the registers.
+// ---------------------------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ void dfx_c0_patch(const float *__restrict__ feat, int64_t b, int64_t t, int f, bool valid,
+                                                    int64_t T, int Fin, int L, int q, float (&bv)[5]) {
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        const int k = 4 * ks + q, tap = k >> 1, ch = k & 1, kt = tap / 3, kf = tap - 3 * kt;
+        const int64_t tau = t - 2 + kt, tin = tau + L;
+        const int fin = f - 1 + kf;
+        float v = 0.f;
+        if (valid && k < 18 && tau >= 0 && tin < T && fin >= 0 && fin < Fin) v = feat[((b * T + tin) * Fin + fin) * 2 + ch];
+        bv[ks] = v;
+    }
+}
+
+template <int C>
+static __device__ __forceinline__ void dfx_c0_tile(const float (&areg0)[C / 16][5], const float4 (&bias0)[C / 16],
+                                                   const float (&bv)[5], bool keep, float (&dst)[C / 4]) {
+    constexpr int NT = C / 16;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg0[nt][ks], bv[ks], acc[nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        dst[4 * nt + 0] = keep ? fmaxf(acc[nt][0] + bias0[nt].x, 0.f) : 0.f;
+        dst[4 * nt + 1] = keep ? fmaxf(acc[nt][1] + bias0[nt].y, 0.f) : 0.f;
+        dst[4 * nt + 2] = keep ? fmaxf(acc[nt][2] + bias0[nt].z, 0.f) : 0.f;
+        dst[4 * nt + 3] = keep ? fmaxf(acc[nt][3] + bias0[nt].w, 0.f) : 0.f;
+    }
+}
+
+// enc.df_conv0 -> enc.df_conv1 fused (deepfilternet3.py:115-119,176-177): c1 = relu(bn(pw(dw_{1x3, fstride}(c0)))) with the three c0
+// tiles a 16-position output tile needs (bins stride*fo - 1 + j) recomputed from feat_spec.  Per 16 outputs: 3*5*C/16 MFMAs for c0 +
+// (C/4)*(C/16) for the pointwise conv; HBM traffic is the c1 store (4*Fout*C bytes per frame) and the (cached) feat_spec reads.
+struct DfxC01Args {
+    const float *feat;   // [B, T, Fin, 2]
+    const float *weff0;  // [20][C]  folded df_conv0 (see dfx_k_conv_in_df)
+    const float *bias0;  // [C]
+    const float *dw;     // [3][C]
+    const float *wt;     // [C][C]  wt[k][n] = W_pw[n][k] * bn_scale[n]
+    const float *bias;   // [C]
+    float *out;          // [B*T, Fout, C]
+    int64_t B, T;
+    int Fin, Fout, stride, L;
+};
+
+template <int C>
+__global__ void __launch_bounds__(DFX_PW_THREADS) dfx_k_df_conv01(DfxC01Args A) {
+    constexpr int CPL = C / 4, NT = C / 16;
+    __shared__ float4 dws[3 * C / 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
+    for (int i = tid; i < 3 * C / 4; i += DFX_PW_THREADS) dws[i] = reinterpret_cast<const float4 *>(A.dw)[i];
+    float areg0[NT][5];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) areg0[nt][ks] = A.weff0[(4 * ks + q) * C + 16 * nt + jl];
+    float areg[NT][CPL];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < CPL; ++ks) areg[nt][ks] = A.wt[(16 * (ks >> 2) + 4 * q + (ks & 3)) * C + 16 * nt + jl];
+    float4 bias0[NT], biasr[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        bias0[nt] = reinterpret_cast<const float4 *>(A.bias0)[4 * nt + q];
+        biasr[nt] = reinterpret_cast<const float4 *>(A.bias)[4 * nt + q];
+    }
+    __syncthreads();
+    const int64_t total = A.B * A.T * A.Fout;
+    const int64_t ntiles = (total + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t pos = tile * 16 + jl;
+        const bool valid = pos < total;
+        const int64_t r = pos / A.Fout;
+        const int fo = (int)(pos - r * A.Fout);
+        const int64_t b = r / A.T, t = r - b * A.T;
+        float u[CPL];
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) u[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int fi = fo * A.stride + j - 1;
+            const bool ok = valid && fi >= 0 && fi < A.Fin;
+            float bv[5], c0v[CPL];
+            dfx_c0_patch(A.feat, b, t, fi, ok, A.T, A.Fin, A.L, q, bv);
+            dfx_c0_tile<C>(areg0, bias0, bv, ok, c0v);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 w = dws[j * (C / 4) + 4 * nt + q];
+                u[4 * nt + 0] += w.x * c0v[4 * nt + 0];
+                u[4 * nt + 1] += w.y * c0v[4 * nt + 1];
+                u[4 * nt + 2] += w.z * c0v[4 * nt + 2];
+                u[4 * nt + 3] += w.w * c0v[4 * nt + 3];
+            }
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < CPL; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[nt][ks], u[ks], acc[nt], 0, 0, 0);
+        if (valid) {
+            float4 *op = reinterpret_cast<float4 *>(A.out + pos * C + 4 * q);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                op[4 * nt] = make_float4(fmaxf(acc[nt][0] + biasr[nt].x, 0.f), fmaxf(acc[nt][1] + biasr[nt].y, 0.f),
+                                         fmaxf(acc[nt][2] + biasr[nt].z, 0.f), fmaxf(acc[nt][3] + biasr[nt].w, 0.f));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp16-split ("fp16x3", see dfx_env.h) forms of the two fused DF-encoder kernels; these are the default, the fp32-MFMA forms
+// above serve DFX_EXACT_FP32=1 and conv_ch < 32.  With fp32 MFMAs the fused kernels are matrix-pipe bound (the recomputation of c0
+// costs 5*C/16 16x16x4 MFMAs per tile); on v_mfma_f32_16x16x32_f16 the whole K = 18 contraction is ONE k-chunk (3 MFMAs per 16
+// channels) and the C-deep contractions take C/32 chunks.  Operands:
+//   c0      B = patch, lane (pos, q) holds k = 8q..8q+7 = taps 4q..4q+3 x (re, im): four float2 loads from feat_spec
+//           A = folded df_conv0 weights, fragment [nt][hi,lo] (k >= 18 zero), pre-scaled by a power of two
+//   chained B = the 16 channels {16*i + 4*q + r} a lane holds after dfx_c0_tile (element e = 4*i + r): chunk kc takes elements
+//           8*kc .. 8*kc+7, so k-index (kc, q, i) <-> channel 16*((8kc+i)>>2) + 4q + ((8kc+i)&3); the host packs the A fragments
+//           of df_conv1's pointwise conv and of df_convp in that order (pack_h3 in dfx_model.hip).
+// The feat_spec loads of the NEXT tile / frame are issued before the current one is computed (the only HBM/L2 latency in the loop).
+// ---------------------------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ void dfx_c0_patch_load(const float *__restrict__ feat, int64_t b, int64_t t, int f, bool valid,
+                                                         int64_t T, int Fin, int L, int q, float2 (&raw)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int tap = 4 * q + i, kt = tap / 3, kf = tap - 3 * kt;
+        const int64_t tau = t - 2 + kt, tin = tau + L;
+        const int fin = f - 1 + kf;
+        float2 v = make_float2(0.f, 0.f);
+        if (valid && tap < 9 && tau >= 0 && tin < T && fin >= 0 && fin < Fin)
+            v = *reinterpret_cast<const float2 *>(feat + ((b * T + tin) * Fin + fin) * 2);
+        raw[i] = v;
+    }
+}
+
+template <int C>
+static __device__ __forceinline__ void dfx_c0_tile_h3(const dfx_h8 (&w0h)[C / 16], const dfx_h8 (&w0l)[C / 16],
+                                                      const float4 (&bias0)[C / 16], float unscale0, const float2 (&raw)[4],
+                                                      bool keep, float (&dst)[C / 4]) {
+    constexpr int NT = C / 16;
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[2 * i] = raw[i].x, x[2 * i + 1] = raw[i].y;
+    dfx_h8 ph, pl;
+    dfx_split8(x, ph, pl);
+    f32x4 acc[NT];  // the NT chains are independent: term-major order keeps dependent MFMAs NT issues apart
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(w0l[nt], ph, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(w0h[nt], pl, acc[nt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(w0h[nt], ph, acc[nt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        dst[4 * nt + 0] = keep ? fmaxf(acc[nt][0] * unscale0 + bias0[nt].x, 0.f) : 0.f;
+        dst[4 * nt + 1] = keep ? fmaxf(acc[nt][1] * unscale0 + bias0[nt].y, 0.f) : 0.f;
+        dst[4 * nt + 2] = keep ? fmaxf(acc[nt][2] * unscale0 + bias0[nt].z, 0.f) : 0.f;
+        dst[4 * nt + 3] = keep ? fmaxf(acc[nt][3] * unscale0 + bias0[nt].w, 0.f) : 0.f;
+    }
+}
+
+struct DfxC01hArgs {
+    const float *feat;   // [B, T, Fin, 2]
+    const dfx_h8 *w0f;   // [C/16][hi,lo][64]        folded df_conv0
+    const float *bias0;  // [C]
+    const float *dw;     // [3][C]
+    const dfx_h8 *wpf;   // [C/16][C/32][hi,lo][64]  df_conv1 pointwise (BN-scaled)
+    const float *bias;   // [C]
+    float *out;          // [B*T, Fout, C]
+    int64_t B, T;
+    int Fin, Fout, stride, L;
+    float unscale0, unscale;
+};
+
+template <int C>
+__global__ void __launch_bounds__(DFX_PW_THREADS, 1) dfx_k_df_conv01_h3(DfxC01hArgs A) {
+    constexpr int CPL = C / 4, NT = C / 16, KC = C >= 32 ? C / 32 : 1;
+    static_assert(C % 32 == 0, "one k-chunk is 32 channels");
+    __shared__ float4 dws[3 * C / 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
+    for (int i = tid; i < 3 * C / 4; i += DFX_PW_THREADS) dws[i] = reinterpret_cast<const float4 *>(A.dw)[i];
+    dfx_h8 w0h[NT], w0l[NT], wph[NT][KC], wpl[NT][KC];
+    float4 bias0[NT], biasr[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        w0h[nt] = A.w0f[(nt * 2 + 0) * 64 + lane];
+        w0l[nt] = A.w0f[(nt * 2 + 1) * 64 + lane];
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            wph[nt][kc] = A.wpf[((nt * KC + kc) * 2 + 0) * 64 + lane];
+            wpl[nt][kc] = A.wpf[((nt * KC + kc) * 2 + 1) * 64 + lane];
+        }
+        bias0[nt] = reinterpret_cast<const float4 *>(A.bias0)[4 * nt + q];
+        biasr[nt] = reinterpret_cast<const float4 *>(A.bias)[4 * nt + q];
+    }
+    __syncthreads();
+    const int64_t total = A.B * A.T * A.Fout;
+    const int64_t ntiles = (total + 15) / 16;
+    const int64_t tstep = (int64_t)gridDim.x * 4;
+    float2 raw[3][4];
+    bool okj[3];
+    auto issue = [&](int64_t tile) {  // feat_spec loads of one tile (three c0 positions per lane)
+        const int64_t pos = tile * 16 + jl;
+        const bool valid = tile < ntiles && pos < total;
+        const int64_t r = pos / A.Fout;
+        const int fo = (int)(pos - r * A.Fout);
+        const int64_t b = r / A.T, t = r - b * A.T;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int fi = fo * A.stride + j - 1;
+            okj[j] = valid && fi >= 0 && fi < A.Fin;
+            dfx_c0_patch_load(A.feat, b, t, fi, okj[j], A.T, A.Fin, A.L, q, raw[j]);
+        }
+    };
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    issue(tile);
+    for (; tile < ntiles; tile += tstep) {
+        const int64_t pos = tile * 16 + jl;
+        const bool valid = pos < total;
+        float2 cur[3][4];
+        bool okc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            okc[j] = okj[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cur[j][i] = raw[j][i];
+        }
+        issue(tile + tstep);
+        float u[CPL];
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) u[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float c0v[CPL];
+            dfx_c0_tile_h3<C>(w0h, w0l, bias0, A.unscale0, cur[j], okc[j], c0v);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 w = dws[j * (C / 4) + 4 * nt + q];
+                u[4 * nt + 0] += w.x * c0v[4 * nt + 0];
+                u[4 * nt + 1] += w.y * c0v[4 * nt + 1];
+                u[4 * nt + 2] += w.z * c0v[4 * nt + 2];
+                u[4 * nt + 3] += w.w * c0v[4 * nt + 3];
+            }
+        }
+        dfx_h8 uh[KC], ul[KC];
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) dfx_split8(u + 8 * kc, uh[kc], ul[kc]);
+        float4 *op = reinterpret_cast<float4 *>(A.out + pos * C + 4 * q);
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(wpl[nt][kc], uh[kc], acc[nt]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(wph[nt][kc], ul[kc], acc[nt]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(wph[nt][kc], uh[kc], acc[nt]);
+        }
+        if (valid) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                op[4 * nt] = make_float4(fmaxf(acc[nt][0] * A.unscale + biasr[nt].x, 0.f), fmaxf(acc[nt][1] * A.unscale + biasr[nt].y, 0.f),
+                                         fmaxf(acc[nt][2] * A.unscale + biasr[nt].z, 0.f), fmaxf(acc[nt][3] * A.unscale + biasr[nt].w, 0.f));
+        }
+    }
+}
+
+// df_dec.df_convp with df_conv0 recomputed, fp16-split form of dfx_k_df_convp2<C, KT, true> (same run decomposition: a wave walks a
+// segment of frames for 16 bins of one clip).  The window holds the hi/lo halves of the last KT c0 frames (the B operands), the
+// A fragments [KT][C/32][hi,lo] are persistent: 3*KT*C/32 + 3*C/16 MFMAs per 16 bins and frame.
+struct DfxCphArgs {
+    const float *feat;   // [B, T, Fd, 2]
+    const dfx_h8 *w0f;   // [C/16][hi,lo][64]       folded df_conv0
+    const float *bias0;  // [C]
+    const dfx_h8 *wf;    // [KT][C/32][hi,lo][64]   folded df_convp, n = 2*O outputs padded to 16
+    const float *bias;   // [16]
+    float *out;          // [B, NO/2, T, Fd, 2]  (tap-major, DFX_COEF_BOTF)
+    int64_t B, T;
+    int Fd, NO, nfb, nseg, tseg, L;
+    float unscale0, unscale;
+};
+
+template <int C, int KT>
+__global__ void __launch_bounds__(256, 1) dfx_k_df_convp_h3(DfxCphArgs A) {
+    constexpr int CPL = C / 4, NT = C / 16, KC = C >= 32 ? C / 32 : 1;
+    static_assert(C % 32 == 0, "one k-chunk is 32 channels");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
+    dfx_h8 w0h[NT], w0l[NT], wh[KT][KC], wl[KT][KC];
+    float4 bias0[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        w0h[nt] = A.w0f[(nt * 2 + 0) * 64 + lane];
+        w0l[nt] = A.w0f[(nt * 2 + 1) * 64 + lane];
+        bias0[nt] = reinterpret_cast<const float4 *>(A.bias0)[4 * nt + q];
+    }
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            wh[k][kc] = A.wf[((k * KC + kc) * 2 + 0) * 64 + lane];
+            wl[k][kc] = A.wf[((k * KC + kc) * 2 + 1) * 64 + lane];
+        }
+    float biasr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) biasr[r] = A.bias[4 * q + r];
+    const int64_t nruns = A.B * A.nfb * A.nseg;
+    for (int64_t run = (int64_t)blockIdx.x * 4 + wave; run < nruns; run += (int64_t)gridDim.x * 4) {
+        const int seg = (int)(run % A.nseg);
+        const int64_t rest = run / A.nseg;
+        const int fb = (int)(rest % A.nfb);
+        const int64_t b = rest / A.nfb;
+        const int f = fb * 16 + jl;
+        const bool fvalid = f < A.Fd;
+        const int64_t t0 = (int64_t)seg * A.tseg;
+        const int64_t t1 = (t0 + A.tseg < A.T) ? t0 + A.tseg : A.T;
+        dfx_h8 xh[KT][KC], xl[KT][KC];  // frame tau lives in slot (tau - t0) mod KT
+        float2 raw[4];
+        auto make_frame = [&](dfx_h8 (&dh)[KC], dfx_h8 (&dl)[KC], int64_t tau, const float2 (&rw)[4]) {
+            float c0v[CPL];
+            // frames before the clip are the zero padding of c0 itself (wave-uniform test)
+            dfx_c0_tile_h3<C>(w0h, w0l, bias0, A.unscale0, rw, fvalid && tau >= 0, c0v);
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) dfx_split8(c0v + 8 * kc, dh[kc], dl[kc]);
+        };
+        dfx_static_for<1, KT>([&](auto sc) {
+            constexpr int sl = decltype(sc)::value;
+            const int64_t tau = t0 - KT + sl;
+            dfx_c0_patch_load(A.feat, b, tau, f, fvalid && tau >= 0, A.T, A.Fd, A.L, q, raw);
+            make_frame(xh[sl], xl[sl], tau, raw);
+        });
+        dfx_c0_patch_load(A.feat, b, t0, f, fvalid, A.T, A.Fd, A.L, q, raw);
+        for (int64_t tb = t0; tb < t1; tb += KT) {
+            dfx_static_for<0, KT>([&](auto pc) {
+                constexpr int ph = decltype(pc)::value;
+                const int64_t t = tb + ph;
+                if (t < t1) {  // wave-uniform
+                    float2 cur[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) cur[i] = raw[i];
+                    dfx_c0_patch_load(A.feat, b, t + 1, f, fvalid && t + 1 < t1, A.T, A.Fd, A.L, q, raw);
+                    make_frame(xh[ph], xl[ph], t, cur);
+                    // three independent accumulation chains (one per product term), summed small-to-large at the end
+                    f32x4 aa = f32x4{0.f, 0.f, 0.f, 0.f}, ab = aa, ac = aa;
+                    dfx_static_for<0, KT>([&](auto kcn) {
+                        constexpr int k = decltype(kcn)::value;
+                        constexpr int sl = (ph + 1 + k) % KT;  // tap k reads frame t - (KT-1) + k
+#pragma unroll
+                        for (int kc = 0; kc < KC; ++kc) {
+                            aa = dfx_mfma_16x16x32_f16(wl[k][kc], xh[sl][kc], aa);
+                            ab = dfx_mfma_16x16x32_f16(wh[k][kc], xl[sl][kc], ab);
+                            ac = dfx_mfma_16x16x32_f16(wh[k][kc], xh[sl][kc], ac);
+                        }
+                    });
+                    f32x4 acc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = (aa[r] + ab[r]) + ac[r];
+                    if (fvalid) {
+                        float *op = A.out + ((b * (A.NO / 2) * A.T + t) * A.Fd + f) * 2;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            if (4 * q + 2 * h < A.NO)
+                                *reinterpret_cast<float2 *>(op + (int64_t)(2 * q + h) * A.T * A.Fd * 2) =
+                                    make_float2(fmaxf(acc[2 * h] * A.unscale + biasr[2 * h], 0.f),
+                                                fmaxf(acc[2 * h + 1] * A.unscale + biasr[2 * h + 1], 0.f));
+                    }
+                }
+            });
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // erb_dec.conv0_out: Conv2d(C -> 1, 1x3) + BN(1) + Sigmoid on  xin = relu(a*e0 + b) + d1   (deepfilternet3.py:241-243,253)
 //   m[r, f] = sigmoid(bias + sum_j sum_c w[j][c] * xin[r, f+j-1, c])
 // A tile is a whole number of frames (E positions each); xin is staged in LDS, threads (pos, j) form the three per-
@@ -421,7 +811,10 @@ __global__ void __launch_bounds__(DFX_CP_THREADS) dfx_k_df_convp(DfxCpArgs A) {
 // HBM exactly once (plus kt-1 halo frames per segment), and W_eff is the persistent A fragment (kt*C/4 registers).
 // ---------------------------------------------------------------------------------------------------------------------
 struct DfxCp2Args {
-    const float *c0;    // [B*T, Fd, C]
+    const float *c0;    // [B*T, Fd, C]   (FUSE_C0: unused)
+    const float *feat;  // FUSE_C0: feat_spec [B, T, Fd, 2], folded df_conv0 weights [20][C] and bias [C], lookahead L
+    const float *weff0, *bias0;
+    int L;
     const float *weff;  // [kt][C][16]  weff[(k*C + c)*16 + n], n >= NO zero
     const float *bias;  // [16]
     float *out;         // [B, NO/2, T, Fd, 2]  (tap-major, DFX_COEF_BOTF)
@@ -429,10 +822,22 @@ struct DfxCp2Args {
     int Fd, NO, nfb, nseg, tseg;  // nfb = ceil(Fd/16) bin blocks, nseg segments of tseg frames (tseg % kt == 0)
 };
 
-template <int C, int KT>
+// FUSE_C0: the window frames are not loaded but recomputed from feat_spec (dfx_c0_tile above): no c0 tensor exists and the kernel's
+// HBM traffic is its 8*O*Fd-byte-per-frame store; it then is matrix-core bound (5*C/16 + KT*C/4 MFMAs per 16 bins and frame).
+template <int C, int KT, bool FUSE_C0>
 __global__ void __launch_bounds__(256) dfx_k_df_convp2(DfxCp2Args A) {
-    constexpr int CPL = C / 4, V4 = CPL / 4;
+    constexpr int CPL = C / 4, V4 = CPL / 4, NT = C / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
+    float areg0[NT][5];
+    float4 bias0[NT];
+    if (FUSE_C0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int ks = 0; ks < 5; ++ks) areg0[nt][ks] = A.weff0[(4 * ks + q) * C + 16 * nt + jl];
+            bias0[nt] = reinterpret_cast<const float4 *>(A.bias0)[4 * nt + q];
+        }
+    }
     float areg[KT][CPL];
 #pragma unroll
     for (int k = 0; k < KT; ++k)
@@ -452,8 +857,17 @@ __global__ void __launch_bounds__(256) dfx_k_df_convp2(DfxCp2Args A) {
         const int64_t t0 = (int64_t)seg * A.tseg;
         const int64_t t1 = (t0 + A.tseg < A.T) ? t0 + A.tseg : A.T;
         float win[KT][CPL];
-        auto load_frame = [&](float *dst, int64_t tau) {
-            if (fvalid && tau >= 0) {
+        auto load_frame = [&](float (&dst)[CPL], int64_t tau) {
+            if (FUSE_C0) {
+                if (tau >= 0) {  // wave-uniform; frames before the clip are the zero padding of c0 itself
+                    float bv[5];
+                    dfx_c0_patch(A.feat, b, tau, f, fvalid, A.T, A.Fd, A.L, q, bv);
+                    dfx_c0_tile<C>(areg0, bias0, bv, fvalid, dst);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < CPL; ++i) dst[i] = 0.f;
+                }
+            } else if (fvalid && tau >= 0) {
                 const float4 *p = reinterpret_cast<const float4 *>(A.c0 + ((b * A.T + tau) * A.Fd + f) * C + 4 * q);
 #pragma unroll
                 for (int v = 0; v < V4; ++v) {  // float4 v of this lane = channels 16*v + 4*q .. +3 (k-steps 4v .. 4v+3)

@@ -6,6 +6,20 @@ void dfx_set_error(const char *, ...) {}
 bool dfx_prof_on(int) { return false; }
 void dfx_prof_begin(int, hipStream_t) {}
 void dfx_prof_end(int, hipStream_t) {}
+// streaming traffic beside the recurrences: mode 0 plain float4 copy, 1 non-temporal loads+stores, 2 read-only sum
+template <int MODE> __global__ void __launch_bounds__(256) k_stream(const float4 *__restrict__ in, float4 *__restrict__ out, int64_t n, int reps) {
+    float4 acc = {0, 0, 0, 0};
+    for (int r = 0; r < reps; ++r)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+            float4 v;
+            if (MODE == 1) { v.x = __builtin_nontemporal_load(&in[i].x); v.y = __builtin_nontemporal_load(&in[i].y); v.z = __builtin_nontemporal_load(&in[i].z); v.w = __builtin_nontemporal_load(&in[i].w); }
+            else v = in[i];
+            if (MODE == 2) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            else if (MODE == 1) { __builtin_nontemporal_store(v.x, &out[i].x); __builtin_nontemporal_store(v.y, &out[i].y); __builtin_nontemporal_store(v.z, &out[i].z); __builtin_nontemporal_store(v.w, &out[i].w); }
+            else out[i] = v;
+        }
+    if (MODE == 2 && acc.x == 12345.678f) out[0] = acc;
+}
 int main(int argc, char **argv) {
     const int64_t B = 256, T = argc > 2 ? atoll(argv[2]) : 167;
     const int NK = argc > 1 ? atoi(argv[1]) : 5;
@@ -24,6 +38,10 @@ int main(int argc, char **argv) {
         CK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
     }
     CK(hipFuncSetAttribute((const void *)dfx_k_gru_rec_h3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DFX_GH_SMEM));
+    const int64_t NS = (int64_t)1 << 26;  // 1 GiB in, 1 GiB out
+    float4 *sin_, *sout; CK(hipMalloc(&sin_, NS * 16)); CK(hipMalloc(&sout, NS * 16)); CK(hipMemset(sin_, 0, NS * 16));
+    hipStream_t ss; CK(hipStreamCreateWithFlags(&ss, hipStreamNonBlocking));
+    const int smode = argc > 3 ? atoi(argv[3]) : -1, sblocks = argc > 4 ? atoi(argv[4]) : 2048, sreps = argc > 5 ? atoi(argv[5]) : 2;
     for (int n = 1; n <= NK; ++n) {
         float best = 1e9;
         for (int it = 0; it < 3; ++it) {
@@ -31,12 +49,18 @@ int main(int argc, char **argv) {
             hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
             CK(hipEventRecord(a, 0));
             std::vector<hipEvent_t> done(n);
+            if (smode >= 0) {
+                CK(hipStreamWaitEvent(ss, a, 0));
+                if (smode == 0) hipLaunchKernelGGL(k_stream<0>, dim3(sblocks), dim3(256), 0, ss, sin_, sout, NS, sreps);
+                if (smode == 1) hipLaunchKernelGGL(k_stream<1>, dim3(sblocks), dim3(256), 0, ss, sin_, sout, NS, sreps);
+                if (smode == 2) hipLaunchKernelGGL(k_stream<2>, dim3(sblocks), dim3(256), 0, ss, sin_, sout, NS, sreps);
+            }
             for (int i = 0; i < n; ++i) {
                 CK(hipStreamWaitEvent(st[i], a, 0));
                 hipLaunchKernelGGL(dfx_k_gru_rec_h3, dim3((B + 15) / 16), dim3(DFX_GH_THREADS), DFX_GH_SMEM, st[i], args[i]);
                 CK(hipEventCreate(&done[i])); CK(hipEventRecord(done[i], st[i])); CK(hipStreamWaitEvent(0, done[i], 0));
             }
-            CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+            CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b)); CK(hipDeviceSynchronize());
             float ms; CK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
         }
         printf("%d concurrent gru_h3 kernels (16 blocks each), %lld steps: %.3f ms -> %.3f us/step\n", n, (long long)T, best, best * 1e3 / T);
