@@ -807,6 +807,37 @@ static int launch_conv01_h3(const dfx_model *m, const PwW &w, const float *feat_
     }
 }
 
+// The ERB encoder / decoder conv chains run frame-resident (dfx_k_erb_enc / dfx_k_erb_dec) unless DFX_FUSE_ERB=0 or their LDS
+// strips do not fit a CU (very large nb_erb): then the layer-by-layer kernels are used.
+static bool dfx_fuse_erb(size_t smem) {
+    static const bool off = [] { const char *e = getenv("DFX_FUSE_ERB"); return e && e[0] == '0'; }();
+    return !off && smem <= (size_t)160 * 1024;
+}
+
+template <int C>
+static int launch_erb_enc(const dfx_model *m, const float *feat_erb, float *e0, float *e1, int64_t B, int64_t T, hipStream_t s) {
+    const dfx_model_cfg &c = m->cfg;
+    DfxEncArgs A;
+    A.feat = feat_erb;
+    A.w0 = m->p(m->erb0_w);
+    A.b0 = m->p(m->erb0_b);
+    A.dw = m->p(m->erb1.dw);
+    A.wt = m->p(m->erb1.wt);
+    A.bias = m->p(m->erb1.bias);
+    A.e0 = e0;
+    A.e1 = e1;
+    A.B = B;
+    A.T = T;
+    A.E = c.nb_erb;
+    A.L = c.conv_lookahead;
+    const size_t smem = DFX_ENC_SMEM(C, c.nb_erb);
+    DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_erb_enc<C>, smem));
+    DfxKScope ks(DFX_K_ERB_ENC, s);
+    dfx_launch(dfx_k_erb_enc<C>, dim3((unsigned)nn_grid(dfx_ceil_div(B * T, 4), 2)), dim3(256), smem, s, A);
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
+}
+
 // enc.df_conv0 -> enc.df_conv1 without the c0 round trip (dfx_k_df_conv01)
 template <int C>
 static int launch_conv01(const dfx_model *m, const PwW &w, const float *feat_spec, float *out, int64_t B, int64_t T, int Fin,
@@ -1110,14 +1141,19 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     // compete with the encoder for bandwidth and runs during the GRU phase instead (DFX_CONVP_EARLY=1: right after c0)
     if (!m->convp_late && (rc = run_convp())) return rc;
     // ---- Encoder, ERB branch on s (:168-171)
-    {
-        const int64_t total = R * E * (C / 4);
-        DfxKScope ks(DFX_K_CONV_IN_ERB, s);
-        dfx_launch(dfx_k_conv_in_erb, dim3((unsigned)nn_grid(dfx_ceil_div(total, 256), 16)), dim3(256), 0, s, feat_erb,
-                   m->p(m->erb0_w), m->p(m->erb0_b), e0, B, T, E, C, L);
-        DFX_LAUNCH_CHECK();
+    const bool fuse_enc = E % 2 == 0 && 3 * (E + 2) <= 192 && dfx_fuse_erb(2 * DFX_ENC_SMEM(C, E));
+    if (fuse_enc) {
+        if ((rc = launch_erb_enc<C>(m, feat_erb, e0, e1, B, T, s))) return rc;
+    } else {
+        {
+            const int64_t total = R * E * (C / 4);
+            DfxKScope ks(DFX_K_CONV_IN_ERB, s);
+            dfx_launch(dfx_k_conv_in_erb, dim3((unsigned)nn_grid(dfx_ceil_div(total, 256), 16)), dim3(256), 0, s, feat_erb,
+                       m->p(m->erb0_w), m->p(m->erb0_b), e0, B, T, E, C, L);
+            DFX_LAUNCH_CHECK();
+        }
+        if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb1, e0, nullptr, e1, R, E, E / 2, 2, s))) return rc;
     }
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb1, e0, nullptr, e1, R, E, E / 2, 2, s))) return rc;
     if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb2, e1, nullptr, e2, R, E / 2, E / 4, 2, s))) return rc;
     if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb3, e2, nullptr, e3, R, E / 4, E / 4, 1, s))) return rc;
     if ((rc = wait(EV_C1, s))) return rc;

@@ -668,6 +668,167 @@ __global__ void __launch_bounds__(256, 1) dfx_k_df_convp_h3(DfxCphArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Frame-resident conv chains.  Apart from their first layer every conv of the ERB encoder / decoder is per frame (1x3 over
+// frequency), so a whole chain can run on one frame pair without its intermediates leaving the CU: a wave owns DFX_CH_NF = 2
+// consecutive rows (frames) of the [B*T] axis, keeps each stage's output in a private LDS strip [positions][C + 4] and feeds the
+// next stage's depthwise taps from there.  HBM then only sees what the network really needs (the four encoder outputs, which are
+// the decoder's skips) instead of every intermediate twice.  Two frames make the 8-position stages a full 16-wide MFMA tile.
+// dfx_chain_stage is dfx_k_pwconv's tile body with the B operand read from LDS (same operand roles, same k order -> the same
+// bits); only wave-level synchronisation is needed because a strip is private to its wave.
+// ---------------------------------------------------------------------------------------------------------------------
+#define DFX_CH_NF 2
+template <int C, int MODE, typename Epi>
+static __device__ __forceinline__ void dfx_chain_stage(const float *in, int Fin, int Fout, int stride, int npos,
+                                                       const float4 *dws, const float (&areg)[C / 16][C / 4],
+                                                       const float4 (&biasr)[C / 16], int lane, Epi &&epi) {
+    constexpr int CPL = C / 4, NT = C / 16, V4 = CPL / 4, LD = C + 4;
+    const int q = lane >> 4, jl = lane & 15;
+    for (int p0 = 0; p0 < npos; p0 += 16) {
+        const int p = p0 + jl;
+        const bool valid = p < npos;
+        const int fr = p / Fout, fo = p - fr * Fout;
+        float u[CPL];
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) u[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            int fi;
+            bool ok;
+            if (MODE == DFX_PW_MODE_DW3) {
+                fi = fo * stride + j - 1;
+                ok = fi >= 0 && fi < Fin;
+            } else {  // transposed: fo = 2*fi - 1 + j
+                const int num = fo + 1 - j;
+                fi = num >> 1;
+                ok = num >= 0 && (num & 1) == 0 && fi < Fin;
+            }
+            if (valid && ok) {
+                const float4 *xp = reinterpret_cast<const float4 *>(in + (fr * Fin + fi) * LD + CPL * q);
+#pragma unroll
+                for (int v = 0; v < V4; ++v) {
+                    const float4 xv = xp[v];
+                    const float4 w = dws[j * (C / 4) + V4 * q + v];
+                    u[4 * v + 0] += w.x * xv.x;
+                    u[4 * v + 1] += w.y * xv.y;
+                    u[4 * v + 2] += w.z * xv.z;
+                    u[4 * v + 3] += w.w * xv.w;
+                }
+            }
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < CPL; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[nt][ks], u[ks], acc[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)  // lane (p, q) holds output channels 16*nt + 4*q .. +3
+            epi(p, valid, nt,
+                make_float4(fmaxf(acc[nt][0] + biasr[nt].x, 0.f), fmaxf(acc[nt][1] + biasr[nt].y, 0.f),
+                            fmaxf(acc[nt][2] + biasr[nt].z, 0.f), fmaxf(acc[nt][3] + biasr[nt].w, 0.f)));
+    }
+}
+
+template <int C>
+static __device__ __forceinline__ void dfx_chain_load_w(const float *wt, const float *bias, int lane, float (&areg)[C / 16][C / 4],
+                                                        float4 (&biasr)[C / 16]) {
+    constexpr int CPL = C / 4, NT = C / 16;
+    const int q = lane >> 4, jl = lane & 15;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int ks = 0; ks < CPL; ++ks) areg[nt][ks] = wt[(CPL * q + ks) * C + 16 * nt + jl];
+        biasr[nt] = reinterpret_cast<const float4 *>(bias)[4 * nt + q];
+    }
+}
+
+// ERB encoder head, fused: erb_conv0 (3x3 from one channel, VALU, same arithmetic as dfx_k_conv_in_erb) -> erb_conv1 (stride 2)
+// (deepfilternet3.py:106-109,168-169).  A wave owns one frame: its E positions of e0 are one LDS strip and its E/2 positions of e1
+// one or two MFMA tiles.  e0 (the largest ERB activation) is written once and never read back by the encoder; the three feat_erb
+// rows of the NEXT frame are fetched while the current one is computed.  (Fusing erb_conv2/3 as well was measured slower: their
+// weights push the kernel to one wave per SIMD, where its dependent LDS -> VALU -> MFMA phases cannot overlap.)
+struct DfxEncArgs {
+    const float *feat;  // [B, T, E]
+    const float *w0, *b0;            // erb_conv0 [3][3][C], [C]
+    const float *dw, *wt, *bias;     // erb_conv1: [3][C], [C][C], [C]
+    float *e0, *e1;                  // [B*T, E, C], [B*T, E/2, C]
+    int64_t B, T;
+    int E, L;
+};
+#define DFX_ENC_FS(E) (3 * ((E) + 2))                                   /* zero-bordered feat rows of one frame */
+#define DFX_ENC_WAVE_FLOATS(C, E) ((E) * ((C) + 4) + DFX_ENC_FS(E) + 2) /* + pad to a multiple of 4 floats below */
+#define DFX_ENC_SMEM(C, E) ((size_t)(3 * (C) / 4) * 16 + (size_t)4 * ((DFX_ENC_WAVE_FLOATS(C, E) + 3) / 4 * 4) * 4)
+
+template <int C>
+__global__ void __launch_bounds__(256, 2) dfx_k_erb_enc(DfxEncArgs A) {
+    constexpr int NT = C / 16, CPL = C / 4, LD = C + 4, C4 = C / 4;
+    DFX_DYN_SMEM(float4, sm4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4;
+    const int E = A.E, E1 = E / 2, EP = E + 2;
+    float4 *dws = sm4;  // [3][C/4]
+    float *s0 = reinterpret_cast<float *>(sm4 + 3 * C4) + (size_t)wave * ((DFX_ENC_WAVE_FLOATS(C, E) + 3) / 4 * 4);  // e0 strip [E][LD]
+    float *fs = s0 + E * LD;                                                                                         // [3][E + 2]
+    for (int i = tid; i < 3 * C4; i += 256) dws[i] = reinterpret_cast<const float4 *>(A.dw)[i];
+    float a1[NT][CPL];
+    float4 b1[NT];
+    dfx_chain_load_w<C>(A.wt, A.bias, lane, a1, b1);
+    // erb_conv0: lane -> (position slot lane / C4, channel quad lane % C4); C4 <= 16 divides 64
+    const int c4 = lane % C4, pslot = lane / C4, pstep = 64 / C4;
+    float4 wv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[k] = reinterpret_cast<const float4 *>(A.w0)[k * C4 + c4];
+    const float4 bv = reinterpret_cast<const float4 *>(A.b0)[c4];
+    __syncthreads();
+    const int64_t R = A.B * A.T;
+    const int64_t rstep = (int64_t)gridDim.x * 4;
+    // element i of the zero-bordered tap rows [3][E+2] of frame r (zero: border, causal pad after the lookahead shift, beyond T)
+    float fx[3];
+    auto fetch = [&](int64_t r) {
+        const int64_t b = r / A.T, t = r - b * A.T;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i = lane + 64 * k, kt = i / EP, fp = i - kt * EP;
+            const int64_t tau = t - 2 + kt, tin = tau + A.L;
+            float v = 0.f;
+            if (r < R && i < 3 * EP && fp >= 1 && fp <= E && tau >= 0 && tin < A.T) v = A.feat[(b * A.T + tin) * E + fp - 1];
+            fx[k] = v;
+        }
+    };
+    int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    fetch(r);
+    for (; r < R; r += rstep) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (lane + 64 * k < 3 * EP) fs[lane + 64 * k] = fx[k];
+        fetch(r + rstep);
+        DFX_WAVE_SYNC();
+        for (int p = pslot; p < E; p += pstep) {
+            float4 acc = bv;
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+                for (int kf = 0; kf < 3; ++kf) {
+                    const float x = fs[kt * EP + p + kf];  // bin p - 1 + kf, border included
+                    const float4 ww = wv[kt * 3 + kf];
+                    acc.x += ww.x * x;
+                    acc.y += ww.y * x;
+                    acc.z += ww.z * x;
+                    acc.w += ww.w * x;
+                }
+            const float4 o = make_float4(fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f));
+            reinterpret_cast<float4 *>(A.e0 + (r * E + p) * C)[c4] = o;
+            *reinterpret_cast<float4 *>(s0 + p * LD + 4 * c4) = o;
+        }
+        DFX_WAVE_SYNC();
+        dfx_chain_stage<C, DFX_PW_MODE_DW3>(s0, E, E1, 2, E1, dws, a1, b1, lane, [&](int p, bool valid, int nt, float4 o) {
+            if (valid) *reinterpret_cast<float4 *>(A.e1 + (r * E1 + p) * C + 16 * nt + 4 * q) = o;
+        });
+        DFX_WAVE_SYNC();  // the strips are rewritten by the next frame
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // erb_dec.conv0_out: Conv2d(C -> 1, 1x3) + BN(1) + Sigmoid on  xin = relu(a*e0 + b) + d1   (deepfilternet3.py:241-243,253)
 //   m[r, f] = sigmoid(bias + sum_j sum_c w[j][c] * xin[r, f+j-1, c])
 // A tile is a whole number of frames (E positions each); xin is staged in LDS, threads (pos, j) form the three per-
