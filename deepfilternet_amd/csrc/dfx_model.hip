@@ -814,6 +814,35 @@ static bool dfx_fuse_erb(size_t smem) {
     return !off && smem <= (size_t)160 * 1024;
 }
 
+// erb_dec.convt1 -> conv0_out fused (dfx_k_erb_dec10); x = d2, writes the mask
+template <int C>
+static int launch_erb_dec10(const dfx_model *m, const float *d2, const float *e1, const float *e0, float *mask, int64_t R, int E,
+                            hipStream_t s, DfxRowMap rm) {
+    DfxDec10Args A;
+    A.x = d2;
+    A.skip1 = e1;
+    A.sk1_a = m->p(m->ct1.sk_a);
+    A.sk1_b = m->p(m->ct1.sk_b);
+    A.dw = m->p(m->ct1.dw);
+    A.wt = m->p(m->ct1.wt);
+    A.bias = m->p(m->ct1.bias);
+    A.skip0 = e0;
+    A.sk0_a = m->p(m->co_ska);
+    A.sk0_b = m->p(m->co_skb);
+    A.wo = m->p(m->co_w);
+    A.bias_o = m->co_bias;
+    A.out = mask;
+    A.R = R;
+    A.E = E;
+    A.rm = rm;
+    const size_t smem = DFX_DEC10_SMEM(C, E);
+    DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_erb_dec10<C>, smem));
+    DfxKScope ks(DFX_K_ERB_DEC, s);
+    dfx_launch(dfx_k_erb_dec10<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R, 4), 2)), dim3(256), smem, s, A);
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
+}
+
 template <int C>
 static int launch_erb_enc(const dfx_model *m, const float *feat_erb, float *e0, float *e1, int64_t B, int64_t T, hipStream_t s) {
     const dfx_model_cfg &c = m->cfg;
@@ -1141,6 +1170,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     // compete with the encoder for bandwidth and runs during the GRU phase instead (DFX_CONVP_EARLY=1: right after c0)
     if (!m->convp_late && (rc = run_convp())) return rc;
     // ---- Encoder, ERB branch on s (:168-171)
+    const bool fuse_dec = E % 2 == 0 && dfx_fuse_erb(2 * DFX_DEC10_SMEM(C, E));
     const bool fuse_enc = E % 2 == 0 && 3 * (E + 2) <= 192 && dfx_fuse_erb(2 * DFX_ENC_SMEM(C, E));
     if (fuse_enc) {
         if ((rc = launch_erb_enc<C>(m, feat_erb, e0, e1, B, T, s))) return rc;
@@ -1217,8 +1247,10 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         if ((rc = launch_glin(m, m->dec_out, y, DFX_ACT_RELU, nullptr, demb, R, s))) return rc;
         if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, R, E / 4, E / 4, 1, s))) return rc;
         if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, R, E / 4, E / 2, 2, s))) return rc;
-        if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, R, E / 2, E, 2, s))) return rc;
-        {
+        if (fuse_dec) {
+            if ((rc = launch_erb_dec10<C>(m, d2, e1, e0, mask, R, E, s, DfxRowMap{0, 0, 0}))) return rc;
+        } else {
+            if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, R, E / 2, E, 2, s))) return rc;
             const int fpt = 64 / E > 0 ? 64 / E : 1;
             const size_t smem = ((size_t)fpt * E * (C + 1) + (size_t)fpt * E * 3 + 3 * C) * sizeof(float);
             DfxKScope ks(DFX_K_CONV_OUT, s);
@@ -1308,8 +1340,10 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 if ((rc = launch_glin(m, m->dec_out, ws + w.py[ndec], DFX_ACT_RELU, nullptr, demb, Rk, st, rm))) return rc;
                 if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, Rk, E / 4, E / 4, 1, st, rm))) return rc;
                 if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, Rk, E / 4, E / 2, 2, st, rm))) return rc;
-                if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, Rk, E / 2, E, 2, st, rm))) return rc;
-                {
+                if (fuse_dec) {
+                    if ((rc = launch_erb_dec10<C>(m, d2, e1, e0, mask, Rk, E, st, rm))) return rc;
+                } else {
+                    if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, Rk, E / 2, E, 2, st, rm))) return rc;
                     DfxKScope ks(DFX_K_CONV_OUT, st);
                     dfx_launch(dfx_k_conv_out<C>, dim3((unsigned)nn_grid(dfx_ceil_div(Rk, fpt), 8)), dim3(DFX_CO_THREADS), smem, st,
                                (const float *)d1, (const float *)e0, m->p(m->co_ska), m->p(m->co_skb), m->p(m->co_w), m->co_bias, mask,

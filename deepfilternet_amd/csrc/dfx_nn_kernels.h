@@ -880,6 +880,139 @@ __global__ void __launch_bounds__(DFX_CO_THREADS) dfx_k_conv_out(const float *x,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// ERB decoder tail, fused: erb_dec.convt1 (transposed 1x3, stride 2, with the conv1p pathway) -> erb_dec.conv0_out (with the conv0p
+// pathway) + sigmoid   (deepfilternet3.py:252-253).  d1 [B*T, E, C], the widest decoder activation, never reaches HBM: a wave owns
+// one frame, the convt1 tiles (dfx_k_pwconv's DWT3 + SKIP body, operands from HBM) put  xin = d1 + relu(a0*e0 + b0)  into an LDS
+// strip [E][C + 4], and the 3-tap C -> 1 conv reads it back exactly like dfx_k_conv_out (same per-(position, tap) dot products, same
+// combination order -> the same bits).  HBM per frame: reads d2, e1 (E/2 positions) and e0, writes E mask values.
+// ---------------------------------------------------------------------------------------------------------------------
+struct DfxDec10Args {
+    const float *x;      // d2 [R, E/2, C]
+    const float *skip1;  // e1 [R, E/2, C]
+    const float *sk1_a, *sk1_b;  // conv1p pathway [C]
+    const float *dw;     // convt1 depthwise [3][C]
+    const float *wt;     // convt1 pointwise [C][C] (BN-scaled)
+    const float *bias;   // [C]
+    const float *skip0;  // e0 [R, E, C]
+    const float *sk0_a, *sk0_b;  // conv0p pathway [C]
+    const float *wo;     // conv0_out [3][C]
+    float bias_o;
+    float *out;          // mask [R, E]
+    int64_t R;           // logical rows of this launch
+    int E;
+    DfxRowMap rm;
+};
+#define DFX_DEC10_WAVE_FLOATS(C, E) ((E) * ((C) + 4) + 4 * (E))
+#define DFX_DEC10_SMEM(C, E) ((size_t)(3 * (C) / 4 + 4 * (C) / 4 + 3 * (C) / 4) * 16 + (size_t)4 * DFX_DEC10_WAVE_FLOATS(C, E) * 4)
+
+template <int C>
+__global__ void __launch_bounds__(256, 2) dfx_k_erb_dec10(DfxDec10Args A) {
+    constexpr int NT = C / 16, CPL = C / 4, V4 = CPL / 4, LD = C + 4, C4 = C / 4;
+    DFX_DYN_SMEM(float4, sm4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
+    const int E = A.E, E1 = E / 2;
+    float4 *dws = sm4;            // [3][C/4]
+    float4 *sks = dws + 3 * C4;   // [4][C/4]: a1, b1, a0, b0
+    float4 *wos = sks + 4 * C4;   // [3][C/4]
+    float *strip = reinterpret_cast<float *>(wos + 3 * C4) + (size_t)wave * DFX_DEC10_WAVE_FLOATS(C, E);  // xin [E][LD]
+    float *V = strip + E * LD;                                                                            // [E][3] (+ pad)
+    for (int i = tid; i < 3 * C4; i += 256) {
+        dws[i] = reinterpret_cast<const float4 *>(A.dw)[i];
+        wos[i] = reinterpret_cast<const float4 *>(A.wo)[i];
+    }
+    for (int i = tid; i < C4; i += 256) {
+        sks[i] = reinterpret_cast<const float4 *>(A.sk1_a)[i];
+        sks[C4 + i] = reinterpret_cast<const float4 *>(A.sk1_b)[i];
+        sks[2 * C4 + i] = reinterpret_cast<const float4 *>(A.sk0_a)[i];
+        sks[3 * C4 + i] = reinterpret_cast<const float4 *>(A.sk0_b)[i];
+    }
+    float areg[NT][CPL];
+    float4 biasr[NT];
+    dfx_chain_load_w<C>(A.wt, A.bias, lane, areg, biasr);
+    __syncthreads();
+    for (int64_t rl = (int64_t)blockIdx.x * 4 + wave; rl < A.R; rl += (int64_t)gridDim.x * 4) {
+        const int64_t r = dfx_row(A.rm, rl);
+        for (int p0 = 0; p0 < E; p0 += 16) {
+            const int fo = p0 + jl;
+            const bool valid = fo < E;
+            // conv0p pathway operand of this lane's outputs, fetched ahead of the matrix ops
+            float4 s0v[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                s0v[nt] = valid ? *reinterpret_cast<const float4 *>(A.skip0 + (r * E + fo) * C + 16 * nt + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float u[CPL];
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) u[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {  // transposed: fo = 2*fi - 1 + j
+                const int num = fo + 1 - j, fi = num >> 1;
+                if (valid && num >= 0 && (num & 1) == 0 && fi < E1) {
+                    const int64_t off = (r * E1 + fi) * C + CPL * q;
+                    const float4 *xp = reinterpret_cast<const float4 *>(A.x + off);
+                    const float4 *sp = reinterpret_cast<const float4 *>(A.skip1 + off);
+#pragma unroll
+                    for (int v = 0; v < V4; ++v) {
+                        float4 xv = xp[v];
+                        const float4 sv = sp[v], a = sks[V4 * q + v], bb = sks[C4 + V4 * q + v];
+                        xv.x += fmaxf(a.x * sv.x + bb.x, 0.f);
+                        xv.y += fmaxf(a.y * sv.y + bb.y, 0.f);
+                        xv.z += fmaxf(a.z * sv.z + bb.z, 0.f);
+                        xv.w += fmaxf(a.w * sv.w + bb.w, 0.f);
+                        const float4 w = dws[j * C4 + V4 * q + v];
+                        u[4 * v + 0] += w.x * xv.x;
+                        u[4 * v + 1] += w.y * xv.y;
+                        u[4 * v + 2] += w.z * xv.z;
+                        u[4 * v + 3] += w.w * xv.w;
+                    }
+                }
+            }
+            f32x4 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < CPL; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[nt][ks], u[ks], acc[nt], 0, 0, 0);
+            if (valid) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float4 a = sks[2 * C4 + 4 * nt + q], bb = sks[3 * C4 + 4 * nt + q];
+                    float4 o;  // xin = d1 + relu(a0 * e0 + b0), d1 = relu(acc + bias)
+                    o.x = fmaxf(acc[nt][0] + biasr[nt].x, 0.f) + fmaxf(a.x * s0v[nt].x + bb.x, 0.f);
+                    o.y = fmaxf(acc[nt][1] + biasr[nt].y, 0.f) + fmaxf(a.y * s0v[nt].y + bb.y, 0.f);
+                    o.z = fmaxf(acc[nt][2] + biasr[nt].z, 0.f) + fmaxf(a.z * s0v[nt].z + bb.z, 0.f);
+                    o.w = fmaxf(acc[nt][3] + biasr[nt].w, 0.f) + fmaxf(a.w * s0v[nt].w + bb.w, 0.f);
+                    *reinterpret_cast<float4 *>(strip + fo * LD + 16 * nt + 4 * q) = o;
+                }
+            }
+        }
+        DFX_WAVE_SYNC();
+        for (int i = lane; i < 3 * E; i += 64) {  // V[p][j] = sum_c wo[j][c] * xin[p][c]
+            const int p = i / 3, j = i - 3 * p;
+            const float4 *xr = reinterpret_cast<const float4 *>(strip + p * LD);
+            float acc = 0.f;
+#pragma unroll 4
+            for (int c = 0; c < C4; ++c) {
+                const float4 x = xr[c], w = wos[j * C4 + c];
+                acc += w.x * x.x;
+                acc += w.y * x.y;
+                acc += w.z * x.z;
+                acc += w.w * x.w;
+            }
+            V[i] = acc;
+        }
+        DFX_WAVE_SYNC();
+        for (int f = lane; f < E; f += 64) {
+            float acc = A.bias_o + V[f * 3 + 1];
+            if (f > 0) acc += V[(f - 1) * 3 + 0];
+            if (f < E - 1) acc += V[(f + 1) * 3 + 2];
+            A.out[r * E + f] = dfx_sigmoid(acc);
+        }
+        DFX_WAVE_SYNC();  // strip and V are rewritten by the next frame
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // df_dec.df_convp: Conv2d(C -> 2*O, (kt,1), groups = gcd(C, 2*O)) [+ 1x1 (2O x 2O) when kt > 1] + BN + ReLU
 // (deepfilternet3.py:293-295, modules.py:49-71).  in c0 [R, Fd, C] -> out [R, Fd, 2*O].
 // Per group: out1[pos][o] = sum_k sum_ci c0[t-kt+1+k, f, g*CG+ci] * W1[g][k][ci][o]   (causal: zero for frames < 0 of the clip)
