@@ -83,8 +83,14 @@ struct DfxKScope {
 };
 
 // ---- internal launchers shared between the DSP API and the model --------------------------------------------------
+// x_len < T: the samples [x_len, T) of every row are implicit zeros (x_stride may then be as small as x_len); -1 = T
 int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_stride,
-                        const float *mem_in, float *mem_out, float *spec, float *erb_db, hipStream_t s);
+                        const float *mem_in, float *mem_out, float *spec, float *erb_db, hipStream_t s, int64_t x_len = -1);
+int dfx_features_padded(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_len, int64_t x_stride, int nb_df,
+                        float alpha, float *spec, float *erb_feat, float *spec_feat, void *stream);
+// dfx_synthesis storing only stream samples [out_skip, out_skip + out_len) of every row, at out[row * out_stride + n - out_skip]
+int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int64_t Tf, const float *mem_in, float *mem_out,
+                         float *out, int64_t out_stride, int64_t out_skip, int64_t out_len, hipStream_t s);
 int dfx_launch_norm_scan(const float *erb_in, float *erb_out, int E, const float *spec_in, int64_t spec_frame_stride,
                          float *spec_out, int Fn, int64_t C, int64_t T, float alpha, float *erb_state,
                          float *unit_state, hipStream_t s);

@@ -304,7 +304,7 @@ static int grid_for(int64_t work_groups) {
 }
 
 int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_stride,
-                        const float *mem_in, float *mem_out, float *spec, float *erb_db, hipStream_t s) {
+                        const float *mem_in, float *mem_out, float *spec, float *erb_db, hipStream_t s, int64_t x_len) {
     const int64_t Tf = T / st->hop;
     const int ML = st->N - st->hop;
     if (B > 0 && Tf > 0) {
@@ -320,6 +320,7 @@ int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t 
         A.B = B;
         A.Tf = Tf;
         A.x_stride = x_stride;
+        A.x_len = x_len < 0 ? T : x_len;
         A.hop = st->hop;
         A.nb = st->nb;
         A.wnorm = st->wnorm;
@@ -370,7 +371,14 @@ extern "C" int dfx_synthesis(const dfx_state *st, const float *spec, int64_t B, 
     if (int rc = dfx_require_device()) return rc;
     if (B == 0 || (Tf == 0 && !mem_out)) return DFX_OK;
     if ((Tf > 0 && (!spec || !out))) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_synthesis: null buffer");
+    return dfx_launch_synthesis(st, spec, B, Tf, mem_in, mem_out, out, out_stride, 0, Tf * st->hop, dfx_stream(stream));
+}
+
+int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int64_t Tf, const float *mem_in, float *mem_out,
+                         float *out, int64_t out_stride, int64_t out_skip, int64_t out_len, hipStream_t stream) {
     DfxSynArgs A;
+    A.out_skip = out_skip;
+    A.out_len = out_len;
     A.spec = reinterpret_cast<const float2 *>(spec);
     A.mem_in = mem_in;
     A.mem_out = mem_out;
@@ -390,8 +398,8 @@ extern "C" int dfx_synthesis(const dfx_state *st, const float *spec, int64_t B, 
     if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_synthesis, smem));
     const int64_t nblk = B * A.chunks;
     if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_synthesis: batch too large for one launch");
-    DfxKScope ks(DFX_K_SYNTHESIS, dfx_stream(stream));
-    dfx_launch(dfx_k_synthesis, dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, dfx_stream(stream), A);
+    DfxKScope ks(DFX_K_SYNTHESIS, stream);
+    dfx_launch(dfx_k_synthesis, dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, stream, A);
     DFX_LAUNCH_CHECK();
     return DFX_OK;
 }
@@ -442,14 +450,21 @@ extern "C" int dfx_unit_norm(const float *x, int64_t x_frame_stride, float *out,
 
 extern "C" int dfx_features(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_stride, int nb_df,
                             float alpha, float *spec, float *erb_feat, float *spec_feat, void *stream) {
-    if (!st || B < 0 || T < 0 || x_stride < T || nb_df <= 0 || nb_df > st->N / 2 + 1)
+    if (x_stride < T) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_features: bad arguments");
+    return dfx_features_padded(st, x, B, T, T, x_stride, nb_df, alpha, spec, erb_feat, spec_feat, stream);
+}
+
+// dfx_features over rows of T samples of which only the first x_len exist in memory (the rest are zeros): enhance()'s end padding
+int dfx_features_padded(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_len, int64_t x_stride, int nb_df,
+                        float alpha, float *spec, float *erb_feat, float *spec_feat, void *stream) {
+    if (!st || B < 0 || T < 0 || x_len < 0 || x_len > T || x_stride < x_len || nb_df <= 0 || nb_df > st->N / 2 + 1)
         DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_features: bad arguments");
     if (int rc = dfx_require_device()) return rc;
     const int64_t Tf = T / st->hop;
     if (B == 0 || Tf == 0) return DFX_OK;
     if (!x || !spec || !erb_feat || !spec_feat) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_features: null buffer");
     // enhance.py:190-197: spec = analysis(x); erb_norm(erb(spec)); unit_norm(spec[..., :nb_df])
-    if (int rc = dfx_launch_analysis(st, x, B, T, x_stride, nullptr, nullptr, spec, erb_feat, dfx_stream(stream))) return rc;
+    if (int rc = dfx_launch_analysis(st, x, B, T, x_stride, nullptr, nullptr, spec, erb_feat, dfx_stream(stream), x_len)) return rc;
     return dfx_launch_norm_scan(erb_feat, erb_feat, st->nb, spec, st->N / 2 + 1, spec_feat, nb_df, B, Tf, alpha, nullptr,
                                 nullptr, dfx_stream(stream));
 }

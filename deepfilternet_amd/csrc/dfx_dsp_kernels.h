@@ -120,6 +120,7 @@ struct DfxAnaArgs {
     const int *band_start;  // [nb+1]
     const float *band_invw; // [nb]
     int64_t B, Tf, x_stride;
+    int64_t x_len;        // samples that exist per row; positions >= x_len read as 0 (enhance()'s F.pad(audio, (0, n_fft)) without a copy)
     int hop, nb;
     float wnorm;
     DfxFftPlan plan;
@@ -159,7 +160,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_analysis(DfxAnaArgs A) 
                     const int i = 2 * k + h;
                     const int64_t pos = pos0 + i;
                     float s = 0.f;
-                    if (pos >= 0) s = xb[pos];
+                    if (pos >= 0) s = pos < A.x_len ? xb[pos] : 0.f;
                     else if (A.mem_in) s = A.mem_in[b * ML + (ML + pos)];
                     v[h] = s * win[i];
                 }
@@ -228,6 +229,7 @@ struct DfxSynArgs {
     const float *window;
     const float2 *tw;
     int64_t B, Tf, out_stride;
+    int64_t out_skip, out_len;  // only stream samples [out_skip, out_skip + out_len) are stored, at out[row][n - out_skip]
     int hop, R /* N/hop rounded up: frames overlapping one output hop */, outf /* output frames per chunk */;
     int chunks;           // chunks per row (including the tail chunk that produces mem_out)
     DfxFftPlan plan;
@@ -321,7 +323,8 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_synthesis(DfxSynArgs A)
         }
         const float v = have ? cur + acc : cur;
         if (tf < A.Tf) {
-            A.out[b * A.out_stride + s_glob] = v;
+            const int64_t n = s_glob - A.out_skip;
+            if (n >= 0 && n < A.out_len) A.out[b * A.out_stride + n] = v;
         } else {
             const int64_t mj = s_glob - A.Tf * A.hop;
             if (mj < ML) A.mem_out[b * ML + mj] = v;

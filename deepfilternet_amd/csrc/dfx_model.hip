@@ -1455,7 +1455,7 @@ extern "C" int dfx_model_forward(const dfx_model *m, const dfx_bands *bands, con
 // ------------------------------------------------------------------------------------------------ enhance()
 namespace {
 struct EnhWs {
-    size_t xpad, spec, spec_e, feat_erb, feat_spec, ysyn, model, total;  // bytes
+    size_t spec, spec_e, feat_erb, feat_spec, model, total;  // bytes
 };
 EnhWs plan_enh(const dfx_model *m, const dfx_state *st, int64_t B, int64_t T, int pad) {
     EnhWs w{};
@@ -1466,12 +1466,10 @@ EnhWs plan_enh(const dfx_model *m, const dfx_state *st, int64_t B, int64_t T, in
         return o;
     };
     const int64_t Tp = pad ? T + st->N : T, Tf = Tp / st->hop, F = st->N / 2 + 1;
-    w.xpad = take(pad ? (size_t)B * Tp * 4 : 0);
     w.spec = take((size_t)B * Tf * F * 8);
     w.spec_e = take((size_t)B * Tf * F * 8);
     w.feat_erb = take((size_t)B * Tf * m->cfg.nb_erb * 4);
     w.feat_spec = take((size_t)B * Tf * m->cfg.nb_df * 8);
-    w.ysyn = take((size_t)B * Tf * st->hop * 4);
     int64_t mb = 0;
     dfx_model_workspace_bytes(m, B, Tf, &mb);
     w.model = take((size_t)mb);
@@ -1537,36 +1535,19 @@ static int enhance_chunk(const dfx_model *m, const dfx_state *st, const float *x
     const dfx_model_cfg &c = m->cfg;
     const EnhWs w = plan_enh(m, st, B, T, pad);
     const int64_t Tp = pad ? T + st->N : T, Tf = Tp / st->hop;
-    const float *xin = x;
-    int64_t xstride = T;
-    if (pad) {  // F.pad(audio, (0, n_fft))  (enhance.py:230-233)
-        float *xp = reinterpret_cast<float *>(base + w.xpad);
-        DfxKScope ks(DFX_K_COPY_ROWS, s);
-        dfx_launch(dfx_k_copy_rows, dim3((unsigned)nn_grid(dfx_ceil_div(B * Tp, 256), 16)), dim3(256), 0, s, x, T, T,
-                   (int64_t)0, xp, Tp, Tp, B);
-        DFX_LAUNCH_CHECK();
-        xin = xp;
-        xstride = Tp;
-    }
     float *spec = reinterpret_cast<float *>(base + w.spec), *spec_e = reinterpret_cast<float *>(base + w.spec_e);
     float *fe = reinterpret_cast<float *>(base + w.feat_erb), *fs = reinterpret_cast<float *>(base + w.feat_spec);
-    float *ysyn = reinterpret_cast<float *>(base + w.ysyn);
-    int rc = dfx_features(st, xin, B, Tp, xstride, c.nb_df, c.norm_alpha, spec, fe, fs, (void *)s);
+    // F.pad(audio, (0, n_fft)) (enhance.py:230-233) is implicit: the analysis reads zeros past the T samples of a row
+    int rc = dfx_features_padded(st, x, B, Tp, T, T, c.nb_df, c.norm_alpha, spec, fe, fs, (void *)s);
     if (rc) return rc;
     int64_t mb = 0;
     dfx_model_workspace_bytes(m, B, Tf, &mb);
     rc = model_forward_lane(m, st->bands, spec, fe, fs, B, Tf, lim, spec_e, nullptr, nullptr, nullptr, base + w.model, mb,
                             (void *)s, ln, signal_front);
     if (rc) return rc;
-    if (pad) {
-        rc = dfx_synthesis(st, spec_e, B, Tf, nullptr, nullptr, ysyn, Tf * st->hop, (void *)s);
-        if (rc) return rc;
-        const int64_t d = st->N - st->hop;  // enhance.py:248-249: audio[:, d : orig_len + d]
-        DfxKScope ks(DFX_K_COPY_ROWS, s);
-        dfx_launch(dfx_k_copy_rows, dim3((unsigned)nn_grid(dfx_ceil_div(B * T, 256), 16)), dim3(256), 0, s, (const float *)ysyn,
-                   Tf * st->hop, Tf * st->hop, d, y, T, T, B);
-        DFX_LAUNCH_CHECK();
-        return DFX_OK;
+    if (pad) {  // enhance.py:248-249: audio[:, d : orig_len + d] — the synthesis stores exactly that window
+        const int64_t d = st->N - st->hop;
+        return dfx_launch_synthesis(st, spec_e, B, Tf, nullptr, nullptr, y, T, d, T, s);
     }
     return dfx_synthesis(st, spec_e, B, Tf, nullptr, nullptr, y, Tf * st->hop, (void *)s);
 }
