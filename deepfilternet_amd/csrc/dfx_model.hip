@@ -83,7 +83,7 @@ struct GlinW {
 #define DFX_MAX_LANES 4
 #define DFX_LANE_EVENTS 12
 #define DFX_MAX_GRU_LAYERS 8   /* all GRU layers of the three stacks */
-#define DFX_MAX_TCHUNKS 8      /* time chunks of the layer-pipelined GRU phase */
+#define DFX_MAX_TCHUNKS 16     /* time chunks of the layer-pipelined GRU phase */
 struct DfxLane {
     hipStream_t main = nullptr;
     hipStream_t aux[2] = {nullptr, nullptr};
@@ -125,10 +125,11 @@ struct dfx_model {
     bool concurrent = false;
     bool have_streams = false;
     int max_chunks = 1;       // batch chunks pipelined by dfx_enhance (DFX_CHUNKS; measured: no gain over time-chunk pipelining)
-    int tchunks = 6;          // time chunks of the layer-pipelined GRU phase (DFX_TCHUNKS)
+    int tchunks = 12;         // time chunks of the layer-pipelined GRU phase (DFX_TCHUNKS)
     int tchunk_min = 32;      // shortest chunk worth a launch (frames)
     bool exact_fp32 = false;  // DFX_EXACT_FP32=1: keep the dense contractions on the exact fp32 MFMA path
-    bool convp_late = true;   // DFX_CONVP_EARLY=1 starts df_convp right after c0 instead of after the front
+    bool convp_after_c1 = false;  // DFX_CONVP_EARLY=2: df_convp starts when df_conv1 is done
+    bool convp_late = false;  // DFX_CONVP_EARLY=0 holds df_convp back until the front is enqueued (it then starts beside the GRU phase)
     bool gru_x2 = false;      // DFX_GRU_X2=1: two-CU GRU recurrence (weights fully on chip, h halves exchanged every step);
                               // measured slower than the single-CU kernel (6.6 vs 5.2 us/step): the exchange costs ~4 us
     unsigned int *d_err = nullptr;      // device word: a bounded spin of the two-CU GRU kernel timed out
@@ -332,7 +333,15 @@ static bool dfx_create_lane(dfx_model *m, int l) {
     DfxLane &ln = m->lanes[l];
     if (ln.main) return true;
     bool good = hipStreamCreateWithFlags(&ln.main, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i < 2; ++i) good = good && hipStreamCreateWithFlags(&ln.aux[i], hipStreamNonBlocking) == hipSuccess;
+    good = good && hipStreamCreateWithFlags(&ln.aux[0], hipStreamNonBlocking) == hipSuccess;
+    {   // aux[1] carries df_convp, which has slack until df_out needs it: lowest dispatch priority, so that it fills the CUs the
+        // critical-path kernels leave idle instead of competing with them (DFX_X2_PRIO=normal: same priority as the rest)
+        int lo = 0, hi = 0;
+        const char *pe = getenv("DFX_X2_PRIO");
+        const bool low = !(pe && pe[0] == 'n') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi;
+        good = good && (low ? hipStreamCreateWithPriority(&ln.aux[1], hipStreamNonBlocking, lo)
+                            : hipStreamCreateWithFlags(&ln.aux[1], hipStreamNonBlocking)) == hipSuccess;
+    }
     for (int i = 0; i < DFX_LANE_EVENTS; ++i) good = good && hipEventCreateWithFlags(&ln.ev[i], hipEventDisableTiming) == hipSuccess;
     if (l == 0) {  // the layer-pipelined GRU phase runs on lane 0 only
         const int nl = 1 + (m->cfg.emb_num_layers - 1) + m->cfg.df_num_layers;
@@ -512,7 +521,8 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         const char *x = getenv("DFX_EXACT_FP32");
         m->exact_fp32 = x && x[0] == '1';
         const char *ce = getenv("DFX_CONVP_EARLY");
-        m->convp_late = !(ce && ce[0] == '1');
+        m->convp_late = ce && ce[0] == '0';
+        m->convp_after_c1 = ce && ce[0] == '2';
         const char *g2 = getenv("DFX_GRU_X2");
         m->gru_x2 = g2 && g2[0] == '1' && !dfx_env_is_emulator();
         if (hipMalloc(reinterpret_cast<void **>(&m->d_err), 256) != hipSuccess || hipMemset(m->d_err, 0, 256) != hipSuccess) {
@@ -1166,8 +1176,9 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         if ((rc = signal(EV_C0P, x2))) return rc;
         return DFX_OK;
     };
-    // the pathway conv only has to finish before df_out: by default it is released after the (HBM-bound) front so that it does not
-    // compete with the encoder for bandwidth and runs during the GRU phase instead (DFX_CONVP_EARLY=1: right after c0)
+    // the pathway conv only has to finish before df_out: it starts right away on the low-priority stream x2 and fills whatever the
+    // encoder kernels leave idle (DFX_CONVP_EARLY=0: released only after the front has been enqueued)
+    if (m->convp_after_c1 && (rc = wait(EV_C1, x2))) return rc;
     if (!m->convp_late && (rc = run_convp())) return rc;
     // ---- Encoder, ERB branch on s (:168-171)
     const bool fuse_dec = E % 2 == 0 && dfx_fuse_erb(2 * DFX_DEC10_SMEM(C, E));

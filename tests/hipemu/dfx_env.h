@@ -119,6 +119,14 @@ static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) {
     *s = nullptr;
     return hipSuccess;
 }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) {
+    *s = nullptr;
+    return hipSuccess;
+}
+static inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) {
+    *lo = *hi = 0;
+    return hipSuccess;
+}
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
