@@ -90,7 +90,8 @@ int dfx_features_padded(const dfx_state *st, const float *x, int64_t B, int64_t 
                         float alpha, float *spec, float *erb_feat, float *spec_feat, void *stream);
 // dfx_synthesis storing only stream samples [out_skip, out_skip + out_len) of every row, at out[row * out_stride + n - out_skip]
 int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int64_t Tf, const float *mem_in, float *mem_out,
-                         float *out, int64_t out_stride, int64_t out_skip, int64_t out_len, hipStream_t s);
+                         float *out, int64_t out_stride, int64_t out_skip, int64_t out_len, hipStream_t s, int64_t f_begin = 0,
+                         int64_t f_end = -1);  // only output frames [f_begin, f_end) (time-chunked finishing)
 int dfx_launch_norm_scan(const float *erb_in, float *erb_out, int E, const float *spec_in, int64_t spec_frame_stride,
                          float *spec_out, int Fn, int64_t C, int64_t T, float alpha, float *erb_state,
                          float *unit_state, hipStream_t s);

@@ -375,8 +375,12 @@ extern "C" int dfx_synthesis(const dfx_state *st, const float *spec, int64_t B, 
 }
 
 int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int64_t Tf, const float *mem_in, float *mem_out,
-                         float *out, int64_t out_stride, int64_t out_skip, int64_t out_len, hipStream_t stream) {
+                         float *out, int64_t out_stride, int64_t out_skip, int64_t out_len, hipStream_t stream, int64_t f_begin,
+                         int64_t f_end) {
     DfxSynArgs A;
+    const int Rr = (st->N + st->hop - 1) / st->hop;
+    A.f_begin = f_begin;
+    A.f_end = f_end < 0 ? Tf + (mem_out ? Rr - 1 : 0) : f_end;
     A.out_skip = out_skip;
     A.out_len = out_len;
     A.spec = reinterpret_cast<const float2 *>(spec);
@@ -391,7 +395,7 @@ int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int6
     A.hop = st->hop;
     A.R = (st->N + st->hop - 1) / st->hop;
     A.outf = DFX_DSP_TEAMS - (A.R - 1);
-    A.chunks = (int)dfx_ceil_div(Tf + (mem_out ? A.R - 1 : 0), A.outf);
+    A.chunks = (int)dfx_ceil_div(A.f_end - A.f_begin, A.outf);
     A.plan = st->plan;
     if (A.chunks <= 0) return DFX_OK;
     const size_t smem = dsp_smem_bytes(st);
@@ -471,11 +475,12 @@ int dfx_features_padded(const dfx_state *st, const float *x, int64_t B, int64_t 
 
 int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, const float *gains,
                         const dfx_bands *bands, int64_t B, int64_t T, int F, int nb_df, int order, int lookahead,
-                        float pf_beta, float atten_lim, float *out, hipStream_t s);
+                        float pf_beta, float atten_lim, float *out, hipStream_t s, int64_t t_begin = 0, int64_t t_end = -1);
 
+// frames [t_begin, t_end) of every clip (t_end < 0: T)
 int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, const float *gains,
                         const dfx_bands *bands, int64_t B, int64_t T, int F, int nb_df, int order, int lookahead,
-                        float pf_beta, float atten_lim, float *out, hipStream_t s) {
+                        float pf_beta, float atten_lim, float *out, hipStream_t s, int64_t t_begin, int64_t t_end) {
     DfxDfaArgs A;
     A.spec = reinterpret_cast<const float2 *>(spec);
     A.coefs = reinterpret_cast<const float2 *>(coefs);
@@ -506,7 +511,11 @@ int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, 
         rows_sel = (e && atoi(e) == 32) ? 32 : DFX_DFA_ROWS;
     }
     const int ROWS = rows_sel;
-    A.chunks = (int)dfx_ceil_div(T, ROWS);
+    if (t_end < 0) t_end = T;
+    if (t_end <= t_begin) return DFX_OK;
+    A.t_begin = (int)t_begin;
+    A.t_end = (int)t_end;
+    A.chunks = (int)dfx_ceil_div(t_end - t_begin, ROWS);
     if (T * (int64_t)F > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_df_apply: T*F exceeds 2^31 elements per clip");
     const int64_t nblk = dfx_ceil_div(B, 8) * 8 * A.chunks;
     if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_df_apply: batch too large for one launch");

@@ -229,6 +229,7 @@ struct DfxSynArgs {
     const float *window;
     const float2 *tw;
     int64_t B, Tf, out_stride;
+    int64_t f_begin, f_end;     // output frames [f_begin, f_end) are produced by this launch (f_end may include the R-1 memory frames)
     int64_t out_skip, out_len;  // only stream samples [out_skip, out_skip + out_len) are stored, at out[row][n - out_skip]
     int hop, R /* N/hop rounded up: frames overlapping one output hop */, outf /* output frames per chunk */;
     int chunks;           // chunks per row (including the tail chunk that produces mem_out)
@@ -259,7 +260,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_synthesis(DfxSynArgs A)
     const int ML = N - A.hop;
     const int64_t b = blockIdx.x / A.chunks;
     const int chunk = (int)(blockIdx.x - b * A.chunks);
-    const int64_t t0 = (int64_t)chunk * A.outf;      // first output frame of this chunk
+    const int64_t t0 = A.f_begin + (int64_t)chunk * A.outf;  // first output frame of this chunk
     const int64_t t = t0 - (A.R - 1) + team;         // real frame handled by this team
     const bool active = t >= 0 && t < A.Tf;
     if (active) {
@@ -297,7 +298,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_synthesis(DfxSynArgs A)
     for (int idx = threadIdx.x; idx < total; idx += DFX_DSP_THREADS) {
         const int j = idx / A.hop, i = idx - j * A.hop;
         const int64_t tf = t0 + j;
-        if (tf >= A.Tf + (A.mem_out ? A.R - 1 : 0)) break;
+        if (tf >= A.Tf + (A.mem_out ? A.R - 1 : 0) || tf >= A.f_end) break;
         const int64_t s_glob = tf * A.hop + i;  // sample index in the row's output stream
         float acc = 0.f;
         bool have = false;
@@ -458,6 +459,7 @@ struct DfxDfaArgs {
     int F, nbdf, order, lookahead, nb;
     float pf_beta, atten_lim;
     int chunks;           // row chunks per clip
+    int t_begin, t_end;   // frames [t_begin, t_end) of every clip are produced by this launch
 };
 
 static __device__ __forceinline__ float2 dfx_dfa_finish(float2 y, float2 x, float pf_beta, float lim) {
@@ -517,8 +519,8 @@ __global__ void __launch_bounds__(DFX_DFA_THREADS) dfx_k_df_apply(DfxDfaArgs A) 
     const int64_t b = (j / A.chunks) * 8 + xcd;
     if (b >= A.B) return;
     const int F = A.F, nd = A.nbdf;
-    const int t0 = chunk * ROWS;
-    const int nt = (A.T - t0) < ROWS ? (int)(A.T - t0) : ROWS;
+    const int t0 = A.t_begin + chunk * ROWS;
+    const int nt = (A.t_end - t0) < ROWS ? (A.t_end - t0) : ROWS;
     const int halo = ROWS + A.order - 1;
     float2 *xs = reinterpret_cast<float2 *>(smem);                                   // [halo][nd]
     size_t off = ((size_t)halo * nd * 8 + 15) & ~(size_t)15;

@@ -8,7 +8,7 @@
 
 int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, const float *gains,
                         const dfx_bands *bands, int64_t B, int64_t T, int F, int nb_df, int order, int lookahead,
-                        float pf_beta, float atten_lim, float *out, hipStream_t s);
+                        float pf_beta, float atten_lim, float *out, hipStream_t s, int64_t t_begin = 0, int64_t t_end = -1);
 
 // ------------------------------------------------------------------------------------------------ cfg validation
 static int check_cfg(const dfx_model_cfg *c) {
@@ -94,8 +94,17 @@ struct DfxLane {
     hipEvent_t gev[DFX_MAX_GRU_LAYERS][DFX_MAX_TCHUNKS] = {};     // layer l has produced time chunk k
     hipEvent_t pev[DFX_MAX_GRU_LAYERS][DFX_MAX_TCHUNKS] = {};     // gi of layer l, chunk k is ready
     hipEvent_t eev[DFX_MAX_TCHUNKS] = {};                         // emb chunk k is ready
+    hipStream_t fs = nullptr;                                     // finishing stream: df_apply (+ synthesis) per time chunk
+    hipEvent_t mev[DFX_MAX_TCHUNKS] = {};                         // mask chunk k is ready
+    hipEvent_t cev[DFX_MAX_TCHUNKS] = {};                         // DF coefficients of chunk k are ready
 };
-enum { EV_START = 0, EV_C0, EV_C1, EV_C0P, EV_EMB, EV_COEFS, EV_FRONT, EV_DONE, EV_XA, EV_MASK, EV_LSNR };
+// enhance() hands the synthesis to the model forward so that it can run per time chunk behind df_apply
+struct DfxFinish {
+    const dfx_state *st;
+    float *y;
+    int64_t out_stride, out_skip, out_len;
+};
+enum { EV_START = 0, EV_C0, EV_C1, EV_C0P, EV_EMB, EV_COEFS, EV_FRONT, EV_DONE, EV_XA, EV_MASK, EV_LSNR, EV_FIN };
 
 struct dfx_model {
     dfx_model_cfg cfg{};
@@ -128,6 +137,7 @@ struct dfx_model {
     int tchunks = 12;         // time chunks of the layer-pipelined GRU phase (DFX_TCHUNKS)
     int tchunk_min = 32;      // shortest chunk worth a launch (frames)
     bool exact_fp32 = false;  // DFX_EXACT_FP32=1: keep the dense contractions on the exact fp32 MFMA path
+    bool finish_chunked = false;  // DFX_FINISH_CHUNKS=1: df_apply + synthesis per time chunk beside the GRU chain (measured slower)
     bool convp_after_c1 = false;  // DFX_CONVP_EARLY=2: df_convp starts when df_conv1 is done
     bool convp_late = false;  // DFX_CONVP_EARLY=0 holds df_convp back until the front is enqueued (it then starts beside the GRU phase)
     bool gru_x2 = false;      // DFX_GRU_X2=1: two-CU GRU recurrence (weights fully on chip, h halves exchanged every step);
@@ -354,7 +364,12 @@ static bool dfx_create_lane(dfx_model *m, int l) {
             }
         }
         for (int i = 0; i < 2; ++i) good = good && hipStreamCreateWithFlags(&ln.ts[i], hipStreamNonBlocking) == hipSuccess;
-        for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) good = good && hipEventCreateWithFlags(&ln.eev[k], hipEventDisableTiming) == hipSuccess;
+        good = good && hipStreamCreateWithFlags(&ln.fs, hipStreamNonBlocking) == hipSuccess;
+        for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) {
+            good = good && hipEventCreateWithFlags(&ln.eev[k], hipEventDisableTiming) == hipSuccess;
+            good = good && hipEventCreateWithFlags(&ln.mev[k], hipEventDisableTiming) == hipSuccess;
+            good = good && hipEventCreateWithFlags(&ln.cev[k], hipEventDisableTiming) == hipSuccess;
+        }
     }
     return good;
 }
@@ -523,6 +538,9 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         const char *ce = getenv("DFX_CONVP_EARLY");
         m->convp_late = ce && ce[0] == '0';
         m->convp_after_c1 = ce && ce[0] == '2';
+        const char *fc = getenv("DFX_FINISH_CHUNKS");
+        m->finish_chunked = fc && fc[0] == '1';
+
         const char *g2 = getenv("DFX_GRU_X2");
         m->gru_x2 = g2 && g2[0] == '1' && !dfx_env_is_emulator();
         if (hipMalloc(reinterpret_cast<void **>(&m->d_err), 256) != hipSuccess || hipMemset(m->d_err, 0, 256) != hipSuccess) {
@@ -570,8 +588,12 @@ extern "C" void dfx_model_free(dfx_model *m) {
         }
         for (int i = 0; i < 2; ++i)
             if (ln.ts[i]) (void)hipStreamDestroy(ln.ts[i]);
-        for (int k = 0; k < DFX_MAX_TCHUNKS; ++k)
+        for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) {
             if (ln.eev[k]) (void)hipEventDestroy(ln.eev[k]);
+            if (ln.mev[k]) (void)hipEventDestroy(ln.mev[k]);
+            if (ln.cev[k]) (void)hipEventDestroy(ln.cev[k]);
+        }
+        if (ln.fs) (void)hipStreamDestroy(ln.fs);
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->d_err) (void)hipFree(m->d_err);
@@ -1018,7 +1040,7 @@ static int launch_gru_h3x2(const dfx_model *m, const GruW &g, const float *gi, f
 #endif
 
 static int launch_gru_h3(const dfx_model *m, const GruW &g, const float *gi, float *y, const float *h_in, float *h_out,
-                         int64_t B, int64_t T, int64_t t0, int64_t t1, hipStream_t s) {
+                         int64_t B, int64_t T, int64_t t0, int64_t t1, hipStream_t s, int layer = -1) {
     DfxGhArgs A;
     A.gi = gi;
     A.whf = reinterpret_cast<const dfx_h8 *>(m->p(g.whh_h3));
@@ -1031,9 +1053,16 @@ static int launch_gru_h3(const dfx_model *m, const GruW &g, const float *gi, flo
     A.t0 = t0;
     A.t1 = t1;
     A.unscale = g.whh_unscale;
+    // XCDs a layer's workgroups are confined to (1, 2 or 4; 0 = plain grid).  Measured at batch 256 inside the pipeline: 4 -> -0.7 ms
+    // per step (the W_hh lines a layer streams every step are shared by more workgroups per L2), 1 and 2 -> +1.3 ms (L2 bandwidth).
+    static const int xw = [] { const char *e = getenv("DFX_GRU_XCDS"); return e ? atoi(e) : 4; }();
+    const int64_t groups = dfx_ceil_div(B, DFX_GH_ROWS);
+    A.xcd_mask = 0;
+    if (layer >= 0 && (xw == 1 || xw == 2 || xw == 4) && groups <= 32 * xw) A.xcd_mask = (((1 << xw) - 1) << ((layer * xw) % 8)) & 0xff;
+    const int64_t nblk = A.xcd_mask ? dfx_ceil_div(groups, xw) * 8 : groups;
     DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_rec_h3, DFX_GH_SMEM));
     DfxKScope ks(DFX_K_GRU_REC, s);
-    dfx_launch(dfx_k_gru_rec_h3, dim3((unsigned)dfx_ceil_div(B, DFX_GH_ROWS)), dim3(DFX_GH_THREADS), DFX_GH_SMEM, s, A);
+    dfx_launch(dfx_k_gru_rec_h3, dim3((unsigned)nblk), dim3(DFX_GH_THREADS), DFX_GH_SMEM, s, A);
     DFX_LAUNCH_CHECK();
     return DFX_OK;
 }
@@ -1072,7 +1101,8 @@ static int run_gru_stack(const dfx_model *m, const std::vector<GruW> &layers, co
 template <int C>
 static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float *spec, const float *feat_erb,
                         const float *feat_spec, int64_t B, int64_t T, float atten_lim, float *spec_e, float *mask_out,
-                        float *lsnr_out, float *coefs_out, float *ws, hipStream_t s, const DfxLane *ln, bool signal_front) {
+                        float *lsnr_out, float *coefs_out, float *ws, hipStream_t s, const DfxLane *ln, bool signal_front,
+                        const DfxFinish *fin) {
     const dfx_model_cfg &c = m->cfg;
     const int64_t R = B * T;
     const Ws w = plan_ws(c, R, B);
@@ -1289,6 +1319,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         const int nl = 1 + ndec + ndf;
         (void)nl;
         auto proj_chunk = [&](const GruW &g, int l, int k, const float *xin, hipStream_t st) -> int {
+            static const int dev_skip3 = [] { const char *e = getenv("DFX_DEV_SKIP"); return e ? atoi(e) : 0; }();
+            if ((dev_skip3 & 4) && l > 0) return DFX_OK;  // dev timing ablation: no input projections for layers > 0
             return launch_proj_h3(m, g, xin, ws + w.pgi[l], Mk(k), 768, st, rmk(k));
         };
         // two-CU recurrence (weights fully on chip) when all workgroup pairs of all concurrent layers fit on the chip
@@ -1301,7 +1333,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 return launch_gru_h3x2(m, g, ws + w.pgi[l], ws + w.py[l], k == 0 ? nullptr : hl, hl, B, T, tb(k), tb(k + 1), xb2, st);
             }
 #endif
-            return launch_gru_h3(m, g, ws + w.pgi[l], ws + w.py[l], k == 0 ? nullptr : hl, hl, B, T, tb(k), tb(k + 1), st);
+            return launch_gru_h3(m, g, ws + w.pgi[l], ws + w.py[l], k == 0 ? nullptr : hl, hl, B, T, tb(k), tb(k + 1), st, l);
         };
         if (use_x2) {  // fresh tags for this pass (a stale granule of an earlier pass can then never match)
             ++m->epoch;
@@ -1344,10 +1376,12 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             hipStream_t st = ln->ts[0];
             const int fpt = 64 / E > 0 ? 64 / E : 1;
             const size_t smem = ((size_t)fpt * E * (C + 1) + (size_t)fpt * E * 3 + 3 * C) * sizeof(float);
+            static const int dev_skip = [] { const char *e = getenv("DFX_DEV_SKIP"); return e ? atoi(e) : 0; }();
             for (int k = 0; k < K; ++k) {
                 const int64_t Rk = Mk(k);
                 const DfxRowMap rm = rmk(k);
                 if ((rc = ewait(ln->gev[ndec][k], st))) return rc;
+                if (dev_skip & 1) { if ((rc = esig(ln->mev[k], st))) return rc; continue; }
                 if ((rc = launch_glin(m, m->dec_out, ws + w.py[ndec], DFX_ACT_RELU, nullptr, demb, Rk, st, rm))) return rc;
                 if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, Rk, E / 4, E / 4, 1, st, rm))) return rc;
                 if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, Rk, E / 4, E / 2, 2, st, rm))) return rc;
@@ -1361,6 +1395,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                                Rk, E, fpt, rm);
                 }
                 DFX_LAUNCH_CHECK();
+                if ((rc = esig(ln->mev[k], st))) return rc;
             }
             if ((rc = signal(EV_MASK, st))) return rc;
         }
@@ -1386,8 +1421,10 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             const int l = ndec + ndf;
             if ((rc = wait(EV_C0P, st))) return rc;
             if (c.df_gru_skip != DFX_SKIP_IDENTITY) {
+                static const int dev_skip2 = [] { const char *e = getenv("DFX_DEV_SKIP"); return e ? atoi(e) : 0; }();
                 for (int k = 0; k < K; ++k) {
                     if ((rc = ewait(ln->gev[l][k], st))) return rc;
+                    if (dev_skip2 & 2) { if ((rc = esig(ln->cev[k], st))) return rc; continue; }
                     const float *cfeat = ws + w.py[l];
                     if (c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) {
                         if ((rc = launch_glin(m, m->df_skip, embv, DFX_ACT_NONE, ws + w.py[l], xdf, Mk(k), st, rmk(k)))) return rc;
@@ -1397,6 +1434,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                                            m->df_out.Ng, nullptr, DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, Mk(k), st, NO, Fd,
                                            T, rmk(k))))
                         return rc;
+                    if ((rc = esig(ln->cev[k], st))) return rc;
                 }
             } else {
                 if ((rc = ewait(ln->gev[l][K - 1], st))) return rc;
@@ -1409,6 +1447,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 if ((rc = launch_ggemm(xdf, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg, m->df_out.Ng,
                                        nullptr, DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, R, st, NO, Fd, T)))
                     return rc;
+                for (int k = 0; k < K; ++k)  // the identity-skip form is not chunked: all coefficients appear at once
+                    if ((rc = esig(ln->cev[k], st))) return rc;
             }
             if ((rc = signal(EV_COEFS, st))) return rc;
         }
@@ -1420,18 +1460,38 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                        m->lsnr_b, (float)(c.lsnr_max - c.lsnr_min), (float)c.lsnr_min, lsnr, R, emb);
         }
         DFX_LAUNCH_CHECK();
+        // ---- finishing, per time chunk on its own stream as soon as the chunk's mask and coefficients exist: Mask + MF.DF + combine +
+        // post filter + atten_lim (:426-454, enhance.py:238-240) and, for enhance(), the ISTFT of the chunk's output frames.  Only the
+        // last chunk's share of these HBM-bound kernels is left after the GRU chain.
+        if (m->finish_chunked) {
+            hipStream_t st = ln->fs;
+            for (int k = 0; k < K; ++k) {
+                if ((rc = ewait(ln->mev[k], st)) || (rc = ewait(ln->cev[k], st))) return rc;
+                if ((rc = dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead,
+                                              c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, st, tb(k), tb(k + 1))))
+                    return rc;
+                if (fin && (rc = dfx_launch_synthesis(fin->st, spec_e, B, T, nullptr, nullptr, fin->y, fin->out_stride, fin->out_skip,
+                                                      fin->out_len, st, tb(k), tb(k + 1))))
+                    return rc;
+            }
+            if ((rc = signal(EV_FIN, st)) || (rc = wait(EV_FIN, s))) return rc;
+            return DFX_OK;
+        }
         if ((rc = wait(EV_MASK, s))) return rc;
     }
     if ((rc = wait(EV_COEFS, s))) return rc;
     // ---- Mask + MF.DF + combine + post filter + atten_lim (:426-454, enhance.py:238-240)
-    return dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead,
-                               c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, s);
+    if ((rc = dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead,
+                                  c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, s)))
+        return rc;
+    if (fin) return dfx_launch_synthesis(fin->st, spec_e, B, T, nullptr, nullptr, fin->y, fin->out_stride, fin->out_skip, fin->out_len, s);
+    return DFX_OK;
 }
 
 static int model_forward_lane(const dfx_model *m, const dfx_bands *bands, const float *spec, const float *feat_erb,
                               const float *feat_spec, int64_t B, int64_t T, float atten_lim, float *spec_e, float *mask,
                               float *lsnr, float *df_coefs, void *workspace, int64_t workspace_bytes, void *stream,
-                              const DfxLane *ln, bool signal_front) {
+                              const DfxLane *ln, bool signal_front, const DfxFinish *fin = nullptr) {
     if (!m || !bands || B < 0 || T < 0) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_forward: bad arguments");
     if (bands->nb != m->cfg.nb_erb || bands->F != m->cfg.fft_size / 2 + 1)
         DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_forward: band table does not match the model (nb_erb / fft_size)");
@@ -1447,9 +1507,9 @@ static int model_forward_lane(const dfx_model *m, const dfx_bands *bands, const 
     float *ws = reinterpret_cast<float *>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     hipStream_t s = dfx_stream(stream);
     switch (m->cfg.conv_ch) {
-        case 16: return forward_impl<16>(m, bands, spec, feat_erb, feat_spec, B, T, atten_lim, spec_e, mask, lsnr, df_coefs, ws, s, ln, signal_front);
-        case 32: return forward_impl<32>(m, bands, spec, feat_erb, feat_spec, B, T, atten_lim, spec_e, mask, lsnr, df_coefs, ws, s, ln, signal_front);
-        case 64: return forward_impl<64>(m, bands, spec, feat_erb, feat_spec, B, T, atten_lim, spec_e, mask, lsnr, df_coefs, ws, s, ln, signal_front);
+        case 16: return forward_impl<16>(m, bands, spec, feat_erb, feat_spec, B, T, atten_lim, spec_e, mask, lsnr, df_coefs, ws, s, ln, signal_front, fin);
+        case 32: return forward_impl<32>(m, bands, spec, feat_erb, feat_spec, B, T, atten_lim, spec_e, mask, lsnr, df_coefs, ws, s, ln, signal_front, fin);
+        case 64: return forward_impl<64>(m, bands, spec, feat_erb, feat_spec, B, T, atten_lim, spec_e, mask, lsnr, df_coefs, ws, s, ln, signal_front, fin);
     }
     DFX_FAIL(DFX_ERR_UNSUPPORTED, "conv_ch");
 }
@@ -1553,14 +1613,16 @@ static int enhance_chunk(const dfx_model *m, const dfx_state *st, const float *x
     if (rc) return rc;
     int64_t mb = 0;
     dfx_model_workspace_bytes(m, B, Tf, &mb);
-    rc = model_forward_lane(m, st->bands, spec, fe, fs, B, Tf, lim, spec_e, nullptr, nullptr, nullptr, base + w.model, mb,
-                            (void *)s, ln, signal_front);
-    if (rc) return rc;
-    if (pad) {  // enhance.py:248-249: audio[:, d : orig_len + d] — the synthesis stores exactly that window
-        const int64_t d = st->N - st->hop;
-        return dfx_launch_synthesis(st, spec_e, B, Tf, nullptr, nullptr, y, T, d, T, s);
-    }
-    return dfx_synthesis(st, spec_e, B, Tf, nullptr, nullptr, y, Tf * st->hop, (void *)s);
+    // the synthesis is enqueued by the model forward (per time chunk when the GRU phase is pipelined); with pad it stores exactly
+    // the window audio[:, d : orig_len + d] of enhance.py:248-249
+    DfxFinish fin;
+    fin.st = st;
+    fin.y = y;
+    fin.out_stride = pad ? T : Tf * st->hop;
+    fin.out_skip = pad ? st->N - st->hop : 0;
+    fin.out_len = pad ? T : Tf * st->hop;
+    return model_forward_lane(m, st->bands, spec, fe, fs, B, Tf, lim, spec_e, nullptr, nullptr, nullptr, base + w.model, mb, (void *)s, ln,
+                              signal_front, &fin);
 }
 
 extern "C" int dfx_enhance(const dfx_model *m, const dfx_state *st, const float *x, int64_t B, int64_t T, int pad,

@@ -1731,6 +1731,8 @@ struct DfxGhArgs {
     int64_t B, T;
     int64_t t0, t1;       // steps [t0, t1) of the T frames (time-chunked launches carry h through h_in / h_out)
     float unscale;
+    int xcd_mask;         // != 0: the grid is oversized 8x / popcount and only blocks whose blockIdx % 8 (= XCD under the observed
+                          // round-robin dispatch) is in the mask work: a layer's workgroups then share few L2s (placement = speed only)
 };
 
 __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_rec_h3(DfxGhArgs A) {
@@ -1742,7 +1744,14 @@ __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_rec_h
     dfx_h8 *wl = reinterpret_cast<dfx_h8 *>(smraw);                           // [FL][wave][hi,lo][lane]
     uint16_t *h16 = reinterpret_cast<uint16_t *>(smraw + DFX_GH_SMEM_W);      // [buf][hi,lo][16][HROW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
-    const int64_t b0 = (int64_t)blockIdx.x * DFX_GH_ROWS;
+    int64_t grp = blockIdx.x;
+    if (A.xcd_mask) {
+        const int x = (int)(blockIdx.x & 7);
+        if (!((A.xcd_mask >> x) & 1)) return;
+        grp = (int64_t)(blockIdx.x >> 3) * __builtin_popcount(A.xcd_mask) + __builtin_popcount(A.xcd_mask & ((1 << x) - 1));
+        if (grp * DFX_GH_ROWS >= A.B) return;
+    }
+    const int64_t b0 = grp * DFX_GH_ROWS;
     const bool valid = b0 + jl < A.B;
     const int64_t brow = valid ? b0 + jl : A.B - 1;
     // fragment f = kc*TILES + gate*NS + s of this wave is global pair ((unit tile = wave*NS + s)*8 + kc)*3 + gate

@@ -14,7 +14,7 @@ int main(int argc, char **argv) {
     std::vector<uint16_t> hw(768 * 256 * 2); for (size_t i = 0; i < hw.size(); ++i) hw[i] = dfx_f32_to_f16_bits(h[i / 2] * 64.f);
     CK(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemset(gi, 0, B * T * 768 * 4)); CK(hipMemset(bhn, 0, 1024));
-    DfxGhArgs A; A.gi = gi; A.whf = w; A.bhn = bhn; A.h_in = nullptr; A.h_out = nullptr; A.y = y; A.B = B; A.T = T; A.unscale = 1.f / 64.f;
+    DfxGhArgs A; A.gi = gi; A.whf = w; A.bhn = bhn; A.h_in = nullptr; A.h_out = nullptr; A.y = y; A.B = B; A.T = T; A.unscale = 1.f / 64.f; A.xcd_mask = 0;
     CK(hipFuncSetAttribute((const void *)dfx_k_gru_rec_h3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DFX_GH_SMEM));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     float best = 1e9;
