@@ -87,6 +87,7 @@ struct GlinW {
 struct DfxLane {
     hipStream_t main = nullptr;
     hipStream_t aux[2] = {nullptr, nullptr};
+    hipStream_t aux_lo = nullptr;                                 // lane 0: lowest-priority twin of aux[1]
     hipEvent_t ev[DFX_LANE_EVENTS] = {};
     hipStream_t gs[DFX_MAX_GRU_LAYERS] = {};                      // recurrence stream of GRU layer l
     hipStream_t ps[DFX_MAX_GRU_LAYERS] = {};                      // preparation stream of GRU layer l (linear_in, projection)
@@ -343,14 +344,16 @@ static bool dfx_create_lane(dfx_model *m, int l) {
     DfxLane &ln = m->lanes[l];
     if (ln.main) return true;
     bool good = hipStreamCreateWithFlags(&ln.main, hipStreamNonBlocking) == hipSuccess;
-    good = good && hipStreamCreateWithFlags(&ln.aux[0], hipStreamNonBlocking) == hipSuccess;
-    {   // aux[1] carries df_convp, which has slack until df_out needs it: lowest dispatch priority, so that it fills the CUs the
-        // critical-path kernels leave idle instead of competing with them (DFX_X2_PRIO=normal: same priority as the rest)
+    for (int i = 0; i < 2; ++i) good = good && hipStreamCreateWithFlags(&ln.aux[i], hipStreamNonBlocking) == hipSuccess;
+    if (l == 0) {
+        // df_convp has slack until df_out needs it: when lane 0 is the only lane in flight it runs on a lowest-priority stream, so that
+        // it fills the CUs the critical-path kernels leave idle instead of competing with them (-0.3 ms per step).  Never used beside
+        // other lanes: with more streams than hardware queues a low-priority queue was measured to starve for ~1 s.
+        // DFX_X2_PRIO=normal disables it.
         int lo = 0, hi = 0;
         const char *pe = getenv("DFX_X2_PRIO");
-        const bool low = !(pe && pe[0] == 'n') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi;
-        good = good && (low ? hipStreamCreateWithPriority(&ln.aux[1], hipStreamNonBlocking, lo)
-                            : hipStreamCreateWithFlags(&ln.aux[1], hipStreamNonBlocking)) == hipSuccess;
+        if (!(pe && pe[0] == 'n') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+            good = good && hipStreamCreateWithPriority(&ln.aux_lo, hipStreamNonBlocking, lo) == hipSuccess;
     }
     for (int i = 0; i < DFX_LANE_EVENTS; ++i) good = good && hipEventCreateWithFlags(&ln.ev[i], hipEventDisableTiming) == hipSuccess;
     if (l == 0) {  // the layer-pipelined GRU phase runs on lane 0 only
@@ -364,7 +367,7 @@ static bool dfx_create_lane(dfx_model *m, int l) {
             }
         }
         for (int i = 0; i < 2; ++i) good = good && hipStreamCreateWithFlags(&ln.ts[i], hipStreamNonBlocking) == hipSuccess;
-        good = good && hipStreamCreateWithFlags(&ln.fs, hipStreamNonBlocking) == hipSuccess;
+        if (m->finish_chunked) good = good && hipStreamCreateWithFlags(&ln.fs, hipStreamNonBlocking) == hipSuccess;
         for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) {
             good = good && hipEventCreateWithFlags(&ln.eev[k], hipEventDisableTiming) == hipSuccess;
             good = good && hipEventCreateWithFlags(&ln.mev[k], hipEventDisableTiming) == hipSuccess;
@@ -594,6 +597,7 @@ extern "C" void dfx_model_free(dfx_model *m) {
             if (ln.cev[k]) (void)hipEventDestroy(ln.cev[k]);
         }
         if (ln.fs) (void)hipStreamDestroy(ln.fs);
+        if (ln.aux_lo) (void)hipStreamDestroy(ln.aux_lo);
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->d_err) (void)hipFree(m->d_err);
@@ -1121,7 +1125,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     //   x1: c0 -+- c1 ------------------------------------------------------+-- DF decoder: GRU stack, skip, (join c0p) df_out -> coefs
     //   x2:     +- df_convp -> c0p
     const bool par = m->concurrent;
-    hipStream_t x1 = par ? ln->aux[0] : s, x2 = par ? ln->aux[1] : s;
+    hipStream_t x1 = par ? ln->aux[0] : s, x2 = par ? ((ln->aux_lo && !signal_front) ? ln->aux_lo : ln->aux[1]) : s;
     auto signal = [&](int e, hipStream_t from) -> int {
         if (par) DFX_HIP(hipEventRecord(ln->ev[e], from));
         return DFX_OK;
@@ -1463,7 +1467,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // ---- finishing, per time chunk on its own stream as soon as the chunk's mask and coefficients exist: Mask + MF.DF + combine +
         // post filter + atten_lim (:426-454, enhance.py:238-240) and, for enhance(), the ISTFT of the chunk's output frames.  Only the
         // last chunk's share of these HBM-bound kernels is left after the GRU chain.
-        if (m->finish_chunked) {
+        if (m->finish_chunked && ln->fs) {
             hipStream_t st = ln->fs;
             for (int k = 0; k < K; ++k) {
                 if ((rc = ewait(ln->mev[k], st)) || (rc = ewait(ln->cev[k], st))) return rc;
