@@ -138,6 +138,11 @@ struct dfx_model {
     int tchunks = 12;         // time chunks of the layer-pipelined GRU phase (DFX_TCHUNKS)
     int tchunk_min = 32;      // shortest chunk worth a launch (frames)
     bool exact_fp32 = false;  // DFX_EXACT_FP32=1: keep the dense contractions on the exact fp32 MFMA path
+    // df_conv0's output c0 is recomputed by its consumers instead of being stored when the pathway conv has the sliding-window kernel
+    // (kt <= 5); DFX_FUSE_C0=0 restores the materialised c0 (dfx_k_conv_in_df -> dfx_k_pwconv / dfx_k_df_convp2).
+    bool fuse_c0 = true;
+    // frame-resident ERB encoder head / decoder tail (dfx_k_erb_enc, dfx_k_erb_dec10); DFX_FUSE_ERB=0: layer-by-layer kernels
+    bool fuse_erb = true;
     bool finish_chunked = false;  // DFX_FINISH_CHUNKS=1: df_apply + synthesis per time chunk beside the GRU chain (measured slower)
     bool convp_after_c1 = false;  // DFX_CONVP_EARLY=2: df_convp starts when df_conv1 is done
     bool convp_late = false;  // DFX_CONVP_EARLY=0 holds df_convp back until the front is enqueued (it then starts beside the GRU phase)
@@ -541,6 +546,9 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         const char *ce = getenv("DFX_CONVP_EARLY");
         m->convp_late = ce && ce[0] == '0';
         m->convp_after_c1 = ce && ce[0] == '2';
+        const char *f0 = getenv("DFX_FUSE_C0"), *fe = getenv("DFX_FUSE_ERB");
+        m->fuse_c0 = !(f0 && f0[0] == '0') && m->cfg.df_pathway_kernel_size_t <= 5;
+        m->fuse_erb = !(fe && fe[0] == '0');
         const char *fc = getenv("DFX_FINISH_CHUNKS");
         m->finish_chunked = fc && fc[0] == '1';
 
@@ -642,14 +650,7 @@ struct Ws {
     size_t pgi[DFX_MAX_GRU_LAYERS], py[DFX_MAX_GRU_LAYERS], ph[DFX_MAX_GRU_LAYERS];  // layer-pipelined GRU phase: gi, y, h state per layer
     size_t pxb, pxb_floats;   // h exchange buffers of the two-CU GRU kernel: [layer][group][2][2][16][128] granules of 8 bytes
 };
-// df_conv0's output is recomputed by its consumers instead of being stored when the pathway conv has the sliding-window kernel
-// (kt <= 5).  DFX_FUSE_C0=0 restores the materialised c0 (dfx_k_conv_in_df -> dfx_k_pwconv / dfx_k_df_convp2) for A/B runs.
-static bool dfx_fuse_c0(const dfx_model_cfg &c) {
-    static const bool off = [] { const char *e = getenv("DFX_FUSE_C0"); return e && e[0] == '0'; }();
-    return !off && c.df_pathway_kernel_size_t <= 5;
-}
-
-Ws plan_ws(const dfx_model_cfg &c, int64_t R, int64_t B = 0) {
+Ws plan_ws(const dfx_model_cfg &c, bool fuse_c0, int64_t R, int64_t B = 0) {
     Ws w{};
     size_t off = 0;
     auto take = [&](size_t n) {
@@ -662,7 +663,7 @@ Ws plan_ws(const dfx_model_cfg &c, int64_t R, int64_t B = 0) {
     w.e1 = take(R * (E / 2) * C);
     w.e2 = take(R * (E / 4) * C);
     w.e3 = take(R * (E / 4) * C);
-    w.c0 = dfx_fuse_c0(c) ? 0 : take(R * Fd * C);  // only materialised by the unfused DF-encoder path
+    w.c0 = fuse_c0 ? 0 : take(R * Fd * C);  // only materialised by the unfused DF-encoder path
     w.c1 = take(R * (Fd / 2) * C);
     w.emb_in = take(R * emb);
     w.emb = take(R * emb);
@@ -700,7 +701,7 @@ Ws plan_ws(const dfx_model_cfg &c, int64_t R, int64_t B = 0) {
 
 extern "C" int dfx_model_workspace_bytes(const dfx_model *m, int64_t B, int64_t T, int64_t *bytes) {
     if (!m || !bytes || B < 0 || T < 0) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_workspace_bytes: bad arguments");
-    *bytes = (int64_t)(plan_ws(m->cfg, B * T, B).total * sizeof(float)) + 256;
+    *bytes = (int64_t)(plan_ws(m->cfg, m->fuse_c0, B * T, B).total * sizeof(float)) + 256;
     return DFX_OK;
 }
 
@@ -841,13 +842,6 @@ static int launch_conv01_h3(const dfx_model *m, const PwW &w, const float *feat_
         DFX_LAUNCH_CHECK();
         return DFX_OK;
     }
-}
-
-// The ERB encoder / decoder conv chains run frame-resident (dfx_k_erb_enc / dfx_k_erb_dec) unless DFX_FUSE_ERB=0 or their LDS
-// strips do not fit a CU (very large nb_erb): then the layer-by-layer kernels are used.
-static bool dfx_fuse_erb(size_t smem) {
-    static const bool off = [] { const char *e = getenv("DFX_FUSE_ERB"); return e && e[0] == '0'; }();
-    return !off && smem <= (size_t)160 * 1024;
 }
 
 // erb_dec.convt1 -> conv0_out fused (dfx_k_erb_dec10); x = d2, writes the mask
@@ -1109,7 +1103,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                         const DfxFinish *fin) {
     const dfx_model_cfg &c = m->cfg;
     const int64_t R = B * T;
-    const Ws w = plan_ws(c, R, B);
+    const Ws w = plan_ws(c, m->fuse_c0, R, B);
     const int E = c.nb_erb, Fd = c.nb_df, O = c.df_order, NO = 2 * O, emb = C * E / 4, L = c.conv_lookahead;
     float *e0 = ws + w.e0, *e1 = ws + w.e1, *e2 = ws + w.e2, *e3 = ws + w.e3, *c0 = ws + w.c0, *c1 = ws + w.c1;
     float *emb_in = ws + w.emb_in, *embv = ws + w.emb, *xa = ws + w.xa, *xb = ws + w.xb, *gi = ws + w.gi;
@@ -1137,7 +1131,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     if ((rc = signal(EV_START, s)) || (rc = wait(EV_START, x1))) return rc;
     // ---- Encoder, DF branch on x1 (deepfilternet3.py:176-179).  By default c0 = df_conv0(feat_spec) never exists in HBM: its two
     // consumers (df_conv1 here, df_convp below) recompute the tiles they need from feat_spec on the matrix core.
-    const bool fuse_c0 = dfx_fuse_c0(c);
+    const bool fuse_c0 = m->fuse_c0;
     const float *cp_feat = fuse_c0 ? feat_spec : nullptr;
     const bool fuse_h3 = fuse_c0 && !m->exact_fp32 && C % 32 == 0 && m->cp_h3;  // fp16-split matrix ops (default)
     if (fuse_c0) {
@@ -1215,8 +1209,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     if (m->convp_after_c1 && (rc = wait(EV_C1, x2))) return rc;
     if (!m->convp_late && (rc = run_convp())) return rc;
     // ---- Encoder, ERB branch on s (:168-171)
-    const bool fuse_dec = E % 2 == 0 && dfx_fuse_erb(2 * DFX_DEC10_SMEM(C, E));
-    const bool fuse_enc = E % 2 == 0 && 3 * (E + 2) <= 192 && dfx_fuse_erb(2 * DFX_ENC_SMEM(C, E));
+    const bool fuse_dec = E % 2 == 0 && m->fuse_erb && 2 * DFX_DEC10_SMEM(C, E) <= (size_t)160 * 1024;
+    const bool fuse_enc = E % 2 == 0 && 3 * (E + 2) <= 192 && m->fuse_erb && 2 * DFX_ENC_SMEM(C, E) <= (size_t)160 * 1024;
     if (fuse_enc) {
         if ((rc = launch_erb_enc<C>(m, feat_erb, e0, e1, B, T, s))) return rc;
     } else {
