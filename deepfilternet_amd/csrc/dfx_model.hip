@@ -836,7 +836,7 @@ static int launch_conv01_h3(const dfx_model *m, const PwW &w, const float *feat_
         A.L = m->cfg.conv_lookahead;
         A.unscale0 = m->c0_unscale;
         A.unscale = m->dfc1_unscale;
-        const int grid = nn_grid(dfx_ceil_div(B * T * Fout, 64), 2);
+        const int grid = nn_grid(dfx_ceil_div(B * T * Fout, 64), 3);
         DfxKScope ks(DFX_K_PWCONV, s);
         dfx_launch(dfx_k_df_conv01_h3<C>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
         DFX_LAUNCH_CHECK();

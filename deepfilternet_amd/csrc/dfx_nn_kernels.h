@@ -468,26 +468,29 @@ struct DfxC01hArgs {
     float unscale0, unscale;
 };
 
+// Register budget: two waves per SIMD (<= 256 registers) so that one wave's LDS / global latencies hide behind the other's matrix
+// ops — with everything in registers the kernel needs ~430 and runs 1.6x slower.  Only the df_conv0 fragments (used 3x per tile)
+// stay in registers; the pointwise fragments (16 KB) and the biases are read from LDS where they are used, and the feat_spec
+// patch of the next tile is requested as soon as the current one has been split.
 template <int C>
-__global__ void __launch_bounds__(DFX_PW_THREADS, 1) dfx_k_df_conv01_h3(DfxC01hArgs A) {
-    constexpr int CPL = C / 4, NT = C / 16, KC = C >= 32 ? C / 32 : 1;
+__global__ void __launch_bounds__(DFX_PW_THREADS, 2) dfx_k_df_conv01_h3(DfxC01hArgs A) {
+    constexpr int CPL = C / 4, NT = C / 16, KC = C >= 32 ? C / 32 : 1, C4 = C / 4;
     static_assert(C % 32 == 0, "one k-chunk is 32 channels");
-    __shared__ float4 dws[3 * C / 4];
+    __shared__ float4 dws[3 * C4];
+    __shared__ float4 b0s[C4], b1s[C4];
+    __shared__ dfx_h8 wps[NT * KC * 2 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
-    for (int i = tid; i < 3 * C / 4; i += DFX_PW_THREADS) dws[i] = reinterpret_cast<const float4 *>(A.dw)[i];
-    dfx_h8 w0h[NT], w0l[NT], wph[NT][KC], wpl[NT][KC];
-    float4 bias0[NT], biasr[NT];
+    for (int i = tid; i < 3 * C4; i += DFX_PW_THREADS) dws[i] = reinterpret_cast<const float4 *>(A.dw)[i];
+    for (int i = tid; i < C4; i += DFX_PW_THREADS) {
+        b0s[i] = reinterpret_cast<const float4 *>(A.bias0)[i];
+        b1s[i] = reinterpret_cast<const float4 *>(A.bias)[i];
+    }
+    for (int i = tid; i < NT * KC * 2 * 64; i += DFX_PW_THREADS) wps[i] = A.wpf[i];
+    dfx_h8 w0h[NT], w0l[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         w0h[nt] = A.w0f[(nt * 2 + 0) * 64 + lane];
         w0l[nt] = A.w0f[(nt * 2 + 1) * 64 + lane];
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-            wph[nt][kc] = A.wpf[((nt * KC + kc) * 2 + 0) * 64 + lane];
-            wpl[nt][kc] = A.wpf[((nt * KC + kc) * 2 + 1) * 64 + lane];
-        }
-        bias0[nt] = reinterpret_cast<const float4 *>(A.bias0)[4 * nt + q];
-        biasr[nt] = reinterpret_cast<const float4 *>(A.bias)[4 * nt + q];
     }
     __syncthreads();
     const int64_t total = A.B * A.T * A.Fout;
@@ -495,70 +498,83 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 1) dfx_k_df_conv01_h3(DfxC01hA
     const int64_t tstep = (int64_t)gridDim.x * 4;
     float2 raw[3][4];
     bool okj[3];
-    auto issue = [&](int64_t tile) {  // feat_spec loads of one tile (three c0 positions per lane)
+    // position of this lane in a tile: (b, t, fo); patch j of the tile is requested with issue(j)
+    int64_t nb = 0, ntm = 0;
+    int nfo = 0;
+    bool nvalid = false;
+    auto locate = [&](int64_t tile) {
         const int64_t pos = tile * 16 + jl;
-        const bool valid = tile < ntiles && pos < total;
+        nvalid = tile < ntiles && pos < total;
         const int64_t r = pos / A.Fout;
-        const int fo = (int)(pos - r * A.Fout);
-        const int64_t b = r / A.T, t = r - b * A.T;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int fi = fo * A.stride + j - 1;
-            okj[j] = valid && fi >= 0 && fi < A.Fin;
-            dfx_c0_patch_load(A.feat, b, t, fi, okj[j], A.T, A.Fin, A.L, q, raw[j]);
-        }
+        nfo = (int)(pos - r * A.Fout);
+        nb = r / A.T;
+        ntm = r - nb * A.T;
+    };
+    auto issue = [&](int j) {
+        const int fi = nfo * A.stride + j - 1;
+        okj[j] = nvalid && fi >= 0 && fi < A.Fin;
+        dfx_c0_patch_load(A.feat, nb, ntm, fi, okj[j], A.T, A.Fin, A.L, q, raw[j]);
     };
     int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    issue(tile);
+    locate(tile);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) issue(j);
     for (; tile < ntiles; tile += tstep) {
         const int64_t pos = tile * 16 + jl;
         const bool valid = pos < total;
-        float2 cur[3][4];
-        bool okc[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            okc[j] = okj[j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) cur[j][i] = raw[j][i];
-        }
-        issue(tile + tstep);
+        locate(tile + tstep);
         float u[CPL];
 #pragma unroll
         for (int i = 0; i < CPL; ++i) u[i] = 0.f;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            float c0v[CPL];
-            dfx_c0_tile_h3<C>(w0h, w0l, bias0, A.unscale0, cur[j], okc[j], c0v);
+            float x[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[2 * i] = raw[j][i].x, x[2 * i + 1] = raw[j][i].y;
+            const bool keep = okj[j];
+            dfx_h8 ph, pl;
+            dfx_split8(x, ph, pl);
+            issue(j);  // raw[j] is free again: fetch the same patch of the next tile
+            f32x4 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(w0l[nt], ph, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(w0h[nt], pl, acc[nt]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(w0h[nt], ph, acc[nt]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const float4 w = dws[j * (C / 4) + 4 * nt + q];
-                u[4 * nt + 0] += w.x * c0v[4 * nt + 0];
-                u[4 * nt + 1] += w.y * c0v[4 * nt + 1];
-                u[4 * nt + 2] += w.z * c0v[4 * nt + 2];
-                u[4 * nt + 3] += w.w * c0v[4 * nt + 3];
+                const float4 bz = b0s[4 * nt + q], w = dws[j * C4 + 4 * nt + q];
+                u[4 * nt + 0] += w.x * (keep ? fmaxf(acc[nt][0] * A.unscale0 + bz.x, 0.f) : 0.f);
+                u[4 * nt + 1] += w.y * (keep ? fmaxf(acc[nt][1] * A.unscale0 + bz.y, 0.f) : 0.f);
+                u[4 * nt + 2] += w.z * (keep ? fmaxf(acc[nt][2] * A.unscale0 + bz.z, 0.f) : 0.f);
+                u[4 * nt + 3] += w.w * (keep ? fmaxf(acc[nt][3] * A.unscale0 + bz.w, 0.f) : 0.f);
             }
         }
         dfx_h8 uh[KC], ul[KC];
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) dfx_split8(u + 8 * kc, uh[kc], ul[kc]);
         float4 *op = reinterpret_cast<float4 *>(A.out + pos * C + 4 * q);
-        f32x4 acc[NT];
+        int zoff = 0;
+        DFX_OPAQUE(zoff);  // the fragment reads are loop invariant: keep the compiler from hoisting them into 64 registers
+        const dfx_h8 *wpl_ = wps + lane + zoff;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 aa = f32x4{0.f, 0.f, 0.f, 0.f}, ab = aa, ac = aa;  // independent chains per product term
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(wpl[nt][kc], uh[kc], acc[nt]);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(wph[nt][kc], ul[kc], acc[nt]);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(wph[nt][kc], uh[kc], acc[nt]);
-        }
-        if (valid) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                op[4 * nt] = make_float4(fmaxf(acc[nt][0] * A.unscale + biasr[nt].x, 0.f), fmaxf(acc[nt][1] * A.unscale + biasr[nt].y, 0.f),
-                                         fmaxf(acc[nt][2] * A.unscale + biasr[nt].z, 0.f), fmaxf(acc[nt][3] * A.unscale + biasr[nt].w, 0.f));
+            for (int kc = 0; kc < KC; ++kc) {
+                const dfx_h8 wh = wpl_[((nt * KC + kc) * 2 + 0) * 64], wl = wpl_[((nt * KC + kc) * 2 + 1) * 64];
+                aa = dfx_mfma_16x16x32_f16(wl, uh[kc], aa);
+                ab = dfx_mfma_16x16x32_f16(wh, ul[kc], ab);
+                ac = dfx_mfma_16x16x32_f16(wh, uh[kc], ac);
+            }
+            if (valid) {
+                const float4 bz = b1s[4 * nt + q];
+                op[4 * nt] = make_float4(fmaxf(((aa[0] + ab[0]) + ac[0]) * A.unscale + bz.x, 0.f),
+                                         fmaxf(((aa[1] + ab[1]) + ac[1]) * A.unscale + bz.y, 0.f),
+                                         fmaxf(((aa[2] + ab[2]) + ac[2]) * A.unscale + bz.z, 0.f),
+                                         fmaxf(((aa[3] + ab[3]) + ac[3]) * A.unscale + bz.w, 0.f));
+            }
         }
     }
 }
