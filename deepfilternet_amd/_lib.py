@@ -84,6 +84,14 @@ SIGNATURES = {
     "dfx_model_forward": (_i, [_vp, _vp, _fp, _fp, _fp, _i64, _i64, _f, _fp, _fp, _fp, _fp, _fp, _i64, _vp]),
     "dfx_enhance_workspace_bytes": (_i, [_vp, _vp, _i64, _i64, _i, C.POINTER(_i64)]),
     "dfx_enhance": (_i, [_vp, _vp, _fp, _i64, _i64, _i, _f, _fp, _fp, _i64, _vp]),
+    "dfx_stream_create": (_i, [_vp, _vp, _i64, _i, C.POINTER(_vp)]),
+    "dfx_stream_free": (None, [_vp]),
+    "dfx_stream_reset": (_i, [_vp, _vp]),
+    "dfx_stream_frame_length": (_i, [_vp]),
+    "dfx_stream_delay_frames": (_i, [_vp]),
+    "dfx_stream_set_atten_lim": (_i, [_vp, _f]),
+    "dfx_stream_set_post_filter_beta": (_i, [_vp, _f]),
+    "dfx_stream_process": (_i, [_vp, _fp, _i64, _fp, _fp, _vp]),
     "dfx_prof_kernel_count": (_i, []),
     "dfx_prof_kernel_name": (C.c_char_p, [_i]),
     "dfx_prof_enable": (_i, [C.c_uint32]),

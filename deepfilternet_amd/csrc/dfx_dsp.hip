@@ -475,12 +475,15 @@ int dfx_features_padded(const dfx_state *st, const float *x, int64_t B, int64_t 
 
 int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, const float *gains,
                         const dfx_bands *bands, int64_t B, int64_t T, int F, int nb_df, int order, int lookahead,
-                        float pf_beta, float atten_lim, float *out, hipStream_t s, int64_t t_begin = 0, int64_t t_end = -1);
+                        float pf_beta, float atten_lim, float *out, hipStream_t s, int64_t t_begin = 0, int64_t t_end = -1,
+                        int64_t coef_T = -1, int64_t out_T = -1, int64_t out_toff = 0);
 
-// frames [t_begin, t_end) of every clip (t_end < 0: T)
+// frames [t_begin, t_end) of every clip (t_end < 0: T); coef_T: frames per clip of the coefficient / gain arrays (default T);
+// out_T / out_toff: compacted output rows (default T / 0)
 int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, const float *gains,
                         const dfx_bands *bands, int64_t B, int64_t T, int F, int nb_df, int order, int lookahead,
-                        float pf_beta, float atten_lim, float *out, hipStream_t s, int64_t t_begin, int64_t t_end) {
+                        float pf_beta, float atten_lim, float *out, hipStream_t s, int64_t t_begin, int64_t t_end, int64_t coef_T,
+                        int64_t out_T, int64_t out_toff) {
     DfxDfaArgs A;
     A.spec = reinterpret_cast<const float2 *>(spec);
     A.coefs = reinterpret_cast<const float2 *>(coefs);
@@ -496,13 +499,17 @@ int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, 
     A.nb = (gains && bands) ? bands->nb : 0;
     if (!(gains && bands)) A.gains = nullptr;
     const int64_t nd = nb_df, O = order;
-    if (coef_layout == DFX_COEF_BOTF) {         // [B,O,T,nd]
-        A.cs_b = O * T * nd, A.cs_n = T * nd, A.cs_t = nd, A.cs_f = 1;
-    } else if (coef_layout == DFX_COEF_BTFO) {  // [B,T,nd,O]
-        A.cs_b = T * nd * O, A.cs_t = nd * O, A.cs_f = O, A.cs_n = 1;
-    } else {                                    // DFX_COEF_BTOF [B,T,O,nd]
-        A.cs_b = T * O * nd, A.cs_t = O * nd, A.cs_n = nd, A.cs_f = 1;
+    const int64_t Tc = coef_T < 0 ? T : coef_T;
+    if (coef_layout == DFX_COEF_BOTF) {         // [B,O,Tc,nd]
+        A.cs_b = O * Tc * nd, A.cs_n = Tc * nd, A.cs_t = nd, A.cs_f = 1;
+    } else if (coef_layout == DFX_COEF_BTFO) {  // [B,Tc,nd,O]
+        A.cs_b = Tc * nd * O, A.cs_t = nd * O, A.cs_f = O, A.cs_n = 1;
+    } else {                                    // DFX_COEF_BTOF [B,Tc,O,nd]
+        A.cs_b = Tc * O * nd, A.cs_t = O * nd, A.cs_n = nd, A.cs_f = 1;
     }
+    A.gT = Tc;
+    A.out_T = out_T < 0 ? T : out_T;
+    A.out_toff = out_toff;
     A.pf_beta = pf_beta;
     A.atten_lim = atten_lim;
     static int rows_sel = 0;

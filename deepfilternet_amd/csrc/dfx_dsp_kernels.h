@@ -460,6 +460,8 @@ struct DfxDfaArgs {
     float pf_beta, atten_lim;
     int chunks;           // row chunks per clip
     int t_begin, t_end;   // frames [t_begin, t_end) of every clip are produced by this launch
+    int64_t gT;           // frames per clip of the gains array (== T except for streaming windows, whose spec carries extra lookahead frames)
+    int64_t out_T, out_toff;  // frame t of clip b is stored at out[(b*out_T + t - out_toff)*F ...]  (== T, 0 unless compacted)
 };
 
 static __device__ __forceinline__ float2 dfx_dfa_finish(float2 y, float2 x, float pf_beta, float lim) {
@@ -528,7 +530,7 @@ __global__ void __launch_bounds__(DFX_DFA_THREADS) dfx_k_df_apply(DfxDfaArgs A) 
     off += ((size_t)ROWS * (A.nb > 0 ? A.nb : 1) * 4 + 15) & ~(size_t)15;
     unsigned char *b2b = smem + off;                                                 // [F]
     const float2 *spec_b = A.spec + b * A.T * F;
-    float2 *out_b = A.out + b * A.T * F;
+    float2 *out_b = A.out + (b * A.out_T - A.out_toff) * F;
     const float2 *coef_b = A.coefs + b * A.cs_b;
     const int tid = threadIdx.x;
     // ---- stage the deep filter's input window: every low bin of the chunk (+ order-1 halo frames) is read from HBM once
@@ -541,7 +543,7 @@ __global__ void __launch_bounds__(DFX_DFA_THREADS) dfx_k_df_apply(DfxDfaArgs A) 
         xs[i] = v;
     }
     if (A.gains) {
-        const float *gp = A.gains + (b * A.T + t0) * A.nb;
+        const float *gp = A.gains + (b * A.gT + t0) * A.nb;
         for (int i = tid; i < nt * A.nb; i += DFX_DFA_THREADS) gs[i] = gp[i];
         for (int i = tid; i < F; i += DFX_DFA_THREADS) b2b[i] = A.bin2band[i];
     } else {

@@ -8,7 +8,8 @@
 
 int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, const float *gains,
                         const dfx_bands *bands, int64_t B, int64_t T, int F, int nb_df, int order, int lookahead,
-                        float pf_beta, float atten_lim, float *out, hipStream_t s, int64_t t_begin = 0, int64_t t_end = -1);
+                        float pf_beta, float atten_lim, float *out, hipStream_t s, int64_t t_begin = 0, int64_t t_end = -1,
+                        int64_t coef_T = -1, int64_t out_T = -1, int64_t out_toff = 0);
 
 // ------------------------------------------------------------------------------------------------ cfg validation
 static int check_cfg(const dfx_model_cfg *c) {
@@ -104,6 +105,18 @@ struct DfxFinish {
     const dfx_state *st;
     float *y;
     int64_t out_stride, out_skip, out_len;
+};
+// Streaming (dfx_stream_process): a forward pass over a window.  Every feature / activation array holds T = H + n frames per clip
+// (H history frames, then the n new ones); only the new frames are computed (kernels take t_begin, per-frame kernels a DfxRowMap),
+// the GRUs continue from h_state, the spec array has spec_T = T + lookahead frames and the enhanced spectra are stored compactly.
+struct DfxStreamCtx {
+    int64_t H;         // history frames in front of the new ones
+    int64_t t_zero;    // local frames < t_zero precede the start of the stream (df_convp sees zero padding there)
+    int64_t spec_T;    // frames per clip of the spec array
+    float *h_state;    // [GRU layers][B][256], in model order enc, erb_dec, df_dec
+    float pf_beta;     // < 0: the model's setting
+    float *out;        // [B, out_T, F][2]: local frame t of clip b is stored at frame t - out_toff
+    int64_t out_T, out_toff;
 };
 enum { EV_START = 0, EV_C0, EV_C1, EV_C0P, EV_EMB, EV_COEFS, EV_FRONT, EV_DONE, EV_XA, EV_MASK, EV_LSNR, EV_FIN };
 
@@ -743,13 +756,15 @@ static int launch_pw(int mode, const dfx_model *m, const PwW &w, const float *x,
 
 template <int C, int KT>
 static int launch_convp2(const dfx_model *m, const float *c0, const float *feat_spec, float *out, int64_t B, int64_t T, int Fd,
-                         int NO, hipStream_t s) {
+                         int NO, hipStream_t s, int64_t t_begin = 0, int64_t t_zero = 0, int L = -1) {
     DfxCp2Args A;
     A.c0 = c0;
     A.feat = feat_spec;  // non-null: df_conv0 is recomputed on the fly, c0 is not read
     A.weff0 = m->p(m->cin_weff);
     A.bias0 = m->p(m->cin_b);
-    A.L = m->cfg.conv_lookahead;
+    A.L = L < 0 ? m->cfg.conv_lookahead : L;
+    A.t_begin = t_begin;
+    A.t_zero = t_zero;
     A.weff = m->p(m->cp_weff);
     A.bias = m->p(m->cp_b16);
     A.out = out;
@@ -761,12 +776,13 @@ static int launch_convp2(const dfx_model *m, const float *c0, const float *feat_
     // enough independent wave-runs to fill the chip (each run re-reads KT-1 halo frames): target >= 8 waves per SIMD-slot
     const int64_t want = (int64_t)dfx_env_num_cus() * 4 * 8;
     int64_t nseg = dfx_ceil_div(want, B * A.nfb);
-    const int64_t max_seg = dfx_ceil_div(T, (int64_t)8 * KT);
+    const int64_t Tn = T - t_begin;  // frames produced
+    const int64_t max_seg = dfx_ceil_div(Tn, (int64_t)8 * KT);
     if (nseg > max_seg) nseg = max_seg;
     if (nseg < 1) nseg = 1;
-    int64_t tseg = dfx_ceil_div(dfx_ceil_div(T, nseg), (int64_t)KT) * KT;
+    int64_t tseg = dfx_ceil_div(dfx_ceil_div(Tn, nseg), (int64_t)KT) * KT;
     A.tseg = (int)tseg;
-    A.nseg = (int)dfx_ceil_div(T, tseg);
+    A.nseg = (int)dfx_ceil_div(Tn, tseg);
     const int64_t nruns = B * A.nfb * A.nseg;
     const int grid = nn_grid(dfx_ceil_div(nruns, 4), 8);
     DfxKScope ks(DFX_K_DF_CONVP, s);
@@ -778,7 +794,7 @@ static int launch_convp2(const dfx_model *m, const float *c0, const float *feat_
 
 template <int C, int KT>
 static int launch_convp_h3(const dfx_model *m, const float *feat_spec, float *out, int64_t B, int64_t T, int Fd, int NO,
-                           hipStream_t s) {
+                           hipStream_t s, int64_t t_begin = 0, int64_t t_zero = 0, int L = -1) {
     if constexpr (C % 32 != 0) {
         DFX_FAIL(DFX_ERR_UNSUPPORTED, "fp16-split df_convp needs conv_ch %% 32 == 0");
     } else {
@@ -793,18 +809,21 @@ static int launch_convp_h3(const dfx_model *m, const float *feat_spec, float *ou
         A.T = T;
         A.Fd = Fd;
         A.NO = NO;
-        A.L = m->cfg.conv_lookahead;
+        A.L = L < 0 ? m->cfg.conv_lookahead : L;
+        A.t_begin = t_begin;
+        A.t_zero = t_zero;
         A.unscale0 = m->c0_unscale;
         A.unscale = m->cp_unscale;
         A.nfb = (Fd + 15) / 16;
         const int64_t want = (int64_t)dfx_env_num_cus() * 4 * 4;  // two resident waves per SIMD, two rounds
         int64_t nseg = dfx_ceil_div(want, B * A.nfb);
-        const int64_t max_seg = dfx_ceil_div(T, (int64_t)8 * KT);
+        const int64_t Tn = T - t_begin;  // frames produced
+        const int64_t max_seg = dfx_ceil_div(Tn, (int64_t)8 * KT);
         if (nseg > max_seg) nseg = max_seg;
         if (nseg < 1) nseg = 1;
-        const int64_t tseg = dfx_ceil_div(dfx_ceil_div(T, nseg), (int64_t)KT) * KT;
+        const int64_t tseg = dfx_ceil_div(dfx_ceil_div(Tn, nseg), (int64_t)KT) * KT;
         A.tseg = (int)tseg;
-        A.nseg = (int)dfx_ceil_div(T, tseg);
+        A.nseg = (int)dfx_ceil_div(Tn, tseg);
         const int64_t nruns = B * A.nfb * A.nseg;
         const int grid = nn_grid(dfx_ceil_div(nruns, 4), 2);
         DfxKScope ks(DFX_K_DF_CONVP, s);
@@ -816,7 +835,7 @@ static int launch_convp_h3(const dfx_model *m, const float *feat_spec, float *ou
 
 template <int C>
 static int launch_conv01_h3(const dfx_model *m, const PwW &w, const float *feat_spec, float *out, int64_t B, int64_t T, int Fin,
-                            int Fout, int stride, hipStream_t s) {
+                            int Fout, int stride, hipStream_t s, int64_t t_begin = 0, int L = -1) {
     if constexpr (C % 32 != 0) {
         DFX_FAIL(DFX_ERR_UNSUPPORTED, "fp16-split df_conv1 needs conv_ch %% 32 == 0");
     } else {
@@ -833,10 +852,11 @@ static int launch_conv01_h3(const dfx_model *m, const PwW &w, const float *feat_
         A.Fin = Fin;
         A.Fout = Fout;
         A.stride = stride;
-        A.L = m->cfg.conv_lookahead;
+        A.L = L < 0 ? m->cfg.conv_lookahead : L;
+        A.t_begin = t_begin;
         A.unscale0 = m->c0_unscale;
         A.unscale = m->dfc1_unscale;
-        const int grid = nn_grid(dfx_ceil_div(B * T * Fout, 64), 3);
+        const int grid = nn_grid(dfx_ceil_div(B * (T - t_begin) * Fout, 64), 3);
         DfxKScope ks(DFX_K_PWCONV, s);
         dfx_launch(dfx_k_df_conv01_h3<C>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
         DFX_LAUNCH_CHECK();
@@ -874,7 +894,8 @@ static int launch_erb_dec10(const dfx_model *m, const float *d2, const float *e1
 }
 
 template <int C>
-static int launch_erb_enc(const dfx_model *m, const float *feat_erb, float *e0, float *e1, int64_t B, int64_t T, hipStream_t s) {
+static int launch_erb_enc(const dfx_model *m, const float *feat_erb, float *e0, float *e1, int64_t B, int64_t T, hipStream_t s,
+                          int64_t t_begin = 0, int L = -1) {
     const dfx_model_cfg &c = m->cfg;
     DfxEncArgs A;
     A.feat = feat_erb;
@@ -888,11 +909,12 @@ static int launch_erb_enc(const dfx_model *m, const float *feat_erb, float *e0, 
     A.B = B;
     A.T = T;
     A.E = c.nb_erb;
-    A.L = c.conv_lookahead;
+    A.L = L < 0 ? c.conv_lookahead : L;
+    A.t_begin = t_begin;
     const size_t smem = DFX_ENC_SMEM(C, c.nb_erb);
     DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_erb_enc<C>, smem));
     DfxKScope ks(DFX_K_ERB_ENC, s);
-    dfx_launch(dfx_k_erb_enc<C>, dim3((unsigned)nn_grid(dfx_ceil_div(B * T, 4), 2)), dim3(256), smem, s, A);
+    dfx_launch(dfx_k_erb_enc<C>, dim3((unsigned)nn_grid(dfx_ceil_div(B * (T - t_begin), 4), 2)), dim3(256), smem, s, A);
     DFX_LAUNCH_CHECK();
     return DFX_OK;
 }
@@ -900,7 +922,7 @@ static int launch_erb_enc(const dfx_model *m, const float *feat_erb, float *e0, 
 // enc.df_conv0 -> enc.df_conv1 without the c0 round trip (dfx_k_df_conv01)
 template <int C>
 static int launch_conv01(const dfx_model *m, const PwW &w, const float *feat_spec, float *out, int64_t B, int64_t T, int Fin,
-                         int Fout, int stride, hipStream_t s) {
+                         int Fout, int stride, hipStream_t s, int64_t t_begin = 0, int L = -1) {
     DfxC01Args A;
     A.feat = feat_spec;
     A.weff0 = m->p(m->cin_weff);
@@ -914,8 +936,9 @@ static int launch_conv01(const dfx_model *m, const PwW &w, const float *feat_spe
     A.Fin = Fin;
     A.Fout = Fout;
     A.stride = stride;
-    A.L = m->cfg.conv_lookahead;
-    const int grid = nn_grid(dfx_ceil_div(B * T * Fout, 64), 8);
+    A.L = L < 0 ? m->cfg.conv_lookahead : L;
+    A.t_begin = t_begin;
+    const int grid = nn_grid(dfx_ceil_div(B * (T - t_begin) * Fout, 64), 8);
     DfxKScope ks(DFX_K_PWCONV, s);
     dfx_launch(dfx_k_df_conv01<C>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
     DFX_LAUNCH_CHECK();
@@ -1067,9 +1090,12 @@ static int launch_gru_h3(const dfx_model *m, const GruW &g, const float *gi, flo
 
 // SqueezedGRU_S without its linear_in/linear_out (modules.py:702-738): layers of (input projection GEMM, recurrence).
 // x: [R,256] input; result pointer returned through *y (ping-pong between xa/xb).
+// hstate != null (streaming): layer l continues from / leaves its state in hstate + l*B*256 and only the frames [t0, T) are run
 static int run_gru_stack(const dfx_model *m, const std::vector<GruW> &layers, const float *x, float *bufa, float *bufb,
-                         float *gi, int64_t B, int64_t T, const float **y, hipStream_t s) {
-    const int64_t R = B * T;
+                         float *gi, int64_t B, int64_t T, const float **y, hipStream_t s, float *hstate = nullptr, int64_t t0 = 0,
+                         DfxRowMap rm = DfxRowMap{0, 0, 0}) {
+    const int64_t R = B * (T - t0);
+    if (hstate && m->exact_fp32) DFX_FAIL(DFX_ERR_UNSUPPORTED, "streaming needs the fp16-split GRU kernels (unset DFX_EXACT_FP32)");
     const float *in = x;
     float *outb = (x == bufa) ? bufb : bufa;
     for (size_t l = 0; l < layers.size(); ++l) {
@@ -1077,7 +1103,7 @@ static int run_gru_stack(const dfx_model *m, const std::vector<GruW> &layers, co
         if (m->exact_fp32) {
             if (int rc = launch_proj(in, m->p(g.wih_t), m->p(g.bias_i), gi, R, 768, s)) return rc;
         } else {
-            if (int rc = launch_proj_h3(m, g, in, gi, R, 768, s)) return rc;
+            if (int rc = launch_proj_h3(m, g, in, gi, R, 768, s, rm)) return rc;
         }
         if (m->exact_fp32) {
             DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_rec, DFX_GRU_SMEM));
@@ -1087,7 +1113,8 @@ static int run_gru_stack(const dfx_model *m, const std::vector<GruW> &layers, co
                        (float *)nullptr, outb, B, T);
             DFX_LAUNCH_CHECK();
         } else {
-            if (int rc = launch_gru_h3(m, g, gi, outb, nullptr, nullptr, B, T, 0, T, s)) return rc;
+            float *hl = hstate ? hstate + l * B * 256 : nullptr;
+            if (int rc = launch_gru_h3(m, g, gi, outb, hl, hl, B, T, t0, T, s)) return rc;
         }
         in = outb;
         outb = (outb == bufa) ? bufb : bufa;
@@ -1100,9 +1127,15 @@ template <int C>
 static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float *spec, const float *feat_erb,
                         const float *feat_spec, int64_t B, int64_t T, float atten_lim, float *spec_e, float *mask_out,
                         float *lsnr_out, float *coefs_out, float *ws, hipStream_t s, const DfxLane *ln, bool signal_front,
-                        const DfxFinish *fin) {
+                        const DfxFinish *fin, const DfxStreamCtx *sc = nullptr) {
     const dfx_model_cfg &c = m->cfg;
     const int64_t R = B * T;
+    // streaming window (sc): the arrays hold T = H + n frames per clip, only the n new ones are computed; per-frame kernels reach
+    // their rows through rmw, the lookahead shift is already in the feature stream (kernel lookahead 0)
+    const int64_t t_begin = sc ? sc->H : 0, Rn = B * (T - t_begin);
+    const DfxRowMap rmw = sc ? DfxRowMap{T, T - t_begin, t_begin} : DfxRowMap{0, 0, 0};
+    const int Lk = sc ? 0 : c.conv_lookahead;
+    const int64_t t_zero = sc ? sc->t_zero : 0;
     const Ws w = plan_ws(c, m->fuse_c0, R, B);
     const int E = c.nb_erb, Fd = c.nb_df, O = c.df_order, NO = 2 * O, emb = C * E / 4, L = c.conv_lookahead;
     float *e0 = ws + w.e0, *e1 = ws + w.e1, *e2 = ws + w.e2, *e3 = ws + w.e3, *c0 = ws + w.c0, *c1 = ws + w.c1;
@@ -1132,12 +1165,13 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     // ---- Encoder, DF branch on x1 (deepfilternet3.py:176-179).  By default c0 = df_conv0(feat_spec) never exists in HBM: its two
     // consumers (df_conv1 here, df_convp below) recompute the tiles they need from feat_spec on the matrix core.
     const bool fuse_c0 = m->fuse_c0;
+    if (sc && !fuse_c0) DFX_FAIL(DFX_ERR_UNSUPPORTED, "streaming needs the fused DF encoder (df_pathway_kernel_size_t <= 5, DFX_FUSE_C0 unset)");
     const float *cp_feat = fuse_c0 ? feat_spec : nullptr;
     const bool fuse_h3 = fuse_c0 && !m->exact_fp32 && C % 32 == 0 && m->cp_h3;  // fp16-split matrix ops (default)
     if (fuse_c0) {
         if ((rc = signal(EV_C0, x1)) || (rc = wait(EV_C0, x2))) return rc;  // df_convp only needs feat_spec
-        if (fuse_h3) rc = launch_conv01_h3<C>(m, m->dfc1, feat_spec, c1, B, T, Fd, Fd / 2, 2, x1);
-        else rc = launch_conv01<C>(m, m->dfc1, feat_spec, c1, B, T, Fd, Fd / 2, 2, x1);
+        if (fuse_h3) rc = launch_conv01_h3<C>(m, m->dfc1, feat_spec, c1, B, T, Fd, Fd / 2, 2, x1, t_begin, Lk);
+        else rc = launch_conv01<C>(m, m->dfc1, feat_spec, c1, B, T, Fd, Fd / 2, 2, x1, t_begin, Lk);
         if (rc) return rc;
     } else {
         DfxCinArgs A;
@@ -1160,20 +1194,20 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // ---- df_dec.df_convp on x2 (only needs c0; :328)
         if (fuse_h3) {
             switch (c.df_pathway_kernel_size_t) {
-                case 1: rc = launch_convp_h3<C, 1>(m, feat_spec, c0p, B, T, Fd, NO, x2); break;
-                case 2: rc = launch_convp_h3<C, 2>(m, feat_spec, c0p, B, T, Fd, NO, x2); break;
-                case 3: rc = launch_convp_h3<C, 3>(m, feat_spec, c0p, B, T, Fd, NO, x2); break;
-                case 4: rc = launch_convp_h3<C, 4>(m, feat_spec, c0p, B, T, Fd, NO, x2); break;
-                default: rc = launch_convp_h3<C, 5>(m, feat_spec, c0p, B, T, Fd, NO, x2); break;
+                case 1: rc = launch_convp_h3<C, 1>(m, feat_spec, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
+                case 2: rc = launch_convp_h3<C, 2>(m, feat_spec, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
+                case 3: rc = launch_convp_h3<C, 3>(m, feat_spec, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
+                case 4: rc = launch_convp_h3<C, 4>(m, feat_spec, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
+                default: rc = launch_convp_h3<C, 5>(m, feat_spec, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
             }
             if (rc) return rc;
         } else if (c.df_pathway_kernel_size_t <= 5) {
             switch (c.df_pathway_kernel_size_t) {
-                case 1: rc = launch_convp2<C, 1>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2); break;
-                case 2: rc = launch_convp2<C, 2>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2); break;
-                case 3: rc = launch_convp2<C, 3>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2); break;
-                case 4: rc = launch_convp2<C, 4>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2); break;
-                default: rc = launch_convp2<C, 5>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2); break;
+                case 1: rc = launch_convp2<C, 1>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
+                case 2: rc = launch_convp2<C, 2>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
+                case 3: rc = launch_convp2<C, 3>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
+                case 4: rc = launch_convp2<C, 4>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
+                default: rc = launch_convp2<C, 5>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
             }
             if (rc) return rc;
         } else {
@@ -1211,8 +1245,9 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     // ---- Encoder, ERB branch on s (:168-171)
     const bool fuse_dec = E % 2 == 0 && m->fuse_erb && 2 * DFX_DEC10_SMEM(C, E) <= (size_t)160 * 1024;
     const bool fuse_enc = E % 2 == 0 && 3 * (E + 2) <= 192 && m->fuse_erb && 2 * DFX_ENC_SMEM(C, E) <= (size_t)160 * 1024;
+    if (sc && !fuse_enc) DFX_FAIL(DFX_ERR_UNSUPPORTED, "streaming needs the fused ERB encoder head (DFX_FUSE_ERB unset)");
     if (fuse_enc) {
-        if ((rc = launch_erb_enc<C>(m, feat_erb, e0, e1, B, T, s))) return rc;
+        if ((rc = launch_erb_enc<C>(m, feat_erb, e0, e1, B, T, s, t_begin, Lk))) return rc;
     } else {
         {
             const int64_t total = R * E * (C / 4);
@@ -1223,13 +1258,13 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         }
         if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb1, e0, nullptr, e1, R, E, E / 2, 2, s))) return rc;
     }
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb2, e1, nullptr, e2, R, E / 2, E / 4, 2, s))) return rc;
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb3, e2, nullptr, e3, R, E / 4, E / 4, 1, s))) return rc;
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb2, e1, nullptr, e2, Rn, E / 2, E / 4, 2, s, rmw))) return rc;
+    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb3, e2, nullptr, e3, Rn, E / 4, E / 4, 1, s, rmw))) return rc;
     if ((rc = wait(EV_C1, s))) return rc;
     // cemb = relu(df_fc_emb(c1.flatten)); emb_in = e3.flatten + cemb   (:179-182)
-    if ((rc = launch_glin(m, m->fc_emb, c1, DFX_ACT_RELU, e3, emb_in, R, s))) return rc;
+    if ((rc = launch_glin(m, m->fc_emb, c1, DFX_ACT_RELU, e3, emb_in, Rn, s, rmw))) return rc;
     // enc.emb_gru (SqueezedGRU_S :149-158)
-    if ((rc = launch_glin(m, m->enc_in, emb_in, DFX_ACT_RELU, nullptr, xa, R, s))) return rc;
+    if ((rc = launch_glin(m, m->enc_in, emb_in, DFX_ACT_RELU, nullptr, xa, Rn, s, rmw))) return rc;
     // the chip-filling front of this chunk is enqueued: the next chunk of a pipelined dfx_enhance may start its own front
     // (it then overlaps this chunk's GRU chain, which occupies only a few CUs)
     if (signal_front && (rc = signal(EV_FRONT, s))) return rc;
@@ -1243,11 +1278,13 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     int K = m->tchunks;
     if (T / K < m->tchunk_min) K = (int)(T / m->tchunk_min);
     const int nenc = (int)m->enc_gru.size(), ndec = (int)m->dec_gru.size(), ndf = (int)m->df_gru.size();
-    const bool pipe = par && !m->exact_fp32 && K > 1 && nenc == 1 && 1 + ndec + ndf <= DFX_MAX_GRU_LAYERS && ln == &m->lanes[0];
+    const bool pipe = par && !sc && !m->exact_fp32 && K > 1 && nenc == 1 && 1 + ndec + ndf <= DFX_MAX_GRU_LAYERS && ln == &m->lanes[0];
+    float *hs_enc = sc ? sc->h_state : nullptr, *hs_dec = sc ? sc->h_state + (int64_t)nenc * B * 256 : nullptr;
+    float *hs_df = sc ? sc->h_state + (int64_t)(nenc + ndec) * B * 256 : nullptr;
     if (!pipe) {
         const float *y = nullptr;
-        if ((rc = run_gru_stack(m, m->enc_gru, xa, xa, xb, gi, B, T, &y, s))) return rc;
-        if ((rc = launch_glin(m, m->enc_out, y, DFX_ACT_RELU, nullptr, embv, R, s))) return rc;
+        if ((rc = run_gru_stack(m, m->enc_gru, xa, xa, xb, gi, B, T, &y, s, hs_enc, t_begin, rmw))) return rc;
+        if ((rc = launch_glin(m, m->enc_out, y, DFX_ACT_RELU, nullptr, embv, Rn, s, rmw))) return rc;
         if ((rc = signal(EV_EMB, s)) || (rc = wait(EV_EMB, x1))) return rc;
         {
             DfxKScope ks(DFX_K_LSNR, s);
@@ -1258,11 +1295,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // ---- DfDecoder on x1 (:323-331)
         {
             const float *y2 = nullptr;
-            if ((rc = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, R, x1))) return rc;
-            if ((rc = run_gru_stack(m, m->df_gru, xa2, xa2, xb2, gi2, B, T, &y2, x1))) return rc;
+            if ((rc = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, Rn, x1, rmw))) return rc;
+            if ((rc = run_gru_stack(m, m->df_gru, xa2, xa2, xb2, gi2, B, T, &y2, x1, hs_df, t_begin, rmw))) return rc;
             const float *cfeat = y2;
             if (c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) {
-                if ((rc = launch_glin(m, m->df_skip, embv, DFX_ACT_NONE, y2, xdf, R, x1))) return rc;
+                if ((rc = launch_glin(m, m->df_skip, embv, DFX_ACT_NONE, y2, xdf, Rn, x1, rmw))) return rc;
                 cfeat = xdf;
             } else if (c.df_gru_skip == DFX_SKIP_IDENTITY) {
                 DfxKScope ks(DFX_K_ADD, x1);
@@ -1276,26 +1313,26 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             // tap-major, [B,O,T,F'][2] (DFX_COEF_BOTF == the reference's DfOutputReshapeMF layout), so the deep-filter kernel
             // reads coefficients coalesced over f
             if ((rc = launch_ggemm(cfeat, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg, m->df_out.Ng,
-                                   nullptr, DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, R, x1, NO, Fd, T)))
+                                   nullptr, DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, Rn, x1, NO, Fd, T, rmw)))
                 return rc;
             if ((rc = signal(EV_COEFS, x1))) return rc;
         }
         // ---- ErbDecoder on s (:245-254)
-        if ((rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, xa, R, s))) return rc;
-        if ((rc = run_gru_stack(m, m->dec_gru, xa, xa, xb, gi, B, T, &y, s))) return rc;
-        if ((rc = launch_glin(m, m->dec_out, y, DFX_ACT_RELU, nullptr, demb, R, s))) return rc;
-        if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, R, E / 4, E / 4, 1, s))) return rc;
-        if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, R, E / 4, E / 2, 2, s))) return rc;
+        if ((rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, xa, Rn, s, rmw))) return rc;
+        if ((rc = run_gru_stack(m, m->dec_gru, xa, xa, xb, gi, B, T, &y, s, hs_dec, t_begin, rmw))) return rc;
+        if ((rc = launch_glin(m, m->dec_out, y, DFX_ACT_RELU, nullptr, demb, Rn, s, rmw))) return rc;
+        if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, Rn, E / 4, E / 4, 1, s, rmw))) return rc;
+        if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, Rn, E / 4, E / 2, 2, s, rmw))) return rc;
         if (fuse_dec) {
-            if ((rc = launch_erb_dec10<C>(m, d2, e1, e0, mask, R, E, s, DfxRowMap{0, 0, 0}))) return rc;
+            if ((rc = launch_erb_dec10<C>(m, d2, e1, e0, mask, Rn, E, s, rmw))) return rc;
         } else {
-            if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, R, E / 2, E, 2, s))) return rc;
+            if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, Rn, E / 2, E, 2, s, rmw))) return rc;
             const int fpt = 64 / E > 0 ? 64 / E : 1;
             const size_t smem = ((size_t)fpt * E * (C + 1) + (size_t)fpt * E * 3 + 3 * C) * sizeof(float);
             DfxKScope ks(DFX_K_CONV_OUT, s);
-            dfx_launch(dfx_k_conv_out<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R, fpt), 8)), dim3(DFX_CO_THREADS), smem, s,
+            dfx_launch(dfx_k_conv_out<C>, dim3((unsigned)nn_grid(dfx_ceil_div(Rn, fpt), 8)), dim3(DFX_CO_THREADS), smem, s,
                        (const float *)d1, (const float *)e0, m->p(m->co_ska), m->p(m->co_skb), m->p(m->co_w), m->co_bias, mask,
-                       R, E, fpt, DfxRowMap{0, 0, 0});
+                       Rn, E, fpt, rmw);
             DFX_LAUNCH_CHECK();
         }
     } else {
@@ -1479,6 +1516,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     }
     if ((rc = wait(EV_COEFS, s))) return rc;
     // ---- Mask + MF.DF + combine + post filter + atten_lim (:426-454, enhance.py:238-240)
+    if (sc) {  // spec has sc->spec_T frames per clip, coefficients / gains T; the n enhanced frames are stored compactly
+        const float beta = sc->pf_beta >= 0.f ? sc->pf_beta : (c.mask_pf ? c.pf_beta : 0.f);
+        return dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, sc->spec_T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead, beta,
+                                   atten_lim, sc->out, s, t_begin, T, T, sc->out_T, sc->out_toff);
+    }
     if ((rc = dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead,
                                   c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, s)))
         return rc;
@@ -1556,6 +1598,220 @@ __global__ void dfx_k_copy_rows(const float *src, int64_t src_stride, int64_t sr
         const int64_t sj = j + src_off;
         dst[b * dst_stride + j] = sj < src_len ? src[b * src_stride + sj] : 0.f;
     }
+}
+
+// ------------------------------------------------------------------------------------------------ streaming (dfx_stream_*)
+// Frame loop of DfTract::process (tract.rs:509-642) for many lockstep streams: every call runs the batch kernels on a window of
+// H history + n new frames per stream (DfxStreamCtx), with all recurrent state carried in the handle.
+struct dfx_stream_state {
+    const dfx_model *m = nullptr;
+    const dfx_state *st = nullptr;
+    int64_t B = 0;
+    int nmax = 0, H = 0, L = 0, layers = 0;
+    int64_t frames = 0;       // hops consumed since the last reset
+    float lim = 0.f;          // linear attenuation limit: 0 = off, 1 = bypass (tract.rs:387-398)
+    float pf_beta = -1.f;     // < 0: the model's setting
+    unsigned char *buf = nullptr;
+    size_t bytes = 0;
+    // byte offsets into buf
+    size_t ana_mem[2], syn_mem[2], erb_state, unit_state, hist_fe, hist_fs, hist_spec, new_spec, new_fe, new_fs, work_fe, work_fs,
+        work_spec, out_spec, h_state, lsnr, model_ws;
+    int64_t model_ws_bytes = 0;
+    int flip = 0;             // which of the double-buffered STFT memories is current
+};
+
+static int stream_copy_rows(const float *src, int64_t src_stride, int64_t src_len, int64_t src_off, float *dst, int64_t dst_stride,
+                            int64_t dst_len, int64_t B, hipStream_t s) {
+    if (B <= 0 || dst_len <= 0) return DFX_OK;
+    DfxKScope ks(DFX_K_COPY_ROWS, s);
+    dfx_launch(dfx_k_copy_rows, dim3((unsigned)nn_grid(dfx_ceil_div(B * dst_len, 256), 16)), dim3(256), 0, s, src, src_stride, src_len,
+               src_off, dst, dst_stride, dst_len, B);
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
+}
+
+extern "C" int dfx_stream_create(const dfx_model *m, const dfx_state *st, int64_t streams, int max_frames, dfx_stream_state **out) {
+    if (!m || !st || !out || streams <= 0 || max_frames <= 0) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_stream_create: bad arguments");
+    const dfx_model_cfg &c = m->cfg;
+    if (st->N != c.fft_size || st->hop != c.hop_size || st->nb != c.nb_erb)
+        DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_stream_create: the DF state does not match the model (fft/hop/nb_erb)");
+    if (c.conv_lookahead != c.df_lookahead)
+        DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_stream_create: conv_lookahead != df_lookahead is not supported by the streaming path");
+    if (!m->fuse_c0 || !m->fuse_erb || m->exact_fp32)
+        DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_stream_create: streaming needs the default (fused, fp16-split) engine configuration");
+    if (int rc = dfx_require_device()) return rc;
+    dfx_stream_state *s = new dfx_stream_state();
+    s->m = m;
+    s->st = st;
+    s->B = streams;
+    s->nmax = max_frames;
+    s->L = c.df_lookahead;
+    // history in front of the new frames: 2 frames for the 3-tap input convolutions + kt-1 frames of (recomputed) c0 for df_convp
+    const int hist_conv = 2 + (c.df_pathway_kernel_size_t - 1), hist_df = c.df_order - 1 - c.df_lookahead;
+    s->H = hist_conv > hist_df ? hist_conv : hist_df;
+    s->layers = c.emb_num_layers + (c.emb_num_layers - 1) + c.df_num_layers;
+    s->layers = (int)(m->enc_gru.size() + m->dec_gru.size() + m->df_gru.size());
+    const int64_t B = streams, n = max_frames, H = s->H, Hs = s->H + s->L, F = st->N / 2 + 1, E = c.nb_erb, Fd = c.nb_df, ML = st->N - st->hop;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    for (int i = 0; i < 2; ++i) s->ana_mem[i] = take((size_t)B * ML * 4), s->syn_mem[i] = take((size_t)B * ML * 4);
+    s->erb_state = take((size_t)B * E * 4);
+    s->unit_state = take((size_t)B * Fd * 4);
+    s->hist_fe = take((size_t)B * H * E * 4);
+    s->hist_fs = take((size_t)B * H * Fd * 8);
+    s->hist_spec = take((size_t)B * Hs * F * 8);
+    s->new_spec = take((size_t)B * n * F * 8);
+    s->new_fe = take((size_t)B * n * E * 4);
+    s->new_fs = take((size_t)B * n * Fd * 8);
+    s->work_fe = take((size_t)B * (H + n) * E * 4);
+    s->work_fs = take((size_t)B * (H + n) * Fd * 8);
+    s->work_spec = take((size_t)B * (Hs + n) * F * 8);
+    s->out_spec = take((size_t)B * n * F * 8);
+    s->h_state = take((size_t)s->layers * B * 256 * 4);
+    s->lsnr = take((size_t)B * (H + n) * 4);
+    dfx_model_workspace_bytes(m, B, H + n, &s->model_ws_bytes);
+    s->model_ws = take((size_t)s->model_ws_bytes);
+    s->bytes = off;
+    if (hipMalloc(reinterpret_cast<void **>(&s->buf), s->bytes) != hipSuccess) {
+        delete s;
+        DFX_FAIL(DFX_ERR_ALLOC, "dfx_stream_create: device allocation of %zu bytes failed", off);
+    }
+    if (int rc = dfx_stream_reset(s, nullptr)) {
+        dfx_stream_free(s);
+        return rc;
+    }
+    *out = s;
+    return DFX_OK;
+}
+
+extern "C" void dfx_stream_free(dfx_stream_state *s) {
+    if (!s) return;
+    if (s->buf) (void)hipFree(s->buf);
+    delete s;
+}
+
+extern "C" int dfx_stream_reset(dfx_stream_state *s, void *stream) {
+    if (!s) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_stream_reset: null handle");
+    hipStream_t hs = dfx_stream(stream);
+    DFX_HIP(hipMemsetAsync(s->buf, 0, s->model_ws, hs));  // every state and history buffer (all of buf but the model workspace)
+    // running means start like a fresh erb_norm / unit_norm (lib.rs:12-13, transforms.rs:308-318,339-349): the same expressions as
+    // dfx_k_norm_scan evaluates when it is given no state
+    const dfx_model_cfg &c = s->m->cfg;
+    const int E = c.nb_erb, Fd = c.nb_df;
+    std::vector<float> es((size_t)s->B * E), us((size_t)s->B * Fd);
+    for (int ch = 0; ch < E; ++ch) {
+        volatile float step = E > 1 ? (-90.f - -60.f) / (float)(E - 1) : 0.f;
+        volatile float prod = step * (float)ch;
+        const float v = -60.f + prod;
+        for (int64_t b = 0; b < s->B; ++b) es[(size_t)b * E + ch] = v;
+    }
+    for (int ch = 0; ch < Fd; ++ch) {
+        volatile float step = Fd > 1 ? (0.0001f - 0.001f) / (float)(Fd - 1) : 0.f;
+        volatile float prod = step * (float)ch;
+        const float v = 0.001f + prod;
+        for (int64_t b = 0; b < s->B; ++b) us[(size_t)b * Fd + ch] = v;
+    }
+    DFX_HIP(hipStreamSynchronize(hs));
+    DFX_HIP(hipMemcpy(s->buf + s->erb_state, es.data(), es.size() * 4, hipMemcpyHostToDevice));
+    DFX_HIP(hipMemcpy(s->buf + s->unit_state, us.data(), us.size() * 4, hipMemcpyHostToDevice));
+    s->frames = 0;
+    s->flip = 0;
+    return DFX_OK;
+}
+
+extern "C" int dfx_stream_frame_length(const dfx_stream_state *s) { return s ? s->st->hop : 0; }
+extern "C" int dfx_stream_delay_frames(const dfx_stream_state *s) { return s ? s->L : 0; }
+
+extern "C" int dfx_stream_set_atten_lim(dfx_stream_state *s, float lim_db) {
+    if (!s) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_stream_set_atten_lim: null handle");
+    const float lim = fabsf(lim_db);  // tract.rs:387-398
+    if (lim >= 100.f) s->lim = 0.f;
+    else if (lim < 0.01f) s->lim = 1.f;
+    else s->lim = powf(10.f, -lim / 20.f);
+    return DFX_OK;
+}
+
+extern "C" int dfx_stream_set_post_filter_beta(dfx_stream_state *s, float beta) {
+    if (!s || beta < 0.f) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_stream_set_post_filter_beta: bad arguments");
+    s->pf_beta = beta;
+    return DFX_OK;
+}
+
+extern "C" int dfx_stream_process(dfx_stream_state *S, const float *x, int64_t n, float *y, float *lsnr_out, void *stream) {
+    if (!S || n <= 0 || n > S->nmax || !x || !y) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_stream_process: bad arguments (1 <= n_frames <= max_frames)");
+    if (int rc = dfx_require_device()) return rc;
+    const dfx_model *m = S->m;
+    const dfx_state *st = S->st;
+    const dfx_model_cfg &c = m->cfg;
+    hipStream_t s = dfx_stream(stream);
+    const int64_t B = S->B, H = S->H, L = S->L, Hs = H + L, F = st->N / 2 + 1, E = c.nb_erb, Fd = c.nb_df, hop = st->hop, ML = st->N - hop;
+    auto fp = [&](size_t o) { return reinterpret_cast<float *>(S->buf + o); };
+    int rc;
+    if (S->lim == 1.f) {  // tract.rs:540-543: the frame is passed through untouched (and undelayed); the state does not advance
+        if ((rc = stream_copy_rows(x, n * hop, n * hop, 0, y, n * hop, n * hop, B, s))) return rc;
+        if (lsnr_out) DFX_HIP(hipMemsetAsync(lsnr_out, 0, (size_t)B * n * 4, s));
+        return DFX_OK;
+    }
+    // ---- STFT + features of the n new hops (state: analysis memory, running means)
+    float *am_in = fp(S->ana_mem[S->flip]), *am_out = fp(S->ana_mem[S->flip ^ 1]);
+    float *sm_in = fp(S->syn_mem[S->flip]), *sm_out = fp(S->syn_mem[S->flip ^ 1]);
+    float *new_spec = fp(S->new_spec), *new_fe = fp(S->new_fe), *new_fs = fp(S->new_fs);
+    if ((rc = dfx_launch_analysis(st, x, B, n * hop, n * hop, am_in, am_out, new_spec, new_fe, s))) return rc;
+    if ((rc = dfx_launch_norm_scan(new_fe, new_fe, (int)E, new_spec, F, new_fs, (int)Fd, B, n, c.norm_alpha, fp(S->erb_state),
+                                   fp(S->unit_state), s)))
+        return rc;
+    // ---- windows: [history ; new].  Net position p uses the features of hop p + L, so the hops of this call are the positions
+    // a0 - L .. a0 + n - 1 - L; positions < 0 do not exist: their features are zero for the taps of later positions (the causal
+    // padding of pad_feat, deepfilternet3.py:357-361) and they are not computed.
+    const int64_t a0 = S->frames, T = H + n;
+    const int64_t skip = a0 < L ? ((L - a0) < n ? (L - a0) : n) : 0;
+    float *work_fe = fp(S->work_fe), *work_fs = fp(S->work_fs), *work_spec = fp(S->work_spec);
+    struct Ring { float *hist, *nw, *work; int64_t h, row; bool zero_skipped; } rings[3] = {
+        {fp(S->hist_fe), new_fe, work_fe, H, E, true}, {fp(S->hist_fs), new_fs, work_fs, H, Fd * 2, true},
+        {fp(S->hist_spec), new_spec, work_spec, Hs, F * 2, false}};
+    for (const Ring &r : rings) {
+        const int64_t wl = (r.h + n) * r.row;
+        if ((rc = stream_copy_rows(r.hist, r.h * r.row, r.h * r.row, 0, r.work, wl, r.h * r.row, B, s))) return rc;
+        if ((rc = stream_copy_rows(r.nw, n * r.row, n * r.row, 0, r.work + r.h * r.row, wl, n * r.row, B, s))) return rc;
+        if (r.zero_skipped && skip > 0 && (rc = stream_copy_rows(r.nw, 0, 0, 0, r.work + r.h * r.row, wl, skip * r.row, B, s))) return rc;
+        if ((rc = stream_copy_rows(r.work, wl, wl, n * r.row, r.hist, r.h * r.row, r.h * r.row, B, s))) return rc;  // next call's history
+    }
+    float *out_spec = fp(S->out_spec);
+    if (skip > 0) DFX_HIP(hipMemsetAsync(out_spec, 0, (size_t)B * n * F * 8, s));  // warm-up hops: zero spectra (tract.rs rolling buffers)
+    if (skip < n) {
+        DfxStreamCtx sc;
+        sc.H = H + skip;
+        const int64_t pos0 = Hs - a0;  // local index of net position 0
+        sc.t_zero = pos0 > 0 ? pos0 : 0;
+        sc.spec_T = Hs + n;
+        sc.h_state = fp(S->h_state);
+        sc.pf_beta = S->pf_beta;
+        sc.out = out_spec;  // local frame t of clip b lands at out_spec[(b*n + t - H) * F]
+        sc.out_T = n;
+        sc.out_toff = H;
+        float *ws = reinterpret_cast<float *>(((uintptr_t)(S->buf + S->model_ws) + 255) & ~(uintptr_t)255);
+        const DfxLane *ln = &m->lanes[0];
+        switch (c.conv_ch) {
+            case 16: rc = forward_impl<16>(m, st->bands, work_spec, work_fe, work_fs, B, T, S->lim, nullptr, nullptr, fp(S->lsnr), nullptr, ws, s, ln, false, nullptr, &sc); break;
+            case 32: rc = forward_impl<32>(m, st->bands, work_spec, work_fe, work_fs, B, T, S->lim, nullptr, nullptr, fp(S->lsnr), nullptr, ws, s, ln, false, nullptr, &sc); break;
+            case 64: rc = forward_impl<64>(m, st->bands, work_spec, work_fe, work_fs, B, T, S->lim, nullptr, nullptr, fp(S->lsnr), nullptr, ws, s, ln, false, nullptr, &sc); break;
+            default: DFX_FAIL(DFX_ERR_UNSUPPORTED, "conv_ch");
+        }
+        if (rc) return rc;
+    }
+    // ---- ISTFT of the n enhanced hops (state: overlap-add memory)
+    if ((rc = dfx_launch_synthesis(st, out_spec, B, n, sm_in, sm_out, y, n * hop, 0, n * hop, s))) return rc;
+    (void)ML;
+    if (lsnr_out) {  // the window's lsnr is [B, T]: take the n new frames (the entries of warm-up hops are not meaningful)
+        if ((rc = stream_copy_rows(fp(S->lsnr), T, T, H, lsnr_out, n, n, B, s))) return rc;
+    }
+    S->frames += n;
+    S->flip ^= 1;
+    return DFX_OK;
 }
 
 // Batch-chunk pipelining: the GRU chain of a chunk is a long latency chain on a handful of CUs, so dfx_enhance splits the

@@ -334,6 +334,7 @@ struct DfxC01Args {
     float *out;          // [B*T, Fout, C]
     int64_t B, T;
     int Fin, Fout, stride, L;
+    int64_t t_begin;     // only frames [t_begin, T) of every clip are produced
 };
 
 template <int C>
@@ -359,14 +360,16 @@ __global__ void __launch_bounds__(DFX_PW_THREADS) dfx_k_df_conv01(DfxC01Args A) 
         biasr[nt] = reinterpret_cast<const float4 *>(A.bias)[4 * nt + q];
     }
     __syncthreads();
-    const int64_t total = A.B * A.T * A.Fout;
+    const int64_t Tn = A.T - A.t_begin;
+    const int64_t total = A.B * Tn * A.Fout;
     const int64_t ntiles = (total + 15) / 16;
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
-        const int64_t pos = tile * 16 + jl;
-        const bool valid = pos < total;
-        const int64_t r = pos / A.Fout;
-        const int fo = (int)(pos - r * A.Fout);
-        const int64_t b = r / A.T, t = r - b * A.T;
+        const int64_t lpos = tile * 16 + jl;
+        const bool valid = lpos < total;
+        const int64_t rl = lpos / A.Fout;
+        const int fo = (int)(lpos - rl * A.Fout);
+        const int64_t b = rl / Tn, t = A.t_begin + (rl - b * Tn);
+        const int64_t pos = (b * A.T + t) * A.Fout + fo;  // physical output position
         float u[CPL];
 #pragma unroll
         for (int i = 0; i < CPL; ++i) u[i] = 0.f;
@@ -466,6 +469,7 @@ struct DfxC01hArgs {
     int64_t B, T;
     int Fin, Fout, stride, L;
     float unscale0, unscale;
+    int64_t t_begin;     // only frames [t_begin, T) of every clip are produced
 };
 
 // Register budget: two waves per SIMD (<= 256 registers) so that one wave's LDS / global latencies hide behind the other's matrix
@@ -493,7 +497,8 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 2) dfx_k_df_conv01_h3(DfxC01hA
         w0l[nt] = A.w0f[(nt * 2 + 1) * 64 + lane];
     }
     __syncthreads();
-    const int64_t total = A.B * A.T * A.Fout;
+    const int64_t Tn = A.T - A.t_begin;
+    const int64_t total = A.B * Tn * A.Fout;
     const int64_t ntiles = (total + 15) / 16;
     const int64_t tstep = (int64_t)gridDim.x * 4;
     float2 raw[3][4];
@@ -503,12 +508,12 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 2) dfx_k_df_conv01_h3(DfxC01hA
     int nfo = 0;
     bool nvalid = false;
     auto locate = [&](int64_t tile) {
-        const int64_t pos = tile * 16 + jl;
-        nvalid = tile < ntiles && pos < total;
-        const int64_t r = pos / A.Fout;
-        nfo = (int)(pos - r * A.Fout);
-        nb = r / A.T;
-        ntm = r - nb * A.T;
+        const int64_t lpos = tile * 16 + jl;
+        nvalid = tile < ntiles && lpos < total;
+        const int64_t rl = lpos / A.Fout;
+        nfo = (int)(lpos - rl * A.Fout);
+        nb = rl / Tn;
+        ntm = A.t_begin + (rl - nb * Tn);
     };
     auto issue = [&](int j) {
         const int fi = nfo * A.stride + j - 1;
@@ -520,8 +525,8 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 2) dfx_k_df_conv01_h3(DfxC01hA
 #pragma unroll
     for (int j = 0; j < 3; ++j) issue(j);
     for (; tile < ntiles; tile += tstep) {
-        const int64_t pos = tile * 16 + jl;
-        const bool valid = pos < total;
+        const bool valid = nvalid;                              // located for this tile by the previous iteration
+        const int64_t pos = (nb * A.T + ntm) * A.Fout + nfo;    // physical output position
         locate(tile + tstep);
         float u[CPL];
 #pragma unroll
@@ -592,6 +597,7 @@ struct DfxCphArgs {
     int64_t B, T;
     int Fd, NO, nfb, nseg, tseg, L;
     float unscale0, unscale;
+    int64_t t_begin, t_zero;  // as in DfxCp2Args
 };
 
 template <int C, int KT>
@@ -625,14 +631,14 @@ __global__ void __launch_bounds__(256, 1) dfx_k_df_convp_h3(DfxCphArgs A) {
         const int64_t b = rest / A.nfb;
         const int f = fb * 16 + jl;
         const bool fvalid = f < A.Fd;
-        const int64_t t0 = (int64_t)seg * A.tseg;
+        const int64_t t0 = A.t_begin + (int64_t)seg * A.tseg;
         const int64_t t1 = (t0 + A.tseg < A.T) ? t0 + A.tseg : A.T;
         dfx_h8 xh[KT][KC], xl[KT][KC];  // frame tau lives in slot (tau - t0) mod KT
         float2 raw[4];
         auto make_frame = [&](dfx_h8 (&dh)[KC], dfx_h8 (&dl)[KC], int64_t tau, const float2 (&rw)[4]) {
             float c0v[CPL];
             // frames before the clip are the zero padding of c0 itself (wave-uniform test)
-            dfx_c0_tile_h3<C>(w0h, w0l, bias0, A.unscale0, rw, fvalid && tau >= 0, c0v);
+            dfx_c0_tile_h3<C>(w0h, w0l, bias0, A.unscale0, rw, fvalid && tau >= A.t_zero, c0v);
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) dfx_split8(c0v + 8 * kc, dh[kc], dl[kc]);
         };
@@ -771,6 +777,7 @@ struct DfxEncArgs {
     float *e0, *e1;                  // [B*T, E, C], [B*T, E/2, C]
     int64_t B, T;
     int E, L;
+    int64_t t_begin;                 // only frames [t_begin, T) of every clip are produced (streaming: the frames before are history)
 };
 #define DFX_ENC_FS(E) (3 * ((E) + 2))                                   /* zero-bordered feat rows of one frame */
 #define DFX_ENC_WAVE_FLOATS(C, E) ((E) * ((C) + 4) + DFX_ENC_FS(E) + 2) /* + pad to a multiple of 4 floats below */
@@ -796,28 +803,29 @@ __global__ void __launch_bounds__(256, 2) dfx_k_erb_enc(DfxEncArgs A) {
     for (int k = 0; k < 9; ++k) wv[k] = reinterpret_cast<const float4 *>(A.w0)[k * C4 + c4];
     const float4 bv = reinterpret_cast<const float4 *>(A.b0)[c4];
     __syncthreads();
-    const int64_t R = A.B * A.T;
+    const int64_t Tn = A.T - A.t_begin, R = A.B * Tn;  // logical rows: (clip, produced frame)
     const int64_t rstep = (int64_t)gridDim.x * 4;
     // element i of the zero-bordered tap rows [3][E+2] of frame r (zero: border, causal pad after the lookahead shift, beyond T)
     float fx[3];
-    auto fetch = [&](int64_t r) {
-        const int64_t b = r / A.T, t = r - b * A.T;
+    auto fetch = [&](int64_t rl) {
+        const int64_t b = rl / Tn, t = A.t_begin + (rl - b * Tn);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int i = lane + 64 * k, kt = i / EP, fp = i - kt * EP;
             const int64_t tau = t - 2 + kt, tin = tau + A.L;
             float v = 0.f;
-            if (r < R && i < 3 * EP && fp >= 1 && fp <= E && tau >= 0 && tin < A.T) v = A.feat[(b * A.T + tin) * E + fp - 1];
+            if (rl < R && i < 3 * EP && fp >= 1 && fp <= E && tau >= 0 && tin < A.T) v = A.feat[(b * A.T + tin) * E + fp - 1];
             fx[k] = v;
         }
     };
-    int64_t r = (int64_t)blockIdx.x * 4 + wave;
-    fetch(r);
-    for (; r < R; r += rstep) {
+    int64_t rl = (int64_t)blockIdx.x * 4 + wave;
+    fetch(rl);
+    for (; rl < R; rl += rstep) {
+        const int64_t r = (rl / Tn) * A.T + A.t_begin + rl % Tn;  // physical row
 #pragma unroll
         for (int k = 0; k < 3; ++k)
             if (lane + 64 * k < 3 * EP) fs[lane + 64 * k] = fx[k];
-        fetch(r + rstep);
+        fetch(rl + rstep);
         DFX_WAVE_SYNC();
         for (int p = pslot; p < E; p += pstep) {
             float4 acc = bv;
@@ -1125,6 +1133,8 @@ struct DfxCp2Args {
     const float *feat;  // FUSE_C0: feat_spec [B, T, Fd, 2], folded df_conv0 weights [20][C] and bias [C], lookahead L
     const float *weff0, *bias0;
     int L;
+    int64_t t_begin;    // only frames [t_begin, T) are produced (the segments start there)
+    int64_t t_zero;     // FUSE_C0: c0 of frames < t_zero is the zero padding (0 for whole clips; streaming: frames before the stream began)
     const float *weff;  // [kt][C][16]  weff[(k*C + c)*16 + n], n >= NO zero
     const float *bias;  // [16]
     float *out;         // [B, NO/2, T, Fd, 2]  (tap-major, DFX_COEF_BOTF)
@@ -1164,12 +1174,12 @@ __global__ void __launch_bounds__(256) dfx_k_df_convp2(DfxCp2Args A) {
         const int64_t b = rest / A.nfb;
         const int f = fb * 16 + jl;
         const bool fvalid = f < A.Fd;
-        const int64_t t0 = (int64_t)seg * A.tseg;
+        const int64_t t0 = A.t_begin + (int64_t)seg * A.tseg;
         const int64_t t1 = (t0 + A.tseg < A.T) ? t0 + A.tseg : A.T;
         float win[KT][CPL];
         auto load_frame = [&](float (&dst)[CPL], int64_t tau) {
             if (FUSE_C0) {
-                if (tau >= 0) {  // wave-uniform; frames before the clip are the zero padding of c0 itself
+                if (tau >= A.t_zero) {  // wave-uniform; frames before the clip are the zero padding of c0 itself
                     float bv[5];
                     dfx_c0_patch(A.feat, b, tau, f, fvalid, A.T, A.Fd, A.L, q, bv);
                     dfx_c0_tile<C>(areg0, bias0, bv, fvalid, dst);
@@ -1177,7 +1187,7 @@ __global__ void __launch_bounds__(256) dfx_k_df_convp2(DfxCp2Args A) {
 #pragma unroll
                     for (int i = 0; i < CPL; ++i) dst[i] = 0.f;
                 }
-            } else if (fvalid && tau >= 0) {
+            } else if (fvalid && tau >= A.t_zero) {
                 const float4 *p = reinterpret_cast<const float4 *>(A.c0 + ((b * A.T + tau) * A.Fd + f) * C + 4 * q);
 #pragma unroll
                 for (int v = 0; v < V4; ++v) {  // float4 v of this lane = channels 16*v + 4*q .. +3 (k-steps 4v .. 4v+3)

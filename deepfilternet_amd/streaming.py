@@ -1,0 +1,82 @@
+"""Frame-by-frame (streaming) enhancement: the host-side mirror of the reference's real-time runtime ``DfTract``
+(libDF/src/tract.rs:509-642) and its C API ``df_create / df_process_frame / df_set_atten_lim / df_set_post_filter_beta / df_free``
+(libDF/src/capi.rs:83-253), for many independent mono streams advanced in lockstep on one MI355X.
+
+    rt = DfStream(model, df_state, streams=4096)           # df_create, once
+    for hop in audio.split(rt.frame_length, dim=1):        # [streams, 480] per call
+        out = rt.process(hop)                              # df_process_frame: the enhanced hop of `lookahead` calls ago
+
+``process`` also accepts several hops per call (``[streams, n * hop]``, ``n <= max_frames``); the concatenated output does not depend
+on how the signal is cut.  It equals ``enhance(model, df_state, audio, pad=False)`` delayed by ``delay_frames`` hops (the first
+``delay_frames`` output hops are silence, like the reference's rolling buffers).  Not implemented: the reference's LSNR-dependent
+stage skipping and silent-input shortcut (every hop runs all stages), and multi-channel mask reduction.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from .libdf import DF
+from .model import DfNet
+
+
+class DfStream:
+    def __init__(self, model: DfNet, df_state: DF, streams: int = 1, max_frames: int = 1, atten_lim_db: Optional[float] = None):
+        if not isinstance(model, DfNet):
+            raise TypeError("DfStream needs a deepfilternet_amd.DfNet (see init_df)")
+        h = C.c_void_p()
+        _lib.check(_lib.lib().dfx_stream_create(model.handle, df_state.handle, int(streams), int(max_frames), C.byref(h)))
+        self._h = h
+        self._model, self._df = model, df_state  # keep the handles the runtime points into alive
+        self.streams, self.max_frames = int(streams), int(max_frames)
+        if atten_lim_db is not None:
+            self.set_atten_lim(atten_lim_db)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().dfx_stream_free(h)
+            except Exception:  # noqa: BLE001  (interpreter shutdown)
+                pass
+
+    @property
+    def frame_length(self) -> int:
+        """df_get_frame_length (capi.rs:108): samples per hop."""
+        return int(_lib.lib().dfx_stream_frame_length(self._h))
+
+    @property
+    def delay_frames(self) -> int:
+        """Hops by which the output lags the input (the model's lookahead), on top of the STFT's fft-hop samples."""
+        return int(_lib.lib().dfx_stream_delay_frames(self._h))
+
+    def set_atten_lim(self, lim_db: float) -> None:
+        """df_set_atten_lim (capi.rs:136, tract.rs:387-398): |dB| >= 100 = no limit, < 0.01 = pass the input through."""
+        _lib.check(_lib.lib().dfx_stream_set_atten_lim(self._h, float(lim_db)))
+
+    def set_post_filter_beta(self, beta: float) -> None:
+        """df_set_post_filter_beta (capi.rs:146): 0 disables the post filter."""
+        _lib.check(_lib.lib().dfx_stream_set_post_filter_beta(self._h, float(beta)))
+
+    def reset(self) -> None:
+        _lib.check(_lib.lib().dfx_stream_reset(self._h, _lib.stream()))
+
+    def process(self, frames: torch.Tensor, return_lsnr: bool = False):
+        """df_process_frame (capi.rs:161) for every stream: ``frames`` [streams, n*hop] float32 -> enhanced [streams, n*hop]
+        (on the device the input came from); with ``return_lsnr`` also the local SNR estimates [streams, n] in dB."""
+        src_dev = frames.device
+        x = frames.to(_lib.device(), torch.float32).contiguous()
+        hop = self.frame_length
+        if x.dim() != 2 or x.shape[0] != self.streams or x.shape[1] % hop or x.shape[1] == 0:
+            raise ValueError(f"frames must have shape [{self.streams}, n*{hop}]")
+        n = x.shape[1] // hop
+        if n > self.max_frames:
+            raise ValueError(f"at most max_frames={self.max_frames} hops per call")
+        y = torch.empty_like(x)
+        lsnr = torch.empty((self.streams, n), dtype=torch.float32, device=x.device) if return_lsnr else None
+        _lib.check(_lib.lib().dfx_stream_process(self._h, _lib.ptr(x), n, _lib.ptr(y), _lib.ptr(lsnr), _lib.stream()))
+        y = y.to(src_dev)
+        return (y, lsnr.to(src_dev)) if return_lsnr else y

@@ -195,6 +195,32 @@ int dfx_enhance(const dfx_model *m, const dfx_state *st, const float *x, int64_t
                 float atten_lim_db, float *y, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Streaming: the frame loop of the reference's real-time runtime, libDF/src/tract.rs `DfTract::process` (:509-642), exported by
+ * its C API as df_create / df_get_frame_length / df_set_atten_lim / df_set_post_filter_beta / df_process_frame / df_free
+ * (libDF/src/capi.rs:83-253), for `streams` independent mono streams advanced in lockstep on one GPU.
+ *   dfx_stream_process(x [streams, n*hop]) -> y [streams, n*hop]: n hops per stream and call (1 <= n <= max_frames; n = 1 is
+ *   df_process_frame).  All state lives in the handle: STFT/ISTFT memories, the running ERB / unit-norm means, the convolution
+ *   input histories, the hidden states of the five GRU layers and the rolling spectra the deep filter reads.
+ *   Like the reference the output is delayed by `lookahead` hops (max(conv_lookahead, df_lookahead), dfx_stream_delay_frames)
+ *   on top of the fft-hop samples of the STFT: output hop k is the enhanced input hop k - lookahead; the first `lookahead`
+ *   output hops are zero (tract.rs: the rolling spectra start as zeros).  Concatenated over calls, the output equals
+ *   dfx_enhance(pad=0) of the whole signal delayed by `lookahead` hops — however the signal is cut into calls.
+ *   Not implemented (the reference does them per frame on the CPU): the LSNR-dependent stage skipping (tract.rs:658-672) and the
+ *   silent-input shortcut (:513-525) — every frame runs all stages; multi-channel mask reduction (:868-902).
+ * lsnr (optional) receives the local SNR estimate [streams, n] in dB (df_process_frame's return value); not meaningful for the
+ * warm-up hops.
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct dfx_stream_state dfx_stream_state;
+int dfx_stream_create(const dfx_model *m, const dfx_state *st, int64_t streams, int max_frames, dfx_stream_state **out);
+void dfx_stream_free(dfx_stream_state *s);
+int dfx_stream_reset(dfx_stream_state *s, void *stream);                 /* back to the state after create */
+int dfx_stream_frame_length(const dfx_stream_state *s);                  /* hop size in samples (df_get_frame_length) */
+int dfx_stream_delay_frames(const dfx_stream_state *s);                  /* lookahead in hops */
+int dfx_stream_set_atten_lim(dfx_stream_state *s, float lim_db);         /* df_set_atten_lim: |dB| >= 100 off, < 0.01 bypass */
+int dfx_stream_set_post_filter_beta(dfx_stream_state *s, float beta);    /* df_set_post_filter_beta: 0 disables the post filter */
+int dfx_stream_process(dfx_stream_state *s, const float *x, int64_t n_frames, float *y, float *lsnr, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Per-kernel timing (measurement aid, no reference counterpart; the reference only logs wall-clock RTF,
  * DeepFilterNet/df/enhance.py:77-87).  When a kernel's bit is set in `kernel_mask`, every launch of it is bracketed by
  * two hipEvents recorded on the stream the kernel is launched on.  dfx_prof_read() synchronises the pending events and
