@@ -103,6 +103,16 @@ static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) {
     return hipSuccess;
 }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+// graphs: not available on the interpreter (the streaming runtime then launches plainly)
+typedef void *hipGraph_t;
+typedef void *hipGraphExec_t;
+#define hipStreamCaptureModeRelaxed 2
+static inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return 801; }
+static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *) { return 801; }
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t *, hipGraph_t, void *, void *, size_t) { return 801; }
+static inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return 801; }
+static inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
 typedef void *hipEvent_t;
 static inline hipError_t hipEventCreate(hipEvent_t *e) {
     *e = nullptr;
