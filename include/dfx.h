@@ -165,7 +165,7 @@ int dfx_model_cfg_get(const dfx_model *m, dfx_model_cfg *out);
  * streams, forked from and joined to the caller's stream with events.  enable = 0 serialises everything on the caller's
  * stream (useful for per-kernel timing).  Default: enabled (environment DFX_STREAMS=0 disables at creation). */
 int dfx_model_set_streams(dfx_model *m, int enable);
-/* Pipelining knobs (defaults 6, 32, 1; environment DFX_TCHUNKS / DFX_CHUNKS at creation):
+/* Pipelining knobs (defaults 12, 32, 1; time_chunks <= 16; environment DFX_TCHUNKS / DFX_CHUNKS at creation):
  *   time_chunks      the GRU phase is cut into this many time chunks and every GRU layer runs on its own stream, chunk k of
  *                    layer l starting when layer l-1 has produced chunk k (chain = T*(1 + 2/K) steps instead of 3T);
  *   min_chunk_frames shortest chunk worth a launch;
