@@ -84,12 +84,82 @@ static __device__ __forceinline__ void dfx_fft_pass(const float2 *x, float2 *y, 
     }
 }
 
+// The same pass with every size a compile-time constant: the butterfly index split b -> (p, q), the strides and the twiddle step
+// become shifts / multiplies by constants.  The generic pass spends most of its instructions on that index arithmetic (the
+// kernels were VALU-issue bound at ~2500 instructions per frame); the arithmetic on the data is unchanged, so the bits are too.
+template <int R, int SG, int M, int NCUR, int S>
+static __device__ __forceinline__ void dfx_fft_pass_c(const float2 *x, float2 *y, const float2 *tw, int lane) {
+    constexpr int m = NCUR / R, nbf = M / R, tws = (2 * M) / NCUR;
+    for (int b = lane; b < nbf; b += DFX_DSP_TEAM) {
+        const int p = b / S, q = b - p * S;
+        float2 a[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) a[j] = x[q + S * (p + m * j)];
+        float2 o[R];
+        if constexpr (R == 2) {
+            o[0] = dfx_cadd(a[0], a[1]);
+            o[1] = dfx_csub(a[0], a[1]);
+        } else if constexpr (R == 3) {
+            const float2 sm = dfx_cadd(a[1], a[2]), d = dfx_csub(a[1], a[2]);
+            const float2 mm = make_float2(a[0].x - 0.5f * sm.x, a[0].y - 0.5f * sm.y);
+            float2 jd = dfx_mul_sgi<SG>(d);
+            jd.x *= 0.86602540378443864676f;
+            jd.y *= 0.86602540378443864676f;
+            o[0] = dfx_cadd(a[0], sm);
+            o[1] = dfx_cadd(mm, jd);
+            o[2] = dfx_csub(mm, jd);
+        } else if constexpr (R == 4) {
+            const float2 t0 = dfx_cadd(a[0], a[2]), t1 = dfx_csub(a[0], a[2]);
+            const float2 t2 = dfx_cadd(a[1], a[3]), t3 = dfx_mul_sgi<SG>(dfx_csub(a[1], a[3]));
+            o[0] = dfx_cadd(t0, t2);
+            o[1] = dfx_cadd(t1, t3);
+            o[2] = dfx_csub(t0, t2);
+            o[3] = dfx_csub(t1, t3);
+        } else {  // R == 5
+            const float c1 = 0.30901699437494742410f, s1 = 0.95105651629515357212f;
+            const float c2 = -0.80901699437494742410f, s2 = 0.58778525229247312917f;
+            const float2 s14 = dfx_cadd(a[1], a[4]), d14 = dfx_csub(a[1], a[4]);
+            const float2 s23 = dfx_cadd(a[2], a[3]), d23 = dfx_csub(a[2], a[3]);
+            const float2 m1 = make_float2(a[0].x + c1 * s14.x + c2 * s23.x, a[0].y + c1 * s14.y + c2 * s23.y);
+            const float2 m2 = make_float2(a[0].x + c2 * s14.x + c1 * s23.x, a[0].y + c2 * s14.y + c1 * s23.y);
+            const float2 n1 = dfx_mul_sgi<SG>(make_float2(s1 * d14.x + s2 * d23.x, s1 * d14.y + s2 * d23.y));
+            const float2 n2 = dfx_mul_sgi<SG>(make_float2(s2 * d14.x - s1 * d23.x, s2 * d14.y - s1 * d23.y));
+            o[0] = make_float2(a[0].x + s14.x + s23.x, a[0].y + s14.y + s23.y);
+            o[1] = dfx_cadd(m1, n1);
+            o[4] = dfx_csub(m1, n1);
+            o[2] = dfx_cadd(m2, n2);
+            o[3] = dfx_csub(m2, n2);
+        }
+        y[q + S * (R * p)] = o[0];
+#pragma unroll
+        for (int j = 1; j < R; ++j) {
+            float2 w = tw[j * p * tws];
+            if (SG > 0) w.y = -w.y;
+            y[q + S * (R * p + j)] = dfx_cmul(o[j], w);
+        }
+    }
+}
+
 // Complex FFT of length pl.M by one 64-lane team.  Data starts in `a`; returns the buffer that holds the result.
 // A team is exactly one wave, so the passes only need a wave-level barrier (DFX_WAVE_SYNC): the 8 teams of a workgroup run
 // their FFTs independently instead of meeting at a workgroup barrier after every pass.
 template <int SG>
 static __device__ __forceinline__ float2 *dfx_fft_team(float2 *a, float2 *b, const float2 *tw, const DfxFftPlan &pl,
                                                        int lane, bool active) {
+    // the 48 kHz / 20 ms configuration of every shipped model: N = 960, M = 480 = 4*4*2*3*5 (make_plan's order)
+    if (pl.M == 480 && pl.nstage == 5 && pl.radix[0] == 4 && pl.radix[1] == 4 && pl.radix[2] == 2 && pl.radix[3] == 3 && pl.radix[4] == 5) {
+        if (active) dfx_fft_pass_c<4, SG, 480, 480, 1>(a, b, tw, lane);
+        DFX_WAVE_SYNC();
+        if (active) dfx_fft_pass_c<4, SG, 480, 120, 4>(b, a, tw, lane);
+        DFX_WAVE_SYNC();
+        if (active) dfx_fft_pass_c<2, SG, 480, 30, 16>(a, b, tw, lane);
+        DFX_WAVE_SYNC();
+        if (active) dfx_fft_pass_c<3, SG, 480, 15, 32>(b, a, tw, lane);
+        DFX_WAVE_SYNC();
+        if (active) dfx_fft_pass_c<5, SG, 480, 5, 96>(a, b, tw, lane);
+        DFX_WAVE_SYNC();
+        return b;
+    }
     int ncur = pl.M, s = 1;
     float2 *x = a, *y = b;
     for (int st = 0; st < pl.nstage; ++st) {
