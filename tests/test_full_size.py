@@ -1,0 +1,90 @@
+"""BASELINE.json configs[1] at full size (256 clips x 10 s of 48 kHz audio, DeepFilterNet3 shape) on the MI355X: the oracle cannot
+run the whole batch in test time, so parity is shown through size-independent properties plus an oracle spot check of a few rows."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dfnet_oracle as O
+from tests.helpers import rms
+
+pytestmark = pytest.mark.gpu
+SR, HOP, FFT = 48000, 480, 960
+
+
+def _setup(hip_backend):
+    from deepfilternet_amd.config import ModelParams
+    from deepfilternet_amd.enhance import init_df
+    from deepfilternet_amd.state_dict import random_state_dict
+
+    p = ModelParams.deepfilternet3()
+    sd = random_state_dict(p, 21)
+    model, df_state, _, _ = init_df(params=p, state_dict=sd, epoch="none")
+    return p, sd, model, df_state
+
+
+def _audio(B, T, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    t = torch.arange(T, device="cuda", dtype=torch.float32) / SR
+    f0 = 100.0 + 200.0 * torch.rand((B, 1), device="cuda", generator=g)
+    x = 0.1 * torch.sin(2 * np.pi * f0 * t[None, :]) * (1 + 0.5 * torch.sin(2 * np.pi * 4.0 * t))[None, :]
+    return (x + 0.05 * torch.randn((B, T), device="cuda", generator=g)).contiguous()
+
+
+def test_full_batch_rows_match_oracle_and_single_clip_runs(hip_backend):
+    from deepfilternet_amd.enhance import enhance
+
+    p, sd, model, df_state = _setup(hip_backend)
+    B, T = 256, 10 * SR
+    x = _audio(B, T, 5)
+    y = enhance(model, df_state, x)
+    model.check()
+    assert y.shape == (B, T) and bool(torch.isfinite(y).all())
+    sdt = {k: torch.as_tensor(v) for k, v in sd.items()}
+    for i in (0, 131, 255):
+        # a clip gives the same bits alone as inside the batch (no cross-clip state, whatever the grid / chunking)
+        yi = enhance(model, df_state, x[i:i + 1])
+        assert torch.equal(yi, y[i:i + 1]), i
+    # oracle (CPU restatement of the reference) on two of the rows
+    rows = [7, 200]
+    ref = O.enhance(p, sdt, x[rows].cpu().numpy())
+    err = rms(y[rows].cpu().numpy() - ref)
+    assert err < 2e-6, err
+
+
+def test_full_batch_time_prefix_property(hip_backend):
+    """The network is causal up to its lookahead: the enhanced first half of a clip does not depend on the second half, except for
+    the hops within lookahead (+ the STFT overlap) of the cut."""
+    from deepfilternet_amd.enhance import enhance
+
+    p, sd, model, df_state = _setup(hip_backend)
+    B, T = 256, 10 * SR
+    x = _audio(B, T, 6)
+    y = enhance(model, df_state, x)
+    Th = 5 * SR
+    yh = enhance(model, df_state, x[:, :Th].contiguous())
+    keep = Th - (max(p.conv_lookahead, p.df_lookahead) + 2) * HOP - FFT
+    assert torch.equal(yh[:, :keep], y[:, :keep])
+    assert not torch.equal(yh[:, keep:], y[:, keep:Th])  # the tail of the short run saw zero padding instead of the future
+
+
+def test_full_size_streaming_equals_batch(hip_backend):
+    """4096 lockstep streams, hop by hop and in blocks: equal to the batch path delayed by the lookahead (dfx_stream_process)."""
+    from deepfilternet_amd.enhance import enhance
+    from deepfilternet_amd.streaming import DfStream
+
+    p, sd, model, df_state = _setup(hip_backend)
+    B, n_hops = 4096, 40
+    x = _audio(B, n_hops * HOP, 7)
+    ref = enhance(model, df_state, x, pad=False)
+    rt = DfStream(model, df_state, streams=B, max_frames=8)
+    d = rt.delay_frames
+    for cuts in ([1] * n_hops, [8, 8, 8, 8, 8]):
+        rt.reset()
+        ys, pos = [], 0
+        for n in cuts:
+            ys.append(rt.process(x[:, pos * HOP:(pos + n) * HOP]))
+            pos += n
+        y = torch.cat(ys, dim=1)
+        err = rms((y[:, d * HOP:] - ref[:, : (n_hops - d) * HOP]).cpu().numpy())
+        assert err < 1e-6, (cuts[0], err)
+        assert float(y[:, : d * HOP].abs().max()) == 0.0
