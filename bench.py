@@ -19,7 +19,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # one hardware queue per engine stream (read when HIP initialises)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # one hardware queue per engine stream (read when HIP initialises)
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)

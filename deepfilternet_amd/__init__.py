@@ -8,7 +8,7 @@ import os as _os
 
 # every GRU layer / branch of the forward pass runs on its own HIP stream; ROCm multiplexes streams onto 4 hardware queues
 # unless told otherwise, which serialises them again (must be set before the HIP runtime initialises)
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 from .config import ModelParams  # noqa: F401,E402
 

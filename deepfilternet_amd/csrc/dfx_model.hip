@@ -157,6 +157,7 @@ struct dfx_model {
     bool fuse_c0 = true;
     // frame-resident ERB encoder head / decoder tail (dfx_k_erb_enc, dfx_k_erb_dec10); DFX_FUSE_ERB=0: layer-by-layer kernels
     bool fuse_erb = true;
+    int finish_tail = 0;          // DFX_FINISH_TAIL=j (with chunked finishing): two pieces, the second = the last j time chunks
     bool finish_chunked = false;  // DFX_FINISH_CHUNKS=1: df_apply + synthesis per time chunk beside the GRU chain (measured slower)
     bool convp_after_c1 = false;  // DFX_CONVP_EARLY=2: df_convp starts when df_conv1 is done
     bool convp_late = false;  // DFX_CONVP_EARLY=0 holds df_convp back until the front is enqueued (it then starts beside the GRU phase)
@@ -365,13 +366,13 @@ static bool dfx_create_lane(dfx_model *m, int l) {
     bool good = hipStreamCreateWithFlags(&ln.main, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 2; ++i) good = good && hipStreamCreateWithFlags(&ln.aux[i], hipStreamNonBlocking) == hipSuccess;
     if (l == 0) {
-        // df_convp has slack until df_out needs it: when lane 0 is the only lane in flight it runs on a lowest-priority stream, so that
-        // it fills the CUs the critical-path kernels leave idle instead of competing with them (-0.3 ms per step).  Never used beside
-        // other lanes: with more streams than hardware queues a low-priority queue was measured to starve for ~1 s.
-        // DFX_X2_PRIO=normal disables it.
+        // DFX_X2_PRIO=low: df_convp (which has slack until df_out needs it) runs on a lowest-priority stream when lane 0 is the only
+        // lane in flight, so that it fills the CUs the critical-path kernels leave idle (-0.3 ms per step).  Opt-in: whenever the
+        // process had more streams than hardware queues (a second lane, one more helper stream, and presumably a communication
+        // library's streams) the low-priority queue was seen to starve and a step took ~1 s instead of 23 ms.
         int lo = 0, hi = 0;
         const char *pe = getenv("DFX_X2_PRIO");
-        if (!(pe && pe[0] == 'n') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+        if (pe && pe[0] == 'l' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
             good = good && hipStreamCreateWithPriority(&ln.aux_lo, hipStreamNonBlocking, lo) == hipSuccess;
     }
     for (int i = 0; i < DFX_LANE_EVENTS; ++i) good = good && hipEventCreateWithFlags(&ln.ev[i], hipEventDisableTiming) == hipSuccess;
@@ -565,6 +566,11 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         m->fuse_erb = !(fe && fe[0] == '0');
         const char *fc = getenv("DFX_FINISH_CHUNKS");
         m->finish_chunked = fc && fc[0] == '1';
+        const char *ft = getenv("DFX_FINISH_TAIL");
+        if (ft && atoi(ft) > 0) {
+            m->finish_tail = atoi(ft);
+            m->finish_chunked = true;
+        }
 
         const char *g2 = getenv("DFX_GRU_X2");
         m->gru_x2 = g2 && g2[0] == '1' && !dfx_env_is_emulator();
@@ -1501,14 +1507,20 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // last chunk's share of these HBM-bound kernels is left after the GRU chain.
         if (m->finish_chunked && ln->fs) {
             hipStream_t st = ln->fs;
-            for (int k = 0; k < K; ++k) {
-                if ((rc = ewait(ln->mev[k], st)) || (rc = ewait(ln->cev[k], st))) return rc;
+            // pieces of `step` chunks; finish_tail > 0: two pieces only, the second being the last finish_tail chunks
+            const int step = m->finish_tail > 0 ? K : 1;
+            for (int k0 = 0; k0 < K;) {
+                int k1 = k0 + step;
+                if (m->finish_tail > 0) k1 = (k0 == 0 && K - m->finish_tail > 0) ? K - m->finish_tail : K;
+                if (k1 > K) k1 = K;
+                if ((rc = ewait(ln->mev[k1 - 1], st)) || (rc = ewait(ln->cev[k1 - 1], st))) return rc;
                 if ((rc = dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead,
-                                              c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, st, tb(k), tb(k + 1))))
+                                              c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, st, tb(k0), tb(k1))))
                     return rc;
                 if (fin && (rc = dfx_launch_synthesis(fin->st, spec_e, B, T, nullptr, nullptr, fin->y, fin->out_stride, fin->out_skip,
-                                                      fin->out_len, st, tb(k), tb(k + 1))))
+                                                      fin->out_len, st, tb(k0), tb(k1))))
                     return rc;
+                k0 = k1;
             }
             if ((rc = signal(EV_FIN, st)) || (rc = wait(EV_FIN, s))) return rc;
             return DFX_OK;
