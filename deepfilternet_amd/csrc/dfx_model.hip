@@ -118,7 +118,124 @@ struct DfxStreamCtx {
     float *out;        // [B, out_T, F][2]: local frame t of clip b is stored at frame t - out_toff
     int64_t out_T, out_toff;
     bool serial;       // every kernel on the caller's stream (graph capture records a single-stream chain)
+    const struct DfxGate *gate = nullptr;  // per-stream stage gating (one new frame per pass); null: every frame runs every stage
 };
+
+// ---- per-stream stage gating of the streaming runtime (DfTract::process / apply_stages, tract.rs:509-616,658-672) ----------------
+// The reference decides per frame, from the encoder's local-SNR estimate, whether the ERB decoder (stage 1) and the DF decoder
+// (stage 2) run at all; a decoder that does not run keeps its state (tract's pulsed models only advance when they are run), and a
+// stream that has been silent for more than 5 hops is not processed at all.  Lockstep streams take those decisions independently:
+// every kernel still runs for every stream (a skipped stream costs the same as a busy one on a GPU), and the decisions are applied
+// as data: flags[b] selects whose state is kept (dfx_k_gate_commit) and what the deep-filter kernel is fed (dfx_k_gate_edit).
+enum { DFX_GATE_FROZEN = 1, DFX_GATE_GAINS = 2, DFX_GATE_ZEROS = 4, DFX_GATE_DF = 8 };
+struct DfxGate {
+    unsigned char *flags;  // [B]
+    float thr[3];          // min_db_thresh, max_db_erb_thresh, max_db_df_thresh
+    float *c0_win;         // [B, T, Fd, C]: slots T-kt .. T-2 = c0 of the last kt-1 frames the DF decoder ran on, T-1 = this frame
+};
+
+// tract.rs:513-525: mean square of the hop (sequential f32 fold like the reference: the comparison with 1e-7 is then the same
+// decision); below the threshold the counter goes up, else it is cleared; above 5 the stream is frozen for this hop.
+__global__ void dfx_k_gate_pre(const float *x, int64_t x_stride, int hop, int64_t B, int *skip_counter, unsigned char *flags) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float *xp = x + b * x_stride;
+    float e = 0.f;
+    for (int i = 0; i < hop; ++i) e = __fadd_rn(e, __fmul_rn(xp[i], xp[i]));
+    const float ms = __fdiv_rn(e, (float)hop);
+    int c = skip_counter[b];
+    c = ms < 1e-7f ? c + 1 : 0;
+    skip_counter[b] = c;
+    flags[b] = c > 5 ? DFX_GATE_FROZEN : 0;
+}
+
+// tract.rs:658-672 apply_stages on the newest frame's lsnr (lsnr[b*T + T-1])
+__global__ void dfx_k_gate_post(const float *lsnr, int64_t T, float thr_min, float thr_erb, float thr_df, unsigned char *flags,
+                                int64_t B) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    unsigned char f = flags[b];
+    if (f & DFX_GATE_FROZEN) return;
+    const float v = lsnr[b * T + T - 1];
+    if (v < thr_min) f |= DFX_GATE_ZEROS;
+    else if (v > thr_erb) f |= 0;
+    else if (v > thr_df) f |= DFX_GATE_GAINS;
+    else f |= DFX_GATE_GAINS | DFX_GATE_DF;
+    flags[b] = f;
+}
+
+// The decisions as inputs of the (unchanged) deep-filter kernel, newest frame of every stream:
+//   no stage 1: the band gains become 0 (zero mask, tract.rs:485-486) or 1 (gains absent: the spectrum passes, :565-567);
+//   no stage 2: the low bins take the masked spectrum (:570-581) = a deep filter whose only non-zero tap is the current frame's,
+//               with the band gain as a real coefficient (x*g - y*0 and 0-taps add exact zeros: the same bits as the mask path).
+__global__ void dfx_k_gate_edit(const unsigned char *flags, float *mask, float *coefs, const unsigned char *bin2band, int64_t B,
+                                int64_t T, int E, int Fd, int O, int tap0) {
+    const int64_t b = blockIdx.x;
+    if (b >= B) return;
+    const unsigned char f = flags[b];
+    float *mrow = mask + (b * T + T - 1) * E;
+    if (!(f & DFX_GATE_GAINS)) {
+        const float g = (f & DFX_GATE_ZEROS) ? 0.f : 1.f;
+        for (int i = threadIdx.x; i < E; i += blockDim.x) mrow[i] = g;
+    }
+    __syncthreads();
+    if (!(f & DFX_GATE_DF)) {
+        for (int i = threadIdx.x; i < O * Fd; i += blockDim.x) {
+            const int n = i / Fd, fq = i - n * Fd;
+            float2 *cp = reinterpret_cast<float2 *>(coefs) + ((b * O + n) * T + T - 1) * Fd + fq;
+            *cp = make_float2(n == tap0 ? mrow[bin2band[fq]] : 0.f, 0.f);
+        }
+    }
+}
+
+// State selection after a gated pass: entry e copies row b of src to dst when (flags[b] & mask) == want.  Frozen streams get all
+// their state back (STFT memories, running means, history rings, hidden states), a stream whose stage 1 / stage 2 was skipped its
+// decoder's hidden states.
+#define DFX_GATE_MAX_ENTRIES 24
+struct DfxGateTable {
+    float *dst[DFX_GATE_MAX_ENTRIES];
+    const float *src[DFX_GATE_MAX_ENTRIES];
+    int64_t row[DFX_GATE_MAX_ENTRIES];
+    unsigned char mask[DFX_GATE_MAX_ENTRIES], want[DFX_GATE_MAX_ENTRIES];
+    int n;
+};
+__global__ void dfx_k_gate_commit(DfxGateTable G, const unsigned char *flags, int64_t B) {
+    const int64_t b = blockIdx.x;
+    if (b >= B) return;
+    const unsigned char f = flags[b];
+    for (int e = 0; e < G.n; ++e) {
+        if ((f & G.mask[e]) != G.want[e]) continue;
+        const float *sp = G.src[e] + b * G.row[e];
+        float *dp = G.dst[e] + b * G.row[e];
+        for (int64_t i = threadIdx.x; i < G.row[e]; i += blockDim.x) dp[i] = sp[i];
+    }
+}
+
+// Streams whose DF decoder ran push the newest c0 frame into their window (slot j <- slot j+1, j = T-kt .. T-2); the others keep
+// theirs: the delay line in front of df_convp only moves when the DF decoder runs.
+__global__ void dfx_k_gate_c0_shift(const unsigned char *flags, float *c0_win, int64_t B, int64_t T, int kt, int64_t frame) {
+    const int64_t b = blockIdx.x;
+    if (b >= B || !(flags[b] & DFX_GATE_DF)) return;
+    float *w = c0_win + (b * T + T - kt) * frame;
+    for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < frame; i += (int64_t)gridDim.y * blockDim.x)
+        for (int j = 0; j + 1 < kt; ++j) w[j * frame + i] = w[(j + 1) * frame + i];
+}
+
+// End of a gated hop: frozen streams answer zeros and lsnr = -15 (tract.rs:522-525); the others update the skip counter from the
+// stage decision (:562-567: gains present -> 0, absent -> += 1).  warm: the hop produced no net position yet (no decision taken).
+__global__ void dfx_k_gate_finish(const unsigned char *flags, int *skip_counter, float *y, int64_t y_stride, int hop, float *lsnr_out,
+                                  int64_t lsnr_stride, int64_t B, int warm) {
+    const int64_t b = blockIdx.x;
+    if (b >= B) return;
+    const unsigned char f = flags[b];
+    if (f & DFX_GATE_FROZEN) {
+        for (int i = threadIdx.x; i < hop; i += blockDim.x) y[b * y_stride + i] = 0.f;
+        if (threadIdx.x == 0 && lsnr_out) lsnr_out[b * lsnr_stride] = -15.f;
+    } else if (threadIdx.x == 0 && !warm) {
+        skip_counter[b] = (f & (DFX_GATE_GAINS | DFX_GATE_ZEROS)) ? 0 : skip_counter[b] + 1;
+    }
+}
+
 enum { EV_START = 0, EV_C0, EV_C1, EV_C0P, EV_EMB, EV_COEFS, EV_FRONT, EV_DONE, EV_XA, EV_MASK, EV_LSNR, EV_FIN };
 
 struct dfx_model {
@@ -1190,6 +1307,9 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         A.T = T;
         A.Fin = Fd;
         A.L = L;
+        A.t_begin = 0;
+        A.out_T = T;
+        A.out_toff = 0;
         DfxKScope ks(DFX_K_CONV_IN_DF, x1);
         dfx_launch(dfx_k_conv_in_df<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R * Fd, 64), 8)), dim3(DFX_PW_THREADS), 0, x1, A);
         DFX_LAUNCH_CHECK();
@@ -1197,9 +1317,40 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->dfc1, c0, nullptr, c1, R, Fd, Fd / 2, 2, x1))) return rc;
     }
     if ((rc = signal(EV_C1, x1))) return rc;
+    const DfxGate *gate = sc ? sc->gate : nullptr;
+    if (gate && T - t_begin != 1) DFX_FAIL(DFX_ERR_INVALID_ARG, "gated streaming passes carry exactly one new frame");
     auto run_convp = [&]() -> int {
         // ---- df_dec.df_convp on x2 (only needs c0; :328)
-        if (fuse_h3) {
+        if (gate && c.df_pathway_kernel_size_t > 1) {
+            // gated streaming: the (kt-1)-frame delay line in front of df_convp belongs to the DF decoder and only moves on the frames
+            // that decoder ran on, per stream.  c0 of the newest frame goes into the last slot of the per-stream window (exact fp32
+            // matrix ops), the pathway conv reads the window; dfx_k_gate_c0_shift advances it where stage 2 ran.
+            if (c.df_pathway_kernel_size_t > 5) DFX_FAIL(DFX_ERR_UNSUPPORTED, "gated streaming needs df_pathway_kernel_size_t <= 5");
+            DfxCinArgs A;
+            A.feat = feat_spec;
+            A.weff = m->p(m->cin_weff);
+            A.bias = m->p(m->cin_b);
+            A.out = gate->c0_win;
+            A.B = B;
+            A.T = T;
+            A.Fin = Fd;
+            A.L = Lk;
+            A.t_begin = T - 1;
+            A.out_T = T;
+            A.out_toff = T - 1;
+            {
+                DfxKScope ks(DFX_K_CONV_IN_DF, x2);
+                dfx_launch(dfx_k_conv_in_df<C>, dim3((unsigned)nn_grid(dfx_ceil_div(B * Fd, 64), 8)), dim3(DFX_PW_THREADS), 0, x2, A);
+                DFX_LAUNCH_CHECK();
+            }
+            switch (c.df_pathway_kernel_size_t) {
+                case 2: rc = launch_convp2<C, 2>(m, gate->c0_win, nullptr, c0p, B, T, Fd, NO, x2, T - 1, 0, Lk); break;
+                case 3: rc = launch_convp2<C, 3>(m, gate->c0_win, nullptr, c0p, B, T, Fd, NO, x2, T - 1, 0, Lk); break;
+                case 4: rc = launch_convp2<C, 4>(m, gate->c0_win, nullptr, c0p, B, T, Fd, NO, x2, T - 1, 0, Lk); break;
+                default: rc = launch_convp2<C, 5>(m, gate->c0_win, nullptr, c0p, B, T, Fd, NO, x2, T - 1, 0, Lk); break;
+            }
+            if (rc) return rc;
+        } else if (fuse_h3) {
             switch (c.df_pathway_kernel_size_t) {
                 case 1: rc = launch_convp_h3<C, 1>(m, feat_spec, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
                 case 2: rc = launch_convp_h3<C, 2>(m, feat_spec, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
@@ -1299,6 +1450,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                        m->lsnr_b, (float)(c.lsnr_max - c.lsnr_min), (float)c.lsnr_min, lsnr, R, emb);
         }
         DFX_LAUNCH_CHECK();
+        if (gate) {  // stage decisions of the newest frame (tract.rs:658-672)
+            dfx_launch(dfx_k_gate_post, dim3((unsigned)dfx_ceil_div(B, 256)), dim3(256), 0, s, (const float *)lsnr, T, gate->thr[0],
+                       gate->thr[1], gate->thr[2], gate->flags, B);
+            DFX_LAUNCH_CHECK();
+        }
         // ---- DfDecoder on x1 (:323-331)
         {
             const float *y2 = nullptr;
@@ -1531,6 +1687,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     // ---- Mask + MF.DF + combine + post filter + atten_lim (:426-454, enhance.py:238-240)
     if (sc) {  // spec has sc->spec_T frames per clip, coefficients / gains T; the n enhanced frames are stored compactly
         const float beta = sc->pf_beta >= 0.f ? sc->pf_beta : (c.mask_pf ? c.pf_beta : 0.f);
+        if (gate) {
+            dfx_launch(dfx_k_gate_edit, dim3((unsigned)B), dim3(128), 0, s, (const unsigned char *)gate->flags, mask, coefs,
+                       (const unsigned char *)bands->d_bin2band, B, T, E, Fd, O, O - 1 - c.df_lookahead);
+            DFX_LAUNCH_CHECK();
+        }
         return dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, sc->spec_T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead, beta,
                                    atten_lim, sc->out, s, t_begin, T, T, sc->out_T, sc->out_toff);
     }
@@ -1628,6 +1789,14 @@ __global__ void dfx_k_copy_rows(const float *src, int64_t src_stride, int64_t sr
     }
 }
 
+__global__ void dfx_k_fill_rows(float *dst, int64_t dst_stride, int64_t len, int64_t B, float v) {
+    const int64_t n = B * len;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / len;
+        dst[b * dst_stride + (i - b * len)] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ streaming (dfx_stream_*)
 // Frame loop of DfTract::process (tract.rs:509-642) for many lockstep streams: every call runs the batch kernels on a window of
 // H history + n new frames per stream (DfxStreamCtx), with all recurrent state carried in the handle.
@@ -1646,6 +1815,11 @@ struct dfx_stream_state {
         work_spec, out_spec, h_state, lsnr, model_ws;
     int64_t model_ws_bytes = 0;
     int flip = 0;             // which of the double-buffered STFT memories is current
+    // per-stream stage gating (dfx_stream_set_gating; DfTract::process, tract.rs:509-616,658-672): off by default
+    bool gated = false;
+    float thr[3] = {-10.f, 30.f, 20.f};   // RuntimeParams::default_with_ch (tract.rs:177-189)
+    unsigned char *gate_buf = nullptr;    // own allocation, made when gating is first switched on
+    size_t g_flags = 0, g_counter = 0, g_sh_erb = 0, g_sh_unit = 0, g_sh_h = 0, g_c0_win = 0, gate_bytes = 0;
     // DFX_STREAM_GRAPH=1: steady-state calls are replayed from a hipGraph (one per memory parity) captured as a single-stream chain on
     // handle-owned I/O buffers (x / y are copied in and out around it).  Off by default: on ROCm 7.2 the replay of the ~35 kernel
     // nodes takes 2.0-2.2 ms per call where the plain three-stream launches take 1.4-1.6 ms.
@@ -1750,6 +1924,7 @@ extern "C" void dfx_stream_free(dfx_stream_state *s) {
     if (s->ev_in) (void)hipEventDestroy(s->ev_in);
     if (s->ev_out) (void)hipEventDestroy(s->ev_out);
     if (s->buf) (void)hipFree(s->buf);
+    if (s->gate_buf) (void)hipFree(s->gate_buf);
     delete s;
 }
 
@@ -1777,8 +1952,53 @@ extern "C" int dfx_stream_reset(dfx_stream_state *s, void *stream) {
     DFX_HIP(hipStreamSynchronize(hs));
     DFX_HIP(hipMemcpy(s->buf + s->erb_state, es.data(), es.size() * 4, hipMemcpyHostToDevice));
     DFX_HIP(hipMemcpy(s->buf + s->unit_state, us.data(), us.size() * 4, hipMemcpyHostToDevice));
+    if (s->gate_buf) DFX_HIP(hipMemset(s->gate_buf, 0, s->gate_bytes));  // skip counters, c0 windows (zero = the causal padding)
     s->frames = 0;
     s->flip = 0;
+    return DFX_OK;
+}
+
+// tract.rs:658-672 / RuntimeParams::with_thresholds (:160-170).  Gating needs the stream to be at a reset point only in the sense
+// that the decoders' delay lines start empty when it is switched on.
+extern "C" int dfx_stream_set_thresholds(dfx_stream_state *s, float min_db_thresh, float max_db_erb_thresh, float max_db_df_thresh) {
+    if (!s) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_stream_set_thresholds: null handle");
+    s->thr[0] = min_db_thresh;
+    s->thr[1] = max_db_erb_thresh;
+    s->thr[2] = max_db_df_thresh;
+    return DFX_OK;
+}
+
+extern "C" int dfx_stream_set_gating(dfx_stream_state *s, int enable) {
+    if (!s) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_stream_set_gating: null handle");
+    if (!enable) {
+        s->gated = false;
+        return DFX_OK;
+    }
+    const dfx_model_cfg &c = s->m->cfg;
+    if (c.df_lookahead > 5) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_stream_set_gating: lookahead > 5 hops is not supported");
+    if (c.df_pathway_kernel_size_t > 5) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_stream_set_gating: df_pathway_kernel_size_t > 5 is not supported");
+    if (!s->gate_buf) {
+        const int64_t B = s->B, T = s->H + 1;
+        size_t off = 0;
+        auto take = [&](size_t bytes) {
+            size_t o = off;
+            off += (bytes + 255) & ~(size_t)255;
+            return o;
+        };
+        s->g_flags = take((size_t)B);
+        s->g_counter = take((size_t)B * 4);
+        s->g_sh_erb = take((size_t)B * c.nb_erb * 4);
+        s->g_sh_unit = take((size_t)B * c.nb_df * 4);
+        s->g_sh_h = take((size_t)s->layers * B * 256 * 4);
+        s->g_c0_win = take(c.df_pathway_kernel_size_t > 1 ? (size_t)B * T * c.nb_df * c.conv_ch * 4 : 256);
+        s->gate_bytes = off;
+        if (hipMalloc(reinterpret_cast<void **>(&s->gate_buf), off) != hipSuccess) {
+            s->gate_buf = nullptr;
+            DFX_FAIL(DFX_ERR_ALLOC, "dfx_stream_set_gating: device allocation of %zu bytes failed", off);
+        }
+        DFX_HIP(hipMemset(s->gate_buf, 0, off));
+    }
+    s->gated = true;
     return DFX_OK;
 }
 
@@ -1801,23 +2021,45 @@ extern "C" int dfx_stream_set_post_filter_beta(dfx_stream_state *s, float beta) 
 }
 
 // one call's kernels, enqueued on s (and the model's auxiliary streams); does not advance the handle's counters
-static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y, float *lsnr_out, hipStream_t s) {
+// x / y / lsnr_out rows may be strided (xs, ys, ls; -1: packed): a gated call of n hops is n one-hop passes over the caller's arrays
+static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y, float *lsnr_out, hipStream_t s, int64_t xs = -1,
+                       int64_t ys = -1, int64_t ls = -1) {
     const dfx_model *m = S->m;
     const dfx_state *st = S->st;
     const dfx_model_cfg &c = m->cfg;
     const int64_t B = S->B, H = S->H, L = S->L, Hs = H + L, F = st->N / 2 + 1, E = c.nb_erb, Fd = c.nb_df, hop = st->hop, ML = st->N - hop;
     auto fp = [&](size_t o) { return reinterpret_cast<float *>(S->buf + o); };
+    auto gp = [&](size_t o) { return reinterpret_cast<float *>(S->gate_buf + o); };
+    if (xs < 0) xs = n * hop;
+    if (ys < 0) ys = n * hop;
+    if (ls < 0) ls = n;
     int rc;
-    if (S->lim == 1.f) {  // tract.rs:540-543: the frame is passed through untouched (and undelayed); the state does not advance
-        if ((rc = stream_copy_rows(x, n * hop, n * hop, 0, y, n * hop, n * hop, B, s))) return rc;
-        if (lsnr_out) DFX_HIP(hipMemsetAsync(lsnr_out, 0, (size_t)B * n * 4, s));
+    if (S->lim == 1.f) {  // tract.rs:540-543: the frame is passed through untouched (and undelayed), lsnr = 35; the state does not advance
+        if ((rc = stream_copy_rows(x, xs, n * hop, 0, y, ys, n * hop, B, s))) return rc;
+        if (lsnr_out) {
+            dfx_launch(dfx_k_fill_rows, dim3((unsigned)nn_grid(dfx_ceil_div(B * n, 256), 16)), dim3(256), 0, s, lsnr_out, ls, n, B, 35.f);
+            DFX_LAUNCH_CHECK();
+        }
         return DFX_OK;
+    }
+    const bool gated = S->gated && S->gate_buf;
+    if (gated && n != 1) DFX_FAIL(DFX_ERR_INVALID_ARG, "gated streaming passes carry one hop");
+    unsigned char *gflags = gated ? S->gate_buf + S->g_flags : nullptr;
+    int *gcount = gated ? reinterpret_cast<int *>(S->gate_buf + S->g_counter) : nullptr;
+    if (gated) {
+        // silent-input shortcut (tract.rs:513-525) + a copy of the in-place state, so that the streams that turn out not to advance
+        // (frozen, or a decoder stage skipped) can be given their state back after the pass
+        dfx_launch(dfx_k_gate_pre, dim3((unsigned)dfx_ceil_div(B, 64)), dim3(64), 0, s, x, xs, (int)hop, B, gcount, gflags);
+        DFX_LAUNCH_CHECK();
+        DFX_HIP(hipMemcpyAsync(gp(S->g_sh_erb), fp(S->erb_state), (size_t)B * E * 4, hipMemcpyDeviceToDevice, s));
+        DFX_HIP(hipMemcpyAsync(gp(S->g_sh_unit), fp(S->unit_state), (size_t)B * Fd * 4, hipMemcpyDeviceToDevice, s));
+        DFX_HIP(hipMemcpyAsync(gp(S->g_sh_h), fp(S->h_state), (size_t)S->layers * B * 256 * 4, hipMemcpyDeviceToDevice, s));
     }
     // ---- STFT + features of the n new hops (state: analysis memory, running means)
     float *am_in = fp(S->ana_mem[S->flip]), *am_out = fp(S->ana_mem[S->flip ^ 1]);
     float *sm_in = fp(S->syn_mem[S->flip]), *sm_out = fp(S->syn_mem[S->flip ^ 1]);
     float *new_spec = fp(S->new_spec), *new_fe = fp(S->new_fe), *new_fs = fp(S->new_fs);
-    if ((rc = dfx_launch_analysis(st, x, B, n * hop, n * hop, am_in, am_out, new_spec, new_fe, s))) return rc;
+    if ((rc = dfx_launch_analysis(st, x, B, n * hop, xs, am_in, am_out, new_spec, new_fe, s))) return rc;
     if ((rc = dfx_launch_norm_scan(new_fe, new_fe, (int)E, new_spec, F, new_fs, (int)Fd, B, n, c.norm_alpha, fp(S->erb_state),
                                    fp(S->unit_state), s)))
         return rc;
@@ -1850,6 +2092,13 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         sc.out_T = n;
         sc.out_toff = H;
         sc.serial = S->capturing;
+        DfxGate gate;
+        if (gated) {
+            gate.flags = gflags;
+            gate.thr[0] = S->thr[0], gate.thr[1] = S->thr[1], gate.thr[2] = S->thr[2];
+            gate.c0_win = gp(S->g_c0_win);
+            sc.gate = &gate;
+        }
         float *ws = reinterpret_cast<float *>(((uintptr_t)(S->buf + S->model_ws) + 255) & ~(uintptr_t)255);
         const DfxLane *ln = &m->lanes[0];
         switch (c.conv_ch) {
@@ -1859,12 +2108,47 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
             default: DFX_FAIL(DFX_ERR_UNSUPPORTED, "conv_ch");
         }
         if (rc) return rc;
+        if (gated && c.df_pathway_kernel_size_t > 1) {  // the DF decoder's delay line moves where that decoder ran
+            const int64_t frame = (int64_t)Fd * c.conv_ch;
+            dfx_launch(dfx_k_gate_c0_shift, dim3((unsigned)B, 4), dim3(256), 0, s, (const unsigned char *)gflags, gp(S->g_c0_win), B, T,
+                       c.df_pathway_kernel_size_t, frame);
+            DFX_LAUNCH_CHECK();
+        }
     }
     // ---- ISTFT of the n enhanced hops (state: overlap-add memory)
-    if ((rc = dfx_launch_synthesis(st, out_spec, B, n, sm_in, sm_out, y, n * hop, 0, n * hop, s))) return rc;
-    (void)ML;
+    if ((rc = dfx_launch_synthesis(st, out_spec, B, n, sm_in, sm_out, y, ys, 0, n * hop, s))) return rc;
     if (lsnr_out) {  // the window's lsnr is [B, T]: take the n new frames (the entries of warm-up hops are not meaningful)
-        if ((rc = stream_copy_rows(fp(S->lsnr), T, T, H, lsnr_out, n, n, B, s))) return rc;
+        if ((rc = stream_copy_rows(fp(S->lsnr), T, T, H, lsnr_out, ls, n, B, s))) return rc;
+    }
+    if (gated) {
+        // ---- who keeps which state (dfx_k_gate_commit), then the frozen streams' answer and the skip counters
+        DfxGateTable G;
+        G.n = 0;
+        auto entry = [&](float *dst, const float *src, int64_t row, unsigned char mask, unsigned char want) {
+            G.dst[G.n] = dst, G.src[G.n] = src, G.row[G.n] = row, G.mask[G.n] = mask, G.want[G.n] = want;
+            ++G.n;
+        };
+        const unsigned char FZ = DFX_GATE_FROZEN;
+        entry(am_out, am_in, ML, FZ, FZ);
+        entry(sm_out, sm_in, ML, FZ, FZ);
+        entry(fp(S->hist_fe[S->flip ^ 1]), fp(S->hist_fe[S->flip]), H * E, FZ, FZ);
+        entry(fp(S->hist_fs[S->flip ^ 1]), fp(S->hist_fs[S->flip]), H * Fd * 2, FZ, FZ);
+        entry(fp(S->hist_spec[S->flip ^ 1]), fp(S->hist_spec[S->flip]), Hs * F * 2, FZ, FZ);
+        entry(fp(S->erb_state), gp(S->g_sh_erb), E, FZ, FZ);
+        entry(fp(S->unit_state), gp(S->g_sh_unit), Fd, FZ, FZ);
+        const int nenc = (int)m->enc_gru.size(), ndec = (int)m->dec_gru.size();
+        for (int l = 0; l < S->layers; ++l) {
+            float *h = fp(S->h_state) + (int64_t)l * B * 256;
+            const float *hs = gp(S->g_sh_h) + (int64_t)l * B * 256;
+            if (l < nenc) entry(h, hs, 256, FZ, FZ);
+            else if (l < nenc + ndec) entry(h, hs, 256, DFX_GATE_GAINS, 0);   // stage 1 did not run (frozen streams included)
+            else entry(h, hs, 256, DFX_GATE_DF, 0);                           // stage 2 did not run
+        }
+        dfx_launch(dfx_k_gate_commit, dim3((unsigned)B), dim3(128), 0, s, G, (const unsigned char *)gflags, B);
+        DFX_LAUNCH_CHECK();
+        dfx_launch(dfx_k_gate_finish, dim3((unsigned)B), dim3(128), 0, s, (const unsigned char *)gflags, gcount, y, ys, (int)hop, lsnr_out,
+                   ls, B, (int)(skip >= n));
+        DFX_LAUNCH_CHECK();
     }
     return DFX_OK;
 }
@@ -1876,6 +2160,14 @@ extern "C" int dfx_stream_process(dfx_stream_state *S, const float *x, int64_t n
     const bool advances = S->lim != 1.f;  // the pass-through case leaves the state alone (tract.rs:540-543)
     const int64_t hop = S->st->hop, B = S->B;
     // steady state (every history frame is a real frame): replay the call from a graph
+    if (S->gated && advances) {  // one hop per pass: the stage decisions of hop i shape the state hop i+1 starts from
+        for (int64_t i = 0; i < n; ++i) {
+            if (int rc = stream_body(S, x + i * hop, 1, y + i * hop, lsnr_out ? lsnr_out + i : nullptr, s, n * hop, n * hop, n)) return rc;
+            S->frames += 1;
+            S->flip ^= 1;
+        }
+        return DFX_OK;
+    }
     if (S->use_graph && advances && S->frames >= S->H + S->L) {
         auto fp = [&](size_t o) { return reinterpret_cast<float *>(S->buf + o); };
         dfx_stream_state::Graph &g = S->graph[S->flip];

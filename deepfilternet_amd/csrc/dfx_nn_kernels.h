@@ -227,6 +227,9 @@ struct DfxCinArgs {
     float *out;         // [B*T, Fin, C]
     int64_t B, T;
     int Fin, L;
+    // only frames [t_begin, T) of every clip are produced; frame t of clip b is stored at row b*out_T + t - t_begin + out_toff
+    // (0, T, 0 for whole clips; the gated streaming runtime writes the newest frame into its per-stream c0 window)
+    int64_t t_begin, out_T, out_toff;
 };
 
 template <int C>
@@ -241,14 +244,15 @@ __global__ void __launch_bounds__(DFX_PW_THREADS) dfx_k_conv_in_df(DfxCinArgs A)
     float4 biasr[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) biasr[nt] = reinterpret_cast<const float4 *>(A.bias)[4 * nt + q];
-    const int64_t total = A.B * A.T * A.Fin;
+    const int64_t Tn = A.T - A.t_begin;
+    const int64_t total = A.B * Tn * A.Fin;
     const int64_t ntiles = (total + 15) / 16;
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
         const int64_t pos = tile * 16 + jl;
         const bool valid = pos < total;
         const int64_t r = pos / A.Fin;
         const int fo = (int)(pos - r * A.Fin);
-        const int64_t b = r / A.T, t = r - b * A.T;
+        const int64_t b = r / Tn, t = r - b * Tn + A.t_begin;
         float bv[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -268,7 +272,7 @@ __global__ void __launch_bounds__(DFX_PW_THREADS) dfx_k_conv_in_df(DfxCinArgs A)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[nt][ks], bv[ks], acc[nt], 0, 0, 0);
         if (valid) {
-            float4 *op = reinterpret_cast<float4 *>(A.out + pos * C + 4 * q);
+            float4 *op = reinterpret_cast<float4 *>(A.out + ((b * A.out_T + t - A.t_begin + A.out_toff) * A.Fin + fo) * C + 4 * q);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 op[4 * nt] = make_float4(fmaxf(acc[nt][0] + biasr[nt].x, 0.f), fmaxf(acc[nt][1] + biasr[nt].y, 0.f),

@@ -8,8 +8,12 @@
 
 ``process`` also accepts several hops per call (``[streams, n * hop]``, ``n <= max_frames``); the concatenated output does not depend
 on how the signal is cut.  It equals ``enhance(model, df_state, audio, pad=False)`` delayed by ``delay_frames`` hops (the first
-``delay_frames`` output hops are silence, like the reference's rolling buffers).  Not implemented: the reference's LSNR-dependent
-stage skipping and silent-input shortcut (every hop runs all stages), and multi-channel mask reduction.
+``delay_frames`` output hops are silence, like the reference's rolling buffers).
+
+``gating=True`` switches on the reference runtime's per-frame decisions (tract.rs:513-525,658-672), taken independently by every
+stream: stages are skipped according to the local SNR (``thresholds`` = min_db, max_db_erb, max_db_df; reference defaults
+-10 / 30 / 20 dB), skipped decoders keep their state, and a stream that has been silent for more than five hops is answered with
+zeros without being processed.  Not implemented: multi-channel streams (mask reduction, tract.rs:868-902).
 """
 from __future__ import annotations
 
@@ -24,7 +28,8 @@ from .model import DfNet
 
 
 class DfStream:
-    def __init__(self, model: DfNet, df_state: DF, streams: int = 1, max_frames: int = 1, atten_lim_db: Optional[float] = None):
+    def __init__(self, model: DfNet, df_state: DF, streams: int = 1, max_frames: int = 1, atten_lim_db: Optional[float] = None,
+                 gating: bool = False, thresholds: Optional[Tuple[float, float, float]] = None):
         if not isinstance(model, DfNet):
             raise TypeError("DfStream needs a deepfilternet_amd.DfNet (see init_df)")
         h = C.c_void_p()
@@ -34,6 +39,10 @@ class DfStream:
         self.streams, self.max_frames = int(streams), int(max_frames)
         if atten_lim_db is not None:
             self.set_atten_lim(atten_lim_db)
+        if thresholds is not None:
+            self.set_thresholds(*thresholds)
+        if gating:
+            self.set_gating(True)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -60,6 +69,15 @@ class DfStream:
     def set_post_filter_beta(self, beta: float) -> None:
         """df_set_post_filter_beta (capi.rs:146): 0 disables the post filter."""
         _lib.check(_lib.lib().dfx_stream_set_post_filter_beta(self._h, float(beta)))
+
+    def set_gating(self, enable: bool) -> None:
+        """DfTract::process's stage skipping and silent-input shortcut (tract.rs:513-525,658-672), per stream."""
+        _lib.check(_lib.lib().dfx_stream_set_gating(self._h, int(bool(enable))))
+
+    def set_thresholds(self, min_db_thresh: float, max_db_erb_thresh: float, max_db_df_thresh: float) -> None:
+        """RuntimeParams::with_thresholds (tract.rs:160-170)."""
+        _lib.check(_lib.lib().dfx_stream_set_thresholds(self._h, float(min_db_thresh), float(max_db_erb_thresh),
+                                                        float(max_db_df_thresh)))
 
     def reset(self) -> None:
         _lib.check(_lib.lib().dfx_stream_reset(self._h, _lib.stream()))

@@ -205,8 +205,14 @@ int dfx_enhance(const dfx_model *m, const dfx_state *st, const float *x, int64_t
  *   on top of the fft-hop samples of the STFT: output hop k is the enhanced input hop k - lookahead; the first `lookahead`
  *   output hops are zero (tract.rs: the rolling spectra start as zeros).  Concatenated over calls, the output equals
  *   dfx_enhance(pad=0) of the whole signal delayed by `lookahead` hops — however the signal is cut into calls.
- *   Not implemented (the reference does them per frame on the CPU): the LSNR-dependent stage skipping (tract.rs:658-672) and the
- *   silent-input shortcut (:513-525) — every frame runs all stages; multi-channel mask reduction (:868-902).
+ *   Stage gating (off by default; dfx_stream_set_gating): the reference decides per frame from the encoder's local SNR whether the
+ *   ERB decoder (stage 1) and the DF decoder (stage 2) run — `apply_stages`, tract.rs:658-672, thresholds of RuntimeParams
+ *   (:160-189, defaults -10 / 30 / 20 dB) — and answers a stream that has been silent (mean square < 1e-7) for more than 5 hops with
+ *   zeros and lsnr = -15 without processing it (:513-525).  With gating on every stream takes these decisions on its own, hop by
+ *   hop: lsnr < min: zero mask, no DF; lsnr > max_erb: the spectrum passes unchanged; lsnr > max_df: mask only; otherwise mask +
+ *   DF.  A decoder that is skipped keeps its state (GRU hidden states, the delay line in front of df_convp), a frozen stream all of
+ *   its state, exactly like tract's pulsed sub-models, which only advance when they are run.  A call of n hops is then n passes.
+ *   Not implemented: multi-channel streams and their mask reduction (tract.rs:868-902; df_create is mono, capi.rs:83-104).
  * lsnr (optional) receives the local SNR estimate [streams, n] in dB (df_process_frame's return value); not meaningful for the
  * warm-up hops.
  * ---------------------------------------------------------------------------------------------------------------- */
@@ -218,6 +224,9 @@ int dfx_stream_frame_length(const dfx_stream_state *s);                  /* hop 
 int dfx_stream_delay_frames(const dfx_stream_state *s);                  /* lookahead in hops */
 int dfx_stream_set_atten_lim(dfx_stream_state *s, float lim_db);         /* df_set_atten_lim: |dB| >= 100 off, < 0.01 bypass */
 int dfx_stream_set_post_filter_beta(dfx_stream_state *s, float beta);    /* df_set_post_filter_beta: 0 disables the post filter */
+int dfx_stream_set_gating(dfx_stream_state *s, int enable);              /* DfTract::process's per-frame stage decisions, per stream */
+int dfx_stream_set_thresholds(dfx_stream_state *s, float min_db_thresh, float max_db_erb_thresh,
+                              float max_db_df_thresh);                   /* RuntimeParams::with_thresholds (tract.rs:160-170) */
 int dfx_stream_process(dfx_stream_state *s, const float *x, int64_t n_frames, float *y, float *lsnr, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -163,19 +163,10 @@ def post_filter(spec: Tensor, spec_e: Tensor, beta: float) -> Tensor:
 
 
 @torch.no_grad()
-def dfnet_forward(p: ModelParams, sd: Dict[str, Tensor], widths: np.ndarray, spec: Tensor, feat_erb: Tensor,
-                  feat_spec: Tensor, manual_gru: bool = False) -> Dict[str, Tensor]:
-    """deepfilternet3.py:389-456 DfNet.forward (lsnr_dropout=False path).
-
-    spec [B,1,T,F,2], feat_erb [B,1,T,E], feat_spec [B,1,T,F',2]  (all float32).
-    Returns dict with spec_e [B,1,T,F,2], m [B,1,T,E], lsnr [B,T,1], df_coefs [B,O,T,F',2] plus intermediates.
-    """
-    C, O = p.conv_ch, p.df_order
+def dfnet_encoder(p: ModelParams, sd, fe: Tensor, fs: Tensor, manual_gru: bool = False) -> Dict[str, Tensor]:
+    """deepfilternet3.py:166-185 Encoder.forward.  fe [B,1,T,E], fs [B,2,T,F'] (already shifted by pad_feat)."""
+    C = p.conv_ch
     ck, cki = tuple(p.conv_kernel), tuple(p.conv_kernel_inp)
-    fs = feat_spec.squeeze(1).permute(0, 3, 1, 2)  # [B,2,T,F']   :407
-    fe = pad_feat(feat_erb, p.conv_lookahead)      # :409
-    fs = pad_feat(fs, p.conv_lookahead)            # :410
-    # Encoder.forward :166-185
     e0 = conv_norm_act(fe, sd, "enc.erb_conv0", 1, C, cki)
     e1 = conv_norm_act(e0, sd, "enc.erb_conv1", C, C, ck, fstride=2)
     e2 = conv_norm_act(e1, sd, "enc.erb_conv2", C, C, ck, fstride=2)
@@ -188,7 +179,15 @@ def dfnet_forward(p: ModelParams, sd: Dict[str, Tensor], widths: np.ndarray, spe
     emb = squeezed_gru(emb_in, sd, "enc.emb_gru", 1, True, manual_gru)
     lsnr = torch.sigmoid(F.linear(emb, _t(sd, "enc.lsnr_fc.0.weight"), _t(sd, "enc.lsnr_fc.0.bias")))
     lsnr = lsnr * (p.lsnr_max - p.lsnr_min) + p.lsnr_min
-    # ErbDecoder.forward :245-254
+    return {"e0": e0, "e1": e1, "e2": e2, "e3": e3, "c0": c0, "c1": c1, "cemb": cemb, "emb_in": emb_in, "emb": emb, "lsnr": lsnr}
+
+
+@torch.no_grad()
+def dfnet_erb_decoder(p: ModelParams, sd, emb: Tensor, e3: Tensor, e2: Tensor, e1: Tensor, e0: Tensor,
+                      manual_gru: bool = False) -> Dict[str, Tensor]:
+    """deepfilternet3.py:245-254 ErbDecoder.forward -> m [B,1,T,E]."""
+    C = p.conv_ch
+    ck = tuple(p.conv_kernel)
     b, _, t, f8 = e3.shape
     d_emb = squeezed_gru(emb, sd, "erb_dec.emb_gru", p.emb_num_layers - 1, True, manual_gru)
     d_emb = d_emb.view(b, t, f8, -1).permute(0, 3, 1, 2)
@@ -199,10 +198,14 @@ def dfnet_forward(p: ModelParams, sd: Dict[str, Tensor], widths: np.ndarray, spe
                         tuple(p.convt_kernel), 2)
     m = conv_norm_act(conv_norm_act(e0, sd, "erb_dec.conv0p", C, C, (1, 1)) + d1, sd, "erb_dec.conv0_out", C, 1, ck,
                       act="sigmoid")
-    # Mask :248-269 (no post filter / atten_lim inside the module for DF3)
-    spec_c = torch.view_as_complex(spec.squeeze(1).contiguous())  # [B,T,F]
-    spec_m = spec_c * band_gain(m.squeeze(1), widths)
-    # DfDecoder.forward :323-331
+    return {"m": m, "d3": d3, "d2": d2, "d1": d1}
+
+
+@torch.no_grad()
+def dfnet_df_decoder(p: ModelParams, sd, emb: Tensor, c0: Tensor, manual_gru: bool = False) -> Dict[str, Tensor]:
+    """deepfilternet3.py:323-331 DfDecoder.forward + DfOutputReshapeMF :268-275 -> df_coefs [B,O,T,F',2]."""
+    C, O = p.conv_ch, p.df_order
+    b, t, _ = emb.shape
     c = squeezed_gru(emb, sd, "df_dec.df_gru", p.df_num_layers, False, manual_gru)
     if p.df_gru_skip == "groupedlinear":
         c = c + grouped_linear(emb, _t(sd, "df_dec.df_skip.weight"))
@@ -211,19 +214,40 @@ def dfnet_forward(p: ModelParams, sd: Dict[str, Tensor], widths: np.ndarray, spe
     c0p = conv_norm_act(c0, sd, "df_dec.df_convp", C, 2 * O, (p.df_pathway_kernel_size_t, 1)).permute(0, 2, 3, 1)
     c = torch.tanh(grouped_linear(c, _t(sd, "df_dec.df_out.0.weight")))
     c = c.view(b, t, p.nb_df, 2 * O) + c0p                      # [B,T,F',2O]
-    # DfOutputReshapeMF :268-275 -> [B,O,T,F',2]
     df_coefs = c.view(b, t, p.nb_df, O, 2).permute(0, 3, 1, 2, 4)
-    coefs_c = torch.view_as_complex(df_coefs.contiguous())
+    return {"df_coefs": df_coefs.contiguous(), "c0p": c0p, "coefs_raw": c}
+
+
+@torch.no_grad()
+def dfnet_forward(p: ModelParams, sd: Dict[str, Tensor], widths: np.ndarray, spec: Tensor, feat_erb: Tensor,
+                  feat_spec: Tensor, manual_gru: bool = False) -> Dict[str, Tensor]:
+    """deepfilternet3.py:389-456 DfNet.forward (lsnr_dropout=False path).
+
+    spec [B,1,T,F,2], feat_erb [B,1,T,E], feat_spec [B,1,T,F',2]  (all float32).
+    Returns dict with spec_e [B,1,T,F,2], m [B,1,T,E], lsnr [B,T,1], df_coefs [B,O,T,F',2] plus intermediates.
+    """
+    O = p.df_order
+    fs = feat_spec.squeeze(1).permute(0, 3, 1, 2)  # [B,2,T,F']   :407
+    fe = pad_feat(feat_erb, p.conv_lookahead)      # :409
+    fs = pad_feat(fs, p.conv_lookahead)            # :410
+    enc = dfnet_encoder(p, sd, fe, fs, manual_gru)
+    dec = dfnet_erb_decoder(p, sd, enc["emb"], enc["e3"], enc["e2"], enc["e1"], enc["e0"], manual_gru)
+    m = dec["m"]
+    # Mask :248-269 (no post filter / atten_lim inside the module for DF3)
+    spec_c = torch.view_as_complex(spec.squeeze(1).contiguous())  # [B,T,F]
+    spec_m = spec_c * band_gain(m.squeeze(1), widths)
+    dfd = dfnet_df_decoder(p, sd, enc["emb"], enc["c0"], manual_gru)
+    coefs_c = torch.view_as_complex(dfd["df_coefs"])
     # MF.DF on the *noisy* spec (:442), then high bins from the masked spec (:443)
     spec_e = spec_m.clone()
     spec_e[..., : p.nb_df] = df_apply(spec_c, coefs_c, O, p.df_lookahead, p.nb_df)
     if p.mask_pf:
         spec_e = post_filter(spec_c, spec_e, p.pf_beta)
-    return {
-        "spec_e": torch.view_as_real(spec_e).unsqueeze(1), "m": m, "lsnr": lsnr, "df_coefs": df_coefs.contiguous(),
-        "e0": e0, "e1": e1, "e2": e2, "e3": e3, "c0": c0, "c1": c1, "cemb": cemb, "emb_in": emb_in, "emb": emb,
-        "d3": d3, "d2": d2, "d1": d1, "c0p": c0p, "coefs_raw": c,
-    }
+    out = {"spec_e": torch.view_as_real(spec_e).unsqueeze(1)}
+    out.update(enc)
+    out.update(dec)
+    out.update(dfd)
+    return out
 
 
 def df_features(libdf, audio: np.ndarray, df_state, nb_df: int, alpha: float):

@@ -1,0 +1,164 @@
+"""CPU restatement of the reference's real-time frame loop ``DfTract::process`` — TEST INFRASTRUCTURE ONLY.
+
+Follows /root/reference/libDF/src/tract.rs:
+  * :509-525  silent-input shortcut: ``rms = sum(x^2)/len`` (a mean square, accumulated sequentially in f32); below 1e-7 the
+              skip counter goes up, otherwise it is cleared; above 5 the hop is answered with zeros and lsnr = -15 and *nothing*
+              else runs (no STFT, no state moves);
+  * :540-543  attenuation limit 1.0 (|dB| < 0.01): the hop is passed through, lsnr = 35;
+  * :545-567  stage 1: gains present -> mask applied and the skip counter cleared; gains absent (lsnr above the ERB threshold)
+              -> counter += 1;
+  * :571-581  stage 2: DF only when its coefficients were produced;
+  * :603-610  post filter only when stage 1 ran (``apply_erb``) and it is switched on;
+  * :612-616  attenuation-limit mix;
+  * :658-672  ``apply_stages``: lsnr < min_db_thresh -> zero mask, no DF; > max_db_erb_thresh -> nothing; > max_db_df_thresh ->
+              mask only; else mask + DF.  Defaults -10 / 30 / 20 dB (:177-189).
+
+Third-party boundary: the three sub-networks are *pulsed* tract 0.21.4 models (tract.rs:769-999, not available here), each a
+stateful runner that only advances when it is run.  A decoder that is skipped for a frame therefore keeps its state (GRU hidden
+state, the (kt-1)-frame delay line in front of ``df_convp``): each decoder sees the *compacted* sequence of the frames it ran on —
+the same thing the reference's PyTorch model does under ``lsnr_dropout`` (deepfilternet3.py:413-441: ``emb[:, idcs]``,
+``c0[:, :, idcs]``).  This restatement expresses exactly that with the batch oracle (dfnet_oracle, pinned against the reference's
+goldens): encoder over the accepted hops, ERB decoder over the stage-1 frames, DF decoder over the stage-2 frames.
+Parity against tract itself is **unpinned** (no Rust toolchain, no ONNX models in the container): with every threshold at
++-inf this oracle reduces to the batch path delayed by the lookahead, which is pinned.
+
+Warm-up: like dfx_stream_process the first ``lookahead`` accepted hops of a stream produce silence and take no stage decision.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from deepfilternet_amd.config import ModelParams
+
+from . import dfnet_oracle as O
+from . import libdf_oracle as L
+
+MIN_DB_THRESH, MAX_DB_ERB_THRESH, MAX_DB_DF_THRESH = -10.0, 30.0, 20.0   # RuntimeParams::default_with_ch, tract.rs:177-189
+
+
+def apply_stages(lsnr: float, thr: Tuple[float, float, float]) -> Tuple[bool, bool, bool]:
+    """tract.rs:658-672 -> (apply_gains, apply_gain_zeros, apply_df)."""
+    if lsnr < thr[0]:
+        return False, True, False
+    if lsnr > thr[1]:
+        return False, False, False
+    if lsnr > thr[2]:
+        return True, False, False
+    return True, False, True
+
+
+def hop_mean_square(x: np.ndarray) -> np.float32:
+    """tract.rs:513-516: fold over the hop in f32, acc + x.powi(2), divided by the length."""
+    e = np.float32(0.0)
+    for v in x.astype(np.float32):
+        e = np.float32(e + np.float32(v * v))
+    return np.float32(e / np.float32(len(x)))
+
+
+def _features(p: ModelParams, hops: np.ndarray):
+    st = L.DF(p.sr, p.fft_size, p.hop_size, p.nb_erb, p.min_nb_freqs)
+    audio = np.ascontiguousarray(hops.reshape(1, -1), dtype=np.float32)
+    spec, fe, fs = O.df_features(L, audio, st, p.nb_df, p.norm_alpha())
+    return st, spec, fe, fs
+
+
+def _encoder(p: ModelParams, sd, fe: np.ndarray, fs: np.ndarray):
+    fe_t = O.pad_feat(torch.from_numpy(fe).unsqueeze(1), p.conv_lookahead)
+    fs_t = torch.view_as_real(torch.from_numpy(fs)).unsqueeze(1).squeeze(1).permute(0, 3, 1, 2)
+    fs_t = O.pad_feat(fs_t, p.conv_lookahead)
+    return O.dfnet_encoder(p, sd, fe_t, fs_t)
+
+
+@torch.no_grad()
+def process_stream(p: ModelParams, sd: Dict[str, torch.Tensor], x: np.ndarray, atten_lim_db: Optional[float] = None,
+                   pf_beta: Optional[float] = None,
+                   thresholds: Tuple[float, float, float] = (MIN_DB_THRESH, MAX_DB_ERB_THRESH, MAX_DB_DF_THRESH)):
+    """One mono stream, hop by hop.  x f32 [n_hops*hop] -> (y f32 [n_hops*hop], lsnr f32 [n_hops], info dict).
+
+    info["accepted"]: hop indices that were processed; info["flags"]: per net position (apply_gains, zeros, apply_df)."""
+    assert p.conv_lookahead == p.df_lookahead, "like dfx_stream_create"
+    hop, Lk, O_ = p.hop_size, p.df_lookahead, p.df_order
+    n_hops = len(x) // hop
+    hops = np.ascontiguousarray(x[: n_hops * hop].reshape(n_hops, hop), dtype=np.float32)
+    y = np.zeros_like(hops)
+    lsnr_out = np.zeros(n_hops, dtype=np.float32)
+    lim = None
+    if atten_lim_db is not None:
+        a = abs(atten_lim_db)
+        lim = None if a >= 100 else (1.0 if a < 0.01 else float(np.float32(10.0) ** np.float32(-a / 20.0)))
+    if lim == 1.0:  # dfx_stream_process: pass-through, no state moves at all
+        return hops.reshape(-1).copy(), np.full(n_hops, 35.0, np.float32), {"accepted": [], "flags": []}
+    beta = pf_beta if pf_beta is not None else (p.pf_beta if p.mask_pf else 0.0)
+    # ---- pass 1: which hops are processed.  The decision for hop a depends on the lsnr of earlier positions (counter += 1 when the
+    # gains were skipped), which is causal: the encoder run on the accepted prefix gives it (prefix property of the batch path).
+    accepted, skip_counter, lsnr_pos = [], 0, []
+    for a in range(n_hops):
+        if hop_mean_square(hops[a]) < np.float32(1e-7):
+            skip_counter += 1
+        else:
+            skip_counter = 0
+        if skip_counter > 5:
+            lsnr_out[a] = -15.0
+            continue
+        accepted.append(a)
+        k = len(accepted) - 1
+        pos = k - Lk
+        if pos < 0:
+            continue
+        _, _, fe, fs = _features(p, hops[accepted])
+        v = float(_encoder(p, sd, fe, fs)["lsnr"][0, pos, 0])
+        lsnr_pos.append(v)
+        g, z, _ = apply_stages(v, thresholds)
+        skip_counter = 0 if (g or z) else skip_counter + 1
+    K = len(accepted)
+    if K == 0:
+        return y.reshape(-1), lsnr_out, {"accepted": [], "flags": []}
+    # ---- pass 2: the accepted hops as one sequence; positions 0 .. K-1-Lk are emitted at steps Lk .. K-1
+    st, spec, fe, fs = _features(p, hops[accepted])
+    enc = _encoder(p, sd, fe, fs)
+    P = max(K - Lk, 0)
+    lsnr = enc["lsnr"][0, :, 0].numpy()
+    flags = [apply_stages(float(lsnr[q]), thresholds) for q in range(P)]
+    F = p.fft_size // 2 + 1
+    widths = st.erb_widths()
+    spec_t = torch.from_numpy(spec)                                    # [1, K, F] complex
+    gains = torch.ones(P, p.nb_erb)
+    idx_g = [q for q in range(P) if flags[q][0]]
+    idx_d = [q for q in range(P) if flags[q][2]]
+    for q in range(P):
+        if flags[q][1]:
+            gains[q] = 0.0
+    if idx_g:
+        ig = torch.as_tensor(idx_g)
+        m = O.dfnet_erb_decoder(p, sd, enc["emb"][:, ig], enc["e3"][:, :, ig], enc["e2"][:, :, ig], enc["e1"][:, :, ig],
+                                enc["e0"][:, :, ig])["m"]
+        gains[ig] = m[0, 0]
+    spec_e = spec_t[0, :P] * O.band_gain(gains, widths)                # mask on frame q (rolling_spec_buf_y[df_order-1])
+    if idx_d:
+        idd = torch.as_tensor(idx_d)
+        coefs = O.dfnet_df_decoder(p, sd, enc["emb"][:, idd], enc["c0"][:, :, idd])["df_coefs"]   # [1,O,nd,F',2]
+        cc = torch.view_as_complex(coefs.contiguous())[0]              # [O, nd, F']
+        xp = torch.view_as_real(spec_t[0, :, : p.nb_df])
+        xp = torch.nn.functional.pad(xp, (0, 0, 0, 0, O_ - 1 - Lk, Lk))
+        xp = torch.view_as_complex(xp.contiguous())                    # frame q + n - (O-1-la) at row q + n
+        for j, q in enumerate(idx_d):
+            acc = torch.zeros(p.nb_df, dtype=spec_t.dtype)
+            for n in range(O_):
+                acc = acc + cc[n, j] * xp[q + n]
+            spec_e[q, : p.nb_df] = acc
+    if beta > 0:
+        for q in idx_g:                                                # tract.rs:603-610: only when stage 1 ran
+            spec_e[q] = O.post_filter(spec_t[0, q], spec_e[q], beta)
+    if lim is not None:
+        spec_e = spec_t[0, :P] * lim + spec_e * (1 - lim)
+    out_spec = np.zeros((1, K, F), dtype=np.complex64)
+    out_spec[0, Lk:] = spec_e.numpy()
+    ys = st.synthesis(out_spec).reshape(K, hop)
+    for k, a in enumerate(accepted):
+        y[a] = ys[k]
+        if k >= Lk:
+            lsnr_out[a] = lsnr[k - Lk]
+    return y.reshape(-1), lsnr_out, {"accepted": accepted, "flags": flags, "lsnr_pass1": lsnr_pos}

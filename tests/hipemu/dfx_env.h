@@ -513,6 +513,7 @@ static inline float dfx_fast_exp(float x) { return expf(x); }
 static inline float dfx_fast_rcp(float x) { return 1.0f / x; }
 static inline float __fadd_rn(float a, float b) { return a + b; }  // the emulator is built with -ffp-contract=off
 static inline float __fmul_rn(float a, float b) { return a * b; }
+static inline float __fdiv_rn(float a, float b) { return a / b; }
 static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
 
 #define DFX_OPAQUE(x) asm volatile("" : "+r"(x))
