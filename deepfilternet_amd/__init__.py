@@ -13,7 +13,7 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 from .config import ModelParams  # noqa: F401,E402
 
 __version__ = "0.1.0"
-__all__ = ["ModelParams", "init_df", "enhance", "df_features", "DfNet", "libdf"]
+__all__ = ["ModelParams", "init_df", "enhance", "df_features", "DfNet", "libdf", "export_dfx"]
 
 
 def __getattr__(name):
@@ -26,6 +26,10 @@ def __getattr__(name):
         from .model import DfNet
 
         return DfNet
+    if name == "export_dfx":
+        from .model import export_dfx
+
+        return export_dfx
     if name == "libdf":
         import importlib
 

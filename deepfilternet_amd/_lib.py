@@ -76,6 +76,8 @@ SIGNATURES = {
     "dfx_model_blob_floats": (_i, [C.POINTER(ModelCfg), C.POINTER(_i64)]),
     "dfx_model_create": (_i, [C.POINTER(ModelCfg), _f32p, C.POINTER(_vp)]),
     "dfx_model_free": (None, [_vp]),
+    "dfx_model_save_file": (_i, [C.POINTER(ModelCfg), _f32p, C.c_char_p]),
+    "dfx_model_load_file": (_i, [C.c_char_p, C.POINTER(_vp)]),
     "dfx_model_cfg_get": (_i, [_vp, C.POINTER(ModelCfg)]),
     "dfx_model_set_streams": (_i, [_vp, _i]),
     "dfx_model_set_pipeline": (_i, [_vp, _i, _i, _i]),

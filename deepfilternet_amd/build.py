@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 REPO = os.path.dirname(HERE)
 LIB = os.path.join(CSRC, "libdfx.so")
-SOURCES = ["dfx_dsp.hip", "dfx_model.hip"]
+SOURCES = ["dfx_dsp.hip", "dfx_model.hip", "dfx_capi.hip"]
 ARCH = "gfx950"
 
 
@@ -32,6 +32,7 @@ def _deps() -> List[str]:
     for root, _, files in os.walk(CSRC):
         out += [os.path.join(root, f) for f in files if f.endswith((".h", ".hip"))]
     out.append(os.path.join(REPO, "include", "dfx.h"))
+    out.append(os.path.join(REPO, "include", "df_capi.h"))
     return out
 
 

@@ -1,0 +1,162 @@
+// The reference's C API (libDF/src/capi.rs) on top of the dfx streaming runtime, and the .dfx model file it loads.
+#include <cmath>
+#include <deque>
+#include <string>
+
+#include "dfx_common.h"
+#include "df_capi.h"
+
+// ---------------------------------------------------------------------------------------------------- .dfx model files
+// "DFXM" | u32 version | u32 sizeof(dfx_model_cfg) | dfx_model_cfg | i64 n_floats | float32[n_floats]   (little endian)
+// The floats are the raw reference state-dict tensors packed per dfx_model_tensor_info — what dfx_model_create takes.
+static const char DFX_FILE_MAGIC[4] = {'D', 'F', 'X', 'M'};
+static const uint32_t DFX_FILE_VERSION = 1;
+
+extern "C" int dfx_model_save_file(const dfx_model_cfg *cfg, const float *blob_host, const char *path) {
+    if (!cfg || !blob_host || !path) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_save_file: null argument");
+    int64_t n = 0;
+    if (int rc = dfx_model_blob_floats(cfg, &n)) return rc;
+    FILE *f = fopen(path, "wb");
+    if (!f) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_save_file: cannot open '%s' for writing", path);
+    const uint32_t ver = DFX_FILE_VERSION, csz = (uint32_t)sizeof(dfx_model_cfg);
+    bool ok = fwrite(DFX_FILE_MAGIC, 1, 4, f) == 4 && fwrite(&ver, 4, 1, f) == 1 && fwrite(&csz, 4, 1, f) == 1 &&
+              fwrite(cfg, sizeof(*cfg), 1, f) == 1 && fwrite(&n, 8, 1, f) == 1 && fwrite(blob_host, 4, (size_t)n, f) == (size_t)n;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_save_file: short write to '%s'", path);
+    return DFX_OK;
+}
+
+static int read_model_file(const char *path, dfx_model_cfg *cfg, std::vector<float> *blob) {
+    FILE *f = fopen(path, "rb");
+    if (!f) DFX_FAIL(DFX_ERR_INVALID_ARG, "cannot open model file '%s'", path);
+    char magic[4];
+    uint32_t ver = 0, csz = 0;
+    int64_t n = 0, want = -1;
+    bool ok = fread(magic, 1, 4, f) == 4 && memcmp(magic, DFX_FILE_MAGIC, 4) == 0 && fread(&ver, 4, 1, f) == 1 && ver == DFX_FILE_VERSION &&
+              fread(&csz, 4, 1, f) == 1 && csz == sizeof(dfx_model_cfg) && fread(cfg, sizeof(*cfg), 1, f) == 1 && fread(&n, 8, 1, f) == 1;
+    if (ok) ok = dfx_model_blob_floats(cfg, &want) == DFX_OK && want == n;
+    if (ok) {
+        blob->resize((size_t)n);
+        ok = fread(blob->data(), 4, (size_t)n, f) == (size_t)n;
+    }
+    fclose(f);
+    if (!ok) DFX_FAIL(DFX_ERR_INVALID_ARG, "'%s' is not a valid .dfx model file (version %u)", path, DFX_FILE_VERSION);
+    return DFX_OK;
+}
+
+extern "C" int dfx_model_load_file(const char *path, dfx_model **out) {
+    if (!path || !out) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_load_file: null argument");
+    dfx_model_cfg cfg;
+    std::vector<float> blob;
+    if (int rc = read_model_file(path, &cfg, &blob)) return rc;
+    return dfx_model_create(&cfg, blob.data(), out);
+}
+
+// ---------------------------------------------------------------------------------------------------- df_* (capi.rs)
+struct DFState {
+    dfx_model *model = nullptr;
+    dfx_state *st = nullptr;
+    dfx_stream_state *rt = nullptr;
+    float *d_io = nullptr;  // [hop] in, [hop] out, [1] lsnr
+    int hop = 0;
+    bool logging = false;
+    std::deque<std::string> log;
+    void msg(const char *level, const std::string &text) {
+        if (logging) log.push_back(std::string(level) + " | DF | " + text);  // capi.rs:47-57: "{level} | {target} | {message}"
+    }
+};
+
+static void df_destroy(DFState *s) {
+    if (!s) return;
+    if (s->rt) dfx_stream_free(s->rt);
+    if (s->st) dfx_state_free(s->st);
+    if (s->model) dfx_model_free(s->model);
+    if (s->d_io) (void)hipFree(s->d_io);
+    delete s;
+}
+
+static void df_panic(const char *what) {  // the reference's `expect(...)`: message on stderr, then abort
+    fprintf(stderr, "%s: %s\n", what, dfx_last_error());
+    abort();
+}
+
+extern "C" DFState *df_create(const char *path, float atten_lim, const char *log_level) {
+    if (!path) {
+        dfx_set_error("df_create: null path");
+        return nullptr;
+    }
+    DFState *s = new DFState();
+    s->logging = log_level != nullptr;
+    dfx_model_cfg c;
+    bool ok = dfx_model_load_file(path, &s->model) == DFX_OK && dfx_model_cfg_get(s->model, &c) == DFX_OK &&
+              dfx_state_create(c.sr, c.fft_size, c.hop_size, c.nb_erb, c.min_nb_freqs, &s->st) == DFX_OK &&
+              dfx_stream_create(s->model, s->st, 1, 1, &s->rt) == DFX_OK &&
+              dfx_stream_set_gating(s->rt, 1) == DFX_OK &&  // RuntimeParams::default_with_ch(1): thresholds -10 / 30 / 20 dB
+              dfx_stream_set_post_filter_beta(s->rt, 0.f) == DFX_OK && dfx_stream_set_atten_lim(s->rt, atten_lim) == DFX_OK;
+    if (ok) {
+        s->hop = c.hop_size;
+        ok = hipMalloc(reinterpret_cast<void **>(&s->d_io), ((size_t)2 * s->hop + 1) * sizeof(float)) == hipSuccess;
+        if (!ok) dfx_set_error("df_create: device allocation failed");
+    }
+    if (!ok) {
+        df_destroy(s);
+        return nullptr;
+    }
+    char buf[160];
+    snprintf(buf, sizeof(buf), "Running with model type deepfilternet3 lookahead %d", dfx_stream_delay_frames(s->rt));  // tract.rs:318-322
+    s->msg("INFO", buf);
+    const float lim = fabsf(atten_lim);
+    if (lim >= 100.f) {
+    } else if (lim < 0.01f) {
+        s->msg("WARN", "Attenuation limit too strong. No noise reduction will be performed");  // tract.rs:291-293
+    } else {
+        snprintf(buf, sizeof(buf), "Running with an attenuation limit of %.0f dB", lim);  // tract.rs:295
+        s->msg("INFO", buf);
+    }
+    return s;
+}
+
+extern "C" size_t df_get_frame_length(DFState *st) {
+    if (!st) df_panic("Invalid pointer");
+    return (size_t)st->hop;
+}
+
+extern "C" char *df_next_log_msg(DFState *st) {
+    if (!st) df_panic("Invalid pointer");
+    if (st->log.empty()) return nullptr;
+    const std::string m = st->log.front();
+    st->log.pop_front();
+    char *out = static_cast<char *>(malloc(m.size() + 1));
+    if (out) memcpy(out, m.c_str(), m.size() + 1);
+    return out;
+}
+
+extern "C" void df_free_log_msg(char *ptr) { free(ptr); }
+
+extern "C" void df_set_atten_lim(DFState *st, float lim_db) {
+    if (!st) df_panic("Invalid pointer");
+    (void)dfx_stream_set_atten_lim(st->rt, lim_db);
+}
+
+extern "C" void df_set_post_filter_beta(DFState *st, float beta) {
+    if (!st) df_panic("Invalid pointer");
+    if (beta < 0.f) {  // tract.rs:380-384
+        st->msg("WARN", "Post-filter beta cannot be smaller than 0.");
+        beta = 0.f;
+    }
+    (void)dfx_stream_set_post_filter_beta(st->rt, beta);
+}
+
+extern "C" float df_process_frame(DFState *st, float *input, float *output) {
+    if (!st || !input || !output) df_panic("Invalid pointer");
+    const size_t hb = (size_t)st->hop * sizeof(float);
+    float *dx = st->d_io, *dy = st->d_io + st->hop, *dl = st->d_io + 2 * st->hop;
+    float lsnr = 0.f;
+    if (hipMemcpy(dx, input, hb, hipMemcpyHostToDevice) != hipSuccess) df_panic("Failed to process DF frame (upload)");
+    if (dfx_stream_process(st->rt, dx, 1, dy, dl, nullptr) != DFX_OK) df_panic("Failed to process DF frame");
+    if (hipMemcpy(output, dy, hb, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&lsnr, dl, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+        df_panic("Failed to process DF frame (download)");
+    return lsnr;
+}
+
+extern "C" void df_free(DFState *model) { df_destroy(model); }

@@ -193,3 +193,26 @@ def read_cp(dirname: str, epoch="best") -> Tuple[Optional[Dict[str, torch.Tensor
     for k, v in sd.items():  # checkpoint.py:86-92: rename legacy 'clc' keys
         out[k.replace("clc", "df")] = v
     return out, ep
+
+
+# ---------------------------------------------------------------------------------------------------- .dfx model files
+def export_dfx(path: str, model_base_dir: Optional[str] = None, epoch="best", *, params: Optional[ModelParams] = None,
+               state_dict: Optional[Dict[str, "np.ndarray | torch.Tensor"]] = None) -> str:
+    """Writes the model file that the C API's ``df_create(path, ...)`` (include/df_capi.h == libDF/src/capi.rs:83-104) and
+    ``dfx_model_load_file`` read: configuration + raw float32 state-dict (the role of the reference's ``export.py`` tar.gz of ONNX
+    graphs, export.py:331-337 / tract.rs:37-70).  Source: a reference model directory (``config.ini`` + ``checkpoints/``) or
+    ``params`` + ``state_dict``.  Needs libdfx.so for the tensor manifest, not a GPU."""
+    if params is None:
+        if model_base_dir is None:
+            raise ValueError("export_dfx needs a model directory or params= + state_dict=")
+        params = ModelParams.from_ini(os.path.join(model_base_dir, "config.ini"), must_exist=True)
+    if state_dict is None:
+        if model_base_dir is None:
+            raise ValueError("export_dfx needs a model directory or params= + state_dict=")
+        state_dict, _ = read_cp(os.path.join(model_base_dir, "checkpoints"), epoch)
+        if state_dict is None:
+            raise FileNotFoundError("Could not find a checkpoint")
+    cfg = make_cfg(params)
+    blob = pack_state_dict(cfg, state_dict)
+    _lib.check(_lib.lib().dfx_model_save_file(C.byref(cfg), blob.ctypes.data_as(C.POINTER(C.c_float)), os.fsencode(path)))
+    return path

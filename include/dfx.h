@@ -160,6 +160,11 @@ typedef struct dfx_model dfx_model;
  * uploads them.  blob_host: float32[dfx_model_blob_floats] packed per dfx_model_tensor_info. */
 int dfx_model_create(const dfx_model_cfg *cfg, const float *blob_host, dfx_model **out);
 void dfx_model_free(dfx_model *m);
+/* .dfx model file = the configuration + the packed blob above ("DFXM", version, cfg, float32 data; written by
+ * deepfilternet_amd.export_dfx from a reference model directory or state-dict).  It is what df_create() (include/df_capi.h, the
+ * reference's C API) takes as its model path, in place of the reference's tar.gz of ONNX graphs (tract.rs:37-70). */
+int dfx_model_save_file(const dfx_model_cfg *cfg, const float *blob_host, const char *path);
+int dfx_model_load_file(const char *path, dfx_model **out);
 int dfx_model_cfg_get(const dfx_model *m, dfx_model_cfg *out);
 /* The forward pass runs its independent branches (ERB encoder/decoder | DF encoder/decoder | df_convp) on internal
  * streams, forked from and joined to the caller's stream with events.  enable = 0 serialises everything on the caller's

@@ -10,11 +10,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(REPO, "deepfilternet_amd", "csrc")
 OUT = os.path.join(HERE, "_build", "libdfx_emu.so")
-SOURCES = ["dfx_dsp.hip", "dfx_model.hip"]
+SOURCES = ["dfx_dsp.hip", "dfx_model.hip", "dfx_capi.hip"]
 
 
 def _deps():
-    out = [os.path.join(HERE, "dfx_env.h"), os.path.join(REPO, "include", "dfx.h")]
+    out = [os.path.join(HERE, "dfx_env.h"), os.path.join(REPO, "include", "dfx.h"), os.path.join(REPO, "include", "df_capi.h")]
     for f in os.listdir(CSRC):
         if f.endswith((".h", ".hip")):
             out.append(os.path.join(CSRC, f))

@@ -1,0 +1,99 @@
+"""The reference's C API (libDF/src/capi.rs:83-253: df_create / df_get_frame_length / df_next_log_msg / df_set_atten_lim /
+df_set_post_filter_beta / df_process_frame / df_free) served by libdfx.so (include/df_capi.h), called through ctypes exactly as a C
+host would call it: host float buffers of one hop, one mono stream per state.  Checked against the streaming oracle (the
+reference loop's logic with its default thresholds) and against the batched runtime."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stream_oracle as S
+from tests.helpers import named_params, rms, torch_sd
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOP = 480
+
+
+def _capi(lib):
+    fp = C.POINTER(C.c_float)
+    lib.df_create.restype, lib.df_create.argtypes = C.c_void_p, [C.c_char_p, C.c_float, C.c_char_p]
+    lib.df_get_frame_length.restype, lib.df_get_frame_length.argtypes = C.c_size_t, [C.c_void_p]
+    lib.df_next_log_msg.restype, lib.df_next_log_msg.argtypes = C.c_void_p, [C.c_void_p]
+    lib.df_free_log_msg.restype, lib.df_free_log_msg.argtypes = None, [C.c_void_p]
+    lib.df_set_atten_lim.restype, lib.df_set_atten_lim.argtypes = None, [C.c_void_p, C.c_float]
+    lib.df_set_post_filter_beta.restype, lib.df_set_post_filter_beta.argtypes = None, [C.c_void_p, C.c_float]
+    lib.df_process_frame.restype, lib.df_process_frame.argtypes = C.c_float, [C.c_void_p, fp, fp]
+    lib.df_free.restype, lib.df_free.argtypes = None, [C.c_void_p]
+    return lib
+
+
+def test_header_symbols_exported():
+    from deepfilternet_amd.build import build
+
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(REPO, "include", "df_capi.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(df_[a-z_]+)\s*\(", src)))
+    assert names == ["df_create", "df_free", "df_free_log_msg", "df_get_frame_length", "df_next_log_msg", "df_process_frame",
+                     "df_set_atten_lim", "df_set_post_filter_beta"]
+    lib = C.CDLL(build())
+    for n in names:
+        assert hasattr(lib, n), n
+    lib = _capi(lib)
+    assert lib.df_create(b"/nonexistent/model.dfx", 100.0, None) is None      # no model, no state (the reference panics here)
+
+
+def _process(lib, st, x):
+    fp = C.POINTER(C.c_float)
+    y = np.zeros_like(x)
+    lsnr = np.zeros(len(x) // HOP, np.float32)
+    for k in range(len(x) // HOP):
+        xin = np.ascontiguousarray(x[k * HOP:(k + 1) * HOP])
+        out = np.zeros(HOP, np.float32)
+        lsnr[k] = lib.df_process_frame(st, xin.ctypes.data_as(fp), out.ctypes.data_as(fp))
+        y[k * HOP:(k + 1) * HOP] = out
+    return y, lsnr
+
+
+def test_df_capi_frame_loop(backend, tmp_path):
+    from deepfilternet_amd import _lib, export_dfx
+    from deepfilternet_amd.state_dict import random_state_dict
+
+    p = named_params("pf32")
+    sd_np = random_state_dict(p, 9)
+    path = export_dfx(str(tmp_path / "model.dfx"), params=p, state_dict=sd_np)
+    lib = _capi(C.CDLL(_lib.library_path()))
+    st = lib.df_create(os.fsencode(path), 100.0, b"info")
+    assert st, lib.dfx_last_error
+    assert lib.df_get_frame_length(st) == HOP
+    msgs = []
+    while True:
+        m = lib.df_next_log_msg(st)
+        if not m:
+            break
+        msgs.append(C.cast(m, C.c_char_p).value.decode())
+        lib.df_free_log_msg(m)
+    assert any("lookahead 1" in m for m in msgs), msgs
+    T = 10
+    rng = np.random.default_rng(7)
+    x = (0.1 * rng.standard_normal(HOP * T)).astype(np.float32)
+    sd = torch_sd(p, 9)
+    # defaults of the reference runtime: thresholds -10 / 30 / 20 dB, post filter off (tract.rs:177-189)
+    y, lsnr = _process(lib, st, x)
+    yr, lr, _ = S.process_stream(p, sd, x, pf_beta=0.0)
+    assert rms(y - yr) < 1e-6 and np.abs(lsnr - lr)[p.df_lookahead:].max() < 1e-3
+    lib.df_free(st)
+    # post filter + attenuation limit through the setters, fresh state
+    st = lib.df_create(os.fsencode(path), 100.0, None)
+    assert not lib.df_next_log_msg(st)                       # no log level, no messages (capi.rs:91-101)
+    lib.df_set_post_filter_beta(st, 0.02)
+    lib.df_set_atten_lim(st, 12.0)
+    y, _ = _process(lib, st, x)
+    yr, _, _ = S.process_stream(p, sd, x, atten_lim_db=12.0, pf_beta=0.02)
+    assert rms(y - yr) < 1e-6
+    lib.df_free(st)
+    # a corrupt file is refused
+    bad = tmp_path / "bad.dfx"
+    bad.write_bytes(open(path, "rb").read()[:1000])
+    assert lib.df_create(os.fsencode(str(bad)), 100.0, None) is None
