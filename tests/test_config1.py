@@ -1,0 +1,84 @@
+"""BASELINE.json configs[0]: DeepFilterNet2 ``enhance()`` on assets/noisy_snr0.wav with CPU PyTorch + pyDF — the reference's own
+CPU-runnable case, "plumbing": what this repo replaces there is pyDF, i.e. the ``libdf`` module under the reference's enhance().
+
+tests/golden/config1_df2.npz holds everything that crossed the pyDF boundary when the reference's own enhance() + DeepFilterNet2
+(df/deepfilternet2.py, seeded weights) ran on a cut of the reference's asset (tools/gen_golden_config1.py).  Here that traffic is
+replayed through ``deepfilternet_amd.libdf`` (same call sequence as enhance.py:190-203,231-249), and — in the build container, where
+/root/reference exists — the reference's enhance() + DF2 model themselves run on top of it."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import rms
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, "config1_df2.npz")))
+
+
+def _rel(a, b):
+    return rms(np.asarray(a) - np.asarray(b)) / max(rms(b), 1e-30)
+
+
+def test_config1_pydf_boundary_replay(backend, g):
+    from deepfilternet_amd import libdf
+
+    sr, fft, hop, nb_erb, nb_df, min_nb = (int(v) for v in g["meta"])
+    df = libdf.DF(sr=sr, fft_size=fft, hop_size=hop, nb_bands=nb_erb, min_nb_erb_freqs=min_nb)
+    assert df.erb_widths().dtype == np.uint64 and np.array_equal(df.erb_widths(), g["erb_widths"])   # band indexing: bit-exact
+    alpha = float(g["alpha"])
+    # df_features(): analysis -> erb -> erb_norm, unit_norm   (enhance.py:190-203)
+    spec = df.analysis(g["analysis_in"])
+    assert spec.shape == g["analysis_out"].shape and spec.dtype == np.complex64
+    assert _rel(spec, g["analysis_out"]) < 2e-6
+    e = libdf.erb(spec, df.erb_widths())
+    assert np.abs(e - g["erb_out"]).max() < 2e-3            # dB; 1e-10 floor inside the log
+    ef = libdf.erb_norm(e, alpha)
+    assert np.abs(ef - g["erb_norm_out"]).max() < 1e-4
+    sf = libdf.unit_norm(np.ascontiguousarray(spec[..., :nb_df]), alpha)
+    assert _rel(sf, g["unit_norm_out"]) < 1e-5
+    # each stage on the reference's own input (no error carried over)
+    assert np.abs(libdf.erb(g["analysis_out"], g["erb_widths"]) - g["erb_out"]).max() < 1e-4
+    assert np.abs(libdf.erb_norm(g["erb_out"].copy(), alpha) - g["erb_norm_out"]).max() < 1e-5
+    assert _rel(libdf.unit_norm(g["unit_norm_in"], alpha), g["unit_norm_out"]) < 1e-6
+    # synthesis of the spectrum the reference's DF2 model produced, then enhance()'s slice (enhance.py:241-249)
+    y = df.synthesis(g["synthesis_in"].copy())
+    assert y.shape == g["synthesis_out"].shape and rms(y - g["synthesis_out"]) < 1e-6
+    d = fft - hop
+    n = g["audio"].shape[1]
+    assert rms(y[:, d:n + d] - g["enhanced"]) < 1e-6        # north_star: <= 1e-4 RMS on the waveform
+    # reference error conventions at this boundary (pyDF/src/lib.rs:59-64)
+    with pytest.raises(RuntimeError, match="empty or not contiguous"):
+        df.analysis(np.asfortranarray(np.zeros((2, 960), np.float32)))
+
+
+@pytest.mark.needs_reference
+def test_config1_reference_enhance_on_our_libdf(g):
+    """The reference's enhance() and DeepFilterNet2 model, unchanged, with this repo's libdf in place of pyDF (kernels on the CPU
+    interpreter here: no GPU in the build container)."""
+    import importlib
+
+    from tests.conftest import _use_backend
+    from tools.gen_golden_config1 import build_df2
+
+    _use_backend("emu")
+    from deepfilternet_amd import libdf
+
+    model, _, p = build_df2()
+    E = importlib.import_module("df.enhance")
+    saved = {n: getattr(E, n) for n in ("erb", "erb_norm", "unit_norm")}
+    try:
+        for n in saved:
+            setattr(E, n, getattr(libdf, n))
+        df = libdf.DF(sr=p.sr, fft_size=p.fft_size, hop_size=p.hop_size, nb_bands=p.nb_erb, min_nb_erb_freqs=p.min_nb_freqs)
+        audio = torch.from_numpy(g["audio"].copy())
+        y = E.enhance(model, df, audio).numpy()
+        y12 = E.enhance(model, df, audio, atten_lim_db=12.0).numpy()
+    finally:
+        for n, f in saved.items():
+            setattr(E, n, f)
+    assert y.shape == g["enhanced"].shape
+    assert rms(y - g["enhanced"]) < 1e-6 and rms(y12 - g["enhanced_lim12"]) < 1e-6
