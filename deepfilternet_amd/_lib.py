@@ -86,6 +86,13 @@ SIGNATURES = {
     "dfx_model_forward": (_i, [_vp, _vp, _fp, _fp, _fp, _i64, _i64, _f, _fp, _fp, _fp, _fp, _fp, _i64, _vp]),
     "dfx_enhance_workspace_bytes": (_i, [_vp, _vp, _i64, _i64, _i, C.POINTER(_i64)]),
     "dfx_enhance": (_i, [_vp, _vp, _fp, _i64, _i64, _i, _f, _fp, _fp, _i64, _vp]),
+    "dfx_pcm16_to_f32": (_i, [_vp, _i64, _fp, _vp]),
+    "dfx_f32_to_pcm16": (_i, [_fp, _i64, _vp, _vp]),
+    "dfx_resampler_create": (_i, [_i, _i, _i, C.c_double, _i, C.c_double, C.POINTER(_vp)]),
+    "dfx_resampler_free": (None, [_vp]),
+    "dfx_resampler_out_len": (_i64, [_vp, _i64]),
+    "dfx_resampler_kernel": (_i, [_i, _i, _i, C.c_double, _i, C.c_double, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _f32p, _i64]),
+    "dfx_resample": (_i, [_vp, _fp, _i64, _i64, _i64, _fp, _i64, _vp]),
     "dfx_stream_create": (_i, [_vp, _vp, _i64, _i, C.POINTER(_vp)]),
     "dfx_stream_free": (None, [_vp]),
     "dfx_stream_reset": (_i, [_vp, _vp]),

@@ -235,6 +235,29 @@ int dfx_stream_set_thresholds(dfx_stream_state *s, float min_db_thresh, float ma
 int dfx_stream_process(dfx_stream_state *s, const float *x, int64_t n_frames, float *y, float *lsnr, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Either side of enhance() in the reference's file loop (df/enhance.py:73-89: load_audio -> enhance -> resample back -> save_audio):
+ *   dfx_pcm16_to_f32   torchaudio.load's normalisation of 16-bit PCM, x / 32768 (df/io.py:48)
+ *   dfx_f32_to_pcm16   save_audio's encoding, (audio * (1 << 15)).to(int16) (df/io.py:79-80): truncation toward zero, wrap-around
+ *   dfx_resample       df.io.resample (io.py:114-116) == torchaudio.functional.resample(audio, orig_sr, new_sr, **params): polyphase
+ *                      windowed-sinc bank, method 0 = "sinc_interp_hann", 1 = "sinc_interp_kaiser" (beta); io.py:92-111 parameter sets:
+ *                      sinc_fast (0, width 16, rolloff 0.99) | sinc_best (0, 64, 0.99) | kaiser_fast (1, 16, 0.85, beta 8.555504641634386)
+ *                      | kaiser_best (1, 16, 0.9475937167399596, 14.769656459379492).  x [B, T] (row stride x_stride) ->
+ *                      y [B, dfx_resampler_out_len(T)] (row stride y_stride), device pointers.
+ *   dfx_resampler_kernel   the filter bank itself (host arithmetic, no device): W [phases][taps] float32.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int dfx_pcm16_to_f32(const int16_t *pcm, int64_t n, float *out, void *stream);
+int dfx_f32_to_pcm16(const float *x, int64_t n, int16_t *out, void *stream);
+typedef struct dfx_resampler dfx_resampler;
+int dfx_resampler_create(int orig_sr, int new_sr, int lowpass_filter_width, double rolloff, int method, double beta,
+                         dfx_resampler **out);
+void dfx_resampler_free(dfx_resampler *r);
+int64_t dfx_resampler_out_len(const dfx_resampler *r, int64_t in_len);   /* ceil(new_sr * in_len / orig_sr) */
+int dfx_resampler_kernel(int orig_sr, int new_sr, int lowpass_filter_width, double rolloff, int method, double beta, int *phases,
+                         int *taps, int *width, float *w_host /* may be NULL */, int64_t cap_floats);
+int dfx_resample(const dfx_resampler *r, const float *x, int64_t B, int64_t T, int64_t x_stride, float *y, int64_t y_stride,
+                 void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Per-kernel timing (measurement aid, no reference counterpart; the reference only logs wall-clock RTF,
  * DeepFilterNet/df/enhance.py:77-87).  When a kernel's bit is set in `kernel_mask`, every launch of it is bracketed by
  * two hipEvents recorded on the stream the kernel is launched on.  dfx_prof_read() synchronises the pending events and

@@ -1,0 +1,112 @@
+"""The steps either side of enhance() in the reference's file loop (df/enhance.py:73-89; df/io.py:25-116): PCM16 <-> float and the
+torchaudio-style sinc resampler as HIP kernels, against oracle/io_oracle.py (torchaudio is absent here: its published algorithm is
+restated and checked by properties — see that file's header: parity unpinned)."""
+import ctypes as C
+import math
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import io_oracle as IO
+from tests.helpers import rms
+
+
+def _bank(orig, new, method):
+    from deepfilternet_amd import _lib
+
+    p = IO.PARAMS[method]
+    ph, taps, width = C.c_int(), C.c_int(), C.c_int()
+    args = (orig, new, p["lowpass_filter_width"], p["rolloff"], int(p["kaiser"]), p["beta"] or 0.0)
+    _lib.check(_lib.lib().dfx_resampler_kernel(*args, C.byref(ph), C.byref(taps), C.byref(width), None, 0))
+    w = np.zeros((ph.value, taps.value), np.float32)
+    _lib.check(_lib.lib().dfx_resampler_kernel(*args, None, None, None, w.ctypes.data_as(C.POINTER(C.c_float)), w.size))
+    return w, width.value
+
+
+@pytest.mark.parametrize("orig,new,method", [(44100, 48000, "sinc_fast"), (16000, 48000, "sinc_best"), (48000, 16000, "kaiser_fast"),
+                                             (48000, 44100, "kaiser_best"), (8000, 48000, "sinc_fast")])
+def test_filter_bank_matches_restated_torchaudio_kernel(orig, new, method):
+    """Host arithmetic only (runs without a GPU): the bank libdfx builds == the numpy restatement, and it behaves like a resampling
+    filter: every phase sums to ~1 when upsampling (DC gain), the bank is mirror-symmetric."""
+    from deepfilternet_amd import _lib
+    from deepfilternet_amd.build import build
+
+    _lib.use_library(build())
+    w, width = _bank(orig, new, method)
+    W, width_o, o, n = IO.sinc_resample_kernel(orig, new, method)
+    assert w.shape == W.shape == (n, 2 * width_o + o) and width == width_o
+    assert np.abs(w - W).max() < 1e-7
+    if new >= orig:
+        assert np.abs(W.sum(1) - 1).max() < 2e-3
+    else:
+        assert abs(W.sum() / n - 1) < 2e-3
+    assert np.abs(W[0, : 2 * width_o + 1] - W[0, : 2 * width_o + 1][::-1]).max() < 1e-7   # phase 0 is symmetric about tap `width`
+
+
+def test_oracle_resample_properties():
+    sr, new = 44100, 48000
+    t = np.arange(sr // 10) / sr
+    x = (0.5 * np.sin(2 * np.pi * 1000 * t)).astype(np.float32)[None]
+    y = IO.resample(x, sr, new)
+    assert y.shape == (1, math.ceil(new * x.shape[1] / sr))
+    tn = np.arange(y.shape[1]) / new
+    ref = 0.5 * np.sin(2 * np.pi * 1000 * tn)
+    assert rms((y[0] - ref)[200:-200]) < 2e-3            # a tone far below the cutoff is reproduced on the new grid
+    assert IO.resample(x, sr, sr) is x
+
+
+@pytest.mark.parametrize("orig,new,method,T", [(44100, 48000, "sinc_fast", 7000), (16000, 48000, "sinc_fast", 3001),
+                                               (48000, 16000, "kaiser_best", 5000), (48000, 44100, "sinc_fast", 4801),
+                                               (22050, 48000, "kaiser_fast", 2500)])
+def test_resample_kernel_matches_oracle(backend, orig, new, method, T):
+    from deepfilternet_amd import io as dio
+
+    if backend == "emu" and T > 5000:
+        T = 2000
+    rng = np.random.default_rng(0)
+    x = (0.3 * rng.standard_normal((3, T))).astype(np.float32)
+    y = dio.resample(torch.from_numpy(x), orig, new, method=method)
+    ref = IO.resample(x, orig, new, method)
+    assert tuple(y.shape) == ref.shape and y.dtype == torch.float32
+    assert rms(y.cpu().numpy() - ref) < 1e-6
+    assert dio.resample(torch.from_numpy(x), orig, orig) is not None
+    # ragged / tiny inputs
+    for n in (1, 2, 37):
+        yy = dio.resample(torch.from_numpy(x[:1, :n].copy()), orig, new, method=method)
+        rr = IO.resample(x[:1, :n], orig, new, method)
+        assert tuple(yy.shape) == rr.shape and rms(yy.cpu().numpy() - rr) < 1e-6
+
+
+def test_pcm16_roundtrip_and_wav_files(backend, tmp_path):
+    from deepfilternet_amd import io as dio
+
+    pcm = torch.arange(-32768, 32768, dtype=torch.int32).to(torch.int16).reshape(2, -1)
+    f = dio.pcm16_to_float(pcm)
+    assert torch.equal(f.cpu(), pcm.to(torch.float32) / 32768)                       # torchaudio.load's normalisation
+    assert torch.equal(dio.float_to_pcm16(f).cpu(), pcm)                             # exact round trip
+    x = torch.tensor([[0.5, -0.5, 0.99999, -1.0, 1.0 / 65536, -1.0 / 65536, 0.3333]])
+    assert torch.equal(dio.float_to_pcm16(x).cpu(), (x * (1 << 15)).to(torch.int16))   # io.py:79-80: truncation toward zero
+    # file -> device -> file like enhance.main (enhance.py:73-89), 44.1 kHz stereo
+    sr = 44100
+    t = np.arange(sr // 20) / sr
+    wavdata = np.stack([0.4 * np.sin(2 * np.pi * 440 * t), 0.2 * np.sin(2 * np.pi * 880 * t)], 1)
+    pcm_np = (wavdata * 32768).astype("<i2")
+    path = str(tmp_path / "in.wav")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(2), w.setsampwidth(2), w.setframerate(sr)
+        w.writeframes(pcm_np.tobytes())
+    with pytest.warns(UserWarning, match="Resampling"):
+        audio, meta = dio.load_audio(path, sr=48000)
+    assert meta.sample_rate == sr and meta.num_channels == 2 and meta.num_frames == len(t)
+    ref = IO.resample((pcm_np.T.astype(np.float32) / 32768), sr, 48000)
+    assert tuple(audio.shape) == ref.shape and rms(audio.cpu().numpy() - ref) < 1e-6
+    raw, _ = dio.load_audio(path)
+    assert torch.equal(raw.cpu(), torch.from_numpy(pcm_np.T.astype(np.float32) / 32768))
+    out = dio.save_audio(path, dio.resample(audio, 48000, sr), sr, output_dir=str(tmp_path), suffix="enh")
+    assert out.endswith("in_enh.wav")
+    back, meta2 = dio.load_audio(out)
+    assert meta2.sample_rate == sr and back.shape[0] == 2
+    n = min(back.shape[1], raw.shape[1])
+    assert rms((back[:, 300:n - 300] - raw[:, 300:n - 300]).cpu().numpy()) < 2e-3   # 44.1k -> 48k -> 44.1k reproduces the tones

@@ -24,8 +24,8 @@ def test_stream_equals_batch_delayed(backend, name):
     from deepfilternet_amd.enhance import enhance, init_df
     from deepfilternet_amd.streaming import DfStream
 
-    if backend == "emu" and name == "df3":
-        pytest.skip("conv_ch=64 on the interpreter is slow; the GPU run covers it")
+    if backend == "emu" and name != "pf32":
+        pytest.skip("the interpreter is slow: it covers the conv_ch=32 model (kt=3, lookahead 1); the GPU run covers all three")
     p = named_params(name)
     model, df_state, _, _ = init_df(params=p, epoch="none", seed=9)
     hop, T = 480, (11 if backend == "emu" else 23)   # the interpreter is slow: fewer hops and cut patterns there

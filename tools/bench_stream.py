@@ -22,7 +22,9 @@ def main() -> None:
     ap.add_argument("--streams", type=int, default=4096)
     ap.add_argument("--frames-per-call", type=int, nargs="+", default=[1, 4, 16])
     ap.add_argument("--calls", type=int, default=200)
-    ap.add_argument("--model", default="df3", choices=["df3", "defaults"])
+    ap.add_argument("--model", default="df3", choices=["df3", "df3_ll", "defaults"],
+                    help="df3_ll: DeepFilterNet3 without lookahead (the reference's low-latency LADSPA model, ladspa/README.md:3)")
+    ap.add_argument("--gating", action="store_true", help="per-stream stage gating + silent-input shortcut (tract.rs:513-525,658-672)")
     args = ap.parse_args()
     from deepfilternet_amd import _lib
     from deepfilternet_amd.config import ModelParams
@@ -30,11 +32,13 @@ def main() -> None:
     from deepfilternet_amd.state_dict import random_state_dict
     from deepfilternet_amd.streaming import DfStream
 
-    p = ModelParams.deepfilternet3() if args.model == "df3" else ModelParams.defaults()
+    p = ModelParams.defaults() if args.model == "defaults" else ModelParams.deepfilternet3()
+    if args.model == "df3_ll":
+        p.conv_lookahead = p.df_lookahead = 0
     model, df_state, _, _ = init_df(params=p, state_dict=random_state_dict(p, 0), epoch="none")
     dev = _lib.device()
     for n in args.frames_per_call:
-        rt = DfStream(model, df_state, streams=args.streams, max_frames=n)
+        rt = DfStream(model, df_state, streams=args.streams, max_frames=n, gating=args.gating)
         hop = rt.frame_length
         x = 0.1 * torch.randn((args.streams, n * hop), device=dev)
         for _ in range(10):
@@ -50,7 +54,7 @@ def main() -> None:
         ms_call = dt / args.calls * 1e3
         print(json.dumps({"metric": "streaming 48 kHz hops/s over all streams", "value": hops / dt, "unit": "frames/s", "streams": args.streams,
                           "frames_per_call": n, "ms_per_call": ms_call, "call_budget_ms": 10.0 * n,
-                          "realtime_streams_per_gpu": int(hops / dt / 100.0), "model": args.model,
+                          "realtime_streams_per_gpu": int(hops / dt / 100.0), "model": args.model, "gating": bool(args.gating),
                           "algorithmic_latency_ms": (p.fft_size - p.hop_size + rt.delay_frames * p.hop_size) / p.sr * 1e3}), flush=True)
         del rt
 
