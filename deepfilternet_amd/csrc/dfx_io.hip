@@ -17,49 +17,62 @@
 
 struct dfx_resampler {
     int orig_sr = 0, new_sr = 0;
-    int orig = 0, nw = 0, width = 0, K = 0, nw_pad = 0;
-    float *d_wt = nullptr;  // [K][nw_pad]: W transposed, phases padded to a multiple of DFX_RS_JT (zeros)
+    int orig = 0, nw = 0, width = 0, K = 0, K4 = 0, nw_pad = 0;
+    float *d_wt = nullptr;  // [K4][nw_pad]: W transposed, taps padded to a multiple of 4 and phases to a multiple of DFX_RS_JT (zeros)
     std::vector<float> w_host;  // [nw][K]
 };
 
 struct DfxRsArgs {
     int64_t B, T, x_stride, y_stride, out_len, frames;  // frames = ceil(out_len / nw) per clip
-    int orig, nw, nw_pad, width, K, tn;                 // tn = frames per workgroup (== blockDim.x)
+    int orig, nw, nw_pad, width, K4, tn, fw, jw;        // K4 = taps padded to a multiple of 4 (zero taps); tn = 64*fw frames per workgroup
 };
 
-// One thread per output frame n (nw consecutive output samples); the input segment of the workgroup's frames sits in LDS (lane n
-// reads xs[n*orig + k]: stride orig words, conflict-free when orig is odd), the filter taps are wave-uniform (scalar loads through
-// the constant cache), DFX_RS_JT phases accumulate in registers: one LDS read per DFX_RS_JT FMAs.
-// x [B, x_stride], y [B, y_stride], wt [K][nw_pad] are separate __restrict__ parameters: only then may the compiler read the (never
+// One thread per output frame n (nw consecutive output samples).  A workgroup is 4 waves = fw groups of 64 frames x jw groups of
+// phase tiles (fw * jw == 4): the input segment of its 64*fw frames sits in LDS once (lane n reads xs[n*orig + k]: stride orig
+// words, conflict-free when orig is odd) and is shared by the jw waves that split the DFX_RS_JT-phase register tiles between them;
+// the filter taps are wave-uniform (s_load through the scalar cache); four taps per iteration: 4 LDS reads per 4*DFX_RS_JT FMAs.
+// x [B, x_stride], y [B, y_stride], wt [K4][nw_pad] are separate __restrict__ parameters: only then may the compiler read the (never
 // written) filter through s_load instead of 64 identical vector loads.
-__global__ void dfx_k_resample(const float *__restrict__ x, float *__restrict__ y, const float *__restrict__ wt, DfxRsArgs A) {
+__global__ void __launch_bounds__(256) dfx_k_resample(const float *__restrict__ x, float *__restrict__ y, const float *__restrict__ wt,
+                                                      DfxRsArgs A) {
     DFX_DYN_SMEM(float, xs);
     const int64_t tiles = (A.frames + A.tn - 1) / A.tn;
     const int64_t b = blockIdx.x / tiles;
     const int64_t n0 = (int64_t)(blockIdx.x - b * tiles) * A.tn;
     if (b >= A.B) return;
     const float *xb = x + b * A.x_stride;
-    const int seg = (A.tn - 1) * A.orig + A.K;
+    const int seg = (A.tn - 1) * A.orig + A.K4;
     const int64_t s0 = n0 * A.orig - A.width;  // stream index of xs[0]
     for (int i = threadIdx.x; i < seg; i += blockDim.x) {
         const int64_t si = s0 + i;
         xs[i] = (si >= 0 && si < A.T) ? xb[si] : 0.f;
     }
     __syncthreads();
-    const int64_t n = n0 + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wf = dfx_wave_uniform(wave % A.fw), wj = dfx_wave_uniform(wave / A.fw);
+    const int nl = wf * 64 + lane;
+    const int64_t n = n0 + nl;
     if (n >= A.frames) return;
-    const float *xp = xs + (int64_t)threadIdx.x * A.orig;
+    const float *xp = xs + (int64_t)nl * A.orig;
     float *yb = y + b * A.y_stride + n * A.nw;
     const int64_t left = A.out_len - n * A.nw;  // output samples this frame may store
-    for (int j0 = 0; j0 < A.nw; j0 += DFX_RS_JT) {
+    for (int j0 = wj * DFX_RS_JT; j0 < A.nw; j0 += A.jw * DFX_RS_JT) {
         float acc[DFX_RS_JT];
 #pragma unroll
         for (int i = 0; i < DFX_RS_JT; ++i) acc[i] = 0.f;
         const float *wp = wt + j0;
-        for (int k = 0; k < A.K; ++k) {
-            const float xv = xp[k];
+        for (int k = 0; k < A.K4; k += 4) {
+            const float x0 = xp[k], x1 = xp[k + 1], x2 = xp[k + 2], x3 = xp[k + 3];
+            const float *w0 = wp + (int64_t)k * A.nw_pad;
 #pragma unroll
-            for (int i = 0; i < DFX_RS_JT; ++i) acc[i] = fmaf(wp[(int64_t)k * A.nw_pad + i], xv, acc[i]);
+            for (int i = 0; i < DFX_RS_JT; ++i) {
+                float a = acc[i];
+                a = fmaf(w0[i], x0, a);
+                a = fmaf(w0[A.nw_pad + i], x1, a);
+                a = fmaf(w0[2 * A.nw_pad + i], x2, a);
+                a = fmaf(w0[3 * A.nw_pad + i], x3, a);
+                acc[i] = a;
+            }
         }
 #pragma unroll
         for (int i = 0; i < DFX_RS_JT; ++i)
@@ -138,6 +151,7 @@ static int build_bank(dfx_resampler *r, int orig_sr, int new_sr, int lpw, double
     const double base = (double)(r->orig < r->nw ? r->orig : r->nw) * rolloff;
     r->width = (int)std::ceil((double)lpw * r->orig / base);
     r->K = 2 * r->width + r->orig;
+    r->K4 = (r->K + 3) / 4 * 4;
     r->nw_pad = (r->nw + DFX_RS_JT - 1) / DFX_RS_JT * DFX_RS_JT;
     if ((int64_t)r->K * r->nw_pad > ((int64_t)1 << 26)) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_resampler_create: filter bank too large (reduce the rates' ratio)");
     r->w_host.assign((size_t)r->nw * r->K, 0.f);
@@ -173,7 +187,7 @@ extern "C" int dfx_resampler_create(int orig_sr, int new_sr, int lowpass_filter_
         delete r;
         return rc;
     }
-    std::vector<float> wt((size_t)r->K * r->nw_pad, 0.f);
+    std::vector<float> wt((size_t)r->K4 * r->nw_pad, 0.f);
     for (int j = 0; j < r->nw; ++j)
         for (int k = 0; k < r->K; ++k) wt[(size_t)k * r->nw_pad + j] = r->w_host[(size_t)j * r->K + k];
     if (hipMalloc(reinterpret_cast<void **>(&r->d_wt), wt.size() * 4) != hipSuccess) {
@@ -225,18 +239,19 @@ extern "C" int dfx_resample(const dfx_resampler *r, const float *x, int64_t B, i
     DfxRsArgs A;
     A.B = B, A.T = T, A.x_stride = x_stride, A.y_stride = y_stride, A.out_len = out_len;
     A.frames = dfx_ceil_div(out_len, r->nw);
-    A.orig = r->orig, A.nw = r->nw, A.nw_pad = r->nw_pad, A.width = r->width, A.K = r->K;
-    // frames per workgroup: as many as keep the input segment within ~64 KB of LDS (two workgroups per CU), 64 .. 256
-    int tn = 256;
-    while (tn > 64 && ((int64_t)(tn - 1) * r->orig + r->K) * 4 > 64 * 1024) tn -= 64;
-    const size_t smem = ((size_t)(tn - 1) * r->orig + r->K) * sizeof(float);
+    A.orig = r->orig, A.nw = r->nw, A.nw_pad = r->nw_pad, A.width = r->width, A.K4 = r->K4;
+    // 4 waves per workgroup: jw of them split the phase tiles (as many as there are tiles, 1 / 2 / 4), fw = 4 / jw own 64 frames each
+    const int ntiles = r->nw_pad / DFX_RS_JT;
+    A.jw = ntiles >= 4 ? 4 : (ntiles >= 2 ? 2 : 1);
+    A.fw = 4 / A.jw;
+    A.tn = 64 * A.fw;
+    const size_t smem = ((size_t)(A.tn - 1) * r->orig + r->K4) * sizeof(float);
     if (smem > 160 * 1024) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_resample: rate ratio %d:%d needs more than 160 KB of LDS per workgroup", r->orig, r->nw);
-    A.tn = tn;
-    const int64_t nblk = B * dfx_ceil_div(A.frames, tn);
+    const int64_t nblk = B * dfx_ceil_div(A.frames, A.tn);
     if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_resample: grid too large");
     if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_resample, smem));
     DfxKScope ks(DFX_K_RESAMPLE, dfx_stream(stream));
-    dfx_launch(dfx_k_resample, dim3((unsigned)nblk), dim3(tn), smem, dfx_stream(stream), x, y, (const float *)r->d_wt, A);
+    dfx_launch(dfx_k_resample, dim3((unsigned)nblk), dim3(256), smem, dfx_stream(stream), x, y, (const float *)r->d_wt, A);
     DFX_LAUNCH_CHECK();
     return DFX_OK;
 }

@@ -37,6 +37,9 @@ static inline int dfx_env_num_cus() {
     return n;
 }
 static inline bool dfx_env_is_emulator() { return false; }
+// a value that is the same in every lane of a wave by construction (e.g. derived from threadIdx.x >> 6): tells the compiler so
+// (address arithmetic on it stays in SGPRs and loads through it can be scalar loads)
+static __device__ __forceinline__ int dfx_wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 static inline hipError_t dfx_env_set_max_dyn_smem(const void *func, size_t bytes) {
     return hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }

@@ -514,6 +514,8 @@ static inline float dfx_fast_rcp(float x) { return 1.0f / x; }
 static inline float __fadd_rn(float a, float b) { return a + b; }  // the emulator is built with -ffp-contract=off
 static inline float __fmul_rn(float a, float b) { return a * b; }
 static inline float __fdiv_rn(float a, float b) { return a / b; }
+// wave-uniform values: identity on the interpreter (callers only pass values that are uniform across the wave by construction)
+static inline int dfx_wave_uniform(int v) { return v; }
 static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
 
 #define DFX_OPAQUE(x) asm volatile("" : "+r"(x))
