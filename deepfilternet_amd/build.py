@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 REPO = os.path.dirname(HERE)
 LIB = os.path.join(CSRC, "libdfx.so")
-SOURCES = ["dfx_dsp.hip", "dfx_model.hip", "dfx_capi.hip", "dfx_io.hip"]
+SOURCES = ["dfx_dsp.hip", "dfx_model.hip", "dfx_capi.hip", "dfx_io.hip", "dfx_mf.hip"]
 ARCH = "gfx950"
 
 

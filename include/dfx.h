@@ -235,6 +235,18 @@ int dfx_stream_set_thresholds(dfx_stream_state *s, float min_db_thresh, float ma
 int dfx_stream_process(dfx_stream_state *s, const float *x, int64_t n_frames, float *y, float *lsnr, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Multi-frame Wiener / MVDR filters: df.multiframe.MfWf.forward (multiframe.py:282-321) and MfMvdr.forward (:373-413), the filter
+ * stage of the reference's DeepFilterNetMF model (deepfilternetmf.py:335-352).  op 0 = MfWf, 1 = MfMvdr; frame_size N <= 8.
+ *   spec [B,T,F][2], ifc [B,T,nb,N][2] (speech inter-frame correlation), mat [B,T,nb,N,N][2] (row-major; an inverse correlation
+ *   matrix, a correlation matrix, or a Cholesky factor of either: cholesky_decomp / inverse exactly as the module's constructor
+ *   flags, enforce_constraints / eps / dload likewise, defaults 1 / 1e-8 / 1e-7)  ->  out [B,T,F][2] (out != spec; bins >= nb are
+ *   copied).  Y[t,f] = sum_n w[n] X[t + n - (N-1-lookahead), f], zero outside the clip (MultiFrameModule.pad :72-76).
+ * ---------------------------------------------------------------------------------------------------------------- */
+int dfx_mf_filter(const float *spec, const float *ifc, const float *mat, int op, int frame_size, int lookahead, int cholesky_decomp,
+                  int inverse, int enforce_constraints, float eps, float dload, int64_t B, int64_t T, int F, int nb, float *out,
+                  void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Either side of enhance() in the reference's file loop (df/enhance.py:73-89: load_audio -> enhance -> resample back -> save_audio):
  *   dfx_pcm16_to_f32   torchaudio.load's normalisation of 16-bit PCM, x / 32768 (df/io.py:48)
  *   dfx_f32_to_pcm16   save_audio's encoding, (audio * (1 << 15)).to(int16) (df/io.py:79-80): truncation toward zero, wrap-around

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(REPO, "deepfilternet_amd", "csrc")
 OUT = os.path.join(HERE, "_build", "libdfx_emu.so")
-SOURCES = ["dfx_dsp.hip", "dfx_model.hip", "dfx_capi.hip", "dfx_io.hip"]
+SOURCES = ["dfx_dsp.hip", "dfx_model.hip", "dfx_capi.hip", "dfx_io.hip", "dfx_mf.hip"]
 
 
 def _deps():

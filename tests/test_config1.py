@@ -60,6 +60,7 @@ def test_config1_reference_enhance_on_our_libdf(g):
     """The reference's enhance() and DeepFilterNet2 model, unchanged, with this repo's libdf in place of pyDF (kernels on the CPU
     interpreter here: no GPU in the build container)."""
     import importlib
+    import sys
 
     from tests.conftest import _use_backend
     from tools.gen_golden_config1 import build_df2
@@ -67,6 +68,7 @@ def test_config1_reference_enhance_on_our_libdf(g):
     _use_backend("emu")
     from deepfilternet_amd import libdf
 
+    path0 = list(sys.path)   # importing the reference puts /root/reference/DeepFilterNet (which has its own `tests`) first
     model, _, p = build_df2()
     E = importlib.import_module("df.enhance")
     saved = {n: getattr(E, n) for n in ("erb", "erb_norm", "unit_norm")}
@@ -80,5 +82,6 @@ def test_config1_reference_enhance_on_our_libdf(g):
     finally:
         for n, f in saved.items():
             setattr(E, n, f)
+        sys.path[:] = path0
     assert y.shape == g["enhanced"].shape
     assert rms(y - g["enhanced"]) < 1e-6 and rms(y12 - g["enhanced_lim12"]) < 1e-6

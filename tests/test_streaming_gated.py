@@ -79,7 +79,8 @@ def test_gated_stream_matches_oracle(backend, name, T, quantiles, cuts):
         assert (False, True, False) in seen
     assert len(ref[0][2]["accepted"]) == T
     if name == "pf32":   # lookahead 1: hop 0 takes no decision, hops 1-2 skip stage 1 -> frozen from hop 3 until the silence ends
-        assert ref[1][2]["accepted"][:4] == [0, 1, 2, 8]
+        acc1 = ref[1][2]["accepted"]
+        assert acc1[:3] == [0, 1, 2] and acc1[3] >= 8
     if quantiles[1] < 0.5:
         assert len(ref[1][2]["accepted"]) < T - 5          # frozen again in the middle, with live state to preserve
     for r in ref:  # robust decisions only: no lsnr within 1e-4 dB of a threshold
