@@ -36,8 +36,17 @@ def _deps() -> List[str]:
     return out
 
 
+STAMP = LIB + ".sources"   # the source list the library was linked from (a library built from another list is stale)
+
+
 def is_stale() -> bool:
     if not os.path.exists(LIB):
+        return True
+    try:
+        with open(STAMP) as f:
+            if f.read().split() != SOURCES:
+                return True
+    except OSError:
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(d) > t for d in _deps())
@@ -70,6 +79,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
     os.replace(LIB + ".tmp", LIB)
+    with open(STAMP, "w") as f:
+        f.write(" ".join(SOURCES))
     return LIB
 
 

@@ -22,7 +22,13 @@ def _deps():
 
 
 def build(force: bool = False) -> str:
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in _deps()):
+    stamp = OUT + ".sources"
+    try:
+        with open(stamp) as f:
+            same = f.read().split() == SOURCES
+    except OSError:
+        same = False
+    if not force and same and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in _deps()):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     flags = ["-O2", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mf16c", "-Wall", "-Wno-unused-function",
@@ -45,6 +51,8 @@ def build(force: bool = False) -> str:
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
     os.replace(OUT + ".tmp", OUT)
+    with open(stamp, "w") as f:
+        f.write(" ".join(SOURCES))
     return OUT
 
 

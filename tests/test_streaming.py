@@ -28,7 +28,7 @@ def test_stream_equals_batch_delayed(backend, name):
         pytest.skip("the interpreter is slow: it covers the conv_ch=32 model (kt=3, lookahead 1); the GPU run covers all three")
     p = named_params(name)
     model, df_state, _, _ = init_df(params=p, epoch="none", seed=9)
-    hop, T = 480, (11 if backend == "emu" else 23)   # the interpreter is slow: fewer hops and cut patterns there
+    hop, T = 480, (9 if backend == "emu" else 23)   # the interpreter is slow: fewer hops and cut patterns there
     rng = np.random.default_rng(2)
     x = torch.from_numpy((0.1 * rng.standard_normal((3, hop * T))).astype(np.float32))
     ref = enhance(model, df_state, x, pad=False)                      # batch path (itself checked against the oracle below)
@@ -36,7 +36,7 @@ def test_stream_equals_batch_delayed(backend, name):
     rt = DfStream(model, df_state, streams=3, max_frames=7)
     d = rt.delay_frames
     assert d == p.df_lookahead and rt.frame_length == hop
-    for cuts in (([1] * T, [3, 1, 5, 2]) if backend == "emu" else ([1] * T, [7, 7, 7, 2], [3, 1, 5, 2, 7, 1, 4])):
+    for cuts in (([1, 1, 1, 3, 1, 2],) if backend == "emu" else ([1] * T, [7, 7, 7, 2], [3, 1, 5, 2, 7, 1, 4])):
         rt.reset()
         y = _run_stream(rt, x, cuts)
         assert y.shape == x.shape
@@ -53,14 +53,14 @@ def test_stream_controls(backend):
 
     p = named_params("pf32")
     model, df_state, _, _ = init_df(params=p, epoch="none", seed=3)
-    hop, T = 480, 12
+    hop, T = 480, (8 if backend == "emu" else 12)
     rng = np.random.default_rng(4)
     x = torch.from_numpy((0.1 * rng.standard_normal((2, hop * T))).astype(np.float32))
     rt = DfStream(model, df_state, streams=2, max_frames=4)
     d = rt.delay_frames
     # attenuation limit: same mix as enhance(atten_lim_db=...)
     rt.set_atten_lim(12.0)
-    y = _run_stream(rt, x, [4, 4, 4])
+    y = _run_stream(rt, x, [4] * (T // 4))
     ref = enhance(model, df_state, x, pad=False, atten_lim_db=12.0)
     assert rms((y[:, d * hop:] - ref[:, : (T - d) * hop]).numpy()) < 1e-6
     # |dB| < 0.01: the reference passes the input through untouched and undelayed (tract.rs:540-543)
@@ -70,7 +70,7 @@ def test_stream_controls(backend):
     # >= 100 dB switches the limit off again
     rt.reset()
     rt.set_atten_lim(100.0)
-    y = _run_stream(rt, x, [4, 4, 4])
+    y = _run_stream(rt, x, [4] * (T // 4))
     ref = enhance(model, df_state, x, pad=False)
     assert rms((y[:, d * hop:] - ref[:, : (T - d) * hop]).numpy()) < 1e-6
     lsnr = rt.process(x[:, : hop], return_lsnr=True)[1]
