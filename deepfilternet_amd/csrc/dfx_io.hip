@@ -43,9 +43,17 @@ __global__ void __launch_bounds__(256) dfx_k_resample(const float *__restrict__ 
     const float *xb = x + b * A.x_stride;
     const int seg = (A.tn - 1) * A.orig + A.K4;
     const int64_t s0 = n0 * A.orig - A.width;  // stream index of xs[0]
-    for (int i = threadIdx.x; i < seg; i += blockDim.x) {
-        const int64_t si = s0 + i;
-        xs[i] = (si >= 0 && si < A.T) ? xb[si] : 0.f;
+    // eight loads in flight per lane before the first LDS store (a load -> store loop would wait out one memory latency per element)
+    for (int i = threadIdx.x; i < seg; i += 8 * 256) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t si = s0 + i + 256 * u;
+            v[u] = (i + 256 * u < seg && si >= 0 && si < A.T) ? xb[si] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i + 256 * u < seg) xs[i + 256 * u] = v[u];
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

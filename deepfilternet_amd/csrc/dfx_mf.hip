@@ -9,12 +9,12 @@
 //    inverse:  u = M r
 //   Wiener:    w = u                                   MVDR:  w = u * conj(r[N-1]) / (Re(r^H u) + eps)         (:406-409)
 //   Y[b,t,f] = sum_n w[n] X[b, t + n - (N-1-lookahead), f]   (zero outside the clip);   bins >= nb pass through.
-// HBM-bound: 8 N^2 + 8 N + 16 bytes and ~8 N^3/3 + 8 N^2 flops per bin (N = 5: 256 B, ~550 flop).  A wave owns 64 consecutive
+// HBM-bound: 8 N^2 + 8 N + 16 bytes and ~8 N^3/3 + 8 N^2 flops per bin (N = 5: 256 B, ~550 flop).  A wave (= a workgroup) owns 64 consecutive
 // (t, f) items, whose matrices are one contiguous 64 * 8 N^2-byte run: staged through LDS with coalesced float4 loads, then every
 // lane works on its own matrix in registers (rows padded to an odd word stride: conflict-free).
 #include "dfx_common.h"
 
-#define DFX_MF_THREADS 256
+#define DFX_MF_THREADS 64   // one wave per workgroup: no cross-wave barrier, ~10 independent workgroups per CU overlap their load / solve / store phases
 #define DFX_MF_MAXN 8
 
 struct DfxMfArgs {
@@ -46,14 +46,57 @@ __global__ void __launch_bounds__(DFX_MF_THREADS) dfx_k_mf_filter(DfxMfArgs A) {
     const int64_t i0 = (int64_t)blockIdx.x * DFX_MF_THREADS;
     const int tid = threadIdx.x;
     const int cnt = (int)((items - i0) < DFX_MF_THREADS ? (items - i0) : DFX_MF_THREADS);
-    // ---- stage: the block's matrices and vectors are two contiguous runs in HBM
+    // ---- stage: the block's matrices and vectors are two contiguous runs in HBM (16-byte aligned: 64 items per block), read as
+    // float4.  Full blocks issue ALL their loads before the first LDS store (compile-time trip counts, values held in registers):
+    // a load -> store loop would wait out one HBM latency per iteration.
     {
         const float *mg = reinterpret_cast<const float *>(A.mat) + i0 * (2 * N * N);
-        const int nm = cnt * 2 * N * N;
-        for (int e = tid; e < nm; e += DFX_MF_THREADS) sm[(e / (2 * N * N)) * LD + e % (2 * N * N)] = mg[e];
         const float *vg = reinterpret_cast<const float *>(A.ifc) + i0 * (2 * N);
-        const int nv = cnt * 2 * N;
-        for (int e = tid; e < nv; e += DFX_MF_THREADS) sm[(e / (2 * N)) * LD + 2 * N * N + e % (2 * N)] = vg[e];
+        if (cnt == DFX_MF_THREADS) {
+            constexpr int NQ = DFX_MF_THREADS * 2 * N * N / 4, IT = (NQ + DFX_MF_THREADS - 1) / DFX_MF_THREADS;
+            constexpr int VQ = DFX_MF_THREADS * 2 * N / 4, VT = (VQ + DFX_MF_THREADS - 1) / DFX_MF_THREADS;
+            const float4 *mg4 = reinterpret_cast<const float4 *>(mg);
+            const float4 *vg4 = reinterpret_cast<const float4 *>(vg);
+            float4 mv[IT], vv[VT];
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int q = tid + DFX_MF_THREADS * it;
+                mv[it] = q < NQ ? mg4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int it = 0; it < VT; ++it) {
+                const int q = tid + DFX_MF_THREADS * it;
+                vv[it] = q < VQ ? vg4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int q = tid + DFX_MF_THREADS * it;
+                if (q < NQ) {
+                    const float w[4] = {mv[it].x, mv[it].y, mv[it].z, mv[it].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = 4 * q + j;
+                        sm[(e / (2 * N * N)) * LD + e % (2 * N * N)] = w[j];
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < VT; ++it) {
+                const int q = tid + DFX_MF_THREADS * it;
+                if (q < VQ) {
+                    const float w[4] = {vv[it].x, vv[it].y, vv[it].z, vv[it].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = 4 * q + j;
+                        sm[(e / (2 * N)) * LD + 2 * N * N + e % (2 * N)] = w[j];
+                    }
+                }
+            }
+        } else {  // the last, partial block
+            const int nm = cnt * 2 * N * N, nv = cnt * 2 * N;
+            for (int e = tid; e < nm; e += DFX_MF_THREADS) sm[(e / (2 * N * N)) * LD + e % (2 * N * N)] = mg[e];
+            for (int e = tid; e < nv; e += DFX_MF_THREADS) sm[(e / (2 * N)) * LD + 2 * N * N + e % (2 * N)] = vg[e];
+        }
     }
     __syncthreads();
     // ---- pass-through bins (f >= nb) of the frames this block touches are copied by a grid-stride loop over all of them
