@@ -400,8 +400,10 @@ int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int6
     if (A.chunks <= 0) return DFX_OK;
     const size_t smem = dsp_smem_bytes(st);
     if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_synthesis, smem));
-    const int64_t nblk = B * A.chunks;
-    if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_synthesis: batch too large for one launch");
+    int64_t nblk = B * A.chunks;
+    // persistent workgroups (the twiddle / window tables are staged once per workgroup): a few per CU, grid-stride over the work items
+    const int64_t cap = (int64_t)dfx_env_num_cus() * 8;
+    if (nblk > cap) nblk = cap;
     DfxKScope ks(DFX_K_SYNTHESIS, stream);
     dfx_launch(dfx_k_synthesis, dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, stream, A);
     DFX_LAUNCH_CHECK();

@@ -209,9 +209,25 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_analysis(DfxAnaArgs A) 
     const int team = threadIdx.x / DFX_DSP_TEAM, lane = threadIdx.x % DFX_DSP_TEAM;
     float2 *bufA = reinterpret_cast<float2 *>(smem + team_off) + (size_t)team * 2 * buf_elems;
     float2 *bufB = bufA + buf_elems;
-    for (int i = threadIdx.x; i < N; i += DFX_DSP_THREADS) {
-        tw[i] = A.tw[i];
-        win[i] = A.window[i];
+    // twiddles + window: every load of a pass is issued before the first LDS store (a load -> store loop waits out one memory
+    // latency per iteration; the compiler does not batch across a runtime trip count)
+    for (int i0 = threadIdx.x; i0 < N; i0 += 4 * DFX_DSP_THREADS) {
+        float2 tv[4];
+        float wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * DFX_DSP_THREADS;
+            tv[u] = i < N ? A.tw[i] : make_float2(0.f, 0.f);
+            wv[u] = i < N ? A.window[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * DFX_DSP_THREADS;
+            if (i < N) {
+                tw[i] = tv[u];
+                win[i] = wv[u];
+            }
+        }
     }
     __syncthreads();
     const int64_t nframes = A.B * A.Tf;
@@ -223,18 +239,40 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_analysis(DfxAnaArgs A) 
         if (active) {
             const float *xb = A.x + b * A.x_stride;
             const int64_t pos0 = t * A.hop - ML;
-            for (int k = lane; k < M; k += DFX_DSP_TEAM) {
-                float v[2];
+            const float *xf = xb + pos0;
+            if (pos0 >= 0 && pos0 + N <= A.x_len && (reinterpret_cast<uintptr_t>(xf) & 7) == 0) {
+                // interior frame (wave-uniform test; all but the first of a clip and the ones reaching into the implicit zero padding):
+                // 8-byte loads, 8 per lane in flight before the first LDS store (M = 480: one pass) — a load -> store loop would
+                // wait out one memory latency per iteration.  (Requesting the NEXT frame before this one's FFT, as the synthesis
+                // kernel does, was measured slower here: 16 more live registers cost the second resident workgroup: 0.76 -> 1.14 ms.)
+                const float2 *xf2 = reinterpret_cast<const float2 *>(xf);
+                for (int k0 = lane; k0 < M; k0 += 8 * DFX_DSP_TEAM) {
+                    float2 v[8];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int i = 2 * k + h;
-                    const int64_t pos = pos0 + i;
-                    float s = 0.f;
-                    if (pos >= 0) s = pos < A.x_len ? xb[pos] : 0.f;
-                    else if (A.mem_in) s = A.mem_in[b * ML + (ML + pos)];
-                    v[h] = s * win[i];
+                    for (int u = 0; u < 8; ++u) {
+                        const int k = k0 + u * DFX_DSP_TEAM;
+                        v[u] = xf2[k < M ? k : k0];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int k = k0 + u * DFX_DSP_TEAM;
+                        if (k < M) bufA[k] = make_float2(v[u].x * win[2 * k], v[u].y * win[2 * k + 1]);
+                    }
                 }
-                bufA[k] = make_float2(v[0], v[1]);
+            } else {
+                for (int k = lane; k < M; k += DFX_DSP_TEAM) {
+                    float v[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int i = 2 * k + h;
+                        const int64_t pos = pos0 + i;
+                        float s = 0.f;
+                        if (pos >= 0) s = pos < A.x_len ? xb[pos] : 0.f;
+                        else if (A.mem_in) s = A.mem_in[b * ML + (ML + pos)];
+                        v[h] = s * win[i];
+                    }
+                    bufA[k] = make_float2(v[0], v[1]);
+                }
             }
         }
         DFX_WAVE_SYNC();
@@ -322,20 +360,81 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_synthesis(DfxSynArgs A)
     float2 *bufB = bufA + buf_elems;
     // the last 4 bytes of the team area of team 0 would be too fragile for a flag: keep result-buffer parity in a
     // register instead (identical for all teams because the plan is uniform)
-    for (int i = threadIdx.x; i < N; i += DFX_DSP_THREADS) {
-        tw[i] = A.tw[i];
-        win[i] = A.window[i];
+    // twiddles + window: every load of a pass is issued before the first LDS store (a load -> store loop waits out one memory
+    // latency per iteration; the compiler does not batch across a runtime trip count)
+    for (int i0 = threadIdx.x; i0 < N; i0 += 4 * DFX_DSP_THREADS) {
+        float2 tv[4];
+        float wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * DFX_DSP_THREADS;
+            tv[u] = i < N ? A.tw[i] : make_float2(0.f, 0.f);
+            wv[u] = i < N ? A.window[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * DFX_DSP_THREADS;
+            if (i < N) {
+                tw[i] = tv[u];
+                win[i] = wv[u];
+            }
+        }
     }
     __syncthreads();
     const int ML = N - A.hop;
-    const int64_t b = blockIdx.x / A.chunks;
-    const int chunk = (int)(blockIdx.x - b * A.chunks);
+    // persistent workgroups: the tables above are staged once, then the workgroup walks (row, chunk) work items grid-stride
+    const bool single = M + 1 <= 8 * DFX_DSP_TEAM;
+    float2 pre[8];
+    bool have_pre = false;
+    auto request = [&](const float2 *Y) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = lane + u * DFX_DSP_TEAM;
+            pre[u] = Y[k <= M ? k : lane];
+        }
+    };
+    for (int64_t item = blockIdx.x; item < A.B * A.chunks; item += gridDim.x) {
+    const int64_t b = item / A.chunks;
+    const int chunk = (int)(item - b * A.chunks);
     const int64_t t0 = A.f_begin + (int64_t)chunk * A.outf;  // first output frame of this chunk
     const int64_t t = t0 - (A.R - 1) + team;         // real frame handled by this team
     const bool active = t >= 0 && t < A.Tf;
     if (active) {
         const float2 *Y = A.spec + (b * A.Tf + t) * F;
-        for (int k = lane; k <= M; k += DFX_DSP_TEAM) bufB[k] = Y[k];
+        if (single) {  // F <= 512: the frame was requested while the previous work item was being transformed (or right now)
+            if (!have_pre) request(Y);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = lane + u * DFX_DSP_TEAM;
+                if (k <= M) bufB[k] = pre[u];
+            }
+        } else {
+            for (int k0 = lane; k0 <= M; k0 += 8 * DFX_DSP_TEAM) {  // 8 loads per lane in flight before the first LDS store
+                float2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + u * DFX_DSP_TEAM;
+                    v[u] = k <= M ? Y[k] : make_float2(0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + u * DFX_DSP_TEAM;
+                    if (k <= M) bufB[k] = v[u];
+                }
+            }
+        }
+    }
+    have_pre = false;
+    {   // request this team's frame of the next work item: its HBM latency hides behind the transform and the overlap-add below
+        const int64_t nitem = item + gridDim.x;
+        if (single && nitem < A.B * A.chunks) {
+            const int64_t nb = nitem / A.chunks;
+            const int64_t nt = A.f_begin + (nitem - nb * A.chunks) * A.outf - (A.R - 1) + team;
+            if (nt >= 0 && nt < A.Tf) {
+                request(A.spec + (nb * A.Tf + nt) * F);
+                have_pre = true;
+            }
+        }
     }
     DFX_WAVE_SYNC();
     if (active) {
@@ -400,6 +499,8 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_synthesis(DfxSynArgs A)
             const int64_t mj = s_glob - A.Tf * A.hop;
             if (mj < ML) A.mem_out[b * ML + mj] = v;
         }
+    }
+    __syncthreads();  // the team buffers are reused by the next work item
     }
 }
 
