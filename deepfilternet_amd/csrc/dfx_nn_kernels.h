@@ -1283,29 +1283,51 @@ __global__ void __launch_bounds__(DFX_GG_THREADS) dfx_k_ggemm(DfxGgArgs A) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float *wg = A.w + (size_t)g * A.Kg * A.Ng;
-    for (int k0 = 0; k0 < A.Kg; k0 += DFX_GG_KT) {
-        // A tile: 64 rows x 32 k, float4 along k
-        for (int i = tid; i < DFX_GG_BM * (DFX_GG_KT / 4); i += DFX_GG_THREADS) {
+    // Tiles go HBM -> registers -> LDS: all loads of a k-tile are issued together (a load -> LDS-store loop waits out one memory
+    // latency per iteration), and the next k-tile is requested before the matrix ops of the current one (its latency hides behind
+    // them and the barriers).  A tile: 64 rows x 32 k, float4 along k (2 per thread); B tile: 32 k x BN n, float4 along n.
+    constexpr int AI = DFX_GG_BM * (DFX_GG_KT / 4) / DFX_GG_THREADS;                                    // 2
+    constexpr int BI = (DFX_GG_KT * (BN / 4) + DFX_GG_THREADS - 1) / DFX_GG_THREADS;                    // 1 (BN <= 32) or 2
+    float4 ra[AI], rb[BI];
+    auto request = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < AI; ++u) {
+            const int i = tid + u * DFX_GG_THREADS;
             const int row = i / (DFX_GG_KT / 4), kq = i - row * (DFX_GG_KT / 4);
             const int64_t m = m0 + row;
             const int k = k0 + 4 * kq;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < A.M && k < A.Kg) v = *reinterpret_cast<const float4 *>(A.a + dfx_row(A.rm, m) * A.lda + g * A.Kg + k);
-            float *d = As + row * LDA + 4 * kq;
-            d[0] = v.x;
-            d[1] = v.y;
-            d[2] = v.z;
-            d[3] = v.w;
+            ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < A.M && k < A.Kg) ra[u] = *reinterpret_cast<const float4 *>(A.a + dfx_row(A.rm, m) * A.lda + g * A.Kg + k);
         }
-        // B tile: 32 k x BN n, float4 along n
-        for (int i = tid; i < DFX_GG_KT * (BN / 4); i += DFX_GG_THREADS) {
+#pragma unroll
+        for (int u = 0; u < BI; ++u) {
+            const int i = tid + u * DFX_GG_THREADS;
             const int kk = i / (BN / 4), nq = i - kk * (BN / 4);
             const int k = k0 + kk, n = n0 + 4 * nq;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < A.Kg && n < A.Ng) v = *reinterpret_cast<const float4 *>(wg + (size_t)k * A.Ng + n);
-            *reinterpret_cast<float4 *>(Bs + kk * LDB + 4 * nq) = v;
+            rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < DFX_GG_KT * (BN / 4) && k < A.Kg && n < A.Ng) rb[u] = *reinterpret_cast<const float4 *>(wg + (size_t)k * A.Ng + n);
+        }
+    };
+    request(0);
+    for (int k0 = 0; k0 < A.Kg; k0 += DFX_GG_KT) {
+#pragma unroll
+        for (int u = 0; u < AI; ++u) {
+            const int i = tid + u * DFX_GG_THREADS;
+            const int row = i / (DFX_GG_KT / 4), kq = i - row * (DFX_GG_KT / 4);
+            float *d = As + row * LDA + 4 * kq;
+            d[0] = ra[u].x;
+            d[1] = ra[u].y;
+            d[2] = ra[u].z;
+            d[3] = ra[u].w;
+        }
+#pragma unroll
+        for (int u = 0; u < BI; ++u) {
+            const int i = tid + u * DFX_GG_THREADS;
+            const int kk = i / (BN / 4), nq = i - kk * (BN / 4);
+            if (i < DFX_GG_KT * (BN / 4)) *reinterpret_cast<float4 *>(Bs + kk * LDB + 4 * nq) = rb[u];
         }
         __syncthreads();
+        if (k0 + DFX_GG_KT < A.Kg) request(k0 + DFX_GG_KT);
         const float *arow = As + (16 * wave + (lane & 15)) * LDA + (lane >> 4);
         const float *brow = Bs + (lane >> 4) * LDB + (lane & 15);
 #pragma unroll
