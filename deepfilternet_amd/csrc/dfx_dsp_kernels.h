@@ -553,16 +553,27 @@ __global__ void dfx_k_norm_scan(const float *erb_in, float *erb_out, int E, cons
         else s = -60.f + (E > 1 ? (-90.f - -60.f) / (float)(E - 1) : 0.f) * (float)ch;
         const float *in = erb_in + c * T * E + ch;
         float *out = erb_out + c * T * E + ch;
+        // batches of DFX_SCAN_UNROLL frames, double-buffered: batch k+1 is requested before batch k is scanned, so the recurrence
+        // never waits for memory (a plain load-batch / scan-batch loop spends most of its time in the load latency)
         int64_t t = 0;
-        for (; t + DFX_SCAN_UNROLL <= T; t += DFX_SCAN_UNROLL) {
-            float v[DFX_SCAN_UNROLL];
+        const int64_t nbatch = T / DFX_SCAN_UNROLL;
+        float v[DFX_SCAN_UNROLL] = {}, nv[DFX_SCAN_UNROLL] = {};
+        if (nbatch > 0) {
 #pragma unroll
-            for (int u = 0; u < DFX_SCAN_UNROLL; ++u) v[u] = in[(t + u) * E];
+            for (int u = 0; u < DFX_SCAN_UNROLL; ++u) v[u] = in[u * E];
+        }
+        for (int64_t bi = 0; bi < nbatch; ++bi, t += DFX_SCAN_UNROLL) {
+            if (bi + 1 < nbatch) {
+#pragma unroll
+                for (int u = 0; u < DFX_SCAN_UNROLL; ++u) nv[u] = in[(t + DFX_SCAN_UNROLL + u) * E];
+            }
 #pragma unroll
             for (int u = 0; u < DFX_SCAN_UNROLL; ++u) {
                 s = v[u] * one_m_a + s * alpha;
                 out[(t + u) * E] = (v[u] - s) / 40.f;
             }
+#pragma unroll
+            for (int u = 0; u < DFX_SCAN_UNROLL; ++u) v[u] = nv[u];
         }
         for (; t < T; ++t) {
             const float v = in[t * E];
@@ -580,16 +591,25 @@ __global__ void dfx_k_norm_scan(const float *erb_in, float *erb_out, int E, cons
         const float2 *in = spec_in + c * T * spec_frame_stride + ch;
         float2 *out = spec_out + c * T * Fn + ch;
         int64_t t = 0;
-        for (; t + DFX_SCAN_UNROLL <= T; t += DFX_SCAN_UNROLL) {
-            float2 v[DFX_SCAN_UNROLL];
+        const int64_t nbatch = T / DFX_SCAN_UNROLL;
+        float2 v[DFX_SCAN_UNROLL] = {}, nv[DFX_SCAN_UNROLL] = {};
+        if (nbatch > 0) {
 #pragma unroll
-            for (int u = 0; u < DFX_SCAN_UNROLL; ++u) v[u] = in[(t + u) * spec_frame_stride];
+            for (int u = 0; u < DFX_SCAN_UNROLL; ++u) v[u] = in[u * spec_frame_stride];
+        }
+        for (int64_t bi = 0; bi < nbatch; ++bi, t += DFX_SCAN_UNROLL) {
+            if (bi + 1 < nbatch) {
+#pragma unroll
+                for (int u = 0; u < DFX_SCAN_UNROLL; ++u) nv[u] = in[(t + DFX_SCAN_UNROLL + u) * spec_frame_stride];
+            }
 #pragma unroll
             for (int u = 0; u < DFX_SCAN_UNROLL; ++u) {
                 s = hypotf(v[u].x, v[u].y) * one_m_a + s * alpha;
                 const float d = sqrtf(s);
                 out[(t + u) * Fn] = make_float2(v[u].x / d, v[u].y / d);
             }
+#pragma unroll
+            for (int u = 0; u < DFX_SCAN_UNROLL; ++u) v[u] = nv[u];
         }
         for (; t < T; ++t) {
             const float2 v = in[t * spec_frame_stride];
