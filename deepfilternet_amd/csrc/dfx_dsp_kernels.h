@@ -531,7 +531,7 @@ __global__ void dfx_k_erb_inv(const float *gains, int64_t rows, int F, int nb, c
     out[i] = gains[r * nb + bin2band[f]];
 }
 
-#define DFX_SCAN_UNROLL 8
+#define DFX_SCAN_UNROLL 16
 // Exponential mean norm of the ERB features (lib.rs:244-251) and exponential unit norm of the complex features
 // (lib.rs:253-259) — true recurrences over time, so one thread owns one (row, channel) and walks T sequentially; the
 // loads do not depend on the recurrence and are issued DFX_SCAN_UNROLL frames ahead.  Channels [0,E) are ERB bands,
