@@ -88,3 +88,54 @@ def test_full_size_streaming_equals_batch(hip_backend):
         err = rms((y[:, d * HOP:] - ref[:, : (n_hops - d) * HOP]).cpu().numpy())
         assert err < 1e-6, (cuts[0], err)
         assert float(y[:, : d * HOP].abs().max()) == 0.0
+
+
+def test_full_size_gated_streams(hip_backend):
+    """BASELINE.json configs[3]: DeepFilterNet3 without lookahead, 4096 concurrent streams frame by frame, with the reference
+    runtime's per-stream decisions (tract.rs:513-525,658-672) switched on.  Size-independent properties: a stream's output does not
+    depend on its neighbours (row 0 == the same signal run alone), streams that take every stage equal the ungated runtime,
+    digitally silent streams are frozen (zeros, lsnr -15) while their neighbours run; three rows against the streaming oracle."""
+    from deepfilternet_amd.config import ModelParams
+    from deepfilternet_amd.enhance import init_df
+    from deepfilternet_amd.state_dict import random_state_dict
+    from deepfilternet_amd.streaming import DfStream
+    from oracle import stream_oracle as S
+
+    p = ModelParams.deepfilternet3()
+    p.conv_lookahead = p.df_lookahead = 0          # the "_ll" (low latency) model of ladspa/README.md:3
+    sd = random_state_dict(p, 23)
+    model, df_state, _, _ = init_df(params=p, state_dict=sd, epoch="none")
+    B, n_hops = 4096, 24
+    x = _audio(B, n_hops * HOP, 9)
+    x[1::64] = 0.0                                  # every 64th stream is digital silence
+    sdt = {k: torch.as_tensor(v) for k, v in sd.items()}
+    # thresholds inside the lsnr distribution of this random-weight model (from three oracle rows), away from any observed value
+    rows = [0, 2, 1]
+    ungated = [S.process_stream(p, sdt, x[r].cpu().numpy(), thresholds=(-1e9, 1e9, 1e9)) for r in rows[:2]]
+    vals = np.sort(np.concatenate([u[1] for u in ungated]))
+    thr_df = float(vals[len(vals) // 2] + vals[len(vals) // 2 + 1]) / 2
+    thr = (-1e9, 1e9, thr_df)                       # stage 1 always, stage 2 for the lower half of the lsnr values
+    rt = DfStream(model, df_state, streams=B, max_frames=4, gating=True, thresholds=thr)
+    ys, ls = [], []
+    for c in range(0, n_hops, 4):
+        y, l = rt.process(x[:, c * HOP:(c + 4) * HOP], return_lsnr=True)
+        ys.append(y), ls.append(l)
+    y, lsnr = torch.cat(ys, 1), torch.cat(ls, 1)
+    assert bool(torch.isfinite(y).all())
+    for r in rows:
+        yr, lr, info = S.process_stream(p, sdt, x[r].cpu().numpy(), thresholds=thr)
+        assert min(abs(v - thr_df) for v in info["lsnr_pass1"]) > 1e-4 if info["lsnr_pass1"] else True
+        assert rms(y[r].cpu().numpy() - yr) < 1e-6, r
+    # a stream alone == the same stream among 4095 others
+    rt1 = DfStream(model, df_state, streams=1, max_frames=4, gating=True, thresholds=thr)
+    y0 = torch.cat([rt1.process(x[:1, c * HOP:(c + 4) * HOP]) for c in range(0, n_hops, 4)], 1)
+    assert rms((y0 - y[:1]).cpu().numpy()) < 1e-7
+    # silent streams: with every lsnr above max_db_erb nothing resets the counter -> frozen after 3 hops (+1 silent, +1 no gains each)
+    rt.reset()
+    rt.set_thresholds(-1e9, -1e9, -1e9)
+    y2, l2 = rt.process(x[:, : 4 * HOP], return_lsnr=True)
+    y3, l3 = rt.process(x[:, 4 * HOP: 8 * HOP], return_lsnr=True)
+    assert float(y3[1::64].abs().max()) == 0.0 and bool((l3[1::64] == -15.0).all())
+    d = FFT - HOP                                   # nothing applied: the live streams come back delayed by the STFT only
+    live = torch.cat([y2, y3], 1)[0::64]
+    assert rms((live[:, d:] - x[0::64, : 8 * HOP - d]).cpu().numpy()) < 1e-6
