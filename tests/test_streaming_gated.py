@@ -65,7 +65,7 @@ def test_gated_stream_matches_oracle(backend, name, T, quantiles, cuts):
     if backend == "emu" and name != "pf32":
         pytest.skip("the interpreter covers the conv_ch=32 model; the others run on the GPU")
     if backend == "emu":  # the interpreter is slow: fewer hops, one cut pattern
-        T, cuts = 16, ([4] * 4 if len(cuts) < 10 else [1] * 16)
+        T, cuts = 14, ([2] * 7 if len(cuts) < 10 else [1] * 14)
     p = named_params(name)
     sd = torch_sd(p, 9)
     model, df_state, _, _ = init_df(params=p, epoch="none", seed=9)
@@ -124,19 +124,19 @@ def test_gating_defaults_and_controls(backend):
 
     p = named_params("defaults")
     model, df_state, _, _ = init_df(params=p, epoch="none", seed=3)
-    T = 6
+    T = 4 if backend == "emu" else 8
     rng = np.random.default_rng(4)
     x = (0.1 * rng.standard_normal((2, HOP * T))).astype(np.float32)
     x[1] = 0
-    rt = DfStream(model, df_state, streams=2, max_frames=3)
-    y0, _ = _run(rt, x, [3] * 2)
+    rt = DfStream(model, df_state, streams=2, max_frames=2)
+    y0, _ = _run(rt, x, [2] * (T // 2))
     rt.reset()
     rt.set_gating(True)
-    y1, l1 = _run(rt, x, [3] * 2)
+    y1, l1 = _run(rt, x, [2] * (T // 2))
     assert np.array_equal(y0, y1) and np.all(l1 != -15.0)
     rt.reset()
     rt.set_thresholds(-1e9, -1e9, -1e9)
-    y2, l2 = _run(rt, x, [3] * 2)
+    y2, l2 = _run(rt, x, [2] * (T // 2))
     d = p.fft_size - p.hop_size
     assert rms(y2[0, d:] - x[0, :-d]) < 1e-6                               # nothing applied: STFT -> ISTFT
     assert np.all(y2[1] == 0) and np.all(l2[1, 3:] == -15.0) and np.all(l2[1, :3] != -15.0)
