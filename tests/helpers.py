@@ -35,3 +35,11 @@ def torch_sd(p: ModelParams, seed: int):
 def rms(a):
     a = np.asarray(a)
     return float(np.sqrt(np.mean(np.abs(a) ** 2)))
+
+
+def emu_subset(backend: str) -> bool:
+    """True when a test case should be skipped on the CPU interpreter to keep the CPU suite within a few minutes: the case still runs
+    on the GPU (-m gpu), and on the interpreter too with DFX_EMU_ALL=1."""
+    import os
+
+    return backend == "emu" and os.environ.get("DFX_EMU_ALL", "0") != "1"

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import dfnet_oracle as O
-from tests.helpers import named_params, rms, torch_sd
+from tests.helpers import emu_subset, named_params, rms, torch_sd
 
 
 def _run_stream(rt, x, cuts):
@@ -51,6 +51,8 @@ def test_stream_controls(backend):
     from deepfilternet_amd.enhance import enhance, init_df
     from deepfilternet_amd.streaming import DfStream
 
+    if emu_subset(backend):
+        pytest.skip("interpreter subset: the controls are exercised through test_streaming_gated.py there (DFX_EMU_ALL=1 runs this too)")
     p = named_params("pf32")
     model, df_state, _, _ = init_df(params=p, epoch="none", seed=3)
     hop, T = 480, (8 if backend == "emu" else 12)
