@@ -13,12 +13,12 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 from .config import ModelParams  # noqa: F401,E402
 
 __version__ = "0.1.0"
-__all__ = ["ModelParams", "init_df", "enhance", "df_features", "DfNet", "libdf", "export_dfx"]
+__all__ = ["ModelParams", "init_df", "enhance", "enhance_files", "df_features", "DfNet", "libdf", "export_dfx"]
 
 
 def __getattr__(name):
     # lazy: importing the package must not require torch/HIP until something is used
-    if name in ("init_df", "enhance", "df_features"):
+    if name in ("init_df", "enhance", "enhance_files", "df_features"):
         from . import enhance as _e
 
         return getattr(_e, name)

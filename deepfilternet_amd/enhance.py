@@ -127,3 +127,21 @@ def enhance(model: DfNet, df_state: DF, audio: torch.Tensor, pad: bool = True, a
     _lib.check(L.dfx_enhance(model.handle, df_state.handle, _lib.ptr(x), B, T, int(bool(pad)), lim_db, _lib.ptr(y),
                              _lib.ptr(ws), ws.numel(), _lib.stream()))
     return y.to(src_dev)
+
+
+def enhance_files(model: DfNet, df_state: DF, input_files, output_dir: Optional[str] = None, suffix: Optional[str] = None,
+                  compensate_delay: bool = True, atten_lim_db: Optional[float] = None, method: str = "sinc_fast"):
+    """The body of the reference's file loop, ``df.enhance.main`` (enhance.py:73-89), without its argument parser: every file is
+    decoded, brought to the model's sampling rate, enhanced, brought back to its own rate and written next to the input (or into
+    ``output_dir``) as ``<name>_<suffix>.wav``.  The audio stays on the device from the int16 -> float conversion to the float ->
+    int16 one (deepfilternet_amd.io); channels of a file are the batch, as in the reference.  Returns the written paths."""
+    from .io import load_audio, resample, save_audio
+
+    sr = df_state.sr()
+    out = []
+    for file in input_files:
+        audio, meta = load_audio(file, sr=sr, verbose=False, method=method)
+        enhanced = enhance(model, df_state, audio, pad=compensate_delay, atten_lim_db=atten_lim_db)
+        enhanced = resample(enhanced, sr, meta.sample_rate, method=method)
+        out.append(save_audio(file, enhanced, sr=meta.sample_rate, output_dir=output_dir, suffix=suffix))
+    return out

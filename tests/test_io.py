@@ -110,3 +110,31 @@ def test_pcm16_roundtrip_and_wav_files(backend, tmp_path):
     assert meta2.sample_rate == sr and back.shape[0] == 2
     n = min(back.shape[1], raw.shape[1])
     assert rms((back[:, 300:n - 300] - raw[:, 300:n - 300]).cpu().numpy()) < 2e-3   # 44.1k -> 48k -> 44.1k reproduces the tones
+
+
+def test_enhance_files_loop(backend, tmp_path):
+    """df.enhance.main's loop (enhance.py:73-89): file -> load/resample -> enhance -> resample back -> save, against the same chain
+    on the oracles."""
+    from deepfilternet_amd.enhance import enhance_files, init_df
+    from oracle import dfnet_oracle as O
+    from tests.helpers import named_params, torch_sd
+
+    p = named_params("defaults")
+    model, df_state, suffix, _ = init_df(params=p, epoch="none", seed=5)
+    sr = 16000
+    n = 1600 if backend == "emu" else 8000
+    rng = np.random.default_rng(3)
+    pcm_np = (0.2 * rng.standard_normal((n, 1)) * 32768).astype("<i2")
+    path = str(tmp_path / "noisy.wav")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1), w.setsampwidth(2), w.setframerate(sr)
+        w.writeframes(pcm_np.tobytes())
+    (out,) = enhance_files(model, df_state, [path], output_dir=str(tmp_path), suffix=suffix)
+    assert out.endswith(f"noisy_{suffix}.wav")
+    with wave.open(out, "rb") as w:
+        assert w.getframerate() == sr and w.getnchannels() == 1
+        got = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").astype(np.float32) / 32768
+    x48 = IO.resample(pcm_np.T.astype(np.float32) / 32768, sr, 48000)
+    ref = IO.resample(O.enhance(p, torch_sd(p, 5), x48), 48000, sr)[0]
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 1.5 / 32768          # one quantisation step of the 16-bit output
