@@ -19,9 +19,10 @@ __all__ = ["ModelParams", "init_df", "enhance", "enhance_files", "df_features", 
 def __getattr__(name):
     # lazy: importing the package must not require torch/HIP until something is used
     if name in ("init_df", "enhance", "enhance_files", "df_features"):
-        from . import enhance as _e
+        import importlib
 
-        return getattr(_e, name)
+        # (not `from . import enhance`: that form asks the package for the attribute first, i.e. re-enters this function)
+        return getattr(importlib.import_module(".enhance", __name__), name)
     if name == "DfNet":
         from .model import DfNet
 

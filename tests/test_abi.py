@@ -70,3 +70,15 @@ def test_python_layer_raises_without_gpu():
 
     with pytest.raises(RuntimeError):
         libdf.DF(48000, 960, 480, 32, 2)
+
+
+def test_package_lazy_attributes():
+    """`import deepfilternet_amd as d; d.init_df / d.enhance_files / ...` resolve without importing torch-heavy modules up front
+    (and without re-entering the package's __getattr__)."""
+    import deepfilternet_amd as d
+
+    for name in ("init_df", "enhance_files", "df_features", "DfNet", "export_dfx", "libdf", "ModelParams"):
+        assert getattr(d, name) is not None, name
+    assert callable(d.init_df) and callable(d.enhance_files)
+    with pytest.raises(AttributeError):
+        d.no_such_thing
