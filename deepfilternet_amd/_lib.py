@@ -101,6 +101,7 @@ SIGNATURES = {
     "dfx_stream_delay_frames": (_i, [_vp]),
     "dfx_stream_set_atten_lim": (_i, [_vp, _f]),
     "dfx_stream_set_post_filter_beta": (_i, [_vp, _f]),
+    "dfx_stream_set_channels": (_i, [_vp, _i, _i]),
     "dfx_stream_set_gating": (_i, [_vp, _i]),
     "dfx_stream_set_thresholds": (_i, [_vp, _f, _f, _f]),
     "dfx_stream_process": (_i, [_vp, _fp, _i64, _fp, _fp, _vp]),

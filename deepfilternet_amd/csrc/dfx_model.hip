@@ -119,6 +119,8 @@ struct DfxStreamCtx {
     int64_t out_T, out_toff;
     bool serial;       // every kernel on the caller's stream (graph capture records a single-stream chain)
     const struct DfxGate *gate = nullptr;  // per-stream stage gating (one new frame per pass); null: every frame runs every stage
+    int channels = 1;                      // > 1: consecutive streams are the channels of one multi-channel stream ...
+    int reduce_mask = 0;                   // ... whose ERB masks are reduced over the channels: 0 none, 1 max, 2 mean (tract.rs:96-118,868-902)
 };
 
 // ---- per-stream stage gating of the streaming runtime (DfTract::process / apply_stages, tract.rs:509-616,658-672) ----------------
@@ -132,17 +134,23 @@ struct DfxGate {
     unsigned char *flags;  // [B]
     float thr[3];          // min_db_thresh, max_db_erb_thresh, max_db_df_thresh
     float *c0_win;         // [B, T, Fd, C]: slots T-kt .. T-2 = c0 of the last kt-1 frames the DF decoder ran on, T-1 = this frame
+    int channels;          // streams per multi-channel group: one skip counter and one stage decision (the first channel's lsnr) per group
 };
 
 // tract.rs:513-525: mean square of the hop (sequential f32 fold like the reference: the comparison with 1e-7 is then the same
 // decision); below the threshold the counter goes up, else it is cleared; above 5 the stream is frozen for this hop.
-__global__ void dfx_k_gate_pre(const float *x, int64_t x_stride, int hop, int64_t B, int *skip_counter, unsigned char *flags) {
+// Multi-channel streams (ch consecutive rows): the fold runs over all channels of the hop, channel after channel, like the
+// reference's `noisy.iter()` over its [ch, hop] array; every row of the group keeps an identical copy of the group's counter.
+__global__ void dfx_k_gate_pre(const float *x, int64_t x_stride, int hop, int64_t B, int *skip_counter, unsigned char *flags, int ch) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const float *xp = x + b * x_stride;
+    const int64_t b0 = b - b % ch;
     float e = 0.f;
-    for (int i = 0; i < hop; ++i) e = __fadd_rn(e, __fmul_rn(xp[i], xp[i]));
-    const float ms = __fdiv_rn(e, (float)hop);
+    for (int c = 0; c < ch; ++c) {
+        const float *xp = x + (b0 + c) * x_stride;
+        for (int i = 0; i < hop; ++i) e = __fadd_rn(e, __fmul_rn(xp[i], xp[i]));
+    }
+    const float ms = __fdiv_rn(e, (float)(hop * ch));
     int c = skip_counter[b];
     c = ms < 1e-7f ? c + 1 : 0;
     skip_counter[b] = c;
@@ -150,13 +158,14 @@ __global__ void dfx_k_gate_pre(const float *x, int64_t x_stride, int hop, int64_
 }
 
 // tract.rs:658-672 apply_stages on the newest frame's lsnr (lsnr[b*T + T-1])
+// (multi-channel: the decision of a group is taken from its first channel's lsnr, tract.rs:468 `to_scalar`)
 __global__ void dfx_k_gate_post(const float *lsnr, int64_t T, float thr_min, float thr_erb, float thr_df, unsigned char *flags,
-                                int64_t B) {
+                                int64_t B, int ch) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     unsigned char f = flags[b];
     if (f & DFX_GATE_FROZEN) return;
-    const float v = lsnr[b * T + T - 1];
+    const float v = lsnr[(b - b % ch) * T + T - 1];
     if (v < thr_min) f |= DFX_GATE_ZEROS;
     else if (v > thr_erb) f |= 0;
     else if (v > thr_df) f |= DFX_GATE_GAINS;
@@ -185,6 +194,26 @@ __global__ void dfx_k_gate_edit(const unsigned char *flags, float *mask, float *
             float2 *cp = reinterpret_cast<float2 *>(coefs) + ((b * O + n) * T + T - 1) * Fd + fq;
             *cp = make_float2(n == tap0 ? mrow[bin2band[fq]] : 0.f, 0.f);
         }
+    }
+}
+
+// Multi-channel streams: the ERB decoder's mask is reduced over the channels of a group and the reduced mask is applied to every
+// channel (tract.rs:868-902: Reduce<Max> or Reduce<Sum> * (1/ch) wired behind the decoder; :547-556 the one mask for all channels).
+// mask [B*T, E]; frames [t_begin, T) of every stream; mode 1 max, 2 mean.
+__global__ void dfx_k_mask_reduce(float *mask, int64_t B, int64_t T, int64_t t_begin, int E, int ch, int mode) {
+    const int64_t n = (B / ch) * (T - t_begin) * E;
+    const float inv = 1.f / (float)ch;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i % E);
+        const int64_t r = i / E, g = r / (T - t_begin), t = t_begin + r % (T - t_begin);
+        float *p = mask + ((g * ch) * T + t) * E + e;
+        float acc = p[0];
+        for (int c = 1; c < ch; ++c) {
+            const float v = p[(int64_t)c * T * E];
+            acc = mode == 1 ? fmaxf(acc, v) : acc + v;
+        }
+        if (mode == 2) acc *= inv;
+        for (int c = 0; c < ch; ++c) p[(int64_t)c * T * E] = acc;
     }
 }
 
@@ -1452,7 +1481,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         DFX_LAUNCH_CHECK();
         if (gate) {  // stage decisions of the newest frame (tract.rs:658-672)
             dfx_launch(dfx_k_gate_post, dim3((unsigned)dfx_ceil_div(B, 256)), dim3(256), 0, s, (const float *)lsnr, T, gate->thr[0],
-                       gate->thr[1], gate->thr[2], gate->flags, B);
+                       gate->thr[1], gate->thr[2], gate->flags, B, gate->channels);
             DFX_LAUNCH_CHECK();
         }
         // ---- DfDecoder on x1 (:323-331)
@@ -1687,6 +1716,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     // ---- Mask + MF.DF + combine + post filter + atten_lim (:426-454, enhance.py:238-240)
     if (sc) {  // spec has sc->spec_T frames per clip, coefficients / gains T; the n enhanced frames are stored compactly
         const float beta = sc->pf_beta >= 0.f ? sc->pf_beta : (c.mask_pf ? c.pf_beta : 0.f);
+        if (sc->channels > 1 && sc->reduce_mask != 0) {
+            dfx_launch(dfx_k_mask_reduce, dim3((unsigned)nn_grid(dfx_ceil_div(Rn * E / sc->channels, 256), 8)), dim3(256), 0, s, mask, B, T, t_begin,
+                       E, sc->channels, sc->reduce_mask);
+            DFX_LAUNCH_CHECK();
+        }
         if (gate) {
             dfx_launch(dfx_k_gate_edit, dim3((unsigned)B), dim3(128), 0, s, (const unsigned char *)gate->flags, mask, coefs,
                        (const unsigned char *)bands->d_bin2band, B, T, E, Fd, O, O - 1 - c.df_lookahead);
@@ -1817,6 +1851,7 @@ struct dfx_stream_state {
     int flip = 0;             // which of the double-buffered STFT memories is current
     // per-stream stage gating (dfx_stream_set_gating; DfTract::process, tract.rs:509-616,658-672): off by default
     bool gated = false;
+    int channels = 1, reduce_mask = 2;    // multi-channel streams: ch consecutive rows per stream; ReduceMask::MEAN is the reference default
     float thr[3] = {-10.f, 30.f, 20.f};   // RuntimeParams::default_with_ch (tract.rs:177-189)
     unsigned char *gate_buf = nullptr;    // own allocation, made when gating is first switched on
     size_t g_flags = 0, g_counter = 0, g_sh_erb = 0, g_sh_unit = 0, g_sh_h = 0, g_c0_win = 0, gate_bytes = 0;
@@ -1968,6 +2003,15 @@ extern "C" int dfx_stream_set_thresholds(dfx_stream_state *s, float min_db_thres
     return DFX_OK;
 }
 
+// RuntimeParams::n_ch / with_mask_reduce (tract.rs:119-176): rows [k*ch, (k+1)*ch) are the channels of stream k
+extern "C" int dfx_stream_set_channels(dfx_stream_state *s, int channels, int reduce_mask) {
+    if (!s || channels < 1 || s->B % channels != 0 || reduce_mask < 0 || reduce_mask > 2)
+        DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_stream_set_channels: channels must divide the number of rows; reduce_mask 0 none, 1 max, 2 mean");
+    s->channels = channels;
+    s->reduce_mask = reduce_mask;
+    return DFX_OK;
+}
+
 extern "C" int dfx_stream_set_gating(dfx_stream_state *s, int enable) {
     if (!s) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_stream_set_gating: null handle");
     if (!enable) {
@@ -2049,7 +2093,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     if (gated) {
         // silent-input shortcut (tract.rs:513-525) + a copy of the in-place state, so that the streams that turn out not to advance
         // (frozen, or a decoder stage skipped) can be given their state back after the pass
-        dfx_launch(dfx_k_gate_pre, dim3((unsigned)dfx_ceil_div(B, 64)), dim3(64), 0, s, x, xs, (int)hop, B, gcount, gflags);
+        dfx_launch(dfx_k_gate_pre, dim3((unsigned)dfx_ceil_div(B, 64)), dim3(64), 0, s, x, xs, (int)hop, B, gcount, gflags, S->channels);
         DFX_LAUNCH_CHECK();
         DFX_HIP(hipMemcpyAsync(gp(S->g_sh_erb), fp(S->erb_state), (size_t)B * E * 4, hipMemcpyDeviceToDevice, s));
         DFX_HIP(hipMemcpyAsync(gp(S->g_sh_unit), fp(S->unit_state), (size_t)B * Fd * 4, hipMemcpyDeviceToDevice, s));
@@ -2092,8 +2136,11 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         sc.out_T = n;
         sc.out_toff = H;
         sc.serial = S->capturing;
+        sc.channels = S->channels;
+        sc.reduce_mask = S->reduce_mask;
         DfxGate gate;
         if (gated) {
+            gate.channels = S->channels;
             gate.flags = gflags;
             gate.thr[0] = S->thr[0], gate.thr[1] = S->thr[1], gate.thr[2] = S->thr[2];
             gate.c0_win = gp(S->g_c0_win);
@@ -2168,7 +2215,7 @@ extern "C" int dfx_stream_process(dfx_stream_state *S, const float *x, int64_t n
         }
         return DFX_OK;
     }
-    if (S->use_graph && advances && S->frames >= S->H + S->L) {
+    if (S->use_graph && advances && S->channels == 1 && S->frames >= S->H + S->L) {
         auto fp = [&](size_t o) { return reinterpret_cast<float *>(S->buf + o); };
         dfx_stream_state::Graph &g = S->graph[S->flip];
         const float beta = S->pf_beta;

@@ -13,7 +13,11 @@ on how the signal is cut.  It equals ``enhance(model, df_state, audio, pad=False
 ``gating=True`` switches on the reference runtime's per-frame decisions (tract.rs:513-525,658-672), taken independently by every
 stream: stages are skipped according to the local SNR (``thresholds`` = min_db, max_db_erb, max_db_df; reference defaults
 -10 / 30 / 20 dB), skipped decoders keep their state, and a stream that has been silent for more than five hops is answered with
-zeros without being processed.  Not implemented: multi-channel streams (mask reduction, tract.rs:868-902).
+zeros without being processed.
+
+``channels=k`` makes every k consecutive rows the channels of one stream (``RuntimeParams::n_ch``): per-channel STFT / network state,
+one ERB mask per stream (``reduce_mask`` = "mean" (reference default) | "max" | "none", tract.rs:96-118,868-902), one stage decision
+per stream (taken from its first channel's local SNR).
 """
 from __future__ import annotations
 
@@ -29,7 +33,8 @@ from .model import DfNet
 
 class DfStream:
     def __init__(self, model: DfNet, df_state: DF, streams: int = 1, max_frames: int = 1, atten_lim_db: Optional[float] = None,
-                 gating: bool = False, thresholds: Optional[Tuple[float, float, float]] = None):
+                 gating: bool = False, thresholds: Optional[Tuple[float, float, float]] = None, channels: int = 1,
+                 reduce_mask: str = "mean"):
         if not isinstance(model, DfNet):
             raise TypeError("DfStream needs a deepfilternet_amd.DfNet (see init_df)")
         h = C.c_void_p()
@@ -39,6 +44,9 @@ class DfStream:
         self.streams, self.max_frames = int(streams), int(max_frames)
         if atten_lim_db is not None:
             self.set_atten_lim(atten_lim_db)
+        if channels != 1:
+            _lib.check(_lib.lib().dfx_stream_set_channels(self._h, int(channels), {"none": 0, "max": 1, "mean": 2}[reduce_mask]))
+        self.channels = int(channels)
         if thresholds is not None:
             self.set_thresholds(*thresholds)
         if gating:

@@ -217,7 +217,11 @@ int dfx_enhance(const dfx_model *m, const dfx_state *st, const float *x, int64_t
  *   hop: lsnr < min: zero mask, no DF; lsnr > max_erb: the spectrum passes unchanged; lsnr > max_df: mask only; otherwise mask +
  *   DF.  A decoder that is skipped keeps its state (GRU hidden states, the delay line in front of df_convp), a frozen stream all of
  *   its state, exactly like tract's pulsed sub-models, which only advance when they are run.  A call of n hops is then n passes.
- *   Not implemented: multi-channel streams and their mask reduction (tract.rs:868-902; df_create is mono, capi.rs:83-104).
+ *   Multi-channel streams (dfx_stream_set_channels; RuntimeParams::n_ch, tract.rs:119-176; df_create itself is mono, capi.rs:83-104):
+ *   `channels` consecutive rows are the channels of one stream.  Every channel has its own STFT / feature / network state; the ERB
+ *   masks of a stream's channels are reduced to one mask (ReduceMask: 0 none, 1 max, 2 mean = the reference default, :96-118,868-902)
+ *   that is applied to all of them; with gating the silent-input test runs over all channels of the hop and the stage decision is
+ *   taken from the first channel's local SNR (:468), one decision and one skip counter per stream.
  * lsnr (optional) receives the local SNR estimate [streams, n] in dB (df_process_frame's return value); not meaningful for the
  * warm-up hops.
  * ---------------------------------------------------------------------------------------------------------------- */
@@ -229,6 +233,7 @@ int dfx_stream_frame_length(const dfx_stream_state *s);                  /* hop 
 int dfx_stream_delay_frames(const dfx_stream_state *s);                  /* lookahead in hops */
 int dfx_stream_set_atten_lim(dfx_stream_state *s, float lim_db);         /* df_set_atten_lim: |dB| >= 100 off, < 0.01 bypass */
 int dfx_stream_set_post_filter_beta(dfx_stream_state *s, float beta);    /* df_set_post_filter_beta: 0 disables the post filter */
+int dfx_stream_set_channels(dfx_stream_state *s, int channels, int reduce_mask); /* rows per stream; 0 none / 1 max / 2 mean */
 int dfx_stream_set_gating(dfx_stream_state *s, int enable);              /* DfTract::process's per-frame stage decisions, per stream */
 int dfx_stream_set_thresholds(dfx_stream_state *s, float min_db_thresh, float max_db_erb_thresh,
                               float max_db_df_thresh);                   /* RuntimeParams::with_thresholds (tract.rs:160-170) */

@@ -51,23 +51,27 @@ def apply_stages(lsnr: float, thr: Tuple[float, float, float]) -> Tuple[bool, bo
 
 
 def hop_mean_square(x: np.ndarray) -> np.float32:
-    """tract.rs:513-516: fold over the hop in f32, acc + x.powi(2), divided by the length."""
+    """tract.rs:513-516: fold over the hop in f32, acc + x.powi(2), divided by the length.  x: [hop] or [ch, hop] (the reference
+    iterates its [ch, hop] array in memory order: channel after channel)."""
     e = np.float32(0.0)
-    for v in x.astype(np.float32):
+    flat = np.asarray(x, dtype=np.float32).reshape(-1)
+    for v in flat:
         e = np.float32(e + np.float32(v * v))
-    return np.float32(e / np.float32(len(x)))
+    return np.float32(e / np.float32(flat.size))
 
 
 def _features(p: ModelParams, hops: np.ndarray):
+    """hops [K, ch, hop] -> (DF state, spec [ch, K, F], erb feat [ch, K, E], spec feat [ch, K, F']); channels are independent (each
+    has its own DFState in the reference, tract.rs:424-436)."""
     st = L.DF(p.sr, p.fft_size, p.hop_size, p.nb_erb, p.min_nb_freqs)
-    audio = np.ascontiguousarray(hops.reshape(1, -1), dtype=np.float32)
+    audio = np.ascontiguousarray(hops.transpose(1, 0, 2).reshape(hops.shape[1], -1), dtype=np.float32)
     spec, fe, fs = O.df_features(L, audio, st, p.nb_df, p.norm_alpha())
     return st, spec, fe, fs
 
 
 def _encoder(p: ModelParams, sd, fe: np.ndarray, fs: np.ndarray):
     fe_t = O.pad_feat(torch.from_numpy(fe).unsqueeze(1), p.conv_lookahead)
-    fs_t = torch.view_as_real(torch.from_numpy(fs)).unsqueeze(1).squeeze(1).permute(0, 3, 1, 2)
+    fs_t = torch.view_as_real(torch.from_numpy(fs)).permute(0, 3, 1, 2)
     fs_t = O.pad_feat(fs_t, p.conv_lookahead)
     return O.dfnet_encoder(p, sd, fe_t, fs_t)
 
@@ -75,22 +79,35 @@ def _encoder(p: ModelParams, sd, fe: np.ndarray, fs: np.ndarray):
 @torch.no_grad()
 def process_stream(p: ModelParams, sd: Dict[str, torch.Tensor], x: np.ndarray, atten_lim_db: Optional[float] = None,
                    pf_beta: Optional[float] = None,
-                   thresholds: Tuple[float, float, float] = (MIN_DB_THRESH, MAX_DB_ERB_THRESH, MAX_DB_DF_THRESH)):
-    """One mono stream, hop by hop.  x f32 [n_hops*hop] -> (y f32 [n_hops*hop], lsnr f32 [n_hops], info dict).
+                   thresholds: Tuple[float, float, float] = (MIN_DB_THRESH, MAX_DB_ERB_THRESH, MAX_DB_DF_THRESH),
+                   reduce_mask: str = "mean"):
+    """One stream, hop by hop.  x f32 [n_hops*hop] (mono) or [ch, n_hops*hop] -> (y like x, lsnr f32 [n_hops], info dict).
 
+    Multi-channel (tract.rs:119-176 ``n_ch``, :96-118,868-902 ``ReduceMask``): per-channel STFT / features / network state; the
+    silent-input fold runs over all channels of the hop; the stage decision is taken from channel 0's lsnr (:468 ``to_scalar``); the
+    ERB decoder's masks are reduced over the channels ("mean": sum * (1/ch); "max"; "none") and the reduced mask is applied to every
+    channel (:547-556).
     info["accepted"]: hop indices that were processed; info["flags"]: per net position (apply_gains, zeros, apply_df)."""
     assert p.conv_lookahead == p.df_lookahead, "like dfx_stream_create"
+    mono = x.ndim == 1
+    x2 = np.asarray(x, dtype=np.float32).reshape(1, -1) if mono else np.asarray(x, dtype=np.float32)
+    ch = x2.shape[0]
     hop, Lk, O_ = p.hop_size, p.df_lookahead, p.df_order
-    n_hops = len(x) // hop
-    hops = np.ascontiguousarray(x[: n_hops * hop].reshape(n_hops, hop), dtype=np.float32)
+    n_hops = x2.shape[1] // hop
+    hops = np.ascontiguousarray(x2[:, : n_hops * hop].reshape(ch, n_hops, hop).transpose(1, 0, 2))   # [n_hops, ch, hop]
     y = np.zeros_like(hops)
     lsnr_out = np.zeros(n_hops, dtype=np.float32)
+
+    def ret(yh, ls, info):
+        out = np.ascontiguousarray(yh.transpose(1, 0, 2).reshape(ch, -1))
+        return (out[0] if mono else out), ls, info
+
     lim = None
     if atten_lim_db is not None:
         a = abs(atten_lim_db)
         lim = None if a >= 100 else (1.0 if a < 0.01 else float(np.float32(10.0) ** np.float32(-a / 20.0)))
     if lim == 1.0:  # dfx_stream_process: pass-through, no state moves at all
-        return hops.reshape(-1).copy(), np.full(n_hops, 35.0, np.float32), {"accepted": [], "flags": []}
+        return ret(hops.copy(), np.full(n_hops, 35.0, np.float32), {"accepted": [], "flags": []})
     beta = pf_beta if pf_beta is not None else (p.pf_beta if p.mask_pf else 0.0)
     # ---- pass 1: which hops are processed.  The decision for hop a depends on the lsnr of earlier positions (counter += 1 when the
     # gains were skipped), which is causal: the encoder run on the accepted prefix gives it (prefix property of the batch path).
@@ -115,7 +132,7 @@ def process_stream(p: ModelParams, sd: Dict[str, torch.Tensor], x: np.ndarray, a
         skip_counter = 0 if (g or z) else skip_counter + 1
     K = len(accepted)
     if K == 0:
-        return y.reshape(-1), lsnr_out, {"accepted": [], "flags": []}
+        return ret(y, lsnr_out, {"accepted": [], "flags": []})
     # ---- pass 2: the accepted hops as one sequence; positions 0 .. K-1-Lk are emitted at steps Lk .. K-1
     st, spec, fe, fs = _features(p, hops[accepted])
     enc = _encoder(p, sd, fe, fs)
@@ -124,41 +141,48 @@ def process_stream(p: ModelParams, sd: Dict[str, torch.Tensor], x: np.ndarray, a
     flags = [apply_stages(float(lsnr[q]), thresholds) for q in range(P)]
     F = p.fft_size // 2 + 1
     widths = st.erb_widths()
-    spec_t = torch.from_numpy(spec)                                    # [1, K, F] complex
-    gains = torch.ones(P, p.nb_erb)
+    spec_t = torch.from_numpy(spec)                                    # [ch, K, F] complex
+    gains = torch.ones(ch, P, p.nb_erb)
     idx_g = [q for q in range(P) if flags[q][0]]
     idx_d = [q for q in range(P) if flags[q][2]]
     for q in range(P):
         if flags[q][1]:
-            gains[q] = 0.0
+            gains[:, q] = 0.0
     if idx_g:
         ig = torch.as_tensor(idx_g)
         m = O.dfnet_erb_decoder(p, sd, enc["emb"][:, ig], enc["e3"][:, :, ig], enc["e2"][:, :, ig], enc["e1"][:, :, ig],
-                                enc["e0"][:, :, ig])["m"]
-        gains[ig] = m[0, 0]
-    spec_e = spec_t[0, :P] * O.band_gain(gains, widths)                # mask on frame q (rolling_spec_buf_y[df_order-1])
+                                enc["e0"][:, :, ig])["m"][:, 0]      # [ch, nG, E]
+        if ch > 1 and reduce_mask == "mean":
+            acc = m[0].clone()
+            for c in range(1, ch):
+                acc = acc + m[c]
+            m = (acc * np.float32(1.0 / ch)).unsqueeze(0).expand(ch, -1, -1)
+        elif ch > 1 and reduce_mask == "max":
+            m = m.max(dim=0, keepdim=True).values.expand(ch, -1, -1)
+        gains[:, ig] = m
+    spec_e = spec_t[:, :P] * O.band_gain(gains, widths)                # mask on frame q (rolling_spec_buf_y[df_order-1])
     if idx_d:
         idd = torch.as_tensor(idx_d)
-        coefs = O.dfnet_df_decoder(p, sd, enc["emb"][:, idd], enc["c0"][:, :, idd])["df_coefs"]   # [1,O,nd,F',2]
-        cc = torch.view_as_complex(coefs.contiguous())[0]              # [O, nd, F']
-        xp = torch.view_as_real(spec_t[0, :, : p.nb_df])
+        coefs = O.dfnet_df_decoder(p, sd, enc["emb"][:, idd], enc["c0"][:, :, idd])["df_coefs"]   # [ch,O,nd,F',2]
+        cc = torch.view_as_complex(coefs.contiguous())                 # [ch, O, nd, F']
+        xp = torch.view_as_real(spec_t[:, :, : p.nb_df])
         xp = torch.nn.functional.pad(xp, (0, 0, 0, 0, O_ - 1 - Lk, Lk))
         xp = torch.view_as_complex(xp.contiguous())                    # frame q + n - (O-1-la) at row q + n
         for j, q in enumerate(idx_d):
-            acc = torch.zeros(p.nb_df, dtype=spec_t.dtype)
+            acc = torch.zeros(ch, p.nb_df, dtype=spec_t.dtype)
             for n in range(O_):
-                acc = acc + cc[n, j] * xp[q + n]
-            spec_e[q, : p.nb_df] = acc
+                acc = acc + cc[:, n, j] * xp[:, q + n]
+            spec_e[:, q, : p.nb_df] = acc
     if beta > 0:
         for q in idx_g:                                                # tract.rs:603-610: only when stage 1 ran
-            spec_e[q] = O.post_filter(spec_t[0, q], spec_e[q], beta)
+            spec_e[:, q] = O.post_filter(spec_t[:, q], spec_e[:, q], beta)
     if lim is not None:
-        spec_e = spec_t[0, :P] * lim + spec_e * (1 - lim)
-    out_spec = np.zeros((1, K, F), dtype=np.complex64)
-    out_spec[0, Lk:] = spec_e.numpy()
-    ys = st.synthesis(out_spec).reshape(K, hop)
+        spec_e = spec_t[:, :P] * lim + spec_e * (1 - lim)
+    out_spec = np.zeros((ch, K, F), dtype=np.complex64)
+    out_spec[:, Lk:] = spec_e.numpy()
+    ys = st.synthesis(out_spec).reshape(ch, K, hop)
     for k, a in enumerate(accepted):
-        y[a] = ys[k]
+        y[a] = ys[:, k]
         if k >= Lk:
             lsnr_out[a] = lsnr[k - Lk]
-    return y.reshape(-1), lsnr_out, {"accepted": accepted, "flags": flags, "lsnr_pass1": lsnr_pos}
+    return ret(y, lsnr_out, {"accepted": accepted, "flags": flags, "lsnr_pass1": lsnr_pos})

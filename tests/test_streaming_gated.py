@@ -150,3 +150,44 @@ def test_gating_defaults_and_controls(backend):
     rt.set_atten_lim(0.0)
     y3, l3 = rt.process(torch.from_numpy(x[:, :HOP]), return_lsnr=True)
     assert np.array_equal(y3.numpy(), x[:, :HOP]) and np.all(l3.numpy() == 35.0)
+
+
+@pytest.mark.parametrize("reduce_mask,gating", [("mean", True), ("max", False)])
+def test_multichannel_streams(backend, reduce_mask, gating):
+    """RuntimeParams::n_ch (tract.rs:119-176): rows [2k, 2k+1] are the two channels of stream k — own STFT / network state per channel,
+    one reduced ERB mask per stream (ReduceMask, :96-118,868-902), one stage decision (channel 0's lsnr) and one silent-input counter
+    per stream."""
+    from deepfilternet_amd.enhance import init_df
+    from deepfilternet_amd.streaming import DfStream
+
+    if emu_subset(backend) and not gating:
+        pytest.skip("interpreter subset: the gated mean-reduction case runs here (DFX_EMU_ALL=1 runs both)")
+    p = named_params("pf32")
+    sd = torch_sd(p, 9)
+    model, df_state, _, _ = init_df(params=p, epoch="none", seed=9)
+    T = 12 if backend == "emu" else 24
+    rng = np.random.default_rng(5)
+    x = (0.1 * rng.standard_normal((4, HOP * T))).astype(np.float32)
+    x[1] *= 0.3                                        # the channels of a stream differ
+    x[2:, : HOP * 8] = 0                               # stream 1 starts with silence on both channels
+    x[3, HOP * 2: HOP * 3] = 0.05                      # ... except one hop on its second channel: the fold runs over all channels
+    if gating:
+        thr = _thresholds(p, sd, x[[0, 2]], (0.15, 0.85, 0.5))
+    else:
+        thr = (-1e9, 1e9, 1e9)
+    ref = [S.process_stream(p, sd, x[2 * k: 2 * k + 2], thresholds=thr, reduce_mask=reduce_mask) for k in range(2)]
+    if gating:
+        for r in ref:
+            v = np.asarray(r[2]["lsnr_pass1"])
+            assert min(np.abs(v - t).min() for t in thr) > 1e-4
+        assert len(ref[1][2]["accepted"]) < T          # stream 1 was frozen for a while, as a whole
+    rt = DfStream(model, df_state, streams=4, max_frames=2, gating=gating, thresholds=thr if gating else None, channels=2,
+                  reduce_mask=reduce_mask)
+    y, lsnr = _run(rt, x, [2] * (T // 2))
+    for k in range(2):
+        assert rms(y[2 * k: 2 * k + 2] - ref[k][0]) < 1e-6, (k, rms(y[2 * k: 2 * k + 2] - ref[k][0]))
+    # the reduction really couples the channels: a mono run of channel 0 differs
+    mono = S.process_stream(p, sd, x[0], thresholds=thr)[0]
+    assert rms(mono - ref[0][0][0]) > 1e-5
+    with pytest.raises(RuntimeError):
+        DfStream(model, df_state, streams=3, channels=2)
