@@ -82,3 +82,27 @@ def test_package_lazy_attributes():
     assert callable(d.init_df) and callable(d.enhance_files)
     with pytest.raises(AttributeError):
         d.no_such_thing
+
+
+def test_headers_are_plain_c_and_the_example_links(tmp_path):
+    """include/dfx.h and include/df_capi.h compile as C99 (no C++-isms leak into the ABI), and a C host written against the
+    reference's API (examples/df_capi_loop.c) links against libdfx.so and fails cleanly when there is no model."""
+    import subprocess
+
+    from deepfilternet_amd.build import build
+
+    lib = build()
+    inc = os.path.join(REPO, "include")
+    probe = tmp_path / "probe.c"
+    probe.write_text('#include "dfx.h"\n#include "df_capi.h"\nint main(void) { dfx_model_cfg c; (void)c; return dfx_version() < 0; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{inc}", "-c", str(probe), "-o", str(tmp_path / "probe.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exe = tmp_path / "df_loop"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", f"-I{inc}", os.path.join(REPO, "examples", "df_capi_loop.c"), f"-L{os.path.dirname(lib)}", "-ldfx",
+                        f"-Wl,-rpath,{os.path.dirname(lib)}", "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+    r = subprocess.run([str(exe), str(tmp_path / "missing.dfx")], capture_output=True, text=True, input="")
+    assert r.returncode == 1 and "df_create failed" in r.stderr and "missing.dfx" in r.stderr
