@@ -105,6 +105,7 @@ SIGNATURES = {
     "dfx_stream_set_gating": (_i, [_vp, _i]),
     "dfx_stream_set_thresholds": (_i, [_vp, _f, _f, _f]),
     "dfx_stream_process": (_i, [_vp, _fp, _i64, _fp, _fp, _vp]),
+    "dfx_stream_process_raw": (_i, [_vp, _fp, _fp, _fp, _vp, _fp, _vp]),
     "dfx_prof_kernel_count": (_i, []),
     "dfx_prof_kernel_name": (C.c_char_p, [_i]),
     "dfx_prof_enable": (_i, [C.c_uint32]),

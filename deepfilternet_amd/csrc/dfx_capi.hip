@@ -58,6 +58,7 @@ struct DFState {
     dfx_state *st = nullptr;
     dfx_stream_state *rt = nullptr;
     float *d_io = nullptr;  // [hop] in, [hop] out, [1] lsnr
+    float *d_raw = nullptr; // df_process_frame_raw: spectrum, gains, coefficients, lsnr, stage flags
     int hop = 0;
     bool logging = false;
     std::deque<std::string> log;
@@ -72,6 +73,7 @@ static void df_destroy(DFState *s) {
     if (s->st) dfx_state_free(s->st);
     if (s->model) dfx_model_free(s->model);
     if (s->d_io) (void)hipFree(s->d_io);
+    if (s->d_raw) (void)hipFree(s->d_raw);
     delete s;
 }
 
@@ -156,6 +158,37 @@ extern "C" float df_process_frame(DFState *st, float *input, float *output) {
     if (dfx_stream_process(st->rt, dx, 1, dy, dl, nullptr) != DFX_OK) df_panic("Failed to process DF frame");
     if (hipMemcpy(output, dy, hb, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&lsnr, dl, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
         df_panic("Failed to process DF frame (download)");
+    return lsnr;
+}
+
+// capi.rs:172-210.  input [n_freqs, 2]; *out_gains_p -> [nb_erb], *out_coefs_p -> [df_order, nb_df, 2] (the shape the reference
+// documents and views its output buffer with, capi.rs:183-184,205-206); a pointer is set to NULL when its stage did not run.
+extern "C" float df_process_frame_raw(DFState *st, float *input, float **out_gains_p, float **out_coefs_p) {
+    if (!st || !input || !out_gains_p || !out_coefs_p) df_panic("Invalid pointer");
+    dfx_model_cfg c;
+    if (dfx_model_cfg_get(st->model, &c) != DFX_OK) df_panic("Failed to process DF spectral frame");
+    const size_t F = (size_t)c.fft_size / 2 + 1, ng = (size_t)c.nb_erb, nc = (size_t)c.df_order * c.nb_df * 2;
+    if (!st->d_raw) {
+        if (hipMalloc(reinterpret_cast<void **>(&st->d_raw), (F * 2 + ng + nc + 2) * sizeof(float)) != hipSuccess) df_panic("Failed to set input spectrum");
+    }
+    float *dspec = st->d_raw, *dg = dspec + F * 2, *dc = dg + ng, *dl = dc + nc;
+    unsigned char *dflag = reinterpret_cast<unsigned char *>(dl + 1);
+    if (hipMemcpy(dspec, input, F * 2 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) df_panic("Failed to set input spectrum");
+    if (dfx_stream_process_raw(st->rt, dspec, dg, dc, dflag, dl, nullptr) != DFX_OK) df_panic("Failed to process DF spectral frame");
+    float lsnr = 0.f;
+    unsigned char flag = 0;
+    if (hipMemcpy(&lsnr, dl, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&flag, dflag, 1, hipMemcpyDeviceToHost) != hipSuccess)
+        df_panic("Failed to process DF spectral frame (download)");
+    if ((flag & 2) && *out_gains_p) {
+        if (hipMemcpy(*out_gains_p, dg, ng * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) df_panic("Failed to process DF spectral frame (download)");
+    } else {
+        *out_gains_p = nullptr;
+    }
+    if ((flag & 8) && *out_coefs_p) {
+        if (hipMemcpy(*out_coefs_p, dc, nc * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) df_panic("Failed to process DF spectral frame (download)");
+    } else {
+        *out_coefs_p = nullptr;
+    }
     return lsnr;
 }
 

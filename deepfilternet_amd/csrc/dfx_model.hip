@@ -1854,7 +1854,7 @@ struct dfx_stream_state {
     int channels = 1, reduce_mask = 2;    // multi-channel streams: ch consecutive rows per stream; ReduceMask::MEAN is the reference default
     float thr[3] = {-10.f, 30.f, 20.f};   // RuntimeParams::default_with_ch (tract.rs:177-189)
     unsigned char *gate_buf = nullptr;    // own allocation, made when gating is first switched on
-    size_t g_flags = 0, g_counter = 0, g_sh_erb = 0, g_sh_unit = 0, g_sh_h = 0, g_c0_win = 0, gate_bytes = 0;
+    size_t g_flags = 0, g_counter = 0, g_sh_erb = 0, g_sh_unit = 0, g_sh_h = 0, g_c0_win = 0, g_mask = 0, g_coefs = 0, gate_bytes = 0;
     // DFX_STREAM_GRAPH=1: steady-state calls are replayed from a hipGraph (one per memory parity) captured as a single-stream chain on
     // handle-owned I/O buffers (x / y are copied in and out around it).  Off by default: on ROCm 7.2 the replay of the ~35 kernel
     // nodes takes 2.0-2.2 ms per call where the plain three-stream launches take 1.4-1.6 ms.
@@ -2035,6 +2035,8 @@ extern "C" int dfx_stream_set_gating(dfx_stream_state *s, int enable) {
         s->g_sh_unit = take((size_t)B * c.nb_df * 4);
         s->g_sh_h = take((size_t)s->layers * B * 256 * 4);
         s->g_c0_win = take(c.df_pathway_kernel_size_t > 1 ? (size_t)B * T * c.nb_df * c.conv_ch * 4 : 256);
+        s->g_mask = take((size_t)B * T * c.nb_erb * 4);                       // dfx_stream_process_raw: the pass's mask / coefficients
+        s->g_coefs = take((size_t)B * c.df_order * T * c.nb_df * 8);
         s->gate_bytes = off;
         if (hipMalloc(reinterpret_cast<void **>(&s->gate_buf), off) != hipSuccess) {
             s->gate_buf = nullptr;
@@ -2265,6 +2267,113 @@ extern "C" int dfx_stream_process(dfx_stream_state *S, const float *x, int64_t n
         S->frames += n;
         S->flip ^= 1;
     }
+    return DFX_OK;
+}
+
+// DfTract::process_raw (tract.rs:441-507; exported as df_process_frame_raw, capi.rs:172-210): one *spectral* frame per stream in, the
+// raw ERB gains and deep-filter coefficients of that pass out — features with the running means, encoder, stage decisions, the
+// decoders that the decision selects (their state only moves when they run).  No STFT, no deep filtering, no synthesis, and (like the
+// reference) neither the rolling spectra nor the silent-input counter are touched.  Needs gating (dfx_stream_set_gating); a handle
+// should be driven either by dfx_stream_process or by this function, not by both.
+//   spec [streams, F][2] -> gains [streams, nb_erb], coefs [streams, df_order, nb_df][2], stages [streams]: bit 1 (2) = gains present
+//   (the network's mask, or zeros when lsnr < min_db_thresh), bit 3 (8) = coefficients present; a caller maps absent to NULL.
+extern "C" int dfx_stream_process_raw(dfx_stream_state *S, const float *spec, float *gains, float *coefs, unsigned char *stages, float *lsnr_out,
+                                      void *stream) {
+    if (!S || !spec || !gains || !coefs || !stages) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_stream_process_raw: null argument");
+    if (!S->gated || !S->gate_buf) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_stream_process_raw: switch gating on first (dfx_stream_set_gating)");
+    if (int rc = dfx_require_device()) return rc;
+    hipStream_t s = dfx_stream(stream);
+    const dfx_model *m = S->m;
+    const dfx_state *st = S->st;
+    const dfx_model_cfg &c = m->cfg;
+    const int64_t B = S->B, H = S->H, L = S->L, Hs = H + L, F = st->N / 2 + 1, E = c.nb_erb, Fd = c.nb_df, hop = st->hop, ML = st->N - hop;
+    const int64_t n = 1, T = H + n, a0 = S->frames;
+    const int O = c.df_order;
+    auto fp = [&](size_t o) { return reinterpret_cast<float *>(S->buf + o); };
+    auto gp = [&](size_t o) { return reinterpret_cast<float *>(S->gate_buf + o); };
+    unsigned char *gflags = S->gate_buf + S->g_flags;
+    int rc;
+    DFX_HIP(hipMemsetAsync(gflags, 0, (size_t)B, s));  // no silent-input test on this path (tract.rs:441: process_raw starts at the features)
+    DFX_HIP(hipMemcpyAsync(gp(S->g_sh_erb), fp(S->erb_state), (size_t)B * E * 4, hipMemcpyDeviceToDevice, s));
+    DFX_HIP(hipMemcpyAsync(gp(S->g_sh_unit), fp(S->unit_state), (size_t)B * Fd * 4, hipMemcpyDeviceToDevice, s));
+    DFX_HIP(hipMemcpyAsync(gp(S->g_sh_h), fp(S->h_state), (size_t)S->layers * B * 256 * 4, hipMemcpyDeviceToDevice, s));
+    // features of the given spectra (state: the running means): erb (dB) -> mean norm, low bins -> unit norm (lib.rs:206-217)
+    float *new_spec = fp(S->new_spec), *new_fe = fp(S->new_fe), *new_fs = fp(S->new_fs);
+    DFX_HIP(hipMemcpyAsync(new_spec, spec, (size_t)B * F * 8, hipMemcpyDeviceToDevice, s));
+    if ((rc = dfx_erb(st->bands, new_spec, B, 1, new_fe, s))) return rc;
+    if ((rc = dfx_launch_norm_scan(new_fe, new_fe, (int)E, new_spec, F, new_fs, (int)Fd, B, n, c.norm_alpha, fp(S->erb_state),
+                                   fp(S->unit_state), s)))
+        return rc;
+    const int64_t skip = a0 < L ? 1 : 0;
+    float *work_fe = fp(S->work_fe), *work_fs = fp(S->work_fs);
+    struct Ring { size_t *hist; float *nw, *work; int64_t h, row; } rings[2] = {{S->hist_fe, new_fe, work_fe, H, E}, {S->hist_fs, new_fs, work_fs, H, Fd * 2}};
+    for (const Ring &r : rings) {
+        DfxKScope ks(DFX_K_COPY_ROWS, s);
+        dfx_launch(dfx_k_ring_step, dim3((unsigned)nn_grid(dfx_ceil_div(B * (r.h + n) * r.row, 256), 16)), dim3(256), 0, s,
+                   (const float *)fp(r.hist[S->flip]), (const float *)r.nw, r.work, fp(r.hist[S->flip ^ 1]), B, r.h, n, r.row, skip);
+        DFX_LAUNCH_CHECK();
+    }
+    // the buffers this path does not use keep their contents across the parity flip
+    DFX_HIP(hipMemcpyAsync(fp(S->ana_mem[S->flip ^ 1]), fp(S->ana_mem[S->flip]), (size_t)B * ML * 4, hipMemcpyDeviceToDevice, s));
+    DFX_HIP(hipMemcpyAsync(fp(S->syn_mem[S->flip ^ 1]), fp(S->syn_mem[S->flip]), (size_t)B * ML * 4, hipMemcpyDeviceToDevice, s));
+    DFX_HIP(hipMemcpyAsync(fp(S->hist_spec[S->flip ^ 1]), fp(S->hist_spec[S->flip]), (size_t)B * Hs * F * 8, hipMemcpyDeviceToDevice, s));
+    float *mask = gp(S->g_mask), *cbuf = gp(S->g_coefs);
+    if (!skip) {
+        DfxStreamCtx sc;
+        sc.H = H;
+        const int64_t pos0 = Hs - a0;
+        sc.t_zero = pos0 > 0 ? pos0 : 0;
+        sc.spec_T = Hs + n;
+        sc.h_state = fp(S->h_state);
+        sc.pf_beta = 0.f;
+        sc.out = fp(S->out_spec);  // the deep-filter kernel still runs (on whatever the spectrum window holds); its output is not used
+        sc.out_T = n;
+        sc.out_toff = H;
+        sc.serial = false;
+        sc.channels = S->channels;
+        sc.reduce_mask = S->reduce_mask;
+        DfxGate gate;
+        gate.channels = S->channels;
+        gate.flags = gflags;
+        gate.thr[0] = S->thr[0], gate.thr[1] = S->thr[1], gate.thr[2] = S->thr[2];
+        gate.c0_win = gp(S->g_c0_win);
+        sc.gate = &gate;
+        float *ws = reinterpret_cast<float *>(((uintptr_t)(S->buf + S->model_ws) + 255) & ~(uintptr_t)255);
+        const DfxLane *ln = &m->lanes[0];
+        switch (c.conv_ch) {
+            case 16: rc = forward_impl<16>(m, st->bands, fp(S->work_spec), work_fe, work_fs, B, T, 0.f, nullptr, mask, fp(S->lsnr), cbuf, ws, s, ln, false, nullptr, &sc); break;
+            case 32: rc = forward_impl<32>(m, st->bands, fp(S->work_spec), work_fe, work_fs, B, T, 0.f, nullptr, mask, fp(S->lsnr), cbuf, ws, s, ln, false, nullptr, &sc); break;
+            case 64: rc = forward_impl<64>(m, st->bands, fp(S->work_spec), work_fe, work_fs, B, T, 0.f, nullptr, mask, fp(S->lsnr), cbuf, ws, s, ln, false, nullptr, &sc); break;
+            default: DFX_FAIL(DFX_ERR_UNSUPPORTED, "conv_ch");
+        }
+        if (rc) return rc;
+        if (c.df_pathway_kernel_size_t > 1) {
+            dfx_launch(dfx_k_gate_c0_shift, dim3((unsigned)B, 4), dim3(256), 0, s, (const unsigned char *)gflags, gp(S->g_c0_win), B, T,
+                       c.df_pathway_kernel_size_t, (int64_t)Fd * c.conv_ch);
+            DFX_LAUNCH_CHECK();
+        }
+        // the newest frame's mask row and coefficient rows (coefficients are [B, O, T, F'][2]: one strided row per (stream, tap))
+        if ((rc = stream_copy_rows(mask, T * E, T * E, (T - 1) * E, gains, E, E, B, s))) return rc;
+        if ((rc = stream_copy_rows(cbuf, T * Fd * 2, T * Fd * 2, (T - 1) * Fd * 2, coefs, Fd * 2, Fd * 2, B * O, s))) return rc;
+        if (lsnr_out && (rc = stream_copy_rows(fp(S->lsnr), T, T, H, lsnr_out, 1, 1, B, s))) return rc;
+        // decoder states of the stages that did not run go back to what they were
+        DfxGateTable G;
+        G.n = 0;
+        const int nenc = (int)m->enc_gru.size(), ndec = (int)m->dec_gru.size();
+        for (int l = nenc; l < S->layers; ++l) {
+            G.dst[G.n] = fp(S->h_state) + (int64_t)l * B * 256, G.src[G.n] = gp(S->g_sh_h) + (int64_t)l * B * 256, G.row[G.n] = 256;
+            G.mask[G.n] = l < nenc + ndec ? DFX_GATE_GAINS : DFX_GATE_DF, G.want[G.n] = 0;
+            ++G.n;
+        }
+        dfx_launch(dfx_k_gate_commit, dim3((unsigned)B), dim3(128), 0, s, G, (const unsigned char *)gflags, B);
+        DFX_LAUNCH_CHECK();
+    } else if (lsnr_out) {
+        dfx_launch(dfx_k_fill_rows, dim3((unsigned)nn_grid(dfx_ceil_div(B, 256), 16)), dim3(256), 0, s, lsnr_out, (int64_t)1, (int64_t)1, B, -15.f);
+        DFX_LAUNCH_CHECK();
+    }
+    DFX_HIP(hipMemcpyAsync(stages, gflags, (size_t)B, hipMemcpyDeviceToDevice, s));
+    S->frames += 1;
+    S->flip ^= 1;
     return DFX_OK;
 }
 

@@ -106,3 +106,22 @@ class DfStream:
         _lib.check(_lib.lib().dfx_stream_process(self._h, _lib.ptr(x), n, _lib.ptr(y), _lib.ptr(lsnr), _lib.stream()))
         y = y.to(src_dev)
         return (y, lsnr.to(src_dev)) if return_lsnr else y
+
+    def process_raw(self, spec: torch.Tensor):
+        """df_process_frame_raw (capi.rs:172-210 -> DfTract::process_raw, tract.rs:441-507) for every stream: one spectral frame
+        ``spec`` [streams, F] complex64 (or [streams, F, 2] float32) -> (lsnr [streams], gains [streams, nb_erb], coefs
+        [streams, df_order, nb_df] complex64, stages [streams] uint8: bit value 2 = gains present, 8 = coefficients present — where the
+        reference hands back NULL pointers the arrays here hold placeholders).  Needs ``gating=True``."""
+        src_dev = spec.device
+        x = torch.view_as_real(spec) if spec.is_complex() else spec
+        x = x.to(_lib.device(), torch.float32).contiguous()
+        p = self._model.p
+        if x.dim() != 3 or x.shape[0] != self.streams or x.shape[1] != p.freq_bins or x.shape[2] != 2:
+            raise ValueError(f"spec must have shape [{self.streams}, {p.freq_bins}] complex")
+        gains = torch.empty((self.streams, p.nb_erb), dtype=torch.float32, device=x.device)
+        coefs = torch.empty((self.streams, p.df_order, p.nb_df, 2), dtype=torch.float32, device=x.device)
+        stages = torch.empty((self.streams,), dtype=torch.uint8, device=x.device)
+        lsnr = torch.empty((self.streams,), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().dfx_stream_process_raw(self._h, _lib.ptr(x), _lib.ptr(gains), _lib.ptr(coefs), _lib.ptr(stages), _lib.ptr(lsnr),
+                                                     _lib.stream()))
+        return lsnr.to(src_dev), gains.to(src_dev), torch.view_as_complex(coefs).to(src_dev), stages.to(src_dev)

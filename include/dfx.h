@@ -238,6 +238,12 @@ int dfx_stream_set_gating(dfx_stream_state *s, int enable);              /* DfTr
 int dfx_stream_set_thresholds(dfx_stream_state *s, float min_db_thresh, float max_db_erb_thresh,
                               float max_db_df_thresh);                   /* RuntimeParams::with_thresholds (tract.rs:160-170) */
 int dfx_stream_process(dfx_stream_state *s, const float *x, int64_t n_frames, float *y, float *lsnr, void *stream);
+/* DfTract::process_raw (tract.rs:441-507) == df_process_frame_raw (capi.rs:172-210) for every stream: one spectral frame
+ * spec [streams, F][2] in, the pass's raw ERB gains [streams, nb_erb] and deep-filter coefficients [streams, df_order, nb_df][2] out,
+ * stages [streams] saying which of them exist (bit value 2: gains — the network's mask, or zeros below min_db_thresh; 8: coefficients;
+ * the reference signals "absent" with NULL pointers).  Gating must be on; no STFT / deep filtering / synthesis happens here. */
+int dfx_stream_process_raw(dfx_stream_state *s, const float *spec, float *gains, float *coefs, unsigned char *stages, float *lsnr,
+                           void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Multi-frame Wiener / MVDR filters: df.multiframe.MfWf.forward (multiframe.py:282-321) and MfMvdr.forward (:373-413), the filter

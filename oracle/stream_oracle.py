@@ -186,3 +186,40 @@ def process_stream(p: ModelParams, sd: Dict[str, torch.Tensor], x: np.ndarray, a
         if k >= Lk:
             lsnr_out[a] = lsnr[k - Lk]
     return ret(y, lsnr_out, {"accepted": accepted, "flags": flags, "lsnr_pass1": lsnr_pos})
+
+
+@torch.no_grad()
+def process_raw_frames(p: ModelParams, sd: Dict[str, torch.Tensor], spec: np.ndarray,
+                       thresholds: Tuple[float, float, float] = (MIN_DB_THRESH, MAX_DB_ERB_THRESH, MAX_DB_DF_THRESH)):
+    """``DfTract::process_raw`` (tract.rs:441-507; df_process_frame_raw, capi.rs:172-210) frame after frame for one mono stream:
+    spec complex64 [K, F] -> per call k a tuple (lsnr, gains [E] or None, coefs complex [O, F'] or None); the first ``lookahead`` calls
+    yield (None, None, None) like the warm-up of dfx_stream_process_raw.  Features: lib.rs:206-217 with running means; stages and
+    decoder-state semantics as in :func:`process_stream`."""
+    K = spec.shape[0]
+    Lk = p.df_lookahead
+    spec1 = np.ascontiguousarray(spec[None].astype(np.complex64))
+    widths = L.erb_fb_widths(p.sr, p.fft_size, p.nb_erb, p.min_nb_freqs)
+    fe = L.erb_norm(L.erb(spec1, widths), p.norm_alpha())
+    fs = L.unit_norm(np.ascontiguousarray(spec1[..., : p.nb_df]), p.norm_alpha())
+    enc = _encoder(p, sd, fe, fs)
+    P = max(K - Lk, 0)
+    lsnr = enc["lsnr"][0, :, 0].numpy()
+    flags = [apply_stages(float(lsnr[q]), thresholds) for q in range(P)]
+    idx_g = [q for q in range(P) if flags[q][0]]
+    idx_d = [q for q in range(P) if flags[q][2]]
+    gains = {q: np.zeros(p.nb_erb, np.float32) for q in range(P) if flags[q][1]}
+    if idx_g:
+        ig = torch.as_tensor(idx_g)
+        m = O.dfnet_erb_decoder(p, sd, enc["emb"][:, ig], enc["e3"][:, :, ig], enc["e2"][:, :, ig], enc["e1"][:, :, ig],
+                                enc["e0"][:, :, ig])["m"][0, 0].numpy()
+        gains.update({q: m[j] for j, q in enumerate(idx_g)})
+    coefs = {}
+    if idx_d:
+        idd = torch.as_tensor(idx_d)
+        c = O.dfnet_df_decoder(p, sd, enc["emb"][:, idd], enc["c0"][:, :, idd])["df_coefs"]      # [1,O,nd,F',2]
+        cc = torch.view_as_complex(c.contiguous())[0].numpy()                                    # [O, nd, F']
+        coefs = {q: cc[:, j] for j, q in enumerate(idx_d)}
+    out = [(None, None, None)] * min(Lk, K)
+    for q in range(P):
+        out.append((float(lsnr[q]), gains.get(q), coefs.get(q)))
+    return out

@@ -36,7 +36,7 @@ def test_header_symbols_exported():
     src = re.sub(r"/\*.*?\*/", "", open(os.path.join(REPO, "include", "df_capi.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(df_[a-z_]+)\s*\(", src)))
     assert names == ["df_create", "df_free", "df_free_log_msg", "df_get_frame_length", "df_next_log_msg", "df_process_frame",
-                     "df_set_atten_lim", "df_set_post_filter_beta"]
+                     "df_process_frame_raw", "df_set_atten_lim", "df_set_post_filter_beta"]
     lib = C.CDLL(build())
     for n in names:
         assert hasattr(lib, n), n
@@ -97,3 +97,67 @@ def test_df_capi_frame_loop(backend, tmp_path):
     bad = tmp_path / "bad.dfx"
     bad.write_bytes(open(path, "rb").read()[:1000])
     assert lib.df_create(os.fsencode(str(bad)), 100.0, None) is None
+
+
+def test_process_frame_raw(backend, tmp_path):
+    """df_process_frame_raw (capi.rs:172-210 -> DfTract::process_raw, tract.rs:441-507): spectral frames in, raw ERB gains and DF
+    coefficients out, NULL where the stage decision skipped the decoder — through the batched dfx_stream_process_raw (two streams) and
+    through the reference-named C entry point, against oracle.stream_oracle.process_raw_frames."""
+    from deepfilternet_amd import _lib, export_dfx
+    from deepfilternet_amd.enhance import init_df
+    from deepfilternet_amd.state_dict import random_state_dict
+    from deepfilternet_amd.streaming import DfStream
+    from oracle import libdf_oracle as L
+
+    p = named_params("pf32")
+    sd_np = random_state_dict(p, 9)
+    sd = torch_sd(p, 9)
+    K = 8 if backend == "emu" else 24
+    rng = np.random.default_rng(11)
+    x = (0.1 * rng.standard_normal((2, HOP * K))).astype(np.float32)
+    x[1] *= np.linspace(0.02, 2.0, HOP * K).astype(np.float32)
+    spec = L.DF(p.sr, p.fft_size, p.hop_size, p.nb_erb, p.min_nb_freqs).analysis(x)        # [2, K, F] complex64
+    # thresholds inside this model's lsnr range (stage 1 always, stage 2 for the lower half), away from every observed value
+    free = [S.process_raw_frames(p, sd, spec[i], thresholds=(-1e9, 1e9, 1e9)) for i in range(2)]
+    vals = np.sort([r[0] for f in free for r in f if r[0] is not None])
+    j = max(range(len(vals) // 2 - 2, len(vals) // 2 + 2), key=lambda i: vals[i + 1] - vals[i])
+    thr = (-1e9, 1e9, float(vals[j] + vals[j + 1]) / 2)
+    ref = [S.process_raw_frames(p, sd, spec[i], thresholds=thr) for i in range(2)]
+    assert any(r[2] is None and r[1] is not None for f in ref for r in f) and any(r[2] is not None for f in ref for r in f)
+    model, df_state, _, _ = init_df(params=p, state_dict=sd_np, epoch="none")
+    rt = DfStream(model, df_state, streams=2, gating=True, thresholds=thr)
+    for k in range(K):
+        lsnr, gains, coefs, stages = rt.process_raw(torch.from_numpy(np.ascontiguousarray(spec[:, k])))
+        for i in range(2):
+            rl, rg, rc = ref[i][k]
+            if rl is None:
+                assert int(stages[i]) == 0 and float(lsnr[i]) == -15.0
+                continue
+            assert abs(float(lsnr[i]) - rl) < 1e-3
+            assert bool(int(stages[i]) & 2) == (rg is not None) and bool(int(stages[i]) & 8) == (rc is not None)
+            if rg is not None:
+                assert np.abs(gains[i].numpy() - rg).max() < 1e-5
+            if rc is not None:
+                assert np.abs(coefs[i].numpy() - rc).max() < 1e-5
+    # the reference-named entry point, one stream: default thresholds (-10 / 30 / 20 dB) -> both stages on these signals
+    path = export_dfx(str(tmp_path / "model.dfx"), params=p, state_dict=sd_np)
+    lib = _capi(C.CDLL(_lib.library_path()))
+    fp = C.POINTER(C.c_float)
+    lib.df_process_frame_raw.restype = C.c_float
+    lib.df_process_frame_raw.argtypes = [C.c_void_p, fp, C.POINTER(fp), C.POINTER(fp)]
+    st = lib.df_create(os.fsencode(path), 100.0, None)
+    assert st
+    dflt = S.process_raw_frames(p, sd, spec[0])
+    for k in range(min(K, 6)):
+        frame = np.ascontiguousarray(spec[0, k]).view(np.float32).copy()
+        g = np.zeros(p.nb_erb, np.float32)
+        c = np.zeros((p.df_order, p.nb_df, 2), np.float32)
+        gp_, cp_ = g.ctypes.data_as(fp), c.ctypes.data_as(fp)
+        lsnr = lib.df_process_frame_raw(st, frame.ctypes.data_as(fp), C.byref(gp_), C.byref(cp_))
+        rl, rg, rc = dflt[k]
+        if rl is None:
+            assert not gp_ and not cp_ and lsnr == -15.0
+            continue
+        assert abs(lsnr - rl) < 1e-3 and bool(gp_) == (rg is not None) and bool(cp_) == (rc is not None)
+        assert np.abs(g - rg).max() < 1e-5 and np.abs(c.view(np.complex64)[..., 0] - rc).max() < 1e-5
+    lib.df_free(st)
