@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import stream_oracle as S
-from tests.helpers import named_params, rms, torch_sd
+from tests.helpers import emu_subset, named_params, rms, torch_sd
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOP = 480
@@ -109,6 +109,8 @@ def test_process_frame_raw(backend, tmp_path):
     from deepfilternet_amd.streaming import DfStream
     from oracle import libdf_oracle as L
 
+    if emu_subset(backend):
+        pytest.skip("interpreter subset: runs on the GPU (DFX_EMU_ALL=1 runs it on the interpreter too)")
     p = named_params("pf32")
     sd_np = random_state_dict(p, 9)
     sd = torch_sd(p, 9)
