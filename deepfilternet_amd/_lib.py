@@ -70,6 +70,7 @@ SIGNATURES = {
     "dfx_unit_norm_init": (_i, [_i, _f32p]),
     "dfx_features": (_i, [_vp, _fp, _i64, _i64, _i64, _i, _f, _fp, _fp, _fp, _vp]),
     "dfx_df_apply": (_i, [_fp, _fp, _i, _fp, _vp, _i64, _i64, _i, _i, _i, _i, _f, _f, _fp, _vp]),
+    "dfx_df_apply_strided": (_i, [_fp, _i64, _fp, _i, _fp, _vp, _i64, _i64, _i, _i, _i, _i, _f, _f, _fp, _i64, _vp]),
     "dfx_model_tensor_count": (_i, [C.POINTER(ModelCfg), C.POINTER(_i)]),
     "dfx_model_tensor_info": (_i, [C.POINTER(ModelCfg), _i, C.c_char_p, _i, C.POINTER(_i64), C.POINTER(_i),
                                    C.POINTER(_i64)]),

@@ -85,13 +85,22 @@ struct DfxKScope {
 // ---- internal launchers shared between the DSP API and the model --------------------------------------------------
 // x_len < T: the samples [x_len, T) of every row are implicit zeros (x_stride may then be as small as x_len); -1 = T
 int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_stride,
-                        const float *mem_in, float *mem_out, float *spec, float *erb_db, hipStream_t s, int64_t x_len = -1);
+                        const float *mem_in, float *mem_out, float *spec, float *erb_db, hipStream_t s, int64_t x_len = -1,
+                        int64_t spec_stride = 0);  // spec_stride: row stride of spec in complex elements (0: F)
 int dfx_features_padded(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_len, int64_t x_stride, int nb_df,
-                        float alpha, float *spec, float *erb_feat, float *spec_feat, void *stream);
+                        float alpha, float *spec, float *erb_feat, float *spec_feat, void *stream, int64_t spec_stride = 0);
 // dfx_synthesis storing only stream samples [out_skip, out_skip + out_len) of every row, at out[row * out_stride + n - out_skip]
 int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int64_t Tf, const float *mem_in, float *mem_out,
                          float *out, int64_t out_stride, int64_t out_skip, int64_t out_len, hipStream_t s, int64_t f_begin = 0,
-                         int64_t f_end = -1);  // only output frames [f_begin, f_end) (time-chunked finishing)
+                         int64_t f_end = -1,   // only output frames [f_begin, f_end) (time-chunked finishing)
+                         int64_t spec_stride = 0);  // row stride of spec in complex elements (0: F)
 int dfx_launch_norm_scan(const float *erb_in, float *erb_out, int E, const float *spec_in, int64_t spec_frame_stride,
                          float *spec_out, int Fn, int64_t C, int64_t T, float alpha, float *erb_state,
                          float *unit_state, hipStream_t s);
+// Mask + MF.DF + post filter + atten_lim on frames [t_begin, t_end) of every clip (t_end < 0: T); coef_T: frames per clip of the
+// coefficient / gain arrays (default T); out_T / out_toff: compacted output rows (default T / 0); spec_stride / out_stride: row
+// strides in complex elements (0: F; even strides = 16-byte aligned rows take the row-streaming kernel)
+int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, const float *gains, const dfx_bands *bands, int64_t B,
+                        int64_t T, int F, int nb_df, int order, int lookahead, float pf_beta, float atten_lim, float *out, hipStream_t s,
+                        int64_t t_begin = 0, int64_t t_end = -1, int64_t coef_T = -1, int64_t out_T = -1, int64_t out_toff = 0,
+                        int64_t spec_stride = 0, int64_t out_stride = 0);

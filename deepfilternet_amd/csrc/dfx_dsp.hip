@@ -304,7 +304,8 @@ static int grid_for(int64_t work_groups) {
 }
 
 int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_stride,
-                        const float *mem_in, float *mem_out, float *spec, float *erb_db, hipStream_t s, int64_t x_len) {
+                        const float *mem_in, float *mem_out, float *spec, float *erb_db, hipStream_t s, int64_t x_len,
+                        int64_t spec_stride) {
     const int64_t Tf = T / st->hop;
     const int ML = st->N - st->hop;
     if (B > 0 && Tf > 0) {
@@ -321,6 +322,7 @@ int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t 
         A.Tf = Tf;
         A.x_stride = x_stride;
         A.x_len = x_len < 0 ? T : x_len;
+        A.spec_stride = spec_stride > 0 ? spec_stride : st->N / 2 + 1;
         A.hop = st->hop;
         A.nb = st->nb;
         A.wnorm = st->wnorm;
@@ -376,8 +378,9 @@ extern "C" int dfx_synthesis(const dfx_state *st, const float *spec, int64_t B, 
 
 int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int64_t Tf, const float *mem_in, float *mem_out,
                          float *out, int64_t out_stride, int64_t out_skip, int64_t out_len, hipStream_t stream, int64_t f_begin,
-                         int64_t f_end) {
+                         int64_t f_end, int64_t spec_stride) {
     DfxSynArgs A;
+    A.spec_stride = spec_stride > 0 ? spec_stride : st->N / 2 + 1;
     const int Rr = (st->N + st->hop - 1) / st->hop;
     A.f_begin = f_begin;
     A.f_end = f_end < 0 ? Tf + (mem_out ? Rr - 1 : 0) : f_end;
@@ -462,7 +465,8 @@ extern "C" int dfx_features(const dfx_state *st, const float *x, int64_t B, int6
 
 // dfx_features over rows of T samples of which only the first x_len exist in memory (the rest are zeros): enhance()'s end padding
 int dfx_features_padded(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_len, int64_t x_stride, int nb_df,
-                        float alpha, float *spec, float *erb_feat, float *spec_feat, void *stream) {
+                        float alpha, float *spec, float *erb_feat, float *spec_feat, void *stream, int64_t spec_stride) {
+    if (spec_stride <= 0) spec_stride = st ? st->N / 2 + 1 : 0;
     if (!st || B < 0 || T < 0 || x_len < 0 || x_len > T || x_stride < x_len || nb_df <= 0 || nb_df > st->N / 2 + 1)
         DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_features: bad arguments");
     if (int rc = dfx_require_device()) return rc;
@@ -470,22 +474,82 @@ int dfx_features_padded(const dfx_state *st, const float *x, int64_t B, int64_t 
     if (B == 0 || Tf == 0) return DFX_OK;
     if (!x || !spec || !erb_feat || !spec_feat) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_features: null buffer");
     // enhance.py:190-197: spec = analysis(x); erb_norm(erb(spec)); unit_norm(spec[..., :nb_df])
-    if (int rc = dfx_launch_analysis(st, x, B, T, x_stride, nullptr, nullptr, spec, erb_feat, dfx_stream(stream), x_len)) return rc;
-    return dfx_launch_norm_scan(erb_feat, erb_feat, st->nb, spec, st->N / 2 + 1, spec_feat, nb_df, B, Tf, alpha, nullptr,
+    if (int rc = dfx_launch_analysis(st, x, B, T, x_stride, nullptr, nullptr, spec, erb_feat, dfx_stream(stream), x_len, spec_stride)) return rc;
+    return dfx_launch_norm_scan(erb_feat, erb_feat, st->nb, spec, spec_stride, spec_feat, nb_df, B, Tf, alpha, nullptr,
                                 nullptr, dfx_stream(stream));
+}
+
+// frames [t_begin, t_end) of every clip (t_end < 0: T); coef_T: frames per clip of the coefficient / gain arrays (default T);
+// out_T / out_toff: compacted output rows (default T / 0); spec_stride / out_stride: row strides in complex elements (0: F).
+// Rows that are 16-byte aligned (even strides: the engine's own padded spec buffers) take the row-streaming kernel
+// dfx_k_df_apply_rows; dense rows of an odd F (the public dfx_df_apply on [B,T,F] arrays) the flat-stream kernel dfx_k_df_apply.
+template <int NPC, bool PF>
+static int launch_dfa_rows(const DfxDfrArgs &A, int order, unsigned grid, hipStream_t s) {
+    switch (order) {
+#define DFX_DFR_CASE(O_) case O_: dfx_launch((dfx_k_df_apply_rows<O_, NPC, PF>), dim3(grid), dim3(256), 0, s, A); break;
+        DFX_DFR_CASE(1) DFX_DFR_CASE(2) DFX_DFR_CASE(3) DFX_DFR_CASE(4) DFX_DFR_CASE(5) DFX_DFR_CASE(6) DFX_DFR_CASE(7) DFX_DFR_CASE(8)
+        DFX_DFR_CASE(9) DFX_DFR_CASE(10) DFX_DFR_CASE(11) DFX_DFR_CASE(12) DFX_DFR_CASE(13) DFX_DFR_CASE(14) DFX_DFR_CASE(15) DFX_DFR_CASE(16)
+#undef DFX_DFR_CASE
+        default: DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_df_apply: order %d > 16", order);
+    }
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
 }
 
 int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, const float *gains,
                         const dfx_bands *bands, int64_t B, int64_t T, int F, int nb_df, int order, int lookahead,
-                        float pf_beta, float atten_lim, float *out, hipStream_t s, int64_t t_begin = 0, int64_t t_end = -1,
-                        int64_t coef_T = -1, int64_t out_T = -1, int64_t out_toff = 0);
-
-// frames [t_begin, t_end) of every clip (t_end < 0: T); coef_T: frames per clip of the coefficient / gain arrays (default T);
-// out_T / out_toff: compacted output rows (default T / 0)
-int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, const float *gains,
-                        const dfx_bands *bands, int64_t B, int64_t T, int F, int nb_df, int order, int lookahead,
                         float pf_beta, float atten_lim, float *out, hipStream_t s, int64_t t_begin, int64_t t_end, int64_t coef_T,
-                        int64_t out_T, int64_t out_toff) {
+                        int64_t out_T, int64_t out_toff, int64_t spec_stride, int64_t out_stride) {
+    if (spec_stride <= 0) spec_stride = F;
+    if (out_stride <= 0) out_stride = F;
+    if (t_end < 0) t_end = T;
+    if (t_end <= t_begin) return DFX_OK;
+    const int nbands = (gains && bands) ? bands->nb : 0;
+    {
+        const int64_t nd = nb_df, O = order, Tc = coef_T < 0 ? T : coef_T;
+        static const int force_flat = [] { const char *e = getenv("DFX_DFA_FLAT"); return e && e[0] == '1' ? 1 : 0; }();
+        const bool rows_ok = spec_stride % 2 == 0 && out_stride % 2 == 0 && coef_layout != DFX_COEF_BTFO && nd % 2 == 0 && nd / 2 <= 64 &&
+                             nbands <= 64 && O <= 16 && !((uintptr_t)spec & 15) && !((uintptr_t)out & 15) && !((uintptr_t)coefs & 15) &&
+                             !(force_flat && spec_stride == F && out_stride == F);
+        if (rows_ok) {
+            DfxDfrArgs R;
+            R.spec = spec;
+            R.coefs = coefs;
+            R.gains = nbands ? gains : nullptr;
+            R.bin2band = bands ? bands->d_bin2band : nullptr;
+            R.out = out;
+            R.B = B;
+            R.T = T;
+            if (coef_layout == DFX_COEF_BOTF) R.cs_b = O * Tc * nd, R.cs_n = Tc * nd, R.cs_t = nd;   // [B,O,Tc,nd]
+            else R.cs_b = Tc * O * nd, R.cs_t = O * nd, R.cs_n = nd;                                  // [B,Tc,O,nd]
+            R.gT = Tc;
+            R.out_T = out_T < 0 ? T : out_T;
+            R.out_toff = out_toff;
+            R.Fs = (int)spec_stride;
+            R.Fso = (int)out_stride;
+            R.F = F;
+            R.nbdf = nb_df;
+            R.lookahead = lookahead;
+            R.nb = nbands;
+            R.pf_beta = pf_beta;
+            R.atten_lim = atten_lim;
+            R.t_begin = (int)t_begin;
+            R.t_end = (int)t_end;
+            static const int rpw_env = [] { const char *e = getenv("DFX_DFA_RPW"); return e ? atoi(e) : 0; }();
+            R.rpw = rpw_env > 0 ? rpw_env : 16;
+            R.chunks = (int)dfx_ceil_div(t_end - t_begin, R.rpw);
+            const int64_t nblk = dfx_ceil_div(B, 8) * 8 * dfx_ceil_div(R.chunks, 4);
+            if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_df_apply: batch too large for one launch");
+            const int np = ((F + 1) / 2 + 63) / 64;
+            DfxKScope ks(DFX_K_DF_APPLY, s);
+            const bool pf = pf_beta > 0.f || atten_lim > 0.f;
+            if (np == 4) return pf ? launch_dfa_rows<4, true>(R, order, (unsigned)nblk, s) : launch_dfa_rows<4, false>(R, order, (unsigned)nblk, s);
+            return pf ? launch_dfa_rows<0, true>(R, order, (unsigned)nblk, s) : launch_dfa_rows<0, false>(R, order, (unsigned)nblk, s);
+        }
+        if (spec_stride != F || out_stride != F)
+            DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_df_apply: padded rows need even strides, a tap-/frame-major coefficient layout, an even nb_df <= 128, "
+                                          "<= 64 bands, order <= 16 and 16-byte aligned buffers");
+    }
     DfxDfaArgs A;
     A.spec = reinterpret_cast<const float2 *>(spec);
     A.coefs = reinterpret_cast<const float2 *>(coefs);
@@ -520,8 +584,6 @@ int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, 
         rows_sel = (e && atoi(e) == 32) ? 32 : DFX_DFA_ROWS;
     }
     const int ROWS = rows_sel;
-    if (t_end < 0) t_end = T;
-    if (t_end <= t_begin) return DFX_OK;
     A.t_begin = (int)t_begin;
     A.t_end = (int)t_end;
     A.chunks = (int)dfx_ceil_div(t_end - t_begin, ROWS);
@@ -560,4 +622,27 @@ extern "C" int dfx_df_apply(const float *spec, const float *coefs, int coef_layo
         DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply: spec and out must be 16-byte aligned, coefs 8-byte aligned");
     return dfx_launch_df_apply(spec, coefs, coef_layout, gains, bands, B, T, F, nb_df, order, lookahead, pf_beta,
                                atten_lim, out, dfx_stream(stream));
+}
+
+// dfx_df_apply on rows with a stride: spec [B,T,spec_stride][2], out [B,T,out_stride][2] (strides in complex elements, >= F).  Even
+// strides make every row 16-byte aligned (F = fft/2 + 1 is odd for every shipped model; the engine pads its own buffers to F + 1)
+// and select the row-streaming kernel.  The pad bins of `out` are written as zeros, those of `spec` are ignored.
+extern "C" int dfx_df_apply_strided(const float *spec, int64_t spec_stride, const float *coefs, int coef_layout, const float *gains,
+                                    const dfx_bands *bands, int64_t B, int64_t T, int F, int nb_df, int order, int lookahead,
+                                    float pf_beta, float atten_lim, float *out, int64_t out_stride, void *stream) {
+    if (B < 0 || T < 0 || F <= 0 || nb_df <= 0 || nb_df > F || order <= 0 || lookahead < 0 || lookahead >= order || spec_stride < F ||
+        out_stride < F)
+        DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply_strided: bad sizes (need 0 <= lookahead < order, 0 < nb_df <= F <= strides)");
+    if (coef_layout != DFX_COEF_BOTF && coef_layout != DFX_COEF_BTFO && coef_layout != DFX_COEF_BTOF)
+        DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply_strided: bad coef_layout");
+    if (gains && (!bands || bands->F != F)) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply_strided: gains need a band table covering F bins");
+    if (atten_lim < 0.f || atten_lim >= 1.f) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply_strided: atten_lim must be in [0,1)");
+    if (int rc = dfx_require_device()) return rc;
+    if (B == 0 || T == 0) return DFX_OK;
+    if (!spec || !coefs || !out) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply_strided: null buffer");
+    if (spec == out) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply_strided: out must not alias spec");
+    if (((uintptr_t)spec & 15) || ((uintptr_t)out & 15) || ((uintptr_t)coefs & 7))
+        DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_df_apply_strided: spec and out must be 16-byte aligned, coefs 8-byte aligned");
+    return dfx_launch_df_apply(spec, coefs, coef_layout, gains, bands, B, T, F, nb_df, order, lookahead, pf_beta, atten_lim, out,
+                               dfx_stream(stream), 0, -1, -1, -1, 0, spec_stride, out_stride);
 }

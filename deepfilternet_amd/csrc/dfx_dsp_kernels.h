@@ -191,6 +191,7 @@ struct DfxAnaArgs {
     const float *band_invw; // [nb]
     int64_t B, Tf, x_stride;
     int64_t x_len;        // samples that exist per row; positions >= x_len read as 0 (enhance()'s F.pad(audio, (0, n_fft)) without a copy)
+    int64_t spec_stride;  // row stride of spec in complex elements (>= F; the engine pads odd F to even so rows are 16-byte aligned)
     int hop, nb;
     float wnorm;
     DfxFftPlan plan;
@@ -280,7 +281,8 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_analysis(DfxAnaArgs A) 
         float2 *other = (Z == bufA) ? bufB : bufA;
         float *pw = reinterpret_cast<float *>(other);  // |X|^2 per bin for the ERB feature
         if (active) {
-            float2 *out = A.spec + (b * A.Tf + t) * F;
+            float2 *out = A.spec + (b * A.Tf + t) * A.spec_stride;
+            if (lane == 0 && A.spec_stride > F) out[F] = make_float2(0.f, 0.f);  // the pad bin of an aligned row
             for (int k = lane; k <= M; k += DFX_DSP_TEAM) {
                 const float2 zk = Z[k == M ? 0 : k];
                 const float2 zc = Z[k == 0 ? 0 : M - k];
@@ -337,6 +339,7 @@ struct DfxSynArgs {
     const float *window;
     const float2 *tw;
     int64_t B, Tf, out_stride;
+    int64_t spec_stride;        // row stride of spec in complex elements (>= F)
     int64_t f_begin, f_end;     // output frames [f_begin, f_end) are produced by this launch (f_end may include the R-1 memory frames)
     int64_t out_skip, out_len;  // only stream samples [out_skip, out_skip + out_len) are stored, at out[row][n - out_skip]
     int hop, R /* N/hop rounded up: frames overlapping one output hop */, outf /* output frames per chunk */;
@@ -349,7 +352,7 @@ struct DfxSynArgs {
 // Sum order per output sample follows the reference: oldest contribution first, the current frame last.
 __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_synthesis(DfxSynArgs A) {
     DFX_DYN_SMEM(unsigned char, smem);
-    const int N = A.plan.N, M = A.plan.M, F = M + 1;
+    const int N = A.plan.N, M = A.plan.M;
     float2 *tw = reinterpret_cast<float2 *>(smem);
     float *win = reinterpret_cast<float *>(smem + (size_t)N * 8);
     const size_t team_off = (size_t)N * 12;
@@ -400,7 +403,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_synthesis(DfxSynArgs A)
     const int64_t t = t0 - (A.R - 1) + team;         // real frame handled by this team
     const bool active = t >= 0 && t < A.Tf;
     if (active) {
-        const float2 *Y = A.spec + (b * A.Tf + t) * F;
+        const float2 *Y = A.spec + (b * A.Tf + t) * A.spec_stride;
         if (single) {  // F <= 512: the frame was requested while the previous work item was being transformed (or right now)
             if (!have_pre) request(Y);
 #pragma unroll
@@ -431,7 +434,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_synthesis(DfxSynArgs A)
             const int64_t nb = nitem / A.chunks;
             const int64_t nt = A.f_begin + (nitem - nb * A.chunks) * A.outf - (A.R - 1) + team;
             if (nt >= 0 && nt < A.Tf) {
-                request(A.spec + (nb * A.Tf + nt) * F);
+                request(A.spec + (nb * A.Tf + nt) * A.spec_stride);
                 have_pre = true;
             }
         }
@@ -793,6 +796,189 @@ __global__ void __launch_bounds__(DFX_DFA_THREADS) dfx_k_df_apply(DfxDfaArgs A) 
             const float2 ya = dfx_dfa_bin(A, xs, gs, b2b, coef_b, t0, tt[u], ff[u], make_float2(xv[u].x, xv[u].y));
             const float2 yb = dfx_dfa_bin(A, xs, gs, b2b, coef_b, t0, tt2[u], ff2[u], make_float2(xv[u].z, xv[u].w));
             y4[u ? i2 : i] = make_float4(ya.x, ya.y, yb.x, yb.y);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-streaming form of the same operator for 16-byte aligned rows (row stride Fs complex elements, Fs even: the engine pads
+// F = 481 to 482 in its own spec / spec_e buffers, so a row is a run of float4 = two bins and nothing straddles rows).
+//   * a WAVE owns `rpw` consecutive frames of one clip and walks them in time order; a workgroup = 4 waves = 4 consecutive
+//     chunks of that clip.  No LDS, no barrier: waves never wait for each other.
+//   * pass 0 (lanes 0..63 = bins 0..127): lanes below nb_df/2 own two deep-filter bins each and keep the O frames the filter
+//     reads in a REGISTER ring (one new 16-byte load per frame, not O); their O coefficients are O float4 loads (tap-major or
+//     frame-major layouts: consecutive lanes read consecutive coefficients).  The remaining lanes / passes multiply by the band
+//     gain; a frame's E gains are one coalesced load (lane e holds band e) + one wave shuffle per bin (the bands of a lane's
+//     bins never change, so their indices live in registers).
+//   * every global access is a whole-row, 16-byte-per-lane access; the pad bin of a row is written as zero.
+// HBM traffic = the algorithmic bytes + the O-1 ring-fill frames per chunk (low bins only: (O-1)/rpw * nb_df*8 B per frame).
+// ---------------------------------------------------------------------------------------------------------------------
+struct DfxDfrArgs {
+    const float *spec;    // [B, T, Fs][2]
+    const float *coefs;   // complex element (b,t,n,f) at b*cs_b + t*cs_t + n*cs_n + f  (cs_* even: float4 aligned)
+    const float *gains;   // [B, gT, nb] or null
+    const unsigned char *bin2band;  // [F]
+    float *out;           // [B, out_T, Fso][2]
+    int64_t B, T;
+    int64_t cs_b, cs_t, cs_n;
+    int64_t gT, out_T, out_toff;
+    int Fs, Fso;          // row strides in complex elements (even)
+    int F, nbdf, lookahead, nb;
+    float pf_beta, atten_lim;
+    int t_begin, t_end;   // frames [t_begin, t_end) of every clip
+    int rpw;              // frames per wave
+    int chunks;           // chunks of rpw frames per clip
+};
+
+// NPC > 0: the number of 64-lane passes over a row (ceil(ceil(F/2) / 64)) as a compile-time constant (all row loads of a frame are
+// then issued together and the band indices live in registers); NPC == 0: any F, one pass at a time.  PF: post filter / attenuation
+// limit compiled in (the common case, neither, then carries no sinf / sqrtf code and fewer live registers).
+// Addressing: everything but the lane index is wave-uniform (clip, frame, tap), so every access is <scalar base> + lane * 16.
+template <int O, int NPC, bool PF>
+__global__ void __launch_bounds__(256) dfx_k_df_apply_rows(DfxDfrArgs A) {
+    const unsigned lane = threadIdx.x & 63;
+    const int wave = dfx_wave_uniform((int)(threadIdx.x >> 6));
+    const int64_t id = blockIdx.x;
+    const int xcd = (int)(id & 7);          // blocks that share blockIdx.x % 8 (one XCD / L2) work on the same clips (speed hint only)
+    const int64_t j = id >> 3;
+    const int wgc = (A.chunks + 3) >> 2;    // workgroups per clip
+    const int64_t b = (j / wgc) * 8 + xcd;
+    const int chunk = (int)(j % wgc) * 4 + wave;
+    if (b >= A.B || chunk >= A.chunks) return;
+    const int t0 = A.t_begin + chunk * A.rpw;
+    const int t1 = (t0 + A.rpw) < A.t_end ? (t0 + A.rpw) : A.t_end;
+    const int F = A.F, la = A.lookahead, toff = O - 1 - la;
+    const unsigned nd4 = (unsigned)A.nbdf >> 1;   // float4 columns that belong to the deep filter (<= 64)
+    const unsigned ncol = (unsigned)(F + 1) >> 1; // float4 columns of a row
+    const int np = NPC > 0 ? NPC : (int)((ncol + 63) >> 6);
+    const bool is_df = lane < nd4;
+    const int64_t rs = A.Fs >> 1, ro = A.Fso >> 1, cst = A.cs_t >> 1, csn = A.cs_n >> 1;
+    const f32x4 *spec_b = reinterpret_cast<const f32x4 *>(A.spec) + b * A.T * rs;
+    const f32x4 *coef_b = reinterpret_cast<const f32x4 *>(A.coefs) + ((b * A.cs_b) >> 1);
+    f32x4 *out_b = reinterpret_cast<f32x4 *>(A.out) + (b * A.out_T - A.out_toff) * ro;
+    const float *gain_b = A.gains ? A.gains + b * A.gT * A.nb : nullptr;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // band indices of this lane's bins (pass p: bins 2*(lane + 64p), +1); a bin past F-1 is the row's pad (written as 0)
+    constexpr int NB = NPC > 0 ? NPC : 1;
+    int band0[NB], band1[NB];
+    if (NPC > 0 && A.gains) {
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            const int f = 2 * ((int)lane + 64 * p);
+            band0[p] = f < F ? A.bin2band[f] : 0;
+            band1[p] = f + 1 < F ? A.bin2band[f + 1] : 0;
+        }
+    }
+    auto finish2 = [&](f32x4 y, f32x4 x, bool second_is_pad) -> f32x4 {
+        if (PF) {
+            const float2 ya = dfx_dfa_finish(make_float2(y[0], y[1]), make_float2(x[0], x[1]), A.pf_beta, A.atten_lim);
+            const float2 yb = dfx_dfa_finish(make_float2(y[2], y[3]), make_float2(x[2], x[3]), A.pf_beta, A.atten_lim);
+            y[0] = ya.x, y[1] = ya.y, y[2] = yb.x, y[3] = yb.y;
+        }
+        if (second_is_pad) y[2] = 0.f, y[3] = 0.f;
+        return y;
+    };
+    // ring[n] = frame t - toff + n of this lane's two deep-filter bins
+    f32x4 ring[O];
+#pragma unroll
+    for (int n = 0; n < O; ++n) ring[n] = zero4;
+    if (is_df) {
+#pragma unroll
+        for (int n = 0; n + 1 < O; ++n) {
+            const int tt = t0 - toff + n;
+            if (tt >= 0 && tt < A.T) ring[n + 1] = (spec_b + (int64_t)tt * rs)[lane];
+        }
+    }
+    for (int t = t0; t < t1; ++t) {
+        const f32x4 *xrow = spec_b + (int64_t)t * rs;
+        f32x4 *yrow = out_b + (int64_t)t * ro;
+        // ---- issue the frame's loads: pass 0 (the ring's newest frame for the deep-filter lanes, the frame itself otherwise),
+        // the coefficients, the gains, then the remaining passes
+        f32x4 x0 = zero4;
+        if (is_df) {
+            if (t + la < A.T) x0 = (xrow + (int64_t)la * rs)[lane];
+        } else if (lane < ncol) {
+            x0 = xrow[lane];
+        }
+        f32x4 cf[O];
+        if (is_df) {
+            const f32x4 *cp = coef_b + (int64_t)t * cst;
+#pragma unroll
+            for (int n = 0; n < O; ++n) cf[n] = (cp + (int64_t)n * csn)[lane];
+        }
+        float gv = 1.f;
+        if (gain_b && lane < (unsigned)A.nb) gv = (gain_b + (int64_t)t * A.nb)[lane];
+        f32x4 xp[NB];
+        if (NPC > 0) {
+#pragma unroll
+            for (int p = 1; p < NB; ++p) xp[p] = (lane + 64u * p) < ncol ? (xrow + 64 * p)[lane] : zero4;
+        }
+        // ---- pass 0
+        {
+            f32x4 x = x0, y;
+            if (is_df) {
+#pragma unroll
+                for (int n = 0; n + 1 < O; ++n) ring[n] = ring[n + 1];
+                ring[O - 1] = x0;
+                if (PF) {  // the frame itself (ring slot toff), selected without a dynamically indexed register array
+#pragma unroll
+                    for (int n = 0; n < O; ++n)
+                        if (n == toff) x = ring[n];
+                }
+                y = zero4;
+#pragma unroll
+                for (int n = 0; n < O; ++n) {
+                    const f32x4 c = cf[n], xx = ring[n];
+                    y[0] += xx[0] * c[0] - xx[1] * c[1];
+                    y[1] += xx[0] * c[1] + xx[1] * c[0];
+                    y[2] += xx[2] * c[2] - xx[3] * c[3];
+                    y[3] += xx[2] * c[3] + xx[3] * c[2];
+                }
+            }
+            float g0 = 1.f, g1 = 1.f;
+            if (A.gains) {  // every lane takes part in the shuffles
+                int i0, i1;
+                if (NPC > 0) {
+                    i0 = band0[0], i1 = band1[0];
+                } else {
+                    const int f = 2 * (int)lane;
+                    i0 = f < F ? A.bin2band[f] : 0;
+                    i1 = f + 1 < F ? A.bin2band[f + 1] : 0;
+                }
+                g0 = __shfl(gv, i0);
+                g1 = __shfl(gv, i1);
+            }
+            if (!is_df) {
+                y[0] = x[0] * g0, y[1] = x[1] * g0;
+                y[2] = x[2] * g1, y[3] = x[3] * g1;
+            }
+            if (lane < ncol) yrow[lane] = finish2(y, x, 2 * (int)lane + 1 >= F);
+        }
+        // ---- the other passes: band gains only
+        auto gain_pass = [&](int p, f32x4 x, int i0, int i1) {
+            const unsigned col = lane + 64u * p;
+            float g0 = 1.f, g1 = 1.f;
+            if (A.gains) {
+                g0 = __shfl(gv, i0);
+                g1 = __shfl(gv, i1);
+            }
+            if (col < ncol) {
+                f32x4 y;
+                y[0] = x[0] * g0, y[1] = x[1] * g0;
+                y[2] = x[2] * g1, y[3] = x[3] * g1;
+                (yrow + 64 * p)[lane] = finish2(y, x, 2 * (int)col + 1 >= F);
+            }
+        };
+        if (NPC > 0) {
+#pragma unroll
+            for (int p = 1; p < NB; ++p) gain_pass(p, xp[p], A.gains ? band0[p] : 0, A.gains ? band1[p] : 0);
+        } else {
+            for (int p = 1; p < np; ++p) {
+                const unsigned col = lane + 64u * p;
+                const int f = 2 * (int)col;
+                const f32x4 x = col < ncol ? (xrow + 64 * p)[lane] : zero4;
+                gain_pass(p, x, (A.gains && f < F) ? A.bin2band[f] : 0, (A.gains && f + 1 < F) ? A.bin2band[f + 1] : 0);
+            }
         }
     }
 }

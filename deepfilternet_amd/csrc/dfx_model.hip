@@ -6,11 +6,6 @@
 #include <cmath>
 #include <map>
 
-int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, const float *gains,
-                        const dfx_bands *bands, int64_t B, int64_t T, int F, int nb_df, int order, int lookahead,
-                        float pf_beta, float atten_lim, float *out, hipStream_t s, int64_t t_begin = 0, int64_t t_end = -1,
-                        int64_t coef_T = -1, int64_t out_T = -1, int64_t out_toff = 0);
-
 // ------------------------------------------------------------------------------------------------ cfg validation
 static int check_cfg(const dfx_model_cfg *c) {
     if (!c) DFX_FAIL(DFX_ERR_INVALID_ARG, "null model cfg");
@@ -105,6 +100,8 @@ struct DfxFinish {
     const dfx_state *st;
     float *y;
     int64_t out_stride, out_skip, out_len;
+    int64_t spec_stride;   // row stride (complex elements) of enhance()'s own spec / spec_e buffers: F rounded up to even, so that
+                           // every row is 16-byte aligned (dfx_k_df_apply_rows); dfx_model_forward's caller-owned arrays are dense
 };
 // Streaming (dfx_stream_process): a forward pass over a window.  Every feature / activation array holds T = H + n frames per clip
 // (H history frames, then the n new ones); only the new frames are computed (kernels take t_begin, per-frame kernels a DfxRowMap),
@@ -1290,6 +1287,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     const int Lk = sc ? 0 : c.conv_lookahead;
     const int64_t t_zero = sc ? sc->t_zero : 0;
     const Ws w = plan_ws(c, m->fuse_c0, R, B);
+    const int64_t sstride = fin ? fin->spec_stride : 0;  // 0: dense rows of F bins
     const int E = c.nb_erb, Fd = c.nb_df, O = c.df_order, NO = 2 * O, emb = C * E / 4, L = c.conv_lookahead;
     float *e0 = ws + w.e0, *e1 = ws + w.e1, *e2 = ws + w.e2, *e3 = ws + w.e3, *c0 = ws + w.c0, *c1 = ws + w.c1;
     float *emb_in = ws + w.emb_in, *embv = ws + w.emb, *xa = ws + w.xa, *xb = ws + w.xb, *gi = ws + w.gi;
@@ -1700,10 +1698,10 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 if (k1 > K) k1 = K;
                 if ((rc = ewait(ln->mev[k1 - 1], st)) || (rc = ewait(ln->cev[k1 - 1], st))) return rc;
                 if ((rc = dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead,
-                                              c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, st, tb(k0), tb(k1))))
+                                              c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, st, tb(k0), tb(k1), -1, -1, 0, sstride, sstride)))
                     return rc;
                 if (fin && (rc = dfx_launch_synthesis(fin->st, spec_e, B, T, nullptr, nullptr, fin->y, fin->out_stride, fin->out_skip,
-                                                      fin->out_len, st, tb(k0), tb(k1))))
+                                                      fin->out_len, st, tb(k0), tb(k1), sstride)))
                     return rc;
                 k0 = k1;
             }
@@ -1730,9 +1728,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                                    atten_lim, sc->out, s, t_begin, T, T, sc->out_T, sc->out_toff);
     }
     if ((rc = dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead,
-                                  c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, s)))
+                                  c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, s, 0, -1, -1, -1, 0, sstride, sstride)))
         return rc;
-    if (fin) return dfx_launch_synthesis(fin->st, spec_e, B, T, nullptr, nullptr, fin->y, fin->out_stride, fin->out_skip, fin->out_len, s);
+    if (fin)
+        return dfx_launch_synthesis(fin->st, spec_e, B, T, nullptr, nullptr, fin->y, fin->out_stride, fin->out_skip, fin->out_len, s, 0, -1,
+                                    sstride);
     return DFX_OK;
 }
 
@@ -1772,6 +1772,13 @@ extern "C" int dfx_model_forward(const dfx_model *m, const dfx_bands *bands, con
 }
 
 // ------------------------------------------------------------------------------------------------ enhance()
+// row stride (complex elements) of enhance()'s spec / spec_e buffers: F rounded up to even = 16-byte aligned rows
+// (DFX_SPEC_PAD=0: dense rows and the flat-stream deep-filter kernel, for A/B measurements)
+static inline int64_t enh_spec_stride(const dfx_state *st) {
+    static const bool pad = [] { const char *e = getenv("DFX_SPEC_PAD"); return !(e && e[0] == '0'); }();
+    const int64_t F = (int64_t)st->N / 2 + 1;
+    return pad ? (F + 1) & ~(int64_t)1 : F;
+}
 namespace {
 struct EnhWs {
     size_t spec, spec_e, feat_erb, feat_spec, model, total;  // bytes
@@ -1784,7 +1791,7 @@ EnhWs plan_enh(const dfx_model *m, const dfx_state *st, int64_t B, int64_t T, in
         off += (bytes + 255) & ~(size_t)255;
         return o;
     };
-    const int64_t Tp = pad ? T + st->N : T, Tf = Tp / st->hop, F = st->N / 2 + 1;
+    const int64_t Tp = pad ? T + st->N : T, Tf = Tp / st->hop, F = enh_spec_stride(st);
     w.spec = take((size_t)B * Tf * F * 8);
     w.spec_e = take((size_t)B * Tf * F * 8);
     w.feat_erb = take((size_t)B * Tf * m->cfg.nb_erb * 4);
@@ -2426,7 +2433,8 @@ static int enhance_chunk(const dfx_model *m, const dfx_state *st, const float *x
     float *spec = reinterpret_cast<float *>(base + w.spec), *spec_e = reinterpret_cast<float *>(base + w.spec_e);
     float *fe = reinterpret_cast<float *>(base + w.feat_erb), *fs = reinterpret_cast<float *>(base + w.feat_spec);
     // F.pad(audio, (0, n_fft)) (enhance.py:230-233) is implicit: the analysis reads zeros past the T samples of a row
-    int rc = dfx_features_padded(st, x, B, Tp, T, T, c.nb_df, c.norm_alpha, spec, fe, fs, (void *)s);
+    const int64_t sstride = enh_spec_stride(st);
+    int rc = dfx_features_padded(st, x, B, Tp, T, T, c.nb_df, c.norm_alpha, spec, fe, fs, (void *)s, sstride);
     if (rc) return rc;
     int64_t mb = 0;
     dfx_model_workspace_bytes(m, B, Tf, &mb);
@@ -2438,6 +2446,7 @@ static int enhance_chunk(const dfx_model *m, const dfx_state *st, const float *x
     fin.out_stride = pad ? T : Tf * st->hop;
     fin.out_skip = pad ? st->N - st->hop : 0;
     fin.out_len = pad ? T : Tf * st->hop;
+    fin.spec_stride = sstride;
     return model_forward_lane(m, st->bands, spec, fe, fs, B, Tf, lim, spec_e, nullptr, nullptr, nullptr, base + w.model, mb, (void *)s, ln,
                               signal_front, &fin);
 }

@@ -127,6 +127,12 @@ int dfx_features(const dfx_state *st, const float *x, int64_t B, int64_t T, int6
 int dfx_df_apply(const float *spec, const float *coefs, int coef_layout, const float *gains, const dfx_bands *bands,
                  int64_t B, int64_t T, int F, int nb_df, int order, int lookahead, float pf_beta, float atten_lim,
                  float *out, void *stream);
+/* The same operator on rows with a stride (complex elements, >= F): spec [B,T,spec_stride][2] -> out [B,T,out_stride][2].  Even
+ * strides make every row 16-byte aligned (F = fft/2 + 1 is odd for every shipped model) and select the row-streaming kernel the
+ * engine uses on its own padded buffers; pad bins of `out` are written as zeros.  No reference counterpart (layout extension). */
+int dfx_df_apply_strided(const float *spec, int64_t spec_stride, const float *coefs, int coef_layout, const float *gains,
+                         const dfx_bands *bands, int64_t B, int64_t T, int F, int nb_df, int order, int lookahead, float pf_beta,
+                         float atten_lim, float *out, int64_t out_stride, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * DeepFilterNet3 model.  Replaces df.deepfilternet3.DfNet (deepfilternet3.py:334-456) for inference.

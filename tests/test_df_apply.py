@@ -28,6 +28,69 @@ def run_df_apply(spec, coefs, layout, gains, widths, nb_df, order, la, pf_beta=0
     return torch.view_as_complex(out.cpu()).numpy()
 
 
+def run_df_apply_strided(spec, coefs, layout, gains, widths, nb_df, order, la, pf_beta=0.0, lim=0.0, pad=1):
+    """The same operator on rows padded to an even stride (the engine's own spec layout; dfx_k_df_apply_rows)."""
+    from deepfilternet_amd import _lib
+    from deepfilternet_amd.libdf import _Bands
+
+    dev = _lib.device()
+    B, T, F = spec.shape
+    Fs = ((F + 1) // 2) * 2 + 2 * (pad - 1)
+    sp = np.full((B, T, Fs), np.nan + 1j * np.nan, np.complex64)   # pad bins of the input must be ignored
+    sp[..., :F] = spec
+    s = torch.view_as_real(torch.from_numpy(sp)).to(dev).contiguous()
+    c = torch.view_as_real(torch.from_numpy(np.ascontiguousarray(coefs))).to(dev).contiguous()
+    g = torch.from_numpy(np.ascontiguousarray(gains)).to(dev) if gains is not None else None
+    bands = _Bands.get(widths) if gains is not None else None
+    out = torch.full_like(s, 7.0)
+    _lib.check(_lib.lib().dfx_df_apply_strided(_lib.ptr(s), Fs, _lib.ptr(c), layout, _lib.ptr(g), bands.handle if bands else None, B,
+                                               T, F, nb_df, order, la, float(pf_beta), float(lim), _lib.ptr(out), Fs, _lib.stream()))
+    o = torch.view_as_complex(out.cpu()).numpy()
+    if F % 2:
+        assert np.all(o[..., F] == 0)                               # the pad bin that shares a float4 with bin F-1 is written as zero
+    return o[..., :F]
+
+
+@pytest.mark.parametrize("B,T,F,nd,O_,la,pf,lim,layout", [
+    (2, 19, 481, 96, 5, 2, 0.0, 0.0, 0),    # DF3 shape: 4 compile-time passes, two waves (16 + 3 frames)
+    (9, 70, 481, 96, 5, 0, 0.02, 0.0, 2),   # 5 chunks = two workgroups per clip, more clips than one XCD group, post filter
+    (1, 1, 481, 96, 5, 2, 0.0, 0.25, 0),    # single frame + attenuation limit
+    (2, 37, 481, 96, 10, 3, 0.02, 0.5, 2),  # order 10 (BASELINE.json configs[4])
+    (2, 9, 97, 32, 16, 7, 0.0, 0.0, 0),     # run-time pass count, largest order
+    (3, 21, 33, 8, 1, 0, 0.0, 0.0, 2),      # one tap, one pass
+    (2, 5, 64, 64, 3, 1, 0.0, 0.0, 0),      # even F (dense rows are already aligned), nb_df == F
+    (2, 33, 257, 128, 2, 1, 0.0, 0.0, 2),   # nb_df fills pass 0 completely
+])
+def test_rows_kernel_matches_oracle_and_flat_kernel(backend, B, T, F, nd, O_, la, pf, lim, layout):
+    rng = np.random.default_rng(B * 1000 + T + O_)
+    spec = (rng.standard_normal((B, T, F)) + 1j * rng.standard_normal((B, T, F))).astype(np.complex64)
+    cbotf = (rng.standard_normal((B, O_, T, nd)) + 1j * rng.standard_normal((B, O_, T, nd))).astype(np.complex64) * 0.3
+    coefs = cbotf if layout == 0 else np.ascontiguousarray(cbotf.transpose(0, 2, 1, 3))
+    nb = 8
+    widths = np.full(nb, F // nb, np.uint64)
+    widths[-1] += F - int(widths.sum())
+    gains = rng.uniform(0, 1, (B, T, nb)).astype(np.float32)
+    for gg in (gains, None):
+        out = run_df_apply_strided(spec, coefs, layout, gg, widths, nd, O_, la, pf, lim)
+        st = torch.from_numpy(spec)
+        ref = st * O.band_gain(torch.from_numpy(gains), widths) if gg is not None else st.clone()
+        ref[..., :nd] = O.df_apply(st, torch.from_numpy(cbotf), O_, la, nd)
+        if pf > 0:
+            ref = O.post_filter(st, ref, pf)
+        if lim > 0:
+            ref = st * lim + ref * (1 - lim)
+        ref = ref.numpy()
+        assert np.abs(out - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+        if F % 2:   # the flat-stream kernel on the dense rows gives the same numbers up to the order of the tap sum
+            flat = run_df_apply(spec, coefs, layout, gg, widths, nd, O_, la, pf, lim)
+            assert np.abs(out - flat).max() < 2e-5 * max(1.0, np.abs(ref).max())
+            if pf == 0 and lim == 0:
+                assert np.array_equal(out[..., nd:], flat[..., nd:])    # gain bins: one multiply per component
+    # a wider pad (stride F + 3 rounded to even) only moves the rows
+    out2 = run_df_apply_strided(spec, coefs, layout, gains, widths, nd, O_, la, pf, lim, pad=2)
+    assert np.array_equal(out2, run_df_apply_strided(spec, coefs, layout, gains, widths, nd, O_, la, pf, lim))
+
+
 @pytest.mark.parametrize("O_,la", [(5, 0), (5, 2), (10, 0), (10, 3), (1, 0)])
 def test_matches_reference_mf_df_golden(backend, O_, la, golden_dir):
     g = np.load(os.path.join(golden_dir, "modules.npz"))
@@ -44,6 +107,10 @@ def test_matches_reference_mf_df_golden(backend, O_, la, golden_dir):
     # and in the engine's own tap-major layout [B,T,O,F'] (DFX_COEF_BTOF)
     out3 = run_df_apply(sc, np.ascontiguousarray(cc.transpose(0, 2, 1, 3)), 2, None, None, 96, O_, la)
     assert np.array_equal(out, out3)
+    # the row-streaming kernel on rows padded to 482 bins (the engine's own layout)
+    out4 = run_df_apply_strided(sc, cc, 0, None, None, 96, O_, la)
+    assert np.abs(out4 - ref).max() < 5e-6 * np.abs(ref).max()
+    assert np.array_equal(out4[..., 96:], sc[..., 96:])
 
 
 def test_mask_matches_reference_golden(backend, golden_dir):

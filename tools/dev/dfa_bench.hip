@@ -1,0 +1,163 @@
+// Dev: HBM streaming microbenchmarks (SURVEY §8d "measure achievable BW with a stream-copy microbench") and the deep-filter kernels
+// stand-alone at config-2 size (256 clips x 1002 frames, F = 481, nb_df = 96, E = 32), O = 5 and 10.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I deepfilternet_amd/csrc/env_hip -I deepfilternet_amd/csrc tools/dev/dfa_bench.hip -o tools/dev/_build/dfa_bench
+#include "dfx_dsp_kernels.h"
+#include <functional>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+void dfx_set_error(const char *, ...) {}
+bool dfx_prof_on(int) { return false; }
+void dfx_prof_begin(int, hipStream_t) {}
+void dfx_prof_end(int, hipStream_t) {}
+
+// ---- plain streams.  MODE 0 copy, 1 copy with non-temporal loads + stores, 2 read only, 3 write only, 4 out = a * b (2 reads : 1 write)
+template <int MODE, int U>
+__global__ void __launch_bounds__(256) k_stream(const f32x4 *__restrict__ a, const f32x4 *__restrict__ b, f32x4 *__restrict__ out, int64_t n) {
+    f32x4 acc = {0, 0, 0, 0};
+    const int64_t step = (int64_t)gridDim.x * 256 * U;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 * U + threadIdx.x; i0 < n; i0 += step) {
+        f32x4 v[U], w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * 256;
+            if (MODE != 3) {
+                if (i < n) v[u] = MODE == 1 ? __builtin_nontemporal_load(a + i) : a[i];
+                if (MODE == 4 && i < n) w[u] = b[i];
+            } else {
+                v[u] = acc;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * 256;
+            if (i >= n) continue;
+            if (MODE == 2) acc += v[u];
+            else if (MODE == 1) __builtin_nontemporal_store(v[u], out + i);
+            else if (MODE == 4) out[i] = v[u] * w[u];
+            else out[i] = v[u];
+        }
+    }
+    if (MODE == 2 && acc[0] == 12345.678f) out[0] = acc;
+}
+// one contiguous slab per workgroup instead of a grid-stride walk
+template <int U>
+__global__ void __launch_bounds__(256) k_copy_slab(const f32x4 *__restrict__ a, f32x4 *__restrict__ out, int64_t n, int64_t per_wg) {
+    const int64_t lo = (int64_t)blockIdx.x * per_wg, hi = lo + per_wg < n ? lo + per_wg : n;
+    for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += 256 * U) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (i0 + u * 256 < hi) v[u] = a[i0 + u * 256];
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (i0 + u * 256 < hi) out[i0 + u * 256] = v[u];
+    }
+}
+
+static float time_it(int iters, const std::function<void()> &f) {
+    for (int i = 0; i < 3; ++i) f();
+    CK(hipDeviceSynchronize());
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(hipEventRecord(a, 0));
+    for (int i = 0; i < iters; ++i) f();
+    CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipGetLastError());
+    return ms / iters;
+}
+
+int main(int argc, char **argv) {
+    const int64_t B = 256, T = 1002, F = 481, Fs = 482, nd = 96, E = 32;
+    const int OM = 10;
+    float *spec_d, *spec_p, *out_d, *out_p, *coefs, *gains;
+    CK(hipMalloc(&spec_d, B * T * F * 8)); CK(hipMalloc(&out_d, B * T * F * 8));
+    CK(hipMalloc(&spec_p, B * T * Fs * 8)); CK(hipMalloc(&out_p, B * T * Fs * 8));
+    CK(hipMalloc(&coefs, B * OM * T * nd * 8)); CK(hipMalloc(&gains, B * T * E * 4));
+    CK(hipMemset(spec_d, 0, B * T * F * 8)); CK(hipMemset(spec_p, 0, B * T * Fs * 8));
+    CK(hipMemset(coefs, 0, B * OM * T * nd * 8)); CK(hipMemset(gains, 0, B * T * E * 4));
+    {   // something non-trivial in the inputs (values do not change the timing of these kernels)
+        std::vector<float> h(1 << 20);
+        for (auto &v : h) v = (float)rand() / RAND_MAX - 0.5f;
+        for (int64_t o = 0; o + (int64_t)h.size() * 4 <= B * T * F * 8; o += (int64_t)h.size() * 4 * 64) {
+            CK(hipMemcpy((char *)spec_d + o, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+            CK(hipMemcpy((char *)spec_p + o, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
+    // band table of the 48 kHz / 960 / 32-band configuration (min_nb_freqs = 2)
+    const int widths[32] = {2,2,2,2,2,2,2,2,2,2,2,2,2,5,5,7,7,8,10,12,13,15,18,20,24,28,31,37,42,50,56,67};
+    std::vector<unsigned char> b2b(F);
+    { int f = 0; for (int e = 0; e < 32; ++e) for (int k = 0; k < widths[e]; ++k) b2b[f++] = (unsigned char)e; }
+    unsigned char *d_b2b; CK(hipMalloc(&d_b2b, F)); CK(hipMemcpy(d_b2b, b2b.data(), F, hipMemcpyHostToDevice));
+
+    // ---------------------------------------------------------------- streams
+    const int64_t n4 = B * T * Fs * 8 / 16;   // float4s in one padded spectrum buffer (0.99 GB)
+    const f32x4 *a4 = (const f32x4 *)spec_p, *b4 = (const f32x4 *)out_d;
+    f32x4 *o4 = (f32x4 *)out_p;
+    auto report = [&](const char *name, double bytes, float ms) { printf("%-44s %8.4f ms  %7.1f GB/s\n", name, ms, bytes / ms / 1e6); fflush(stdout); };
+    const double cb = (double)n4 * 16;
+    for (int blocks : {1024, 2048, 4096, 8192, 16384}) {
+        char nm[96];
+        snprintf(nm, 96, "copy grid-stride U=1 blocks=%d", blocks); report(nm, 2 * cb, time_it(10, [&] { hipLaunchKernelGGL((k_stream<0, 1>), dim3(blocks), dim3(256), 0, 0, a4, b4, o4, n4); }));
+        snprintf(nm, 96, "copy grid-stride U=2 blocks=%d", blocks); report(nm, 2 * cb, time_it(10, [&] { hipLaunchKernelGGL((k_stream<0, 2>), dim3(blocks), dim3(256), 0, 0, a4, b4, o4, n4); }));
+        snprintf(nm, 96, "copy grid-stride U=4 blocks=%d", blocks); report(nm, 2 * cb, time_it(10, [&] { hipLaunchKernelGGL((k_stream<0, 4>), dim3(blocks), dim3(256), 0, 0, a4, b4, o4, n4); }));
+        snprintf(nm, 96, "copy grid-stride U=8 blocks=%d", blocks); report(nm, 2 * cb, time_it(10, [&] { hipLaunchKernelGGL((k_stream<0, 8>), dim3(blocks), dim3(256), 0, 0, a4, b4, o4, n4); }));
+        snprintf(nm, 96, "copy nt U=4 blocks=%d", blocks); report(nm, 2 * cb, time_it(10, [&] { hipLaunchKernelGGL((k_stream<1, 4>), dim3(blocks), dim3(256), 0, 0, a4, b4, o4, n4); }));
+    }
+    for (int64_t per : {1024, 4096, 16384, 65536}) {   // float4s per workgroup slab: 16 KB .. 1 MB
+        char nm[96];
+        const int blocks = (int)((n4 + per - 1) / per);
+        snprintf(nm, 96, "copy slab %lld KB/wg U=4 (%d wgs)", (long long)per * 16 / 1024, blocks);
+        report(nm, 2 * cb, time_it(10, [&] { hipLaunchKernelGGL((k_copy_slab<4>), dim3(blocks), dim3(256), 0, 0, a4, o4, n4, per); }));
+    }
+    report("read only U=4 blocks=4096", cb, time_it(10, [&] { hipLaunchKernelGGL((k_stream<2, 4>), dim3(4096), dim3(256), 0, 0, a4, b4, o4, n4); }));
+    report("read only U=8 blocks=8192", cb, time_it(10, [&] { hipLaunchKernelGGL((k_stream<2, 8>), dim3(8192), dim3(256), 0, 0, a4, b4, o4, n4); }));
+    report("write only U=4 blocks=4096", cb, time_it(10, [&] { hipLaunchKernelGGL((k_stream<3, 4>), dim3(4096), dim3(256), 0, 0, a4, b4, o4, n4); }));
+    {
+        const int64_t m4 = B * T * F * 8 / 16;  // out_d as the second input
+        report("a*b -> out (2R:1W) U=4 blocks=4096", 3.0 * m4 * 16, time_it(10, [&] { hipLaunchKernelGGL((k_stream<4, 4>), dim3(4096), dim3(256), 0, 0, a4, b4, o4, m4); }));
+        report("a*b -> out (2R:1W) U=2 blocks=8192", 3.0 * m4 * 16, time_it(10, [&] { hipLaunchKernelGGL((k_stream<4, 2>), dim3(8192), dim3(256), 0, 0, a4, b4, o4, m4); }));
+    }
+    {   // hipMemcpyAsync device-to-device of the same size
+        report("hipMemcpyDtoD", 2 * cb, time_it(10, [&] { CK(hipMemcpyAsync(out_p, spec_p, n4 * 16, hipMemcpyDeviceToDevice, 0)); }));
+    }
+
+    // ---------------------------------------------------------------- deep-filter kernels
+    for (int O : {5, 10}) {
+        const int la = 2;
+        const double alg = (double)(F * 8 + nd * O * 8 + E * 4 + F * 8) * B * T;
+        {   // flat-stream kernel on dense rows (round 1)
+            DfxDfaArgs A;
+            A.spec = (const float2 *)spec_d; A.coefs = (const float2 *)coefs; A.gains = gains; A.bin2band = d_b2b; A.out = (float2 *)out_d;
+            A.B = B; A.T = T; A.cs_b = (int64_t)O * T * nd; A.cs_n = T * nd; A.cs_t = nd; A.cs_f = 1;
+            A.F = F; A.nbdf = nd; A.order = O; A.lookahead = la; A.nb = E; A.pf_beta = 0.f; A.atten_lim = 0.f;
+            A.t_begin = 0; A.t_end = T; A.chunks = (T + 15) / 16; A.gT = T; A.out_T = T; A.out_toff = 0;
+            auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+            const size_t smem = al((size_t)(16 + O - 1) * nd * 8) + al((size_t)16 * E * 4) + al((size_t)F);
+            const unsigned nblk = (unsigned)(B * A.chunks);
+            char nm[96]; snprintf(nm, 96, "df_apply flat (dense rows)  O=%d", O);
+            report(nm, alg, time_it(20, [&] { hipLaunchKernelGGL(dfx_k_df_apply<16>, dim3(nblk), dim3(256), smem, 0, A); }));
+        }
+        for (int rpw : {4, 8, 16, 32, 64}) {
+            DfxDfrArgs R;
+            R.spec = spec_p; R.coefs = coefs; R.gains = gains; R.bin2band = d_b2b; R.out = out_p;
+            R.B = B; R.T = T; R.cs_b = (int64_t)O * T * nd; R.cs_n = T * nd; R.cs_t = nd;
+            R.gT = T; R.out_T = T; R.out_toff = 0; R.Fs = Fs; R.Fso = Fs; R.F = F; R.nbdf = nd; R.lookahead = la; R.nb = E;
+            R.pf_beta = 0.f; R.atten_lim = 0.f; R.t_begin = 0; R.t_end = T; R.rpw = rpw; R.chunks = (int)((T + rpw - 1) / rpw);
+            const unsigned nblk = (unsigned)(((B + 7) / 8) * 8 * ((R.chunks + 3) / 4));
+            char nm[96]; snprintf(nm, 96, "df_apply rows  rpw=%d  O=%d", rpw, O);
+            if (O == 5) report(nm, alg, time_it(20, [&] { hipLaunchKernelGGL((dfx_k_df_apply_rows<5, 4, false>), dim3(nblk), dim3(256), 0, 0, R); }));
+            else report(nm, alg, time_it(20, [&] { hipLaunchKernelGGL((dfx_k_df_apply_rows<10, 4, false>), dim3(nblk), dim3(256), 0, 0, R); }));
+            if (rpw == 16) {
+                R.gains = nullptr;
+                snprintf(nm, 96, "df_apply rows  rpw=%d  O=%d  no gains", rpw, O);
+                const double alg2 = alg - (double)E * 4 * B * T;
+                if (O == 5) report(nm, alg2, time_it(20, [&] { hipLaunchKernelGGL((dfx_k_df_apply_rows<5, 4, false>), dim3(nblk), dim3(256), 0, 0, R); }));
+                else report(nm, alg2, time_it(20, [&] { hipLaunchKernelGGL((dfx_k_df_apply_rows<10, 4, false>), dim3(nblk), dim3(256), 0, 0, R); }));
+                R.gains = gains; R.nbdf = 2;   // almost pure stream: the deep filter on one float4 column only
+                snprintf(nm, 96, "df_apply rows  rpw=%d  nb_df=2 (stream+gains)", rpw);
+                const double alg3 = (double)(F * 8 + 2 * O * 8 + E * 4 + F * 8) * B * T;
+                R.cs_b = (int64_t)O * T * 2; R.cs_n = T * 2; R.cs_t = 2;
+                if (O == 5) report(nm, alg3, time_it(20, [&] { hipLaunchKernelGGL((dfx_k_df_apply_rows<5, 4, false>), dim3(nblk), dim3(256), 0, 0, R); }));
+            }
+        }
+    }
+    return 0;
+}

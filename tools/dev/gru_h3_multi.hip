@@ -7,10 +7,18 @@ bool dfx_prof_on(int) { return false; }
 void dfx_prof_begin(int, hipStream_t) {}
 void dfx_prof_end(int, hipStream_t) {}
 // streaming traffic beside the recurrences: mode 0 plain float4 copy, 1 non-temporal loads+stores, 2 read-only sum
-template <int MODE> __global__ void __launch_bounds__(256) k_stream(const float4 *__restrict__ in, float4 *__restrict__ out, int64_t n, int reps) {
+// xmask != 0: only blocks whose blockIdx % 8 (= XCD under the observed round-robin dispatch) is in the mask work
+template <int MODE> __global__ void __launch_bounds__(256) k_stream(const float4 *__restrict__ in, float4 *__restrict__ out, int64_t n, int reps, int xmask) {
     float4 acc = {0, 0, 0, 0};
+    int64_t bid = blockIdx.x, nb = gridDim.x;
+    if (xmask) {
+        const int x = (int)(blockIdx.x & 7), pc = __builtin_popcount(xmask);
+        if (!((xmask >> x) & 1)) return;
+        bid = (int64_t)(blockIdx.x >> 3) * pc + __builtin_popcount(xmask & ((1 << x) - 1));
+        nb = (int64_t)(gridDim.x >> 3) * pc;
+    }
     for (int r = 0; r < reps; ++r)
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        for (int64_t i = bid * 256 + threadIdx.x; i < n; i += nb * 256) {
             float4 v;
             if (MODE == 1) { v.x = __builtin_nontemporal_load(&in[i].x); v.y = __builtin_nontemporal_load(&in[i].y); v.z = __builtin_nontemporal_load(&in[i].z); v.w = __builtin_nontemporal_load(&in[i].w); }
             else v = in[i];
@@ -42,7 +50,13 @@ int main(int argc, char **argv) {
     float4 *sin_, *sout; CK(hipMalloc(&sin_, NS * 16)); CK(hipMalloc(&sout, NS * 16)); CK(hipMemset(sin_, 0, NS * 16));
     hipStream_t ss; CK(hipStreamCreateWithFlags(&ss, hipStreamNonBlocking));
     const int smode = argc > 3 ? atoi(argv[3]) : -1, sblocks = argc > 4 ? atoi(argv[4]) : 2048, sreps = argc > 5 ? atoi(argv[5]) : 2;
-    for (int n = 1; n <= NK; ++n) {
+    // argv[6]: XCD mask of the recurrence kernels (hex; 0 = plain grid, "p" = the product's per-layer 4-XCD windows), argv[7]: XCD mask of the stream
+    const bool gprod = argc > 6 && argv[6][0] == 'p';
+    const int gmask = (argc > 6 && !gprod) ? (int)strtol(argv[6], nullptr, 16) : 0, smask = argc > 7 ? (int)strtol(argv[7], nullptr, 16) : 0;
+    const int nfirst = argc > 8 ? atoi(argv[8]) : 1;
+    for (int i = 0; i < NK; ++i) args[i].xcd_mask = gprod ? ((0xF << ((i * 4) % 8)) & 0xff) : gmask;
+    printf("# recurrence XCD mask %s, stream mode %d XCD mask 0x%x\n", gprod ? "product" : (argc > 6 ? argv[6] : "0"), smode, smask);
+    for (int n = nfirst; n <= NK; ++n) {
         float best = 1e9;
         for (int it = 0; it < 3; ++it) {
             CK(hipDeviceSynchronize());
@@ -51,13 +65,15 @@ int main(int argc, char **argv) {
             std::vector<hipEvent_t> done(n);
             if (smode >= 0) {
                 CK(hipStreamWaitEvent(ss, a, 0));
-                if (smode == 0) hipLaunchKernelGGL(k_stream<0>, dim3(sblocks), dim3(256), 0, ss, sin_, sout, NS, sreps);
-                if (smode == 1) hipLaunchKernelGGL(k_stream<1>, dim3(sblocks), dim3(256), 0, ss, sin_, sout, NS, sreps);
-                if (smode == 2) hipLaunchKernelGGL(k_stream<2>, dim3(sblocks), dim3(256), 0, ss, sin_, sout, NS, sreps);
+                if (smode == 0) hipLaunchKernelGGL(k_stream<0>, dim3(sblocks), dim3(256), 0, ss, sin_, sout, NS, sreps, smask);
+                if (smode == 1) hipLaunchKernelGGL(k_stream<1>, dim3(sblocks), dim3(256), 0, ss, sin_, sout, NS, sreps, smask);
+                if (smode == 2) hipLaunchKernelGGL(k_stream<2>, dim3(sblocks), dim3(256), 0, ss, sin_, sout, NS, sreps, smask);
             }
             for (int i = 0; i < n; ++i) {
                 CK(hipStreamWaitEvent(st[i], a, 0));
-                hipLaunchKernelGGL(dfx_k_gru_rec_h3, dim3((B + 15) / 16), dim3(DFX_GH_THREADS), DFX_GH_SMEM, st[i], args[i]);
+                const int pc = args[i].xcd_mask ? __builtin_popcount(args[i].xcd_mask) : 8;
+                const unsigned nblk = args[i].xcd_mask ? (unsigned)(((B + 15) / 16 + pc - 1) / pc * 8) : (unsigned)((B + 15) / 16);
+                hipLaunchKernelGGL(dfx_k_gru_rec_h3, dim3(nblk), dim3(DFX_GH_THREADS), DFX_GH_SMEM, st[i], args[i]);
                 CK(hipEventCreate(&done[i])); CK(hipEventRecord(done[i], st[i])); CK(hipStreamWaitEvent(0, done[i], 0));
             }
             CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b)); CK(hipDeviceSynchronize());
