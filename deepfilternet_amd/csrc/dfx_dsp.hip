@@ -87,8 +87,13 @@ const char *const g_kernel_names[DFX_K_COUNT] = {
 }  // namespace
 
 bool dfx_prof_on(int id) { return g_prof.mask != 0 && id >= 0 && id < DFX_K_COUNT && ((g_prof.mask >> id) & 1u); }
+// An empty kernel in front of the start event: a marker that directly follows hipStreamWaitEvent packets was seen to carry a
+// timestamp from BEFORE the awaited events (the in-loop df_apply interval then included the wait for the last decoder tail:
+// 0.69 ms by events against 0.60 ms in the rocprofv3 kernel trace of the same run).  Behind a dispatch the marker is ordered.
+__global__ void dfx_k_prof_fence() {}
 void dfx_prof_begin(int, hipStream_t s) {
     g_prof.cur = g_prof.get();
+    dfx_launch(dfx_k_prof_fence, dim3(1), dim3(64), 0, s);
     (void)hipEventRecord(g_prof.cur, s);
 }
 void dfx_prof_end(int id, hipStream_t s) {
@@ -536,9 +541,19 @@ int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, 
             R.t_begin = (int)t_begin;
             R.t_end = (int)t_end;
             static const int rpw_env = [] { const char *e = getenv("DFX_DFA_RPW"); return e ? atoi(e) : 0; }();
-            R.rpw = rpw_env > 0 ? rpw_env : 16;
+            R.rpw = rpw_env > 0 ? rpw_env : 1;   // one frame per wave measured fastest (the O-1 extra rows a wave reads are L2 hits)
             R.chunks = (int)dfx_ceil_div(t_end - t_begin, R.rpw);
-            const int64_t nblk = dfx_ceil_div(B, 8) * 8 * dfx_ceil_div(R.chunks, 4);
+            R.zcols = (F + 1) / 2;
+            if ((out_stride * 8) % 64 == 0) {   // 64-byte aligned output rows: complete the last sector of every row with zeros
+                const int64_t z = dfx_ceil_div((int64_t)F * 8, 64) * 4;
+                R.zcols = (int)(z < out_stride / 2 ? z : out_stride / 2);
+            }
+            R.items = dfx_ceil_div(B, 8) * 8 * dfx_ceil_div(R.chunks, 4);
+            // one workgroup per work item by default (DFX_DFA_WGS=n: a persistent grid of n workgroups per CU walking the items, measured
+            // slower: 0.54 vs 0.47 ms stand-alone, profiles/r02_dfa_bench.log)
+            static const int wg_per_cu = [] { const char *e = getenv("DFX_DFA_WGS"); return e ? atoi(e) : 0; }();
+            int64_t nblk = R.items;
+            if (wg_per_cu > 0 && nblk > (int64_t)dfx_env_num_cus() * wg_per_cu) nblk = (int64_t)dfx_env_num_cus() * wg_per_cu;
             if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_df_apply: batch too large for one launch");
             const int np = ((F + 1) / 2 + 63) / 64;
             DfxKScope ks(DFX_K_DF_APPLY, s);

@@ -803,8 +803,9 @@ __global__ void __launch_bounds__(DFX_DFA_THREADS) dfx_k_df_apply(DfxDfaArgs A) 
 // ---------------------------------------------------------------------------------------------------------------------
 // Row-streaming form of the same operator for 16-byte aligned rows (row stride Fs complex elements, Fs even: the engine pads
 // F = 481 to 482 in its own spec / spec_e buffers, so a row is a run of float4 = two bins and nothing straddles rows).
-//   * a WAVE owns `rpw` consecutive frames of one clip and walks them in time order; a workgroup = 4 waves = 4 consecutive
-//     chunks of that clip.  No LDS, no barrier: waves never wait for each other.
+//   * a WAVE owns `rpw` consecutive frames of one clip (default 1: measured fastest, 6.2 TB/s vs 5.9 at 4 and 5.4 at 16) and walks
+//     them in time order; a workgroup = 4 waves = 4 consecutive chunks of that clip.  No LDS, no barrier: waves never wait for
+//     each other.  All streams are non-temporal (every byte is touched once; a plain copy gains 10 % from the hint on this part).
 //   * pass 0 (lanes 0..63 = bins 0..127): lanes below nb_df/2 own two deep-filter bins each and keep the O frames the filter
 //     reads in a REGISTER ring (one new 16-byte load per frame, not O); their O coefficients are O float4 loads (tap-major or
 //     frame-major layouts: consecutive lanes read consecutive coefficients).  The remaining lanes / passes multiply by the band
@@ -827,30 +828,38 @@ struct DfxDfrArgs {
     float pf_beta, atten_lim;
     int t_begin, t_end;   // frames [t_begin, t_end) of every clip
     int rpw;              // frames per wave
+    int zcols;            // float4 columns stored per output row: ceil(F/2), or more (zeros) to complete the row's last 64-byte sector
     int chunks;           // chunks of rpw frames per clip
+    int64_t items;        // work items = ceil(B / 8) * 8 * ceil(chunks / 4)
 };
 
 // NPC > 0: the number of 64-lane passes over a row (ceil(ceil(F/2) / 64)) as a compile-time constant (all row loads of a frame are
 // then issued together and the band indices live in registers); NPC == 0: any F, one pass at a time.  PF: post filter / attenuation
 // limit compiled in (the common case, neither, then carries no sinf / sqrtf code and fewer live registers).
 // Addressing: everything but the lane index is wave-uniform (clip, frame, tap), so every access is <scalar base> + lane * 16.
-template <int O, int NPC, bool PF>
+template <int O, int NPC, bool PF, int NT = 7>   // NT bit 0: non-temporal spec loads, bit 1: non-temporal stores, bit 2: non-temporal coefficient loads
 __global__ void __launch_bounds__(256) dfx_k_df_apply_rows(DfxDfrArgs A) {
+    auto ld = [](const f32x4 *p) -> f32x4 { return (NT & 1) ? DFX_NT_LOAD(p) : *p; };
+    auto ldc = [](const f32x4 *p) -> f32x4 { return (NT & 4) ? DFX_NT_LOAD(p) : *p; };
+    auto st = [](f32x4 v, f32x4 *p) { if (NT & 2) DFX_NT_STORE(v, p); else *p = v; };
     const unsigned lane = threadIdx.x & 63;
     const int wave = dfx_wave_uniform((int)(threadIdx.x >> 6));
-    const int64_t id = blockIdx.x;
-    const int xcd = (int)(id & 7);          // blocks that share blockIdx.x % 8 (one XCD / L2) work on the same clips (speed hint only)
+    const int wgc = (A.chunks + 3) >> 2;    // work items (4 chunks = one workgroup pass) per clip
+    // the grid is a multiple of 8 and walks the work items grid-stride; by default it has one workgroup per item (a persistent grid of
+    // a few workgroups per CU was measured slower, 0.54 vs 0.47 ms: short-lived workgroups keep more independent rows in flight)
+    for (int64_t id = blockIdx.x; id < A.items; id += gridDim.x) {
+    const int xcd = (int)(id & 7);          // items that share id % 8 run on one XCD / L2 (gridDim % 8 == 0) and work on the same clips
     const int64_t j = id >> 3;
-    const int wgc = (A.chunks + 3) >> 2;    // workgroups per clip
     const int64_t b = (j / wgc) * 8 + xcd;
     const int chunk = (int)(j % wgc) * 4 + wave;
-    if (b >= A.B || chunk >= A.chunks) return;
+    if (b >= A.B || chunk >= A.chunks) continue;
     const int t0 = A.t_begin + chunk * A.rpw;
     const int t1 = (t0 + A.rpw) < A.t_end ? (t0 + A.rpw) : A.t_end;
     const int F = A.F, la = A.lookahead, toff = O - 1 - la;
     const unsigned nd4 = (unsigned)A.nbdf >> 1;   // float4 columns that belong to the deep filter (<= 64)
     const unsigned ncol = (unsigned)(F + 1) >> 1; // float4 columns of a row
-    const int np = NPC > 0 ? NPC : (int)((ncol + 63) >> 6);
+    const unsigned zcol = (unsigned)A.zcols;      // columns written per row (>= ncol: the extra ones are zero padding)
+    const int np = NPC > 0 ? NPC : (int)(((zcol > ncol ? zcol : ncol) + 63) >> 6);
     const bool is_df = lane < nd4;
     const int64_t rs = A.Fs >> 1, ro = A.Fso >> 1, cst = A.cs_t >> 1, csn = A.cs_n >> 1;
     const f32x4 *spec_b = reinterpret_cast<const f32x4 *>(A.spec) + b * A.T * rs;
@@ -886,7 +895,7 @@ __global__ void __launch_bounds__(256) dfx_k_df_apply_rows(DfxDfrArgs A) {
 #pragma unroll
         for (int n = 0; n + 1 < O; ++n) {
             const int tt = t0 - toff + n;
-            if (tt >= 0 && tt < A.T) ring[n + 1] = (spec_b + (int64_t)tt * rs)[lane];
+            if (tt >= 0 && tt < A.T) ring[n + 1] = (spec_b + (int64_t)tt * rs)[lane];   // re-read by the neighbouring chunk: default policy
         }
     }
     for (int t = t0; t < t1; ++t) {
@@ -896,22 +905,22 @@ __global__ void __launch_bounds__(256) dfx_k_df_apply_rows(DfxDfrArgs A) {
         // the coefficients, the gains, then the remaining passes
         f32x4 x0 = zero4;
         if (is_df) {
-            if (t + la < A.T) x0 = (xrow + (int64_t)la * rs)[lane];
+            if (t + la < A.T) x0 = ld(xrow + (int64_t)la * rs + lane);
         } else if (lane < ncol) {
-            x0 = xrow[lane];
+            x0 = ld(xrow + lane);
         }
         f32x4 cf[O];
         if (is_df) {
             const f32x4 *cp = coef_b + (int64_t)t * cst;
 #pragma unroll
-            for (int n = 0; n < O; ++n) cf[n] = (cp + (int64_t)n * csn)[lane];
+            for (int n = 0; n < O; ++n) cf[n] = ldc(cp + (int64_t)n * csn + lane);
         }
         float gv = 1.f;
         if (gain_b && lane < (unsigned)A.nb) gv = (gain_b + (int64_t)t * A.nb)[lane];
         f32x4 xp[NB];
         if (NPC > 0) {
 #pragma unroll
-            for (int p = 1; p < NB; ++p) xp[p] = (lane + 64u * p) < ncol ? (xrow + 64 * p)[lane] : zero4;
+            for (int p = 1; p < NB; ++p) xp[p] = (lane + 64u * p) < ncol ? ld(xrow + 64 * p + lane) : zero4;
         }
         // ---- pass 0
         {
@@ -952,7 +961,8 @@ __global__ void __launch_bounds__(256) dfx_k_df_apply_rows(DfxDfrArgs A) {
                 y[0] = x[0] * g0, y[1] = x[1] * g0;
                 y[2] = x[2] * g1, y[3] = x[3] * g1;
             }
-            if (lane < ncol) yrow[lane] = finish2(y, x, 2 * (int)lane + 1 >= F);
+            if (lane < ncol) st(finish2(y, x, 2 * (int)lane + 1 >= F), yrow + lane);
+            else if (lane < zcol) st(zero4, yrow + lane);
         }
         // ---- the other passes: band gains only
         auto gain_pass = [&](int p, f32x4 x, int i0, int i1) {
@@ -966,7 +976,9 @@ __global__ void __launch_bounds__(256) dfx_k_df_apply_rows(DfxDfrArgs A) {
                 f32x4 y;
                 y[0] = x[0] * g0, y[1] = x[1] * g0;
                 y[2] = x[2] * g1, y[3] = x[3] * g1;
-                (yrow + 64 * p)[lane] = finish2(y, x, 2 * (int)col + 1 >= F);
+                st(finish2(y, x, 2 * (int)col + 1 >= F), yrow + 64 * p + lane);
+            } else if (col < zcol) {
+                st(zero4, yrow + 64 * p + lane);   // pad columns that complete the row's last 64-byte sector
             }
         };
         if (NPC > 0) {
@@ -976,9 +988,10 @@ __global__ void __launch_bounds__(256) dfx_k_df_apply_rows(DfxDfrArgs A) {
             for (int p = 1; p < np; ++p) {
                 const unsigned col = lane + 64u * p;
                 const int f = 2 * (int)col;
-                const f32x4 x = col < ncol ? (xrow + 64 * p)[lane] : zero4;
+                const f32x4 x = col < ncol ? ld(xrow + 64 * p + lane) : zero4;
                 gain_pass(p, x, (A.gains && f < F) ? A.bin2band[f] : 0, (A.gains && f + 1 < F) ? A.bin2band[f + 1] : 0);
             }
         }
+    }
     }
 }

@@ -262,6 +262,14 @@ __global__ void dfx_k_gate_finish(const unsigned char *flags, int *skip_counter,
     }
 }
 
+#ifndef DFX_HIPEMU
+__global__ void dfx_k_dev_spin(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+#else
+__global__ void dfx_k_dev_spin(long long) {}
+#endif
 enum { EV_START = 0, EV_C0, EV_C1, EV_C0P, EV_EMB, EV_COEFS, EV_FRONT, EV_DONE, EV_XA, EV_MASK, EV_LSNR, EV_FIN };
 
 struct dfx_model {
@@ -1288,6 +1296,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     const int64_t t_zero = sc ? sc->t_zero : 0;
     const Ws w = plan_ws(c, m->fuse_c0, R, B);
     const int64_t sstride = fin ? fin->spec_stride : 0;  // 0: dense rows of F bins
+    hipStream_t fin_s = s;                               // stream of the finishing kernels (deep filter, synthesis)
     const int E = c.nb_erb, Fd = c.nb_df, O = c.df_order, NO = 2 * O, emb = C * E / 4, L = c.conv_lookahead;
     float *e0 = ws + w.e0, *e1 = ws + w.e1, *e2 = ws + w.e2, *e3 = ws + w.e3, *c0 = ws + w.c0, *c1 = ws + w.c1;
     float *emb_in = ws + w.emb_in, *embv = ws + w.emb, *xa = ws + w.xa, *xb = ws + w.xb, *gi = ws + w.gi;
@@ -1708,9 +1717,14 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             if ((rc = signal(EV_FIN, st)) || (rc = wait(EV_FIN, s))) return rc;
             return DFX_OK;
         }
-        if ((rc = wait(EV_MASK, s))) return rc;
+        // The finishing kernels run on the DF tail's stream, directly behind its last df_out launch: a kernel that starts behind a
+        // cross-queue join starts after ~45 us of idle chip and was measured 17 % slower for its whole duration (0.59 vs 0.50 ms
+        // for the deep filter in the rocprofv3 trace, same data, nothing overlapping); behind a kernel of its own queue the gap is
+        // 6 us.  The ERB tail's masks are normally complete by then (its event is already signalled).
+        fin_s = ln->ts[1];
+        if ((rc = wait(EV_MASK, fin_s))) return rc;
     }
-    if ((rc = wait(EV_COEFS, s))) return rc;
+    if (fin_s == s && (rc = wait(EV_COEFS, s))) return rc;
     // ---- Mask + MF.DF + combine + post filter + atten_lim (:426-454, enhance.py:238-240)
     if (sc) {  // spec has sc->spec_T frames per clip, coefficients / gains T; the n enhanced frames are stored compactly
         const float beta = sc->pf_beta >= 0.f ? sc->pf_beta : (c.mask_pf ? c.pf_beta : 0.f);
@@ -1727,12 +1741,29 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         return dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, sc->spec_T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead, beta,
                                    atten_lim, sc->out, s, t_begin, T, T, sc->out_T, sc->out_toff);
     }
+    {   // dev experiment: DFX_DEV_SPIN="<blocks>,<microseconds>" launches a spinning kernel in front of the deep filter
+        static const char *sp = getenv("DFX_DEV_SPIN");
+        if (sp && sp[0] == 'd') {  // "d": the deep filter twice in a row (is the second launch as slow as the first?)
+            if ((rc = dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead,
+                                          c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, fin_s, 0, -1, -1, -1, 0, sstride, sstride)))
+                return rc;
+        } else if (sp && sp[0] == 'c') {  // "c<MB>": a device copy spec -> spec_e of that many MB first (spec_e is overwritten afterwards anyway)
+            const size_t mb = (size_t)atoi(sp + 1);
+            const char *xr = strchr(sp, 'x');
+            for (int r = 0; r < (xr ? atoi(xr + 1) : 1); ++r) (void)hipMemcpyAsync(spec_e, spec, mb << 20, hipMemcpyDeviceToDevice, fin_s);
+        } else if (sp) {
+            int blocks = 1, us = 0;
+            sscanf(sp, "%d,%d", &blocks, &us);
+            dfx_launch(dfx_k_dev_spin, dim3((unsigned)blocks), dim3(64), 0, fin_s, (long long)us * 100);  // wall_clock64 ticks at 100 MHz
+        }
+    }
     if ((rc = dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead,
-                                  c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, s, 0, -1, -1, -1, 0, sstride, sstride)))
+                                  c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, fin_s, 0, -1, -1, -1, 0, sstride, sstride)))
         return rc;
-    if (fin)
-        return dfx_launch_synthesis(fin->st, spec_e, B, T, nullptr, nullptr, fin->y, fin->out_stride, fin->out_skip, fin->out_len, s, 0, -1,
-                                    sstride);
+    if (fin && (rc = dfx_launch_synthesis(fin->st, spec_e, B, T, nullptr, nullptr, fin->y, fin->out_stride, fin->out_skip, fin->out_len,
+                                          fin_s, 0, -1, sstride)))
+        return rc;
+    if (fin_s != s && ((rc = signal(EV_FIN, fin_s)) || (rc = wait(EV_FIN, s)))) return rc;
     return DFX_OK;
 }
 
@@ -1772,12 +1803,14 @@ extern "C" int dfx_model_forward(const dfx_model *m, const dfx_bands *bands, con
 }
 
 // ------------------------------------------------------------------------------------------------ enhance()
-// row stride (complex elements) of enhance()'s spec / spec_e buffers: F rounded up to even = 16-byte aligned rows
-// (DFX_SPEC_PAD=0: dense rows and the flat-stream deep-filter kernel, for A/B measurements)
+// row stride (complex elements) of enhance()'s spec / spec_e buffers: F rounded up to a multiple of 8 = rows that start on a
+// 64-byte boundary (F = 481 -> 488): every access of the row-streaming deep-filter kernel is then a 16-byte access inside whole
+// 64-byte sectors.  Measured (tools/dev/dfa_bench.hip, profiles/r02_dfa_bench.log): stride 481 (flat-stream kernel) 4.9 TB/s,
+// 482 -> 6.0, 488 / 496 / 512 -> 6.2 TB/s.  (DFX_SPEC_PAD=0: dense rows and the flat-stream kernel, for A/B measurements)
 static inline int64_t enh_spec_stride(const dfx_state *st) {
     static const bool pad = [] { const char *e = getenv("DFX_SPEC_PAD"); return !(e && e[0] == '0'); }();
     const int64_t F = (int64_t)st->N / 2 + 1;
-    return pad ? (F + 1) & ~(int64_t)1 : F;
+    return pad ? (F + 7) & ~(int64_t)7 : F;
 }
 namespace {
 struct EnhWs {

@@ -1757,7 +1757,7 @@ __global__ void __launch_bounds__(DFX_GRU_THREADS, 2) dfx_k_gru_rec(const float 
 // ---------------------------------------------------------------------------------------------------------------------
 #define DFX_GH_ROWS 16
 #ifndef DFX_GH_ABLATE
-#define DFX_GH_ABLATE 0  /* dev ablations (tools/dev/gru_h3_bench.hip): 1 no stream refill, 2 no gi loads, 4 no matrix ops, 8 no gate math */
+#define DFX_GH_ABLATE 0  /* dev ablations (tools/dev/gru_h3_bench.hip): 1 no stream refill, 2 no gi loads, 4 no matrix ops, 8 no gate math, 16 no y stores */
 #endif
 #ifndef DFX_GH_NW
 #define DFX_GH_NW 4      /* waves per workgroup: 4 (one per SIMD, 512 registers each) or 8 */
@@ -1820,8 +1820,9 @@ struct DfxGhArgs {
     int64_t B, T;
     int64_t t0, t1;       // steps [t0, t1) of the T frames (time-chunked launches carry h through h_in / h_out)
     float unscale;
-    int xcd_mask;         // != 0: the grid is oversized 8x / popcount and only blocks whose blockIdx % 8 (= XCD under the observed
-                          // round-robin dispatch) is in the mask work: a layer's workgroups then share few L2s (placement = speed only)
+    int xcd_mask;         // != 0: the grid is oversized 8x / popcount and only blocks that find themselves on an XCD of the mask work
+                          // (the k-th block of an XCD is blockIdx >> 3 under the round-robin dispatch): a layer's workgroups then
+                          // share few L2s, and L2s that other kernels can be kept away from (placement = speed only)
 };
 
 __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_rec_h3(DfxGhArgs A) {
@@ -1835,7 +1836,7 @@ __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_rec_h
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
     int64_t grp = blockIdx.x;
     if (A.xcd_mask) {
-        const int x = (int)(blockIdx.x & 7);
+        const int x = dfx_xcc_id();   // the XCD itself, not blockIdx % 8 (equal only up to a per-launch rotation)
         if (!((A.xcd_mask >> x) & 1)) return;
         grp = (int64_t)(blockIdx.x >> 3) * __builtin_popcount(A.xcd_mask) + __builtin_popcount(A.xcd_mask & ((1 << x) - 1));
         if (grp * DFX_GH_ROWS >= A.B) return;
@@ -1983,7 +1984,7 @@ __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_rec_h
 #pragma unroll
                 for (int g = 0; g < 3; ++g) gv[g][s] = *reinterpret_cast<const float4 *>(gp + tn * (3 * H) + g * H + 16 * s);
             }
-            if (valid) *reinterpret_cast<float4 *>(yp + t * H + 16 * s) = make_float4(hp[s][0], hp[s][1], hp[s][2], hp[s][3]);
+            if (valid && !(DFX_GH_ABLATE & 16)) *reinterpret_cast<float4 *>(yp + t * H + 16 * s) = make_float4(hp[s][0], hp[s][1], hp[s][2], hp[s][3]);
             put_h16(cur ^ 1, s);
         }
         __syncthreads();

@@ -40,6 +40,14 @@ static inline bool dfx_env_is_emulator() { return false; }
 // a value that is the same in every lane of a wave by construction (e.g. derived from threadIdx.x >> 6): tells the compiler so
 // (address arithmetic on it stays in SGPRs and loads through it can be scalar loads)
 static __device__ __forceinline__ int dfx_wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// non-temporal (streaming) global accesses for data that is touched exactly once: the lines are not kept in L2 / MALL at the
+// expense of others (measured on a plain copy: 6.0 -> 6.7 TB/s, tools/dev/dfa_bench.hip)
+#define DFX_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define DFX_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+// XCD (accelerator complex die) this wave runs on: HW_REG_XCC_ID[3:0].  The dispatcher deals the workgroups of a launch round-robin
+// over the 8 XCDs but starts where the previous dispatch stopped (measured: tools/dev/xcd_probe.hip), so blockIdx % 8 identifies
+// the XCD only up to a rotation that is constant within a launch; code that needs a *specific* XCD reads the register.
+static __device__ __forceinline__ int dfx_xcc_id() { return (int)__builtin_amdgcn_s_getreg((3 << 11) | 20); }
 static inline hipError_t dfx_env_set_max_dyn_smem(const void *func, size_t bytes) {
     return hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }

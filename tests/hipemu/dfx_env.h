@@ -516,6 +516,10 @@ static inline float __fmul_rn(float a, float b) { return a * b; }
 static inline float __fdiv_rn(float a, float b) { return a / b; }
 // wave-uniform values: identity on the interpreter (callers only pass values that are uniform across the wave by construction)
 static inline int dfx_wave_uniform(int v) { return v; }
+#define DFX_NT_LOAD(p) (*(p))
+#define DFX_NT_STORE(v, p) (*(p) = (v))
+// the interpreter has no XCDs: the round-robin dispatch without rotation
+#define dfx_xcc_id() ((int)(blockIdx.x & 7))
 static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
 
 #define DFX_OPAQUE(x) asm volatile("" : "+r"(x))

@@ -39,6 +39,10 @@ __global__ void __launch_bounds__(256) k_stream(const f32x4 *__restrict__ a, con
     }
     if (MODE == 2 && acc[0] == 12345.678f) out[0] = acc;
 }
+__global__ void k_spin(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
 // one contiguous slab per workgroup instead of a grid-stride walk
 template <int U>
 __global__ void __launch_bounds__(256) k_copy_slab(const f32x4 *__restrict__ a, f32x4 *__restrict__ out, int64_t n, int64_t per_wg) {
@@ -87,11 +91,12 @@ int main(int argc, char **argv) {
     { int f = 0; for (int e = 0; e < 32; ++e) for (int k = 0; k < widths[e]; ++k) b2b[f++] = (unsigned char)e; }
     unsigned char *d_b2b; CK(hipMalloc(&d_b2b, F)); CK(hipMemcpy(d_b2b, b2b.data(), F, hipMemcpyHostToDevice));
 
+    auto report = [&](const char *name, double bytes, float ms) { printf("%-44s %8.4f ms  %7.1f GB/s\n", name, ms, bytes / ms / 1e6); fflush(stdout); };
+    if (argc > 1) {
     // ---------------------------------------------------------------- streams
     const int64_t n4 = B * T * Fs * 8 / 16;   // float4s in one padded spectrum buffer (0.99 GB)
     const f32x4 *a4 = (const f32x4 *)spec_p, *b4 = (const f32x4 *)out_d;
     f32x4 *o4 = (f32x4 *)out_p;
-    auto report = [&](const char *name, double bytes, float ms) { printf("%-44s %8.4f ms  %7.1f GB/s\n", name, ms, bytes / ms / 1e6); fflush(stdout); };
     const double cb = (double)n4 * 16;
     for (int blocks : {1024, 2048, 4096, 8192, 16384}) {
         char nm[96];
@@ -119,6 +124,67 @@ int main(int argc, char **argv) {
         report("hipMemcpyDtoD", 2 * cb, time_it(10, [&] { CK(hipMemcpyAsync(out_p, spec_p, n4 * 16, hipMemcpyDeviceToDevice, 0)); }));
     }
 
+    }
+    if (argc > 2) {   // argv[2] = N: does a kernel run slower once N other streams (HW queues) of the process have been used?
+        const int NS = atoi(argv[2]);
+        std::vector<hipStream_t> st(NS);
+        for (auto &q : st) CK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+        DfxDfrArgs R;
+        const int O = 5, la = 2, Fs2 = 488;
+        float *sp, *op; CK(hipMalloc(&sp, B * T * Fs2 * 8)); CK(hipMalloc(&op, B * T * Fs2 * 8)); CK(hipMemset(sp, 0, B * T * Fs2 * 8));
+        R.spec = sp; R.coefs = coefs; R.gains = gains; R.bin2band = d_b2b; R.out = op;
+        R.B = B; R.T = T; R.cs_b = (int64_t)O * T * nd; R.cs_n = T * nd; R.cs_t = nd;
+        R.gT = T; R.out_T = T; R.out_toff = 0; R.Fs = Fs2; R.Fso = Fs2; R.F = F; R.nbdf = nd; R.lookahead = la; R.nb = E;
+        R.pf_beta = 0.f; R.atten_lim = 0.f; R.t_begin = 0; R.t_end = T; R.rpw = 1; R.chunks = (int)T; R.zcols = 244;
+        R.items = ((B + 7) / 8) * 8 * ((R.chunks + 3) / 4);
+        const unsigned nblk = argc > 3 ? (unsigned)atoi(argv[3]) : (unsigned)R.items;
+        const double alg = (double)(F * 8 + nd * O * 8 + E * 4 + F * 8) * B * T;
+        hipStream_t main_s; CK(hipStreamCreateWithFlags(&main_s, hipStreamNonBlocking));
+        auto timed = [&](const char *nm) {
+            hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((dfx_k_df_apply_rows<5, 4, false, 7>), dim3(nblk), dim3(256), 0, main_s, R);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(a, main_s));
+            for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((dfx_k_df_apply_rows<5, 4, false, 7>), dim3(nblk), dim3(256), 0, main_s, R);
+            CK(hipEventRecord(b, main_s)); CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b)); report(nm, alg, ms / 10);
+        };
+        timed("df_apply, fresh process");
+        hipEvent_t ev; CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        for (int rep = 0; rep < 20; ++rep)
+            for (int i = 0; i < NS; ++i) {   // a chain of small kernels hopping over the streams, like the engine's event graph
+                if (i) CK(hipStreamWaitEvent(st[i], ev, 0));
+                hipLaunchKernelGGL((k_stream<0, 1>), dim3(64), dim3(256), 0, st[i], (const f32x4 *)spec_p, (const f32x4 *)out_d, (f32x4 *)out_p, (int64_t)1 << 16);
+                CK(hipEventRecord(ev, st[i]));
+            }
+        CK(hipDeviceSynchronize());
+        char nm[96]; snprintf(nm, 96, "df_apply after %d other streams were used", NS); timed(nm);
+        // the same launches while the other streams hold PENDING packets: each waits for an event that is recorded behind the timed
+        // launches (what the queues of the next enhance() call look like while the current call's last kernels run)
+        for (int depth : {1, 8}) {
+            hipEvent_t a, b, after; CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); CK(hipEventCreateWithFlags(&after, hipEventDisableTiming));
+            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, main_s, (long long)300000);   // 3 ms: time to enqueue everything below
+            CK(hipEventRecord(a, main_s));
+            for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((dfx_k_df_apply_rows<5, 4, false, 7>), dim3(nblk), dim3(256), 0, main_s, R);
+            CK(hipEventRecord(b, main_s));
+            CK(hipEventRecord(after, main_s));
+            for (int i = 0; i < NS; ++i) {
+                CK(hipStreamWaitEvent(st[i], after, 0));
+                for (int d = 0; d < depth; ++d) {
+                    hipLaunchKernelGGL((k_stream<0, 1>), dim3(64), dim3(256), 0, st[i], (const f32x4 *)spec_p, (const f32x4 *)out_d, (f32x4 *)out_p, (int64_t)1 << 16);
+                    CK(hipEventRecord(ev, st[i]));
+                    CK(hipStreamWaitEvent(st[(i + 1) % NS], ev, 0));
+                }
+            }
+            CK(hipDeviceSynchronize());
+            float ms; CK(hipEventElapsedTime(&ms, a, b));
+            snprintf(nm, 96, "df_apply, %d streams with pending packets (x%d)", NS, depth); report(nm, alg, ms / 10);
+        }
+        for (auto &q : st) CK(hipStreamDestroy(q));
+        CK(hipDeviceSynchronize());
+        timed("df_apply after those streams were destroyed");
+        return 0;
+    }
     // ---------------------------------------------------------------- deep-filter kernels
     for (int O : {5, 10}) {
         const int la = 2;
@@ -135,28 +201,26 @@ int main(int argc, char **argv) {
             char nm[96]; snprintf(nm, 96, "df_apply flat (dense rows)  O=%d", O);
             report(nm, alg, time_it(20, [&] { hipLaunchKernelGGL(dfx_k_df_apply<16>, dim3(nblk), dim3(256), smem, 0, A); }));
         }
-        for (int rpw : {4, 8, 16, 32, 64}) {
-            DfxDfrArgs R;
-            R.spec = spec_p; R.coefs = coefs; R.gains = gains; R.bin2band = d_b2b; R.out = out_p;
-            R.B = B; R.T = T; R.cs_b = (int64_t)O * T * nd; R.cs_n = T * nd; R.cs_t = nd;
-            R.gT = T; R.out_T = T; R.out_toff = 0; R.Fs = Fs; R.Fso = Fs; R.F = F; R.nbdf = nd; R.lookahead = la; R.nb = E;
-            R.pf_beta = 0.f; R.atten_lim = 0.f; R.t_begin = 0; R.t_end = T; R.rpw = rpw; R.chunks = (int)((T + rpw - 1) / rpw);
-            const unsigned nblk = (unsigned)(((B + 7) / 8) * 8 * ((R.chunks + 3) / 4));
-            char nm[96]; snprintf(nm, 96, "df_apply rows  rpw=%d  O=%d", rpw, O);
-            if (O == 5) report(nm, alg, time_it(20, [&] { hipLaunchKernelGGL((dfx_k_df_apply_rows<5, 4, false>), dim3(nblk), dim3(256), 0, 0, R); }));
-            else report(nm, alg, time_it(20, [&] { hipLaunchKernelGGL((dfx_k_df_apply_rows<10, 4, false>), dim3(nblk), dim3(256), 0, 0, R); }));
-            if (rpw == 16) {
-                R.gains = nullptr;
-                snprintf(nm, 96, "df_apply rows  rpw=%d  O=%d  no gains", rpw, O);
-                const double alg2 = alg - (double)E * 4 * B * T;
-                if (O == 5) report(nm, alg2, time_it(20, [&] { hipLaunchKernelGGL((dfx_k_df_apply_rows<5, 4, false>), dim3(nblk), dim3(256), 0, 0, R); }));
-                else report(nm, alg2, time_it(20, [&] { hipLaunchKernelGGL((dfx_k_df_apply_rows<10, 4, false>), dim3(nblk), dim3(256), 0, 0, R); }));
-                R.gains = gains; R.nbdf = 2;   // almost pure stream: the deep filter on one float4 column only
-                snprintf(nm, 96, "df_apply rows  rpw=%d  nb_df=2 (stream+gains)", rpw);
-                const double alg3 = (double)(F * 8 + 2 * O * 8 + E * 4 + F * 8) * B * T;
-                R.cs_b = (int64_t)O * T * 2; R.cs_n = T * 2; R.cs_t = 2;
-                if (O == 5) report(nm, alg3, time_it(20, [&] { hipLaunchKernelGGL((dfx_k_df_apply_rows<5, 4, false>), dim3(nblk), dim3(256), 0, 0, R); }));
+        for (int Fs : {482, 488, 496, 512}) {
+            float *sp = spec_p, *op = out_p;
+            if (Fs != 482) { CK(hipMalloc(&sp, B * T * Fs * 8)); CK(hipMalloc(&op, B * T * Fs * 8)); CK(hipMemset(sp, 0, B * T * Fs * 8)); }
+            for (int rpw : {1, 2, 3, 4, 6, 8}) {
+                DfxDfrArgs R;
+                R.spec = sp; R.coefs = coefs; R.gains = gains; R.bin2band = d_b2b; R.out = op;
+                R.B = B; R.T = T; R.cs_b = (int64_t)O * T * nd; R.cs_n = T * nd; R.cs_t = nd;
+                R.gT = T; R.out_T = T; R.out_toff = 0; R.Fs = Fs; R.Fso = Fs; R.F = F; R.nbdf = nd; R.lookahead = la; R.nb = E;
+                R.pf_beta = 0.f; R.atten_lim = 0.f; R.t_begin = 0; R.t_end = T; R.rpw = rpw; R.chunks = (int)((T + rpw - 1) / rpw);
+                R.zcols = Fs == 482 ? 241 : 244;
+                R.items = ((B + 7) / 8) * 8 * ((R.chunks + 3) / 4);
+                const unsigned nblk = (unsigned)R.items;
+                const double bytes = Fs == 496 ? alg + (double)2 * 56 * B * T : alg;   // + the 7 pad bins read and written per row
+                char nm[96];
+#define RUN(O_, NT_) do { snprintf(nm, 96, "df_apply rows Fs=%d rpw=%d O=%d nt=%d", Fs, rpw, O_, NT_); \
+                    report(nm, alg, time_it(20, [&] { hipLaunchKernelGGL((dfx_k_df_apply_rows<O_, 4, false, NT_>), dim3(nblk), dim3(256), 0, 0, R); })); } while (0)
+                (void)bytes;
+                if (O == 5) { RUN(5, 2); RUN(5, 3); RUN(5, 6); RUN(5, 7); } else { RUN(10, 3); RUN(10, 7); }
             }
+            if (Fs != 482) { CK(hipFree(sp)); CK(hipFree(op)); }
         }
     }
     return 0;

@@ -12,7 +12,7 @@ template <int MODE> __global__ void __launch_bounds__(256) k_stream(const float4
     float4 acc = {0, 0, 0, 0};
     int64_t bid = blockIdx.x, nb = gridDim.x;
     if (xmask) {
-        const int x = (int)(blockIdx.x & 7), pc = __builtin_popcount(xmask);
+        const int x = dfx_xcc_id(), pc = __builtin_popcount(xmask);
         if (!((xmask >> x) & 1)) return;
         bid = (int64_t)(blockIdx.x >> 3) * pc + __builtin_popcount(xmask & ((1 << x) - 1));
         nb = (int64_t)(gridDim.x >> 3) * pc;
@@ -54,6 +54,10 @@ int main(int argc, char **argv) {
     const bool gprod = argc > 6 && argv[6][0] == 'p';
     const int gmask = (argc > 6 && !gprod) ? (int)strtol(argv[6], nullptr, 16) : 0, smask = argc > 7 ? (int)strtol(argv[7], nullptr, 16) : 0;
     const int nfirst = argc > 8 ? atoi(argv[8]) : 1;
+    const bool stream_last = argc > 9 && atoi(argv[9]) == 1;
+    const int npend = argc > 10 ? atoi(argv[10]) : 0;   // streams that hold pending packets (blocked on an event recorded behind the recurrences)
+    std::vector<hipStream_t> pst(npend);
+    for (auto &q : pst) CK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));   // launch the stream kernel AFTER the recurrences (they then own their CUs first)
     for (int i = 0; i < NK; ++i) args[i].xcd_mask = gprod ? ((0xF << ((i * 4) % 8)) & 0xff) : gmask;
     printf("# recurrence XCD mask %s, stream mode %d XCD mask 0x%x\n", gprod ? "product" : (argc > 6 ? argv[6] : "0"), smode, smask);
     for (int n = nfirst; n <= NK; ++n) {
@@ -63,21 +67,39 @@ int main(int argc, char **argv) {
             hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
             CK(hipEventRecord(a, 0));
             std::vector<hipEvent_t> done(n);
-            if (smode >= 0) {
+            std::vector<hipEvent_t> kb(n), ke(n);
+            auto launch_stream = [&]() {
                 CK(hipStreamWaitEvent(ss, a, 0));
                 if (smode == 0) hipLaunchKernelGGL(k_stream<0>, dim3(sblocks), dim3(256), 0, ss, sin_, sout, NS, sreps, smask);
                 if (smode == 1) hipLaunchKernelGGL(k_stream<1>, dim3(sblocks), dim3(256), 0, ss, sin_, sout, NS, sreps, smask);
                 if (smode == 2) hipLaunchKernelGGL(k_stream<2>, dim3(sblocks), dim3(256), 0, ss, sin_, sout, NS, sreps, smask);
-            }
+            };
+            if (smode >= 0 && !stream_last) launch_stream();
             for (int i = 0; i < n; ++i) {
                 CK(hipStreamWaitEvent(st[i], a, 0));
+                CK(hipEventCreate(&kb[i])); CK(hipEventCreate(&ke[i])); CK(hipEventRecord(kb[i], st[i]));
                 const int pc = args[i].xcd_mask ? __builtin_popcount(args[i].xcd_mask) : 8;
                 const unsigned nblk = args[i].xcd_mask ? (unsigned)(((B + 15) / 16 + pc - 1) / pc * 8) : (unsigned)((B + 15) / 16);
                 hipLaunchKernelGGL(dfx_k_gru_rec_h3, dim3(nblk), dim3(DFX_GH_THREADS), DFX_GH_SMEM, st[i], args[i]);
+                CK(hipEventRecord(ke[i], st[i]));
                 CK(hipEventCreate(&done[i])); CK(hipEventRecord(done[i], st[i])); CK(hipStreamWaitEvent(0, done[i], 0));
             }
-            CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b)); CK(hipDeviceSynchronize());
+            if (smode >= 0 && stream_last) launch_stream();
+            CK(hipEventRecord(b, 0));
+            if (npend) {   // pending work on other queues: waits for b, i.e. for everything timed here
+                hipEvent_t pe; CK(hipEventCreateWithFlags(&pe, hipEventDisableTiming));
+                for (int i = 0; i < npend; ++i) {
+                    CK(hipStreamWaitEvent(pst[i], b, 0));
+                    hipLaunchKernelGGL(k_stream<2>, dim3(8), dim3(256), 0, pst[i], sin_, sout, (int64_t)4096, 1, 0);
+                    CK(hipEventRecord(pe, pst[i])); CK(hipStreamWaitEvent(pst[(i + 1) % npend], pe, 0));
+                }
+            } CK(hipEventSynchronize(b)); CK(hipDeviceSynchronize());
             float ms; CK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
+            if (it == 2) {  // per-kernel spans (start offset from the common start event, duration)
+                printf("   kernel spans:");
+                for (int i = 0; i < n; ++i) { float o, d; CK(hipEventElapsedTime(&o, a, kb[i])); CK(hipEventElapsedTime(&d, kb[i], ke[i])); printf(" [+%.3f %.3f]", o, d); }
+                printf(" ms\n");
+            }
         }
         printf("%d concurrent gru_h3 kernels (16 blocks each), %lld steps: %.3f ms -> %.3f us/step\n", n, (long long)T, best, best * 1e3 / T);
     }
