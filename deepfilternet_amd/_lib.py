@@ -31,7 +31,7 @@ class ModelCfg(C.Structure):
         "sr", "fft_size", "hop_size", "nb_erb", "nb_df", "min_nb_freqs", "df_order", "df_lookahead", "lsnr_min",
         "lsnr_max", "conv_lookahead", "conv_ch", "emb_hidden_dim", "emb_num_layers", "df_hidden_dim", "df_num_layers",
         "df_gru_skip", "df_pathway_kernel_size_t", "lin_groups", "enc_lin_groups", "mask_pf")] + [
-        ("pf_beta", C.c_float), ("norm_alpha", C.c_float)]
+        ("pf_beta", C.c_float), ("norm_alpha", C.c_float)] + [(n, C.c_int32) for n in ("emb_gru_skip_enc", "emb_gru_skip", "enc_concat")]
 
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -81,6 +81,7 @@ SIGNATURES = {
     "dfx_model_load_file": (_i, [C.c_char_p, C.POINTER(_vp)]),
     "dfx_model_cfg_get": (_i, [_vp, C.POINTER(ModelCfg)]),
     "dfx_model_set_streams": (_i, [_vp, _i]),
+    "dfx_model_set_run_df": (_i, [_vp, _i]),
     "dfx_model_set_pipeline": (_i, [_vp, _i, _i, _i]),
     "dfx_model_check": (_i, [_vp]),
     "dfx_model_workspace_bytes": (_i, [_vp, _i64, _i64, C.POINTER(_i64)]),

@@ -138,7 +138,7 @@ class ModelParams:
                 val = default
             kw[attr] = cast(val)
         p = cls(**kw)
-        p.df_gru_skip = p.df_gru_skip.lower()
+        p.df_gru_skip = p.df_gru_skip.lower()   # deepfilternet3.py:303 lower-cases this option only
         return p
 
     @classmethod
@@ -200,9 +200,11 @@ class ModelParams:
         need(self.conv_depthwise and self.convt_depthwise, "non-depthwise convolutions")
         need(tuple(self.conv_kernel) == (1, 3) and tuple(self.convt_kernel) == (1, 3), "conv kernels other than (1,3)")
         need(tuple(self.conv_kernel_inp) == (3, 3), "conv_kernel_inp other than (3,3)")
-        need(self.emb_gru_skip_enc == "none" and self.emb_gru_skip == "none", "embedding GRU skip connections")
-        need(self.df_gru_skip in ("none", "identity", "groupedlinear"), f"df_gru_skip={self.df_gru_skip!r}")
-        need(not self.enc_concat, "enc_concat")
+        for opt in ("emb_gru_skip_enc", "emb_gru_skip", "df_gru_skip"):
+            need(getattr(self, opt) in ("none", "identity", "groupedlinear"), f"{opt}={getattr(self, opt)!r}")
+        # deepfilternet3.py:138-146: the concatenated embedding is twice as wide as the GRU's output; the reference's own assert /
+        # einsum shapes exclude both skip forms then
+        need(not (self.enc_concat and self.emb_gru_skip_enc != "none"), "enc_concat together with emb_gru_skip_enc (dimensions do not match)")
         need(self.df_n_iter == 1, "df_n_iter != 1")
         need(not self.lsnr_dropout, "lsnr_dropout")
         need(self.conv_ch % 16 == 0, "conv_ch must be a multiple of 16")
@@ -210,7 +212,7 @@ class ModelParams:
         need(self.nb_df % 2 == 0, "nb_df must be even")
         need(self.emb_hidden_dim == 256 and self.df_hidden_dim == 256, "GRU hidden size other than 256")
         need(self.conv_lookahead >= self.df_lookahead or self.conv_lookahead == 0, "conv_lookahead < df_lookahead")
-        need(self.pad_mode == "input", "pad_mode other than 'input'")
+        # pad_mode is a DfParams option that deepfilternet3.py never reads (only deepfilternet.py / deepfilternet2.py do): any value is fine
 
 
 def _fix_legacy_sections(parser: ConfigParser) -> None:

@@ -10,7 +10,7 @@
 // "DFXM" | u32 version | u32 sizeof(dfx_model_cfg) | dfx_model_cfg | i64 n_floats | float32[n_floats]   (little endian)
 // The floats are the raw reference state-dict tensors packed per dfx_model_tensor_info — what dfx_model_create takes.
 static const char DFX_FILE_MAGIC[4] = {'D', 'F', 'X', 'M'};
-static const uint32_t DFX_FILE_VERSION = 1;
+static const uint32_t DFX_FILE_VERSION = 2;  // 2: dfx_model_cfg grew emb_gru_skip_enc / emb_gru_skip / enc_concat
 
 extern "C" int dfx_model_save_file(const dfx_model_cfg *cfg, const float *blob_host, const char *path) {
     if (!cfg || !blob_host || !path) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_save_file: null argument");
@@ -93,7 +93,9 @@ extern "C" DFState *df_create(const char *path, float atten_lim, const char *log
     bool ok = dfx_model_load_file(path, &s->model) == DFX_OK && dfx_model_cfg_get(s->model, &c) == DFX_OK &&
               dfx_state_create(c.sr, c.fft_size, c.hop_size, c.nb_erb, c.min_nb_freqs, &s->st) == DFX_OK &&
               dfx_stream_create(s->model, s->st, 1, 1, &s->rt) == DFX_OK &&
-              dfx_stream_set_gating(s->rt, 1) == DFX_OK &&  // RuntimeParams::default_with_ch(1): thresholds -10 / 30 / 20 dB
+              dfx_stream_set_gating(s->rt, 1) == DFX_OK &&
+              // capi.rs:27-34: with_thresholds(-15, 35, 35), with_post_filter(0), with_mask_reduce(ReduceMask::MAX)
+              dfx_stream_set_thresholds(s->rt, -15.f, 35.f, 35.f) == DFX_OK && dfx_stream_set_channels(s->rt, 1, 1) == DFX_OK &&
               dfx_stream_set_post_filter_beta(s->rt, 0.f) == DFX_OK && dfx_stream_set_atten_lim(s->rt, atten_lim) == DFX_OK;
     if (ok) {
         s->hop = c.hop_size;

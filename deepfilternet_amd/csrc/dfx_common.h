@@ -103,4 +103,5 @@ int dfx_launch_norm_scan(const float *erb_in, float *erb_out, int E, const float
 int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, const float *gains, const dfx_bands *bands, int64_t B,
                         int64_t T, int F, int nb_df, int order, int lookahead, float pf_beta, float atten_lim, float *out, hipStream_t s,
                         int64_t t_begin = 0, int64_t t_end = -1, int64_t coef_T = -1, int64_t out_T = -1, int64_t out_toff = 0,
-                        int64_t spec_stride = 0, int64_t out_stride = 0);
+                        int64_t spec_stride = 0, int64_t out_stride = 0,
+                        int pf_rs_channels = 0);  // > 0: the real-time runtime's post filter (lib.rs:446-471) over frames of that many rows

@@ -504,7 +504,7 @@ static int launch_dfa_rows(const DfxDfrArgs &A, int order, unsigned grid, hipStr
 int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, const float *gains,
                         const dfx_bands *bands, int64_t B, int64_t T, int F, int nb_df, int order, int lookahead,
                         float pf_beta, float atten_lim, float *out, hipStream_t s, int64_t t_begin, int64_t t_end, int64_t coef_T,
-                        int64_t out_T, int64_t out_toff, int64_t spec_stride, int64_t out_stride) {
+                        int64_t out_T, int64_t out_toff, int64_t spec_stride, int64_t out_stride, int pf_rs_channels) {
     if (spec_stride <= 0) spec_stride = F;
     if (out_stride <= 0) out_stride = F;
     if (t_end < 0) t_end = T;
@@ -515,7 +515,7 @@ int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, 
         static const int force_flat = [] { const char *e = getenv("DFX_DFA_FLAT"); return e && e[0] == '1' ? 1 : 0; }();
         const bool rows_ok = spec_stride % 2 == 0 && out_stride % 2 == 0 && coef_layout != DFX_COEF_BTFO && nd % 2 == 0 && nd / 2 <= 64 &&
                              nbands <= 64 && O <= 16 && !((uintptr_t)spec & 15) && !((uintptr_t)out & 15) && !((uintptr_t)coefs & 15) &&
-                             !(force_flat && spec_stride == F && out_stride == F);
+                             !(force_flat && spec_stride == F && out_stride == F) && !(pf_rs_channels > 0 && spec_stride == F && out_stride == F);
         if (rows_ok) {
             DfxDfrArgs R;
             R.spec = spec;
@@ -593,6 +593,7 @@ int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, 
     A.out_toff = out_toff;
     A.pf_beta = pf_beta;
     A.atten_lim = atten_lim;
+    A.pf_ch = pf_rs_channels > 0 ? pf_rs_channels : 0;
     static int rows_sel = 0;
     if (!rows_sel) {
         const char *e = getenv("DFX_DFA_ROWS");

@@ -656,7 +656,24 @@ struct DfxDfaArgs {
     int t_begin, t_end;   // frames [t_begin, t_end) of every clip are produced by this launch
     int64_t gT;           // frames per clip of the gains array (== T except for streaming windows, whose spec carries extra lookahead frames)
     int64_t out_T, out_toff;  // frame t of clip b is stored at out[(b*out_T + t - out_toff)*F ...]  (== T, 0 unless compacted)
+    // post filter of the real-time runtime (DfTract::process -> lib.rs:446-471): pf_ch > 0 selects the Rust arithmetic and its
+    // chunks_exact(4) walk over the frame's [pf_ch * F] bins (the pf_ch rows of a stream are consecutive clips): the last
+    // (pf_ch * F) % 4 bins of the flattened frame are NOT filtered (mono, F = 481: bin 480).  0: deepfilternet3.py:448-454.
+    int pf_ch = 0;
 };
+
+// lib.rs:446-471 post_filter, one bin: g = min(|e| / (|n| + eps), 1).max(eps); g_sin = g * sin(g * pi / 2);
+// pf = (beta_p1 * g / (1 + beta * (g / g_sin)^2)) / g   — the reference's own order of operations, no clamp on the sine
+static __device__ __forceinline__ float2 dfx_dfa_post_filter_rs(float2 y, float2 x, float beta) {
+#pragma clang fp contract(off)
+    const float eps = 1e-12f, pi = 3.14159265358979323846f, beta_p1 = beta + 1.f;
+    float g = hypotf(y.x, y.y) / (hypotf(x.x, x.y) + eps);
+    g = fmaxf(fminf(g, 1.f), eps);
+    const float g_sin = g * sinf(g * pi / 2.0f);
+    const float q = g / g_sin;
+    const float pf = (beta_p1 * g / (1.f + beta * (q * q))) / g;
+    return make_float2(y.x * pf, y.y * pf);
+}
 
 static __device__ __forceinline__ float2 dfx_dfa_finish(float2 y, float2 x, float pf_beta, float lim) {
     if (pf_beta > 0.f) {
@@ -682,7 +699,7 @@ static __device__ __forceinline__ float2 dfx_dfa_finish(float2 y, float2 x, floa
 // t0-toff .. of this chunk staged in LDS (zeros outside the clip); gs / b2b: the chunk's gains and the bin->band map in LDS.
 static __device__ __forceinline__ float2 dfx_dfa_bin(const DfxDfaArgs &A, const float2 *xs, const float *gs,
                                                      const unsigned char *b2b, const float2 *coef_b, int t0, int t, int f,
-                                                     float2 x) {
+                                                     float2 x, int ch_off = 0) {
     float2 y;
     if (f < A.nbdf) {
         float re = 0.f, im = 0.f;
@@ -701,6 +718,10 @@ static __device__ __forceinline__ float2 dfx_dfa_bin(const DfxDfaArgs &A, const 
     } else {
         y = x;
     }
+    if (A.pf_ch > 0) {   // the runtime's post filter: Rust arithmetic, the tail of the flattened [pf_ch * F] frame left alone
+        if (A.pf_beta > 0.f && ch_off + f < ((A.pf_ch * A.F) & ~3)) y = dfx_dfa_post_filter_rs(y, x, A.pf_beta);
+        return dfx_dfa_finish(y, x, 0.f, A.atten_lim);
+    }
     return dfx_dfa_finish(y, x, A.pf_beta, A.atten_lim);
 }
 
@@ -715,6 +736,7 @@ __global__ void __launch_bounds__(DFX_DFA_THREADS) dfx_k_df_apply(DfxDfaArgs A) 
     const int64_t b = (j / A.chunks) * 8 + xcd;
     if (b >= A.B) return;
     const int F = A.F, nd = A.nbdf;
+    const int ch_off = A.pf_ch > 0 ? (int)(b % A.pf_ch) * F : 0;   // position of this row's bin 0 in its stream's flattened frame
     const int t0 = A.t_begin + chunk * ROWS;
     const int nt = (A.t_end - t0) < ROWS ? (A.t_end - t0) : ROWS;
     const int halo = ROWS + A.order - 1;
@@ -754,12 +776,12 @@ __global__ void __launch_bounds__(DFX_DFA_THREADS) dfx_k_df_apply(DfxDfaArgs A) 
     for (int e = e0 + tid; e < a0; e += DFX_DFA_THREADS) {
         const int t = e / F, f = e - t * F;
         const float2 x = (f < nd) ? xs[(t - t0 + toff) * nd + f] : spec_b[e];
-        out_b[e] = dfx_dfa_bin(A, xs, gs, b2b, coef_b, t0, t, f, x);
+        out_b[e] = dfx_dfa_bin(A, xs, gs, b2b, coef_b, t0, t, f, x, ch_off);
     }
     for (int e = a1 + tid; e < e1; e += DFX_DFA_THREADS) {
         const int t = e / F, f = e - t * F;
         const float2 x = (f < nd) ? xs[(t - t0 + toff) * nd + f] : spec_b[e];
-        out_b[e] = dfx_dfa_bin(A, xs, gs, b2b, coef_b, t0, t, f, x);
+        out_b[e] = dfx_dfa_bin(A, xs, gs, b2b, coef_b, t0, t, f, x, ch_off);
     }
     const float4 *x4 = reinterpret_cast<const float4 *>(spec_b + a0);
     float4 *y4 = reinterpret_cast<float4 *>(out_b + a0);
@@ -793,8 +815,8 @@ __global__ void __launch_bounds__(DFX_DFA_THREADS) dfx_k_df_apply(DfxDfaArgs A) 
                 const float2 xa = xs[(tt[u] - t0 + toff) * nd + ff[u]], xb = xs[(tt[u] - t0 + toff) * nd + ff2[u]];
                 xv[u] = make_float4(xa.x, xa.y, xb.x, xb.y);
             }
-            const float2 ya = dfx_dfa_bin(A, xs, gs, b2b, coef_b, t0, tt[u], ff[u], make_float2(xv[u].x, xv[u].y));
-            const float2 yb = dfx_dfa_bin(A, xs, gs, b2b, coef_b, t0, tt2[u], ff2[u], make_float2(xv[u].z, xv[u].w));
+            const float2 ya = dfx_dfa_bin(A, xs, gs, b2b, coef_b, t0, tt[u], ff[u], make_float2(xv[u].x, xv[u].y), ch_off);
+            const float2 yb = dfx_dfa_bin(A, xs, gs, b2b, coef_b, t0, tt2[u], ff2[u], make_float2(xv[u].z, xv[u].w), ch_off);
             y4[u ? i2 : i] = make_float4(ya.x, ya.y, yb.x, yb.y);
         }
     }

@@ -86,13 +86,15 @@ static inline DfxManifest dfx_build_manifest(const dfx_model_cfg &c) {
     dfx_manifest_conv(m, "enc.df_conv0", 2, C, 3, 3, false);
     dfx_manifest_conv(m, "enc.df_conv1", C, C, 1, 3, false);
     glin("enc.df_fc_emb.0.weight", C * Fd / 2, emb, c.enc_lin_groups);
-    glin("enc.emb_gru.linear_in.0.weight", emb, H, c.lin_groups);
+    glin("enc.emb_gru.linear_in.0.weight", c.enc_concat ? 2 * emb : emb, H, c.lin_groups);
     dfx_manifest_gru(m, "enc.emb_gru.gru", H, 1);
+    if (c.emb_gru_skip_enc == DFX_SKIP_GROUPEDLINEAR) glin("enc.emb_gru.gru_skip.weight", emb, emb, c.lin_groups);
     glin("enc.emb_gru.linear_out.0.weight", H, emb, c.lin_groups);
     m.add("enc.lsnr_fc.0.weight", {1, emb});
     m.add("enc.lsnr_fc.0.bias", {1});
     glin("erb_dec.emb_gru.linear_in.0.weight", emb, H, c.lin_groups);
     dfx_manifest_gru(m, "erb_dec.emb_gru.gru", H, c.emb_num_layers - 1);
+    if (c.emb_gru_skip == DFX_SKIP_GROUPEDLINEAR) glin("erb_dec.emb_gru.gru_skip.weight", emb, emb, c.lin_groups);
     glin("erb_dec.emb_gru.linear_out.0.weight", H, emb, c.lin_groups);
     dfx_manifest_conv(m, "erb_dec.conv3p", C, C, 1, 1, false);
     dfx_manifest_conv(m, "erb_dec.convt3", C, C, 1, 3, false);

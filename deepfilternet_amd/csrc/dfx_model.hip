@@ -29,6 +29,14 @@ static int check_cfg(const dfx_model_cfg *c) {
     if ((c->conv_ch / G) % 4 || (2 * c->df_order / G) > 16) DFX_FAIL(DFX_ERR_UNSUPPORTED, "df_convp group shape unsupported");
     if (c->df_gru_skip == DFX_SKIP_IDENTITY && emb != 256) DFX_FAIL(DFX_ERR_INVALID_ARG, "df_gru_skip=identity needs emb_dim == 256");
     if (c->df_gru_skip < 0 || c->df_gru_skip > 2) DFX_FAIL(DFX_ERR_INVALID_ARG, "bad df_gru_skip");
+    if (c->emb_gru_skip_enc < 0 || c->emb_gru_skip_enc > 2 || c->emb_gru_skip < 0 || c->emb_gru_skip > 2 || (c->enc_concat & ~1))
+        DFX_FAIL(DFX_ERR_INVALID_ARG, "bad emb_gru_skip_enc / emb_gru_skip / enc_concat");
+    // deepfilternet3.py:138-146: with enc_concat the encoder GRU's input is twice as wide as its output; identity then fails the
+    // reference's own assert and the grouped-linear skip (built for emb_out_dim inputs) cannot take it either
+    if (c->enc_concat && c->emb_gru_skip_enc != DFX_SKIP_NONE) DFX_FAIL(DFX_ERR_INVALID_ARG, "enc_concat excludes emb_gru_skip_enc (dimensions do not match)");
+    if (!div_ok(2 * emb, 256, c->lin_groups) && c->enc_concat) DFX_FAIL(DFX_ERR_UNSUPPORTED, "linear_groups does not tile the concatenated embedding");
+    if ((c->emb_gru_skip_enc == DFX_SKIP_GROUPEDLINEAR || c->emb_gru_skip == DFX_SKIP_GROUPEDLINEAR) && !div_ok(emb, emb, c->lin_groups))
+        DFX_FAIL(DFX_ERR_UNSUPPORTED, "linear_groups does not tile the embedding skip into multiples of 4");
     return DFX_OK;
 }
 
@@ -214,6 +222,14 @@ __global__ void dfx_k_mask_reduce(float *mask, int64_t B, int64_t T, int64_t t_b
     }
 }
 
+// The stage decisions as dfx_stream_process_raw reports them: DFX_GATE_GAINS and DFX_GATE_ZEROS both mean "gains exist".
+__global__ void dfx_k_gate_stages(const unsigned char *flags, unsigned char *stages, int64_t B) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const unsigned char f = flags[b];
+    stages[b] = (unsigned char)((f & DFX_GATE_DF) | ((f & (DFX_GATE_GAINS | DFX_GATE_ZEROS)) ? DFX_GATE_GAINS : 0));
+}
+
 // State selection after a gated pass: entry e copies row b of src to dst when (flags[b] & mask) == want.  Frozen streams get all
 // their state back (STFT memories, running means, history rings, hidden states), a stream whose stage 1 / stage 2 was skipped its
 // decoder's hidden states.
@@ -281,7 +297,7 @@ struct dfx_model {
     PwW erb1, erb2, erb3, dfc0, dfc1, ct3, ct2, ct1;
     size_t co_w = 0, co_ska = 0, co_skb = 0;
     float co_bias = 0.f;
-    GlinW fc_emb, enc_in, enc_out, dec_in, dec_out, dfg_in, df_skip, df_out;
+    GlinW fc_emb, enc_in, enc_out, dec_in, dec_out, dfg_in, df_skip, df_out, enc_skip, dec_skip;
     std::vector<GruW> enc_gru, dec_gru, df_gru;
     size_t lsnr_w = 0;
     float lsnr_b = 0.f;
@@ -302,6 +318,7 @@ struct dfx_model {
     int max_chunks = 1;       // batch chunks pipelined by dfx_enhance (DFX_CHUNKS; measured: no gain over time-chunk pipelining)
     int tchunks = 12;         // time chunks of the layer-pipelined GRU phase (DFX_TCHUNKS)
     int tchunk_min = 32;      // shortest chunk worth a launch (frames)
+    bool run_df = true;       // DfNet(run_df=False): mask only (dfx_model_set_run_df)
     bool exact_fp32 = false;  // DFX_EXACT_FP32=1: keep the dense contractions on the exact fp32 MFMA path
     // df_conv0's output c0 is recomputed by its consumers instead of being stored when the pathway conv has the sliding-window kernel
     // (kt <= 5); DFX_FUSE_C0=0 restores the materialised c0 (dfx_k_conv_in_df -> dfx_k_pwconv / dfx_k_df_convp2).
@@ -594,6 +611,8 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
     }
     ok = ok && prep_glin(P, "enc.df_fc_emb.0.weight", m->fc_emb) && prep_glin(P, "enc.emb_gru.linear_in.0.weight", m->enc_in) &&
          prep_gru(P, "enc.emb_gru.gru", 1, m->enc_gru) && prep_glin(P, "enc.emb_gru.linear_out.0.weight", m->enc_out);
+    if (ok && c.emb_gru_skip_enc == DFX_SKIP_GROUPEDLINEAR) ok = prep_glin(P, "enc.emb_gru.gru_skip.weight", m->enc_skip);
+    if (ok && c.emb_gru_skip == DFX_SKIP_GROUPEDLINEAR) ok = prep_glin(P, "erb_dec.emb_gru.gru_skip.weight", m->dec_skip);
     if (ok) {
         const float *w = P.get("enc.lsnr_fc.0.weight"), *b = P.get("enc.lsnr_fc.0.bias");
         ok = w && b;
@@ -788,6 +807,11 @@ extern "C" int dfx_model_set_streams(dfx_model *m, int enable) {
     m->concurrent = enable != 0 && m->have_streams;
     return DFX_OK;
 }
+extern "C" int dfx_model_set_run_df(dfx_model *m, int enable) {
+    if (!m) DFX_FAIL(DFX_ERR_INVALID_ARG, "null");
+    m->run_df = enable != 0;
+    return DFX_OK;
+}
 extern "C" int dfx_model_set_pipeline(dfx_model *m, int time_chunks, int min_chunk_frames, int batch_chunks) {
     if (!m || time_chunks < 1 || min_chunk_frames < 1 || batch_chunks < 1) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_set_pipeline: bad arguments");
     m->tchunks = time_chunks < DFX_MAX_TCHUNKS ? time_chunks : DFX_MAX_TCHUNKS;
@@ -799,12 +823,13 @@ extern "C" int dfx_model_set_pipeline(dfx_model *m, int time_chunks, int min_chu
 }
 extern "C" int dfx_model_check(const dfx_model *m) {
     if (!m) DFX_FAIL(DFX_ERR_INVALID_ARG, "null");
-    unsigned int e = 0;
-    DFX_HIP(hipMemcpy(&e, m->d_err, sizeof(e), hipMemcpyDeviceToHost));  // synchronises with the device
-    if (e) {
-        (void)hipMemset(m->d_err, 0, sizeof(e));
-        DFX_FAIL(DFX_ERR_HIP, "dfx: a workgroup pair of the two-CU GRU kernel timed out waiting for its partner; the last results are invalid");
-    }
+    unsigned int e[2] = {0, 0};
+    DFX_HIP(hipMemcpy(e, m->d_err, sizeof(e), hipMemcpyDeviceToHost));  // synchronises with the device
+    if (e[0] || e[1]) (void)hipMemset(m->d_err, 0, sizeof(e));
+    if (e[0]) DFX_FAIL(DFX_ERR_HIP, "dfx: a workgroup pair of the two-CU GRU kernel timed out waiting for its partner; the last results are invalid");
+    if (e[1])
+        DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx: an activation of magnitude >= 6e4 reached an fp16-split matrix kernel (df_conv0 / df_conv1 / df_convp "
+                                      "path); the last results are invalid.  DFX_EXACT_FP32=1 selects the exact fp32 kernels");
     return DFX_OK;
 }
 extern "C" int dfx_model_cfg_get(const dfx_model *m, dfx_model_cfg *out) {
@@ -817,7 +842,7 @@ extern "C" int dfx_model_cfg_get(const dfx_model *m, dfx_model_cfg *out) {
 namespace {
 struct Ws {
     // offsets in floats, each 64-float (256 B) aligned
-    size_t e0, e1, e2, e3, c0, c1, emb_in, emb, xa, xb, gi, xa2, xb2, gi2, demb, d3, d2, d1, mask, c0p, xdf, coefs, lsnr, total;
+    size_t e0, e1, e2, e3, c0, c1, emb_in, emb, xa, xb, gi, xa2, xb2, gi2, demb, d3, d2, d1, mask, c0p, xdf, coefs, lsnr, skp_e, skp_d, total;
     size_t pgi[DFX_MAX_GRU_LAYERS], py[DFX_MAX_GRU_LAYERS], ph[DFX_MAX_GRU_LAYERS];  // layer-pipelined GRU phase: gi, y, h state per layer
     size_t pxb, pxb_floats;   // h exchange buffers of the two-CU GRU kernel: [layer][group][2][2][16][128] granules of 8 bytes
 };
@@ -836,7 +861,7 @@ Ws plan_ws(const dfx_model_cfg &c, bool fuse_c0, int64_t R, int64_t B = 0) {
     w.e3 = take(R * (E / 4) * C);
     w.c0 = fuse_c0 ? 0 : take(R * Fd * C);  // only materialised by the unfused DF-encoder path
     w.c1 = take(R * (Fd / 2) * C);
-    w.emb_in = take(R * emb);
+    w.emb_in = take(R * emb * (c.enc_concat ? 2 : 1));
     w.emb = take(R * emb);
     w.xa = take(R * 256);
     w.xb = take(R * 256);
@@ -853,6 +878,8 @@ Ws plan_ws(const dfx_model_cfg &c, bool fuse_c0, int64_t R, int64_t B = 0) {
     w.xdf = take(R * 256);
     w.coefs = take(R * Fd * NO);
     w.lsnr = take(R);
+    w.skp_e = take(c.emb_gru_skip_enc == DFX_SKIP_GROUPEDLINEAR ? R * emb : 0);   // grouped-linear skips around the embedding GRUs
+    w.skp_d = take(c.emb_gru_skip == DFX_SKIP_GROUPEDLINEAR ? R * emb : 0);
     const int nlayers = 1 + (c.emb_num_layers - 1) + c.df_num_layers;
     for (int l = 0; l < DFX_MAX_GRU_LAYERS; ++l) {
         const bool used = l < nlayers;
@@ -972,6 +999,7 @@ static int launch_convp_h3(const dfx_model *m, const float *feat_spec, float *ou
         A.t_zero = t_zero;
         A.unscale0 = m->c0_unscale;
         A.unscale = m->cp_unscale;
+        A.err = m->d_err;
         A.nfb = (Fd + 15) / 16;
         const int64_t want = (int64_t)dfx_env_num_cus() * 4 * 4;  // two resident waves per SIMD, two rounds
         int64_t nseg = dfx_ceil_div(want, B * A.nfb);
@@ -1014,6 +1042,7 @@ static int launch_conv01_h3(const dfx_model *m, const PwW &w, const float *feat_
         A.t_begin = t_begin;
         A.unscale0 = m->c0_unscale;
         A.unscale = m->dfc1_unscale;
+        A.err = m->d_err;
         const int grid = nn_grid(dfx_ceil_div(B * (T - t_begin) * Fout, 64), 3);
         DfxKScope ks(DFX_K_PWCONV, s);
         dfx_launch(dfx_k_df_conv01_h3<C>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
@@ -1281,6 +1310,9 @@ static int run_gru_stack(const dfx_model *m, const std::vector<GruW> &layers, co
     return DFX_OK;
 }
 
+static int stream_copy_rows(const float *src, int64_t src_stride, int64_t src_len, int64_t src_off, float *dst, int64_t dst_stride,
+                            int64_t dst_len, int64_t B, hipStream_t s);
+
 template <int C>
 static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float *spec, const float *feat_erb,
                         const float *feat_spec, int64_t B, int64_t T, float atten_lim, float *spec_e, float *mask_out,
@@ -1306,7 +1338,28 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     float *coefs = coefs_out ? coefs_out : ws + w.coefs;
     float *lsnr = lsnr_out ? lsnr_out : ws + w.lsnr;
     float *xa2 = ws + w.xa2, *xb2 = ws + w.xb2, *gi2 = ws + w.gi2;
+    float *skp_e = ws + w.skp_e, *skp_d = ws + w.skp_d;
     int rc;
+    const bool run_df = m->run_df;
+    // SqueezedGRU_S (modules.py:702-738): x = linear_out(gru(linear_in(in))) [+ gru_skip(in)]; the skip joins after linear_out's ReLU
+    auto enc_out_skip = [&](const float *y, int64_t M, hipStream_t st, DfxRowMap rm) -> int {   // deepfilternet3.py:138-158
+        const float *res = nullptr;
+        if (c.emb_gru_skip_enc == DFX_SKIP_IDENTITY) res = emb_in;
+        else if (c.emb_gru_skip_enc == DFX_SKIP_GROUPEDLINEAR) {
+            if (int r = launch_glin(m, m->enc_skip, emb_in, DFX_ACT_NONE, nullptr, skp_e, M, st, rm)) return r;
+            res = skp_e;
+        }
+        return launch_glin(m, m->enc_out, y, DFX_ACT_RELU, res, embv, M, st, rm);
+    };
+    auto dec_out_skip = [&](const float *y, int64_t M, hipStream_t st, DfxRowMap rm) -> int {   // deepfilternet3.py:198-216
+        const float *res = nullptr;
+        if (c.emb_gru_skip == DFX_SKIP_IDENTITY) res = embv;
+        else if (c.emb_gru_skip == DFX_SKIP_GROUPEDLINEAR) {
+            if (int r = launch_glin(m, m->dec_skip, embv, DFX_ACT_NONE, nullptr, skp_d, M, st, rm)) return r;
+            res = skp_d;
+        }
+        return launch_glin(m, m->dec_out, y, DFX_ACT_RELU, res, demb, M, st, rm);
+    };
     // Stream plan (s = caller's stream, x1/x2 = auxiliary; all joins are events, the host never blocks):
     //   s : e0..e3 ----------------(join c1)-- fc_emb, enc GRU, emb, lsnr --+-- ERB decoder: GRU stack, convt3..conv0_out --(join coefs)-- df_apply
     //   x1: c0 -+- c1 ------------------------------------------------------+-- DF decoder: GRU stack, skip, (join c0p) df_out -> coefs
@@ -1435,7 +1488,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     // the pathway conv only has to finish before df_out: it starts right away on the low-priority stream x2 and fills whatever the
     // encoder kernels leave idle (DFX_CONVP_EARLY=0: released only after the front has been enqueued)
     if (m->convp_after_c1 && (rc = wait(EV_C1, x2))) return rc;
-    if (!m->convp_late && (rc = run_convp())) return rc;
+    if (run_df && !m->convp_late && (rc = run_convp())) return rc;
     // ---- Encoder, ERB branch on s (:168-171)
     const bool fuse_dec = E % 2 == 0 && m->fuse_erb && 2 * DFX_DEC10_SMEM(C, E) <= (size_t)160 * 1024;
     const bool fuse_enc = E % 2 == 0 && 3 * (E + 2) <= 192 && m->fuse_erb && 2 * DFX_ENC_SMEM(C, E) <= (size_t)160 * 1024;
@@ -1456,13 +1509,18 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb3, e2, nullptr, e3, Rn, E / 4, E / 4, 1, s, rmw))) return rc;
     if ((rc = wait(EV_C1, s))) return rc;
     // cemb = relu(df_fc_emb(c1.flatten)); emb_in = e3.flatten + cemb   (:179-182)
-    if ((rc = launch_glin(m, m->fc_emb, c1, DFX_ACT_RELU, e3, emb_in, Rn, s, rmw))) return rc;
+    if (c.enc_concat) {  // emb = cat(e3.flatten, cemb) (deepfilternet3.py:132-134,181): e3 rows into the left half, cemb written into the right half
+        if ((rc = stream_copy_rows(e3, emb, emb, 0, emb_in, 2 * emb, emb, R, s))) return rc;
+        if ((rc = launch_ggemm(c1, m->fc_emb.G * m->fc_emb.Kg, m->p(m->fc_emb.w), m->fc_emb.G, m->fc_emb.Kg, m->fc_emb.Ng, nullptr, DFX_ACT_RELU,
+                               nullptr, emb_in + emb, 2 * emb, Rn, s, 0, 0, 1, rmw)))
+            return rc;
+    } else if ((rc = launch_glin(m, m->fc_emb, c1, DFX_ACT_RELU, e3, emb_in, Rn, s, rmw))) return rc;
     // enc.emb_gru (SqueezedGRU_S :149-158)
     if ((rc = launch_glin(m, m->enc_in, emb_in, DFX_ACT_RELU, nullptr, xa, Rn, s, rmw))) return rc;
     // the chip-filling front of this chunk is enqueued: the next chunk of a pipelined dfx_enhance may start its own front
     // (it then overlaps this chunk's GRU chain, which occupies only a few CUs)
     if (signal_front && (rc = signal(EV_FRONT, s))) return rc;
-    if (m->convp_late) {
+    if (run_df && m->convp_late) {
         if ((rc = signal(EV_LSNR, s)) || (rc = wait(EV_LSNR, x2)) || (rc = run_convp())) return rc;
     }
     // ---- GRU phase.  Layer-pipelined over time chunks when the fp16-split kernels are in use: every GRU layer has its own
@@ -1471,14 +1529,14 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     // CUs; the per-chunk projections and grouped linears address their rows through a DfxRowMap.
     int K = m->tchunks;
     if (T / K < m->tchunk_min) K = (int)(T / m->tchunk_min);
-    const int nenc = (int)m->enc_gru.size(), ndec = (int)m->dec_gru.size(), ndf = (int)m->df_gru.size();
+    const int nenc = (int)m->enc_gru.size(), ndec = (int)m->dec_gru.size(), ndf = run_df ? (int)m->df_gru.size() : 0;
     const bool pipe = par && !sc && !m->exact_fp32 && K > 1 && nenc == 1 && 1 + ndec + ndf <= DFX_MAX_GRU_LAYERS && ln == &m->lanes[0];
     float *hs_enc = sc ? sc->h_state : nullptr, *hs_dec = sc ? sc->h_state + (int64_t)nenc * B * 256 : nullptr;
     float *hs_df = sc ? sc->h_state + (int64_t)(nenc + ndec) * B * 256 : nullptr;
     if (!pipe) {
         const float *y = nullptr;
         if ((rc = run_gru_stack(m, m->enc_gru, xa, xa, xb, gi, B, T, &y, s, hs_enc, t_begin, rmw))) return rc;
-        if ((rc = launch_glin(m, m->enc_out, y, DFX_ACT_RELU, nullptr, embv, Rn, s, rmw))) return rc;
+        if ((rc = enc_out_skip(y, Rn, s, rmw))) return rc;
         if ((rc = signal(EV_EMB, s)) || (rc = wait(EV_EMB, x1))) return rc;
         {
             DfxKScope ks(DFX_K_LSNR, s);
@@ -1492,7 +1550,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             DFX_LAUNCH_CHECK();
         }
         // ---- DfDecoder on x1 (:323-331)
-        {
+        if (run_df) {
             const float *y2 = nullptr;
             if ((rc = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, Rn, x1, rmw))) return rc;
             if ((rc = run_gru_stack(m, m->df_gru, xa2, xa2, xb2, gi2, B, T, &y2, x1, hs_df, t_begin, rmw))) return rc;
@@ -1519,7 +1577,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // ---- ErbDecoder on s (:245-254)
         if ((rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, xa, Rn, s, rmw))) return rc;
         if ((rc = run_gru_stack(m, m->dec_gru, xa, xa, xb, gi, B, T, &y, s, hs_dec, t_begin, rmw))) return rc;
-        if ((rc = launch_glin(m, m->dec_out, y, DFX_ACT_RELU, nullptr, demb, Rn, s, rmw))) return rc;
+        if ((rc = dec_out_skip(y, Rn, s, rmw))) return rc;
         if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, Rn, E / 4, E / 4, 1, s, rmw))) return rc;
         if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, Rn, E / 4, E / 2, 2, s, rmw))) return rc;
         if (fuse_dec) {
@@ -1594,7 +1652,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 if ((rc = ewait(ln->gev[l - 1][k], pst))) return rc;
                 const float *xin = ws + w.py[l - 1];
                 if (j == 0) {
-                    if ((rc = launch_glin(m, m->enc_out, ws + w.py[0], DFX_ACT_RELU, nullptr, embv, Mk(k), pst, rmk(k)))) return rc;
+                    if ((rc = enc_out_skip(ws + w.py[0], Mk(k), pst, rmk(k)))) return rc;
                     if ((rc = esig(ln->eev[k], pst))) return rc;  // emb chunk k exists (the DF stack waits for it)
                     if ((rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, xb, Mk(k), pst, rmk(k)))) return rc;
                     xin = xb;
@@ -1616,7 +1674,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 const DfxRowMap rm = rmk(k);
                 if ((rc = ewait(ln->gev[ndec][k], st))) return rc;
                 if (dev_skip & 1) { if ((rc = esig(ln->mev[k], st))) return rc; continue; }
-                if ((rc = launch_glin(m, m->dec_out, ws + w.py[ndec], DFX_ACT_RELU, nullptr, demb, Rk, st, rm))) return rc;
+                if ((rc = dec_out_skip(ws + w.py[ndec], Rk, st, rm))) return rc;
                 if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, Rk, E / 4, E / 4, 1, st, rm))) return rc;
                 if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, Rk, E / 4, E / 2, 2, st, rm))) return rc;
                 if (fuse_dec) {
@@ -1650,7 +1708,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 if ((rc = ewait(ln->pev[l][k], gst)) || (rc = gru_chunk(m->df_gru[j], l, k, gst)) || (rc = esig(ln->gev[l][k], gst))) return rc;
             }
         }
-        {   // DF tail: skip + df_out (+ c0p) per chunk (:324-330)
+        if (run_df) {   // DF tail: skip + df_out (+ c0p) per chunk (:324-330)
             hipStream_t st = ln->ts[1];
             const int l = ndec + ndf;
             if ((rc = wait(EV_C0P, st))) return rc;
@@ -1706,7 +1764,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 if (m->finish_tail > 0) k1 = (k0 == 0 && K - m->finish_tail > 0) ? K - m->finish_tail : K;
                 if (k1 > K) k1 = K;
                 if ((rc = ewait(ln->mev[k1 - 1], st)) || (rc = ewait(ln->cev[k1 - 1], st))) return rc;
-                if ((rc = dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead,
+                if ((rc = dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, run_df ? Fd : 0, O, c.df_lookahead,
                                               c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, st, tb(k0), tb(k1), -1, -1, 0, sstride, sstride)))
                     return rc;
                 if (fin && (rc = dfx_launch_synthesis(fin->st, spec_e, B, T, nullptr, nullptr, fin->y, fin->out_stride, fin->out_skip,
@@ -1724,7 +1782,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         fin_s = ln->ts[1];
         if ((rc = wait(EV_MASK, fin_s))) return rc;
     }
-    if (fin_s == s && (rc = wait(EV_COEFS, s))) return rc;
+    if (run_df && fin_s == s && (rc = wait(EV_COEFS, s))) return rc;
+    if (!run_df && coefs_out) DFX_HIP(hipMemsetAsync(coefs_out, 0, (size_t)R * Fd * NO * sizeof(float), fin_s));  // DfNet(run_df=False) has no coefficients
     // ---- Mask + MF.DF + combine + post filter + atten_lim (:426-454, enhance.py:238-240)
     if (sc) {  // spec has sc->spec_T frames per clip, coefficients / gains T; the n enhanced frames are stored compactly
         const float beta = sc->pf_beta >= 0.f ? sc->pf_beta : (c.mask_pf ? c.pf_beta : 0.f);
@@ -1738,8 +1797,10 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                        (const unsigned char *)bands->d_bin2band, B, T, E, Fd, O, O - 1 - c.df_lookahead);
             DFX_LAUNCH_CHECK();
         }
-        return dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, sc->spec_T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead, beta,
-                                   atten_lim, sc->out, s, t_begin, T, T, sc->out_T, sc->out_toff);
+        // the real-time runtime filters with libDF's own post_filter (lib.rs:446-471 via tract.rs:603-610): Rust arithmetic and its
+        // chunks_exact(4) walk over the stream's flattened [channels * F] frame
+        return dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, sc->spec_T, c.fft_size / 2 + 1, run_df ? Fd : 0, O, c.df_lookahead, beta,
+                                   atten_lim, sc->out, s, t_begin, T, T, sc->out_T, sc->out_toff, 0, 0, sc->channels > 0 ? sc->channels : 1);
     }
     {   // dev experiment: DFX_DEV_SPIN="<blocks>,<microseconds>" launches a spinning kernel in front of the deep filter
         static const char *sp = getenv("DFX_DEV_SPIN");
@@ -1757,7 +1818,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             dfx_launch(dfx_k_dev_spin, dim3((unsigned)blocks), dim3(64), 0, fin_s, (long long)us * 100);  // wall_clock64 ticks at 100 MHz
         }
     }
-    if ((rc = dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead,
+    if ((rc = dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, run_df ? Fd : 0, O, c.df_lookahead,
                                   c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, fin_s, 0, -1, -1, -1, 0, sstride, sstride)))
         return rc;
     if (fin && (rc = dfx_launch_synthesis(fin->st, spec_e, B, T, nullptr, nullptr, fin->y, fin->out_stride, fin->out_skip, fin->out_len,
@@ -1927,8 +1988,8 @@ extern "C" int dfx_stream_create(const dfx_model *m, const dfx_state *st, int64_
         DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_stream_create: the DF state does not match the model (fft/hop/nb_erb)");
     if (c.conv_lookahead != c.df_lookahead)
         DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_stream_create: conv_lookahead != df_lookahead is not supported by the streaming path");
-    if (!m->fuse_c0 || !m->fuse_erb || m->exact_fp32)
-        DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_stream_create: streaming needs the default (fused, fp16-split) engine configuration");
+    if (!m->fuse_c0 || !m->fuse_erb || m->exact_fp32 || !m->run_df)
+        DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_stream_create: streaming needs the default (fused, fp16-split, DF stage on) engine configuration");
     if (int rc = dfx_require_device()) return rc;
     dfx_stream_state *s = new dfx_stream_state();
     s->m = m;
@@ -2120,16 +2181,52 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     if (ys < 0) ys = n * hop;
     if (ls < 0) ls = n;
     int rc;
-    if (S->lim == 1.f) {  // tract.rs:540-543: the frame is passed through untouched (and undelayed), lsnr = 35; the state does not advance
+    const bool gated = S->gated && S->gate_buf;
+    if (gated && n != 1) DFX_FAIL(DFX_ERR_INVALID_ARG, "gated streaming passes carry one hop");
+    if (S->lim == 1.f) {
+        // tract.rs:509-543 with atten_lim == 1: the silent-input counter, the STFT analysis and the rolling spectra still advance (so
+        // that switching the limit back mid-stream continues from the right history); features, network and synthesis do not run, the
+        // hop is passed through undelayed with lsnr = 35 — unless the stream has been silent for more than 5 hops (zeros, -15).
+        unsigned char *gflags = gated ? S->gate_buf + S->g_flags : nullptr;
+        if (gated) {
+            dfx_launch(dfx_k_gate_pre, dim3((unsigned)dfx_ceil_div(B, 64)), dim3(64), 0, s, x, xs, (int)hop, B,
+                       reinterpret_cast<int *>(S->gate_buf + S->g_counter), gflags, S->channels);
+            DFX_LAUNCH_CHECK();
+        }
+        float *am_in = fp(S->ana_mem[S->flip]), *am_out = fp(S->ana_mem[S->flip ^ 1]);
+        float *new_spec = fp(S->new_spec);
+        if ((rc = dfx_launch_analysis(st, x, B, n * hop, xs, am_in, am_out, new_spec, nullptr, s))) return rc;
+        {
+            DfxKScope ks(DFX_K_COPY_ROWS, s);
+            dfx_launch(dfx_k_ring_step, dim3((unsigned)nn_grid(dfx_ceil_div(B * (Hs + n) * F * 2, 256), 16)), dim3(256), 0, s,
+                       (const float *)fp(S->hist_spec[S->flip]), (const float *)new_spec, fp(S->work_spec), fp(S->hist_spec[S->flip ^ 1]), B, Hs, n,
+                       F * 2, (int64_t)0);
+            DFX_LAUNCH_CHECK();
+        }
+        // what this path does not touch keeps its contents across the parity flip
+        DFX_HIP(hipMemcpyAsync(fp(S->syn_mem[S->flip ^ 1]), fp(S->syn_mem[S->flip]), (size_t)B * ML * 4, hipMemcpyDeviceToDevice, s));
+        DFX_HIP(hipMemcpyAsync(fp(S->hist_fe[S->flip ^ 1]), fp(S->hist_fe[S->flip]), (size_t)B * H * E * 4, hipMemcpyDeviceToDevice, s));
+        DFX_HIP(hipMemcpyAsync(fp(S->hist_fs[S->flip ^ 1]), fp(S->hist_fs[S->flip]), (size_t)B * H * Fd * 8, hipMemcpyDeviceToDevice, s));
         if ((rc = stream_copy_rows(x, xs, n * hop, 0, y, ys, n * hop, B, s))) return rc;
         if (lsnr_out) {
             dfx_launch(dfx_k_fill_rows, dim3((unsigned)nn_grid(dfx_ceil_div(B * n, 256), 16)), dim3(256), 0, s, lsnr_out, ls, n, B, 35.f);
             DFX_LAUNCH_CHECK();
         }
+        if (gated) {  // frozen streams: zeros / -15, and their analysis memory and rolling spectra stay where they were
+            DfxGateTable G;
+            G.n = 0;
+            const unsigned char FZ = DFX_GATE_FROZEN;
+            G.dst[0] = am_out, G.src[0] = am_in, G.row[0] = ML, G.mask[0] = FZ, G.want[0] = FZ;
+            G.dst[1] = fp(S->hist_spec[S->flip ^ 1]), G.src[1] = fp(S->hist_spec[S->flip]), G.row[1] = Hs * F * 2, G.mask[1] = FZ, G.want[1] = FZ;
+            G.n = 2;
+            dfx_launch(dfx_k_gate_commit, dim3((unsigned)B), dim3(128), 0, s, G, (const unsigned char *)gflags, B);
+            DFX_LAUNCH_CHECK();
+            dfx_launch(dfx_k_gate_finish, dim3((unsigned)B), dim3(128), 0, s, (const unsigned char *)gflags,
+                       reinterpret_cast<int *>(S->gate_buf + S->g_counter), y, ys, (int)hop, lsnr_out, ls, B, 1 /* no stage decision was taken */);
+            DFX_LAUNCH_CHECK();
+        }
         return DFX_OK;
     }
-    const bool gated = S->gated && S->gate_buf;
-    if (gated && n != 1) DFX_FAIL(DFX_ERR_INVALID_ARG, "gated streaming passes carry one hop");
     unsigned char *gflags = gated ? S->gate_buf + S->g_flags : nullptr;
     int *gcount = gated ? reinterpret_cast<int *>(S->gate_buf + S->g_counter) : nullptr;
     if (gated) {
@@ -2246,17 +2343,17 @@ extern "C" int dfx_stream_process(dfx_stream_state *S, const float *x, int64_t n
     if (!S || n <= 0 || n > S->nmax || !x || !y) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_stream_process: bad arguments (1 <= n_frames <= max_frames)");
     if (int rc = dfx_require_device()) return rc;
     hipStream_t s = dfx_stream(stream);
-    const bool advances = S->lim != 1.f;  // the pass-through case leaves the state alone (tract.rs:540-543)
+    const bool advances = S->lim != 1.f;  // the pass-through case (tract.rs:540-543) moves the STFT memory and the rolling spectra only
     const int64_t hop = S->st->hop, B = S->B;
-    // steady state (every history frame is a real frame): replay the call from a graph
-    if (S->gated && advances) {  // one hop per pass: the stage decisions of hop i shape the state hop i+1 starts from
+    if (S->gated && S->gate_buf) {  // one hop per pass: the stage decisions of hop i shape the state hop i+1 starts from
         for (int64_t i = 0; i < n; ++i) {
             if (int rc = stream_body(S, x + i * hop, 1, y + i * hop, lsnr_out ? lsnr_out + i : nullptr, s, n * hop, n * hop, n)) return rc;
-            S->frames += 1;
+            if (advances) S->frames += 1;
             S->flip ^= 1;
         }
         return DFX_OK;
     }
+    // steady state (every history frame is a real frame): replay the call from a graph
     if (S->use_graph && advances && S->channels == 1 && S->frames >= S->H + S->L) {
         auto fp = [&](size_t o) { return reinterpret_cast<float *>(S->buf + o); };
         dfx_stream_state::Graph &g = S->graph[S->flip];
@@ -2303,10 +2400,8 @@ extern "C" int dfx_stream_process(dfx_stream_state *S, const float *x, int64_t n
         }
     }
     if (int rc = stream_body(S, x, n, y, lsnr_out, s)) return rc;
-    if (advances) {
-        S->frames += n;
-        S->flip ^= 1;
-    }
+    if (advances) S->frames += n;
+    S->flip ^= 1;
     return DFX_OK;
 }
 
@@ -2411,7 +2506,10 @@ extern "C" int dfx_stream_process_raw(dfx_stream_state *S, const float *spec, fl
         dfx_launch(dfx_k_fill_rows, dim3((unsigned)nn_grid(dfx_ceil_div(B, 256), 16)), dim3(256), 0, s, lsnr_out, (int64_t)1, (int64_t)1, B, -15.f);
         DFX_LAUNCH_CHECK();
     }
-    DFX_HIP(hipMemcpyAsync(stages, gflags, (size_t)B, hipMemcpyDeviceToDevice, s));
+    // stages: bit 2 = gains exist (the network's mask, or zeros below min_db_thresh: the reference returns Some(zeros) there,
+    // tract.rs:485-486), bit 8 = coefficients exist
+    dfx_launch(dfx_k_gate_stages, dim3((unsigned)dfx_ceil_div(B, 256)), dim3(256), 0, s, (const unsigned char *)gflags, stages, B);
+    DFX_LAUNCH_CHECK();
     S->frames += 1;
     S->flip ^= 1;
     return DFX_OK;
@@ -2508,7 +2606,10 @@ extern "C" int dfx_enhance(const dfx_model *m, const dfx_state *st, const float 
         return DFX_OK;
     }
     float lim = 0.f;
-    if (atten_lim_db != 0.f) lim = powf(10.f, -fabsf(atten_lim_db) / 20.f);  // enhance.py:238-239
+    if (atten_lim_db != 0.f) {
+        lim = powf(10.f, -fabsf(atten_lim_db) / 20.f);  // enhance.py:238-239
+        if (lim >= 1.f) lim = 0.99999994f;              // |dB| tiny: the reference mixes with lim == 1.0f (the noisy signal passes)
+    }
     if (nc == 1) return enhance_chunk(m, st, x, B, T, pad, lim, y, base, s, &m->lanes[0], false);
     // ---- pipelined chunks: fork from the caller's stream, stagger the fronts, join back
     DFX_HIP(hipEventRecord(m->ev_fork, s));

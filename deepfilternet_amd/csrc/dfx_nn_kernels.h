@@ -476,13 +476,13 @@ static __device__ __forceinline__ void dfx_c0_patch_load(const float *__restrict
 template <int C>
 static __device__ __forceinline__ void dfx_c0_tile_h3(const dfx_h8 (&w0h)[C / 16], const dfx_h8 (&w0l)[C / 16],
                                                       const float4 (&bias0)[C / 16], float unscale0, const float2 (&raw)[4],
-                                                      bool keep, float (&dst)[C / 4]) {
+                                                      bool keep, float (&dst)[C / 4], float &amax) {
     constexpr int NT = C / 16;
     float x[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) x[2 * i] = raw[i].x, x[2 * i + 1] = raw[i].y;
     dfx_h8 ph, pl;
-    dfx_split8(x, ph, pl);
+    dfx_split8_g(x, ph, pl, amax);
     f32x4 acc[NT];  // the NT chains are independent: term-major order keeps dependent MFMAs NT issues apart
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(w0l[nt], ph, f32x4{0.f, 0.f, 0.f, 0.f});
@@ -511,6 +511,7 @@ struct DfxC01hArgs {
     int Fin, Fout, stride, L;
     float unscale0, unscale;
     int64_t t_begin;     // only frames [t_begin, T) of every clip are produced
+    unsigned int *err;   // model error words: bit 0 of err[1] = a value >= DFX_H3_LIMIT reached an f16 split (results invalid)
 };
 
 // Register budget: two waves per SIMD (<= 256 registers) so that one wave's LDS / global latencies hide behind the other's matrix
@@ -561,6 +562,7 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 2) dfx_k_df_conv01_h3(DfxC01hA
         okj[j] = nvalid && fi >= 0 && fi < A.Fin;
         dfx_c0_patch_load(A.feat, nb, ntm, fi, okj[j], A.T, A.Fin, A.L, q, raw[j]);
     };
+    float amax = 0.f;   // largest magnitude that went through an f16 split (range guard)
     int64_t tile = (int64_t)blockIdx.x * 4 + wave;
     locate(tile);
 #pragma unroll
@@ -579,7 +581,7 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 2) dfx_k_df_conv01_h3(DfxC01hA
             for (int i = 0; i < 4; ++i) x[2 * i] = raw[j][i].x, x[2 * i + 1] = raw[j][i].y;
             const bool keep = okj[j];
             dfx_h8 ph, pl;
-            dfx_split8(x, ph, pl);
+            dfx_split8_g(x, ph, pl, amax);
             issue(j);  // raw[j] is free again: fetch the same patch of the next tile
             f32x4 acc[NT];
 #pragma unroll
@@ -599,7 +601,7 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 2) dfx_k_df_conv01_h3(DfxC01hA
         }
         dfx_h8 uh[KC], ul[KC];
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) dfx_split8(u + 8 * kc, uh[kc], ul[kc]);
+        for (int kc = 0; kc < KC; ++kc) dfx_split8_g(u + 8 * kc, uh[kc], ul[kc], amax);
         float4 *op = reinterpret_cast<float4 *>(A.out + pos * C + 4 * q);
         int zoff = 0;
         DFX_OPAQUE(zoff);  // the fragment reads are loop invariant: keep the compiler from hoisting them into 64 registers
@@ -623,6 +625,7 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 2) dfx_k_df_conv01_h3(DfxC01hA
             }
         }
     }
+    if (amax >= DFX_H3_LIMIT && A.err) atomicOr(A.err + 1, 1u);
 }
 
 // df_dec.df_convp with df_conv0 recomputed, fp16-split form of dfx_k_df_convp2<C, KT, true> (same run decomposition: a wave walks a
@@ -639,6 +642,7 @@ struct DfxCphArgs {
     int Fd, NO, nfb, nseg, tseg, L;
     float unscale0, unscale;
     int64_t t_begin, t_zero;  // as in DfxCp2Args
+    unsigned int *err;        // as in DfxC01hArgs
 };
 
 template <int C, int KT>
@@ -665,6 +669,7 @@ __global__ void __launch_bounds__(256, 1) dfx_k_df_convp_h3(DfxCphArgs A) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) biasr[r] = A.bias[4 * q + r];
     const int64_t nruns = A.B * A.nfb * A.nseg;
+    float amax = 0.f;   // range guard of the f16 splits
     for (int64_t run = (int64_t)blockIdx.x * 4 + wave; run < nruns; run += (int64_t)gridDim.x * 4) {
         const int seg = (int)(run % A.nseg);
         const int64_t rest = run / A.nseg;
@@ -679,9 +684,9 @@ __global__ void __launch_bounds__(256, 1) dfx_k_df_convp_h3(DfxCphArgs A) {
         auto make_frame = [&](dfx_h8 (&dh)[KC], dfx_h8 (&dl)[KC], int64_t tau, const float2 (&rw)[4]) {
             float c0v[CPL];
             // frames before the clip are the zero padding of c0 itself (wave-uniform test)
-            dfx_c0_tile_h3<C>(w0h, w0l, bias0, A.unscale0, rw, fvalid && tau >= A.t_zero, c0v);
+            dfx_c0_tile_h3<C>(w0h, w0l, bias0, A.unscale0, rw, fvalid && tau >= A.t_zero, c0v, amax);
 #pragma unroll
-            for (int kc = 0; kc < KC; ++kc) dfx_split8(c0v + 8 * kc, dh[kc], dl[kc]);
+            for (int kc = 0; kc < KC; ++kc) dfx_split8_g(c0v + 8 * kc, dh[kc], dl[kc], amax);
         };
         dfx_static_for<1, KT>([&](auto sc) {
             constexpr int sl = decltype(sc)::value;
@@ -728,6 +733,7 @@ __global__ void __launch_bounds__(256, 1) dfx_k_df_convp_h3(DfxCphArgs A) {
             });
         }
     }
+    if (amax >= DFX_H3_LIMIT && A.err) atomicOr(A.err + 1, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1208,6 +1214,7 @@ __global__ void __launch_bounds__(256) dfx_k_df_convp2(DfxCp2Args A) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) biasr[r] = A.bias[4 * q + r];
     const int64_t nruns = A.B * A.nfb * A.nseg;
+    float amax = 0.f;   // range guard of the f16 splits
     for (int64_t run = (int64_t)blockIdx.x * 4 + wave; run < nruns; run += (int64_t)gridDim.x * 4) {
         const int seg = (int)(run % A.nseg);
         const int64_t rest = run / A.nseg;
@@ -1541,18 +1548,42 @@ __global__ void __launch_bounds__(DFX_PH_THREADS, 2) dfx_k_proj256_h3(DfxPhArgs 
     // stage chunk 0
 #pragma unroll
     for (int i = 0; i < PER_T; ++i) ws[i * DFX_PH_THREADS + tid] = A.wf[i * DFX_PH_THREADS + tid];
-    // this lane's B operands: row m, k = 32*kc + 8*q .. +7
+    // this lane's B operands: row m, k = 32*kc + 8*q .. +7.  The row is scaled by a power of two (exact) so that its largest magnitude
+    // sits just below 2^14 before the f16 split: any finite row then keeps ~22 bits relative to ITS OWN scale — rows of tiny values
+    // would otherwise lose their lo halves to the f16 subnormals (|x| < 6e-5) and values above 65504 would turn into inf.
     dfx_h8 xh[8], xl[8];
+    float row_unscale = 1.f;
     {
         const float4 *p = reinterpret_cast<const float4 *>(A.a + m * 256 + 8 * q);
+        float4 xu[8], xv[8];
+        float mx = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            xu[kc] = ok ? p[8 * kc] : make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[kc] = ok ? p[8 * kc + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(xu[kc].x), fabsf(xu[kc].y)), fmaxf(fabsf(xu[kc].z), fabsf(xu[kc].w))));
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(xv[kc].x), fabsf(xv[kc].y)), fmaxf(fabsf(xv[kc].z), fabsf(xv[kc].w))));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));   // the four lanes (q) that share row jl
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        int e = 0;
+        if (mx > 0.f && mx < 3.0e38f) {
+            int ex;
+            (void)frexpf(mx, &ex);            // mx = f * 2^ex, f in [0.5, 1)
+            e = 14 - ex;
+            e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        }
+        const float sc = ldexpf(1.f, e);
+        row_unscale = ldexpf(1.f, -e);
 #pragma unroll
         for (int kc = 0; kc < 8; ++kc) {
             float x[8];
-            const float4 u = ok ? p[8 * kc] : make_float4(0.f, 0.f, 0.f, 0.f), v = ok ? p[8 * kc + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-            x[0] = u.x, x[1] = u.y, x[2] = u.z, x[3] = u.w, x[4] = v.x, x[5] = v.y, x[6] = v.z, x[7] = v.w;
+            x[0] = xu[kc].x * sc, x[1] = xu[kc].y * sc, x[2] = xu[kc].z * sc, x[3] = xu[kc].w * sc;
+            x[4] = xv[kc].x * sc, x[5] = xv[kc].y * sc, x[6] = xv[kc].z * sc, x[7] = xv[kc].w * sc;
             dfx_split8(x, xh[kc], xl[kc]);
         }
     }
+    const float unscale = A.unscale * row_unscale;   // D leaves lane (jl, q) with row jl: the row's own scale
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const dfx_h8 *wc = ws + (size_t)(c & 1) * DFX_PH_CHUNK_H8;
@@ -1576,7 +1607,7 @@ __global__ void __launch_bounds__(DFX_PH_THREADS, 2) dfx_k_proj256_h3(DfxPhArgs 
                 const int n = c * DFX_PH_NC + 16 * ct + 4 * q;
                 const float4 bz = *reinterpret_cast<const float4 *>(A.bias + n);
                 *reinterpret_cast<float4 *>(A.out + m * A.N + n) =
-                    make_float4(acc[0] * A.unscale + bz.x, acc[1] * A.unscale + bz.y, acc[2] * A.unscale + bz.z, acc[3] * A.unscale + bz.w);
+                    make_float4(acc[0] * unscale + bz.x, acc[1] * unscale + bz.y, acc[2] * unscale + bz.z, acc[3] * unscale + bz.w);
             }
         }
         if (c + 1 < nchunks) {

@@ -75,6 +75,14 @@ static __device__ __forceinline__ void dfx_split8(const float *x, dfx_h8 &hi, df
         lo[i] = (_Float16)(x[i] - (float)h);
     }
 }
+// the same, also tracking the largest magnitude that went through the split (range guard of the fp16-split kernels: above 65504 the
+// hi half is inf; the kernels report amax >= DFX_H3_LIMIT through the model's error word instead of handing back garbage)
+#define DFX_H3_LIMIT 6.0e4f
+static __device__ __forceinline__ void dfx_split8_g(const float *x, dfx_h8 &hi, dfx_h8 &lo, float &amax) {
+    amax = fmaxf(amax, fmaxf(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))),
+                             fmaxf(fmaxf(fabsf(x[4]), fabsf(x[5])), fmaxf(fabsf(x[6]), fabsf(x[7])))));
+    dfx_split8(x, hi, lo);
+}
 // D[i][j] += sum_k A[i][k] B[k][j]; lane l: A row i = l&15, B col j = l&15, both hold k = 8*(l>>4) .. +7; D: col = l&15, row = 4*(l>>4)+r
 static __device__ __forceinline__ f32x4 dfx_mfma_16x16x32_f16(dfx_h8 a, dfx_h8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);

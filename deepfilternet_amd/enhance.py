@@ -50,8 +50,6 @@ def init_df(
     Extensions (keyword-only): ``params`` + ``state_dict`` build the model from memory; ``epoch="none"`` (or None) with no
     checkpoint initialises seeded synthetic weights (``seed``), which is what the benchmarks use.
     """
-    if mask_only:
-        raise NotImplementedError("mask_only is not supported by the HIP engine")
     load_cp = epoch is not None and not (isinstance(epoch, str) and epoch.lower() == "none")
     if params is None:
         if model_base_dir is None or model_base_dir in PRETRAINED_MODELS:
@@ -67,13 +65,16 @@ def init_df(
         p.mask_pf = True  # enhance.py:152-159
     df_state = DF(sr=p.sr, fft_size=p.fft_size, hop_size=p.hop_size, nb_bands=p.nb_erb, min_nb_erb_freqs=p.min_nb_freqs)
     ep = 0
+    from_checkpoint = False
     if state_dict is None and load_cp and model_base_dir is not None:
         state_dict, ep = read_cp(os.path.join(model_base_dir, "checkpoints"), epoch)
         if state_dict is None:
             raise FileNotFoundError("Could not find a checkpoint")  # reference: logger.error + exit(1)
+        from_checkpoint = True
     if state_dict is None:
         state_dict = random_state_dict(p, seed)
-    model = DfNet(p, state_dict, df_state)
+    # enhance.py:172-175: init_model(df_state, run_df=not mask_only); checkpoints load like read_cp (non-strict, size mismatches dropped)
+    model = DfNet(p, state_dict, df_state, run_df=not mask_only, strict=not from_checkpoint)
     suffix = os.path.basename(os.path.abspath(model_base_dir)) if model_base_dir else p.model
     if post_filter:
         suffix += "_pf"

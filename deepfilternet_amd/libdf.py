@@ -109,6 +109,8 @@ class DF:
         Cn, T = input.shape
         hop, F, ML = self._hop, self._fft // 2 + 1, self._fft - self._hop
         Tf = T // hop
+        if reset and Cn > 0:
+            self._syn_mem = None   # pyDF resets the whole DFState per channel (lib.rs:56-58,155-158): analysis AND synthesis memory
         if Cn == 0 or Tf == 0:
             if Cn > 0:
                 _check_contig(input)
@@ -146,6 +148,8 @@ class DF:
         if F != self._fft // 2 + 1:
             raise RuntimeError(f"DF shape error: expected {self._fft // 2 + 1} frequency bins, got {F}")
         hop, ML = self._hop, self._fft - self._hop
+        if reset and Cn > 0:
+            self._ana_mem = None   # lib.rs:88-90: the same reset from the synthesis side
         y = _to_dev(input, torch.complex64)
         yr = torch.view_as_real(y)
         out = torch.empty((Cn, Tf * hop), dtype=torch.float32, device=y.device)

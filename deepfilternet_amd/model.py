@@ -36,6 +36,7 @@ def make_cfg(p: ModelParams) -> _lib.ModelCfg:
     c.df_pathway_kernel_size_t = p.df_pathway_kernel_size_t
     c.lin_groups, c.enc_lin_groups = p.lin_groups, p.enc_lin_groups
     c.mask_pf, c.pf_beta, c.norm_alpha = int(p.mask_pf), float(p.pf_beta), float(p.norm_alpha())
+    c.emb_gru_skip_enc, c.emb_gru_skip, c.enc_concat = _SKIP[p.emb_gru_skip_enc], _SKIP[p.emb_gru_skip], int(bool(p.enc_concat))
     return c
 
 
@@ -54,31 +55,61 @@ def tensor_manifest(cfg: _lib.ModelCfg):
     return out
 
 
-def pack_state_dict(cfg: _lib.ModelCfg, sd: Dict[str, "np.ndarray | torch.Tensor"]) -> np.ndarray:
+def pack_state_dict(cfg: _lib.ModelCfg, sd: Dict[str, "np.ndarray | torch.Tensor"], strict: bool = True,
+                    warn=None) -> np.ndarray:
+    """Packs the tensors the engine consumes into one float32 blob (dfx_model_create's input).
+
+    ``strict=False`` follows ``read_cp`` (checkpoint.py:85-103): the reference loads with ``load_state_dict(strict=False)``, DROPS
+    every tensor whose size does not match and only warns about missing keys — the affected parameters then keep the values the
+    freshly constructed module had.  Here those are the deterministic ones of PyTorch's constructors for BatchNorm (weight 1, bias 0,
+    running_mean 0, running_var 1) and zeros for everything else (the reference's random initialisation cannot be reproduced)."""
+    import warnings
+
+    warn = warn or (lambda msg: warnings.warn(msg, stacklevel=3))
     total = C.c_int64()
     _lib.check(_lib.lib().dfx_model_blob_floats(C.byref(cfg), C.byref(total)))
     blob = np.zeros(total.value, dtype=np.float32)
     for name, shape, off in tensor_manifest(cfg):
-        if name not in sd:
+        v = sd.get(name)
+        if v is not None:
+            v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            if tuple(v.shape) != shape:
+                if strict:
+                    raise ValueError(f"size mismatch for {name}: checkpoint {tuple(v.shape)}, model {shape}")
+                warn(f"size mismatch for {name}: copying a param with shape {tuple(v.shape)} from checkpoint, the shape in current "
+                     f"model is {shape}. (dropped)")
+                v = None
+        elif strict:
             raise KeyError(f"state dict is missing '{name}'")
-        v = sd[name]
-        v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
-        if tuple(v.shape) != shape:
-            raise ValueError(f"size mismatch for {name}: checkpoint {tuple(v.shape)}, model {shape}")
-        blob[off:off + v.size] = v.astype(np.float32, copy=False).ravel()
+        else:
+            warn(f"Missing key: '{name}'")
+        n = int(np.prod(shape)) if shape else 1
+        if v is None:
+            leaf = name.rsplit(".", 1)[-1]
+            is_bn = len(shape) == 1 and ".gru." not in name and "lsnr_fc" not in name
+            fill = 1.0 if is_bn and leaf in ("weight", "running_var") else 0.0
+            blob[off:off + n] = fill
+        else:
+            blob[off:off + n] = v.astype(np.float32, copy=False).ravel()
     return blob
 
 
 class DfNet:
     """Inference-only DeepFilterNet3 on libdfx.  Call signature and output shapes of deepfilternet3.py:389-456."""
 
-    def __init__(self, p: ModelParams, state_dict: Dict[str, "np.ndarray | torch.Tensor"], df_state: Optional[DF] = None):
+    def __init__(self, p: ModelParams, state_dict: Dict[str, "np.ndarray | torch.Tensor"], df_state: Optional[DF] = None,
+                 run_df: bool = True, strict: bool = True):
+        """``run_df=False``: DfNet(run_df=False) of the reference (deepfilternet3.py:383; init_df(mask_only=True)) — mask only.
+        ``strict=False``: checkpoint.py:85-103 semantics for incomplete state-dicts (see :func:`pack_state_dict`)."""
         self.p = p
         self.cfg = make_cfg(p)
-        blob = pack_state_dict(self.cfg, state_dict)
+        blob = pack_state_dict(self.cfg, state_dict, strict=strict)
         h = C.c_void_p()
         _lib.check(_lib.lib().dfx_model_create(C.byref(self.cfg), blob.ctypes.data_as(C.POINTER(C.c_float)), C.byref(h)))
         self._h = h
+        self.run_df = bool(run_df)
+        if not self.run_df:
+            _lib.check(_lib.lib().dfx_model_set_run_df(self._h, 0))
         self.df_state = df_state or DF(p.sr, p.fft_size, p.hop_size, p.nb_erb, p.min_nb_freqs)
         # attributes the reference's enhance() probes (enhance.py:234)
         self.nb_df = p.nb_df
@@ -149,6 +180,8 @@ class DfNet:
                                        B, T, float(atten_lim), _lib.ptr(spec_e), _lib.ptr(m), _lib.ptr(lsnr),
                                        _lib.ptr(coefs), _lib.ptr(ws), ws.numel(), _lib.stream()))
         # the engine writes the coefficients directly in DfOutputReshapeMF's layout [B,O,T,F',2] (deepfilternet3.py:268-275)
+        if not self.run_df:
+            coefs = torch.zeros((), device=dev)   # deepfilternet3.py:444
         return spec_e, m, lsnr, coefs
 
     forward = __call__

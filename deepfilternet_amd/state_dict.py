@@ -74,13 +74,17 @@ def state_dict_manifest(p: ModelParams) -> "OrderedDict[str, Tuple[int, ...]]":
     d.update(_conv_block("enc.df_conv0", 2, C, tuple(p.conv_kernel_inp)))
     d.update(_conv_block("enc.df_conv1", C, C, tuple(p.conv_kernel)))
     d["enc.df_fc_emb.0.weight"] = _glin(C * Fd // 2, emb, p.enc_lin_groups)
-    d["enc.emb_gru.linear_in.0.weight"] = _glin(emb, H, p.lin_groups)
+    d["enc.emb_gru.linear_in.0.weight"] = _glin(2 * emb if p.enc_concat else emb, H, p.lin_groups)
     d.update(_gru("enc.emb_gru.gru", H, 1))
+    if p.emb_gru_skip_enc == "groupedlinear":   # SqueezedGRU_S registers linear_in, gru, gru_skip, linear_out in this order
+        d["enc.emb_gru.gru_skip.weight"] = _glin(emb, emb, p.lin_groups)
     d["enc.emb_gru.linear_out.0.weight"] = _glin(H, emb, p.lin_groups)
     d["enc.lsnr_fc.0.weight"] = (1, emb)
     d["enc.lsnr_fc.0.bias"] = (1,)
     d["erb_dec.emb_gru.linear_in.0.weight"] = _glin(emb, H, p.lin_groups)
     d.update(_gru("erb_dec.emb_gru.gru", H, p.emb_num_layers - 1))
+    if p.emb_gru_skip == "groupedlinear":
+        d["erb_dec.emb_gru.gru_skip.weight"] = _glin(emb, emb, p.lin_groups)
     d["erb_dec.emb_gru.linear_out.0.weight"] = _glin(H, emb, p.lin_groups)
     d.update(_conv_block("erb_dec.conv3p", C, C, (1, 1)))
     d.update(_conv_block("erb_dec.convt3", C, C, tuple(p.conv_kernel)))

@@ -34,7 +34,7 @@ extern "C" {
 #define DFX_ERR_NO_DEVICE 4
 #define DFX_ERR_ALLOC 5
 
-#define DFX_VERSION 100 /* 0.1.0 */
+#define DFX_VERSION 200 /* 0.2.0 */
 
 int dfx_version(void);
 const char *dfx_status_string(int status);
@@ -152,6 +152,9 @@ typedef struct dfx_model_cfg {
     int32_t mask_pf;
     float pf_beta;
     float norm_alpha; /* utils.py:111-127 get_norm_alpha() */
+    /* skip connections around the embedding GRUs (SqueezedGRU_S gru_skip_op, modules.py:702-738: x = linear_out(gru(linear_in(in))) +
+     * skip(in); deepfilternet3.py:138-146 encoder, :198-206 ERB decoder) and the encoder's combine op (:132-136): DFX_SKIP_* / 0|1 */
+    int32_t emb_gru_skip_enc, emb_gru_skip, enc_concat;
 } dfx_model_cfg;
 
 /* Tensor manifest: the tensors of the reference state-dict the engine consumes, in state_dict() order, with their
@@ -176,6 +179,9 @@ int dfx_model_cfg_get(const dfx_model *m, dfx_model_cfg *out);
  * streams, forked from and joined to the caller's stream with events.  enable = 0 serialises everything on the caller's
  * stream (useful for per-kernel timing).  Default: enabled (environment DFX_STREAMS=0 disables at creation). */
 int dfx_model_set_streams(dfx_model *m, int enable);
+/* DfNet(run_df=False) (deepfilternet3.py:383,433-443; init_df(mask_only=True), enhance.py:109,172-175): the DF decoder does not run,
+ * the enhanced spectrum is the masked spectrum on every bin, df_coefs is not produced (a caller's buffer is zero-filled). */
+int dfx_model_set_run_df(dfx_model *m, int enable);
 /* Pipelining knobs (defaults 12, 32, 1; time_chunks <= 16; environment DFX_TCHUNKS / DFX_CHUNKS at creation):
  *   time_chunks      the GRU phase is cut into this many time chunks and every GRU layer runs on its own stream, chunk k of
  *                    layer l starting when layer l-1 has produced chunk k (chain = T*(1 + 2/K) steps instead of 3T);
@@ -184,7 +190,8 @@ int dfx_model_set_streams(dfx_model *m, int enable);
  * The streams need their own hardware queues: export GPU_MAX_HW_QUEUES=16 (ROCm maps streams onto 4 queues by default). */
 int dfx_model_set_pipeline(dfx_model *m, int time_chunks, int min_chunk_frames, int batch_chunks);
 /* Synchronises with the device and reports DFX_ERR_HIP if a workgroup pair of the two-CU GRU kernel ever timed out waiting for
- * its partner (bounded spins: the engine never hangs; results of that pass are invalid).  DFX_OK otherwise. */
+ * its partner (bounded spins: the engine never hangs; results of that pass are invalid), and DFX_ERR_UNSUPPORTED if an activation left
+ * the range of the fp16-split matrix kernels (|x| >= 6e4 at a split; DFX_EXACT_FP32=1 selects the exact fp32 kernels).  DFX_OK otherwise. */
 int dfx_model_check(const dfx_model *m);
 
 /* Scratch memory the caller must provide (device bytes) for a [B, T-frames] batch. */

@@ -115,12 +115,17 @@ def gru_aten(x: Tensor, sd, prefix: str, layers: int) -> Tensor:
     return y
 
 
-def squeezed_gru(x: Tensor, sd, prefix: str, layers: int, has_out: bool, manual: bool = False) -> Tensor:
-    """modules.py:702-738 SqueezedGRU_S with linear_act_layer=ReLU, gru_skip_op=None."""
+def squeezed_gru(x: Tensor, sd, prefix: str, layers: int, has_out: bool, manual: bool = False, skip: str = "none") -> Tensor:
+    """modules.py:702-738 SqueezedGRU_S with linear_act_layer=ReLU; gru_skip_op none / identity / GroupedLinearEinsum: the skip takes
+    the module's INPUT and joins after linear_out (:733-737)."""
     y = torch.relu(grouped_linear(x, _t(sd, f"{prefix}.linear_in.0.weight")))
     y = gru_manual(y, sd, f"{prefix}.gru", layers)[0] if manual else gru_aten(y, sd, f"{prefix}.gru", layers)
     if has_out:
         y = torch.relu(grouped_linear(y, _t(sd, f"{prefix}.linear_out.0.weight")))
+    if skip == "identity":
+        y = y + x
+    elif skip == "groupedlinear":
+        y = y + grouped_linear(x, _t(sd, f"{prefix}.gru_skip.weight"))
     return y
 
 
@@ -175,8 +180,9 @@ def dfnet_encoder(p: ModelParams, sd, fe: Tensor, fs: Tensor, manual_gru: bool =
     c1 = conv_norm_act(c0, sd, "enc.df_conv1", C, C, ck, fstride=2)
     cemb = c1.permute(0, 2, 3, 1).flatten(2)
     cemb = torch.relu(grouped_linear(cemb, _t(sd, "enc.df_fc_emb.0.weight")))
-    emb_in = e3.permute(0, 2, 3, 1).flatten(2) + cemb
-    emb = squeezed_gru(emb_in, sd, "enc.emb_gru", 1, True, manual_gru)
+    e3f = e3.permute(0, 2, 3, 1).flatten(2)
+    emb_in = torch.cat((e3f, cemb), dim=-1) if p.enc_concat else e3f + cemb    # :132-136,181 Concat / Add
+    emb = squeezed_gru(emb_in, sd, "enc.emb_gru", 1, True, manual_gru, skip=p.emb_gru_skip_enc)
     lsnr = torch.sigmoid(F.linear(emb, _t(sd, "enc.lsnr_fc.0.weight"), _t(sd, "enc.lsnr_fc.0.bias")))
     lsnr = lsnr * (p.lsnr_max - p.lsnr_min) + p.lsnr_min
     return {"e0": e0, "e1": e1, "e2": e2, "e3": e3, "c0": c0, "c1": c1, "cemb": cemb, "emb_in": emb_in, "emb": emb, "lsnr": lsnr}
@@ -189,7 +195,7 @@ def dfnet_erb_decoder(p: ModelParams, sd, emb: Tensor, e3: Tensor, e2: Tensor, e
     C = p.conv_ch
     ck = tuple(p.conv_kernel)
     b, _, t, f8 = e3.shape
-    d_emb = squeezed_gru(emb, sd, "erb_dec.emb_gru", p.emb_num_layers - 1, True, manual_gru)
+    d_emb = squeezed_gru(emb, sd, "erb_dec.emb_gru", p.emb_num_layers - 1, True, manual_gru, skip=p.emb_gru_skip)
     d_emb = d_emb.view(b, t, f8, -1).permute(0, 3, 1, 2)
     d3 = conv_norm_act(conv_norm_act(e3, sd, "erb_dec.conv3p", C, C, (1, 1)) + d_emb, sd, "erb_dec.convt3", C, C, ck)
     d2 = convt_norm_act(conv_norm_act(e2, sd, "erb_dec.conv2p", C, C, (1, 1)) + d3, sd, "erb_dec.convt2", C,
@@ -220,8 +226,8 @@ def dfnet_df_decoder(p: ModelParams, sd, emb: Tensor, c0: Tensor, manual_gru: bo
 
 @torch.no_grad()
 def dfnet_forward(p: ModelParams, sd: Dict[str, Tensor], widths: np.ndarray, spec: Tensor, feat_erb: Tensor,
-                  feat_spec: Tensor, manual_gru: bool = False) -> Dict[str, Tensor]:
-    """deepfilternet3.py:389-456 DfNet.forward (lsnr_dropout=False path).
+                  feat_spec: Tensor, manual_gru: bool = False, run_df: bool = True) -> Dict[str, Tensor]:
+    """deepfilternet3.py:389-456 DfNet.forward (lsnr_dropout=False path); run_df=False: :433-446 (mask only, no coefficients).
 
     spec [B,1,T,F,2], feat_erb [B,1,T,E], feat_spec [B,1,T,F',2]  (all float32).
     Returns dict with spec_e [B,1,T,F,2], m [B,1,T,E], lsnr [B,T,1], df_coefs [B,O,T,F',2] plus intermediates.
@@ -236,11 +242,13 @@ def dfnet_forward(p: ModelParams, sd: Dict[str, Tensor], widths: np.ndarray, spe
     # Mask :248-269 (no post filter / atten_lim inside the module for DF3)
     spec_c = torch.view_as_complex(spec.squeeze(1).contiguous())  # [B,T,F]
     spec_m = spec_c * band_gain(m.squeeze(1), widths)
-    dfd = dfnet_df_decoder(p, sd, enc["emb"], enc["c0"], manual_gru)
-    coefs_c = torch.view_as_complex(dfd["df_coefs"])
-    # MF.DF on the *noisy* spec (:442), then high bins from the masked spec (:443)
     spec_e = spec_m.clone()
-    spec_e[..., : p.nb_df] = df_apply(spec_c, coefs_c, O, p.df_lookahead, p.nb_df)
+    dfd = {}
+    if run_df:
+        dfd = dfnet_df_decoder(p, sd, enc["emb"], enc["c0"], manual_gru)
+        coefs_c = torch.view_as_complex(dfd["df_coefs"])
+        # MF.DF on the *noisy* spec (:442), then high bins from the masked spec (:443)
+        spec_e[..., : p.nb_df] = df_apply(spec_c, coefs_c, O, p.df_lookahead, p.nb_df)
     if p.mask_pf:
         spec_e = post_filter(spec_c, spec_e, p.pf_beta)
     out = {"spec_e": torch.view_as_real(spec_e).unsqueeze(1)}

@@ -12,9 +12,9 @@ def named_params(name: str) -> ModelParams:
         return ModelParams.defaults()
     if name == "df3":
         return ModelParams.deepfilternet3()
-    if name == "pf32":
+    if name in ("pf32", "pf32_nopf"):
         p = ModelParams.defaults()
-        p.mask_pf, p.df_lookahead, p.conv_lookahead = True, 1, 1
+        p.mask_pf, p.df_lookahead, p.conv_lookahead = name == "pf32", 1, 1
         p.df_gru_skip, p.df_pathway_kernel_size_t, p.conv_ch = "identity", 3, 32
         return p
     raise KeyError(name)

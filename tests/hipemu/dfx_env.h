@@ -485,6 +485,16 @@ static inline void dfx_split8(const float *x, dfx_h8 &hi, dfx_h8 &lo) {
         lo.v[i] = dfx_f32_to_f16_bits(x[i] - dfx_f16_bits_to_f32(h));
     }
 }
+#define DFX_H3_LIMIT 6.0e4f
+static inline void dfx_split8_g(const float *x, dfx_h8 &hi, dfx_h8 &lo, float &amax) {
+    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(x[i]));
+    dfx_split8(x, hi, lo);
+}
+static inline unsigned atomicOr(unsigned *p, unsigned v) {
+    unsigned o = *p;
+    *p = o | v;
+    return o;
+}
 // v_mfma_f32_16x16x32_f16: lane l holds A[i = l&15][k = 8*(l>>4)+0..7] and B[k = 8*(l>>4)+0..7][j = l&15];
 // D[4*(l>>4)+r][l&15].  Products are exact in fp32; the accumulation order inside the instruction is unspecified (k ascending here).
 static inline f32x4 dfx_mfma_16x16x32_f16(dfx_h8 a, dfx_h8 b, f32x4 c) {

@@ -15,6 +15,7 @@ from tests.helpers import emu_subset, named_params, rms, torch_sd
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOP = 480
+CAPI_THRESHOLDS = (-15.0, 35.0, 35.0)   # DFState::new, capi.rs:27-34
 
 
 def _capi(lib):
@@ -79,9 +80,9 @@ def test_df_capi_frame_loop(backend, tmp_path):
     rng = np.random.default_rng(7)
     x = (0.1 * rng.standard_normal(HOP * T)).astype(np.float32)
     sd = torch_sd(p, 9)
-    # defaults of the reference runtime: thresholds -10 / 30 / 20 dB, post filter off (tract.rs:177-189)
+    # what the reference's C API fixes in DFState::new (capi.rs:27-34): thresholds -15 / 35 / 35 dB, post filter off
     y, lsnr = _process(lib, st, x)
-    yr, lr, _ = S.process_stream(p, sd, x, pf_beta=0.0)
+    yr, lr, _ = S.process_stream(p, sd, x, pf_beta=0.0, thresholds=CAPI_THRESHOLDS)
     assert rms(y - yr) < 1e-6 and np.abs(lsnr - lr)[p.df_lookahead:].max() < 1e-3
     lib.df_free(st)
     # post filter + attenuation limit through the setters, fresh state
@@ -90,7 +91,7 @@ def test_df_capi_frame_loop(backend, tmp_path):
     lib.df_set_post_filter_beta(st, 0.02)
     lib.df_set_atten_lim(st, 12.0)
     y, _ = _process(lib, st, x)
-    yr, _, _ = S.process_stream(p, sd, x, atten_lim_db=12.0, pf_beta=0.02)
+    yr, _, _ = S.process_stream(p, sd, x, atten_lim_db=12.0, pf_beta=0.02, thresholds=CAPI_THRESHOLDS)
     assert rms(y - yr) < 1e-6
     lib.df_free(st)
     # a corrupt file is refused
@@ -141,7 +142,13 @@ def test_process_frame_raw(backend, tmp_path):
                 assert np.abs(gains[i].numpy() - rg).max() < 1e-5
             if rc is not None:
                 assert np.abs(coefs[i].numpy() - rc).max() < 1e-5
-    # the reference-named entry point, one stream: default thresholds (-10 / 30 / 20 dB) -> both stages on these signals
+    # lsnr below min_db_thresh: the reference returns Some(zeros) as gains and no coefficients (tract.rs:485-486, :658-661)
+    rz = DfStream(model, df_state, streams=2, gating=True, thresholds=(1e9, 2e9, 2e9))
+    for k in range(3 + p.df_lookahead):
+        lsnr, gains, coefs, stages = rz.process_raw(torch.from_numpy(np.ascontiguousarray(spec[:, k])))
+        if k >= p.df_lookahead:
+            assert np.all(stages.numpy() == 2) and np.all(gains.numpy() == 0)
+    # the reference-named entry point, one stream: the C API's thresholds (-15 / 35 / 35 dB, capi.rs:27-34) -> both stages on these signals
     path = export_dfx(str(tmp_path / "model.dfx"), params=p, state_dict=sd_np)
     lib = _capi(C.CDLL(_lib.library_path()))
     fp = C.POINTER(C.c_float)
@@ -149,7 +156,7 @@ def test_process_frame_raw(backend, tmp_path):
     lib.df_process_frame_raw.argtypes = [C.c_void_p, fp, C.POINTER(fp), C.POINTER(fp)]
     st = lib.df_create(os.fsencode(path), 100.0, None)
     assert st
-    dflt = S.process_raw_frames(p, sd, spec[0])
+    dflt = S.process_raw_frames(p, sd, spec[0], thresholds=CAPI_THRESHOLDS)
     for k in range(min(K, 6)):
         frame = np.ascontiguousarray(spec[0, k]).view(np.float32).copy()
         g = np.zeros(p.nb_erb, np.float32)

@@ -1,0 +1,157 @@
+"""Configuration options of deepfilternet3.py that round 1 refused, against outputs of the reference's own ``DfNet.forward``
+(tests/golden/dfnet_opts_*.npz, tools/gen_golden_r2.py): skip connections around the embedding GRUs (``emb_gru_skip_enc`` /
+``emb_gru_skip``: identity, groupedlinear; deepfilternet3.py:138-146,198-206, modules.py:733-737), ``enc_concat`` (:132-136),
+``run_df=False`` / ``init_df(mask_only=True)`` (:383,433-446; enhance.py:109,172-175), any ``pad_mode`` (never read by DF3), and
+``read_cp``'s non-strict checkpoint loading (checkpoint.py:85-103)."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from deepfilternet_amd.config import ModelParams
+from deepfilternet_amd.state_dict import random_state_dict, state_dict_manifest
+from oracle import dfnet_oracle as O
+from tests.helpers import widths_for
+from tools.gen_golden_r2 import opt_cases
+
+NAMES = ["skip_id_gl", "skip_gl_id", "concat", "mask_only"]
+SEEDS = {n: 20 + i for i, n in enumerate(NAMES)}
+
+
+def _cmp(a, b, tol, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b).max()
+    assert err <= tol * max(1.0, np.abs(b).max()), (what, err)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_matches_reference(name, golden_dir):
+    g = np.load(os.path.join(golden_dir, f"dfnet_opts_{name}.npz"))
+    p, run_df = opt_cases()[name]
+    sd = {k: torch.as_tensor(v) for k, v in random_state_dict(p, SEEDS[name], widths=widths_for(p)).items()}
+    out = O.dfnet_forward(p, sd, widths_for(p), torch.from_numpy(g["spec"]), torch.from_numpy(g["feat_erb"]), torch.from_numpy(g["feat_spec"]),
+                          run_df=run_df)
+    _cmp(out["m"], g["m"], 1e-5, "mask")
+    _cmp(out["lsnr"], g["lsnr"], 1e-5, "lsnr")
+    _cmp(out["spec_e"], g["spec_e"], 1e-5, "spec_e")
+    if run_df:
+        _cmp(out["df_coefs"], g["df_coefs"], 1e-5, "df_coefs")
+    else:
+        assert g["df_coefs"].shape == ()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_engine_matches_reference(backend, name, golden_dir):
+    from deepfilternet_amd.model import DfNet, make_cfg, tensor_manifest
+
+    g = np.load(os.path.join(golden_dir, f"dfnet_opts_{name}.npz"))
+    p, run_df = opt_cases()[name]
+    # the C manifest lists the reference's state-dict names in the reference's order (incl. the gru_skip weights)
+    man = state_dict_manifest(p)
+    got = tensor_manifest(make_cfg(p))
+    skip = ("erb_fb", "mask.erb_inv_fb", "df_dec.df_fc_a")
+    assert [n for n, _, _ in got] == [k for k in man if not k.endswith("num_batches_tracked") and not k.startswith(skip)]
+    assert all(tuple(man[n]) == tuple(shape) for n, shape, _ in got)
+    model = DfNet(p, random_state_dict(p, SEEDS[name]), run_df=run_df)
+    spec_e, m, lsnr, coefs = model(torch.from_numpy(g["spec"]), torch.from_numpy(g["feat_erb"]), torch.from_numpy(g["feat_spec"]))
+    _cmp(m.cpu(), g["m"], 2e-5, "mask")
+    _cmp(lsnr.cpu(), g["lsnr"], 2e-5, "lsnr")
+    _cmp(spec_e.cpu(), g["spec_e"], 3e-5, "spec_e")
+    if run_df:
+        _cmp(coefs.cpu(), g["df_coefs"], 3e-5, "df_coefs")
+    else:
+        assert coefs.shape == ()
+
+
+def test_mask_only_enhance_and_variants(backend):
+    """init_df(mask_only=True) -> enhance(): the oracle's enhance() with the DF stage off; serial and stream-parallel engines agree."""
+    from deepfilternet_amd.enhance import enhance, init_df
+
+    p = ModelParams.defaults()
+    sd = random_state_dict(p, 5, widths=widths_for(p))
+    model, df_state, _, _ = init_df(params=p, state_dict=sd, epoch="none", mask_only=True)
+    rng = np.random.default_rng(0)
+    x = (0.1 * rng.standard_normal((2, 4800 + 77))).astype(np.float32)
+    y = enhance(model, df_state, torch.from_numpy(x)).numpy()
+    sdt = {k: torch.as_tensor(v) for k, v in sd.items()}
+
+    # oracle enhance() with run_df=False
+    from oracle import libdf_oracle as L
+    st = L.DF(p.sr, p.fft_size, p.hop_size, p.nb_erb, p.min_nb_freqs)
+    xp = np.ascontiguousarray(np.pad(x, ((0, 0), (0, p.fft_size))), dtype=np.float32)
+    spec, fe, fs = O.df_features(L, xp, st, p.nb_df, p.norm_alpha())
+    out = O.dfnet_forward(p, sdt, st.erb_widths(), torch.view_as_real(torch.from_numpy(spec)).unsqueeze(1), torch.from_numpy(fe).unsqueeze(1),
+                          torch.view_as_real(torch.from_numpy(fs)).unsqueeze(1), run_df=False)
+    enh = torch.view_as_complex(out["spec_e"].squeeze(1).contiguous()).numpy()
+    d = p.fft_size - p.hop_size
+    ref = st.synthesis(np.ascontiguousarray(enh))[:, d: x.shape[1] + d]
+    assert np.sqrt(np.mean((y - ref) ** 2)) < 2e-6
+    model.set_streams(False)
+    y2 = enhance(model, df_state, torch.from_numpy(x)).numpy()
+    assert np.sqrt(np.mean((y - y2) ** 2)) < 1e-6
+
+
+def test_options_that_are_accepted_or_refused(backend):
+    from deepfilternet_amd.model import DfNet
+
+    p = ModelParams.defaults()
+    p.pad_mode = "output"            # a DfParams option deepfilternet3.py never reads
+    DfNet(p, random_state_dict(p, 0))
+    p = ModelParams.defaults()
+    p.enc_concat, p.emb_gru_skip_enc = True, "identity"      # the reference's own assert (deepfilternet3.py:141)
+    with pytest.raises(NotImplementedError, match="enc_concat"):
+        DfNet(p, {})
+    p = ModelParams.defaults()
+    p.emb_gru_skip = "conv"
+    with pytest.raises(NotImplementedError, match="emb_gru_skip"):
+        DfNet(p, {})
+
+
+def test_non_strict_checkpoint_loading(backend, tmp_path):
+    """read_cp (checkpoint.py:85-103): load_state_dict(strict=False); tensors with a size mismatch are dropped with a warning, missing
+    keys are warned about, unexpected keys are ignored — the model is built all the same.  Dropped BatchNorm tensors take the module
+    constructor's values (1 / 0 / 0 / 1), so dropping an identity-valued BatchNorm changes nothing."""
+    from deepfilternet_amd.enhance import enhance, init_df
+    from deepfilternet_amd.model import DfNet
+
+    p = ModelParams.defaults()
+    sd = random_state_dict(p, 3, widths=widths_for(p))
+    bn = "erb_dec.conv0_out.1"
+    sd[bn + ".weight"][:] = 1
+    sd[bn + ".bias"][:] = 0
+    sd[bn + ".running_mean"][:] = 0
+    sd[bn + ".running_var"][:] = 1
+    base = DfNet(p, sd)
+    broken = dict(sd)
+    del broken[bn + ".weight"]                                        # missing key
+    broken[bn + ".running_var"] = np.ones(3, np.float32)              # size mismatch -> dropped
+    broken["erb_fb"] = np.zeros((5, 5), np.float32)                   # stale buffer: ignored
+    broken["enc.emb_gru.h0"] = np.zeros(4, np.float32)                # unexpected key: ignored
+    with pytest.raises((KeyError, ValueError)):
+        DfNet(p, broken)                                              # strict (explicit state-dicts): loud
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        loose = DfNet(p, broken, strict=False)
+    text = " | ".join(str(x.message) for x in w)
+    assert "Missing key" in text and bn + ".weight" in text and "size mismatch" in text and bn + ".running_var" in text
+    rng = np.random.default_rng(1)
+    spec = torch.from_numpy((0.05 * rng.standard_normal((1, 1, 6, p.freq_bins, 2))).astype(np.float32))
+    fe = torch.from_numpy((0.5 * rng.standard_normal((1, 1, 6, p.nb_erb))).astype(np.float32))
+    fs = torch.from_numpy(rng.standard_normal((1, 1, 6, p.nb_df, 2)).astype(np.float32))
+    a, b = base(spec, fe, fs), loose(spec, fe, fs)
+    assert all(torch.equal(x.cpu(), y.cpu()) for x, y in zip(a, b))
+    # the same through a model directory (init_df -> read_cp -> non-strict)
+    mdir = tmp_path / "model"
+    (mdir / "checkpoints").mkdir(parents=True)
+    (mdir / "config.ini").write_text(p.to_ini())
+    torch.save({k: torch.as_tensor(v) for k, v in broken.items()}, str(mdir / "checkpoints" / "model_7.ckpt.best"))
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        model, df_state, _, ep = init_df(str(mdir), log_file=None)
+    assert ep == 7
+    x = (0.1 * rng.standard_normal((1, 2400))).astype(np.float32)
+    y0 = enhance(base, df_state, torch.from_numpy(x))
+    assert torch.equal(enhance(model, df_state, torch.from_numpy(x)), y0)

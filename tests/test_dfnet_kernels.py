@@ -79,8 +79,8 @@ def test_unsupported_configs_fail_loudly(backend):
     with pytest.raises(Exception, match="conv_ch|unsupported"):
         DfNet(p, random_state_dict(p, 0))
     p = named_params("defaults")
-    p.enc_concat = True
-    with pytest.raises(NotImplementedError, match="enc_concat"):
+    p.emb_hidden_dim = 128
+    with pytest.raises(NotImplementedError, match="hidden size"):
         DfNet(p, {})
     p = named_params("defaults")
     sd = random_state_dict(p, 0)

@@ -139,3 +139,69 @@ def test_full_size_gated_streams(hip_backend):
     d = FFT - HOP                                   # nothing applied: the live streams come back delayed by the STFT only
     live = torch.cat([y2, y3], 1)[0::64]
     assert rms((live[:, d:] - x[0::64, : 8 * HOP - d]).cpu().numpy()) < 1e-6
+
+
+def test_full_size_order10_deep_filter(hip_backend):
+    """BASELINE.json configs[4]: the multi-frame stress configuration (df_order = 10, nb_df = 96) at batch 256 x 10 s — the whole
+    enhance() with a DeepFilterNet3 whose deep filter has 10 taps (lookahead 3), and the deep-filter kernel alone on [256, 1002, 481]
+    spectra.  Oracle rows + size-independent properties (a clip alone gives the same bits; linearity of the filter in its coefficients)."""
+    from deepfilternet_amd import _lib
+    from deepfilternet_amd.config import ModelParams
+    from deepfilternet_amd.enhance import enhance, init_df
+    from deepfilternet_amd.libdf import DF, _Bands
+    from deepfilternet_amd.state_dict import random_state_dict
+
+    p = ModelParams.deepfilternet3()
+    p.df_order, p.df_lookahead, p.conv_lookahead = 10, 3, 3
+    sd = random_state_dict(p, 25)
+    model, df_state, _, _ = init_df(params=p, state_dict=sd, epoch="none")
+    B, T = 256, 10 * SR
+    x = _audio(B, T, 11)
+    y = enhance(model, df_state, x)
+    model.check()
+    assert y.shape == (B, T) and bool(torch.isfinite(y).all())
+    for i in (3, 255):
+        assert torch.equal(enhance(model, df_state, x[i:i + 1]), y[i:i + 1]), i
+    sdt = {k: torch.as_tensor(v) for k, v in sd.items()}
+    rows = [17, 140]
+    ref = O.enhance(p, sdt, x[rows].cpu().numpy())
+    err = rms(y[rows].cpu().numpy() - ref)
+    assert err < 2e-6, err
+    # ---- the kernel alone at [256, 1002, 481], O = 10 (tap-major coefficients), dense rows and the engine's 64-byte aligned rows
+    Tf, F, nd, O_, la, E = 1002, 481, 96, 10, 3, 32
+    g = torch.Generator(device="cuda").manual_seed(3)
+    spec = torch.randn((B, Tf, F, 2), device="cuda", generator=g)
+    coefs = 0.3 * torch.randn((B, O_, Tf, nd, 2), device="cuda", generator=g)
+    gains = torch.rand((B, Tf, E), device="cuda", generator=g)
+    bands = _Bands.get(DF(48000, 960, 480, 32, 2).erb_widths())
+    L = _lib.lib()
+
+    def run(c, strided):
+        Fs = 488 if strided else F
+        s = torch.zeros((B, Tf, Fs, 2), device="cuda")
+        s[:, :, :F] = spec
+        out = torch.empty_like(s)
+        if strided:
+            _lib.check(L.dfx_df_apply_strided(_lib.ptr(s), Fs, _lib.ptr(c), 0, _lib.ptr(gains), bands.handle, B, Tf, F, nd, O_, la, 0.0, 0.0,
+                                              _lib.ptr(out), Fs, _lib.stream()))
+        else:
+            _lib.check(L.dfx_df_apply(_lib.ptr(s), _lib.ptr(c), 0, _lib.ptr(gains), bands.handle, B, Tf, F, nd, O_, la, 0.0, 0.0, _lib.ptr(out),
+                                      _lib.stream()))
+        return out[:, :, :F]
+
+    ya, yb = run(coefs, True), run(coefs, False)
+    assert float((ya - yb).abs().max()) < 2e-5 * float(yb.abs().max())
+    # oracle on one clip
+    b = 77
+    st = torch.view_as_complex(spec[b:b + 1].cpu().contiguous())
+    ct = torch.view_as_complex(coefs[b:b + 1].cpu().contiguous())
+    refk = st * O.band_gain(gains[b:b + 1].cpu(), DF(48000, 960, 480, 32, 2).erb_widths())
+    refk[..., :nd] = O.df_apply(st, ct, O_, la, nd)
+    assert float((torch.view_as_complex(ya[b:b + 1].cpu().contiguous()) - refk).abs().max()) < 2e-5 * float(refk.abs().max())
+    # linearity in the coefficients on the deep-filter bins: DF(2c) == 2 DF(c) exactly (powers of two), DF(c1 + c2) == DF(c1) + DF(c2) up to rounding
+    y2 = run(2.0 * coefs, True)
+    assert torch.equal(y2[..., :nd, :], 2.0 * ya[..., :nd, :])
+    c2 = 0.3 * torch.randn(coefs.shape, device="cuda", generator=g)
+    ysum = run(coefs + c2, True)[..., :nd, :]
+    ysep = ya[..., :nd, :] + run(c2, True)[..., :nd, :]
+    assert float((ysum - ysep).abs().max()) < 1e-4 * float(ysep.abs().max())

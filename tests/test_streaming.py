@@ -33,6 +33,14 @@ def test_stream_equals_batch_delayed(backend, name):
     x = torch.from_numpy((0.1 * rng.standard_normal((3, hop * T))).astype(np.float32))
     ref = enhance(model, df_state, x, pad=False)                      # batch path (itself checked against the oracle below)
     assert rms(ref.numpy() - O.enhance(p, torch_sd(p, 9), x.numpy(), pad=False)) < 2e-6
+    tol = 1e-6
+    if p.mask_pf:
+        # with a post filter the two paths are different reference code: enhance() runs the PyTorch model's filter on every bin
+        # (deepfilternet3.py:448-454), the runtime libDF's, which leaves the last (ch * F) % 4 bins of a frame alone (lib.rs:446-471)
+        from oracle import stream_oracle as S
+
+        refs = np.stack([S.process_stream(p, torch_sd(p, 9), xi, pf_beta=p.pf_beta, thresholds=(-1e9, 1e9, 1e9))[0] for xi in x.numpy()])
+        tol = 1e-4
     rt = DfStream(model, df_state, streams=3, max_frames=7)
     d = rt.delay_frames
     assert d == p.df_lookahead and rt.frame_length == hop
@@ -43,7 +51,9 @@ def test_stream_equals_batch_delayed(backend, name):
         if d:
             assert float(y[:, : d * hop].abs().max()) == 0.0  # warm-up hops are silence
         err = rms((y[:, d * hop:] - ref[:, : (T - d) * hop]).numpy())
-        assert err < 1e-6, (cuts, err)
+        assert err < tol, (cuts, err)
+        if p.mask_pf:
+            assert rms(y.numpy() - refs) < 1e-6, (cuts, rms(y.numpy() - refs))
     model.check()
 
 
@@ -62,8 +72,10 @@ def test_stream_controls(backend):
     d = rt.delay_frames
     # attenuation limit: same mix as enhance(atten_lim_db=...)
     rt.set_atten_lim(12.0)
+    rt.set_post_filter_beta(0.0)          # (with the post filter the runtime and enhance() are different reference code, see above)
+    model_nopf, _, _, _ = init_df(params=named_params("pf32_nopf"), epoch="none", seed=3)
     y = _run_stream(rt, x, [4] * (T // 4))
-    ref = enhance(model, df_state, x, pad=False, atten_lim_db=12.0)
+    ref = enhance(model_nopf, df_state, x, pad=False, atten_lim_db=12.0)
     assert rms((y[:, d * hop:] - ref[:, : (T - d) * hop]).numpy()) < 1e-6
     # |dB| < 0.01: the reference passes the input through untouched and undelayed (tract.rs:540-543)
     rt.reset()
@@ -73,7 +85,7 @@ def test_stream_controls(backend):
     rt.reset()
     rt.set_atten_lim(100.0)
     y = _run_stream(rt, x, [4] * (T // 4))
-    ref = enhance(model, df_state, x, pad=False)
+    ref = enhance(model_nopf, df_state, x, pad=False)
     assert rms((y[:, d * hop:] - ref[:, : (T - d) * hop]).numpy()) < 1e-6
     lsnr = rt.process(x[:, : hop], return_lsnr=True)[1]
     assert lsnr.shape == (2, 1) and bool(torch.isfinite(lsnr).all())
@@ -81,3 +93,32 @@ def test_stream_controls(backend):
         rt.process(x[:, : 5 * hop])      # more than max_frames
     with pytest.raises(ValueError):
         rt.process(x[:, : hop + 1])      # not a whole number of hops
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_stream_post_filter_is_libdfs(backend, channels):
+    """The real-time runtime filters with libDF's post_filter (lib.rs:446-471 via tract.rs:603-610): chunks_exact(4) over the frame's
+    flattened [ch * F] bins — mono, F = 481: the Nyquist bin is never filtered; two channels: the last two bins of the second channel —
+    not with the PyTorch model's formula on every bin (deepfilternet3.py:448-454).  The signal has energy at Nyquist, so the two differ."""
+    from deepfilternet_amd.enhance import init_df
+    from deepfilternet_amd.streaming import DfStream
+    from oracle import stream_oracle as S
+
+    if channels == 2 and emu_subset(backend):
+        pytest.skip("interpreter subset: the mono case runs here, the two-channel case on the GPU (DFX_EMU_ALL=1 runs both)")
+    p = named_params("defaults")
+    sd = torch_sd(p, 4)
+    model, df_state, _, _ = init_df(params=p, epoch="none", seed=4)
+    T = 6 if backend == "emu" else 16
+    hop = p.hop_size
+    rng = np.random.default_rng(3)
+    n = np.arange(T * hop)
+    x = (0.05 * rng.standard_normal((channels, T * hop)) + 0.2 * np.cos(np.pi * n) + 0.1 * np.cos(np.pi * n * 479 / 480)).astype(np.float32)
+    rt = DfStream(model, df_state, streams=channels, max_frames=2, channels=channels, gating=True, thresholds=(-1e9, 1e9, 1e9))
+    rt.set_post_filter_beta(0.3)
+    y = torch.cat([rt.process(torch.from_numpy(x[:, k * hop:(k + 2) * hop])) for k in range(0, T, 2)], dim=1).numpy()
+    xin = x[0] if channels == 1 else x
+    ref = S.process_stream(p, sd, xin, pf_beta=0.3, thresholds=(-1e9, 1e9, 1e9))[0].reshape(channels, -1)
+    alt = S.process_stream(p, sd, xin, pf_beta=0.3, thresholds=(-1e9, 1e9, 1e9), pf_like_torch=True)[0].reshape(channels, -1)
+    assert rms(y - ref) < 1e-6, rms(y - ref)
+    assert rms(alt - ref) > 20 * rms(y - ref) and rms(alt - ref) > 1e-5     # the test can see which filter ran
