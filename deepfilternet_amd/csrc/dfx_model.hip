@@ -669,10 +669,13 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
                 for (int o = 0; o < NO; ++o) P.out[m->cp_w2 + (size_t)n * NO + o] = has_pw ? pw[(size_t)n * NO + o] * sc[n] : (n == o ? 1.f : 0.f);
                 P.out[m->cp_b + n] = sh[n];
             }
-            // folded form: W_eff[k][c][n] = scale[n] * sum_o PW[n][o] * W1[o][c - group(o)*CG][k]   (PW = identity if absent)
-            m->cp_weff = P.alloc((size_t)kt * C * 16);
+            // folded form: W_eff[k][c][n] = scale[n] * sum_o PW[n][o] * W1[o][c - group(o)*CG][k]   (PW = identity if absent).
+            // One 16-wide MFMA tile of outputs: 2 * df_order <= 16; longer filters (BASELINE.json configs[4]: df_order = 10) take the
+            // tiled kernel dfx_k_df_convp on a materialised c0.
+            const bool folded = NO <= 16;
+            m->cp_weff = P.alloc(folded ? (size_t)kt * C * 16 : 0);
             m->cp_b16 = P.alloc(16);
-            for (int k = 0; k < kt; ++k)
+            for (int k = 0; folded && k < kt; ++k)
                 for (int ch = 0; ch < C; ++ch) {
                     const int g = ch / CG, ci = ch - g * CG;
                     for (int n = 0; n < NO; ++n) {
@@ -684,8 +687,8 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
                         P.out[m->cp_weff + ((size_t)k * C + ch) * 16 + n] = (float)(acc * (double)sc[n]);
                     }
                 }
-            for (int n = 0; n < NO; ++n) P.out[m->cp_b16 + n] = sh[n];
-            if (C % 32 == 0) {  // fragments of the fused fp16-split DF-encoder kernels (dfx_k_df_conv01_h3, dfx_k_df_convp_h3)
+            for (int n = 0; folded && n < NO; ++n) P.out[m->cp_b16 + n] = sh[n];
+            if (C % 32 == 0 && folded) {  // fragments of the fused fp16-split DF-encoder kernels (dfx_k_df_conv01_h3, dfx_k_df_convp_h3)
                 const int KC = C / 32;
                 // channel a lane (q = l>>4) feeds as element i of k-chunk kc after dfx_c0_tile
                 auto chan = [](int kc, int l, int i) { const int e = 8 * kc + i; return 16 * (e >> 2) + 4 * (l >> 4) + (e & 3); };
@@ -732,7 +735,7 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         m->convp_late = ce && ce[0] == '0';
         m->convp_after_c1 = ce && ce[0] == '2';
         const char *f0 = getenv("DFX_FUSE_C0"), *fe = getenv("DFX_FUSE_ERB");
-        m->fuse_c0 = !(f0 && f0[0] == '0') && m->cfg.df_pathway_kernel_size_t <= 5;
+        m->fuse_c0 = !(f0 && f0[0] == '0') && m->cfg.df_pathway_kernel_size_t <= 5 && 2 * m->cfg.df_order <= 16;
         m->fuse_erb = !(fe && fe[0] == '0');
         const char *fc = getenv("DFX_FINISH_CHUNKS");
         m->finish_chunked = fc && fc[0] == '1';
@@ -1378,7 +1381,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     // ---- Encoder, DF branch on x1 (deepfilternet3.py:176-179).  By default c0 = df_conv0(feat_spec) never exists in HBM: its two
     // consumers (df_conv1 here, df_convp below) recompute the tiles they need from feat_spec on the matrix core.
     const bool fuse_c0 = m->fuse_c0;
-    if (sc && !fuse_c0) DFX_FAIL(DFX_ERR_UNSUPPORTED, "streaming needs the fused DF encoder (df_pathway_kernel_size_t <= 5, DFX_FUSE_C0 unset)");
+    if (sc && !fuse_c0) DFX_FAIL(DFX_ERR_UNSUPPORTED, "streaming needs the fused DF encoder (df_pathway_kernel_size_t <= 5, df_order <= 8, DFX_FUSE_C0 unset)");
     const float *cp_feat = fuse_c0 ? feat_spec : nullptr;
     const bool fuse_h3 = fuse_c0 && !m->exact_fp32 && C % 32 == 0 && m->cp_h3;  // fp16-split matrix ops (default)
     if (fuse_c0) {
@@ -1448,7 +1451,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 default: rc = launch_convp_h3<C, 5>(m, feat_spec, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
             }
             if (rc) return rc;
-        } else if (c.df_pathway_kernel_size_t <= 5) {
+        } else if (c.df_pathway_kernel_size_t <= 5 && NO <= 16) {
             switch (c.df_pathway_kernel_size_t) {
                 case 1: rc = launch_convp2<C, 1>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
                 case 2: rc = launch_convp2<C, 2>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;

@@ -17,6 +17,10 @@ def named_params(name: str) -> ModelParams:
         p.mask_pf, p.df_lookahead, p.conv_lookahead = name == "pf32", 1, 1
         p.df_gru_skip, p.df_pathway_kernel_size_t, p.conv_ch = "identity", 3, 32
         return p
+    if name == "df3_o10":   # BASELINE.json configs[4]: deep filter of order 10 (the tiled df_convp path: 2 * df_order > 16)
+        p = ModelParams.deepfilternet3()
+        p.df_order, p.df_lookahead, p.conv_lookahead = 10, 3, 3
+        return p
     raise KeyError(name)
 
 

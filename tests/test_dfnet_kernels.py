@@ -54,7 +54,7 @@ def test_forward_matches_reference_golden(backend, name, golden_dir):
     assert coefs.shape == (g["spec"].shape[0], p.df_order, g["spec"].shape[2], p.nb_df, 2)
 
 
-@pytest.mark.parametrize("name,B,T", [("df3", 3, 21), ("defaults", 5, 9), ("pf32", 1, 1)])
+@pytest.mark.parametrize("name,B,T", [("df3", 3, 21), ("defaults", 5, 9), ("pf32", 1, 1), ("df3_o10", 2, 13)])
 def test_forward_matches_oracle_other_shapes(backend, name, B, T):
     """ragged sizes: B not a multiple of the GRU row tile, T not a multiple of the time tiles, single frame."""
     p, model = _model(name, 11)
