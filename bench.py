@@ -7,7 +7,14 @@ One "step" = one enhance() over one batch of B synthetic noisy 48 kHz clips alre
 (config.workload: DeepFilterNet3, B=256 x 10 s per GPU = BASELINE.json configs[1]; weak scaling over GPUs: every rank
 owns its own B clips, no data-path collective; the finished waveforms are gathered to rank 0 over RCCL, overlapped with
 the next step).  Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline      the north-star DF-apply kernel (fused deep filter + ERB gains): algorithmic bytes / hipEvent-timed launch
+  dtype         "f32" data and accumulation; the dense contractions of the GRU projections / recurrences and of the fused DF-encoder
+                convolutions run as fp16-split MFMAs (x = hi + lo in f16, 3 products, fp32 accumulate: ~2^-21 relative).
+                exact_fp32_ms_per_step: the same step with every contraction on the exact fp32 kernels (DFX_EXACT_FP32=1), same run.
+  roofline      the north-star DF-apply kernel (fused deep filter + ERB gains): algorithmic bytes / hipEvent-timed launch inside the
+                timed loop; roofline.standalone: the same launch timed alone (serialised extra step); rooflines: the other kernels
+                SURVEY.md §8(d) prices (GRU recurrence alone / under load vs the matrix peaks, STFT / ISTFT vs HBM)
+  configs       driver-timed BASELINE.json configs[3] (4096 streams frame by frame, DeepFilterNet3 without lookahead) and configs[4]
+                (deep filter of order 10 at batch 256: kernel roofline)
   kernels       hipEvent-timed per-kernel breakdown of one extra (untimed) step with the stream-level concurrency off
   cpu_baseline  the CPU oracle (oracle/, a port of the reference path) timed on this host on a bounded sample
 """
@@ -27,7 +34,9 @@ if REPO not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy; 6.0 plain / 6.7 non-temporal here)
+FP32_MATRIX_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32 MFMA / VALU peak
+F16_MFMA_PEAK_TF = 2500.0     # dense f16 MFMA peak (what the fp16-split kernels issue at: 3 MFMA flops per fp32-equivalent flop)
 SR, HOP, FFT = 48000, 480, 960
 
 
@@ -158,6 +167,23 @@ def main() -> None:
     assert torch.isfinite(y).all()
     model.check()  # raises if a workgroup pair of the two-CU GRU kernel ever timed out (results would be invalid)
 
+    # ---- multi-GPU: the same timed loop without the final gather (so that a scaling run can tell compute from the collective)
+    no_gather_ms = None
+    if gather:
+        for i in range(2):
+            enhance(model, df_state, x)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            enhance(model, df_state, x)
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt2 = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        dist.all_reduce(dt2, op=dist.ReduceOp.MAX)
+        no_gather_ms = float(dt2.item()) / args.steps * 1e3
+
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -168,23 +194,6 @@ def main() -> None:
     F, E, O, nd = p.freq_bins, p.nb_erb, p.df_order, p.nb_df
     bytes_per_frame = F * 8 + nd * O * 8 + E * 4 + F * 8  # read X, read coefs, read gains, write Y   
     alg_bytes = bytes_per_frame * B * Tf
-    roofline = None
-    if dfa_n:
-        avg_ms = dfa_ms / dfa_n
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "df_apply_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as f:
-                    tj = json.load(f)
-                if tj.get("batch") == B and tj.get("frames_per_clip") == Tf and tj.get("model") == args.model:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:  # noqa: BLE001
-                traffic = None
-        roofline = {"kernel": "dfx_k_df_apply", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4), "launches": dfa_n}
 
     # ---- per-kernel breakdown of one extra, untimed step, branches serialised so that kernel times do not overlap
     _lib.prof_reset()
@@ -193,8 +202,108 @@ def main() -> None:
     enhance(model, df_state, x)
     torch.cuda.synchronize()
     model.set_streams(True)
-    kern = {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in sorted(_lib.prof_read().items(), key=lambda kv: -kv[1][0])}
+    serial = _lib.prof_read()
+    kern = {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in sorted(serial.items(), key=lambda kv: -kv[1][0])}
     _lib.prof_enable(None)
+
+    def hbm_record(kernel, ms, nbytes, extra=None):
+        ach = nbytes / (ms * 1e-3) / 1e9
+        r = {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+             "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(ms, 4)}
+        r.update(extra or {})
+        return r
+
+    roofline = None
+    if dfa_n:
+        traffic, traffic_src = None, None
+        tpath = os.path.join(REPO, "profiles", "df_apply_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    tj = json.load(f)
+                if tj.get("batch") == B and tj.get("frames_per_clip") == Tf and tj.get("model") == args.model:
+                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_src = "static: profiles/df_apply_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, not measured in this run)"
+            except Exception:  # noqa: BLE001
+                traffic = None
+        roofline = hbm_record("dfx_k_df_apply", dfa_ms / dfa_n, alg_bytes,
+                              {"traffic": traffic, "traffic_source": traffic_src, "launches": dfa_n,
+                               "where": "inside the timed loop (hipEvents on the launch stream, one launch per step)"})
+        if "dfx_k_df_apply" in serial and serial["dfx_k_df_apply"][1]:
+            sm = serial["dfx_k_df_apply"][0] / serial["dfx_k_df_apply"][1]
+            roofline["standalone"] = {"avg_launch_ms": round(sm, 4), "achieved": round(alg_bytes / (sm * 1e-3) / 1e9, 1),
+                                      "frac": round(alg_bytes / (sm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                      "where": "the extra serialised step (no other queue of the process holds pending work)"}
+
+    # ---- the other kernels SURVEY.md §8(d) prices
+    rooflines = {}
+    nfr = B * Tf
+    for name, bpf in (("dfx_k_analysis", 480 * 4 + F * 8 + E * 4), ("dfx_k_synthesis", F * 8 + 480 * 4)):
+        if name in serial and serial[name][1]:
+            rooflines[name] = hbm_record(name, serial[name][0] / serial[name][1], bpf * nfr, {"where": "serialised step"})
+    nlayers = 1 + (p.emb_num_layers - 1) + p.df_num_layers
+    flop_step = 2.0 * B * 256 * 768          # h[B,256] x W_hh^T[256,768] per time step and layer (fp32-equivalent flops)
+    gru = {"kernel": "dfx_k_gru_rec_h3", "bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MATRIX_PEAK_TF, "peak_f16_mfma": F16_MFMA_PEAK_TF,
+           "flop_per_step_and_layer": flop_step, "layers": nlayers, "steps_per_layer": Tf,
+           "note": "fp32-equivalent flops; the kernel issues 3 f16 MFMA flops per flop (fp16-split). One layer = B/16 workgroups (16 CUs at B=256): "
+                   "a sequential chain, latency-bound by construction; 'frac' prices one layer-kernel against the whole chip's fp32 matrix peak"}
+    if "dfx_k_gru_rec" in serial and serial["dfx_k_gru_rec"][1]:
+        us_alone = serial["dfx_k_gru_rec"][0] * 1e3 / (nlayers * Tf)
+        gru["alone"] = {"us_per_step": round(us_alone, 3), "achieved": round(flop_step / us_alone / 1e6, 2),
+                        "frac": round(flop_step / us_alone / 1e6 / FP32_MATRIX_PEAK_TF, 4), "where": "serialised step: one layer at a time"}
+    # under load: three more steps with events around every recurrence launch (all layers and the background kernels in flight)
+    _lib.prof_reset()
+    _lib.prof_enable(["dfx_k_gru_rec"])
+    for i in range(3):
+        enhance(model, df_state, x)
+    torch.cuda.synchronize()
+    g_ms, g_n = _lib.prof_read().get("dfx_k_gru_rec", (0.0, 0))
+    _lib.prof_enable(None)
+    if g_n:
+        us_load = g_ms * 1e3 / (3 * nlayers * Tf)
+        gru["under_load"] = {"us_per_step": round(us_load, 3), "achieved": round(flop_step / us_load / 1e6, 2),
+                             "frac": round(flop_step / us_load / 1e6 / FP32_MATRIX_PEAK_TF, 4), "launches": g_n,
+                             "where": "3 extra steps of the normal pipeline (layers concurrent, projections / decoder tails beside them)"}
+        gru["achieved"], gru["frac"] = gru["under_load"]["achieved"], gru["under_load"]["frac"]
+    rooflines["dfx_k_gru_rec_h3"] = gru
+
+    # ---- exact fp32: the same step with every contraction on the exact fp32 MFMA / VALU kernels
+    exact_ms = None
+    try:
+        os.environ["DFX_EXACT_FP32"] = "1"
+        m_exact, _, _, _ = init_df(params=p, state_dict=sd, epoch="none")
+        del os.environ["DFX_EXACT_FP32"]
+        enhance(m_exact, df_state, x)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(3):
+            ye = enhance(m_exact, df_state, x)
+        torch.cuda.synchronize()
+        exact_ms = (time.perf_counter() - t1) / 3 * 1e3
+        exact_diff = float((ye - y).pow(2).mean().sqrt())
+        del m_exact, ye
+    except Exception as e:  # noqa: BLE001
+        exact_diff = repr(e)
+    finally:
+        os.environ.pop("DFX_EXACT_FP32", None)
+
+    # ---- BASELINE.json configs[3] and configs[4] (the batch model's streams are released first: a process with more streams than
+    # hardware queues makes them share queues, which serialises the streaming runtime's three branches)
+    import gc
+
+    del model
+    gc.collect()
+    torch.cuda.empty_cache()
+    configs = {}
+    try:
+        configs["streaming_4096"] = bench_streaming(dev)
+    except Exception as e:  # noqa: BLE001
+        configs["streaming_4096"] = {"error": repr(e)}
+    try:
+        configs["df_apply_o10"] = bench_df_apply_o10(dev, df_state, B, Tf)
+    except Exception as e:  # noqa: BLE001
+        configs["df_apply_o10"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
@@ -208,19 +317,88 @@ def main() -> None:
         "metric": "48 kHz audio frames/sec (hop=480), DeepFilterNet3 enhance()",
         "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (seeded harmonic+noise 48 kHz audio, seeded random DeepFilterNet3 weights)",
+        "dtype": "f32 (storage and accumulation; GRU projections / recurrences and the fused DF-encoder convolutions as fp16-split MFMAs: "
+                 "x = hi + lo in f16, hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16, ~2^-21 relative; see exact_fp32_ms_per_step)",
+        "exact_fp32_ms_per_step": exact_ms, "exact_fp32_rms_diff_of_output": exact_diff,
+        "data": "synthetic (seeded harmonic+noise 48 kHz audio, seeded random DeepFilterNet3 weights)",
         "config": {"workload": f"DeepFilterNet3 ({'recalled shipped shape, conv_ch=64' if args.model == 'df3' else 'code defaults'}) "
                                f"enhance(pad=True), batch={B} clips x {args.seconds:g} s @48 kHz per GPU, {Tf} STFT frames per clip",
                    "batch_per_gpu": B, "clip_seconds": args.seconds, "global_batch": B * world,
                    "parallelism": f"clips sharded over {world} GPU(s); " + ("async RCCL gather of waveforms to rank 0" if gather else "no collective"),
                    "inputs_resident_in_hbm": True},
-        "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
+        "ms_per_step_without_gather": no_gather_ms,
+        "roofline": roofline, "rooflines": rooflines, "configs": configs, "cpu_baseline": cpu, "kernels": kern,
         "realtime_factor": frames / dt / 100.0,
     }
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_streaming(dev, streams: int = 4096, calls: int = 100) -> dict:
+    """BASELINE.json configs[3]: DeepFilterNet3 without lookahead (the reference's low-latency LADSPA model, ladspa/README.md:3), 4096
+    concurrent streams advanced frame by frame (one hop of every stream per call = df_process_frame for all of them), with the
+    reference runtime's per-stream stage decisions (DfTract::process) on."""
+    from deepfilternet_amd.config import ModelParams
+    from deepfilternet_amd.enhance import init_df
+    from deepfilternet_amd.state_dict import random_state_dict
+    from deepfilternet_amd.streaming import DfStream
+
+    p = ModelParams.deepfilternet3_ll()
+    model, df_state, _, _ = init_df(params=p, state_dict=random_state_dict(p, 0), epoch="none")
+    out = {"workload": f"DeepFilterNet3 without lookahead, {streams} streams x 1 hop (480 samples) per call, {calls} calls, inputs resident in HBM"}
+    for tag, gating in (("ungated", False), ("stage_gating", True)):
+        rt = DfStream(model, df_state, streams=streams, max_frames=1, gating=gating)
+        x = 0.1 * torch.randn((streams, p.hop_size), device=dev)
+        for _ in range(10):
+            rt.process(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            yy = rt.process(x)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert bool(torch.isfinite(yy).all())
+        out[tag] = {"value": streams * calls / dt, "unit": "frames/s", "ms_per_call": dt / calls * 1e3, "call_budget_ms": 10.0,
+                    "realtime_streams_per_gpu": int(streams * calls / dt / 100.0),
+                    "algorithmic_latency_ms": (p.fft_size - p.hop_size + rt.delay_frames * p.hop_size) / p.sr * 1e3}
+        del rt
+    return out
+
+
+def bench_df_apply_o10(dev, df_state, B: int, Tf: int, iters: int = 20) -> dict:
+    """BASELINE.json configs[4]: the deep filter of order 10 over nb_df = 96 bins (+ ERB gains on the rest) at batch 256, the kernel alone
+    on the engine's own layout (rows of 488 bins = 64-byte aligned, tap-major coefficients); hipEvents on the launch stream."""
+    from deepfilternet_amd import _lib
+
+    F, Fs, nd, O, la, E = 481, 488, 96, 10, 3, 32
+    g = torch.Generator(device=dev).manual_seed(0)
+    spec = torch.randn((B, Tf, Fs, 2), device=dev, generator=g)
+    coefs = 0.3 * torch.randn((B, O, Tf, nd, 2), device=dev, generator=g)
+    gains = torch.rand((B, Tf, E), device=dev, generator=g)
+    out = torch.empty_like(spec)
+    L = _lib.lib()
+
+    def run():
+        _lib.check(L.dfx_df_apply_strided(_lib.ptr(spec), Fs, _lib.ptr(coefs), 0, _lib.ptr(gains), df_state.bands_handle, B, Tf, F, nd, O, la, 0.0,
+                                          0.0, _lib.ptr(out), Fs, _lib.stream()))
+
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    nbytes = (F * 8 + nd * O * 8 + E * 4 + F * 8) * B * Tf
+    ach = nbytes / (ms * 1e-3) / 1e9
+    return {"workload": f"deep filter order 10 (lookahead 3) + ERB gains, [{B}, {Tf}, 481] spectra, kernel alone", "kernel": "dfx_k_df_apply_rows<10>",
+            "bound": "hbm", "avg_launch_ms": ms, "algorithmic_bytes_per_launch": nbytes, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "frames_per_s": B * Tf / (ms * 1e-3)}
 
 
 if __name__ == "__main__":
