@@ -88,6 +88,7 @@ struct GlinW {
 #define DFX_LANE_EVENTS 12
 #define DFX_MAX_GRU_LAYERS 8   /* all GRU layers of the three stacks */
 #define DFX_MAX_TCHUNKS 16     /* time chunks of the layer-pipelined GRU phase */
+#define DFX_SEQ_GMAX 64        /* most 16-clip groups per layer the persistent GRU phase is used for (all workgroups must be co-resident) */
 struct DfxLane {
     hipStream_t main = nullptr;
     hipStream_t aux[2] = {nullptr, nullptr};
@@ -331,7 +332,13 @@ struct dfx_model {
     bool convp_late = false;  // DFX_CONVP_EARLY=0 holds df_convp back until the front is enqueued (it then starts beside the GRU phase)
     bool gru_x2 = false;      // DFX_GRU_X2=1: two-CU GRU recurrence (weights fully on chip, h halves exchanged every step);
                               // measured slower than the single-CU kernel (6.6 vs 5.2 us/step): the exchange costs ~4 us
-    unsigned int *d_err = nullptr;      // device word: a bounded spin of the two-CU GRU kernel timed out
+    // persistent GRU phase (dfx_k_gru_seq): flag words [ready: 8][emb: 1][pad][done: 8 * DFX_SEQ_GMAX], monotonic over the model's life
+    unsigned int *d_sync = nullptr;
+    mutable unsigned int seq_base = 0;  // flag value of "nothing of the current forward pass yet"
+    unsigned long long *d_trace = nullptr;   // dev aid (DFX_SEQ_TRACE=1): chunk timestamps of the last persistent GRU launch
+    mutable int trace_dims[3] = {0, 0, 0};
+    bool gru_seq = true;                // DFX_GRU_SEQ=0: one launch per (layer, time chunk) synchronised with events (round-1 form)
+    unsigned int *d_err = nullptr;      // device words: [0] a bounded spin of the two-CU GRU kernel timed out, [1] fp16-split range, [2] flag wait timed out
     mutable unsigned int epoch = 0;     // tags the h exchange of one forward pass
     const float *p(size_t off) const { return d_w + off; }
 };
@@ -747,7 +754,15 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
 
         const char *g2 = getenv("DFX_GRU_X2");
         m->gru_x2 = g2 && g2[0] == '1' && !dfx_env_is_emulator();
-        if (hipMalloc(reinterpret_cast<void **>(&m->d_err), 256) != hipSuccess || hipMemset(m->d_err, 0, 256) != hipSuccess) {
+        const char *gq = getenv("DFX_GRU_SEQ");
+        m->gru_seq = !(gq && gq[0] == '0') && !dfx_env_is_emulator();
+        {
+            const char *tq = getenv("DFX_SEQ_TRACE");
+            if (tq && tq[0] == '1') (void)hipMalloc(reinterpret_cast<void **>(&m->d_trace), (size_t)DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX * DFX_GS_MAX_CHUNKS * 3 * 8);
+        }
+        const size_t sync_bytes = (size_t)(16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX) * sizeof(unsigned int);
+        if (hipMalloc(reinterpret_cast<void **>(&m->d_sync), sync_bytes) != hipSuccess || hipMemset(m->d_sync, 0, sync_bytes) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&m->d_err), 256) != hipSuccess || hipMemset(m->d_err, 0, 256) != hipSuccess) {
             dfx_model_free(m);
             DFX_FAIL(DFX_ERR_ALLOC, "dfx_model_create: device allocation failed");
         }
@@ -802,6 +817,8 @@ extern "C" void dfx_model_free(dfx_model *m) {
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->d_err) (void)hipFree(m->d_err);
+    if (m->d_sync) (void)hipFree(m->d_sync);
+    if (m->d_trace) (void)hipFree(m->d_trace);
     if (m->d_w) (void)hipFree(m->d_w);
     delete m;
 }
@@ -826,13 +843,23 @@ extern "C" int dfx_model_set_pipeline(dfx_model *m, int time_chunks, int min_chu
 }
 extern "C" int dfx_model_check(const dfx_model *m) {
     if (!m) DFX_FAIL(DFX_ERR_INVALID_ARG, "null");
-    unsigned int e[2] = {0, 0};
+    unsigned int e[3] = {0, 0, 0};
     DFX_HIP(hipMemcpy(e, m->d_err, sizeof(e), hipMemcpyDeviceToHost));  // synchronises with the device
-    if (e[0] || e[1]) (void)hipMemset(m->d_err, 0, sizeof(e));
+    if (e[0] || e[1] || e[2]) (void)hipMemset(m->d_err, 0, sizeof(e));
+    if (e[2]) DFX_FAIL(DFX_ERR_HIP, "dfx: a flag wait of the persistent GRU phase timed out (bounded spin); the last results are invalid");
     if (e[0]) DFX_FAIL(DFX_ERR_HIP, "dfx: a workgroup pair of the two-CU GRU kernel timed out waiting for its partner; the last results are invalid");
     if (e[1])
         DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx: an activation of magnitude >= 6e4 reached an fp16-split matrix kernel (df_conv0 / df_conv1 / df_convp "
                                       "path); the last results are invalid.  DFX_EXACT_FP32=1 selects the exact fp32 kernels");
+    return DFX_OK;
+}
+// dev aid: chunk timestamps (100 MHz ticks) of the last persistent GRU launch, [layers][groups][chunks][3]; dims -> {layers, groups, chunks}
+extern "C" int dfx_model_seq_trace(const dfx_model *m, unsigned long long *out_host, int64_t cap, int *dims) {
+    if (!m || !m->d_trace || !out_host || !dims) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_seq_trace: tracing is off (DFX_SEQ_TRACE=1 at model creation)");
+    const int64_t n = (int64_t)m->trace_dims[0] * m->trace_dims[1] * m->trace_dims[2] * 3;
+    if (n > cap) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_seq_trace: buffer too small");
+    DFX_HIP(hipMemcpy(out_host, m->d_trace, (size_t)n * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 3; ++i) dims[i] = m->trace_dims[i];
     return DFX_OK;
 }
 extern "C" int dfx_model_cfg_get(const dfx_model *m, dfx_model_cfg *out) {
@@ -1278,6 +1305,17 @@ static int launch_gru_h3(const dfx_model *m, const GruW &g, const float *gi, flo
     return DFX_OK;
 }
 
+static int launch_flag_set(unsigned int *flag, unsigned int value, hipStream_t s) {
+    dfx_launch(dfx_k_flag_set, dim3(1), dim3(64), 0, s, flag, value);
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
+}
+static int launch_wait_ge(const dfx_model *m, const unsigned int *flags, int n, unsigned int target, hipStream_t s) {
+    dfx_launch(dfx_k_wait_ge, dim3(1), dim3(64), 0, s, flags, n, target, m->d_err);
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
+}
+
 // SqueezedGRU_S without its linear_in/linear_out (modules.py:702-738): layers of (input projection GEMM, recurrence).
 // x: [R,256] input; result pointer returned through *y (ping-pong between xa/xb).
 // hstate != null (streaming): layer l continues from / leaves its state in hstate + l*B*256 and only the frames [t0, T) are run
@@ -1618,6 +1656,181 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             if ((dev_skip3 & 4) && l > 0) return DFX_OK;  // dev timing ablation: no input projections for layers > 0
             return launch_proj_h3(m, g, xin, ws + w.pgi[l], Mk(k), 768, st, rmk(k));
         };
+        // ---- persistent form (default on the GPU): ONE launch runs the recurrences of all layers for the whole sequence
+        // (dfx_k_gru_seq); the projections / grouped linears / decoder tails stay per time chunk on three streams and meet the
+        // recurrences through flag words in device memory instead of events — no kernel boundary, no relaunch, no pending
+        // cross-queue barrier packet inside the phase.  Needs every (layer, group) workgroup resident at once (each owns a CU).
+        const int groups = (int)dfx_ceil_div(B, DFX_GH_ROWS);
+        const bool use_seq = m->gru_seq && !m->gru_x2 && !m->finish_chunked && groups <= DFX_SEQ_GMAX && nl * groups + 8 <= dfx_env_num_cus();
+        if (use_seq) {
+            // chunk boundaries: short chunks at the start (the next layer can begin after the first chunk + its preparation: the
+            // pipeline of 3 layers fills in ~3 short chunks instead of 3 long ones) and at the end (what is left to do after the last
+            // recurrence step is one short chunk's decoder tail), uniform in between
+            int sb[DFX_GS_MAX_CHUNKS + 1];
+            int Ks = 0;
+            {
+                // measured at batch 256 x 1002 frames (ms per step): 8 body chunks + ramp from 32: 21.28; 12 + 16: 21.91; 12, no ramp: 21.47;
+                // 6 + 32: 21.35; 4 + 32: 22.45; 16 + 16: 22.69 (the event-based form: 22.07)
+                static const int ramp0 = [] { const char *e = getenv("DFX_SEQ_RAMP"); return e ? atoi(e) : 32; }();
+                static const int kbody = [] { const char *e = getenv("DFX_SEQ_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 8; }();
+                const int64_t body = T / kbody > m->tchunk_min ? T / kbody : m->tchunk_min;   // uniform chunk length
+                std::vector<int> sizes;
+                int64_t left = T;
+                for (int64_t r = ramp0; ramp0 > 0 && r < body && left > 4 * body; r *= 2) sizes.push_back((int)r), left -= r;   // up
+                std::vector<int> down;
+                for (int64_t r = ramp0; ramp0 > 0 && r < body && left > 3 * body; r *= 2) down.push_back((int)r), left -= r;     // down
+                const int nbody = (int)std::max<int64_t>(1, std::min<int64_t>(dfx_ceil_div(left, body), DFX_GS_MAX_CHUNKS - (int64_t)sizes.size() - (int64_t)down.size()));
+                for (int i = 0; i < nbody; ++i) sizes.push_back((int)(left * (i + 1) / nbody - left * i / nbody));
+                for (auto it = down.rbegin(); it != down.rend(); ++it) sizes.push_back(*it);
+                Ks = (int)sizes.size();
+                sb[0] = 0;
+                for (int i = 0; i < Ks; ++i) sb[i + 1] = sb[i] + sizes[i];
+            }
+            const int K = Ks;   // (shadows the uniform chunk count of the event-based form)
+            auto tb = [&](int k) { return (int64_t)sb[k]; };
+            auto rmk = [&](int k) { return DfxRowMap{T, tb(k + 1) - tb(k), tb(k)}; };
+            auto Mk = [&](int k) { return B * (tb(k + 1) - tb(k)); };
+            auto proj_chunk = [&](const GruW &g, int l, int k, const float *xin, hipStream_t st) -> int {
+                return launch_proj_h3(m, g, xin, ws + w.pgi[l], Mk(k), 768, st, rmk(k));
+            };
+            const unsigned int base = m->seq_base;
+            m->seq_base += (unsigned int)K + 1u;
+            unsigned int *ready = m->d_sync, *embf = m->d_sync + 8, *done = m->d_sync + 16;
+            auto donep = [&](int l) { return done + (size_t)l * DFX_SEQ_GMAX; };
+            auto tgt = [&](int k) { return base + (unsigned int)k + 1u; };
+            hipStream_t G = ln->gs[1], Eq = ln->ts[0], Dq = ln->ts[1], Pq = ln->ps[0];
+            if ((rc = signal(EV_XA, s)) || (rc = wait(EV_XA, G)) || (rc = wait(EV_XA, Eq)) || (rc = wait(EV_XA, Dq)) || (rc = wait(EV_XA, Pq))) return rc;
+            {   // the recurrences
+                DfxGsArgs S;
+                for (int l = 0; l < DFX_GS_MAX_LAYERS; ++l) S.gi[l] = nullptr, S.y[l] = nullptr, S.whf[l] = nullptr, S.bhn[l] = nullptr, S.unscale[l] = 1.f;
+                for (int l = 0; l < nl; ++l) {
+                    const GruW &g = l == 0 ? m->enc_gru[0] : (l <= ndec ? m->dec_gru[l - 1] : m->df_gru[l - 1 - ndec]);
+                    S.gi[l] = ws + w.pgi[l];
+                    S.y[l] = ws + w.py[l];
+                    S.whf[l] = reinterpret_cast<const dfx_h8 *>(m->p(g.whh_h3));
+                    S.bhn[l] = m->p(g.bhn);
+                    S.unscale[l] = g.whh_unscale;
+                }
+                S.B = B, S.T = T, S.nlayers = nl, S.groups = groups, S.K = K;
+                for (int i = 0; i <= K; ++i) S.tb[i] = sb[i];
+                S.ready = ready, S.done = done, S.done_stride = DFX_SEQ_GMAX, S.base = base, S.err = m->d_err;
+                S.trace = m->d_trace;
+                m->trace_dims[0] = nl, m->trace_dims[1] = groups, m->trace_dims[2] = K;
+                DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_seq, DFX_GH_SMEM));
+                DfxKScope ks(DFX_K_GRU_REC, G);
+                dfx_launch(dfx_k_gru_seq, dim3((unsigned)(nl * groups)), dim3(DFX_GH_THREADS), DFX_GH_SMEM, G, S);
+                DFX_LAUNCH_CHECK();
+            }
+            // layer 0 (encoder GRU): its input xa is complete; one projection + flag per chunk
+            // (stays two chunks ahead of the recurrence instead of flooding the chip with all K projections while the decoders'
+            // first chunks are being prepared)
+            for (int k = 0; k < K; ++k) {
+                if (k >= 3 && (rc = launch_wait_ge(m, donep(0), groups, tgt(k - 3), Pq))) return rc;
+                if ((rc = proj_chunk(m->enc_gru[0], 0, k, xa, Pq)) || (rc = launch_flag_set(ready + 0, tgt(k), Pq))) return rc;
+            }
+            const int fpt = 64 / E > 0 ? 64 / E : 1;
+            const size_t co_smem = ((size_t)fpt * E * (C + 1) + (size_t)fpt * E * 3 + 3 * C) * sizeof(float);
+            // Every consumer has its own stream and walks the chunks in order: wait for its producer's flag, work, raise its own flag.
+            //   ps[l]  (decoder layers): input of layer l, chunk k = linear_out / linear_in around the producer's y + the projection
+            //   ts[0]  ERB tail (linear_out + the decoder's convolutions), ts[1] DF tail (skip + df_out), then the finishing kernels
+            for (int l = 1; l < nl; ++l)
+                if ((rc = wait(EV_XA, ln->ps[l]))) return rc;
+            // ---- ERB decoder layers
+            for (int j = 0; j < ndec; ++j) {
+                const int l = 1 + j;
+                hipStream_t st = ln->ps[l];
+                for (int k = 0; k < K; ++k) {
+                    if ((rc = launch_wait_ge(m, donep(l - 1), groups, tgt(k), st))) return rc;
+                    const float *xin = ws + w.py[l - 1];
+                    if (j == 0) {
+                        if ((rc = enc_out_skip(ws + w.py[0], Mk(k), st, rmk(k))) || (rc = launch_flag_set(embf, tgt(k), st))) return rc;
+                        if (k == K - 1 && (rc = signal(EV_EMB, st))) return rc;   // the whole embedding exists (lsnr)
+                        if ((rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, xb, Mk(k), st, rmk(k)))) return rc;
+                        xin = xb;
+                    }
+                    if ((rc = proj_chunk(m->dec_gru[j], l, k, xin, st)) || (rc = launch_flag_set(ready + l, tgt(k), st))) return rc;
+                }
+            }
+            // ---- ERB tail
+            for (int k = 0; k < K; ++k) {
+                const int64_t Rk = Mk(k);
+                const DfxRowMap rm = rmk(k);
+                if ((rc = launch_wait_ge(m, donep(ndec), groups, tgt(k), Eq))) return rc;
+                if ((rc = dec_out_skip(ws + w.py[ndec], Rk, Eq, rm))) return rc;
+                if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, Rk, E / 4, E / 4, 1, Eq, rm))) return rc;
+                if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, Rk, E / 4, E / 2, 2, Eq, rm))) return rc;
+                if (fuse_dec) {
+                    if ((rc = launch_erb_dec10<C>(m, d2, e1, e0, mask, Rk, E, Eq, rm))) return rc;
+                } else {
+                    if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, Rk, E / 2, E, 2, Eq, rm))) return rc;
+                    DfxKScope ks(DFX_K_CONV_OUT, Eq);
+                    dfx_launch(dfx_k_conv_out<C>, dim3((unsigned)nn_grid(dfx_ceil_div(Rk, fpt), 8)), dim3(DFX_CO_THREADS), co_smem, Eq,
+                               (const float *)d1, (const float *)e0, m->p(m->co_ska), m->p(m->co_skb), m->p(m->co_w), m->co_bias, mask, Rk, E,
+                               fpt, rm);
+                    DFX_LAUNCH_CHECK();
+                }
+            }
+            if ((rc = signal(EV_MASK, Eq))) return rc;
+            // ---- DF decoder layers and tail
+            if (run_df) {
+                const int lf = 1 + ndec;   // first DF layer
+                for (int j = 0; j < ndf; ++j) {
+                    const int l = lf + j;
+                    hipStream_t st = ln->ps[l];
+                    for (int k = 0; k < K; ++k) {
+                        const float *xin = ws + w.py[l - 1];
+                        if (j == 0) {
+                            if ((rc = launch_wait_ge(m, embf, 1, tgt(k), st))) return rc;
+                            if ((rc = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, Mk(k), st, rmk(k)))) return rc;
+                            xin = xa2;
+                        } else if ((rc = launch_wait_ge(m, donep(l - 1), groups, tgt(k), st))) return rc;
+                        if ((rc = proj_chunk(m->df_gru[j], l, k, xin, st)) || (rc = launch_flag_set(ready + l, tgt(k), st))) return rc;
+                    }
+                }
+                const int l = ndec + ndf;
+                if ((rc = wait(EV_C0P, Dq))) return rc;
+                for (int k = 0; k < K; ++k) {
+                    if ((rc = launch_wait_ge(m, donep(l), groups, tgt(k), Dq))) return rc;
+                    if (c.df_gru_skip == DFX_SKIP_IDENTITY) {
+                        if (k < K - 1) continue;   // the identity-skip form is not chunked: one add + df_out over all frames at the end
+                        {
+                            DfxKScope ks(DFX_K_ADD, Dq);
+                            dfx_launch(dfx_k_add, dim3((unsigned)nn_grid(dfx_ceil_div(R * 256, 256), 16)), dim3(256), 0, Dq,
+                                       (const float *)(ws + w.py[l]), (const float *)embv, xdf, R * 256);
+                        }
+                        DFX_LAUNCH_CHECK();
+                        if ((rc = launch_ggemm(xdf, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg, m->df_out.Ng,
+                                               nullptr, DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, R, Dq, NO, Fd, T)))
+                            return rc;
+                        continue;
+                    }
+                    const float *cfeat = ws + w.py[l];
+                    if (c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) {
+                        if ((rc = launch_glin(m, m->df_skip, embv, DFX_ACT_NONE, ws + w.py[l], xdf, Mk(k), Dq, rmk(k)))) return rc;
+                        cfeat = xdf;
+                    }
+                    if ((rc = launch_ggemm(cfeat, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg, m->df_out.Ng, nullptr,
+                                           DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, Mk(k), Dq, NO, Fd, T, rmk(k))))
+                        return rc;
+                }
+            }
+            // ---- lsnr on the caller's stream once the whole embedding exists (:163-165,184)
+            if ((rc = wait(EV_EMB, s))) return rc;
+            {
+                DfxKScope ks(DFX_K_LSNR, s);
+                dfx_launch(dfx_k_lsnr, dim3((unsigned)dfx_ceil_div(R * 64, 256)), dim3(256), 0, s, (const float *)embv, m->p(m->lsnr_w),
+                           m->lsnr_b, (float)(c.lsnr_max - c.lsnr_min), (float)c.lsnr_min, lsnr, R, emb);
+            }
+            DFX_LAUNCH_CHECK();
+            // the persistent launch and the layer-0 projections end before the decoders' last chunks do; join their streams all the same
+            // (on the caller's stream, which has nothing else to do until the finishing kernels are through)
+            DFX_HIP(hipEventRecord(ln->gev[0][0], G));
+            DFX_HIP(hipStreamWaitEvent(s, ln->gev[0][0], 0));
+            for (int l = 0; l < nl; ++l) {
+                DFX_HIP(hipEventRecord(ln->pev[l][0], ln->ps[l]));
+                DFX_HIP(hipStreamWaitEvent(s, ln->pev[l][0], 0));
+            }
+        } else {
         // two-CU recurrence (weights fully on chip) when all workgroup pairs of all concurrent layers fit on the chip
         const bool use_x2 = m->gru_x2 && 2 * dfx_ceil_div(B, 16) * nl <= dfx_env_num_cus();
         auto gru_chunk = [&](const GruW &g, int l, int k, hipStream_t st) -> int {
@@ -1778,6 +1991,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             if ((rc = signal(EV_FIN, st)) || (rc = wait(EV_FIN, s))) return rc;
             return DFX_OK;
         }
+        }   // !use_seq
         // The finishing kernels run on the DF tail's stream, directly behind its last df_out launch: a kernel that starts behind a
         // cross-queue join starts after ~45 us of idle chip and was measured 17 % slower for its whole duration (0.59 vs 0.50 ms
         // for the deep filter in the rocprofv3 trace, same data, nothing overlapping); behind a kernel of its own queue the gap is

@@ -1787,6 +1787,8 @@ __global__ void __launch_bounds__(DFX_GRU_THREADS, 2) dfx_k_gru_rec(const float 
 //   ring that is refilled right after use and wraps into the next step (the weights do not depend on t).
 // ---------------------------------------------------------------------------------------------------------------------
 #define DFX_GH_ROWS 16
+#define DFX_GS_MAX_LAYERS 8   /* layers one persistent dfx_k_gru_seq launch can carry */
+#define DFX_GS_MAX_CHUNKS 24  /* time chunks of the persistent GRU phase */
 #ifndef DFX_GH_ABLATE
 #define DFX_GH_ABLATE 0  /* dev ablations (tools/dev/gru_h3_bench.hip): 1 no stream refill, 2 no gi loads, 4 no matrix ops, 8 no gate math, 16 no y stores */
 #endif
@@ -1856,7 +1858,23 @@ struct DfxGhArgs {
                           // share few L2s, and L2s that other kernels can be kept away from (placement = speed only)
 };
 
-__global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_rec_h3(DfxGhArgs A) {
+// Chunk-level synchronisation of the persistent form (dfx_k_gru_seq): the time axis is cut into K chunks; chunk k of a layer may run once
+// the layer's input projection of that chunk exists (ready >= base + k + 1, written by a flag kernel behind the projection on its
+// stream) and is announced to the consumers when it is complete (done[group] = base + k + 1).  Flags are monotonic over the life of the
+// model (no resets), compared as signed differences; every spin is bounded (a timeout sets err[2] and lets the kernel run on).
+struct DfxGhSync {
+    const unsigned int *ready;   // one word: chunks of gi available for this layer
+    unsigned int *done;          // [groups]: chunks of y completed by each workgroup of this layer
+    unsigned int base;
+    int K;
+    const int *tb;               // [K + 1] chunk boundaries in frames (short chunks at both ends fill and drain the layer pipeline quickly)
+    unsigned int *err;
+    unsigned long long *trace;   // dev aid (DFX_SEQ_TRACE=1): [K][3] wall-clock ticks of this workgroup: wait begin, compute begin, chunk end
+};
+#define DFX_SYNC_SPIN_LIMIT (1 << 22)   /* polls with s_sleep: ~2 s */
+
+template <bool SEQ>
+static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_t grp, const DfxGhSync &Y) {
     constexpr int H = 256, FR = DFX_GH_FR, FS = DFX_GH_FS, NF = DFX_GH_NF, D = DFX_GH_D, HROW = DFX_GH_HROW;
     constexpr int NW = DFX_GH_NW, NS = DFX_GH_NS, TILES = DFX_GH_TILES, UW = 16 * NS;  // UW = units per wave
     static_assert(FS % D == 0 && FS >= D, "ring slots must line up across the step boundary");
@@ -1865,13 +1883,6 @@ __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_rec_h
     dfx_h8 *wl = reinterpret_cast<dfx_h8 *>(smraw);                           // [FL][wave][hi,lo][lane]
     uint16_t *h16 = reinterpret_cast<uint16_t *>(smraw + DFX_GH_SMEM_W);      // [buf][hi,lo][16][HROW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
-    int64_t grp = blockIdx.x;
-    if (A.xcd_mask) {
-        const int x = dfx_xcc_id();   // the XCD itself, not blockIdx % 8 (equal only up to a per-launch rotation)
-        if (!((A.xcd_mask >> x) & 1)) return;
-        grp = (int64_t)(blockIdx.x >> 3) * __builtin_popcount(A.xcd_mask) + __builtin_popcount(A.xcd_mask & ((1 << x) - 1));
-        if (grp * DFX_GH_ROWS >= A.B) return;
-    }
     const int64_t b0 = grp * DFX_GH_ROWS;
     const bool valid = b0 + jl < A.B;
     const int64_t brow = valid ? b0 + jl : A.B - 1;
@@ -1933,13 +1944,38 @@ __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_rec_h
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
+        for (int s = 0; s < NS; ++s) gv[g][s] = make_float4(0.1f, 0.2f, 0.3f, 0.4f);
+    const int nchunk = SEQ ? Y.K : 1;
+    const bool dead = false;
+    for (int ck = 0; ck < nchunk; ++ck) {
+    const int64_t c0 = SEQ ? (int64_t)Y.tb[ck] : A.t0, c1 = SEQ ? (int64_t)Y.tb[ck + 1] : A.t1;
+    if (SEQ) {   // the input projection of this chunk must exist
+        if (tid == 0 && Y.trace) Y.trace[ck * 3 + 0] = wall_clock64();
+        if (tid == 0 && !dead) {
+            const unsigned int want = Y.base + (unsigned int)ck + 1u;
+            int spins = 0;
+            while ((int)(__hip_atomic_load(Y.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+                if (++spins > DFX_SYNC_SPIN_LIMIT) {
+                    atomicOr(Y.err + 2, 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (tid == 0 && Y.trace) Y.trace[ck * 3 + 1] = wall_clock64();
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
         for (int s = 0; s < NS; ++s)
-            gv[g][s] = (A.t1 > A.t0 && !(DFX_GH_ABLATE & 2)) ? *reinterpret_cast<const float4 *>(gp + A.t0 * (3 * H) + g * H + 16 * s) : make_float4(0.1f, 0.2f, 0.3f, 0.4f);
-    for (int64_t t = A.t0; t < A.t1; ++t) {
+            if (c1 > c0 && !(DFX_GH_ABLATE & 2)) gv[g][s] = *reinterpret_cast<const float4 *>(gp + c0 * (3 * H) + g * H + 16 * s);
+    for (int64_t t = c0; t < c1; ++t) {
         int zoff = 0;
         DFX_OPAQUE(zoff);  // keeps the (loop-invariant) streamed weight loads inside the time loop
         const dfx_h8 *wst = wg + zoff;
-        const int64_t tn = t + 1 < A.t1 ? t + 1 : t;
+        const int64_t tn = t + 1 < c1 ? t + 1 : t;
         const uint16_t *hb = h16 + (size_t)(cur * 2) * DFX_GH_ROWS * HROW + (size_t)jl * HROW + 8 * q;
         f32x4 acc[TILES];
 #pragma unroll
@@ -2021,6 +2057,13 @@ __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_rec_h
         __syncthreads();
         cur ^= 1;
     }
+    if (SEQ) {   // this workgroup's rows of chunk ck are complete: make them visible device-wide, then say so
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(Y.done + grp, Y.base + (unsigned int)ck + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && Y.trace) Y.trace[ck * 3 + 2] = wall_clock64();
+    }
+    }
     if (A.h_out && valid) {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
@@ -2028,6 +2071,85 @@ __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_rec_h
     }
 }
 #undef DFX_GH_GIDX
+
+__global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_rec_h3(DfxGhArgs A) {
+    int64_t grp = blockIdx.x;
+    if (A.xcd_mask) {
+        const int x = dfx_xcc_id();   // the XCD itself, not blockIdx % 8 (equal only up to a per-launch rotation)
+        if (!((A.xcd_mask >> x) & 1)) return;
+        grp = (int64_t)(blockIdx.x >> 3) * __builtin_popcount(A.xcd_mask) + __builtin_popcount(A.xcd_mask & ((1 << x) - 1));
+        if (grp * DFX_GH_ROWS >= A.B) return;
+    }
+    dfx_gru_h3_run<false>(A, grp, DfxGhSync{nullptr, nullptr, 0u, 1, nullptr, nullptr, nullptr});
+}
+
+// All GRU layers of a forward pass in ONE persistent launch: workgroup (layer l, group g) keeps its share of W_hh on the CU for the
+// whole sequence and walks the K time chunks, synchronised with the kernels around it through DfxGhSync flags instead of kernel
+// boundaries.  What this removes compared with one launch per (layer, chunk): the launch gaps between chunks (45-90 us each), the wait
+// for a completely free CU at every relaunch while background kernels occupy the chip, and the pending cross-queue barrier packets
+// that were measured to slow every running kernel (tools/dev/dfa_bench.hip: -22 % with 16 waiting queues).
+// Needs all nlayers * groups workgroups co-resident (each owns a CU): the host only uses it when they fit.
+struct DfxGsArgs {
+    const float *gi[DFX_GS_MAX_LAYERS];
+    float *y[DFX_GS_MAX_LAYERS];
+    const dfx_h8 *whf[DFX_GS_MAX_LAYERS];
+    const float *bhn[DFX_GS_MAX_LAYERS];
+    float unscale[DFX_GS_MAX_LAYERS];
+    int64_t B, T;
+    int nlayers, groups, K;
+    int tb[DFX_GS_MAX_CHUNKS + 1];   // chunk boundaries (frames)
+    unsigned int *ready;   // [DFX_GS_MAX_LAYERS]
+    unsigned int *done;    // [DFX_GS_MAX_LAYERS][done_stride]
+    int done_stride;
+    unsigned int base;
+    unsigned int *err;
+    unsigned long long *trace;   // dev aid: [layers][groups][K][3] or null
+};
+__global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_seq(DfxGsArgs S) {
+    // block -> (layer, group): consecutive blocks of a layer are dealt round-robin over the XCDs, so every L2 holds a part of every
+    // layer's streamed weights (16 groups of a layer = 2 per XCD)
+    const int l = (int)(blockIdx.x / (unsigned)S.groups), g = (int)(blockIdx.x % (unsigned)S.groups);
+    if (l >= S.nlayers) return;
+    DfxGhArgs A;
+    A.gi = S.gi[l];
+    A.whf = S.whf[l];
+    A.bhn = S.bhn[l];
+    A.h_in = nullptr;
+    A.h_out = nullptr;
+    A.y = S.y[l];
+    A.B = S.B;
+    A.T = S.T;
+    A.t0 = 0;
+    A.t1 = S.T;
+    A.unscale = S.unscale[l];
+    A.xcd_mask = 0;
+    dfx_gru_h3_run<true>(A, g, DfxGhSync{S.ready + l, S.done + (size_t)l * S.done_stride, S.base, S.K, S.tb, S.err,
+                                         S.trace ? S.trace + ((size_t)l * S.groups + g) * S.K * 3 : nullptr});
+}
+
+// flag kernels of the persistent GRU phase: dfx_k_flag_set runs behind a producer on its stream (the kernel boundary in front of it
+// has made the producer's writes visible), dfx_k_wait_ge holds its stream until all n flags have reached the target
+__global__ void dfx_k_flag_set(unsigned int *flag, unsigned int value) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void dfx_k_wait_ge(const unsigned int *flags, int n, unsigned int target, unsigned int *err) {
+    bool ok = false;
+    int spins = 0;
+    while (!ok) {
+        ok = true;
+        for (int i = threadIdx.x; i < n; i += blockDim.x)
+            ok = ok && (int)(__hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0;
+        ok = __all(ok);   // one wave
+        if (!ok) {
+            if (++spins > DFX_SYNC_SPIN_LIMIT) {
+                if (threadIdx.x == 0) atomicOr(err + 2, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
 
 #ifndef DFX_HIPEMU
 // ---------------------------------------------------------------------------------------------------------------------

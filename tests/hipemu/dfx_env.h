@@ -526,6 +526,18 @@ static inline float __fmul_rn(float a, float b) { return a * b; }
 static inline float __fdiv_rn(float a, float b) { return a / b; }
 // wave-uniform values: identity on the interpreter (callers only pass values that are uniform across the wave by construction)
 static inline int dfx_wave_uniform(int v) { return v; }
+// agent-scope atomics / fences / sleep of the flag-synchronised kernels (dfx_k_gru_seq, dfx_k_wait_ge): plain accesses here — the
+// interpreter runs one launch at a time to completion, so the host never selects the persistent GRU phase on it (dfx_env_is_emulator)
+#define __HIP_MEMORY_SCOPE_AGENT 4
+template <typename T>
+static inline T __hip_atomic_load(const T *p, int, int) { return *p; }
+template <typename T, typename V>
+static inline void __hip_atomic_store(T *p, V v, int, int) { *p = (T)v; }
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline unsigned long long wall_clock64() { return 0; }
+static inline unsigned long long __ballot(int pred);
+static inline int __all(int pred) { return __ballot(!pred) == 0ull; }
 #define DFX_NT_LOAD(p) (*(p))
 #define DFX_NT_STORE(v, p) (*(p) = (v))
 // the interpreter has no XCDs: the round-robin dispatch without rotation

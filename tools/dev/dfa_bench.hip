@@ -43,6 +43,13 @@ __global__ void k_spin(long long ticks) {
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
+__global__ void k_set(unsigned int *flag, unsigned int v) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_wait(const unsigned int *flag, unsigned int target) {
+    int spins = 0;
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0 && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(16);
+}
 // one contiguous slab per workgroup instead of a grid-stride walk
 template <int U>
 __global__ void __launch_bounds__(256) k_copy_slab(const f32x4 *__restrict__ a, f32x4 *__restrict__ out, int64_t n, int64_t per_wg) {
@@ -179,6 +186,22 @@ int main(int argc, char **argv) {
             CK(hipDeviceSynchronize());
             float ms; CK(hipEventElapsedTime(&ms, a, b));
             snprintf(nm, 96, "df_apply, %d streams with pending packets (x%d)", NS, depth); report(nm, alg, ms / 10);
+        }
+        {   // the same dependency expressed with spinning wait kernels on the other streams (a flag in device memory set behind the timed launches)
+            unsigned int *flag; CK(hipMalloc(&flag, 256)); CK(hipMemset(flag, 0, 256));
+            hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, main_s, (long long)300000);
+            CK(hipEventRecord(a, main_s));
+            for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((dfx_k_df_apply_rows<5, 4, false, 7>), dim3(nblk), dim3(256), 0, main_s, R);
+            CK(hipEventRecord(b, main_s));
+            hipLaunchKernelGGL(k_set, dim3(1), dim3(64), 0, main_s, flag, 1u);
+            for (int i = 0; i < NS; ++i) {
+                hipLaunchKernelGGL(k_wait, dim3(1), dim3(64), 0, st[i], (const unsigned int *)flag, 1u);
+                hipLaunchKernelGGL((k_stream<0, 1>), dim3(64), dim3(256), 0, st[i], (const f32x4 *)spec_p, (const f32x4 *)out_d, (f32x4 *)out_p, (int64_t)1 << 16);
+            }
+            CK(hipDeviceSynchronize());
+            float ms; CK(hipEventElapsedTime(&ms, a, b));
+            snprintf(nm, 96, "df_apply, %d streams held by spinning wait kernels", NS); report(nm, alg, ms / 10);
         }
         for (auto &q : st) CK(hipStreamDestroy(q));
         CK(hipDeviceSynchronize());
