@@ -234,7 +234,8 @@ def main() -> None:
                     tj = json.load(f)
                 if tj.get("batch") == B and tj.get("frames_per_clip") == Tf and tj.get("model") == args.model:
                     traffic = tj.get("hbm_bytes_per_launch")
-                    traffic_src = "static: profiles/df_apply_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, not measured in this run)"
+                    traffic_src = ("static: profiles/df_apply_traffic.json — rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_pmc_dfa.sh) over this kernel at "
+                                   "this size, calibrated on pure-stream dispatches of the same kernel; not measured in this run (PMC needs rocprofv3)")
             except Exception:  # noqa: BLE001
                 traffic = None
         roofline = hbm_record("dfx_k_df_apply", dfa_ms / dfa_n, alg_bytes,

@@ -22,14 +22,16 @@ def series(sub, counter):
 
 fetch, write = series("pmc_fetch", "FETCH_SIZE"), series("pmc_write", "WRITE_SIZE")
 assert len(fetch) >= 8 and len(write) >= 8, (len(fetch), len(write))
-cal_read = B * T * F * 8 + 0  # the calibration dispatches read spec once (the 2 deep-filter bins read 1 coefficient each: negligible)
-cal_write = B * T * F * 8
+# the calibration dispatches of dfx_k_df_apply_rows read 241 float4 of every 488-bin row (bins 0..481; the one coefficient float4 per frame
+# of the 2-bin deep filter is counted too) and write 244 float4 (the row's 61 sectors of 64 bytes)
+cal_read = B * T * (241 + 1) * 16
+cal_write = B * T * 244 * 16
 f_cal, w_cal = sum(fetch[:4]) / 4, sum(write[:4]) / 4
 f_dfa, w_dfa = sum(fetch[4:8]) / 4, sum(write[4:8]) / 4
 read_bytes = f_dfa * cal_read / f_cal
 write_bytes = w_dfa * cal_write / w_cal
 alg = (F * 8 + nd * O * 8 + E * 4 + F * 8) * B * T
-res = {"kernel": "dfx_k_df_apply", "model": "df3", "batch": B, "frames_per_clip": T,
+res = {"kernel": "dfx_k_df_apply_rows", "model": "df3", "batch": B, "frames_per_clip": T,
        "counters": {"FETCH_SIZE_calibration": f_cal, "WRITE_SIZE_calibration": w_cal, "FETCH_SIZE": f_dfa, "WRITE_SIZE": w_dfa},
        "calibration": "bytes per counter unit from 4 pure-stream dispatches of the same kernel (nb_df=2, order=1, no gains) with known byte counts",
        "hbm_read_bytes_per_launch": round(read_bytes), "hbm_write_bytes_per_launch": round(write_bytes),
