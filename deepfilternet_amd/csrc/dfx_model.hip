@@ -71,6 +71,8 @@ extern "C" int dfx_model_blob_floats(const dfx_model_cfg *cfg, int64_t *n) {
 struct PwW {   // separable conv block: depthwise + pointwise(+BN) [+ pathway skip scalars]
     size_t dw = 0, wt = 0, bias = 0, sk_a = 0, sk_b = 0;
     bool has_skip = false;
+    size_t wt_h3 = 0;       // pointwise weights as pre-scaled f16 hi/lo MFMA fragments (dfx_chain_stage_h3), 0 = none (C % 32 != 0)
+    float unscale = 1.f;
 };
 struct GruW {
     size_t wih_t = 0, bias_i = 0, whh4 = 0, bhn = 0;
@@ -437,6 +439,17 @@ size_t pack_h3(Prep &P, int nfrag, F val, float *unscale) {
             }
     return off;
 }
+// pointwise weights of a separable block as dfx_chain_stage_h3's A fragments: fragment (nt, kc), lane l, element i = the weight of output
+// channel 16 nt + (l & 15) for input channel (C/4) (l >> 4) + 8 kc + i (lane (pos, q) owns the C/4 consecutive channels from (C/4) q)
+void pack_pw_h3(Prep &P, int C, PwW &w) {
+    if (C % 32 != 0) return;
+    const int KC = C / 32;
+    const std::vector<float> src(P.out.begin() + (long)w.wt, P.out.begin() + (long)w.wt + (size_t)C * C);   // pack_h3 may reallocate P.out
+    w.wt_h3 = pack_h3(P, (C / 16) * KC, [&](int fr, int l, int i) {
+        const int nt = fr / KC, kc = fr % KC;
+        return src[(size_t)((C / 4) * (l >> 4) + 8 * kc + i) * C + 16 * nt + (l & 15)];
+    }, &w.unscale);
+}
 bool prep_glin(Prep &P, const std::string &name, GlinW &g) {
     const DfxTensor *t = nullptr;
     const float *w = P.get(name, &t);
@@ -638,6 +651,8 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
          prep_sep(P, "erb_dec.convt1", C, m->ct1) && prep_path(P, "erb_dec.conv1p", C, m->ct1.sk_a, m->ct1.sk_b) &&
          prep_path(P, "erb_dec.conv0p", C, m->co_ska, m->co_skb);
     m->ct3.has_skip = m->ct2.has_skip = m->ct1.has_skip = true;
+    if (ok)
+        for (PwW *w : {&m->erb1, &m->erb2, &m->erb3, &m->ct3, &m->ct2, &m->ct1}) pack_pw_h3(P, C, *w);
     if (ok) {   // erb_dec.conv0_out: conv [1,C,1,3] (.0) bn(1) (.1)
         const float *w = P.get("erb_dec.conv0_out.0.weight");
         std::vector<float> sc, sh;
@@ -956,8 +971,48 @@ static int launch_pw(int mode, const dfx_model *m, const PwW &w, const float *x,
     A.Fout = Fout;
     A.stride = stride;
     A.rm = rm;
-    const int grid = nn_grid(dfx_ceil_div(R * Fout, 64), 8);
     DfxKScope ks(DFX_K_PWCONV, s);
+    // frame-staged form (coalesced loads / stores through wave-private LDS strips; same bits): whenever whole frames make whole tiles
+    static const bool staged = [] { const char *e = getenv("DFX_PW_STAGED"); return !e || atoi(e) != 0; }();
+    if (staged && dfx_pwf_ok(C, Fin, Fout)) {
+        const size_t smem = dfx_pwf_smem(C, Fin, Fout);
+        const int gridf = nn_grid(dfx_ceil_div(dfx_ceil_div(R, dfx_pwf_group(C, Fin, Fout)), 4), 2);
+        const bool n4 = dfx_pwf_nvi(C, Fin, Fout) == 4;
+        auto go = [&](auto kern) -> int {
+            DFX_HIP(dfx_env_set_max_dyn_smem((const void *)kern, smem));
+            dfx_launch(kern, dim3((unsigned)gridf), dim3(DFX_PW_THREADS), smem, s, A);
+            return DFX_OK;
+        };
+        int rc;
+        if constexpr (C % 32 == 0) {
+            if (!m->exact_fp32 && w.wt_h3) {   // fp16-split pointwise contraction (default)
+                A.wt_h3 = reinterpret_cast<const dfx_h8 *>(m->p(w.wt_h3));
+                A.unscale = w.unscale;
+                A.err = m->d_err;
+                if (mode == DFX_PW_MODE_DW3) {
+                    if (skip) rc = n4 ? go(dfx_k_pwconv_f<C, DFX_PW_MODE_DW3, true, 4, true>) : go(dfx_k_pwconv_f<C, DFX_PW_MODE_DW3, true, DFX_PWF_MAXV, true>);
+                    else rc = n4 ? go(dfx_k_pwconv_f<C, DFX_PW_MODE_DW3, false, 4, true>) : go(dfx_k_pwconv_f<C, DFX_PW_MODE_DW3, false, DFX_PWF_MAXV, true>);
+                } else {
+                    if (skip) rc = n4 ? go(dfx_k_pwconv_f<C, DFX_PW_MODE_DWT3, true, 4, true>) : go(dfx_k_pwconv_f<C, DFX_PW_MODE_DWT3, true, DFX_PWF_MAXV, true>);
+                    else rc = n4 ? go(dfx_k_pwconv_f<C, DFX_PW_MODE_DWT3, false, 4, true>) : go(dfx_k_pwconv_f<C, DFX_PW_MODE_DWT3, false, DFX_PWF_MAXV, true>);
+                }
+                if (rc) return rc;
+                DFX_LAUNCH_CHECK();
+                return DFX_OK;
+            }
+        }
+        if (mode == DFX_PW_MODE_DW3) {
+            if (skip) rc = n4 ? go(dfx_k_pwconv_f<C, DFX_PW_MODE_DW3, true, 4>) : go(dfx_k_pwconv_f<C, DFX_PW_MODE_DW3, true, DFX_PWF_MAXV>);
+            else rc = n4 ? go(dfx_k_pwconv_f<C, DFX_PW_MODE_DW3, false, 4>) : go(dfx_k_pwconv_f<C, DFX_PW_MODE_DW3, false, DFX_PWF_MAXV>);
+        } else {
+            if (skip) rc = n4 ? go(dfx_k_pwconv_f<C, DFX_PW_MODE_DWT3, true, 4>) : go(dfx_k_pwconv_f<C, DFX_PW_MODE_DWT3, true, DFX_PWF_MAXV>);
+            else rc = n4 ? go(dfx_k_pwconv_f<C, DFX_PW_MODE_DWT3, false, 4>) : go(dfx_k_pwconv_f<C, DFX_PW_MODE_DWT3, false, DFX_PWF_MAXV>);
+        }
+        if (rc) return rc;
+        DFX_LAUNCH_CHECK();
+        return DFX_OK;
+    }
+    const int grid = nn_grid(dfx_ceil_div(R * Fout, 64), 8);
     if (mode == DFX_PW_MODE_DW3) {
         if (skip) dfx_launch(dfx_k_pwconv<C, DFX_PW_MODE_DW3, true>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
         else dfx_launch(dfx_k_pwconv<C, DFX_PW_MODE_DW3, false>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
@@ -1102,9 +1157,31 @@ static int launch_erb_dec10(const dfx_model *m, const float *d2, const float *e1
     A.R = R;
     A.E = E;
     A.rm = rm;
+    DfxKScope ks(DFX_K_ERB_DEC, s);
+    static const bool staged = [] { const char *e = getenv("DFX_PW_STAGED"); return !e || atoi(e) != 0; }();
+    if (staged && dfx_dec10f_ok(C, E)) {   // whole frames streamed through LDS strips (dfx_k_erb_dec10_f)
+        DfxDec10fArgs AA;
+        AA.a = A;
+        const size_t smemf = DFX_DEC10F_SMEM(C, E);
+        const dim3 grid((unsigned)nn_grid(dfx_ceil_div(R, 4), 2));
+        if constexpr (C % 32 == 0) {
+            if (!m->exact_fp32 && m->ct1.wt_h3) {
+                AA.wt_h3 = reinterpret_cast<const dfx_h8 *>(m->p(m->ct1.wt_h3));
+                AA.unscale = m->ct1.unscale;
+                AA.err = m->d_err;
+                DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_erb_dec10_f<C, true>, smemf));
+                dfx_launch(dfx_k_erb_dec10_f<C, true>, grid, dim3(256), smemf, s, AA);
+                DFX_LAUNCH_CHECK();
+                return DFX_OK;
+            }
+        }
+        DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_erb_dec10_f<C, false>, smemf));
+        dfx_launch(dfx_k_erb_dec10_f<C, false>, grid, dim3(256), smemf, s, AA);
+        DFX_LAUNCH_CHECK();
+        return DFX_OK;
+    }
     const size_t smem = DFX_DEC10_SMEM(C, E);
     DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_erb_dec10<C>, smem));
-    DfxKScope ks(DFX_K_ERB_DEC, s);
     dfx_launch(dfx_k_erb_dec10<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R, 4), 2)), dim3(256), smem, s, A);
     DFX_LAUNCH_CHECK();
     return DFX_OK;
@@ -1129,9 +1206,21 @@ static int launch_erb_enc(const dfx_model *m, const float *feat_erb, float *e0, 
     A.L = L < 0 ? c.conv_lookahead : L;
     A.t_begin = t_begin;
     const size_t smem = DFX_ENC_SMEM(C, c.nb_erb);
-    DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_erb_enc<C>, smem));
     DfxKScope ks(DFX_K_ERB_ENC, s);
-    dfx_launch(dfx_k_erb_enc<C>, dim3((unsigned)nn_grid(dfx_ceil_div(B * (T - t_begin), 4), 2)), dim3(256), smem, s, A);
+    const dim3 grid((unsigned)nn_grid(dfx_ceil_div(B * (T - t_begin), 4), 2));
+    if constexpr (C % 32 == 0) {
+        if (!m->exact_fp32 && m->erb1.wt_h3) {   // erb_conv1's pointwise contraction on the fp16-split path
+            A.wt_h3 = reinterpret_cast<const dfx_h8 *>(m->p(m->erb1.wt_h3));
+            A.unscale = m->erb1.unscale;
+            A.err = m->d_err;
+            DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_erb_enc<C, true>, smem));
+            dfx_launch(dfx_k_erb_enc<C, true>, grid, dim3(256), smem, s, A);
+            DFX_LAUNCH_CHECK();
+            return DFX_OK;
+        }
+    }
+    DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_erb_enc<C, false>, smem));
+    dfx_launch(dfx_k_erb_enc<C, false>, grid, dim3(256), smem, s, A);
     DFX_LAUNCH_CHECK();
     return DFX_OK;
 }

@@ -125,6 +125,9 @@ struct DfxPwArgs {
     int64_t R;          // logical rows (frames) of this launch
     int Fin, Fout, stride;
     DfxRowMap rm;       // logical row -> physical row of x, skip and out (time-chunked launches)
+    const dfx_h8 *wt_h3 = nullptr;   // pointwise weights as pre-scaled f16 hi/lo fragments (dfx_k_pwconv_f<..., true>)
+    float unscale = 1.f;
+    unsigned int *err = nullptr;     // model error words ([1]: fp16-split range guard)
 };
 
 template <int C, int MODE, bool SKIP>
@@ -812,6 +815,202 @@ static __device__ __forceinline__ void dfx_chain_load_w(const float *wt, const f
     }
 }
 
+// The same stage on the fp16-split matrix path: the pointwise C x C contraction runs as hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_16x16x32_f16 (3 * C/32 matrix ops of 16 cycles per 16 output channels instead of C/4 fp32 ops of 32 cycles: the fp32
+// form keeps the matrix pipe busy for more than half of these kernels' run time).  The depthwise taps stay fp32 on the VALU; u is
+// split on the fly; lane (pos, q) feeds channels (C/4)q + 8kc + i as element i of k-chunk kc, the host packs W accordingly (pack_pw_h3).
+template <int C>
+static __device__ __forceinline__ void dfx_chain_load_w_h3(const dfx_h8 *frags, const float *bias, int lane, dfx_h8 (&ahi)[C / 16][C / 32],
+                                                           dfx_h8 (&alo)[C / 16][C / 32], float4 (&biasr)[C / 16]) {
+    constexpr int NT = C / 16, KC = C / 32;
+    const int q = lane >> 4;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            ahi[nt][kc] = frags[((size_t)(nt * KC + kc) * 2 + 0) * 64 + lane];
+            alo[nt][kc] = frags[((size_t)(nt * KC + kc) * 2 + 1) * 64 + lane];
+        }
+        biasr[nt] = reinterpret_cast<const float4 *>(bias)[4 * nt + q];
+    }
+}
+template <int C, int MODE, typename Epi>
+static __device__ __forceinline__ void dfx_chain_stage_h3(const float *in, int Fin, int Fout, int stride, int npos, const float4 *dws,
+                                                          const dfx_h8 (&ahi)[C / 16][C / 32], const dfx_h8 (&alo)[C / 16][C / 32],
+                                                          const float4 (&biasr)[C / 16], float unscale, float &amax, int lane, Epi &&epi) {
+    constexpr int CPL = C / 4, NT = C / 16, KC = C / 32, V4 = CPL / 4, LD = C + 4;
+    const int q = lane >> 4, jl = lane & 15;
+    for (int p0 = 0; p0 < npos; p0 += 16) {
+        const int p = p0 + jl;
+        const bool valid = p < npos;
+        const int fr = p / Fout, fo = p - fr * Fout;
+        float u[CPL];
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) u[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            int fi;
+            bool ok;
+            if (MODE == DFX_PW_MODE_DW3) {
+                fi = fo * stride + j - 1;
+                ok = fi >= 0 && fi < Fin;
+            } else {  // transposed: fo = 2*fi - 1 + j
+                const int num = fo + 1 - j;
+                fi = num >> 1;
+                ok = num >= 0 && (num & 1) == 0 && fi < Fin;
+            }
+            if (valid && ok) {
+                const float4 *xp = reinterpret_cast<const float4 *>(in + (fr * Fin + fi) * LD + CPL * q);
+#pragma unroll
+                for (int v = 0; v < V4; ++v) {
+                    const float4 xv = xp[v];
+                    const float4 w = dws[j * (C / 4) + V4 * q + v];
+                    u[4 * v + 0] += w.x * xv.x;
+                    u[4 * v + 1] += w.y * xv.y;
+                    u[4 * v + 2] += w.z * xv.z;
+                    u[4 * v + 3] += w.w * xv.w;
+                }
+            }
+        }
+        dfx_h8 bhi[KC], blo[KC];
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) dfx_split8_g(u + 8 * kc, bhi[kc], blo[kc], amax);
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[nt] = dfx_mfma_16x16x32_f16(alo[nt][kc], bhi[kc], acc[nt]);
+                acc[nt] = dfx_mfma_16x16x32_f16(ahi[nt][kc], blo[kc], acc[nt]);
+                acc[nt] = dfx_mfma_16x16x32_f16(ahi[nt][kc], bhi[kc], acc[nt]);
+            }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            epi(p, valid, nt,
+                make_float4(fmaxf(acc[nt][0] * unscale + biasr[nt].x, 0.f), fmaxf(acc[nt][1] * unscale + biasr[nt].y, 0.f),
+                            fmaxf(acc[nt][2] * unscale + biasr[nt].z, 0.f), fmaxf(acc[nt][3] * unscale + biasr[nt].w, 0.f)));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dfx_k_pwconv_f: dfx_k_pwconv with whole frames staged through LDS.  dfx_k_pwconv hands every lane the 64 bytes of ITS position and
+// channel quarter straight from HBM: a 16-byte load instruction of a wave then touches 16 positions x 4 quarters = 64 separate
+// 64-byte segments, and the four stores of a tile do the same — the vector cache serves such an instruction segment by segment
+// and the kernel runs at ~1.8 TB/s.  Here a wave owns G consecutive frames (G * Fout = one or more 16-position tiles): it reads
+// their G * Fin * C input floats as ONE contiguous run per frame with fully coalesced float4 loads (the pathway operand of the
+// decoder is folded in on the way: x + relu(a * skip + b)), parks them in a wave-private strip [rows][C + 4], runs
+// dfx_chain_stage on the strip (same operand roles and k order as dfx_k_pwconv: same bits), collects the D fragments in a second
+// strip and writes the G * Fout * C outputs back as contiguous float4 runs.  The next item's loads are issued before the current
+// item's matrix work; only wave-level synchronisation.
+// ---------------------------------------------------------------------------------------------------------------------
+#define DFX_PWF_MAXV 8   /* float4s per lane and item, in and out */
+static __host__ __device__ __forceinline__ int dfx_pwf_group(int C, int Fin, int Fout) {
+    int g = Fout < 16 && 16 % Fout == 0 ? 16 / Fout : 1;   // whole 16-position tiles
+    while (2 * g * Fin * (C / 4) <= 64 * 4 && 2 * g * Fout * (C / 4) <= 64 * DFX_PWF_MAXV) g *= 2;   // fill four loads per lane
+    return g;
+}
+static __host__ __device__ __forceinline__ size_t dfx_pwf_wave_floats(int C, int Fin, int Fout) {
+    return (size_t)dfx_pwf_group(C, Fin, Fout) * (size_t)(Fin + Fout) * (size_t)(C + 4);
+}
+static __host__ __device__ __forceinline__ size_t dfx_pwf_smem(int C, int Fin, int Fout) {
+    return (size_t)(5 * C / 4) * 16 + 4 * dfx_pwf_wave_floats(C, Fin, Fout) * sizeof(float);
+}
+static __host__ __device__ __forceinline__ int dfx_pwf_nvi(int C, int Fin, int Fout) {
+    return dfx_pwf_group(C, Fin, Fout) * Fin * (C / 4) <= 64 * 4 ? 4 : DFX_PWF_MAXV;
+}
+static __host__ __device__ __forceinline__ bool dfx_pwf_ok(int C, int Fin, int Fout) {
+    const int G = dfx_pwf_group(C, Fin, Fout);
+    return G * Fin * (C / 4) <= 64 * DFX_PWF_MAXV && G * Fout * (C / 4) <= 64 * DFX_PWF_MAXV && dfx_pwf_smem(C, Fin, Fout) <= 64 * 1024;
+}
+
+template <int C, int MODE, bool SKIP, int NVI /* input float4s per lane and item: 4 or DFX_PWF_MAXV */, bool H3 = false>
+__global__ void __launch_bounds__(DFX_PW_THREADS, 2) dfx_k_pwconv_f(DfxPwArgs A) {
+    constexpr int NT = C / 16, CPL = C / 4, LD = C + 4, C4 = C / 4, KC = H3 ? C / 32 : 1;
+    DFX_DYN_SMEM(float4, dfx_pwf_smem4);
+    float4 *dws = dfx_pwf_smem4, *sks = dfx_pwf_smem4 + 3 * C4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4;
+    const int G = dfx_pwf_group(C, A.Fin, A.Fout);
+    const int nrow_in = G * A.Fin, npos = G * A.Fout;
+    float *sin = reinterpret_cast<float *>(dfx_pwf_smem4 + 5 * C4) + (size_t)wave * dfx_pwf_wave_floats(C, A.Fin, A.Fout);
+    float *sout = sin + (size_t)nrow_in * LD;
+    for (int i = tid; i < 3 * C4; i += DFX_PW_THREADS) dws[i] = reinterpret_cast<const float4 *>(A.dw)[i];
+    for (int i = tid; i < 2 * C4; i += DFX_PW_THREADS)
+        sks[i] = SKIP ? (i < C4 ? reinterpret_cast<const float4 *>(A.sk_a)[i] : reinterpret_cast<const float4 *>(A.sk_b)[i - C4])
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    float areg[H3 ? 1 : NT][H3 ? 1 : CPL];
+    dfx_h8 ahi[NT][KC], alo[NT][KC];
+    float4 biasr[NT];
+    float amax = 0.f;
+    if constexpr (H3) dfx_chain_load_w_h3<C>(A.wt_h3, A.bias, lane, ahi, alo, biasr);
+    else dfx_chain_load_w<C>(A.wt, A.bias, lane, areg, biasr);
+    __syncthreads();
+    const int64_t nitems = (A.R + G - 1) / G;
+    const int nin4 = nrow_in * C4, nout4 = npos * C4, fin4 = A.Fin * C4, fout4 = A.Fout * C4;
+    const float4 *x4 = reinterpret_cast<const float4 *>(A.x);
+    const float4 *s4 = reinterpret_cast<const float4 *>(A.skip);
+    float4 *o4 = reinterpret_cast<float4 *>(A.out);
+    float4 xr[NVI], sr[SKIP ? NVI : 1];
+    auto issue = [&](int64_t item) {
+#pragma unroll
+        for (int i = 0; i < NVI; ++i) {
+            const int idx = lane + 64 * i;
+            xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (SKIP) sr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < nin4) {
+                const int fr = idx / fin4;
+                const int64_t rl = item * G + fr;
+                if (rl < A.R) {
+                    const int64_t off = dfx_row(A.rm, rl) * fin4 + (idx - fr * fin4);
+                    xr[i] = x4[off];
+                    if (SKIP) sr[i] = s4[off];
+                }
+            }
+        }
+    };
+    int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    if (item < nitems) issue(item);
+    for (; item < nitems; item += (int64_t)gridDim.x * 4) {
+#pragma unroll
+        for (int i = 0; i < NVI; ++i) {
+            const int idx = lane + 64 * i;
+            if (idx < nin4) {
+                const int row = idx / C4, c4 = idx - row * C4;
+                float4 v = xr[i];
+                if (SKIP) {
+                    const float4 sv = sr[i], a = sks[c4], bb = sks[C4 + c4];
+                    v.x += fmaxf(a.x * sv.x + bb.x, 0.f);
+                    v.y += fmaxf(a.y * sv.y + bb.y, 0.f);
+                    v.z += fmaxf(a.z * sv.z + bb.z, 0.f);
+                    v.w += fmaxf(a.w * sv.w + bb.w, 0.f);
+                }
+                *reinterpret_cast<float4 *>(sin + row * LD + 4 * c4) = v;
+            }
+        }
+        const int64_t next = item + (int64_t)gridDim.x * 4;
+        if (next < nitems) issue(next);   // in flight during this item's matrix work
+        DFX_WAVE_SYNC();
+        auto epi = [&](int p, bool valid, int nt, float4 v) {
+            if (valid) *reinterpret_cast<float4 *>(sout + p * LD + 16 * nt + 4 * q) = v;
+        };
+        if constexpr (H3) dfx_chain_stage_h3<C, MODE>(sin, A.Fin, A.Fout, A.stride, npos, dws, ahi, alo, biasr, A.unscale, amax, lane, epi);
+        else dfx_chain_stage<C, MODE>(sin, A.Fin, A.Fout, A.stride, npos, dws, areg, biasr, lane, epi);
+        DFX_WAVE_SYNC();
+#pragma unroll
+        for (int i = 0; i < DFX_PWF_MAXV; ++i) {
+            const int idx = lane + 64 * i;
+            if (idx < nout4) {
+                const int p = idx / C4, c4 = idx - p * C4;
+                const int fr = p / A.Fout;
+                const int64_t rl = item * G + fr;
+                if (rl < A.R) o4[dfx_row(A.rm, rl) * fout4 + (idx - fr * fout4)] = *reinterpret_cast<const float4 *>(sout + p * LD + 4 * c4);
+            }
+        }
+    }
+    if (H3 && amax >= DFX_H3_LIMIT && A.err) atomicOr(A.err + 1, 1u);   // a value left the f16 range of the split: reported, not hidden
+}
+
 // ERB encoder head, fused: erb_conv0 (3x3 from one channel, VALU, same arithmetic as dfx_k_conv_in_erb) -> erb_conv1 (stride 2)
 // (deepfilternet3.py:106-109,168-169).  A wave owns one frame: its E positions of e0 are one LDS strip and its E/2 positions of e1
 // one or two MFMA tiles.  e0 (the largest ERB activation) is written once and never read back by the encoder; the three feat_erb
@@ -825,14 +1024,17 @@ struct DfxEncArgs {
     int64_t B, T;
     int E, L;
     int64_t t_begin;                 // only frames [t_begin, T) of every clip are produced (streaming: the frames before are history)
+    const dfx_h8 *wt_h3 = nullptr;   // erb_conv1's pointwise weights as f16 hi/lo fragments (H3 form)
+    float unscale = 1.f;
+    unsigned int *err = nullptr;
 };
 #define DFX_ENC_FS(E) (3 * ((E) + 2))                                   /* zero-bordered feat rows of one frame */
 #define DFX_ENC_WAVE_FLOATS(C, E) ((E) * ((C) + 4) + DFX_ENC_FS(E) + 2) /* + pad to a multiple of 4 floats below */
 #define DFX_ENC_SMEM(C, E) ((size_t)(3 * (C) / 4) * 16 + (size_t)4 * ((DFX_ENC_WAVE_FLOATS(C, E) + 3) / 4 * 4) * 4)
 
-template <int C>
+template <int C, bool H3 = false>
 __global__ void __launch_bounds__(256, 2) dfx_k_erb_enc(DfxEncArgs A) {
-    constexpr int NT = C / 16, CPL = C / 4, LD = C + 4, C4 = C / 4;
+    constexpr int NT = C / 16, CPL = C / 4, LD = C + 4, C4 = C / 4, KC = H3 ? C / 32 : 1;
     DFX_DYN_SMEM(float4, sm4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4;
     const int E = A.E, E1 = E / 2, EP = E + 2;
@@ -840,9 +1042,12 @@ __global__ void __launch_bounds__(256, 2) dfx_k_erb_enc(DfxEncArgs A) {
     float *s0 = reinterpret_cast<float *>(sm4 + 3 * C4) + (size_t)wave * ((DFX_ENC_WAVE_FLOATS(C, E) + 3) / 4 * 4);  // e0 strip [E][LD]
     float *fs = s0 + E * LD;                                                                                         // [3][E + 2]
     for (int i = tid; i < 3 * C4; i += 256) dws[i] = reinterpret_cast<const float4 *>(A.dw)[i];
-    float a1[NT][CPL];
+    float a1[H3 ? 1 : NT][H3 ? 1 : CPL];
+    dfx_h8 ahi[NT][KC], alo[NT][KC];
     float4 b1[NT];
-    dfx_chain_load_w<C>(A.wt, A.bias, lane, a1, b1);
+    float amax = 0.f;
+    if constexpr (H3) dfx_chain_load_w_h3<C>(A.wt_h3, A.bias, lane, ahi, alo, b1);
+    else dfx_chain_load_w<C>(A.wt, A.bias, lane, a1, b1);
     // erb_conv0: lane -> (position slot lane / C4, channel quad lane % C4); C4 <= 16 divides 64
     const int c4 = lane % C4, pslot = lane / C4, pstep = 64 / C4;
     float4 wv[9];
@@ -892,11 +1097,14 @@ __global__ void __launch_bounds__(256, 2) dfx_k_erb_enc(DfxEncArgs A) {
             *reinterpret_cast<float4 *>(s0 + p * LD + 4 * c4) = o;
         }
         DFX_WAVE_SYNC();
-        dfx_chain_stage<C, DFX_PW_MODE_DW3>(s0, E, E1, 2, E1, dws, a1, b1, lane, [&](int p, bool valid, int nt, float4 o) {
+        auto epi = [&](int p, bool valid, int nt, float4 o) {
             if (valid) *reinterpret_cast<float4 *>(A.e1 + (r * E1 + p) * C + 16 * nt + 4 * q) = o;
-        });
+        };
+        if constexpr (H3) dfx_chain_stage_h3<C, DFX_PW_MODE_DW3>(s0, E, E1, 2, E1, dws, ahi, alo, b1, A.unscale, amax, lane, epi);
+        else dfx_chain_stage<C, DFX_PW_MODE_DW3>(s0, E, E1, 2, E1, dws, a1, b1, lane, epi);
         DFX_WAVE_SYNC();  // the strips are rewritten by the next frame
     }
+    if (H3 && amax >= DFX_H3_LIMIT && A.err) atomicOr(A.err + 1, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1081,6 +1289,140 @@ __global__ void __launch_bounds__(256, 2) dfx_k_erb_dec10(DfxDec10Args A) {
         }
         DFX_WAVE_SYNC();  // strip and V are rewritten by the next frame
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dfx_k_erb_dec10_f: the same fused decoder tail with every HBM operand streamed as whole contiguous frames (see dfx_k_pwconv_f):
+// d2 + the conv1p pathway of e1 -> in-strip [E/2][C+4]; the conv0p pathway of e0 -> xin strip [E][C+4]; dfx_chain_stage (fp32 or
+// fp16-split) adds d1 = relu(convt1) into the xin strip; the C -> 1 conv reads it back as before.  The three operand runs of the NEXT
+// frame are requested before the current frame's matrix work.  Needs E/2 * C/4 <= 256 and E * C/4 <= 512 float4s per frame.
+// ---------------------------------------------------------------------------------------------------------------------
+#define DFX_DEC10F_WAVE_FLOATS(C, E) (((E) / 2 + (E)) * ((C) + 4) + 4 * (E))
+#define DFX_DEC10F_SMEM(C, E) ((size_t)(3 * (C) / 4 + 4 * (C) / 4 + 3 * (C) / 4) * 16 + (size_t)4 * DFX_DEC10F_WAVE_FLOATS(C, E) * 4)
+static __host__ __device__ __forceinline__ bool dfx_dec10f_ok(int C, int E) {
+    return E % 2 == 0 && (E / 2) * (C / 4) <= 64 * 4 && E * (C / 4) <= 64 * 8 && DFX_DEC10F_SMEM(C, E) <= 64 * 1024;
+}
+struct DfxDec10fArgs {
+    DfxDec10Args a;
+    const dfx_h8 *wt_h3 = nullptr;
+    float unscale = 1.f;
+    unsigned int *err = nullptr;
+};
+
+template <int C, bool H3>
+__global__ void __launch_bounds__(256, 2) dfx_k_erb_dec10_f(DfxDec10fArgs AA) {
+    const DfxDec10Args &A = AA.a;
+    constexpr int NT = C / 16, CPL = C / 4, LD = C + 4, C4 = C / 4, KC = H3 ? C / 32 : 1;
+    DFX_DYN_SMEM(float4, sm4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4;
+    const int E = A.E, E1 = E / 2;
+    float4 *dws = sm4;            // [3][C/4]
+    float4 *sks = dws + 3 * C4;   // [4][C/4]: a1, b1, a0, b0
+    float4 *wos = sks + 4 * C4;   // [3][C/4]
+    float *sin = reinterpret_cast<float *>(wos + 3 * C4) + (size_t)wave * DFX_DEC10F_WAVE_FLOATS(C, E);  // convt1 input [E/2][LD]
+    float *strip = sin + E1 * LD;                                                                         // xin [E][LD]
+    float *V = strip + E * LD;                                                                            // [E][3] (+ pad)
+    for (int i = tid; i < 3 * C4; i += 256) {
+        dws[i] = reinterpret_cast<const float4 *>(A.dw)[i];
+        wos[i] = reinterpret_cast<const float4 *>(A.wo)[i];
+    }
+    for (int i = tid; i < C4; i += 256) {
+        sks[i] = reinterpret_cast<const float4 *>(A.sk1_a)[i];
+        sks[C4 + i] = reinterpret_cast<const float4 *>(A.sk1_b)[i];
+        sks[2 * C4 + i] = reinterpret_cast<const float4 *>(A.sk0_a)[i];
+        sks[3 * C4 + i] = reinterpret_cast<const float4 *>(A.sk0_b)[i];
+    }
+    float areg[H3 ? 1 : NT][H3 ? 1 : CPL];
+    dfx_h8 ahi[NT][KC], alo[NT][KC];
+    float4 biasr[NT];
+    float amax = 0.f;
+    if constexpr (H3) dfx_chain_load_w_h3<C>(AA.wt_h3, A.bias, lane, ahi, alo, biasr);
+    else dfx_chain_load_w<C>(A.wt, A.bias, lane, areg, biasr);
+    __syncthreads();
+    const int n1 = E1 * C4, n0 = E * C4;   // float4s per frame of d2 / e1 and of e0
+    const float4 *x4 = reinterpret_cast<const float4 *>(A.x), *s14 = reinterpret_cast<const float4 *>(A.skip1),
+                 *s04 = reinterpret_cast<const float4 *>(A.skip0);
+    float4 xr[4], s1r[4], s0r[8];
+    auto issue = [&](int64_t rl) {
+        const int64_t r = dfx_row(A.rm, rl);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = lane + 64 * i;
+            xr[i] = s1r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < n1) xr[i] = x4[r * n1 + idx], s1r[i] = s14[r * n1 + idx];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = lane + 64 * i;
+            s0r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < n0) s0r[i] = s04[r * n0 + idx];
+        }
+    };
+    int64_t rl = (int64_t)blockIdx.x * 4 + wave;
+    if (rl < A.R) issue(rl);
+    for (; rl < A.R; rl += (int64_t)gridDim.x * 4) {
+        const int64_t r = dfx_row(A.rm, rl);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = lane + 64 * i;
+            if (idx < n1) {
+                const int row = idx / C4, c4 = idx - row * C4;
+                float4 v = xr[i];
+                const float4 sv = s1r[i], a = sks[c4], bb = sks[C4 + c4];
+                v.x += fmaxf(a.x * sv.x + bb.x, 0.f);
+                v.y += fmaxf(a.y * sv.y + bb.y, 0.f);
+                v.z += fmaxf(a.z * sv.z + bb.z, 0.f);
+                v.w += fmaxf(a.w * sv.w + bb.w, 0.f);
+                *reinterpret_cast<float4 *>(sin + row * LD + 4 * c4) = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = lane + 64 * i;
+            if (idx < n0) {
+                const int row = idx / C4, c4 = idx - row * C4;
+                const float4 sv = s0r[i], a = sks[2 * C4 + c4], bb = sks[3 * C4 + c4];
+                *reinterpret_cast<float4 *>(strip + row * LD + 4 * c4) =
+                    make_float4(fmaxf(a.x * sv.x + bb.x, 0.f), fmaxf(a.y * sv.y + bb.y, 0.f), fmaxf(a.z * sv.z + bb.z, 0.f), fmaxf(a.w * sv.w + bb.w, 0.f));
+            }
+        }
+        const int64_t next = rl + (int64_t)gridDim.x * 4;
+        if (next < A.R) issue(next);
+        DFX_WAVE_SYNC();
+        auto epi = [&](int p, bool valid, int nt, float4 d1) {   // xin = d1 + relu(a0 * e0 + b0)
+            if (valid) {
+                float4 *dst = reinterpret_cast<float4 *>(strip + p * LD + 16 * nt + 4 * q);
+                const float4 e = *dst;
+                *dst = make_float4(d1.x + e.x, d1.y + e.y, d1.z + e.z, d1.w + e.w);
+            }
+        };
+        if constexpr (H3) dfx_chain_stage_h3<C, DFX_PW_MODE_DWT3>(sin, E1, E, 2, E, dws, ahi, alo, biasr, AA.unscale, amax, lane, epi);
+        else dfx_chain_stage<C, DFX_PW_MODE_DWT3>(sin, E1, E, 2, E, dws, areg, biasr, lane, epi);
+        DFX_WAVE_SYNC();
+        for (int i = lane; i < 3 * E; i += 64) {  // V[p][j] = sum_c wo[j][c] * xin[p][c]
+            const int p = i / 3, j = i - 3 * p;
+            const float4 *xrow = reinterpret_cast<const float4 *>(strip + p * LD);
+            float acc = 0.f;
+#pragma unroll 4
+            for (int c = 0; c < C4; ++c) {
+                const float4 x = xrow[c], w = wos[j * C4 + c];
+                acc += w.x * x.x;
+                acc += w.y * x.y;
+                acc += w.z * x.z;
+                acc += w.w * x.w;
+            }
+            V[i] = acc;
+        }
+        DFX_WAVE_SYNC();
+        for (int f = lane; f < E; f += 64) {
+            float acc = A.bias_o + V[f * 3 + 1];
+            if (f > 0) acc += V[(f - 1) * 3 + 0];
+            if (f < E - 1) acc += V[(f + 1) * 3 + 2];
+            A.out[r * E + f] = dfx_sigmoid(acc);
+        }
+        DFX_WAVE_SYNC();  // the strips and V are rewritten by the next frame
+    }
+    if (H3 && amax >= DFX_H3_LIMIT && AA.err) atomicOr(AA.err + 1, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
