@@ -13,7 +13,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_LIB = os.path.join(_HERE, "csrc", "libdfx.so")
+# DFX_LIBRARY: another build of the same library (dev: kernel-parameter variants under tools/dev/_build/); never a different backend
+DEFAULT_LIB = os.environ.get("DFX_LIBRARY") or os.path.join(_HERE, "csrc", "libdfx.so")
 
 DFX_OK = 0
 _ERRNAMES = {1: "invalid argument", 2: "unsupported configuration", 3: "HIP runtime error", 4: "no HIP device",

@@ -568,7 +568,7 @@ static bool dfx_create_lane(dfx_model *m, int l) {
         const int nl = 1 + (m->cfg.emb_num_layers - 1) + m->cfg.df_num_layers;
         for (int i = 0; i < nl && i < DFX_MAX_GRU_LAYERS; ++i) {
             if (i > 0) good = good && hipStreamCreateWithFlags(&ln.gs[i], hipStreamNonBlocking) == hipSuccess;  // layer 0 recurs on the caller's stream
-            good = good && hipStreamCreateWithFlags(&ln.ps[i], hipStreamNonBlocking) == hipSuccess;
+            good = good && hipStreamCreateWithFlags(&ln.ps[i], hipStreamNonBlocking) == hipSuccess;   // (highest priority for these was measured: the spinning wait kernels then starve every other queue, seconds per step)
             for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) {
                 good = good && hipEventCreateWithFlags(&ln.gev[i][k], hipEventDisableTiming) == hipSuccess;
                 good = good && hipEventCreateWithFlags(&ln.pev[i][k], hipEventDisableTiming) == hipSuccess;
@@ -1759,9 +1759,10 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             int Ks = 0;
             {
                 // measured at batch 256 x 1002 frames (ms per step): 8 body chunks + ramp from 32: 21.28; 12 + 16: 21.91; 12, no ramp: 21.47;
-                // 6 + 32: 21.35; 4 + 32: 22.45; 16 + 16: 22.69 (the event-based form: 22.07)
+                // 6 + 32: 21.35; 4 + 32: 22.45; 16 + 16: 22.69 (the event-based form: 22.07); after the decoder convolutions went to the
+                // staged fp16-split kernels (lighter background): 8 + 32: 20.1; 10 + 32: 19.85; 12 + 32: 19.99; 12 + 16: 20.27; 16 + 32: 21.0
                 static const int ramp0 = [] { const char *e = getenv("DFX_SEQ_RAMP"); return e ? atoi(e) : 32; }();
-                static const int kbody = [] { const char *e = getenv("DFX_SEQ_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 8; }();
+                static const int kbody = [] { const char *e = getenv("DFX_SEQ_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 10; }();
                 const int64_t body = T / kbody > m->tchunk_min ? T / kbody : m->tchunk_min;   // uniform chunk length
                 std::vector<int> sizes;
                 int64_t left = T;

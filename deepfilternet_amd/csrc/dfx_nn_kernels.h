@@ -522,7 +522,10 @@ struct DfxC01hArgs {
 // stay in registers; the pointwise fragments (16 KB) and the biases are read from LDS where they are used, and the feat_spec
 // patch of the next tile is requested as soon as the current one has been split.
 template <int C>
-__global__ void __launch_bounds__(DFX_PW_THREADS, 2) dfx_k_df_conv01_h3(DfxC01hArgs A) {
+#ifndef DFX_C01_MINB
+#define DFX_C01_MINB 3   /* three waves per SIMD (168 registers): 2.2 -> 1.6 ms at config 2; the range guard pushed the two-wave build to 178 */
+#endif
+__global__ void __launch_bounds__(DFX_PW_THREADS, DFX_C01_MINB) dfx_k_df_conv01_h3(DfxC01hArgs A) {
     constexpr int CPL = C / 4, NT = C / 16, KC = C >= 32 ? C / 32 : 1, C4 = C / 4;
     static_assert(C % 32 == 0, "one k-chunk is 32 channels");
     __shared__ float4 dws[3 * C4];
@@ -2142,14 +2145,14 @@ __global__ void __launch_bounds__(DFX_GRU_THREADS, 2) dfx_k_gru_rec(const float 
 #define DFX_GH_TILES (3 * DFX_GH_NS)        /* accumulator tiles per wave */
 #define DFX_GH_NF (8 * DFX_GH_TILES)        /* fragment pairs a wave consumes per step (8 k-chunks) */
 #ifndef DFX_GH_FR
-#define DFX_GH_FR 33     /* pairs per wave resident in registers */
+#define DFX_GH_FR 27     /* pairs per wave resident in registers (33 with a 4-slot ring measured 0.2 ms slower per step under load) */
 #endif
 #ifndef DFX_GH_FL
 #define DFX_GH_FL 15     /* pairs per wave resident in LDS */
 #endif
 #define DFX_GH_FS (DFX_GH_NF - DFX_GH_FR - DFX_GH_FL)
 #ifndef DFX_GH_D
-#define DFX_GH_D 4       /* ring slots for the streamed pairs */
+#define DFX_GH_D 6       /* ring slots for the streamed pairs */
 #endif
 #define DFX_GH_HROW 264  /* halves per row of the f16 copy of h (256 + 8 pad) */
 #define DFX_GH_SMEM_W ((size_t)DFX_GH_FL * DFX_GH_NW * 2 * 64 * 16)

@@ -79,8 +79,10 @@ static __device__ __forceinline__ void dfx_split8(const float *x, dfx_h8 &hi, df
 // hi half is inf; the kernels report amax >= DFX_H3_LIMIT through the model's error word instead of handing back garbage)
 #define DFX_H3_LIMIT 6.0e4f
 static __device__ __forceinline__ void dfx_split8_g(const float *x, dfx_h8 &hi, dfx_h8 &lo, float &amax) {
+#ifndef DFX_NO_H3_GUARD   /* dev: cost of the guard */
     amax = fmaxf(amax, fmaxf(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))),
                              fmaxf(fmaxf(fabsf(x[4]), fabsf(x[5])), fmaxf(fabsf(x[6]), fabsf(x[7])))));
+#endif
     dfx_split8(x, hi, lo);
 }
 // D[i][j] += sum_k A[i][k] B[k][j]; lane l: A row i = l&15, B col j = l&15, both hold k = 8*(l>>4) .. +7; D: col = l&15, row = 4*(l>>4)+r
