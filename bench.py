@@ -340,7 +340,7 @@ def main() -> None:
         "metric": "48 kHz audio frames/sec (hop=480), DeepFilterNet3 enhance()",
         "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (storage and accumulation; GRU projections / recurrences and the fused DF-encoder convolutions as fp16-split MFMAs: "
+        "dtype": "f32 (storage and accumulation; GRU projections / recurrences, the fused DF-encoder convolutions and the pointwise halves of the ERB separable convolutions as fp16-split MFMAs: "
                  "x = hi + lo in f16, hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16, ~2^-21 relative; see exact_fp32_ms_per_step)",
         "exact_fp32_ms_per_step": exact_ms, "exact_fp32_rms_diff_of_output": exact_diff,
         "data": "synthetic (seeded harmonic+noise 48 kHz audio, seeded random DeepFilterNet3 weights)",
