@@ -80,6 +80,7 @@ SIGNATURES = {
     "dfx_model_free": (None, [_vp]),
     "dfx_model_save_file": (_i, [C.POINTER(ModelCfg), _f32p, C.c_char_p]),
     "dfx_model_load_file": (_i, [C.c_char_p, C.POINTER(_vp)]),
+    "dfx_onnx_targz_read": (_i, [C.c_char_p, C.POINTER(ModelCfg), _f32p, _i64, C.POINTER(_i64)]),
     "dfx_model_cfg_get": (_i, [_vp, C.POINTER(ModelCfg)]),
     "dfx_model_set_streams": (_i, [_vp, _i]),
     "dfx_model_set_run_df": (_i, [_vp, _i]),

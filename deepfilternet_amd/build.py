@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 REPO = os.path.dirname(HERE)
 LIB = os.path.join(CSRC, "libdfx.so")
-SOURCES = ["dfx_dsp.hip", "dfx_model.hip", "dfx_capi.hip", "dfx_io.hip", "dfx_mf.hip"]
+SOURCES = ["dfx_dsp.hip", "dfx_model.hip", "dfx_capi.hip", "dfx_io.hip", "dfx_mf.hip", "dfx_onnx.hip"]
 ARCH = "gfx950"
 
 
@@ -74,7 +74,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out)
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB + ".tmp"]
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-lz", "-o", LIB + ".tmp"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")

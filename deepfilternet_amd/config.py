@@ -113,6 +113,8 @@ class ModelParams:
     pf_beta: float = 0.02
     lsnr_dropout: bool = False
     model: str = "deepfilternet3"
+    # set when the artefact states the smoothing factor itself (config.ini `norm_alpha` of an exported model, tract.rs:279-284)
+    norm_alpha_value: Optional[float] = None
 
     # ---- constructors -------------------------------------------------------------------------------------------
     @classmethod
@@ -174,6 +176,8 @@ class ModelParams:
 
     def norm_alpha(self) -> float:
         """DeepFilterNet/df/utils.py:111-127 get_norm_alpha(): exp(-hop/sr/tau) rounded to >=3 digits, < 1."""
+        if self.norm_alpha_value is not None:
+            return float(self.norm_alpha_value)
         a_ = math.exp(-(self.hop_size / self.sr) / self.norm_tau)
         precision, a = 3, 1.0
         while a >= 1.0:

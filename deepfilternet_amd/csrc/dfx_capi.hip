@@ -44,13 +44,27 @@ static int read_model_file(const char *path, dfx_model_cfg *cfg, std::vector<flo
     return DFX_OK;
 }
 
-extern "C" int dfx_model_load_file(const char *path, dfx_model **out) {
+int dfx_read_onnx_targz(const char *path, dfx_model_cfg *cfg, std::vector<float> *blob, std::string *version);  // dfx_onnx.hip
+
+// .dfx file or the reference's <model>_onnx.tar.gz (gzip magic 1f 8b); `version` receives the tar's version.txt
+static int load_model_any(const char *path, dfx_model **out, std::string *version) {
     if (!path || !out) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_load_file: null argument");
+    unsigned char magic[2] = {0, 0};
+    FILE *f = fopen(path, "rb");
+    if (!f) DFX_FAIL(DFX_ERR_INVALID_ARG, "cannot open model file '%s'", path);
+    const size_t got = fread(magic, 1, 2, f);
+    fclose(f);
     dfx_model_cfg cfg;
     std::vector<float> blob;
-    if (int rc = read_model_file(path, &cfg, &blob)) return rc;
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+        if (int rc = dfx_read_onnx_targz(path, &cfg, &blob, version)) return rc;
+    } else if (int rc = read_model_file(path, &cfg, &blob)) {
+        return rc;
+    }
     return dfx_model_create(&cfg, blob.data(), out);
 }
+
+extern "C" int dfx_model_load_file(const char *path, dfx_model **out) { return load_model_any(path, out, nullptr); }
 
 // ---------------------------------------------------------------------------------------------------- df_* (capi.rs)
 struct DFState {
@@ -90,7 +104,8 @@ extern "C" DFState *df_create(const char *path, float atten_lim, const char *log
     DFState *s = new DFState();
     s->logging = log_level != nullptr;
     dfx_model_cfg c;
-    bool ok = dfx_model_load_file(path, &s->model) == DFX_OK && dfx_model_cfg_get(s->model, &c) == DFX_OK &&
+    std::string version;
+    bool ok = load_model_any(path, &s->model, &version) == DFX_OK && dfx_model_cfg_get(s->model, &c) == DFX_OK &&
               dfx_state_create(c.sr, c.fft_size, c.hop_size, c.nb_erb, c.min_nb_freqs, &s->st) == DFX_OK &&
               dfx_stream_create(s->model, s->st, 1, 1, &s->rt) == DFX_OK &&
               dfx_stream_set_gating(s->rt, 1) == DFX_OK &&
@@ -106,6 +121,7 @@ extern "C" DFState *df_create(const char *path, float atten_lim, const char *log
         df_destroy(s);
         return nullptr;
     }
+    if (!version.empty()) s->msg("INFO", "Loading model with id: " + version);  // tract.rs:56-59
     char buf[160];
     snprintf(buf, sizeof(buf), "Running with model type deepfilternet3 lookahead %d", dfx_stream_delay_frames(s->rt));  // tract.rs:318-322
     s->msg("INFO", buf);

@@ -56,9 +56,15 @@ def init_df(
             raise FileNotFoundError(
                 f"pretrained model '{model_base_dir or default_model}' is not available offline; pass a model directory "
                 "with config.ini + checkpoints/, or params=/state_dict=")
-        if not os.path.isdir(model_base_dir):
+        if os.path.isfile(model_base_dir) and model_base_dir.endswith(".tar.gz"):
+            # extension: the reference's exported artefact (<model>_onnx.tar.gz, tract.rs:29-70) in place of a model directory
+            from .model import read_onnx_targz
+
+            p, state_dict = read_onnx_targz(model_base_dir)
+        elif not os.path.isdir(model_base_dir):
             raise NotADirectoryError("Base directory not found at {}".format(model_base_dir))
-        p = ModelParams.from_ini(os.path.join(model_base_dir, "config.ini"), must_exist=True)
+        else:
+            p = ModelParams.from_ini(os.path.join(model_base_dir, "config.ini"), must_exist=True)
     else:
         p = params
     if post_filter:
@@ -66,7 +72,7 @@ def init_df(
     df_state = DF(sr=p.sr, fft_size=p.fft_size, hop_size=p.hop_size, nb_bands=p.nb_erb, min_nb_erb_freqs=p.min_nb_freqs)
     ep = 0
     from_checkpoint = False
-    if state_dict is None and load_cp and model_base_dir is not None:
+    if state_dict is None and load_cp and model_base_dir is not None and os.path.isdir(model_base_dir):
         state_dict, ep = read_cp(os.path.join(model_base_dir, "checkpoints"), epoch)
         if state_dict is None:
             raise FileNotFoundError("Could not find a checkpoint")  # reference: logger.error + exit(1)

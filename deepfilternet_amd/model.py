@@ -229,6 +229,33 @@ def read_cp(dirname: str, epoch="best") -> Tuple[Optional[Dict[str, torch.Tensor
 
 
 # ---------------------------------------------------------------------------------------------------- .dfx model files
+def read_onnx_targz(path: str) -> Tuple[ModelParams, Dict[str, np.ndarray]]:
+    """The reference's shipped artefact, ``<model>_onnx.tar.gz`` (tract.rs:29-70 ``DfParams::from_targz``; export.py:331-337), as
+    (ModelParams, state-dict with the reference's key names).  All the reading happens in libdfx (``dfx_onnx_targz_read``,
+    csrc/dfx_onnx.hip): DSP parameters from config.ini, structure and weights from the three ONNX graphs; BatchNorm layers come back
+    as the exporter folded them (identity statistics, the folded bias as ``bias``)."""
+    L = _lib.lib()
+    cfg = _lib.ModelCfg()
+    n = C.c_int64()
+    _lib.check(L.dfx_onnx_targz_read(os.fsencode(path), C.byref(cfg), None, 0, C.byref(n)))
+    blob = np.empty(n.value, dtype=np.float32)
+    _lib.check(L.dfx_onnx_targz_read(os.fsencode(path), C.byref(cfg), blob.ctypes.data_as(C.POINTER(C.c_float)), n.value, C.byref(n)))
+    skip = {v: k for k, v in _SKIP.items()}
+    p = ModelParams(sr=cfg.sr, fft_size=cfg.fft_size, hop_size=cfg.hop_size, nb_erb=cfg.nb_erb, nb_df=cfg.nb_df,
+                    min_nb_freqs=cfg.min_nb_freqs, df_order=cfg.df_order, df_lookahead=cfg.df_lookahead, lsnr_min=cfg.lsnr_min,
+                    lsnr_max=cfg.lsnr_max, conv_lookahead=cfg.conv_lookahead, conv_ch=cfg.conv_ch, emb_hidden_dim=cfg.emb_hidden_dim,
+                    emb_num_layers=cfg.emb_num_layers, df_hidden_dim=cfg.df_hidden_dim, df_num_layers=cfg.df_num_layers,
+                    df_gru_skip=skip[cfg.df_gru_skip], df_pathway_kernel_size_t=cfg.df_pathway_kernel_size_t, lin_groups=cfg.lin_groups,
+                    enc_lin_groups=cfg.enc_lin_groups, mask_pf=bool(cfg.mask_pf), pf_beta=cfg.pf_beta,
+                    emb_gru_skip_enc=skip[cfg.emb_gru_skip_enc], emb_gru_skip=skip[cfg.emb_gru_skip], enc_concat=bool(cfg.enc_concat),
+                    norm_alpha_value=float(cfg.norm_alpha))
+    sd = {}
+    for name, shape, off in tensor_manifest(cfg):
+        k = int(np.prod(shape)) if shape else 1
+        sd[name] = blob[off:off + k].reshape(shape).copy()
+    return p, sd
+
+
 def export_dfx(path: str, model_base_dir: Optional[str] = None, epoch="best", *, params: Optional[ModelParams] = None,
                state_dict: Optional[Dict[str, "np.ndarray | torch.Tensor"]] = None) -> str:
     """Writes the model file that the C API's ``df_create(path, ...)`` (include/df_capi.h == libDF/src/capi.rs:83-104) and

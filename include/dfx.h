@@ -173,7 +173,14 @@ void dfx_model_free(dfx_model *m);
  * deepfilternet_amd.export_dfx from a reference model directory or state-dict).  It is what df_create() (include/df_capi.h, the
  * reference's C API) takes as its model path, in place of the reference's tar.gz of ONNX graphs (tract.rs:37-70). */
 int dfx_model_save_file(const dfx_model_cfg *cfg, const float *blob_host, const char *path);
+/* Takes either file kind (told apart by their magic bytes): a .dfx file, or the reference's own `<model>_onnx.tar.gz` (below). */
 int dfx_model_load_file(const char *path, dfx_model **out);
+/* The reference's shipped model artefact (libDF/src/tract.rs:29-70 DfParams::from_targz; written by
+ * DeepFilterNet/df/scripts/export.py:331-337): a gzip'ed tar of enc.onnx, erb_dec.onnx, df_dec.onnx and config.ini.  The DSP
+ * parameters come from the config.ini keys DfTract::new reads (tract.rs:264-315), the network structure and the weights from the
+ * three ONNX graphs (BatchNorm as folded by the exporter, GRU gates re-ordered z,r,h -> r,z,n); the result is the
+ * (configuration, packed state-dict blob) pair of dfx_model_create().  blob_out may be NULL to query *blob_floats. */
+int dfx_onnx_targz_read(const char *path, dfx_model_cfg *cfg_out, float *blob_out, int64_t blob_cap, int64_t *blob_floats);
 int dfx_model_cfg_get(const dfx_model *m, dfx_model_cfg *out);
 /* The forward pass runs its independent branches (ERB encoder/decoder | DF encoder/decoder | df_convp) on internal
  * streams, forked from and joined to the caller's stream with events.  enable = 0 serialises everything on the caller's

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(REPO, "deepfilternet_amd", "csrc")
 OUT = os.path.join(HERE, "_build", "libdfx_emu.so")
-SOURCES = ["dfx_dsp.hip", "dfx_model.hip", "dfx_capi.hip", "dfx_io.hip", "dfx_mf.hip"]
+SOURCES = ["dfx_dsp.hip", "dfx_model.hip", "dfx_capi.hip", "dfx_io.hip", "dfx_mf.hip", "dfx_onnx.hip"]
 
 
 def _deps():
@@ -46,7 +46,7 @@ def build(force: bool = False) -> str:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"g++ failed on {src}:\n{out}")
-    r = subprocess.run(["g++", "-shared", "-fPIC", *objs, "-o", OUT + ".tmp"], stdout=subprocess.PIPE,
+    r = subprocess.run(["g++", "-shared", "-fPIC", *objs, "-lz", "-o", OUT + ".tmp"], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")

@@ -1,0 +1,210 @@
+"""the reference's shipped model artefact, ``<model>_onnx.tar.gz`` (enc.onnx + erb_dec.onnx + df_dec.onnx + config.ini;
+written by DeepFilterNet/df/scripts/export.py:133-337, opened by libDF/src/tract.rs:29-70), read directly by libdfx
+(csrc/dfx_onnx.hip: gzip/tar, config.ini, a protobuf wire reader and a structural match of the graphs against DeepFilterNet3).
+
+Fixture: ``tests/golden/df3s_onnx.tar.gz`` was produced by ``tools/gen_golden_onnx.py`` from the REFERENCE's own ``DfNet`` (seeded
+weights) through ``torch.onnx.export`` with export.py's argument lists; ``tests/golden/onnx_df3s.npz`` holds the reference's own
+``enhance()`` output for that model.  The ``needs_reference`` cases export further configurations on the fly (build container only).
+"""
+import ctypes as C
+import gzip
+import io
+import os
+import tarfile
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import rms
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TARGZ = os.path.join(REPO, "tests", "golden", "df3s_onnx.tar.gz")
+SEED = 11
+
+
+def _expected():
+    from deepfilternet_amd.state_dict import random_state_dict
+    from tools.gen_golden_onnx import quantise_gru, small_params
+
+    p = small_params()
+    sd = random_state_dict(p, SEED)
+    quantise_gru(sd)
+    return p, sd
+
+
+def _check_against_state_dict(p, sd, q, ref):
+    """Structure as exported, GRU / grouped-linear / lsnr weights bit-exact, convolutions = the seeded weights with BatchNorm folded."""
+    for f in ("sr", "fft_size", "hop_size", "nb_erb", "nb_df", "min_nb_freqs", "df_order", "df_lookahead", "conv_lookahead", "conv_ch",
+              "emb_hidden_dim", "emb_num_layers", "df_hidden_dim", "df_num_layers", "df_gru_skip", "df_pathway_kernel_size_t", "lin_groups",
+              "enc_lin_groups", "emb_gru_skip_enc", "emb_gru_skip", "enc_concat", "lsnr_min", "lsnr_max"):
+        assert getattr(p, f) == getattr(q, f), f
+    assert abs(p.norm_alpha() - q.norm_alpha()) < 1e-7
+    n_exact = n_conv = 0
+    for k, v in sd.items():
+        leaf = k.rsplit(".", 1)[-1]
+        if ".gru." in k or v.ndim == 3 or "lsnr_fc" in k:
+            assert np.array_equal(v, np.asarray(ref[k]).reshape(v.shape)), k
+            n_exact += 1
+        elif v.ndim == 4:
+            base, idx = k[: -len(".weight")].rsplit(".", 1)
+            bn = f"{base}.{int(idx) + 1}"
+            if bn + ".running_var" in ref:      # the conv right in front of the BatchNorm carries the folded scale
+                s = np.asarray(ref[bn + ".weight"], np.float64) / np.sqrt(np.asarray(ref[bn + ".running_var"], np.float64) + 1e-5)
+                want = np.asarray(ref[k], np.float64) * s.reshape(-1, 1, 1, 1)
+                shift = np.asarray(ref[bn + ".bias"], np.float64) - np.asarray(ref[bn + ".running_mean"], np.float64) * s
+                assert np.abs(v - want).max() <= 2e-6 * np.abs(want).max(), k
+                assert np.abs(sd[bn + ".bias"] - shift).max() <= 2e-6 * max(1.0, np.abs(shift).max()), bn
+                assert np.all(sd[bn + ".weight"] == 1) and np.all(sd[bn + ".running_mean"] == 0)
+                assert np.all((sd[bn + ".running_var"] + np.float32(1e-5)).astype(np.float32) == 1)
+                n_conv += 1
+            else:
+                assert np.array_equal(v, ref[k]), k
+        else:
+            assert leaf in ("weight", "bias", "running_mean", "running_var"), k
+    return n_exact, n_conv
+
+
+def test_reader_recovers_structure_and_weights(backend):
+    from deepfilternet_amd.model import read_onnx_targz
+
+    if backend != "emu":
+        pytest.skip("host-side reader: one backend is enough")
+    q, ref = _expected()
+    p, sd = read_onnx_targz(TARGZ)
+    n_exact, n_conv = _check_against_state_dict(p, sd, q, ref)
+    assert n_exact == 22 and n_conv == 15      # 3 GRU layers x 4 + 9 grouped linears + lsnr_fc; every Conv2dNormAct block
+
+
+def test_enhance_from_targz_matches_reference(backend, golden_dir):
+    """init_df(<tar.gz>) -> enhance() against the reference's own enhance() with the model the archive was exported from."""
+    from deepfilternet_amd.enhance import enhance, init_df
+
+    g = np.load(os.path.join(golden_dir, "onnx_df3s.npz"))
+    model, df_state, suffix, _ = init_df(TARGZ)
+    assert suffix == "df3s_onnx.tar.gz"
+    audio = torch.from_numpy(g["audio"][:1, :4800 * 2] if backend == "emu" else g["audio"])
+    y = enhance(model, df_state, audio, pad=True).cpu().numpy()
+    want = g["y_pad"][: y.shape[0], : y.shape[1]]
+    if backend == "emu":    # a shorter clip: the prefix is independent of what follows beyond the lookahead + one frame
+        n = y.shape[1] - 4 * 480
+        assert rms(y[:, :n] - want[:, :n]) < 2e-6, rms(y[:, :n] - want[:, :n])
+    else:
+        assert rms(y - want) < 2e-6, rms(y - want)
+
+
+def test_df_create_takes_the_reference_archive(backend, tmp_path):
+    """df_create(path) of the reference's C API (capi.rs:83-103) on the archive itself; same frames as on the .dfx file of the seeded
+    state-dict (BatchNorm folded by the exporter there, by the engine here: equal to rounding), version.txt is logged (tract.rs:56-59)."""
+    from deepfilternet_amd import _lib, export_dfx
+    from tests.test_capi import HOP, _capi, _process
+
+    q, ref = _expected()
+    dfx = export_dfx(str(tmp_path / "model.dfx"), params=q, state_dict=ref)
+    lib = _capi(C.CDLL(_lib.library_path()))
+    T = 4 if backend == "emu" else 16
+    x = (0.1 * np.random.default_rng(3).standard_normal(HOP * T)).astype(np.float32)
+    outs = []
+    for path, level in ((TARGZ, b"info"), (dfx, None)):
+        st = lib.df_create(os.fsencode(path), 100.0, level)
+        assert st
+        if level:
+            msgs = []
+            while True:
+                m = lib.df_next_log_msg(st)
+                if not m:
+                    break
+                msgs.append(C.cast(m, C.c_char_p).value.decode())
+                lib.df_free_log_msg(m)
+            assert any("Loading model with id: df3s_epoch_0" in m for m in msgs), msgs
+            assert any("lookahead 2" in m for m in msgs), msgs
+        outs.append(_process(lib, st, x))
+        lib.df_free(st)
+    (y1, l1), (y2, l2) = outs
+    assert rms(y1) > 0 or T <= 4
+    assert rms(y1 - y2) < 1e-6 and np.abs(l1 - l2).max() < 1e-3
+
+
+def _repack(edit):
+    """The fixture with members renamed / dropped / rewritten: {basename: bytes | None | (new name, bytes)}."""
+    buf = io.BytesIO()
+    with tarfile.open(TARGZ, "r:gz") as src, tarfile.open(fileobj=buf, mode="w:gz", compresslevel=1) as dst:
+        for m in src.getmembers():
+            data = src.extractfile(m).read()
+            base = os.path.basename(m.name)
+            if base in edit:
+                if edit[base] is None:
+                    continue
+                data = edit[base]
+            info = tarfile.TarInfo(m.name)
+            info.size = len(data)
+            dst.addfile(info, io.BytesIO(data))
+    return buf.getvalue()
+
+
+def test_bad_archives_are_refused_with_the_reason(backend, tmp_path):
+    from deepfilternet_amd import _lib
+    from deepfilternet_amd.model import read_onnx_targz
+
+    if backend != "emu":
+        pytest.skip("host-side reader: one backend is enough")
+    with tarfile.open(TARGZ, "r:gz") as t:
+        ini = [t.extractfile(m).read() for m in t.getmembers() if m.name.endswith("config.ini")][0].decode()
+        enc = [t.extractfile(m).read() for m in t.getmembers() if m.name.endswith("/enc.onnx")][0]
+    cases = {
+        "no_erb_dec": ({"erb_dec.onnx": None}, "not all present"),
+        "df2": ({"config.ini": ini.replace("model = deepfilternet3", "model = deepfilternet2").encode()}, "DeepFilterNet2 models are deprecated"),
+        "other_model": ({"config.ini": ini.replace("model = deepfilternet3", "model = foo").encode()}, "Unsupported model type foo"),
+        "no_sr": ({"config.ini": ini.replace("sr = 48000\n", "").encode()}, "option 'sr' missing"),
+        "order": ({"config.ini": ini.replace("df_order = 5", "df_order = 4").encode()}, "df_order 4"),
+        "swapped": ({"erb_dec.onnx": enc}, "erb_dec.onnx"),
+        "truncated_graph": ({"enc.onnx": enc[: len(enc) // 2]}, "onnx"),
+    }
+    for name, (edit, msg) in cases.items():
+        f = tmp_path / f"{name}.tar.gz"
+        f.write_bytes(_repack(edit))
+        with pytest.raises(_lib.DfxError, match=msg):
+            read_onnx_targz(str(f))
+    f = tmp_path / "plain.tar.gz"
+    f.write_bytes(b"\x1f\x8bnot really gzip")
+    with pytest.raises(_lib.DfxError, match="gzip"):
+        read_onnx_targz(str(f))
+    # legacy placement (config.py:171-206 / tract.rs:270-278): df_order and df_lookahead in [deepfilternet]
+    lines = [l for l in ini.splitlines() if not l.startswith(("df_order", "df_lookahead"))]
+    i = lines.index("[deepfilternet]")
+    legacy = "\n".join(lines[: i + 1] + ["df_order = 5", "df_lookahead = 2"] + lines[i + 1:]) + "\n"
+    f = tmp_path / "legacy.tar.gz"
+    f.write_bytes(_repack({"config.ini": legacy.encode()}))
+    p, _ = read_onnx_targz(str(f))
+    assert (p.df_order, p.df_lookahead) == (5, 2)
+    # norm_alpha stated in the ini wins over norm_tau (tract.rs:279-284)
+    f = tmp_path / "alpha.tar.gz"
+    f.write_bytes(_repack({"config.ini": ini.replace("[df]\n", "[df]\nnorm_alpha = 0.985\n").encode()}))
+    assert abs(read_onnx_targz(str(f))[0].norm_alpha() - 0.985) < 1e-7
+
+
+@pytest.mark.needs_reference
+@pytest.mark.parametrize("case", ["df3_opset14", "skip_id_gl", "skip_gl_id", "concat", "defaults_order3"])
+def test_exports_of_other_configurations(backend, case, tmp_path):
+    """Exported here, by the reference's modules, then read back: every structural switch the graphs can carry."""
+    from deepfilternet_amd.config import ModelParams
+    from deepfilternet_amd.model import read_onnx_targz
+    from tools.gen_golden_onnx import make
+    from tools.gen_golden_r2 import opt_cases
+    from tools.ref_import import install_shims
+
+    if backend != "emu":
+        pytest.skip("host-side reader: one backend is enough")
+    install_shims()
+    opset = 12
+    if case == "df3_opset14":
+        q, opset = ModelParams.deepfilternet3(), 14
+    elif case == "defaults_order3":
+        q = ModelParams.defaults()
+        q.df_order, q.lsnr_min, q.lsnr_max, q.df_num_layers = 3, -10, 30, 2
+    else:
+        q = opt_cases()[case][0]
+    path = str(tmp_path / f"{case}_onnx.tar.gz")
+    _, _, ref = make(q, 5, path, opset=opset, quantise=False, name=case)
+    p, sd = read_onnx_targz(path)
+    _check_against_state_dict(p, sd, q, ref)
