@@ -151,8 +151,11 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    dev_sync = os.environ.get("DFX_BENCH_DEV_SYNC") == "1"   # dev diagnosis only (the host waits for every step: no enqueue-ahead)
     for i in range(args.steps):
         y = step(i)
+        if dev_sync:
+            torch.cuda.synchronize()
     drain()
     torch.cuda.synchronize()
     if dist is not None:

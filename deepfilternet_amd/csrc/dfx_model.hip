@@ -316,6 +316,13 @@ struct dfx_model {
     //   stream plays that role) + two auxiliary streams for the independent branches of the forward pass + fork/join events
     DfxLane lanes[DFX_MAX_LANES];
     hipEvent_t ev_fork = nullptr;
+    // One big pass in flight per handle: a call that would enqueue a multi-stream pass while the previous one is still running first
+    // waits (on the host) for that one to drain.  Packets queued ahead on the pass's ~13 hardware queues slow the running pass — measured
+    // at config 2: 19.45 ms per step with free enqueue-ahead, 18.8 ms when the host holds the next step back (DF-apply inside the loop
+    // 0.60 -> 0.50 ms, the rate it has alone).  DFX_ENQUEUE_AHEAD=1 restores the unthrottled enqueue.
+    hipEvent_t ev_pass = nullptr;
+    mutable bool pass_pending = false;
+    bool enqueue_ahead = false;
     bool concurrent = false;
     bool have_streams = false;
     int max_chunks = 1;       // batch chunks pipelined by dfx_enhance (DFX_CHUNKS; measured: no gain over time-chunk pipelining)
@@ -340,6 +347,12 @@ struct dfx_model {
     unsigned long long *d_trace = nullptr;   // dev aid (DFX_SEQ_TRACE=1): chunk timestamps of the last persistent GRU launch
     mutable int trace_dims[3] = {0, 0, 0};
     bool gru_seq = true;                // DFX_GRU_SEQ=0: one launch per (layer, time chunk) synchronised with events (round-1 form)
+    // The encoder front per time chunk UNDER the persistent GRU launch (DFX_FRONT_OVERLAP=0: the whole front first, then the GRU phase):
+    // the recurrences of chunk k only need the front of chunk k, and the chain (80 of 256 CUs) is what bounds the step.
+    bool front_overlap = false;
+    int front_ahead = 0;                // DFX_FRONT_AHEAD=n > 0: the front stays at most n chunks ahead of the encoder GRU
+    int front_split = 1;                // DFX_FRONT_SPLIT=n: (test hook) the front in n time ranges, one after the other, without overlap
+    mutable unsigned int seq_started = 0;  // workgroups of all persistent GRU launches so far (the front waits until they are resident)
     unsigned int *d_err = nullptr;      // device words: [0] a bounded spin of the two-CU GRU kernel timed out, [1] fp16-split range, [2] flag wait timed out
     mutable unsigned int epoch = 0;     // tags the h exchange of one forward pass
     const float *p(size_t off) const { return d_w + off; }
@@ -771,6 +784,10 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         m->gru_x2 = g2 && g2[0] == '1' && !dfx_env_is_emulator();
         const char *gq = getenv("DFX_GRU_SEQ");
         m->gru_seq = !(gq && gq[0] == '0') && !dfx_env_is_emulator();
+        const char *fo = getenv("DFX_FRONT_OVERLAP"), *fa = getenv("DFX_FRONT_AHEAD"), *fsp = getenv("DFX_FRONT_SPLIT");
+        m->front_overlap = fo && fo[0] == '1';
+        m->front_ahead = fa ? atoi(fa) : 0;
+        m->front_split = fsp && atoi(fsp) > 1 ? atoi(fsp) : 1;
         {
             const char *tq = getenv("DFX_SEQ_TRACE");
             if (tq && tq[0] == '1') (void)hipMalloc(reinterpret_cast<void **>(&m->d_trace), (size_t)DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX * DFX_GS_MAX_CHUNKS * 3 * 8);
@@ -790,6 +807,11 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
             // that share a queue serialise each other.  Lane 0 gets exactly the streams its model needs; lanes 1.. (batch-chunk
             // pipelining, off by default) are created on demand by dfx_model_set_pipeline.
             bool good = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) == hipSuccess;
+            good = good && hipEventCreateWithFlags(&m->ev_pass, hipEventDisableTiming) == hipSuccess;
+            {
+                const char *ea = getenv("DFX_ENQUEUE_AHEAD");
+                m->enqueue_ahead = ea && ea[0] == '1';
+            }
             good = good && dfx_create_lane(m, 0);
             for (int l = 1; l < m->max_chunks && good; ++l) good = dfx_create_lane(m, l);
             if (!good) {
@@ -831,6 +853,7 @@ extern "C" void dfx_model_free(dfx_model *m) {
         if (ln.aux_lo) (void)hipStreamDestroy(ln.aux_lo);
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_pass) (void)hipEventDestroy(m->ev_pass);
     if (m->d_err) (void)hipFree(m->d_err);
     if (m->d_sync) (void)hipFree(m->d_sync);
     if (m->d_trace) (void)hipFree(m->d_trace);
@@ -1026,8 +1049,10 @@ static int launch_pw(int mode, const dfx_model *m, const PwW &w, const float *x,
 
 template <int C, int KT>
 static int launch_convp2(const dfx_model *m, const float *c0, const float *feat_spec, float *out, int64_t B, int64_t T, int Fd,
-                         int NO, hipStream_t s, int64_t t_begin = 0, int64_t t_zero = 0, int L = -1) {
+                         int NO, hipStream_t s, int64_t t_begin = 0, int64_t t_zero = 0, int L = -1, int64_t t_end = -1) {
+    if (t_end < 0) t_end = T;
     DfxCp2Args A;
+    A.t_end = t_end;
     A.c0 = c0;
     A.feat = feat_spec;  // non-null: df_conv0 is recomputed on the fly, c0 is not read
     A.weff0 = m->p(m->cin_weff);
@@ -1046,7 +1071,7 @@ static int launch_convp2(const dfx_model *m, const float *c0, const float *feat_
     // enough independent wave-runs to fill the chip (each run re-reads KT-1 halo frames): target >= 8 waves per SIMD-slot
     const int64_t want = (int64_t)dfx_env_num_cus() * 4 * 8;
     int64_t nseg = dfx_ceil_div(want, B * A.nfb);
-    const int64_t Tn = T - t_begin;  // frames produced
+    const int64_t Tn = t_end - t_begin;  // frames produced
     const int64_t max_seg = dfx_ceil_div(Tn, (int64_t)8 * KT);
     if (nseg > max_seg) nseg = max_seg;
     if (nseg < 1) nseg = 1;
@@ -1064,11 +1089,13 @@ static int launch_convp2(const dfx_model *m, const float *c0, const float *feat_
 
 template <int C, int KT>
 static int launch_convp_h3(const dfx_model *m, const float *feat_spec, float *out, int64_t B, int64_t T, int Fd, int NO,
-                           hipStream_t s, int64_t t_begin = 0, int64_t t_zero = 0, int L = -1) {
+                           hipStream_t s, int64_t t_begin = 0, int64_t t_zero = 0, int L = -1, int64_t t_end = -1) {
     if constexpr (C % 32 != 0) {
         DFX_FAIL(DFX_ERR_UNSUPPORTED, "fp16-split df_convp needs conv_ch %% 32 == 0");
     } else {
+        if (t_end < 0) t_end = T;
         DfxCphArgs A;
+        A.t_end = t_end;
         A.feat = feat_spec;
         A.w0f = reinterpret_cast<const dfx_h8 *>(m->p(m->c0_h3));
         A.bias0 = m->p(m->cin_b);
@@ -1088,7 +1115,7 @@ static int launch_convp_h3(const dfx_model *m, const float *feat_spec, float *ou
         A.nfb = (Fd + 15) / 16;
         const int64_t want = (int64_t)dfx_env_num_cus() * 4 * 4;  // two resident waves per SIMD, two rounds
         int64_t nseg = dfx_ceil_div(want, B * A.nfb);
-        const int64_t Tn = T - t_begin;  // frames produced
+        const int64_t Tn = t_end - t_begin;  // frames produced
         const int64_t max_seg = dfx_ceil_div(Tn, (int64_t)8 * KT);
         if (nseg > max_seg) nseg = max_seg;
         if (nseg < 1) nseg = 1;
@@ -1106,11 +1133,13 @@ static int launch_convp_h3(const dfx_model *m, const float *feat_spec, float *ou
 
 template <int C>
 static int launch_conv01_h3(const dfx_model *m, const PwW &w, const float *feat_spec, float *out, int64_t B, int64_t T, int Fin,
-                            int Fout, int stride, hipStream_t s, int64_t t_begin = 0, int L = -1) {
+                            int Fout, int stride, hipStream_t s, int64_t t_begin = 0, int L = -1, int64_t t_end = -1) {
     if constexpr (C % 32 != 0) {
         DFX_FAIL(DFX_ERR_UNSUPPORTED, "fp16-split df_conv1 needs conv_ch %% 32 == 0");
     } else {
+        if (t_end < 0) t_end = T;
         DfxC01hArgs A;
+        A.t_end = t_end;
         A.feat = feat_spec;
         A.w0f = reinterpret_cast<const dfx_h8 *>(m->p(m->c0_h3));
         A.bias0 = m->p(m->cin_b);
@@ -1128,7 +1157,7 @@ static int launch_conv01_h3(const dfx_model *m, const PwW &w, const float *feat_
         A.unscale0 = m->c0_unscale;
         A.unscale = m->dfc1_unscale;
         A.err = m->d_err;
-        const int grid = nn_grid(dfx_ceil_div(B * (T - t_begin) * Fout, 64), 3);
+        const int grid = nn_grid(dfx_ceil_div(B * (t_end - t_begin) * Fout, 64), 3);
         DfxKScope ks(DFX_K_PWCONV, s);
         dfx_launch(dfx_k_df_conv01_h3<C>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
         DFX_LAUNCH_CHECK();
@@ -1189,9 +1218,11 @@ static int launch_erb_dec10(const dfx_model *m, const float *d2, const float *e1
 
 template <int C>
 static int launch_erb_enc(const dfx_model *m, const float *feat_erb, float *e0, float *e1, int64_t B, int64_t T, hipStream_t s,
-                          int64_t t_begin = 0, int L = -1) {
+                          int64_t t_begin = 0, int L = -1, int64_t t_end = -1) {
     const dfx_model_cfg &c = m->cfg;
+    if (t_end < 0) t_end = T;
     DfxEncArgs A;
+    A.t_end = t_end;
     A.feat = feat_erb;
     A.w0 = m->p(m->erb0_w);
     A.b0 = m->p(m->erb0_b);
@@ -1207,7 +1238,7 @@ static int launch_erb_enc(const dfx_model *m, const float *feat_erb, float *e0, 
     A.t_begin = t_begin;
     const size_t smem = DFX_ENC_SMEM(C, c.nb_erb);
     DfxKScope ks(DFX_K_ERB_ENC, s);
-    const dim3 grid((unsigned)nn_grid(dfx_ceil_div(B * (T - t_begin), 4), 2));
+    const dim3 grid((unsigned)nn_grid(dfx_ceil_div(B * (t_end - t_begin), 4), 2));
     if constexpr (C % 32 == 0) {
         if (!m->exact_fp32 && m->erb1.wt_h3) {   // erb_conv1's pointwise contraction on the fp16-split path
             A.wt_h3 = reinterpret_cast<const dfx_h8 *>(m->p(m->erb1.wt_h3));
@@ -1228,8 +1259,10 @@ static int launch_erb_enc(const dfx_model *m, const float *feat_erb, float *e0, 
 // enc.df_conv0 -> enc.df_conv1 without the c0 round trip (dfx_k_df_conv01)
 template <int C>
 static int launch_conv01(const dfx_model *m, const PwW &w, const float *feat_spec, float *out, int64_t B, int64_t T, int Fin,
-                         int Fout, int stride, hipStream_t s, int64_t t_begin = 0, int L = -1) {
+                         int Fout, int stride, hipStream_t s, int64_t t_begin = 0, int L = -1, int64_t t_end = -1) {
+    if (t_end < 0) t_end = T;
     DfxC01Args A;
+    A.t_end = t_end;
     A.feat = feat_spec;
     A.weff0 = m->p(m->cin_weff);
     A.bias0 = m->p(m->cin_b);
@@ -1244,7 +1277,7 @@ static int launch_conv01(const dfx_model *m, const PwW &w, const float *feat_spe
     A.stride = stride;
     A.L = L < 0 ? m->cfg.conv_lookahead : L;
     A.t_begin = t_begin;
-    const int grid = nn_grid(dfx_ceil_div(B * (T - t_begin) * Fout, 64), 8);
+    const int grid = nn_grid(dfx_ceil_div(B * (t_end - t_begin) * Fout, 64), 8);
     DfxKScope ks(DFX_K_PWCONV, s);
     dfx_launch(dfx_k_df_conv01<C>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
     DFX_LAUNCH_CHECK();
@@ -1327,8 +1360,15 @@ static int launch_proj_h3(const dfx_model *m, const GruW &g, const float *a, flo
     A.rm = rm;
     const int64_t nblk = dfx_ceil_div(M, DFX_PH_BM);
     if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "projection grid too large");
-    DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_proj256_h3, DFX_PH_SMEM));
     DfxKScope ks(DFX_K_PROJ, s);
+    static const int row_tiles = [] { const char *e = getenv("DFX_PROJ_RT"); return e ? atoi(e) : 2; }();   // DFX_PROJ_RT=1: one row tile per wave
+    if (row_tiles == 2) {
+        DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_proj256_h3x2<8>, DFX_PH_SMEM));
+        dfx_launch(dfx_k_proj256_h3x2<8>, dim3((unsigned)dfx_ceil_div(M, 256)), dim3(512), DFX_PH_SMEM, s, A);
+        DFX_LAUNCH_CHECK();
+        return DFX_OK;
+    }
+    DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_proj256_h3, DFX_PH_SMEM));
     dfx_launch(dfx_k_proj256_h3, dim3((unsigned)nblk), dim3(DFX_PH_THREADS), DFX_PH_SMEM, s, A);
     DFX_LAUNCH_CHECK();
     return DFX_OK;
@@ -1511,40 +1551,66 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     if (sc && !fuse_c0) DFX_FAIL(DFX_ERR_UNSUPPORTED, "streaming needs the fused DF encoder (df_pathway_kernel_size_t <= 5, df_order <= 8, DFX_FUSE_C0 unset)");
     const float *cp_feat = fuse_c0 ? feat_spec : nullptr;
     const bool fuse_h3 = fuse_c0 && !m->exact_fp32 && C % 32 == 0 && m->cp_h3;  // fp16-split matrix ops (default)
-    if (fuse_c0) {
-        if ((rc = signal(EV_C0, x1)) || (rc = wait(EV_C0, x2))) return rc;  // df_convp only needs feat_spec
-        if (fuse_h3) rc = launch_conv01_h3<C>(m, m->dfc1, feat_spec, c1, B, T, Fd, Fd / 2, 2, x1, t_begin, Lk);
-        else rc = launch_conv01<C>(m, m->dfc1, feat_spec, c1, B, T, Fd, Fd / 2, 2, x1, t_begin, Lk);
-        if (rc) return rc;
-    } else {
-        DfxCinArgs A;
-        A.feat = feat_spec;
-        A.weff = m->p(m->cin_weff);
-        A.bias = m->p(m->cin_b);
-        A.out = c0;
-        A.B = B;
-        A.T = T;
-        A.Fin = Fd;
-        A.L = L;
-        A.t_begin = 0;
-        A.out_T = T;
-        A.out_toff = 0;
-        DfxKScope ks(DFX_K_CONV_IN_DF, x1);
-        dfx_launch(dfx_k_conv_in_df<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R * Fd, 64), 8)), dim3(DFX_PW_THREADS), 0, x1, A);
-        DFX_LAUNCH_CHECK();
-        if ((rc = signal(EV_C0, x1)) || (rc = wait(EV_C0, x2))) return rc;
-        if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->dfc1, c0, nullptr, c1, R, Fd, Fd / 2, 2, x1))) return rc;
-    }
-    if ((rc = signal(EV_C1, x1))) return rc;
+    const bool fuse_dec = E % 2 == 0 && m->fuse_erb && 2 * DFX_DEC10_SMEM(C, E) <= (size_t)160 * 1024;
+    const bool fuse_enc = E % 2 == 0 && 3 * (E + 2) <= 192 && m->fuse_erb && 2 * DFX_ENC_SMEM(C, E) <= (size_t)160 * 1024;
+    if (sc && !fuse_enc) DFX_FAIL(DFX_ERR_UNSUPPORTED, "streaming needs the fused ERB encoder head (DFX_FUSE_ERB unset)");
     const DfxGate *gate = sc ? sc->gate : nullptr;
     if (gate && T - t_begin != 1) DFX_FAIL(DFX_ERR_INVALID_ARG, "gated streaming passes carry exactly one new frame");
-    auto run_convp = [&]() -> int {
-        // ---- df_dec.df_convp on x2 (only needs c0; :328)
-        if (gate && c.df_pathway_kernel_size_t > 1) {
+    // ---- How the GRU phase will run — decided before the front, because its persistent form starts UNDER the front.
+    // Layer-pipelined over time chunks when the fp16-split kernels are in use: every GRU layer has its own
+    // stream; layer l may run chunk k as soon as layer l-1 has produced chunk k, so the three-layer chain
+    // enc -> dec1 -> dec2 (and enc -> df1 -> df2) costs T*(1 + 2/K) steps instead of 3T.  Each layer-kernel occupies B/16
+    // CUs; the per-chunk projections and grouped linears address their rows through a DfxRowMap.
+    int K = m->tchunks;
+    if (T / K < m->tchunk_min) K = (int)(T / m->tchunk_min);
+    const int nenc = (int)m->enc_gru.size(), ndec = (int)m->dec_gru.size(), ndf = run_df ? (int)m->df_gru.size() : 0;
+    const bool pipe = par && !sc && !m->exact_fp32 && K > 1 && nenc == 1 && 1 + ndec + ndf <= DFX_MAX_GRU_LAYERS && ln == &m->lanes[0];
+    const int nl = 1 + ndec + ndf;
+    // persistent form (default on the GPU): ONE launch runs the recurrences of all layers for the whole sequence
+    // (dfx_k_gru_seq); needs every (layer, group) workgroup resident at once (each owns a CU)
+    const int groups = (int)dfx_ceil_div(B, DFX_GH_ROWS);
+    const bool use_seq = pipe && m->gru_seq && !m->gru_x2 && !m->finish_chunked && groups <= DFX_SEQ_GMAX && nl * groups + 8 <= dfx_env_num_cus();
+    int sb[DFX_GS_MAX_CHUNKS + 1];   // chunk boundaries of the persistent form
+    int Ks = 0;
+    if (use_seq) {
+        // short chunks at the start (the next layer can begin after the first chunk + its preparation: the
+        // pipeline of 3 layers fills in ~3 short chunks instead of 3 long ones) and at the end (what is left to do after the last
+        // recurrence step is one short chunk's decoder tail), uniform in between
+        // measured at batch 256 x 1002 frames (ms per step): 8 body chunks + ramp from 32: 21.28; 12 + 16: 21.91; 12, no ramp: 21.47;
+        // 6 + 32: 21.35; 4 + 32: 22.45; 16 + 16: 22.69 (the event-based form: 22.07); after the decoder convolutions went to the
+        // staged fp16-split kernels (lighter background): 8 + 32: 20.1; 10 + 32: 19.85; 12 + 32: 19.99; 12 + 16: 20.27; 16 + 32: 21.0
+        static const int ramp0 = [] { const char *e = getenv("DFX_SEQ_RAMP"); return e ? atoi(e) : 32; }();
+        static const int kbody = [] { const char *e = getenv("DFX_SEQ_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 10; }();
+        const int64_t body = T / kbody > m->tchunk_min ? T / kbody : m->tchunk_min;   // uniform chunk length
+        std::vector<int> sizes;
+        int64_t left = T;
+        for (int64_t r = ramp0; ramp0 > 0 && r < body && left > 4 * body; r *= 2) sizes.push_back((int)r), left -= r;   // up
+        std::vector<int> down;
+        for (int64_t r = ramp0; ramp0 > 0 && r < body && left > 3 * body; r *= 2) down.push_back((int)r), left -= r;     // down
+        const int nbody = (int)std::max<int64_t>(1, std::min<int64_t>(dfx_ceil_div(left, body), DFX_GS_MAX_CHUNKS - (int64_t)sizes.size() - (int64_t)down.size()));
+        for (int i = 0; i < nbody; ++i) sizes.push_back((int)(left * (i + 1) / nbody - left * i / nbody));
+        for (auto it = down.rbegin(); it != down.rend(); ++it) sizes.push_back(*it);
+        Ks = (int)sizes.size();
+        sb[0] = 0;
+        for (int i = 0; i < Ks; ++i) sb[i + 1] = sb[i] + sizes[i];
+    }
+    // The front kernels that take a frame range [t0, t1) (everything but the materialised-c0 and the tiled df_convp forms): the front can
+    // then run range by range — under the persistent GRU launch (overlap), or as a test of the ranges themselves (DFX_FRONT_SPLIT)
+    const int kt = c.df_pathway_kernel_size_t;
+    const bool front_ranges = fuse_c0 && fuse_enc && !sc && !c.enc_concat && (!run_df || fuse_h3 || (kt <= 5 && NO <= 16));
+    const bool overlap = use_seq && m->front_overlap && front_ranges && Ks <= DFX_MAX_TCHUNKS;
+    // df_conv0 -> df_conv1 of frames [t0, t1) (fuse_c0)
+    auto df1_range = [&](int64_t t0, int64_t t1, hipStream_t st) -> int {
+        if (fuse_h3) return launch_conv01_h3<C>(m, m->dfc1, feat_spec, c1, B, T, Fd, Fd / 2, 2, st, t0, Lk, t1);
+        return launch_conv01<C>(m, m->dfc1, feat_spec, c1, B, T, Fd, Fd / 2, 2, st, t0, Lk, t1);
+    };
+    // df_dec.df_convp of frames [t0, t1) (only needs c0 / feat_spec; :328)
+    auto convp_range = [&](int64_t t0, int64_t t1, hipStream_t st) -> int {
+        if (gate && kt > 1) {
             // gated streaming: the (kt-1)-frame delay line in front of df_convp belongs to the DF decoder and only moves on the frames
             // that decoder ran on, per stream.  c0 of the newest frame goes into the last slot of the per-stream window (exact fp32
             // matrix ops), the pathway conv reads the window; dfx_k_gate_c0_shift advances it where stage 2 ran.
-            if (c.df_pathway_kernel_size_t > 5) DFX_FAIL(DFX_ERR_UNSUPPORTED, "gated streaming needs df_pathway_kernel_size_t <= 5");
+            if (kt > 5) DFX_FAIL(DFX_ERR_UNSUPPORTED, "gated streaming needs df_pathway_kernel_size_t <= 5");
             DfxCinArgs A;
             A.feat = feat_spec;
             A.weff = m->p(m->cin_weff);
@@ -1558,109 +1624,140 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             A.out_T = T;
             A.out_toff = T - 1;
             {
-                DfxKScope ks(DFX_K_CONV_IN_DF, x2);
-                dfx_launch(dfx_k_conv_in_df<C>, dim3((unsigned)nn_grid(dfx_ceil_div(B * Fd, 64), 8)), dim3(DFX_PW_THREADS), 0, x2, A);
+                DfxKScope ks(DFX_K_CONV_IN_DF, st);
+                dfx_launch(dfx_k_conv_in_df<C>, dim3((unsigned)nn_grid(dfx_ceil_div(B * Fd, 64), 8)), dim3(DFX_PW_THREADS), 0, st, A);
                 DFX_LAUNCH_CHECK();
             }
-            switch (c.df_pathway_kernel_size_t) {
-                case 2: rc = launch_convp2<C, 2>(m, gate->c0_win, nullptr, c0p, B, T, Fd, NO, x2, T - 1, 0, Lk); break;
-                case 3: rc = launch_convp2<C, 3>(m, gate->c0_win, nullptr, c0p, B, T, Fd, NO, x2, T - 1, 0, Lk); break;
-                case 4: rc = launch_convp2<C, 4>(m, gate->c0_win, nullptr, c0p, B, T, Fd, NO, x2, T - 1, 0, Lk); break;
-                default: rc = launch_convp2<C, 5>(m, gate->c0_win, nullptr, c0p, B, T, Fd, NO, x2, T - 1, 0, Lk); break;
+            switch (kt) {
+                case 2: return launch_convp2<C, 2>(m, gate->c0_win, nullptr, c0p, B, T, Fd, NO, st, T - 1, 0, Lk);
+                case 3: return launch_convp2<C, 3>(m, gate->c0_win, nullptr, c0p, B, T, Fd, NO, st, T - 1, 0, Lk);
+                case 4: return launch_convp2<C, 4>(m, gate->c0_win, nullptr, c0p, B, T, Fd, NO, st, T - 1, 0, Lk);
+                default: return launch_convp2<C, 5>(m, gate->c0_win, nullptr, c0p, B, T, Fd, NO, st, T - 1, 0, Lk);
             }
-            if (rc) return rc;
         } else if (fuse_h3) {
-            switch (c.df_pathway_kernel_size_t) {
-                case 1: rc = launch_convp_h3<C, 1>(m, feat_spec, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
-                case 2: rc = launch_convp_h3<C, 2>(m, feat_spec, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
-                case 3: rc = launch_convp_h3<C, 3>(m, feat_spec, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
-                case 4: rc = launch_convp_h3<C, 4>(m, feat_spec, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
-                default: rc = launch_convp_h3<C, 5>(m, feat_spec, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
+            switch (kt) {
+                case 1: return launch_convp_h3<C, 1>(m, feat_spec, c0p, B, T, Fd, NO, st, t0, t_zero, Lk, t1);
+                case 2: return launch_convp_h3<C, 2>(m, feat_spec, c0p, B, T, Fd, NO, st, t0, t_zero, Lk, t1);
+                case 3: return launch_convp_h3<C, 3>(m, feat_spec, c0p, B, T, Fd, NO, st, t0, t_zero, Lk, t1);
+                case 4: return launch_convp_h3<C, 4>(m, feat_spec, c0p, B, T, Fd, NO, st, t0, t_zero, Lk, t1);
+                default: return launch_convp_h3<C, 5>(m, feat_spec, c0p, B, T, Fd, NO, st, t0, t_zero, Lk, t1);
             }
-            if (rc) return rc;
-        } else if (c.df_pathway_kernel_size_t <= 5 && NO <= 16) {
-            switch (c.df_pathway_kernel_size_t) {
-                case 1: rc = launch_convp2<C, 1>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
-                case 2: rc = launch_convp2<C, 2>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
-                case 3: rc = launch_convp2<C, 3>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
-                case 4: rc = launch_convp2<C, 4>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
-                default: rc = launch_convp2<C, 5>(m, c0, cp_feat, c0p, B, T, Fd, NO, x2, t_begin, t_zero, Lk); break;
+        } else if (kt <= 5 && NO <= 16) {
+            switch (kt) {
+                case 1: return launch_convp2<C, 1>(m, c0, cp_feat, c0p, B, T, Fd, NO, st, t0, t_zero, Lk, t1);
+                case 2: return launch_convp2<C, 2>(m, c0, cp_feat, c0p, B, T, Fd, NO, st, t0, t_zero, Lk, t1);
+                case 3: return launch_convp2<C, 3>(m, c0, cp_feat, c0p, B, T, Fd, NO, st, t0, t_zero, Lk, t1);
+                case 4: return launch_convp2<C, 4>(m, c0, cp_feat, c0p, B, T, Fd, NO, st, t0, t_zero, Lk, t1);
+                default: return launch_convp2<C, 5>(m, c0, cp_feat, c0p, B, T, Fd, NO, st, t0, t_zero, Lk, t1);
             }
-            if (rc) return rc;
-        } else {
-            DfxCpArgs A;
-            A.c0 = c0;
-            A.w1 = m->p(m->cp_w1);
-            A.w2 = m->p(m->cp_w2);
-            A.bias = m->p(m->cp_b);
-            A.out = c0p;
-            A.B = B;
-            A.T = T;
-            A.Fd = Fd;
-            A.kt = c.df_pathway_kernel_size_t;
-            A.G = m->cp_G;
-            A.NO = NO;
-            A.tchunks = (int)dfx_ceil_div(T, DFX_CP_TT);
-            A.fchunks = (Fd + DFX_CP_FB - 1) / DFX_CP_FB;
-            const int CG = C / A.G;
-            const size_t smem = ((size_t)(DFX_CP_TT + A.kt - 1) * DFX_CP_FB * (C + 2) + (size_t)A.G * A.kt * CG * 16 +
-                                 (size_t)DFX_CP_TT * DFX_CP_FB * NO) * sizeof(float);
-            if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_df_convp<C>, smem));
-            const int64_t nblk = B * A.tchunks * A.fchunks;
-            if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "df_convp grid too large");
-            DfxKScope ks(DFX_K_DF_CONVP, x2);
-            dfx_launch(dfx_k_df_convp<C>, dim3((unsigned)nblk), dim3(DFX_CP_THREADS), smem, x2, A);
-            DFX_LAUNCH_CHECK();
         }
-        if ((rc = signal(EV_C0P, x2))) return rc;
+        // tiled form (kt > 5 or more than 8 taps): whole sequences only
+        DfxCpArgs A;
+        A.c0 = c0;
+        A.w1 = m->p(m->cp_w1);
+        A.w2 = m->p(m->cp_w2);
+        A.bias = m->p(m->cp_b);
+        A.out = c0p;
+        A.B = B;
+        A.T = T;
+        A.Fd = Fd;
+        A.kt = kt;
+        A.G = m->cp_G;
+        A.NO = NO;
+        A.tchunks = (int)dfx_ceil_div(T, DFX_CP_TT);
+        A.fchunks = (Fd + DFX_CP_FB - 1) / DFX_CP_FB;
+        const int CG = C / A.G;
+        const size_t smem = ((size_t)(DFX_CP_TT + A.kt - 1) * DFX_CP_FB * (C + 2) + (size_t)A.G * A.kt * CG * 16 +
+                             (size_t)DFX_CP_TT * DFX_CP_FB * NO) * sizeof(float);
+        if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_df_convp<C>, smem));
+        const int64_t nblk = B * A.tchunks * A.fchunks;
+        if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "df_convp grid too large");
+        DfxKScope ks(DFX_K_DF_CONVP, st);
+        dfx_launch(dfx_k_df_convp<C>, dim3((unsigned)nblk), dim3(DFX_CP_THREADS), smem, st, A);
+        DFX_LAUNCH_CHECK();
         return DFX_OK;
     };
-    // the pathway conv only has to finish before df_out: it starts right away on the low-priority stream x2 and fills whatever the
-    // encoder kernels leave idle (DFX_CONVP_EARLY=0: released only after the front has been enqueued)
-    if (m->convp_after_c1 && (rc = wait(EV_C1, x2))) return rc;
-    if (run_df && !m->convp_late && (rc = run_convp())) return rc;
-    // ---- Encoder, ERB branch on s (:168-171)
-    const bool fuse_dec = E % 2 == 0 && m->fuse_erb && 2 * DFX_DEC10_SMEM(C, E) <= (size_t)160 * 1024;
-    const bool fuse_enc = E % 2 == 0 && 3 * (E + 2) <= 192 && m->fuse_erb && 2 * DFX_ENC_SMEM(C, E) <= (size_t)160 * 1024;
-    if (sc && !fuse_enc) DFX_FAIL(DFX_ERR_UNSUPPORTED, "streaming needs the fused ERB encoder head (DFX_FUSE_ERB unset)");
-    if (fuse_enc) {
-        if ((rc = launch_erb_enc<C>(m, feat_erb, e0, e1, B, T, s, t_begin, Lk))) return rc;
-    } else {
-        {
-            const int64_t total = R * E * (C / 4);
-            DfxKScope ks(DFX_K_CONV_IN_ERB, s);
-            dfx_launch(dfx_k_conv_in_erb, dim3((unsigned)nn_grid(dfx_ceil_div(total, 256), 16)), dim3(256), 0, s, feat_erb,
-                       m->p(m->erb0_w), m->p(m->erb0_b), e0, B, T, E, C, L);
-            DFX_LAUNCH_CHECK();
+    // Encoder, ERB branch (:168-171) for frames [t0, t1) = Rk rows reached through rm
+    auto erb_range = [&](int64_t t0, int64_t t1, int64_t Rk, DfxRowMap rm, hipStream_t st) -> int {
+        int r;
+        if (fuse_enc) {
+            if ((r = launch_erb_enc<C>(m, feat_erb, e0, e1, B, T, st, t0, Lk, t1))) return r;
+        } else {
+            {
+                const int64_t total = R * E * (C / 4);
+                DfxKScope ks(DFX_K_CONV_IN_ERB, st);
+                dfx_launch(dfx_k_conv_in_erb, dim3((unsigned)nn_grid(dfx_ceil_div(total, 256), 16)), dim3(256), 0, st, feat_erb,
+                           m->p(m->erb0_w), m->p(m->erb0_b), e0, B, T, E, C, L);
+                DFX_LAUNCH_CHECK();
+            }
+            if ((r = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb1, e0, nullptr, e1, R, E, E / 2, 2, st))) return r;
         }
-        if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb1, e0, nullptr, e1, R, E, E / 2, 2, s))) return rc;
+        if ((r = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb2, e1, nullptr, e2, Rk, E / 2, E / 4, 2, st, rm))) return r;
+        return launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb3, e2, nullptr, e3, Rk, E / 4, E / 4, 1, st, rm);
+    };
+    // cemb = relu(df_fc_emb(c1.flatten)); emb_in = e3.flatten + cemb (:179-182), then enc.emb_gru's linear_in (SqueezedGRU_S :149-158)
+    auto emb_range = [&](int64_t Rk, DfxRowMap rm, hipStream_t st) -> int {
+        int r;
+        if (c.enc_concat) {  // emb = cat(e3.flatten, cemb) (deepfilternet3.py:132-134,181): e3 rows into the left half, cemb written into the right half
+            if ((r = stream_copy_rows(e3, emb, emb, 0, emb_in, 2 * emb, emb, R, st))) return r;   // (all rows: enc_concat excludes the ranged front)
+            if ((r = launch_ggemm(c1, m->fc_emb.G * m->fc_emb.Kg, m->p(m->fc_emb.w), m->fc_emb.G, m->fc_emb.Kg, m->fc_emb.Ng, nullptr, DFX_ACT_RELU,
+                                  nullptr, emb_in + emb, 2 * emb, Rk, st, 0, 0, 1, rm)))
+                return r;
+        } else if ((r = launch_glin(m, m->fc_emb, c1, DFX_ACT_RELU, e3, emb_in, Rk, st, rm))) return r;
+        return launch_glin(m, m->enc_in, emb_in, DFX_ACT_RELU, nullptr, xa, Rk, st, rm);
+    };
+    if (!overlap) {
+        // frame ranges of the front: one (everything that is computed), or DFX_FRONT_SPLIT of them one after the other
+        const int nfr = front_ranges && m->front_split > 1 && T - t_begin >= m->front_split ? m->front_split : 1;
+        auto fb = [&](int i) { return t_begin + (T - t_begin) * i / nfr; };
+        auto frm = [&](int i) { return nfr > 1 ? DfxRowMap{T, fb(i + 1) - fb(i), fb(i)} : rmw; };
+        auto fR = [&](int i) { return nfr > 1 ? B * (fb(i + 1) - fb(i)) : Rn; };
+        if (fuse_c0) {
+            if ((rc = signal(EV_C0, x1)) || (rc = wait(EV_C0, x2))) return rc;  // df_convp only needs feat_spec
+            for (int i = 0; i < nfr; ++i)
+                if ((rc = df1_range(fb(i), fb(i + 1), x1))) return rc;
+        } else {
+            DfxCinArgs A;
+            A.feat = feat_spec;
+            A.weff = m->p(m->cin_weff);
+            A.bias = m->p(m->cin_b);
+            A.out = c0;
+            A.B = B;
+            A.T = T;
+            A.Fin = Fd;
+            A.L = L;
+            A.t_begin = 0;
+            A.out_T = T;
+            A.out_toff = 0;
+            DfxKScope ks(DFX_K_CONV_IN_DF, x1);
+            dfx_launch(dfx_k_conv_in_df<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R * Fd, 64), 8)), dim3(DFX_PW_THREADS), 0, x1, A);
+            DFX_LAUNCH_CHECK();
+            if ((rc = signal(EV_C0, x1)) || (rc = wait(EV_C0, x2))) return rc;
+            if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->dfc1, c0, nullptr, c1, R, Fd, Fd / 2, 2, x1))) return rc;
+        }
+        if ((rc = signal(EV_C1, x1))) return rc;
+        auto run_convp = [&]() -> int {
+            for (int i = 0; i < nfr; ++i)
+                if (int r = convp_range(fb(i), fb(i + 1), x2)) return r;
+            return signal(EV_C0P, x2);
+        };
+        // the pathway conv only has to finish before df_out: it starts right away on the low-priority stream x2 and fills whatever the
+        // encoder kernels leave idle (DFX_CONVP_EARLY=0: released only after the front has been enqueued)
+        if (m->convp_after_c1 && (rc = wait(EV_C1, x2))) return rc;
+        if (run_df && !m->convp_late && (rc = run_convp())) return rc;
+        for (int i = 0; i < nfr; ++i)
+            if ((rc = erb_range(fb(i), fb(i + 1), fR(i), frm(i), s))) return rc;
+        if ((rc = wait(EV_C1, s))) return rc;
+        for (int i = 0; i < nfr; ++i)
+            if ((rc = emb_range(fR(i), frm(i), s))) return rc;
+        // the chip-filling front of this chunk is enqueued: the next chunk of a pipelined dfx_enhance may start its own front
+        // (it then overlaps this chunk's GRU chain, which occupies only a few CUs)
+        if (signal_front && (rc = signal(EV_FRONT, s))) return rc;
+        if (run_df && m->convp_late) {
+            if ((rc = signal(EV_LSNR, s)) || (rc = wait(EV_LSNR, x2)) || (rc = run_convp())) return rc;
+        }
     }
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb2, e1, nullptr, e2, Rn, E / 2, E / 4, 2, s, rmw))) return rc;
-    if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb3, e2, nullptr, e3, Rn, E / 4, E / 4, 1, s, rmw))) return rc;
-    if ((rc = wait(EV_C1, s))) return rc;
-    // cemb = relu(df_fc_emb(c1.flatten)); emb_in = e3.flatten + cemb   (:179-182)
-    if (c.enc_concat) {  // emb = cat(e3.flatten, cemb) (deepfilternet3.py:132-134,181): e3 rows into the left half, cemb written into the right half
-        if ((rc = stream_copy_rows(e3, emb, emb, 0, emb_in, 2 * emb, emb, R, s))) return rc;
-        if ((rc = launch_ggemm(c1, m->fc_emb.G * m->fc_emb.Kg, m->p(m->fc_emb.w), m->fc_emb.G, m->fc_emb.Kg, m->fc_emb.Ng, nullptr, DFX_ACT_RELU,
-                               nullptr, emb_in + emb, 2 * emb, Rn, s, 0, 0, 1, rmw)))
-            return rc;
-    } else if ((rc = launch_glin(m, m->fc_emb, c1, DFX_ACT_RELU, e3, emb_in, Rn, s, rmw))) return rc;
-    // enc.emb_gru (SqueezedGRU_S :149-158)
-    if ((rc = launch_glin(m, m->enc_in, emb_in, DFX_ACT_RELU, nullptr, xa, Rn, s, rmw))) return rc;
-    // the chip-filling front of this chunk is enqueued: the next chunk of a pipelined dfx_enhance may start its own front
-    // (it then overlaps this chunk's GRU chain, which occupies only a few CUs)
-    if (signal_front && (rc = signal(EV_FRONT, s))) return rc;
-    if (run_df && m->convp_late) {
-        if ((rc = signal(EV_LSNR, s)) || (rc = wait(EV_LSNR, x2)) || (rc = run_convp())) return rc;
-    }
-    // ---- GRU phase.  Layer-pipelined over time chunks when the fp16-split kernels are in use: every GRU layer has its own
-    // stream; layer l may run chunk k as soon as layer l-1 has produced chunk k (event), so the three-layer chain
-    // enc -> dec1 -> dec2 (and enc -> df1 -> df2) costs T*(1 + 2/K) steps instead of 3T.  Each layer-kernel occupies B/16
-    // CUs; the per-chunk projections and grouped linears address their rows through a DfxRowMap.
-    int K = m->tchunks;
-    if (T / K < m->tchunk_min) K = (int)(T / m->tchunk_min);
-    const int nenc = (int)m->enc_gru.size(), ndec = (int)m->dec_gru.size(), ndf = run_df ? (int)m->df_gru.size() : 0;
-    const bool pipe = par && !sc && !m->exact_fp32 && K > 1 && nenc == 1 && 1 + ndec + ndf <= DFX_MAX_GRU_LAYERS && ln == &m->lanes[0];
+    // ---- GRU phase (planned above)
     float *hs_enc = sc ? sc->h_state : nullptr, *hs_dec = sc ? sc->h_state + (int64_t)nenc * B * 256 : nullptr;
     float *hs_df = sc ? sc->h_state + (int64_t)(nenc + ndec) * B * 256 : nullptr;
     if (!pipe) {
@@ -1738,8 +1835,6 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // as its input rows exist and signals pev[l][k]; gs[l] runs nothing but the recurrences, chunk after chunk, and
         // signals gev[l][k].  Two tail streams consume the last layers' chunks (linear_out / skip / df_out) and then run the
         // rest of their decoder.  The latency chain is therefore K+2 recurrence chunks and nothing else.
-        const int nl = 1 + ndec + ndf;
-        (void)nl;
         auto proj_chunk = [&](const GruW &g, int l, int k, const float *xin, hipStream_t st) -> int {
             static const int dev_skip3 = [] { const char *e = getenv("DFX_DEV_SKIP"); return e ? atoi(e) : 0; }();
             if ((dev_skip3 & 4) && l > 0) return DFX_OK;  // dev timing ablation: no input projections for layers > 0
@@ -1748,34 +1843,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // ---- persistent form (default on the GPU): ONE launch runs the recurrences of all layers for the whole sequence
         // (dfx_k_gru_seq); the projections / grouped linears / decoder tails stay per time chunk on three streams and meet the
         // recurrences through flag words in device memory instead of events — no kernel boundary, no relaunch, no pending
-        // cross-queue barrier packet inside the phase.  Needs every (layer, group) workgroup resident at once (each owns a CU).
-        const int groups = (int)dfx_ceil_div(B, DFX_GH_ROWS);
-        const bool use_seq = m->gru_seq && !m->gru_x2 && !m->finish_chunked && groups <= DFX_SEQ_GMAX && nl * groups + 8 <= dfx_env_num_cus();
+        // cross-queue barrier packet inside the phase.  Chunk boundaries sb[0..Ks]: planned above.
         if (use_seq) {
-            // chunk boundaries: short chunks at the start (the next layer can begin after the first chunk + its preparation: the
-            // pipeline of 3 layers fills in ~3 short chunks instead of 3 long ones) and at the end (what is left to do after the last
-            // recurrence step is one short chunk's decoder tail), uniform in between
-            int sb[DFX_GS_MAX_CHUNKS + 1];
-            int Ks = 0;
-            {
-                // measured at batch 256 x 1002 frames (ms per step): 8 body chunks + ramp from 32: 21.28; 12 + 16: 21.91; 12, no ramp: 21.47;
-                // 6 + 32: 21.35; 4 + 32: 22.45; 16 + 16: 22.69 (the event-based form: 22.07); after the decoder convolutions went to the
-                // staged fp16-split kernels (lighter background): 8 + 32: 20.1; 10 + 32: 19.85; 12 + 32: 19.99; 12 + 16: 20.27; 16 + 32: 21.0
-                static const int ramp0 = [] { const char *e = getenv("DFX_SEQ_RAMP"); return e ? atoi(e) : 32; }();
-                static const int kbody = [] { const char *e = getenv("DFX_SEQ_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 10; }();
-                const int64_t body = T / kbody > m->tchunk_min ? T / kbody : m->tchunk_min;   // uniform chunk length
-                std::vector<int> sizes;
-                int64_t left = T;
-                for (int64_t r = ramp0; ramp0 > 0 && r < body && left > 4 * body; r *= 2) sizes.push_back((int)r), left -= r;   // up
-                std::vector<int> down;
-                for (int64_t r = ramp0; ramp0 > 0 && r < body && left > 3 * body; r *= 2) down.push_back((int)r), left -= r;     // down
-                const int nbody = (int)std::max<int64_t>(1, std::min<int64_t>(dfx_ceil_div(left, body), DFX_GS_MAX_CHUNKS - (int64_t)sizes.size() - (int64_t)down.size()));
-                for (int i = 0; i < nbody; ++i) sizes.push_back((int)(left * (i + 1) / nbody - left * i / nbody));
-                for (auto it = down.rbegin(); it != down.rend(); ++it) sizes.push_back(*it);
-                Ks = (int)sizes.size();
-                sb[0] = 0;
-                for (int i = 0; i < Ks; ++i) sb[i + 1] = sb[i] + sizes[i];
-            }
             const int K = Ks;   // (shadows the uniform chunk count of the event-based form)
             auto tb = [&](int k) { return (int64_t)sb[k]; };
             auto rmk = [&](int k) { return DfxRowMap{T, tb(k + 1) - tb(k), tb(k)}; };
@@ -1792,7 +1861,13 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             auto donep = [&](int l) { return done + (size_t)l * DFX_SEQ_GMAX; };
             auto tgt = [&](int k) { return base + (unsigned int)k + 1u; };
             hipStream_t G = ln->gs[1], Eq = ln->ts[0], Dq = ln->ts[1], Pq = ln->ps[0];
-            if ((rc = signal(EV_XA, s)) || (rc = wait(EV_XA, G)) || (rc = wait(EV_XA, Eq)) || (rc = wait(EV_XA, Dq)) || (rc = wait(EV_XA, Pq))) return rc;
+            // overlap: the launch goes out FIRST and the front follows under it, chunk by chunk (EV_START: the features exist); otherwise
+            // the front is complete (EV_XA)
+            const int ev_go = overlap ? EV_START : EV_XA;
+            if (!overlap && (rc = signal(EV_XA, s))) return rc;
+            if ((rc = wait(ev_go, G)) || (rc = wait(ev_go, Eq)) || (rc = wait(ev_go, Dq)) || (rc = wait(ev_go, Pq))) return rc;
+            unsigned int *started = m->d_sync + 12;   // workgroups of the persistent launches that have begun to run (monotonic)
+            m->seq_started += (unsigned int)(nl * groups);
             {   // the recurrences
                 DfxGsArgs S;
                 for (int l = 0; l < DFX_GS_MAX_LAYERS; ++l) S.gi[l] = nullptr, S.y[l] = nullptr, S.whf[l] = nullptr, S.bhn[l] = nullptr, S.unscale[l] = 1.f;
@@ -1808,18 +1883,49 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 for (int i = 0; i <= K; ++i) S.tb[i] = sb[i];
                 S.ready = ready, S.done = done, S.done_stride = DFX_SEQ_GMAX, S.base = base, S.err = m->d_err;
                 S.trace = m->d_trace;
+                S.started = started;
                 m->trace_dims[0] = nl, m->trace_dims[1] = groups, m->trace_dims[2] = K;
                 DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_seq, DFX_GH_SMEM));
                 DfxKScope ks(DFX_K_GRU_REC, G);
                 dfx_launch(dfx_k_gru_seq, dim3((unsigned)(nl * groups)), dim3(DFX_GH_THREADS), DFX_GH_SMEM, G, S);
                 DFX_LAUNCH_CHECK();
             }
-            // layer 0 (encoder GRU): its input xa is complete; one projection + flag per chunk
-            // (stays two chunks ahead of the recurrence instead of flooding the chip with all K projections while the decoders'
-            // first chunks are being prepared)
-            for (int k = 0; k < K; ++k) {
-                if (k >= 3 && (rc = launch_wait_ge(m, donep(0), groups, tgt(k - 3), Pq))) return rc;
-                if ((rc = proj_chunk(m->enc_gru[0], 0, k, xa, Pq)) || (rc = launch_flag_set(ready + 0, tgt(k), Pq))) return rc;
+            if (overlap) {
+                // ---- the encoder front, chunk by chunk, under the running recurrences: chunk k of the encoder GRU needs the front of chunk
+                // k and nothing else.  x1: df_conv0 -> df_conv1 (event eev[k]); x2: df_convp (event mev[k], the DF tail's operand), released
+                // once the first chunk's df_conv1 is through; ps[0]: ERB encoder, the embedding GEMMs, the encoder GRU's projection + flag
+                // (not the caller's stream: everything the recurrences wait for stays on streams of this handle, whose hardware queues
+                // are not shared with the persistent launch's).
+                // The front starts when every workgroup of the persistent launch is resident: those need a whole CU's LDS each and
+                // would otherwise queue behind a chip full of short-lived encoder workgroups.
+                if ((rc = launch_wait_ge(m, started, 1, m->seq_started, Pq)) || (rc = launch_wait_ge(m, started, 1, m->seq_started, x1))) return rc;
+                for (int k = 0; k < K; ++k) {
+                    if ((rc = df1_range(tb(k), tb(k + 1), x1))) return rc;
+                    DFX_HIP(hipEventRecord(ln->eev[k], x1));
+                }
+                if (run_df) {
+                    DFX_HIP(hipStreamWaitEvent(x2, ln->eev[0], 0));
+                    for (int k = 0; k < K; ++k) {
+                        if ((rc = convp_range(tb(k), tb(k + 1), x2))) return rc;
+                        DFX_HIP(hipEventRecord(ln->mev[k], x2));
+                    }
+                }
+                for (int k = 0; k < K; ++k) {
+                    if (m->front_ahead > 0 && k >= m->front_ahead && (rc = launch_wait_ge(m, donep(0), groups, tgt(k - m->front_ahead), Pq))) return rc;
+                    if ((rc = erb_range(tb(k), tb(k + 1), Mk(k), rmk(k), Pq))) return rc;
+                    DFX_HIP(hipStreamWaitEvent(Pq, ln->eev[k], 0));
+                    if ((rc = emb_range(Mk(k), rmk(k), Pq))) return rc;
+                    if ((rc = proj_chunk(m->enc_gru[0], 0, k, xa, Pq)) || (rc = launch_flag_set(ready + 0, tgt(k), Pq))) return rc;
+                }
+                if (signal_front && (rc = signal(EV_FRONT, Pq))) return rc;
+            } else {
+                // layer 0 (encoder GRU): its input xa is complete; one projection + flag per chunk
+                // (stays two chunks ahead of the recurrence instead of flooding the chip with all K projections while the decoders'
+                // first chunks are being prepared)
+                for (int k = 0; k < K; ++k) {
+                    if (k >= 3 && (rc = launch_wait_ge(m, donep(0), groups, tgt(k - 3), Pq))) return rc;
+                    if ((rc = proj_chunk(m->enc_gru[0], 0, k, xa, Pq)) || (rc = launch_flag_set(ready + 0, tgt(k), Pq))) return rc;
+                }
             }
             const int fpt = 64 / E > 0 ? 64 / E : 1;
             const size_t co_smem = ((size_t)fpt * E * (C + 1) + (size_t)fpt * E * 3 + 3 * C) * sizeof(float);
@@ -1827,7 +1933,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             //   ps[l]  (decoder layers): input of layer l, chunk k = linear_out / linear_in around the producer's y + the projection
             //   ts[0]  ERB tail (linear_out + the decoder's convolutions), ts[1] DF tail (skip + df_out), then the finishing kernels
             for (int l = 1; l < nl; ++l)
-                if ((rc = wait(EV_XA, ln->ps[l]))) return rc;
+                if ((rc = wait(ev_go, ln->ps[l]))) return rc;
             // ---- ERB decoder layers
             for (int j = 0; j < ndec; ++j) {
                 const int l = 1 + j;
@@ -1882,8 +1988,13 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                     }
                 }
                 const int l = ndec + ndf;
-                if ((rc = wait(EV_C0P, Dq))) return rc;
+                if (!overlap && (rc = wait(EV_C0P, Dq))) return rc;
                 for (int k = 0; k < K; ++k) {
+                    if (overlap) {
+                        if (c.df_gru_skip == DFX_SKIP_IDENTITY) {   // (one df_out over all frames at the end: needs every chunk of c0p)
+                            if (k == K - 1) DFX_HIP(hipStreamWaitEvent(Dq, ln->mev[K - 1], 0));
+                        } else DFX_HIP(hipStreamWaitEvent(Dq, ln->mev[k], 0));
+                    }
                     if ((rc = launch_wait_ge(m, donep(l), groups, tgt(k), Dq))) return rc;
                     if (dev_skip_seq & 2) continue;
                     if (c.df_gru_skip == DFX_SKIP_IDENTITY) {
@@ -2166,13 +2277,32 @@ static int model_forward_lane(const dfx_model *m, const dfx_bands *bands, const 
     DFX_FAIL(DFX_ERR_UNSUPPORTED, "conv_ch");
 }
 
+// Enqueue throttle of the multi-stream pass (see dfx_model::ev_pass): big passes only — a small pass is over before the host has
+// enqueued the next one, and holding the host back would serialise its launch overhead with the device's work.
+#define DFX_THROTTLE_MIN_FRAMES 16384
+static int pass_begin(const dfx_model *m, int64_t frames) {
+    if (m->pass_pending && m->ev_pass && !m->enqueue_ahead && m->concurrent && frames >= DFX_THROTTLE_MIN_FRAMES) DFX_HIP(hipEventSynchronize(m->ev_pass));
+    m->pass_pending = false;
+    return DFX_OK;
+}
+static int pass_end(const dfx_model *m, int64_t frames, hipStream_t s) {
+    if (m->ev_pass && !m->enqueue_ahead && m->concurrent && frames >= DFX_THROTTLE_MIN_FRAMES) {
+        DFX_HIP(hipEventRecord(m->ev_pass, s));
+        m->pass_pending = true;
+    }
+    return DFX_OK;
+}
+
 extern "C" int dfx_model_forward(const dfx_model *m, const dfx_bands *bands, const float *spec, const float *feat_erb,
                                  const float *feat_spec, int64_t B, int64_t T, float atten_lim, float *spec_e,
                                  float *mask, float *lsnr, float *df_coefs, void *workspace, int64_t workspace_bytes,
                                  void *stream) {
     if (!m) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_forward: bad arguments");
-    return model_forward_lane(m, bands, spec, feat_erb, feat_spec, B, T, atten_lim, spec_e, mask, lsnr, df_coefs, workspace,
-                              workspace_bytes, stream, &m->lanes[0], false);
+    if (int rc = pass_begin(m, B * T)) return rc;
+    if (int rc = model_forward_lane(m, bands, spec, feat_erb, feat_spec, B, T, atten_lim, spec_e, mask, lsnr, df_coefs, workspace,
+                                    workspace_bytes, stream, &m->lanes[0], false))
+        return rc;
+    return pass_end(m, B * T, dfx_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------------ enhance()
@@ -2922,7 +3052,11 @@ extern "C" int dfx_enhance(const dfx_model *m, const dfx_state *st, const float 
         lim = powf(10.f, -fabsf(atten_lim_db) / 20.f);  // enhance.py:238-239
         if (lim >= 1.f) lim = 0.99999994f;              // |dB| tiny: the reference mixes with lim == 1.0f (the noisy signal passes)
     }
-    if (nc == 1) return enhance_chunk(m, st, x, B, T, pad, lim, y, base, s, &m->lanes[0], false);
+    if (int rc = pass_begin(m, B * Tf)) return rc;
+    if (nc == 1) {
+        if (int rc = enhance_chunk(m, st, x, B, T, pad, lim, y, base, s, &m->lanes[0], false)) return rc;
+        return pass_end(m, B * Tf, s);
+    }
     // ---- pipelined chunks: fork from the caller's stream, stagger the fronts, join back
     DFX_HIP(hipEventRecord(m->ev_fork, s));
     int64_t row = 0;
@@ -2936,5 +3070,5 @@ extern "C" int dfx_enhance(const dfx_model *m, const dfx_state *st, const float 
         row += sizes[i];
     }
     for (int i = 0; i < nc; ++i) DFX_HIP(hipStreamWaitEvent(s, m->lanes[i].ev[EV_DONE], 0));
-    return DFX_OK;
+    return pass_end(m, B * Tf, s);
 }

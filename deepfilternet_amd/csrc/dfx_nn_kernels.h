@@ -378,7 +378,8 @@ struct DfxC01Args {
     float *out;          // [B*T, Fout, C]
     int64_t B, T;
     int Fin, Fout, stride, L;
-    int64_t t_begin;     // only frames [t_begin, T) of every clip are produced
+    int64_t t_begin;     // only frames [t_begin, t_end) of every clip are produced (t_end <= T; frames up to T may be read)
+    int64_t t_end;
 };
 
 template <int C>
@@ -404,7 +405,7 @@ __global__ void __launch_bounds__(DFX_PW_THREADS) dfx_k_df_conv01(DfxC01Args A) 
         biasr[nt] = reinterpret_cast<const float4 *>(A.bias)[4 * nt + q];
     }
     __syncthreads();
-    const int64_t Tn = A.T - A.t_begin;
+    const int64_t Tn = A.t_end - A.t_begin;
     const int64_t total = A.B * Tn * A.Fout;
     const int64_t ntiles = (total + 15) / 16;
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
@@ -513,7 +514,8 @@ struct DfxC01hArgs {
     int64_t B, T;
     int Fin, Fout, stride, L;
     float unscale0, unscale;
-    int64_t t_begin;     // only frames [t_begin, T) of every clip are produced
+    int64_t t_begin;     // only frames [t_begin, t_end) of every clip are produced (t_end <= T; frames up to T may be read)
+    int64_t t_end;
     unsigned int *err;   // model error words: bit 0 of err[1] = a value >= DFX_H3_LIMIT reached an f16 split (results invalid)
 };
 
@@ -545,7 +547,7 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, DFX_C01_MINB) dfx_k_df_conv01_
         w0l[nt] = A.w0f[(nt * 2 + 1) * 64 + lane];
     }
     __syncthreads();
-    const int64_t Tn = A.T - A.t_begin;
+    const int64_t Tn = A.t_end - A.t_begin;
     const int64_t total = A.B * Tn * A.Fout;
     const int64_t ntiles = (total + 15) / 16;
     const int64_t tstep = (int64_t)gridDim.x * 4;
@@ -647,7 +649,7 @@ struct DfxCphArgs {
     int64_t B, T;
     int Fd, NO, nfb, nseg, tseg, L;
     float unscale0, unscale;
-    int64_t t_begin, t_zero;  // as in DfxCp2Args
+    int64_t t_begin, t_zero, t_end;  // as in DfxCp2Args
     unsigned int *err;        // as in DfxC01hArgs
 };
 
@@ -684,7 +686,7 @@ __global__ void __launch_bounds__(256, 1) dfx_k_df_convp_h3(DfxCphArgs A) {
         const int f = fb * 16 + jl;
         const bool fvalid = f < A.Fd;
         const int64_t t0 = A.t_begin + (int64_t)seg * A.tseg;
-        const int64_t t1 = (t0 + A.tseg < A.T) ? t0 + A.tseg : A.T;
+        const int64_t t1 = (t0 + A.tseg < A.t_end) ? t0 + A.tseg : A.t_end;
         dfx_h8 xh[KT][KC], xl[KT][KC];  // frame tau lives in slot (tau - t0) mod KT
         float2 raw[4];
         auto make_frame = [&](dfx_h8 (&dh)[KC], dfx_h8 (&dl)[KC], int64_t tau, const float2 (&rw)[4]) {
@@ -1026,7 +1028,7 @@ struct DfxEncArgs {
     float *e0, *e1;                  // [B*T, E, C], [B*T, E/2, C]
     int64_t B, T;
     int E, L;
-    int64_t t_begin;                 // only frames [t_begin, T) of every clip are produced (streaming: the frames before are history)
+    int64_t t_begin, t_end;          // only frames [t_begin, t_end) of every clip are produced (streaming: the frames before are history)
     const dfx_h8 *wt_h3 = nullptr;   // erb_conv1's pointwise weights as f16 hi/lo fragments (H3 form)
     float unscale = 1.f;
     unsigned int *err = nullptr;
@@ -1058,7 +1060,7 @@ __global__ void __launch_bounds__(256, 2) dfx_k_erb_enc(DfxEncArgs A) {
     for (int k = 0; k < 9; ++k) wv[k] = reinterpret_cast<const float4 *>(A.w0)[k * C4 + c4];
     const float4 bv = reinterpret_cast<const float4 *>(A.b0)[c4];
     __syncthreads();
-    const int64_t Tn = A.T - A.t_begin, R = A.B * Tn;  // logical rows: (clip, produced frame)
+    const int64_t Tn = A.t_end - A.t_begin, R = A.B * Tn;  // logical rows: (clip, produced frame)
     const int64_t rstep = (int64_t)gridDim.x * 4;
     // element i of the zero-bordered tap rows [3][E+2] of frame r (zero: border, causal pad after the lookahead shift, beyond T)
     float fx[3];
@@ -1525,7 +1527,8 @@ struct DfxCp2Args {
     const float *feat;  // FUSE_C0: feat_spec [B, T, Fd, 2], folded df_conv0 weights [20][C] and bias [C], lookahead L
     const float *weff0, *bias0;
     int L;
-    int64_t t_begin;    // only frames [t_begin, T) are produced (the segments start there)
+    int64_t t_begin;    // only frames [t_begin, t_end) are produced (the segments start there)
+    int64_t t_end;
     int64_t t_zero;     // FUSE_C0: c0 of frames < t_zero is the zero padding (0 for whole clips; streaming: frames before the stream began)
     const float *weff;  // [kt][C][16]  weff[(k*C + c)*16 + n], n >= NO zero
     const float *bias;  // [16]
@@ -1568,7 +1571,7 @@ __global__ void __launch_bounds__(256) dfx_k_df_convp2(DfxCp2Args A) {
         const int f = fb * 16 + jl;
         const bool fvalid = f < A.Fd;
         const int64_t t0 = A.t_begin + (int64_t)seg * A.tseg;
-        const int64_t t1 = (t0 + A.tseg < A.T) ? t0 + A.tseg : A.T;
+        const int64_t t1 = (t0 + A.tseg < A.t_end) ? t0 + A.tseg : A.t_end;
         float win[KT][CPL];
         auto load_frame = [&](float (&dst)[CPL], int64_t tau) {
             if (FUSE_C0) {
@@ -1938,27 +1941,147 @@ __global__ void __launch_bounds__(DFX_PH_THREADS, 2) dfx_k_proj256_h3(DfxPhArgs 
 #pragma unroll
             for (int i = 0; i < PER_T; ++i) pre[i] = src[i * DFX_PH_THREADS + tid];
         }
+        // the four column tiles of the chunk advance together: consecutive matrix ops go to DIFFERENT accumulators (an op that waits for
+        // the previous op's accumulator stalls for the whole latency of that op; per accumulator the order of the terms is unchanged)
+        f32x4 acc[4];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kc = 0; kc < 8; ++kc) {
-                const dfx_h8 whi = wc[((kc * 4 + ct) * 2 + 0) * 64 + lane], wlo = wc[((kc * 4 + ct) * 2 + 1) * 64 + lane];
-                acc = dfx_mfma_16x16x32_f16(wlo, xh[kc], acc);
-                acc = dfx_mfma_16x16x32_f16(whi, xl[kc], acc);
-                acc = dfx_mfma_16x16x32_f16(whi, xh[kc], acc);
+        for (int kc = 0; kc < 8; ++kc) {
+            dfx_h8 whi[4], wlo[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                whi[ct] = wc[((kc * 4 + ct) * 2 + 0) * 64 + lane];
+                wlo[ct] = wc[((kc * 4 + ct) * 2 + 1) * 64 + lane];
             }
-            if (ok) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = dfx_mfma_16x16x32_f16(wlo[ct], xh[kc], acc[ct]);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = dfx_mfma_16x16x32_f16(whi[ct], xl[kc], acc[ct]);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = dfx_mfma_16x16x32_f16(whi[ct], xh[kc], acc[ct]);
+        }
+        if (ok) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
                 const int n = c * DFX_PH_NC + 16 * ct + 4 * q;
                 const float4 bz = *reinterpret_cast<const float4 *>(A.bias + n);
                 *reinterpret_cast<float4 *>(A.out + m * A.N + n) =
-                    make_float4(acc[0] * unscale + bz.x, acc[1] * unscale + bz.y, acc[2] * unscale + bz.z, acc[3] * unscale + bz.w);
+                    make_float4(acc[ct][0] * unscale + bz.x, acc[ct][1] * unscale + bz.y, acc[ct][2] * unscale + bz.z, acc[ct][3] * unscale + bz.w);
             }
         }
         if (c + 1 < nchunks) {
             dfx_h8 *dst = ws + (size_t)((c + 1) & 1) * DFX_PH_CHUNK_H8;
 #pragma unroll
             for (int i = 0; i < PER_T; ++i) dst[i * DFX_PH_THREADS + tid] = pre[i];
+        }
+        __syncthreads();
+    }
+}
+
+// The same projection with TWO row tiles per wave: every W fragment read from LDS feeds 6 matrix ops instead of 3.  dfx_k_proj256_h3 is
+// bound by its LDS fragment reads (per 64-column chunk and CU: 8 waves x 64 ds_read_b128 = 512 KB against 3072 matrix-pipe cycles per
+// SIMD, and ds_read_b128 runs at half the LDS rate); here a workgroup is NW waves x 32 rows: NW = 8 (256 rows, two waves per SIMD, ~220
+// registers) halves the fragment reads per row; NW = 4 (128 rows, one wave per SIMD) was measured slower than the one-tile kernel
+// (0.61 vs 0.43 ms for 256 k rows: a lone wave per SIMD cannot hide its own LDS / barrier latencies).
+template <int NW>
+__global__ void __launch_bounds__(64 * NW, 1) dfx_k_proj256_h3x2(DfxPhArgs A) {
+    constexpr int DFX_PH2_THREADS = 64 * NW, BM2 = 32 * NW;
+    DFX_DYN_SMEM(dfx_h8, ws);  // [2][DFX_PH_CHUNK_H8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
+    const int nchunks = A.N / DFX_PH_NC;
+    constexpr int PER_T = DFX_PH_CHUNK_H8 / DFX_PH2_THREADS;  // 16 x 16 bytes per thread and chunk
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) ws[i * DFX_PH2_THREADS + tid] = A.wf[i * DFX_PH2_THREADS + tid];
+    dfx_h8 xh[2][8], xl[2][8];
+    float unscale[2];
+    int64_t mrow[2];
+    bool okr[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int64_t ml = (int64_t)blockIdx.x * BM2 + 32 * wave + 16 * t + jl;
+        okr[t] = ml < A.M;
+        mrow[t] = okr[t] ? dfx_row(A.rm, ml) : 0;
+        const float4 *p = reinterpret_cast<const float4 *>(A.a + mrow[t] * 256 + 8 * q);
+        float4 xu[8], xv[8];
+        float mx = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            xu[kc] = okr[t] ? p[8 * kc] : make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[kc] = okr[t] ? p[8 * kc + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(xu[kc].x), fabsf(xu[kc].y)), fmaxf(fabsf(xu[kc].z), fabsf(xu[kc].w))));
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(xv[kc].x), fabsf(xv[kc].y)), fmaxf(fabsf(xv[kc].z), fabsf(xv[kc].w))));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));   // the four lanes (q) that share row jl
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        int e = 0;
+        if (mx > 0.f && mx < 3.0e38f) {       // per-row power-of-two scale, exactly as in dfx_k_proj256_h3
+            int ex;
+            (void)frexpf(mx, &ex);
+            e = 14 - ex;
+            e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        }
+        const float sc = ldexpf(1.f, e);
+        unscale[t] = A.unscale * ldexpf(1.f, -e);
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            float x[8];
+            x[0] = xu[kc].x * sc, x[1] = xu[kc].y * sc, x[2] = xu[kc].z * sc, x[3] = xu[kc].w * sc;
+            x[4] = xv[kc].x * sc, x[5] = xv[kc].y * sc, x[6] = xv[kc].z * sc, x[7] = xv[kc].w * sc;
+            dfx_split8(x, xh[t][kc], xl[t][kc]);
+        }
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const dfx_h8 *wc = ws + (size_t)(c & 1) * DFX_PH_CHUNK_H8;
+        dfx_h8 pre[PER_T];
+        if (c + 1 < nchunks) {
+            const dfx_h8 *src = A.wf + (size_t)(c + 1) * DFX_PH_CHUNK_H8;
+#pragma unroll
+            for (int i = 0; i < PER_T; ++i) pre[i] = src[i * DFX_PH2_THREADS + tid];
+        }
+        f32x4 acc[2][4];   // eight independent accumulators: no matrix op waits for its predecessor
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[t][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            dfx_h8 whi[4], wlo[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                whi[ct] = wc[((kc * 4 + ct) * 2 + 0) * 64 + lane];
+                wlo[ct] = wc[((kc * 4 + ct) * 2 + 1) * 64 + lane];
+            }
+            // per accumulator the same order of the three terms as in the one-tile kernel: same bits
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t][ct] = dfx_mfma_16x16x32_f16(wlo[ct], xh[t][kc], acc[t][ct]);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t][ct] = dfx_mfma_16x16x32_f16(whi[ct], xl[t][kc], acc[t][ct]);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t][ct] = dfx_mfma_16x16x32_f16(whi[ct], xh[t][kc], acc[t][ct]);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const int n = c * DFX_PH_NC + 16 * ct + 4 * q;
+            const float4 bz = *reinterpret_cast<const float4 *>(A.bias + n);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                if (okr[t])
+                    *reinterpret_cast<float4 *>(A.out + mrow[t] * A.N + n) =
+                        make_float4(acc[t][ct][0] * unscale[t] + bz.x, acc[t][ct][1] * unscale[t] + bz.y, acc[t][ct][2] * unscale[t] + bz.z,
+                                    acc[t][ct][3] * unscale[t] + bz.w);
+        }
+        if (c + 1 < nchunks) {
+            dfx_h8 *dst = ws + (size_t)((c + 1) & 1) * DFX_PH_CHUNK_H8;
+#pragma unroll
+            for (int i = 0; i < PER_T; ++i) dst[i * DFX_PH2_THREADS + tid] = pre[i];
         }
         __syncthreads();
     }
@@ -2449,8 +2572,10 @@ struct DfxGsArgs {
     unsigned int base;
     unsigned int *err;
     unsigned long long *trace;   // dev aid: [layers][groups][K][3] or null
+    unsigned int *started;       // counts the workgroups that have begun to run (the host lets the encoder front wait for all of them)
 };
 __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_seq(DfxGsArgs S) {
+    if (S.started && threadIdx.x == 0) __hip_atomic_fetch_add(S.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // block -> (layer, group): consecutive blocks of a layer are dealt round-robin over the XCDs, so every L2 holds a part of every
     // layer's streamed weights (16 groups of a layer = 2 per XCD)
     const int l = (int)(blockIdx.x / (unsigned)S.groups), g = (int)(blockIdx.x % (unsigned)S.groups);

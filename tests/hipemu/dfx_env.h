@@ -533,6 +533,8 @@ template <typename T>
 static inline T __hip_atomic_load(const T *p, int, int) { return *p; }
 template <typename T, typename V>
 static inline void __hip_atomic_store(T *p, V v, int, int) { *p = (T)v; }
+template <typename T, typename V>
+static inline T __hip_atomic_fetch_add(T *p, V v, int, int) { const T o = *p; *p = (T)(o + (T)v); return o; }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline unsigned long long wall_clock64() { return 0; }
