@@ -88,6 +88,7 @@ struct GlinW {
 
 #define DFX_MAX_LANES 4
 #define DFX_LANE_EVENTS 12
+#define DFX_THROTTLE_MIN_FRAMES 16384   /* passes of at least this many frames are enqueued one at a time (dfx_model::ev_pass) */
 #define DFX_MAX_GRU_LAYERS 8   /* all GRU layers of the three stacks */
 #define DFX_MAX_TCHUNKS 16     /* time chunks of the layer-pipelined GRU phase */
 #define DFX_SEQ_GMAX 64        /* most 16-clip groups per layer the persistent GRU phase is used for (all workgroups must be co-resident) */
@@ -1844,6 +1845,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // (dfx_k_gru_seq); the projections / grouped linears / decoder tails stay per time chunk on three streams and meet the
         // recurrences through flag words in device memory instead of events — no kernel boundary, no relaunch, no pending
         // cross-queue barrier packet inside the phase.  Chunk boundaries sb[0..Ks]: planned above.
+        hipStream_t seq_tail = nullptr;   // the stream that carries the DF tail of the persistent form
         if (use_seq) {
             const int K = Ks;   // (shadows the uniform chunk count of the event-based form)
             auto tb = [&](int k) { return (int64_t)sb[k]; };
@@ -1865,6 +1867,12 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             // the front is complete (EV_XA)
             const int ev_go = overlap ? EV_START : EV_XA;
             if (!overlap && (rc = signal(EV_XA, s))) return rc;
+            // Staged enqueue (big passes; off with DFX_ENQUEUE_AHEAD=1 or DFX_PHASE_LATE=0): the host enqueues the phase only once the front
+            // has run, so that no barrier packets sit at the head of the phase's ~10 queues while the front's kernels run — measured
+            // 18.83 -> 18.20 ms per step (the same effect as between passes, dfx_model::ev_pass).  The persistent launch goes out first
+            // and the rest follows chunk-major, faster than the chain consumes it.
+            static const bool phase_late = [] { const char *e = getenv("DFX_PHASE_LATE"); return !(e && e[0] == '0'); }();
+            if (phase_late && !m->enqueue_ahead && !overlap && R >= DFX_THROTTLE_MIN_FRAMES) DFX_HIP(hipEventSynchronize(ln->ev[EV_XA]));
             if ((rc = wait(ev_go, G)) || (rc = wait(ev_go, Eq)) || (rc = wait(ev_go, Dq)) || (rc = wait(ev_go, Pq))) return rc;
             unsigned int *started = m->d_sync + 12;   // workgroups of the persistent launches that have begun to run (monotonic)
             m->seq_started += (unsigned int)(nl * groups);
@@ -1934,92 +1942,103 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             //   ts[0]  ERB tail (linear_out + the decoder's convolutions), ts[1] DF tail (skip + df_out), then the finishing kernels
             for (int l = 1; l < nl; ++l)
                 if ((rc = wait(ev_go, ln->ps[l]))) return rc;
-            // ---- ERB decoder layers
-            for (int j = 0; j < ndec; ++j) {
+            // Host enqueue order: chunk-major (every stream still sees its own packets in chunk order).  DFX_SEQ_MERGE=1 puts the consumers of
+            // equal pipeline depth on one stream — dec layer j with DF layer j, the ERB tail with the DF tail — 5 streams with 4 flag
+            // waits in flight instead of 8 with 7: every active hardware queue costs the running kernels time (see dfx_model::ev_pass).
+            static const int merge = [] { const char *e = getenv("DFX_SEQ_MERGE"); return e ? atoi(e) : 0; }();
+            const int lf = 1 + ndec;   // first DF layer
+            auto psx = [&](int l) { return merge ? ln->ps[1 + (l >= lf ? l - lf : l - 1)] : ln->ps[l]; };
+            if (merge) Dq = Eq;
+            seq_tail = Dq;
+            // ---- ERB decoder layer j, chunk k
+            auto prep_dec = [&](int j, int k) -> int {
                 const int l = 1 + j;
-                hipStream_t st = ln->ps[l];
-                for (int k = 0; k < K; ++k) {
-                    if ((rc = launch_wait_ge(m, donep(l - 1), groups, tgt(k), st))) return rc;
-                    const float *xin = ws + w.py[l - 1];
-                    if (j == 0) {
-                        if ((rc = enc_out_skip(ws + w.py[0], Mk(k), st, rmk(k))) || (rc = launch_flag_set(embf, tgt(k), st))) return rc;
-                        if (k == K - 1 && (rc = signal(EV_EMB, st))) return rc;   // the whole embedding exists (lsnr)
-                        if ((rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, xb, Mk(k), st, rmk(k)))) return rc;
-                        xin = xb;
-                    }
-                    if ((rc = proj_chunk(m->dec_gru[j], l, k, xin, st)) || (rc = launch_flag_set(ready + l, tgt(k), st))) return rc;
+                hipStream_t st = psx(l);
+                int r;
+                if ((r = launch_wait_ge(m, donep(l - 1), groups, tgt(k), st))) return r;
+                const float *xin = ws + w.py[l - 1];
+                if (j == 0) {
+                    if ((r = enc_out_skip(ws + w.py[0], Mk(k), st, rmk(k))) || (r = launch_flag_set(embf, tgt(k), st))) return r;
+                    if (k == K - 1 && (r = signal(EV_EMB, st))) return r;   // the whole embedding exists (lsnr)
+                    if ((r = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, xb, Mk(k), st, rmk(k)))) return r;
+                    xin = xb;
                 }
-            }
-            // ---- ERB tail
-            for (int k = 0; k < K; ++k) {
+                if ((r = proj_chunk(m->dec_gru[j], l, k, xin, st)) || (r = launch_flag_set(ready + l, tgt(k), st))) return r;
+                return DFX_OK;
+            };
+            // ---- ERB tail, chunk k
+            auto erb_tail = [&](int k) -> int {
                 const int64_t Rk = Mk(k);
                 const DfxRowMap rm = rmk(k);
-                if ((rc = launch_wait_ge(m, donep(ndec), groups, tgt(k), Eq))) return rc;
-                if (dev_skip_seq & 1) continue;
-                if ((rc = dec_out_skip(ws + w.py[ndec], Rk, Eq, rm))) return rc;
-                if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, Rk, E / 4, E / 4, 1, Eq, rm))) return rc;
-                if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, Rk, E / 4, E / 2, 2, Eq, rm))) return rc;
-                if (fuse_dec) {
-                    if ((rc = launch_erb_dec10<C>(m, d2, e1, e0, mask, Rk, E, Eq, rm))) return rc;
-                } else {
-                    if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, Rk, E / 2, E, 2, Eq, rm))) return rc;
-                    DfxKScope ks(DFX_K_CONV_OUT, Eq);
-                    dfx_launch(dfx_k_conv_out<C>, dim3((unsigned)nn_grid(dfx_ceil_div(Rk, fpt), 8)), dim3(DFX_CO_THREADS), co_smem, Eq,
-                               (const float *)d1, (const float *)e0, m->p(m->co_ska), m->p(m->co_skb), m->p(m->co_w), m->co_bias, mask, Rk, E,
-                               fpt, rm);
-                    DFX_LAUNCH_CHECK();
+                int r;
+                if ((r = launch_wait_ge(m, donep(ndec), groups, tgt(k), Eq))) return r;
+                if (dev_skip_seq & 1) return DFX_OK;
+                if ((r = dec_out_skip(ws + w.py[ndec], Rk, Eq, rm))) return r;
+                if ((r = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, Rk, E / 4, E / 4, 1, Eq, rm))) return r;
+                if ((r = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, Rk, E / 4, E / 2, 2, Eq, rm))) return r;
+                if (fuse_dec) return launch_erb_dec10<C>(m, d2, e1, e0, mask, Rk, E, Eq, rm);
+                if ((r = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, Rk, E / 2, E, 2, Eq, rm))) return r;
+                DfxKScope ks(DFX_K_CONV_OUT, Eq);
+                dfx_launch(dfx_k_conv_out<C>, dim3((unsigned)nn_grid(dfx_ceil_div(Rk, fpt), 8)), dim3(DFX_CO_THREADS), co_smem, Eq,
+                           (const float *)d1, (const float *)e0, m->p(m->co_ska), m->p(m->co_skb), m->p(m->co_w), m->co_bias, mask, Rk, E,
+                           fpt, rm);
+                DFX_LAUNCH_CHECK();
+                return DFX_OK;
+            };
+            // ---- DF decoder layer j, chunk k
+            auto prep_df = [&](int j, int k) -> int {
+                const int l = lf + j;
+                hipStream_t st = psx(l);
+                int r;
+                const float *xin = ws + w.py[l - 1];
+                if (j == 0) {
+                    if ((r = launch_wait_ge(m, embf, 1, tgt(k), st))) return r;
+                    if ((r = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, Mk(k), st, rmk(k)))) return r;
+                    xin = xa2;
+                } else if ((r = launch_wait_ge(m, donep(l - 1), groups, tgt(k), st))) return r;
+                if ((r = proj_chunk(m->df_gru[j], l, k, xin, st)) || (r = launch_flag_set(ready + l, tgt(k), st))) return r;
+                return DFX_OK;
+            };
+            // ---- DF tail, chunk k
+            auto df_tail = [&](int k) -> int {
+                const int l = ndec + ndf;
+                int r;
+                if (overlap) {
+                    if (c.df_gru_skip == DFX_SKIP_IDENTITY) {   // (one df_out over all frames at the end: needs every chunk of c0p)
+                        if (k == K - 1) DFX_HIP(hipStreamWaitEvent(Dq, ln->mev[K - 1], 0));
+                    } else DFX_HIP(hipStreamWaitEvent(Dq, ln->mev[k], 0));
                 }
+                if ((r = launch_wait_ge(m, donep(l), groups, tgt(k), Dq))) return r;
+                if (dev_skip_seq & 2) return DFX_OK;
+                if (c.df_gru_skip == DFX_SKIP_IDENTITY) {
+                    if (k < K - 1) return DFX_OK;   // the identity-skip form is not chunked: one add + df_out over all frames at the end
+                    {
+                        DfxKScope ks(DFX_K_ADD, Dq);
+                        dfx_launch(dfx_k_add, dim3((unsigned)nn_grid(dfx_ceil_div(R * 256, 256), 16)), dim3(256), 0, Dq,
+                                   (const float *)(ws + w.py[l]), (const float *)embv, xdf, R * 256);
+                    }
+                    DFX_LAUNCH_CHECK();
+                    return launch_ggemm(xdf, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg, m->df_out.Ng,
+                                        nullptr, DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, R, Dq, NO, Fd, T);
+                }
+                const float *cfeat = ws + w.py[l];
+                if (c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) {
+                    if ((r = launch_glin(m, m->df_skip, embv, DFX_ACT_NONE, ws + w.py[l], xdf, Mk(k), Dq, rmk(k)))) return r;
+                    cfeat = xdf;
+                }
+                return launch_ggemm(cfeat, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg, m->df_out.Ng, nullptr,
+                                    DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, Mk(k), Dq, NO, Fd, T, rmk(k));
+            };
+            if (run_df && !overlap && (rc = wait(EV_C0P, Dq))) return rc;
+            for (int k = 0; k < K; ++k) {
+                for (int j = 0; j < (ndec > ndf ? ndec : ndf); ++j) {
+                    if (j < ndec && (rc = prep_dec(j, k))) return rc;
+                    if (j < ndf && (rc = prep_df(j, k))) return rc;
+                }
+                if ((rc = erb_tail(k))) return rc;
+                if (run_df && (rc = df_tail(k))) return rc;
             }
             if ((rc = signal(EV_MASK, Eq))) return rc;
-            // ---- DF decoder layers and tail
-            if (run_df) {
-                const int lf = 1 + ndec;   // first DF layer
-                for (int j = 0; j < ndf; ++j) {
-                    const int l = lf + j;
-                    hipStream_t st = ln->ps[l];
-                    for (int k = 0; k < K; ++k) {
-                        const float *xin = ws + w.py[l - 1];
-                        if (j == 0) {
-                            if ((rc = launch_wait_ge(m, embf, 1, tgt(k), st))) return rc;
-                            if ((rc = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, Mk(k), st, rmk(k)))) return rc;
-                            xin = xa2;
-                        } else if ((rc = launch_wait_ge(m, donep(l - 1), groups, tgt(k), st))) return rc;
-                        if ((rc = proj_chunk(m->df_gru[j], l, k, xin, st)) || (rc = launch_flag_set(ready + l, tgt(k), st))) return rc;
-                    }
-                }
-                const int l = ndec + ndf;
-                if (!overlap && (rc = wait(EV_C0P, Dq))) return rc;
-                for (int k = 0; k < K; ++k) {
-                    if (overlap) {
-                        if (c.df_gru_skip == DFX_SKIP_IDENTITY) {   // (one df_out over all frames at the end: needs every chunk of c0p)
-                            if (k == K - 1) DFX_HIP(hipStreamWaitEvent(Dq, ln->mev[K - 1], 0));
-                        } else DFX_HIP(hipStreamWaitEvent(Dq, ln->mev[k], 0));
-                    }
-                    if ((rc = launch_wait_ge(m, donep(l), groups, tgt(k), Dq))) return rc;
-                    if (dev_skip_seq & 2) continue;
-                    if (c.df_gru_skip == DFX_SKIP_IDENTITY) {
-                        if (k < K - 1) continue;   // the identity-skip form is not chunked: one add + df_out over all frames at the end
-                        {
-                            DfxKScope ks(DFX_K_ADD, Dq);
-                            dfx_launch(dfx_k_add, dim3((unsigned)nn_grid(dfx_ceil_div(R * 256, 256), 16)), dim3(256), 0, Dq,
-                                       (const float *)(ws + w.py[l]), (const float *)embv, xdf, R * 256);
-                        }
-                        DFX_LAUNCH_CHECK();
-                        if ((rc = launch_ggemm(xdf, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg, m->df_out.Ng,
-                                               nullptr, DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, R, Dq, NO, Fd, T)))
-                            return rc;
-                        continue;
-                    }
-                    const float *cfeat = ws + w.py[l];
-                    if (c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) {
-                        if ((rc = launch_glin(m, m->df_skip, embv, DFX_ACT_NONE, ws + w.py[l], xdf, Mk(k), Dq, rmk(k)))) return rc;
-                        cfeat = xdf;
-                    }
-                    if ((rc = launch_ggemm(cfeat, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg, m->df_out.Ng, nullptr,
-                                           DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, Mk(k), Dq, NO, Fd, T, rmk(k))))
-                        return rc;
-                }
-            }
             // ---- lsnr on the caller's stream once the whole embedding exists (:163-165,184)
             if ((rc = wait(EV_EMB, s))) return rc;
             {
@@ -2202,7 +2221,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // cross-queue join starts after ~45 us of idle chip and was measured 17 % slower for its whole duration (0.59 vs 0.50 ms
         // for the deep filter in the rocprofv3 trace, same data, nothing overlapping); behind a kernel of its own queue the gap is
         // 6 us.  The ERB tail's masks are normally complete by then (its event is already signalled).
-        fin_s = ln->ts[1];
+        fin_s = seq_tail ? seq_tail : ln->ts[1];
         if ((rc = wait(EV_MASK, fin_s))) return rc;
     }
     if (run_df && fin_s == s && (rc = wait(EV_COEFS, s))) return rc;
@@ -2279,7 +2298,6 @@ static int model_forward_lane(const dfx_model *m, const dfx_bands *bands, const 
 
 // Enqueue throttle of the multi-stream pass (see dfx_model::ev_pass): big passes only — a small pass is over before the host has
 // enqueued the next one, and holding the host back would serialise its launch overhead with the device's work.
-#define DFX_THROTTLE_MIN_FRAMES 16384
 static int pass_begin(const dfx_model *m, int64_t frames) {
     if (m->pass_pending && m->ev_pass && !m->enqueue_ahead && m->concurrent && frames >= DFX_THROTTLE_MIN_FRAMES) DFX_HIP(hipEventSynchronize(m->ev_pass));
     m->pass_pending = false;
