@@ -1139,6 +1139,7 @@ static int launch_conv01_h3(const dfx_model *m, const PwW &w, const float *feat_
         DFX_FAIL(DFX_ERR_UNSUPPORTED, "fp16-split df_conv1 needs conv_ch %% 32 == 0");
     } else {
         if (t_end < 0) t_end = T;
+        if (B * T >= ((int64_t)1 << 31) || T * Fin >= ((int64_t)1 << 30)) DFX_FAIL(DFX_ERR_UNSUPPORTED, "df_conv0->1: batch too large for one launch (32-bit frame index)");
         DfxC01hArgs A;
         A.t_end = t_end;
         A.feat = feat_spec;

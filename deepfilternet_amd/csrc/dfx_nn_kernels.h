@@ -547,38 +547,66 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, DFX_C01_MINB) dfx_k_df_conv01_
         w0l[nt] = A.w0f[(nt * 2 + 1) * 64 + lane];
     }
     __syncthreads();
-    const int64_t Tn = A.t_end - A.t_begin;
-    const int64_t total = A.B * Tn * A.Fout;
-    const int64_t ntiles = (total + 15) / 16;
-    const int64_t tstep = (int64_t)gridDim.x * 4;
+    // Work decomposition: a wave takes whole frames (frame = wave index + i * waves of the grid) and walks the frame's ceil(Fout/16) tiles
+    // of 16 output bins.  Clip, frame and tile are then WAVE-UNIFORM (scalar registers, one 32-bit division per frame) and a lane only adds
+    // its bin: the flat (clip, frame, bin) decomposition of every lane and tap in 64-bit arithmetic was most of this kernel's
+    // instructions (780 integer VALU + 880 scalar against 540 floating-point / matrix instructions per tile).
+    const unsigned Tn = (unsigned)(A.t_end - A.t_begin);
+    const unsigned NF = (unsigned)A.B * Tn;                 // frames to produce (B * T < 2^31: checked by the host)
+    const int TPF = (A.Fout + 15) >> 4;                     // tiles per frame
+    const unsigned nwaves = gridDim.x * 4;
+    const int T32 = (int)A.T, Fin = A.Fin, Lk = A.L;
+    // the four taps (of the 3x3 window over (t, f), padded to 16) this lane feeds into the k index of the matrix op: loop invariant
+    int tdt[4], tdf[4];
+    bool tok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int tap = 4 * q + i, kt = tap / 3;
+        tok[i] = tap < 9;
+        tdt[i] = kt - 2 + Lk;            // input frame = t + tdt (tau = t - 2 + kt must be >= 0, tau + L < T)
+        tdf[i] = tap - 3 * kt - 1;
+    }
     float2 raw[3][4];
     bool okj[3];
-    // position of this lane in a tile: (b, t, fo); patch j of the tile is requested with issue(j)
-    int64_t nb = 0, ntm = 0;
-    int nfo = 0;
-    bool nvalid = false;
-    auto locate = [&](int64_t tile) {
-        const int64_t lpos = tile * 16 + jl;
-        nvalid = tile < ntiles && lpos < total;
-        const int64_t rl = lpos / A.Fout;
-        nfo = (int)(lpos - rl * A.Fout);
-        nb = rl / Tn;
-        ntm = A.t_begin + (rl - nb * Tn);
+    // next position (uniform): frame nfr = (clip nb, frame nt_), tile nft; patch j of that tile is requested with issue(j)
+    unsigned nfr = (unsigned)blockIdx.x * 4 + (unsigned)dfx_wave_uniform(wave);
+    int nft = 0, nb = 0, nt_ = 0;
+    bool nlive = nfr < NF;
+    auto settle = [&]() {   // (nb, nt_) of frame nfr
+        if (nlive) {
+            nb = (int)(nfr / Tn);
+            nt_ = (int)A.t_begin + (int)(nfr - (unsigned)nb * Tn);
+        }
     };
+    settle();
     auto issue = [&](int j) {
-        const int fi = nfo * A.stride + j - 1;
-        okj[j] = nvalid && fi >= 0 && fi < A.Fin;
-        dfx_c0_patch_load(A.feat, nb, ntm, fi, okj[j], A.T, A.Fin, A.L, q, raw[j]);
+        const int fo = nft * 16 + jl;
+        const int fi = fo * A.stride + j - 1;
+        okj[j] = nlive && fo < A.Fout && fi >= 0 && fi < Fin;
+        const float2 *clip = reinterpret_cast<const float2 *>(A.feat) + (int64_t)nb * T32 * Fin;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tin = nt_ + tdt[i], fin = fi + tdf[i];
+            float2 v = make_float2(0.f, 0.f);
+            if (okj[j] && tok[i] && tin - Lk >= 0 && tin < T32 && fin >= 0 && fin < Fin) v = clip[tin * Fin + fin];
+            raw[j][i] = v;
+        }
     };
     float amax = 0.f;   // largest magnitude that went through an f16 split (range guard)
-    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    locate(tile);
 #pragma unroll
     for (int j = 0; j < 3; ++j) issue(j);
-    for (; tile < ntiles; tile += tstep) {
-        const bool valid = nvalid;                              // located for this tile by the previous iteration
-        const int64_t pos = (nb * A.T + ntm) * A.Fout + nfo;    // physical output position
-        locate(tile + tstep);
+    while (nlive) {
+        // the tile whose patches are in raw[]
+        const int fo_c = nft * 16 + jl;
+        const bool valid = fo_c < A.Fout;
+        const int64_t pos = ((int64_t)nb * T32 + nt_) * A.Fout + fo_c;    // physical output position
+        // advance to the next tile (its patches are requested below, one by one, as raw[j] becomes free)
+        if (++nft == TPF) {
+            nft = 0;
+            nfr += nwaves;
+            nlive = nfr < NF;
+            settle();
+        }
         float u[CPL];
 #pragma unroll
         for (int i = 0; i < CPL; ++i) u[i] = 0.f;

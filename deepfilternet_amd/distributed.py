@@ -64,6 +64,10 @@ def enhance_sharded(model, df_state, audio: torch.Tensor, pad: bool = True, atte
     else:
         lo, hi = shard_range(audio.shape[0], rank, world)
         mine = audio[lo:hi]
+        if mine.device.type == "cpu" and not mine.is_pinned() and torch.cuda.is_available() and mine.numel() >= (1 << 18):
+            # this rank's slice of a pageable host batch: page-lock it (a copy of 1/world of the batch) so that enhance() moves it — and
+            # the result — by DMA on its stream instead of through the driver's pageable staging
+            mine = mine.pin_memory()
         sizes = [b - a for a, b in (shard_range(audio.shape[0], r, world) for r in range(world))]
     y = enhance_fn(model, df_state, mine, pad=pad, atten_lim_db=atten_lim_db)
     if not gather or world == 1:

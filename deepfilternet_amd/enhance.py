@@ -116,7 +116,10 @@ def enhance(model: DfNet, df_state: DF, audio: torch.Tensor, pad: bool = True, a
     if not isinstance(model, DfNet):
         raise TypeError("enhance() of deepfilternet_amd needs a deepfilternet_amd.DfNet (see init_df)")
     src_dev = audio.device
-    x = audio.to(_lib.device(), torch.float32).contiguous()
+    # a page-locked host batch moves by DMA without the driver's staging copies (and comes back into page-locked memory): the
+    # transfer is then asynchronous on the launch stream, ~55 GB/s over PCIe Gen5 instead of ~10 for pageable memory
+    pinned = src_dev.type == "cpu" and audio.is_pinned() and _lib.device().type == "cuda"
+    x = audio.to(_lib.device(), torch.float32, non_blocking=pinned).contiguous()
     if x.dim() != 2:
         raise ValueError("audio must have shape [C, T]")
     B, T = x.shape
@@ -133,6 +136,11 @@ def enhance(model: DfNet, df_state: DF, audio: torch.Tensor, pad: bool = True, a
     lim_db = float(atten_lim_db) if atten_lim_db is not None else 0.0
     _lib.check(L.dfx_enhance(model.handle, df_state.handle, _lib.ptr(x), B, T, int(bool(pad)), lim_db, _lib.ptr(y),
                              _lib.ptr(ws), ws.numel(), _lib.stream()))
+    if pinned:
+        out = torch.empty(y.shape, dtype=y.dtype, pin_memory=True)
+        out.copy_(y, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return out
     return y.to(src_dev)
 
 

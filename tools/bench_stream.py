@@ -45,8 +45,11 @@ def main() -> None:
             rt.process(x)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.calls):
+        dev_sync = int(os.environ.get("DFX_BENCH_DEV_SYNC", "0"))   # dev: the host waits after every n-th call (enqueue depth experiment)
+        for i in range(args.calls):
             y = rt.process(x)
+            if dev_sync and (i + 1) % dev_sync == 0:
+                torch.cuda.synchronize()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         assert torch.isfinite(y).all()
