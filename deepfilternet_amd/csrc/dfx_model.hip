@@ -1363,8 +1363,11 @@ static int launch_proj_h3(const dfx_model *m, const GruW &g, const float *a, flo
     const int64_t nblk = dfx_ceil_div(M, DFX_PH_BM);
     if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "projection grid too large");
     DfxKScope ks(DFX_K_PROJ, s);
-    static const int row_tiles = [] { const char *e = getenv("DFX_PROJ_RT"); return e ? atoi(e) : 2; }();   // DFX_PROJ_RT=1: one row tile per wave
-    if (row_tiles == 2) {
+    // two row tiles per wave (256-row workgroups: half the fragment reads per row, 0.36 vs 0.40 ms for 256 k rows) unless the launch is a
+    // single round of workgroups anyway — then the one-tile kernel's shorter workgroup latency wins (49 vs 79 us: the frame-by-frame
+    // streaming runtime, 4096 rows per call).  DFX_PROJ_RT=1 / 2 forces one form.
+    static const int row_tiles = [] { const char *e = getenv("DFX_PROJ_RT"); return e ? atoi(e) : 0; }();
+    if (row_tiles == 2 || (row_tiles == 0 && M > 8192)) {
         DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_proj256_h3x2<8>, DFX_PH_SMEM));
         dfx_launch(dfx_k_proj256_h3x2<8>, dim3((unsigned)dfx_ceil_div(M, 256)), dim3(512), DFX_PH_SMEM, s, A);
         DFX_LAUNCH_CHECK();

@@ -547,10 +547,11 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, DFX_C01_MINB) dfx_k_df_conv01_
         w0l[nt] = A.w0f[(nt * 2 + 1) * 64 + lane];
     }
     __syncthreads();
-    // Work decomposition: a wave takes whole frames (frame = wave index + i * waves of the grid) and walks the frame's ceil(Fout/16) tiles
-    // of 16 output bins.  Clip, frame and tile are then WAVE-UNIFORM (scalar registers, one 32-bit division per frame) and a lane only adds
-    // its bin: the flat (clip, frame, bin) decomposition of every lane and tap in 64-bit arithmetic was most of this kernel's
-    // instructions (780 integer VALU + 880 scalar against 540 floating-point / matrix instructions per tile).
+    // Work decomposition: tile = (frame, one of its ceil(Fout/16) groups of 16 output bins); a wave takes tiles wave index + i * waves of
+    // the grid.  Clip, frame and group are WAVE-UNIFORM (scalar registers: the (frame, group) pair advances incrementally, one 32-bit
+    // division per tile finds the clip) and a lane only adds its bin: the flat (clip, frame, bin) decomposition of every lane and tap
+    // in 64-bit arithmetic cost 780 integer VALU + 880 scalar instructions per tile against 540 floating-point / matrix ones (now 560 +
+    // 670; the kernel's time did not move: it is bound by the floating-point VALU work of the splits and epilogues, see profiles/).
     const unsigned Tn = (unsigned)(A.t_end - A.t_begin);
     const unsigned NF = (unsigned)A.B * Tn;                 // frames to produce (B * T < 2^31: checked by the host)
     const int TPF = (A.Fout + 15) >> 4;                     // tiles per frame
@@ -569,8 +570,11 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, DFX_C01_MINB) dfx_k_df_conv01_
     float2 raw[3][4];
     bool okj[3];
     // next position (uniform): frame nfr = (clip nb, frame nt_), tile nft; patch j of that tile is requested with issue(j)
-    unsigned nfr = (unsigned)blockIdx.x * 4 + (unsigned)dfx_wave_uniform(wave);
-    int nft = 0, nb = 0, nt_ = 0;
+    const unsigned wid = (unsigned)blockIdx.x * 4 + (unsigned)dfx_wave_uniform(wave);
+    const unsigned step_fr = nwaves / (unsigned)TPF;
+    const int step_ft = (int)(nwaves - step_fr * (unsigned)TPF);
+    unsigned nfr = wid / (unsigned)TPF;
+    int nft = (int)(wid - nfr * (unsigned)TPF), nb = 0, nt_ = 0;
     bool nlive = nfr < NF;
     auto settle = [&]() {   // (nb, nt_) of frame nfr
         if (nlive) {
@@ -601,12 +605,11 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, DFX_C01_MINB) dfx_k_df_conv01_
         const bool valid = fo_c < A.Fout;
         const int64_t pos = ((int64_t)nb * T32 + nt_) * A.Fout + fo_c;    // physical output position
         // advance to the next tile (its patches are requested below, one by one, as raw[j] becomes free)
-        if (++nft == TPF) {
-            nft = 0;
-            nfr += nwaves;
-            nlive = nfr < NF;
-            settle();
-        }
+        nft += step_ft;
+        nfr += step_fr;
+        if (nft >= TPF) nft -= TPF, ++nfr;
+        nlive = nfr < NF;
+        settle();
         float u[CPL];
 #pragma unroll
         for (int i = 0; i < CPL; ++i) u[i] = 0.f;
