@@ -353,6 +353,7 @@ struct dfx_model {
     bool front_overlap = false;
     int front_ahead = 0;                // DFX_FRONT_AHEAD=n > 0: the front stays at most n chunks ahead of the encoder GRU
     int front_split = 1;                // DFX_FRONT_SPLIT=n: (test hook) the front in n time ranges, one after the other, without overlap
+    mutable unsigned int seq_xcd_base = 0;  // per-XCD arrival counters of the persistent launches (10 workgroups per XCD and launch)
     mutable unsigned int seq_started = 0;  // workgroups of all persistent GRU launches so far (the front waits until they are resident)
     unsigned int *d_err = nullptr;      // device words: [0] a bounded spin of the two-CU GRU kernel timed out, [1] fp16-split range, [2] flag wait timed out
     mutable unsigned int epoch = 0;     // tags the h exchange of one forward pass
@@ -793,7 +794,7 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
             const char *tq = getenv("DFX_SEQ_TRACE");
             if (tq && tq[0] == '1') (void)hipMalloc(reinterpret_cast<void **>(&m->d_trace), (size_t)DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX * DFX_GS_MAX_CHUNKS * 3 * 8);
         }
-        const size_t sync_bytes = (size_t)(16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX) * sizeof(unsigned int);
+        const size_t sync_bytes = (size_t)(16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX + 8) * sizeof(unsigned int);   // ready | emb, started | done | per-XCD arrival counters
         if (hipMalloc(reinterpret_cast<void **>(&m->d_sync), sync_bytes) != hipSuccess || hipMemset(m->d_sync, 0, sync_bytes) != hipSuccess ||
             hipMalloc(reinterpret_cast<void **>(&m->d_err), 256) != hipSuccess || hipMemset(m->d_err, 0, 256) != hipSuccess) {
             dfx_model_free(m);
@@ -1896,6 +1897,15 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 S.ready = ready, S.done = done, S.done_stride = DFX_SEQ_GMAX, S.base = base, S.err = m->d_err;
                 S.trace = m->d_trace;
                 S.started = started;
+                // XCD placement of the layers (DFX_SEQ_XCD=1; default: every layer on every XCD).  Measured at config 2: 17.96 vs 18.02 ms per
+                // step — the chain's slowdown under load is not an L2-capacity effect
+                static const bool seq_xcd = [] { const char *e = getenv("DFX_SEQ_XCD"); return e && e[0] == '1'; }();
+                S.xcd_cnt = nullptr, S.xcd_base = 0;
+                if (seq_xcd && nl == 5 && groups == 16 && dfx_env_num_xcds() == 8) {
+                    S.xcd_cnt = m->d_sync + 16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX;
+                    S.xcd_base = m->seq_xcd_base;
+                    m->seq_xcd_base += 10u;
+                }
                 m->trace_dims[0] = nl, m->trace_dims[1] = groups, m->trace_dims[2] = K;
                 DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_seq, DFX_GH_SMEM));
                 DfxKScope ks(DFX_K_GRU_REC, G);

@@ -2604,12 +2604,39 @@ struct DfxGsArgs {
     unsigned int *err;
     unsigned long long *trace;   // dev aid: [layers][groups][K][3] or null
     unsigned int *started;       // counts the workgroups that have begun to run (the host lets the encoder front wait for all of them)
+    // XCD placement (null: block -> (layer, group) by index, every layer on every XCD).  With 5 layers x 16 groups on 8 XCDs a workgroup
+    // takes its role from the XCD it finds itself on and its arrival order there (xcd_cnt[x], monotonic; 10 workgroups per XCD and
+    // launch): layers 0 / 2 live on XCDs 0-3, layers 1 / 3 on XCDs 4-7 (4 groups per XCD), layer 4 on all (2 per XCD) — an L2 then
+    // holds the streamed W_hh share of 2-3 layers (1.1 MB) instead of all five (2.2 MB of its 4 MB) beside the background kernels' streams
+    unsigned int *xcd_cnt;
+    unsigned int xcd_base;
 };
 __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_seq(DfxGsArgs S) {
     if (S.started && threadIdx.x == 0) __hip_atomic_fetch_add(S.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // block -> (layer, group): consecutive blocks of a layer are dealt round-robin over the XCDs, so every L2 holds a part of every
     // layer's streamed weights (16 groups of a layer = 2 per XCD)
-    const int l = (int)(blockIdx.x / (unsigned)S.groups), g = (int)(blockIdx.x % (unsigned)S.groups);
+    int l = (int)(blockIdx.x / (unsigned)S.groups), g = (int)(blockIdx.x % (unsigned)S.groups);
+    if (S.xcd_cnt) {   // (host: only with nlayers == 5, groups == 16, an 80-block grid on 8 XCDs)
+        __shared__ int role;
+        if (threadIdx.x == 0) {
+            const int x = dfx_xcc_id() & 7;
+            const int slot = (int)(__hip_atomic_fetch_add(S.xcd_cnt + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - S.xcd_base);
+            int ll, gg;
+            if (slot < 8) {
+                ll = (x < 4 ? 0 : 1) + 2 * (slot >> 2);
+                gg = 4 * (x & 3) + (slot & 3);
+            } else {
+                ll = 4;
+                gg = 2 * x + (slot - 8);
+            }
+            role = (slot >= 0 && slot < 10) ? ll * 16 + gg : -1;
+        }
+        __syncthreads();
+        const int rr = role;
+        __syncthreads();
+        if (rr < 0) return;   // (cannot happen with an even round-robin dispatch; the bounded flag waits of the consumers would report it)
+        l = rr >> 4, g = rr & 15;
+    }
     if (l >= S.nlayers) return;
     DfxGhArgs A;
     A.gi = S.gi[l];

@@ -36,6 +36,8 @@ static inline int dfx_env_num_cus() {
     }
     return n;
 }
+// XCDs of the device (MI355X: 256 CUs in 8 XCDs; the runtime does not report the count: 32 CUs per XCD on gfx950)
+static inline int dfx_env_num_xcds() { return dfx_env_num_cus() / 32; }
 static inline bool dfx_env_is_emulator() { return false; }
 // a value that is the same in every lane of a wave by construction (e.g. derived from threadIdx.x >> 6): tells the compiler so
 // (address arithmetic on it stays in SGPRs and loads through it can be scalar loads)

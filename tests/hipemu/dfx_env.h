@@ -157,6 +157,7 @@ static inline hipError_t hipGetDevice(int *d) {
     *d = 0;
     return hipSuccess;
 }
+static inline int dfx_env_num_xcds() { return 1; }
 static inline int dfx_env_num_cus() { return 4; }  // tiny "chip" so grid-stride paths are exercised
 static inline bool dfx_env_is_emulator() { return true; }
 
