@@ -220,6 +220,12 @@ def main() -> None:
     kern = {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in sorted(serial.items(), key=lambda kv: -kv[1][0])}
     _lib.prof_enable(None)
 
+    if os.environ.get("DFX_BENCH_SKIP_EXTRAS") == "1":   # dev (tools/gpu_kern.sh): the timed loop and the per-kernel breakdown only
+        frames = world * B * (T // HOP) * args.steps
+        print(json.dumps({"value": frames / dt, "ms_per_step": dt / args.steps * 1e3, "dfa_in_loop_ms": (dfa_ms / dfa_n) if dfa_n else None,
+                          "kernels": kern}), flush=True)
+        return
+
     def hbm_record(kernel, ms, nbytes, extra=None):
         ach = nbytes / (ms * 1e-3) / 1e9
         r = {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),

@@ -303,8 +303,17 @@ extern "C" int dfx_unit_norm_init(int n, float *out) {
 static size_t dsp_smem_bytes(const dfx_state *st) {
     return (size_t)st->N * 12 + (size_t)DFX_DSP_TEAMS * 2 * (size_t)(st->plan.M + 2) * 8;
 }
-static int grid_for(int64_t work_groups) {
-    const int64_t cap = (int64_t)dfx_env_num_cus() * 8;  // memory-bound: ~8 workgroups per CU, grid-stride the rest
+// analysis: the 480-point plan transforms in place — one buffer per frame (dfx_plan_is_480, dfx_k_analysis)
+static bool ana_in_place(const dfx_state *st) {
+    static const bool off = [] { const char *e = getenv("DFX_FFT_IN_PLACE"); return e && e[0] == '0'; }();   // DFX_FFT_IN_PLACE=0: two buffers per frame
+    const DfxFftPlan &pl = st->plan;
+    return !off && pl.M == 480 && pl.nstage == 5 && pl.radix[0] == 4 && pl.radix[1] == 4 && pl.radix[2] == 2 && pl.radix[3] == 3 && pl.radix[4] == 5;
+}
+static size_t ana_smem_bytes(const dfx_state *st) {
+    return (size_t)st->N * 12 + (size_t)DFX_DSP_TEAMS * (ana_in_place(st) ? 1 : 2) * (size_t)(st->plan.M + 2) * 8;
+}
+static int grid_for(int64_t work_groups, int per_cu = 8) {
+    const int64_t cap = (int64_t)dfx_env_num_cus() * per_cu;  // memory-bound: ~8 workgroups per CU, grid-stride the rest
     return (int)(work_groups < cap ? (work_groups > 0 ? work_groups : 1) : cap);
 }
 
@@ -332,11 +341,17 @@ int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t 
         A.nb = st->nb;
         A.wnorm = st->wnorm;
         A.plan = st->plan;
-        const size_t smem = dsp_smem_bytes(st);
-        if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_analysis, smem));
-        const int grid = grid_for(dfx_ceil_div(B * Tf, DFX_DSP_TEAMS));
+        const bool ip = ana_in_place(st);
+        const size_t smem = ana_smem_bytes(st);
+        const int grid = grid_for(dfx_ceil_div(B * Tf, DFX_DSP_TEAMS), ip ? 9 : 8);   // (three resident workgroups per CU in place: whole rounds)
         DfxKScope ks(DFX_K_ANALYSIS, s);
-        dfx_launch(dfx_k_analysis, dim3(grid), dim3(DFX_DSP_THREADS), smem, s, A);
+        if (ip) {
+            if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_analysis<true>, smem));
+            dfx_launch(dfx_k_analysis<true>, dim3(grid), dim3(DFX_DSP_THREADS), smem, s, A);
+        } else {
+            if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_analysis<false>, smem));
+            dfx_launch(dfx_k_analysis<false>, dim3(grid), dim3(DFX_DSP_THREADS), smem, s, A);
+        }
         DFX_LAUNCH_CHECK();
     }
     if (mem_out && B > 0) {
@@ -406,14 +421,21 @@ int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int6
     A.chunks = (int)dfx_ceil_div(A.f_end - A.f_begin, A.outf);
     A.plan = st->plan;
     if (A.chunks <= 0) return DFX_OK;
-    const size_t smem = dsp_smem_bytes(st);
-    if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_synthesis, smem));
+    static const bool syn_off = [] { const char *e = getenv("DFX_FFT_IN_PLACE"); return e && e[0] == '2'; }();   // =2: analysis only
+    const bool ip = ana_in_place(st) && !syn_off;   // the 480-point plan transforms in place: one buffer per frame
+    const size_t smem = ip ? ana_smem_bytes(st) : dsp_smem_bytes(st);
     int64_t nblk = B * A.chunks;
     // persistent workgroups (the twiddle / window tables are staged once per workgroup): a few per CU, grid-stride over the work items
-    const int64_t cap = (int64_t)dfx_env_num_cus() * 8;
+    const int64_t cap = (int64_t)dfx_env_num_cus() * (ip ? 9 : 8);   // (three resident workgroups per CU in place: whole rounds)
     if (nblk > cap) nblk = cap;
     DfxKScope ks(DFX_K_SYNTHESIS, stream);
-    dfx_launch(dfx_k_synthesis, dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, stream, A);
+    if (ip) {
+        if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_synthesis<true>, smem));
+        dfx_launch(dfx_k_synthesis<true>, dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, stream, A);
+    } else {
+        if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_synthesis<false>, smem));
+        dfx_launch(dfx_k_synthesis<false>, dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, stream, A);
+    }
     DFX_LAUNCH_CHECK();
     return DFX_OK;
 }

@@ -140,6 +140,98 @@ static __device__ __forceinline__ void dfx_fft_pass_c(const float2 *x, float2 *y
     }
 }
 
+// The same pass IN PLACE: a lane first reads the inputs of all its butterflies, then writes their outputs.  One team is one wave, whose
+// lanes run in lockstep and whose LDS accesses complete in program order, so every read of the pass precedes every write (the wave-level
+// sync between the two halves costs nothing on the GPU and is what the CPU interpreter needs).  Same butterflies, same twiddles, same
+// order of operations as dfx_fft_pass_c — same bits — with half the LDS per frame: 3 workgroups per CU instead of 2 (the STFT kernels
+// wait on LDS / memory latencies for more than half of their wave-cycles; profiles/r02_pmc_stft_kernels.txt).
+template <int R, int SG, int M, int NCUR, int S>
+static __device__ __forceinline__ void dfx_fft_pass_ip(float2 *x, const float2 *tw, int lane, bool active) {
+    constexpr int m = NCUR / R, nbf = M / R, tws = (2 * M) / NCUR, NR = (nbf + DFX_DSP_TEAM - 1) / DFX_DSP_TEAM;
+    float2 a[NR][R];
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int b = lane + r * DFX_DSP_TEAM;
+            const int p = b / S, q = b - p * S;
+#pragma unroll
+            for (int j = 0; j < R; ++j) a[r][j] = b < nbf ? x[q + S * (p + m * j)] : make_float2(0.f, 0.f);
+        }
+    }
+    DFX_WAVE_SYNC();
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int b = lane + r * DFX_DSP_TEAM;
+            if (b >= nbf) continue;
+            const int p = b / S, q = b - p * S;
+            float2 o[R];
+            if constexpr (R == 2) {
+                o[0] = dfx_cadd(a[r][0], a[r][1]);
+                o[1] = dfx_csub(a[r][0], a[r][1]);
+            } else if constexpr (R == 3) {
+                const float2 sm = dfx_cadd(a[r][1], a[r][2]), d = dfx_csub(a[r][1], a[r][2]);
+                const float2 mm = make_float2(a[r][0].x - 0.5f * sm.x, a[r][0].y - 0.5f * sm.y);
+                float2 jd = dfx_mul_sgi<SG>(d);
+                jd.x *= 0.86602540378443864676f;
+                jd.y *= 0.86602540378443864676f;
+                o[0] = dfx_cadd(a[r][0], sm);
+                o[1] = dfx_cadd(mm, jd);
+                o[2] = dfx_csub(mm, jd);
+            } else if constexpr (R == 4) {
+                const float2 t0 = dfx_cadd(a[r][0], a[r][2]), t1 = dfx_csub(a[r][0], a[r][2]);
+                const float2 t2 = dfx_cadd(a[r][1], a[r][3]), t3 = dfx_mul_sgi<SG>(dfx_csub(a[r][1], a[r][3]));
+                o[0] = dfx_cadd(t0, t2);
+                o[1] = dfx_cadd(t1, t3);
+                o[2] = dfx_csub(t0, t2);
+                o[3] = dfx_csub(t1, t3);
+            } else {  // R == 5
+                const float c1 = 0.30901699437494742410f, s1 = 0.95105651629515357212f;
+                const float c2 = -0.80901699437494742410f, s2 = 0.58778525229247312917f;
+                const float2 s14 = dfx_cadd(a[r][1], a[r][4]), d14 = dfx_csub(a[r][1], a[r][4]);
+                const float2 s23 = dfx_cadd(a[r][2], a[r][3]), d23 = dfx_csub(a[r][2], a[r][3]);
+                const float2 m1 = make_float2(a[r][0].x + c1 * s14.x + c2 * s23.x, a[r][0].y + c1 * s14.y + c2 * s23.y);
+                const float2 m2 = make_float2(a[r][0].x + c2 * s14.x + c1 * s23.x, a[r][0].y + c2 * s14.y + c1 * s23.y);
+                const float2 n1 = dfx_mul_sgi<SG>(make_float2(s1 * d14.x + s2 * d23.x, s1 * d14.y + s2 * d23.y));
+                const float2 n2 = dfx_mul_sgi<SG>(make_float2(s2 * d14.x - s1 * d23.x, s2 * d14.y - s1 * d23.y));
+                o[0] = make_float2(a[r][0].x + s14.x + s23.x, a[r][0].y + s14.y + s23.y);
+                o[1] = dfx_cadd(m1, n1);
+                o[4] = dfx_csub(m1, n1);
+                o[2] = dfx_cadd(m2, n2);
+                o[3] = dfx_csub(m2, n2);
+            }
+            x[q + S * (R * p)] = o[0];
+#pragma unroll
+            for (int j = 1; j < R; ++j) {
+                float2 w = tw[j * p * tws];
+                if (SG > 0) w.y = -w.y;
+                x[q + S * (R * p + j)] = dfx_cmul(o[j], w);
+            }
+        }
+    }
+    DFX_WAVE_SYNC();
+}
+// the 48 kHz / 20 ms configuration of every shipped model: N = 960, M = 480 = 4*4*2*3*5 (make_plan's order)
+static __device__ __forceinline__ bool dfx_plan_is_480(const DfxFftPlan &pl) {
+    return pl.M == 480 && pl.nstage == 5 && pl.radix[0] == 4 && pl.radix[1] == 4 && pl.radix[2] == 2 && pl.radix[3] == 3 && pl.radix[4] == 5;
+}
+// (the lane index is made opaque before every pass: the passes' LDS addresses depend on nothing but the lane, and a compiler that hoists
+// all ~100 of them out of the kernel's frame loop — it does — pushes the kernel from 80 to 150 registers, i.e. from six waves per SIMD to three)
+template <int SG>
+static __device__ __forceinline__ void dfx_fft480_ip(float2 *x, const float2 *tw, int lane, bool active) {
+    int l = lane;
+    DFX_OPAQUE(l);
+    dfx_fft_pass_ip<4, SG, 480, 480, 1>(x, tw, l, active);
+    DFX_OPAQUE(l);
+    dfx_fft_pass_ip<4, SG, 480, 120, 4>(x, tw, l, active);
+    DFX_OPAQUE(l);
+    dfx_fft_pass_ip<2, SG, 480, 30, 16>(x, tw, l, active);
+    DFX_OPAQUE(l);
+    dfx_fft_pass_ip<3, SG, 480, 15, 32>(x, tw, l, active);
+    DFX_OPAQUE(l);
+    dfx_fft_pass_ip<5, SG, 480, 5, 96>(x, tw, l, active);
+}
+
 // Complex FFT of length pl.M by one 64-lane team.  Data starts in `a`; returns the buffer that holds the result.
 // A team is exactly one wave, so the passes only need a wave-level barrier (DFX_WAVE_SYNC): the 8 teams of a workgroup run
 // their FFTs independently instead of meeting at a workgroup barrier after every pass.
@@ -200,7 +292,10 @@ struct DfxAnaArgs {
 // STFT analysis: frame (b,t) = rfft_N( window * stream[(t+1)*hop-N : (t+1)*hop] ) * wnorm   (lib.rs:356-394),
 // stream = [mem_in (N-hop zeros after a reset) ; x].  One wave per frame, 8 frames per workgroup pass, grid-stride.
 // Optional fused ERB band energies in dB (lib.rs:206-212 without the norm; transforms.rs:236-253).
-__global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_analysis(DfxAnaArgs A) {
+// IP: the 480-point plan, transformed in place (one LDS buffer per frame; a kernel of its own so that the generic plan's run-time loops
+// do not cost it registers: three workgroups = six waves per SIMD have to fit)
+template <bool IP>
+__global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_analysis(DfxAnaArgs A) {
     DFX_DYN_SMEM(unsigned char, smem);
     const int N = A.plan.N, M = A.plan.M, F = M + 1;
     float2 *tw = reinterpret_cast<float2 *>(smem);                       // [N]
@@ -208,8 +303,10 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_analysis(DfxAnaArgs A) 
     const size_t team_off = (size_t)N * 12;
     const size_t buf_elems = (size_t)(M + 2);                            // M+1 used, padded to keep 16-byte carve
     const int team = threadIdx.x / DFX_DSP_TEAM, lane = threadIdx.x % DFX_DSP_TEAM;
-    float2 *bufA = reinterpret_cast<float2 *>(smem + team_off) + (size_t)team * 2 * buf_elems;
-    float2 *bufB = bufA + buf_elems;
+    // the 480-point plan transforms in place: one buffer per frame (the host sizes the dynamic LDS accordingly, dfx_dsp.hip)
+    constexpr bool ip = IP;
+    float2 *bufA = reinterpret_cast<float2 *>(smem + team_off) + (size_t)team * (ip ? 1 : 2) * buf_elems;
+    float2 *bufB = bufA + buf_elems;   // (not ip only)
     // twiddles + window: every load of a pass is issued before the first LDS store (a load -> store loop waits out one memory
     // latency per iteration; the compiler does not batch across a runtime trip count)
     for (int i0 = threadIdx.x; i0 < N; i0 += 4 * DFX_DSP_THREADS) {
@@ -277,9 +374,47 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_analysis(DfxAnaArgs A) 
             }
         }
         DFX_WAVE_SYNC();
-        float2 *Z = dfx_fft_team<-1>(bufA, bufB, tw, A.plan, lane, active);
+        float2 *Z = bufA;
+        float *pw = nullptr;    // |X|^2 per bin for the ERB feature (float array)
+        int pws = 1;            // stride of pw in floats
+        if constexpr (IP) {
+            dfx_fft480_ip<-1>(bufA, tw, lane, active);
+            // real post-pass on the pairs (k, M-k): both bins of a pair need Z[k] and Z[M-k] and nothing else, so a lane that owns the pair
+            // can put |X|^2 of the two bins back into the .x halves of the two slots it has just read (pw stride 2 floats; slot M takes
+            // the Nyquist bin)
+            pw = reinterpret_cast<float *>(bufA);
+            pws = 2;
+            if (active) {
+                float2 *out = A.spec + (b * A.Tf + t) * A.spec_stride;
+                if (lane == 0 && A.spec_stride > F) out[F] = make_float2(0.f, 0.f);  // the pad bin of an aligned row
+                auto bin = [&](int k, float2 zk, float2 zc) -> float2 {
+                    // E = (Z[k] + conj(Z[M-k]))/2 ; O = (Z[k] - conj(Z[M-k]))/(2i) ; X[k] = E + exp(-2*pi*i*k/N) * O
+                    const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);
+                    const float dr = 0.5f * (zk.x - zc.x), di = 0.5f * (zk.y + zc.y);
+                    const float2 tt = dfx_cmul(make_float2(di, -dr), tw[k]);
+                    return make_float2((er + tt.x) * A.wnorm, (ei + tt.y) * A.wnorm);
+                };
+                for (int k = lane; k <= M / 2; k += DFX_DSP_TEAM) {
+                    const int kc = M - k;                     // partner bin (k = 0: the Nyquist bin M, both from Z[0])
+                    const float2 za = Z[k], zb = Z[k == 0 ? 0 : kc];
+                    const float2 Xa = bin(k, za, zb);
+                    out[k] = Xa;
+                    float pa = __fadd_rn(__fmul_rn(Xa.x, Xa.x), __fmul_rn(Xa.y, Xa.y)), pb = 0.f;
+                    if (kc != k) {
+                        const float2 Xb = bin(kc, zb, za);
+                        out[kc] = Xb;
+                        pb = __fadd_rn(__fmul_rn(Xb.x, Xb.x), __fmul_rn(Xb.y, Xb.y));
+                    }
+                    if (A.erb_db) {
+                        pw[2 * k] = pa;
+                        if (kc != k) pw[2 * kc] = pb;
+                    }
+                }
+            }
+        } else {
+        Z = dfx_fft_team<-1>(bufA, bufB, tw, A.plan, lane, active);
         float2 *other = (Z == bufA) ? bufB : bufA;
-        float *pw = reinterpret_cast<float *>(other);  // |X|^2 per bin for the ERB feature
+        pw = reinterpret_cast<float *>(other);
         if (active) {
             float2 *out = A.spec + (b * A.Tf + t) * A.spec_stride;
             if (lane == 0 && A.spec_stride > F) out[F] = make_float2(0.f, 0.f);  // the pad bin of an aligned row
@@ -295,6 +430,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_analysis(DfxAnaArgs A) 
                 if (A.erb_db) pw[k] = __fadd_rn(__fmul_rn(X.x, X.x), __fmul_rn(X.y, X.y));
             }
         }
+        }
         if (A.erb_db) {
             DFX_WAVE_SYNC();
             if (active && lane < A.nb) {
@@ -302,14 +438,14 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_analysis(DfxAnaArgs A) 
                 const int s0 = A.band_start[lane], s1 = A.band_start[lane + 1];
                 const float kk = A.band_invw[lane];
                 float acc = 0.f;
-                for (int j = s0; j < s1; ++j) acc = __fadd_rn(acc, __fmul_rn(pw[j], kk));
+                for (int j = s0; j < s1; ++j) acc = __fadd_rn(acc, __fmul_rn(pw[pws * j], kk));
                 A.erb_db[(b * A.Tf + t) * A.nb + lane] = log10f(acc + 1e-10f) * 10.f;
             }
             for (int e = DFX_DSP_TEAM + lane; active && e < A.nb; e += DFX_DSP_TEAM) {  // nb > 64 (rare)
                 const int s0 = A.band_start[e], s1 = A.band_start[e + 1];
                 const float kk = A.band_invw[e];
                 float acc = 0.f;
-                for (int j = s0; j < s1; ++j) acc = __fadd_rn(acc, __fmul_rn(pw[j], kk));
+                for (int j = s0; j < s1; ++j) acc = __fadd_rn(acc, __fmul_rn(pw[pws * j], kk));
                 A.erb_db[(b * A.Tf + t) * A.nb + e] = log10f(acc + 1e-10f) * 10.f;
             }
         }
@@ -350,17 +486,20 @@ struct DfxSynArgs {
 // ISTFT + window + overlap-add (lib.rs:396-427).  A workgroup produces `outf` consecutive output hops of one row from
 // DFX_DSP_TEAMS = outf + R - 1 frames (the first R-1 are halo frames recomputed instead of carried through memory).
 // Sum order per output sample follows the reference: oldest contribution first, the current frame last.
-__global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_synthesis(DfxSynArgs A) {
+// IP: the 480-point plan in place, one LDS buffer per frame (see dfx_k_analysis<IP>).
+template <bool IP>
+__global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_synthesis(DfxSynArgs A) {
     DFX_DYN_SMEM(unsigned char, smem);
     const int N = A.plan.N, M = A.plan.M;
     float2 *tw = reinterpret_cast<float2 *>(smem);
     float *win = reinterpret_cast<float *>(smem + (size_t)N * 8);
     const size_t team_off = (size_t)N * 12;
     const size_t buf_elems = (size_t)(M + 2);
+    constexpr int NBUF = IP ? 1 : 2;   // buffers per frame
     const int team = threadIdx.x / DFX_DSP_TEAM, lane = threadIdx.x % DFX_DSP_TEAM;
     float2 *bufs = reinterpret_cast<float2 *>(smem + team_off);
-    float2 *bufA = bufs + (size_t)team * 2 * buf_elems;
-    float2 *bufB = bufA + buf_elems;
+    float2 *bufA = bufs + (size_t)team * NBUF * buf_elems;
+    float2 *bufB = IP ? bufA : bufA + buf_elems;   // the frame is staged here
     // the last 4 bytes of the team area of team 0 would be too fragile for a flag: keep result-buffer parity in a
     // register instead (identical for all teams because the plan is uniform)
     // twiddles + window: every load of a pass is issued before the first LDS store (a load -> store loop waits out one memory
@@ -440,23 +579,39 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_synthesis(DfxSynArgs A)
         }
     }
     DFX_WAVE_SYNC();
-    if (active) {
-        for (int k = lane; k < M; k += DFX_DSP_TEAM) {
-            float2 xk = bufB[k], xm = bufB[M - k];
-            if (k == 0) {  // C2R ignores imag(DC) and imag(Nyquist)
-                xk.y = 0.f;
-                xm.y = 0.f;
-            }
-            // E' = X[k] + conj(X[M-k]) ; O' = conj(w^k) * (X[k] - conj(X[M-k])) ; Z = E' + i*O'
-            const float er = xk.x + xm.x, ei = xk.y - xm.y;
-            float2 w = tw[k];
-            w.y = -w.y;
-            const float2 o = dfx_cmul(make_float2(xk.x - xm.x, xk.y + xm.y), w);
-            bufA[k] = make_float2(er - o.y, ei + o.x);
+    // E' = X[k] + conj(X[M-k]) ; O' = conj(w^k) * (X[k] - conj(X[M-k])) ; Z[k] = E' + i*O'
+    auto zbin = [&](int k, float2 xk, float2 xm) -> float2 {
+        if (k == 0) {  // C2R ignores imag(DC) and imag(Nyquist)
+            xk.y = 0.f;
+            xm.y = 0.f;
         }
+        const float er = xk.x + xm.x, ei = xk.y - xm.y;
+        float2 w = tw[k];
+        w.y = -w.y;
+        const float2 o = dfx_cmul(make_float2(xk.x - xm.x, xk.y + xm.y), w);
+        return make_float2(er - o.y, ei + o.x);
+    };
+    float2 *Z = bufA;
+    if constexpr (IP) {
+        // in place on the pairs (k, M-k): Z[k] and Z[M-k] need X[k] and X[M-k] and nothing else (k = 0 pairs with the Nyquist bin M and
+        // only produces Z[0]; k = M/2 is its own partner)
+        if (active) {
+            for (int k = lane; k <= M / 2; k += DFX_DSP_TEAM) {
+                const int kc = M - k;
+                const float2 xa = bufA[k], xb = bufA[kc];
+                const float2 za = zbin(k, xa, xb);
+                if (k != 0 && kc != k) bufA[kc] = zbin(kc, xb, xa);
+                bufA[k] = za;
+            }
+        }
+        DFX_WAVE_SYNC();
+        dfx_fft480_ip<+1>(bufA, tw, lane, active);
+    } else {
+        if (active)
+            for (int k = lane; k < M; k += DFX_DSP_TEAM) bufA[k] = zbin(k, bufB[k], bufB[M - k]);
+        DFX_WAVE_SYNC();
+        Z = dfx_fft_team<+1>(bufA, bufB, tw, A.plan, lane, active);
     }
-    DFX_WAVE_SYNC();
-    float2 *Z = dfx_fft_team<+1>(bufA, bufB, tw, A.plan, lane, active);
     const bool in_a = (Z == bufA);
     {
         // apply_window_in_place (lib.rs:406): the interleaved (re, im) pairs of z ARE the time samples
@@ -483,7 +638,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_synthesis(DfxSynArgs A)
             const int off = r * A.hop + i;
             if (tr >= 0 && tr < A.Tf && off < N) {
                 const int tm = (int)(tr - (t0 - (A.R - 1)));
-                const float *fr = reinterpret_cast<const float *>(bufs + (size_t)tm * 2 * buf_elems + (in_a ? 0 : buf_elems));
+                const float *fr = reinterpret_cast<const float *>(bufs + (size_t)tm * NBUF * buf_elems + (in_a ? 0 : buf_elems));
                 acc = have ? acc + fr[off] : fr[off];
                 have = true;
             }
@@ -491,7 +646,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS) dfx_k_synthesis(DfxSynArgs A)
         float cur = 0.f;
         if (tf < A.Tf) {
             const int tm = (int)(tf - (t0 - (A.R - 1)));
-            const float *fr = reinterpret_cast<const float *>(bufs + (size_t)tm * 2 * buf_elems + (in_a ? 0 : buf_elems));
+            const float *fr = reinterpret_cast<const float *>(bufs + (size_t)tm * NBUF * buf_elems + (in_a ? 0 : buf_elems));
             cur = fr[i];
         }
         const float v = have ? cur + acc : cur;
