@@ -76,7 +76,7 @@ def test_df_capi_frame_loop(backend, tmp_path):
         msgs.append(C.cast(m, C.c_char_p).value.decode())
         lib.df_free_log_msg(m)
     assert any(f"lookahead {p.df_lookahead}" in m for m in msgs), msgs
-    T = 5 if backend == "emu" else 20
+    T = (3 if emu_subset(backend) else 5) if backend == "emu" else 20
     rng = np.random.default_rng(7)
     x = (0.1 * rng.standard_normal(HOP * T)).astype(np.float32)
     sd = torch_sd(p, 9)
