@@ -11,6 +11,7 @@
 #include <utility>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));   // arithmetic on these compiles to the packed fp32 ops (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // dynamic LDS carve: base kept 16-byte aligned (cdna_hip_programming.md Guideline 17)

@@ -65,6 +65,7 @@ static inline float4 make_float4(float x, float y, float z, float w) { return fl
 static inline int2 make_int2(int x, int y) { return int2{x, y}; }
 
 typedef float f32x4 __attribute__((vector_size(16)));
+typedef float f32x2 __attribute__((vector_size(8)));
 typedef float f32x16 __attribute__((vector_size(64)));
 
 typedef int hipError_t;
