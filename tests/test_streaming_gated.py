@@ -67,7 +67,7 @@ def test_gated_stream_matches_oracle(backend, name, T, quantiles, cuts):
     if emu_subset(backend) and quantiles[0] == 0.0:
         pytest.skip("interpreter subset: the all-branches scenario runs here, this one on the GPU (DFX_EMU_ALL=1 runs both)")
     if backend == "emu":  # the interpreter is slow: fewer hops, one cut pattern
-        T, cuts = (14, ([2] * 7 if len(cuts) < 10 else [1] * 14)) if not emu_subset(backend) else (10, [2] * 5)
+        T, cuts = 14, ([2] * 7 if len(cuts) < 10 else [1] * 14)
     p = named_params(name)
     sd = torch_sd(p, 9)
     model, df_state, _, _ = init_df(params=p, epoch="none", seed=9)
@@ -166,7 +166,7 @@ def test_multichannel_streams(backend, reduce_mask, gating):
     p = named_params("pf32")
     sd = torch_sd(p, 9)
     model, df_state, _, _ = init_df(params=p, epoch="none", seed=9)
-    T = (8 if emu_subset(backend) else 12) if backend == "emu" else 24
+    T = 12 if backend == "emu" else 24
     rng = np.random.default_rng(5)
     x = (0.1 * rng.standard_normal((4, HOP * T))).astype(np.float32)
     x[1] *= 0.3                                        # the channels of a stream differ
