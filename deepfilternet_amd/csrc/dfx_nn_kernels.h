@@ -2309,6 +2309,29 @@ __global__ void __launch_bounds__(DFX_GRU_THREADS, 2) dfx_k_gru_rec(const float 
 #define DFX_GH_D 6       /* ring slots for the streamed pairs */
 #endif
 #define DFX_GH_HROW 264  /* halves per row of the f16 copy of h (256 + 8 pad) */
+#ifndef DFX_GH_SPLIT
+#define DFX_GH_SPLIT 0   /* 1: the sub-tiles are walked in two halves and the gate math of the first half is issued between the matrix ops of the second (measured: +0.2 ms per step, not the default) */
+#endif
+// Consumption order of the fragments: position f -> (k-chunk, gate, sub-tile).  DFX_GH_SPLIT=0: kc-major over all 3*NS tiles.  =1: two
+// halves of the sub-tiles (s < NS/2, then s >= NS/2), each kc-major over its 3*NS/2 tiles — the accumulators of the first half are complete
+// when the second half starts, and their gate math (exp / rcp chains on the VALU, ~1.3 us of a 5.1 us step when it runs after the last
+// matrix op) is issued in slices between the matrix ops of the second half (one wave per SIMD: nothing else would overlap the two pipes).
+#if DFX_GH_SPLIT
+#define DFX_GH_HT (DFX_GH_TILES / 2)
+#define DFX_GH_POS_HALF(f) ((f) / (DFX_GH_NF / 2))
+#define DFX_GH_POS_KC(f) (((f) % (DFX_GH_NF / 2)) / DFX_GH_HT)
+#define DFX_GH_POS_TT(f) (((f) % (DFX_GH_NF / 2)) % DFX_GH_HT)
+#define DFX_GH_POS_GATE(f) (DFX_GH_POS_TT(f) / (DFX_GH_NS / 2))
+#define DFX_GH_POS_S(f) (DFX_GH_POS_HALF(f) * (DFX_GH_NS / 2) + DFX_GH_POS_TT(f) % (DFX_GH_NS / 2))
+#else
+#define DFX_GH_HT DFX_GH_TILES
+#define DFX_GH_POS_HALF(f) 0
+#define DFX_GH_POS_KC(f) ((f) / DFX_GH_TILES)
+#define DFX_GH_POS_TT(f) ((f) % DFX_GH_TILES)
+#define DFX_GH_POS_GATE(f) (((f) % DFX_GH_TILES) / DFX_GH_NS)
+#define DFX_GH_POS_S(f) (((f) % DFX_GH_TILES) % DFX_GH_NS)
+#endif
+#define DFX_GH_POS_TILE(f) (DFX_GH_POS_GATE(f) * DFX_GH_NS + DFX_GH_POS_S(f))
 #define DFX_GH_SMEM_W ((size_t)DFX_GH_FL * DFX_GH_NW * 2 * 64 * 16)
 #define DFX_GH_SMEM (DFX_GH_SMEM_W + (size_t)2 * 2 * DFX_GH_ROWS * DFX_GH_HROW * 2)
 
@@ -2387,7 +2410,7 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
     const int64_t brow = valid ? b0 + jl : A.B - 1;
     // fragment f = kc*TILES + gate*NS + s of this wave is global pair ((unit tile = wave*NS + s)*8 + kc)*3 + gate
     const dfx_h8 *wg = A.whf + lane;
-#define DFX_GH_GIDX(f) (((((size_t)wave * NS + ((f) % TILES) % NS) * 8 + (f) / TILES) * 3 + ((f) % TILES) / NS) * 2 * 64)
+#define DFX_GH_GIDX(f) (((((size_t)wave * NS + DFX_GH_POS_S(f)) * 8 + DFX_GH_POS_KC(f)) * 3 + DFX_GH_POS_GATE(f)) * 2 * 64)
     // ---- resident fragments
     dfx_h8 wr[FR][2];
     dfx_static_for<0, NF>([&](auto fc) {
@@ -2482,14 +2505,41 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
         dfx_h8 bh[2], bl[2];
         bh[0] = *reinterpret_cast<const dfx_h8 *>(hb);
         bl[0] = *reinterpret_cast<const dfx_h8 *>(hb + (size_t)DFX_GH_ROWS * HROW);
+        // ---- gates, new state (lane: clip jl, units UW*w + 16s + 4q + r): one unit per call, so that the first half's can be issued in
+        // slices between the second half's matrix ops
+        auto gate_unit = [&](int s, int r) {
+            const float gr = r == 0 ? gv[0][s].x : r == 1 ? gv[0][s].y : r == 2 ? gv[0][s].z : gv[0][s].w;
+            const float gz = r == 0 ? gv[1][s].x : r == 1 ? gv[1][s].y : r == 2 ? gv[1][s].z : gv[1][s].w;
+            const float gn = r == 0 ? gv[2][s].x : r == 1 ? gv[2][s].y : r == 2 ? gv[2][s].z : gv[2][s].w;
+            const float bb = r == 0 ? bn[s].x : r == 1 ? bn[s].y : r == 2 ? bn[s].z : bn[s].w;
+            if (DFX_GH_ABLATE & 8) {
+                hp[s][r] = 0.5f * hp[s][r] + 1e-3f * (gr + gz + gn + bb + acc[s][r] + acc[NS + s][r] + acc[2 * NS + s][r]);
+                return;
+            }
+            const float rg = dfx_fast_rcp(1.f + dfx_fast_exp(-(gr + acc[0 * NS + s][r] * A.unscale)));
+            const float zg = dfx_fast_rcp(1.f + dfx_fast_exp(-(gz + acc[1 * NS + s][r] * A.unscale)));
+            const float pre = gn + rg * (acc[2 * NS + s][r] * A.unscale + bb);
+            const float ng = 2.f * dfx_fast_rcp(1.f + dfx_fast_exp(-2.f * pre)) - 1.f;
+            hp[s][r] = (1.f - zg) * ng + zg * hp[s][r];
+        };
+        auto gate_finish = [&](int s) {   // the sub-tile's four units are done: next step's gi, y, the f16 copy of h for the next step
+            if (!(DFX_GH_ABLATE & 2)) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) gv[g][s] = *reinterpret_cast<const float4 *>(gp + tn * (3 * H) + g * H + 16 * s);
+            }
+            if (valid && !(DFX_GH_ABLATE & 16)) *reinterpret_cast<float4 *>(yp + t * H + 16 * s) = make_float4(hp[s][0], hp[s][1], hp[s][2], hp[s][3]);
+            put_h16(cur ^ 1, s);
+        };
         // three fragments (= three different accumulator tiles of one k-chunk) per group: the 9 MFMAs are issued so that
         // consecutive ones never touch the same accumulator (a dependent 16x16x32 MFMA would wait for its predecessor)
         dfx_static_for<0, NF / 3>([&](auto gc) {
-            constexpr int f0 = 3 * decltype(gc)::value;
-            constexpr int kc = f0 / TILES, tile0 = f0 % TILES;
-            if constexpr (tile0 == (TILES / 6) * 3 && kc + 1 < 8) {  // next k-chunk of h, half a chunk ahead
-                bh[(kc + 1) & 1] = *reinterpret_cast<const dfx_h8 *>(hb + 32 * (kc + 1));
-                bl[(kc + 1) & 1] = *reinterpret_cast<const dfx_h8 *>(hb + (size_t)DFX_GH_ROWS * HROW + 32 * (kc + 1));
+            constexpr int grp = decltype(gc)::value, f0 = 3 * grp;
+            constexpr int kc = DFX_GH_POS_KC(f0), tt0 = DFX_GH_POS_TT(f0), half = DFX_GH_POS_HALF(f0);
+            // next k-chunk of h, half a chunk ahead (the first chunk of the second half: at the end of the first)
+            if constexpr (tt0 == (DFX_GH_HT / 6) * 3 && (kc + 1 < 8 || (DFX_GH_SPLIT && half == 0))) {
+                constexpr int kn = (kc + 1) % 8;
+                bh[kn & 1] = *reinterpret_cast<const dfx_h8 *>(hb + 32 * kn);
+                bl[kn & 1] = *reinterpret_cast<const dfx_h8 *>(hb + (size_t)DFX_GH_ROWS * HROW + 32 * kn);
             }
             dfx_h8 whi[3], wlo[3];
             dfx_static_for<0, 3>([&](auto ic) {
@@ -2505,16 +2555,41 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
                     wlo[i] = ring[SC.idx[f] % D][1];
                 }
             });
+            constexpr int ta = DFX_GH_POS_TILE(f0), tb_ = DFX_GH_POS_TILE(f0 + 1), tc = DFX_GH_POS_TILE(f0 + 2);
+            // One unit of the first half's gate math per group PAIR of the second half (16 groups, 8 units), in the same scheduling region
+            // as the group's nine matrix ops, with the instruction order asked for as 1 matrix op : 3 VALU (sched_group_barrier): the matrix
+            // pipe takes a new op every 16 cycles and the wave would otherwise sit out 12 of them — a block of VALU work *behind* the
+            // nine ops was measured to gain nothing (the pipe then idles during the block).
+            constexpr int NU1 = (NS / 2) * 4;                                   // units of the first half per lane
+            constexpr int G1 = NF / 6;                                          // groups per half
+            constexpr bool has_unit = DFX_GH_SPLIT && half == 1 && ((grp - G1) % (G1 / NU1)) == 0 && (grp - G1) / (G1 / NU1) < NU1;
+            constexpr int uu = has_unit ? (grp - G1) / (G1 / NU1) : 0, su = uu / 4, ru = uu % 4;
+            if constexpr (has_unit) gate_unit(su, ru);
             if (!(DFX_GH_ABLATE & 4)) {
+                acc[ta] = dfx_mfma_16x16x32_f16(wlo[0], bh[kc & 1], acc[ta]);
+                acc[tb_] = dfx_mfma_16x16x32_f16(wlo[1], bh[kc & 1], acc[tb_]);
+                acc[tc] = dfx_mfma_16x16x32_f16(wlo[2], bh[kc & 1], acc[tc]);
+                acc[ta] = dfx_mfma_16x16x32_f16(whi[0], bl[kc & 1], acc[ta]);
+                acc[tb_] = dfx_mfma_16x16x32_f16(whi[1], bl[kc & 1], acc[tb_]);
+                acc[tc] = dfx_mfma_16x16x32_f16(whi[2], bl[kc & 1], acc[tc]);
+                acc[ta] = dfx_mfma_16x16x32_f16(whi[0], bh[kc & 1], acc[ta]);
+                acc[tb_] = dfx_mfma_16x16x32_f16(whi[1], bh[kc & 1], acc[tb_]);
+                acc[tc] = dfx_mfma_16x16x32_f16(whi[2], bh[kc & 1], acc[tc]);
+                if constexpr (has_unit) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) acc[tile0 + i] = dfx_mfma_16x16x32_f16(wlo[i], bh[kc & 1], acc[tile0 + i]);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) acc[tile0 + i] = dfx_mfma_16x16x32_f16(whi[i], bl[kc & 1], acc[tile0 + i]);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) acc[tile0 + i] = dfx_mfma_16x16x32_f16(whi[i], bh[kc & 1], acc[tile0 + i]);
+                    for (int i = 0; i < 9; ++i) {
+                        DFX_SCHED_GROUP(0x008, 1);   // one matrix op
+                        DFX_SCHED_GROUP(0x002, 3);   // three VALU instructions of the gate unit
+                    }
+                }
             } else {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) acc[tile0 + i][0] += (float)whi[i][0] + (float)wlo[i][1] + (float)bh[kc & 1][0] + (float)bl[kc & 1][0];
+                acc[ta][0] += (float)whi[0][0] + (float)wlo[0][1] + (float)bh[kc & 1][0] + (float)bl[kc & 1][0];
+                acc[tb_][0] += (float)whi[1][0] + (float)wlo[1][1] + (float)bh[kc & 1][0] + (float)bl[kc & 1][0];
+                acc[tc][0] += (float)whi[2][0] + (float)wlo[2][1] + (float)bh[kc & 1][0] + (float)bl[kc & 1][0];
+            }
+            if constexpr (has_unit && ru == 3) {
+                DFX_SCHED_BARRIER();
+                gate_finish(su);
             }
             DFX_SCHED_BARRIER();
             dfx_static_for<0, 3>([&](auto ic) {
@@ -2527,31 +2602,12 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
             });
             DFX_SCHED_BARRIER();
         });
-        // ---- gates, new state (lane: clip jl, units UW*w + 16s + 4q + r)
+        // ---- the sub-tiles whose gate math has not been issued yet (all of them with DFX_GH_SPLIT=0, the second half otherwise)
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const float gr[4] = {gv[0][s].x, gv[0][s].y, gv[0][s].z, gv[0][s].w};
-            const float gz[4] = {gv[1][s].x, gv[1][s].y, gv[1][s].z, gv[1][s].w};
-            const float gn[4] = {gv[2][s].x, gv[2][s].y, gv[2][s].z, gv[2][s].w};
-            const float bb[4] = {bn[s].x, bn[s].y, bn[s].z, bn[s].w};
+        for (int s = DFX_GH_SPLIT ? NS / 2 : 0; s < NS; ++s) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (DFX_GH_ABLATE & 8) {
-                    hp[s][r] = 0.5f * hp[s][r] + 1e-3f * (gr[r] + gz[r] + gn[r] + bb[r] + acc[s][r] + acc[NS + s][r] + acc[2 * NS + s][r]);
-                    continue;
-                }
-                const float rg = dfx_fast_rcp(1.f + dfx_fast_exp(-(gr[r] + acc[0 * NS + s][r] * A.unscale)));
-                const float zg = dfx_fast_rcp(1.f + dfx_fast_exp(-(gz[r] + acc[1 * NS + s][r] * A.unscale)));
-                const float pre = gn[r] + rg * (acc[2 * NS + s][r] * A.unscale + bb[r]);
-                const float ng = 2.f * dfx_fast_rcp(1.f + dfx_fast_exp(-2.f * pre)) - 1.f;
-                hp[s][r] = (1.f - zg) * ng + zg * hp[s][r];
-            }
-            if (!(DFX_GH_ABLATE & 2)) {
-#pragma unroll
-                for (int g = 0; g < 3; ++g) gv[g][s] = *reinterpret_cast<const float4 *>(gp + tn * (3 * H) + g * H + 16 * s);
-            }
-            if (valid && !(DFX_GH_ABLATE & 16)) *reinterpret_cast<float4 *>(yp + t * H + 16 * s) = make_float4(hp[s][0], hp[s][1], hp[s][2], hp[s][3]);
-            put_h16(cur ^ 1, s);
+            for (int r = 0; r < 4; ++r) gate_unit(s, r);
+            gate_finish(s);
         }
         __syncthreads();
         cur ^= 1;

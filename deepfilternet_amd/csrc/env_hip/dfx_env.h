@@ -104,6 +104,7 @@ static __device__ __forceinline__ f32x4 dfx_mfma_16x16x32_f16(dfx_h8 a, dfx_h8 b
 // compiler fences used by the hand-scheduled kernels
 #define DFX_OPAQUE(x) asm volatile("" : "+v"(x))
 #define DFX_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#define DFX_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)   /* ask for n instructions of a class next (0x008 MFMA, 0x002 VALU) */
 // barrier + LDS visibility among the 64 lanes of ONE wave (LDS operations of a wave complete in order; the fences only pin the
 // compiler's ordering) — costs nothing compared with s_barrier across the workgroup
 #define DFX_WAVE_SYNC()                                          \
@@ -114,4 +115,10 @@ static __device__ __forceinline__ f32x4 dfx_mfma_16x16x32_f16(dfx_h8 a, dfx_h8 b
     } while (0)
 
 static __device__ __forceinline__ float dfx_fast_exp(float x) { return __expf(x); }
+// v_rcp_f32: one instruction, 1 ulp.  (__frcp_rn — the correctly rounded reciprocal — is a ten-instruction sequence: v_div_scale, v_rcp,
+// four v_fma, v_div_fmas, v_div_fixup; the GRU gates take three reciprocals per hidden unit and step, on the latency chain of the step.)
+#ifndef DFX_RCP_RN
+static __device__ __forceinline__ float dfx_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#else
 static __device__ __forceinline__ float dfx_fast_rcp(float x) { return __frcp_rn(x); }
+#endif
