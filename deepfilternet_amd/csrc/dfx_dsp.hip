@@ -305,7 +305,7 @@ static size_t dsp_smem_bytes(const dfx_state *st) {
 }
 // analysis: the 480-point plan transforms in place — one buffer per frame (dfx_plan_is_480, dfx_k_analysis)
 static bool ana_in_place(const dfx_state *st) {
-    static const bool off = [] { const char *e = getenv("DFX_FFT_IN_PLACE"); return e && e[0] == '0'; }();   // DFX_FFT_IN_PLACE=0: two buffers per frame
+    static const bool off = [] { const char *e = getenv("DFX_FFT_IN_PLACE"); return e && e[0] == '0'; }();   // DFX_FFT_IN_PLACE=0: two buffers per frame (1: the ISTFT in place too)
     const DfxFftPlan &pl = st->plan;
     return !off && pl.M == 480 && pl.nstage == 5 && pl.radix[0] == 4 && pl.radix[1] == 4 && pl.radix[2] == 2 && pl.radix[3] == 3 && pl.radix[4] == 5;
 }
@@ -421,8 +421,10 @@ int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int6
     A.chunks = (int)dfx_ceil_div(A.f_end - A.f_begin, A.outf);
     A.plan = st->plan;
     if (A.chunks <= 0) return DFX_OK;
-    static const bool syn_off = [] { const char *e = getenv("DFX_FFT_IN_PLACE"); return e && e[0] == '2'; }();   // =2: analysis only
-    const bool ip = ana_in_place(st) && !syn_off;   // the 480-point plan transforms in place: one buffer per frame
+    // the synthesis kernel keeps two buffers per frame by default: in place it fits six waves per SIMD only with 14 spilled registers (its
+    // frame prefetch) and was measured no faster in the pipeline and slower / erratic alone (1.15 -> 1.2-1.8 ms); DFX_FFT_IN_PLACE=1 selects it
+    static const bool syn_on = [] { const char *e = getenv("DFX_FFT_IN_PLACE"); return e && e[0] == '1'; }();
+    const bool ip = ana_in_place(st) && syn_on;
     const size_t smem = ip ? ana_smem_bytes(st) : dsp_smem_bytes(st);
     int64_t nblk = B * A.chunks;
     // persistent workgroups (the twiddle / window tables are staged once per workgroup): a few per CU, grid-stride over the work items
