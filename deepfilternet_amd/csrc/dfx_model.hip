@@ -1366,11 +1366,17 @@ static int launch_proj_h3(const dfx_model *m, const GruW &g, const float *a, flo
     DfxKScope ks(DFX_K_PROJ, s);
     // two row tiles per wave (256-row workgroups: half the fragment reads per row, 0.36 vs 0.40 ms for 256 k rows) unless the launch is a
     // single round of workgroups anyway — then the one-tile kernel's shorter workgroup latency wins (49 vs 79 us: the frame-by-frame
-    // streaming runtime, 4096 rows per call).  DFX_PROJ_RT=1 / 2 forces one form.
+    // streaming runtime, 4096 rows per call).  DFX_PROJ_RT=1 / 2 / 3 forces one form.
     static const int row_tiles = [] { const char *e = getenv("DFX_PROJ_RT"); return e ? atoi(e) : 0; }();
+    if (row_tiles == 3) {   // two workgroups of 4 waves per CU on 32-column chunks (measured 0.375 vs 0.363 ms: not the default)
+        DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_proj256_h3x2<4, 2>, DFX_PH_SMEM / 2));
+        dfx_launch((dfx_k_proj256_h3x2<4, 2>), dim3((unsigned)dfx_ceil_div(M, 128)), dim3(256), DFX_PH_SMEM / 2, s, A);
+        DFX_LAUNCH_CHECK();
+        return DFX_OK;
+    }
     if (row_tiles == 2 || (row_tiles == 0 && M > 8192)) {
-        DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_proj256_h3x2<8>, DFX_PH_SMEM));
-        dfx_launch(dfx_k_proj256_h3x2<8>, dim3((unsigned)dfx_ceil_div(M, 256)), dim3(512), DFX_PH_SMEM, s, A);
+        DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_proj256_h3x2<8, 4>, DFX_PH_SMEM));
+        dfx_launch((dfx_k_proj256_h3x2<8, 4>), dim3((unsigned)dfx_ceil_div(M, 256)), dim3(512), DFX_PH_SMEM, s, A);
         DFX_LAUNCH_CHECK();
         return DFX_OK;
     }

@@ -2015,15 +2015,31 @@ __global__ void __launch_bounds__(DFX_PH_THREADS, 2) dfx_k_proj256_h3(DfxPhArgs 
 // SIMD, and ds_read_b128 runs at half the LDS rate); here a workgroup is NW waves x 32 rows: NW = 8 (256 rows, two waves per SIMD, ~220
 // registers) halves the fragment reads per row; NW = 4 (128 rows, one wave per SIMD) was measured slower than the one-tile kernel
 // (0.61 vs 0.43 ms for 256 k rows: a lone wave per SIMD cannot hide its own LDS / barrier latencies).
-template <int NW>
-__global__ void __launch_bounds__(64 * NW, 1) dfx_k_proj256_h3x2(DfxPhArgs A) {
+#ifndef DFX_PH_ABLATE
+#define DFX_PH_ABLATE 0   /* dev ablations (tools/dev/proj_h3_bench.hip): 1 no output stores, 2 no LDS refill of the next chunk, 4 no matrix ops, 8 no prefetch loads */
+#endif
+// CT: 16-column tiles per LDS chunk.  CT = 4 (64 columns, 2 x 64 KB of LDS: one workgroup per CU) or CT = 2 (32 columns, 2 x 32 KB: TWO
+// workgroups of 4 waves per CU).  What the ablations of tools/dev/proj_h3_ablate.sh show for <8, 4> (0.364 ms per 256 k rows): without the
+// output stores 0.262, without the matrix ops 0.308, without the LDS refill 0.33 — the phases of a chunk (matrix ops | 64 KB of output
+// stores at the HBM write rate | refill | barrier) run one after the other, in all eight waves at once.  Two independent workgroups per
+// CU do not share a barrier: one stores while the other computes.
+template <int NW, int CT>
+__global__ void __launch_bounds__(64 * NW, CT == 2 ? 2 : 1) dfx_k_proj256_h3x2(DfxPhArgs A) {
     constexpr int DFX_PH2_THREADS = 64 * NW, BM2 = 32 * NW;
-    DFX_DYN_SMEM(dfx_h8, ws);  // [2][DFX_PH_CHUNK_H8]
+    constexpr int CH8 = 8 * CT * 2 * 64;   // dfx_h8 per chunk: [kc][ct][hi,lo][lane]
+    DFX_DYN_SMEM(dfx_h8, ws);  // [2][CH8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
-    const int nchunks = A.N / DFX_PH_NC;
-    constexpr int PER_T = DFX_PH_CHUNK_H8 / DFX_PH2_THREADS;  // 16 x 16 bytes per thread and chunk
+    const int nchunks = A.N / (16 * CT);
+    constexpr int PER_T = CH8 / DFX_PH2_THREADS;  // 16-byte pieces per thread and chunk
+    // chunk c of CT tiles inside the host's 64-column blocks [N/64][8][4][hi,lo][64]: piece i -> (kc, ct, half, lane)
+    auto src_of = [&](int c, int i) -> const dfx_h8 * {
+        const int e = i * DFX_PH2_THREADS + tid;              // element inside the chunk: ((kc * CT + ct) * 2 + half) * 64 + lane
+        const int kc = e / (CT * 128), r = e - kc * (CT * 128);   // r = (ct * 2 + half) * 64 + lane
+        const int blk = (c * CT) / 4, ct0 = (c * CT) % 4;
+        return A.wf + (size_t)blk * DFX_PH_CHUNK_H8 + (size_t)(kc * 4 + ct0) * 128 + r;
+    };
 #pragma unroll
-    for (int i = 0; i < PER_T; ++i) ws[i * DFX_PH2_THREADS + tid] = A.wf[i * DFX_PH2_THREADS + tid];
+    for (int i = 0; i < PER_T; ++i) ws[i * DFX_PH2_THREADS + tid] = *src_of(0, i);
     dfx_h8 xh[2][8], xl[2][8];
     float unscale[2];
     int64_t mrow[2];
@@ -2064,53 +2080,52 @@ __global__ void __launch_bounds__(64 * NW, 1) dfx_k_proj256_h3x2(DfxPhArgs A) {
     }
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
-        const dfx_h8 *wc = ws + (size_t)(c & 1) * DFX_PH_CHUNK_H8;
+        const dfx_h8 *wc = ws + (size_t)(c & 1) * CH8;
         dfx_h8 pre[PER_T];
-        if (c + 1 < nchunks) {
-            const dfx_h8 *src = A.wf + (size_t)(c + 1) * DFX_PH_CHUNK_H8;
+        if (c + 1 < nchunks && !(DFX_PH_ABLATE & 8)) {
 #pragma unroll
-            for (int i = 0; i < PER_T; ++i) pre[i] = src[i * DFX_PH2_THREADS + tid];
+            for (int i = 0; i < PER_T; ++i) pre[i] = *src_of(c + 1, i);
         }
-        f32x4 acc[2][4];   // eight independent accumulators: no matrix op waits for its predecessor
+        f32x4 acc[2][CT];  // 2 * CT independent accumulators: no matrix op waits for its predecessor
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[t][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ct = 0; ct < CT; ++ct) acc[t][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kc = 0; kc < 8; ++kc) {
-            dfx_h8 whi[4], wlo[4];
+            dfx_h8 whi[CT], wlo[CT];
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                whi[ct] = wc[((kc * 4 + ct) * 2 + 0) * 64 + lane];
-                wlo[ct] = wc[((kc * 4 + ct) * 2 + 1) * 64 + lane];
+            for (int ct = 0; ct < CT; ++ct) {
+                whi[ct] = wc[((kc * CT + ct) * 2 + 0) * 64 + lane];
+                wlo[ct] = wc[((kc * CT + ct) * 2 + 1) * 64 + lane];
             }
             // per accumulator the same order of the three terms as in the one-tile kernel: same bits
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
+            for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc[t][ct] = dfx_mfma_16x16x32_f16(wlo[ct], xh[t][kc], acc[t][ct]);
+                for (int t = 0; t < 2; ++t) acc[t][ct] = (DFX_PH_ABLATE & 4) ? acc[t][ct] + f32x4{(float)wlo[ct][0], 0.f, 0.f, (float)xh[t][kc][0]} : dfx_mfma_16x16x32_f16(wlo[ct], xh[t][kc], acc[t][ct]);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
+            for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc[t][ct] = dfx_mfma_16x16x32_f16(whi[ct], xl[t][kc], acc[t][ct]);
+                for (int t = 0; t < 2; ++t) acc[t][ct] = (DFX_PH_ABLATE & 4) ? acc[t][ct] : dfx_mfma_16x16x32_f16(whi[ct], xl[t][kc], acc[t][ct]);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
+            for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc[t][ct] = dfx_mfma_16x16x32_f16(whi[ct], xh[t][kc], acc[t][ct]);
+                for (int t = 0; t < 2; ++t) acc[t][ct] = (DFX_PH_ABLATE & 4) ? acc[t][ct] : dfx_mfma_16x16x32_f16(whi[ct], xh[t][kc], acc[t][ct]);
         }
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            const int n = c * DFX_PH_NC + 16 * ct + 4 * q;
+        for (int ct = 0; ct < CT; ++ct) {
+            const int n = c * (16 * CT) + 16 * ct + 4 * q;
             const float4 bz = *reinterpret_cast<const float4 *>(A.bias + n);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-                if (okr[t])
+                if (okr[t] && (!(DFX_PH_ABLATE & 1) || acc[t][ct][0] == 1.2345e-30f))
                     *reinterpret_cast<float4 *>(A.out + mrow[t] * A.N + n) =
                         make_float4(acc[t][ct][0] * unscale[t] + bz.x, acc[t][ct][1] * unscale[t] + bz.y, acc[t][ct][2] * unscale[t] + bz.z,
                                     acc[t][ct][3] * unscale[t] + bz.w);
         }
-        if (c + 1 < nchunks) {
-            dfx_h8 *dst = ws + (size_t)((c + 1) & 1) * DFX_PH_CHUNK_H8;
+        if (c + 1 < nchunks && !(DFX_PH_ABLATE & 2)) {
+            dfx_h8 *dst = ws + (size_t)((c + 1) & 1) * CH8;
 #pragma unroll
             for (int i = 0; i < PER_T; ++i) dst[i * DFX_PH2_THREADS + tid] = pre[i];
         }
