@@ -305,7 +305,8 @@ static size_t dsp_smem_bytes(const dfx_state *st) {
 }
 // analysis: the 480-point plan transforms in place — one buffer per frame (dfx_plan_is_480, dfx_k_analysis)
 static bool ana_in_place(const dfx_state *st) {
-    static const bool off = [] { const char *e = getenv("DFX_FFT_IN_PLACE"); return e && e[0] == '0'; }();   // DFX_FFT_IN_PLACE=0: two buffers per frame (1: the ISTFT in place too)
+    const char *e = getenv("DFX_FFT_IN_PLACE");   // read per launch (one STFT launch per call): =0 two buffers per frame, =1 the ISTFT in place too
+    const bool off = e && e[0] == '0';
     const DfxFftPlan &pl = st->plan;
     return !off && pl.M == 480 && pl.nstage == 5 && pl.radix[0] == 4 && pl.radix[1] == 4 && pl.radix[2] == 2 && pl.radix[3] == 3 && pl.radix[4] == 5;
 }
@@ -423,7 +424,8 @@ int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int6
     if (A.chunks <= 0) return DFX_OK;
     // the synthesis kernel keeps two buffers per frame by default: in place it fits six waves per SIMD only with 14 spilled registers (its
     // frame prefetch) and was measured no faster in the pipeline and slower / erratic alone (1.15 -> 1.2-1.8 ms); DFX_FFT_IN_PLACE=1 selects it
-    static const bool syn_on = [] { const char *e = getenv("DFX_FFT_IN_PLACE"); return e && e[0] == '1'; }();
+    const char *ipe = getenv("DFX_FFT_IN_PLACE");
+    const bool syn_on = ipe && ipe[0] == '1';
     const bool ip = ana_in_place(st) && syn_on;
     const size_t smem = ip ? ana_smem_bytes(st) : dsp_smem_bytes(st);
     int64_t nblk = B * A.chunks;

@@ -353,6 +353,9 @@ struct dfx_model {
     bool front_overlap = false;
     int front_ahead = 0;                // DFX_FRONT_AHEAD=n > 0: the front stays at most n chunks ahead of the encoder GRU
     int front_split = 1;                // DFX_FRONT_SPLIT=n: (test hook) the front in n time ranges, one after the other, without overlap
+    bool phase_late = true;             // DFX_PHASE_LATE=0: the GRU phase is enqueued right behind the front (no staged enqueue)
+    bool seq_xcd = false, seq_merge = false;   // DFX_SEQ_XCD=1 / DFX_SEQ_MERGE=1 (measured: no gain)
+    int proj_rt = 0;                    // DFX_PROJ_RT=1|2|3: one form of the projection kernel for every launch size
     mutable unsigned int seq_xcd_base = 0;  // per-XCD arrival counters of the persistent launches (10 workgroups per XCD and launch)
     mutable unsigned int seq_started = 0;  // workgroups of all persistent GRU launches so far (the front waits until they are resident)
     unsigned int *d_err = nullptr;      // device words: [0] a bounded spin of the two-CU GRU kernel timed out, [1] fp16-split range, [2] flag wait timed out
@@ -790,6 +793,11 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         m->front_overlap = fo && fo[0] == '1';
         m->front_ahead = fa ? atoi(fa) : 0;
         m->front_split = fsp && atoi(fsp) > 1 ? atoi(fsp) : 1;
+        const char *pl = getenv("DFX_PHASE_LATE"), *sx = getenv("DFX_SEQ_XCD"), *sm = getenv("DFX_SEQ_MERGE"), *prt = getenv("DFX_PROJ_RT");
+        m->phase_late = !(pl && pl[0] == '0');
+        m->seq_xcd = sx && sx[0] == '1';
+        m->seq_merge = sm && atoi(sm) != 0;
+        m->proj_rt = prt ? atoi(prt) : 0;
         {
             const char *tq = getenv("DFX_SEQ_TRACE");
             if (tq && tq[0] == '1') (void)hipMalloc(reinterpret_cast<void **>(&m->d_trace), (size_t)DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX * DFX_GS_MAX_CHUNKS * 3 * 8);
@@ -1367,7 +1375,7 @@ static int launch_proj_h3(const dfx_model *m, const GruW &g, const float *a, flo
     // two row tiles per wave (256-row workgroups: half the fragment reads per row, 0.36 vs 0.40 ms for 256 k rows) unless the launch is a
     // single round of workgroups anyway — then the one-tile kernel's shorter workgroup latency wins (49 vs 79 us: the frame-by-frame
     // streaming runtime, 4096 rows per call).  DFX_PROJ_RT=1 / 2 / 3 forces one form.
-    static const int row_tiles = [] { const char *e = getenv("DFX_PROJ_RT"); return e ? atoi(e) : 0; }();
+    const int row_tiles = m->proj_rt;
     if (row_tiles == 3) {   // two workgroups of 4 waves per CU on 32-column chunks (measured 0.375 vs 0.363 ms: not the default)
         DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_proj256_h3x2<4, 2>, DFX_PH_SMEM / 2));
         dfx_launch((dfx_k_proj256_h3x2<4, 2>), dim3((unsigned)dfx_ceil_div(M, 128)), dim3(256), DFX_PH_SMEM / 2, s, A);
@@ -1882,8 +1890,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             // has run, so that no barrier packets sit at the head of the phase's ~10 queues while the front's kernels run — measured
             // 18.83 -> 18.20 ms per step (the same effect as between passes, dfx_model::ev_pass).  The persistent launch goes out first
             // and the rest follows chunk-major, faster than the chain consumes it.
-            static const bool phase_late = [] { const char *e = getenv("DFX_PHASE_LATE"); return !(e && e[0] == '0'); }();
-            if (phase_late && !m->enqueue_ahead && !overlap && R >= DFX_THROTTLE_MIN_FRAMES) DFX_HIP(hipEventSynchronize(ln->ev[EV_XA]));
+            if (m->phase_late && !m->enqueue_ahead && !overlap && R >= DFX_THROTTLE_MIN_FRAMES) DFX_HIP(hipEventSynchronize(ln->ev[EV_XA]));
             if ((rc = wait(ev_go, G)) || (rc = wait(ev_go, Eq)) || (rc = wait(ev_go, Dq)) || (rc = wait(ev_go, Pq))) return rc;
             unsigned int *started = m->d_sync + 12;   // workgroups of the persistent launches that have begun to run (monotonic)
             m->seq_started += (unsigned int)(nl * groups);
@@ -1905,9 +1912,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 S.started = started;
                 // XCD placement of the layers (DFX_SEQ_XCD=1; default: every layer on every XCD).  Measured at config 2: 17.96 vs 18.02 ms per
                 // step — the chain's slowdown under load is not an L2-capacity effect
-                static const bool seq_xcd = [] { const char *e = getenv("DFX_SEQ_XCD"); return e && e[0] == '1'; }();
                 S.xcd_cnt = nullptr, S.xcd_base = 0;
-                if (seq_xcd && nl == 5 && groups == 16 && dfx_env_num_xcds() == 8) {
+                if (m->seq_xcd && nl == 5 && groups == 16 && dfx_env_num_xcds() == 8) {
                     S.xcd_cnt = m->d_sync + 16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX;
                     S.xcd_base = m->seq_xcd_base;
                     m->seq_xcd_base += 10u;
@@ -1965,7 +1971,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             // Host enqueue order: chunk-major (every stream still sees its own packets in chunk order).  DFX_SEQ_MERGE=1 puts the consumers of
             // equal pipeline depth on one stream — dec layer j with DF layer j, the ERB tail with the DF tail — 5 streams with 4 flag
             // waits in flight instead of 8 with 7: every active hardware queue costs the running kernels time (see dfx_model::ev_pass).
-            static const int merge = [] { const char *e = getenv("DFX_SEQ_MERGE"); return e ? atoi(e) : 0; }();
+            const bool merge = m->seq_merge;
             const int lf = 1 + ndec;   // first DF layer
             auto psx = [&](int l) { return merge ? ln->ps[1 + (l >= lf ? l - lf : l - 1)] : ln->ps[l]; };
             if (merge) Dq = Eq;
