@@ -107,6 +107,19 @@ def _norm_alpha(df: DF, tau: float = 1.0) -> float:
     return p.norm_alpha()
 
 
+def _workspace_cap(model: DfNet) -> Optional[int]:
+    """Bytes the enhance() workspace may take: DFX_WORKSPACE_CAP_GB if set, else 90 % of what the device has free plus the workspace this
+    model already holds (None when that cannot be asked, e.g. on the CPU interpreter build)."""
+    env = os.environ.get("DFX_WORKSPACE_CAP_GB")
+    if env:
+        return int(float(env) * (1 << 30))
+    if _lib.device().type != "cuda":
+        return None
+    free, _ = torch.cuda.mem_get_info(_lib.device())
+    held = model._ws.numel() if getattr(model, "_ws", None) is not None else 0
+    return int(0.9 * (free + held))
+
+
 @torch.no_grad()
 def enhance(model: DfNet, df_state: DF, audio: torch.Tensor, pad: bool = True, atten_lim_db: Optional[float] = None
             ) -> torch.Tensor:
@@ -131,11 +144,33 @@ def enhance(model: DfNet, df_state: DF, audio: torch.Tensor, pad: bool = True, a
         return y.to(src_dev)
     nbytes = C.c_int64()
     L = _lib.lib()
-    _lib.check(L.dfx_enhance_workspace_bytes(model.handle, df_state.handle, B, T, int(bool(pad)), C.byref(nbytes)))
-    ws = model.workspace(nbytes.value)
     lim_db = float(atten_lim_db) if atten_lim_db is not None else 0.0
-    _lib.check(L.dfx_enhance(model.handle, df_state.handle, _lib.ptr(x), B, T, int(bool(pad)), lim_db, _lib.ptr(y),
-                             _lib.ptr(ws), ws.numel(), _lib.stream()))
+
+    def ws_bytes(b: int) -> int:
+        _lib.check(L.dfx_enhance_workspace_bytes(model.handle, df_state.handle, b, T, int(bool(pad)), C.byref(nbytes)))
+        return int(nbytes.value)
+
+    # The engine's scratch is ~82 MB per 10 s clip: a batch whose workspace does not fit what the device has free is
+    # enhanced in sub-batches of whole clips, one after the other in the same workspace (clips are independent: same samples).
+    # DFX_WORKSPACE_CAP_GB bounds the workspace explicitly (tests; shared devices).
+    cap = _workspace_cap(model)
+    sub = B
+    if cap is not None and ws_bytes(B) > cap:
+        lo, hi = 1, B                      # largest sub-batch whose workspace fits (the requirement grows with the batch)
+        if ws_bytes(1) > cap:
+            raise MemoryError(f"enhance(): a single clip of {T} samples needs {ws_bytes(1)} bytes of workspace, {cap} available")
+        while lo < hi:
+            mid = (lo + hi + 1) // 2
+            if ws_bytes(mid) <= cap:
+                lo = mid
+            else:
+                hi = mid - 1
+        sub = lo if lo < 16 else lo - lo % 16   # whole groups of 16 clips (one GRU workgroup each) when there are that many
+    ws = model.workspace(ws_bytes(sub))
+    for b0 in range(0, B, sub):
+        n = min(sub, B - b0)
+        _lib.check(L.dfx_enhance(model.handle, df_state.handle, _lib.ptr(x[b0:b0 + n]), n, T, int(bool(pad)), lim_db, _lib.ptr(y[b0:b0 + n]),
+                                 _lib.ptr(ws), ws.numel(), _lib.stream()))
     if pinned:
         out = torch.empty(y.shape, dtype=y.dtype, pin_memory=True)
         out.copy_(y, non_blocking=True)

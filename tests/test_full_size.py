@@ -205,3 +205,21 @@ def test_full_size_order10_deep_filter(hip_backend):
     ysum = run(coefs + c2, True)[..., :nd, :]
     ysep = ya[..., :nd, :] + run(c2, True)[..., :nd, :]
     assert float((ysum - ysep).abs().max()) < 1e-4 * float(ysep.abs().max())
+
+
+def test_full_size_sub_batches_under_a_workspace_cap(hip_backend, monkeypatch):
+    """384 clips x 10 s with the workspace capped at 24 GB (a 256-clip batch needs ~21 GB): enhance() runs the batch as
+    256 + 128 clips in one workspace; every clip comes out as in a batch of its own size class (rows are independent)."""
+    from deepfilternet_amd.enhance import enhance
+
+    p, sd, model, df_state = _setup(hip_backend)
+    B, T = 384, 10 * SR
+    x = _audio(B, T, 9)
+    monkeypatch.setenv("DFX_WORKSPACE_CAP_GB", "24")
+    y = enhance(model, df_state, x)
+    model.check()
+    assert model._ws.numel() <= 24 * (1 << 30) and torch.isfinite(y).all()
+    monkeypatch.delenv("DFX_WORKSPACE_CAP_GB")
+    for rows in (slice(0, 16), slice(256, 272), slice(368, 384)):       # first sub-batch, the start and the end of the second
+        yr = enhance(model, df_state, x[rows])
+        assert torch.equal(y[rows], yr), rows
