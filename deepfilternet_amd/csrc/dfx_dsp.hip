@@ -305,7 +305,7 @@ static size_t dsp_smem_bytes(const dfx_state *st) {
 }
 // analysis: the 480-point plan transforms in place — one buffer per frame (dfx_plan_is_480, dfx_k_analysis)
 static bool ana_in_place(const dfx_state *st) {
-    const char *e = getenv("DFX_FFT_IN_PLACE");   // read per launch (one STFT launch per call): =0 two buffers per frame, =1 the ISTFT in place too
+    const char *e = getenv("DFX_FFT_IN_PLACE");   // read per launch (one STFT launch per call): =0 two buffers per frame, =2 only in the ISTFT
     const bool off = e && e[0] == '0';
     const DfxFftPlan &pl = st->plan;
     return !off && pl.M == 480 && pl.nstage == 5 && pl.radix[0] == 4 && pl.radix[1] == 4 && pl.radix[2] == 2 && pl.radix[3] == 3 && pl.radix[4] == 5;
@@ -422,11 +422,10 @@ int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int6
     A.chunks = (int)dfx_ceil_div(A.f_end - A.f_begin, A.outf);
     A.plan = st->plan;
     if (A.chunks <= 0) return DFX_OK;
-    // the synthesis kernel keeps two buffers per frame by default: in place it fits six waves per SIMD only with 14 spilled registers (its
-    // frame prefetch) and was measured no faster in the pipeline and slower / erratic alone (1.15 -> 1.2-1.8 ms); DFX_FFT_IN_PLACE=1 selects it
+    // in place like the analysis (one buffer per frame, six waves per SIMD; without the register prefetch of the next frame, which would spill
+    // there): 1.07-1.13 -> 0.93-1.03 ms alone; DFX_FFT_IN_PLACE=2 keeps two buffers here, =0 in both kernels
     const char *ipe = getenv("DFX_FFT_IN_PLACE");
-    const bool syn_on = ipe && ipe[0] == '1';
-    const bool ip = ana_in_place(st) && syn_on;
+    const bool ip = ana_in_place(st) && !(ipe && ipe[0] == '2');
     const size_t smem = ip ? ana_smem_bytes(st) : dsp_smem_bytes(st);
     int64_t nblk = B * A.chunks;
     // persistent workgroups (the twiddle / window tables are staged once per workgroup): a few per CU, grid-stride over the work items

@@ -569,7 +569,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_synthesis(D
     have_pre = false;
     {   // request this team's frame of the next work item: its HBM latency hides behind the transform and the overlap-add below
         const int64_t nitem = item + gridDim.x;
-        if (single && nitem < A.B * A.chunks) {
+        if (!IP && single && nitem < A.B * A.chunks) {   // (in place: six waves per SIMD cover the latency; the 16 prefetch registers would spill)
             const int64_t nb = nitem / A.chunks;
             const int64_t nt = A.f_begin + (nitem - nb * A.chunks) * A.outf - (A.R - 1) + team;
             if (nt >= 0 && nt < A.Tf) {
