@@ -356,6 +356,13 @@ struct dfx_model {
     bool phase_late = true;             // DFX_PHASE_LATE=0: the GRU phase is enqueued right behind the front (no staged enqueue)
     bool seq_xcd = false, seq_merge = false;   // DFX_SEQ_XCD=1 / DFX_SEQ_MERGE=1 (measured: no gain)
     int proj_rt = 0;                    // DFX_PROJ_RT=1|2|3: one form of the projection kernel for every launch size
+    // DFX_FRONT_GRAIN=k[,kp]: k (kp) times as many, shorter workgroups for df_conv0->1 (df_convp).  df_convp owns whole SIMDs (one wave of
+    // 512 registers each) and is needed last (by df_out, deep in the GRU phase): as a persistent grid of long workgroups it held every SIMD
+    // for 4.7 ms while the kernels on the front's critical path (ERB encoder convs -> embedding GEMMs) waited for slots (erb_conv2: 1.8 ms
+    // instead of 0.3).  In 16 x shorter workgroups (40-frame segments, 10 % warm-up overhead) its slots come free every ~35 us and the
+    // dispatcher lets the other queues in: the front ends 1.1 ms earlier, df_convp finishes under the first 2 ms of the GRU phase;
+    // 17.7 -> 17.15 ms per step (8 ... 32: the same; df_conv0->1's own grain: no effect).
+    int front_grain = 1, front_grain_p = 16;
     mutable unsigned int seq_xcd_base = 0;  // per-XCD arrival counters of the persistent launches (10 workgroups per XCD and launch)
     mutable unsigned int seq_started = 0;  // workgroups of all persistent GRU launches so far (the front waits until they are resident)
     unsigned int *d_err = nullptr;      // device words: [0] a bounded spin of the two-CU GRU kernel timed out, [1] fp16-split range, [2] flag wait timed out
@@ -798,6 +805,12 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         m->seq_xcd = sx && sx[0] == '1';
         m->seq_merge = sm && atoi(sm) != 0;
         m->proj_rt = prt ? atoi(prt) : 0;
+        const char *fg = getenv("DFX_FRONT_GRAIN");
+        if (fg) {
+            m->front_grain = atoi(fg) > 1 ? atoi(fg) : 1;
+            m->front_grain_p = m->front_grain;
+            if (strchr(fg, ',')) m->front_grain_p = atoi(strchr(fg, ',') + 1) > 1 ? atoi(strchr(fg, ',') + 1) : 1;
+        }
         {
             const char *tq = getenv("DFX_SEQ_TRACE");
             if (tq && tq[0] == '1') (void)hipMalloc(reinterpret_cast<void **>(&m->d_trace), (size_t)DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX * DFX_GS_MAX_CHUNKS * 3 * 8);
@@ -1123,7 +1136,7 @@ static int launch_convp_h3(const dfx_model *m, const float *feat_spec, float *ou
         A.unscale = m->cp_unscale;
         A.err = m->d_err;
         A.nfb = (Fd + 15) / 16;
-        const int64_t want = (int64_t)dfx_env_num_cus() * 4 * 4;  // two resident waves per SIMD, two rounds
+        const int64_t want = (int64_t)dfx_env_num_cus() * 4 * 4 * m->front_grain_p;  // two resident waves per SIMD, two rounds
         int64_t nseg = dfx_ceil_div(want, B * A.nfb);
         const int64_t Tn = t_end - t_begin;  // frames produced
         const int64_t max_seg = dfx_ceil_div(Tn, (int64_t)8 * KT);
@@ -1133,7 +1146,7 @@ static int launch_convp_h3(const dfx_model *m, const float *feat_spec, float *ou
         A.tseg = (int)tseg;
         A.nseg = (int)dfx_ceil_div(Tn, tseg);
         const int64_t nruns = B * A.nfb * A.nseg;
-        const int grid = nn_grid(dfx_ceil_div(nruns, 4), 2);
+        const int grid = nn_grid(dfx_ceil_div(nruns, 4), 2 * m->front_grain_p);
         DfxKScope ks(DFX_K_DF_CONVP, s);
         dfx_launch((dfx_k_df_convp_h3<C, KT>), dim3(grid), dim3(256), 0, s, A);
         DFX_LAUNCH_CHECK();
@@ -1168,7 +1181,7 @@ static int launch_conv01_h3(const dfx_model *m, const PwW &w, const float *feat_
         A.unscale0 = m->c0_unscale;
         A.unscale = m->dfc1_unscale;
         A.err = m->d_err;
-        const int grid = nn_grid(dfx_ceil_div(B * (t_end - t_begin) * Fout, 64), 3);
+        const int grid = nn_grid(dfx_ceil_div(B * (t_end - t_begin) * Fout, 64), 3 * m->front_grain);
         DfxKScope ks(DFX_K_PWCONV, s);
         dfx_launch(dfx_k_df_conv01_h3<C>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
         DFX_LAUNCH_CHECK();
