@@ -363,6 +363,7 @@ struct dfx_model {
     // dispatcher lets the other queues in: the front ends 1.1 ms earlier, df_convp finishes under the first 2 ms of the GRU phase;
     // 17.7 -> 17.15 ms per step (8 ... 32: the same; df_conv0->1's own grain: no effect).
     int front_grain = 1, front_grain_p = 16;
+    bool split_emb = false;             // DFX_SPLIT_EMB=1: df_fc_emb on the DF branch's stream behind df_conv1, linear_in reads cemb + e3 (measured: 17.55 vs 17.46 ms, no gain)
     mutable unsigned int seq_xcd_base = 0;  // per-XCD arrival counters of the persistent launches (10 workgroups per XCD and launch)
     mutable unsigned int seq_started = 0;  // workgroups of all persistent GRU launches so far (the front waits until they are resident)
     unsigned int *d_err = nullptr;      // device words: [0] a bounded spin of the two-CU GRU kernel timed out, [1] fp16-split range, [2] flag wait timed out
@@ -806,6 +807,8 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         m->seq_merge = sm && atoi(sm) != 0;
         m->proj_rt = prt ? atoi(prt) : 0;
         const char *fg = getenv("DFX_FRONT_GRAIN");
+        const char *se = getenv("DFX_SPLIT_EMB");
+        m->split_emb = se && se[0] == '1';
         if (fg) {
             m->front_grain = atoi(fg) > 1 ? atoi(fg) : 1;
             m->front_grain_p = m->front_grain;
@@ -1310,11 +1313,12 @@ static int launch_conv01(const dfx_model *m, const PwW &w, const float *feat_spe
 
 static int launch_ggemm(const float *a, int lda, const float *w, int G, int Kg, int Ng, const float *bias, int act,
                         const float *res, float *out, int ldo, int64_t M, hipStream_t s, int perm_inner = 0, int perm_F = 0,
-                        int64_t perm_T = 1, DfxRowMap rm = DfxRowMap{0, 0, 0}) {
+                        int64_t perm_T = 1, DfxRowMap rm = DfxRowMap{0, 0, 0}, const float *a2 = nullptr) {
     if (M <= 0) return DFX_OK;
     if (Kg % 4 || Ng % 4 || lda % 4) DFX_FAIL(DFX_ERR_UNSUPPORTED, "grouped GEMM needs K, N, lda multiples of 4 (got %d, %d, %d)", Kg, Ng, lda);
     DfxGgArgs A;
     A.a = a;
+    A.a2 = a2;
     A.w = w;
     A.bias = bias;
     A.res = res;
@@ -1408,8 +1412,8 @@ static int launch_proj_h3(const dfx_model *m, const GruW &g, const float *a, flo
 }
 
 static int launch_glin(const dfx_model *m, const GlinW &g, const float *a, int act, const float *res, float *out, int64_t M,
-                       hipStream_t s, DfxRowMap rm = DfxRowMap{0, 0, 0}) {
-    return launch_ggemm(a, g.G * g.Kg, m->p(g.w), g.G, g.Kg, g.Ng, nullptr, act, res, out, g.G * g.Ng, M, s, 0, 0, 1, rm);
+                       hipStream_t s, DfxRowMap rm = DfxRowMap{0, 0, 0}, const float *a2 = nullptr) {
+    return launch_ggemm(a, g.G * g.Kg, m->p(g.w), g.G, g.Kg, g.Ng, nullptr, act, res, out, g.G * g.Ng, M, s, 0, 0, 1, rm, a2);
 }
 
 #ifndef DFX_HIPEMU
@@ -1728,9 +1732,17 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         if ((r = launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb2, e1, nullptr, e2, Rk, E / 2, E / 4, 2, st, rm))) return r;
         return launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb3, e2, nullptr, e3, Rk, E / 4, E / 4, 1, st, rm);
     };
-    // cemb = relu(df_fc_emb(c1.flatten)); emb_in = e3.flatten + cemb (:179-182), then enc.emb_gru's linear_in (SqueezedGRU_S :149-158)
+    // cemb = relu(df_fc_emb(c1.flatten)); emb_in = e3.flatten + cemb (:179-182), then enc.emb_gru's linear_in (SqueezedGRU_S :149-158).
+    // split_emb (DFX_SPLIT_EMB=1, measured: no gain): nothing but linear_in reads emb_in (no encoder skip connection, no concat) — df_fc_emb
+    // then runs on the DF branch's stream right behind df_conv1, without waiting for the ERB convolutions, and writes cemb; linear_in
+    // takes cemb + e3 as its operand (DfxGgArgs::a2: the same two addends, the same sum).
+    const bool split_emb = m->split_emb && !c.enc_concat && c.emb_gru_skip_enc == DFX_SKIP_NONE && par && !sc;
+    auto cemb_range = [&](int64_t Rk, DfxRowMap rm, hipStream_t st) -> int {
+        return launch_glin(m, m->fc_emb, c1, DFX_ACT_RELU, nullptr, emb_in, Rk, st, rm);
+    };
     auto emb_range = [&](int64_t Rk, DfxRowMap rm, hipStream_t st) -> int {
         int r;
+        if (split_emb) return launch_glin(m, m->enc_in, emb_in, DFX_ACT_RELU, nullptr, xa, Rk, st, rm, e3);
         if (c.enc_concat) {  // emb = cat(e3.flatten, cemb) (deepfilternet3.py:132-134,181): e3 rows into the left half, cemb written into the right half
             if ((r = stream_copy_rows(e3, emb, emb, 0, emb_in, 2 * emb, emb, R, st))) return r;   // (all rows: enc_concat excludes the ranged front)
             if ((r = launch_ggemm(c1, m->fc_emb.G * m->fc_emb.Kg, m->p(m->fc_emb.w), m->fc_emb.G, m->fc_emb.Kg, m->fc_emb.Ng, nullptr, DFX_ACT_RELU,
@@ -1747,8 +1759,10 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         auto fR = [&](int i) { return nfr > 1 ? B * (fb(i + 1) - fb(i)) : Rn; };
         if (fuse_c0) {
             if ((rc = signal(EV_C0, x1)) || (rc = wait(EV_C0, x2))) return rc;  // df_convp only needs feat_spec
-            for (int i = 0; i < nfr; ++i)
+            for (int i = 0; i < nfr; ++i) {
                 if ((rc = df1_range(fb(i), fb(i + 1), x1))) return rc;
+                if (split_emb && (rc = cemb_range(fR(i), frm(i), x1))) return rc;
+            }
         } else {
             DfxCinArgs A;
             A.feat = feat_spec;
@@ -1767,6 +1781,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             DFX_LAUNCH_CHECK();
             if ((rc = signal(EV_C0, x1)) || (rc = wait(EV_C0, x2))) return rc;
             if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->dfc1, c0, nullptr, c1, R, Fd, Fd / 2, 2, x1))) return rc;
+            if (split_emb && (rc = cemb_range(Rn, rmw, x1))) return rc;
         }
         if ((rc = signal(EV_C1, x1))) return rc;
         auto run_convp = [&]() -> int {
@@ -1948,6 +1963,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 if ((rc = launch_wait_ge(m, started, 1, m->seq_started, Pq)) || (rc = launch_wait_ge(m, started, 1, m->seq_started, x1))) return rc;
                 for (int k = 0; k < K; ++k) {
                     if ((rc = df1_range(tb(k), tb(k + 1), x1))) return rc;
+                    if (split_emb && (rc = cemb_range(Mk(k), rmk(k), x1))) return rc;
                     DFX_HIP(hipEventRecord(ln->eev[k], x1));
                 }
                 if (run_df) {

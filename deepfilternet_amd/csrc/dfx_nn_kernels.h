@@ -1674,6 +1674,7 @@ __global__ void __launch_bounds__(256) dfx_k_df_convp2(DfxCp2Args A) {
 #define DFX_GG_THREADS 256
 struct DfxGgArgs {
     const float *a;     // [M, lda]
+    const float *a2;    // [M, lda] or null: the operand is a + a2 (an operand that is the sum of two activations, without materialising it)
     const float *w;     // [G][Kg][Ng]
     const float *bias;  // [G*Ng] or null
     const float *res;   // [M, ldo] or null (added after the activation)
@@ -1720,7 +1721,14 @@ __global__ void __launch_bounds__(DFX_GG_THREADS) dfx_k_ggemm(DfxGgArgs A) {
             const int64_t m = m0 + row;
             const int k = k0 + 4 * kq;
             ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < A.M && k < A.Kg) ra[u] = *reinterpret_cast<const float4 *>(A.a + dfx_row(A.rm, m) * A.lda + g * A.Kg + k);
+            if (m < A.M && k < A.Kg) {
+                const int64_t off = dfx_row(A.rm, m) * A.lda + g * A.Kg + k;
+                ra[u] = *reinterpret_cast<const float4 *>(A.a + off);
+                if (A.a2) {
+                    const float4 r2 = *reinterpret_cast<const float4 *>(A.a2 + off);
+                    ra[u] = make_float4(ra[u].x + r2.x, ra[u].y + r2.y, ra[u].z + r2.z, ra[u].w + r2.w);
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < BI; ++u) {
