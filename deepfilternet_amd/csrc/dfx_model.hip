@@ -1184,7 +1184,8 @@ static int launch_conv01_h3(const dfx_model *m, const PwW &w, const float *feat_
         A.unscale0 = m->c0_unscale;
         A.unscale = m->dfc1_unscale;
         A.err = m->d_err;
-        const int grid = nn_grid(dfx_ceil_div(B * (t_end - t_begin) * Fout, 64), 3 * m->front_grain);
+        static const int c01_wgs = [] { const char *e = getenv("DFX_C01_WGS"); return e && atoi(e) > 0 ? atoi(e) : 3; }();   // dev: resident workgroups per CU
+        const int grid = nn_grid(dfx_ceil_div(B * (t_end - t_begin) * Fout, 64), c01_wgs * m->front_grain);
         DfxKScope ks(DFX_K_PWCONV, s);
         dfx_launch(dfx_k_df_conv01_h3<C>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
         DFX_LAUNCH_CHECK();
