@@ -372,9 +372,18 @@ int dfx_launch_norm_scan(const float *erb_in, float *erb_out, int E, const float
     const int64_t n = C * nch;
     if (n <= 0) return DFX_OK;
     DfxKScope ks(DFX_K_NORM_SCAN, s);
-    dfx_launch(dfx_k_norm_scan, dim3((unsigned)dfx_ceil_div(n, 64)), dim3(64), 0, s, erb_in, erb_out, E,
-               reinterpret_cast<const float2 *>(spec_in), spec_frame_stride, reinterpret_cast<float2 *>(spec_out), Fn, C,
-               T, alpha, erb_state, unit_state);
+    // four lanes per (row, channel) when there are frames to share (the frame-by-frame streaming runtime keeps one lane per channel);
+    // DFX_NORM_SCAN4=0: always one lane
+    const char *q4 = getenv("DFX_NORM_SCAN4");
+    if (T >= 16 && !(q4 && q4[0] == '0')) {
+        dfx_launch(dfx_k_norm_scan4, dim3((unsigned)dfx_ceil_div(4 * n, 256)), dim3(256), 0, s, erb_in, erb_out, E,
+                   reinterpret_cast<const float2 *>(spec_in), spec_frame_stride, reinterpret_cast<float2 *>(spec_out), Fn, C,
+                   T, alpha, erb_state, unit_state);
+    } else {
+        dfx_launch(dfx_k_norm_scan, dim3((unsigned)dfx_ceil_div(n, 64)), dim3(64), 0, s, erb_in, erb_out, E,
+                   reinterpret_cast<const float2 *>(spec_in), spec_frame_stride, reinterpret_cast<float2 *>(spec_out), Fn, C,
+                   T, alpha, erb_state, unit_state);
+    }
     DFX_LAUNCH_CHECK();
     return DFX_OK;
 }
