@@ -45,6 +45,8 @@ struct dfx_bands {
     int *d_start = nullptr;               // [nb+1] first bin of each band
     float *d_invw = nullptr;              // [nb]   1/width (f32 division, lib.rs:287)
     unsigned char *d_bin2band = nullptr;  // [F]
+    int *d_segtab = nullptr;              // [3*64 + nb + 1] the bands cut into <= 64 near-equal segments (dfx_k_analysis), nseg > 0
+    int nseg = 0;
 };
 
 struct dfx_state {

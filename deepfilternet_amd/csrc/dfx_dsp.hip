@@ -153,8 +153,34 @@ extern "C" int dfx_bands_create(const uint64_t *widths, int nb, dfx_bands **out)
     std::vector<unsigned char> b2b(b->F);
     for (int i = 0; i < nb; ++i)
         for (int f = start[i]; f < start[i + 1]; ++f) b2b[f] = (unsigned char)i;
+    // the bands cut into at most 64 segments of at most `cap` bins (smallest cap that fits): one lane of the analysis kernel per segment
+    std::vector<int> segtab(3 * 64 + nb + 1, 0);
+    if (nb <= 64) {
+        uint64_t cap = 1;
+        for (;; ++cap) {
+            uint64_t cnt = 0;
+            for (int i = 0; i < nb; ++i) cnt += (widths[i] + cap - 1) / cap;
+            if (cnt <= 64) break;
+        }
+        int ns = 0;
+        for (int i = 0; i < nb; ++i) {
+            segtab[3 * 64 + i] = ns;
+            const int w = (int)widths[i], parts = (int)((widths[i] + cap - 1) / cap);
+            for (int k = 0, at = 0; k < parts; ++k) {      // near-equal parts, the longer ones first
+                const int len = w / parts + (k < w % parts ? 1 : 0);
+                segtab[ns] = start[i] + at;
+                segtab[64 + ns] = len;
+                memcpy(&segtab[128 + ns], &invw[i], 4);
+                at += len;
+                ++ns;
+            }
+        }
+        segtab[3 * 64 + nb] = ns;
+        b->nseg = ns;
+    }
     int rc = upload(&b->d_start, start.data(), start.size());
     if (!rc) rc = upload(&b->d_invw, invw.data(), invw.size());
+    if (!rc) rc = upload(&b->d_segtab, segtab.data(), segtab.size());
     if (!rc) rc = upload(&b->d_bin2band, b2b.data(), b2b.size());
     if (rc) {
         dfx_bands_free(b);
@@ -168,6 +194,7 @@ extern "C" void dfx_bands_free(dfx_bands *b) {
     if (b->d_start) (void)hipFree(b->d_start);
     if (b->d_invw) (void)hipFree(b->d_invw);
     if (b->d_bin2band) (void)hipFree(b->d_bin2band);
+    if (b->d_segtab) (void)hipFree(b->d_segtab);
     delete b;
 }
 extern "C" int dfx_bands_nb(const dfx_bands *b) { return b ? b->nb : 0; }
@@ -311,7 +338,8 @@ static bool ana_in_place(const dfx_state *st) {
     return !off && pl.M == 480 && pl.nstage == 5 && pl.radix[0] == 4 && pl.radix[1] == 4 && pl.radix[2] == 2 && pl.radix[3] == 3 && pl.radix[4] == 5;
 }
 static size_t ana_smem_bytes(const dfx_state *st) {
-    return (size_t)st->N * 12 + (size_t)DFX_DSP_TEAMS * (ana_in_place(st) ? 1 : 2) * (size_t)(st->plan.M + 2) * 8;
+    return (size_t)st->N * 12 + (size_t)DFX_DSP_TEAMS * (ana_in_place(st) ? 1 : 2) * (size_t)(st->plan.M + 2) * 8 +
+           (((size_t)(2 * st->nb + 1 + 3 * 64 + st->nb + 1 + DFX_DSP_TEAMS * 64) * 4 + 15) & ~(size_t)15);   // + the ERB band tables and segment sums (analysis)
 }
 static int grid_for(int64_t work_groups, int per_cu = 8) {
     const int64_t cap = (int64_t)dfx_env_num_cus() * per_cu;  // memory-bound: ~8 workgroups per CU, grid-stride the rest
@@ -333,6 +361,8 @@ int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t 
         A.tw = st->d_tw;
         A.band_start = st->bands->d_start;
         A.band_invw = st->bands->d_invw;
+        A.seg_tab = st->bands->d_segtab;
+        A.nseg = getenv("DFX_ERB_SEGMENTS") && getenv("DFX_ERB_SEGMENTS")[0] == '0' ? 0 : st->bands->nseg;   // (=0: one lane per band)
         A.B = B;
         A.Tf = Tf;
         A.x_stride = x_stride;

@@ -149,13 +149,22 @@ template <int R, int SG, int M, int NCUR, int S>
 static __device__ __forceinline__ void dfx_fft_pass_ip(float2 *x, const float2 *tw, int lane, bool active) {
     constexpr int m = NCUR / R, nbf = M / R, tws = (2 * M) / NCUR, NR = (nbf + DFX_DSP_TEAM - 1) / DFX_DSP_TEAM;
     float2 a[NR][R];
+    // the twiddles are read here too, with the data: the table lives in the same LDS allocation as the frames, so a read of it placed
+    // between the stores of the second half cannot be moved across them by the compiler and every one of them became a separate LDS
+    // round trip (load, wait, multiply, store: 6-8 dependent latencies per pass instead of one)
+    float2 w[NR][R - 1];
     if (active) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const int b = lane + r * DFX_DSP_TEAM;
+            // (lanes beyond the last butterfly of a partial round read butterfly 0 and drop it: a predicated LDS read costs five
+            // instructions — zero the destination, save / narrow / restore exec — where the plain one costs one)
+            const bool full = (r + 1) * DFX_DSP_TEAM <= nbf;
+            const int b0 = lane + r * DFX_DSP_TEAM, b = full || b0 < nbf ? b0 : 0;
             const int p = b / S, q = b - p * S;
 #pragma unroll
-            for (int j = 0; j < R; ++j) a[r][j] = b < nbf ? x[q + S * (p + m * j)] : make_float2(0.f, 0.f);
+            for (int j = 0; j < R; ++j) a[r][j] = x[q + S * (p + m * j)];
+#pragma unroll
+            for (int j = 1; j < R; ++j) w[r][j - 1] = tw[j * p * tws];
         }
     }
     DFX_WAVE_SYNC();
@@ -163,7 +172,7 @@ static __device__ __forceinline__ void dfx_fft_pass_ip(float2 *x, const float2 *
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int b = lane + r * DFX_DSP_TEAM;
-            if (b >= nbf) continue;
+            if ((r + 1) * DFX_DSP_TEAM > nbf && b >= nbf) continue;
             const int p = b / S, q = b - p * S;
             float2 o[R];
             if constexpr (R == 2) {
@@ -203,9 +212,9 @@ static __device__ __forceinline__ void dfx_fft_pass_ip(float2 *x, const float2 *
             x[q + S * (R * p)] = o[0];
 #pragma unroll
             for (int j = 1; j < R; ++j) {
-                float2 w = tw[j * p * tws];
-                if (SG > 0) w.y = -w.y;
-                x[q + S * (R * p + j)] = dfx_cmul(o[j], w);
+                float2 wj = w[r][j - 1];
+                if (SG > 0) wj.y = -wj.y;
+                x[q + S * (R * p + j)] = dfx_cmul(o[j], wj);
             }
         }
     }
@@ -281,6 +290,9 @@ struct DfxAnaArgs {
     const float2 *tw;     // [N]
     const int *band_start;  // [nb+1]
     const float *band_invw; // [nb]
+    const int *seg_tab;     // [3*64 + nb + 1] band sums on all 64 lanes (dfx_bands_create): start bin, bins, 1/width (float bits) of each
+                            // segment, then the first segment of every band; used when nseg > 0
+    int nseg;
     int64_t B, Tf, x_stride;
     int64_t x_len;        // samples that exist per row; positions >= x_len read as 0 (enhance()'s F.pad(audio, (0, n_fft)) without a copy)
     int64_t spec_stride;  // row stride of spec in complex elements (>= F; the engine pads odd F to even so rows are 16-byte aligned)
@@ -307,6 +319,19 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_analysis(Df
     constexpr bool ip = IP;
     float2 *bufA = reinterpret_cast<float2 *>(smem + team_off) + (size_t)team * (ip ? 1 : 2) * buf_elems;
     float2 *bufB = bufA + buf_elems;   // (not ip only)
+    // band edges and 1/width of the ERB feature, behind the frames
+    int *bstart = reinterpret_cast<int *>(smem + team_off + (size_t)DFX_DSP_TEAMS * (ip ? 1 : 2) * buf_elems * 8);   // [nb + 1]
+    float *binvw = reinterpret_cast<float *>(bstart + A.nb + 1);                                                       // [nb]
+    int *segs = reinterpret_cast<int *>(binvw + A.nb);                              // [3*64 + nb + 1]  (A.nseg > 0)
+    float *part = reinterpret_cast<float *>(segs + 3 * DFX_DSP_TEAM + A.nb + 1) + team * DFX_DSP_TEAM;   // [64] per frame
+    if (A.erb_db) {
+        for (int i = threadIdx.x; i <= A.nb; i += DFX_DSP_THREADS) {
+            bstart[i] = A.band_start[i];
+            if (i < A.nb) binvw[i] = A.band_invw[i];
+        }
+        if (A.nseg > 0)
+            for (int i = threadIdx.x; i < 3 * DFX_DSP_TEAM + A.nb + 1; i += DFX_DSP_THREADS) segs[i] = A.seg_tab[i];
+    }
     // twiddles + window: every load of a pass is issued before the first LDS store (a load -> store loop waits out one memory
     // latency per iteration; the compiler does not batch across a runtime trip count)
     for (int i0 = threadIdx.x; i0 < N; i0 += 4 * DFX_DSP_THREADS) {
@@ -338,27 +363,30 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_analysis(Df
             const float *xb = A.x + b * A.x_stride;
             const int64_t pos0 = t * A.hop - ML;
             const float *xf = xb + pos0;
+            int ll = lane;
+            DFX_OPAQUE(ll);   // (addresses recomputed per frame instead of living in registers across the loop: see dfx_fft480_ip)
             if (pos0 >= 0 && pos0 + N <= A.x_len && (reinterpret_cast<uintptr_t>(xf) & 7) == 0) {
                 // interior frame (wave-uniform test; all but the first of a clip and the ones reaching into the implicit zero padding):
                 // 8-byte loads, 8 per lane in flight before the first LDS store (M = 480: one pass) — a load -> store loop would
                 // wait out one memory latency per iteration.  (Requesting the NEXT frame before this one's FFT, as the synthesis
                 // kernel does, was measured slower here: 16 more live registers cost the second resident workgroup: 0.76 -> 1.14 ms.)
                 const float2 *xf2 = reinterpret_cast<const float2 *>(xf);
-                for (int k0 = lane; k0 < M; k0 += 8 * DFX_DSP_TEAM) {
-                    float2 v[8];
+                for (int k0 = ll; k0 < M; k0 += 8 * DFX_DSP_TEAM) {
+                    float2 v[8], wv[8];   // (the window too: an LDS read between LDS stores is a round trip of its own, see dfx_fft_pass_ip)
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int k = k0 + u * DFX_DSP_TEAM;
                         v[u] = xf2[k < M ? k : k0];
+                        wv[u] = reinterpret_cast<const float2 *>(win)[k < M ? k : k0];
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int k = k0 + u * DFX_DSP_TEAM;
-                        if (k < M) bufA[k] = make_float2(v[u].x * win[2 * k], v[u].y * win[2 * k + 1]);
+                        if (k < M) bufA[k] = make_float2(v[u].x * wv[u].x, v[u].y * wv[u].y);
                     }
                 }
             } else {
-                for (int k = lane; k < M; k += DFX_DSP_TEAM) {
+                for (int k = ll; k < M; k += DFX_DSP_TEAM) {
                     float v[2];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
@@ -387,21 +415,33 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_analysis(Df
             if (active) {
                 float2 *out = A.spec + (b * A.Tf + t) * A.spec_stride;
                 if (lane == 0 && A.spec_stride > F) out[F] = make_float2(0.f, 0.f);  // the pad bin of an aligned row
-                auto bin = [&](int k, float2 zk, float2 zc) -> float2 {
+                auto bin = [&](float2 zk, float2 zc, float2 twk) -> float2 {
                     // E = (Z[k] + conj(Z[M-k]))/2 ; O = (Z[k] - conj(Z[M-k]))/(2i) ; X[k] = E + exp(-2*pi*i*k/N) * O
                     const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);
                     const float dr = 0.5f * (zk.x - zc.x), di = 0.5f * (zk.y + zc.y);
-                    const float2 tt = dfx_cmul(make_float2(di, -dr), tw[k]);
+                    const float2 tt = dfx_cmul(make_float2(di, -dr), twk);
                     return make_float2((er + tt.x) * A.wnorm, (ei + tt.y) * A.wnorm);
                 };
-                for (int k = lane; k <= M / 2; k += DFX_DSP_TEAM) {
-                    const int kc = M - k;                     // partner bin (k = 0: the Nyquist bin M, both from Z[0])
-                    const float2 za = Z[k], zb = Z[k == 0 ? 0 : kc];
-                    const float2 Xa = bin(k, za, zb);
+                // (every LDS read of the pass before its first LDS store, as in the transform's passes)
+                constexpr int MI = 480, NPR = (MI / 2 + DFX_DSP_TEAM) / DFX_DSP_TEAM;
+                float2 za[NPR], zb[NPR], ta[NPR], tb[NPR];
+                int lp = lane;
+                DFX_OPAQUE(lp);
+#pragma unroll
+                for (int i = 0; i < NPR; ++i) {
+                    const int k = lp + i * DFX_DSP_TEAM, kk = k <= MI / 2 ? k : 0, kc = MI - kk;
+                    za[i] = Z[kk], zb[i] = Z[kk == 0 ? 0 : kc];   // partner bin (k = 0: the Nyquist bin M, both from Z[0])
+                    ta[i] = tw[kk], tb[i] = tw[kc];
+                }
+#pragma unroll
+                for (int i = 0; i < NPR; ++i) {
+                    const int k = lp + i * DFX_DSP_TEAM, kc = MI - k;
+                    if (k > MI / 2) continue;
+                    const float2 Xa = bin(za[i], zb[i], ta[i]);
                     out[k] = Xa;
                     float pa = __fadd_rn(__fmul_rn(Xa.x, Xa.x), __fmul_rn(Xa.y, Xa.y)), pb = 0.f;
                     if (kc != k) {
-                        const float2 Xb = bin(kc, zb, za);
+                        const float2 Xb = bin(zb[i], za[i], tb[i]);
                         out[kc] = Xb;
                         pb = __fadd_rn(__fmul_rn(Xb.x, Xb.x), __fmul_rn(Xb.y, Xb.y));
                     }
@@ -433,17 +473,63 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_analysis(Df
         }
         if (A.erb_db) {
             DFX_WAVE_SYNC();
-            if (active && lane < A.nb) {
-                // compute_band_corr (lib.rs:280-295): acc += |X|^2 * (1/width), bins in ascending order
-                const int s0 = A.band_start[lane], s1 = A.band_start[lane + 1];
-                const float kk = A.band_invw[lane];
+            if (A.nseg > 0) {
+                // compute_band_corr (lib.rs:280-295): acc += |X|^2 * (1/width) over the bins of a band.  The bands are cut into at most 64
+                // segments of near-equal length (11 bins at 48 kHz, where the widest band has 67): every lane sums one segment, bins in
+                // ascending order, then the lane of a band adds its segments in ascending order.  (One lane per band, as below, makes the
+                // widest band the length of the whole stage — a third of this kernel's instructions with half of the lanes idle.)
+                int le = lane;
+                DFX_OPAQUE(le);
+                const bool mine = active && le < A.nseg;
+                const int s0 = segs[mine ? le : 0], n = mine ? segs[DFX_DSP_TEAM + le] : 0;
+                const float kk = __int_as_float(segs[2 * DFX_DSP_TEAM + (mine ? le : 0)]);
                 float acc = 0.f;
-                for (int j = s0; j < s1; ++j) acc = __fadd_rn(acc, __fmul_rn(pw[pws * j], kk));
-                A.erb_db[(b * A.Tf + t) * A.nb + lane] = log10f(acc + 1e-10f) * 10.f;
+                for (int j0 = 0; j0 < n; j0 += 6) {
+                    float pv[6];
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) pv[u] = pw[pws * (s0 + (j0 + u < n ? j0 + u : 0))];
+#pragma unroll
+                    for (int u = 0; u < 6; ++u)
+                        if (j0 + u < n) acc = __fadd_rn(acc, __fmul_rn(pv[u], kk));
+                }
+                if (mine) part[le] = acc;
+                DFX_WAVE_SYNC();
+                if (active && le < A.nb) {
+                    const int *bseg = segs + 3 * DFX_DSP_TEAM;
+                    const int g0 = bseg[le], g1 = bseg[le + 1];
+                    float tot = 0.f;
+                    for (int g = g0; g < g1; g += 8) {
+                        float pv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) pv[u] = part[g + u < g1 ? g + u : g0];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (g + u < g1) tot = __fadd_rn(tot, pv[u]);
+                    }
+                    A.erb_db[(b * A.Tf + t) * A.nb + le] = log10f(tot + 1e-10f) * 10.f;
+                }
+            } else if (active && lane < A.nb) {
+                // compute_band_corr (lib.rs:280-295): acc += |X|^2 * (1/width), bins in ascending order.  Eight bins are read before they are
+                // added (same order, same sum): with one read per trip the widest band — 67 bins at 48 kHz — was 67 dependent LDS round
+                // trips, more than the five passes of the transform together
+                int le = lane;
+                DFX_OPAQUE(le);
+                const int s0 = bstart[le], s1 = bstart[le + 1];
+                const float kk = binvw[le];
+                float acc = 0.f;
+                for (int j0 = s0; j0 < s1; j0 += 8) {
+                    float pv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) pv[u] = pw[pws * (j0 + u < s1 ? j0 + u : s0)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (j0 + u < s1) acc = __fadd_rn(acc, __fmul_rn(pv[u], kk));
+                }
+                A.erb_db[(b * A.Tf + t) * A.nb + le] = log10f(acc + 1e-10f) * 10.f;
             }
-            for (int e = DFX_DSP_TEAM + lane; active && e < A.nb; e += DFX_DSP_TEAM) {  // nb > 64 (rare)
-                const int s0 = A.band_start[e], s1 = A.band_start[e + 1];
-                const float kk = A.band_invw[e];
+            for (int e = DFX_DSP_TEAM + lane; A.nseg <= 0 && active && e < A.nb; e += DFX_DSP_TEAM) {  // nb > 64 (rare)
+                const int s0 = bstart[e], s1 = bstart[e + 1];
+                const float kk = binvw[e];
                 float acc = 0.f;
                 for (int j = s0; j < s1; ++j) acc = __fadd_rn(acc, __fmul_rn(pw[pws * j], kk));
                 A.erb_db[(b * A.Tf + t) * A.nb + e] = log10f(acc + 1e-10f) * 10.f;
@@ -529,10 +615,12 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_synthesis(D
     float2 pre[8];
     bool have_pre = false;
     auto request = [&](const float2 *Y) {
+        int lr = lane;
+        DFX_OPAQUE(lr);   // (per-frame address / bounds arithmetic instead of registers held across the work-item loop: see dfx_fft480_ip)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int k = lane + u * DFX_DSP_TEAM;
-            pre[u] = Y[k <= M ? k : lane];
+            const int k = lr + u * DFX_DSP_TEAM;
+            pre[u] = Y[k <= M ? k : lr];
         }
     };
     for (int64_t item = blockIdx.x; item < A.B * A.chunks; item += gridDim.x) {
@@ -545,9 +633,11 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_synthesis(D
         const float2 *Y = A.spec + (b * A.Tf + t) * A.spec_stride;
         if (single) {  // F <= 512: the frame was requested while the previous work item was being transformed (or right now)
             if (!have_pre) request(Y);
+            int ls = lane;
+            DFX_OPAQUE(ls);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int k = lane + u * DFX_DSP_TEAM;
+                const int k = ls + u * DFX_DSP_TEAM;
                 if (k <= M) bufB[k] = pre[u];
             }
         } else {
@@ -580,27 +670,39 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_synthesis(D
     }
     DFX_WAVE_SYNC();
     // E' = X[k] + conj(X[M-k]) ; O' = conj(w^k) * (X[k] - conj(X[M-k])) ; Z[k] = E' + i*O'
-    auto zbin = [&](int k, float2 xk, float2 xm) -> float2 {
+    auto zbin_w = [&](int k, float2 xk, float2 xm, float2 w) -> float2 {
         if (k == 0) {  // C2R ignores imag(DC) and imag(Nyquist)
             xk.y = 0.f;
             xm.y = 0.f;
         }
         const float er = xk.x + xm.x, ei = xk.y - xm.y;
-        float2 w = tw[k];
         w.y = -w.y;
         const float2 o = dfx_cmul(make_float2(xk.x - xm.x, xk.y + xm.y), w);
         return make_float2(er - o.y, ei + o.x);
     };
+    auto zbin = [&](int k, float2 xk, float2 xm) -> float2 { return zbin_w(k, xk, xm, tw[k]); };
     float2 *Z = bufA;
     if constexpr (IP) {
         // in place on the pairs (k, M-k): Z[k] and Z[M-k] need X[k] and X[M-k] and nothing else (k = 0 pairs with the Nyquist bin M and
         // only produces Z[0]; k = M/2 is its own partner)
+        // (every LDS read of the pass before its first LDS store: see dfx_fft_pass_ip)
         if (active) {
-            for (int k = lane; k <= M / 2; k += DFX_DSP_TEAM) {
-                const int kc = M - k;
-                const float2 xa = bufA[k], xb = bufA[kc];
-                const float2 za = zbin(k, xa, xb);
-                if (k != 0 && kc != k) bufA[kc] = zbin(kc, xb, xa);
+            constexpr int MI = 480, NPR = (MI / 2 + DFX_DSP_TEAM) / DFX_DSP_TEAM;
+            float2 xa[NPR], xb[NPR], wa[NPR], wb[NPR];
+            int lp = lane;
+            DFX_OPAQUE(lp);
+#pragma unroll
+            for (int i = 0; i < NPR; ++i) {
+                const int k = lp + i * DFX_DSP_TEAM, kk = k <= MI / 2 ? k : 0, kc = MI - kk;
+                xa[i] = bufA[kk], xb[i] = bufA[kc];
+                wa[i] = tw[kk], wb[i] = tw[kc];
+            }
+#pragma unroll
+            for (int i = 0; i < NPR; ++i) {
+                const int k = lp + i * DFX_DSP_TEAM, kc = MI - k;
+                if (k > MI / 2) continue;
+                const float2 za = zbin_w(k, xa[i], xb[i], wa[i]);
+                if (k != 0 && kc != k) bufA[kc] = zbin_w(kc, xb[i], xa[i], wb[i]);
                 bufA[k] = za;
             }
         }
@@ -616,13 +718,89 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_synthesis(D
     {
         // apply_window_in_place (lib.rs:406): the interleaved (re, im) pairs of z ARE the time samples
         float *xt = reinterpret_cast<float *>(Z);
-        if (active)
+        if constexpr (IP) {
+            // four samples per access, all reads before the first store (a read-multiply-store loop is one LDS round trip per trip: 15)
+            constexpr int NQ = 960 / 4, NR4 = (NQ + DFX_DSP_TEAM - 1) / DFX_DSP_TEAM;
+            f32x4 *xq = reinterpret_cast<f32x4 *>(xt);
+            const f32x4 *wq = reinterpret_cast<const f32x4 *>(win);
+            f32x4 xv[NR4], wv[NR4];
+            int lw = lane;
+            DFX_OPAQUE(lw);
+            if (active) {
+#pragma unroll
+                for (int r = 0; r < NR4; ++r) {
+                    const int i = lw + r * DFX_DSP_TEAM, ii = i < NQ ? i : 0;
+                    xv[r] = xq[ii], wv[r] = wq[ii];
+                }
+#pragma unroll
+                for (int r = 0; r < NR4; ++r) {
+                    const int i = lw + r * DFX_DSP_TEAM;
+                    if (i < NQ) xq[i] = xv[r] * wv[r];
+                }
+            }
+        } else if (active)
             for (int i = lane; i < N; i += DFX_DSP_TEAM) xt[i] *= win[i];
     }
     __syncthreads();
     // overlap-add: output frame tf = t0 + j (j < outf), sample i < hop, gets real frames tf-R+1 .. tf
     const int total = A.outf * A.hop;
-    for (int idx = threadIdx.x; idx < total; idx += DFX_DSP_THREADS) {
+    const bool quads = (A.hop & 3) == 0 && (N & 3) == 0;   // four consecutive samples share every index and bound below
+    if (quads) {
+        // the same sums on four samples at a time: one set of index arithmetic, 16-byte LDS reads and (where the row position allows)
+        // 16-byte stores per four samples — the scalar form below spent more instructions on its indices than the transform on its data
+        const int hq = A.hop >> 2, totq = A.outf * hq;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        for (int q = threadIdx.x; q < totq; q += DFX_DSP_THREADS) {
+            const int j = q / hq, i = (q - j * hq) << 2;
+            const int64_t tf = t0 + j;
+            if (tf >= A.Tf + (A.mem_out ? A.R - 1 : 0) || tf >= A.f_end) break;
+            const int64_t s_glob = tf * A.hop + i;
+            f32x4 acc = zero4;
+            bool have = false;
+            if (A.mem_in && s_glob < ML) {
+                const float *mi = A.mem_in + b * ML + s_glob;
+                acc = f32x4{mi[0], mi[1], mi[2], mi[3]};
+                have = true;
+            }
+            for (int r = A.R - 1; r >= 1; --r) {  // older frames first
+                const int64_t tr = tf - r;
+                const int off = r * A.hop + i;
+                if (tr >= 0 && tr < A.Tf && off < N) {
+                    const int tm = (int)(tr - (t0 - (A.R - 1)));
+                    const float *fr = reinterpret_cast<const float *>(bufs + (size_t)tm * NBUF * buf_elems + (in_a ? 0 : buf_elems));
+                    const f32x4 fv = *reinterpret_cast<const f32x4 *>(fr + off);
+                    acc = have ? acc + fv : fv;
+                    have = true;
+                }
+            }
+            f32x4 cur = zero4;
+            if (tf < A.Tf) {
+                const int tm = (int)(tf - (t0 - (A.R - 1)));
+                const float *fr = reinterpret_cast<const float *>(bufs + (size_t)tm * NBUF * buf_elems + (in_a ? 0 : buf_elems));
+                cur = *reinterpret_cast<const f32x4 *>(fr + i);
+            }
+            const f32x4 v = have ? cur + acc : cur;
+            if (tf < A.Tf) {
+                const int64_t n = s_glob - A.out_skip;
+                float *o = A.out + b * A.out_stride + n;
+                if (n >= 0 && n + 3 < A.out_len && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+                    *reinterpret_cast<f32x4 *>(o) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e >= 0 && n + e < A.out_len) o[e] = v[e];
+                }
+            } else {
+                const int64_t mj = s_glob - A.Tf * A.hop;
+                if (mj < ML) {
+                    float *o = A.mem_out + b * ML + mj;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = v[e];
+                }
+            }
+        }
+    }
+    for (int idx = threadIdx.x; !quads && idx < total; idx += DFX_DSP_THREADS) {
         const int j = idx / A.hop, i = idx - j * A.hop;
         const int64_t tf = t0 + j;
         if (tf >= A.Tf + (A.mem_out ? A.R - 1 : 0) || tf >= A.f_end) break;

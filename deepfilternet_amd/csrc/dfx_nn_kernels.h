@@ -2148,7 +2148,19 @@ __global__ void dfx_k_lsnr(const float *emb, const float *w, float bias, float s
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (row >= R) return;  // whole waves exit together (blockDim is a multiple of 64)
     float acc = 0.f;
-    for (int i = lane; i < D; i += 64) acc += emb[row * D + i] * w[i];
+    const float *e = emb + row * D;
+    if ((D & 255) == 0 && ((reinterpret_cast<uintptr_t>(e) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {
+        // a row of 256 values is one 16-byte load per lane (four 4-byte loads per lane moved the 260 MB of emb at 1.5 TB/s)
+        for (int i = 4 * lane; i < D; i += 256) {
+            const float4 ev = *reinterpret_cast<const float4 *>(e + i), wv = *reinterpret_cast<const float4 *>(w + i);
+            acc += ev.x * wv.x;
+            acc += ev.y * wv.y;
+            acc += ev.z * wv.z;
+            acc += ev.w * wv.w;
+        }
+    } else {
+        for (int i = lane; i < D; i += 64) acc += e[i] * w[i];
+    }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
     if (lane == 0) out[row] = dfx_sigmoid(acc + bias) * scale + offset;
 }

@@ -526,6 +526,11 @@ static inline float dfx_fast_rcp(float x) { return 1.0f / x; }
 static inline float __fadd_rn(float a, float b) { return a + b; }  // the emulator is built with -ffp-contract=off
 static inline float __fmul_rn(float a, float b) { return a * b; }
 static inline float __fdiv_rn(float a, float b) { return a / b; }
+static inline float __int_as_float(int v) {
+    float f;
+    std::memcpy(&f, &v, 4);
+    return f;
+}
 // wave-uniform values: identity on the interpreter (callers only pass values that are uniform across the wave by construction)
 static inline int dfx_wave_uniform(int v) { return v; }
 // agent-scope atomics / fences / sleep of the flag-synchronised kernels (dfx_k_gru_seq, dfx_k_wait_ge): plain accesses here — the
