@@ -1007,6 +1007,10 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 2) dfx_k_pwconv_f(DfxPwArgs A)
     };
     int64_t item = (int64_t)blockIdx.x * 4 + wave;
     if (item < nitems) issue(item);
+    // the pathway's scale / shift of this lane's channel quad: (lane + 64 i) % C4 does not depend on i (C4 divides 64), and read from LDS
+    // between the strip stores below each pair was a round trip of its own (an LDS read cannot be moved across an LDS store)
+    static_assert(64 % C4 == 0, "channel quad of a lane must not depend on the load index");
+    const float4 ska = sks[lane % C4], skb = sks[C4 + lane % C4];
     for (; item < nitems; item += (int64_t)gridDim.x * 4) {
 #pragma unroll
         for (int i = 0; i < NVI; ++i) {
@@ -1015,7 +1019,7 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 2) dfx_k_pwconv_f(DfxPwArgs A)
                 const int row = idx / C4, c4 = idx - row * C4;
                 float4 v = xr[i];
                 if (SKIP) {
-                    const float4 sv = sr[i], a = sks[c4], bb = sks[C4 + c4];
+                    const float4 sv = sr[i], a = ska, bb = skb;
                     v.x += fmaxf(a.x * sv.x + bb.x, 0.f);
                     v.y += fmaxf(a.y * sv.y + bb.y, 0.f);
                     v.z += fmaxf(a.z * sv.z + bb.z, 0.f);
@@ -1396,15 +1400,21 @@ __global__ void __launch_bounds__(256, 2) dfx_k_erb_dec10_f(DfxDec10fArgs AA) {
     };
     int64_t rl = (int64_t)blockIdx.x * 4 + wave;
     if (rl < A.R) issue(rl);
+    static_assert(64 % C4 == 0, "channel quad of a lane must not depend on the load index");
     for (; rl < A.R; rl += (int64_t)gridDim.x * 4) {
         const int64_t r = dfx_row(A.rm, rl);
+        // scale / shift of the two pathways for this lane's channel quad: read once per frame, before the first strip store (see
+        // dfx_k_pwconv_f; held across the frame loop they would not fit the 256 registers of two waves per SIMD)
+        int lq = lane % C4;
+        DFX_OPAQUE(lq);
+        const float4 sk1a = sks[lq], sk1b = sks[C4 + lq], sk0a = sks[2 * C4 + lq], sk0b = sks[3 * C4 + lq];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = lane + 64 * i;
             if (idx < n1) {
                 const int row = idx / C4, c4 = idx - row * C4;
                 float4 v = xr[i];
-                const float4 sv = s1r[i], a = sks[c4], bb = sks[C4 + c4];
+                const float4 sv = s1r[i], a = sk1a, bb = sk1b;
                 v.x += fmaxf(a.x * sv.x + bb.x, 0.f);
                 v.y += fmaxf(a.y * sv.y + bb.y, 0.f);
                 v.z += fmaxf(a.z * sv.z + bb.z, 0.f);
@@ -1417,7 +1427,7 @@ __global__ void __launch_bounds__(256, 2) dfx_k_erb_dec10_f(DfxDec10fArgs AA) {
             const int idx = lane + 64 * i;
             if (idx < n0) {
                 const int row = idx / C4, c4 = idx - row * C4;
-                const float4 sv = s0r[i], a = sks[2 * C4 + c4], bb = sks[3 * C4 + c4];
+                const float4 sv = s0r[i], a = sk0a, bb = sk0b;
                 *reinterpret_cast<float4 *>(strip + row * LD + 4 * c4) =
                     make_float4(fmaxf(a.x * sv.x + bb.x, 0.f), fmaxf(a.y * sv.y + bb.y, 0.f), fmaxf(a.z * sv.z + bb.z, 0.f), fmaxf(a.w * sv.w + bb.w, 0.f));
             }
@@ -1712,22 +1722,28 @@ __global__ void __launch_bounds__(DFX_GG_THREADS) dfx_k_ggemm(DfxGgArgs A) {
     // them and the barriers).  A tile: 64 rows x 32 k, float4 along k (2 per thread); B tile: 32 k x BN n, float4 along n.
     constexpr int AI = DFX_GG_BM * (DFX_GG_KT / 4) / DFX_GG_THREADS;                                    // 2
     constexpr int BI = (DFX_GG_KT * (BN / 4) + DFX_GG_THREADS - 1) / DFX_GG_THREADS;                    // 1 (BN <= 32) or 2
-    float4 ra[AI], rb[BI];
+    float4 ra[AI], ra2[AI], rb[BI];
+#pragma unroll
+    for (int u = 0; u < AI; ++u) ra2[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // a thread stages the same rows of every k-tile: their offsets once (the row map of a time-chunked launch is a 64-bit division,
+    // ~130 instructions; inside request() it ran twice per k-tile and thread, against 8 * NT matrix ops per tile and wave)
+    int64_t aoff[AI];
+#pragma unroll
+    for (int u = 0; u < AI; ++u) {
+        const int64_t m = m0 + (tid + u * DFX_GG_THREADS) / (DFX_GG_KT / 4);
+        aoff[u] = m < A.M ? dfx_row(A.rm, m) * A.lda + g * A.Kg : -1;
+    }
     auto request = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < AI; ++u) {
             const int i = tid + u * DFX_GG_THREADS;
             const int row = i / (DFX_GG_KT / 4), kq = i - row * (DFX_GG_KT / 4);
-            const int64_t m = m0 + row;
             const int k = k0 + 4 * kq;
-            ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < A.M && k < A.Kg) {
-                const int64_t off = dfx_row(A.rm, m) * A.lda + g * A.Kg + k;
+            ra[u] = ra2[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (aoff[u] >= 0 && k < A.Kg) {
+                const int64_t off = aoff[u] + k;
                 ra[u] = *reinterpret_cast<const float4 *>(A.a + off);
-                if (A.a2) {
-                    const float4 r2 = *reinterpret_cast<const float4 *>(A.a2 + off);
-                    ra[u] = make_float4(ra[u].x + r2.x, ra[u].y + r2.y, ra[u].z + r2.z, ra[u].w + r2.w);
-                }
+                if (A.a2) ra2[u] = *reinterpret_cast<const float4 *>(A.a2 + off);   // (added when the tile is stored: adding here would wait for both loads)
             }
         }
 #pragma unroll
@@ -1746,6 +1762,7 @@ __global__ void __launch_bounds__(DFX_GG_THREADS) dfx_k_ggemm(DfxGgArgs A) {
             const int i = tid + u * DFX_GG_THREADS;
             const int row = i / (DFX_GG_KT / 4), kq = i - row * (DFX_GG_KT / 4);
             float *d = As + row * LDA + 4 * kq;
+            if (A.a2) ra[u] = make_float4(ra[u].x + ra2[u].x, ra[u].y + ra2[u].y, ra[u].z + ra2[u].z, ra[u].w + ra2[u].w);
             d[0] = ra[u].x;
             d[1] = ra[u].y;
             d[2] = ra[u].z;
