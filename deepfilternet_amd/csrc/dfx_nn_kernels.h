@@ -527,6 +527,13 @@ template <int C>
 #ifndef DFX_C01_MINB
 #define DFX_C01_MINB 3   /* three waves per SIMD (168 registers): 2.2 -> 1.6 ms at config 2; the range guard pushed the two-wave build to 178 */
 #endif
+#ifndef DFX_C01_PIN
+#define DFX_C01_PIN 0         /* dev: bias / tap reads pinned ahead of the `keep` branches (the compiler sinks each read into the branch of its
+                                 use: 36 dependent LDS round trips per tile) — costs registers the three-wave build does not have: measured below */
+#endif
+#ifndef DFX_C01_EPI_BATCH
+#define DFX_C01_EPI_BATCH 2   /* channel groups whose bias / tap are read together (DFX_C01_PIN) */
+#endif
 __global__ void __launch_bounds__(DFX_PW_THREADS, DFX_C01_MINB) dfx_k_df_conv01_h3(DfxC01hArgs A) {
     constexpr int CPL = C / 4, NT = C / 16, KC = C >= 32 ? C / 32 : 1, C4 = C / 4;
     static_assert(C % 32 == 0, "one k-chunk is 32 channels");
@@ -629,6 +636,34 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, DFX_C01_MINB) dfx_k_df_conv01_
             for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(w0h[nt], pl, acc[nt]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(w0h[nt], ph, acc[nt]);
+#if DFX_C01_PIN
+#pragma unroll
+            for (int n0 = 0; n0 < NT; n0 += DFX_C01_EPI_BATCH) {
+                float4 bz[DFX_C01_EPI_BATCH], w[DFX_C01_EPI_BATCH];
+#pragma unroll
+                for (int d = 0; d < DFX_C01_EPI_BATCH; ++d) {
+                    bz[d] = b0s[4 * (n0 + d) + q], w[d] = dws[j * C4 + 4 * (n0 + d) + q];
+                    // pinned here: the compiler otherwise sinks each read into the `keep` branch of its use (read -> wait -> four operations,
+                    // 36 dependent LDS round trips per tile)
+                    DFX_OPAQUE(bz[d].x);
+                    DFX_OPAQUE(bz[d].y);
+                    DFX_OPAQUE(bz[d].z);
+                    DFX_OPAQUE(bz[d].w);
+                    DFX_OPAQUE(w[d].x);
+                    DFX_OPAQUE(w[d].y);
+                    DFX_OPAQUE(w[d].z);
+                    DFX_OPAQUE(w[d].w);
+                }
+#pragma unroll
+                for (int d = 0; d < DFX_C01_EPI_BATCH; ++d) {
+                    const int nt = n0 + d;
+                    u[4 * nt + 0] += w[d].x * (keep ? fmaxf(acc[nt][0] * A.unscale0 + bz[d].x, 0.f) : 0.f);
+                    u[4 * nt + 1] += w[d].y * (keep ? fmaxf(acc[nt][1] * A.unscale0 + bz[d].y, 0.f) : 0.f);
+                    u[4 * nt + 2] += w[d].z * (keep ? fmaxf(acc[nt][2] * A.unscale0 + bz[d].z, 0.f) : 0.f);
+                    u[4 * nt + 3] += w[d].w * (keep ? fmaxf(acc[nt][3] * A.unscale0 + bz[d].w, 0.f) : 0.f);
+                }
+            }
+#else
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const float4 bz = b0s[4 * nt + q], w = dws[j * C4 + 4 * nt + q];
@@ -637,6 +672,7 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, DFX_C01_MINB) dfx_k_df_conv01_
                 u[4 * nt + 2] += w.z * (keep ? fmaxf(acc[nt][2] * A.unscale0 + bz.z, 0.f) : 0.f);
                 u[4 * nt + 3] += w.w * (keep ? fmaxf(acc[nt][3] * A.unscale0 + bz.w, 0.f) : 0.f);
             }
+#endif
         }
         dfx_h8 uh[KC], ul[KC];
 #pragma unroll
