@@ -163,8 +163,10 @@ static __device__ __forceinline__ void dfx_fft_pass_ip(float2 *x, const float2 *
             const int p = b / S, q = b - p * S;
 #pragma unroll
             for (int j = 0; j < R; ++j) a[r][j] = x[q + S * (p + m * j)];
+            if constexpr (NCUR != R) {   // (the last pass has p = 0: every twiddle is 1)
 #pragma unroll
-            for (int j = 1; j < R; ++j) w[r][j - 1] = tw[j * p * tws];
+                for (int j = 1; j < R; ++j) w[r][j - 1] = tw[j * p * tws];
+            }
         }
     }
     DFX_WAVE_SYNC();
@@ -194,6 +196,24 @@ static __device__ __forceinline__ void dfx_fft_pass_ip(float2 *x, const float2 *
                 o[1] = dfx_cadd(t1, t3);
                 o[2] = dfx_csub(t0, t2);
                 o[3] = dfx_csub(t1, t3);
+            } else if constexpr (R == 6) {
+                // 6 = 2 x 3 with coprime factors: input n = 3 n1 + 2 n2, output k = 3 k1 + 4 k2 (mod 6) need no twiddles between the
+                // three 2-point and the two 3-point transforms
+                const float2 s0 = dfx_cadd(a[r][0], a[r][3]), t0 = dfx_csub(a[r][0], a[r][3]);
+                const float2 s1 = dfx_cadd(a[r][2], a[r][5]), t1 = dfx_csub(a[r][2], a[r][5]);
+                const float2 s2 = dfx_cadd(a[r][4], a[r][1]), t2 = dfx_csub(a[r][4], a[r][1]);
+                auto dft3 = [](float2 x0, float2 x1, float2 x2, float2 &y0, float2 &y1, float2 &y2) {
+                    const float2 sm = dfx_cadd(x1, x2), d = dfx_csub(x1, x2);
+                    const float2 mm = make_float2(x0.x - 0.5f * sm.x, x0.y - 0.5f * sm.y);
+                    float2 jd = dfx_mul_sgi<SG>(d);
+                    jd.x *= 0.86602540378443864676f;
+                    jd.y *= 0.86602540378443864676f;
+                    y0 = dfx_cadd(x0, sm);
+                    y1 = dfx_cadd(mm, jd);
+                    y2 = dfx_csub(mm, jd);
+                };
+                dft3(s0, s1, s2, o[0], o[4], o[2]);   // k1 = 0: k = 4 k2 mod 6
+                dft3(t0, t1, t2, o[3], o[1], o[5]);   // k1 = 1: k = 3 + 4 k2 mod 6
             } else {  // R == 5
                 const float c1 = 0.30901699437494742410f, s1 = 0.95105651629515357212f;
                 const float c2 = -0.80901699437494742410f, s2 = 0.58778525229247312917f;
@@ -212,9 +232,13 @@ static __device__ __forceinline__ void dfx_fft_pass_ip(float2 *x, const float2 *
             x[q + S * (R * p)] = o[0];
 #pragma unroll
             for (int j = 1; j < R; ++j) {
-                float2 wj = w[r][j - 1];
-                if (SG > 0) wj.y = -wj.y;
-                x[q + S * (R * p + j)] = dfx_cmul(o[j], wj);
+                if constexpr (NCUR != R) {
+                    float2 wj = w[r][j - 1];
+                    if (SG > 0) wj.y = -wj.y;
+                    x[q + S * (R * p + j)] = dfx_cmul(o[j], wj);
+                } else {
+                    x[q + S * (R * p + j)] = o[j];
+                }
             }
         }
     }
@@ -226,6 +250,9 @@ static __device__ __forceinline__ bool dfx_plan_is_480(const DfxFftPlan &pl) {
 }
 // (the lane index is made opaque before every pass: the passes' LDS addresses depend on nothing but the lane, and a compiler that hoists
 // all ~100 of them out of the kernel's frame loop — it does — pushes the kernel from 80 to 150 registers, i.e. from six waves per SIMD to three)
+#ifndef DFX_FFT480_FIVE_PASSES
+#define DFX_FFT480_FIVE_PASSES 0
+#endif
 template <int SG>
 static __device__ __forceinline__ void dfx_fft480_ip(float2 *x, const float2 *tw, int lane, bool active) {
     int l = lane;
@@ -234,9 +261,13 @@ static __device__ __forceinline__ void dfx_fft480_ip(float2 *x, const float2 *tw
     DFX_OPAQUE(l);
     dfx_fft_pass_ip<4, SG, 480, 120, 4>(x, tw, l, active);
     DFX_OPAQUE(l);
+#if DFX_FFT480_FIVE_PASSES   /* the plan of make_plan, pass for pass (= the two-buffer path's bits) */
     dfx_fft_pass_ip<2, SG, 480, 30, 16>(x, tw, l, active);
     DFX_OPAQUE(l);
     dfx_fft_pass_ip<3, SG, 480, 15, 32>(x, tw, l, active);
+#else                        /* 480 = 4 * 4 * 6 * 5: the radix-2 and radix-3 passes as one twiddle-free 6-point pass */
+    dfx_fft_pass_ip<6, SG, 480, 30, 16>(x, tw, l, active);
+#endif
     DFX_OPAQUE(l);
     dfx_fft_pass_ip<5, SG, 480, 5, 96>(x, tw, l, active);
 }
