@@ -140,6 +140,41 @@ static __device__ __forceinline__ void dfx_fft_pass_c(const float2 *x, float2 *y
     }
 }
 
+// multiply by exp(SG * 2*pi*i * K / 8), K = 1 or 3 (the two 8th roots that are not axis rotations)
+template <int SG, int K>
+static __device__ __forceinline__ float2 dfx_mul_w8(float2 a) {
+    const float h = 0.70710678118654752440f;
+    if constexpr (K == 1) return SG < 0 ? make_float2((a.x + a.y) * h, (a.y - a.x) * h) : make_float2((a.x - a.y) * h, (a.y + a.x) * h);
+    else return SG < 0 ? make_float2((a.y - a.x) * h, (-a.x - a.y) * h) : make_float2((-a.x - a.y) * h, (a.x - a.y) * h);
+}
+// 4- and 5-point transforms on values (the butterflies of the passes below)
+template <int SG>
+static __device__ __forceinline__ void dfx_dft4(float2 x0, float2 x1, float2 x2, float2 x3, float2 &y0, float2 &y1, float2 &y2, float2 &y3) {
+    const float2 t0 = dfx_cadd(x0, x2), t1 = dfx_csub(x0, x2);
+    const float2 t2 = dfx_cadd(x1, x3), t3 = dfx_mul_sgi<SG>(dfx_csub(x1, x3));
+    y0 = dfx_cadd(t0, t2);
+    y1 = dfx_cadd(t1, t3);
+    y2 = dfx_csub(t0, t2);
+    y3 = dfx_csub(t1, t3);
+}
+template <int SG>
+static __device__ __forceinline__ void dfx_dft5(float2 x0, float2 x1, float2 x2, float2 x3, float2 x4, float2 &y0, float2 &y1, float2 &y2,
+                                                float2 &y3, float2 &y4) {
+    const float c1 = 0.30901699437494742410f, s1 = 0.95105651629515357212f;
+    const float c2 = -0.80901699437494742410f, s2 = 0.58778525229247312917f;
+    const float2 s14 = dfx_cadd(x1, x4), d14 = dfx_csub(x1, x4);
+    const float2 s23 = dfx_cadd(x2, x3), d23 = dfx_csub(x2, x3);
+    const float2 m1 = make_float2(x0.x + c1 * s14.x + c2 * s23.x, x0.y + c1 * s14.y + c2 * s23.y);
+    const float2 m2 = make_float2(x0.x + c2 * s14.x + c1 * s23.x, x0.y + c2 * s14.y + c1 * s23.y);
+    const float2 n1 = dfx_mul_sgi<SG>(make_float2(s1 * d14.x + s2 * d23.x, s1 * d14.y + s2 * d23.y));
+    const float2 n2 = dfx_mul_sgi<SG>(make_float2(s2 * d14.x - s1 * d23.x, s2 * d14.y - s1 * d23.y));
+    y0 = make_float2(x0.x + s14.x + s23.x, x0.y + s14.y + s23.y);
+    y1 = dfx_cadd(m1, n1);
+    y4 = dfx_csub(m1, n1);
+    y2 = dfx_cadd(m2, n2);
+    y3 = dfx_csub(m2, n2);
+}
+
 // The same pass IN PLACE: a lane first reads the inputs of all its butterflies, then writes their outputs.  One team is one wave, whose
 // lanes run in lockstep and whose LDS accesses complete in program order, so every read of the pass precedes every write (the wave-level
 // sync between the two halves costs nothing on the GPU and is what the CPU interpreter needs).  Same butterflies, same twiddles, same
@@ -196,6 +231,24 @@ static __device__ __forceinline__ void dfx_fft_pass_ip(float2 *x, const float2 *
                 o[1] = dfx_cadd(t1, t3);
                 o[2] = dfx_csub(t0, t2);
                 o[3] = dfx_csub(t1, t3);
+            } else if constexpr (R == 8) {
+                // even / odd inputs through two 4-point transforms, then o[k] = E[k] + W8^k O[k], o[k + 4] = E[k] - W8^k O[k]
+                float2 e0, e1, e2, e3, q0, q1, q2, q3;
+                dfx_dft4<SG>(a[r][0], a[r][2], a[r][4], a[r][6], e0, e1, e2, e3);
+                dfx_dft4<SG>(a[r][1], a[r][3], a[r][5], a[r][7], q0, q1, q2, q3);
+                q1 = dfx_mul_w8<SG, 1>(q1);
+                q2 = dfx_mul_sgi<SG>(q2);
+                q3 = dfx_mul_w8<SG, 3>(q3);
+                o[0] = dfx_cadd(e0, q0), o[4] = dfx_csub(e0, q0);
+                o[1] = dfx_cadd(e1, q1), o[5] = dfx_csub(e1, q1);
+                o[2] = dfx_cadd(e2, q2), o[6] = dfx_csub(e2, q2);
+                o[3] = dfx_cadd(e3, q3), o[7] = dfx_csub(e3, q3);
+            } else if constexpr (R == 10) {
+                // 10 = 2 x 5 with coprime factors: input n = 5 n1 + 2 n2, output k = 5 k1 + 6 k2 (mod 10), no twiddles in between
+                dfx_dft5<SG>(dfx_cadd(a[r][0], a[r][5]), dfx_cadd(a[r][2], a[r][7]), dfx_cadd(a[r][4], a[r][9]), dfx_cadd(a[r][6], a[r][1]),
+                             dfx_cadd(a[r][8], a[r][3]), o[0], o[6], o[2], o[8], o[4]);
+                dfx_dft5<SG>(dfx_csub(a[r][0], a[r][5]), dfx_csub(a[r][2], a[r][7]), dfx_csub(a[r][4], a[r][9]), dfx_csub(a[r][6], a[r][1]),
+                             dfx_csub(a[r][8], a[r][3]), o[5], o[1], o[7], o[3], o[9]);
             } else if constexpr (R == 6) {
                 // 6 = 2 x 3 with coprime factors: input n = 3 n1 + 2 n2, output k = 3 k1 + 4 k2 (mod 6) need no twiddles between the
                 // three 2-point and the two 3-point transforms
@@ -250,26 +303,34 @@ static __device__ __forceinline__ bool dfx_plan_is_480(const DfxFftPlan &pl) {
 }
 // (the lane index is made opaque before every pass: the passes' LDS addresses depend on nothing but the lane, and a compiler that hoists
 // all ~100 of them out of the kernel's frame loop — it does — pushes the kernel from 80 to 150 registers, i.e. from six waves per SIMD to three)
-#ifndef DFX_FFT480_FIVE_PASSES
-#define DFX_FFT480_FIVE_PASSES 0
+#ifndef DFX_FFT480_PASSES
+#define DFX_FFT480_PASSES 3
 #endif
 template <int SG>
 static __device__ __forceinline__ void dfx_fft480_ip(float2 *x, const float2 *tw, int lane, bool active) {
     int l = lane;
     DFX_OPAQUE(l);
+#if DFX_FFT480_PASSES == 3     /* 480 = 8 * 6 * 10: 60 + 80 + 48 butterflies, the 6- and 10-point ones without inner twiddles (coprime factors) */
+    dfx_fft_pass_ip<8, SG, 480, 480, 1>(x, tw, l, active);
+    DFX_OPAQUE(l);
+    dfx_fft_pass_ip<6, SG, 480, 60, 8>(x, tw, l, active);
+    DFX_OPAQUE(l);
+    dfx_fft_pass_ip<10, SG, 480, 10, 48>(x, tw, l, active);
+#else
     dfx_fft_pass_ip<4, SG, 480, 480, 1>(x, tw, l, active);
     DFX_OPAQUE(l);
     dfx_fft_pass_ip<4, SG, 480, 120, 4>(x, tw, l, active);
     DFX_OPAQUE(l);
-#if DFX_FFT480_FIVE_PASSES   /* the plan of make_plan, pass for pass (= the two-buffer path's bits) */
+#if DFX_FFT480_PASSES == 5     /* the plan of make_plan, pass for pass (= the two-buffer path's bits) */
     dfx_fft_pass_ip<2, SG, 480, 30, 16>(x, tw, l, active);
     DFX_OPAQUE(l);
     dfx_fft_pass_ip<3, SG, 480, 15, 32>(x, tw, l, active);
-#else                        /* 480 = 4 * 4 * 6 * 5: the radix-2 and radix-3 passes as one twiddle-free 6-point pass */
+#else                          /* 480 = 4 * 4 * 6 * 5: the radix-2 and radix-3 passes as one 6-point pass */
     dfx_fft_pass_ip<6, SG, 480, 30, 16>(x, tw, l, active);
 #endif
     DFX_OPAQUE(l);
     dfx_fft_pass_ip<5, SG, 480, 5, 96>(x, tw, l, active);
+#endif
 }
 
 // Complex FFT of length pl.M by one 64-lane team.  Data starts in `a`; returns the buffer that holds the result.
