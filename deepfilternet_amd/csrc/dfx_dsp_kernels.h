@@ -406,7 +406,8 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_analysis(Df
     float *win = reinterpret_cast<float *>(smem + (size_t)N * 8);        // [N]
     const size_t team_off = (size_t)N * 12;
     const size_t buf_elems = (size_t)(M + 2);                            // M+1 used, padded to keep 16-byte carve
-    const int team = threadIdx.x / DFX_DSP_TEAM, lane = threadIdx.x % DFX_DSP_TEAM;
+    // (the team = wave index is uniform across the wave: frame index, clip / frame split — a 64-bit division — and the row bases stay scalar)
+    const int team = dfx_wave_uniform(threadIdx.x / DFX_DSP_TEAM), lane = threadIdx.x % DFX_DSP_TEAM;
     // the 480-point plan transforms in place: one buffer per frame (the host sizes the dynamic LDS accordingly, dfx_dsp.hip)
     constexpr bool ip = IP;
     float2 *bufA = reinterpret_cast<float2 *>(smem + team_off) + (size_t)team * (ip ? 1 : 2) * buf_elems;
@@ -674,7 +675,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_synthesis(D
     const size_t team_off = (size_t)N * 12;
     const size_t buf_elems = (size_t)(M + 2);
     constexpr int NBUF = IP ? 1 : 2;   // buffers per frame
-    const int team = threadIdx.x / DFX_DSP_TEAM, lane = threadIdx.x % DFX_DSP_TEAM;
+    const int team = dfx_wave_uniform(threadIdx.x / DFX_DSP_TEAM), lane = threadIdx.x % DFX_DSP_TEAM;   // (wave-uniform: scalar frame / row arithmetic)
     float2 *bufs = reinterpret_cast<float2 *>(smem + team_off);
     float2 *bufA = bufs + (size_t)team * NBUF * buf_elems;
     float2 *bufB = IP ? bufA : bufA + buf_elems;   // the frame is staged here

@@ -1528,6 +1528,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                         const DfxFinish *fin, const DfxStreamCtx *sc = nullptr) {
     const dfx_model_cfg &c = m->cfg;
     const int64_t R = B * T;
+    // (row maps of the time-chunked launches divide in 32 bits, dfx_row; the workspace of 2^31 frames would be ~170 TB)
+    if (R >= ((int64_t)1 << 31)) DFX_FAIL(DFX_ERR_UNSUPPORTED, "forward: %lld x %lld frames in one call (32-bit row index)", (long long)B, (long long)T);
     // streaming window (sc): the arrays hold T = H + n frames per clip, only the n new ones are computed; per-frame kernels reach
     // their rows through rmw, the lookahead shift is already in the feature stream (kernel lookahead 0)
     const int64_t t_begin = sc ? sc->H : 0, Rn = B * (T - t_begin);

@@ -42,8 +42,10 @@ struct DfxRowMap {
 };
 static __device__ __forceinline__ int64_t dfx_row(const DfxRowMap &rm, int64_t m) {
     if (rm.Tk == 0) return m;
-    const int64_t b = m / rm.Tk;
-    return b * rm.T + rm.t0 + (m - b * rm.Tk);
+    // logical rows of a chunk launch are B * Tk <= B * T < 2^31 (forward_impl refuses more): a 32-bit division (~25 instructions; the 64-bit
+    // one is ~130, and the staged kernels map a row per 16-byte piece they move: a dozen per item in the time-chunked pipeline)
+    const uint32_t b = (uint32_t)m / (uint32_t)rm.Tk;
+    return (int64_t)b * rm.T + rm.t0 + ((uint32_t)m - b * (uint32_t)rm.Tk);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1828,6 +1830,12 @@ __global__ void __launch_bounds__(DFX_GG_THREADS) dfx_k_ggemm(DfxGgArgs A) {
         const int64_t ml = m0 + 16 * wave + 4 * (lane >> 4) + r;
         if (ml >= A.M) continue;
         const int64_t m = dfx_row(A.rm, ml);
+        // (clip / frame of the row once per row and in 32 bits — rows are < 2^31, see dfx_row — instead of a 64-bit division per output value)
+        uint32_t pb = 0, pt = 0;
+        if (A.perm_inner > 0) {
+            pb = (uint32_t)m / (uint32_t)A.perm_T;
+            pt = (uint32_t)m - pb * (uint32_t)A.perm_T;
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int n = n0 + 16 * nt + (lane & 15);
@@ -1839,7 +1847,7 @@ __global__ void __launch_bounds__(DFX_GG_THREADS) dfx_k_ggemm(DfxGgArgs A) {
             int64_t idx = m * A.ldo + col;
             if (A.perm_inner > 0) {
                 const int f = col / A.perm_inner, i = col - f * A.perm_inner;
-                const int64_t b = m / A.perm_T, t = m - b * A.perm_T;
+                const int64_t b = pb, t = pt;
                 idx = (((b * (A.perm_inner >> 1) + (i >> 1)) * A.perm_T + t) * A.perm_F + f) * 2 + (i & 1);
             }
             if (A.res) v += A.res[idx];
