@@ -142,6 +142,26 @@ def test_features_fused_matches_oracle_pipeline(backend):
     assert np.abs(fsc - FS).max() < 2e-5 * np.abs(FS).max()
 
 
+@pytest.mark.parametrize("N,H,nb,minf", [(960, 480, 32, 2), (960, 480, 80, 1), (320, 160, 24, 1), (192, 96, 8, 1), (960, 240, 64, 1)])
+@pytest.mark.parametrize("segments", ["1", "0"])
+def test_fused_erb_feature_band_layouts(backend, N, H, nb, minf, segments, monkeypatch):
+    """The ERB feature the STFT kernel writes (band energies in dB, before the norm) for several band layouts: summed on 64 segment lanes
+    (dfx_bands_create cuts the bands into near-equal segments), one lane per band (DFX_ERB_SEGMENTS=0), and with more than 64 bands
+    (no segment table; the kernel's second round of lanes).  Oracle: lib.rs:280-295 compute_band_corr, bins strictly in order."""
+    from deepfilternet_amd.enhance import _norm_alpha, df_features
+
+    D = _libdf()
+    monkeypatch.setenv("DFX_ERB_SEGMENTS", segments)
+    rng = np.random.default_rng(N + nb)
+    x = (0.2 * rng.standard_normal((2, H * 9))).astype(np.float32)
+    d, o = D.DF(48000, N, H, nb, minf), L.DF(48000, N, H, nb, minf)
+    assert d.erb_widths().tolist() == o.erb_widths().tolist() and len(d.erb_widths()) == nb
+    _, fe, _ = df_features(torch.from_numpy(x), d, min(96, N // 2))
+    FE = L.erb_norm(L.erb(o.analysis(x), o.erb_widths()), _norm_alpha(d))   # (get_norm_alpha of this sr / hop, as df_features takes it)
+    assert fe.shape == (2, 1, 9, nb)
+    assert np.abs(fe.squeeze(1).cpu().numpy() - FE).max() < 2e-5
+
+
 def test_device_tensor_path_no_host_roundtrip(backend):
     from deepfilternet_amd import _lib
 
