@@ -48,6 +48,33 @@ static __device__ __forceinline__ int64_t dfx_row(const DfxRowMap &rm, int64_t m
     return (int64_t)b * rm.T + rm.t0 + ((uint32_t)m - b * (uint32_t)rm.Tk);
 }
 
+// a / d for 0 <= a < 2^22 and d > 0 with inv = 1.0f / d: the float quotient is within one of the integer one (8 instructions; the
+// integer division by a run-time value is ~20)
+static __device__ __forceinline__ int dfx_div_small(int a, int d, float inv) {
+    int q = (int)((float)a * inv);
+    const int r = a - q * d;
+    q += (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+    return q;
+}
+// The row map for the rows base + fr of ONE item (fr small): the division once per item (dfx_row_base), an add and a compare per row.
+struct DfxRowBase {
+    uint32_t b, r;   // base = b * Tk + r
+};
+static __device__ __forceinline__ DfxRowBase dfx_row_base(const DfxRowMap &rm, int64_t base) {
+    DfxRowBase rb{0u, 0u};
+    if (rm.Tk != 0) {
+        rb.b = (uint32_t)base / (uint32_t)rm.Tk;
+        rb.r = (uint32_t)base - rb.b * (uint32_t)rm.Tk;
+    }
+    return rb;
+}
+static __device__ __forceinline__ int64_t dfx_row_at(const DfxRowMap &rm, int64_t base, const DfxRowBase &rb, int fr) {
+    if (rm.Tk == 0) return base + fr;
+    uint32_t b = rb.b, r = rb.r + (uint32_t)fr;
+    while (r >= (uint32_t)rm.Tk) r -= (uint32_t)rm.Tk, ++b;
+    return (int64_t)b * rm.T + rm.t0 + r;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // enc.erb_conv0: Conv2d(1 -> C, 3x3, causal in time, pad 1 in freq) + BN + ReLU   (deepfilternet3.py:106-108)
 //   feat [B,T,E] -> out [B*T, E, C].  Lookahead L: tap kt of output frame t reads input frame t+L-2+kt, and is zero when
@@ -1026,17 +1053,22 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 2) dfx_k_pwconv_f(DfxPwArgs A)
     const float4 *s4 = reinterpret_cast<const float4 *>(A.skip);
     float4 *o4 = reinterpret_cast<float4 *>(A.out);
     float4 xr[NVI], sr[SKIP ? NVI : 1];
+    // frame of a 16-byte piece and its row: a float-reciprocal quotient and an incremental row map (one division per item) — as integer
+    // divisions per piece these were two dozen per item, a third of the kernel's vector instructions in the time-chunked pipeline
+    const float inv_fin4 = 1.0f / (float)fin4, inv_fout = 1.0f / (float)A.Fout;
     auto issue = [&](int64_t item) {
+        const int64_t base = item * G;
+        const DfxRowBase rb = dfx_row_base(A.rm, base);
 #pragma unroll
         for (int i = 0; i < NVI; ++i) {
             const int idx = lane + 64 * i;
             xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (SKIP) sr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (idx < nin4) {
-                const int fr = idx / fin4;
-                const int64_t rl = item * G + fr;
+                const int fr = dfx_div_small(idx, fin4, inv_fin4);
+                const int64_t rl = base + fr;
                 if (rl < A.R) {
-                    const int64_t off = dfx_row(A.rm, rl) * fin4 + (idx - fr * fin4);
+                    const int64_t off = dfx_row_at(A.rm, base, rb, fr) * fin4 + (idx - fr * fin4);
                     xr[i] = x4[off];
                     if (SKIP) sr[i] = s4[off];
                 }
@@ -1075,14 +1107,16 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 2) dfx_k_pwconv_f(DfxPwArgs A)
         if constexpr (H3) dfx_chain_stage_h3<C, MODE>(sin, A.Fin, A.Fout, A.stride, npos, dws, ahi, alo, biasr, A.unscale, amax, lane, epi);
         else dfx_chain_stage<C, MODE>(sin, A.Fin, A.Fout, A.stride, npos, dws, areg, biasr, lane, epi);
         DFX_WAVE_SYNC();
+        const int64_t obase = item * G;
+        const DfxRowBase orb = dfx_row_base(A.rm, obase);
 #pragma unroll
         for (int i = 0; i < DFX_PWF_MAXV; ++i) {
             const int idx = lane + 64 * i;
             if (idx < nout4) {
                 const int p = idx / C4, c4 = idx - p * C4;
-                const int fr = p / A.Fout;
-                const int64_t rl = item * G + fr;
-                if (rl < A.R) o4[dfx_row(A.rm, rl) * fout4 + (idx - fr * fout4)] = *reinterpret_cast<const float4 *>(sout + p * LD + 4 * c4);
+                const int fr = dfx_div_small(p, A.Fout, inv_fout);
+                const int64_t rl = obase + fr;
+                if (rl < A.R) o4[dfx_row_at(A.rm, obase, orb, fr) * fout4 + (idx - fr * fout4)] = *reinterpret_cast<const float4 *>(sout + p * LD + 4 * c4);
             }
         }
     }
