@@ -72,6 +72,22 @@ def test_roundtrip_and_streaming_state(backend):
     assert np.abs(np.concatenate([y1, y2], 1) - ys).max() < 2e-6
 
 
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_two_buffer_transforms_agree_with_in_place(backend, mode, monkeypatch):
+    """DFX_FFT_IN_PLACE=0 / 2: the 480-point STFT / ISTFT on two LDS buffers per frame in make_plan's five passes (the form every other
+    size uses) against the default in-place three-pass form: different factorisations of the same transform."""
+    D = _libdf()
+    rng = np.random.default_rng(21)
+    x = (0.3 * rng.standard_normal((2, 480 * 9 + 3))).astype(np.float32)
+    S0 = D.DF(48000, 960, 480, 32, 2).analysis(x)
+    y0 = D.DF(48000, 960, 480, 32, 2).synthesis(S0.copy())
+    monkeypatch.setenv("DFX_FFT_IN_PLACE", mode)
+    S1 = D.DF(48000, 960, 480, 32, 2).analysis(x)
+    y1 = D.DF(48000, 960, 480, 32, 2).synthesis(S0.copy())
+    assert np.abs(S1 - S0).max() < 3e-7 * max(1.0, np.abs(S0).max() / 0.02)
+    assert np.abs(y1 - y0).max() < 2e-6
+
+
 def test_roundtrip_quarter_hop_streaming(backend):
     D = _libdf()
     rng = np.random.default_rng(4)
