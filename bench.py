@@ -92,19 +92,27 @@ def main() -> None:
     ap.add_argument("--main-only", action="store_true", help="only the timed loop and the DF-apply roofline (profiling runs: no extra steps / configs)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ---- ranks: one process per GPU.  Under an external launcher (torch.distributed.run) WORLD_SIZE must equal --gpus; without one,
+    # --gpus N > 1 starts the N ranks here (deepfilternet_amd.distributed.launch_ranks) and this process only waits for them.
+    from deepfilternet_amd.distributed import WorldError, check_world, init_world, launch_ranks
+
+    try:
+        env_world = check_world(args.gpus, torch.cuda.device_count() if torch.cuda.is_available() else None)
+    except WorldError as e:
+        raise SystemExit(f"bench.py: {e}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: the HIP engine has no CPU fallback")
+    if env_world is None and args.gpus > 1:
+        raise SystemExit(launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+    world, rank, local_rank = env_world if env_world is not None else (1, 0, 0)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist  # noqa: PLW0642
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        init_world("nccl", world, rank, dev)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from deepfilternet_amd import _lib
     from deepfilternet_amd.config import ModelParams
@@ -164,8 +172,12 @@ def main() -> None:
     dt = time.perf_counter() - t0
     dfa_ms, dfa_n = _lib.prof_read().get("dfx_k_df_apply", (0.0, 0))
     _lib.prof_enable(None)
+    per_rank_ms = [dt / args.steps * 1e3]
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in allt]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(y).all()
@@ -300,8 +312,11 @@ def main() -> None:
     rooflines["dfx_k_gru_rec_h3"] = gru
 
     # ---- exact fp32: the same step with every contraction on the exact fp32 MFMA / VALU kernels
-    exact_ms = None
+    exact_ms, exact_diff = None, None
+    extras = world == 1   # a scaling run (N > 1) keeps the other ranks waiting at the final barrier: the N = 1 line carries the extras
     try:
+        if not extras:
+            raise RuntimeError("N > 1: reported by the N = 1 run")
         os.environ["DFX_EXACT_FP32"] = "1"
         m_exact, _, _, _ = init_df(params=p, state_dict=sd, epoch="none")
         del os.environ["DFX_EXACT_FP32"]
@@ -333,6 +348,9 @@ def main() -> None:
     try:
         import subprocess
 
+        if not extras:
+            raise RuntimeError("N > 1: reported by the N = 1 run")
+
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
                                                                  "TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT")}
         env["DFX_ENQUEUE_AHEAD"] = "1"
@@ -342,14 +360,15 @@ def main() -> None:
     except Exception as e:  # noqa: BLE001
         ahead_ms = repr(e)
     configs = {}
-    try:
-        configs["streaming_4096"] = bench_streaming(dev)
-    except Exception as e:  # noqa: BLE001
-        configs["streaming_4096"] = {"error": repr(e)}
-    try:
-        configs["df_apply_o10"] = bench_df_apply_o10(dev, df_state, B, Tf)
-    except Exception as e:  # noqa: BLE001
-        configs["df_apply_o10"] = {"error": repr(e)}
+    if extras:
+        try:
+            configs["streaming_4096"] = bench_streaming(dev)
+        except Exception as e:  # noqa: BLE001
+            configs["streaming_4096"] = {"error": repr(e)}
+        try:
+            configs["df_apply_o10"] = bench_df_apply_o10(dev, df_state, B, Tf)
+        except Exception as e:  # noqa: BLE001
+            configs["df_apply_o10"] = {"error": repr(e)}
     torch.cuda.empty_cache()
 
     cpu = None
@@ -373,7 +392,8 @@ def main() -> None:
                    "batch_per_gpu": B, "clip_seconds": args.seconds, "global_batch": B * world,
                    "parallelism": f"clips sharded over {world} GPU(s); " + ("async RCCL gather of waveforms to rank 0" if gather else "no collective"),
                    "inputs_resident_in_hbm": True},
-        "ms_per_step_without_gather": no_gather_ms,
+        "ms_per_step_without_gather": no_gather_ms, "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
+        "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
         "enqueue": {"policy": "one big pass in flight per model handle (a call first waits, on the host, for the previous pass to drain) and the GRU phase "
                               "of a pass is enqueued once its encoder front has run: packets waiting at the head of the pass's ~13 hardware queues slow "
                               "the kernels that are running; every step of the timed loop still runs to completion inside the timed region",

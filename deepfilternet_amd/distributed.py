@@ -86,3 +86,105 @@ def enhance_sharded(model, df_state, audio: torch.Tensor, pad: bool = True, atte
     parts = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
     work = dist.gather(send.contiguous(), parts, dst=dst, group=group, async_op=True)
     return GatherHandle(work, parts, sizes, y)
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+# One process per GPU.  `python bench.py --gpus N` (or any script that calls `ensure_world`) starts its own N ranks when no
+# launcher did; under an external launcher (torch.distributed.run: WORLD_SIZE / RANK / LOCAL_RANK in the environment) it checks
+# that the launcher's world is the one that was asked for.  Nothing here needs a GPU: the CPU tests drive it with gloo.
+_RANK_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE",
+             "TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT")
+
+
+class WorldError(RuntimeError):
+    """The requested number of ranks cannot be had (devices missing, or the external launcher started another number)."""
+
+
+def free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def world_from_env() -> Optional[Tuple[int, int, int]]:
+    """(world, rank, local_rank) when a launcher set them, else None."""
+    import os
+
+    if "WORLD_SIZE" not in os.environ:
+        return None
+    world = int(os.environ["WORLD_SIZE"])
+    rank = int(os.environ.get("RANK", "0"))
+    return world, rank, int(os.environ.get("LOCAL_RANK", str(rank)))
+
+
+def check_world(requested: int, device_count: Optional[int]) -> Optional[Tuple[int, int, int]]:
+    """Validates ``--gpus requested`` against the environment.  Returns the launcher's (world, rank, local_rank), or None when this
+    process has to start the ranks itself.  ``device_count`` = visible GPUs (None: not a GPU run, e.g. the gloo tests)."""
+    if requested < 1:
+        raise WorldError(f"--gpus {requested}: need at least one rank")
+    env = world_from_env()
+    if env is not None and env[0] != requested:
+        raise WorldError(f"--gpus {requested} but the launcher started WORLD_SIZE={env[0]} ranks: pass the same number to both "
+                         f"(python -m torch.distributed.run --nproc-per-node {requested} ... --gpus {requested})")
+    if device_count is not None and device_count < requested:
+        raise WorldError(f"{requested} ranks requested, {device_count} device{'s' if device_count != 1 else ''} visible: "
+                         "one process per GPU, ranks never share a device")
+    if env is not None and not (0 <= env[1] < env[0]):
+        raise WorldError(f"RANK={env[1]} outside WORLD_SIZE={env[0]}")
+    return env
+
+
+def launch_ranks(argv: List[str], nproc: int, *, extra_env: Optional[dict] = None, timeout: Optional[float] = None) -> int:
+    """Starts ``nproc`` copies of ``argv`` (a full command line), one per rank, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT set (rendezvous on 127.0.0.1, a free port), and waits for them.  Rank 0 inherits stdout (its one JSON line is the
+    job's); the first failing rank ends the others.  Returns the job's exit code (0 only if every rank returned 0)."""
+    import os
+    import subprocess
+    import time
+
+    port = free_port()
+    procs = []
+    for r in range(nproc):
+        env = {k: v for k, v in os.environ.items() if k not in _RANK_ENV}
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes on this driver)
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen(argv, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    t0, rc = time.monotonic(), 0
+    live = set(range(nproc))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+        if rc != 0 or (timeout is not None and time.monotonic() - t0 > timeout):
+            if rc == 0:
+                rc = 124
+            for r in live:       # exactly the processes started above
+                procs[r].terminate()
+            for r in live:
+                try:
+                    procs[r].wait(10)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            break
+        if live:
+            time.sleep(0.05)
+    return rc
+
+
+def init_world(backend: str, world: int, rank: int, device=None) -> None:
+    """``init_process_group`` on 127.0.0.1 + the check the bench relies on: the group really has ``world`` ranks."""
+    import os
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    kw = {"device_id": device} if (device is not None and backend == "nccl") else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    if dist.get_world_size() != world or dist.get_rank() != rank:
+        raise WorldError(f"process group has {dist.get_world_size()} ranks (this is {dist.get_rank()}), expected {world} / {rank}")

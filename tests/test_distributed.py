@@ -76,3 +76,79 @@ def test_two_rank_sharded_enhance_matches_single_process(tmp_path):
     model, df_state, _, _ = init_df(params=named_params("defaults"), epoch="none", seed=3)
     ref = enhance(model, df_state, torch.from_numpy(x)).numpy()
     assert got.shape == ref.shape and np.array_equal(got, ref)  # rows are independent: sharding must not change a bit
+
+
+# ---- the launcher bench.py --gpus N uses (deepfilternet_amd.distributed.check_world / launch_ranks / init_world)
+def test_check_world_refuses_what_it_cannot_give(monkeypatch):
+    from deepfilternet_amd.distributed import WorldError, check_world
+
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert check_world(1, 1) is None and check_world(2, 8) is None and check_world(2, None) is None
+    with pytest.raises(WorldError, match="2 ranks requested, 1 device visible"):
+        check_world(2, 1)
+    with pytest.raises(WorldError, match="at least one"):
+        check_world(0, 8)
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("RANK", "3")
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert check_world(4, 8) == (4, 3, 3)
+    with pytest.raises(WorldError, match="--gpus 2 but the launcher started WORLD_SIZE=4"):
+        check_world(2, 8)
+    with pytest.raises(WorldError, match="4 ranks requested, 2 devices"):
+        check_world(4, 2)
+
+
+def _run(cmd, env=None, timeout=900):
+    import subprocess
+    import sys
+
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable] + cmd, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_gpus_flag_starts_its_own_ranks(tmp_path):
+    """`script --gpus 2` with no launcher in the environment starts 2 ranks itself (gloo, interpreter build); the gathered result is
+    the single-process one, bit for bit."""
+    import json
+
+    from tests.hipemu.build_emu import build
+
+    build()
+    here = os.path.dirname(os.path.abspath(__file__))
+    script = os.path.join(here, "rank_script.py")
+    o1, o2 = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    r2 = _run([script, "--gpus", "2", "--out", o2])
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    line = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    assert line == {"n_gpus": 2, "ranks_in_group": 2, "clips": 3}
+    r1 = _run([script, "--gpus", "1", "--out", o1])
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    assert np.array_equal(np.load(o1), np.load(o2))
+
+
+def test_gpus_flag_fails_loudly():
+    here = os.path.dirname(os.path.abspath(__file__))
+    script = os.path.join(here, "rank_script.py")
+    r = _run([script, "--gpus", "2", "--devices", "1"])
+    assert r.returncode != 0 and "2 ranks requested, 1 device visible" in r.stderr
+    r = _run([script, "--gpus", "2"], env={"WORLD_SIZE": "3", "RANK": "0"})
+    assert r.returncode != 0 and "--gpus 2 but the launcher started WORLD_SIZE=3" in r.stderr
+    # bench.py itself: the mismatch is refused before anything touches a device
+    r = _run([os.path.join(os.path.dirname(here), "bench.py"), "--gpus", "2"], env={"WORLD_SIZE": "8", "RANK": "0"})
+    assert r.returncode != 0 and "--gpus 2 but the launcher started WORLD_SIZE=8" in r.stderr
+
+
+def test_launch_ranks_ends_the_job_when_a_rank_fails(tmp_path):
+    import sys
+
+    from deepfilternet_amd.distributed import launch_ranks
+
+    s = tmp_path / "r.py"
+    s.write_text("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(7)\ntime.sleep(60)\n")
+    import time
+
+    t0 = time.monotonic()
+    assert launch_ranks([sys.executable, str(s)], 2) == 7
+    assert time.monotonic() - t0 < 30
