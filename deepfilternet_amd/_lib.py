@@ -86,6 +86,8 @@ SIGNATURES = {
     "dfx_model_set_run_df": (_i, [_vp, _i]),
     "dfx_model_set_pipeline": (_i, [_vp, _i, _i, _i]),
     "dfx_model_check": (_i, [_vp]),
+    "dfx_model_poll": (_i, [_vp]),
+    "dfx_model_query": (_i, [_vp, _i, C.POINTER(_i64)]),
     "dfx_model_workspace_bytes": (_i, [_vp, _i64, _i64, C.POINTER(_i64)]),
     "dfx_model_forward": (_i, [_vp, _vp, _fp, _fp, _fp, _i64, _i64, _f, _fp, _fp, _fp, _fp, _fp, _i64, _vp]),
     "dfx_enhance_workspace_bytes": (_i, [_vp, _vp, _i64, _i64, _i, C.POINTER(_i64)]),

@@ -176,6 +176,8 @@ extern "C" float df_process_frame(DFState *st, float *input, float *output) {
     if (dfx_stream_process(st->rt, dx, 1, dy, dl, nullptr) != DFX_OK) df_panic("Failed to process DF frame");
     if (hipMemcpy(output, dy, hb, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&lsnr, dl, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
         df_panic("Failed to process DF frame (download)");
+    // the downloads above waited for the pass: a fault one of its kernels raised (invalid results) ends the process like the reference's panics
+    if (dfx_model_poll(st->model) != DFX_OK) df_panic(dfx_last_error());
     return lsnr;
 }
 
@@ -197,6 +199,7 @@ extern "C" float df_process_frame_raw(DFState *st, float *input, float **out_gai
     unsigned char flag = 0;
     if (hipMemcpy(&lsnr, dl, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&flag, dflag, 1, hipMemcpyDeviceToHost) != hipSuccess)
         df_panic("Failed to process DF spectral frame (download)");
+    if (dfx_model_poll(st->model) != DFX_OK) df_panic(dfx_last_error());
     if ((flag & 2) && *out_gains_p) {
         if (hipMemcpy(*out_gains_p, dg, ng * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) df_panic("Failed to process DF spectral frame (download)");
     } else {

@@ -366,7 +366,16 @@ struct dfx_model {
     bool split_emb = false;             // DFX_SPLIT_EMB=1: df_fc_emb on the DF branch's stream behind df_conv1, linear_in reads cemb + e3 (measured: 17.55 vs 17.46 ms, no gain)
     mutable unsigned int seq_xcd_base = 0;  // per-XCD arrival counters of the persistent launches (10 workgroups per XCD and launch)
     mutable unsigned int seq_started = 0;  // workgroups of all persistent GRU launches so far (the front waits until they are resident)
-    unsigned int *d_err = nullptr;      // device words: [0] a bounded spin of the two-CU GRU kernel timed out, [1] fp16-split range, [2] flag wait timed out
+    // Error words, written by kernels, read by the host (page-locked host memory the device can store to: dfx_env_err_words_alloc):
+    // [0] a bounded spin of the two-CU GRU kernel timed out, [1] fp16-split range, [2] a flag wait of the persistent GRU phase timed out.
+    // The host looks at them wherever it waits for the device anyway (pass_begin, dfx_model_check) and at the start of every call
+    // (model_poll: plain loads, no synchronisation), so a fault is reported by the NEXT call on the handle at the latest;
+    // DFX_CHECK_EVERY_PASS=1 makes every call wait for its own pass and report its own faults.
+    unsigned int *d_err = nullptr;      // device address
+    unsigned int *h_err = nullptr;      // host address of the same words
+    bool check_every_pass = false;
+    int spin_limit = DFX_SYNC_SPIN_LIMIT;   // DFX_SYNC_SPIN_LIMIT=n (tests: force the timeouts)
+    int hwq_probe = -1;                 // -1 not run, 1: the phase's streams run concurrently, 0: they do not (event-based GRU phase instead)
     mutable unsigned int epoch = 0;     // tags the h exchange of one forward pass
     const float *p(size_t off) const { return d_w + off; }
 };
@@ -797,6 +806,9 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         m->gru_x2 = g2 && g2[0] == '1' && !dfx_env_is_emulator();
         const char *gq = getenv("DFX_GRU_SEQ");
         m->gru_seq = !(gq && gq[0] == '0') && !dfx_env_is_emulator();
+        const char *cep = getenv("DFX_CHECK_EVERY_PASS"), *spl = getenv("DFX_SYNC_SPIN_LIMIT");
+        m->check_every_pass = cep && cep[0] == '1';
+        if (spl && atoi(spl) > 0) m->spin_limit = atoi(spl);
         const char *fo = getenv("DFX_FRONT_OVERLAP"), *fa = getenv("DFX_FRONT_AHEAD"), *fsp = getenv("DFX_FRONT_SPLIT");
         m->front_overlap = fo && fo[0] == '1';
         m->front_ahead = fa ? atoi(fa) : 0;
@@ -820,7 +832,7 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         }
         const size_t sync_bytes = (size_t)(16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX + 8) * sizeof(unsigned int);   // ready | emb, started | done | per-XCD arrival counters
         if (hipMalloc(reinterpret_cast<void **>(&m->d_sync), sync_bytes) != hipSuccess || hipMemset(m->d_sync, 0, sync_bytes) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void **>(&m->d_err), 256) != hipSuccess || hipMemset(m->d_err, 0, 256) != hipSuccess) {
+            dfx_env_err_words_alloc(&m->h_err, &m->d_err, 256) != hipSuccess) {
             dfx_model_free(m);
             DFX_FAIL(DFX_ERR_ALLOC, "dfx_model_create: device allocation failed");
         }
@@ -845,6 +857,35 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
                 DFX_FAIL(DFX_ERR_HIP, "dfx_model_create: could not create the auxiliary streams/events");
             }
             m->have_streams = true;
+        }
+        // The persistent GRU phase synchronises through device flags: the stream of the persistent launch, the preparation stream of
+        // every layer and the two decoder-tail streams must make progress independently.  Streams that share a hardware queue
+        // (GPU_MAX_HW_QUEUES left at ROCm's default of 4, or set after HIP had initialised) would put a spinning wait in front of the
+        // launch it waits for — a timeout and an invalid pass.  Checked once, here, with a handshake between exactly those streams.
+        if (m->gru_seq && m->concurrent && !m->exact_fp32 && !dfx_env_is_emulator()) {
+            const DfxLane &ln = m->lanes[0];
+            const int nl = 1 + (m->cfg.emb_num_layers - 1) + m->cfg.df_num_layers;
+            std::vector<hipStream_t> ss;
+            if (ln.gs[1]) ss.push_back(ln.gs[1]);
+            for (int i = 0; i < nl && i < DFX_MAX_GRU_LAYERS; ++i)
+                if (ln.ps[i]) ss.push_back(ln.ps[i]);
+            for (int i = 0; i < 2; ++i)
+                if (ln.ts[i]) ss.push_back(ln.ts[i]);
+            const char *pe = getenv("DFX_HWQ_PROBE");   // "0": skip the probe (trust the environment); "fail": dev / test hook
+            if (pe && pe[0] == '0') {
+            } else if (pe && pe[0] == 'f') {
+                m->hwq_probe = 0;
+            } else {
+                unsigned int *cnt = m->d_sync + 13;   // (a spare word of the flag block: ready 0-7 | emb 8 | started 12 | probe 13 | done 16-)
+                m->h_err[8] = 0u;
+                for (hipStream_t st : ss) dfx_launch(dfx_k_probe_meet, dim3(1), dim3(64), 0, st, cnt, (unsigned int)ss.size(), 1 << 16, m->d_err + 8);
+                bool okp = hipGetLastError() == hipSuccess;
+                for (hipStream_t st : ss) okp = hipStreamSynchronize(st) == hipSuccess && okp;
+                m->hwq_probe = okp && ((volatile unsigned int *)m->h_err)[8] == 0u ? 1 : 0;
+                m->h_err[8] = 0u;
+                (void)hipMemset(cnt, 0, sizeof(unsigned int));
+            }
+            if (m->hwq_probe == 0) m->gru_seq = false;   // the event-synchronised form (DFX_GRU_SEQ=0) needs no concurrency to be correct
         }
     }
     *out = m;
@@ -880,7 +921,7 @@ extern "C" void dfx_model_free(dfx_model *m) {
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_pass) (void)hipEventDestroy(m->ev_pass);
-    if (m->d_err) (void)hipFree(m->d_err);
+    dfx_env_err_words_free(m->h_err);
     if (m->d_sync) (void)hipFree(m->d_sync);
     if (m->d_trace) (void)hipFree(m->d_trace);
     if (m->d_w) (void)hipFree(m->d_w);
@@ -905,17 +946,39 @@ extern "C" int dfx_model_set_pipeline(dfx_model *m, int time_chunks, int min_chu
         if (!dfx_create_lane(m, l)) DFX_FAIL(DFX_ERR_HIP, "dfx_model_set_pipeline: could not create the streams of lane %d", l);
     return DFX_OK;
 }
+// Reads (and clears) the error words without waiting for anything: faults of work that has completed.
+static int model_poll(const dfx_model *m) {
+    volatile unsigned int *h = m->h_err;
+    if (!h) return DFX_OK;
+    const unsigned int e0 = h[0], e1 = h[1], e2 = h[2];
+    if (!(e0 | e1 | e2)) return DFX_OK;
+    h[0] = 0u, h[1] = 0u, h[2] = 0u;
+    if (e2)
+        DFX_FAIL(DFX_ERR_HIP, "dfx: a flag wait of the persistent GRU phase timed out (bounded spin: the streams of the pass did not make progress "
+                              "independently — hardware queues shared with other work, or the GPU shared with another process); the results of "
+                              "the previous pass on this model are invalid.  DFX_GRU_SEQ=0 selects the event-synchronised form");
+    if (e0) DFX_FAIL(DFX_ERR_HIP, "dfx: a workgroup pair of the two-CU GRU kernel timed out waiting for its partner; the results of the previous pass on this model are invalid");
+    DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx: an activation of magnitude >= 6e4 reached an fp16-split matrix kernel (GRU / DF-encoder / separable-conv "
+                                  "path); the results of the previous pass on this model are invalid.  DFX_EXACT_FP32=1 selects the exact fp32 kernels");
+}
+extern "C" int dfx_model_poll(const dfx_model *m) {
+    if (!m) DFX_FAIL(DFX_ERR_INVALID_ARG, "null");
+    return model_poll(m);
+}
 extern "C" int dfx_model_check(const dfx_model *m) {
     if (!m) DFX_FAIL(DFX_ERR_INVALID_ARG, "null");
-    unsigned int e[3] = {0, 0, 0};
-    DFX_HIP(hipMemcpy(e, m->d_err, sizeof(e), hipMemcpyDeviceToHost));  // synchronises with the device
-    if (e[0] || e[1] || e[2]) (void)hipMemset(m->d_err, 0, sizeof(e));
-    if (e[2]) DFX_FAIL(DFX_ERR_HIP, "dfx: a flag wait of the persistent GRU phase timed out (bounded spin); the last results are invalid");
-    if (e[0]) DFX_FAIL(DFX_ERR_HIP, "dfx: a workgroup pair of the two-CU GRU kernel timed out waiting for its partner; the last results are invalid");
-    if (e[1])
-        DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx: an activation of magnitude >= 6e4 reached an fp16-split matrix kernel (df_conv0 / df_conv1 / df_convp "
-                                      "path); the last results are invalid.  DFX_EXACT_FP32=1 selects the exact fp32 kernels");
-    return DFX_OK;
+    DFX_HIP(hipDeviceSynchronize());   // every stream of the process: whatever this model has in flight is over
+    return model_poll(m);
+}
+extern "C" int dfx_model_query(const dfx_model *m, int what, int64_t *value) {
+    if (!m || !value) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_query: null");
+    switch (what) {
+        case DFX_Q_GRU_PERSISTENT: *value = m->gru_seq && !m->exact_fp32 && m->concurrent ? 1 : 0; return DFX_OK;
+        case DFX_Q_HWQ_PROBE: *value = m->hwq_probe; return DFX_OK;
+        case DFX_Q_EXACT_FP32: *value = m->exact_fp32 ? 1 : 0; return DFX_OK;
+        case DFX_Q_SPIN_LIMIT: *value = m->spin_limit; return DFX_OK;
+    }
+    DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_query: unknown item %d", what);
 }
 // dev aid: chunk timestamps (100 MHz ticks) of the last persistent GRU launch, [layers][groups][chunks][3]; dims -> {layers, groups, chunks}
 extern "C" int dfx_model_seq_trace(const dfx_model *m, unsigned long long *out_host, int64_t cap, int *dims) {
@@ -1478,7 +1541,7 @@ static int launch_flag_set(unsigned int *flag, unsigned int value, hipStream_t s
     return DFX_OK;
 }
 static int launch_wait_ge(const dfx_model *m, const unsigned int *flags, int n, unsigned int target, hipStream_t s) {
-    dfx_launch(dfx_k_wait_ge, dim3(1), dim3(64), 0, s, flags, n, target, m->d_err);
+    dfx_launch(dfx_k_wait_ge, dim3(1), dim3(64), 0, s, flags, n, target, m->d_err, m->spin_limit);
     DFX_LAUNCH_CHECK();
     return DFX_OK;
 }
@@ -1944,6 +2007,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 // XCD placement of the layers (DFX_SEQ_XCD=1; default: every layer on every XCD).  Measured at config 2: 17.96 vs 18.02 ms per
                 // step — the chain's slowdown under load is not an L2-capacity effect
                 S.xcd_cnt = nullptr, S.xcd_base = 0;
+                S.spin_limit = m->spin_limit;
                 if (m->seq_xcd && nl == 5 && groups == 16 && dfx_env_num_xcds() == 8) {
                     S.xcd_cnt = m->d_sync + 16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX;
                     S.xcd_base = m->seq_xcd_base;
@@ -2359,12 +2423,18 @@ static int model_forward_lane(const dfx_model *m, const dfx_bands *bands, const 
 static int pass_begin(const dfx_model *m, int64_t frames) {
     if (m->pass_pending && m->ev_pass && !m->enqueue_ahead && m->concurrent && frames >= DFX_THROTTLE_MIN_FRAMES) DFX_HIP(hipEventSynchronize(m->ev_pass));
     m->pass_pending = false;
-    return DFX_OK;
+    // the previous pass has drained (big passes) or may have (small ones): a fault it raised is reported now, before new work is enqueued
+    return model_poll(m);
 }
 static int pass_end(const dfx_model *m, int64_t frames, hipStream_t s) {
     if (m->ev_pass && !m->enqueue_ahead && m->concurrent && frames >= DFX_THROTTLE_MIN_FRAMES) {
         DFX_HIP(hipEventRecord(m->ev_pass, s));
         m->pass_pending = true;
+    }
+    if (m->check_every_pass) {   // DFX_CHECK_EVERY_PASS=1: the call waits for its own pass and reports its own faults
+        DFX_HIP(hipStreamSynchronize(s));
+        m->pass_pending = false;
+        return model_poll(m);
     }
     return DFX_OK;
 }
@@ -2857,10 +2927,23 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     return DFX_OK;
 }
 
+// Faults raised by kernels (dfx_model::h_err): a call reports what earlier passes on the model raised before it starts its own, and — with
+// DFX_CHECK_EVERY_PASS=1 — waits for its own pass and reports that too.
+static int stream_call_end(const dfx_model *m, hipStream_t s) {
+    if (!m->check_every_pass) return DFX_OK;
+    DFX_HIP(hipStreamSynchronize(s));
+    return model_poll(m);
+}
+static int stream_process_impl(dfx_stream_state *S, const float *x, int64_t n, float *y, float *lsnr_out, hipStream_t s);
 extern "C" int dfx_stream_process(dfx_stream_state *S, const float *x, int64_t n, float *y, float *lsnr_out, void *stream) {
     if (!S || n <= 0 || n > S->nmax || !x || !y) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_stream_process: bad arguments (1 <= n_frames <= max_frames)");
     if (int rc = dfx_require_device()) return rc;
+    if (int rc = model_poll(S->m)) return rc;
     hipStream_t s = dfx_stream(stream);
+    if (int rc = stream_process_impl(S, x, n, y, lsnr_out, s)) return rc;
+    return stream_call_end(S->m, s);
+}
+static int stream_process_impl(dfx_stream_state *S, const float *x, int64_t n, float *y, float *lsnr_out, hipStream_t s) {
     const bool advances = S->lim != 1.f;  // the pass-through case (tract.rs:540-543) moves the STFT memory and the rolling spectra only
     const int64_t hop = S->st->hop, B = S->B;
     if (S->gated && S->gate_buf) {  // one hop per pass: the stage decisions of hop i shape the state hop i+1 starts from
@@ -2935,6 +3018,7 @@ extern "C" int dfx_stream_process_raw(dfx_stream_state *S, const float *spec, fl
     if (!S || !spec || !gains || !coefs || !stages) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_stream_process_raw: null argument");
     if (!S->gated || !S->gate_buf) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_stream_process_raw: switch gating on first (dfx_stream_set_gating)");
     if (int rc = dfx_require_device()) return rc;
+    if (int rc = model_poll(S->m)) return rc;
     hipStream_t s = dfx_stream(stream);
     const dfx_model *m = S->m;
     const dfx_state *st = S->st;
@@ -3030,7 +3114,7 @@ extern "C" int dfx_stream_process_raw(dfx_stream_state *S, const float *spec, fl
     DFX_LAUNCH_CHECK();
     S->frames += 1;
     S->flip ^= 1;
-    return DFX_OK;
+    return stream_call_end(m, s);
 }
 
 // Batch-chunk pipelining: the GRU chain of a chunk is a long latency chain on a handful of CUs, so dfx_enhance splits the

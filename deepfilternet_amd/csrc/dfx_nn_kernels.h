@@ -729,7 +729,7 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, DFX_C01_MINB) dfx_k_df_conv01_
             }
         }
     }
-    if (amax >= DFX_H3_LIMIT && A.err) atomicOr(A.err + 1, 1u);
+    if (amax >= DFX_H3_LIMIT && A.err) dfx_raise(A.err + 1);
 }
 
 // df_dec.df_convp with df_conv0 recomputed, fp16-split form of dfx_k_df_convp2<C, KT, true> (same run decomposition: a wave walks a
@@ -837,7 +837,7 @@ __global__ void __launch_bounds__(256, 1) dfx_k_df_convp_h3(DfxCphArgs A) {
             });
         }
     }
-    if (amax >= DFX_H3_LIMIT && A.err) atomicOr(A.err + 1, 1u);
+    if (amax >= DFX_H3_LIMIT && A.err) dfx_raise(A.err + 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1120,7 +1120,7 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 2) dfx_k_pwconv_f(DfxPwArgs A)
             }
         }
     }
-    if (H3 && amax >= DFX_H3_LIMIT && A.err) atomicOr(A.err + 1, 1u);   // a value left the f16 range of the split: reported, not hidden
+    if (H3 && amax >= DFX_H3_LIMIT && A.err) dfx_raise(A.err + 1);   // a value left the f16 range of the split: reported, not hidden
 }
 
 // ERB encoder head, fused: erb_conv0 (3x3 from one channel, VALU, same arithmetic as dfx_k_conv_in_erb) -> erb_conv1 (stride 2)
@@ -1216,7 +1216,7 @@ __global__ void __launch_bounds__(256, 2) dfx_k_erb_enc(DfxEncArgs A) {
         else dfx_chain_stage<C, DFX_PW_MODE_DW3>(s0, E, E1, 2, E1, dws, a1, b1, lane, epi);
         DFX_WAVE_SYNC();  // the strips are rewritten by the next frame
     }
-    if (H3 && amax >= DFX_H3_LIMIT && A.err) atomicOr(A.err + 1, 1u);
+    if (H3 && amax >= DFX_H3_LIMIT && A.err) dfx_raise(A.err + 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1540,7 +1540,7 @@ __global__ void __launch_bounds__(256, 2) dfx_k_erb_dec10_f(DfxDec10fArgs AA) {
         }
         DFX_WAVE_SYNC();  // the strips and V are rewritten by the next frame
     }
-    if (H3 && amax >= DFX_H3_LIMIT && AA.err) atomicOr(AA.err + 1, 1u);
+    if (H3 && amax >= DFX_H3_LIMIT && AA.err) dfx_raise(AA.err + 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -2522,8 +2522,9 @@ struct DfxGhSync {
     const int *tb;               // [K + 1] chunk boundaries in frames (short chunks at both ends fill and drain the layer pipeline quickly)
     unsigned int *err;
     unsigned long long *trace;   // dev aid (DFX_SEQ_TRACE=1): [K][3] wall-clock ticks of this workgroup: wait begin, compute begin, chunk end
+    int spin_limit;              // polls before a wait gives up and raises err[2]
 };
-#define DFX_SYNC_SPIN_LIMIT (1 << 22)   /* polls with s_sleep: ~2 s */
+#define DFX_SYNC_SPIN_LIMIT (1 << 22)   /* default bound of every flag wait: polls with s_sleep, ~2 s (dfx_model::spin_limit, DFX_SYNC_SPIN_LIMIT) */
 
 template <bool SEQ>
 static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_t grp, const DfxGhSync &Y) {
@@ -2607,8 +2608,8 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
             const unsigned int want = Y.base + (unsigned int)ck + 1u;
             int spins = 0;
             while ((int)(__hip_atomic_load(Y.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
-                if (++spins > DFX_SYNC_SPIN_LIMIT) {
-                    atomicOr(Y.err + 2, 1u);
+                if (++spins > Y.spin_limit) {
+                    dfx_raise(Y.err + 2);
                     break;
                 }
                 __builtin_amdgcn_s_sleep(8);
@@ -2765,7 +2766,7 @@ __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_rec_h
         grp = (int64_t)(blockIdx.x >> 3) * __builtin_popcount(A.xcd_mask) + __builtin_popcount(A.xcd_mask & ((1 << x) - 1));
         if (grp * DFX_GH_ROWS >= A.B) return;
     }
-    dfx_gru_h3_run<false>(A, grp, DfxGhSync{nullptr, nullptr, 0u, 1, nullptr, nullptr, nullptr});
+    dfx_gru_h3_run<false>(A, grp, DfxGhSync{nullptr, nullptr, 0u, 1, nullptr, nullptr, nullptr, 0});
 }
 
 // All GRU layers of a forward pass in ONE persistent launch: workgroup (layer l, group g) keeps its share of W_hh on the CU for the
@@ -2796,6 +2797,7 @@ struct DfxGsArgs {
     // holds the streamed W_hh share of 2-3 layers (1.1 MB) instead of all five (2.2 MB of its 4 MB) beside the background kernels' streams
     unsigned int *xcd_cnt;
     unsigned int xcd_base;
+    int spin_limit;
 };
 __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_seq(DfxGsArgs S) {
     if (S.started && threadIdx.x == 0) __hip_atomic_fetch_add(S.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2838,7 +2840,7 @@ __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_seq(D
     A.unscale = S.unscale[l];
     A.xcd_mask = 0;
     dfx_gru_h3_run<true>(A, g, DfxGhSync{S.ready + l, S.done + (size_t)l * S.done_stride, S.base, S.K, S.tb, S.err,
-                                         S.trace ? S.trace + ((size_t)l * S.groups + g) * S.K * 3 : nullptr});
+                                         S.trace ? S.trace + ((size_t)l * S.groups + g) * S.K * 3 : nullptr, S.spin_limit});
 }
 
 // flag kernels of the persistent GRU phase: dfx_k_flag_set runs behind a producer on its stream (the kernel boundary in front of it
@@ -2846,7 +2848,7 @@ __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_seq(D
 __global__ void dfx_k_flag_set(unsigned int *flag, unsigned int value) {
     if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void dfx_k_wait_ge(const unsigned int *flags, int n, unsigned int target, unsigned int *err) {
+__global__ void dfx_k_wait_ge(const unsigned int *flags, int n, unsigned int target, unsigned int *err, int spin_limit) {
     bool ok = false;
     int spins = 0;
     while (!ok) {
@@ -2855,14 +2857,31 @@ __global__ void dfx_k_wait_ge(const unsigned int *flags, int n, unsigned int tar
             ok = ok && (int)(__hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0;
         ok = __all(ok);   // one wave
         if (!ok) {
-            if (++spins > DFX_SYNC_SPIN_LIMIT) {
-                if (threadIdx.x == 0) atomicOr(err + 2, 1u);
+            if (++spins > spin_limit) {
+                if (threadIdx.x == 0) dfx_raise(err + 2);
                 break;
             }
             __builtin_amdgcn_s_sleep(16);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// Handshake of dfx_model_create (DFX_Q_HWQ_PROBE): one single-wave launch per stream of the persistent phase; each adds itself to a
+// counter and waits, bounded, until all n have arrived — which only happens if the n streams really run at the same time (streams
+// that share a hardware queue run one after the other: the first then waits in vain and raises *fail).
+__global__ void dfx_k_probe_meet(unsigned int *cnt, unsigned int n, int spin_limit, unsigned int *fail) {
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
+            if (++spins > spin_limit) {
+                dfx_raise(fail);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
 }
 
 #ifndef DFX_HIPEMU
@@ -3075,7 +3094,7 @@ __global__ void __launch_bounds__(256, 1) dfx_k_gru_rec_h3x2(DfxG2Args A) {
                 }
                 if (!ok) {
                     if (dead || ++spins > DFX_G2_SPIN_LIMIT) {
-                        if (!dead) atomicExch(A.err, 1u);
+                        if (!dead) dfx_raise(A.err);
                         dead = true;
                         break;
                     }

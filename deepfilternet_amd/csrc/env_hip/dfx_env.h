@@ -55,6 +55,28 @@ static inline hipError_t dfx_env_set_max_dyn_smem(const void *func, size_t bytes
     return hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// ---- model error words.  They live in page-locked host memory that the device can write (fine-grained, uncached on the GPU): a kernel
+// that finds a fault raises a word with ONE plain system-scope store (no read-modify-write: PCIe only carries add / swap / cas as atomics),
+// the host reads the words with ordinary loads wherever it already waits for the device — no copy, no extra launch, nothing on the
+// fault-free path.  (dev == host pointer value on this platform's unified addressing; both are kept.)
+static inline hipError_t dfx_env_err_words_alloc(unsigned int **host, unsigned int **dev, size_t bytes) {
+    void *h = nullptr, *d = nullptr;
+    hipError_t e = hipHostMalloc(&h, bytes, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e != hipSuccess) return e;
+    memset(h, 0, bytes);
+    e = hipHostGetDevicePointer(&d, h, 0);
+    if (e != hipSuccess) {
+        (void)hipHostFree(h);
+        return e;
+    }
+    *host = static_cast<unsigned int *>(h), *dev = static_cast<unsigned int *>(d);
+    return hipSuccess;
+}
+static inline void dfx_env_err_words_free(unsigned int *host) {
+    if (host) (void)hipHostFree(host);
+}
+static __device__ __forceinline__ void dfx_raise(unsigned int *word) { __hip_atomic_store(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 // ---- fp16 split ("fp16x3") MFMA helpers: x = hi + lo with hi = f16(x), lo = f16(x - hi) carries 22 mantissa bits; the three
 // products hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 (fp32 accumulate, f16 x f16 products are exact in fp32)
 // reproduce an fp32 dot product to ~2^-21 relative at 16/3 x the fp32 MFMA rate.

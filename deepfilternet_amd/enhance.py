@@ -116,6 +116,7 @@ def _workspace_cap(model: DfNet) -> Optional[int]:
     if _lib.device().type != "cuda":
         return None
     free, _ = torch.cuda.mem_get_info(_lib.device())
+    # the workspace this model already holds counts as available: DfNet.workspace() releases it before it allocates a larger one
     held = model._ws.numel() if getattr(model, "_ws", None) is not None else 0
     return int(0.9 * (free + held))
 
@@ -171,12 +172,19 @@ def enhance(model: DfNet, df_state: DF, audio: torch.Tensor, pad: bool = True, a
         n = min(sub, B - b0)
         _lib.check(L.dfx_enhance(model.handle, df_state.handle, _lib.ptr(x[b0:b0 + n]), n, T, int(bool(pad)), lim_db, _lib.ptr(y[b0:b0 + n]),
                                  _lib.ptr(ws), ws.numel(), _lib.stream()))
+    # No silent garbage: a kernel that found a fault (fp16-split range, flag-wait timeout) raised an error word of the model.  A host
+    # result is only handed back after the device has finished, so its own pass is checked; a device result is asynchronous, and the
+    # words are looked at without waiting — the C entry points do the same before they start the next pass, so a fault surfaces in the
+    # next call at the latest (DFX_CHECK_EVERY_PASS=1: in dfx_enhance itself).
     if pinned:
         out = torch.empty(y.shape, dtype=y.dtype, pin_memory=True)
         out.copy_(y, non_blocking=True)
         torch.cuda.current_stream().synchronize()
+        model.poll()
         return out
-    return y.to(src_dev)
+    out = y.to(src_dev)
+    model.poll()
+    return out
 
 
 def enhance_files(model: DfNet, df_state: DF, input_files, output_dir: Optional[str] = None, suffix: Optional[str] = None,

@@ -141,8 +141,23 @@ class DfNet:
         _lib.check(_lib.lib().dfx_model_set_pipeline(self._h, int(time_chunks), int(min_chunk_frames), int(batch_chunks)))
 
     def check(self) -> None:
-        """Synchronise and raise if the two-CU GRU kernel ever hit a spin timeout (see dfx_model_check)."""
+        """Wait for the device, then raise if a kernel of this model raised a fault (fp16-split range, a flag-wait / spin timeout): the
+        results of that pass are invalid (dfx_model_check, include/dfx.h)."""
         _lib.check(_lib.lib().dfx_model_check(self._h))
+
+    def poll(self) -> None:
+        """The same without waiting: faults of passes that have completed (dfx_model_poll).  ``enhance()``, ``__call__`` and
+        ``DfStream.process`` call it after enqueueing their work, and the C entry points look before they start new work, so a fault
+        is raised by the next call on the model at the latest (``DFX_CHECK_EVERY_PASS=1``: by the call that caused it)."""
+        _lib.check(_lib.lib().dfx_model_poll(self._h))
+
+    Q_GRU_PERSISTENT, Q_HWQ_PROBE, Q_EXACT_FP32, Q_SPIN_LIMIT = 1, 2, 3, 4
+
+    def query(self, what: int) -> int:
+        """dfx_model_query (include/dfx.h DFX_Q_*)."""
+        v = C.c_int64()
+        _lib.check(_lib.lib().dfx_model_query(self._h, int(what), C.byref(v)))
+        return int(v.value)
 
     # nn.Module-ish no-ops so that callers written against the reference keep working
     def eval(self):
@@ -153,6 +168,7 @@ class DfNet:
 
     def workspace(self, nbytes: int) -> torch.Tensor:
         if self._ws is None or self._ws.numel() < nbytes or not _lib.on_device(self._ws):
+            self._ws = None   # release the smaller buffer first: the two never have to fit side by side
             self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=_lib.device())
         return self._ws
 
@@ -182,6 +198,7 @@ class DfNet:
         # the engine writes the coefficients directly in DfOutputReshapeMF's layout [B,O,T,F',2] (deepfilternet3.py:268-275)
         if not self.run_df:
             coefs = torch.zeros((), device=dev)   # deepfilternet3.py:444
+        self.poll()
         return spec_e, m, lsnr, coefs
 
     forward = __call__

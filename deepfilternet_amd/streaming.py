@@ -105,6 +105,7 @@ class DfStream:
         lsnr = torch.empty((self.streams, n), dtype=torch.float32, device=x.device) if return_lsnr else None
         _lib.check(_lib.lib().dfx_stream_process(self._h, _lib.ptr(x), n, _lib.ptr(y), _lib.ptr(lsnr), _lib.stream()))
         y = y.to(src_dev)
+        self._model.poll()   # faults raised by kernels (invalid results) are never silent: see DfNet.poll
         return (y, lsnr.to(src_dev)) if return_lsnr else y
 
     def process_raw(self, spec: torch.Tensor):
@@ -124,4 +125,6 @@ class DfStream:
         lsnr = torch.empty((self.streams,), dtype=torch.float32, device=x.device)
         _lib.check(_lib.lib().dfx_stream_process_raw(self._h, _lib.ptr(x), _lib.ptr(gains), _lib.ptr(coefs), _lib.ptr(stages), _lib.ptr(lsnr),
                                                      _lib.stream()))
-        return lsnr.to(src_dev), gains.to(src_dev), torch.view_as_complex(coefs).to(src_dev), stages.to(src_dev)
+        out = lsnr.to(src_dev), gains.to(src_dev), torch.view_as_complex(coefs).to(src_dev), stages.to(src_dev)
+        self._model.poll()
+        return out

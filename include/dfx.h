@@ -194,12 +194,34 @@ int dfx_model_set_run_df(dfx_model *m, int enable);
  *                    layer l starting when layer l-1 has produced chunk k (chain = T*(1 + 2/K) steps instead of 3T);
  *   min_chunk_frames shortest chunk worth a launch;
  *   batch_chunks     dfx_enhance additionally pipelines this many batch chunks (multiples of 16 clips) on separate stream sets.
- * The streams need their own hardware queues: export GPU_MAX_HW_QUEUES=16 (ROCm maps streams onto 4 queues by default). */
+ * The streams need their own hardware queues: export GPU_MAX_HW_QUEUES=24 before HIP initialises (ROCm maps streams onto 4 queues by
+ * default; the Python package sets it on import if it is unset).  The persistent, flag-synchronised GRU phase REQUIRES that its ~8
+ * streams make progress independently; dfx_model_create checks that with a handshake between them (DFX_Q_HWQ_PROBE) and selects the
+ * event-synchronised form when they do not.  Co-residency with another process's kernels is not under the engine's control: a
+ * starved flag wait then ends as a reported DFX_ERR_HIP (see dfx_model_check), never as silent garbage or a hang. */
 int dfx_model_set_pipeline(dfx_model *m, int time_chunks, int min_chunk_frames, int batch_chunks);
-/* Synchronises with the device and reports DFX_ERR_HIP if a workgroup pair of the two-CU GRU kernel ever timed out waiting for
- * its partner (bounded spins: the engine never hangs; results of that pass are invalid), and DFX_ERR_UNSUPPORTED if an activation left
- * the range of the fp16-split matrix kernels (|x| >= 6e4 at a split; DFX_EXACT_FP32=1 selects the exact fp32 kernels).  DFX_OK otherwise. */
+/* Faults a kernel can find while it runs — an activation that left the range of the fp16-split matrix kernels (|x| >= 6e4 at a
+ * split: DFX_ERR_UNSUPPORTED; DFX_EXACT_FP32=1 selects the exact fp32 kernels), a flag wait of the persistent GRU phase or a workgroup
+ * pair of the two-CU GRU kernel that timed out (bounded spins, the engine never hangs: DFX_ERR_HIP) — are raised in three error words
+ * of the model that the device writes and the host reads.  The results of the pass that raised one are INVALID, and no call hides
+ * that: every entry point that starts work on the model (dfx_enhance, dfx_model_forward, dfx_stream_process[_raw]) first looks at
+ * the words and returns the error of the PREVIOUS pass instead of starting (the words are cleared by being reported; a big pass
+ * waits for its predecessor anyway, see dfx_enhance).  So a fault is reported by the next call at the latest;
+ *   dfx_model_poll   looks now, without waiting (faults of work that has completed);
+ *   dfx_model_check  waits for the device, then looks: call it before trusting the LAST results of a sequence of calls;
+ *   DFX_CHECK_EVERY_PASS=1 (environment, read at dfx_model_create): every call waits for its own pass and reports its own faults.
+ * The Python surface (enhance(), DfNet.__call__, DfStream.process) and the reference C API (df_process_frame: aborts like the
+ * reference's panics) do this themselves. */
+int dfx_model_poll(const dfx_model *m);
 int dfx_model_check(const dfx_model *m);
+/* Read-only facts about a model handle (what = DFX_Q_*). */
+#define DFX_Q_GRU_PERSISTENT 1 /* 1: big multi-stream passes run the GRU phase as ONE persistent, flag-synchronised launch (default on the GPU) */
+#define DFX_Q_HWQ_PROBE 2      /* 1: the streams of that phase were seen to run concurrently at dfx_model_create; 0: they were not (hardware
+                                * queues shared: GPU_MAX_HW_QUEUES too small or HIP initialised before it was set) and the event-synchronised
+                                * form is used instead; -1: not probed (no streams, exact fp32, CPU interpreter) */
+#define DFX_Q_EXACT_FP32 3     /* 1: DFX_EXACT_FP32=1 was set at creation */
+#define DFX_Q_SPIN_LIMIT 4     /* polls a flag wait makes before it gives up (DFX_SYNC_SPIN_LIMIT, default 2^22 ~ 2 s) */
+int dfx_model_query(const dfx_model *m, int what, int64_t *value);
 
 /* Scratch memory the caller must provide (device bytes) for a [B, T-frames] batch. */
 int dfx_model_workspace_bytes(const dfx_model *m, int64_t B, int64_t T, int64_t *bytes);

@@ -492,6 +492,15 @@ static inline void dfx_split8_g(const float *x, dfx_h8 &hi, dfx_h8 &lo, float &a
     for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(x[i]));
     dfx_split8(x, hi, lo);
 }
+static inline hipError_t dfx_env_err_words_alloc(unsigned int **host, unsigned int **dev, size_t bytes) {
+    void *h = nullptr;
+    if (posix_memalign(&h, 256, bytes ? bytes : 256) != 0) return 2;
+    memset(h, 0, bytes);
+    *host = *dev = static_cast<unsigned int *>(h);
+    return hipSuccess;
+}
+static inline void dfx_env_err_words_free(unsigned int *host) { free(host); }
+static inline void dfx_raise(unsigned int *word) { *word = 1u; }
 static inline unsigned atomicOr(unsigned *p, unsigned v) {
     unsigned o = *p;
     *p = o | v;

@@ -1,0 +1,166 @@
+"""No silent garbage: faults that only a running kernel can find — an activation outside the range of the fp16-split matrix kernels, a
+flag wait of the persistent GRU phase that timed out — are raised in error words of the model, and every way into the engine reports
+them: enhance(), DfNet.__call__, DfStream.process, the C entry points before they start new work (include/dfx.h, dfx_model_poll /
+dfx_model_check), DFX_CHECK_EVERY_PASS=1 synchronously."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from deepfilternet_amd.config import ModelParams
+from deepfilternet_amd.state_dict import random_state_dict
+from tests.helpers import widths_for
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _overflowing_model(seed=5, boost=3e6):
+    """DeepFilterNet3 shape whose df_conv0 output is ~1e6: beyond the f16 range of the split inside the fused DF-encoder kernels."""
+    from deepfilternet_amd.enhance import init_df
+
+    p = ModelParams.deepfilternet3()
+    sd = random_state_dict(p, seed, widths=widths_for(p))
+    k = "enc.df_conv0.1.weight"
+    assert k in sd, [n for n in sd if "df_conv0" in n]
+    sd = dict(sd)
+    sd[k] = np.asarray(sd[k]) * boost
+    return init_df(params=p, state_dict=sd, epoch="none")[:2]
+
+
+def _audio(B, T, seed=0):
+    rng = np.random.default_rng(seed)
+    return torch.from_numpy((0.1 * rng.standard_normal((B, T))).astype(np.float32))
+
+
+def test_range_fault_raises_from_enhance_with_host_audio(backend):
+    """CPU tensor in, CPU tensor out (the reference's calling convention): the result is only handed back after the pass has run, so
+    the call that computed garbage is the call that raises."""
+    from deepfilternet_amd import _lib
+    from deepfilternet_amd.enhance import enhance
+
+    model, df_state = _overflowing_model()
+    x = _audio(2, 480 * 6)
+    with pytest.raises(_lib.DfxError, match="fp16-split"):
+        enhance(model, df_state, x)
+    model.check()   # reported once: the words are cleared by the report
+
+
+def test_range_fault_raises_from_the_next_call_at_the_latest(backend):
+    from deepfilternet_amd import _lib
+    from deepfilternet_amd.enhance import enhance
+
+    model, df_state = _overflowing_model()
+    dev = _lib.device()
+    x = _audio(2, 480 * 6).to(dev)
+    raised = 0
+    try:
+        enhance(model, df_state, x)     # asynchronous on the GPU: may or may not see its own fault (the interpreter is synchronous: it does)
+    except _lib.DfxError as e:
+        assert "fp16-split" in str(e)
+        raised += 1
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    if not raised:
+        with pytest.raises(_lib.DfxError, match="fp16-split"):
+            enhance(model, df_state, x)  # dfx_enhance looks at the words before it starts a new pass
+        raised += 1
+    assert raised == 1
+
+
+def test_range_fault_raises_from_the_stream_runtime(backend):
+    from deepfilternet_amd import _lib
+    from deepfilternet_amd.streaming import DfStream
+
+    model, df_state = _overflowing_model()
+    rt = DfStream(model, df_state, streams=2, max_frames=2)
+    x = _audio(2, 480 * 2)   # host frames: process() waits for the result
+    with pytest.raises(_lib.DfxError, match="fp16-split"):
+        for _ in range(4):
+            rt.process(x)
+    model.check()
+
+
+def test_check_every_pass_reports_in_the_call_itself(backend, monkeypatch):
+    from deepfilternet_amd import _lib
+    from deepfilternet_amd.enhance import enhance
+
+    monkeypatch.setenv("DFX_CHECK_EVERY_PASS", "1")
+    model, df_state = _overflowing_model()
+    x = _audio(2, 480 * 6).to(_lib.device())
+    with pytest.raises(_lib.DfxError, match="fp16-split"):
+        enhance(model, df_state, x)
+    monkeypatch.delenv("DFX_CHECK_EVERY_PASS")
+
+
+def test_a_healthy_model_reports_nothing(backend):
+    from deepfilternet_amd.enhance import enhance, init_df
+
+    p = ModelParams.deepfilternet3()
+    model, df_state, _, _ = init_df(params=p, epoch="none", seed=5)
+    y = enhance(model, df_state, _audio(2, 480 * 6))
+    model.check()
+    assert bool(torch.isfinite(y).all())
+    assert model.query(model.Q_EXACT_FP32) == 0 and model.query(model.Q_SPIN_LIMIT) == 1 << 22
+    with pytest.raises(Exception, match="unknown item"):
+        model.query(99)
+
+
+# ------------------------------------------------------------------------------------------------ persistent GRU phase (GPU only)
+_CHILD = r"""
+import json, os, sys
+sys.path.insert(0, {repo!r})
+import numpy as np, torch
+from deepfilternet_amd import _lib
+from deepfilternet_amd.config import ModelParams
+from deepfilternet_amd.enhance import enhance, init_df
+p = ModelParams.deepfilternet3()
+model, df_state, _, _ = init_df(params=p, epoch="none", seed=9)
+rng = np.random.default_rng(3)
+x = torch.from_numpy((0.1 * rng.standard_normal((32, 48000 * 3))).astype(np.float32))
+out = {{"probe": model.query(model.Q_HWQ_PROBE), "persistent": model.query(model.Q_GRU_PERSISTENT)}}
+try:
+    y = enhance(model, df_state, x)
+    model.check()
+    out["finite"] = bool(torch.isfinite(y).all())
+    np.save({out!r}, y.numpy())
+except _lib.DfxError as e:
+    out["error"] = str(e)
+print(json.dumps(out))
+"""
+
+
+def _child(tmp_path, name, env):
+    import json
+
+    out = str(tmp_path / (name + ".npy"))
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", _CHILD.format(repo=REPO, out=out)], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]), out
+
+
+@pytest.mark.gpu
+def test_flag_wait_timeout_is_reported_not_hidden(hip_backend, tmp_path):
+    """DFX_SYNC_SPIN_LIMIT=1: every flag wait of the persistent phase gives up at once (as it would after ~2 s on a starved GPU); the pass
+    runs to its end on whatever was there — and enhance() raises instead of handing that back."""
+    res, _ = _child(tmp_path, "spin", {"DFX_SYNC_SPIN_LIMIT": "1"})
+    assert res["persistent"] == 1 and res["probe"] == 1, res
+    assert "error" in res and "flag wait" in res["error"], res
+
+
+@pytest.mark.gpu
+def test_shared_hardware_queues_select_the_event_form(hip_backend, tmp_path):
+    """GPU_MAX_HW_QUEUES=2: the ~8 streams of the persistent phase cannot run concurrently; dfx_model_create's handshake sees that and the
+    pass runs event-synchronised — slower, and correct."""
+    good, ygood = _child(tmp_path, "good", {})
+    assert good == {"probe": 1, "persistent": 1, "finite": True}, good
+    few, yfew = _child(tmp_path, "few", {"GPU_MAX_HW_QUEUES": "2"})
+    assert few["probe"] == 0 and few["persistent"] == 0 and few.get("finite") is True, few
+    a, b = np.load(ygood), np.load(yfew)
+    assert float(np.sqrt(np.mean((a - b) ** 2))) < 1e-6
+    forced, _ = _child(tmp_path, "forced", {"DFX_HWQ_PROBE": "fail"})
+    assert forced["probe"] == 0 and forced["persistent"] == 0 and forced.get("finite") is True, forced

@@ -223,3 +223,26 @@ def test_full_size_sub_batches_under_a_workspace_cap(hip_backend, monkeypatch):
     for rows in (slice(0, 16), slice(256, 272), slice(368, 384)):       # first sub-batch, the start and the end of the second
         yr = enhance(model, df_state, x[rows])
         assert torch.equal(y[rows], yr), rows
+
+
+def test_full_size_fp16_split_vs_exact_fp32_every_row(hip_backend, monkeypatch):
+    """The default arithmetic (fp16-split matrix ops: hi*hi + hi*lo + lo*hi, ~2^-21) against the exact fp32 kernels (DFX_EXACT_FP32=1) on
+    ALL 256 clips of the config-2 batch, row by row: < 1e-6 RMS per row (signal RMS ~ 0.1; the north-star bar is 1e-4)."""
+    from deepfilternet_amd.enhance import enhance, init_df
+
+    p, sd, model, df_state = _setup(hip_backend)
+    assert model.query(model.Q_EXACT_FP32) == 0
+    monkeypatch.setenv("DFX_EXACT_FP32", "1")
+    exact, _, _, _ = init_df(params=p, state_dict=sd, epoch="none")
+    monkeypatch.delenv("DFX_EXACT_FP32")
+    assert exact.query(exact.Q_EXACT_FP32) == 1
+    B, T = 256, 10 * SR
+    x = _audio(B, T, 9)
+    y = enhance(model, df_state, x)
+    model.check()
+    ye = enhance(exact, df_state, x)
+    exact.check()
+    row_rms = (y - ye).pow(2).mean(dim=1).sqrt()
+    worst = float(row_rms.max())
+    assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(ye).all())
+    assert worst < 1e-6, (worst, int(row_rms.argmax()))
