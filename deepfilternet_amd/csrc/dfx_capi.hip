@@ -32,8 +32,16 @@ static int read_model_file(const char *path, dfx_model_cfg *cfg, std::vector<flo
     char magic[4];
     uint32_t ver = 0, csz = 0;
     int64_t n = 0, want = -1;
-    bool ok = fread(magic, 1, 4, f) == 4 && memcmp(magic, DFX_FILE_MAGIC, 4) == 0 && fread(&ver, 4, 1, f) == 1 && ver == DFX_FILE_VERSION &&
-              fread(&csz, 4, 1, f) == 1 && csz == sizeof(dfx_model_cfg) && fread(cfg, sizeof(*cfg), 1, f) == 1 && fread(&n, 8, 1, f) == 1;
+    // version 1 = version 2 without the last three configuration fields (emb_gru_skip_enc, emb_gru_skip, enc_concat: all "none" / off then)
+    const size_t v1_cfg = sizeof(dfx_model_cfg) - 3 * sizeof(int32_t);
+    memset(cfg, 0, sizeof(*cfg));
+    bool ok = fread(magic, 1, 4, f) == 4 && memcmp(magic, DFX_FILE_MAGIC, 4) == 0 && fread(&ver, 4, 1, f) == 1 && fread(&csz, 4, 1, f) == 1;
+    if (ok && ver != 1 && ver != DFX_FILE_VERSION) {
+        fclose(f);
+        DFX_FAIL(DFX_ERR_INVALID_ARG, "'%s' is a .dfx model file of version %u; this library reads versions 1 and %u: re-export it with export_dfx", path, ver,
+                 DFX_FILE_VERSION);
+    }
+    ok = ok && csz == (ver == 1 ? v1_cfg : sizeof(dfx_model_cfg)) && fread(cfg, csz, 1, f) == 1 && fread(&n, 8, 1, f) == 1;
     if (ok) ok = dfx_model_blob_floats(cfg, &want) == DFX_OK && want == n;
     if (ok) {
         blob->resize((size_t)n);

@@ -99,7 +99,7 @@ std::vector<TarEntry> untar(const Bytes &t) {
         }
         const char type = (char)h[156];
         const unsigned char *data = h + 512;
-        if (off + 512 + size > t.size()) fail("Could not open model tar entry: truncated archive");
+        if (size > t.size() - off - 512) fail("Could not open model tar entry: truncated archive");   // (no sum: a base-256 size near 2^64 must not wrap)
         if (type == 'L') {  // GNU long name for the next entry
             longname.assign(reinterpret_cast<const char *>(data), strnlen(reinterpret_cast<const char *>(data), size));
         } else if (type == 'x' || type == 'g') {  // pax header: "len path=value\n" records
@@ -255,9 +255,13 @@ struct Tensor {
     std::vector<int64_t> dims;
     int dtype = 0;  // TensorProto.DataType: 1 = FLOAT, 7 = INT64
     std::vector<float> f;
-    int64_t numel() const {
+    int64_t numel() const {   // -1: a negative dimension or more than 2^31 elements (no tensor of these models comes near; a malformed file might)
         int64_t n = 1;
-        for (int64_t d : dims) n *= d;
+        for (int64_t d : dims) {
+            if (d < 0 || d > ((int64_t)1 << 31)) return -1;
+            n *= d;
+            if (n > ((int64_t)1 << 31)) return -1;
+        }
         return n;
     }
 };
@@ -296,6 +300,7 @@ Tensor parse_tensor(Rd r, std::string *name) {
         default: break;
         }
     }
+    if (t.numel() < 0) fail("onnx: tensor '%s' has a negative or absurd dimension", name ? name->c_str() : "?");
     if (t.dtype == 1) {
         const int64_t n = t.numel();
         if (raw.p && (int64_t)(raw.e - raw.p) == 4 * n) {
@@ -550,6 +555,7 @@ int take_grus(Cursor &c, Builder &b, const std::string &p, int *hidden) {
         const Node *n = c.take("GRU", p.c_str());
         const Tensor &W = c.weight(n, 1, p.c_str()), &R = c.weight(n, 2, p.c_str());
         const int64_t H = n->attr_i("hidden_size", 0);
+        if (H <= 0 || H > 65536 || W.dims.size() != 3 || W.dims[2] <= 0) fail("%s: %s layer %d: GRU with hidden_size %lld / W %s", c.g.file.c_str(), p.c_str(), layers, (long long)H, dims_str(W).c_str());
         if (W.dims.size() != 3 || W.dims[0] != 1 || W.dims[1] != 3 * H || !dims_are(R, {1, 3 * H, H}))
             fail("%s: %s layer %d: W %s / R %s do not fit a unidirectional GRU of hidden size %lld", c.g.file.c_str(), p.c_str(), layers, dims_str(W).c_str(), dims_str(R).c_str(), (long long)H);
         if (n->attr_i("linear_before_reset", 0) != 1) fail("%s: %s: GRU without linear_before_reset (not PyTorch's GRU)", c.g.file.c_str(), p.c_str());

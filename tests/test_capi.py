@@ -170,3 +170,38 @@ def test_process_frame_raw(backend, tmp_path):
         assert abs(lsnr - rl) < 1e-3 and bool(gp_) == (rg is not None) and bool(cp_) == (rc is not None)
         assert np.abs(g - rg).max() < 1e-5 and np.abs(c.view(np.complex64)[..., 0] - rc).max() < 1e-5
     lib.df_free(st)
+
+
+def test_dfx_file_versions(backend, tmp_path):
+    """A version-1 .dfx file (before dfx_model_cfg grew emb_gru_skip_enc / emb_gru_skip / enc_concat) is a version-2 file with those three
+    fields absent = 0 and still loads; an unknown version is refused with a message that says what to do."""
+    import ctypes as C
+    import struct
+
+    from deepfilternet_amd import _lib, export_dfx
+    from deepfilternet_amd.config import ModelParams
+    from deepfilternet_amd.state_dict import random_state_dict
+
+    p = ModelParams.defaults()
+    sd = random_state_dict(p, 4)
+    v2 = export_dfx(str(tmp_path / "v2.dfx"), params=p, state_dict=sd)
+    raw = open(v2, "rb").read()
+    magic, ver, csz = raw[:4], *struct.unpack("<II", raw[4:12])
+    assert magic == b"DFXM" and ver == 2 and csz == C.sizeof(_lib.ModelCfg)
+    cfg, rest = raw[12:12 + csz], raw[12 + csz:]
+    assert cfg[-12:] == b"\0" * 12           # the defaults: no embedding-GRU skips, no concat
+    v1 = str(tmp_path / "v1.dfx")
+    open(v1, "wb").write(magic + struct.pack("<II", 1, csz - 12) + cfg[:-12] + rest)
+    L = _lib.lib()
+    for path in (v2, v1):
+        h = C.c_void_p()
+        _lib.check(L.dfx_model_load_file(os.fsencode(path), C.byref(h)))
+        got = _lib.ModelCfg()
+        _lib.check(L.dfx_model_cfg_get(h, C.byref(got)))
+        assert bytes(got) == cfg, path
+        L.dfx_model_free(h)
+    v9 = str(tmp_path / "v9.dfx")
+    open(v9, "wb").write(magic + struct.pack("<II", 9, csz) + cfg + rest)
+    h = C.c_void_p()
+    assert L.dfx_model_load_file(os.fsencode(v9), C.byref(h)) != 0
+    assert b"version 9" in L.dfx_last_error() and b"re-export" in L.dfx_last_error()
