@@ -66,7 +66,7 @@ static inline int64_t dfx_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / 
 enum DfxKernelId {
     DFX_K_ANALYSIS = 0, DFX_K_ANALYSIS_MEM, DFX_K_NORM_SCAN, DFX_K_SYNTHESIS, DFX_K_ERB, DFX_K_ERB_INV, DFX_K_DF_APPLY,
     DFX_K_CONV_IN_ERB, DFX_K_PWCONV, DFX_K_CONV_OUT, DFX_K_DF_CONVP, DFX_K_GGEMM, DFX_K_GRU_REC, DFX_K_LSNR, DFX_K_ADD,
-    DFX_K_COPY_ROWS, DFX_K_CONV_IN_DF, DFX_K_PROJ, DFX_K_ERB_ENC, DFX_K_ERB_DEC, DFX_K_RESAMPLE, DFX_K_PCM, DFX_K_MF, DFX_K_COUNT
+    DFX_K_COPY_ROWS, DFX_K_CONV_IN_DF, DFX_K_PROJ, DFX_K_ERB_ENC, DFX_K_ERB_DEC, DFX_K_RESAMPLE, DFX_K_PCM, DFX_K_MF, DFX_K_EMB_FAN, DFX_K_ERB_TAIL, DFX_K_COUNT
 };
 bool dfx_prof_on(int kernel_id);
 void dfx_prof_begin(int kernel_id, hipStream_t s);

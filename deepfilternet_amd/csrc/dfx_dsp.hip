@@ -83,7 +83,7 @@ const char *const g_kernel_names[DFX_K_COUNT] = {
     "dfx_k_analysis", "dfx_k_analysis_mem_out", "dfx_k_norm_scan", "dfx_k_synthesis", "dfx_k_erb", "dfx_k_erb_inv",
     "dfx_k_df_apply", "dfx_k_conv_in_erb", "dfx_k_pwconv", "dfx_k_conv_out", "dfx_k_df_convp", "dfx_k_ggemm",
     "dfx_k_gru_rec", "dfx_k_lsnr", "dfx_k_add", "dfx_k_copy_rows", "dfx_k_conv_in_df", "dfx_k_proj256", "dfx_k_erb_enc",
-    "dfx_k_erb_dec", "dfx_k_resample", "dfx_k_pcm", "dfx_k_mf_filter"};
+    "dfx_k_erb_dec", "dfx_k_resample", "dfx_k_pcm", "dfx_k_mf_filter", "dfx_k_emb_fan", "dfx_k_erb_tail"};
 }  // namespace
 
 bool dfx_prof_on(int id) { return g_prof.mask != 0 && id >= 0 && id < DFX_K_COUNT && ((g_prof.mask >> id) & 1u); }

@@ -305,6 +305,12 @@ struct dfx_model {
     std::vector<GruW> enc_gru, dec_gru, df_gru;
     size_t lsnr_w = 0;
     float lsnr_b = 0.f;
+    // dfx_k_emb_fan (one pass over the encoder GRU's output for emb and its consumers): fragments [chunks][8][64] float4, 0 chunks = the
+    // grouped linears of this model do not nest the way the kernel needs (then the separate grouped GEMMs run); DFX_FUSE_EMB=0: off
+    size_t fan_w = 0;
+    int fan_chunks = 0;            // super-chunks of 32 hidden columns (0: not available)
+    int fan_kind[3] = {0, 0, 0};   // per consumer (dec_in, dfg_in, df_skip): 0 absent, 1 narrow (32 -> 16 groups), 2 wide (64 -> 32 groups)
+    bool fuse_emb = true;
     size_t cp_w1 = 0, cp_w2 = 0, cp_b = 0;   // df_convp, tiled form (kt > 5)
     size_t cp_weff = 0, cp_b16 = 0;          // df_convp, folded sliding-window form (kt <= 5)
     size_t cin_weff = 0, cin_b = 0;          // enc.df_conv0 folded into a dense 3x3 conv 2 -> C
@@ -495,6 +501,53 @@ bool prep_glin(Prep &P, const std::string &name, GlinW &g) {
     g.w = P.alloc((size_t)t->numel());
     memcpy(&P.out[g.w], w, sizeof(float) * (size_t)t->numel());
     return true;
+}
+// Fragments of dfx_k_emb_fan.  Needs the nesting of DeepFilterNet3's released shape: linear_out of the encoder GRU in groups of
+// 16 -> 32 (lin_groups = 16 over 256 -> 512), erb_dec's linear_in and df_skip in groups of 32 -> 16 ("narrow": lin_groups = 16 over
+// 512 -> 256), df_gru's linear_in in groups of 64 -> 32 ("wide": SqueezedGRU_S's default of 8 groups, deepfilternet3.py:296-302), so that
+// y[:, 32J:32J+32] -> emb[:, 64J:64J+64] -> out[:, 32J:32J+32] is closed for every super-chunk J.  Other shapes: fan_nj stays 0.
+//   fragment (J, i), lane l = (m = l & 15, kq = l >> 4), component s:
+//     i = 2 ch + t            stage 1, chunk ch of the super-chunk, output features 16 t + m of it: W_out[2J + ch][4 kq + s][16 t + m]
+//     i = 4 + 8 c + 2 u + t   narrow consumer c, output column 16 u + m: W_c[2J + u][16 t + 4 kq + s][m]
+//     i = 4 + 8 c + 4 u + tt  wide consumer c, output column 16 u + m:   W_c[J][16 tt + 4 kq + s][16 u + m]
+void pack_fan(Prep &P, dfx_model *m) {
+    const GlinW &o = m->enc_out;
+    const GlinW *cons[DFX_FAN_NC] = {&m->dec_in, &m->dfg_in, m->cfg.df_gru_skip == DFX_SKIP_GROUPEDLINEAR ? &m->df_skip : nullptr};
+    if (o.Kg != 16 || o.Ng != 32 || o.G % 2 != 0) return;
+    const int nj = o.G / 2;
+    for (int c = 0; c < DFX_FAN_NC; ++c) {
+        const GlinW *g = cons[c];
+        m->fan_kind[c] = 0;
+        if (!g) continue;
+        if (g->G == 2 * nj && g->Kg == 32 && g->Ng == 16) m->fan_kind[c] = 1;
+        else if (g->G == nj && g->Kg == 64 && g->Ng == 32) m->fan_kind[c] = 2;
+        else return;
+    }
+    // the instantiated combinations (launch_emb_fan)
+    if (m->fan_kind[0] != 1 || m->fan_kind[1] != 2 || (m->fan_kind[2] != 1 && m->fan_kind[2] != 0)) return;
+    const size_t off = P.alloc((size_t)nj * DFX_FAN_WPJ * 64 * 4);   // (may reallocate P.out: offsets only below)
+    auto frag = [&](int J, int i, int l, int sidx) -> float & { return P.out[off + (((size_t)J * DFX_FAN_WPJ + i) * 64 + l) * 4 + sidx]; };
+    for (int J = 0; J < nj; ++J)
+        for (int l = 0; l < 64; ++l) {
+            const int mm = l & 15, kq = l >> 4;
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                for (int ch = 0; ch < 2; ++ch)
+                    for (int t = 0; t < 2; ++t) frag(J, 2 * ch + t, l, sidx) = P.out[o.w + ((size_t)(2 * J + ch) * 16 + 4 * kq + sidx) * 32 + 16 * t + mm];
+                for (int c = 0; c < DFX_FAN_NC; ++c) {
+                    if (m->fan_kind[c] == 1) {
+                        for (int u = 0; u < 2; ++u)
+                            for (int t = 0; t < 2; ++t)
+                                frag(J, 4 + 8 * c + 2 * u + t, l, sidx) = P.out[cons[c]->w + ((size_t)(2 * J + u) * 32 + 16 * t + 4 * kq + sidx) * 16 + mm];
+                    } else if (m->fan_kind[c] == 2) {
+                        for (int u = 0; u < 2; ++u)
+                            for (int tt = 0; tt < 4; ++tt)
+                                frag(J, 4 + 8 * c + 4 * u + tt, l, sidx) = P.out[cons[c]->w + ((size_t)J * 64 + 16 * tt + 4 * kq + sidx) * 32 + 16 * u + mm];
+                    }
+                }
+            }
+        }
+    m->fan_w = off;
+    m->fan_chunks = nj;
 }
 bool prep_gru(Prep &P, const std::string &name, int layers, std::vector<GruW> &out) {
     const int H = 256;
@@ -770,6 +823,7 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
     ok = ok && prep_glin(P, "df_dec.df_gru.linear_in.0.weight", m->dfg_in) && prep_gru(P, "df_dec.df_gru.gru", c.df_num_layers, m->df_gru);
     if (ok && c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) ok = prep_glin(P, "df_dec.df_skip.weight", m->df_skip);
     ok = ok && prep_glin(P, "df_dec.df_out.0.weight", m->df_out);
+    if (ok) pack_fan(P, m);
     if (!ok) {
         delete m;
         DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_create: %s", P.err.empty() ? "weight preparation failed" : P.err.c_str());
@@ -806,6 +860,8 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         m->gru_x2 = g2 && g2[0] == '1' && !dfx_env_is_emulator();
         const char *gq = getenv("DFX_GRU_SEQ");
         m->gru_seq = !(gq && gq[0] == '0') && !dfx_env_is_emulator();
+        const char *fem = getenv("DFX_FUSE_EMB");
+        m->fuse_emb = !(fem && fem[0] == '0');
         const char *cep = getenv("DFX_CHECK_EVERY_PASS"), *spl = getenv("DFX_SYNC_SPIN_LIMIT");
         m->check_every_pass = cep && cep[0] == '1';
         if (spl && atoi(spl) > 0) m->spin_limit = atoi(spl);
@@ -1480,6 +1536,35 @@ static int launch_glin(const dfx_model *m, const GlinW &g, const float *a, int a
     return launch_ggemm(a, g.G * g.Kg, m->p(g.w), g.G, g.Kg, g.Ng, nullptr, act, res, out, g.G * g.Ng, M, s, 0, 0, 1, rm, a2);
 }
 
+// emb and everything that reads it, in one pass over the encoder GRU's output (dfx_k_emb_fan); outs[c] null = consumer not wanted
+static int launch_emb_fan(const dfx_model *m, const float *y, const float *res, float *emb_out, float *dec_x, float *dfg_x, float *skp,
+                          float *lsnr, int64_t M, hipStream_t s, DfxRowMap rm) {
+    const dfx_model_cfg &c = m->cfg;
+    DfxFanArgs A;
+    A.y = y;
+    A.wfrag = reinterpret_cast<const float4 *>(m->p(m->fan_w));
+    A.res = res;
+    A.emb_out = emb_out;
+    A.out[0] = dec_x, A.out[1] = dfg_x, A.out[2] = skp;
+    A.act[0] = DFX_ACT_RELU, A.act[1] = DFX_ACT_RELU, A.act[2] = DFX_ACT_NONE;
+    A.lsnr_w = lsnr ? m->p(m->lsnr_w) : nullptr;
+    A.lsnr_b = m->lsnr_b, A.lsnr_scale = (float)(c.lsnr_max - c.lsnr_min), A.lsnr_off = (float)c.lsnr_min;
+    A.lsnr = lsnr;
+    A.R = M;
+    A.nj = m->fan_chunks;
+    A.rm = rm;
+    constexpr int RT = 2;
+    const int64_t tiles = dfx_ceil_div(M, 16 * RT);
+    const dim3 grid((unsigned)nn_grid(dfx_ceil_div(tiles, 4), 8));
+    DfxKScope ks(DFX_K_EMB_FAN, s);
+    // (the kinds are what pack_fan accepted: dec_in narrow, dfg_in wide, df_skip narrow; a consumer that is not wanted drops out)
+    if (dfg_x && skp) dfx_launch((dfx_k_emb_fan<RT, 1, 2, 1>), grid, dim3(256), 0, s, A);
+    else if (dfg_x) dfx_launch((dfx_k_emb_fan<RT, 1, 2, 0>), grid, dim3(256), 0, s, A);
+    else dfx_launch((dfx_k_emb_fan<RT, 1, 0, 0>), grid, dim3(256), 0, s, A);
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
+}
+
 #ifndef DFX_HIPEMU
 static int launch_gru_h3x2(const dfx_model *m, const GruW &g, const float *gi, float *y, const float *h_in, float *h_out,
                            int64_t B, int64_t T, int64_t t0, int64_t t1, unsigned long long *xbuf, hipStream_t s) {
@@ -1632,6 +1717,26 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             res = skp_d;
         }
         return launch_glin(m, m->dec_out, y, DFX_ACT_RELU, res, demb, M, st, rm);
+    };
+    // dfx_k_emb_fan: emb = enc_out_skip(y) and its consumers in one pass.  emb itself is only written when something outside the kernel
+    // still reads it (the ERB decoder's skip connection, an identity skip around the DF GRU).  df_skip(emb) lands in xdf WITHOUT the
+    // DF GRU's output (which does not exist yet): df_out then takes its operand as the sum y_df + xdf (DfxGgArgs::a2).
+    const bool fan = m->fuse_emb && m->fan_chunks > 0 && !c.enc_concat && emb == 64 * m->fan_chunks && !m->exact_fp32;
+    const bool fan_skp = fan && run_df && c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR && m->fan_kind[2] == 1;
+    auto emb_fan = [&](const float *y, float *dec_x, int64_t M, hipStream_t st, DfxRowMap rm) -> int {
+        const float *res = nullptr;
+        if (c.emb_gru_skip_enc == DFX_SKIP_IDENTITY) res = emb_in;
+        else if (c.emb_gru_skip_enc == DFX_SKIP_GROUPEDLINEAR) {
+            if (int r = launch_glin(m, m->enc_skip, emb_in, DFX_ACT_NONE, nullptr, skp_e, M, st, rm)) return r;
+            res = skp_e;
+        }
+        const bool need_emb = c.emb_gru_skip != DFX_SKIP_NONE || (run_df && c.df_gru_skip == DFX_SKIP_IDENTITY);
+        return launch_emb_fan(m, y, res, need_emb ? embv : nullptr, dec_x, run_df ? xa2 : nullptr, fan_skp ? xdf : nullptr, lsnr, M, st, rm);
+    };
+    // c = tanh(df_out(c)).view(b,t,F',2O) + c0p   (:329-330) of M rows; cfeat (+ cfeat2) is df_out's operand
+    auto df_out_rows = [&](const float *cfeat, const float *cfeat2, int64_t M, hipStream_t st, DfxRowMap rm) -> int {
+        return launch_ggemm(cfeat, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg, m->df_out.Ng, nullptr, DFX_ACT_TANH,
+                            c0p, coefs, m->df_out.G * m->df_out.Ng, M, st, NO, Fd, T, rm, cfeat2);
     };
     // Stream plan (s = caller's stream, x1/x2 = auxiliary; all joins are events, the host never blocks):
     //   s : e0..e3 ----------------(join c1)-- fc_emb, enc GRU, emb, lsnr --+-- ERB decoder: GRU stack, convt3..conv0_out --(join coefs)-- df_apply
@@ -1877,14 +1982,20 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     if (!pipe) {
         const float *y = nullptr;
         if ((rc = run_gru_stack(m, m->enc_gru, xa, xa, xb, gi, B, T, &y, s, hs_enc, t_begin, rmw))) return rc;
-        if ((rc = enc_out_skip(y, Rn, s, rmw))) return rc;
-        if ((rc = signal(EV_EMB, s)) || (rc = wait(EV_EMB, x1))) return rc;
-        {
-            DfxKScope ks(DFX_K_LSNR, s);
-            dfx_launch(dfx_k_lsnr, dim3((unsigned)dfx_ceil_div(R * 64, 256)), dim3(256), 0, s, (const float *)embv, m->p(m->lsnr_w),
-                       m->lsnr_b, (float)(c.lsnr_max - c.lsnr_min), (float)c.lsnr_min, lsnr, R, emb);
+        float *dec_x = y == xa ? xb : xa;   // input of the ERB decoder's GRU stack
+        if (fan) {
+            if ((rc = emb_fan(y, dec_x, Rn, s, rmw))) return rc;
+            if ((rc = signal(EV_EMB, s)) || (rc = wait(EV_EMB, x1))) return rc;
+        } else {
+            if ((rc = enc_out_skip(y, Rn, s, rmw))) return rc;
+            if ((rc = signal(EV_EMB, s)) || (rc = wait(EV_EMB, x1))) return rc;
+            {
+                DfxKScope ks(DFX_K_LSNR, s);
+                dfx_launch(dfx_k_lsnr, dim3((unsigned)dfx_ceil_div(R * 64, 256)), dim3(256), 0, s, (const float *)embv, m->p(m->lsnr_w),
+                           m->lsnr_b, (float)(c.lsnr_max - c.lsnr_min), (float)c.lsnr_min, lsnr, R, emb);
+            }
+            DFX_LAUNCH_CHECK();
         }
-        DFX_LAUNCH_CHECK();
         if (gate) {  // stage decisions of the newest frame (tract.rs:658-672)
             dfx_launch(dfx_k_gate_post, dim3((unsigned)dfx_ceil_div(B, 256)), dim3(256), 0, s, (const float *)lsnr, T, gate->thr[0],
                        gate->thr[1], gate->thr[2], gate->flags, B, gate->channels);
@@ -1893,10 +2004,12 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // ---- DfDecoder on x1 (:323-331)
         if (run_df) {
             const float *y2 = nullptr;
-            if ((rc = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, Rn, x1, rmw))) return rc;
+            if (!fan && (rc = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, Rn, x1, rmw))) return rc;
             if ((rc = run_gru_stack(m, m->df_gru, xa2, xa2, xb2, gi2, B, T, &y2, x1, hs_df, t_begin, rmw))) return rc;
-            const float *cfeat = y2;
-            if (c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) {
+            const float *cfeat = y2, *cfeat2 = nullptr;
+            if (fan_skp) {
+                cfeat2 = xdf;   // df_skip(emb), written by dfx_k_emb_fan
+            } else if (c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) {
                 if ((rc = launch_glin(m, m->df_skip, embv, DFX_ACT_NONE, y2, xdf, Rn, x1, rmw))) return rc;
                 cfeat = xdf;
             } else if (c.df_gru_skip == DFX_SKIP_IDENTITY) {
@@ -1910,14 +2023,12 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             // c = tanh(df_out(c)).view(b,t,F',2O) + c0p   (:329-330); the reference's flat index f*2O + 2n + {re,im} is stored
             // tap-major, [B,O,T,F'][2] (DFX_COEF_BOTF == the reference's DfOutputReshapeMF layout), so the deep-filter kernel
             // reads coefficients coalesced over f
-            if ((rc = launch_ggemm(cfeat, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg, m->df_out.Ng,
-                                   nullptr, DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, Rn, x1, NO, Fd, T, rmw)))
-                return rc;
+            if ((rc = df_out_rows(cfeat, cfeat2, Rn, x1, rmw))) return rc;
             if ((rc = signal(EV_COEFS, x1))) return rc;
         }
         // ---- ErbDecoder on s (:245-254)
-        if ((rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, xa, Rn, s, rmw))) return rc;
-        if ((rc = run_gru_stack(m, m->dec_gru, xa, xa, xb, gi, B, T, &y, s, hs_dec, t_begin, rmw))) return rc;
+        if (!fan && (rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, dec_x, Rn, s, rmw))) return rc;
+        if ((rc = run_gru_stack(m, m->dec_gru, dec_x, xa, xb, gi, B, T, &y, s, hs_dec, t_begin, rmw))) return rc;
         if ((rc = dec_out_skip(y, Rn, s, rmw))) return rc;
         if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, Rn, E / 4, E / 4, 1, s, rmw))) return rc;
         if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, Rn, E / 4, E / 2, 2, s, rmw))) return rc;
@@ -2079,7 +2190,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 int r;
                 if ((r = launch_wait_ge(m, donep(l - 1), groups, tgt(k), st))) return r;
                 const float *xin = ws + w.py[l - 1];
-                if (j == 0) {
+                if (j == 0 && fan) {   // emb, lsnr and the inputs of both decoders' GRU stacks in one pass over the encoder GRU's chunk
+                    if ((r = emb_fan(ws + w.py[0], xb, Mk(k), st, rmk(k))) || (r = launch_flag_set(embf, tgt(k), st))) return r;
+                    if (k == K - 1 && (r = signal(EV_EMB, st))) return r;
+                    xin = xb;
+                } else if (j == 0) {
                     if ((r = enc_out_skip(ws + w.py[0], Mk(k), st, rmk(k))) || (r = launch_flag_set(embf, tgt(k), st))) return r;
                     if (k == K - 1 && (r = signal(EV_EMB, st))) return r;   // the whole embedding exists (lsnr)
                     if ((r = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, xb, Mk(k), st, rmk(k)))) return r;
@@ -2115,7 +2230,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 const float *xin = ws + w.py[l - 1];
                 if (j == 0) {
                     if ((r = launch_wait_ge(m, embf, 1, tgt(k), st))) return r;
-                    if ((r = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, Mk(k), st, rmk(k)))) return r;
+                    if (!fan && (r = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, Mk(k), st, rmk(k)))) return r;
                     xin = xa2;
                 } else if ((r = launch_wait_ge(m, donep(l - 1), groups, tgt(k), st))) return r;
                 if ((r = proj_chunk(m->df_gru[j], l, k, xin, st)) || (r = launch_flag_set(ready + l, tgt(k), st))) return r;
@@ -2143,13 +2258,14 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                     return launch_ggemm(xdf, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg, m->df_out.Ng,
                                         nullptr, DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, R, Dq, NO, Fd, T);
                 }
-                const float *cfeat = ws + w.py[l];
-                if (c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) {
+                const float *cfeat = ws + w.py[l], *cfeat2 = nullptr;
+                if (fan_skp) {
+                    cfeat2 = xdf;
+                } else if (c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) {
                     if ((r = launch_glin(m, m->df_skip, embv, DFX_ACT_NONE, ws + w.py[l], xdf, Mk(k), Dq, rmk(k)))) return r;
                     cfeat = xdf;
                 }
-                return launch_ggemm(cfeat, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg, m->df_out.Ng, nullptr,
-                                    DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, Mk(k), Dq, NO, Fd, T, rmk(k));
+                return df_out_rows(cfeat, cfeat2, Mk(k), Dq, rmk(k));
             };
             if (run_df && !overlap && (rc = wait(EV_C0P, Dq))) return rc;
             for (int k = 0; k < K; ++k) {
@@ -2161,14 +2277,14 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 if (run_df && (rc = df_tail(k))) return rc;
             }
             if ((rc = signal(EV_MASK, Eq))) return rc;
-            // ---- lsnr on the caller's stream once the whole embedding exists (:163-165,184)
+            // ---- lsnr on the caller's stream once the whole embedding exists (:163-165,184); dfx_k_emb_fan has written it per chunk
             if ((rc = wait(EV_EMB, s))) return rc;
-            {
+            if (!fan) {
                 DfxKScope ks(DFX_K_LSNR, s);
                 dfx_launch(dfx_k_lsnr, dim3((unsigned)dfx_ceil_div(R * 64, 256)), dim3(256), 0, s, (const float *)embv, m->p(m->lsnr_w),
                            m->lsnr_b, (float)(c.lsnr_max - c.lsnr_min), (float)c.lsnr_min, lsnr, R, emb);
+                DFX_LAUNCH_CHECK();
             }
-            DFX_LAUNCH_CHECK();
             // the persistent launch and the layer-0 projections end before the decoders' last chunks do; join their streams all the same
             // (on the caller's stream, which has nothing else to do until the finishing kernels are through)
             DFX_HIP(hipEventRecord(ln->gev[0][0], G));
@@ -2214,7 +2330,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             for (int k = 0; k < K; ++k) {
                 if ((rc = ewait(ln->gev[l - 1][k], pst))) return rc;
                 const float *xin = ws + w.py[l - 1];
-                if (j == 0) {
+                if (j == 0 && fan) {
+                    if ((rc = emb_fan(ws + w.py[0], xb, Mk(k), pst, rmk(k)))) return rc;
+                    if ((rc = esig(ln->eev[k], pst))) return rc;
+                    xin = xb;
+                } else if (j == 0) {
                     if ((rc = enc_out_skip(ws + w.py[0], Mk(k), pst, rmk(k)))) return rc;
                     if ((rc = esig(ln->eev[k], pst))) return rc;  // emb chunk k exists (the DF stack waits for it)
                     if ((rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, xb, Mk(k), pst, rmk(k)))) return rc;
@@ -2262,7 +2382,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 const float *xin = ws + w.py[l - 1];
                 if (j == 0) {
                     if ((rc = ewait(ln->eev[k], pst))) return rc;
-                    if ((rc = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, Mk(k), pst, rmk(k)))) return rc;
+                    if (!fan && (rc = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, Mk(k), pst, rmk(k)))) return rc;
                     xin = xa2;
                 } else if ((rc = ewait(ln->gev[l - 1][k], pst))) return rc;
                 if ((rc = proj_chunk(m->df_gru[j], l, k, xin, pst)) || (rc = esig(ln->pev[l][k], pst))) return rc;
@@ -2280,15 +2400,14 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 for (int k = 0; k < K; ++k) {
                     if ((rc = ewait(ln->gev[l][k], st))) return rc;
                     if (dev_skip2 & 2) { if ((rc = esig(ln->cev[k], st))) return rc; continue; }
-                    const float *cfeat = ws + w.py[l];
-                    if (c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) {
+                    const float *cfeat = ws + w.py[l], *cfeat2 = nullptr;
+                    if (fan_skp) {
+                        cfeat2 = xdf;
+                    } else if (c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) {
                         if ((rc = launch_glin(m, m->df_skip, embv, DFX_ACT_NONE, ws + w.py[l], xdf, Mk(k), st, rmk(k)))) return rc;
                         cfeat = xdf;
                     }
-                    if ((rc = launch_ggemm(cfeat, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg,
-                                           m->df_out.Ng, nullptr, DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, Mk(k), st, NO, Fd,
-                                           T, rmk(k))))
-                        return rc;
+                    if ((rc = df_out_rows(cfeat, cfeat2, Mk(k), st, rmk(k)))) return rc;
                     if ((rc = esig(ln->cev[k], st))) return rc;
                 }
             } else {
@@ -2307,14 +2426,14 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             }
             if ((rc = signal(EV_COEFS, st))) return rc;
         }
-        // ---- lsnr on the caller's stream once the whole embedding exists (:163-165,184)
+        // ---- lsnr on the caller's stream once the whole embedding exists (:163-165,184); dfx_k_emb_fan has written it per chunk
         if ((rc = ewait(ln->eev[K - 1], s))) return rc;
-        {
+        if (!fan) {
             DfxKScope ks(DFX_K_LSNR, s);
             dfx_launch(dfx_k_lsnr, dim3((unsigned)dfx_ceil_div(R * 64, 256)), dim3(256), 0, s, (const float *)embv, m->p(m->lsnr_w),
                        m->lsnr_b, (float)(c.lsnr_max - c.lsnr_min), (float)c.lsnr_min, lsnr, R, emb);
+            DFX_LAUNCH_CHECK();
         }
-        DFX_LAUNCH_CHECK();
         // ---- finishing, per time chunk on its own stream as soon as the chunk's mask and coefficients exist: Mask + MF.DF + combine +
         // post filter + atten_lim (:426-454, enhance.py:238-240) and, for enhance(), the ISTFT of the chunk's output frames.  Only the
         // last chunk's share of these HBM-bound kernels is left after the GRU chain.

@@ -2236,6 +2236,146 @@ __global__ void __launch_bounds__(64 * NW, CT == 2 ? 2 : 1) dfx_k_proj256_h3x2(D
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// dfx_k_emb_fan: everything that hangs off the encoder GRU's output, in ONE pass over its rows (deepfilternet3.py:149-158 linear_out of
+// enc.emb_gru [+ skip], :163-165 lsnr_fc, :245-249 erb_dec.emb_gru.linear_in, :323-326 df_dec.df_gru.linear_in and df_skip):
+//     emb   = relu(y . W_out) [+ res]                      y [R,256] -> emb [R,512]      (16 groups of 16 -> 32)
+//     out_c = act_c(emb . W_c)       c = dec_in, df_skip: 16 groups of 32 -> 16 ("narrow"); dfg_in: 8 groups of 64 -> 32 ("wide")
+//     lsnr  = sigmoid(emb . w_l + b) * scale + offset
+// As separate grouped GEMMs these moved emb (2 KB per frame) five times beside the GRU chain (written once, read by four consumers:
+// 16 KB per frame in all); here emb only exists in registers: 1 KB in, <= 3 KB out per frame.
+// The grouped linears are block diagonal and their blocks nest: columns [32J, 32J+32) of y -> features [64J, 64J+64) of emb ->
+// columns [32J, 32J+32) of every consumer.  A wave owns 16 * RT rows and walks the super-chunks J; per super-chunk and row tile the work
+// is a chain of exact fp32 matrix ops (v_mfma_f32_16x16x4_f32) that never leaves the registers, with the roles transposed like
+// dfx_chain_stage: D[feature][row] = W^T (A) x y^T (B) leaves lane (row, q) with features 16t + 4q + r of its row, which IS a valid B
+// operand of the next product once its contraction index is enumerated in that order (the host packs W_c accordingly, pack_fan).
+// No LDS: the kernel can share a CU with anything.  KIND of a consumer: 0 absent, 1 narrow, 2 wide.
+// ---------------------------------------------------------------------------------------------------------------------
+#define DFX_FAN_NC 3       /* consumers: dec_in, dfg_in, df_skip */
+#define DFX_FAN_WPJ 28     /* float4 fragments per lane and super-chunk: 4 (stage 1) + 8 per consumer (a narrow one uses 4) */
+struct DfxFanArgs {
+    const float *y;             // [R, 32 * nj]
+    const float4 *wfrag;        // [nj][DFX_FAN_WPJ][64] (pack_fan)
+    const float *res;           // [R, 64 * nj] or null: added to emb after the ReLU (identity / grouped-linear skip of the encoder GRU)
+    float *emb_out;             // [R, 64 * nj] or null (only written when something else still reads emb)
+    float *out[DFX_FAN_NC];     // [R, 32 * nj] each
+    int act[DFX_FAN_NC];
+    const float *lsnr_w;        // [64 * nj] or null
+    float lsnr_b, lsnr_scale, lsnr_off;
+    float *lsnr;                // [R]
+    int64_t R;
+    int nj;                     // super-chunks: hidden / 32
+    DfxRowMap rm;
+};
+template <int RT, int K0, int K1, int K2>
+__global__ void __launch_bounds__(256, 2) dfx_k_emb_fan(DfxFanArgs A) {
+    const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
+    const int H = 32 * A.nj, EMB = 64 * A.nj;
+    const int64_t ntile = (A.R + 16 * RT - 1) / (16 * RT);
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntile; tile += (int64_t)gridDim.x * 4) {
+        int64_t prow[RT];
+        bool ok[RT];
+        float ls[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int64_t lr = tile * (16 * RT) + 16 * rt + n;
+            ok[rt] = lr < A.R;
+            prow[rt] = ok[rt] ? dfx_row(A.rm, lr) : 0;
+            ls[rt] = 0.f;
+        }
+        // stage-1 fragments and the y columns of the NEXT super-chunk are requested before the current one's matrix ops; the consumers'
+        // fragments of a super-chunk are requested at its top and first used after its stage 1
+        float4 w1n[4], yn[RT][2];
+        auto request = [&](int J) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w1n[i] = A.wfrag[((size_t)J * DFX_FAN_WPJ + i) * 64 + lane];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch)
+                    yn[rt][ch] = ok[rt] ? *reinterpret_cast<const float4 *>(A.y + prow[rt] * H + 32 * J + 16 * ch + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        request(0);
+        for (int J = 0; J < A.nj; ++J) {
+            float4 w1[4], yc[RT][2], wc[DFX_FAN_NC][8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w1[i] = w1n[i];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) yc[rt][0] = yn[rt][0], yc[rt][1] = yn[rt][1];
+            dfx_static_for<0, DFX_FAN_NC>([&](auto CI) {
+                constexpr int c = decltype(CI)::value;
+                constexpr int kind = c == 0 ? K0 : (c == 1 ? K1 : K2);
+#pragma unroll
+                for (int i = 0; i < (kind == 2 ? 8 : (kind == 1 ? 4 : 0)); ++i) wc[c][i] = A.wfrag[((size_t)J * DFX_FAN_WPJ + 4 + 8 * c + i) * 64 + lane];
+            });
+            if (J + 1 < A.nj) request(J + 1);
+            float4 lw[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                lw[tt] = A.lsnr_w ? *reinterpret_cast<const float4 *>(A.lsnr_w + 64 * J + 16 * tt + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                float e[4][4];   // [feature tile tt = 2 ch + t][r]: feature 64 J + 16 tt + 4 q + r of row n
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    const float ys[4] = {yc[rt][ch].x, yc[rt][ch].y, yc[rt][ch].z, yc[rt][ch].w};
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int tt = 2 * ch + t;
+                        const float ws[4] = {w1[tt].x, w1[tt].y, w1[tt].z, w1[tt].w};
+                        f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) d = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[k], ys[k], d, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) e[tt][r] = fmaxf(d[r], 0.f);
+                        const int64_t eoff = prow[rt] * EMB + 64 * J + 16 * tt + 4 * q;
+                        if (A.res && ok[rt]) {
+                            const float4 rv = *reinterpret_cast<const float4 *>(A.res + eoff);
+                            e[tt][0] += rv.x, e[tt][1] += rv.y, e[tt][2] += rv.z, e[tt][3] += rv.w;
+                        }
+                        if (A.emb_out && ok[rt]) *reinterpret_cast<float4 *>(A.emb_out + eoff) = make_float4(e[tt][0], e[tt][1], e[tt][2], e[tt][3]);
+                        ls[rt] += e[tt][0] * lw[tt].x;
+                        ls[rt] += e[tt][1] * lw[tt].y;
+                        ls[rt] += e[tt][2] * lw[tt].z;
+                        ls[rt] += e[tt][3] * lw[tt].w;
+                    }
+                }
+                dfx_static_for<0, DFX_FAN_NC>([&](auto CI) {
+                    constexpr int c = decltype(CI)::value;
+                    constexpr int kind = c == 0 ? K0 : (c == 1 ? K1 : K2);
+                    if constexpr (kind != 0) {
+                        constexpr int NTT = kind == 2 ? 4 : 2;   // feature tiles an output tile contracts over
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {   // output columns 32 J + 16 u + 4 q + r
+                            f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int i = 0; i < NTT; ++i) {
+                                const int tt = kind == 2 ? i : 2 * u + i;
+                                const float4 wv = wc[c][NTT * u + i];
+                                const float ws[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) d = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[r], e[tt][r], d, 0, 0, 0);
+                            }
+                            if (ok[rt])
+                                *reinterpret_cast<float4 *>(A.out[c] + prow[rt] * H + 32 * J + 16 * u + 4 * q) =
+                                    make_float4(dfx_act(d[0], A.act[c]), dfx_act(d[1], A.act[c]), dfx_act(d[2], A.act[c]), dfx_act(d[3], A.act[c]));
+                        }
+                    }
+                });
+            }
+        }
+        if (A.lsnr) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                float v = ls[rt];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (q == 0 && ok[rt]) A.lsnr[prow[rt]] = dfx_sigmoid(v + A.lsnr_b) * A.lsnr_scale + A.lsnr_off;
+            }
+        }
+    }
+}
+
 // enc.lsnr_fc: Linear(emb -> 1) + Sigmoid, scaled to [lsnr_min, lsnr_max] (deepfilternet3.py:163-165,184).  One wave per row.
 __global__ void dfx_k_lsnr(const float *emb, const float *w, float bias, float scale, float offset, float *out, int64_t R,
                            int D) {
