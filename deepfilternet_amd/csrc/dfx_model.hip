@@ -311,6 +311,10 @@ struct dfx_model {
     int fan_chunks = 0;            // super-chunks of 32 hidden columns (0: not available)
     int fan_kind[3] = {0, 0, 0};   // per consumer (dec_in, dfg_in, df_skip): 0 absent, 1 narrow (32 -> 16 groups), 2 wide (64 -> 32 groups)
     bool fuse_emb = true;
+    // DFX_FUSE_TAIL=1: the ERB decoder's convolutions as ONE launch (dfx_k_erb_tail: d3 / d2 stay in LDS, -12 KB per frame beside the chain).
+    // Measured at config 2 (profiles/r03_fusion_ab.log): the kernel alone 2.19 ms against 1.5 ms for the three launches it replaces
+    // (one fat workgroup per CU, a half-empty first tile, fragments re-read from LDS per stage), step 16.37 vs 16.00 ms: not the default.
+    bool fuse_tail = false;
     size_t cp_w1 = 0, cp_w2 = 0, cp_b = 0;   // df_convp, tiled form (kt > 5)
     size_t cp_weff = 0, cp_b16 = 0;          // df_convp, folded sliding-window form (kt <= 5)
     size_t cin_weff = 0, cin_b = 0;          // enc.df_conv0 folded into a dense 3x3 conv 2 -> C
@@ -862,6 +866,8 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         m->gru_seq = !(gq && gq[0] == '0') && !dfx_env_is_emulator();
         const char *fem = getenv("DFX_FUSE_EMB");
         m->fuse_emb = !(fem && fem[0] == '0');
+        const char *ftl = getenv("DFX_FUSE_TAIL");
+        m->fuse_tail = ftl && ftl[0] == '1';
         const char *cep = getenv("DFX_CHECK_EVERY_PASS"), *spl = getenv("DFX_SYNC_SPIN_LIMIT");
         m->check_every_pass = cep && cep[0] == '1';
         if (spl && atoi(spl) > 0) m->spin_limit = atoi(spl);
@@ -1363,6 +1369,47 @@ static int launch_erb_dec10(const dfx_model *m, const float *d2, const float *e1
     return DFX_OK;
 }
 
+// erb_dec.convt3 -> convt2 -> convt1 -> conv0_out in one kernel (dfx_k_erb_tail): d3 / d2 / d1 never reach HBM
+template <int C>
+static bool erb_tail_ok(const dfx_model *m, int E) {
+    if constexpr (C % 32 != 0) return false;
+    return m->fuse_tail && m->fuse_erb && !m->exact_fp32 && m->ct3.wt_h3 && m->ct2.wt_h3 && m->ct1.wt_h3 && dfx_tail_ok(C, E);
+}
+template <int C>
+static int launch_erb_tail(const dfx_model *m, const float *demb, const float *e3, const float *e2, const float *e1, const float *e0,
+                           float *mask, int64_t R, int E, hipStream_t s, DfxRowMap rm) {
+    if constexpr (C % 32 != 0) {
+        DFX_FAIL(DFX_ERR_UNSUPPORTED, "erb tail: conv_ch");
+    } else {
+        DfxTailArgs A;
+        A.demb = demb, A.e3 = e3, A.e2 = e2, A.e1 = e1, A.e0 = e0;
+        const PwW *L3[3] = {&m->ct3, &m->ct2, &m->ct1};
+        for (int l = 0; l < 3; ++l) {
+            A.dw[l] = m->p(L3[l]->dw);
+            A.bias[l] = m->p(L3[l]->bias);
+            A.wh3[l] = reinterpret_cast<const dfx_h8 *>(m->p(L3[l]->wt_h3));
+            A.unscale[l] = L3[l]->unscale;
+            A.ska[l] = m->p(L3[l]->sk_a);
+            A.skb[l] = m->p(L3[l]->sk_b);
+        }
+        A.ska[3] = m->p(m->co_ska);
+        A.skb[3] = m->p(m->co_skb);
+        A.wo = m->p(m->co_w);
+        A.bias_o = m->co_bias;
+        A.out = mask;
+        A.R = R;
+        A.E = E;
+        A.rm = rm;
+        A.err = m->d_err;
+        const size_t smem = DFX_TAIL_SMEM(C, E);
+        DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_erb_tail<C>, smem));
+        DfxKScope ks(DFX_K_ERB_TAIL, s);
+        dfx_launch(dfx_k_erb_tail<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R, DFX_TAIL_WAVES), 1)), dim3(64 * DFX_TAIL_WAVES), smem, s, A);
+        DFX_LAUNCH_CHECK();
+        return DFX_OK;
+    }
+}
+
 template <int C>
 static int launch_erb_enc(const dfx_model *m, const float *feat_erb, float *e0, float *e1, int64_t B, int64_t T, hipStream_t s,
                           int64_t t_begin = 0, int L = -1, int64_t t_end = -1) {
@@ -1760,6 +1807,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     const float *cp_feat = fuse_c0 ? feat_spec : nullptr;
     const bool fuse_h3 = fuse_c0 && !m->exact_fp32 && C % 32 == 0 && m->cp_h3;  // fp16-split matrix ops (default)
     const bool fuse_dec = E % 2 == 0 && m->fuse_erb && 2 * DFX_DEC10_SMEM(C, E) <= (size_t)160 * 1024;
+    const bool fuse_tail = fuse_dec && erb_tail_ok<C>(m, E);
     const bool fuse_enc = E % 2 == 0 && 3 * (E + 2) <= 192 && m->fuse_erb && 2 * DFX_ENC_SMEM(C, E) <= (size_t)160 * 1024;
     if (sc && !fuse_enc) DFX_FAIL(DFX_ERR_UNSUPPORTED, "streaming needs the fused ERB encoder head (DFX_FUSE_ERB unset)");
     const DfxGate *gate = sc ? sc->gate : nullptr;
@@ -2030,9 +2078,12 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         if (!fan && (rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, dec_x, Rn, s, rmw))) return rc;
         if ((rc = run_gru_stack(m, m->dec_gru, dec_x, xa, xb, gi, B, T, &y, s, hs_dec, t_begin, rmw))) return rc;
         if ((rc = dec_out_skip(y, Rn, s, rmw))) return rc;
-        if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, Rn, E / 4, E / 4, 1, s, rmw))) return rc;
-        if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, Rn, E / 4, E / 2, 2, s, rmw))) return rc;
-        if (fuse_dec) {
+        if (fuse_tail) {
+            if ((rc = launch_erb_tail<C>(m, demb, e3, e2, e1, e0, mask, Rn, E, s, rmw))) return rc;
+        } else if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, Rn, E / 4, E / 4, 1, s, rmw)) ||
+                   (rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, Rn, E / 4, E / 2, 2, s, rmw))) {
+            return rc;
+        } else if (fuse_dec) {
             if ((rc = launch_erb_dec10<C>(m, d2, e1, e0, mask, Rn, E, s, rmw))) return rc;
         } else {
             if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, Rn, E / 2, E, 2, s, rmw))) return rc;
@@ -2211,6 +2262,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 if ((r = launch_wait_ge(m, donep(ndec), groups, tgt(k), Eq))) return r;
                 if (dev_skip_seq & 1) return DFX_OK;
                 if ((r = dec_out_skip(ws + w.py[ndec], Rk, Eq, rm))) return r;
+                if (fuse_tail) return launch_erb_tail<C>(m, demb, e3, e2, e1, e0, mask, Rk, E, Eq, rm);
                 if ((r = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, Rk, E / 4, E / 4, 1, Eq, rm))) return r;
                 if ((r = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, Rk, E / 4, E / 2, 2, Eq, rm))) return r;
                 if (fuse_dec) return launch_erb_dec10<C>(m, d2, e1, e0, mask, Rk, E, Eq, rm);
@@ -2358,9 +2410,12 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 if ((rc = ewait(ln->gev[ndec][k], st))) return rc;
                 if (dev_skip & 1) { if ((rc = esig(ln->mev[k], st))) return rc; continue; }
                 if ((rc = dec_out_skip(ws + w.py[ndec], Rk, st, rm))) return rc;
-                if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, Rk, E / 4, E / 4, 1, st, rm))) return rc;
-                if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, Rk, E / 4, E / 2, 2, st, rm))) return rc;
-                if (fuse_dec) {
+                if (fuse_tail) {
+                    if ((rc = launch_erb_tail<C>(m, demb, e3, e2, e1, e0, mask, Rk, E, st, rm))) return rc;
+                } else if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, Rk, E / 4, E / 4, 1, st, rm)) ||
+                           (rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, Rk, E / 4, E / 2, 2, st, rm))) {
+                    return rc;
+                } else if (fuse_dec) {
                     if ((rc = launch_erb_dec10<C>(m, d2, e1, e0, mask, Rk, E, st, rm))) return rc;
                 } else {
                     if ((rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct1, d2, e1, d1, Rk, E / 2, E, 2, st, rm))) return rc;

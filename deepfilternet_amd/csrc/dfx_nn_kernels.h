@@ -1544,6 +1544,218 @@ __global__ void __launch_bounds__(256, 2) dfx_k_erb_dec10_f(DfxDec10fArgs AA) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// dfx_k_erb_tail: the whole convolutional half of the ERB decoder for one frame in one kernel (deepfilternet3.py:250-253):
+//     d3 = convt3(demb + conv3p(e3))   [E/4] -> [E/4]        d2 = convt2(d3 + conv2p(e2))   [E/4] -> [E/2]
+//     d1 = convt1(d2 + conv1p(e1))     [E/2] -> [E]          mask = sigmoid(conv0_out(d1 + conv0p(e0)))
+// As three launches (dfx_k_pwconv_f x 2, dfx_k_erb_dec10_f) d3 and d2 made a round trip through HBM each — 12 KB per frame written
+// and read back BESIDE the GRU chain, where every byte costs the chain time; here they live in LDS strips.
+// A wave owns a frame.  Strips [rows][C + 4], wave-private (wave-level synchronisation only):
+//     X [E]:   rows [0, E/4) = convt3's input, rows [E/4, E/2) = convt2's input (conv2p(e2), d3 added by convt3's epilogue); once
+//              convt2 has run, all of X becomes conv0_out's input (conv0p(e0) stored, d1 added by convt1's epilogue)
+//     Y [E/2]: convt1's input (conv1p(e1), d2 added by convt2's epilogue); once convt1 has run, the per-position partial sums of conv0_out
+// The three pointwise contractions run on the fp16-split path (dfx_chain_stage_h3, same tile body and k order as the separate kernels);
+// their fragments (48 KB for C = 64) sit in LDS and are read into registers stage by stage, so only one layer's are live at a time.
+// All five operand runs of the NEXT frame are requested as soon as the current frame's e0 has been stored (before convt1, the largest
+// stage).  One workgroup of 8 waves per CU (LDS: 156 KB at C = 64, E = 32).
+// ---------------------------------------------------------------------------------------------------------------------
+#define DFX_TAIL_WAVES 8
+#define DFX_TAIL_WAVE_FLOATS(C, E) (((E) + (E) / 2) * ((C) + 4))
+#define DFX_TAIL_TAB4(C) (3 * 3 * (C) / 4 + 4 * 2 * (C) / 4 + 3 * (C) / 4 + 3 * (C) / 4)   /* float4s: dw x3, pathway a/b x4, wo, bias x3 */
+#define DFX_TAIL_WFRAG(C) ((size_t)((C) / 16) * ((C) / 32) * 2 * 64)                     /* dfx_h8 per layer */
+#define DFX_TAIL_SMEM(C, E) ((size_t)DFX_TAIL_TAB4(C) * 16 + 3 * DFX_TAIL_WFRAG(C) * 16 + (size_t)DFX_TAIL_WAVES * DFX_TAIL_WAVE_FLOATS(C, E) * 4)
+static __host__ __device__ __forceinline__ bool dfx_tail_ok(int C, int E) {
+    return C % 32 == 0 && E % 8 == 0 && (E / 4) * (C / 4) <= 64 * 2 && (E / 2) * (C / 4) <= 64 * 4 && E * (C / 4) <= 64 * 8 && 3 * E <= (E / 2) * (C + 4) &&
+           DFX_TAIL_SMEM(C, E) <= (size_t)160 * 1024;
+}
+struct DfxTailArgs {
+    const float *demb, *e3, *e2, *e1, *e0;   // [R, E/4, C] x3, [R, E/2, C], [R, E, C]
+    const float *dw[3], *bias[3];            // ct3, ct2, ct1: depthwise [3][C], BN shift [C]
+    const dfx_h8 *wh3[3];                    // their pointwise fragments (pack_pw_h3)
+    float unscale[3];
+    const float *ska[4], *skb[4];            // pathway scale / shift of conv3p, conv2p, conv1p, conv0p
+    const float *wo;                         // conv0_out [3][C]
+    float bias_o;
+    float *out;                              // mask [R, E]
+    int64_t R;
+    int E;
+    DfxRowMap rm;
+    unsigned int *err;
+};
+template <int C>
+__global__ void __launch_bounds__(64 * DFX_TAIL_WAVES, 1) dfx_k_erb_tail(DfxTailArgs A) {
+    constexpr int NT = C / 16, LD = C + 4, C4 = C / 4, KC = C / 32;
+    DFX_DYN_SMEM(float4, sm4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4;
+    const int E = A.E, E1 = E / 2, E4 = E / 4;
+    float4 *dws = sm4;                  // [3 layers][3][C4]
+    float4 *sks = dws + 9 * C4;         // [4 pathways][a, b][C4]
+    float4 *wos = sks + 8 * C4;         // [3][C4]
+    float4 *bis = wos + 3 * C4;         // [3 layers][C4]
+    dfx_h8 *wfr = reinterpret_cast<dfx_h8 *>(bis + 3 * C4);   // [3 layers][NT * KC * 2 * 64]
+    float *X = reinterpret_cast<float *>(wfr + 3 * DFX_TAIL_WFRAG(C)) + (size_t)wave * DFX_TAIL_WAVE_FLOATS(C, E);
+    float *Y = X + E * LD;
+    float *V = Y;                       // [E][3], after convt1 has consumed Y
+    constexpr int NTH = 64 * DFX_TAIL_WAVES;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {   // (constant indices into the argument arrays: a run-time index would move the struct to scratch)
+        for (int i = tid; i < 3 * C4; i += NTH) dws[l * 3 * C4 + i] = reinterpret_cast<const float4 *>(A.dw[l])[i];
+        for (int i = tid; i < C4; i += NTH) bis[l * C4 + i] = reinterpret_cast<const float4 *>(A.bias[l])[i];
+        for (int i = tid; i < (int)DFX_TAIL_WFRAG(C); i += NTH) wfr[l * DFX_TAIL_WFRAG(C) + i] = A.wh3[l][i];
+    }
+#pragma unroll
+    for (int pth = 0; pth < 4; ++pth)
+        for (int i = tid; i < C4; i += NTH) {
+            sks[pth * 2 * C4 + i] = reinterpret_cast<const float4 *>(A.ska[pth])[i];
+            sks[pth * 2 * C4 + C4 + i] = reinterpret_cast<const float4 *>(A.skb[pth])[i];
+        }
+    for (int i = tid; i < 3 * C4; i += NTH) wos[i] = reinterpret_cast<const float4 *>(A.wo)[i];
+    __syncthreads();
+    const int n3 = E4 * C4, n1 = E1 * C4, n0 = E * C4;   // float4s per frame: demb / e3 / e2, e1, e0
+    const float4 *pd = reinterpret_cast<const float4 *>(A.demb), *p3 = reinterpret_cast<const float4 *>(A.e3), *p2 = reinterpret_cast<const float4 *>(A.e2),
+                 *p1 = reinterpret_cast<const float4 *>(A.e1), *p0 = reinterpret_cast<const float4 *>(A.e0);
+    float4 rd[2], r3[2], r2[2], r1[4], r0[8];
+    // demb / e3 / e2 / e1 of a frame are requested one frame ahead (40 registers); its e0 (32 registers) at the top of the frame itself —
+    // it is only needed after convt3 and convt2 have run — so that the two never overlap with a layer's fragments (64) all at once
+    auto issue = [&](int64_t rl) {
+        const int64_t r = dfx_row(A.rm, rl);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = lane + 64 * i;
+            rd[i] = r3[i] = r2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < n3) rd[i] = pd[r * n3 + idx], r3[i] = p3[r * n3 + idx], r2[i] = p2[r * n3 + idx];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = lane + 64 * i;
+            r1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < n1) r1[i] = p1[r * n1 + idx];
+        }
+    };
+    auto issue_e0 = [&](int64_t r) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = lane + 64 * i;
+            r0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < n0) r0[i] = p0[r * n0 + idx];
+        }
+    };
+    auto path = [](float4 sv, float4 a, float4 b) {
+        return make_float4(fmaxf(a.x * sv.x + b.x, 0.f), fmaxf(a.y * sv.y + b.y, 0.f), fmaxf(a.z * sv.z + b.z, 0.f), fmaxf(a.w * sv.w + b.w, 0.f));
+    };
+    static_assert(64 % C4 == 0, "channel quad of a lane must not depend on the load index");
+    float amax = 0.f;
+    dfx_h8 ahi[NT][KC], alo[NT][KC];
+    float4 biasr[NT];
+    int64_t rl = (int64_t)blockIdx.x * DFX_TAIL_WAVES + wave;
+    if (rl < A.R) issue(rl);
+    for (; rl < A.R; rl += (int64_t)gridDim.x * DFX_TAIL_WAVES) {
+        const int64_t r = dfx_row(A.rm, rl);
+        int lq = lane % C4;
+        DFX_OPAQUE(lq);
+        {   // convt3's input, conv2p(e2), conv1p(e1) into the strips
+            const float4 a3 = sks[lq], b3 = sks[C4 + lq], a2 = sks[2 * C4 + lq], b2 = sks[3 * C4 + lq], a1 = sks[4 * C4 + lq], b1 = sks[5 * C4 + lq];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = lane + 64 * i;
+                if (idx < n3) {
+                    const int row = idx / C4, c4 = idx - row * C4;
+                    const float4 pv = path(r3[i], a3, b3);
+                    *reinterpret_cast<float4 *>(X + row * LD + 4 * c4) = make_float4(rd[i].x + pv.x, rd[i].y + pv.y, rd[i].z + pv.z, rd[i].w + pv.w);
+                    *reinterpret_cast<float4 *>(X + (E4 + row) * LD + 4 * c4) = path(r2[i], a2, b2);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = lane + 64 * i;
+                if (idx < n1) {
+                    const int row = idx / C4, c4 = idx - row * C4;
+                    *reinterpret_cast<float4 *>(Y + row * LD + 4 * c4) = path(r1[i], a1, b1);
+                }
+            }
+        }
+        issue_e0(r);
+        DFX_WAVE_SYNC();
+        // ---- convt3: X[0, E/4) -> += into X[E/4, E/2)
+        dfx_chain_load_w_h3<C>(wfr, reinterpret_cast<const float *>(bis), lane, ahi, alo, biasr);
+        {
+            float *dst0 = X + E4 * LD;
+            auto epi = [&](int p, bool valid, int nt, float4 d) {
+                if (valid) {
+                    float4 *dst = reinterpret_cast<float4 *>(dst0 + p * LD + 16 * nt + 4 * q);
+                    const float4 e = *dst;
+                    *dst = make_float4(d.x + e.x, d.y + e.y, d.z + e.z, d.w + e.w);
+                }
+            };
+            dfx_chain_stage_h3<C, DFX_PW_MODE_DW3>(X, E4, E4, 1, E4, dws, ahi, alo, biasr, A.unscale[0], amax, lane, epi);
+        }
+        DFX_WAVE_SYNC();
+        // ---- convt2: X[E/4, E/2) -> += into Y[0, E/2)
+        dfx_chain_load_w_h3<C>(wfr + DFX_TAIL_WFRAG(C), reinterpret_cast<const float *>(bis + C4), lane, ahi, alo, biasr);
+        {
+            auto epi = [&](int p, bool valid, int nt, float4 d) {
+                if (valid) {
+                    float4 *dst = reinterpret_cast<float4 *>(Y + p * LD + 16 * nt + 4 * q);
+                    const float4 e = *dst;
+                    *dst = make_float4(d.x + e.x, d.y + e.y, d.z + e.z, d.w + e.w);
+                }
+            };
+            dfx_chain_stage_h3<C, DFX_PW_MODE_DWT3>(X + E4 * LD, E4, E1, 2, E1, dws + 3 * C4, ahi, alo, biasr, A.unscale[1], amax, lane, epi);
+        }
+        DFX_WAVE_SYNC();
+        {   // conv0p(e0) over all of X (its former contents are dead), then the next frame's operands are requested
+            const float4 a0 = sks[6 * C4 + lq], b0 = sks[7 * C4 + lq];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = lane + 64 * i;
+                if (idx < n0) {
+                    const int row = idx / C4, c4 = idx - row * C4;
+                    *reinterpret_cast<float4 *>(X + row * LD + 4 * c4) = path(r0[i], a0, b0);
+                }
+            }
+        }
+        const int64_t next = rl + (int64_t)gridDim.x * DFX_TAIL_WAVES;
+        if (next < A.R) issue(next);
+        DFX_WAVE_SYNC();
+        // ---- convt1: Y[0, E/2) -> += into X[0, E)
+        dfx_chain_load_w_h3<C>(wfr + 2 * DFX_TAIL_WFRAG(C), reinterpret_cast<const float *>(bis + 2 * C4), lane, ahi, alo, biasr);
+        {
+            auto epi = [&](int p, bool valid, int nt, float4 d) {
+                if (valid) {
+                    float4 *dst = reinterpret_cast<float4 *>(X + p * LD + 16 * nt + 4 * q);
+                    const float4 e = *dst;
+                    *dst = make_float4(d.x + e.x, d.y + e.y, d.z + e.z, d.w + e.w);
+                }
+            };
+            dfx_chain_stage_h3<C, DFX_PW_MODE_DWT3>(Y, E1, E, 2, E, dws + 6 * C4, ahi, alo, biasr, A.unscale[2], amax, lane, epi);
+        }
+        DFX_WAVE_SYNC();
+        for (int i = lane; i < 3 * E; i += 64) {  // V[p][j] = sum_c wo[j][c] * xin[p][c]
+            const int p = i / 3, j = i - 3 * p;
+            const float4 *xrow = reinterpret_cast<const float4 *>(X + p * LD);
+            float acc = 0.f;
+#pragma unroll 4
+            for (int c = 0; c < C4; ++c) {
+                const float4 x = xrow[c], w = wos[j * C4 + c];
+                acc += w.x * x.x;
+                acc += w.y * x.y;
+                acc += w.z * x.z;
+                acc += w.w * x.w;
+            }
+            V[i] = acc;
+        }
+        DFX_WAVE_SYNC();
+        for (int f = lane; f < E; f += 64) {
+            float acc = A.bias_o + V[f * 3 + 1];
+            if (f > 0) acc += V[(f - 1) * 3 + 0];
+            if (f < E - 1) acc += V[(f + 1) * 3 + 2];
+            A.out[r * E + f] = dfx_sigmoid(acc);
+        }
+        DFX_WAVE_SYNC();  // the strips are rewritten by the next frame
+    }
+    if (amax >= DFX_H3_LIMIT && A.err) dfx_raise(A.err + 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // df_dec.df_convp: Conv2d(C -> 2*O, (kt,1), groups = gcd(C, 2*O)) [+ 1x1 (2O x 2O) when kt > 1] + BN + ReLU
 // (deepfilternet3.py:293-295, modules.py:49-71).  in c0 [R, Fd, C] -> out [R, Fd, 2*O].
 // Per group: out1[pos][o] = sum_k sum_ci c0[t-kt+1+k, f, g*CG+ci] * W1[g][k][ci][o]   (causal: zero for frames < 0 of the clip)

@@ -56,7 +56,7 @@ def test_fused_side_kernels_match_the_separate_ones(backend, switch, variant, fo
     x = torch.from_numpy((0.1 * rng.standard_normal((B, T))).astype(np.float32))
     base = {"serial": ["DFX_STREAMS=0"], "pipelined": ["DFX_GRU_SEQ=0"], "persistent": []}[form]
     pipe = form == "pipelined" or (form == "persistent" and False)
-    y_fused = _run(p, sd, x, base, monkeypatch, pipe, mask_only)
+    y_fused = _run(p, sd, x, base + [switch + "=1"], monkeypatch, pipe, mask_only)
     y_sep = _run(p, sd, x, base + [switch + "=0"], monkeypatch, pipe, mask_only)
     assert rms((y_fused - y_sep).numpy()) < 1e-6, (switch, variant, form)
     if not mask_only:   # (the mask-only oracle comparison lives in tests/test_config_options.py)
