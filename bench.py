@@ -154,7 +154,10 @@ def main() -> None:
     drain()
     torch.cuda.synchronize()
     _lib.prof_reset()
-    _lib.prof_enable(["dfx_k_df_apply"])  # two hipEventRecords per step on the launch stream; everything else untouched
+    # two hipEventRecords per step on the launch stream around the finishing kernel; everything else untouched.  (Since round 3 enhance()
+    # applies the deep filter + gains INSIDE the ISTFT kernel, dfx_k_synthesis_rows; with DFX_FUSE_DFA=0 the separate deep-filter kernel is
+    # timed in the loop as before.)
+    _lib.prof_enable(["dfx_k_df_apply", "dfx_k_synthesis"])
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -170,7 +173,9 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    dfa_ms, dfa_n = _lib.prof_read().get("dfx_k_df_apply", (0.0, 0))
+    loop_prof = _lib.prof_read()
+    dfa_ms, dfa_n = loop_prof.get("dfx_k_df_apply", (0.0, 0))
+    syn_ms, syn_n = loop_prof.get("dfx_k_synthesis", (0.0, 0))
     _lib.prof_enable(None)
     per_rank_ms = [dt / args.steps * 1e3]
     if dist is not None:
@@ -181,6 +186,7 @@ def main() -> None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(y).all()
+    gru_persistent = bool(model.query(model.Q_GRU_PERSISTENT))
     model.check()  # raises if a workgroup pair of the two-CU GRU kernel ever timed out (results would be invalid)
 
     # ---- multi-GPU: the same timed loop without the final gather (so that a scaling run can tell compute from the collective)
@@ -215,7 +221,7 @@ def main() -> None:
         frames = world * B * (T // HOP) * args.steps
         print(json.dumps({"metric": "48 kHz audio frames/sec (hop=480), DeepFilterNet3 enhance()", "value": frames / dt, "unit": "frames/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-                          "dfa_in_loop_ms": (dfa_ms / dfa_n) if dfa_n else None}), flush=True)
+                          "dfa_in_loop_ms": (dfa_ms / dfa_n) if dfa_n else None, "finish_in_loop_ms": (syn_ms / syn_n) if syn_n else None}), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -245,35 +251,57 @@ def main() -> None:
         r.update(extra or {})
         return r
 
+    # ---- roofline of the north-star kernel, dfx_k_df_apply_rows (fused deep filter + ERB gains over the full spectrum: the kernel behind
+    # dfx_df_apply / dfx_model_forward).  enhance() no longer launches it (the same arithmetic runs inside the ISTFT kernel, see
+    # rooflines.dfx_k_synthesis_rows), so it is timed here on this workload's own buffers: stand-alone launches on the launch stream with
+    # the library's hipEvents around each (dfx_prof_*), in this process, right after the timed loop.
+    traffic, traffic_src = None, None
+    tpath = os.path.join(REPO, "profiles", "df_apply_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("batch") == B and tj.get("frames_per_clip") == Tf and tj.get("model") == args.model:
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_src = ("static: profiles/df_apply_traffic.json — rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_pmc_dfa.sh) over this kernel at "
+                               "this size, calibrated on pure-stream dispatches of the same kernel; not measured in this run (PMC needs rocprofv3)")
+        except Exception:  # noqa: BLE001
+            traffic = None
     roofline = None
-    if dfa_n:
-        traffic, traffic_src = None, None
-        tpath = os.path.join(REPO, "profiles", "df_apply_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as f:
-                    tj = json.load(f)
-                if tj.get("batch") == B and tj.get("frames_per_clip") == Tf and tj.get("model") == args.model:
-                    traffic = tj.get("hbm_bytes_per_launch")
-                    traffic_src = ("static: profiles/df_apply_traffic.json — rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_pmc_dfa.sh) over this kernel at "
-                                   "this size, calibrated on pure-stream dispatches of the same kernel; not measured in this run (PMC needs rocprofv3)")
-            except Exception:  # noqa: BLE001
-                traffic = None
-        roofline = hbm_record("dfx_k_df_apply", dfa_ms / dfa_n, alg_bytes,
-                              {"traffic": traffic, "traffic_source": traffic_src, "launches": dfa_n,
-                               "where": "inside the timed loop (hipEvents on the launch stream, one launch per step)"})
-        if "dfx_k_df_apply" in serial and serial["dfx_k_df_apply"][1]:
-            sm = serial["dfx_k_df_apply"][0] / serial["dfx_k_df_apply"][1]
-            roofline["standalone"] = {"avg_launch_ms": round(sm, 4), "achieved": round(alg_bytes / (sm * 1e-3) / 1e9, 1),
-                                      "frac": round(alg_bytes / (sm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                      "where": "the extra serialised step (one stream, no other queue of the process holds work)"}
+    try:
+        sa_ms, sa_n = bench_df_apply_rows(dev, df_state, B, Tf, F, p.nb_df, O, p.df_lookahead, E)
+        roofline = hbm_record("dfx_k_df_apply", sa_ms / sa_n, alg_bytes,
+                              {"traffic": traffic, "traffic_source": traffic_src, "launches": sa_n,
+                               "where": "stand-alone launches of dfx_df_apply_strided at this workload's size (engine layout: 488-bin rows, tap-major coefficients), "
+                                        "library hipEvents on the launch stream, inside bench.py after the timed loop"})
+    except Exception as e:  # noqa: BLE001
+        roofline = {"error": repr(e)}
+    cfg_o10 = None
+    if world == 1:   # BASELINE.json configs[4], same kind of stand-alone launches (before the extras below create more streams / pinned buffers)
+        try:
+            cfg_o10 = bench_df_apply_o10(dev, df_state, B, Tf)
+        except Exception as e:  # noqa: BLE001
+            cfg_o10 = {"error": repr(e)}
+    if dfa_n and isinstance(roofline, dict) and "error" not in roofline:   # DFX_FUSE_DFA=0: the kernel also runs inside the loop
+        roofline["in_loop"] = {"avg_launch_ms": round(dfa_ms / dfa_n, 4), "frac": round(alg_bytes / (dfa_ms / dfa_n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
     # ---- the other kernels SURVEY.md §8(d) prices
     rooflines = {}
     nfr = B * Tf
-    for name, bpf in (("dfx_k_analysis", 480 * 4 + F * 8 + E * 4), ("dfx_k_synthesis", F * 8 + 480 * 4)):
-        if name in serial and serial[name][1]:
-            rooflines[name] = hbm_record(name, serial[name][0] / serial[name][1], bpf * nfr, {"where": "serialised step"})
+    fused_finish = not dfa_n   # enhance() finished with dfx_k_synthesis_rows (deep filter + gains + ISTFT in one kernel)
+    fin_bpf = (F * 8 + p.nb_df * O * 8 + E * 4 + 480 * 4) if fused_finish else (F * 8 + 480 * 4)
+    fin_name = "dfx_k_synthesis_rows" if fused_finish else "dfx_k_synthesis"
+    for name, key, bpf in (("dfx_k_analysis", "dfx_k_analysis", 480 * 4 + F * 8 + E * 4), (fin_name, "dfx_k_synthesis", fin_bpf)):
+        if key in serial and serial[key][1]:
+            rooflines[name] = hbm_record(name, serial[key][0] / serial[key][1], bpf * nfr, {"where": "serialised step"})
+    if syn_n and fin_name in rooflines:
+        rooflines[fin_name]["in_loop"] = {"avg_launch_ms": round(syn_ms / syn_n, 4), "launches": syn_n,
+                                          "frac": round(fin_bpf * nfr / (syn_ms / syn_n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                          "where": "inside the timed loop (hipEvents on the launch stream, one launch per step)"}
+    if fused_finish and fin_name in rooflines:
+        rooflines[fin_name]["algorithmic_bytes_per_frame"] = fin_bpf
+        rooflines[fin_name]["note"] = ("read X 3848 + coefficients 3840 + gains 128, write 1920 bytes of audio per frame; the enhanced spectrum "
+                                       "(7696 B per frame written + read back by the two-kernel form) never exists in HBM")
     nlayers = 1 + (p.emb_num_layers - 1) + p.df_num_layers
     flop_step = 2.0 * B * 256 * 768          # h[B,256] x W_hh^T[256,768] per time step and layer (fp32-equivalent flops)
     gru = {"kernel": "dfx_k_gru_rec_h3", "bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MATRIX_PEAK_TF, "peak_f16_mfma": F16_MFMA_PEAK_TF,
@@ -334,6 +362,15 @@ def main() -> None:
     finally:
         os.environ.pop("DFX_EXACT_FP32", None)
 
+    # ---- host to host: the reference's enhance() takes and returns CPU tensors (enhance.py:206-250).  Page-locked [B, T] input and output,
+    # H2D of batch k+1 and D2H of batch k-1 on their own streams under the compute of batch k.
+    host_io = None
+    if extras:
+        try:
+            host_io = bench_host_io(model, df_state, x, args.steps)
+        except Exception as e:  # noqa: BLE001
+            host_io = {"error": repr(e)}
+
     # ---- BASELINE.json configs[3] and configs[4] (the batch model's streams are released first: a process with more streams than
     # hardware queues makes them share queues, which serialises the streaming runtime's three branches)
     import gc
@@ -365,10 +402,7 @@ def main() -> None:
             configs["streaming_4096"] = bench_streaming(dev)
         except Exception as e:  # noqa: BLE001
             configs["streaming_4096"] = {"error": repr(e)}
-        try:
-            configs["df_apply_o10"] = bench_df_apply_o10(dev, df_state, B, Tf)
-        except Exception as e:  # noqa: BLE001
-            configs["df_apply_o10"] = {"error": repr(e)}
+        configs["df_apply_o10"] = cfg_o10
     torch.cuda.empty_cache()
 
     cpu = None
@@ -398,6 +432,8 @@ def main() -> None:
                               "of a pass is enqueued once its encoder front has run: packets waiting at the head of the pass's ~13 hardware queues slow "
                               "the kernels that are running; every step of the timed loop still runs to completion inside the timed region",
                     "ms_per_step_with_free_enqueue_ahead": ahead_ms, "switch": "DFX_ENQUEUE_AHEAD=1"},
+        "host_io": host_io,
+        "gru_phase_form": ("persistent flag-synchronised launch (dfx_k_gru_seq)" if gru_persistent else "event-synchronised launches per (layer, time chunk)"),
         "roofline": roofline, "rooflines": rooflines, "configs": configs, "cpu_baseline": cpu, "kernels": kern,
         "realtime_factor": frames / dt / 100.0,
     }
@@ -429,6 +465,104 @@ def bench_streaming(dev, streams: int = 4096, calls: int = 100) -> dict:
         j = json.loads(line[-1])
         out[tag] = {k: j[k] for k in ("value", "unit", "ms_per_call", "call_budget_ms", "realtime_streams_per_gpu", "algorithmic_latency_ms")}
     return out
+
+
+def bench_df_apply_rows(dev, df_state, B: int, Tf: int, F: int, nd: int, O: int, la: int, E: int, iters: int = 20):
+    """The north-star kernel alone at the workload's size, on the engine's own layout (rows of 488 bins = 64-byte aligned, tap-major
+    coefficients), timed by the library's hipEvents on the launch stream (dfx_prof_*).  -> (total ms, launches)."""
+    from deepfilternet_amd import _lib
+
+    Fs = (F + 7) // 8 * 8
+    g = torch.Generator(device=dev).manual_seed(0)
+    spec = torch.randn((B, Tf, Fs, 2), device=dev, generator=g)
+    coefs = 0.3 * torch.randn((B, O, Tf, nd, 2), device=dev, generator=g)
+    gains = torch.rand((B, Tf, E), device=dev, generator=g)
+    out = torch.empty_like(spec)
+    L = _lib.lib()
+
+    def run():
+        _lib.check(L.dfx_df_apply_strided(_lib.ptr(spec), Fs, _lib.ptr(coefs), 0, _lib.ptr(gains), df_state.bands_handle, B, Tf, F, nd, O, la, 0.0,
+                                          0.0, _lib.ptr(out), Fs, _lib.stream()))
+
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    _lib.prof_reset()
+    _lib.prof_enable(["dfx_k_df_apply"])
+    for _ in range(iters):
+        run()
+    torch.cuda.synchronize()
+    ms, n = _lib.prof_read().get("dfx_k_df_apply", (0.0, 0))
+    _lib.prof_enable(None)
+    return ms, n
+
+
+def bench_host_io(model, df_state, x, steps: int) -> dict:
+    """enhance() host to host: page-locked input and output batches, the upload of batch k+1 and the download of batch k-1 on copy streams
+    of their own while batch k is computed (double-buffered device input, the outputs are the tensors enhance() returns)."""
+    from deepfilternet_amd.enhance import enhance
+
+    B, T = x.shape
+    nbytes = B * T * 4
+    xh = torch.empty((B, T), dtype=torch.float32, pin_memory=True)
+    xh.copy_(x)
+    yh = [torch.empty((B, T), dtype=torch.float32, pin_memory=True) for _ in range(2)]
+    xd = [torch.empty_like(x) for _ in range(3)]
+    main = torch.cuda.current_stream()
+    s_in, s_out = torch.cuda.Stream(), torch.cuda.Stream()
+    ev_in = [torch.cuda.Event() for _ in range(3)]
+    ev_done = [torch.cuda.Event() for _ in range(3)]
+    ev_out = [torch.cuda.Event() for _ in range(2)]
+    ys = [None, None, None]
+
+    # The copies carry NO device-side dependency on the compute queues (a copy that has to wait for a kernel's signal is executed by a
+    # blit kernel on the CUs instead of the DMA engines here — measured: 31 instead of 17.7 ms per step, tools/dev/hostio_probe.py): the
+    # host makes sure a copy's operands are free before it enqueues it (the passes it has to wait for are long over: enhance() paces
+    # itself to one pass in flight), and only the compute stream waits for an upload.
+    def upload(k):
+        i = k % 3
+        ev_done[i].synchronize()             # batch k - 3 (the last reader of xd[i]) is over — it is, for two passes already
+        with torch.cuda.stream(s_in):
+            xd[i].copy_(xh, non_blocking=True)
+            ev_in[i].record(s_in)
+
+    def download(k):
+        ev_done[k % 3].synchronize()         # pass k is over (enhance(k + 1) has waited for it before it started its own pass)
+        j = k & 1
+        ev_out[j].synchronize()              # yh[j] of batch k - 2 has arrived: this is where a consumer takes it
+        with torch.cuda.stream(s_out):
+            yh[j].copy_(ys[k % 3], non_blocking=True)
+            ev_out[j].record(s_out)
+
+    def run(n):
+        for e in ev_done:
+            e.record(main)
+        for e in ev_out:
+            e.record(s_out)
+        torch.cuda.synchronize()
+        upload(0)
+        for k in range(n):
+            if k + 1 < n:
+                upload(k + 1)                  # runs under the compute of batch k
+            main.wait_event(ev_in[k % 3])
+            ys[k % 3] = enhance(model, df_state, xd[k % 3])
+            ev_done[k % 3].record(main)
+            if k >= 1:
+                download(k - 1)                # runs under the compute of batch k
+        download(n - 1)
+        torch.cuda.synchronize()
+
+    run(3)
+    t0 = time.perf_counter()
+    run(steps)
+    dt = (time.perf_counter() - t0) / steps
+    ok = bool(torch.isfinite(yh[(steps - 1) & 1]).all())
+    return {"ms_per_step_host_to_host": dt * 1e3, "frames_per_s_host_to_host": B * (T // HOP) / dt,
+            "pcie_gb_per_s_each_way": nbytes / dt / 1e9, "bytes_each_way_per_step": nbytes, "steps": steps, "finite": ok,
+            "how": "page-locked [B, T] f32 input and output; H2D of batch k+1 and D2H of batch k-1 on their own HIP streams under the compute of "
+                   "batch k (device input triple-buffered, copies without device-side dependencies so that the DMA engines take them); not part of "
+                   "`value`, which keeps its inputs resident in HBM.  This box moves 57 GB/s in one direction and 2 x 28.7 GB/s in both at once "
+                   "(tools/dev/hostio_probe.py): 2 x 492 MB per step is 17.2 ms of DMA time, i.e. the host-to-host step is bound by the link"}
 
 
 def bench_df_apply_o10(dev, df_state, B: int, Tf: int, iters: int = 20) -> dict:

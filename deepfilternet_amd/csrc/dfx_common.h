@@ -96,6 +96,14 @@ int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int6
                          float *out, int64_t out_stride, int64_t out_skip, int64_t out_len, hipStream_t s, int64_t f_begin = 0,
                          int64_t f_end = -1,   // only output frames [f_begin, f_end) (time-chunked finishing)
                          int64_t spec_stride = 0);  // row stride of spec in complex elements (0: F)
+// The finishing pass of enhance() in one kernel (dfx_k_synthesis_rows): Mask + MF.DF [+ post filter + attenuation limit] applied on the way
+// into the ISTFT, whole rows, no STFT memories.  coefs == null: spec IS the enhanced spectrum (no deep filter, the chunk carry alone).
+// dfx_synthesis_rows_ok: the configuration the kernel is written for (N = 960, hop = 480, the in-place plan; order 5 taps in the tap-major
+// layout, nb_df <= 128, <= 64 bands).
+bool dfx_synthesis_rows_ok(const dfx_state *st, bool with_df, int order, int nb_df, int nbands);
+int dfx_launch_synthesis_rows(const dfx_state *st, const float *spec, int64_t spec_stride, const float *coefs, int nb_df, int order, int lookahead,
+                              const float *gains, float pf_beta, float atten_lim, int64_t B, int64_t Tf, float *out, int64_t out_stride,
+                              int64_t out_skip, int64_t out_len, hipStream_t s);
 int dfx_launch_norm_scan(const float *erb_in, float *erb_out, int E, const float *spec_in, int64_t spec_frame_stride,
                          float *spec_out, int Fn, int64_t C, int64_t T, float alpha, float *erb_state,
                          float *unit_state, hipStream_t s);

@@ -482,6 +482,60 @@ int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int6
     return DFX_OK;
 }
 
+bool dfx_synthesis_rows_ok(const dfx_state *st, bool with_df, int order, int nb_df, int nbands) {
+    if (!st || st->N != 960 || st->hop != 480 || !ana_in_place(st)) return false;
+    if (!with_df) return true;
+    return (order == 5 || nb_df == 0) && nb_df >= 0 && nb_df <= 128 && nbands <= 64 && st->bands && st->bands->F == 481;
+}
+int dfx_launch_synthesis_rows(const dfx_state *st, const float *spec, int64_t spec_stride, const float *coefs, int nb_df, int order, int lookahead,
+                              const float *gains, float pf_beta, float atten_lim, int64_t B, int64_t Tf, float *out, int64_t out_stride,
+                              int64_t out_skip, int64_t out_len, hipStream_t s) {
+    if (B <= 0 || Tf <= 0) return DFX_OK;
+    const bool with_df = coefs != nullptr || gains != nullptr;
+    if (!dfx_synthesis_rows_ok(st, with_df, order, coefs ? nb_df : 0, gains ? st->bands->nb : 0))
+        DFX_FAIL(DFX_ERR_UNSUPPORTED, "synthesis_rows: configuration (needs fft 960 / hop 480, deep-filter order 5, nb_df <= 128)");
+    DfxSynRowsArgs A;
+    A.spec = reinterpret_cast<const float2 *>(spec);
+    A.coefs = reinterpret_cast<const float2 *>(coefs);
+    A.gains = gains;
+    A.bin2band = st->bands ? st->bands->d_bin2band : nullptr;
+    A.out = out;
+    A.window = st->d_window;
+    A.tw = st->d_tw;
+    A.B = B, A.Tf = Tf;
+    A.spec_stride = spec_stride > 0 ? spec_stride : st->N / 2 + 1;
+    A.out_stride = out_stride, A.out_skip = out_skip, A.out_len = out_len;
+    const int64_t nd = coefs ? nb_df : 0;
+    A.cs_b = (int64_t)order * Tf * nd, A.cs_n = Tf * nd, A.cs_t = nd;   // [B, O, Tf, nd] (DFX_COEF_BOTF)
+    A.nbdf = (int)nd, A.lookahead = lookahead, A.nb = gains ? st->bands->nb : 0;
+    A.pf_beta = pf_beta, A.atten_lim = atten_lim;
+    // segments: enough (row, segment) items to fill three workgroups per CU, but at least 4 chunks each (a segment that does not start a
+    // row costs one extra single-wave item)
+    const int64_t chunks = dfx_ceil_div(Tf, DFX_DSP_TEAMS);
+    const int64_t want = dfx_ceil_div((int64_t)dfx_env_num_cus() * 3, B);
+    int64_t segs = want < 1 ? 1 : want;
+    if (segs > chunks / 4) segs = chunks / 4 > 0 ? chunks / 4 : 1;
+    static const int seg_env = [] { const char *e = getenv("DFX_SYN_SEGS"); return e ? atoi(e) : 0; }();   // dev: segments per row
+    if (seg_env > 0) segs = seg_env < chunks ? seg_env : chunks;
+    A.seg_chunks = (int)dfx_ceil_div(chunks, segs);
+    A.segs = (int)dfx_ceil_div(chunks, A.seg_chunks);
+    int64_t nblk = B * A.segs;
+    const int64_t cap = (int64_t)dfx_env_num_cus() * 3;
+    if (nblk > cap) nblk = cap;
+    const size_t smem = DFX_SYNR_SMEM;
+    const bool pf = pf_beta > 0.f || atten_lim > 0.f;
+    DfxKScope ks(DFX_K_SYNTHESIS, s);
+    if (!with_df) {
+        dfx_launch((dfx_k_synthesis_rows<0, false>), dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, s, A);
+    } else if (pf) {
+        dfx_launch((dfx_k_synthesis_rows<5, true>), dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, s, A);
+    } else {
+        dfx_launch((dfx_k_synthesis_rows<5, false>), dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, s, A);
+    }
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
+}
+
 extern "C" int dfx_erb(const dfx_bands *bands, const float *spec, int64_t rows, int db, float *out, void *stream) {
     if (!bands || rows < 0) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_erb: bad arguments");
     if (int rc = dfx_require_device()) return rc;

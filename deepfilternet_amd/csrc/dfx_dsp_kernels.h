@@ -1569,3 +1569,241 @@ __global__ void __launch_bounds__(256) dfx_k_df_apply_rows(DfxDfrArgs A) {
     }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dfx_k_synthesis_rows<O, PF>: the finishing pass of enhance() for the 48 kHz / 20 ms configuration (N = 960, hop = 480, the in-place
+// 480-point transform) in ONE kernel — Mask + MF.DF + combine [+ post filter + attenuation limit] (multiframe.py:126-180,
+// deepfilternet3.py:426-454, enhance.py:238-240: the arithmetic of dfx_k_df_apply_rows) applied while a frame is on its way INTO the
+// inverse transform, then ISTFT + window + overlap-add (lib.rs:396-427: dfx_k_synthesis<true>).  The enhanced spectrum never exists in
+// HBM: per frame the pass reads X (3848 B), the O taps' coefficients (O * nb_df * 8 B) and the band gains (128 B), and writes 1920 B of
+// audio — 9736 algorithmic bytes instead of 11664 + 5768 for the two kernels (the O - 1 neighbouring frames a frame's taps read are
+// L2 hits: the neighbouring waves of the workgroup load the same rows at the same time).
+// Work: a workgroup walks a SEGMENT of consecutive 8-frame chunks of one row and carries the second half of a chunk's last frame to the
+// next chunk in LDS (double buffered); all 8 frames of a chunk are output frames (dfx_k_synthesis recomputes one halo frame per 7).
+// A segment that does not start at frame 0 begins with one prologue item in which a single wave transforms the frame before it.
+// O = 0: the input is the enhanced spectrum itself (no deep filter: the carry alone).  Sums in the reference's order (older frame first).
+// ---------------------------------------------------------------------------------------------------------------------
+struct DfxSynRowsArgs {
+    const float2 *spec;       // [B, Tf, spec_stride]: O > 0 the noisy spectrum X, O == 0 the enhanced spectrum
+    const float2 *coefs;      // O > 0: complex element (b, n, t, f) at b * cs_b + n * cs_n + t * cs_t + f
+    const float *gains;       // [B, Tf, nb] or null (O > 0)
+    const unsigned char *bin2band;   // [F]
+    float *out;               // [B, out_stride]
+    const float *window;      // [960]
+    const float2 *tw;         // [960]
+    int64_t B, Tf, spec_stride, out_stride, out_skip, out_len;
+    int64_t cs_b, cs_n, cs_t;
+    int nbdf, lookahead, nb;
+    float pf_beta, atten_lim;
+    int segs, seg_chunks;     // segments per row, 8-frame chunks per segment
+};
+#define DFX_SYNR_SMEM ((size_t)960 * 12 + (size_t)DFX_DSP_TEAMS * 482 * 8 + (size_t)2 * 480 * 4 + 512)
+
+template <int O, bool PF>
+__global__ void __launch_bounds__(DFX_DSP_THREADS, 6) dfx_k_synthesis_rows(DfxSynRowsArgs A) {
+    constexpr int M = 480, N = 960, HOP = 480, NTM = DFX_DSP_TEAMS, BUF = M + 2;
+    DFX_DYN_SMEM(unsigned char, smem);
+    float2 *tw = reinterpret_cast<float2 *>(smem);
+    float *win = reinterpret_cast<float *>(smem + (size_t)N * 8);
+    float2 *bufs = reinterpret_cast<float2 *>(smem + (size_t)N * 12);
+    float *carry = reinterpret_cast<float *>(bufs + (size_t)NTM * BUF);   // [2][HOP]
+    unsigned char *b2b = reinterpret_cast<unsigned char *>(carry + 2 * HOP);   // [M + 1] (+ pad)
+    const int team = dfx_wave_uniform(threadIdx.x / DFX_DSP_TEAM), lane = threadIdx.x % DFX_DSP_TEAM;
+    float2 *bufA = bufs + (size_t)team * BUF;
+    for (int i0 = threadIdx.x; i0 < N; i0 += 4 * DFX_DSP_THREADS) {   // all loads of a pass before its first LDS store
+        float2 tv[4];
+        float wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * DFX_DSP_THREADS;
+            tv[u] = i < N ? A.tw[i] : make_float2(0.f, 0.f);
+            wv[u] = i < N ? A.window[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * DFX_DSP_THREADS;
+            if (i < N) {
+                tw[i] = tv[u];
+                win[i] = wv[u];
+            }
+        }
+    }
+    if (O > 0 && A.gains && threadIdx.x <= M) b2b[threadIdx.x] = A.bin2band[threadIdx.x];
+    __syncthreads();
+    const int toff = O - 1 - A.lookahead;
+    const int64_t chunks = (A.Tf + NTM - 1) / NTM;
+    int par = 0;   // carry buffer the current item reads
+    for (int64_t seg = blockIdx.x; seg < A.B * A.segs; seg += gridDim.x) {
+    const int64_t b = seg / A.segs;
+    const int64_t c0 = (seg - b * A.segs) * A.seg_chunks;
+    const int64_t c1 = c0 + A.seg_chunks < chunks ? c0 + A.seg_chunks : chunks;
+    for (int64_t ch = c0 > 0 ? c0 - 1 : c0; ch < c1; ++ch) {
+    const bool pro = ch < c0;                  // prologue item: only the frame in front of the segment, nothing stored
+    const int64_t t0 = ch * NTM, t = t0 + team;
+    const bool active = t < A.Tf && (!pro || team == NTM - 1);
+    if (active) {
+        const float2 *Xr = A.spec + (b * A.Tf + t) * A.spec_stride;
+        int lr = lane;
+        DFX_OPAQUE(lr);
+        if constexpr (O == 0) {
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = lr + u * DFX_DSP_TEAM;
+                v[u] = Xr[k <= M ? k : lr];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = lr + u * DFX_DSP_TEAM;
+                if (k <= M) bufA[k] = v[u];
+            }
+        } else {
+            // ---- the deep-filter bins (k < nb_df <= 128: passes 0 and 1): taps n read frame t + n - toff, zero outside the clip
+            const float2 *Cr = A.coefs + b * A.cs_b + t * A.cs_t;
+            float2 x01[2], cf[2][O], xt[2][O];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = lr + u * DFX_DSP_TEAM;
+                const bool df = k < A.nbdf;
+                x01[u] = Xr[k];
+#pragma unroll
+                for (int n = 0; n < O; ++n) {
+                    const int64_t tt = t + n - toff;
+                    cf[u][n] = df ? Cr[n * A.cs_n + k] : make_float2(0.f, 0.f);
+                    xt[u][n] = (df && tt >= 0 && tt < A.Tf) ? A.spec[(b * A.Tf + tt) * A.spec_stride + k] : make_float2(0.f, 0.f);
+                }
+            }
+            float gv = 1.f;
+            if (A.gains) gv = A.gains[(b * A.Tf + t) * A.nb + (lr < A.nb ? lr : 0)];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = lr + u * DFX_DSP_TEAM;
+                float g = 1.f;
+                if (A.gains) g = __shfl(gv, (int)b2b[k]);   // (every lane takes part)
+                float2 y;
+                if (k < A.nbdf) {
+                    float re = 0.f, im = 0.f;
+#pragma unroll
+                    for (int n = 0; n < O; ++n) {
+                        const float2 c = cf[u][n], xx = xt[u][n];
+                        re += xx.x * c.x - xx.y * c.y;
+                        im += xx.x * c.y + xx.y * c.x;
+                    }
+                    y = make_float2(re, im);
+                } else {
+                    y = make_float2(x01[u].x * g, x01[u].y * g);
+                }
+                if (PF) y = dfx_dfa_finish(y, x01[u], A.pf_beta, A.atten_lim);
+                bufA[k] = y;
+            }
+            // ---- the other bins: band gains only
+            float2 v[6];
+#pragma unroll
+            for (int u = 2; u < 8; ++u) {
+                const int k = lr + u * DFX_DSP_TEAM;
+                v[u - 2] = Xr[k <= M ? k : lr];
+            }
+#pragma unroll
+            for (int u = 2; u < 8; ++u) {
+                const int k = lr + u * DFX_DSP_TEAM, kk = k <= M ? k : lr;
+                float g = 1.f;
+                if (A.gains) g = __shfl(gv, (int)b2b[kk]);
+                float2 y = make_float2(v[u - 2].x * g, v[u - 2].y * g);
+                if (PF) y = dfx_dfa_finish(y, v[u - 2], A.pf_beta, A.atten_lim);
+                if (k <= M) bufA[k] = y;
+            }
+        }
+    }
+    DFX_WAVE_SYNC();
+    // E' = X[k] + conj(X[M-k]) ; O' = conj(w^k) * (X[k] - conj(X[M-k])) ; Z[k] = E' + i*O'   (in place on the pairs (k, M-k), see dfx_k_synthesis)
+    auto zbin_w = [&](int k, float2 xk, float2 xm, float2 w) -> float2 {
+        if (k == 0) {  // C2R ignores imag(DC) and imag(Nyquist)
+            xk.y = 0.f;
+            xm.y = 0.f;
+        }
+        const float er = xk.x + xm.x, ei = xk.y - xm.y;
+        w.y = -w.y;
+        const float2 o = dfx_cmul(make_float2(xk.x - xm.x, xk.y + xm.y), w);
+        return make_float2(er - o.y, ei + o.x);
+    };
+    if (active) {
+        constexpr int NPR = (M / 2 + DFX_DSP_TEAM) / DFX_DSP_TEAM;
+        float2 xa[NPR], xb[NPR], wa[NPR], wb[NPR];
+        int lp = lane;
+        DFX_OPAQUE(lp);
+#pragma unroll
+        for (int i = 0; i < NPR; ++i) {
+            const int k = lp + i * DFX_DSP_TEAM, kk = k <= M / 2 ? k : 0, kc = M - kk;
+            xa[i] = bufA[kk], xb[i] = bufA[kc];
+            wa[i] = tw[kk], wb[i] = tw[kc];
+        }
+#pragma unroll
+        for (int i = 0; i < NPR; ++i) {
+            const int k = lp + i * DFX_DSP_TEAM, kc = M - k;
+            if (k > M / 2) continue;
+            const float2 za = zbin_w(k, xa[i], xb[i], wa[i]);
+            if (k != 0 && kc != k) bufA[kc] = zbin_w(kc, xb[i], xa[i], wb[i]);
+            bufA[k] = za;
+        }
+    }
+    DFX_WAVE_SYNC();
+    dfx_fft480_ip<+1>(bufA, tw, lane, active);
+    {   // apply_window_in_place (lib.rs:406): the interleaved (re, im) pairs of z ARE the time samples
+        constexpr int NQ = N / 4, NR4 = (NQ + DFX_DSP_TEAM - 1) / DFX_DSP_TEAM;
+        f32x4 *xq = reinterpret_cast<f32x4 *>(bufA);
+        const f32x4 *wq = reinterpret_cast<const f32x4 *>(win);
+        f32x4 xv[NR4], wv[NR4];
+        int lw = lane;
+        DFX_OPAQUE(lw);
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < NR4; ++r) {
+                const int i = lw + r * DFX_DSP_TEAM, ii = i < NQ ? i : 0;
+                xv[r] = xq[ii], wv[r] = wq[ii];
+            }
+#pragma unroll
+            for (int r = 0; r < NR4; ++r) {
+                const int i = lw + r * DFX_DSP_TEAM;
+                if (i < NQ) xq[i] = xv[r] * wv[r];
+            }
+        }
+    }
+    __syncthreads();
+    // overlap-add: output frame tf = t0 + j gets the second half of frame tf - 1 (the previous wave's buffer, or the carry) + the first
+    // half of frame tf; the second half of the chunk's last frame becomes the next item's carry
+    constexpr int HQ = HOP / 4;
+    const float *cin = carry + par * HOP;
+    float *cout = carry + (par ^ 1) * HOP;
+    if (!pro) {
+        for (int q = threadIdx.x; q < NTM * HQ; q += DFX_DSP_THREADS) {
+            const int j = q / HQ, i = (q - j * HQ) << 2;
+            const int64_t tf = t0 + j;
+            if (tf >= A.Tf) break;
+            const float *fr = reinterpret_cast<const float *>(bufs + (size_t)j * BUF);
+            const f32x4 cur = *reinterpret_cast<const f32x4 *>(fr + i);
+            f32x4 v = cur;
+            if (tf > 0) {
+                const f32x4 old = j > 0 ? *reinterpret_cast<const f32x4 *>(fr - 2 * BUF + HOP + i) : *reinterpret_cast<const f32x4 *>(cin + i);
+                v = cur + old;
+            }
+            const int64_t n = tf * HOP + i - A.out_skip;
+            float *o = A.out + b * A.out_stride + n;
+            if (n >= 0 && n + 3 < A.out_len && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+                *reinterpret_cast<f32x4 *>(o) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e >= 0 && n + e < A.out_len) o[e] = v[e];
+            }
+        }
+    }
+    if (threadIdx.x < HQ && t0 + NTM - 1 < A.Tf) {
+        const float *fr = reinterpret_cast<const float *>(bufs + (size_t)(NTM - 1) * BUF);
+        *reinterpret_cast<f32x4 *>(cout + 4 * threadIdx.x) = *reinterpret_cast<const f32x4 *>(fr + HOP + 4 * threadIdx.x);
+    }
+    par ^= 1;
+    __syncthreads();  // the frame buffers are rewritten by the next item, which also reads the carry just stored
+    }
+    }
+}
+

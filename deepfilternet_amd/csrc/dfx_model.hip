@@ -311,6 +311,7 @@ struct dfx_model {
     int fan_chunks = 0;            // super-chunks of 32 hidden columns (0: not available)
     int fan_kind[3] = {0, 0, 0};   // per consumer (dec_in, dfg_in, df_skip): 0 absent, 1 narrow (32 -> 16 groups), 2 wide (64 -> 32 groups)
     bool fuse_emb = true;
+    bool fuse_dfa = true;          // DFX_FUSE_DFA=0: deep filter and ISTFT of enhance() as two kernels with spec_e between them
     // DFX_FUSE_TAIL=1: the ERB decoder's convolutions as ONE launch (dfx_k_erb_tail: d3 / d2 stay in LDS, -12 KB per frame beside the chain).
     // Measured at config 2 (profiles/r03_fusion_ab.log): the kernel alone 2.19 ms against 1.5 ms for the three launches it replaces
     // (one fat workgroup per CU, a half-empty first tile, fragments re-read from LDS per stage), step 16.37 vs 16.00 ms: not the default.
@@ -866,6 +867,8 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         m->gru_seq = !(gq && gq[0] == '0') && !dfx_env_is_emulator();
         const char *fem = getenv("DFX_FUSE_EMB");
         m->fuse_emb = !(fem && fem[0] == '0');
+        const char *fdf = getenv("DFX_FUSE_DFA");
+        m->fuse_dfa = !(fdf && fdf[0] == '0');
         const char *ftl = getenv("DFX_FUSE_TAIL");
         m->fuse_tail = ftl && ftl[0] == '1';
         const char *cep = getenv("DFX_CHECK_EVERY_PASS"), *spl = getenv("DFX_SYNC_SPIN_LIMIT");
@@ -2556,12 +2559,21 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             dfx_launch(dfx_k_dev_spin, dim3((unsigned)blocks), dim3(64), 0, fin_s, (long long)us * 100);  // wall_clock64 ticks at 100 MHz
         }
     }
-    if ((rc = dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, run_df ? Fd : 0, O, c.df_lookahead,
-                                  c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, fin_s, 0, -1, -1, -1, 0, sstride, sstride)))
-        return rc;
-    if (fin && (rc = dfx_launch_synthesis(fin->st, spec_e, B, T, nullptr, nullptr, fin->y, fin->out_stride, fin->out_skip, fin->out_len,
-                                          fin_s, 0, -1, sstride)))
-        return rc;
+    // enhance(): the deep filter + gains are applied on the way into the inverse transform (dfx_k_synthesis_rows): spec_e never exists.
+    // DFX_FUSE_DFA=0: dfx_k_df_apply_rows -> spec_e -> dfx_k_synthesis (the stand-alone deep-filter kernel stays the API of
+    // dfx_model_forward / dfx_df_apply and the roofline kernel of bench.py)
+    if (fin && m->fuse_dfa && dfx_synthesis_rows_ok(fin->st, true, O, run_df ? Fd : 0, E) && bands == fin->st->bands) {
+        if ((rc = dfx_launch_synthesis_rows(fin->st, spec, sstride, run_df ? coefs : nullptr, run_df ? Fd : 0, O, c.df_lookahead, mask,
+                                            c.mask_pf ? c.pf_beta : 0.f, atten_lim, B, T, fin->y, fin->out_stride, fin->out_skip, fin->out_len, fin_s)))
+            return rc;
+    } else {
+        if ((rc = dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, run_df ? Fd : 0, O, c.df_lookahead,
+                                      c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, fin_s, 0, -1, -1, -1, 0, sstride, sstride)))
+            return rc;
+        if (fin && (rc = dfx_launch_synthesis(fin->st, spec_e, B, T, nullptr, nullptr, fin->y, fin->out_stride, fin->out_skip, fin->out_len,
+                                              fin_s, 0, -1, sstride)))
+            return rc;
+    }
     if (fin_s != s && ((rc = signal(EV_FIN, fin_s)) || (rc = wait(EV_FIN, s)))) return rc;
     return DFX_OK;
 }
