@@ -312,10 +312,11 @@ struct dfx_model {
     int fan_kind[3] = {0, 0, 0};   // per consumer (dec_in, dfg_in, df_skip): 0 absent, 1 narrow (32 -> 16 groups), 2 wide (64 -> 32 groups)
     bool fuse_emb = true;
     bool fuse_dfa = true;          // DFX_FUSE_DFA=0: deep filter and ISTFT of enhance() as two kernels with spec_e between them
-    // DFX_FUSE_TAIL=1: the ERB decoder's convolutions as ONE launch (dfx_k_erb_tail: d3 / d2 stay in LDS, -12 KB per frame beside the chain).
-    // Measured at config 2 (profiles/r03_fusion_ab.log): the kernel alone 2.19 ms against 1.5 ms for the three launches it replaces
-    // (one fat workgroup per CU, a half-empty first tile, fragments re-read from LDS per stage), step 16.37 vs 16.00 ms: not the default.
-    bool fuse_tail = false;
+    // The ERB decoder's convolutions as ONE launch (dfx_k_erb_tail: d3 / d2 / d1 stay in LDS, -12 KB per frame beside the GRU chain);
+    // DFX_FUSE_TAIL=0: three launches (convt3, convt2, convt1 + conv0_out).  Measured at config 2 (profiles/r03_fusion_ab.log): the first
+    // version (8 waves per CU) 2.19 ms alone against 1.5 ms for the three launches and +0.37 ms per step; the second (12 waves per CU, 8.5 KB
+    // of strips per wave, fragments read from LDS per k-chunk) 1.32 ms alone and -0.25 ... -0.45 ms per step.
+    bool fuse_tail = true;
     size_t cp_w1 = 0, cp_w2 = 0, cp_b = 0;   // df_convp, tiled form (kt > 5)
     size_t cp_weff = 0, cp_b16 = 0;          // df_convp, folded sliding-window form (kt <= 5)
     size_t cin_weff = 0, cin_b = 0;          // enc.df_conv0 folded into a dense 3x3 conv 2 -> C
@@ -870,7 +871,7 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         const char *fdf = getenv("DFX_FUSE_DFA");
         m->fuse_dfa = !(fdf && fdf[0] == '0');
         const char *ftl = getenv("DFX_FUSE_TAIL");
-        m->fuse_tail = ftl && ftl[0] == '1';
+        m->fuse_tail = !(ftl && ftl[0] == '0');
         const char *cep = getenv("DFX_CHECK_EVERY_PASS"), *spl = getenv("DFX_SYNC_SPIN_LIMIT");
         m->check_every_pass = cep && cep[0] == '1';
         if (spl && atoi(spl) > 0) m->spin_limit = atoi(spl);
@@ -1404,7 +1405,7 @@ static int launch_erb_tail(const dfx_model *m, const float *demb, const float *e
         A.E = E;
         A.rm = rm;
         A.err = m->d_err;
-        const size_t smem = DFX_TAIL_SMEM(C, E);
+        const size_t smem = DFX_TAIL_SMEM(C);
         DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_erb_tail<C>, smem));
         DfxKScope ks(DFX_K_ERB_TAIL, s);
         dfx_launch(dfx_k_erb_tail<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R, DFX_TAIL_WAVES), 1)), dim3(64 * DFX_TAIL_WAVES), smem, s, A);

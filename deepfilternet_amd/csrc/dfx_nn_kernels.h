@@ -1549,23 +1549,24 @@ __global__ void __launch_bounds__(256, 2) dfx_k_erb_dec10_f(DfxDec10fArgs AA) {
 //     d1 = convt1(d2 + conv1p(e1))     [E/2] -> [E]          mask = sigmoid(conv0_out(d1 + conv0p(e0)))
 // As three launches (dfx_k_pwconv_f x 2, dfx_k_erb_dec10_f) d3 and d2 made a round trip through HBM each — 12 KB per frame written
 // and read back BESIDE the GRU chain, where every byte costs the chain time; here they live in LDS strips.
-// A wave owns a frame.  Strips [rows][C + 4], wave-private (wave-level synchronisation only):
-//     X [E]:   rows [0, E/4) = convt3's input, rows [E/4, E/2) = convt2's input (conv2p(e2), d3 added by convt3's epilogue); once
-//              convt2 has run, all of X becomes conv0_out's input (conv0p(e0) stored, d1 added by convt1's epilogue)
-//     Y [E/2]: convt1's input (conv1p(e1), d2 added by convt2's epilogue); once convt1 has run, the per-position partial sums of conv0_out
-// The three pointwise contractions run on the fp16-split path (dfx_chain_stage_h3, same tile body and k order as the separate kernels);
-// their fragments (48 KB for C = 64) sit in LDS and are read into registers stage by stage, so only one layer's are live at a time.
-// All five operand runs of the NEXT frame are requested as soon as the current frame's e0 has been stored (before convt1, the largest
-// stage).  One workgroup of 8 waves per CU (LDS: 156 KB at C = 64, E = 32).
+// A wave owns a frame (E = 32: 8 / 8 / 16 / 32 positions).  Strips [16 rows][C + 4], wave-private (wave-level synchronisation only):
+//     X: rows [0, 8) = convt3's input, rows [8, 16) = convt2's input (conv2p(e2), d3 added by convt3's epilogue); during convt1 it holds
+//        one 16-position tile of conv0_out's input at a time (conv0p(e0) stored, d1 added by the epilogue, the C -> 1 taps taken, next tile)
+//     Y: convt1's input (conv1p(e1), d2 added by convt2's epilogue)
+// The pad columns of the strips' rows carry the per-position partial sums of conv0_out across the two tiles.
+// What bounds these per-frame chains is latency (LDS -> taps -> split -> matrix ops -> LDS, four times per frame), i.e. waves per SIMD, and
+// what bounds the waves is LDS: the first version (strips for a whole frame, 8 waves per CU, a layer's fragments held in 64 registers)
+// ran at 2.19 ms for the 1.5 ms of the three launches it replaced.  Here the strips are 8.5 KB per wave and the three layers' fp16-split
+// fragments (48 KB at C = 64) are read from LDS one k-chunk at a time (32 registers), so that a workgroup of 12 waves = 3 per SIMD fits
+// one CU (156 KB of LDS, <= 168 registers).
 // ---------------------------------------------------------------------------------------------------------------------
-#define DFX_TAIL_WAVES 8
-#define DFX_TAIL_WAVE_FLOATS(C, E) (((E) + (E) / 2) * ((C) + 4))
+#define DFX_TAIL_WAVES 12
+#define DFX_TAIL_WAVE_FLOATS(C) (32 * ((C) + 4))
 #define DFX_TAIL_TAB4(C) (3 * 3 * (C) / 4 + 4 * 2 * (C) / 4 + 3 * (C) / 4 + 3 * (C) / 4)   /* float4s: dw x3, pathway a/b x4, wo, bias x3 */
 #define DFX_TAIL_WFRAG(C) ((size_t)((C) / 16) * ((C) / 32) * 2 * 64)                     /* dfx_h8 per layer */
-#define DFX_TAIL_SMEM(C, E) ((size_t)DFX_TAIL_TAB4(C) * 16 + 3 * DFX_TAIL_WFRAG(C) * 16 + (size_t)DFX_TAIL_WAVES * DFX_TAIL_WAVE_FLOATS(C, E) * 4)
+#define DFX_TAIL_SMEM(C) ((size_t)DFX_TAIL_TAB4(C) * 16 + 3 * DFX_TAIL_WFRAG(C) * 16 + (size_t)DFX_TAIL_WAVES * DFX_TAIL_WAVE_FLOATS(C) * 4)
 static __host__ __device__ __forceinline__ bool dfx_tail_ok(int C, int E) {
-    return C % 32 == 0 && E % 8 == 0 && (E / 4) * (C / 4) <= 64 * 2 && (E / 2) * (C / 4) <= 64 * 4 && E * (C / 4) <= 64 * 8 && 3 * E <= (E / 2) * (C + 4) &&
-           DFX_TAIL_SMEM(C, E) <= (size_t)160 * 1024;
+    return (C == 32 || C == 64) && E == 32 && DFX_TAIL_SMEM(C) <= (size_t)160 * 1024;
 }
 struct DfxTailArgs {
     const float *demb, *e3, *e2, *e1, *e0;   // [R, E/4, C] x3, [R, E/2, C], [R, E, C]
@@ -1581,21 +1582,87 @@ struct DfxTailArgs {
     DfxRowMap rm;
     unsigned int *err;
 };
+// one 16-position tile of a separable stage on the fp16-split path, fragments and bias read from LDS (dfx_chain_stage_h3's tile body: same
+// operand roles, same k order, same bits); positions [p0, p0 + 16) of npos, input rows in `in`
+template <int C, int MODE, typename Epi>
+static __device__ __forceinline__ void dfx_chain_tile_h3_lds(const float *in, int Fin, int stride, int p0, int npos, const float4 *dws,
+                                                             const dfx_h8 *wfr, const float4 *bias4, float unscale, float &amax, int lane, Epi &&epi) {
+    constexpr int CPL = C / 4, NT = C / 16, KC = C / 32, V4 = CPL / 4, LD = C + 4;
+    const int q = lane >> 4, jl = lane & 15;
+    const int fo = p0 + jl;
+    const bool valid = fo < npos;
+    float u[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) u[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        int fi;
+        bool ok;
+        if (MODE == DFX_PW_MODE_DW3) {
+            fi = fo * stride + j - 1;
+            ok = fi >= 0 && fi < Fin;
+        } else {  // transposed: fo = 2*fi - 1 + j
+            const int num = fo + 1 - j;
+            fi = num >> 1;
+            ok = num >= 0 && (num & 1) == 0 && fi < Fin;
+        }
+        if (valid && ok) {
+            const float4 *xp = reinterpret_cast<const float4 *>(in + fi * LD + CPL * q);
+#pragma unroll
+            for (int v = 0; v < V4; ++v) {
+                const float4 xv = xp[v];
+                const float4 w = dws[j * (C / 4) + V4 * q + v];
+                u[4 * v + 0] += w.x * xv.x;
+                u[4 * v + 1] += w.y * xv.y;
+                u[4 * v + 2] += w.z * xv.z;
+                u[4 * v + 3] += w.w * xv.w;
+            }
+        }
+    }
+    dfx_h8 bhi[KC], blo[KC];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) dfx_split8_g(u + 8 * kc, bhi[kc], blo[kc], amax);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+        dfx_h8 ahi[NT], alo[NT];   // one k-chunk of fragments at a time
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            ahi[nt] = wfr[((size_t)(nt * KC + kc) * 2 + 0) * 64 + lane];
+            alo[nt] = wfr[((size_t)(nt * KC + kc) * 2 + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            acc[nt] = dfx_mfma_16x16x32_f16(alo[nt], bhi[kc], acc[nt]);
+            acc[nt] = dfx_mfma_16x16x32_f16(ahi[nt], blo[kc], acc[nt]);
+            acc[nt] = dfx_mfma_16x16x32_f16(ahi[nt], bhi[kc], acc[nt]);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float4 bz = bias4[4 * nt + q];
+        epi(fo, valid, nt,
+            make_float4(fmaxf(acc[nt][0] * unscale + bz.x, 0.f), fmaxf(acc[nt][1] * unscale + bz.y, 0.f), fmaxf(acc[nt][2] * unscale + bz.z, 0.f),
+                        fmaxf(acc[nt][3] * unscale + bz.w, 0.f)));
+    }
+}
 template <int C>
 __global__ void __launch_bounds__(64 * DFX_TAIL_WAVES, 1) dfx_k_erb_tail(DfxTailArgs A) {
-    constexpr int NT = C / 16, LD = C + 4, C4 = C / 4, KC = C / 32;
+    constexpr int LD = C + 4, C4 = C / 4, NTH = 64 * DFX_TAIL_WAVES;
+    constexpr int E = 32, E1 = 16, E4 = 8;
+    constexpr int N3 = E4 * C4, N1 = E1 * C4, N0T = 16 * C4;   // float4s per frame of demb / e3 / e2, of e1, and per 16-position tile of e0
+    constexpr int NV3 = (N3 + 63) / 64, NV1 = (N1 + 63) / 64, NV0 = (N0T + 63) / 64;
     DFX_DYN_SMEM(float4, sm4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4;
-    const int E = A.E, E1 = E / 2, E4 = E / 4;
     float4 *dws = sm4;                  // [3 layers][3][C4]
     float4 *sks = dws + 9 * C4;         // [4 pathways][a, b][C4]
     float4 *wos = sks + 8 * C4;         // [3][C4]
     float4 *bis = wos + 3 * C4;         // [3 layers][C4]
     dfx_h8 *wfr = reinterpret_cast<dfx_h8 *>(bis + 3 * C4);   // [3 layers][NT * KC * 2 * 64]
-    float *X = reinterpret_cast<float *>(wfr + 3 * DFX_TAIL_WFRAG(C)) + (size_t)wave * DFX_TAIL_WAVE_FLOATS(C, E);
-    float *Y = X + E * LD;
-    float *V = Y;                       // [E][3], after convt1 has consumed Y
-    constexpr int NTH = 64 * DFX_TAIL_WAVES;
+    float *X = reinterpret_cast<float *>(wfr + 3 * DFX_TAIL_WFRAG(C)) + (size_t)wave * DFX_TAIL_WAVE_FLOATS(C);
+    float *Y = X + 16 * LD;
 #pragma unroll
     for (int l = 0; l < 3; ++l) {   // (constant indices into the argument arrays: a run-time index would move the struct to scratch)
         for (int i = tid; i < 3 * C4; i += NTH) dws[l * 3 * C4 + i] = reinterpret_cast<const float4 *>(A.dw[l])[i];
@@ -1610,144 +1677,135 @@ __global__ void __launch_bounds__(64 * DFX_TAIL_WAVES, 1) dfx_k_erb_tail(DfxTail
         }
     for (int i = tid; i < 3 * C4; i += NTH) wos[i] = reinterpret_cast<const float4 *>(A.wo)[i];
     __syncthreads();
-    const int n3 = E4 * C4, n1 = E1 * C4, n0 = E * C4;   // float4s per frame: demb / e3 / e2, e1, e0
     const float4 *pd = reinterpret_cast<const float4 *>(A.demb), *p3 = reinterpret_cast<const float4 *>(A.e3), *p2 = reinterpret_cast<const float4 *>(A.e2),
                  *p1 = reinterpret_cast<const float4 *>(A.e1), *p0 = reinterpret_cast<const float4 *>(A.e0);
-    float4 rd[2], r3[2], r2[2], r1[4], r0[8];
-    // demb / e3 / e2 / e1 of a frame are requested one frame ahead (40 registers); its e0 (32 registers) at the top of the frame itself —
-    // it is only needed after convt3 and convt2 have run — so that the two never overlap with a layer's fragments (64) all at once
-    auto issue = [&](int64_t rl) {
-        const int64_t r = dfx_row(A.rm, rl);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 rd[NV3], r3[NV3], r2[NV3];
+    // demb / e3 / e2 of a frame are requested one frame ahead; e1 and e0 inside the frame, each one stage before it is needed
+    auto issue = [&](int64_t r) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NV3; ++i) {
             const int idx = lane + 64 * i;
-            rd[i] = r3[i] = r2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < n3) rd[i] = pd[r * n3 + idx], r3[i] = p3[r * n3 + idx], r2[i] = p2[r * n3 + idx];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = lane + 64 * i;
-            r1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < n1) r1[i] = p1[r * n1 + idx];
-        }
-    };
-    auto issue_e0 = [&](int64_t r) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = lane + 64 * i;
-            r0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < n0) r0[i] = p0[r * n0 + idx];
+            rd[i] = r3[i] = r2[i] = z4;
+            if (idx < N3) rd[i] = pd[r * N3 + idx], r3[i] = p3[r * N3 + idx], r2[i] = p2[r * N3 + idx];
         }
     };
     auto path = [](float4 sv, float4 a, float4 b) {
         return make_float4(fmaxf(a.x * sv.x + b.x, 0.f), fmaxf(a.y * sv.y + b.y, 0.f), fmaxf(a.z * sv.z + b.z, 0.f), fmaxf(a.w * sv.w + b.w, 0.f));
     };
+    auto add_into = [&](float *strip, int prow0) {
+        return [=](int p, bool valid, int nt, float4 d) {
+            if (valid) {
+                float4 *dst = reinterpret_cast<float4 *>(strip + (p - prow0) * LD + 16 * nt + 4 * q);
+                const float4 e = *dst;
+                *dst = make_float4(d.x + e.x, d.y + e.y, d.z + e.z, d.w + e.w);
+            }
+        };
+    };
     static_assert(64 % C4 == 0, "channel quad of a lane must not depend on the load index");
     float amax = 0.f;
-    dfx_h8 ahi[NT][KC], alo[NT][KC];
-    float4 biasr[NT];
     int64_t rl = (int64_t)blockIdx.x * DFX_TAIL_WAVES + wave;
-    if (rl < A.R) issue(rl);
+    if (rl < A.R) issue(dfx_row(A.rm, rl));
     for (; rl < A.R; rl += (int64_t)gridDim.x * DFX_TAIL_WAVES) {
         const int64_t r = dfx_row(A.rm, rl);
         int lq = lane % C4;
         DFX_OPAQUE(lq);
-        {   // convt3's input, conv2p(e2), conv1p(e1) into the strips
-            const float4 a3 = sks[lq], b3 = sks[C4 + lq], a2 = sks[2 * C4 + lq], b2 = sks[3 * C4 + lq], a1 = sks[4 * C4 + lq], b1 = sks[5 * C4 + lq];
+        float4 r1[NV1];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NV1; ++i) {
+            const int idx = lane + 64 * i;
+            r1[i] = idx < N1 ? p1[r * N1 + idx] : z4;
+        }
+        {   // convt3's input and conv2p(e2) into X
+            const float4 a3 = sks[lq], b3 = sks[C4 + lq], a2 = sks[2 * C4 + lq], b2 = sks[3 * C4 + lq];
+#pragma unroll
+            for (int i = 0; i < NV3; ++i) {
                 const int idx = lane + 64 * i;
-                if (idx < n3) {
+                if (idx < N3) {
                     const int row = idx / C4, c4 = idx - row * C4;
                     const float4 pv = path(r3[i], a3, b3);
                     *reinterpret_cast<float4 *>(X + row * LD + 4 * c4) = make_float4(rd[i].x + pv.x, rd[i].y + pv.y, rd[i].z + pv.z, rd[i].w + pv.w);
                     *reinterpret_cast<float4 *>(X + (E4 + row) * LD + 4 * c4) = path(r2[i], a2, b2);
                 }
             }
+        }
+        DFX_WAVE_SYNC();
+        // ---- convt3: X[0, 8) -> += into X[8, 16)
+        dfx_chain_tile_h3_lds<C, DFX_PW_MODE_DW3>(X, E4, 1, 0, E4, dws, wfr, bis, A.unscale[0], amax, lane, add_into(X + E4 * LD, 0));
+        {   // conv1p(e1) into Y
+            const float4 a1 = sks[4 * C4 + lq], b1 = sks[5 * C4 + lq];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NV1; ++i) {
                 const int idx = lane + 64 * i;
-                if (idx < n1) {
+                if (idx < N1) {
                     const int row = idx / C4, c4 = idx - row * C4;
                     *reinterpret_cast<float4 *>(Y + row * LD + 4 * c4) = path(r1[i], a1, b1);
                 }
             }
         }
-        issue_e0(r);
-        DFX_WAVE_SYNC();
-        // ---- convt3: X[0, E/4) -> += into X[E/4, E/2)
-        dfx_chain_load_w_h3<C>(wfr, reinterpret_cast<const float *>(bis), lane, ahi, alo, biasr);
-        {
-            float *dst0 = X + E4 * LD;
-            auto epi = [&](int p, bool valid, int nt, float4 d) {
-                if (valid) {
-                    float4 *dst = reinterpret_cast<float4 *>(dst0 + p * LD + 16 * nt + 4 * q);
-                    const float4 e = *dst;
-                    *dst = make_float4(d.x + e.x, d.y + e.y, d.z + e.z, d.w + e.w);
-                }
-            };
-            dfx_chain_stage_h3<C, DFX_PW_MODE_DW3>(X, E4, E4, 1, E4, dws, ahi, alo, biasr, A.unscale[0], amax, lane, epi);
-        }
-        DFX_WAVE_SYNC();
-        // ---- convt2: X[E/4, E/2) -> += into Y[0, E/2)
-        dfx_chain_load_w_h3<C>(wfr + DFX_TAIL_WFRAG(C), reinterpret_cast<const float *>(bis + C4), lane, ahi, alo, biasr);
-        {
-            auto epi = [&](int p, bool valid, int nt, float4 d) {
-                if (valid) {
-                    float4 *dst = reinterpret_cast<float4 *>(Y + p * LD + 16 * nt + 4 * q);
-                    const float4 e = *dst;
-                    *dst = make_float4(d.x + e.x, d.y + e.y, d.z + e.z, d.w + e.w);
-                }
-            };
-            dfx_chain_stage_h3<C, DFX_PW_MODE_DWT3>(X + E4 * LD, E4, E1, 2, E1, dws + 3 * C4, ahi, alo, biasr, A.unscale[1], amax, lane, epi);
-        }
-        DFX_WAVE_SYNC();
-        {   // conv0p(e0) over all of X (its former contents are dead), then the next frame's operands are requested
-            const float4 a0 = sks[6 * C4 + lq], b0 = sks[7 * C4 + lq];
+        float4 r0[NV0];   // e0, one 16-position tile at a time: tile 0 requested here (needed after convt2), tile 1 when tile 0 has been stored
+        auto issue_e0 = [&](int t) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NV0; ++i) {
                 const int idx = lane + 64 * i;
-                if (idx < n0) {
+                r0[i] = idx < N0T ? p0[(r * 2 + t) * N0T + idx] : z4;
+            }
+        };
+        issue_e0(0);
+        DFX_WAVE_SYNC();
+        // ---- convt2: X[8, 16) -> += into Y[0, 16)
+        dfx_chain_tile_h3_lds<C, DFX_PW_MODE_DWT3>(X + E4 * LD, E4, 2, 0, E1, dws + 3 * C4, wfr + DFX_TAIL_WFRAG(C), bis + C4, A.unscale[1], amax, lane,
+                                                   add_into(Y, 0));
+        DFX_WAVE_SYNC();
+        // ---- convt1 + conv0_out, one 16-position tile at a time through X
+        const float4 a0 = sks[6 * C4 + lq], b0 = sks[7 * C4 + lq];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int i = 0; i < NV0; ++i) {
+                const int idx = lane + 64 * i;
+                if (idx < N0T) {
                     const int row = idx / C4, c4 = idx - row * C4;
                     *reinterpret_cast<float4 *>(X + row * LD + 4 * c4) = path(r0[i], a0, b0);
                 }
             }
-        }
-        const int64_t next = rl + (int64_t)gridDim.x * DFX_TAIL_WAVES;
-        if (next < A.R) issue(next);
-        DFX_WAVE_SYNC();
-        // ---- convt1: Y[0, E/2) -> += into X[0, E)
-        dfx_chain_load_w_h3<C>(wfr + 2 * DFX_TAIL_WFRAG(C), reinterpret_cast<const float *>(bis + 2 * C4), lane, ahi, alo, biasr);
-        {
-            auto epi = [&](int p, bool valid, int nt, float4 d) {
-                if (valid) {
-                    float4 *dst = reinterpret_cast<float4 *>(X + p * LD + 16 * nt + 4 * q);
-                    const float4 e = *dst;
-                    *dst = make_float4(d.x + e.x, d.y + e.y, d.z + e.z, d.w + e.w);
-                }
-            };
-            dfx_chain_stage_h3<C, DFX_PW_MODE_DWT3>(Y, E1, E, 2, E, dws + 6 * C4, ahi, alo, biasr, A.unscale[2], amax, lane, epi);
-        }
-        DFX_WAVE_SYNC();
-        for (int i = lane; i < 3 * E; i += 64) {  // V[p][j] = sum_c wo[j][c] * xin[p][c]
-            const int p = i / 3, j = i - 3 * p;
-            const float4 *xrow = reinterpret_cast<const float4 *>(X + p * LD);
-            float acc = 0.f;
-#pragma unroll 4
-            for (int c = 0; c < C4; ++c) {
-                const float4 x = xrow[c], w = wos[j * C4 + c];
-                acc += w.x * x.x;
-                acc += w.y * x.y;
-                acc += w.z * x.z;
-                acc += w.w * x.w;
+            if (t == 0) {
+                issue_e0(1);
+            } else {   // the next frame's first operands: in flight during this frame's last tile
+                const int64_t next = rl + (int64_t)gridDim.x * DFX_TAIL_WAVES;
+                if (next < A.R) issue(dfx_row(A.rm, next));
             }
-            V[i] = acc;
+            DFX_WAVE_SYNC();
+            dfx_chain_tile_h3_lds<C, DFX_PW_MODE_DWT3>(Y, E1, 2, 16 * t, E, dws + 6 * C4, wfr + 2 * DFX_TAIL_WFRAG(C), bis + 2 * C4, A.unscale[2], amax, lane,
+                                                       add_into(X, 16 * t));
+            DFX_WAVE_SYNC();
+            // V[p][j] = sum_c wo[j][c] * xin[p][c] for the tile's 16 positions: 48 values, parked in the pad columns of Y (tile 0) / X (tile 1)
+            float vacc = 0.f;
+            if (lane < 48) {
+                const int p = lane / 3, j = lane - 3 * p;
+                const float4 *xrow = reinterpret_cast<const float4 *>(X + p * LD);
+#pragma unroll 4
+                for (int c = 0; c < C4; ++c) {
+                    const float4 x = xrow[c], w = wos[j * C4 + c];
+                    vacc += w.x * x.x;
+                    vacc += w.y * x.y;
+                    vacc += w.z * x.z;
+                    vacc += w.w * x.w;
+                }
+            }
+            DFX_WAVE_SYNC();   // (the row reads above are done before a pad column of X is written)
+            if (lane < 48) (t == 0 ? Y : X)[(lane >> 2) * LD + C + (lane & 3)] = vacc;
         }
         DFX_WAVE_SYNC();
-        for (int f = lane; f < E; f += 64) {
-            float acc = A.bias_o + V[f * 3 + 1];
-            if (f > 0) acc += V[(f - 1) * 3 + 0];
-            if (f < E - 1) acc += V[(f + 1) * 3 + 2];
+        if (lane < E) {
+            auto V = [&](int p, int j) -> float {
+                const int i = (p & 15) * 3 + j;
+                return (p < 16 ? Y : X)[(i >> 2) * LD + C + (i & 3)];
+            };
+            const int f = lane;
+            float acc = A.bias_o + V(f, 1);
+            if (f > 0) acc += V(f - 1, 0);
+            if (f < E - 1) acc += V(f + 1, 2);
             A.out[r * E + f] = dfx_sigmoid(acc);
         }
         DFX_WAVE_SYNC();  // the strips are rewritten by the next frame
