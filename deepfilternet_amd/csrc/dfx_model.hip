@@ -311,6 +311,10 @@ struct dfx_model {
     int fan_chunks = 0;            // super-chunks of 32 hidden columns (0: not available)
     int fan_kind[3] = {0, 0, 0};   // per consumer (dec_in, dfg_in, df_skip): 0 absent, 1 narrow (32 -> 16 groups), 2 wide (64 -> 32 groups)
     bool fuse_emb = true;
+    // dfx_k_enc_fan (df_fc_emb + the encoder GRU's linear_in in one pass over c1): fragment offsets, 0 groups = shapes do not nest
+    size_t efan_w1 = 0, efan_w2 = 0;
+    int efan_groups = 0;
+    bool fuse_encfan = true;       // DFX_FUSE_ENCFAN=0 (dev A/B): df_fc_emb and linear_in as two grouped GEMMs while the rest of DFX_FUSE_EMB stays on
     bool fuse_dfa = true;          // DFX_FUSE_DFA=0: deep filter and ISTFT of enhance() as two kernels with spec_e between them
     // The ERB decoder's convolutions as ONE launch (dfx_k_erb_tail: d3 / d2 / d1 stay in LDS, -12 KB per frame beside the GRU chain);
     // DFX_FUSE_TAIL=0: three launches (convt3, convt2, convt1 + conv0_out).  Measured at config 2 (profiles/r03_fusion_ab.log): the first
@@ -554,6 +558,26 @@ void pack_fan(Prep &P, dfx_model *m) {
         }
     m->fan_w = off;
     m->fan_chunks = nj;
+}
+// Fragments of dfx_k_enc_fan: df_fc_emb in groups of 96 -> 16 (enc_lin_groups = 32 over 3072 -> 512) feeding linear_in of the encoder GRU in
+// groups of 32 -> 16 (lin_groups = 16 over 512 -> 256), i.e. two groups of the first per group of the second.
+//   w1 (g, i), lane (m, kq), component s: W_fc[g][16 i + 4 kq + s][m];   w2 (h, t), component r: W_in[h][16 t + 4 kq + r][m]
+void pack_encfan(Prep &P, dfx_model *m) {
+    const GlinW &a = m->fc_emb, &b = m->enc_in;
+    if (a.Kg != 96 || a.Ng != 16 || a.G % 2 != 0 || b.G * 2 != a.G || b.Kg != 32 || b.Ng != 16) return;
+    const size_t o1 = P.alloc((size_t)a.G * 6 * 64 * 4);
+    const size_t o2 = P.alloc((size_t)b.G * 2 * 64 * 4);
+    for (int l = 0; l < 64; ++l) {
+        const int mm = l & 15, kq = l >> 4;
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            for (int g = 0; g < a.G; ++g)
+                for (int i = 0; i < 6; ++i) P.out[o1 + (((size_t)g * 6 + i) * 64 + l) * 4 + sidx] = P.out[a.w + ((size_t)g * 96 + 16 * i + 4 * kq + sidx) * 16 + mm];
+            for (int h = 0; h < b.G; ++h)
+                for (int t = 0; t < 2; ++t) P.out[o2 + (((size_t)h * 2 + t) * 64 + l) * 4 + sidx] = P.out[b.w + ((size_t)h * 32 + 16 * t + 4 * kq + sidx) * 16 + mm];
+        }
+    }
+    m->efan_w1 = o1, m->efan_w2 = o2;
+    m->efan_groups = a.G;
 }
 bool prep_gru(Prep &P, const std::string &name, int layers, std::vector<GruW> &out) {
     const int H = 256;
@@ -830,6 +854,7 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
     if (ok && c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) ok = prep_glin(P, "df_dec.df_skip.weight", m->df_skip);
     ok = ok && prep_glin(P, "df_dec.df_out.0.weight", m->df_out);
     if (ok) pack_fan(P, m);
+    if (ok) pack_encfan(P, m);
     if (!ok) {
         delete m;
         DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_create: %s", P.err.empty() ? "weight preparation failed" : P.err.c_str());
@@ -868,6 +893,8 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         m->gru_seq = !(gq && gq[0] == '0') && !dfx_env_is_emulator();
         const char *fem = getenv("DFX_FUSE_EMB");
         m->fuse_emb = !(fem && fem[0] == '0');
+        const char *fef = getenv("DFX_FUSE_ENCFAN");
+        m->fuse_encfan = !(fef && fef[0] == '0');
         const char *fdf = getenv("DFX_FUSE_DFA");
         m->fuse_dfa = !(fdf && fdf[0] == '0');
         const char *ftl = getenv("DFX_FUSE_TAIL");
@@ -1587,6 +1614,30 @@ static int launch_glin(const dfx_model *m, const GlinW &g, const float *a, int a
     return launch_ggemm(a, g.G * g.Kg, m->p(g.w), g.G, g.Kg, g.Ng, nullptr, act, res, out, g.G * g.Ng, M, s, 0, 0, 1, rm, a2);
 }
 
+// df_fc_emb (+ e3) and the encoder GRU's linear_in in one pass over c1 (dfx_k_enc_fan)
+static int launch_enc_fan(const dfx_model *m, const float *c1, const float *e3, float *emb_out, float *xa, int64_t M, hipStream_t s, DfxRowMap rm) {
+    DfxEncFanArgs A;
+    A.c1 = c1;
+    A.w1 = reinterpret_cast<const float4 *>(m->p(m->efan_w1));
+    A.w2 = reinterpret_cast<const float4 *>(m->p(m->efan_w2));
+    A.e3 = e3;
+    A.emb_out = emb_out;
+    A.out = xa;
+    A.R = M;
+    A.ng = m->efan_groups;
+    A.rm = rm;
+    DfxKScope ks(DFX_K_GGEMM, s);
+    if (M > 16384) {
+        constexpr int RT = 2;
+        A.parts = 1;
+        dfx_launch(dfx_k_enc_fan<RT>, dim3((unsigned)nn_grid(dfx_ceil_div(dfx_ceil_div(M, 16 * RT), 4), 8)), dim3(256), 0, s, A);
+    } else {   // few rows (a streaming hop: 4096): one wave per (16 rows, pair of groups)
+        A.parts = A.ng / 2;
+        dfx_launch(dfx_k_enc_fan<1>, dim3((unsigned)nn_grid(dfx_ceil_div(dfx_ceil_div(M, 16) * A.parts, 4), 8)), dim3(256), 0, s, A);
+    }
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
+}
 // emb and everything that reads it, in one pass over the encoder GRU's output (dfx_k_emb_fan); outs[c] null = consumer not wanted
 static int launch_emb_fan(const dfx_model *m, const float *y, const float *res, float *emb_out, float *dec_x, float *dfg_x, float *skp,
                           float *lsnr, int64_t M, hipStream_t s, DfxRowMap rm) {
@@ -1963,8 +2014,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     auto cemb_range = [&](int64_t Rk, DfxRowMap rm, hipStream_t st) -> int {
         return launch_glin(m, m->fc_emb, c1, DFX_ACT_RELU, nullptr, emb_in, Rk, st, rm);
     };
+    // (DFX_FUSE_EMB=0 also restores the two grouped GEMMs of the front)
+    const bool enc_fan = m->fuse_emb && m->fuse_encfan && m->efan_groups > 0 && !c.enc_concat && !split_emb && !m->exact_fp32 && emb == 16 * m->efan_groups;
     auto emb_range = [&](int64_t Rk, DfxRowMap rm, hipStream_t st) -> int {
         int r;
+        if (enc_fan) return launch_enc_fan(m, c1, e3, c.emb_gru_skip_enc != DFX_SKIP_NONE ? emb_in : nullptr, xa, Rk, st, rm);
         if (split_emb) return launch_glin(m, m->enc_in, emb_in, DFX_ACT_RELU, nullptr, xa, Rk, st, rm, e3);
         if (c.enc_concat) {  // emb = cat(e3.flatten, cemb) (deepfilternet3.py:132-134,181): e3 rows into the left half, cemb written into the right half
             if ((r = stream_copy_rows(e3, emb, emb, 0, emb_in, 2 * emb, emb, R, st))) return r;   // (all rows: enc_concat excludes the ranged front)

@@ -2646,6 +2646,108 @@ __global__ void __launch_bounds__(256, 2) dfx_k_emb_fan(DfxFanArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// dfx_k_enc_fan: the two grouped linears at the end of the encoder front in one pass over c1 (deepfilternet3.py:179-182, modules.py:702-738):
+//     emb_in = relu(df_fc_emb(c1.flatten)) + e3.flatten          c1 [R, 3072] -> [R, 512]    (32 groups of 96 -> 16)
+//     xa     = relu(linear_in(emb_in))                            -> [R, 256]                 (16 groups of 32 -> 16): the encoder GRU's input
+// Same register-chained exact fp32 matrix ops as dfx_k_emb_fan (the D fragment of the first product is the B operand of the second):
+// emb_in (2 KB per frame written and read back on the front's critical path) only exists in registers unless a skip connection of the
+// encoder GRU needs it, and the front loses a launch.  A wave owns 16 * RT rows and walks the 32 groups of df_fc_emb; the 96 inputs of a
+// group are one 384-byte run per row (six float4 per lane quad).  The next group's operands are requested before the current one's
+// matrix ops.
+// ---------------------------------------------------------------------------------------------------------------------
+struct DfxEncFanArgs {
+    const float *c1;            // [R, 96 * ng]
+    const float4 *w1;           // [ng][6][64] (pack_encfan)
+    const float4 *w2;           // [ng / 2][2][64]
+    const float *e3;            // [R, 16 * ng]: added after the ReLU
+    float *emb_out;             // [R, 16 * ng] or null
+    float *out;                 // [R, 8 * ng]
+    int64_t R;
+    int ng;                     // groups of df_fc_emb (even)
+    int parts;                  // a row tile's groups are dealt to this many waves (divides ng / 2): few rows (a streaming hop) then still fill the chip
+    DfxRowMap rm;
+};
+template <int RT>
+__global__ void __launch_bounds__(256, 2) dfx_k_enc_fan(DfxEncFanArgs A) {
+    const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
+    const int K = 96 * A.ng, EMB = 16 * A.ng, H = 8 * A.ng;
+    const int64_t ntile = (A.R + 16 * RT - 1) / (16 * RT);
+    const int gper = A.ng / A.parts;   // (even)
+    for (int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); item < ntile * A.parts; item += (int64_t)gridDim.x * 4) {
+        const int64_t tile = item / A.parts;
+        const int g0 = (int)(item - tile * A.parts) * gper, g1 = g0 + gper;
+        int64_t prow[RT];
+        bool ok[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int64_t lr = tile * (16 * RT) + 16 * rt + n;
+            ok[rt] = lr < A.R;
+            prow[rt] = ok[rt] ? dfx_row(A.rm, lr) : 0;
+        }
+        float4 wn[6], yn[RT][6];
+        auto request = [&](int g) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) wn[i] = A.w1[((size_t)g * 6 + i) * 64 + lane];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    yn[rt][i] = ok[rt] ? *reinterpret_cast<const float4 *>(A.c1 + prow[rt] * K + 96 * g + 16 * i + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        request(g0);
+        float e[RT][2][4];   // emb_in features 16 g + 4 q + r of the two groups of the current pair
+        for (int g = g0; g < g1; ++g) {
+            float4 w[6], y[RT][6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) w[i] = wn[i];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) y[rt][i] = yn[rt][i];
+            const int t = g & 1;
+            float4 w2[2];
+            if (t) {
+                w2[0] = A.w2[((size_t)(g >> 1) * 2 + 0) * 64 + lane];
+                w2[1] = A.w2[((size_t)(g >> 1) * 2 + 1) * 64 + lane];
+            }
+            if (g + 1 < g1) request(g + 1);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const float ws[4] = {w[i].x, w[i].y, w[i].z, w[i].w}, ys[4] = {y[rt][i].x, y[rt][i].y, y[rt][i].z, y[rt][i].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) d = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[k], ys[k], d, 0, 0, 0);
+                }
+                const int64_t eoff = prow[rt] * EMB + 16 * g + 4 * q;
+                float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok[rt]) rv = *reinterpret_cast<const float4 *>(A.e3 + eoff);
+                float ev[4] = {fmaxf(d[0], 0.f) + rv.x, fmaxf(d[1], 0.f) + rv.y, fmaxf(d[2], 0.f) + rv.z, fmaxf(d[3], 0.f) + rv.w};
+                if (A.emb_out && ok[rt]) *reinterpret_cast<float4 *>(A.emb_out + eoff) = make_float4(ev[0], ev[1], ev[2], ev[3]);
+                if (t == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) e[rt][0][r] = ev[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) e[rt][1][r] = ev[r];
+                    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const float ws[4] = {w2[tt].x, w2[tt].y, w2[tt].z, w2[tt].w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[r], e[rt][tt][r], o, 0, 0, 0);
+                    }
+                    if (ok[rt])
+                        *reinterpret_cast<float4 *>(A.out + prow[rt] * H + 16 * (g >> 1) + 4 * q) =
+                            make_float4(fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f));
+                }
+            }
+        }
+    }
+}
+
 // enc.lsnr_fc: Linear(emb -> 1) + Sigmoid, scaled to [lsnr_min, lsnr_max] (deepfilternet3.py:163-165,184).  One wave per row.
 __global__ void dfx_k_lsnr(const float *emb, const float *w, float bias, float scale, float offset, float *out, int64_t R,
                            int D) {
