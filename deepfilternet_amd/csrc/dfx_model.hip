@@ -80,6 +80,7 @@ struct GruW {
     float wih_unscale = 1.f;
     size_t whh_h3 = 0;      // W_hh as pre-scaled f16 hi/lo MFMA fragments (dfx_k_gru_rec_h3)
     float whh_unscale = 1.f;
+    size_t whh_pj = 0;      // W_hh in the projection kernel's fragment order (dfx_k_gru_step_h3: one time step of many streams), same scale
 };
 struct GlinW {
     size_t w = 0;
@@ -123,6 +124,7 @@ struct DfxStreamCtx {
     int64_t t_zero;    // local frames < t_zero precede the start of the stream (df_convp sees zero padding there)
     int64_t spec_T;    // frames per clip of the spec array
     float *h_state;    // [GRU layers][B][256], in model order enc, erb_dec, df_dec
+    float *h_next = nullptr;   // non-null (one new frame, ungated): the layers run as dfx_k_gru_step_h3 and leave their new states HERE
     float pf_beta;     // < 0: the model's setting
     float *out;        // [B, out_T, F][2]: local frame t of clip b is stored at frame t - out_toff
     int64_t out_T, out_toff;
@@ -631,6 +633,23 @@ bool prep_gru(Prep &P, const std::string &name, int layers, std::vector<GruW> &o
                                 dst[((frag + 1) * 64 + l) * 8 + i] = lb;
                             }
         }
+        auto pack_whh_pj = [&](float sc) {   // W_hh in the same fragment order (dfx_k_gru_step_h3)
+            g.whh_pj = P.alloc((size_t)3 * H * H);
+            uint16_t *dst = reinterpret_cast<uint16_t *>(&P.out[g.whh_pj]);
+            for (int ch = 0; ch < 3 * H / 64; ++ch)
+                for (int kc = 0; kc < 8; ++kc)
+                    for (int ct = 0; ct < 4; ++ct)
+                        for (int l = 0; l < 64; ++l)
+                            for (int i = 0; i < 8; ++i) {
+                                const int n = ch * 64 + ct * 16 + (l & 15), k = 32 * kc + 8 * (l >> 4) + i;
+                                const float w = whh[(size_t)n * H + k] * sc;
+                                const uint16_t hb = dfx_f32_to_f16_bits(w);
+                                const uint16_t lb = dfx_f32_to_f16_bits(w - dfx_f16_bits_to_f32(hb));
+                                const size_t frag = (((size_t)ch * 8 + kc) * 4 + ct) * 2;
+                                dst[((frag + 0) * 64 + l) * 8 + i] = hb;
+                                dst[((frag + 1) * 64 + l) * 8 + i] = lb;
+                            }
+        };
         {   // W_hh fragments for dfx_k_gru_rec_h3: [16-unit tile][k-chunk][gate][hi,lo][lane][8]
             float mx = 0.f;
             for (size_t i = 0; i < (size_t)3 * H * H; ++i) mx = fmaxf(mx, fabsf(whh[i]));
@@ -644,6 +663,7 @@ bool prep_gru(Prep &P, const std::string &name, int layers, std::vector<GruW> &o
             }
             const float sc = ldexpf(1.f, e);
             g.whh_unscale = ldexpf(1.f, -e);
+            pack_whh_pj(sc);
             g.whh_h3 = P.alloc((size_t)3 * H * H);  // 2 halves per weight
             uint16_t *dst = reinterpret_cast<uint16_t *>(&P.out[g.whh_h3]);
             for (int ut = 0; ut < 16; ++ut)          // 16-unit tile
@@ -1603,8 +1623,19 @@ static int launch_proj_h3(const dfx_model *m, const GruW &g, const float *a, flo
         DFX_LAUNCH_CHECK();
         return DFX_OK;
     }
+    // few row blocks (a streaming hop): the 64-column chunks of W are dealt to `parts` workgroups per row block — one workgroup per CU
+    // (128 KB of LDS each) — so that the launch covers the chip instead of nblk CUs streaming all of W each (DFX_PROJ_PARTS=n: dev)
+    {
+        static const int parts_env = [] { const char *e = getenv("DFX_PROJ_PARTS"); return e ? atoi(e) : 0; }();
+        const int nch = N / DFX_PH_NC;
+        int parts = 1;
+        for (int d = 1; d <= nch; ++d)
+            if (nch % d == 0 && nblk * d <= dfx_env_num_cus()) parts = d;
+        if (parts_env > 0 && nch % parts_env == 0) parts = parts_env;
+        A.parts = parts;
+    }
     DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_proj256_h3, DFX_PH_SMEM));
-    dfx_launch(dfx_k_proj256_h3, dim3((unsigned)nblk), dim3(DFX_PH_THREADS), DFX_PH_SMEM, s, A);
+    dfx_launch(dfx_k_proj256_h3, dim3((unsigned)(nblk * A.parts)), dim3(DFX_PH_THREADS), DFX_PH_SMEM, s, A);
     DFX_LAUNCH_CHECK();
     return DFX_OK;
 }
@@ -1655,14 +1686,21 @@ static int launch_emb_fan(const dfx_model *m, const float *y, const float *res, 
     A.R = M;
     A.nj = m->fan_chunks;
     A.rm = rm;
-    constexpr int RT = 2;
-    const int64_t tiles = dfx_ceil_div(M, 16 * RT);
-    const dim3 grid((unsigned)nn_grid(dfx_ceil_div(tiles, 4), 8));
     DfxKScope ks(DFX_K_EMB_FAN, s);
     // (the kinds are what pack_fan accepted: dec_in narrow, dfg_in wide, df_skip narrow; a consumer that is not wanted drops out)
-    if (dfg_x && skp) dfx_launch((dfx_k_emb_fan<RT, 1, 2, 1>), grid, dim3(256), 0, s, A);
-    else if (dfg_x) dfx_launch((dfx_k_emb_fan<RT, 1, 2, 0>), grid, dim3(256), 0, s, A);
-    else dfx_launch((dfx_k_emb_fan<RT, 1, 0, 0>), grid, dim3(256), 0, s, A);
+    if (M > 16384) {
+        constexpr int RT = 2;
+        const dim3 grid((unsigned)nn_grid(dfx_ceil_div(dfx_ceil_div(M, 16 * RT), 4), 8));
+        if (dfg_x && skp) dfx_launch((dfx_k_emb_fan<RT, 1, 2, 1>), grid, dim3(256), 0, s, A);
+        else if (dfg_x) dfx_launch((dfx_k_emb_fan<RT, 1, 2, 0>), grid, dim3(256), 0, s, A);
+        else dfx_launch((dfx_k_emb_fan<RT, 1, 0, 0>), grid, dim3(256), 0, s, A);
+    } else {   // few rows (a streaming hop): one row tile per wave — twice the waves, half the serial matrix work per wave
+        constexpr int RT = 1;
+        const dim3 grid((unsigned)nn_grid(dfx_ceil_div(dfx_ceil_div(M, 16 * RT), 4), 8));
+        if (dfg_x && skp) dfx_launch((dfx_k_emb_fan<RT, 1, 2, 1>), grid, dim3(256), 0, s, A);
+        else if (dfg_x) dfx_launch((dfx_k_emb_fan<RT, 1, 2, 0>), grid, dim3(256), 0, s, A);
+        else dfx_launch((dfx_k_emb_fan<RT, 1, 0, 0>), grid, dim3(256), 0, s, A);
+    }
     DFX_LAUNCH_CHECK();
     return DFX_OK;
 }
@@ -1738,13 +1776,31 @@ static int launch_wait_ge(const dfx_model *m, const unsigned int *flags, int n, 
 // hstate != null (streaming): layer l continues from / leaves its state in hstate + l*B*256 and only the frames [t0, T) are run
 static int run_gru_stack(const dfx_model *m, const std::vector<GruW> &layers, const float *x, float *bufa, float *bufb,
                          float *gi, int64_t B, int64_t T, const float **y, hipStream_t s, float *hstate = nullptr, int64_t t0 = 0,
-                         DfxRowMap rm = DfxRowMap{0, 0, 0}) {
+                         DfxRowMap rm = DfxRowMap{0, 0, 0}, float *hnext = nullptr) {
     const int64_t R = B * (T - t0);
     if (hstate && m->exact_fp32) DFX_FAIL(DFX_ERR_UNSUPPORTED, "streaming needs the fp16-split GRU kernels (unset DFX_EXACT_FP32)");
     const float *in = x;
     float *outb = (x == bufa) ? bufb : bufa;
     for (size_t l = 0; l < layers.size(); ++l) {
         const GruW &g = layers[l];
+        if (hstate && hnext && T - t0 == 1 && !m->exact_fp32) {   // one time step of many streams: projection + recurrence + gates in one launch
+            DfxGstArgs A;
+            A.x = in, A.xrm = rm;
+            A.h_in = hstate + l * B * 256, A.h_out = hnext + l * B * 256;
+            A.y = outb, A.yrm = rm;
+            A.wif = reinterpret_cast<const dfx_h8 *>(m->p(g.wih_h3));
+            A.whf = reinterpret_cast<const dfx_h8 *>(m->p(g.whh_pj));
+            A.bias_i = m->p(g.bias_i), A.bhn = m->p(g.bhn);
+            A.unscale_i = g.wih_unscale, A.unscale_h = g.whh_unscale;
+            A.B = B;
+            DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_step_h3, DFX_PH_SMEM));
+            DfxKScope ks(DFX_K_GRU_REC, s);
+            dfx_launch(dfx_k_gru_step_h3, dim3((unsigned)(dfx_ceil_div(B, DFX_PH_BM) * 4)), dim3(DFX_PH_THREADS), DFX_PH_SMEM, s, A);
+            DFX_LAUNCH_CHECK();
+            in = outb;
+            outb = (outb == bufa) ? bufb : bufa;
+            continue;
+        }
         if (m->exact_fp32) {
             if (int rc = launch_proj(in, m->p(g.wih_t), m->p(g.bias_i), gi, R, 768, s)) return rc;
         } else {
@@ -2085,9 +2141,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     // ---- GRU phase (planned above)
     float *hs_enc = sc ? sc->h_state : nullptr, *hs_dec = sc ? sc->h_state + (int64_t)nenc * B * 256 : nullptr;
     float *hs_df = sc ? sc->h_state + (int64_t)(nenc + ndec) * B * 256 : nullptr;
+    float *hn_enc = sc && sc->h_next ? sc->h_next : nullptr, *hn_dec = hn_enc ? hn_enc + (int64_t)nenc * B * 256 : nullptr;
+    float *hn_df = hn_enc ? hn_enc + (int64_t)(nenc + ndec) * B * 256 : nullptr;
     if (!pipe) {
         const float *y = nullptr;
-        if ((rc = run_gru_stack(m, m->enc_gru, xa, xa, xb, gi, B, T, &y, s, hs_enc, t_begin, rmw))) return rc;
+        if ((rc = run_gru_stack(m, m->enc_gru, xa, xa, xb, gi, B, T, &y, s, hs_enc, t_begin, rmw, hn_enc))) return rc;
         float *dec_x = y == xa ? xb : xa;   // input of the ERB decoder's GRU stack
         if (fan) {
             if ((rc = emb_fan(y, dec_x, Rn, s, rmw))) return rc;
@@ -2111,7 +2169,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         if (run_df) {
             const float *y2 = nullptr;
             if (!fan && (rc = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, Rn, x1, rmw))) return rc;
-            if ((rc = run_gru_stack(m, m->df_gru, xa2, xa2, xb2, gi2, B, T, &y2, x1, hs_df, t_begin, rmw))) return rc;
+            if ((rc = run_gru_stack(m, m->df_gru, xa2, xa2, xb2, gi2, B, T, &y2, x1, hs_df, t_begin, rmw, hn_df))) return rc;
             const float *cfeat = y2, *cfeat2 = nullptr;
             if (fan_skp) {
                 cfeat2 = xdf;   // df_skip(emb), written by dfx_k_emb_fan
@@ -2134,7 +2192,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         }
         // ---- ErbDecoder on s (:245-254)
         if (!fan && (rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, dec_x, Rn, s, rmw))) return rc;
-        if ((rc = run_gru_stack(m, m->dec_gru, dec_x, xa, xb, gi, B, T, &y, s, hs_dec, t_begin, rmw))) return rc;
+        if ((rc = run_gru_stack(m, m->dec_gru, dec_x, xa, xb, gi, B, T, &y, s, hs_dec, t_begin, rmw, hn_dec))) return rc;
         if ((rc = dec_out_skip(y, Rn, s, rmw))) return rc;
         if (fuse_tail) {
             if ((rc = launch_erb_tail<C>(m, demb, e3, e2, e1, e0, mask, Rn, E, s, rmw))) return rc;
@@ -2776,9 +2834,18 @@ struct dfx_stream_state {
     size_t bytes = 0;
     // byte offsets into buf
     size_t ana_mem[2], syn_mem[2], erb_state, unit_state, hist_fe[2], hist_fs[2], hist_spec[2], new_spec, new_fe, new_fs, work_fe, work_fs,
-        work_spec, out_spec, h_state, lsnr, model_ws;
+        work_spec, out_spec, h_state, h_state2, lsnr, model_ws;
+    int hflip = 0;            // which of h_state / h_state2 holds the GRU states (the one-step kernel writes the other one: dfx_k_gru_step_h3)
     int64_t model_ws_bytes = 0;
     int flip = 0;             // which of the double-buffered STFT memories is current
+    // The rolling spectra of an ungated handle live in a LINEAR buffer [B, lin_cap, F] through which the window [lin_pos, lin_pos + Hs + n)
+    // slides: a call appends its n new frames and the deep filter reads the window in place (clip stride lin_cap frames); only when the
+    // window reaches the end are its last Hs frames moved back to the front (once per lin_cap - Hs - n hops).  The ring form below
+    // (hist_spec -> work_spec, dfx_k_ring_step) rewrites the whole window on every call — at 4096 streams 95 us of a 720 us hop — and stays
+    // for gated handles (a frozen stream's spectra must not move) and graph replay (fixed addresses).  lin_owns: which form holds the state.
+    size_t spec_lin = 0;
+    int64_t lin_cap = 0, lin_pos = 0;
+    bool lin_owns = false;
     // per-stream stage gating (dfx_stream_set_gating; DfTract::process, tract.rs:509-616,658-672): off by default
     bool gated = false;
     int channels = 1, reduce_mask = 2;    // multi-channel streams: ch consecutive rows per stream; ReduceMask::MEAN is the reference default
@@ -2853,7 +2920,18 @@ extern "C" int dfx_stream_create(const dfx_model *m, const dfx_state *st, int64_
     s->work_fs = take((size_t)B * (H + n) * Fd * 8);
     s->work_spec = take((size_t)B * (Hs + n) * F * 8);
     s->out_spec = take((size_t)B * n * F * 8);
+    {   // linear rolling-spectra buffer: slack of at least one window (so that the move back to the front never overlaps), at most ~1 GB
+        static const int lin_env = [] { const char *e = getenv("DFX_STREAM_LINEAR"); return e ? atoi(e) : 1; }();
+        int64_t slack = lin_env > 1 ? lin_env : 32;   // (DFX_STREAM_LINEAR=0: ring form only; = n > 1: slack of n frames, tests)
+        while (slack > Hs + n && (size_t)B * (Hs + n + slack) * F * 8 > ((size_t)1 << 30)) slack /= 2;
+        if (slack < Hs + n) slack = Hs + n;
+        if (lin_env && (size_t)B * (Hs + n + slack) * F * 8 <= ((size_t)3 << 29)) {
+            s->lin_cap = Hs + n + slack;
+            s->spec_lin = take((size_t)B * s->lin_cap * F * 8);
+        }
+    }
     s->h_state = take((size_t)s->layers * B * 256 * 4);
+    s->h_state2 = take((size_t)s->layers * B * 256 * 4);
     s->lsnr = take((size_t)B * (H + n) * 4);
     s->x_in = take((size_t)B * n * st->hop * 4);
     s->y_out = take((size_t)B * n * st->hop * 4);
@@ -2920,6 +2998,9 @@ extern "C" int dfx_stream_reset(dfx_stream_state *s, void *stream) {
     if (s->gate_buf) DFX_HIP(hipMemset(s->gate_buf, 0, s->gate_bytes));  // skip counters, c0 windows (zero = the causal padding)
     s->frames = 0;
     s->flip = 0;
+    s->lin_pos = 0;
+    s->lin_owns = false;   // (both forms are all zeros now)
+    s->hflip = 0;
     return DFX_OK;
 }
 
@@ -3012,6 +3093,42 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     int rc;
     const bool gated = S->gated && S->gate_buf;
     if (gated && n != 1) DFX_FAIL(DFX_ERR_INVALID_ARG, "gated streaming passes carry one hop");
+    // ---- rolling spectra: linear (sliding window, see dfx_stream_state::spec_lin) or ring.  spec_window() brings the form this call uses
+    // up to date with the other one if that one holds the state, appends the call's new frames and returns the window [Hs + n frames]
+    // and the clip stride (in frames) the deep filter has to use.
+    const bool lin = S->lin_cap > 0 && !gated && !S->use_graph && !S->capturing;
+    const int64_t F2 = F * 2;
+    auto spec_window = [&](const float *new_spec, const float **win, int64_t *win_T) -> int {
+        int r;
+        if (lin) {
+            float *L0 = fp(S->spec_lin);
+            const int64_t cap = S->lin_cap;
+            if (!S->lin_owns) {   // the ring form's history becomes the window's first Hs frames
+                if ((r = stream_copy_rows(fp(S->hist_spec[S->flip]), Hs * F2, Hs * F2, 0, L0, cap * F2, Hs * F2, B, s))) return r;
+                S->lin_pos = 0;
+                S->lin_owns = true;
+            } else if (S->lin_pos + Hs + n > cap) {   // the window has reached the end: its last Hs frames go back to the front (no overlap: lin_pos >= Hs)
+                if ((r = stream_copy_rows(L0, cap * F2, cap * F2, S->lin_pos * F2, L0, cap * F2, Hs * F2, B, s))) return r;
+                S->lin_pos = 0;
+            }
+            if ((r = stream_copy_rows(new_spec, n * F2, n * F2, 0, L0 + (S->lin_pos + Hs) * F2, cap * F2, n * F2, B, s))) return r;
+            *win = L0 + S->lin_pos * F2;
+            *win_T = cap;
+            S->lin_pos += n;   // (advanced here, not by the caller: this form is never replayed from a graph nor walked hop by hop)
+            return DFX_OK;
+        }
+        if (S->lin_owns) {   // back to the ring form (gating was switched on): the window's last Hs frames are its history
+            if ((r = stream_copy_rows(fp(S->spec_lin), S->lin_cap * F2, S->lin_cap * F2, S->lin_pos * F2, fp(S->hist_spec[S->flip]), Hs * F2, Hs * F2, B, s))) return r;
+            S->lin_owns = false;
+        }
+        DfxKScope ks(DFX_K_COPY_ROWS, s);
+        dfx_launch(dfx_k_ring_step, dim3((unsigned)nn_grid(dfx_ceil_div(B * (Hs + n) * F2, 256), 16)), dim3(256), 0, s,
+                   (const float *)fp(S->hist_spec[S->flip]), new_spec, fp(S->work_spec), fp(S->hist_spec[S->flip ^ 1]), B, Hs, n, F2, (int64_t)0);
+        DFX_LAUNCH_CHECK();
+        *win = fp(S->work_spec);
+        *win_T = Hs + n;
+        return DFX_OK;
+    };
     if (S->lim == 1.f) {
         // tract.rs:509-543 with atten_lim == 1: the silent-input counter, the STFT analysis and the rolling spectra still advance (so
         // that switching the limit back mid-stream continues from the right history); features, network and synthesis do not run, the
@@ -3026,11 +3143,9 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         float *new_spec = fp(S->new_spec);
         if ((rc = dfx_launch_analysis(st, x, B, n * hop, xs, am_in, am_out, new_spec, nullptr, s))) return rc;
         {
-            DfxKScope ks(DFX_K_COPY_ROWS, s);
-            dfx_launch(dfx_k_ring_step, dim3((unsigned)nn_grid(dfx_ceil_div(B * (Hs + n) * F * 2, 256), 16)), dim3(256), 0, s,
-                       (const float *)fp(S->hist_spec[S->flip]), (const float *)new_spec, fp(S->work_spec), fp(S->hist_spec[S->flip ^ 1]), B, Hs, n,
-                       F * 2, (int64_t)0);
-            DFX_LAUNCH_CHECK();
+            const float *win = nullptr;
+            int64_t win_T = 0;
+            if ((rc = spec_window(new_spec, &win, &win_T))) return rc;
         }
         // what this path does not touch keeps its contents across the parity flip
         DFX_HIP(hipMemcpyAsync(fp(S->syn_mem[S->flip ^ 1]), fp(S->syn_mem[S->flip]), (size_t)B * ML * 4, hipMemcpyDeviceToDevice, s));
@@ -3065,7 +3180,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         DFX_LAUNCH_CHECK();
         DFX_HIP(hipMemcpyAsync(gp(S->g_sh_erb), fp(S->erb_state), (size_t)B * E * 4, hipMemcpyDeviceToDevice, s));
         DFX_HIP(hipMemcpyAsync(gp(S->g_sh_unit), fp(S->unit_state), (size_t)B * Fd * 4, hipMemcpyDeviceToDevice, s));
-        DFX_HIP(hipMemcpyAsync(gp(S->g_sh_h), fp(S->h_state), (size_t)S->layers * B * 256 * 4, hipMemcpyDeviceToDevice, s));
+        DFX_HIP(hipMemcpyAsync(gp(S->g_sh_h), fp(S->hflip ? S->h_state2 : S->h_state), (size_t)S->layers * B * 256 * 4, hipMemcpyDeviceToDevice, s));
     }
     // ---- STFT + features of the n new hops (state: analysis memory, running means)
     float *am_in = fp(S->ana_mem[S->flip]), *am_out = fp(S->ana_mem[S->flip ^ 1]);
@@ -3081,8 +3196,11 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     const int64_t a0 = S->frames, T = H + n;
     const int64_t skip = a0 < L ? ((L - a0) < n ? (L - a0) : n) : 0;
     float *work_fe = fp(S->work_fe), *work_fs = fp(S->work_fs), *work_spec = fp(S->work_spec);
-    struct Ring { size_t *hist; float *nw, *work; int64_t h, row; bool zero_skipped; } rings[3] = {
-        {S->hist_fe, new_fe, work_fe, H, E, true}, {S->hist_fs, new_fs, work_fs, H, Fd * 2, true}, {S->hist_spec, new_spec, work_spec, Hs, F * 2, false}};
+    struct Ring { size_t *hist; float *nw, *work; int64_t h, row; bool zero_skipped; } rings[2] = {
+        {S->hist_fe, new_fe, work_fe, H, E, true}, {S->hist_fs, new_fs, work_fs, H, Fd * 2, true}};
+    const float *spec_win = work_spec;
+    int64_t spec_win_T = Hs + n;
+    if ((rc = spec_window(new_spec, &spec_win, &spec_win_T))) return rc;
     for (const Ring &r : rings) {  // one launch per ring: window = [history ; new], next call's history = its last h frames
         DfxKScope ks(DFX_K_COPY_ROWS, s);
         dfx_launch(dfx_k_ring_step, dim3((unsigned)nn_grid(dfx_ceil_div(B * (r.h + n) * r.row, 256), 16)), dim3(256), 0, s,
@@ -3092,13 +3210,20 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     }
     float *out_spec = fp(S->out_spec);
     if (skip > 0) DFX_HIP(hipMemsetAsync(out_spec, 0, (size_t)B * n * F * 8, s));  // warm-up hops: zero spectra (tract.rs rolling buffers)
+    bool stepped = false;
     if (skip < n) {
         DfxStreamCtx sc;
         sc.H = H + skip;
         const int64_t pos0 = Hs - a0;  // local index of net position 0
         sc.t_zero = pos0 > 0 ? pos0 : 0;
-        sc.spec_T = Hs + n;
-        sc.h_state = fp(S->h_state);
+        sc.spec_T = spec_win_T;
+        sc.h_state = fp(S->hflip ? S->h_state2 : S->h_state);
+        // one new hop, ungated, plain launches: every GRU layer is ONE launch (projection + recurrence + gates) that leaves the new states in
+        // the other buffer (DFX_STREAM_STEP=0: the projection and the recurrence kernel of the batch path, in place)
+        static const bool step_env = [] { const char *e = getenv("DFX_STREAM_STEP"); return !(e && e[0] == '0'); }();
+        const bool step = step_env && n - skip == 1 && !gated && !S->capturing && !S->use_graph;
+        sc.h_next = step ? fp(S->hflip ? S->h_state : S->h_state2) : nullptr;
+        stepped = step;
         sc.pf_beta = S->pf_beta;
         sc.out = out_spec;  // local frame t of clip b lands at out_spec[(b*n + t - H) * F]
         sc.out_T = n;
@@ -3117,12 +3242,13 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         float *ws = reinterpret_cast<float *>(((uintptr_t)(S->buf + S->model_ws) + 255) & ~(uintptr_t)255);
         const DfxLane *ln = &m->lanes[0];
         switch (c.conv_ch) {
-            case 16: rc = forward_impl<16>(m, st->bands, work_spec, work_fe, work_fs, B, T, S->lim, nullptr, nullptr, fp(S->lsnr), nullptr, ws, s, ln, false, nullptr, &sc); break;
-            case 32: rc = forward_impl<32>(m, st->bands, work_spec, work_fe, work_fs, B, T, S->lim, nullptr, nullptr, fp(S->lsnr), nullptr, ws, s, ln, false, nullptr, &sc); break;
-            case 64: rc = forward_impl<64>(m, st->bands, work_spec, work_fe, work_fs, B, T, S->lim, nullptr, nullptr, fp(S->lsnr), nullptr, ws, s, ln, false, nullptr, &sc); break;
+            case 16: rc = forward_impl<16>(m, st->bands, spec_win, work_fe, work_fs, B, T, S->lim, nullptr, nullptr, fp(S->lsnr), nullptr, ws, s, ln, false, nullptr, &sc); break;
+            case 32: rc = forward_impl<32>(m, st->bands, spec_win, work_fe, work_fs, B, T, S->lim, nullptr, nullptr, fp(S->lsnr), nullptr, ws, s, ln, false, nullptr, &sc); break;
+            case 64: rc = forward_impl<64>(m, st->bands, spec_win, work_fe, work_fs, B, T, S->lim, nullptr, nullptr, fp(S->lsnr), nullptr, ws, s, ln, false, nullptr, &sc); break;
             default: DFX_FAIL(DFX_ERR_UNSUPPORTED, "conv_ch");
         }
         if (rc) return rc;
+        if (stepped) S->hflip ^= 1;   // (like lin_pos: this form is neither replayed from a graph nor walked hop by hop by the caller)
         if (gated && c.df_pathway_kernel_size_t > 1) {  // the DF decoder's delay line moves where that decoder ran
             const int64_t frame = (int64_t)Fd * c.conv_ch;
             dfx_launch(dfx_k_gate_c0_shift, dim3((unsigned)B, 4), dim3(256), 0, s, (const unsigned char *)gflags, gp(S->g_c0_win), B, T,
@@ -3153,7 +3279,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         entry(fp(S->unit_state), gp(S->g_sh_unit), Fd, FZ, FZ);
         const int nenc = (int)m->enc_gru.size(), ndec = (int)m->dec_gru.size();
         for (int l = 0; l < S->layers; ++l) {
-            float *h = fp(S->h_state) + (int64_t)l * B * 256;
+            float *h = fp(S->hflip ? S->h_state2 : S->h_state) + (int64_t)l * B * 256;
             const float *hs = gp(S->g_sh_h) + (int64_t)l * B * 256;
             if (l < nenc) entry(h, hs, 256, FZ, FZ);
             else if (l < nenc + ndec) entry(h, hs, 256, DFX_GATE_GAINS, 0);   // stage 1 did not run (frozen streams included)
@@ -3274,7 +3400,7 @@ extern "C" int dfx_stream_process_raw(dfx_stream_state *S, const float *spec, fl
     DFX_HIP(hipMemsetAsync(gflags, 0, (size_t)B, s));  // no silent-input test on this path (tract.rs:441: process_raw starts at the features)
     DFX_HIP(hipMemcpyAsync(gp(S->g_sh_erb), fp(S->erb_state), (size_t)B * E * 4, hipMemcpyDeviceToDevice, s));
     DFX_HIP(hipMemcpyAsync(gp(S->g_sh_unit), fp(S->unit_state), (size_t)B * Fd * 4, hipMemcpyDeviceToDevice, s));
-    DFX_HIP(hipMemcpyAsync(gp(S->g_sh_h), fp(S->h_state), (size_t)S->layers * B * 256 * 4, hipMemcpyDeviceToDevice, s));
+    DFX_HIP(hipMemcpyAsync(gp(S->g_sh_h), fp(S->hflip ? S->h_state2 : S->h_state), (size_t)S->layers * B * 256 * 4, hipMemcpyDeviceToDevice, s));
     // features of the given spectra (state: the running means): erb (dB) -> mean norm, low bins -> unit norm (lib.rs:206-217)
     float *new_spec = fp(S->new_spec), *new_fe = fp(S->new_fe), *new_fs = fp(S->new_fs);
     DFX_HIP(hipMemcpyAsync(new_spec, spec, (size_t)B * F * 8, hipMemcpyDeviceToDevice, s));
@@ -3302,7 +3428,7 @@ extern "C" int dfx_stream_process_raw(dfx_stream_state *S, const float *spec, fl
         const int64_t pos0 = Hs - a0;
         sc.t_zero = pos0 > 0 ? pos0 : 0;
         sc.spec_T = Hs + n;
-        sc.h_state = fp(S->h_state);
+        sc.h_state = fp(S->hflip ? S->h_state2 : S->h_state);
         sc.pf_beta = 0.f;
         sc.out = fp(S->out_spec);  // the deep-filter kernel still runs (on whatever the spectrum window holds); its output is not used
         sc.out_T = n;
@@ -3339,7 +3465,7 @@ extern "C" int dfx_stream_process_raw(dfx_stream_state *S, const float *spec, fl
         G.n = 0;
         const int nenc = (int)m->enc_gru.size(), ndec = (int)m->dec_gru.size();
         for (int l = nenc; l < S->layers; ++l) {
-            G.dst[G.n] = fp(S->h_state) + (int64_t)l * B * 256, G.src[G.n] = gp(S->g_sh_h) + (int64_t)l * B * 256, G.row[G.n] = 256;
+            G.dst[G.n] = fp(S->hflip ? S->h_state2 : S->h_state) + (int64_t)l * B * 256, G.src[G.n] = gp(S->g_sh_h) + (int64_t)l * B * 256, G.row[G.n] = 256;
             G.mask[G.n] = l < nenc + ndec ? DFX_GATE_GAINS : DFX_GATE_DF, G.want[G.n] = 0;
             ++G.n;
         }

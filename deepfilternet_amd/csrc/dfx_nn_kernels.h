@@ -2287,19 +2287,23 @@ struct DfxPhArgs {
     int N;
     float unscale;       // 1 / weight scale (a power of two)
     DfxRowMap rm;        // logical row -> physical row of a and out
+    int parts = 1;       // dfx_k_proj256_h3 only: the column chunks of a row block are dealt to this many workgroups (divides N / 64).  A launch of
+                         // few rows (a streaming hop: 4096 rows = 32 row blocks) then runs on parts x 32 CUs and each workgroup streams 1 / parts of W
 };
 
 __global__ void __launch_bounds__(DFX_PH_THREADS, 2) dfx_k_proj256_h3(DfxPhArgs A) {
     DFX_DYN_SMEM(dfx_h8, ws);  // [2][DFX_PH_CHUNK_H8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
-    const int nchunks = A.N / DFX_PH_NC;
-    const int64_t ml = (int64_t)blockIdx.x * DFX_PH_BM + 16 * wave + jl;
+    const int nparts = A.parts > 0 ? A.parts : 1;
+    const int cper = A.N / DFX_PH_NC / nparts;
+    const int cfirst = (int)(blockIdx.x % nparts) * cper, nchunks = cfirst + cper;
+    const int64_t ml = (int64_t)(blockIdx.x / nparts) * DFX_PH_BM + 16 * wave + jl;
     const bool ok = ml < A.M;
     const int64_t m = ok ? dfx_row(A.rm, ml) : 0;
     constexpr int PER_T = DFX_PH_CHUNK_H8 / DFX_PH_THREADS;  // 8 x 16 bytes per thread and chunk
-    // stage chunk 0
+    // stage the first chunk
 #pragma unroll
-    for (int i = 0; i < PER_T; ++i) ws[i * DFX_PH_THREADS + tid] = A.wf[i * DFX_PH_THREADS + tid];
+    for (int i = 0; i < PER_T; ++i) ws[(size_t)(cfirst & 1) * DFX_PH_CHUNK_H8 + i * DFX_PH_THREADS + tid] = A.wf[(size_t)cfirst * DFX_PH_CHUNK_H8 + i * DFX_PH_THREADS + tid];
     // this lane's B operands: row m, k = 32*kc + 8*q .. +7.  The row is scaled by a power of two (exact) so that its largest magnitude
     // sits just below 2^14 before the f16 split: any finite row then keeps ~22 bits relative to ITS OWN scale — rows of tiny values
     // would otherwise lose their lo halves to the f16 subnormals (|x| < 6e-5) and values above 65504 would turn into inf.
@@ -2337,7 +2341,7 @@ __global__ void __launch_bounds__(DFX_PH_THREADS, 2) dfx_k_proj256_h3(DfxPhArgs 
     }
     const float unscale = A.unscale * row_unscale;   // D leaves lane (jl, q) with row jl: the row's own scale
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = cfirst; c < nchunks; ++c) {
         const dfx_h8 *wc = ws + (size_t)(c & 1) * DFX_PH_CHUNK_H8;
         dfx_h8 pre[PER_T];
         if (c + 1 < nchunks) {
@@ -2380,6 +2384,148 @@ __global__ void __launch_bounds__(DFX_PH_THREADS, 2) dfx_k_proj256_h3(DfxPhArgs 
             for (int i = 0; i < PER_T; ++i) dst[i * DFX_PH_THREADS + tid] = pre[i];
         }
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dfx_k_gru_step_h3: ONE time step of a GRU layer for many streams — input projection, recurrent product, gates and the new state in one
+// launch (the frame-by-frame streaming runtime: 4096 streams x 1 hop).  As dfx_k_proj256_h3 + dfx_k_gru_rec_h3 a step cost two dependent
+// launches (29 + 37 us at 4096 streams, three layers deep per hop), the second of which made each of its 256 workgroups stream all of
+// W_hh for 16 rows.  Here a workgroup owns 128 rows and ONE block of 64 hidden units: it streams the three gates' 64-column chunks of
+// W_ih and of W_hh (6 x 64 KB, double-buffered through LDS like the projection kernel), keeps gi in accumulators, and finishes its
+// units.  The old state is read from h_in and the new one goes to h_out (another buffer: other workgroups still read all of h_in).
+//   gates as in dfx_k_gru_rec_h3: r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r * (gh_n + b_hn)), h' = (1 - z) n + z h
+// ---------------------------------------------------------------------------------------------------------------------
+struct DfxGstArgs {
+    const float *x;        // layer input, row of stream b = dfx_row(xrm, b), 256 values
+    const float *h_in;     // [B, 256]
+    float *h_out;          // [B, 256]
+    float *y;              // the layer's output for the following kernels (row dfx_row(yrm, b)) or null
+    const dfx_h8 *wif, *whf;   // W_ih / W_hh as dfx_k_proj256_h3's fragments [12][8][4][2][64]
+    const float *bias_i;   // [768]: b_ih (+ b_hr, b_hz)
+    const float *bhn;      // [256]
+    float unscale_i, unscale_h;
+    int64_t B;
+    DfxRowMap xrm, yrm;
+};
+__global__ void __launch_bounds__(DFX_PH_THREADS, 2) dfx_k_gru_step_h3(DfxGstArgs A) {
+    DFX_DYN_SMEM(dfx_h8, ws);  // [2][DFX_PH_CHUNK_H8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
+    const int u = blockIdx.x & 3;   // block of 64 hidden units
+    const int64_t b = (int64_t)(blockIdx.x >> 2) * DFX_PH_BM + 16 * wave + jl;
+    const bool ok = b < A.B;
+    constexpr int PER_T = DFX_PH_CHUNK_H8 / DFX_PH_THREADS;
+    // chunk i of this workgroup: i < 3: W_ih, gate i; else W_hh, gate i - 3 (columns 256 g + 64 u .. + 63 = chunk 4 g + u)
+    auto chunk_src = [&](int i) { return (i < 3 ? A.wif : A.whf) + (size_t)(4 * (i % 3) + u) * DFX_PH_CHUNK_H8; };
+    {
+        const dfx_h8 *src = chunk_src(0);
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) ws[i * DFX_PH_THREADS + tid] = src[i * DFX_PH_THREADS + tid];
+    }
+    // a row's 256 values as B operands, scaled by the row's own power of two before the f16 split (see dfx_k_proj256_h3)
+    dfx_h8 vh[8], vl[8];
+    auto load_row = [&](const float *row) -> float {
+        const float4 *p = reinterpret_cast<const float4 *>(row + 8 * q);
+        float4 xu[8], xv[8];
+        float mx = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            xu[kc] = ok ? p[8 * kc] : make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[kc] = ok ? p[8 * kc + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(xu[kc].x), fabsf(xu[kc].y)), fmaxf(fabsf(xu[kc].z), fabsf(xu[kc].w))));
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(xv[kc].x), fabsf(xv[kc].y)), fmaxf(fabsf(xv[kc].z), fabsf(xv[kc].w))));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        int e = 0;
+        if (mx > 0.f && mx < 3.0e38f) {
+            int ex;
+            (void)frexpf(mx, &ex);
+            e = 14 - ex;
+            e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        }
+        const float sc = ldexpf(1.f, e);
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            float x[8];
+            x[0] = xu[kc].x * sc, x[1] = xu[kc].y * sc, x[2] = xu[kc].z * sc, x[3] = xu[kc].w * sc;
+            x[4] = xv[kc].x * sc, x[5] = xv[kc].y * sc, x[6] = xv[kc].z * sc, x[7] = xv[kc].w * sc;
+            dfx_split8(x, vh[kc], vl[kc]);
+        }
+        return ldexpf(1.f, -e);
+    };
+    const int64_t xr = ok ? dfx_row(A.xrm, b) : 0;
+    float us = A.unscale_i * load_row(A.x + xr * 256);
+    f32x4 gi[3][4], gh[3][4];
+    __syncthreads();
+    for (int c = 0; c < 6; ++c) {
+        const dfx_h8 *wc = ws + (size_t)(c & 1) * DFX_PH_CHUNK_H8;
+        dfx_h8 pre[PER_T];
+        if (c + 1 < 6) {
+            const dfx_h8 *src = chunk_src(c + 1);
+#pragma unroll
+            for (int i = 0; i < PER_T; ++i) pre[i] = src[i * DFX_PH_THREADS + tid];
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            dfx_h8 whi[4], wlo[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                whi[ct] = wc[((kc * 4 + ct) * 2 + 0) * 64 + lane];
+                wlo[ct] = wc[((kc * 4 + ct) * 2 + 1) * 64 + lane];
+            }
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = dfx_mfma_16x16x32_f16(wlo[ct], vh[kc], acc[ct]);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = dfx_mfma_16x16x32_f16(whi[ct], vl[kc], acc[ct]);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = dfx_mfma_16x16x32_f16(whi[ct], vh[kc], acc[ct]);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const f32x4 v = acc[ct] * us;
+            // (c is a loop counter of a loop that is not unrolled: select the destination without a dynamically indexed register array)
+            if (c == 0) gi[0][ct] = v;
+            else if (c == 1) gi[1][ct] = v;
+            else if (c == 2) gi[2][ct] = v;
+            else if (c == 3) gh[0][ct] = v;
+            else if (c == 4) gh[1][ct] = v;
+            else gh[2][ct] = v;
+        }
+        if (c == 2) us = A.unscale_h * load_row(A.h_in + (ok ? b : 0) * 256);   // the recurrent operand replaces the input's
+        if (c + 1 < 6) {
+            dfx_h8 *dst = ws + (size_t)((c + 1) & 1) * DFX_PH_CHUNK_H8;
+#pragma unroll
+            for (int i = 0; i < PER_T; ++i) dst[i * DFX_PH_THREADS + tid] = pre[i];
+        }
+        __syncthreads();
+    }
+    if (ok) {
+        const int64_t yr = A.y ? dfx_row(A.yrm, b) : 0;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const int n0 = 64 * u + 16 * ct + 4 * q;   // D leaves lane (row jl, q) with the units n0 .. n0 + 3
+            const float4 br = *reinterpret_cast<const float4 *>(A.bias_i + n0), bz = *reinterpret_cast<const float4 *>(A.bias_i + 256 + n0),
+                         bn = *reinterpret_cast<const float4 *>(A.bias_i + 512 + n0), bh = *reinterpret_cast<const float4 *>(A.bhn + n0),
+                         hp = *reinterpret_cast<const float4 *>(A.h_in + b * 256 + n0);
+            const float brr[4] = {br.x, br.y, br.z, br.w}, bzz[4] = {bz.x, bz.y, bz.z, bz.w}, bnn[4] = {bn.x, bn.y, bn.z, bn.w},
+                        bhh[4] = {bh.x, bh.y, bh.z, bh.w}, hpp[4] = {hp.x, hp.y, hp.z, hp.w};
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float rg = dfx_fast_rcp(1.f + dfx_fast_exp(-((gi[0][ct][r] + brr[r]) + gh[0][ct][r])));
+                const float zg = dfx_fast_rcp(1.f + dfx_fast_exp(-((gi[1][ct][r] + bzz[r]) + gh[1][ct][r])));
+                const float pre = (gi[2][ct][r] + bnn[r]) + rg * (gh[2][ct][r] + bhh[r]);
+                const float ng = 2.f * dfx_fast_rcp(1.f + dfx_fast_exp(-2.f * pre)) - 1.f;
+                o[r] = (1.f - zg) * ng + zg * hpp[r];
+            }
+            const float4 ov = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4 *>(A.h_out + b * 256 + n0) = ov;
+            if (A.y) *reinterpret_cast<float4 *>(A.y + yr * 256 + n0) = ov;
+        }
     }
 }
 

@@ -122,3 +122,42 @@ def test_stream_post_filter_is_libdfs(backend, channels):
     alt = S.process_stream(p, sd, xin, pf_beta=0.3, thresholds=(-1e9, 1e9, 1e9), pf_like_torch=True)[0].reshape(channels, -1)
     assert rms(y - ref) < 1e-6, rms(y - ref)
     assert rms(alt - ref) > 20 * rms(y - ref) and rms(alt - ref) > 1e-5     # the test can see which filter ran
+
+
+def test_linear_rolling_spectra_equal_the_ring_form(backend, monkeypatch):
+    """The rolling spectra of an ungated handle live in a linear buffer through which the deep filter's window slides (the last frames go
+    back to the front when it reaches the end: DFX_STREAM_LINEAR=<slack> makes that happen every few hops here); the ring form
+    (DFX_STREAM_LINEAR=0) rewrites the window every call.  Same bits — also across a switch to gating (the state changes form) and back,
+    and through the pass-through setting of the attenuation limit, which keeps the spectra moving."""
+    from deepfilternet_amd.enhance import init_df
+    from deepfilternet_amd.streaming import DfStream
+
+    p = named_params("pf32")
+    model, df_state, _, _ = init_df(params=p, epoch="none", seed=9)
+    hop, T = 480, (12 if backend == "emu" else 60)
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy((0.1 * rng.standard_normal((2, hop * T))).astype(np.float32))
+    cuts = [1, 2, 1, 1, 3, 1, 1, 2] + [1] * (T - 12)
+
+    def run(env, toggle):
+        monkeypatch.setenv("DFX_STREAM_LINEAR", env)
+        rt = DfStream(model, df_state, streams=2, max_frames=3)
+        out, pos = [], 0
+        for i, n in enumerate(cuts):
+            if toggle and i == 5:
+                rt.set_gating(True)
+                rt.set_thresholds(-1e9, 1e9, 1e9)   # decisions that never skip a stage: the gated runtime computes the same frames
+            if toggle and i == 9:
+                rt.set_gating(False)
+            if i == 12:
+                rt.set_atten_lim(0.0)               # pass-through: analysis + rolling spectra only
+            if i == 14:
+                rt.set_atten_lim(100.0)
+            out.append(rt.process(x[:, pos * hop:(pos + n) * hop]))
+            pos += n
+        return torch.cat(out, dim=1)
+
+    for toggle in ((False,) if backend == "emu" else (False, True)):   # (the interpreter is slow: the form switches run on the GPU)
+        ref = run("0", toggle)   # (switching gating on mid-stream starts the DF decoder's delay line empty: like is compared with like)
+        for env in (("6",) if (toggle or backend == "emu") else ("1", "6")):
+            assert torch.equal(run(env, toggle), ref), (env, toggle)
