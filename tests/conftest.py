@@ -11,7 +11,39 @@ sys.dont_write_bytecode = False
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
 
+def pytest_cmdline_main(config):
+    """CPU runs (-m "not gpu") execute the kernel sources on the SIMT interpreter — one slow OS thread per test — so they are spread
+    over worker processes (pytest-xdist) unless the caller chose a number himself (-n) or DFX_TEST_WORKERS=0.  GPU runs (-m gpu) stay in
+    one process: the engine's persistent launches own the device."""
+    expr = getattr(config.option, "markexpr", "") or ""
+    if "not gpu" not in expr or hasattr(config, "workerinput") or getattr(config.option, "numprocesses", None) is not None:
+        return None
+    try:
+        import xdist  # noqa: F401
+    except ImportError:
+        return None
+    env = os.environ.get("DFX_TEST_WORKERS")
+    n = int(env) if env is not None else min(6, max(1, (os.cpu_count() or 2) - 1))
+    if n > 1 and hasattr(config.option, "numprocesses"):
+        # build the shared native artefacts once, before the workers start (they would race for the same output files)
+        from tests.hipemu.build_emu import build as emu_build
+
+        emu_build()
+        from oracle import libdf_oracle
+
+        libdf_oracle.build()
+        config.option.numprocesses = n   # (xdist's own pytest_cmdline_main has already run: what it derives from -n is set here too)
+        config.option.dist = "load"
+        config.option.tx = ["popen"] * n
+        os.environ["DFX_TEST_WORKER_THREADS"] = str(max(1, (os.cpu_count() or n) // n))
+    return None
+
+
 def pytest_configure(config):
+    if os.environ.get("PYTEST_XDIST_WORKER") and os.environ.get("DFX_TEST_WORKER_THREADS"):
+        import torch
+
+        torch.set_num_threads(int(os.environ["DFX_TEST_WORKER_THREADS"]))   # the torch oracle would otherwise oversubscribe the cores
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "needs_reference: imports /root/reference (build container only)")
 
