@@ -1671,7 +1671,7 @@ static int launch_enc_fan(const dfx_model *m, const float *c1, const float *e3, 
 }
 // emb and everything that reads it, in one pass over the encoder GRU's output (dfx_k_emb_fan); outs[c] null = consumer not wanted
 static int launch_emb_fan(const dfx_model *m, const float *y, const float *res, float *emb_out, float *dec_x, float *dfg_x, float *skp,
-                          float *lsnr, int64_t M, hipStream_t s, DfxRowMap rm) {
+                          float *lsnr, int64_t M, hipStream_t s, DfxRowMap rm, float *embv_for_split = nullptr) {
     const dfx_model_cfg &c = m->cfg;
     DfxFanArgs A;
     A.y = y;
@@ -1686,6 +1686,16 @@ static int launch_emb_fan(const dfx_model *m, const float *y, const float *res, 
     A.R = M;
     A.nj = m->fan_chunks;
     A.rm = rm;
+    A.parts = 1;
+    // few rows (a streaming hop): one wave per (16 rows, super-chunk) instead of a wave walking all super-chunks — emb is then written out
+    // (embv: 2 KB per row of a few thousand rows) and lsnr, the one consumer that needs all of a row's features, is a launch of its own
+    const bool split = M <= 16384 && lsnr && embv_for_split;
+    if (split) {
+        A.parts = A.nj;
+        A.emb_out = embv_for_split;
+        A.lsnr = nullptr, A.lsnr_w = nullptr;
+    }
+    {
     DfxKScope ks(DFX_K_EMB_FAN, s);
     // (the kinds are what pack_fan accepted: dec_in narrow, dfg_in wide, df_skip narrow; a consumer that is not wanted drops out)
     if (M > 16384) {
@@ -1696,12 +1706,19 @@ static int launch_emb_fan(const dfx_model *m, const float *y, const float *res, 
         else dfx_launch((dfx_k_emb_fan<RT, 1, 0, 0>), grid, dim3(256), 0, s, A);
     } else {   // few rows (a streaming hop): one row tile per wave — twice the waves, half the serial matrix work per wave
         constexpr int RT = 1;
-        const dim3 grid((unsigned)nn_grid(dfx_ceil_div(dfx_ceil_div(M, 16 * RT), 4), 8));
+        const dim3 grid((unsigned)nn_grid(dfx_ceil_div(dfx_ceil_div(M, 16 * RT) * A.parts, 4), 8));
         if (dfg_x && skp) dfx_launch((dfx_k_emb_fan<RT, 1, 2, 1>), grid, dim3(256), 0, s, A);
         else if (dfg_x) dfx_launch((dfx_k_emb_fan<RT, 1, 2, 0>), grid, dim3(256), 0, s, A);
         else dfx_launch((dfx_k_emb_fan<RT, 1, 0, 0>), grid, dim3(256), 0, s, A);
     }
     DFX_LAUNCH_CHECK();
+    }
+    if (split) {   // (needs identity rows: the streaming window's new frame is reached through rm — one wave per logical row)
+        DfxKScope ks(DFX_K_LSNR, s);
+        dfx_launch(dfx_k_lsnr_rows, dim3((unsigned)dfx_ceil_div(M * 64, 256)), dim3(256), 0, s, (const float *)embv_for_split, m->p(m->lsnr_w), m->lsnr_b,
+                   (float)(c.lsnr_max - c.lsnr_min), (float)c.lsnr_min, lsnr, M, 64 * A.nj, rm);
+        DFX_LAUNCH_CHECK();
+    }
     return DFX_OK;
 }
 
@@ -1889,7 +1906,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             res = skp_e;
         }
         const bool need_emb = c.emb_gru_skip != DFX_SKIP_NONE || (run_df && c.df_gru_skip == DFX_SKIP_IDENTITY);
-        return launch_emb_fan(m, y, res, need_emb ? embv : nullptr, dec_x, run_df ? xa2 : nullptr, fan_skp ? xdf : nullptr, lsnr, M, st, rm);
+        return launch_emb_fan(m, y, res, need_emb ? embv : nullptr, dec_x, run_df ? xa2 : nullptr, fan_skp ? xdf : nullptr, lsnr, M, st, rm, embv);
     };
     // c = tanh(df_out(c)).view(b,t,F',2O) + c0p   (:329-330) of M rows; cfeat (+ cfeat2) is df_out's operand
     auto df_out_rows = [&](const float *cfeat, const float *cfeat2, int64_t M, hipStream_t st, DfxRowMap rm) -> int {

@@ -2681,6 +2681,7 @@ struct DfxFanArgs {
     float *lsnr;                // [R]
     int64_t R;
     int nj;                     // super-chunks: hidden / 32
+    int parts;                  // a row tile's super-chunks are dealt to this many waves (divides nj; > 1 only without lsnr: few rows, a streaming hop)
     DfxRowMap rm;
 };
 template <int RT, int K0, int K1, int K2>
@@ -2688,7 +2689,10 @@ __global__ void __launch_bounds__(256, 2) dfx_k_emb_fan(DfxFanArgs A) {
     const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
     const int H = 32 * A.nj, EMB = 64 * A.nj;
     const int64_t ntile = (A.R + 16 * RT - 1) / (16 * RT);
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntile; tile += (int64_t)gridDim.x * 4) {
+    const int jper = A.nj / A.parts;
+    for (int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); item < ntile * A.parts; item += (int64_t)gridDim.x * 4) {
+        const int64_t tile = item / A.parts;
+        const int J0 = (int)(item - tile * A.parts) * jper, J1 = J0 + jper;
         int64_t prow[RT];
         bool ok[RT];
         float ls[RT];
@@ -2711,8 +2715,8 @@ __global__ void __launch_bounds__(256, 2) dfx_k_emb_fan(DfxFanArgs A) {
                 for (int ch = 0; ch < 2; ++ch)
                     yn[rt][ch] = ok[rt] ? *reinterpret_cast<const float4 *>(A.y + prow[rt] * H + 32 * J + 16 * ch + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
         };
-        request(0);
-        for (int J = 0; J < A.nj; ++J) {
+        request(J0);
+        for (int J = J0; J < J1; ++J) {
             float4 w1[4], yc[RT][2], wc[DFX_FAN_NC][8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) w1[i] = w1n[i];
@@ -2724,7 +2728,7 @@ __global__ void __launch_bounds__(256, 2) dfx_k_emb_fan(DfxFanArgs A) {
 #pragma unroll
                 for (int i = 0; i < (kind == 2 ? 8 : (kind == 1 ? 4 : 0)); ++i) wc[c][i] = A.wfrag[((size_t)J * DFX_FAN_WPJ + 4 + 8 * c + i) * 64 + lane];
             });
-            if (J + 1 < A.nj) request(J + 1);
+            if (J + 1 < J1) request(J + 1);
             float4 lw[4];
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt)
@@ -2913,6 +2917,25 @@ __global__ void dfx_k_lsnr(const float *emb, const float *w, float bias, float s
         }
     } else {
         for (int i = lane; i < D; i += 64) acc += e[i] * w[i];
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) out[row] = dfx_sigmoid(acc + bias) * scale + offset;
+}
+
+// the same for the logical rows of a row-mapped launch (the new frames of a streaming window)
+__global__ void dfx_k_lsnr_rows(const float *emb, const float *w, float bias, float scale, float offset, float *out, int64_t R, int D, DfxRowMap rm) {
+    const int lane = threadIdx.x & 63;
+    const int64_t lrow = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (lrow >= R) return;
+    const int64_t row = dfx_row(rm, lrow);
+    float acc = 0.f;
+    const float *e = emb + row * D;
+    for (int i = 4 * lane; i < D; i += 256) {
+        const float4 ev = *reinterpret_cast<const float4 *>(e + i), wv = *reinterpret_cast<const float4 *>(w + i);
+        acc += ev.x * wv.x;
+        acc += ev.y * wv.y;
+        acc += ev.z * wv.z;
+        acc += ev.w * wv.w;
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
     if (lane == 0) out[row] = dfx_sigmoid(acc + bias) * scale + offset;
