@@ -443,7 +443,7 @@ def main() -> None:
         dist.destroy_process_group()
 
 
-def bench_streaming(dev, streams: int = 4096, calls: int = 100) -> dict:
+def bench_streaming(dev, streams: int = 4096, calls: int = 1000) -> dict:
     """BASELINE.json configs[3]: DeepFilterNet3 without lookahead (the reference's low-latency LADSPA model, ladspa/README.md:3), 4096
     concurrent streams advanced frame by frame (one hop of every stream per call = df_process_frame for all of them), without and
     with the reference runtime's per-stream stage decisions (DfTract::process).  Runs tools/bench_stream.py in a process of its own:

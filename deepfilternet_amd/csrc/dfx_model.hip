@@ -125,6 +125,9 @@ struct DfxStreamCtx {
     int64_t spec_T;    // frames per clip of the spec array
     float *h_state;    // [GRU layers][B][256], in model order enc, erb_dec, df_dec
     float *h_next = nullptr;   // non-null (one new frame, ungated): the layers run as dfx_k_gru_step_h3 and leave their new states HERE
+    void *c0ring = nullptr;    // non-null (one new frame, ungated): df_convp reads the split c0 tiles of the kt - 1 older frames from this ring
+    int c0slot = 0;            //   slot of the new frame = its net position % (kt - 1)
+    bool c0rebuild = false;    //   the ring is not current: recompute the older frames from the feature window and store them
     float pf_beta;     // < 0: the model's setting
     float *out;        // [B, out_T, F][2]: local frame t of clip b is stored at frame t - out_toff
     int64_t out_T, out_toff;
@@ -1333,6 +1336,37 @@ static int launch_convp_h3(const dfx_model *m, const float *feat_spec, float *ou
     }
 }
 
+// df_convp of the newest frame of every stream with the older frames' c0 tiles from the handle's ring (dfx_k_df_convp_step)
+template <int C, int KT>
+static int launch_convp_step(const dfx_model *m, const float *feat_spec, float *out, int64_t B, int64_t T, int Fd, int NO, hipStream_t s,
+                             int64_t t_zero, int L, void *ring, int slot, bool rebuild) {
+    if constexpr (C % 32 != 0 || KT < 2) {
+        DFX_FAIL(DFX_ERR_UNSUPPORTED, "df_convp step kernel: conv_ch %% 32 == 0 and kt >= 2");
+    } else {
+        DfxCphArgs A;
+        A.t_end = T;
+        A.feat = feat_spec;
+        A.w0f = reinterpret_cast<const dfx_h8 *>(m->p(m->c0_h3));
+        A.bias0 = m->p(m->cin_b);
+        A.wf = reinterpret_cast<const dfx_h8 *>(m->p(m->cp_h3));
+        A.bias = m->p(m->cp_b16);
+        A.out = out;
+        A.B = B, A.T = T, A.Fd = Fd, A.NO = NO;
+        A.L = L;
+        A.t_begin = T - 1, A.t_zero = t_zero;
+        A.unscale0 = m->c0_unscale, A.unscale = m->cp_unscale;
+        A.err = m->d_err;
+        A.nfb = (Fd + 15) / 16;
+        A.nseg = 1, A.tseg = 1;
+        const int grid = nn_grid(dfx_ceil_div(B * A.nfb, 4), 8);
+        DfxKScope ks(DFX_K_DF_CONVP, s);
+        if (rebuild) dfx_launch((dfx_k_df_convp_step<C, KT, true>), dim3(grid), dim3(256), 0, s, A, reinterpret_cast<dfx_h8 *>(ring), slot);
+        else dfx_launch((dfx_k_df_convp_step<C, KT, false>), dim3(grid), dim3(256), 0, s, A, reinterpret_cast<dfx_h8 *>(ring), slot);
+        DFX_LAUNCH_CHECK();
+        return DFX_OK;
+    }
+}
+
 template <int C>
 static int launch_conv01_h3(const dfx_model *m, const PwW &w, const float *feat_spec, float *out, int64_t B, int64_t T, int Fin,
                             int Fout, int stride, hipStream_t s, int64_t t_begin = 0, int L = -1, int64_t t_end = -1) {
@@ -2017,6 +2051,13 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 case 3: return launch_convp2<C, 3>(m, gate->c0_win, nullptr, c0p, B, T, Fd, NO, st, T - 1, 0, Lk);
                 case 4: return launch_convp2<C, 4>(m, gate->c0_win, nullptr, c0p, B, T, Fd, NO, st, T - 1, 0, Lk);
                 default: return launch_convp2<C, 5>(m, gate->c0_win, nullptr, c0p, B, T, Fd, NO, st, T - 1, 0, Lk);
+            }
+        } else if (fuse_h3 && sc && sc->c0ring && !gate && t1 - t0 == 1 && t1 == T && kt >= 2) {
+            switch (kt) {
+                case 2: return launch_convp_step<C, 2>(m, feat_spec, c0p, B, T, Fd, NO, st, t_zero, Lk, sc->c0ring, sc->c0slot, sc->c0rebuild);
+                case 3: return launch_convp_step<C, 3>(m, feat_spec, c0p, B, T, Fd, NO, st, t_zero, Lk, sc->c0ring, sc->c0slot, sc->c0rebuild);
+                case 4: return launch_convp_step<C, 4>(m, feat_spec, c0p, B, T, Fd, NO, st, t_zero, Lk, sc->c0ring, sc->c0slot, sc->c0rebuild);
+                default: return launch_convp_step<C, 5>(m, feat_spec, c0p, B, T, Fd, NO, st, t_zero, Lk, sc->c0ring, sc->c0slot, sc->c0rebuild);
             }
         } else if (fuse_h3) {
             switch (kt) {
@@ -2853,6 +2894,9 @@ struct dfx_stream_state {
     size_t ana_mem[2], syn_mem[2], erb_state, unit_state, hist_fe[2], hist_fs[2], hist_spec[2], new_spec, new_fe, new_fs, work_fe, work_fs,
         work_spec, out_spec, h_state, h_state2, lsnr, model_ws;
     int hflip = 0;            // which of h_state / h_state2 holds the GRU states (the one-step kernel writes the other one: dfx_k_gru_step_h3)
+    size_t c0ring = 0;        // split c0 tiles of the last kt - 1 frames (dfx_k_df_convp_step); c0ring_bytes == 0: not available
+    size_t c0ring_bytes = 0;
+    bool c0ring_ok = true;    // the ring is current (all zeros after a reset; stale after a pass that did not go through the step kernel)
     int64_t model_ws_bytes = 0;
     int flip = 0;             // which of the double-buffered STFT memories is current
     // The rolling spectra of an ungated handle live in a LINEAR buffer [B, lin_cap, F] through which the window [lin_pos, lin_pos + Hs + n)
@@ -2949,6 +2993,15 @@ extern "C" int dfx_stream_create(const dfx_model *m, const dfx_state *st, int64_
     }
     s->h_state = take((size_t)s->layers * B * 256 * 4);
     s->h_state2 = take((size_t)s->layers * B * 256 * 4);
+    {   // c0 ring of dfx_k_df_convp_step: [B][kt-1][nfb][C/32][hi,lo][64 lanes] x 16 bytes (4096 streams of the released model: 403 MB)
+        const int kt = c.df_pathway_kernel_size_t;
+        const size_t rb = kt >= 2 && c.conv_ch % 32 == 0 ? (size_t)B * (kt - 1) * ((Fd + 15) / 16) * (c.conv_ch / 32) * 2 * 64 * 16 : 0;
+        static const bool ring_env = [] { const char *e = getenv("DFX_STREAM_C0RING"); return !(e && e[0] == '0'); }();
+        if (rb > 0 && rb <= ((size_t)1 << 30) && ring_env) {
+            s->c0ring_bytes = rb;
+            s->c0ring = take(rb);
+        }
+    }
     s->lsnr = take((size_t)B * (H + n) * 4);
     s->x_in = take((size_t)B * n * st->hop * 4);
     s->y_out = take((size_t)B * n * st->hop * 4);
@@ -3018,6 +3071,7 @@ extern "C" int dfx_stream_reset(dfx_stream_state *s, void *stream) {
     s->lin_pos = 0;
     s->lin_owns = false;   // (both forms are all zeros now)
     s->hflip = 0;
+    s->c0ring_ok = true;   // (zeros = the causal padding in front of the stream)
     return DFX_OK;
 }
 
@@ -3241,6 +3295,12 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         const bool step = step_env && n - skip == 1 && !gated && !S->capturing && !S->use_graph;
         sc.h_next = step ? fp(S->hflip ? S->h_state : S->h_state2) : nullptr;
         stepped = step;
+        if (step && S->c0ring_bytes) {   // df_convp from the ring of split c0 tiles (dfx_k_df_convp_step)
+            const int ns = c.df_pathway_kernel_size_t - 1;
+            sc.c0ring = S->buf + S->c0ring;
+            sc.c0slot = (int)((((a0 + skip - L) % ns) + ns) % ns);
+            sc.c0rebuild = !S->c0ring_ok;
+        }
         sc.pf_beta = S->pf_beta;
         sc.out = out_spec;  // local frame t of clip b lands at out_spec[(b*n + t - H) * F]
         sc.out_T = n;
@@ -3266,6 +3326,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         }
         if (rc) return rc;
         if (stepped) S->hflip ^= 1;   // (like lin_pos: this form is neither replayed from a graph nor walked hop by hop by the caller)
+        S->c0ring_ok = stepped && S->c0ring_bytes;   // any other pass leaves the ring behind
         if (gated && c.df_pathway_kernel_size_t > 1) {  // the DF decoder's delay line moves where that decoder ran
             const int64_t frame = (int64_t)Fd * c.conv_ch;
             dfx_launch(dfx_k_gate_c0_shift, dim3((unsigned)B, 4), dim3(256), 0, s, (const unsigned char *)gflags, gp(S->g_c0_win), B, T,

@@ -840,6 +840,89 @@ __global__ void __launch_bounds__(256, 1) dfx_k_df_convp_h3(DfxCphArgs A) {
     if (amax >= DFX_H3_LIMIT && A.err) dfx_raise(A.err + 1);
 }
 
+// dfx_k_df_convp_step: df_convp for ONE new frame per stream (the frame-by-frame runtime).  dfx_k_df_convp_h3 recomputes the kt - 1
+// frames of c0 in front of a segment as warm-up — for a segment of one frame four of its five c0 tiles per output (334 us at 4096
+// streams, longer than the whole ERB branch of the hop).  Here the handle keeps the split c0 tiles of the last kt - 1 frames, already in
+// the matrix-op B-operand layout (f16 hi / lo fragments), in a ring: ring[b][slot][fb][kc][hi,lo][lane], slot = frame % (kt - 1).
+// A wave owns (stream, 16-bin block): taps 0 .. kt-2 read their frames' fragments from the ring (tap 0's slot is the one the new frame
+// replaces: read first, written last, by the same lane), the last tap's frame is computed from the features and stored.  REBUILD: the
+// ring is not current (after a reset it is all zeros = the causal padding and needs none; after calls of several hops or gated passes
+// it does): the kt - 1 older frames are recomputed from the feature window like dfx_k_df_convp_h3 does, and stored.
+template <int C, int KT, bool REBUILD>
+__global__ void __launch_bounds__(256, 2) dfx_k_df_convp_step(DfxCphArgs A, dfx_h8 *ring, int slot_new) {
+    constexpr int CPL = C / 4, NT = C / 16, KC = C / 32, NS = KT - 1;
+    static_assert(C % 32 == 0 && KT >= 2, "one k-chunk is 32 channels; kt = 1 has no history");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
+    dfx_h8 w0h[NT], w0l[NT];
+    float4 bias0[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        w0h[nt] = A.w0f[(nt * 2 + 0) * 64 + lane];
+        w0l[nt] = A.w0f[(nt * 2 + 1) * 64 + lane];
+        bias0[nt] = reinterpret_cast<const float4 *>(A.bias0)[4 * nt + q];
+    }
+    float biasr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) biasr[r] = A.bias[4 * q + r];
+    const int64_t nruns = A.B * A.nfb;
+    const int64_t t = A.T - 1;   // the new frame (local index in the feature window)
+    float amax = 0.f;
+    for (int64_t run = (int64_t)blockIdx.x * 4 + wave; run < nruns; run += (int64_t)gridDim.x * 4) {
+        const int fb = (int)(run % A.nfb);
+        const int64_t b = run / A.nfb;
+        const int f = fb * 16 + jl;
+        const bool fvalid = f < A.Fd;
+        auto slot_ptr = [&](int slot) { return ring + ((((size_t)b * NS + slot) * A.nfb + fb) * KC * 2) * 64 + lane; };
+        auto make_frame = [&](dfx_h8 (&dh)[KC], dfx_h8 (&dl)[KC], int64_t tau) {
+            float2 raw[4];
+            dfx_c0_patch_load(A.feat, b, tau, f, fvalid && tau >= 0, A.T, A.Fd, A.L, q, raw);
+            float c0v[CPL];
+            dfx_c0_tile_h3<C>(w0h, w0l, bias0, A.unscale0, raw, fvalid && tau >= A.t_zero, c0v, amax);
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) dfx_split8_g(c0v + 8 * kc, dh[kc], dl[kc], amax);
+        };
+        f32x4 aa = f32x4{0.f, 0.f, 0.f, 0.f}, ab = aa, ac = aa;
+        dfx_static_for<0, KT>([&](auto kcn) {
+            constexpr int k = decltype(kcn)::value;   // tap k reads frame t - (KT-1) + k
+            dfx_h8 xh[KC], xl[KC];
+            const int slot = (slot_new + k) % NS;     // (k = KT-1: the new frame's own slot = tap 0's)
+            if (k == KT - 1) {
+                make_frame(xh, xl, t);
+            } else if (REBUILD) {
+                make_frame(xh, xl, t - (KT - 1) + k);
+            } else {
+                const dfx_h8 *sp = slot_ptr(slot);
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) xh[kc] = sp[(kc * 2 + 0) * 64], xl[kc] = sp[(kc * 2 + 1) * 64];
+            }
+            if (k == KT - 1 || (REBUILD && k > 0)) {   // (REBUILD: frame t - (KT-1) is about to leave the window, its slot is the new frame's)
+                dfx_h8 *sp = slot_ptr(slot);
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) sp[(kc * 2 + 0) * 64] = xh[kc], sp[(kc * 2 + 1) * 64] = xl[kc];
+            }
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const dfx_h8 wl = A.wf[((k * KC + kc) * 2 + 1) * 64 + lane], wh = A.wf[((k * KC + kc) * 2 + 0) * 64 + lane];
+                aa = dfx_mfma_16x16x32_f16(wl, xh[kc], aa);
+                ab = dfx_mfma_16x16x32_f16(wh, xl[kc], ab);
+                ac = dfx_mfma_16x16x32_f16(wh, xh[kc], ac);
+            }
+        });
+        f32x4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = (aa[r] + ab[r]) + ac[r];
+        if (fvalid) {
+            float *op = A.out + ((b * (A.NO / 2) * A.T + t) * A.Fd + f) * 2;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (4 * q + 2 * h < A.NO)
+                    *reinterpret_cast<float2 *>(op + (int64_t)(2 * q + h) * A.T * A.Fd * 2) =
+                        make_float2(fmaxf(acc[2 * h] * A.unscale + biasr[2 * h], 0.f), fmaxf(acc[2 * h + 1] * A.unscale + biasr[2 * h + 1], 0.f));
+        }
+    }
+    if (amax >= DFX_H3_LIMIT && A.err) dfx_raise(A.err + 1);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Frame-resident conv chains.  Apart from their first layer every conv of the ERB encoder / decoder is per frame (1x3 over
 // frequency), so a whole chain can run on one frame pair without its intermediates leaving the CU: a wave owns DFX_CH_NF = 2
