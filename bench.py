@@ -90,6 +90,7 @@ def main() -> None:
     ap.add_argument("--no-gather", action="store_true", help="skip the final RCCL gather of the waveforms to rank 0")
     ap.add_argument("--cpu-clips", type=int, default=32)
     ap.add_argument("--main-only", action="store_true", help="only the timed loop and the DF-apply roofline (profiling runs: no extra steps / configs)")
+    ap.add_argument("--host-io-only", action="store_true", help="only the host-to-host pipeline (bench_host_io), one JSON line; the full run starts this in a process of its own")
     args = ap.parse_args()
 
     # ---- ranks: one process per GPU.  Under an external launcher (torch.distributed.run) WORLD_SIZE must equal --gpus; without one,
@@ -149,6 +150,9 @@ def main() -> None:
                 pending[k].wait()
                 pending[k] = None
 
+    if args.host_io_only:
+        print(json.dumps(bench_host_io(model, df_state, x, args.steps)), flush=True)
+        return
     for i in range(args.warmup):
         step(i)
     drain()
@@ -366,10 +370,7 @@ def main() -> None:
     # H2D of batch k+1 and D2H of batch k-1 on their own streams under the compute of batch k.
     host_io = None
     if extras:
-        try:
-            host_io = bench_host_io(model, df_state, x, args.steps)
-        except Exception as e:  # noqa: BLE001
-            host_io = {"error": repr(e)}
+        host_io = "pending"   # run below in a process of its own (this one has created three model handles and ~40 streams by then)
 
     # ---- BASELINE.json configs[3] and configs[4] (the batch model's streams are released first: a process with more streams than
     # hardware queues makes them share queues, which serialises the streaming runtime's three branches)
@@ -396,6 +397,17 @@ def main() -> None:
         ahead_ms = json.loads(r.stdout.strip().splitlines()[-1])["ms_per_step"]
     except Exception as e:  # noqa: BLE001
         ahead_ms = repr(e)
+    if host_io == "pending":
+        try:
+            import subprocess
+
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                                                     "TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT")}
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--host-io-only", "--steps", str(max(args.steps, 20)), "--batch", str(B), "--seconds",
+                                str(args.seconds), "--model", args.model], env=env, capture_output=True, text=True, timeout=600)
+            host_io = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        except Exception as e:  # noqa: BLE001
+            host_io = {"error": repr(e)}
     configs = {}
     if extras:
         try:
@@ -499,7 +511,11 @@ def bench_df_apply_rows(dev, df_state, B: int, Tf: int, F: int, nd: int, O: int,
 
 def bench_host_io(model, df_state, x, steps: int) -> dict:
     """enhance() host to host: page-locked input and output batches, the upload of batch k+1 and the download of batch k-1 on copy streams
-    of their own while batch k is computed (double-buffered device input, the outputs are the tensors enhance() returns)."""
+    of their own while batch k is computed (device input and output double-buffered).  The copies carry NO device-side dependency on the
+    compute queues and nothing waits on them on the device: the host waits for the device at the top of every iteration (pass k-1, the
+    download of k-2 and the upload of k are over — it would wait for pass k-1 inside enhance() anyway) and then enqueues the two copies and
+    the pass.  (Copies that have to wait for a kernel's signal, or that are enqueued in the middle of a pass, were measured at 20-35 ms
+    per step instead of 16-18: tools/dev/hostio_probe.py --variants, profiles/r03_hostio_probe.log.)"""
     from deepfilternet_amd.enhance import enhance
 
     B, T = x.shape
@@ -507,49 +523,26 @@ def bench_host_io(model, df_state, x, steps: int) -> dict:
     xh = torch.empty((B, T), dtype=torch.float32, pin_memory=True)
     xh.copy_(x)
     yh = [torch.empty((B, T), dtype=torch.float32, pin_memory=True) for _ in range(2)]
-    xd = [torch.empty_like(x) for _ in range(3)]
-    main = torch.cuda.current_stream()
+    xd = [torch.empty_like(x) for _ in range(2)]
+    ys = [None, None]
     s_in, s_out = torch.cuda.Stream(), torch.cuda.Stream()
-    ev_in = [torch.cuda.Event() for _ in range(3)]
-    ev_done = [torch.cuda.Event() for _ in range(3)]
-    ev_out = [torch.cuda.Event() for _ in range(2)]
-    ys = [None, None, None]
-
-    # The copies carry NO device-side dependency on the compute queues (a copy that has to wait for a kernel's signal is executed by a
-    # blit kernel on the CUs instead of the DMA engines here — measured: 31 instead of 17.7 ms per step, tools/dev/hostio_probe.py): the
-    # host makes sure a copy's operands are free before it enqueues it (the passes it has to wait for are long over: enhance() paces
-    # itself to one pass in flight), and only the compute stream waits for an upload.
-    def upload(k):
-        i = k % 3
-        ev_done[i].synchronize()             # batch k - 3 (the last reader of xd[i]) is over — it is, for two passes already
-        with torch.cuda.stream(s_in):
-            xd[i].copy_(xh, non_blocking=True)
-            ev_in[i].record(s_in)
-
-    def download(k):
-        ev_done[k % 3].synchronize()         # pass k is over (enhance(k + 1) has waited for it before it started its own pass)
-        j = k & 1
-        ev_out[j].synchronize()              # yh[j] of batch k - 2 has arrived: this is where a consumer takes it
-        with torch.cuda.stream(s_out):
-            yh[j].copy_(ys[k % 3], non_blocking=True)
-            ev_out[j].record(s_out)
 
     def run(n):
-        for e in ev_done:
-            e.record(main)
-        for e in ev_out:
-            e.record(s_out)
         torch.cuda.synchronize()
-        upload(0)
+        with torch.cuda.stream(s_in):
+            xd[0].copy_(xh, non_blocking=True)
         for k in range(n):
-            if k + 1 < n:
-                upload(k + 1)                  # runs under the compute of batch k
-            main.wait_event(ev_in[k % 3])
-            ys[k % 3] = enhance(model, df_state, xd[k % 3])
-            ev_done[k % 3].record(main)
+            torch.cuda.synchronize()                # pass k-1, the download of batch k-2 and the upload of batch k are over
             if k >= 1:
-                download(k - 1)                # runs under the compute of batch k
-        download(n - 1)
+                with torch.cuda.stream(s_out):      # batch k-1 leaves under the compute of batch k (a consumer would take yh[(k-2) & 1] here)
+                    yh[(k - 1) & 1].copy_(ys[(k - 1) & 1], non_blocking=True)
+            if k + 1 < n:
+                with torch.cuda.stream(s_in):       # batch k+1 arrives under the compute of batch k
+                    xd[(k + 1) & 1].copy_(xh, non_blocking=True)
+            ys[k & 1] = enhance(model, df_state, xd[k & 1])
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s_out):
+            yh[(n - 1) & 1].copy_(ys[(n - 1) & 1], non_blocking=True)
         torch.cuda.synchronize()
 
     run(3)
@@ -560,9 +553,9 @@ def bench_host_io(model, df_state, x, steps: int) -> dict:
     return {"ms_per_step_host_to_host": dt * 1e3, "frames_per_s_host_to_host": B * (T // HOP) / dt,
             "pcie_gb_per_s_each_way": nbytes / dt / 1e9, "bytes_each_way_per_step": nbytes, "steps": steps, "finite": ok,
             "how": "page-locked [B, T] f32 input and output; H2D of batch k+1 and D2H of batch k-1 on their own HIP streams under the compute of "
-                   "batch k (device input triple-buffered, copies without device-side dependencies so that the DMA engines take them); not part of "
-                   "`value`, which keeps its inputs resident in HBM.  This box moves 57 GB/s in one direction and 2 x 28.7 GB/s in both at once "
-                   "(tools/dev/hostio_probe.py): 2 x 492 MB per step is 17.2 ms of DMA time, i.e. the host-to-host step is bound by the link"}
+                   "batch k (device input and output double-buffered, copies without device-side dependencies so that the DMA engines take them; the "
+                   "last batch's download is inside the timed region); a process of its own; not part of `value`, which keeps its inputs resident in "
+                   "HBM.  This box moves 57 GB/s in one direction and 2 x 28.7 GB/s in both at once (tools/dev/hostio_probe.py)"}
 
 
 def bench_df_apply_o10(dev, df_state, B: int, Tf: int, iters: int = 20) -> dict:

@@ -55,3 +55,41 @@ if "--compute" in sys.argv:
         d2h(); enhance(model, st, x)
     out["compute_with_d2h_ms"] = timeit(comp_d2h, 5) * 1e3
 print(json.dumps(out))
+if "--variants" in sys.argv:
+    from deepfilternet_amd.config import ModelParams
+    from deepfilternet_amd.enhance import enhance, init_df
+    import bench
+    p = ModelParams.deepfilternet3()
+    model, st, _, _ = init_df(params=p, epoch="none", seed=0)
+    x = 0.1 * torch.randn((B, T), device=dev)
+    main = torch.cuda.current_stream()
+    e1, e2 = torch.cuda.Event(), torch.cuda.Event()
+    res = {}
+    def v1():
+        both(); enhance(model, st, x)
+    res["v1_probe"] = timeit(v1) * 1e3
+    def v2():
+        both(); e1.record(s1); e2.record(s2); enhance(model, st, x)
+    res["v2_events_recorded"] = timeit(v2) * 1e3
+    def v3():
+        both(); e1.record(s1); e2.record(s2); main.wait_event(e1); enhance(model, st, x)
+    res["v3_compute_waits_for_upload"] = timeit(v3) * 1e3
+    last = [enhance(model, st, x)]
+    def v4():
+        with torch.cuda.stream(s1):
+            xd.copy_(xh, non_blocking=True)
+        with torch.cuda.stream(s2):
+            yh.copy_(last[0], non_blocking=True)
+        last[0] = enhance(model, st, xd)
+    torch.cuda.synchronize()
+    res["v4_real_buffers_no_sync"] = timeit(v4) * 1e3
+    def v5():
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            xd.copy_(xh, non_blocking=True)
+        with torch.cuda.stream(s2):
+            yh.copy_(last[0], non_blocking=True)
+        last[0] = enhance(model, st, x)
+    res["v5_host_sync_then_copies_then_pass"] = timeit(v5) * 1e3
+    res["v6_bench_host_io"] = bench.bench_host_io(model, st, x, 6)["ms_per_step_host_to_host"]
+    print(json.dumps(res))
