@@ -88,7 +88,9 @@ struct DfxKScope {
 // x_len < T: the samples [x_len, T) of every row are implicit zeros (x_stride may then be as small as x_len); -1 = T
 int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_stride,
                         const float *mem_in, float *mem_out, float *spec, float *erb_db, hipStream_t s, int64_t x_len = -1,
-                        int64_t spec_stride = 0);  // spec_stride: row stride of spec in complex elements (0: F)
+                        int64_t spec_stride = 0);
+int dfx_launch_analysis_mem(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_stride, const float *mem_in, float *mem_out,
+                            hipStream_t s);  // spec_stride: row stride of spec in complex elements (0: F)
 int dfx_features_padded(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_len, int64_t x_stride, int nb_df,
                         float alpha, float *spec, float *erb_feat, float *spec_feat, void *stream, int64_t spec_stride = 0);
 // dfx_synthesis storing only stream samples [out_skip, out_skip + out_len) of every row, at out[row * out_stride + n - out_skip]

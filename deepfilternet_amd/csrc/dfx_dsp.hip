@@ -385,13 +385,20 @@ int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t 
         }
         DFX_LAUNCH_CHECK();
     }
-    if (mem_out && B > 0) {
-        const int64_t n = B * ML;
-        DfxKScope ks(DFX_K_ANALYSIS_MEM, s);
-        dfx_launch(dfx_k_analysis_mem_out, dim3((unsigned)dfx_ceil_div(n, 256)), dim3(256), 0, s, x, mem_in, mem_out, B, Tf,
-                   x_stride, st->hop, ML);
-        DFX_LAUNCH_CHECK();
-    }
+    if (mem_out && B > 0) return dfx_launch_analysis_mem(st, x, B, T, x_stride, mem_in, mem_out, s);
+    return DFX_OK;
+}
+// the analysis memory after the T samples of a call (what dfx_launch_analysis does last when it is given mem_out; on its own for callers
+// that want it off the stream the spectra are waited for on: only the NEXT call reads it)
+int dfx_launch_analysis_mem(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_stride, const float *mem_in, float *mem_out,
+                            hipStream_t s) {
+    const int64_t Tf = T / st->hop;
+    const int ML = st->N - st->hop;
+    if (!mem_out || B <= 0) return DFX_OK;
+    const int64_t n = B * ML;
+    DfxKScope ks(DFX_K_ANALYSIS_MEM, s);
+    dfx_launch(dfx_k_analysis_mem_out, dim3((unsigned)dfx_ceil_div(n, 256)), dim3(256), 0, s, x, mem_in, mem_out, B, Tf, x_stride, st->hop, ML);
+    DFX_LAUNCH_CHECK();
     return DFX_OK;
 }
 

@@ -4,6 +4,7 @@
 #include "dfx_nn_kernels.h"
 
 #include <cmath>
+#include <functional>
 #include <map>
 
 // ------------------------------------------------------------------------------------------------ cfg validation
@@ -125,9 +126,13 @@ struct DfxStreamCtx {
     int64_t spec_T;    // frames per clip of the spec array
     float *h_state;    // [GRU layers][B][256], in model order enc, erb_dec, df_dec
     float *h_next = nullptr;   // non-null (one new frame, ungated): the layers run as dfx_k_gru_step_h3 and leave their new states HERE
-    void *c0ring = nullptr;    // non-null (one new frame, ungated): df_convp reads the split c0 tiles of the kt - 1 older frames from this ring
+    void *c0ring = nullptr;    // non-null (one new frame, ungated): df_convp keeps the pending sums of its next kt - 1 outputs here (dfx_k_df_convp_step)
     int c0slot = 0;            //   slot of the new frame = its net position % (kt - 1)
-    bool c0rebuild = false;    //   the ring is not current: recompute the older frames from the feature window and store them
+    bool c0rebuild = false;    //   the sums are not current: recompute the older frames' taps from the feature window
+    std::function<int(hipStream_t)> df_pre;   // set: state updates that only the DF branch reads — enqueued on that branch's stream before its
+                                              //   first kernel instead of in front of the encoder
+    std::function<int(hipStream_t)> df_post;  // set: state updates that nothing before the final deep filter reads — enqueued behind df_convp on
+                                              //   its stream (joined through EV_C0P before df_out), or with df_pre when that kernel does not run
     float pf_beta;     // < 0: the model's setting
     float *out;        // [B, out_T, F][2]: local frame t of clip b is stored at frame t - out_toff
     int64_t out_T, out_toff;
@@ -1358,10 +1363,11 @@ static int launch_convp_step(const dfx_model *m, const float *feat_spec, float *
         A.err = m->d_err;
         A.nfb = (Fd + 15) / 16;
         A.nseg = 1, A.tseg = 1;
-        const int grid = nn_grid(dfx_ceil_div(B * A.nfb, 4), 8);
+        static const int per_cu = [] { const char *e = getenv("DFX_CONVP_STEP_WGS"); return e && atoi(e) > 0 ? atoi(e) : 8; }();
+        const int grid = nn_grid(dfx_ceil_div(B * A.nfb, 4), per_cu);
         DfxKScope ks(DFX_K_DF_CONVP, s);
-        if (rebuild) dfx_launch((dfx_k_df_convp_step<C, KT, true>), dim3(grid), dim3(256), 0, s, A, reinterpret_cast<dfx_h8 *>(ring), slot);
-        else dfx_launch((dfx_k_df_convp_step<C, KT, false>), dim3(grid), dim3(256), 0, s, A, reinterpret_cast<dfx_h8 *>(ring), slot);
+        if (rebuild) dfx_launch((dfx_k_df_convp_step<C, KT, true>), dim3(grid), dim3(256), 0, s, A, reinterpret_cast<f32x4 *>(ring), slot);
+        else dfx_launch((dfx_k_df_convp_step<C, KT, false>), dim3(grid), dim3(256), 0, s, A, reinterpret_cast<f32x4 *>(ring), slot);
         DFX_LAUNCH_CHECK();
         return DFX_OK;
     }
@@ -1844,9 +1850,18 @@ static int run_gru_stack(const dfx_model *m, const std::vector<GruW> &layers, co
             A.bias_i = m->p(g.bias_i), A.bhn = m->p(g.bhn);
             A.unscale_i = g.wih_unscale, A.unscale_h = g.whh_unscale;
             A.B = B;
-            DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_step_h3, DFX_PH_SMEM));
+            // 32 hidden units per workgroup (twice the workgroups, half the chunk) unless 64-unit workgroups already fill the chip
+            static const int ct_env = [] { const char *e = getenv("DFX_GRU_STEP_CT"); return e ? atoi(e) : 0; }();
+            const bool wide = ct_env == 4 || (ct_env != 2 && dfx_ceil_div(B, DFX_PH_BM) * 4 >= 2 * dfx_env_num_cus());
             DfxKScope ks(DFX_K_GRU_REC, s);
-            dfx_launch(dfx_k_gru_step_h3, dim3((unsigned)(dfx_ceil_div(B, DFX_PH_BM) * 4)), dim3(DFX_PH_THREADS), DFX_PH_SMEM, s, A);
+            const unsigned rb8 = (unsigned)(dfx_ceil_div(dfx_ceil_div(B, DFX_PH_BM), 8) * 8);   // row blocks, padded: the kernel deals them to the XCDs
+            if (wide) {
+                DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_step_h3<4>, DFX_PH_SMEM));
+                dfx_launch(dfx_k_gru_step_h3<4>, dim3(rb8 * 4), dim3(DFX_PH_THREADS), DFX_PH_SMEM, s, A);
+            } else {
+                DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_step_h3<2>, DFX_PH_SMEM / 2));
+                dfx_launch(dfx_k_gru_step_h3<2>, dim3(rb8 * 8), dim3(DFX_PH_THREADS), DFX_PH_SMEM / 2, s, A);
+            }
             DFX_LAUNCH_CHECK();
             in = outb;
             outb = (outb == bufa) ? bufb : bufa;
@@ -1962,6 +1977,9 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         return DFX_OK;
     };
     if ((rc = signal(EV_START, s)) || (rc = wait(EV_START, x1))) return rc;
+    const bool post_behind_convp = sc && sc->df_post && m->run_df && !m->convp_late;
+    if (sc && sc->df_pre && (rc = sc->df_pre(x1))) return rc;
+    if (sc && sc->df_post && !post_behind_convp && (rc = sc->df_post(x1))) return rc;
     // ---- Encoder, DF branch on x1 (deepfilternet3.py:176-179).  By default c0 = df_conv0(feat_spec) never exists in HBM: its two
     // consumers (df_conv1 here, df_convp below) recompute the tiles they need from feat_spec on the matrix core.
     const bool fuse_c0 = m->fuse_c0;
@@ -2178,6 +2196,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         auto run_convp = [&]() -> int {
             for (int i = 0; i < nfr; ++i)
                 if (int r = convp_range(fb(i), fb(i + 1), x2)) return r;
+            if (post_behind_convp)
+                if (int r = sc->df_post(x2)) return r;
             return signal(EV_C0P, x2);
         };
         // the pathway conv only has to finish before df_out: it starts right away on the low-priority stream x2 and fills whatever the
@@ -2894,9 +2914,9 @@ struct dfx_stream_state {
     size_t ana_mem[2], syn_mem[2], erb_state, unit_state, hist_fe[2], hist_fs[2], hist_spec[2], new_spec, new_fe, new_fs, work_fe, work_fs,
         work_spec, out_spec, h_state, h_state2, lsnr, model_ws;
     int hflip = 0;            // which of h_state / h_state2 holds the GRU states (the one-step kernel writes the other one: dfx_k_gru_step_h3)
-    size_t c0ring = 0;        // split c0 tiles of the last kt - 1 frames (dfx_k_df_convp_step); c0ring_bytes == 0: not available
+    size_t c0ring = 0;        // pending sums of df_convp's next kt - 1 outputs (dfx_k_df_convp_step); c0ring_bytes == 0: not available
     size_t c0ring_bytes = 0;
-    bool c0ring_ok = true;    // the ring is current (all zeros after a reset; stale after a pass that did not go through the step kernel)
+    bool c0ring_ok = true;    // the sums are current (all zeros after a reset; stale after a pass that did not go through the step kernel)
     int64_t model_ws_bytes = 0;
     int flip = 0;             // which of the double-buffered STFT memories is current
     // The rolling spectra of an ungated handle live in a LINEAR buffer [B, lin_cap, F] through which the window [lin_pos, lin_pos + Hs + n)
@@ -2993,9 +3013,9 @@ extern "C" int dfx_stream_create(const dfx_model *m, const dfx_state *st, int64_
     }
     s->h_state = take((size_t)s->layers * B * 256 * 4);
     s->h_state2 = take((size_t)s->layers * B * 256 * 4);
-    {   // c0 ring of dfx_k_df_convp_step: [B][kt-1][nfb][C/32][hi,lo][64 lanes] x 16 bytes (4096 streams of the released model: 403 MB)
+    {   // pending sums of dfx_k_df_convp_step: [B][kt-1][nfb][64 lanes] x 16 bytes (4096 streams of the released model: 101 MB)
         const int kt = c.df_pathway_kernel_size_t;
-        const size_t rb = kt >= 2 && c.conv_ch % 32 == 0 ? (size_t)B * (kt - 1) * ((Fd + 15) / 16) * (c.conv_ch / 32) * 2 * 64 * 16 : 0;
+        const size_t rb = kt >= 2 && c.conv_ch % 32 == 0 ? (size_t)B * (kt - 1) * ((Fd + 15) / 16) * 64 * 16 : 0;
         static const bool ring_env = [] { const char *e = getenv("DFX_STREAM_C0RING"); return !(e && e[0] == '0'); }();
         if (rb > 0 && rb <= ((size_t)1 << 30) && ring_env) {
             s->c0ring_bytes = rb;
@@ -3169,20 +3189,31 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     // and the clip stride (in frames) the deep filter has to use.
     const bool lin = S->lin_cap > 0 && !gated && !S->use_graph && !S->capturing;
     const int64_t F2 = F * 2;
+    struct RowCopy { const float *src; int64_t src_stride, src_len, src_off; float *dst; int64_t dst_stride, len; };
+    RowCopy later[2];
+    int nlater = 0;
+    bool defer = false;   // the linear form's copies are listed in `later` instead of being enqueued on s (the caller enqueues them elsewhere)
     auto spec_window = [&](const float *new_spec, const float **win, int64_t *win_T) -> int {
         int r;
         if (lin) {
             float *L0 = fp(S->spec_lin);
             const int64_t cap = S->lin_cap;
+            auto copy = [&](const float *src, int64_t src_stride, int64_t src_len, int64_t src_off, float *dst, int64_t dst_stride, int64_t len) -> int {
+                if (defer) {
+                    later[nlater++] = RowCopy{src, src_stride, src_len, src_off, dst, dst_stride, len};
+                    return DFX_OK;
+                }
+                return stream_copy_rows(src, src_stride, src_len, src_off, dst, dst_stride, len, B, s);
+            };
             if (!S->lin_owns) {   // the ring form's history becomes the window's first Hs frames
-                if ((r = stream_copy_rows(fp(S->hist_spec[S->flip]), Hs * F2, Hs * F2, 0, L0, cap * F2, Hs * F2, B, s))) return r;
+                if ((r = copy(fp(S->hist_spec[S->flip]), Hs * F2, Hs * F2, 0, L0, cap * F2, Hs * F2))) return r;
                 S->lin_pos = 0;
                 S->lin_owns = true;
             } else if (S->lin_pos + Hs + n > cap) {   // the window has reached the end: its last Hs frames go back to the front (no overlap: lin_pos >= Hs)
-                if ((r = stream_copy_rows(L0, cap * F2, cap * F2, S->lin_pos * F2, L0, cap * F2, Hs * F2, B, s))) return r;
+                if ((r = copy(L0, cap * F2, cap * F2, S->lin_pos * F2, L0, cap * F2, Hs * F2))) return r;
                 S->lin_pos = 0;
             }
-            if ((r = stream_copy_rows(new_spec, n * F2, n * F2, 0, L0 + (S->lin_pos + Hs) * F2, cap * F2, n * F2, B, s))) return r;
+            if ((r = copy(new_spec, n * F2, n * F2, 0, L0 + (S->lin_pos + Hs) * F2, cap * F2, n * F2))) return r;
             *win = L0 + S->lin_pos * F2;
             *win_T = cap;
             S->lin_pos += n;   // (advanced here, not by the caller: this form is never replayed from a graph nor walked hop by hop)
@@ -3257,7 +3288,12 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     float *am_in = fp(S->ana_mem[S->flip]), *am_out = fp(S->ana_mem[S->flip ^ 1]);
     float *sm_in = fp(S->syn_mem[S->flip]), *sm_out = fp(S->syn_mem[S->flip ^ 1]);
     float *new_spec = fp(S->new_spec), *new_fe = fp(S->new_fe), *new_fs = fp(S->new_fs);
-    if ((rc = dfx_launch_analysis(st, x, B, n * hop, xs, am_in, am_out, new_spec, new_fe, s))) return rc;
+    // The linear form: what only the DF branch needs (the DF feature window) is enqueued on that branch's stream (DfxStreamCtx::df_pre), what
+    // only the final deep filter or the NEXT call needs (the spectrum window, the analysis memory) behind df_convp on its stream
+    // (DfxStreamCtx::df_post) — in front of the encoder these four small launches were 40 us of a 520 us hop at 4096 streams
+    static const bool side_env = [] { const char *e = getenv("DFX_STREAM_SIDE"); return !(e && e[0] == '0'); }();
+    const bool side = side_env && lin && !S->capturing && !S->use_graph;
+    if ((rc = dfx_launch_analysis(st, x, B, n * hop, xs, am_in, side ? nullptr : am_out, new_spec, new_fe, s))) return rc;
     if ((rc = dfx_launch_norm_scan(new_fe, new_fe, (int)E, new_spec, F, new_fs, (int)Fd, B, n, c.norm_alpha, fp(S->erb_state),
                                    fp(S->unit_state), s)))
         return rc;
@@ -3271,13 +3307,37 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         {S->hist_fe, new_fe, work_fe, H, E, true}, {S->hist_fs, new_fs, work_fs, H, Fd * 2, true}};
     const float *spec_win = work_spec;
     int64_t spec_win_T = Hs + n;
-    if ((rc = spec_window(new_spec, &spec_win, &spec_win_T))) return rc;
-    for (const Ring &r : rings) {  // one launch per ring: window = [history ; new], next call's history = its last h frames
-        DfxKScope ks(DFX_K_COPY_ROWS, s);
-        dfx_launch(dfx_k_ring_step, dim3((unsigned)nn_grid(dfx_ceil_div(B * (r.h + n) * r.row, 256), 16)), dim3(256), 0, s,
+    auto ring_step = [&](const Ring &r, hipStream_t on) -> int {  // window = [history ; new], next call's history = its last h frames
+        DfxKScope ks(DFX_K_COPY_ROWS, on);
+        dfx_launch(dfx_k_ring_step, dim3((unsigned)nn_grid(dfx_ceil_div(B * (r.h + n) * r.row, 256), 16)), dim3(256), 0, on,
                    (const float *)fp(r.hist[S->flip]), (const float *)r.nw, r.work, fp(r.hist[S->flip ^ 1]), B, r.h, n, r.row,
                    r.zero_skipped ? skip : (int64_t)0);
         DFX_LAUNCH_CHECK();
+        return DFX_OK;
+    };
+    bool side_done = false;
+    std::function<int(hipStream_t)> side_pre, side_post;
+    if (side) {
+        // the window's address and position are settled now (the forward pass is handed the window); its copies are enqueued by side_post
+        defer = true;
+        rc = spec_window(new_spec, &spec_win, &spec_win_T);
+        defer = false;
+        if (rc) return rc;
+        side_pre = [&](hipStream_t on) -> int { return ring_step(rings[1], on); };
+        side_post = [&](hipStream_t on) -> int {
+            int r;
+            side_done = true;
+            for (int i = 0; i < nlater; ++i)
+                if ((r = stream_copy_rows(later[i].src, later[i].src_stride, later[i].src_len, later[i].src_off, later[i].dst, later[i].dst_stride,
+                                          later[i].len, B, on)))
+                    return r;
+            return dfx_launch_analysis_mem(st, x, B, n * hop, xs, am_in, am_out, on);
+        };
+        if ((rc = ring_step(rings[0], s))) return rc;
+    } else {
+        if ((rc = spec_window(new_spec, &spec_win, &spec_win_T))) return rc;
+        for (const Ring &r : rings)
+            if ((rc = ring_step(r, s))) return rc;
     }
     float *out_spec = fp(S->out_spec);
     if (skip > 0) DFX_HIP(hipMemsetAsync(out_spec, 0, (size_t)B * n * F * 8, s));  // warm-up hops: zero spectra (tract.rs rolling buffers)
@@ -3295,12 +3355,13 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         const bool step = step_env && n - skip == 1 && !gated && !S->capturing && !S->use_graph;
         sc.h_next = step ? fp(S->hflip ? S->h_state : S->h_state2) : nullptr;
         stepped = step;
-        if (step && S->c0ring_bytes) {   // df_convp from the ring of split c0 tiles (dfx_k_df_convp_step)
+        if (step && S->c0ring_bytes) {   // df_convp from its pending sums (dfx_k_df_convp_step)
             const int ns = c.df_pathway_kernel_size_t - 1;
             sc.c0ring = S->buf + S->c0ring;
             sc.c0slot = (int)((((a0 + skip - L) % ns) + ns) % ns);
             sc.c0rebuild = !S->c0ring_ok;
         }
+        if (side) sc.df_pre = side_pre, sc.df_post = side_post;
         sc.pf_beta = S->pf_beta;
         sc.out = out_spec;  // local frame t of clip b lands at out_spec[(b*n + t - H) * F]
         sc.out_T = n;
@@ -3326,7 +3387,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         }
         if (rc) return rc;
         if (stepped) S->hflip ^= 1;   // (like lin_pos: this form is neither replayed from a graph nor walked hop by hop by the caller)
-        S->c0ring_ok = stepped && S->c0ring_bytes;   // any other pass leaves the ring behind
+        S->c0ring_ok = stepped && S->c0ring_bytes;   // any other pass leaves the sums behind
         if (gated && c.df_pathway_kernel_size_t > 1) {  // the DF decoder's delay line moves where that decoder ran
             const int64_t frame = (int64_t)Fd * c.conv_ch;
             dfx_launch(dfx_k_gate_c0_shift, dim3((unsigned)B, 4), dim3(256), 0, s, (const unsigned char *)gflags, gp(S->g_c0_win), B, T,
@@ -3334,6 +3395,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
             DFX_LAUNCH_CHECK();
         }
     }
+    if (side && !side_done && ((rc = side_pre(s)) || (rc = side_post(s)))) return rc;   // (no forward pass ran: warm-up hops)
     // ---- ISTFT of the n enhanced hops (state: overlap-add memory)
     if ((rc = dfx_launch_synthesis(st, out_spec, B, n, sm_in, sm_out, y, ys, 0, n * hop, s))) return rc;
     if (lsnr_out) {  // the window's lsnr is [B, T]: take the n new frames (the entries of warm-up hops are not meaningful)

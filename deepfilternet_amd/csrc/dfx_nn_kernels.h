@@ -842,14 +842,18 @@ __global__ void __launch_bounds__(256, 1) dfx_k_df_convp_h3(DfxCphArgs A) {
 
 // dfx_k_df_convp_step: df_convp for ONE new frame per stream (the frame-by-frame runtime).  dfx_k_df_convp_h3 recomputes the kt - 1
 // frames of c0 in front of a segment as warm-up — for a segment of one frame four of its five c0 tiles per output (334 us at 4096
-// streams, longer than the whole ERB branch of the hop).  Here the handle keeps the split c0 tiles of the last kt - 1 frames, already in
-// the matrix-op B-operand layout (f16 hi / lo fragments), in a ring: ring[b][slot][fb][kc][hi,lo][lane], slot = frame % (kt - 1).
-// A wave owns (stream, 16-bin block): taps 0 .. kt-2 read their frames' fragments from the ring (tap 0's slot is the one the new frame
-// replaces: read first, written last, by the same lane), the last tap's frame is computed from the features and stored.  REBUILD: the
-// ring is not current (after a reset it is all zeros = the causal padding and needs none; after calls of several hops or gated passes
-// it does): the kt - 1 older frames are recomputed from the feature window like dfx_k_df_convp_h3 does, and stored.
+// streams, longer than the whole ERB branch of the hop).  The convolution is linear in its time taps, so the handle keeps, per stream
+// and 16-bin block, the PENDING SUMS of the next kt - 1 outputs instead of any history of c0: out[t + j] so far = the taps of the frames
+// <= t (fp32 accumulator fragments as the matrix op leaves them, in the weights' scale: pend[b][slot][fb][lane], slot = frame % (kt - 1),
+// 1 KB each).  A wave owns (stream, block): it computes the new frame's c0 tile once, multiplies it with all kt taps — tap kt-1 completes
+// out[t] from its pending sum, tap k adds to the sum of out[t + kt-1-k], tap 0 starts the sum of out[t + kt-1] in the slot out[t] frees
+// (read first, written last, by the same lane).  Per block and hop 4 KB are read and 4 KB written; the first form of this kernel kept
+// the split c0 tiles of the last kt - 1 frames (16 KB read, 4 KB written: 490 MB per hop at 4096 streams, 150 us beside which the
+// encoder's GRU step took 95 us instead of 40).  REBUILD: the sums are not current (after a reset they are all zeros = the causal
+// padding and need none; after calls of several hops or gated passes they do): the kt - 1 older frames are recomputed from the feature
+// window like dfx_k_df_convp_h3 does, and their taps summed up.
 template <int C, int KT, bool REBUILD>
-__global__ void __launch_bounds__(256, 2) dfx_k_df_convp_step(DfxCphArgs A, dfx_h8 *ring, int slot_new) {
+__global__ void __launch_bounds__(256, 2) dfx_k_df_convp_step(DfxCphArgs A, f32x4 *pend, int slot_new) {
     constexpr int CPL = C / 4, NT = C / 16, KC = C / 32, NS = KT - 1;
     static_assert(C % 32 == 0 && KT >= 2, "one k-chunk is 32 channels; kt = 1 has no history");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
@@ -872,52 +876,53 @@ __global__ void __launch_bounds__(256, 2) dfx_k_df_convp_step(DfxCphArgs A, dfx_
         const int64_t b = run / A.nfb;
         const int f = fb * 16 + jl;
         const bool fvalid = f < A.Fd;
-        auto slot_ptr = [&](int slot) { return ring + ((((size_t)b * NS + slot) * A.nfb + fb) * KC * 2) * 64 + lane; };
-        auto make_frame = [&](dfx_h8 (&dh)[KC], dfx_h8 (&dl)[KC], int64_t tau) {
+        auto slot_ptr = [&](int j) { return pend + (((size_t)b * NS + (slot_new + j) % NS) * A.nfb + fb) * 64 + lane; };   // sum of out[t + j]
+        // sums[o]: out[t + o] — o = 0 is completed here, 1 .. NS go back to the handle; per sum three chains (one per product term, added
+        // small-to-large at the end: the order of dfx_k_df_convp_h3 within a tap)
+        f32x4 sa[KT], sb[KT], sc[KT];
+#pragma unroll
+        for (int o = 0; o < KT; ++o) sa[o] = sb[o] = f32x4{0.f, 0.f, 0.f, 0.f}, sc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!REBUILD) {
+#pragma unroll
+            for (int o = 0; o < NS; ++o) sc[o] = *slot_ptr(o);   // (out[t + NS] has no taps yet)
+        }
+        dfx_static_for<(REBUILD ? 0 : KT - 1), KT>([&](auto dc) {
+            constexpr int d = decltype(dc)::value;   // frame t - (KT-1) + d; its tap k belongs to out[t + d - k]
+            const int64_t tau = t - (KT - 1) + d;
             float2 raw[4];
             dfx_c0_patch_load(A.feat, b, tau, f, fvalid && tau >= 0, A.T, A.Fd, A.L, q, raw);
             float c0v[CPL];
             dfx_c0_tile_h3<C>(w0h, w0l, bias0, A.unscale0, raw, fvalid && tau >= A.t_zero, c0v, amax);
-#pragma unroll
-            for (int kc = 0; kc < KC; ++kc) dfx_split8_g(c0v + 8 * kc, dh[kc], dl[kc], amax);
-        };
-        f32x4 aa = f32x4{0.f, 0.f, 0.f, 0.f}, ab = aa, ac = aa;
-        dfx_static_for<0, KT>([&](auto kcn) {
-            constexpr int k = decltype(kcn)::value;   // tap k reads frame t - (KT-1) + k
             dfx_h8 xh[KC], xl[KC];
-            const int slot = (slot_new + k) % NS;     // (k = KT-1: the new frame's own slot = tap 0's)
-            if (k == KT - 1) {
-                make_frame(xh, xl, t);
-            } else if (REBUILD) {
-                make_frame(xh, xl, t - (KT - 1) + k);
-            } else {
-                const dfx_h8 *sp = slot_ptr(slot);
 #pragma unroll
-                for (int kc = 0; kc < KC; ++kc) xh[kc] = sp[(kc * 2 + 0) * 64], xl[kc] = sp[(kc * 2 + 1) * 64];
-            }
-            if (k == KT - 1 || (REBUILD && k > 0)) {   // (REBUILD: frame t - (KT-1) is about to leave the window, its slot is the new frame's)
-                dfx_h8 *sp = slot_ptr(slot);
-#pragma unroll
-                for (int kc = 0; kc < KC; ++kc) sp[(kc * 2 + 0) * 64] = xh[kc], sp[(kc * 2 + 1) * 64] = xl[kc];
-            }
+            for (int kc = 0; kc < KC; ++kc) dfx_split8_g(c0v + 8 * kc, xh[kc], xl[kc], amax);
+            // consecutive matrix ops go to different sums (an op that waits for its predecessor's accumulator stalls for that op's latency)
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
-                const dfx_h8 wl = A.wf[((k * KC + kc) * 2 + 1) * 64 + lane], wh = A.wf[((k * KC + kc) * 2 + 0) * 64 + lane];
-                aa = dfx_mfma_16x16x32_f16(wl, xh[kc], aa);
-                ab = dfx_mfma_16x16x32_f16(wh, xl[kc], ab);
-                ac = dfx_mfma_16x16x32_f16(wh, xh[kc], ac);
+                dfx_h8 wl[KT], wh[KT];
+                dfx_static_for<0, d + 1>([&](auto kcn) {
+                    constexpr int k = decltype(kcn)::value;
+                    wl[k] = A.wf[((k * KC + kc) * 2 + 1) * 64 + lane], wh[k] = A.wf[((k * KC + kc) * 2 + 0) * 64 + lane];
+                });
+                dfx_static_for<0, d + 1>([&](auto kcn) { constexpr int k = decltype(kcn)::value; sa[d - k] = dfx_mfma_16x16x32_f16(wl[k], xh[kc], sa[d - k]); });
+                dfx_static_for<0, d + 1>([&](auto kcn) { constexpr int k = decltype(kcn)::value; sb[d - k] = dfx_mfma_16x16x32_f16(wh[k], xl[kc], sb[d - k]); });
+                dfx_static_for<0, d + 1>([&](auto kcn) { constexpr int k = decltype(kcn)::value; sc[d - k] = dfx_mfma_16x16x32_f16(wh[k], xh[kc], sc[d - k]); });
             }
         });
-        f32x4 acc;
+        f32x4 sum[KT];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = (aa[r] + ab[r]) + ac[r];
+        for (int o = 0; o < KT; ++o)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum[o][r] = (sa[o][r] + sb[o][r]) + sc[o][r];
+#pragma unroll
+        for (int o = 1; o < KT; ++o) *slot_ptr(o) = sum[o];   // (slot of out[t + NS] = the one out[t] was read from)
         if (fvalid) {
             float *op = A.out + ((b * (A.NO / 2) * A.T + t) * A.Fd + f) * 2;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
                 if (4 * q + 2 * h < A.NO)
                     *reinterpret_cast<float2 *>(op + (int64_t)(2 * q + h) * A.T * A.Fd * 2) =
-                        make_float2(fmaxf(acc[2 * h] * A.unscale + biasr[2 * h], 0.f), fmaxf(acc[2 * h + 1] * A.unscale + biasr[2 * h + 1], 0.f));
+                        make_float2(fmaxf(sum[0][2 * h] * A.unscale + biasr[2 * h], 0.f), fmaxf(sum[0][2 * h + 1] * A.unscale + biasr[2 * h + 1], 0.f));
         }
     }
     if (amax >= DFX_H3_LIMIT && A.err) dfx_raise(A.err + 1);
@@ -2491,33 +2496,65 @@ struct DfxGstArgs {
     int64_t B;
     DfxRowMap xrm, yrm;
 };
+// CT: 16-unit tiles per workgroup.  CT = 4 (64 units, 64-KB chunks): B / 128 x 4 workgroups — 128 at 4096 streams, half the chip, two waves per
+// SIMD sharing its matrix pipe (576 ops each: 7.7 us of pipe time).  CT = 2 (32 units, 32-KB chunks: the halves of the same fragment
+// chunks): 256 workgroups, one per CU.  Both operands (the layer input and the old state) are loaded and split before the first chunk —
+// the recurrent operand used to be fetched between chunks 2 and 3, a full HBM latency with nothing to cover it — and the six chunk
+// phases are unrolled, so that the accumulators of all six stay in registers without a selection chain.
+#ifndef DFX_GST_ABLATE
+#define DFX_GST_ABLATE 0   /* dev ablations (tools/dev/gru_step_bench.hip): 1 no matrix ops, 2 no chunk loads after the first, 4 no operand rows, 8 no gate math */
+#endif
+template <int CT>
 __global__ void __launch_bounds__(DFX_PH_THREADS, 2) dfx_k_gru_step_h3(DfxGstArgs A) {
-    DFX_DYN_SMEM(dfx_h8, ws);  // [2][DFX_PH_CHUNK_H8]
+    static_assert(CT == 2 || CT == 4, "32 or 64 hidden units per workgroup");
+    constexpr int CHUNK = 8 * CT * 2 * 64;   // dfx_h8 per chunk of this workgroup: [kc][ct][hi,lo][lane]
+    constexpr int PER_T = CHUNK / DFX_PH_THREADS;
+    constexpr int NU = 16 / CT;              // unit blocks per layer
+    DFX_DYN_SMEM(dfx_h8, ws);  // [2][CHUNK]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
-    const int u = blockIdx.x & 3;   // block of 64 hidden units
-    const int64_t b = (int64_t)(blockIdx.x >> 2) * DFX_PH_BM + 16 * wave + jl;
+    // The NU workgroups that share a block of 128 rows are dealt to ONE XCD (workgroups go round-robin over the 8 XCDs: block i runs on XCD
+    // i % 8 up to a rotation that is constant within a launch): the operand rows then come from HBM into one L2 instead of all eight —
+    // with row-major block order the step spent half its time fetching 8 x 8 MB of rows (grid: row blocks padded to a multiple of 8)
+    const int xcd = (int)(blockIdx.x & 7), kk = (int)(blockIdx.x >> 3);
+    const int u = kk % NU;   // block of 16 * CT hidden units
+    const int64_t rb = xcd + 8 * (int64_t)(kk / NU);
+    if (rb * DFX_PH_BM >= A.B) return;
+    const int64_t b = rb * DFX_PH_BM + 16 * wave + jl;
     const bool ok = b < A.B;
-    constexpr int PER_T = DFX_PH_CHUNK_H8 / DFX_PH_THREADS;
-    // chunk i of this workgroup: i < 3: W_ih, gate i; else W_hh, gate i - 3 (columns 256 g + 64 u .. + 63 = chunk 4 g + u)
-    auto chunk_src = [&](int i) { return (i < 3 ? A.wif : A.whf) + (size_t)(4 * (i % 3) + u) * DFX_PH_CHUNK_H8; };
+    // chunk i of this workgroup: i < 3: W_ih, gate i; else W_hh, gate i - 3: columns 256 g + 16 CT u .. of the [12][8][4][2][64] fragments,
+    // i.e. the tiles ct0 .. ct0 + CT - 1 of the 64-column chunk 4 g + (CT u) / 4
+    const int ct0 = (CT * u) & 3;
+    auto chunk_src = [&](int i) { return (i < 3 ? A.wif : A.whf) + (size_t)(4 * (i % 3) + (CT * u) / 4) * DFX_PH_CHUNK_H8; };
+    auto src_index = [&](int e) {   // element e of this workgroup's chunk inside the 64-column chunk
+        const int kc = e / (CT * 128), rem = e - kc * (CT * 128);
+        return (kc * 4 + ct0) * 128 + rem;
+    };
+    // both operand rows are requested before anything waits for data (they are the kernel's only HBM reads: a step without them was
+    // measured 12 us instead of 23), the first chunk goes to LDS meanwhile
+    float4 xraw[16], hraw[16];
+    const int64_t bl = ok ? b : A.B - 1;
+    const int64_t xr = dfx_row(A.xrm, bl);
+    auto fetch_row = [&](const float *row, float4 (&raw)[16]) {
+        const float4 *p = reinterpret_cast<const float4 *>(row + 8 * q);
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            // (rows past the end read the last row: a clamped index is one instruction, a predicated load five and a branch — tools/dev/scan_isa.py)
+            raw[2 * kc] = !(DFX_GST_ABLATE & 4) ? p[8 * kc] : make_float4(0.f, 0.f, 0.f, 0.f);
+            raw[2 * kc + 1] = !(DFX_GST_ABLATE & 4) ? p[8 * kc + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    fetch_row(A.x + xr * 256, xraw);
+    fetch_row(A.h_in + bl * 256, hraw);
     {
         const dfx_h8 *src = chunk_src(0);
 #pragma unroll
-        for (int i = 0; i < PER_T; ++i) ws[i * DFX_PH_THREADS + tid] = src[i * DFX_PH_THREADS + tid];
+        for (int i = 0; i < PER_T; ++i) ws[i * DFX_PH_THREADS + tid] = src[src_index(i * DFX_PH_THREADS + tid)];
     }
     // a row's 256 values as B operands, scaled by the row's own power of two before the f16 split (see dfx_k_proj256_h3)
-    dfx_h8 vh[8], vl[8];
-    auto load_row = [&](const float *row) -> float {
-        const float4 *p = reinterpret_cast<const float4 *>(row + 8 * q);
-        float4 xu[8], xv[8];
+    auto split_row = [&](const float4 (&raw)[16], dfx_h8 (&vh)[8], dfx_h8 (&vl)[8]) -> float {
         float mx = 0.f;
 #pragma unroll
-        for (int kc = 0; kc < 8; ++kc) {
-            xu[kc] = ok ? p[8 * kc] : make_float4(0.f, 0.f, 0.f, 0.f);
-            xv[kc] = ok ? p[8 * kc + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(xu[kc].x), fabsf(xu[kc].y)), fmaxf(fabsf(xu[kc].z), fabsf(xu[kc].w))));
-            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(xv[kc].x), fabsf(xv[kc].y)), fmaxf(fabsf(xv[kc].z), fabsf(xv[kc].w))));
-        }
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, fmaxf(fmaxf(fabsf(raw[i].x), fabsf(raw[i].y)), fmaxf(fabsf(raw[i].z), fabsf(raw[i].w))));
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         int e = 0;
@@ -2530,67 +2567,64 @@ __global__ void __launch_bounds__(DFX_PH_THREADS, 2) dfx_k_gru_step_h3(DfxGstArg
         const float sc = ldexpf(1.f, e);
 #pragma unroll
         for (int kc = 0; kc < 8; ++kc) {
+            const float4 xu = raw[2 * kc], xv = raw[2 * kc + 1];
             float x[8];
-            x[0] = xu[kc].x * sc, x[1] = xu[kc].y * sc, x[2] = xu[kc].z * sc, x[3] = xu[kc].w * sc;
-            x[4] = xv[kc].x * sc, x[5] = xv[kc].y * sc, x[6] = xv[kc].z * sc, x[7] = xv[kc].w * sc;
+            x[0] = xu.x * sc, x[1] = xu.y * sc, x[2] = xu.z * sc, x[3] = xu.w * sc;
+            x[4] = xv.x * sc, x[5] = xv.y * sc, x[6] = xv.z * sc, x[7] = xv.w * sc;
             dfx_split8(x, vh[kc], vl[kc]);
         }
         return ldexpf(1.f, -e);
     };
-    const int64_t xr = ok ? dfx_row(A.xrm, b) : 0;
-    float us = A.unscale_i * load_row(A.x + xr * 256);
-    f32x4 gi[3][4], gh[3][4];
+    dfx_h8 xh[8], xl[8], hh[8], hl[8];
+    const float us_x = A.unscale_i * split_row(xraw, xh, xl);
+    float us_h = 0.f;   // (the recurrent operand is split under the matrix ops of chunk 1: it is first used by chunk 3)
+    f32x4 g[6][CT];   // gi (r, z, n) then gh (r, z, n)
     __syncthreads();
-    for (int c = 0; c < 6; ++c) {
-        const dfx_h8 *wc = ws + (size_t)(c & 1) * DFX_PH_CHUNK_H8;
+    dfx_static_for<0, 6>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        const dfx_h8 *wc = ws + (size_t)(c & 1) * CHUNK;
         dfx_h8 pre[PER_T];
-        if (c + 1 < 6) {
+        if constexpr (c + 1 < 6 && !(DFX_GST_ABLATE & 2)) {
             const dfx_h8 *src = chunk_src(c + 1);
 #pragma unroll
-            for (int i = 0; i < PER_T; ++i) pre[i] = src[i * DFX_PH_THREADS + tid];
+            for (int i = 0; i < PER_T; ++i) pre[i] = src[src_index(i * DFX_PH_THREADS + tid)];
+            DFX_SCHED_BARRIER();   // the loads are issued HERE: left alone, the compiler sinks them below the matrix ops, next to the LDS stores that use them
         }
-        f32x4 acc[4];
+        f32x4 acc[CT];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (c == 1) us_h = A.unscale_h * split_row(hraw, hh, hl);
 #pragma unroll
         for (int kc = 0; kc < 8; ++kc) {
-            dfx_h8 whi[4], wlo[4];
+            dfx_h8 whi[CT], wlo[CT];
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                whi[ct] = wc[((kc * 4 + ct) * 2 + 0) * 64 + lane];
-                wlo[ct] = wc[((kc * 4 + ct) * 2 + 1) * 64 + lane];
+            for (int ct = 0; ct < CT; ++ct) {
+                whi[ct] = wc[((kc * CT + ct) * 2 + 0) * 64 + lane];
+                wlo[ct] = wc[((kc * CT + ct) * 2 + 1) * 64 + lane];
             }
+            const dfx_h8 vh = c < 3 ? xh[kc] : hh[kc], vl = c < 3 ? xl[kc] : hl[kc];
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = dfx_mfma_16x16x32_f16(wlo[ct], vh[kc], acc[ct]);
+            for (int ct = 0; ct < CT; ++ct) acc[ct] = dfx_mfma_16x16x32_f16(wlo[ct], vh, acc[ct]);
+            if (DFX_GST_ABLATE & 1) continue;
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = dfx_mfma_16x16x32_f16(whi[ct], vl[kc], acc[ct]);
+            for (int ct = 0; ct < CT; ++ct) acc[ct] = dfx_mfma_16x16x32_f16(whi[ct], vl, acc[ct]);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = dfx_mfma_16x16x32_f16(whi[ct], vh[kc], acc[ct]);
+            for (int ct = 0; ct < CT; ++ct) acc[ct] = dfx_mfma_16x16x32_f16(whi[ct], vh, acc[ct]);
         }
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            const f32x4 v = acc[ct] * us;
-            // (c is a loop counter of a loop that is not unrolled: select the destination without a dynamically indexed register array)
-            if (c == 0) gi[0][ct] = v;
-            else if (c == 1) gi[1][ct] = v;
-            else if (c == 2) gi[2][ct] = v;
-            else if (c == 3) gh[0][ct] = v;
-            else if (c == 4) gh[1][ct] = v;
-            else gh[2][ct] = v;
-        }
-        if (c == 2) us = A.unscale_h * load_row(A.h_in + (ok ? b : 0) * 256);   // the recurrent operand replaces the input's
-        if (c + 1 < 6) {
-            dfx_h8 *dst = ws + (size_t)((c + 1) & 1) * DFX_PH_CHUNK_H8;
+        for (int ct = 0; ct < CT; ++ct) g[c][ct] = acc[ct] * (c < 3 ? us_x : us_h);
+        if constexpr (c + 1 < 6) {
+            dfx_h8 *dst = ws + (size_t)((c + 1) & 1) * CHUNK;
 #pragma unroll
             for (int i = 0; i < PER_T; ++i) dst[i * DFX_PH_THREADS + tid] = pre[i];
+            __syncthreads();
         }
-        __syncthreads();
-    }
+    });
     if (ok) {
         const int64_t yr = A.y ? dfx_row(A.yrm, b) : 0;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            const int n0 = 64 * u + 16 * ct + 4 * q;   // D leaves lane (row jl, q) with the units n0 .. n0 + 3
+        for (int ct = 0; ct < CT; ++ct) {
+            const int n0 = 16 * CT * u + 16 * ct + 4 * q;   // D leaves lane (row jl, q) with the units n0 .. n0 + 3
             const float4 br = *reinterpret_cast<const float4 *>(A.bias_i + n0), bz = *reinterpret_cast<const float4 *>(A.bias_i + 256 + n0),
                          bn = *reinterpret_cast<const float4 *>(A.bias_i + 512 + n0), bh = *reinterpret_cast<const float4 *>(A.bhn + n0),
                          hp = *reinterpret_cast<const float4 *>(A.h_in + b * 256 + n0);
@@ -2599,9 +2633,13 @@ __global__ void __launch_bounds__(DFX_PH_THREADS, 2) dfx_k_gru_step_h3(DfxGstArg
             float o[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float rg = dfx_fast_rcp(1.f + dfx_fast_exp(-((gi[0][ct][r] + brr[r]) + gh[0][ct][r])));
-                const float zg = dfx_fast_rcp(1.f + dfx_fast_exp(-((gi[1][ct][r] + bzz[r]) + gh[1][ct][r])));
-                const float pre = (gi[2][ct][r] + bnn[r]) + rg * (gh[2][ct][r] + bhh[r]);
+                if (DFX_GST_ABLATE & 8) {
+                    o[r] = g[0][ct][r] + g[1][ct][r] + g[2][ct][r] + g[3][ct][r] + g[4][ct][r] + g[5][ct][r] + brr[r] + bzz[r] + bnn[r] + bhh[r] + hpp[r];
+                    continue;
+                }
+                const float rg = dfx_fast_rcp(1.f + dfx_fast_exp(-((g[0][ct][r] + brr[r]) + g[3][ct][r])));
+                const float zg = dfx_fast_rcp(1.f + dfx_fast_exp(-((g[1][ct][r] + bzz[r]) + g[4][ct][r])));
+                const float pre = (g[2][ct][r] + bnn[r]) + rg * (g[5][ct][r] + bhh[r]);
                 const float ng = 2.f * dfx_fast_rcp(1.f + dfx_fast_exp(-2.f * pre)) - 1.f;
                 o[r] = (1.f - zg) * ng + zg * hpp[r];
             }
