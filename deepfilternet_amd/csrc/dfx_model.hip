@@ -129,6 +129,8 @@ struct DfxStreamCtx {
     void *c0ring = nullptr;    // non-null (one new frame, ungated): df_convp keeps the pending sums of its next kt - 1 outputs here (dfx_k_df_convp_step)
     int c0slot = 0;            //   slot of the new frame = its net position % (kt - 1)
     bool c0rebuild = false;    //   the sums are not current: recompute the older frames' taps from the feature window
+    std::function<int(hipStream_t)> erb_pre;  // set: the ERB feature window's update, enqueued on the caller's stream BEHIND the event the DF branch
+                                              //   starts on (that branch's chain to c1 is the longer one)
     std::function<int(hipStream_t)> df_pre;   // set: state updates that only the DF branch reads — enqueued on that branch's stream before its
                                               //   first kernel instead of in front of the encoder
     std::function<int(hipStream_t)> df_post;  // set: state updates that nothing before the final deep filter reads — enqueued behind df_convp on
@@ -1833,7 +1835,7 @@ static int launch_wait_ge(const dfx_model *m, const unsigned int *flags, int n, 
 // hstate != null (streaming): layer l continues from / leaves its state in hstate + l*B*256 and only the frames [t0, T) are run
 static int run_gru_stack(const dfx_model *m, const std::vector<GruW> &layers, const float *x, float *bufa, float *bufb,
                          float *gi, int64_t B, int64_t T, const float **y, hipStream_t s, float *hstate = nullptr, int64_t t0 = 0,
-                         DfxRowMap rm = DfxRowMap{0, 0, 0}, float *hnext = nullptr) {
+                         DfxRowMap rm = DfxRowMap{0, 0, 0}, float *hnext = nullptr, bool twin = false) {
     const int64_t R = B * (T - t0);
     if (hstate && m->exact_fp32) DFX_FAIL(DFX_ERR_UNSUPPORTED, "streaming needs the fp16-split GRU kernels (unset DFX_EXACT_FP32)");
     const float *in = x;
@@ -1850,9 +1852,10 @@ static int run_gru_stack(const dfx_model *m, const std::vector<GruW> &layers, co
             A.bias_i = m->p(g.bias_i), A.bhn = m->p(g.bhn);
             A.unscale_i = g.wih_unscale, A.unscale_h = g.whh_unscale;
             A.B = B;
-            // 32 hidden units per workgroup (twice the workgroups, half the chunk) unless 64-unit workgroups already fill the chip
+            // 32 hidden units per workgroup (twice the workgroups, half the chunk) unless 64-unit workgroups already fill the chip — by
+            // themselves, or together with the other decoder's stack that runs at the same time (twin: at 4096 streams 0.456 vs 0.470 ms per hop)
             static const int ct_env = [] { const char *e = getenv("DFX_GRU_STEP_CT"); return e ? atoi(e) : 0; }();
-            const bool wide = ct_env == 4 || (ct_env != 2 && dfx_ceil_div(B, DFX_PH_BM) * 4 >= 2 * dfx_env_num_cus());
+            const bool wide = ct_env == 4 || (ct_env != 2 && dfx_ceil_div(B, DFX_PH_BM) * 4 * (twin ? 2 : 1) >= dfx_env_num_cus());
             DfxKScope ks(DFX_K_GRU_REC, s);
             const unsigned rb8 = (unsigned)(dfx_ceil_div(dfx_ceil_div(B, DFX_PH_BM), 8) * 8);   // row blocks, padded: the kernel deals them to the XCDs
             if (wide) {
@@ -1978,6 +1981,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     };
     if ((rc = signal(EV_START, s)) || (rc = wait(EV_START, x1))) return rc;
     const bool post_behind_convp = sc && sc->df_post && m->run_df && !m->convp_late;
+    if (sc && sc->erb_pre && (rc = sc->erb_pre(s))) return rc;
     if (sc && sc->df_pre && (rc = sc->df_pre(x1))) return rc;
     if (sc && sc->df_post && !post_behind_convp && (rc = sc->df_post(x1))) return rc;
     // ---- Encoder, DF branch on x1 (deepfilternet3.py:176-179).  By default c0 = df_conv0(feat_spec) never exists in HBM: its two
@@ -2247,7 +2251,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         if (run_df) {
             const float *y2 = nullptr;
             if (!fan && (rc = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, Rn, x1, rmw))) return rc;
-            if ((rc = run_gru_stack(m, m->df_gru, xa2, xa2, xb2, gi2, B, T, &y2, x1, hs_df, t_begin, rmw, hn_df))) return rc;
+            if ((rc = run_gru_stack(m, m->df_gru, xa2, xa2, xb2, gi2, B, T, &y2, x1, hs_df, t_begin, rmw, hn_df, par))) return rc;
             const float *cfeat = y2, *cfeat2 = nullptr;
             if (fan_skp) {
                 cfeat2 = xdf;   // df_skip(emb), written by dfx_k_emb_fan
@@ -2270,7 +2274,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         }
         // ---- ErbDecoder on s (:245-254)
         if (!fan && (rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, dec_x, Rn, s, rmw))) return rc;
-        if ((rc = run_gru_stack(m, m->dec_gru, dec_x, xa, xb, gi, B, T, &y, s, hs_dec, t_begin, rmw, hn_dec))) return rc;
+        if ((rc = run_gru_stack(m, m->dec_gru, dec_x, xa, xb, gi, B, T, &y, s, hs_dec, t_begin, rmw, hn_dec, par && run_df))) return rc;
         if ((rc = dec_out_skip(y, Rn, s, rmw))) return rc;
         if (fuse_tail) {
             if ((rc = launch_erb_tail<C>(m, demb, e3, e2, e1, e0, mask, Rn, E, s, rmw))) return rc;
@@ -3316,7 +3320,8 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         return DFX_OK;
     };
     bool side_done = false;
-    std::function<int(hipStream_t)> side_pre, side_post;
+    std::function<int(hipStream_t)> side_pre, side_post, erb_ring;
+    bool erb_done = false;
     if (side) {
         // the window's address and position are settled now (the forward pass is handed the window); its copies are enqueued by side_post
         defer = true;
@@ -3333,7 +3338,10 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
                     return r;
             return dfx_launch_analysis_mem(st, x, B, n * hop, xs, am_in, am_out, on);
         };
-        if ((rc = ring_step(rings[0], s))) return rc;
+        erb_ring = [&](hipStream_t on) -> int {
+            erb_done = true;
+            return ring_step(rings[0], on);
+        };
     } else {
         if ((rc = spec_window(new_spec, &spec_win, &spec_win_T))) return rc;
         for (const Ring &r : rings)
@@ -3361,7 +3369,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
             sc.c0slot = (int)((((a0 + skip - L) % ns) + ns) % ns);
             sc.c0rebuild = !S->c0ring_ok;
         }
-        if (side) sc.df_pre = side_pre, sc.df_post = side_post;
+        if (side) sc.erb_pre = erb_ring, sc.df_pre = side_pre, sc.df_post = side_post;
         sc.pf_beta = S->pf_beta;
         sc.out = out_spec;  // local frame t of clip b lands at out_spec[(b*n + t - H) * F]
         sc.out_T = n;
@@ -3395,7 +3403,8 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
             DFX_LAUNCH_CHECK();
         }
     }
-    if (side && !side_done && ((rc = side_pre(s)) || (rc = side_post(s)))) return rc;   // (no forward pass ran: warm-up hops)
+    if (side && !erb_done && (rc = erb_ring(s))) return rc;                              // (no forward pass ran: warm-up hops)
+    if (side && !side_done && ((rc = side_pre(s)) || (rc = side_post(s)))) return rc;
     // ---- ISTFT of the n enhanced hops (state: overlap-add memory)
     if ((rc = dfx_launch_synthesis(st, out_spec, B, n, sm_in, sm_out, y, ys, 0, n * hop, s))) return rc;
     if (lsnr_out) {  // the window's lsnr is [B, T]: take the n new frames (the entries of warm-up hops are not meaningful)
