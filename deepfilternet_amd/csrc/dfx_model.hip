@@ -124,6 +124,7 @@ struct DfxStreamCtx {
     int64_t H;         // history frames in front of the new ones
     int64_t t_zero;    // local frames < t_zero precede the start of the stream (df_convp sees zero padding there)
     int64_t spec_T;    // frames per clip of the spec array
+    int64_t feat_T = 0;    // > 0: frames per clip of feat_erb and feat_spec (windows inside the linear buffers; both share it)
     float *h_state;    // [GRU layers][B][256], in model order enc, erb_dec, df_dec
     float *h_next = nullptr;   // non-null (one new frame, ungated): the layers run as dfx_k_gru_step_h3 and leave their new states HERE
     void *c0ring = nullptr;    // non-null (one new frame, ungated): df_convp keeps the pending sums of its next kt - 1 outputs here (dfx_k_df_convp_step)
@@ -1301,7 +1302,7 @@ static int launch_convp2(const dfx_model *m, const float *c0, const float *feat_
 
 template <int C, int KT>
 static int launch_convp_h3(const dfx_model *m, const float *feat_spec, float *out, int64_t B, int64_t T, int Fd, int NO,
-                           hipStream_t s, int64_t t_begin = 0, int64_t t_zero = 0, int L = -1, int64_t t_end = -1) {
+                           hipStream_t s, int64_t t_begin = 0, int64_t t_zero = 0, int L = -1, int64_t t_end = -1, int64_t feat_T = 0) {
     if constexpr (C % 32 != 0) {
         DFX_FAIL(DFX_ERR_UNSUPPORTED, "fp16-split df_convp needs conv_ch %% 32 == 0");
     } else {
@@ -1309,6 +1310,7 @@ static int launch_convp_h3(const dfx_model *m, const float *feat_spec, float *ou
         DfxCphArgs A;
         A.t_end = t_end;
         A.feat = feat_spec;
+        A.feat_T = feat_T;
         A.w0f = reinterpret_cast<const dfx_h8 *>(m->p(m->c0_h3));
         A.bias0 = m->p(m->cin_b);
         A.wf = reinterpret_cast<const dfx_h8 *>(m->p(m->cp_h3));
@@ -1346,13 +1348,14 @@ static int launch_convp_h3(const dfx_model *m, const float *feat_spec, float *ou
 // df_convp of the newest frame of every stream with the older frames' c0 tiles from the handle's ring (dfx_k_df_convp_step)
 template <int C, int KT>
 static int launch_convp_step(const dfx_model *m, const float *feat_spec, float *out, int64_t B, int64_t T, int Fd, int NO, hipStream_t s,
-                             int64_t t_zero, int L, void *ring, int slot, bool rebuild) {
+                             int64_t t_zero, int L, void *ring, int slot, bool rebuild, int64_t feat_T = 0) {
     if constexpr (C % 32 != 0 || KT < 2) {
         DFX_FAIL(DFX_ERR_UNSUPPORTED, "df_convp step kernel: conv_ch %% 32 == 0 and kt >= 2");
     } else {
         DfxCphArgs A;
         A.t_end = T;
         A.feat = feat_spec;
+        A.feat_T = feat_T;
         A.w0f = reinterpret_cast<const dfx_h8 *>(m->p(m->c0_h3));
         A.bias0 = m->p(m->cin_b);
         A.wf = reinterpret_cast<const dfx_h8 *>(m->p(m->cp_h3));
@@ -1377,7 +1380,7 @@ static int launch_convp_step(const dfx_model *m, const float *feat_spec, float *
 
 template <int C>
 static int launch_conv01_h3(const dfx_model *m, const PwW &w, const float *feat_spec, float *out, int64_t B, int64_t T, int Fin,
-                            int Fout, int stride, hipStream_t s, int64_t t_begin = 0, int L = -1, int64_t t_end = -1) {
+                            int Fout, int stride, hipStream_t s, int64_t t_begin = 0, int L = -1, int64_t t_end = -1, int64_t feat_T = 0) {
     if constexpr (C % 32 != 0) {
         DFX_FAIL(DFX_ERR_UNSUPPORTED, "fp16-split df_conv1 needs conv_ch %% 32 == 0");
     } else {
@@ -1386,6 +1389,7 @@ static int launch_conv01_h3(const dfx_model *m, const PwW &w, const float *feat_
         DfxC01hArgs A;
         A.t_end = t_end;
         A.feat = feat_spec;
+        A.feat_T = feat_T;
         A.w0f = reinterpret_cast<const dfx_h8 *>(m->p(m->c0_h3));
         A.bias0 = m->p(m->cin_b);
         A.dw = m->p(w.dw);
@@ -1505,12 +1509,13 @@ static int launch_erb_tail(const dfx_model *m, const float *demb, const float *e
 
 template <int C>
 static int launch_erb_enc(const dfx_model *m, const float *feat_erb, float *e0, float *e1, int64_t B, int64_t T, hipStream_t s,
-                          int64_t t_begin = 0, int L = -1, int64_t t_end = -1) {
+                          int64_t t_begin = 0, int L = -1, int64_t t_end = -1, int64_t feat_T = 0) {
     const dfx_model_cfg &c = m->cfg;
     if (t_end < 0) t_end = T;
     DfxEncArgs A;
     A.t_end = t_end;
     A.feat = feat_erb;
+    A.feat_T = feat_T;
     A.w0 = m->p(m->erb0_w);
     A.b0 = m->p(m->erb0_b);
     A.dw = m->p(m->erb1.dw);
@@ -1908,6 +1913,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     // streaming window (sc): the arrays hold T = H + n frames per clip, only the n new ones are computed; per-frame kernels reach
     // their rows through rmw, the lookahead shift is already in the feature stream (kernel lookahead 0)
     const int64_t t_begin = sc ? sc->H : 0, Rn = B * (T - t_begin);
+    const int64_t featT = sc ? sc->feat_T : 0;   // frames per clip of feat_erb / feat_spec when they are windows inside longer buffers (0: T)
     const DfxRowMap rmw = sc ? DfxRowMap{T, T - t_begin, t_begin} : DfxRowMap{0, 0, 0};
     const int Lk = sc ? 0 : c.conv_lookahead;
     const int64_t t_zero = sc ? sc->t_zero : 0;
@@ -2041,7 +2047,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     const bool overlap = use_seq && m->front_overlap && front_ranges && Ks <= DFX_MAX_TCHUNKS;
     // df_conv0 -> df_conv1 of frames [t0, t1) (fuse_c0)
     auto df1_range = [&](int64_t t0, int64_t t1, hipStream_t st) -> int {
-        if (fuse_h3) return launch_conv01_h3<C>(m, m->dfc1, feat_spec, c1, B, T, Fd, Fd / 2, 2, st, t0, Lk, t1);
+        if (fuse_h3) return launch_conv01_h3<C>(m, m->dfc1, feat_spec, c1, B, T, Fd, Fd / 2, 2, st, t0, Lk, t1, featT);
         return launch_conv01<C>(m, m->dfc1, feat_spec, c1, B, T, Fd, Fd / 2, 2, st, t0, Lk, t1);
     };
     // df_dec.df_convp of frames [t0, t1) (only needs c0 / feat_spec; :328)
@@ -2076,18 +2082,18 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             }
         } else if (fuse_h3 && sc && sc->c0ring && !gate && t1 - t0 == 1 && t1 == T && kt >= 2) {
             switch (kt) {
-                case 2: return launch_convp_step<C, 2>(m, feat_spec, c0p, B, T, Fd, NO, st, t_zero, Lk, sc->c0ring, sc->c0slot, sc->c0rebuild);
-                case 3: return launch_convp_step<C, 3>(m, feat_spec, c0p, B, T, Fd, NO, st, t_zero, Lk, sc->c0ring, sc->c0slot, sc->c0rebuild);
-                case 4: return launch_convp_step<C, 4>(m, feat_spec, c0p, B, T, Fd, NO, st, t_zero, Lk, sc->c0ring, sc->c0slot, sc->c0rebuild);
-                default: return launch_convp_step<C, 5>(m, feat_spec, c0p, B, T, Fd, NO, st, t_zero, Lk, sc->c0ring, sc->c0slot, sc->c0rebuild);
+                case 2: return launch_convp_step<C, 2>(m, feat_spec, c0p, B, T, Fd, NO, st, t_zero, Lk, sc->c0ring, sc->c0slot, sc->c0rebuild, featT);
+                case 3: return launch_convp_step<C, 3>(m, feat_spec, c0p, B, T, Fd, NO, st, t_zero, Lk, sc->c0ring, sc->c0slot, sc->c0rebuild, featT);
+                case 4: return launch_convp_step<C, 4>(m, feat_spec, c0p, B, T, Fd, NO, st, t_zero, Lk, sc->c0ring, sc->c0slot, sc->c0rebuild, featT);
+                default: return launch_convp_step<C, 5>(m, feat_spec, c0p, B, T, Fd, NO, st, t_zero, Lk, sc->c0ring, sc->c0slot, sc->c0rebuild, featT);
             }
         } else if (fuse_h3) {
             switch (kt) {
-                case 1: return launch_convp_h3<C, 1>(m, feat_spec, c0p, B, T, Fd, NO, st, t0, t_zero, Lk, t1);
-                case 2: return launch_convp_h3<C, 2>(m, feat_spec, c0p, B, T, Fd, NO, st, t0, t_zero, Lk, t1);
-                case 3: return launch_convp_h3<C, 3>(m, feat_spec, c0p, B, T, Fd, NO, st, t0, t_zero, Lk, t1);
-                case 4: return launch_convp_h3<C, 4>(m, feat_spec, c0p, B, T, Fd, NO, st, t0, t_zero, Lk, t1);
-                default: return launch_convp_h3<C, 5>(m, feat_spec, c0p, B, T, Fd, NO, st, t0, t_zero, Lk, t1);
+                case 1: return launch_convp_h3<C, 1>(m, feat_spec, c0p, B, T, Fd, NO, st, t0, t_zero, Lk, t1, featT);
+                case 2: return launch_convp_h3<C, 2>(m, feat_spec, c0p, B, T, Fd, NO, st, t0, t_zero, Lk, t1, featT);
+                case 3: return launch_convp_h3<C, 3>(m, feat_spec, c0p, B, T, Fd, NO, st, t0, t_zero, Lk, t1, featT);
+                case 4: return launch_convp_h3<C, 4>(m, feat_spec, c0p, B, T, Fd, NO, st, t0, t_zero, Lk, t1, featT);
+                default: return launch_convp_h3<C, 5>(m, feat_spec, c0p, B, T, Fd, NO, st, t0, t_zero, Lk, t1, featT);
             }
         } else if (kt <= 5 && NO <= 16) {
             switch (kt) {
@@ -2128,7 +2134,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     auto erb_range = [&](int64_t t0, int64_t t1, int64_t Rk, DfxRowMap rm, hipStream_t st) -> int {
         int r;
         if (fuse_enc) {
-            if ((r = launch_erb_enc<C>(m, feat_erb, e0, e1, B, T, st, t0, Lk, t1))) return r;
+            if ((r = launch_erb_enc<C>(m, feat_erb, e0, e1, B, T, st, t0, Lk, t1, featT))) return r;
         } else {
             {
                 const int64_t total = R * E * (C / 4);
@@ -2931,6 +2937,10 @@ struct dfx_stream_state {
     size_t spec_lin = 0;
     int64_t lin_cap = 0, lin_pos = 0;
     bool lin_owns = false;
+    // the encoder's feature windows in the same form (stream_body): [B, feat_cap, E] and [B, feat_cap, Fd, 2] at the same lin_pos
+    size_t fe_lin = 0, fs_lin = 0;
+    int64_t feat_cap = 0;
+    bool feat_owns = false;
     // per-stream stage gating (dfx_stream_set_gating; DfTract::process, tract.rs:509-616,658-672): off by default
     bool gated = false;
     int channels = 1, reduce_mask = 2;    // multi-channel streams: ch consecutive rows per stream; ReduceMask::MEAN is the reference default
@@ -3013,6 +3023,12 @@ extern "C" int dfx_stream_create(const dfx_model *m, const dfx_state *st, int64_
         if (lin_env && (size_t)B * (Hs + n + slack) * F * 8 <= ((size_t)3 << 29)) {
             s->lin_cap = Hs + n + slack;
             s->spec_lin = take((size_t)B * s->lin_cap * F * 8);
+            static const bool feat_env = [] { const char *e = getenv("DFX_STREAM_LINEAR_FEAT"); return !(e && e[0] == '0'); }();
+            if (feat_env) {
+                s->feat_cap = H + n + slack;   // the same slack: the three windows reach the end in the same call
+                s->fe_lin = take((size_t)B * s->feat_cap * E * 4);
+                s->fs_lin = take((size_t)B * s->feat_cap * Fd * 8);
+            }
         }
     }
     s->h_state = take((size_t)s->layers * B * 256 * 4);
@@ -3094,6 +3110,7 @@ extern "C" int dfx_stream_reset(dfx_stream_state *s, void *stream) {
     s->flip = 0;
     s->lin_pos = 0;
     s->lin_owns = false;   // (both forms are all zeros now)
+    s->feat_owns = false;
     s->hflip = 0;
     s->c0ring_ok = true;   // (zeros = the causal padding in front of the stream)
     return DFX_OK;
@@ -3193,39 +3210,60 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     // and the clip stride (in frames) the deep filter has to use.
     const bool lin = S->lin_cap > 0 && !gated && !S->use_graph && !S->capturing;
     const int64_t F2 = F * 2;
+    // The feature windows of the encoder take the same form when the kernels that read them accept a clip stride (the fp16-split DF
+    // encoder: DfxC01hArgs::feat_T): [B, feat_cap, E] and [B, feat_cap, Fd, 2] with the same slack as the spectra, so that all three
+    // windows sit at lin_pos and go back to the front in the same call.  feat_owns: the linear form holds the feature history.
+    const bool feat_lin_ok = lin && S->feat_cap > 0 && m->fuse_c0 && !m->exact_fp32 && c.conv_ch % 32 == 0 && m->cp_h3;
     struct RowCopy { const float *src; int64_t src_stride, src_len, src_off; float *dst; int64_t dst_stride, len; };
-    RowCopy later[2];
-    int nlater = 0;
-    bool defer = false;   // the linear form's copies are listed in `later` instead of being enqueued on s (the caller enqueues them elsewhere)
+    struct CopyList {
+        RowCopy c[4];
+        int n = 0;
+        void add(const float *src, int64_t src_stride, int64_t src_len, int64_t src_off, float *dst, int64_t dst_stride, int64_t len) {
+            c[n++] = RowCopy{src, src_stride, src_len, src_off, dst, dst_stride, len};
+        }
+    } cp_spec, cp_fe, cp_fs;   // the copies of this call, by array: the caller decides which stream each list is enqueued on
+    auto emit = [&](CopyList &l, hipStream_t on) -> int {
+        for (int i = 0; i < l.n; ++i)
+            if (int r = stream_copy_rows(l.c[i].src, l.c[i].src_stride, l.c[i].src_len, l.c[i].src_off, l.c[i].dst, l.c[i].dst_stride, l.c[i].len, B, on)) return r;
+        l.n = 0;
+        return DFX_OK;
+    };
+    const int64_t capf = S->feat_cap, E1 = E, D2 = Fd * 2;
+    auto feat_to_ring = [&]() {   // the feature windows' last H frames become the ring form's history
+        cp_fe.add(fp(S->fe_lin), capf * E1, capf * E1, S->lin_pos * E1, fp(S->hist_fe[S->flip]), H * E1, H * E1);
+        cp_fs.add(fp(S->fs_lin), capf * D2, capf * D2, S->lin_pos * D2, fp(S->hist_fs[S->flip]), H * D2, H * D2);
+        S->feat_owns = false;
+    };
+    // spec_window(): host-side bookkeeping of the rolling spectra for this call (which form, where the window is) with the copies it takes
+    // listed in cp_spec (and, when the windows go back to the front, in cp_fe / cp_fs); the ring form is stepped on `s` right away.
+    // The caller advances lin_pos by n when it is done with the windows.
     auto spec_window = [&](const float *new_spec, const float **win, int64_t *win_T) -> int {
-        int r;
         if (lin) {
             float *L0 = fp(S->spec_lin);
             const int64_t cap = S->lin_cap;
-            auto copy = [&](const float *src, int64_t src_stride, int64_t src_len, int64_t src_off, float *dst, int64_t dst_stride, int64_t len) -> int {
-                if (defer) {
-                    later[nlater++] = RowCopy{src, src_stride, src_len, src_off, dst, dst_stride, len};
-                    return DFX_OK;
-                }
-                return stream_copy_rows(src, src_stride, src_len, src_off, dst, dst_stride, len, B, s);
-            };
             if (!S->lin_owns) {   // the ring form's history becomes the window's first Hs frames
-                if ((r = copy(fp(S->hist_spec[S->flip]), Hs * F2, Hs * F2, 0, L0, cap * F2, Hs * F2))) return r;
+                cp_spec.add(fp(S->hist_spec[S->flip]), Hs * F2, Hs * F2, 0, L0, cap * F2, Hs * F2);
                 S->lin_pos = 0;
                 S->lin_owns = true;
-            } else if (S->lin_pos + Hs + n > cap) {   // the window has reached the end: its last Hs frames go back to the front (no overlap: lin_pos >= Hs)
-                if ((r = copy(L0, cap * F2, cap * F2, S->lin_pos * F2, L0, cap * F2, Hs * F2))) return r;
+            } else if (S->lin_pos + Hs + n > cap) {   // the windows have reached the end: their last frames go back to the front (no overlap: lin_pos >= Hs)
+                cp_spec.add(L0, cap * F2, cap * F2, S->lin_pos * F2, L0, cap * F2, Hs * F2);
+                if (S->feat_owns) {
+                    cp_fe.add(fp(S->fe_lin), capf * E1, capf * E1, S->lin_pos * E1, fp(S->fe_lin), capf * E1, H * E1);
+                    cp_fs.add(fp(S->fs_lin), capf * D2, capf * D2, S->lin_pos * D2, fp(S->fs_lin), capf * D2, H * D2);
+                }
                 S->lin_pos = 0;
             }
-            if ((r = copy(new_spec, n * F2, n * F2, 0, L0 + (S->lin_pos + Hs) * F2, cap * F2, n * F2))) return r;
+            cp_spec.add(new_spec, n * F2, n * F2, 0, L0 + (S->lin_pos + Hs) * F2, cap * F2, n * F2);
             *win = L0 + S->lin_pos * F2;
             *win_T = cap;
-            S->lin_pos += n;   // (advanced here, not by the caller: this form is never replayed from a graph nor walked hop by hop)
             return DFX_OK;
         }
-        if (S->lin_owns) {   // back to the ring form (gating was switched on): the window's last Hs frames are its history
-            if ((r = stream_copy_rows(fp(S->spec_lin), S->lin_cap * F2, S->lin_cap * F2, S->lin_pos * F2, fp(S->hist_spec[S->flip]), Hs * F2, Hs * F2, B, s))) return r;
+        if (S->lin_owns) {   // back to the ring form (gating was switched on): the windows' last frames are its history
+            if (S->feat_owns) feat_to_ring();
+            cp_spec.add(fp(S->spec_lin), S->lin_cap * F2, S->lin_cap * F2, S->lin_pos * F2, fp(S->hist_spec[S->flip]), Hs * F2, Hs * F2);
             S->lin_owns = false;
+            int r;
+            if ((r = emit(cp_spec, s)) || (r = emit(cp_fe, s)) || (r = emit(cp_fs, s))) return r;
         }
         DfxKScope ks(DFX_K_COPY_ROWS, s);
         dfx_launch(dfx_k_ring_step, dim3((unsigned)nn_grid(dfx_ceil_div(B * (Hs + n) * F2, 256), 16)), dim3(256), 0, s,
@@ -3251,7 +3289,9 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         {
             const float *win = nullptr;
             int64_t win_T = 0;
-            if ((rc = spec_window(new_spec, &win, &win_T))) return rc;
+            if (S->feat_owns) feat_to_ring();   // (the features do not advance here: their history waits in the ring form)
+            if ((rc = spec_window(new_spec, &win, &win_T)) || (rc = emit(cp_fe, s)) || (rc = emit(cp_fs, s)) || (rc = emit(cp_spec, s))) return rc;
+            if (lin) S->lin_pos += n;
         }
         // what this path does not touch keeps its contents across the parity flip
         DFX_HIP(hipMemcpyAsync(fp(S->syn_mem[S->flip ^ 1]), fp(S->syn_mem[S->flip]), (size_t)B * ML * 4, hipMemcpyDeviceToDevice, s));
@@ -3319,34 +3359,43 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         DFX_LAUNCH_CHECK();
         return DFX_OK;
     };
-    bool side_done = false;
-    std::function<int(hipStream_t)> side_pre, side_post, erb_ring;
-    bool erb_done = false;
-    if (side) {
-        // the window's address and position are settled now (the forward pass is handed the window); its copies are enqueued by side_post
-        defer = true;
-        rc = spec_window(new_spec, &spec_win, &spec_win_T);
-        defer = false;
-        if (rc) return rc;
-        side_pre = [&](hipStream_t on) -> int { return ring_step(rings[1], on); };
-        side_post = [&](hipStream_t on) -> int {
-            int r;
-            side_done = true;
-            for (int i = 0; i < nlater; ++i)
-                if ((r = stream_copy_rows(later[i].src, later[i].src_stride, later[i].src_len, later[i].src_off, later[i].dst, later[i].dst_stride,
-                                          later[i].len, B, on)))
-                    return r;
-            return dfx_launch_analysis_mem(st, x, B, n * hop, xs, am_in, am_out, on);
-        };
-        erb_ring = [&](hipStream_t on) -> int {
-            erb_done = true;
-            return ring_step(rings[0], on);
-        };
-    } else {
-        if ((rc = spec_window(new_spec, &spec_win, &spec_win_T))) return rc;
-        for (const Ring &r : rings)
-            if ((rc = ring_step(r, s))) return rc;
+    // settle the three windows (host side), then enqueue their copies / ring steps: on s, or — side — on the streams that need them
+    if ((rc = spec_window(new_spec, &spec_win, &spec_win_T))) return rc;
+    const bool flin = feat_lin_ok && skip == 0;   // (warm-up hops zero their features: the ring step does that)
+    const float *fe_win = work_fe, *fs_win = work_fs;
+    int64_t feat_T = 0;
+    if (flin) {
+        float *Lfe = fp(S->fe_lin), *Lfs = fp(S->fs_lin);
+        if (!S->feat_owns) {   // the ring form's history becomes the windows' first H frames
+            cp_fe.add(fp(S->hist_fe[S->flip]), H * E1, H * E1, 0, Lfe + S->lin_pos * E1, capf * E1, H * E1);
+            cp_fs.add(fp(S->hist_fs[S->flip]), H * D2, H * D2, 0, Lfs + S->lin_pos * D2, capf * D2, H * D2);
+            S->feat_owns = true;
+        }
+        cp_fe.add(new_fe, n * E1, n * E1, 0, Lfe + (S->lin_pos + H) * E1, capf * E1, n * E1);
+        cp_fs.add(new_fs, n * D2, n * D2, 0, Lfs + (S->lin_pos + H) * D2, capf * D2, n * D2);
+        fe_win = Lfe + S->lin_pos * E1, fs_win = Lfs + S->lin_pos * D2;
+        feat_T = capf;
+    } else if (S->feat_owns) {
+        feat_to_ring();
     }
+    if (lin) S->lin_pos += n;   // (advanced here: this form is never replayed from a graph nor walked hop by hop by the caller)
+    bool side_done = false, erb_done = false;
+    std::function<int(hipStream_t)> side_pre, side_post, erb_ring;
+    erb_ring = [&](hipStream_t on) -> int {
+        erb_done = true;
+        if (int r = emit(cp_fe, on)) return r;
+        return flin ? DFX_OK : ring_step(rings[0], on);
+    };
+    side_pre = [&](hipStream_t on) -> int {
+        if (int r = emit(cp_fs, on)) return r;
+        return flin ? DFX_OK : ring_step(rings[1], on);
+    };
+    side_post = [&](hipStream_t on) -> int {
+        side_done = true;
+        if (int r = emit(cp_spec, on)) return r;
+        return side ? dfx_launch_analysis_mem(st, x, B, n * hop, xs, am_in, am_out, on) : DFX_OK;
+    };
+    if (!side && ((rc = side_post(s)) || (rc = erb_ring(s)) || (rc = side_pre(s)))) return rc;
     float *out_spec = fp(S->out_spec);
     if (skip > 0) DFX_HIP(hipMemsetAsync(out_spec, 0, (size_t)B * n * F * 8, s));  // warm-up hops: zero spectra (tract.rs rolling buffers)
     bool stepped = false;
@@ -3356,6 +3405,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         const int64_t pos0 = Hs - a0;  // local index of net position 0
         sc.t_zero = pos0 > 0 ? pos0 : 0;
         sc.spec_T = spec_win_T;
+        sc.feat_T = feat_T;
         sc.h_state = fp(S->hflip ? S->h_state2 : S->h_state);
         // one new hop, ungated, plain launches: every GRU layer is ONE launch (projection + recurrence + gates) that leaves the new states in
         // the other buffer (DFX_STREAM_STEP=0: the projection and the recurrence kernel of the batch path, in place)
@@ -3388,9 +3438,9 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         float *ws = reinterpret_cast<float *>(((uintptr_t)(S->buf + S->model_ws) + 255) & ~(uintptr_t)255);
         const DfxLane *ln = &m->lanes[0];
         switch (c.conv_ch) {
-            case 16: rc = forward_impl<16>(m, st->bands, spec_win, work_fe, work_fs, B, T, S->lim, nullptr, nullptr, fp(S->lsnr), nullptr, ws, s, ln, false, nullptr, &sc); break;
-            case 32: rc = forward_impl<32>(m, st->bands, spec_win, work_fe, work_fs, B, T, S->lim, nullptr, nullptr, fp(S->lsnr), nullptr, ws, s, ln, false, nullptr, &sc); break;
-            case 64: rc = forward_impl<64>(m, st->bands, spec_win, work_fe, work_fs, B, T, S->lim, nullptr, nullptr, fp(S->lsnr), nullptr, ws, s, ln, false, nullptr, &sc); break;
+            case 16: rc = forward_impl<16>(m, st->bands, spec_win, fe_win, fs_win, B, T, S->lim, nullptr, nullptr, fp(S->lsnr), nullptr, ws, s, ln, false, nullptr, &sc); break;
+            case 32: rc = forward_impl<32>(m, st->bands, spec_win, fe_win, fs_win, B, T, S->lim, nullptr, nullptr, fp(S->lsnr), nullptr, ws, s, ln, false, nullptr, &sc); break;
+            case 64: rc = forward_impl<64>(m, st->bands, spec_win, fe_win, fs_win, B, T, S->lim, nullptr, nullptr, fp(S->lsnr), nullptr, ws, s, ln, false, nullptr, &sc); break;
             default: DFX_FAIL(DFX_ERR_UNSUPPORTED, "conv_ch");
         }
         if (rc) return rc;

@@ -493,7 +493,8 @@ __global__ void __launch_bounds__(DFX_PW_THREADS) dfx_k_df_conv01(DfxC01Args A) 
 // The feat_spec loads of the NEXT tile / frame are issued before the current one is computed (the only HBM/L2 latency in the loop).
 // ---------------------------------------------------------------------------------------------------------------------
 static __device__ __forceinline__ void dfx_c0_patch_load(const float *__restrict__ feat, int64_t b, int64_t t, int f, bool valid,
-                                                         int64_t T, int Fin, int L, int q, float2 (&raw)[4]) {
+                                                         int64_t T, int Fin, int L, int q, float2 (&raw)[4], int64_t Ts = 0) {
+    if (Ts <= 0) Ts = T;   // frames per clip of the feature array (a window inside a longer buffer: Ts > T)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int tap = 4 * q + i, kt = tap / 3, kf = tap - 3 * kt;
@@ -501,7 +502,7 @@ static __device__ __forceinline__ void dfx_c0_patch_load(const float *__restrict
         const int fin = f - 1 + kf;
         float2 v = make_float2(0.f, 0.f);
         if (valid && tap < 9 && tau >= 0 && tin < T && fin >= 0 && fin < Fin)
-            v = *reinterpret_cast<const float2 *>(feat + ((b * T + tin) * Fin + fin) * 2);
+            v = *reinterpret_cast<const float2 *>(feat + ((b * Ts + tin) * Fin + fin) * 2);
         raw[i] = v;
     }
 }
@@ -546,6 +547,7 @@ struct DfxC01hArgs {
     int64_t t_begin;     // only frames [t_begin, t_end) of every clip are produced (t_end <= T; frames up to T may be read)
     int64_t t_end;
     unsigned int *err;   // model error words: bit 0 of err[1] = a value >= DFX_H3_LIMIT reached an f16 split (results invalid)
+    int64_t feat_T = 0;  // > 0: frames per clip of feat (the T frames are a window inside a longer buffer: the streaming runtime's linear form)
 };
 
 // Register budget: two waves per SIMD (<= 256 registers) so that one wave's LDS / global latencies hide behind the other's matrix
@@ -623,7 +625,7 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, DFX_C01_MINB) dfx_k_df_conv01_
         const int fo = nft * 16 + jl;
         const int fi = fo * A.stride + j - 1;
         okj[j] = nlive && fo < A.Fout && fi >= 0 && fi < Fin;
-        const float2 *clip = reinterpret_cast<const float2 *>(A.feat) + (int64_t)nb * T32 * Fin;
+        const float2 *clip = reinterpret_cast<const float2 *>(A.feat) + (int64_t)nb * (A.feat_T > 0 ? A.feat_T : (int64_t)T32) * Fin;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int tin = nt_ + tdt[i], fin = fi + tdf[i];
@@ -747,6 +749,7 @@ struct DfxCphArgs {
     float unscale0, unscale;
     int64_t t_begin, t_zero, t_end;  // as in DfxCp2Args
     unsigned int *err;        // as in DfxC01hArgs
+    int64_t feat_T = 0;       // as in DfxC01hArgs
 };
 
 template <int C, int KT>
@@ -795,10 +798,10 @@ __global__ void __launch_bounds__(256, 1) dfx_k_df_convp_h3(DfxCphArgs A) {
         dfx_static_for<1, KT>([&](auto sc) {
             constexpr int sl = decltype(sc)::value;
             const int64_t tau = t0 - KT + sl;
-            dfx_c0_patch_load(A.feat, b, tau, f, fvalid && tau >= 0, A.T, A.Fd, A.L, q, raw);
+            dfx_c0_patch_load(A.feat, b, tau, f, fvalid && tau >= 0, A.T, A.Fd, A.L, q, raw, A.feat_T);
             make_frame(xh[sl], xl[sl], tau, raw);
         });
-        dfx_c0_patch_load(A.feat, b, t0, f, fvalid, A.T, A.Fd, A.L, q, raw);
+        dfx_c0_patch_load(A.feat, b, t0, f, fvalid, A.T, A.Fd, A.L, q, raw, A.feat_T);
         for (int64_t tb = t0; tb < t1; tb += KT) {
             dfx_static_for<0, KT>([&](auto pc) {
                 constexpr int ph = decltype(pc)::value;
@@ -807,7 +810,7 @@ __global__ void __launch_bounds__(256, 1) dfx_k_df_convp_h3(DfxCphArgs A) {
                     float2 cur[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) cur[i] = raw[i];
-                    dfx_c0_patch_load(A.feat, b, t + 1, f, fvalid && t + 1 < t1, A.T, A.Fd, A.L, q, raw);
+                    dfx_c0_patch_load(A.feat, b, t + 1, f, fvalid && t + 1 < t1, A.T, A.Fd, A.L, q, raw, A.feat_T);
                     make_frame(xh[ph], xl[ph], t, cur);
                     // three independent accumulation chains (one per product term), summed small-to-large at the end
                     f32x4 aa = f32x4{0.f, 0.f, 0.f, 0.f}, ab = aa, ac = aa;
@@ -890,7 +893,7 @@ __global__ void __launch_bounds__(256, 2) dfx_k_df_convp_step(DfxCphArgs A, f32x
             constexpr int d = decltype(dc)::value;   // frame t - (KT-1) + d; its tap k belongs to out[t + d - k]
             const int64_t tau = t - (KT - 1) + d;
             float2 raw[4];
-            dfx_c0_patch_load(A.feat, b, tau, f, fvalid && tau >= 0, A.T, A.Fd, A.L, q, raw);
+            dfx_c0_patch_load(A.feat, b, tau, f, fvalid && tau >= 0, A.T, A.Fd, A.L, q, raw, A.feat_T);
             float c0v[CPL];
             dfx_c0_tile_h3<C>(w0h, w0l, bias0, A.unscale0, raw, fvalid && tau >= A.t_zero, c0v, amax);
             dfx_h8 xh[KC], xl[KC];
@@ -1227,6 +1230,7 @@ struct DfxEncArgs {
     const dfx_h8 *wt_h3 = nullptr;   // erb_conv1's pointwise weights as f16 hi/lo fragments (H3 form)
     float unscale = 1.f;
     unsigned int *err = nullptr;
+    int64_t feat_T = 0;              // > 0: frames per clip of feat (see DfxC01hArgs)
 };
 #define DFX_ENC_FS(E) (3 * ((E) + 2))                                   /* zero-bordered feat rows of one frame */
 #define DFX_ENC_WAVE_FLOATS(C, E) ((E) * ((C) + 4) + DFX_ENC_FS(E) + 2) /* + pad to a multiple of 4 floats below */
@@ -1266,7 +1270,7 @@ __global__ void __launch_bounds__(256, 2) dfx_k_erb_enc(DfxEncArgs A) {
             const int i = lane + 64 * k, kt = i / EP, fp = i - kt * EP;
             const int64_t tau = t - 2 + kt, tin = tau + A.L;
             float v = 0.f;
-            if (rl < R && i < 3 * EP && fp >= 1 && fp <= E && tau >= 0 && tin < A.T) v = A.feat[(b * A.T + tin) * E + fp - 1];
+            if (rl < R && i < 3 * EP && fp >= 1 && fp <= E && tau >= 0 && tin < A.T) v = A.feat[(b * (A.feat_T > 0 ? A.feat_T : A.T) + tin) * E + fp - 1];
             fx[k] = v;
         }
     };
