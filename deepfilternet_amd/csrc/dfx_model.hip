@@ -2052,6 +2052,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     };
     // df_dec.df_convp of frames [t0, t1) (only needs c0 / feat_spec; :328)
     auto convp_range = [&](int64_t t0, int64_t t1, hipStream_t st) -> int {
+        static const int dev_skip_cp = [] { const char *e = getenv("DFX_DEV_SKIP"); return e ? atoi(e) : 0; }();   // dev timing ablation (results invalid)
+        if (dev_skip_cp & 8) return DFX_OK;
         if (gate && kt > 1) {
             // gated streaming: the (kt-1)-frame delay line in front of df_convp belongs to the DF decoder and only moves on the frames
             // that decoder ran on, per stream.  c0 of the newest frame goes into the last slot of the per-stream window (exact fp32
