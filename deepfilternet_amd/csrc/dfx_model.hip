@@ -3321,6 +3321,11 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     }
     unsigned char *gflags = gated ? S->gate_buf + S->g_flags : nullptr;
     int *gcount = gated ? reinterpret_cast<int *>(S->gate_buf + S->g_counter) : nullptr;
+    // one new hop, plain launches: every GRU layer is ONE launch (projection + recurrence + gates) that leaves the new states in the
+    // other buffer (DFX_STREAM_STEP=0: the projection and the recurrence kernel of the batch path, in place)
+    static const bool step_env = [] { const char *e = getenv("DFX_STREAM_STEP"); return !(e && e[0] == '0'); }();
+    const int64_t skip_early = S->frames < L ? ((L - S->frames) < n ? (L - S->frames) : n) : 0;
+    const bool step_all = step_env && n - skip_early == 1 && !S->capturing && !S->use_graph;
     if (gated) {
         // silent-input shortcut (tract.rs:513-525) + a copy of the in-place state, so that the streams that turn out not to advance
         // (frozen, or a decoder stage skipped) can be given their state back after the pass
@@ -3328,7 +3333,8 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         DFX_LAUNCH_CHECK();
         DFX_HIP(hipMemcpyAsync(gp(S->g_sh_erb), fp(S->erb_state), (size_t)B * E * 4, hipMemcpyDeviceToDevice, s));
         DFX_HIP(hipMemcpyAsync(gp(S->g_sh_unit), fp(S->unit_state), (size_t)B * Fd * 4, hipMemcpyDeviceToDevice, s));
-        DFX_HIP(hipMemcpyAsync(gp(S->g_sh_h), fp(S->hflip ? S->h_state2 : S->h_state), (size_t)S->layers * B * 256 * 4, hipMemcpyDeviceToDevice, s));
+        // (the GRU states: only when the layers run in place — the one-step kernel leaves the old states in the other buffer)
+        if (!step_all) DFX_HIP(hipMemcpyAsync(gp(S->g_sh_h), fp(S->hflip ? S->h_state2 : S->h_state), (size_t)S->layers * B * 256 * 4, hipMemcpyDeviceToDevice, s));
     }
     // ---- STFT + features of the n new hops (state: analysis memory, running means)
     float *am_in = fp(S->ana_mem[S->flip]), *am_out = fp(S->ana_mem[S->flip ^ 1]);
@@ -3409,13 +3415,10 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         sc.spec_T = spec_win_T;
         sc.feat_T = feat_T;
         sc.h_state = fp(S->hflip ? S->h_state2 : S->h_state);
-        // one new hop, ungated, plain launches: every GRU layer is ONE launch (projection + recurrence + gates) that leaves the new states in
-        // the other buffer (DFX_STREAM_STEP=0: the projection and the recurrence kernel of the batch path, in place)
-        static const bool step_env = [] { const char *e = getenv("DFX_STREAM_STEP"); return !(e && e[0] == '0'); }();
-        const bool step = step_env && n - skip == 1 && !gated && !S->capturing && !S->use_graph;
+        const bool step = step_all;
         sc.h_next = step ? fp(S->hflip ? S->h_state : S->h_state2) : nullptr;
         stepped = step;
-        if (step && S->c0ring_bytes) {   // df_convp from its pending sums (dfx_k_df_convp_step)
+        if (step && !gated && S->c0ring_bytes) {   // df_convp from its pending sums (dfx_k_df_convp_step; a gated handle keeps its per-stream delay line)
             const int ns = c.df_pathway_kernel_size_t - 1;
             sc.c0ring = S->buf + S->c0ring;
             sc.c0slot = (int)((((a0 + skip - L) % ns) + ns) % ns);
@@ -3447,7 +3450,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         }
         if (rc) return rc;
         if (stepped) S->hflip ^= 1;   // (like lin_pos: this form is neither replayed from a graph nor walked hop by hop by the caller)
-        S->c0ring_ok = stepped && S->c0ring_bytes;   // any other pass leaves the sums behind
+        S->c0ring_ok = stepped && !gated && S->c0ring_bytes;   // any other pass leaves the sums behind
         if (gated && c.df_pathway_kernel_size_t > 1) {  // the DF decoder's delay line moves where that decoder ran
             const int64_t frame = (int64_t)Fd * c.conv_ch;
             dfx_launch(dfx_k_gate_c0_shift, dim3((unsigned)B, 4), dim3(256), 0, s, (const unsigned char *)gflags, gp(S->g_c0_win), B, T,
@@ -3481,7 +3484,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         const int nenc = (int)m->enc_gru.size(), ndec = (int)m->dec_gru.size();
         for (int l = 0; l < S->layers; ++l) {
             float *h = fp(S->hflip ? S->h_state2 : S->h_state) + (int64_t)l * B * 256;
-            const float *hs = gp(S->g_sh_h) + (int64_t)l * B * 256;
+            const float *hs = (stepped ? fp(S->hflip ? S->h_state : S->h_state2) : gp(S->g_sh_h)) + (int64_t)l * B * 256;   // the states before this pass
             if (l < nenc) entry(h, hs, 256, FZ, FZ);
             else if (l < nenc + ndec) entry(h, hs, 256, DFX_GATE_GAINS, 0);   // stage 1 did not run (frozen streams included)
             else entry(h, hs, 256, DFX_GATE_DF, 0);                           // stage 2 did not run

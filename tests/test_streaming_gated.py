@@ -135,7 +135,9 @@ def test_gating_defaults_and_controls(backend):
     rt.reset()
     rt.set_gating(True)
     y1, l1 = _run(rt, x, [2] * (T // 2))
-    assert np.array_equal(y0, y1) and np.all(l1 != -15.0)
+    # (to rounding, not to the bit: a gated handle walks hop by hop and its GRU layers then run as the one-step kernel, the ungated
+    # two-hop calls above as projection + recurrence)
+    assert rms(y0 - y1) < 1e-6 * max(rms(y0), 1e-3) and np.array_equal(y0[1], y1[1]) and np.all(l1 != -15.0)
     rt.reset()
     rt.set_thresholds(-1e9, -1e9, -1e9)
     y2, l2 = _run(rt, x, [2] * (T // 2))
