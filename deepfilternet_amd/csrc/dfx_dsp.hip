@@ -640,7 +640,7 @@ int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, 
         static const int force_flat = [] { const char *e = getenv("DFX_DFA_FLAT"); return e && e[0] == '1' ? 1 : 0; }();
         const bool rows_ok = spec_stride % 2 == 0 && out_stride % 2 == 0 && coef_layout != DFX_COEF_BTFO && nd % 2 == 0 && nd / 2 <= 64 &&
                              nbands <= 64 && O <= 16 && !((uintptr_t)spec & 15) && !((uintptr_t)out & 15) && !((uintptr_t)coefs & 15) &&
-                             !(force_flat && spec_stride == F && out_stride == F) && !(pf_rs_channels > 0 && spec_stride == F && out_stride == F);
+                             !(force_flat && spec_stride == F && out_stride == F);
         if (rows_ok) {
             DfxDfrArgs R;
             R.spec = spec;
@@ -663,6 +663,7 @@ int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, 
             R.nb = nbands;
             R.pf_beta = pf_beta;
             R.atten_lim = atten_lim;
+            R.pf_ch = pf_rs_channels > 0 ? pf_rs_channels : 0;
             R.t_begin = (int)t_begin;
             R.t_end = (int)t_end;
             static const int rpw_env = [] { const char *e = getenv("DFX_DFA_RPW"); return e ? atoi(e) : 0; }();

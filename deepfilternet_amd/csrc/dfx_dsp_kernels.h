@@ -1405,6 +1405,7 @@ struct DfxDfrArgs {
     int zcols;            // float4 columns stored per output row: ceil(F/2), or more (zeros) to complete the row's last 64-byte sector
     int chunks;           // chunks of rpw frames per clip
     int64_t items;        // work items = ceil(B / 8) * 8 * ceil(chunks / 4)
+    int pf_ch = 0;        // > 0: the real-time runtime's post filter (see DfxDfaArgs::pf_ch): pf_ch consecutive clips are the channels of one stream
 };
 
 // NPC > 0: the number of 64-lane passes over a row (ceil(ceil(F/2) / 64)) as a compile-time constant (all row loads of a frame are
@@ -1452,10 +1453,20 @@ __global__ void __launch_bounds__(256) dfx_k_df_apply_rows(DfxDfrArgs A) {
             band1[p] = f + 1 < F ? A.bin2band[f + 1] : 0;
         }
     }
-    auto finish2 = [&](f32x4 y, f32x4 x, bool second_is_pad) -> f32x4 {
+    // (pf_ch > 0: libDF's post filter — Rust arithmetic, and the last (pf_ch * F) % 4 bins of the stream's flattened [pf_ch * F] frame are
+    // left alone, lib.rs:446-471 — then the attenuation limit; see dfx_dfa_bin)
+    const int pf_lim4 = (A.pf_ch * F) & ~3, ch_off = A.pf_ch > 0 ? (int)(b % A.pf_ch) * F : 0;
+    auto finish2 = [&](f32x4 y, f32x4 x, bool second_is_pad, int f0) -> f32x4 {
         if (PF) {
-            const float2 ya = dfx_dfa_finish(make_float2(y[0], y[1]), make_float2(x[0], x[1]), A.pf_beta, A.atten_lim);
-            const float2 yb = dfx_dfa_finish(make_float2(y[2], y[3]), make_float2(x[2], x[3]), A.pf_beta, A.atten_lim);
+            float2 ya = make_float2(y[0], y[1]), yb = make_float2(y[2], y[3]);
+            const float2 xa = make_float2(x[0], x[1]), xb = make_float2(x[2], x[3]);
+            if (A.pf_ch > 0) {
+                if (A.pf_beta > 0.f && ch_off + f0 < pf_lim4) ya = dfx_dfa_post_filter_rs(ya, xa, A.pf_beta);
+                if (A.pf_beta > 0.f && ch_off + f0 + 1 < pf_lim4) yb = dfx_dfa_post_filter_rs(yb, xb, A.pf_beta);
+                ya = dfx_dfa_finish(ya, xa, 0.f, A.atten_lim), yb = dfx_dfa_finish(yb, xb, 0.f, A.atten_lim);
+            } else {
+                ya = dfx_dfa_finish(ya, xa, A.pf_beta, A.atten_lim), yb = dfx_dfa_finish(yb, xb, A.pf_beta, A.atten_lim);
+            }
             y[0] = ya.x, y[1] = ya.y, y[2] = yb.x, y[3] = yb.y;
         }
         if (second_is_pad) y[2] = 0.f, y[3] = 0.f;
@@ -1535,7 +1546,7 @@ __global__ void __launch_bounds__(256) dfx_k_df_apply_rows(DfxDfrArgs A) {
                 y[0] = x[0] * g0, y[1] = x[1] * g0;
                 y[2] = x[2] * g1, y[3] = x[3] * g1;
             }
-            if (lane < ncol) st(finish2(y, x, 2 * (int)lane + 1 >= F), yrow + lane);
+            if (lane < ncol) st(finish2(y, x, 2 * (int)lane + 1 >= F, 2 * (int)lane), yrow + lane);
             else if (lane < zcol) st(zero4, yrow + lane);
         }
         // ---- the other passes: band gains only
@@ -1550,7 +1561,7 @@ __global__ void __launch_bounds__(256) dfx_k_df_apply_rows(DfxDfrArgs A) {
                 f32x4 y;
                 y[0] = x[0] * g0, y[1] = x[1] * g0;
                 y[2] = x[2] * g1, y[3] = x[3] * g1;
-                st(finish2(y, x, 2 * (int)col + 1 >= F), yrow + 64 * p + lane);
+                st(finish2(y, x, 2 * (int)col + 1 >= F, 2 * (int)col), yrow + 64 * p + lane);
             } else if (col < zcol) {
                 st(zero4, yrow + 64 * p + lane);   // pad columns that complete the row's last 64-byte sector
             }

@@ -124,6 +124,7 @@ struct DfxStreamCtx {
     int64_t H;         // history frames in front of the new ones
     int64_t t_zero;    // local frames < t_zero precede the start of the stream (df_convp sees zero padding there)
     int64_t spec_T;    // frames per clip of the spec array
+    int64_t spec_stride = 0;   // > 0: bins per row of spec and out (padded rows)
     int64_t feat_T = 0;    // > 0: frames per clip of feat_erb and feat_spec (windows inside the linear buffers; both share it)
     float *h_state;    // [GRU layers][B][256], in model order enc, erb_dec, df_dec
     float *h_next = nullptr;   // non-null (one new frame, ungated): the layers run as dfx_k_gru_step_h3 and leave their new states HERE
@@ -2744,7 +2745,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // the real-time runtime filters with libDF's own post_filter (lib.rs:446-471 via tract.rs:603-610): Rust arithmetic and its
         // chunks_exact(4) walk over the stream's flattened [channels * F] frame
         return dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, sc->spec_T, c.fft_size / 2 + 1, run_df ? Fd : 0, O, c.df_lookahead, beta,
-                                   atten_lim, sc->out, s, t_begin, T, T, sc->out_T, sc->out_toff, 0, 0, sc->channels > 0 ? sc->channels : 1);
+                                   atten_lim, sc->out, s, t_begin, T, T, sc->out_T, sc->out_toff, sc->spec_stride, sc->spec_stride,
+                                   sc->channels > 0 ? sc->channels : 1);
     }
     {   // dev experiment: DFX_DEV_SPIN="<blocks>,<microseconds>" launches a spinning kernel in front of the deep filter
         static const char *sp = getenv("DFX_DEV_SPIN");
@@ -2936,6 +2938,7 @@ struct dfx_stream_state {
     // window reaches the end are its last Hs frames moved back to the front (once per lin_cap - Hs - n hops).  The ring form below
     // (hist_spec -> work_spec, dfx_k_ring_step) rewrites the whole window on every call — at 4096 streams 95 us of a 720 us hop — and stays
     // for gated handles (a frozen stream's spectra must not move) and graph replay (fixed addresses).  lin_owns: which form holds the state.
+    int64_t Fp = 0;           // bins per spectrum row of the handle's buffers: F rounded up to a multiple of 8 (64-byte rows: the row-streaming deep filter takes them)
     size_t spec_lin = 0;
     int64_t lin_cap = 0, lin_pos = 0;
     bool lin_owns = false;
@@ -2995,7 +2998,9 @@ extern "C" int dfx_stream_create(const dfx_model *m, const dfx_state *st, int64_
     s->H = hist_conv > hist_df ? hist_conv : hist_df;
     s->layers = c.emb_num_layers + (c.emb_num_layers - 1) + c.df_num_layers;
     s->layers = (int)(m->enc_gru.size() + m->dec_gru.size() + m->df_gru.size());
-    const int64_t B = streams, n = max_frames, H = s->H, Hs = s->H + s->L, F = st->N / 2 + 1, E = c.nb_erb, Fd = c.nb_df, ML = st->N - st->hop;
+    const int64_t B = streams, n = max_frames, H = s->H, Hs = s->H + s->L, F = (st->N / 2 + 1 + 7) & ~(int64_t)7 /* padded rows */, E = c.nb_erb, Fd = c.nb_df,
+                  ML = st->N - st->hop;
+    s->Fp = F;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         size_t o = off;
@@ -3211,7 +3216,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     // up to date with the other one if that one holds the state, appends the call's new frames and returns the window [Hs + n frames]
     // and the clip stride (in frames) the deep filter has to use.
     const bool lin = S->lin_cap > 0 && !gated && !S->use_graph && !S->capturing;
-    const int64_t F2 = F * 2;
+    const int64_t Fp = S->Fp, F2 = Fp * 2;   // the handle's spectra have rows of Fp >= F bins
     // The feature windows of the encoder take the same form when the kernels that read them accept a clip stride (the fp16-split DF
     // encoder: DfxC01hArgs::feat_T): [B, feat_cap, E] and [B, feat_cap, Fd, 2] with the same slack as the spectra, so that all three
     // windows sit at lin_pos and go back to the front in the same call.  feat_owns: the linear form holds the feature history.
@@ -3287,7 +3292,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         }
         float *am_in = fp(S->ana_mem[S->flip]), *am_out = fp(S->ana_mem[S->flip ^ 1]);
         float *new_spec = fp(S->new_spec);
-        if ((rc = dfx_launch_analysis(st, x, B, n * hop, xs, am_in, am_out, new_spec, nullptr, s))) return rc;
+        if ((rc = dfx_launch_analysis(st, x, B, n * hop, xs, am_in, am_out, new_spec, nullptr, s, -1, Fp))) return rc;
         {
             const float *win = nullptr;
             int64_t win_T = 0;
@@ -3309,7 +3314,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
             G.n = 0;
             const unsigned char FZ = DFX_GATE_FROZEN;
             G.dst[0] = am_out, G.src[0] = am_in, G.row[0] = ML, G.mask[0] = FZ, G.want[0] = FZ;
-            G.dst[1] = fp(S->hist_spec[S->flip ^ 1]), G.src[1] = fp(S->hist_spec[S->flip]), G.row[1] = Hs * F * 2, G.mask[1] = FZ, G.want[1] = FZ;
+            G.dst[1] = fp(S->hist_spec[S->flip ^ 1]), G.src[1] = fp(S->hist_spec[S->flip]), G.row[1] = Hs * F2, G.mask[1] = FZ, G.want[1] = FZ;
             G.n = 2;
             dfx_launch(dfx_k_gate_commit, dim3((unsigned)B), dim3(128), 0, s, G, (const unsigned char *)gflags, B);
             DFX_LAUNCH_CHECK();
@@ -3345,8 +3350,8 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     // (DfxStreamCtx::df_post) — in front of the encoder these four small launches were 40 us of a 520 us hop at 4096 streams
     static const bool side_env = [] { const char *e = getenv("DFX_STREAM_SIDE"); return !(e && e[0] == '0'); }();
     const bool side = side_env && lin && !S->capturing && !S->use_graph;
-    if ((rc = dfx_launch_analysis(st, x, B, n * hop, xs, am_in, side ? nullptr : am_out, new_spec, new_fe, s))) return rc;
-    if ((rc = dfx_launch_norm_scan(new_fe, new_fe, (int)E, new_spec, F, new_fs, (int)Fd, B, n, c.norm_alpha, fp(S->erb_state),
+    if ((rc = dfx_launch_analysis(st, x, B, n * hop, xs, am_in, side ? nullptr : am_out, new_spec, new_fe, s, -1, Fp))) return rc;
+    if ((rc = dfx_launch_norm_scan(new_fe, new_fe, (int)E, new_spec, Fp, new_fs, (int)Fd, B, n, c.norm_alpha, fp(S->erb_state),
                                    fp(S->unit_state), s)))
         return rc;
     // ---- windows: [history ; new].  Net position p uses the features of hop p + L, so the hops of this call are the positions
@@ -3405,7 +3410,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     };
     if (!side && ((rc = side_post(s)) || (rc = erb_ring(s)) || (rc = side_pre(s)))) return rc;
     float *out_spec = fp(S->out_spec);
-    if (skip > 0) DFX_HIP(hipMemsetAsync(out_spec, 0, (size_t)B * n * F * 8, s));  // warm-up hops: zero spectra (tract.rs rolling buffers)
+    if (skip > 0) DFX_HIP(hipMemsetAsync(out_spec, 0, (size_t)B * n * Fp * 8, s));  // warm-up hops: zero spectra (tract.rs rolling buffers)
     bool stepped = false;
     if (skip < n) {
         DfxStreamCtx sc;
@@ -3413,6 +3418,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         const int64_t pos0 = Hs - a0;  // local index of net position 0
         sc.t_zero = pos0 > 0 ? pos0 : 0;
         sc.spec_T = spec_win_T;
+        sc.spec_stride = Fp;
         sc.feat_T = feat_T;
         sc.h_state = fp(S->hflip ? S->h_state2 : S->h_state);
         const bool step = step_all;
@@ -3426,7 +3432,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         }
         if (side) sc.erb_pre = erb_ring, sc.df_pre = side_pre, sc.df_post = side_post;
         sc.pf_beta = S->pf_beta;
-        sc.out = out_spec;  // local frame t of clip b lands at out_spec[(b*n + t - H) * F]
+        sc.out = out_spec;  // local frame t of clip b lands at out_spec[(b*n + t - H) * Fp]
         sc.out_T = n;
         sc.out_toff = H;
         sc.serial = S->capturing;
@@ -3461,7 +3467,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     if (side && !erb_done && (rc = erb_ring(s))) return rc;                              // (no forward pass ran: warm-up hops)
     if (side && !side_done && ((rc = side_pre(s)) || (rc = side_post(s)))) return rc;
     // ---- ISTFT of the n enhanced hops (state: overlap-add memory)
-    if ((rc = dfx_launch_synthesis(st, out_spec, B, n, sm_in, sm_out, y, ys, 0, n * hop, s))) return rc;
+    if ((rc = dfx_launch_synthesis(st, out_spec, B, n, sm_in, sm_out, y, ys, 0, n * hop, s, 0, -1, Fp))) return rc;
     if (lsnr_out) {  // the window's lsnr is [B, T]: take the n new frames (the entries of warm-up hops are not meaningful)
         if ((rc = stream_copy_rows(fp(S->lsnr), T, T, H, lsnr_out, ls, n, B, s))) return rc;
     }
@@ -3478,7 +3484,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         entry(sm_out, sm_in, ML, FZ, FZ);
         entry(fp(S->hist_fe[S->flip ^ 1]), fp(S->hist_fe[S->flip]), H * E, FZ, FZ);
         entry(fp(S->hist_fs[S->flip ^ 1]), fp(S->hist_fs[S->flip]), H * Fd * 2, FZ, FZ);
-        entry(fp(S->hist_spec[S->flip ^ 1]), fp(S->hist_spec[S->flip]), Hs * F * 2, FZ, FZ);
+        entry(fp(S->hist_spec[S->flip ^ 1]), fp(S->hist_spec[S->flip]), Hs * F2, FZ, FZ);
         entry(fp(S->erb_state), gp(S->g_sh_erb), E, FZ, FZ);
         entry(fp(S->unit_state), gp(S->g_sh_unit), Fd, FZ, FZ);
         const int nenc = (int)m->enc_gru.size(), ndec = (int)m->dec_gru.size();
@@ -3606,10 +3612,9 @@ extern "C" int dfx_stream_process_raw(dfx_stream_state *S, const float *spec, fl
     DFX_HIP(hipMemcpyAsync(gp(S->g_sh_unit), fp(S->unit_state), (size_t)B * Fd * 4, hipMemcpyDeviceToDevice, s));
     DFX_HIP(hipMemcpyAsync(gp(S->g_sh_h), fp(S->hflip ? S->h_state2 : S->h_state), (size_t)S->layers * B * 256 * 4, hipMemcpyDeviceToDevice, s));
     // features of the given spectra (state: the running means): erb (dB) -> mean norm, low bins -> unit norm (lib.rs:206-217)
-    float *new_spec = fp(S->new_spec), *new_fe = fp(S->new_fe), *new_fs = fp(S->new_fs);
-    DFX_HIP(hipMemcpyAsync(new_spec, spec, (size_t)B * F * 8, hipMemcpyDeviceToDevice, s));
-    if ((rc = dfx_erb(st->bands, new_spec, B, 1, new_fe, s))) return rc;
-    if ((rc = dfx_launch_norm_scan(new_fe, new_fe, (int)E, new_spec, F, new_fs, (int)Fd, B, n, c.norm_alpha, fp(S->erb_state),
+    float *new_fe = fp(S->new_fe), *new_fs = fp(S->new_fs);   // (the caller's dense [B, F] spectra are read in place)
+    if ((rc = dfx_erb(st->bands, spec, B, 1, new_fe, s))) return rc;
+    if ((rc = dfx_launch_norm_scan(new_fe, new_fe, (int)E, spec, F, new_fs, (int)Fd, B, n, c.norm_alpha, fp(S->erb_state),
                                    fp(S->unit_state), s)))
         return rc;
     const int64_t skip = a0 < L ? 1 : 0;
@@ -3624,7 +3629,7 @@ extern "C" int dfx_stream_process_raw(dfx_stream_state *S, const float *spec, fl
     // the buffers this path does not use keep their contents across the parity flip
     DFX_HIP(hipMemcpyAsync(fp(S->ana_mem[S->flip ^ 1]), fp(S->ana_mem[S->flip]), (size_t)B * ML * 4, hipMemcpyDeviceToDevice, s));
     DFX_HIP(hipMemcpyAsync(fp(S->syn_mem[S->flip ^ 1]), fp(S->syn_mem[S->flip]), (size_t)B * ML * 4, hipMemcpyDeviceToDevice, s));
-    DFX_HIP(hipMemcpyAsync(fp(S->hist_spec[S->flip ^ 1]), fp(S->hist_spec[S->flip]), (size_t)B * Hs * F * 8, hipMemcpyDeviceToDevice, s));
+    DFX_HIP(hipMemcpyAsync(fp(S->hist_spec[S->flip ^ 1]), fp(S->hist_spec[S->flip]), (size_t)B * Hs * S->Fp * 8, hipMemcpyDeviceToDevice, s));
     float *mask = gp(S->g_mask), *cbuf = gp(S->g_coefs);
     if (!skip) {
         DfxStreamCtx sc;
@@ -3632,6 +3637,7 @@ extern "C" int dfx_stream_process_raw(dfx_stream_state *S, const float *spec, fl
         const int64_t pos0 = Hs - a0;
         sc.t_zero = pos0 > 0 ? pos0 : 0;
         sc.spec_T = Hs + n;
+        sc.spec_stride = S->Fp;
         sc.h_state = fp(S->hflip ? S->h_state2 : S->h_state);
         sc.pf_beta = 0.f;
         sc.out = fp(S->out_spec);  // the deep-filter kernel still runs (on whatever the spectrum window holds); its output is not used
