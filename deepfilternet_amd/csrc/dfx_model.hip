@@ -3244,6 +3244,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     // spec_window(): host-side bookkeeping of the rolling spectra for this call (which form, where the window is) with the copies it takes
     // listed in cp_spec (and, when the windows go back to the front, in cp_fe / cp_fs); the ring form is stepped on `s` right away.
     // The caller advances lin_pos by n when it is done with the windows.
+    const float *spec_ring_src = nullptr;
     auto spec_window = [&](const float *new_spec, const float **win, int64_t *win_T) -> int {
         if (lin) {
             float *L0 = fp(S->spec_lin);
@@ -3272,12 +3273,18 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
             int r;
             if ((r = emit(cp_spec, s)) || (r = emit(cp_fe, s)) || (r = emit(cp_fs, s))) return r;
         }
-        DfxKScope ks(DFX_K_COPY_ROWS, s);
-        dfx_launch(dfx_k_ring_step, dim3((unsigned)nn_grid(dfx_ceil_div(B * (Hs + n) * F2, 256), 16)), dim3(256), 0, s,
-                   (const float *)fp(S->hist_spec[S->flip]), new_spec, fp(S->work_spec), fp(S->hist_spec[S->flip ^ 1]), B, Hs, n, F2, (int64_t)0);
-        DFX_LAUNCH_CHECK();
+        spec_ring_src = new_spec;   // the ring step itself is enqueued by spec_ring(): like the copies, where the caller wants it
         *win = fp(S->work_spec);
         *win_T = Hs + n;
+        return DFX_OK;
+    };
+    auto spec_ring = [&](hipStream_t on) -> int {
+        if (!spec_ring_src) return DFX_OK;
+        DfxKScope ks(DFX_K_COPY_ROWS, on);
+        dfx_launch(dfx_k_ring_step, dim3((unsigned)nn_grid(dfx_ceil_div(B * (Hs + n) * F2, 256), 16)), dim3(256), 0, on,
+                   (const float *)fp(S->hist_spec[S->flip]), spec_ring_src, fp(S->work_spec), fp(S->hist_spec[S->flip ^ 1]), B, Hs, n, F2, (int64_t)0);
+        DFX_LAUNCH_CHECK();
+        spec_ring_src = nullptr;
         return DFX_OK;
     };
     if (S->lim == 1.f) {
@@ -3297,7 +3304,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
             const float *win = nullptr;
             int64_t win_T = 0;
             if (S->feat_owns) feat_to_ring();   // (the features do not advance here: their history waits in the ring form)
-            if ((rc = spec_window(new_spec, &win, &win_T)) || (rc = emit(cp_fe, s)) || (rc = emit(cp_fs, s)) || (rc = emit(cp_spec, s))) return rc;
+            if ((rc = spec_window(new_spec, &win, &win_T)) || (rc = emit(cp_fe, s)) || (rc = emit(cp_fs, s)) || (rc = emit(cp_spec, s)) || (rc = spec_ring(s))) return rc;
             if (lin) S->lin_pos += n;
         }
         // what this path does not touch keeps its contents across the parity flip
@@ -3349,7 +3356,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     // only the final deep filter or the NEXT call needs (the spectrum window, the analysis memory) behind df_convp on its stream
     // (DfxStreamCtx::df_post) — in front of the encoder these four small launches were 40 us of a 520 us hop at 4096 streams
     static const bool side_env = [] { const char *e = getenv("DFX_STREAM_SIDE"); return !(e && e[0] == '0'); }();
-    const bool side = side_env && lin && !S->capturing && !S->use_graph;
+    const bool side = side_env && !S->capturing && !S->use_graph;   // (either form of the windows: the ring steps are deferred like the copies)
     if ((rc = dfx_launch_analysis(st, x, B, n * hop, xs, am_in, side ? nullptr : am_out, new_spec, new_fe, s, -1, Fp))) return rc;
     if ((rc = dfx_launch_norm_scan(new_fe, new_fe, (int)E, new_spec, Fp, new_fs, (int)Fd, B, n, c.norm_alpha, fp(S->erb_state),
                                    fp(S->unit_state), s)))
@@ -3406,6 +3413,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     side_post = [&](hipStream_t on) -> int {
         side_done = true;
         if (int r = emit(cp_spec, on)) return r;
+        if (int r = spec_ring(on)) return r;
         return side ? dfx_launch_analysis_mem(st, x, B, n * hop, xs, am_in, am_out, on) : DFX_OK;
     };
     if (!side && ((rc = side_post(s)) || (rc = erb_ring(s)) || (rc = side_pre(s)))) return rc;
