@@ -157,6 +157,9 @@ struct DfxGate {
     unsigned char *flags;  // [B]
     float thr[3];          // min_db_thresh, max_db_erb_thresh, max_db_df_thresh
     float *c0_win;         // [B, T, Fd, C]: slots T-kt .. T-2 = c0 of the last kt-1 frames the DF decoder ran on, T-1 = this frame
+    void *pend2 = nullptr;           // fp16-split models: df_convp's pending sums instead, twice per stream (dfx_k_df_convp_step), with
+    unsigned char *par = nullptr;    //   the half that is current and
+    int *cnt = nullptr;              //   the frames each stream's DF decoder has consumed
     int channels;          // streams per multi-channel group: one skip counter and one stage decision (the first channel's lsnr) per group
 };
 
@@ -279,6 +282,15 @@ __global__ void dfx_k_gate_c0_shift(const unsigned char *flags, float *c0_win, i
     float *w = c0_win + (b * T + T - kt) * frame;
     for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < frame; i += (int64_t)gridDim.y * blockDim.x)
         for (int j = 0; j + 1 < kt; ++j) w[j * frame + i] = w[(j + 1) * frame + i];
+}
+
+// The same for the pending-sum form of df_convp (dfx_k_df_convp_step): where the DF decoder ran the sums written by this pass become
+// current and the stream's frame count goes up.
+__global__ void dfx_k_gate_pend_commit(const unsigned char *flags, unsigned char *par, int *cnt, int64_t B) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B || !(flags[b] & DFX_GATE_DF)) return;
+    par[b] ^= 1;
+    cnt[b] += 1;
 }
 
 // End of a gated hop: frozen streams answer zeros and lsnr = -15 (tract.rs:522-525); the others update the skip counter from the
@@ -1349,7 +1361,8 @@ static int launch_convp_h3(const dfx_model *m, const float *feat_spec, float *ou
 // df_convp of the newest frame of every stream with the older frames' c0 tiles from the handle's ring (dfx_k_df_convp_step)
 template <int C, int KT>
 static int launch_convp_step(const dfx_model *m, const float *feat_spec, float *out, int64_t B, int64_t T, int Fd, int NO, hipStream_t s,
-                             int64_t t_zero, int L, void *ring, int slot, bool rebuild, int64_t feat_T = 0) {
+                             int64_t t_zero, int L, void *ring, int slot, bool rebuild, int64_t feat_T = 0, const unsigned char *par = nullptr,
+                             const int *cnt = nullptr) {
     if constexpr (C % 32 != 0 || KT < 2) {
         DFX_FAIL(DFX_ERR_UNSUPPORTED, "df_convp step kernel: conv_ch %% 32 == 0 and kt >= 2");
     } else {
@@ -1372,8 +1385,8 @@ static int launch_convp_step(const dfx_model *m, const float *feat_spec, float *
         static const int per_cu = [] { const char *e = getenv("DFX_CONVP_STEP_WGS"); return e && atoi(e) > 0 ? atoi(e) : 8; }();
         const int grid = nn_grid(dfx_ceil_div(B * A.nfb, 4), per_cu);
         DfxKScope ks(DFX_K_DF_CONVP, s);
-        if (rebuild) dfx_launch((dfx_k_df_convp_step<C, KT, true>), dim3(grid), dim3(256), 0, s, A, reinterpret_cast<f32x4 *>(ring), slot);
-        else dfx_launch((dfx_k_df_convp_step<C, KT, false>), dim3(grid), dim3(256), 0, s, A, reinterpret_cast<f32x4 *>(ring), slot);
+        if (rebuild) dfx_launch((dfx_k_df_convp_step<C, KT, true>), dim3(grid), dim3(256), 0, s, A, reinterpret_cast<f32x4 *>(ring), slot, par, cnt);
+        else dfx_launch((dfx_k_df_convp_step<C, KT, false>), dim3(grid), dim3(256), 0, s, A, reinterpret_cast<f32x4 *>(ring), slot, par, cnt);
         DFX_LAUNCH_CHECK();
         return DFX_OK;
     }
@@ -2055,6 +2068,14 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     auto convp_range = [&](int64_t t0, int64_t t1, hipStream_t st) -> int {
         static const int dev_skip_cp = [] { const char *e = getenv("DFX_DEV_SKIP"); return e ? atoi(e) : 0; }();   // dev timing ablation (results invalid)
         if (dev_skip_cp & 8) return DFX_OK;
+        if (gate && kt > 1 && gate->pend2 && fuse_h3 && t1 - t0 == 1 && t1 == T) {   // gated, fp16-split: pending sums, two halves per stream
+            switch (kt) {
+                case 2: return launch_convp_step<C, 2>(m, feat_spec, c0p, B, T, Fd, NO, st, t_zero, Lk, gate->pend2, 0, false, featT, gate->par, gate->cnt);
+                case 3: return launch_convp_step<C, 3>(m, feat_spec, c0p, B, T, Fd, NO, st, t_zero, Lk, gate->pend2, 0, false, featT, gate->par, gate->cnt);
+                case 4: return launch_convp_step<C, 4>(m, feat_spec, c0p, B, T, Fd, NO, st, t_zero, Lk, gate->pend2, 0, false, featT, gate->par, gate->cnt);
+                default: return launch_convp_step<C, 5>(m, feat_spec, c0p, B, T, Fd, NO, st, t_zero, Lk, gate->pend2, 0, false, featT, gate->par, gate->cnt);
+            }
+        }
         if (gate && kt > 1) {
             // gated streaming: the (kt-1)-frame delay line in front of df_convp belongs to the DF decoder and only moves on the frames
             // that decoder ran on, per stream.  c0 of the newest frame goes into the last slot of the per-stream window (exact fp32
@@ -2952,6 +2973,8 @@ struct dfx_stream_state {
     float thr[3] = {-10.f, 30.f, 20.f};   // RuntimeParams::default_with_ch (tract.rs:177-189)
     unsigned char *gate_buf = nullptr;    // own allocation, made when gating is first switched on
     size_t g_flags = 0, g_counter = 0, g_sh_erb = 0, g_sh_unit = 0, g_sh_h = 0, g_c0_win = 0, g_mask = 0, g_coefs = 0, gate_bytes = 0;
+    size_t g_pend2 = 0, g_par = 0, g_cnt = 0;   // pending-sum form of the gated df_convp (g_pend2_ok; then g_c0_win is not allocated)
+    bool g_pend2_ok = false;
     // DFX_STREAM_GRAPH=1: steady-state calls are replayed from a hipGraph (one per memory parity) captured as a single-stream chain on
     // handle-owned I/O buffers (x / y are copied in and out around it).  Off by default: on ROCm 7.2 the replay of the ~35 kernel
     // nodes takes 2.0-2.2 ms per call where the plain three-stream launches take 1.4-1.6 ms.
@@ -3164,7 +3187,17 @@ extern "C" int dfx_stream_set_gating(dfx_stream_state *s, int enable) {
         s->g_sh_erb = take((size_t)B * c.nb_erb * 4);
         s->g_sh_unit = take((size_t)B * c.nb_df * 4);
         s->g_sh_h = take((size_t)s->layers * B * 256 * 4);
-        s->g_c0_win = take(c.df_pathway_kernel_size_t > 1 ? (size_t)B * T * c.nb_df * c.conv_ch * 4 : 256);
+        {   // df_convp's state of a gated handle: pending sums (fp16-split models; 2 x what the ungated handle keeps) or the window of c0 frames
+            const int kt = c.df_pathway_kernel_size_t;
+            static const bool pend_env = [] { const char *e = getenv("DFX_GATE_PEND"); return !(e && e[0] == '0'); }();
+            s->g_pend2_ok = pend_env && kt >= 2 && kt <= 5 && c.conv_ch % 32 == 0 && s->m->fuse_c0 && !s->m->exact_fp32 && s->m->cp_h3;
+            if (s->g_pend2_ok) {
+                s->g_pend2 = take((size_t)B * 2 * (kt - 1) * ((c.nb_df + 15) / 16) * 64 * 16);
+                s->g_par = take((size_t)B);
+                s->g_cnt = take((size_t)B * 4);
+            }
+            s->g_c0_win = take(kt > 1 && !s->g_pend2_ok ? (size_t)B * T * c.nb_df * c.conv_ch * 4 : 256);
+        }
         s->g_mask = take((size_t)B * T * c.nb_erb * 4);                       // dfx_stream_process_raw: the pass's mask / coefficients
         s->g_coefs = take((size_t)B * c.df_order * T * c.nb_df * 8);
         s->gate_bytes = off;
@@ -3452,6 +3485,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
             gate.flags = gflags;
             gate.thr[0] = S->thr[0], gate.thr[1] = S->thr[1], gate.thr[2] = S->thr[2];
             gate.c0_win = gp(S->g_c0_win);
+            if (S->g_pend2_ok) gate.pend2 = S->gate_buf + S->g_pend2, gate.par = S->gate_buf + S->g_par, gate.cnt = reinterpret_cast<int *>(S->gate_buf + S->g_cnt);
             sc.gate = &gate;
         }
         float *ws = reinterpret_cast<float *>(((uintptr_t)(S->buf + S->model_ws) + 255) & ~(uintptr_t)255);
@@ -3466,9 +3500,14 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         if (stepped) S->hflip ^= 1;   // (like lin_pos: this form is neither replayed from a graph nor walked hop by hop by the caller)
         S->c0ring_ok = stepped && !gated && S->c0ring_bytes;   // any other pass leaves the sums behind
         if (gated && c.df_pathway_kernel_size_t > 1) {  // the DF decoder's delay line moves where that decoder ran
-            const int64_t frame = (int64_t)Fd * c.conv_ch;
-            dfx_launch(dfx_k_gate_c0_shift, dim3((unsigned)B, 4), dim3(256), 0, s, (const unsigned char *)gflags, gp(S->g_c0_win), B, T,
-                       c.df_pathway_kernel_size_t, frame);
+            if (S->g_pend2_ok) {
+                dfx_launch(dfx_k_gate_pend_commit, dim3((unsigned)dfx_ceil_div(B, 256)), dim3(256), 0, s, (const unsigned char *)gflags,
+                           S->gate_buf + S->g_par, reinterpret_cast<int *>(S->gate_buf + S->g_cnt), B);
+            } else {
+                const int64_t frame = (int64_t)Fd * c.conv_ch;
+                dfx_launch(dfx_k_gate_c0_shift, dim3((unsigned)B, 4), dim3(256), 0, s, (const unsigned char *)gflags, gp(S->g_c0_win), B, T,
+                           c.df_pathway_kernel_size_t, frame);
+            }
             DFX_LAUNCH_CHECK();
         }
     }
@@ -3659,6 +3698,7 @@ extern "C" int dfx_stream_process_raw(dfx_stream_state *S, const float *spec, fl
         gate.flags = gflags;
         gate.thr[0] = S->thr[0], gate.thr[1] = S->thr[1], gate.thr[2] = S->thr[2];
         gate.c0_win = gp(S->g_c0_win);
+        if (S->g_pend2_ok) gate.pend2 = S->gate_buf + S->g_pend2, gate.par = S->gate_buf + S->g_par, gate.cnt = reinterpret_cast<int *>(S->gate_buf + S->g_cnt);
         sc.gate = &gate;
         float *ws = reinterpret_cast<float *>(((uintptr_t)(S->buf + S->model_ws) + 255) & ~(uintptr_t)255);
         const DfxLane *ln = &m->lanes[0];
@@ -3670,8 +3710,12 @@ extern "C" int dfx_stream_process_raw(dfx_stream_state *S, const float *spec, fl
         }
         if (rc) return rc;
         if (c.df_pathway_kernel_size_t > 1) {
-            dfx_launch(dfx_k_gate_c0_shift, dim3((unsigned)B, 4), dim3(256), 0, s, (const unsigned char *)gflags, gp(S->g_c0_win), B, T,
-                       c.df_pathway_kernel_size_t, (int64_t)Fd * c.conv_ch);
+            if (S->g_pend2_ok)
+                dfx_launch(dfx_k_gate_pend_commit, dim3((unsigned)dfx_ceil_div(B, 256)), dim3(256), 0, s, (const unsigned char *)gflags,
+                           S->gate_buf + S->g_par, reinterpret_cast<int *>(S->gate_buf + S->g_cnt), B);
+            else
+                dfx_launch(dfx_k_gate_c0_shift, dim3((unsigned)B, 4), dim3(256), 0, s, (const unsigned char *)gflags, gp(S->g_c0_win), B, T,
+                           c.df_pathway_kernel_size_t, (int64_t)Fd * c.conv_ch);
             DFX_LAUNCH_CHECK();
         }
         // the newest frame's mask row and coefficient rows (coefficients are [B, O, T, F'][2]: one strided row per (stream, tap))

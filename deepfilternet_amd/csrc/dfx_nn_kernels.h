@@ -855,8 +855,14 @@ __global__ void __launch_bounds__(256, 1) dfx_k_df_convp_h3(DfxCphArgs A) {
 // encoder's GRU step took 95 us instead of 40).  REBUILD: the sums are not current (after a reset they are all zeros = the causal
 // padding and need none; after calls of several hops or gated passes they do): the kt - 1 older frames are recomputed from the feature
 // window like dfx_k_df_convp_h3 does, and their taps summed up.
+// Gated handles (par / cnt non-null): the delay line in front of df_convp only moves for the streams whose DF decoder runs on this hop,
+// and that is decided later in the pass.  The sums then live twice per stream, pend[b][parity]: the kernel reads the half par[b] names
+// (slot of the new frame: cnt[b] % (kt - 1), the frames that stream's decoder has consumed) and writes the updated sums into the OTHER half;
+// dfx_k_gate_pend_commit flips par[b] and counts the frame where the decoder ran — elsewhere the new frame is simply dropped, as the
+// reference's pulsed model drops it (tract.rs: a sub-model that is not run does not advance).
 template <int C, int KT, bool REBUILD>
-__global__ void __launch_bounds__(256, 2) dfx_k_df_convp_step(DfxCphArgs A, f32x4 *pend, int slot_new) {
+__global__ void __launch_bounds__(256, 2) dfx_k_df_convp_step(DfxCphArgs A, f32x4 *pend, int slot_new, const unsigned char *par = nullptr,
+                                                             const int *cnt = nullptr) {
     constexpr int CPL = C / 4, NT = C / 16, KC = C / 32, NS = KT - 1;
     static_assert(C % 32 == 0 && KT >= 2, "one k-chunk is 32 channels; kt = 1 has no history");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
@@ -879,7 +885,9 @@ __global__ void __launch_bounds__(256, 2) dfx_k_df_convp_step(DfxCphArgs A, f32x
         const int64_t b = run / A.nfb;
         const int f = fb * 16 + jl;
         const bool fvalid = f < A.Fd;
-        auto slot_ptr = [&](int j) { return pend + (((size_t)b * NS + (slot_new + j) % NS) * A.nfb + fb) * 64 + lane; };   // sum of out[t + j]
+        const int half_in = par ? (int)(par[b] & 1) : 0, half_out = par ? half_in ^ 1 : 0, halves = par ? 2 : 1;
+        const int slot0 = cnt ? cnt[b] % NS : slot_new;
+        auto slot_ptr = [&](int j, int half) { return pend + ((((size_t)b * halves + half) * NS + (slot0 + j) % NS) * A.nfb + fb) * 64 + lane; };   // sum of out[t + j]
         // sums[o]: out[t + o] — o = 0 is completed here, 1 .. NS go back to the handle; per sum three chains (one per product term, added
         // small-to-large at the end: the order of dfx_k_df_convp_h3 within a tap)
         f32x4 sa[KT], sb[KT], sc[KT];
@@ -887,7 +895,7 @@ __global__ void __launch_bounds__(256, 2) dfx_k_df_convp_step(DfxCphArgs A, f32x
         for (int o = 0; o < KT; ++o) sa[o] = sb[o] = f32x4{0.f, 0.f, 0.f, 0.f}, sc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!REBUILD) {
 #pragma unroll
-            for (int o = 0; o < NS; ++o) sc[o] = *slot_ptr(o);   // (out[t + NS] has no taps yet)
+            for (int o = 0; o < NS; ++o) sc[o] = *slot_ptr(o, half_in);   // (out[t + NS] has no taps yet)
         }
         dfx_static_for<(REBUILD ? 0 : KT - 1), KT>([&](auto dc) {
             constexpr int d = decltype(dc)::value;   // frame t - (KT-1) + d; its tap k belongs to out[t + d - k]
@@ -918,7 +926,7 @@ __global__ void __launch_bounds__(256, 2) dfx_k_df_convp_step(DfxCphArgs A, f32x
 #pragma unroll
             for (int r = 0; r < 4; ++r) sum[o][r] = (sa[o][r] + sb[o][r]) + sc[o][r];
 #pragma unroll
-        for (int o = 1; o < KT; ++o) *slot_ptr(o) = sum[o];   // (slot of out[t + NS] = the one out[t] was read from)
+        for (int o = 1; o < KT; ++o) *slot_ptr(o, half_out) = sum[o];   // (slot of out[t + NS] = the one out[t] was read from)
         if (fvalid) {
             float *op = A.out + ((b * (A.NO / 2) * A.T + t) * A.Fd + f) * 2;
 #pragma unroll
