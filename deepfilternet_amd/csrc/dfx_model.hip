@@ -183,6 +183,72 @@ __global__ void dfx_k_gate_pre(const float *x, int64_t x_stride, int hop, int64_
     flags[b] = c > 5 ? DFX_GATE_FROZEN : 0;
 }
 
+// The same for mono streams with the hop staged through LDS: 16 streams per 64-thread workgroup, rows loaded coalesced (a thread walking
+// its own row touches 64 cache lines per load instruction: 50 us at 4096 streams, in front of everything else of a gated hop), then one
+// lane per stream folds its row in the reference's order (rows padded by one float: the 16 lanes read different banks).
+#define DFX_GATE_PRE_ROWS 16
+__global__ void __launch_bounds__(64) dfx_k_gate_pre_lds(const float *x, int64_t x_stride, int hop, int64_t B, int *skip_counter, unsigned char *flags) {
+    DFX_DYN_SMEM(float4, rows4);   // [16][hop / 4 + 1] float4: rows padded by one float4 (16 lanes x 16 bytes then read 64 different banks)
+    const int64_t b0 = (int64_t)blockIdx.x * DFX_GATE_PRE_ROWS;
+    const int q4 = hop >> 2, ld4 = q4 + 1;
+    // all loads of eight rows are requested before the first LDS store (hop = 480: two float4 per thread and row)
+    for (int r0 = 0; r0 < DFX_GATE_PRE_ROWS; r0 += 8) {
+        for (int i0 = threadIdx.x; i0 < q4; i0 += 128) {
+            float4 v[8][2];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int64_t b = b0 + r0 + r < B ? b0 + r0 + r : B - 1;
+                const float4 *xr = reinterpret_cast<const float4 *>(x + b * x_stride);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = i0 + 64 * u;
+                    v[r][u] = xr[i < q4 ? i : i0];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = i0 + 64 * u;
+                    if (i < q4) rows4[(r0 + r) * ld4 + i] = v[r][u];
+                }
+        }
+    }
+    __syncthreads();
+    const int64_t b = b0 + threadIdx.x;
+    if (threadIdx.x >= DFX_GATE_PRE_ROWS || b >= B) return;
+    const float4 *xp = rows4 + threadIdx.x * ld4;
+    float e = 0.f;
+    for (int i0 = 0; i0 < q4; i0 += 8) {   // eight LDS reads in flight, the fold itself in the reference's order
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xp[i0 + u < q4 ? i0 + u : i0];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u >= q4) break;
+            e = __fadd_rn(e, __fmul_rn(v[u].x, v[u].x));
+            e = __fadd_rn(e, __fmul_rn(v[u].y, v[u].y));
+            e = __fadd_rn(e, __fmul_rn(v[u].z, v[u].z));
+            e = __fadd_rn(e, __fmul_rn(v[u].w, v[u].w));
+        }
+    }
+    const float ms = __fdiv_rn(e, (float)hop);
+    int c = skip_counter[b];
+    c = ms < 1e-7f ? c + 1 : 0;
+    skip_counter[b] = c;
+    flags[b] = c > 5 ? DFX_GATE_FROZEN : 0;
+}
+static int launch_gate_pre(const float *x, int64_t x_stride, int hop, int64_t B, int *skip_counter, unsigned char *flags, int ch, hipStream_t s) {
+    const size_t smem = (size_t)DFX_GATE_PRE_ROWS * (hop / 4 + 1) * 16;
+    if (ch == 1 && smem <= 64 * 1024 && hop % 4 == 0 && x_stride % 4 == 0 && !((uintptr_t)x & 15)) {
+        dfx_launch(dfx_k_gate_pre_lds, dim3((unsigned)dfx_ceil_div(B, DFX_GATE_PRE_ROWS)), dim3(64), smem, s, x, x_stride, hop, B, skip_counter, flags);
+    } else {
+        dfx_launch(dfx_k_gate_pre, dim3((unsigned)dfx_ceil_div(B, 64)), dim3(64), 0, s, x, x_stride, hop, B, skip_counter, flags, ch);
+    }
+    DFX_LAUNCH_CHECK();
+    return DFX_OK;
+}
+
 // tract.rs:658-672 apply_stages on the newest frame's lsnr (lsnr[b*T + T-1])
 // (multi-channel: the decision of a group is taken from its first channel's lsnr, tract.rs:468 `to_scalar`)
 __global__ void dfx_k_gate_post(const float *lsnr, int64_t T, float thr_min, float thr_erb, float thr_df, unsigned char *flags,
@@ -3326,9 +3392,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         // hop is passed through undelayed with lsnr = 35 — unless the stream has been silent for more than 5 hops (zeros, -15).
         unsigned char *gflags = gated ? S->gate_buf + S->g_flags : nullptr;
         if (gated) {
-            dfx_launch(dfx_k_gate_pre, dim3((unsigned)dfx_ceil_div(B, 64)), dim3(64), 0, s, x, xs, (int)hop, B,
-                       reinterpret_cast<int *>(S->gate_buf + S->g_counter), gflags, S->channels);
-            DFX_LAUNCH_CHECK();
+            if ((rc = launch_gate_pre(x, xs, (int)hop, B, reinterpret_cast<int *>(S->gate_buf + S->g_counter), gflags, S->channels, s))) return rc;
         }
         float *am_in = fp(S->ana_mem[S->flip]), *am_out = fp(S->ana_mem[S->flip ^ 1]);
         float *new_spec = fp(S->new_spec);
@@ -3374,8 +3438,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     if (gated) {
         // silent-input shortcut (tract.rs:513-525) + a copy of the in-place state, so that the streams that turn out not to advance
         // (frozen, or a decoder stage skipped) can be given their state back after the pass
-        dfx_launch(dfx_k_gate_pre, dim3((unsigned)dfx_ceil_div(B, 64)), dim3(64), 0, s, x, xs, (int)hop, B, gcount, gflags, S->channels);
-        DFX_LAUNCH_CHECK();
+        if ((rc = launch_gate_pre(x, xs, (int)hop, B, gcount, gflags, S->channels, s))) return rc;
         DFX_HIP(hipMemcpyAsync(gp(S->g_sh_erb), fp(S->erb_state), (size_t)B * E * 4, hipMemcpyDeviceToDevice, s));
         DFX_HIP(hipMemcpyAsync(gp(S->g_sh_unit), fp(S->unit_state), (size_t)B * Fd * 4, hipMemcpyDeviceToDevice, s));
         // (the GRU states: only when the layers run in place — the one-step kernel leaves the old states in the other buffer)
