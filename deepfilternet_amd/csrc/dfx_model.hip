@@ -350,6 +350,18 @@ __global__ void dfx_k_gate_c0_shift(const unsigned char *flags, float *c0_win, i
         for (int j = 0; j + 1 < kt; ++j) w[j * frame + i] = w[(j + 1) * frame + i];
 }
 
+// Linear windows (dfx_stream_state::spec_lin, fe_lin, fs_lin) of gated handles: every stream's window slides by the hop, but a frozen stream's
+// history must stay what it was.  After the hop's frame has been appended at frame pos + h, the frozen streams' h history frames
+// [pos, pos + h) are moved up by one frame (the appended frame is overwritten): the next hop's history [pos + 1, pos + 1 + h) is then
+// the old one.  One thread per element of a frame row, walking the frames from the newest down (an overlapping move within its column).
+__global__ void dfx_k_gate_hold(const unsigned char *flags, float *win, int64_t cap, int64_t row, int64_t pos, int64_t h, int64_t B) {
+    const int64_t b = blockIdx.x;
+    if (b >= B || !(flags[b] & DFX_GATE_FROZEN)) return;
+    float *w = win + (b * cap + pos) * row;
+    for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < row; i += (int64_t)gridDim.y * blockDim.x)
+        for (int64_t j = h - 1; j >= 0; --j) w[(j + 1) * row + i] = w[j * row + i];
+}
+
 // The same for the pending-sum form of df_convp (dfx_k_df_convp_step): where the DF decoder ran the sums written by this pass become
 // current and the stream's frame count goes up.
 __global__ void dfx_k_gate_pend_commit(const unsigned char *flags, unsigned char *par, int *cnt, int64_t B) {
@@ -3314,7 +3326,8 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     // ---- rolling spectra: linear (sliding window, see dfx_stream_state::spec_lin) or ring.  spec_window() brings the form this call uses
     // up to date with the other one if that one holds the state, appends the call's new frames and returns the window [Hs + n frames]
     // and the clip stride (in frames) the deep filter has to use.
-    const bool lin = S->lin_cap > 0 && !gated && !S->use_graph && !S->capturing;
+    static const bool gate_lin_env = [] { const char *e = getenv("DFX_GATE_LINEAR"); return !(e && e[0] == '0'); }();
+    const bool lin = S->lin_cap > 0 && !(gated && !gate_lin_env) && !S->use_graph && !S->capturing;
     const int64_t Fp = S->Fp, F2 = Fp * 2;   // the handle's spectra have rows of Fp >= F bins
     // The feature windows of the encoder take the same form when the kernels that read them accept a clip stride (the fp16-split DF
     // encoder: DfxC01hArgs::feat_T): [B, feat_cap, E] and [B, feat_cap, Fd, 2] with the same slack as the spectra, so that all three
@@ -3335,6 +3348,12 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         return DFX_OK;
     };
     const int64_t capf = S->feat_cap, E1 = E, D2 = Fd * 2;
+    auto hold = [&](float *win, int64_t cap, int64_t row, int64_t pos, int64_t h, hipStream_t on) -> int {   // frozen streams keep their history (dfx_k_gate_hold)
+        dfx_launch(dfx_k_gate_hold, dim3((unsigned)B, (unsigned)(row > 1024 ? 4 : 1)), dim3(256), 0, on, (const unsigned char *)(S->gate_buf + S->g_flags), win,
+                   cap, row, pos, h, B);
+        DFX_LAUNCH_CHECK();
+        return DFX_OK;
+    };
     auto feat_to_ring = [&]() {   // the feature windows' last H frames become the ring form's history
         cp_fe.add(fp(S->fe_lin), capf * E1, capf * E1, S->lin_pos * E1, fp(S->hist_fe[S->flip]), H * E1, H * E1);
         cp_fs.add(fp(S->fs_lin), capf * D2, capf * D2, S->lin_pos * D2, fp(S->hist_fs[S->flip]), H * D2, H * D2);
@@ -3402,6 +3421,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
             int64_t win_T = 0;
             if (S->feat_owns) feat_to_ring();   // (the features do not advance here: their history waits in the ring form)
             if ((rc = spec_window(new_spec, &win, &win_T)) || (rc = emit(cp_fe, s)) || (rc = emit(cp_fs, s)) || (rc = emit(cp_spec, s)) || (rc = spec_ring(s))) return rc;
+            if (gated && lin && (rc = hold(fp(S->spec_lin), S->lin_cap, F2, S->lin_pos, Hs, s))) return rc;
             if (lin) S->lin_pos += n;
         }
         // what this path does not touch keeps its contents across the parity flip
@@ -3419,7 +3439,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
             const unsigned char FZ = DFX_GATE_FROZEN;
             G.dst[0] = am_out, G.src[0] = am_in, G.row[0] = ML, G.mask[0] = FZ, G.want[0] = FZ;
             G.dst[1] = fp(S->hist_spec[S->flip ^ 1]), G.src[1] = fp(S->hist_spec[S->flip]), G.row[1] = Hs * F2, G.mask[1] = FZ, G.want[1] = FZ;
-            G.n = 2;
+            G.n = lin ? 1 : 2;   // (linear window: dfx_k_gate_hold above)
             dfx_launch(dfx_k_gate_commit, dim3((unsigned)B), dim3(128), 0, s, G, (const unsigned char *)gflags, B);
             DFX_LAUNCH_CHECK();
             dfx_launch(dfx_k_gate_finish, dim3((unsigned)B), dim3(128), 0, s, (const unsigned char *)gflags,
@@ -3494,22 +3514,27 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     } else if (S->feat_owns) {
         feat_to_ring();
     }
+    const int64_t lin_pos0 = S->lin_pos;
     if (lin) S->lin_pos += n;   // (advanced here: this form is never replayed from a graph nor walked hop by hop by the caller)
     bool side_done = false, erb_done = false;
     std::function<int(hipStream_t)> side_pre, side_post, erb_ring;
     erb_ring = [&](hipStream_t on) -> int {
         erb_done = true;
         if (int r = emit(cp_fe, on)) return r;
-        return flin ? DFX_OK : ring_step(rings[0], on);
+        if (!flin) return ring_step(rings[0], on);
+        return gated ? hold(fp(S->fe_lin), capf, E1, lin_pos0, H, on) : DFX_OK;
     };
     side_pre = [&](hipStream_t on) -> int {
         if (int r = emit(cp_fs, on)) return r;
-        return flin ? DFX_OK : ring_step(rings[1], on);
+        if (!flin) return ring_step(rings[1], on);
+        return gated ? hold(fp(S->fs_lin), capf, D2, lin_pos0, H, on) : DFX_OK;
     };
     side_post = [&](hipStream_t on) -> int {
         side_done = true;
         if (int r = emit(cp_spec, on)) return r;
         if (int r = spec_ring(on)) return r;
+        if (gated && lin)
+            if (int r = hold(fp(S->spec_lin), S->lin_cap, F2, lin_pos0, Hs, on)) return r;
         return side ? dfx_launch_analysis_mem(st, x, B, n * hop, xs, am_in, am_out, on) : DFX_OK;
     };
     if (!side && ((rc = side_post(s)) || (rc = erb_ring(s)) || (rc = side_pre(s)))) return rc;
@@ -3592,9 +3617,11 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         const unsigned char FZ = DFX_GATE_FROZEN;
         entry(am_out, am_in, ML, FZ, FZ);
         entry(sm_out, sm_in, ML, FZ, FZ);
-        entry(fp(S->hist_fe[S->flip ^ 1]), fp(S->hist_fe[S->flip]), H * E, FZ, FZ);
-        entry(fp(S->hist_fs[S->flip ^ 1]), fp(S->hist_fs[S->flip]), H * Fd * 2, FZ, FZ);
-        entry(fp(S->hist_spec[S->flip ^ 1]), fp(S->hist_spec[S->flip]), Hs * F2, FZ, FZ);
+        if (!flin) {   // (linear windows: dfx_k_gate_hold)
+            entry(fp(S->hist_fe[S->flip ^ 1]), fp(S->hist_fe[S->flip]), H * E, FZ, FZ);
+            entry(fp(S->hist_fs[S->flip ^ 1]), fp(S->hist_fs[S->flip]), H * Fd * 2, FZ, FZ);
+        }
+        if (!lin) entry(fp(S->hist_spec[S->flip ^ 1]), fp(S->hist_spec[S->flip]), Hs * F2, FZ, FZ);
         entry(fp(S->erb_state), gp(S->g_sh_erb), E, FZ, FZ);
         entry(fp(S->unit_state), gp(S->g_sh_unit), Fd, FZ, FZ);
         const int nenc = (int)m->enc_gru.size(), ndec = (int)m->dec_gru.size();
