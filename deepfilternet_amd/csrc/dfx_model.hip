@@ -3744,6 +3744,20 @@ extern "C" int dfx_stream_process_raw(dfx_stream_state *S, const float *spec, fl
     auto gp = [&](size_t o) { return reinterpret_cast<float *>(S->gate_buf + o); };
     unsigned char *gflags = S->gate_buf + S->g_flags;
     int rc;
+    // this path keeps the windows in ring form: if an earlier call on the handle left them in the linear buffers, their last frames
+    // become the ring form's history first (as stream_body does when it changes form)
+    if (S->feat_owns) {
+        const int64_t capf = S->feat_cap, D2 = Fd * 2;
+        if ((rc = stream_copy_rows(fp(S->fe_lin), capf * E, capf * E, S->lin_pos * E, fp(S->hist_fe[S->flip]), H * E, H * E, B, s)) ||
+            (rc = stream_copy_rows(fp(S->fs_lin), capf * D2, capf * D2, S->lin_pos * D2, fp(S->hist_fs[S->flip]), H * D2, H * D2, B, s)))
+            return rc;
+        S->feat_owns = false;
+    }
+    if (S->lin_owns) {
+        const int64_t F2 = S->Fp * 2;
+        if ((rc = stream_copy_rows(fp(S->spec_lin), S->lin_cap * F2, S->lin_cap * F2, S->lin_pos * F2, fp(S->hist_spec[S->flip]), Hs * F2, Hs * F2, B, s))) return rc;
+        S->lin_owns = false;
+    }
     DFX_HIP(hipMemsetAsync(gflags, 0, (size_t)B, s));  // no silent-input test on this path (tract.rs:441: process_raw starts at the features)
     DFX_HIP(hipMemcpyAsync(gp(S->g_sh_erb), fp(S->erb_state), (size_t)B * E * 4, hipMemcpyDeviceToDevice, s));
     DFX_HIP(hipMemcpyAsync(gp(S->g_sh_unit), fp(S->unit_state), (size_t)B * Fd * 4, hipMemcpyDeviceToDevice, s));

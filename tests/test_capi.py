@@ -205,3 +205,38 @@ def test_dfx_file_versions(backend, tmp_path):
     h = C.c_void_p()
     assert L.dfx_model_load_file(os.fsencode(v9), C.byref(h)) != 0
     assert b"version 9" in L.dfx_last_error() and b"re-export" in L.dfx_last_error()
+
+
+def test_process_and_process_raw_share_one_state(backend):
+    """A handle may be driven through the waveform entry (dfx_stream_process) and through the spectral one (dfx_stream_process_raw) in
+    turns: the waveform entry keeps the windows of a gated handle in linear buffers, the spectral one in ring form — whichever form holds
+    the history, the other entry continues from it.  Handle A takes every hop as spectra; handle B takes the first hops as waveform and
+    the rest as spectra: the raw answers of the last hops agree."""
+    from deepfilternet_amd.enhance import init_df
+    from deepfilternet_amd.state_dict import random_state_dict
+    from deepfilternet_amd.streaming import DfStream
+    from oracle import libdf_oracle as L
+
+    if emu_subset(backend):
+        pytest.skip("interpreter subset: runs on the GPU (DFX_EMU_ALL=1 runs it on the interpreter too)")
+    p = named_params("pf32")
+    sd_np = random_state_dict(p, 9)
+    K, K0 = (8, 5) if backend == "emu" else (20, 13)
+    rng = np.random.default_rng(12)
+    x = (0.1 * rng.standard_normal((2, HOP * K))).astype(np.float32)
+    spec = L.DF(p.sr, p.fft_size, p.hop_size, p.nb_erb, p.min_nb_freqs).analysis(x)        # [2, K, F] complex64
+    model, df_state, _, _ = init_df(params=p, state_dict=sd_np, epoch="none")
+    thr = (-1e9, 1e9, 1e9)   # every stage runs on every hop: both entries then advance the same state
+    ra = DfStream(model, df_state, streams=2, gating=True, thresholds=thr)
+    rb = DfStream(model, df_state, streams=2, gating=True, thresholds=thr)
+    outs_a = [ra.process_raw(torch.from_numpy(np.ascontiguousarray(spec[:, k]))) for k in range(K)]
+    for k in range(K0):
+        rb.process(torch.from_numpy(x[:, k * HOP:(k + 1) * HOP]))
+    for k in range(K0, K):
+        lsnr, gains, coefs, stages = rb.process_raw(torch.from_numpy(np.ascontiguousarray(spec[:, k])))
+        la, ga, ca, sa = outs_a[k]
+        assert np.array_equal(stages.numpy(), sa.numpy()) and np.all(stages.numpy() & 2)
+        assert np.abs(lsnr.numpy() - la.numpy()).max() < 1e-3
+        assert np.abs(gains.numpy() - ga.numpy()).max() < 1e-5, k
+        assert np.abs(coefs.numpy() - ca.numpy()).max() < 1e-5, k
+    model.check()
