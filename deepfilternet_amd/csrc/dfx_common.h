@@ -108,7 +108,8 @@ int dfx_launch_synthesis_rows(const dfx_state *st, const float *spec, int64_t sp
                               int64_t out_skip, int64_t out_len, hipStream_t s);
 int dfx_launch_norm_scan(const float *erb_in, float *erb_out, int E, const float *spec_in, int64_t spec_frame_stride,
                          float *spec_out, int Fn, int64_t C, int64_t T, float alpha, float *erb_state,
-                         float *unit_state, hipStream_t s);
+                         float *unit_state, hipStream_t s, int64_t erb_out_cs = 0,   // > 0: floats between the clips of erb_out / spec_out (< 16 frames)
+                         int64_t spec_out_cs = 0);
 // Mask + MF.DF + post filter + atten_lim on frames [t_begin, t_end) of every clip (t_end < 0: T); coef_T: frames per clip of the
 // coefficient / gain arrays (default T); out_T / out_toff: compacted output rows (default T / 0); spec_stride / out_stride: row
 // strides in complex elements (0: F; even strides = 16-byte aligned rows take the row-streaming kernel)

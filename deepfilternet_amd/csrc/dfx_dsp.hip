@@ -404,10 +404,11 @@ int dfx_launch_analysis_mem(const dfx_state *st, const float *x, int64_t B, int6
 
 int dfx_launch_norm_scan(const float *erb_in, float *erb_out, int E, const float *spec_in, int64_t spec_frame_stride,
                          float *spec_out, int Fn, int64_t C, int64_t T, float alpha, float *erb_state,
-                         float *unit_state, hipStream_t s) {
+                         float *unit_state, hipStream_t s, int64_t erb_out_cs, int64_t spec_out_cs) {
     const int nch = (erb_in ? E : 0) + (spec_in ? Fn : 0);
     const int64_t n = C * nch;
     if (n <= 0) return DFX_OK;
+    if ((erb_out_cs > 0 || spec_out_cs > 0) && T >= 16) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_launch_norm_scan: strided outputs are for calls of < 16 frames");
     DfxKScope ks(DFX_K_NORM_SCAN, s);
     // four lanes per (row, channel) when there are frames to share (the frame-by-frame streaming runtime keeps one lane per channel);
     // DFX_NORM_SCAN4=0: always one lane
@@ -419,7 +420,7 @@ int dfx_launch_norm_scan(const float *erb_in, float *erb_out, int E, const float
     } else {
         dfx_launch(dfx_k_norm_scan, dim3((unsigned)dfx_ceil_div(n, 64)), dim3(64), 0, s, erb_in, erb_out, E,
                    reinterpret_cast<const float2 *>(spec_in), spec_frame_stride, reinterpret_cast<float2 *>(spec_out), Fn, C,
-                   T, alpha, erb_state, unit_state);
+                   T, alpha, erb_state, unit_state, erb_out_cs, spec_out_cs / 2);
     }
     DFX_LAUNCH_CHECK();
     return DFX_OK;

@@ -965,9 +965,11 @@ __global__ void dfx_k_erb_inv(const float *gains, int64_t rows, int F, int nb, c
 // (lib.rs:253-259) — true recurrences over time, so one thread owns one (row, channel) and walks T sequentially; the
 // loads do not depend on the recurrence and are issued DFX_SCAN_UNROLL frames ahead.  Channels [0,E) are ERB bands,
 // [E, E+Fn) complex bins.  Either half may be disabled by passing a null input pointer.
+// erb_out_cs / spec_out_cs > 0: elements between the clips of erb_out / spec_out (outputs written straight into a window of a longer buffer:
+// the streaming runtime's linear feature windows); 0: dense [C, T, E] / [C, T, Fn].
 __global__ void dfx_k_norm_scan(const float *erb_in, float *erb_out, int E, const float2 *spec_in,
                                 int64_t spec_frame_stride, float2 *spec_out, int Fn, int64_t C, int64_t T, float alpha,
-                                float *erb_state, float *unit_state) {
+                                float *erb_state, float *unit_state, int64_t erb_out_cs = 0, int64_t spec_out_cs = 0) {
 #pragma clang fp contract(off)  // the Rust reference never fuses x*(1-a) + s*a into an FMA (lib.rs:244-259)
     const int nch = (erb_in ? E : 0) + (spec_in ? Fn : 0);
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -981,7 +983,7 @@ __global__ void dfx_k_norm_scan(const float *erb_in, float *erb_out, int E, cons
         if (erb_state) s = erb_state[c * E + ch];
         else s = -60.f + (E > 1 ? (-90.f - -60.f) / (float)(E - 1) : 0.f) * (float)ch;
         const float *in = erb_in + c * T * E + ch;
-        float *out = erb_out + c * T * E + ch;
+        float *out = erb_out + c * (erb_out_cs > 0 ? erb_out_cs : T * E) + ch;
         // batches of DFX_SCAN_UNROLL frames, double-buffered: batch k+1 is requested before batch k is scanned, so the recurrence
         // never waits for memory (a plain load-batch / scan-batch loop spends most of its time in the load latency)
         int64_t t = 0;
@@ -1018,7 +1020,7 @@ __global__ void dfx_k_norm_scan(const float *erb_in, float *erb_out, int E, cons
         if (unit_state) s = unit_state[c * Fn + ch];
         else s = 0.001f + (Fn > 1 ? (0.0001f - 0.001f) / (float)(Fn - 1) : 0.f) * (float)ch;
         const float2 *in = spec_in + c * T * spec_frame_stride + ch;
-        float2 *out = spec_out + c * T * Fn + ch;
+        float2 *out = spec_out + c * (spec_out_cs > 0 ? spec_out_cs : T * Fn) + ch;
         int64_t t = 0;
         const int64_t nbatch = T / DFX_SCAN_UNROLL;
         float2 v[DFX_SCAN_UNROLL] = {}, nv[DFX_SCAN_UNROLL] = {};

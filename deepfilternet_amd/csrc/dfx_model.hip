@@ -3474,9 +3474,6 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     static const bool side_env = [] { const char *e = getenv("DFX_STREAM_SIDE"); return !(e && e[0] == '0'); }();
     const bool side = side_env && !S->capturing && !S->use_graph;   // (either form of the windows: the ring steps are deferred like the copies)
     if ((rc = dfx_launch_analysis(st, x, B, n * hop, xs, am_in, side ? nullptr : am_out, new_spec, new_fe, s, -1, Fp))) return rc;
-    if ((rc = dfx_launch_norm_scan(new_fe, new_fe, (int)E, new_spec, Fp, new_fs, (int)Fd, B, n, c.norm_alpha, fp(S->erb_state),
-                                   fp(S->unit_state), s)))
-        return rc;
     // ---- windows: [history ; new].  Net position p uses the features of hop p + L, so the hops of this call are the positions
     // a0 - L .. a0 + n - 1 - L; positions < 0 do not exist: their features are zero for the taps of later positions (the causal
     // padding of pad_feat, deepfilternet3.py:357-361) and they are not computed.
@@ -3500,6 +3497,8 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     const bool flin = feat_lin_ok && skip == 0;   // (warm-up hops zero their features: the ring step does that)
     const float *fe_win = work_fe, *fs_win = work_fs;
     int64_t feat_T = 0;
+    float *norm_fe = new_fe, *norm_fs = new_fs;   // where the normalised features of the new hops go
+    int64_t norm_fe_cs = 0, norm_fs_cs = 0;
     if (flin) {
         float *Lfe = fp(S->fe_lin), *Lfs = fp(S->fs_lin);
         if (!S->feat_owns) {   // the ring form's history becomes the windows' first H frames
@@ -3507,13 +3506,23 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
             cp_fs.add(fp(S->hist_fs[S->flip]), H * D2, H * D2, 0, Lfs + S->lin_pos * D2, capf * D2, H * D2);
             S->feat_owns = true;
         }
-        cp_fe.add(new_fe, n * E1, n * E1, 0, Lfe + (S->lin_pos + H) * E1, capf * E1, n * E1);
-        cp_fs.add(new_fs, n * D2, n * D2, 0, Lfs + (S->lin_pos + H) * D2, capf * D2, n * D2);
         fe_win = Lfe + S->lin_pos * E1, fs_win = Lfs + S->lin_pos * D2;
         feat_T = capf;
+        static const bool direct_env = [] { const char *e = getenv("DFX_STREAM_NORM_DIRECT"); return !(e && e[0] == '0'); }();
+        if (n < 16 && direct_env) {   // the norms write the new frames straight into the windows (no append copies)
+            norm_fe = Lfe + (S->lin_pos + H) * E1, norm_fs = Lfs + (S->lin_pos + H) * D2;
+            norm_fe_cs = capf * E1, norm_fs_cs = capf * D2;
+        } else {
+            cp_fe.add(new_fe, n * E1, n * E1, 0, Lfe + (S->lin_pos + H) * E1, capf * E1, n * E1);
+            cp_fs.add(new_fs, n * D2, n * D2, 0, Lfs + (S->lin_pos + H) * D2, capf * D2, n * D2);
+        }
     } else if (S->feat_owns) {
         feat_to_ring();
     }
+    // features of the new hops (state: the running means)
+    if ((rc = dfx_launch_norm_scan(new_fe, norm_fe, (int)E, new_spec, Fp, norm_fs, (int)Fd, B, n, c.norm_alpha, fp(S->erb_state), fp(S->unit_state), s,
+                                   norm_fe_cs, norm_fs_cs)))
+        return rc;
     const int64_t lin_pos0 = S->lin_pos;
     if (lin) S->lin_pos += n;   // (advanced here: this form is never replayed from a graph nor walked hop by hop by the caller)
     bool side_done = false, erb_done = false;
