@@ -191,7 +191,7 @@ def main() -> None:
         dt = float(tt.item())
     assert torch.isfinite(y).all()
     gru_persistent = bool(model.query(model.Q_GRU_PERSISTENT))
-    model.check()  # raises if a workgroup pair of the two-CU GRU kernel ever timed out (results would be invalid)
+    model.check()  # raises if a kernel of the loop reported a fault (fp16-split range, a flag wait that timed out): results would be invalid
 
     # ---- multi-GPU: the same timed loop without the final gather (so that a scaling run can tell compute from the collective)
     no_gather_ms = None

@@ -92,6 +92,7 @@ SIGNATURES = {
     "dfx_model_forward": (_i, [_vp, _vp, _fp, _fp, _fp, _i64, _i64, _f, _fp, _fp, _fp, _fp, _fp, _i64, _vp]),
     "dfx_enhance_workspace_bytes": (_i, [_vp, _vp, _i64, _i64, _i, C.POINTER(_i64)]),
     "dfx_enhance": (_i, [_vp, _vp, _fp, _i64, _i64, _i, _f, _fp, _fp, _i64, _vp]),
+    "dfx_enhance_pcm16": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _f, _vp, _fp, _i64, _vp]),
     "dfx_mf_filter": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _f, _i64, _i64, _i, _i, _fp, _vp]),
     "dfx_pcm16_to_f32": (_i, [_vp, _i64, _fp, _vp]),
     "dfx_f32_to_pcm16": (_i, [_fp, _i64, _vp, _vp]),

@@ -194,8 +194,32 @@ class ModelParams:
             lines.setdefault(section, []).append(f"{opt.lower()} = {v}")
         return "\n".join(f"[{s}]\n" + "\n".join(ls) + "\n" for s, ls in lines.items())
 
+    def to_cfg(self):
+        """This configuration as the C library's ``dfx_model_cfg`` (include/dfx.h), unchecked."""
+        from . import _lib
+
+        skip = {"none": 0, "identity": 1, "groupedlinear": 2}
+        c = _lib.ModelCfg()
+        c.sr, c.fft_size, c.hop_size, c.nb_erb, c.nb_df = self.sr, self.fft_size, self.hop_size, self.nb_erb, self.nb_df
+        c.min_nb_freqs, c.df_order, c.df_lookahead = self.min_nb_freqs, self.df_order, self.df_lookahead
+        c.lsnr_min, c.lsnr_max = int(self.lsnr_min), int(self.lsnr_max)
+        c.conv_lookahead, c.conv_ch = self.conv_lookahead, self.conv_ch
+        c.emb_hidden_dim, c.emb_num_layers = self.emb_hidden_dim, self.emb_num_layers
+        c.df_hidden_dim, c.df_num_layers = self.df_hidden_dim, self.df_num_layers
+        c.df_gru_skip = skip[self.df_gru_skip]
+        c.df_pathway_kernel_size_t = self.df_pathway_kernel_size_t
+        c.lin_groups, c.enc_lin_groups = self.lin_groups, self.enc_lin_groups
+        c.mask_pf, c.pf_beta, c.norm_alpha = int(self.mask_pf), float(self.pf_beta), float(self.norm_alpha())
+        c.emb_gru_skip_enc, c.emb_gru_skip, c.enc_concat = skip[self.emb_gru_skip_enc], skip[self.emb_gru_skip], int(bool(self.enc_concat))
+        return c
+
     def check_supported(self) -> None:
-        """The HIP engine covers the DeepFilterNet3 family; anything else is refused loudly (never a silent fallback)."""
+        """The HIP engine covers the DeepFilterNet3 family; anything else is refused loudly (never a silent fallback).
+
+        Two halves, one source of truth each: what the C library cannot see (options that are not part of ``dfx_model_cfg``: the model
+        type, kernel shapes, training-only switches) is checked here; every shape the kernels are or are not instantiated for (conv_ch,
+        band / bin counts, group tilings, hidden sizes, filter order) is asked of the library itself (``dfx_model_blob_floats`` runs the
+        same ``check_cfg`` as ``dfx_model_create``), so Python and C refuse exactly the same configurations with the same message."""
         def need(cond, msg):
             if not cond:
                 raise NotImplementedError(f"deepfilternet_amd: unsupported configuration: {msg}")
@@ -206,17 +230,18 @@ class ModelParams:
         need(tuple(self.conv_kernel_inp) == (3, 3), "conv_kernel_inp other than (3,3)")
         for opt in ("emb_gru_skip_enc", "emb_gru_skip", "df_gru_skip"):
             need(getattr(self, opt) in ("none", "identity", "groupedlinear"), f"{opt}={getattr(self, opt)!r}")
-        # deepfilternet3.py:138-146: the concatenated embedding is twice as wide as the GRU's output; the reference's own assert /
-        # einsum shapes exclude both skip forms then
-        need(not (self.enc_concat and self.emb_gru_skip_enc != "none"), "enc_concat together with emb_gru_skip_enc (dimensions do not match)")
         need(self.df_n_iter == 1, "df_n_iter != 1")
         need(not self.lsnr_dropout, "lsnr_dropout")
-        need(self.conv_ch % 16 == 0, "conv_ch must be a multiple of 16")
-        need(self.nb_erb % 8 == 0, "nb_erb must be divisible by 8")
-        need(self.nb_df % 2 == 0, "nb_df must be even")
-        need(self.emb_hidden_dim == 256 and self.df_hidden_dim == 256, "GRU hidden size other than 256")
         need(self.conv_lookahead >= self.df_lookahead or self.conv_lookahead == 0, "conv_lookahead < df_lookahead")
         # pad_mode is a DfParams option that deepfilternet3.py never reads (only deepfilternet.py / deepfilternet2.py do): any value is fine
+        import ctypes
+
+        from . import _lib
+
+        cfg, n = self.to_cfg(), ctypes.c_int64()
+        rc = _lib.lib().dfx_model_blob_floats(ctypes.byref(cfg), ctypes.byref(n))
+        if rc != _lib.DFX_OK:
+            raise NotImplementedError(f"deepfilternet_amd: unsupported configuration: {_lib.lib().dfx_last_error().decode()}")
 
 
 def _fix_legacy_sections(parser: ConfigParser) -> None:

@@ -86,18 +86,21 @@ struct DfxKScope {
 
 // ---- internal launchers shared between the DSP API and the model --------------------------------------------------
 // x_len < T: the samples [x_len, T) of every row are implicit zeros (x_stride may then be as small as x_len); -1 = T
+// spec_stride: row stride of spec in complex elements (0: F)
 int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_stride,
                         const float *mem_in, float *mem_out, float *spec, float *erb_db, hipStream_t s, int64_t x_len = -1,
-                        int64_t spec_stride = 0);
+                        int64_t spec_stride = 0, bool x_i16 = false);   // x_i16: x points at int16_t PCM samples (x / 32768 on the way in; no memories)
+// only the analysis memory (the last N - hop samples in front of the next call's first hop) of a call over T samples per row
 int dfx_launch_analysis_mem(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_stride, const float *mem_in, float *mem_out,
-                            hipStream_t s);  // spec_stride: row stride of spec in complex elements (0: F)
+                            hipStream_t s);
 int dfx_features_padded(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_len, int64_t x_stride, int nb_df,
-                        float alpha, float *spec, float *erb_feat, float *spec_feat, void *stream, int64_t spec_stride = 0);
+                        float alpha, float *spec, float *erb_feat, float *spec_feat, void *stream, int64_t spec_stride = 0, bool x_i16 = false);
 // dfx_synthesis storing only stream samples [out_skip, out_skip + out_len) of every row, at out[row * out_stride + n - out_skip]
 int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int64_t Tf, const float *mem_in, float *mem_out,
                          float *out, int64_t out_stride, int64_t out_skip, int64_t out_len, hipStream_t s, int64_t f_begin = 0,
                          int64_t f_end = -1,   // only output frames [f_begin, f_end) (time-chunked finishing)
-                         int64_t spec_stride = 0);  // row stride of spec in complex elements (0: F)
+                         int64_t spec_stride = 0,   // row stride of spec in complex elements (0: F)
+                         bool out_i16 = false);     // out points at int16_t PCM samples ((x * 2^15).to(int16) on the way out; no memories)
 // The finishing pass of enhance() in one kernel (dfx_k_synthesis_rows): Mask + MF.DF [+ post filter + attenuation limit] applied on the way
 // into the ISTFT, whole rows, no STFT memories.  coefs == null: spec IS the enhanced spectrum (no deep filter, the chunk carry alone).
 // dfx_synthesis_rows_ok: the configuration the kernel is written for (N = 960, hop = 480, the in-place plan; order 5 taps in the tap-major
@@ -105,7 +108,7 @@ int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int6
 bool dfx_synthesis_rows_ok(const dfx_state *st, bool with_df, int order, int nb_df, int nbands);
 int dfx_launch_synthesis_rows(const dfx_state *st, const float *spec, int64_t spec_stride, const float *coefs, int nb_df, int order, int lookahead,
                               const float *gains, float pf_beta, float atten_lim, int64_t B, int64_t Tf, float *out, int64_t out_stride,
-                              int64_t out_skip, int64_t out_len, hipStream_t s);
+                              int64_t out_skip, int64_t out_len, hipStream_t s, bool out_i16 = false);
 int dfx_launch_norm_scan(const float *erb_in, float *erb_out, int E, const float *spec_in, int64_t spec_frame_stride,
                          float *spec_out, int Fn, int64_t C, int64_t T, float alpha, float *erb_state,
                          float *unit_state, hipStream_t s, int64_t erb_out_cs = 0,   // > 0: floats between the clips of erb_out / spec_out (< 16 frames)

@@ -348,7 +348,8 @@ static int grid_for(int64_t work_groups, int per_cu = 8) {
 
 int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_stride,
                         const float *mem_in, float *mem_out, float *spec, float *erb_db, hipStream_t s, int64_t x_len,
-                        int64_t spec_stride) {
+                        int64_t spec_stride, bool x_i16) {
+    if (x_i16 && (mem_in || mem_out)) DFX_FAIL(DFX_ERR_INVALID_ARG, "analysis of 16-bit PCM input carries no memories (whole rows only)");
     const int64_t Tf = T / st->hop;
     const int ML = st->N - st->hop;
     if (B > 0 && Tf > 0) {
@@ -376,13 +377,14 @@ int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t 
         const size_t smem = ana_smem_bytes(st);
         const int grid = grid_for(dfx_ceil_div(B * Tf, DFX_DSP_TEAMS), ip ? 9 : 8);   // (three resident workgroups per CU in place: whole rounds)
         DfxKScope ks(DFX_K_ANALYSIS, s);
-        if (ip) {
-            if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_analysis<true>, smem));
-            dfx_launch(dfx_k_analysis<true>, dim3(grid), dim3(DFX_DSP_THREADS), smem, s, A);
-        } else {
-            if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_analysis<false>, smem));
-            dfx_launch(dfx_k_analysis<false>, dim3(grid), dim3(DFX_DSP_THREADS), smem, s, A);
-        }
+        auto go = [&](auto kern) -> int {
+            if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)kern, smem));
+            dfx_launch(kern, dim3(grid), dim3(DFX_DSP_THREADS), smem, s, A);
+            return DFX_OK;
+        };
+        if (int rc = ip ? (x_i16 ? go(dfx_k_analysis<true, true>) : go(dfx_k_analysis<true, false>))
+                        : (x_i16 ? go(dfx_k_analysis<false, true>) : go(dfx_k_analysis<false, false>)))
+            return rc;
         DFX_LAUNCH_CHECK();
     }
     if (mem_out && B > 0) return dfx_launch_analysis_mem(st, x, B, T, x_stride, mem_in, mem_out, s);
@@ -446,7 +448,8 @@ extern "C" int dfx_synthesis(const dfx_state *st, const float *spec, int64_t B, 
 
 int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int64_t Tf, const float *mem_in, float *mem_out,
                          float *out, int64_t out_stride, int64_t out_skip, int64_t out_len, hipStream_t stream, int64_t f_begin,
-                         int64_t f_end, int64_t spec_stride) {
+                         int64_t f_end, int64_t spec_stride, bool out_i16) {
+    if (out_i16 && (mem_in || mem_out)) DFX_FAIL(DFX_ERR_INVALID_ARG, "synthesis to 16-bit PCM carries no memories (whole rows only)");
     DfxSynArgs A;
     A.spec_stride = spec_stride > 0 ? spec_stride : st->N / 2 + 1;
     const int Rr = (st->N + st->hop - 1) / st->hop;
@@ -479,13 +482,14 @@ int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int6
     const int64_t cap = (int64_t)dfx_env_num_cus() * (ip ? 9 : 8);   // (three resident workgroups per CU in place: whole rounds)
     if (nblk > cap) nblk = cap;
     DfxKScope ks(DFX_K_SYNTHESIS, stream);
-    if (ip) {
-        if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_synthesis<true>, smem));
-        dfx_launch(dfx_k_synthesis<true>, dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, stream, A);
-    } else {
-        if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_synthesis<false>, smem));
-        dfx_launch(dfx_k_synthesis<false>, dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, stream, A);
-    }
+    auto go = [&](auto kern) -> int {
+        if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)kern, smem));
+        dfx_launch(kern, dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, stream, A);
+        return DFX_OK;
+    };
+    if (int rc = ip ? (out_i16 ? go(dfx_k_synthesis<true, true>) : go(dfx_k_synthesis<true, false>))
+                    : (out_i16 ? go(dfx_k_synthesis<false, true>) : go(dfx_k_synthesis<false, false>)))
+        return rc;
     DFX_LAUNCH_CHECK();
     return DFX_OK;
 }
@@ -497,7 +501,7 @@ bool dfx_synthesis_rows_ok(const dfx_state *st, bool with_df, int order, int nb_
 }
 int dfx_launch_synthesis_rows(const dfx_state *st, const float *spec, int64_t spec_stride, const float *coefs, int nb_df, int order, int lookahead,
                               const float *gains, float pf_beta, float atten_lim, int64_t B, int64_t Tf, float *out, int64_t out_stride,
-                              int64_t out_skip, int64_t out_len, hipStream_t s) {
+                              int64_t out_skip, int64_t out_len, hipStream_t s, bool out_i16) {
     if (B <= 0 || Tf <= 0) return DFX_OK;
     const bool with_df = coefs != nullptr || gains != nullptr;
     if (!dfx_synthesis_rows_ok(st, with_df, order, coefs ? nb_df : 0, gains ? st->bands->nb : 0))
@@ -533,12 +537,13 @@ int dfx_launch_synthesis_rows(const dfx_state *st, const float *spec, int64_t sp
     const size_t smem = DFX_SYNR_SMEM;
     const bool pf = pf_beta > 0.f || atten_lim > 0.f;
     DfxKScope ks(DFX_K_SYNTHESIS, s);
+    auto go = [&](auto kern) { dfx_launch(kern, dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, s, A); };
     if (!with_df) {
-        dfx_launch((dfx_k_synthesis_rows<0, false>), dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, s, A);
+        out_i16 ? go(dfx_k_synthesis_rows<0, false, true>) : go(dfx_k_synthesis_rows<0, false, false>);
     } else if (pf) {
-        dfx_launch((dfx_k_synthesis_rows<5, true>), dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, s, A);
+        out_i16 ? go(dfx_k_synthesis_rows<5, true, true>) : go(dfx_k_synthesis_rows<5, true, false>);
     } else {
-        dfx_launch((dfx_k_synthesis_rows<5, false>), dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, s, A);
+        out_i16 ? go(dfx_k_synthesis_rows<5, false, true>) : go(dfx_k_synthesis_rows<5, false, false>);
     }
     DFX_LAUNCH_CHECK();
     return DFX_OK;
@@ -596,7 +601,7 @@ extern "C" int dfx_features(const dfx_state *st, const float *x, int64_t B, int6
 
 // dfx_features over rows of T samples of which only the first x_len exist in memory (the rest are zeros): enhance()'s end padding
 int dfx_features_padded(const dfx_state *st, const float *x, int64_t B, int64_t T, int64_t x_len, int64_t x_stride, int nb_df,
-                        float alpha, float *spec, float *erb_feat, float *spec_feat, void *stream, int64_t spec_stride) {
+                        float alpha, float *spec, float *erb_feat, float *spec_feat, void *stream, int64_t spec_stride, bool x_i16) {
     if (spec_stride <= 0) spec_stride = st ? st->N / 2 + 1 : 0;
     if (!st || B < 0 || T < 0 || x_len < 0 || x_len > T || x_stride < x_len || nb_df <= 0 || nb_df > st->N / 2 + 1)
         DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_features: bad arguments");
@@ -605,7 +610,7 @@ int dfx_features_padded(const dfx_state *st, const float *x, int64_t B, int64_t 
     if (B == 0 || Tf == 0) return DFX_OK;
     if (!x || !spec || !erb_feat || !spec_feat) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_features: null buffer");
     // enhance.py:190-197: spec = analysis(x); erb_norm(erb(spec)); unit_norm(spec[..., :nb_df])
-    if (int rc = dfx_launch_analysis(st, x, B, T, x_stride, nullptr, nullptr, spec, erb_feat, dfx_stream(stream), x_len, spec_stride)) return rc;
+    if (int rc = dfx_launch_analysis(st, x, B, T, x_stride, nullptr, nullptr, spec, erb_feat, dfx_stream(stream), x_len, spec_stride, x_i16)) return rc;
     return dfx_launch_norm_scan(erb_feat, erb_feat, st->nb, spec, spec_stride, spec_feat, nb_df, B, Tf, alpha, nullptr,
                                 nullptr, dfx_stream(stream));
 }

@@ -373,8 +373,43 @@ static __device__ __forceinline__ float2 *dfx_fft_team(float2 *a, float2 *b, con
     return x;
 }
 
+// 16-bit PCM at the boundary (dfx_enhance_pcm16; df/io.py:48,79-80): torchaudio.load's normalisation x / 32768 on the way in, save_audio's
+// (audio * (1 << 15)).to(int16) on the way out — truncation toward zero, NaN -> 0, out-of-range values wrap like ATen's
+// float -> int64 -> int16 chain.  The same expressions as dfx_k_pcm16_to_f32 / dfx_k_f32_to_pcm16 (dfx_io.hip): same bits.
+static __device__ __forceinline__ float dfx_pcm16_in(int16_t v) { return (float)v * (1.0f / 32768.0f); }
+static __device__ __forceinline__ int16_t dfx_pcm16_out(float x) {
+    float v = x * 32768.0f;
+    v = v != v ? 0.f : fminf(fmaxf(v, -9.0e18f), 9.0e18f);
+    return (int16_t)(uint16_t)(uint64_t)(int64_t)v;
+}
+// four consecutive output samples n .. n + 3 of a row (those inside [0, out_len)) as f32 or as 16-bit PCM
+template <bool I16>
+static __device__ __forceinline__ void dfx_store_out4(float *out_f32, int64_t row_off, int64_t n, int64_t out_len, const f32x4 v) {
+    if constexpr (I16) {
+        int16_t *o = reinterpret_cast<int16_t *>(out_f32) + row_off + n;
+        if (n >= 0 && n + 3 < out_len && (reinterpret_cast<uintptr_t>(o) & 7) == 0) {
+            const uint32_t lo = (uint32_t)(uint16_t)dfx_pcm16_out(v[0]) | ((uint32_t)(uint16_t)dfx_pcm16_out(v[1]) << 16);
+            const uint32_t hi = (uint32_t)(uint16_t)dfx_pcm16_out(v[2]) | ((uint32_t)(uint16_t)dfx_pcm16_out(v[3]) << 16);
+            *reinterpret_cast<uint2 *>(o) = make_uint2(lo, hi);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e >= 0 && n + e < out_len) o[e] = dfx_pcm16_out(v[e]);
+        }
+    } else {
+        float *o = out_f32 + row_off + n;
+        if (n >= 0 && n + 3 < out_len && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+            *reinterpret_cast<f32x4 *>(o) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e >= 0 && n + e < out_len) o[e] = v[e];
+        }
+    }
+}
+
 struct DfxAnaArgs {
-    const float *x;       // [B, x_stride]
+    const float *x;       // [B, x_stride] (I16 instances: int16_t samples behind the same pointer, strides in samples)
     const float *mem_in;  // [B, N-hop] or null
     float2 *spec;         // [B, Tf, F]
     float *erb_db;        // [B, Tf, nb] or null: 10*log10(band energy + 1e-10)
@@ -398,7 +433,7 @@ struct DfxAnaArgs {
 // Optional fused ERB band energies in dB (lib.rs:206-212 without the norm; transforms.rs:236-253).
 // IP: the 480-point plan, transformed in place (one LDS buffer per frame; a kernel of its own so that the generic plan's run-time loops
 // do not cost it registers: three workgroups = six waves per SIMD have to fit)
-template <bool IP>
+template <bool IP, bool I16 = false>
 __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_analysis(DfxAnaArgs A) {
     DFX_DYN_SMEM(unsigned char, smem);
     const int N = A.plan.N, M = A.plan.M, F = M + 1;
@@ -454,11 +489,12 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_analysis(Df
         const int64_t b = active ? fr / A.Tf : 0, t = active ? fr - b * A.Tf : 0;
         if (active) {
             const float *xb = A.x + b * A.x_stride;
+            const int16_t *xs = reinterpret_cast<const int16_t *>(A.x) + b * A.x_stride;   // (I16)
             const int64_t pos0 = t * A.hop - ML;
             const float *xf = xb + pos0;
             int ll = lane;
             DFX_OPAQUE(ll);   // (addresses recomputed per frame instead of living in registers across the loop: see dfx_fft480_ip)
-            if (pos0 >= 0 && pos0 + N <= A.x_len && (reinterpret_cast<uintptr_t>(xf) & 7) == 0) {
+            if (pos0 >= 0 && pos0 + N <= A.x_len && (I16 ? (reinterpret_cast<uintptr_t>(xs + pos0) & 3) == 0 : (reinterpret_cast<uintptr_t>(xf) & 7) == 0)) {
                 // interior frame (wave-uniform test; all but the first of a clip and the ones reaching into the implicit zero padding):
                 // 8-byte loads, 8 per lane in flight before the first LDS store (M = 480: one pass) — a load -> store loop would
                 // wait out one memory latency per iteration.  (Requesting the NEXT frame before this one's FFT, as the synthesis
@@ -469,7 +505,12 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_analysis(Df
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int k = k0 + u * DFX_DSP_TEAM;
-                        v[u] = xf2[k < M ? k : k0];
+                        if constexpr (I16) {   // two samples per 4-byte load
+                            const uint32_t pv = reinterpret_cast<const uint32_t *>(xs + pos0)[k < M ? k : k0];
+                            v[u] = make_float2(dfx_pcm16_in((int16_t)(pv & 0xffffu)), dfx_pcm16_in((int16_t)(pv >> 16)));
+                        } else {
+                            v[u] = xf2[k < M ? k : k0];
+                        }
                         wv[u] = reinterpret_cast<const float2 *>(win)[k < M ? k : k0];
                     }
 #pragma unroll
@@ -486,7 +527,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_analysis(Df
                         const int i = 2 * k + h;
                         const int64_t pos = pos0 + i;
                         float s = 0.f;
-                        if (pos >= 0) s = pos < A.x_len ? xb[pos] : 0.f;
+                        if (pos >= 0) s = pos < A.x_len ? (I16 ? dfx_pcm16_in(xs[pos]) : xb[pos]) : 0.f;
                         else if (A.mem_in) s = A.mem_in[b * ML + (ML + pos)];
                         v[h] = s * win[i];
                     }
@@ -650,7 +691,7 @@ struct DfxSynArgs {
     const float2 *spec;   // [B, Tf, F]
     const float *mem_in;  // [B, N-hop] or null
     float *mem_out;       // [B, N-hop] or null
-    float *out;           // [B, out_stride]
+    float *out;           // [B, out_stride] (I16 instances: int16_t samples behind the same pointer)
     const float *window;
     const float2 *tw;
     int64_t B, Tf, out_stride;
@@ -666,7 +707,7 @@ struct DfxSynArgs {
 // DFX_DSP_TEAMS = outf + R - 1 frames (the first R-1 are halo frames recomputed instead of carried through memory).
 // Sum order per output sample follows the reference: oldest contribution first, the current frame last.
 // IP: the 480-point plan in place, one LDS buffer per frame (see dfx_k_analysis<IP>).
-template <bool IP>
+template <bool IP, bool I16 = false>
 __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_synthesis(DfxSynArgs A) {
     DFX_DYN_SMEM(unsigned char, smem);
     const int N = A.plan.N, M = A.plan.M;
@@ -874,15 +915,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_synthesis(D
             }
             const f32x4 v = have ? cur + acc : cur;
             if (tf < A.Tf) {
-                const int64_t n = s_glob - A.out_skip;
-                float *o = A.out + b * A.out_stride + n;
-                if (n >= 0 && n + 3 < A.out_len && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
-                    *reinterpret_cast<f32x4 *>(o) = v;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e >= 0 && n + e < A.out_len) o[e] = v[e];
-                }
+                dfx_store_out4<I16>(A.out, b * A.out_stride, s_glob - A.out_skip, A.out_len, v);
             } else {
                 const int64_t mj = s_glob - A.Tf * A.hop;
                 if (mj < ML) {
@@ -923,7 +956,10 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_synthesis(D
         const float v = have ? cur + acc : cur;
         if (tf < A.Tf) {
             const int64_t n = s_glob - A.out_skip;
-            if (n >= 0 && n < A.out_len) A.out[b * A.out_stride + n] = v;
+            if (n >= 0 && n < A.out_len) {
+                if constexpr (I16) reinterpret_cast<int16_t *>(A.out)[b * A.out_stride + n] = dfx_pcm16_out(v);
+                else A.out[b * A.out_stride + n] = v;
+            }
         } else {
             const int64_t mj = s_glob - A.Tf * A.hop;
             if (mj < ML) A.mem_out[b * ML + mj] = v;
@@ -1601,7 +1637,7 @@ struct DfxSynRowsArgs {
     const float2 *coefs;      // O > 0: complex element (b, n, t, f) at b * cs_b + n * cs_n + t * cs_t + f
     const float *gains;       // [B, Tf, nb] or null (O > 0)
     const unsigned char *bin2band;   // [F]
-    float *out;               // [B, out_stride]
+    float *out;               // [B, out_stride] (I16 instances: int16_t samples behind the same pointer)
     const float *window;      // [960]
     const float2 *tw;         // [960]
     int64_t B, Tf, spec_stride, out_stride, out_skip, out_len;
@@ -1612,7 +1648,7 @@ struct DfxSynRowsArgs {
 };
 #define DFX_SYNR_SMEM ((size_t)960 * 12 + (size_t)DFX_DSP_TEAMS * 482 * 8 + (size_t)2 * 480 * 4 + 512)
 
-template <int O, bool PF>
+template <int O, bool PF, bool I16 = false>
 __global__ void __launch_bounds__(DFX_DSP_THREADS, 6) dfx_k_synthesis_rows(DfxSynRowsArgs A) {
     constexpr int M = 480, N = 960, HOP = 480, NTM = DFX_DSP_TEAMS, BUF = M + 2;
     DFX_DYN_SMEM(unsigned char, smem);
@@ -1799,15 +1835,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, 6) dfx_k_synthesis_rows(DfxSy
                 const f32x4 old = j > 0 ? *reinterpret_cast<const f32x4 *>(fr - 2 * BUF + HOP + i) : *reinterpret_cast<const f32x4 *>(cin + i);
                 v = cur + old;
             }
-            const int64_t n = tf * HOP + i - A.out_skip;
-            float *o = A.out + b * A.out_stride + n;
-            if (n >= 0 && n + 3 < A.out_len && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
-                *reinterpret_cast<f32x4 *>(o) = v;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n + e >= 0 && n + e < A.out_len) o[e] = v[e];
-            }
+            dfx_store_out4<I16>(A.out, b * A.out_stride, tf * HOP + i - A.out_skip, A.out_len, v);
         }
     }
     if (threadIdx.x < HQ && t0 + NTM - 1 < A.Tf) {

@@ -97,7 +97,6 @@ struct GlinW {
 struct DfxLane {
     hipStream_t main = nullptr;
     hipStream_t aux[2] = {nullptr, nullptr};
-    hipStream_t aux_lo = nullptr;                                 // lane 0: lowest-priority twin of aux[1]
     hipEvent_t ev[DFX_LANE_EVENTS] = {};
     hipStream_t gs[DFX_MAX_GRU_LAYERS] = {};                      // recurrence stream of GRU layer l
     hipStream_t ps[DFX_MAX_GRU_LAYERS] = {};                      // preparation stream of GRU layer l (linear_in, projection)
@@ -105,17 +104,15 @@ struct DfxLane {
     hipEvent_t gev[DFX_MAX_GRU_LAYERS][DFX_MAX_TCHUNKS] = {};     // layer l has produced time chunk k
     hipEvent_t pev[DFX_MAX_GRU_LAYERS][DFX_MAX_TCHUNKS] = {};     // gi of layer l, chunk k is ready
     hipEvent_t eev[DFX_MAX_TCHUNKS] = {};                         // emb chunk k is ready
-    hipStream_t fs = nullptr;                                     // finishing stream: df_apply (+ synthesis) per time chunk
-    hipEvent_t mev[DFX_MAX_TCHUNKS] = {};                         // mask chunk k is ready
-    hipEvent_t cev[DFX_MAX_TCHUNKS] = {};                         // DF coefficients of chunk k are ready
 };
-// enhance() hands the synthesis to the model forward so that it can run per time chunk behind df_apply
+// enhance() hands the synthesis to the model forward so that it runs behind the deep filter on the stream that carries the last coefficients
 struct DfxFinish {
     const dfx_state *st;
     float *y;
     int64_t out_stride, out_skip, out_len;
     int64_t spec_stride;   // row stride (complex elements) of enhance()'s own spec / spec_e buffers: F rounded up to even, so that
                            // every row is 16-byte aligned (dfx_k_df_apply_rows); dfx_model_forward's caller-owned arrays are dense
+    bool out_i16 = false;  // y points at int16_t PCM samples (dfx_enhance_pcm16)
 };
 // Streaming (dfx_stream_process): a forward pass over a window.  Every feature / activation array holds T = H + n frames per clip
 // (H history frames, then the n new ones); only the new frames are computed (kernels take t_begin, per-frame kernels a DfxRowMap),
@@ -131,6 +128,7 @@ struct DfxStreamCtx {
     void *c0ring = nullptr;    // non-null (one new frame, ungated): df_convp keeps the pending sums of its next kt - 1 outputs here (dfx_k_df_convp_step)
     int c0slot = 0;            //   slot of the new frame = its net position % (kt - 1)
     bool c0rebuild = false;    //   the sums are not current: recompute the older frames' taps from the feature window
+    mutable bool c0ring_used = false;   //   out: dfx_k_df_convp_step ran in this pass (only then are the sums current afterwards)
     std::function<int(hipStream_t)> erb_pre;  // set: the ERB feature window's update, enqueued on the caller's stream BEHIND the event the DF branch
                                               //   starts on (that branch's chain to c1 is the longer one)
     std::function<int(hipStream_t)> df_pre;   // set: state updates that only the DF branch reads — enqueued on that branch's stream before its
@@ -394,7 +392,7 @@ __global__ void dfx_k_dev_spin(long long ticks) {
 #else
 __global__ void dfx_k_dev_spin(long long) {}
 #endif
-enum { EV_START = 0, EV_C0, EV_C1, EV_C0P, EV_EMB, EV_COEFS, EV_FRONT, EV_DONE, EV_XA, EV_MASK, EV_LSNR, EV_FIN };
+enum { EV_START = 0, EV_C0, EV_C1, EV_C0P, EV_EMB, EV_COEFS, EV_FRONT, EV_DONE, EV_XA, EV_MASK, EV_FIN };
 
 struct dfx_model {
     dfx_model_cfg cfg{};
@@ -456,25 +454,13 @@ struct dfx_model {
     bool fuse_c0 = true;
     // frame-resident ERB encoder head / decoder tail (dfx_k_erb_enc, dfx_k_erb_dec10); DFX_FUSE_ERB=0: layer-by-layer kernels
     bool fuse_erb = true;
-    int finish_tail = 0;          // DFX_FINISH_TAIL=j (with chunked finishing): two pieces, the second = the last j time chunks
-    bool finish_chunked = false;  // DFX_FINISH_CHUNKS=1: df_apply + synthesis per time chunk beside the GRU chain (measured slower)
-    bool convp_after_c1 = false;  // DFX_CONVP_EARLY=2: df_convp starts when df_conv1 is done
-    bool convp_late = false;  // DFX_CONVP_EARLY=0 holds df_convp back until the front is enqueued (it then starts beside the GRU phase)
-    bool gru_x2 = false;      // DFX_GRU_X2=1: two-CU GRU recurrence (weights fully on chip, h halves exchanged every step);
-                              // measured slower than the single-CU kernel (6.6 vs 5.2 us/step): the exchange costs ~4 us
     // persistent GRU phase (dfx_k_gru_seq): flag words [ready: 8][emb: 1][pad][done: 8 * DFX_SEQ_GMAX], monotonic over the model's life
     unsigned int *d_sync = nullptr;
     mutable unsigned int seq_base = 0;  // flag value of "nothing of the current forward pass yet"
     unsigned long long *d_trace = nullptr;   // dev aid (DFX_SEQ_TRACE=1): chunk timestamps of the last persistent GRU launch
     mutable int trace_dims[3] = {0, 0, 0};
     bool gru_seq = true;                // DFX_GRU_SEQ=0: one launch per (layer, time chunk) synchronised with events (round-1 form)
-    // The encoder front per time chunk UNDER the persistent GRU launch (DFX_FRONT_OVERLAP=0: the whole front first, then the GRU phase):
-    // the recurrences of chunk k only need the front of chunk k, and the chain (80 of 256 CUs) is what bounds the step.
-    bool front_overlap = false;
-    int front_ahead = 0;                // DFX_FRONT_AHEAD=n > 0: the front stays at most n chunks ahead of the encoder GRU
-    int front_split = 1;                // DFX_FRONT_SPLIT=n: (test hook) the front in n time ranges, one after the other, without overlap
     bool phase_late = true;             // DFX_PHASE_LATE=0: the GRU phase is enqueued right behind the front (no staged enqueue)
-    bool seq_xcd = false, seq_merge = false;   // DFX_SEQ_XCD=1 / DFX_SEQ_MERGE=1 (measured: no gain)
     int proj_rt = 0;                    // DFX_PROJ_RT=1|2|3: one form of the projection kernel for every launch size
     // DFX_FRONT_GRAIN=k[,kp]: k (kp) times as many, shorter workgroups for df_conv0->1 (df_convp).  df_convp owns whole SIMDs (one wave of
     // 512 registers each) and is needed last (by df_out, deep in the GRU phase): as a persistent grid of long workgroups it held every SIMD
@@ -483,11 +469,8 @@ struct dfx_model {
     // dispatcher lets the other queues in: the front ends 1.1 ms earlier, df_convp finishes under the first 2 ms of the GRU phase;
     // 17.7 -> 17.15 ms per step (8 ... 32: the same; df_conv0->1's own grain: no effect).
     int front_grain = 1, front_grain_p = 16;
-    bool split_emb = false;             // DFX_SPLIT_EMB=1: df_fc_emb on the DF branch's stream behind df_conv1, linear_in reads cemb + e3 (measured: 17.55 vs 17.46 ms, no gain)
-    mutable unsigned int seq_xcd_base = 0;  // per-XCD arrival counters of the persistent launches (10 workgroups per XCD and launch)
-    mutable unsigned int seq_started = 0;  // workgroups of all persistent GRU launches so far (the front waits until they are resident)
     // Error words, written by kernels, read by the host (page-locked host memory the device can store to: dfx_env_err_words_alloc):
-    // [0] a bounded spin of the two-CU GRU kernel timed out, [1] fp16-split range, [2] a flag wait of the persistent GRU phase timed out.
+    // [0] unused, [1] fp16-split range, [2] a flag wait of the persistent GRU phase timed out.
     // The host looks at them wherever it waits for the device anyway (pass_begin, dfx_model_check) and at the start of every call
     // (model_poll: plain loads, no synchronisation), so a fault is reported by the NEXT call on the handle at the latest;
     // DFX_CHECK_EVERY_PASS=1 makes every call wait for its own pass and report its own faults.
@@ -496,7 +479,6 @@ struct dfx_model {
     bool check_every_pass = false;
     int spin_limit = DFX_SYNC_SPIN_LIMIT;   // DFX_SYNC_SPIN_LIMIT=n (tests: force the timeouts)
     int hwq_probe = -1;                 // -1 not run, 1: the phase's streams run concurrently, 0: they do not (event-based GRU phase instead)
-    mutable unsigned int epoch = 0;     // tags the h exchange of one forward pass
     const float *p(size_t off) const { return d_w + off; }
 };
 
@@ -793,16 +775,6 @@ static bool dfx_create_lane(dfx_model *m, int l) {
     if (ln.main) return true;
     bool good = hipStreamCreateWithFlags(&ln.main, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 2; ++i) good = good && hipStreamCreateWithFlags(&ln.aux[i], hipStreamNonBlocking) == hipSuccess;
-    if (l == 0) {
-        // DFX_X2_PRIO=low: df_convp (which has slack until df_out needs it) runs on a lowest-priority stream when lane 0 is the only
-        // lane in flight, so that it fills the CUs the critical-path kernels leave idle (-0.3 ms per step).  Opt-in: whenever the
-        // process had more streams than hardware queues (a second lane, one more helper stream, and presumably a communication
-        // library's streams) the low-priority queue was seen to starve and a step took ~1 s instead of 23 ms.
-        int lo = 0, hi = 0;
-        const char *pe = getenv("DFX_X2_PRIO");
-        if (pe && pe[0] == 'l' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
-            good = good && hipStreamCreateWithPriority(&ln.aux_lo, hipStreamNonBlocking, lo) == hipSuccess;
-    }
     for (int i = 0; i < DFX_LANE_EVENTS; ++i) good = good && hipEventCreateWithFlags(&ln.ev[i], hipEventDisableTiming) == hipSuccess;
     if (l == 0) {  // the layer-pipelined GRU phase runs on lane 0 only
         const int nl = 1 + (m->cfg.emb_num_layers - 1) + m->cfg.df_num_layers;
@@ -815,12 +787,7 @@ static bool dfx_create_lane(dfx_model *m, int l) {
             }
         }
         for (int i = 0; i < 2; ++i) good = good && hipStreamCreateWithFlags(&ln.ts[i], hipStreamNonBlocking) == hipSuccess;
-        if (m->finish_chunked) good = good && hipStreamCreateWithFlags(&ln.fs, hipStreamNonBlocking) == hipSuccess;
-        for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) {
-            good = good && hipEventCreateWithFlags(&ln.eev[k], hipEventDisableTiming) == hipSuccess;
-            good = good && hipEventCreateWithFlags(&ln.mev[k], hipEventDisableTiming) == hipSuccess;
-            good = good && hipEventCreateWithFlags(&ln.cev[k], hipEventDisableTiming) == hipSuccess;
-        }
+        for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) good = good && hipEventCreateWithFlags(&ln.eev[k], hipEventDisableTiming) == hipSuccess;
     }
     return good;
 }
@@ -995,22 +962,9 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         m->concurrent = !(e && e[0] == '0');
         const char *x = getenv("DFX_EXACT_FP32");
         m->exact_fp32 = x && x[0] == '1';
-        const char *ce = getenv("DFX_CONVP_EARLY");
-        m->convp_late = ce && ce[0] == '0';
-        m->convp_after_c1 = ce && ce[0] == '2';
         const char *f0 = getenv("DFX_FUSE_C0"), *fe = getenv("DFX_FUSE_ERB");
         m->fuse_c0 = !(f0 && f0[0] == '0') && m->cfg.df_pathway_kernel_size_t <= 5 && 2 * m->cfg.df_order <= 16;
         m->fuse_erb = !(fe && fe[0] == '0');
-        const char *fc = getenv("DFX_FINISH_CHUNKS");
-        m->finish_chunked = fc && fc[0] == '1';
-        const char *ft = getenv("DFX_FINISH_TAIL");
-        if (ft && atoi(ft) > 0) {
-            m->finish_tail = atoi(ft);
-            m->finish_chunked = true;
-        }
-
-        const char *g2 = getenv("DFX_GRU_X2");
-        m->gru_x2 = g2 && g2[0] == '1' && !dfx_env_is_emulator();
         const char *gq = getenv("DFX_GRU_SEQ");
         m->gru_seq = !(gq && gq[0] == '0') && !dfx_env_is_emulator();
         const char *fem = getenv("DFX_FUSE_EMB");
@@ -1024,18 +978,10 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         const char *cep = getenv("DFX_CHECK_EVERY_PASS"), *spl = getenv("DFX_SYNC_SPIN_LIMIT");
         m->check_every_pass = cep && cep[0] == '1';
         if (spl && atoi(spl) > 0) m->spin_limit = atoi(spl);
-        const char *fo = getenv("DFX_FRONT_OVERLAP"), *fa = getenv("DFX_FRONT_AHEAD"), *fsp = getenv("DFX_FRONT_SPLIT");
-        m->front_overlap = fo && fo[0] == '1';
-        m->front_ahead = fa ? atoi(fa) : 0;
-        m->front_split = fsp && atoi(fsp) > 1 ? atoi(fsp) : 1;
-        const char *pl = getenv("DFX_PHASE_LATE"), *sx = getenv("DFX_SEQ_XCD"), *sm = getenv("DFX_SEQ_MERGE"), *prt = getenv("DFX_PROJ_RT");
+        const char *pl = getenv("DFX_PHASE_LATE"), *prt = getenv("DFX_PROJ_RT");
         m->phase_late = !(pl && pl[0] == '0');
-        m->seq_xcd = sx && sx[0] == '1';
-        m->seq_merge = sm && atoi(sm) != 0;
         m->proj_rt = prt ? atoi(prt) : 0;
         const char *fg = getenv("DFX_FRONT_GRAIN");
-        const char *se = getenv("DFX_SPLIT_EMB");
-        m->split_emb = se && se[0] == '1';
         if (fg) {
             m->front_grain = atoi(fg) > 1 ? atoi(fg) : 1;
             m->front_grain_p = m->front_grain;
@@ -1045,7 +991,7 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
             const char *tq = getenv("DFX_SEQ_TRACE");
             if (tq && tq[0] == '1') (void)hipMalloc(reinterpret_cast<void **>(&m->d_trace), (size_t)DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX * DFX_GS_MAX_CHUNKS * 3 * 8);
         }
-        const size_t sync_bytes = (size_t)(16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX + 8) * sizeof(unsigned int);   // ready | emb, started | done | per-XCD arrival counters
+        const size_t sync_bytes = (size_t)(16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX) * sizeof(unsigned int);   // ready 0-7 | emb 8 | probe 13 | done 16-
         if (hipMalloc(reinterpret_cast<void **>(&m->d_sync), sync_bytes) != hipSuccess || hipMemset(m->d_sync, 0, sync_bytes) != hipSuccess ||
             dfx_env_err_words_alloc(&m->h_err, &m->d_err, 256) != hipSuccess) {
             dfx_model_free(m);
@@ -1091,16 +1037,30 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
             } else if (pe && pe[0] == 'f') {
                 m->hwq_probe = 0;
             } else {
-                unsigned int *cnt = m->d_sync + 13;   // (a spare word of the flag block: ready 0-7 | emb 8 | started 12 | probe 13 | done 16-)
-                m->h_err[8] = 0u;
-                for (hipStream_t st : ss) dfx_launch(dfx_k_probe_meet, dim3(1), dim3(64), 0, st, cnt, (unsigned int)ss.size(), 1 << 16, m->d_err + 8);
+                unsigned int *cnt = m->d_sync + 13;   // (a spare word of the flag block: ready 0-7 | emb 8 | probe 13 | done 16-)
+                // warm-up: the kernel's code object is loaded and every stream's queue exists before the bounded handshake starts (a slow first
+                // launch must not look like a shared queue); a failed handshake is tried once more with a longer bound before it counts
+                for (hipStream_t st : ss) dfx_launch(dfx_k_probe_meet, dim3(1), dim3(64), 0, st, cnt, 0u, 1, m->d_err + 9);
                 bool okp = hipGetLastError() == hipSuccess;
                 for (hipStream_t st : ss) okp = hipStreamSynchronize(st) == hipSuccess && okp;
-                m->hwq_probe = okp && ((volatile unsigned int *)m->h_err)[8] == 0u ? 1 : 0;
-                m->h_err[8] = 0u;
+                m->hwq_probe = 0;
+                for (int attempt = 0; attempt < 2 && okp && m->hwq_probe == 0; ++attempt) {
+                    (void)hipMemset(cnt, 0, sizeof(unsigned int));
+                    m->h_err[8] = 0u;
+                    for (hipStream_t st : ss) dfx_launch(dfx_k_probe_meet, dim3(1), dim3(64), 0, st, cnt, (unsigned int)ss.size(), 1 << (16 + 3 * attempt), m->d_err + 8);
+                    okp = hipGetLastError() == hipSuccess;
+                    for (hipStream_t st : ss) okp = hipStreamSynchronize(st) == hipSuccess && okp;
+                    m->hwq_probe = okp && ((volatile unsigned int *)m->h_err)[8] == 0u ? 1 : 0;
+                }
+                m->h_err[8] = 0u, m->h_err[9] = 0u;
                 (void)hipMemset(cnt, 0, sizeof(unsigned int));
             }
-            if (m->hwq_probe == 0) m->gru_seq = false;   // the event-synchronised form (DFX_GRU_SEQ=0) needs no concurrency to be correct
+            if (m->hwq_probe == 0) {   // the event-synchronised form (DFX_GRU_SEQ=0) needs no concurrency to be correct
+                m->gru_seq = false;
+                if (!(getenv("DFX_QUIET") && getenv("DFX_QUIET")[0] == '1'))
+                    fprintf(stderr, "dfx: the streams of the persistent GRU phase do not run concurrently (GPU_MAX_HW_QUEUES >= 16 must be in the environment "
+                                    "before HIP initialises): this model uses the slower event-synchronised GRU phase (dfx_model_query DFX_Q_HWQ_PROBE = 0)\n");
+            }
         }
     }
     *out = m;
@@ -1126,13 +1086,8 @@ extern "C" void dfx_model_free(dfx_model *m) {
         }
         for (int i = 0; i < 2; ++i)
             if (ln.ts[i]) (void)hipStreamDestroy(ln.ts[i]);
-        for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) {
+        for (int k = 0; k < DFX_MAX_TCHUNKS; ++k)
             if (ln.eev[k]) (void)hipEventDestroy(ln.eev[k]);
-            if (ln.mev[k]) (void)hipEventDestroy(ln.mev[k]);
-            if (ln.cev[k]) (void)hipEventDestroy(ln.cev[k]);
-        }
-        if (ln.fs) (void)hipStreamDestroy(ln.fs);
-        if (ln.aux_lo) (void)hipStreamDestroy(ln.aux_lo);
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_pass) (void)hipEventDestroy(m->ev_pass);
@@ -1161,18 +1116,20 @@ extern "C" int dfx_model_set_pipeline(dfx_model *m, int time_chunks, int min_chu
         if (!dfx_create_lane(m, l)) DFX_FAIL(DFX_ERR_HIP, "dfx_model_set_pipeline: could not create the streams of lane %d", l);
     return DFX_OK;
 }
-// Reads (and clears) the error words without waiting for anything: faults of work that has completed.
+// Reads (and clears) the error words without waiting for anything: faults of work that has completed.  Each word is taken with one
+// atomic exchange, so a word the device raises while the host is looking is either seen now or stays set for the next look — never
+// lost.  (A fault of an unthrottled small pass can therefore still surface one call later than the pass that raised it: only
+// dfx_model_check / DFX_CHECK_EVERY_PASS=1 wait for the device first.)
 static int model_poll(const dfx_model *m) {
-    volatile unsigned int *h = m->h_err;
+    unsigned int *h = m->h_err;
     if (!h) return DFX_OK;
-    const unsigned int e0 = h[0], e1 = h[1], e2 = h[2];
-    if (!(e0 | e1 | e2)) return DFX_OK;
-    h[0] = 0u, h[1] = 0u, h[2] = 0u;
+    if (!(((volatile unsigned int *)h)[1] | ((volatile unsigned int *)h)[2])) return DFX_OK;
+    const unsigned int e1 = __atomic_exchange_n(&h[1], 0u, __ATOMIC_ACQ_REL), e2 = __atomic_exchange_n(&h[2], 0u, __ATOMIC_ACQ_REL);
+    if (!(e1 | e2)) return DFX_OK;
     if (e2)
         DFX_FAIL(DFX_ERR_HIP, "dfx: a flag wait of the persistent GRU phase timed out (bounded spin: the streams of the pass did not make progress "
                               "independently — hardware queues shared with other work, or the GPU shared with another process); the results of "
                               "the previous pass on this model are invalid.  DFX_GRU_SEQ=0 selects the event-synchronised form");
-    if (e0) DFX_FAIL(DFX_ERR_HIP, "dfx: a workgroup pair of the two-CU GRU kernel timed out waiting for its partner; the results of the previous pass on this model are invalid");
     DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx: an activation of magnitude >= 6e4 reached an fp16-split matrix kernel (GRU / DF-encoder / separable-conv "
                                   "path); the results of the previous pass on this model are invalid.  DFX_EXACT_FP32=1 selects the exact fp32 kernels");
 }
@@ -1216,7 +1173,6 @@ struct Ws {
     // offsets in floats, each 64-float (256 B) aligned
     size_t e0, e1, e2, e3, c0, c1, emb_in, emb, xa, xb, gi, xa2, xb2, gi2, demb, d3, d2, d1, mask, c0p, xdf, coefs, lsnr, skp_e, skp_d, total;
     size_t pgi[DFX_MAX_GRU_LAYERS], py[DFX_MAX_GRU_LAYERS], ph[DFX_MAX_GRU_LAYERS];  // layer-pipelined GRU phase: gi, y, h state per layer
-    size_t pxb, pxb_floats;   // h exchange buffers of the two-CU GRU kernel: [layer][group][2][2][16][128] granules of 8 bytes
 };
 Ws plan_ws(const dfx_model_cfg &c, bool fuse_c0, int64_t R, int64_t B = 0) {
     Ws w{};
@@ -1258,11 +1214,6 @@ Ws plan_ws(const dfx_model_cfg &c, bool fuse_c0, int64_t R, int64_t B = 0) {
         w.pgi[l] = take(used ? R * 768 : 0);
         w.py[l] = take(used ? R * 256 : 0);
         w.ph[l] = take(used ? (B > 0 ? B : R) * 256 : 0);
-    }
-    {
-        const size_t groups = ((B > 0 ? (size_t)B : (size_t)R) + 15) / 16;
-        w.pxb_floats = (size_t)DFX_MAX_GRU_LAYERS * groups * 2 * 2 * 16 * 128 * 2;  // 8-byte granules as float pairs
-        w.pxb = take(w.pxb_floats);
     }
     w.total = off;
     return w;
@@ -1861,32 +1812,6 @@ static int launch_emb_fan(const dfx_model *m, const float *y, const float *res, 
     return DFX_OK;
 }
 
-#ifndef DFX_HIPEMU
-static int launch_gru_h3x2(const dfx_model *m, const GruW &g, const float *gi, float *y, const float *h_in, float *h_out,
-                           int64_t B, int64_t T, int64_t t0, int64_t t1, unsigned long long *xbuf, hipStream_t s) {
-    DfxG2Args A;
-    A.gi = gi;
-    A.whf = reinterpret_cast<const dfx_h8 *>(m->p(g.whh_h3));
-    A.bhn = m->p(g.bhn);
-    A.h_in = h_in;
-    A.h_out = h_out;
-    A.y = y;
-    A.xbuf = xbuf;
-    A.err = m->d_err;
-    A.B = B;
-    A.T = T;
-    A.t0 = t0;
-    A.t1 = t1;
-    A.groups = (int)dfx_ceil_div(B, 16);
-    A.epoch = m->epoch & 0xFFFu;
-    A.unscale = g.whh_unscale;
-    DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_rec_h3x2, DFX_G2_SMEM));
-    DfxKScope ks(DFX_K_GRU_REC, s);
-    dfx_launch(dfx_k_gru_rec_h3x2, dim3((unsigned)(dfx_ceil_div(A.groups, 8) * 8 * 2)), dim3(256), DFX_G2_SMEM, s, A);
-    DFX_LAUNCH_CHECK();
-    return DFX_OK;
-}
-#endif
 
 static int launch_gru_h3(const dfx_model *m, const GruW &g, const float *gi, float *y, const float *h_in, float *h_out,
                          int64_t B, int64_t T, int64_t t0, int64_t t1, hipStream_t s, int layer = -1) {
@@ -2068,7 +1993,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     //   x1: c0 -+- c1 ------------------------------------------------------+-- DF decoder: GRU stack, skip, (join c0p) df_out -> coefs
     //   x2:     +- df_convp -> c0p
     const bool par = m->concurrent && !(sc && sc->serial);
-    hipStream_t x1 = par ? ln->aux[0] : s, x2 = par ? ((ln->aux_lo && !signal_front) ? ln->aux_lo : ln->aux[1]) : s;
+    hipStream_t x1 = par ? ln->aux[0] : s, x2 = par ? ln->aux[1] : s;
     auto signal = [&](int e, hipStream_t from) -> int {
         if (par) DFX_HIP(hipEventRecord(ln->ev[e], from));
         return DFX_OK;
@@ -2078,7 +2003,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         return DFX_OK;
     };
     if ((rc = signal(EV_START, s)) || (rc = wait(EV_START, x1))) return rc;
-    const bool post_behind_convp = sc && sc->df_post && m->run_df && !m->convp_late;
+    const bool post_behind_convp = sc && sc->df_post && m->run_df;
     if (sc && sc->erb_pre && (rc = sc->erb_pre(s))) return rc;
     if (sc && sc->df_pre && (rc = sc->df_pre(x1))) return rc;
     if (sc && sc->df_post && !post_behind_convp && (rc = sc->df_post(x1))) return rc;
@@ -2107,7 +2032,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     // persistent form (default on the GPU): ONE launch runs the recurrences of all layers for the whole sequence
     // (dfx_k_gru_seq); needs every (layer, group) workgroup resident at once (each owns a CU)
     const int groups = (int)dfx_ceil_div(B, DFX_GH_ROWS);
-    const bool use_seq = pipe && m->gru_seq && !m->gru_x2 && !m->finish_chunked && groups <= DFX_SEQ_GMAX && nl * groups + 8 <= dfx_env_num_cus();
+    const bool use_seq = pipe && m->gru_seq && groups <= DFX_SEQ_GMAX && nl * groups + 8 <= dfx_env_num_cus();
     int sb[DFX_GS_MAX_CHUNKS + 1];   // chunk boundaries of the persistent form
     int Ks = 0;
     if (use_seq) {
@@ -2132,11 +2057,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         sb[0] = 0;
         for (int i = 0; i < Ks; ++i) sb[i + 1] = sb[i] + sizes[i];
     }
-    // The front kernels that take a frame range [t0, t1) (everything but the materialised-c0 and the tiled df_convp forms): the front can
-    // then run range by range — under the persistent GRU launch (overlap), or as a test of the ranges themselves (DFX_FRONT_SPLIT)
     const int kt = c.df_pathway_kernel_size_t;
-    const bool front_ranges = fuse_c0 && fuse_enc && !sc && !c.enc_concat && (!run_df || fuse_h3 || (kt <= 5 && NO <= 16));
-    const bool overlap = use_seq && m->front_overlap && front_ranges && Ks <= DFX_MAX_TCHUNKS;
     // df_conv0 -> df_conv1 of frames [t0, t1) (fuse_c0)
     auto df1_range = [&](int64_t t0, int64_t t1, hipStream_t st) -> int {
         if (fuse_h3) return launch_conv01_h3<C>(m, m->dfc1, feat_spec, c1, B, T, Fd, Fd / 2, 2, st, t0, Lk, t1, featT);
@@ -2183,6 +2104,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 default: return launch_convp2<C, 5>(m, gate->c0_win, nullptr, c0p, B, T, Fd, NO, st, T - 1, 0, Lk);
             }
         } else if (fuse_h3 && sc && sc->c0ring && !gate && t1 - t0 == 1 && t1 == T && kt >= 2) {
+            sc->c0ring_used = true;
             switch (kt) {
                 case 2: return launch_convp_step<C, 2>(m, feat_spec, c0p, B, T, Fd, NO, st, t_zero, Lk, sc->c0ring, sc->c0slot, sc->c0rebuild, featT);
                 case 3: return launch_convp_step<C, 3>(m, feat_spec, c0p, B, T, Fd, NO, st, t_zero, Lk, sc->c0ring, sc->c0slot, sc->c0rebuild, featT);
@@ -2251,19 +2173,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         return launch_pw<C>(DFX_PW_MODE_DW3, m, m->erb3, e2, nullptr, e3, Rk, E / 4, E / 4, 1, st, rm);
     };
     // cemb = relu(df_fc_emb(c1.flatten)); emb_in = e3.flatten + cemb (:179-182), then enc.emb_gru's linear_in (SqueezedGRU_S :149-158).
-    // split_emb (DFX_SPLIT_EMB=1, measured: no gain): nothing but linear_in reads emb_in (no encoder skip connection, no concat) — df_fc_emb
-    // then runs on the DF branch's stream right behind df_conv1, without waiting for the ERB convolutions, and writes cemb; linear_in
-    // takes cemb + e3 as its operand (DfxGgArgs::a2: the same two addends, the same sum).
-    const bool split_emb = m->split_emb && !c.enc_concat && c.emb_gru_skip_enc == DFX_SKIP_NONE && par && !sc;
-    auto cemb_range = [&](int64_t Rk, DfxRowMap rm, hipStream_t st) -> int {
-        return launch_glin(m, m->fc_emb, c1, DFX_ACT_RELU, nullptr, emb_in, Rk, st, rm);
-    };
     // (DFX_FUSE_EMB=0 also restores the two grouped GEMMs of the front)
-    const bool enc_fan = m->fuse_emb && m->fuse_encfan && m->efan_groups > 0 && !c.enc_concat && !split_emb && !m->exact_fp32 && emb == 16 * m->efan_groups;
+    const bool enc_fan = m->fuse_emb && m->fuse_encfan && m->efan_groups > 0 && !c.enc_concat && !m->exact_fp32 && emb == 16 * m->efan_groups;
     auto emb_range = [&](int64_t Rk, DfxRowMap rm, hipStream_t st) -> int {
         int r;
         if (enc_fan) return launch_enc_fan(m, c1, e3, c.emb_gru_skip_enc != DFX_SKIP_NONE ? emb_in : nullptr, xa, Rk, st, rm);
-        if (split_emb) return launch_glin(m, m->enc_in, emb_in, DFX_ACT_RELU, nullptr, xa, Rk, st, rm, e3);
         if (c.enc_concat) {  // emb = cat(e3.flatten, cemb) (deepfilternet3.py:132-134,181): e3 rows into the left half, cemb written into the right half
             if ((r = stream_copy_rows(e3, emb, emb, 0, emb_in, 2 * emb, emb, R, st))) return r;   // (all rows: enc_concat excludes the ranged front)
             if ((r = launch_ggemm(c1, m->fc_emb.G * m->fc_emb.Kg, m->p(m->fc_emb.w), m->fc_emb.G, m->fc_emb.Kg, m->fc_emb.Ng, nullptr, DFX_ACT_RELU,
@@ -2272,18 +2186,10 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         } else if ((r = launch_glin(m, m->fc_emb, c1, DFX_ACT_RELU, e3, emb_in, Rk, st, rm))) return r;
         return launch_glin(m, m->enc_in, emb_in, DFX_ACT_RELU, nullptr, xa, Rk, st, rm);
     };
-    if (!overlap) {
-        // frame ranges of the front: one (everything that is computed), or DFX_FRONT_SPLIT of them one after the other
-        const int nfr = front_ranges && m->front_split > 1 && T - t_begin >= m->front_split ? m->front_split : 1;
-        auto fb = [&](int i) { return t_begin + (T - t_begin) * i / nfr; };
-        auto frm = [&](int i) { return nfr > 1 ? DfxRowMap{T, fb(i + 1) - fb(i), fb(i)} : rmw; };
-        auto fR = [&](int i) { return nfr > 1 ? B * (fb(i + 1) - fb(i)) : Rn; };
+    {   // ---- the front: the frames [t_begin, T) that this pass computes
         if (fuse_c0) {
             if ((rc = signal(EV_C0, x1)) || (rc = wait(EV_C0, x2))) return rc;  // df_convp only needs feat_spec
-            for (int i = 0; i < nfr; ++i) {
-                if ((rc = df1_range(fb(i), fb(i + 1), x1))) return rc;
-                if (split_emb && (rc = cemb_range(fR(i), frm(i), x1))) return rc;
-            }
+            if ((rc = df1_range(t_begin, T, x1))) return rc;
         } else {
             DfxCinArgs A;
             A.feat = feat_spec;
@@ -2302,31 +2208,22 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             DFX_LAUNCH_CHECK();
             if ((rc = signal(EV_C0, x1)) || (rc = wait(EV_C0, x2))) return rc;
             if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->dfc1, c0, nullptr, c1, R, Fd, Fd / 2, 2, x1))) return rc;
-            if (split_emb && (rc = cemb_range(Rn, rmw, x1))) return rc;
         }
         if ((rc = signal(EV_C1, x1))) return rc;
-        auto run_convp = [&]() -> int {
-            for (int i = 0; i < nfr; ++i)
-                if (int r = convp_range(fb(i), fb(i + 1), x2)) return r;
-            if (post_behind_convp)
-                if (int r = sc->df_post(x2)) return r;
-            return signal(EV_C0P, x2);
-        };
-        // the pathway conv only has to finish before df_out: it starts right away on the low-priority stream x2 and fills whatever the
-        // encoder kernels leave idle (DFX_CONVP_EARLY=0: released only after the front has been enqueued)
-        if (m->convp_after_c1 && (rc = wait(EV_C1, x2))) return rc;
-        if (run_df && !m->convp_late && (rc = run_convp())) return rc;
-        for (int i = 0; i < nfr; ++i)
-            if ((rc = erb_range(fb(i), fb(i + 1), fR(i), frm(i), s))) return rc;
+        // the pathway conv only has to finish before df_out: it starts right away on x2 and fills whatever the encoder kernels leave idle
+        // (releasing it later — behind df_conv1, or behind the whole front — measured the same within noise, profiles/r01_gru_phase_ablation.log;
+        // per time chunk inside the GRU phase: slower, profiles/r04_gru_floor_and_convp_phase.log)
+        if (run_df) {
+            if ((rc = convp_range(t_begin, T, x2))) return rc;
+            if (post_behind_convp && (rc = sc->df_post(x2))) return rc;
+            if ((rc = signal(EV_C0P, x2))) return rc;
+        }
+        if ((rc = erb_range(t_begin, T, Rn, rmw, s))) return rc;
         if ((rc = wait(EV_C1, s))) return rc;
-        for (int i = 0; i < nfr; ++i)
-            if ((rc = emb_range(fR(i), frm(i), s))) return rc;
+        if ((rc = emb_range(Rn, rmw, s))) return rc;
         // the chip-filling front of this chunk is enqueued: the next chunk of a pipelined dfx_enhance may start its own front
         // (it then overlaps this chunk's GRU chain, which occupies only a few CUs)
         if (signal_front && (rc = signal(EV_FRONT, s))) return rc;
-        if (run_df && m->convp_late) {
-            if ((rc = signal(EV_LSNR, s)) || (rc = wait(EV_LSNR, x2)) || (rc = run_convp())) return rc;
-        }
     }
     // ---- GRU phase (planned above)
     float *hs_enc = sc ? sc->h_state : nullptr, *hs_dec = sc ? sc->h_state + (int64_t)nenc * B * 256 : nullptr;
@@ -2438,24 +2335,20 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             const unsigned int base = m->seq_base;
             m->seq_base += (unsigned int)K + 1u;
             unsigned int *ready = m->d_sync, *embf = m->d_sync + 8, *done = m->d_sync + 16;
-            // (Finishing — deep filter + ISTFT — per time chunk behind the DF tail was built here too and measured: 21.7 vs 20.2 ms per step; the
-            // chunks' traffic beside the chain costs more than the 1.2 ms it takes off the end, as in the event-based form, DFX_FINISH_CHUNKS.)
+            // (Finishing — deep filter + ISTFT — per time chunk behind the DF tail was built here and in the event-based form and measured:
+            // 21.7 vs 20.2 ms per step; the chunks' traffic beside the chain costs more than the 1.2 ms it takes off the end.)
             static const int dev_skip_seq = [] { const char *e = getenv("DFX_DEV_SKIP"); return e ? atoi(e) : 0; }();   // dev timing ablations (results invalid)
             auto donep = [&](int l) { return done + (size_t)l * DFX_SEQ_GMAX; };
             auto tgt = [&](int k) { return base + (unsigned int)k + 1u; };
             hipStream_t G = ln->gs[1], Eq = ln->ts[0], Dq = ln->ts[1], Pq = ln->ps[0];
-            // overlap: the launch goes out FIRST and the front follows under it, chunk by chunk (EV_START: the features exist); otherwise
-            // the front is complete (EV_XA)
-            const int ev_go = overlap ? EV_START : EV_XA;
-            if (!overlap && (rc = signal(EV_XA, s))) return rc;
+            const int ev_go = EV_XA;   // the front is complete
+            if ((rc = signal(EV_XA, s))) return rc;
             // Staged enqueue (big passes; off with DFX_ENQUEUE_AHEAD=1 or DFX_PHASE_LATE=0): the host enqueues the phase only once the front
             // has run, so that no barrier packets sit at the head of the phase's ~10 queues while the front's kernels run — measured
             // 18.83 -> 18.20 ms per step (the same effect as between passes, dfx_model::ev_pass).  The persistent launch goes out first
             // and the rest follows chunk-major, faster than the chain consumes it.
-            if (m->phase_late && !m->enqueue_ahead && !overlap && R >= DFX_THROTTLE_MIN_FRAMES) DFX_HIP(hipEventSynchronize(ln->ev[EV_XA]));
+            if (m->phase_late && !m->enqueue_ahead && R >= DFX_THROTTLE_MIN_FRAMES) DFX_HIP(hipEventSynchronize(ln->ev[EV_XA]));
             if ((rc = wait(ev_go, G)) || (rc = wait(ev_go, Eq)) || (rc = wait(ev_go, Dq)) || (rc = wait(ev_go, Pq))) return rc;
-            unsigned int *started = m->d_sync + 12;   // workgroups of the persistent launches that have begun to run (monotonic)
-            m->seq_started += (unsigned int)(nl * groups);
             {   // the recurrences
                 DfxGsArgs S;
                 for (int l = 0; l < DFX_GS_MAX_LAYERS; ++l) S.gi[l] = nullptr, S.y[l] = nullptr, S.whf[l] = nullptr, S.bhn[l] = nullptr, S.unscale[l] = 1.f;
@@ -2471,52 +2364,14 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 for (int i = 0; i <= K; ++i) S.tb[i] = sb[i];
                 S.ready = ready, S.done = done, S.done_stride = DFX_SEQ_GMAX, S.base = base, S.err = m->d_err;
                 S.trace = m->d_trace;
-                S.started = started;
-                // XCD placement of the layers (DFX_SEQ_XCD=1; default: every layer on every XCD).  Measured at config 2: 17.96 vs 18.02 ms per
-                // step — the chain's slowdown under load is not an L2-capacity effect
-                S.xcd_cnt = nullptr, S.xcd_base = 0;
                 S.spin_limit = m->spin_limit;
-                if (m->seq_xcd && nl == 5 && groups == 16 && dfx_env_num_xcds() == 8) {
-                    S.xcd_cnt = m->d_sync + 16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX;
-                    S.xcd_base = m->seq_xcd_base;
-                    m->seq_xcd_base += 10u;
-                }
                 m->trace_dims[0] = nl, m->trace_dims[1] = groups, m->trace_dims[2] = K;
                 DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_seq, DFX_GH_SMEM));
                 DfxKScope ks(DFX_K_GRU_REC, G);
                 dfx_launch(dfx_k_gru_seq, dim3((unsigned)(nl * groups)), dim3(DFX_GH_THREADS), DFX_GH_SMEM, G, S);
                 DFX_LAUNCH_CHECK();
             }
-            if (overlap) {
-                // ---- the encoder front, chunk by chunk, under the running recurrences: chunk k of the encoder GRU needs the front of chunk
-                // k and nothing else.  x1: df_conv0 -> df_conv1 (event eev[k]); x2: df_convp (event mev[k], the DF tail's operand), released
-                // once the first chunk's df_conv1 is through; ps[0]: ERB encoder, the embedding GEMMs, the encoder GRU's projection + flag
-                // (not the caller's stream: everything the recurrences wait for stays on streams of this handle, whose hardware queues
-                // are not shared with the persistent launch's).
-                // The front starts when every workgroup of the persistent launch is resident: those need a whole CU's LDS each and
-                // would otherwise queue behind a chip full of short-lived encoder workgroups.
-                if ((rc = launch_wait_ge(m, started, 1, m->seq_started, Pq)) || (rc = launch_wait_ge(m, started, 1, m->seq_started, x1))) return rc;
-                for (int k = 0; k < K; ++k) {
-                    if ((rc = df1_range(tb(k), tb(k + 1), x1))) return rc;
-                    if (split_emb && (rc = cemb_range(Mk(k), rmk(k), x1))) return rc;
-                    DFX_HIP(hipEventRecord(ln->eev[k], x1));
-                }
-                if (run_df) {
-                    DFX_HIP(hipStreamWaitEvent(x2, ln->eev[0], 0));
-                    for (int k = 0; k < K; ++k) {
-                        if ((rc = convp_range(tb(k), tb(k + 1), x2))) return rc;
-                        DFX_HIP(hipEventRecord(ln->mev[k], x2));
-                    }
-                }
-                for (int k = 0; k < K; ++k) {
-                    if (m->front_ahead > 0 && k >= m->front_ahead && (rc = launch_wait_ge(m, donep(0), groups, tgt(k - m->front_ahead), Pq))) return rc;
-                    if ((rc = erb_range(tb(k), tb(k + 1), Mk(k), rmk(k), Pq))) return rc;
-                    DFX_HIP(hipStreamWaitEvent(Pq, ln->eev[k], 0));
-                    if ((rc = emb_range(Mk(k), rmk(k), Pq))) return rc;
-                    if ((rc = proj_chunk(m->enc_gru[0], 0, k, xa, Pq)) || (rc = launch_flag_set(ready + 0, tgt(k), Pq))) return rc;
-                }
-                if (signal_front && (rc = signal(EV_FRONT, Pq))) return rc;
-            } else {
+            {
                 // layer 0 (encoder GRU): its input xa is complete; one projection + flag per chunk
                 // (stays two chunks ahead of the recurrence instead of flooding the chip with all K projections while the decoders'
                 // first chunks are being prepared)
@@ -2532,18 +2387,14 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             //   ts[0]  ERB tail (linear_out + the decoder's convolutions), ts[1] DF tail (skip + df_out), then the finishing kernels
             for (int l = 1; l < nl; ++l)
                 if ((rc = wait(ev_go, ln->ps[l]))) return rc;
-            // Host enqueue order: chunk-major (every stream still sees its own packets in chunk order).  DFX_SEQ_MERGE=1 puts the consumers of
-            // equal pipeline depth on one stream — dec layer j with DF layer j, the ERB tail with the DF tail — 5 streams with 4 flag
-            // waits in flight instead of 8 with 7: every active hardware queue costs the running kernels time (see dfx_model::ev_pass).
-            const bool merge = m->seq_merge;
+            // Host enqueue order: chunk-major (every stream still sees its own packets in chunk order).  (Consumers of equal pipeline depth
+            // on one stream — 5 streams with 4 flag waits in flight instead of 8 with 7 — measured the same: 18.96 vs 18.80 ms.)
             const int lf = 1 + ndec;   // first DF layer
-            auto psx = [&](int l) { return merge ? ln->ps[1 + (l >= lf ? l - lf : l - 1)] : ln->ps[l]; };
-            if (merge) Dq = Eq;
             seq_tail = Dq;
             // ---- ERB decoder layer j, chunk k
             auto prep_dec = [&](int j, int k) -> int {
                 const int l = 1 + j;
-                hipStream_t st = psx(l);
+                hipStream_t st = ln->ps[l];
                 int r;
                 if ((r = launch_wait_ge(m, donep(l - 1), groups, tgt(k), st))) return r;
                 const float *xin = ws + w.py[l - 1];
@@ -2583,7 +2434,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             // ---- DF decoder layer j, chunk k
             auto prep_df = [&](int j, int k) -> int {
                 const int l = lf + j;
-                hipStream_t st = psx(l);
+                hipStream_t st = ln->ps[l];
                 int r;
                 const float *xin = ws + w.py[l - 1];
                 if (j == 0) {
@@ -2598,11 +2449,6 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             auto df_tail = [&](int k) -> int {
                 const int l = ndec + ndf;
                 int r;
-                if (overlap) {
-                    if (c.df_gru_skip == DFX_SKIP_IDENTITY) {   // (one df_out over all frames at the end: needs every chunk of c0p)
-                        if (k == K - 1) DFX_HIP(hipStreamWaitEvent(Dq, ln->mev[K - 1], 0));
-                    } else DFX_HIP(hipStreamWaitEvent(Dq, ln->mev[k], 0));
-                }
                 if ((r = launch_wait_ge(m, donep(l), groups, tgt(k), Dq))) return r;
                 if (dev_skip_seq & 2) return DFX_OK;
                 if (c.df_gru_skip == DFX_SKIP_IDENTITY) {
@@ -2625,7 +2471,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 }
                 return df_out_rows(cfeat, cfeat2, Mk(k), Dq, rmk(k));
             };
-            if (run_df && !overlap && (rc = wait(EV_C0P, Dq))) return rc;
+            if (run_df && (rc = wait(EV_C0P, Dq))) return rc;
             for (int k = 0; k < K; ++k) {
                 for (int j = 0; j < (ndec > ndf ? ndec : ndf); ++j) {
                     if (j < ndec && (rc = prep_dec(j, k))) return rc;
@@ -2652,22 +2498,10 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 DFX_HIP(hipStreamWaitEvent(s, ln->pev[l][0], 0));
             }
         } else {
-        // two-CU recurrence (weights fully on chip) when all workgroup pairs of all concurrent layers fit on the chip
-        const bool use_x2 = m->gru_x2 && 2 * dfx_ceil_div(B, 16) * nl <= dfx_env_num_cus();
         auto gru_chunk = [&](const GruW &g, int l, int k, hipStream_t st) -> int {
             float *hl = ws + w.ph[l];
-#ifndef DFX_HIPEMU
-            if (use_x2) {
-                unsigned long long *xb2 = reinterpret_cast<unsigned long long *>(ws + w.pxb) + (size_t)l * dfx_ceil_div(B, 16) * 2 * 2 * 16 * 128;
-                return launch_gru_h3x2(m, g, ws + w.pgi[l], ws + w.py[l], k == 0 ? nullptr : hl, hl, B, T, tb(k), tb(k + 1), xb2, st);
-            }
-#endif
             return launch_gru_h3(m, g, ws + w.pgi[l], ws + w.py[l], k == 0 ? nullptr : hl, hl, B, T, tb(k), tb(k + 1), st, l);
         };
-        if (use_x2) {  // fresh tags for this pass (a stale granule of an earlier pass can then never match)
-            ++m->epoch;
-            DFX_HIP(hipMemsetAsync(ws + w.pxb, 0, (size_t)nl * dfx_ceil_div(B, 16) * 2 * 2 * 16 * 128 * 8, s));
-        }
         if ((rc = signal(EV_XA, s))) return rc;
         for (int l = 0; l < nl; ++l) {
             if (l > 0 && (rc = wait(EV_XA, ln->gs[l]))) return rc;
@@ -2714,7 +2548,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 const int64_t Rk = Mk(k);
                 const DfxRowMap rm = rmk(k);
                 if ((rc = ewait(ln->gev[ndec][k], st))) return rc;
-                if (dev_skip & 1) { if ((rc = esig(ln->mev[k], st))) return rc; continue; }
+                if (dev_skip & 1) continue;
                 if ((rc = dec_out_skip(ws + w.py[ndec], Rk, st, rm))) return rc;
                 if (fuse_tail) {
                     if ((rc = launch_erb_tail<C>(m, demb, e3, e2, e1, e0, mask, Rk, E, st, rm))) return rc;
@@ -2731,7 +2565,6 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                                Rk, E, fpt, rm);
                 }
                 DFX_LAUNCH_CHECK();
-                if ((rc = esig(ln->mev[k], st))) return rc;
             }
             if ((rc = signal(EV_MASK, st))) return rc;
         }
@@ -2760,7 +2593,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 static const int dev_skip2 = [] { const char *e = getenv("DFX_DEV_SKIP"); return e ? atoi(e) : 0; }();
                 for (int k = 0; k < K; ++k) {
                     if ((rc = ewait(ln->gev[l][k], st))) return rc;
-                    if (dev_skip2 & 2) { if ((rc = esig(ln->cev[k], st))) return rc; continue; }
+                    if (dev_skip2 & 2) continue;
                     const float *cfeat = ws + w.py[l], *cfeat2 = nullptr;
                     if (fan_skp) {
                         cfeat2 = xdf;
@@ -2769,7 +2602,6 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                         cfeat = xdf;
                     }
                     if ((rc = df_out_rows(cfeat, cfeat2, Mk(k), st, rmk(k)))) return rc;
-                    if ((rc = esig(ln->cev[k], st))) return rc;
                 }
             } else {
                 if ((rc = ewait(ln->gev[l][K - 1], st))) return rc;
@@ -2782,8 +2614,6 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 if ((rc = launch_ggemm(xdf, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg, m->df_out.Ng,
                                        nullptr, DFX_ACT_TANH, c0p, coefs, m->df_out.G * m->df_out.Ng, R, st, NO, Fd, T)))
                     return rc;
-                for (int k = 0; k < K; ++k)  // the identity-skip form is not chunked: all coefficients appear at once
-                    if ((rc = esig(ln->cev[k], st))) return rc;
             }
             if ((rc = signal(EV_COEFS, st))) return rc;
         }
@@ -2794,29 +2624,6 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             dfx_launch(dfx_k_lsnr, dim3((unsigned)dfx_ceil_div(R * 64, 256)), dim3(256), 0, s, (const float *)embv, m->p(m->lsnr_w),
                        m->lsnr_b, (float)(c.lsnr_max - c.lsnr_min), (float)c.lsnr_min, lsnr, R, emb);
             DFX_LAUNCH_CHECK();
-        }
-        // ---- finishing, per time chunk on its own stream as soon as the chunk's mask and coefficients exist: Mask + MF.DF + combine +
-        // post filter + atten_lim (:426-454, enhance.py:238-240) and, for enhance(), the ISTFT of the chunk's output frames.  Only the
-        // last chunk's share of these HBM-bound kernels is left after the GRU chain.
-        if (m->finish_chunked && ln->fs) {
-            hipStream_t st = ln->fs;
-            // pieces of `step` chunks; finish_tail > 0: two pieces only, the second being the last finish_tail chunks
-            const int step = m->finish_tail > 0 ? K : 1;
-            for (int k0 = 0; k0 < K;) {
-                int k1 = k0 + step;
-                if (m->finish_tail > 0) k1 = (k0 == 0 && K - m->finish_tail > 0) ? K - m->finish_tail : K;
-                if (k1 > K) k1 = K;
-                if ((rc = ewait(ln->mev[k1 - 1], st)) || (rc = ewait(ln->cev[k1 - 1], st))) return rc;
-                if ((rc = dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, run_df ? Fd : 0, O, c.df_lookahead,
-                                              c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, st, tb(k0), tb(k1), -1, -1, 0, sstride, sstride)))
-                    return rc;
-                if (fin && (rc = dfx_launch_synthesis(fin->st, spec_e, B, T, nullptr, nullptr, fin->y, fin->out_stride, fin->out_skip,
-                                                      fin->out_len, st, tb(k0), tb(k1), sstride)))
-                    return rc;
-                k0 = k1;
-            }
-            if ((rc = signal(EV_FIN, st)) || (rc = wait(EV_FIN, s))) return rc;
-            return DFX_OK;
         }
         }   // !use_seq
         // The finishing kernels run on the DF tail's stream, directly behind its last df_out launch: a kernel that starts behind a
@@ -2868,14 +2675,14 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     // dfx_model_forward / dfx_df_apply and the roofline kernel of bench.py)
     if (fin && m->fuse_dfa && dfx_synthesis_rows_ok(fin->st, true, O, run_df ? Fd : 0, E) && bands == fin->st->bands) {
         if ((rc = dfx_launch_synthesis_rows(fin->st, spec, sstride, run_df ? coefs : nullptr, run_df ? Fd : 0, O, c.df_lookahead, mask,
-                                            c.mask_pf ? c.pf_beta : 0.f, atten_lim, B, T, fin->y, fin->out_stride, fin->out_skip, fin->out_len, fin_s)))
+                                            c.mask_pf ? c.pf_beta : 0.f, atten_lim, B, T, fin->y, fin->out_stride, fin->out_skip, fin->out_len, fin_s, fin->out_i16)))
             return rc;
     } else {
         if ((rc = dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, run_df ? Fd : 0, O, c.df_lookahead,
                                       c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, fin_s, 0, -1, -1, -1, 0, sstride, sstride)))
             return rc;
         if (fin && (rc = dfx_launch_synthesis(fin->st, spec_e, B, T, nullptr, nullptr, fin->y, fin->out_stride, fin->out_skip, fin->out_len,
-                                              fin_s, 0, -1, sstride)))
+                                              fin_s, 0, -1, sstride, fin->out_i16)))
             return rc;
     }
     if (fin_s != s && ((rc = signal(EV_FIN, fin_s)) || (rc = wait(EV_FIN, s)))) return rc;
@@ -3595,7 +3402,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         }
         if (rc) return rc;
         if (stepped) S->hflip ^= 1;   // (like lin_pos: this form is neither replayed from a graph nor walked hop by hop by the caller)
-        S->c0ring_ok = stepped && !gated && S->c0ring_bytes;   // any other pass leaves the sums behind
+        S->c0ring_ok = sc.c0ring_used;   // any pass that did not go through the step kernel (several hops, gated, run_df off) leaves the sums behind
         if (gated && c.df_pathway_kernel_size_t > 1) {  // the DF decoder's delay line moves where that decoder ran
             if (S->g_pend2_ok) {
                 dfx_launch(dfx_k_gate_pend_commit, dim3((unsigned)dfx_ceil_div(B, 256)), dim3(256), 0, s, (const unsigned char *)gflags,
@@ -3900,8 +3707,10 @@ extern "C" int dfx_enhance_workspace_bytes(const dfx_model *m, const dfx_state *
     return DFX_OK;
 }
 
+// pcm16: x and y point at int16_t samples (same strides in samples); the conversions of df/io.py run in the STFT kernel's loads and the
+// ISTFT kernel's stores
 static int enhance_chunk(const dfx_model *m, const dfx_state *st, const float *x, int64_t B, int64_t T, int pad, float lim,
-                         float *y, unsigned char *base, hipStream_t s, const DfxLane *ln, bool signal_front) {
+                         float *y, unsigned char *base, hipStream_t s, const DfxLane *ln, bool signal_front, bool pcm16) {
     const dfx_model_cfg &c = m->cfg;
     const EnhWs w = plan_enh(m, st, B, T, pad);
     const int64_t Tp = pad ? T + st->N : T, Tf = Tp / st->hop;
@@ -3909,7 +3718,7 @@ static int enhance_chunk(const dfx_model *m, const dfx_state *st, const float *x
     float *fe = reinterpret_cast<float *>(base + w.feat_erb), *fs = reinterpret_cast<float *>(base + w.feat_spec);
     // F.pad(audio, (0, n_fft)) (enhance.py:230-233) is implicit: the analysis reads zeros past the T samples of a row
     const int64_t sstride = enh_spec_stride(st);
-    int rc = dfx_features_padded(st, x, B, Tp, T, T, c.nb_df, c.norm_alpha, spec, fe, fs, (void *)s, sstride);
+    int rc = dfx_features_padded(st, x, B, Tp, T, T, c.nb_df, c.norm_alpha, spec, fe, fs, (void *)s, sstride, pcm16);
     if (rc) return rc;
     int64_t mb = 0;
     dfx_model_workspace_bytes(m, B, Tf, &mb);
@@ -3922,12 +3731,13 @@ static int enhance_chunk(const dfx_model *m, const dfx_state *st, const float *x
     fin.out_skip = pad ? st->N - st->hop : 0;
     fin.out_len = pad ? T : Tf * st->hop;
     fin.spec_stride = sstride;
+    fin.out_i16 = pcm16;
     return model_forward_lane(m, st->bands, spec, fe, fs, B, Tf, lim, spec_e, nullptr, nullptr, nullptr, base + w.model, mb, (void *)s, ln,
                               signal_front, &fin);
 }
 
-extern "C" int dfx_enhance(const dfx_model *m, const dfx_state *st, const float *x, int64_t B, int64_t T, int pad,
-                           float atten_lim_db, float *y, void *workspace, int64_t workspace_bytes, void *stream) {
+static int enhance_any(const dfx_model *m, const dfx_state *st, const float *x, int64_t B, int64_t T, int pad,
+                       float atten_lim_db, float *y, void *workspace, int64_t workspace_bytes, void *stream, bool pcm16) {
     if (!m || !st || B < 0 || T < 0) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_enhance: bad arguments");
     const dfx_model_cfg &c = m->cfg;
     if (st->N != c.fft_size || st->hop != c.hop_size || st->nb != c.nb_erb)
@@ -3946,7 +3756,7 @@ extern "C" int dfx_enhance(const dfx_model *m, const dfx_state *st, const float 
     const int64_t Tp = pad ? T + st->N : T, Tf = Tp / st->hop;
     const int64_t out_len = pad ? T : Tf * st->hop;
     if (Tf == 0) {
-        if (out_len > 0) DFX_HIP(hipMemsetAsync(y, 0, (size_t)B * out_len * 4, s));
+        if (out_len > 0) DFX_HIP(hipMemsetAsync(y, 0, (size_t)B * out_len * (pcm16 ? 2 : 4), s));
         return DFX_OK;
     }
     float lim = 0.f;
@@ -3956,7 +3766,7 @@ extern "C" int dfx_enhance(const dfx_model *m, const dfx_state *st, const float 
     }
     if (int rc = pass_begin(m, B * Tf)) return rc;
     if (nc == 1) {
-        if (int rc = enhance_chunk(m, st, x, B, T, pad, lim, y, base, s, &m->lanes[0], false)) return rc;
+        if (int rc = enhance_chunk(m, st, x, B, T, pad, lim, y, base, s, &m->lanes[0], false, pcm16)) return rc;
         return pass_end(m, B * Tf, s);
     }
     // ---- pipelined chunks: fork from the caller's stream, stagger the fronts, join back
@@ -3966,11 +3776,23 @@ extern "C" int dfx_enhance(const dfx_model *m, const dfx_state *st, const float 
         const DfxLane *ln = &m->lanes[i];
         DFX_HIP(hipStreamWaitEvent(ln->main, m->ev_fork, 0));
         if (i > 0) DFX_HIP(hipStreamWaitEvent(ln->main, m->lanes[i - 1].ev[EV_FRONT], 0));
-        if (int rc = enhance_chunk(m, st, x + row * T, sizes[i], T, pad, lim, y + row * out_len, base, ln->main, ln, true)) return rc;
+        // (16-bit samples: the float-typed pointers advance by half as many elements)
+        const float *xi = pcm16 ? reinterpret_cast<const float *>(reinterpret_cast<const int16_t *>(x) + row * T) : x + row * T;
+        float *yi = pcm16 ? reinterpret_cast<float *>(reinterpret_cast<int16_t *>(y) + row * out_len) : y + row * out_len;
+        if (int rc = enhance_chunk(m, st, xi, sizes[i], T, pad, lim, yi, base, ln->main, ln, true, pcm16)) return rc;
         DFX_HIP(hipEventRecord(ln->ev[EV_DONE], ln->main));
         base += (plan_enh(m, st, sizes[i], T, pad).total + 255) & ~(size_t)255;
         row += sizes[i];
     }
     for (int i = 0; i < nc; ++i) DFX_HIP(hipStreamWaitEvent(s, m->lanes[i].ev[EV_DONE], 0));
     return pass_end(m, B * Tf, s);
+}
+extern "C" int dfx_enhance(const dfx_model *m, const dfx_state *st, const float *x, int64_t B, int64_t T, int pad,
+                           float atten_lim_db, float *y, void *workspace, int64_t workspace_bytes, void *stream) {
+    return enhance_any(m, st, x, B, T, pad, atten_lim_db, y, workspace, workspace_bytes, stream, false);
+}
+extern "C" int dfx_enhance_pcm16(const dfx_model *m, const dfx_state *st, const int16_t *x, int64_t B, int64_t T, int pad,
+                                 float atten_lim_db, int16_t *y, void *workspace, int64_t workspace_bytes, void *stream) {
+    return enhance_any(m, st, reinterpret_cast<const float *>(x), B, T, pad, atten_lim_db, reinterpret_cast<float *>(y), workspace, workspace_bytes,
+                       stream, true);
 }

@@ -3253,28 +3253,13 @@ __global__ void __launch_bounds__(DFX_GRU_THREADS, 2) dfx_k_gru_rec(const float 
 #define DFX_GH_D 6       /* ring slots for the streamed pairs */
 #endif
 #define DFX_GH_HROW 264  /* halves per row of the f16 copy of h (256 + 8 pad) */
-#ifndef DFX_GH_SPLIT
-#define DFX_GH_SPLIT 0   /* 1: the sub-tiles are walked in two halves and the gate math of the first half is issued between the matrix ops of the second (measured: +0.2 ms per step, not the default) */
-#endif
-// Consumption order of the fragments: position f -> (k-chunk, gate, sub-tile).  DFX_GH_SPLIT=0: kc-major over all 3*NS tiles.  =1: two
-// halves of the sub-tiles (s < NS/2, then s >= NS/2), each kc-major over its 3*NS/2 tiles — the accumulators of the first half are complete
-// when the second half starts, and their gate math (exp / rcp chains on the VALU, ~1.3 us of a 5.1 us step when it runs after the last
-// matrix op) is issued in slices between the matrix ops of the second half (one wave per SIMD: nothing else would overlap the two pipes).
-#if DFX_GH_SPLIT
-#define DFX_GH_HT (DFX_GH_TILES / 2)
-#define DFX_GH_POS_HALF(f) ((f) / (DFX_GH_NF / 2))
-#define DFX_GH_POS_KC(f) (((f) % (DFX_GH_NF / 2)) / DFX_GH_HT)
-#define DFX_GH_POS_TT(f) (((f) % (DFX_GH_NF / 2)) % DFX_GH_HT)
-#define DFX_GH_POS_GATE(f) (DFX_GH_POS_TT(f) / (DFX_GH_NS / 2))
-#define DFX_GH_POS_S(f) (DFX_GH_POS_HALF(f) * (DFX_GH_NS / 2) + DFX_GH_POS_TT(f) % (DFX_GH_NS / 2))
-#else
-#define DFX_GH_HT DFX_GH_TILES
-#define DFX_GH_POS_HALF(f) 0
+// Consumption order of the fragments: position f -> (k-chunk, gate, sub-tile), kc-major over all 3*NS tiles.  (Walking the sub-tiles in two
+// halves with the first half's gate math issued between the second half's matrix ops — one matrix op : three VALU through
+// sched_group_barrier — was built and measured +0.2 ms per step: one wave per SIMD does not overlap the two pipes that way.)
 #define DFX_GH_POS_KC(f) ((f) / DFX_GH_TILES)
 #define DFX_GH_POS_TT(f) ((f) % DFX_GH_TILES)
 #define DFX_GH_POS_GATE(f) (((f) % DFX_GH_TILES) / DFX_GH_NS)
 #define DFX_GH_POS_S(f) (((f) % DFX_GH_TILES) % DFX_GH_NS)
-#endif
 #define DFX_GH_POS_TILE(f) (DFX_GH_POS_GATE(f) * DFX_GH_NS + DFX_GH_POS_S(f))
 #define DFX_GH_SMEM_W ((size_t)DFX_GH_FL * DFX_GH_NW * 2 * 64 * 16)
 #define DFX_GH_SMEM (DFX_GH_SMEM_W + (size_t)2 * 2 * DFX_GH_ROWS * DFX_GH_HROW * 2)
@@ -3450,8 +3435,7 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
         dfx_h8 bh[2], bl[2];
         bh[0] = *reinterpret_cast<const dfx_h8 *>(hb);
         bl[0] = *reinterpret_cast<const dfx_h8 *>(hb + (size_t)DFX_GH_ROWS * HROW);
-        // ---- gates, new state (lane: clip jl, units UW*w + 16s + 4q + r): one unit per call, so that the first half's can be issued in
-        // slices between the second half's matrix ops
+        // ---- gates, new state (lane: clip jl, units UW*w + 16s + 4q + r)
         auto gate_unit = [&](int s, int r) {
             const float gr = r == 0 ? gv[0][s].x : r == 1 ? gv[0][s].y : r == 2 ? gv[0][s].z : gv[0][s].w;
             const float gz = r == 0 ? gv[1][s].x : r == 1 ? gv[1][s].y : r == 2 ? gv[1][s].z : gv[1][s].w;
@@ -3479,10 +3463,10 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
         // consecutive ones never touch the same accumulator (a dependent 16x16x32 MFMA would wait for its predecessor)
         dfx_static_for<0, NF / 3>([&](auto gc) {
             constexpr int grp = decltype(gc)::value, f0 = 3 * grp;
-            constexpr int kc = DFX_GH_POS_KC(f0), tt0 = DFX_GH_POS_TT(f0), half = DFX_GH_POS_HALF(f0);
-            // next k-chunk of h, half a chunk ahead (the first chunk of the second half: at the end of the first)
-            if constexpr (tt0 == (DFX_GH_HT / 6) * 3 && (kc + 1 < 8 || (DFX_GH_SPLIT && half == 0))) {
-                constexpr int kn = (kc + 1) % 8;
+            constexpr int kc = DFX_GH_POS_KC(f0), tt0 = DFX_GH_POS_TT(f0);
+            // next k-chunk of h, half a chunk ahead
+            if constexpr (tt0 == (DFX_GH_TILES / 6) * 3 && kc + 1 < 8) {
+                constexpr int kn = kc + 1;
                 bh[kn & 1] = *reinterpret_cast<const dfx_h8 *>(hb + 32 * kn);
                 bl[kn & 1] = *reinterpret_cast<const dfx_h8 *>(hb + (size_t)DFX_GH_ROWS * HROW + 32 * kn);
             }
@@ -3501,15 +3485,6 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
                 }
             });
             constexpr int ta = DFX_GH_POS_TILE(f0), tb_ = DFX_GH_POS_TILE(f0 + 1), tc = DFX_GH_POS_TILE(f0 + 2);
-            // One unit of the first half's gate math per group PAIR of the second half (16 groups, 8 units), in the same scheduling region
-            // as the group's nine matrix ops, with the instruction order asked for as 1 matrix op : 3 VALU (sched_group_barrier): the matrix
-            // pipe takes a new op every 16 cycles and the wave would otherwise sit out 12 of them — a block of VALU work *behind* the
-            // nine ops was measured to gain nothing (the pipe then idles during the block).
-            constexpr int NU1 = (NS / 2) * 4;                                   // units of the first half per lane
-            constexpr int G1 = NF / 6;                                          // groups per half
-            constexpr bool has_unit = DFX_GH_SPLIT && half == 1 && ((grp - G1) % (G1 / NU1)) == 0 && (grp - G1) / (G1 / NU1) < NU1;
-            constexpr int uu = has_unit ? (grp - G1) / (G1 / NU1) : 0, su = uu / 4, ru = uu % 4;
-            if constexpr (has_unit) gate_unit(su, ru);
             if (!(DFX_GH_ABLATE & 4)) {
                 acc[ta] = dfx_mfma_16x16x32_f16(wlo[0], bh[kc & 1], acc[ta]);
                 acc[tb_] = dfx_mfma_16x16x32_f16(wlo[1], bh[kc & 1], acc[tb_]);
@@ -3520,21 +3495,10 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
                 acc[ta] = dfx_mfma_16x16x32_f16(whi[0], bh[kc & 1], acc[ta]);
                 acc[tb_] = dfx_mfma_16x16x32_f16(whi[1], bh[kc & 1], acc[tb_]);
                 acc[tc] = dfx_mfma_16x16x32_f16(whi[2], bh[kc & 1], acc[tc]);
-                if constexpr (has_unit) {
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) {
-                        DFX_SCHED_GROUP(0x008, 1);   // one matrix op
-                        DFX_SCHED_GROUP(0x002, 3);   // three VALU instructions of the gate unit
-                    }
-                }
             } else {
                 acc[ta][0] += (float)whi[0][0] + (float)wlo[0][1] + (float)bh[kc & 1][0] + (float)bl[kc & 1][0];
                 acc[tb_][0] += (float)whi[1][0] + (float)wlo[1][1] + (float)bh[kc & 1][0] + (float)bl[kc & 1][0];
                 acc[tc][0] += (float)whi[2][0] + (float)wlo[2][1] + (float)bh[kc & 1][0] + (float)bl[kc & 1][0];
-            }
-            if constexpr (has_unit && ru == 3) {
-                DFX_SCHED_BARRIER();
-                gate_finish(su);
             }
             DFX_SCHED_BARRIER();
             dfx_static_for<0, 3>([&](auto ic) {
@@ -3547,9 +3511,8 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
             });
             DFX_SCHED_BARRIER();
         });
-        // ---- the sub-tiles whose gate math has not been issued yet (all of them with DFX_GH_SPLIT=0, the second half otherwise)
 #pragma unroll
-        for (int s = DFX_GH_SPLIT ? NS / 2 : 0; s < NS; ++s) {
+        for (int s = 0; s < NS; ++s) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) gate_unit(s, r);
             gate_finish(s);
@@ -3604,41 +3567,12 @@ struct DfxGsArgs {
     unsigned int base;
     unsigned int *err;
     unsigned long long *trace;   // dev aid: [layers][groups][K][3] or null
-    unsigned int *started;       // counts the workgroups that have begun to run (the host lets the encoder front wait for all of them)
-    // XCD placement (null: block -> (layer, group) by index, every layer on every XCD).  With 5 layers x 16 groups on 8 XCDs a workgroup
-    // takes its role from the XCD it finds itself on and its arrival order there (xcd_cnt[x], monotonic; 10 workgroups per XCD and
-    // launch): layers 0 / 2 live on XCDs 0-3, layers 1 / 3 on XCDs 4-7 (4 groups per XCD), layer 4 on all (2 per XCD) — an L2 then
-    // holds the streamed W_hh share of 2-3 layers (1.1 MB) instead of all five (2.2 MB of its 4 MB) beside the background kernels' streams
-    unsigned int *xcd_cnt;
-    unsigned int xcd_base;
     int spin_limit;
 };
 __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_seq(DfxGsArgs S) {
-    if (S.started && threadIdx.x == 0) __hip_atomic_fetch_add(S.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // block -> (layer, group): consecutive blocks of a layer are dealt round-robin over the XCDs, so every L2 holds a part of every
-    // layer's streamed weights (16 groups of a layer = 2 per XCD)
-    int l = (int)(blockIdx.x / (unsigned)S.groups), g = (int)(blockIdx.x % (unsigned)S.groups);
-    if (S.xcd_cnt) {   // (host: only with nlayers == 5, groups == 16, an 80-block grid on 8 XCDs)
-        __shared__ int role;
-        if (threadIdx.x == 0) {
-            const int x = dfx_xcc_id() & 7;
-            const int slot = (int)(__hip_atomic_fetch_add(S.xcd_cnt + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - S.xcd_base);
-            int ll, gg;
-            if (slot < 8) {
-                ll = (x < 4 ? 0 : 1) + 2 * (slot >> 2);
-                gg = 4 * (x & 3) + (slot & 3);
-            } else {
-                ll = 4;
-                gg = 2 * x + (slot - 8);
-            }
-            role = (slot >= 0 && slot < 10) ? ll * 16 + gg : -1;
-        }
-        __syncthreads();
-        const int rr = role;
-        __syncthreads();
-        if (rr < 0) return;   // (cannot happen with an even round-robin dispatch; the bounded flag waits of the consumers would report it)
-        l = rr >> 4, g = rr & 15;
-    }
+    // layer's streamed weights (16 groups of a layer = 2 per XCD; confining layers to XCD subsets measured the same: 17.96 vs 18.02 ms)
+    const int l = (int)(blockIdx.x / (unsigned)S.groups), g = (int)(blockIdx.x % (unsigned)S.groups);
     if (l >= S.nlayers) return;
     DfxGhArgs A;
     A.gi = S.gi[l];
@@ -3698,247 +3632,3 @@ __global__ void dfx_k_probe_meet(unsigned int *cnt, unsigned int n, int spin_lim
     }
 }
 
-#ifndef DFX_HIPEMU
-// ---------------------------------------------------------------------------------------------------------------------
-// Two-CU form of the fp16-split GRU recurrence: the 16 clips of a row group are served by a PAIR of workgroups, each owning
-// 128 hidden units (all three gates).  Half of W_hh is 384 KB as f16 hi/lo: it fits on one CU (33 fragment pairs per wave in
-// VGPRs + 15 in LDS), so nothing is streamed from L2 any more and the step no longer depends on what else is thrashing the
-// L2 (measured: the single-CU kernel goes from 5.2 to 8 us/step when projections / convolutions run beside it).
-// EXPERIMENTAL, off by default (DFX_GRU_X2=1): correct (GPU parity tests pass with it), but the per-step exchange costs ~4 us on
-// MI355X — 6.6 us/step alone, 9.8 us with five layers running — so the single-CU kernel wins (profiles/r01_gru_x2.log).
-// Price: the two workgroups exchange their halves of h every step through global memory.  Protocol (MI355X_MICROARCH.md,
-// "handoff-1to1", data-tagged granules): every h value travels as ONE naturally aligned 8-byte {f16 hi | f16 lo << 16, tag}
-// written with a single relaxed agent-scope (sc1) store; the consumer polls the granules themselves with relaxed agent-scope
-// loads until the tag equals (epoch, step), so no fence and no separate flag is needed and a granule can never be torn.
-// Slots are double buffered by step parity (a workgroup can only be one step ahead of its partner).  Placement-independent:
-// the pair mapping (blocks b and b+8) merely makes the two workgroups share an XCD.  Every spin is bounded: on timeout an
-// error word is set and the kernel runs to completion (results are then invalid and the host reports it) — never a hang.
-// All workgroups of a launch must be co-resident, which the host guarantees by grid size (2*ceil(B/16) <= number of CUs).
-// ---------------------------------------------------------------------------------------------------------------------
-#define DFX_G2_FR 33
-#define DFX_G2_FL 15
-#define DFX_G2_NF 48
-#define DFX_G2_SMEM_W ((size_t)DFX_G2_FL * 4 * 2 * 64 * 16)
-#define DFX_G2_SMEM (DFX_G2_SMEM_W + (size_t)2 * 2 * DFX_GH_ROWS * DFX_GH_HROW * 2)
-#define DFX_G2_SPIN_LIMIT (1 << 22)
-
-struct DfxG2Args {
-    const float *gi;      // [B, T, 768]
-    const dfx_h8 *whf;    // same fragment layout as dfx_k_gru_rec_h3
-    const float *bhn;     // [256]
-    const float *h_in;    // [B, 256] or null
-    float *h_out;         // [B, 256] or null
-    float *y;             // [B, T, 256]
-    unsigned long long *xbuf;  // [groups][parity 2][half 2][16 rows][128 units] granules
-    unsigned int *err;    // set to 1 on a spin timeout
-    int64_t B, T, t0, t1;
-    int groups;           // ceil(B / 16)
-    unsigned int epoch;   // distinguishes launches sequences that reuse xbuf (tag = epoch << 20 | step + 1)
-    float unscale;
-};
-
-struct DfxG2Sched {
-    int cls[DFX_G2_NF], idx[DFX_G2_NF];
-};
-static constexpr DfxG2Sched dfx_g2_make_sched() {
-    DfxG2Sched sc{};
-    int nr = 0;
-    for (int n = 0; n < DFX_G2_NF; ++n) {
-        const bool lds = ((n + 1) * DFX_G2_FL / DFX_G2_NF) != (n * DFX_G2_FL / DFX_G2_NF);
-        sc.cls[n] = lds ? 1 : 0;
-        sc.idx[n] = lds ? n * DFX_G2_FL / DFX_G2_NF : nr++;
-    }
-    return sc;
-}
-
-__global__ void __launch_bounds__(256, 1) dfx_k_gru_rec_h3x2(DfxG2Args A) {
-    constexpr int H = 256, HU = 128, NF = DFX_G2_NF, HROW = DFX_GH_HROW, NS = 2, TILES = 6, UW = 32;
-    constexpr DfxG2Sched SC = dfx_g2_make_sched();
-    DFX_DYN_SMEM(unsigned char, smraw);
-    dfx_h8 *wl = reinterpret_cast<dfx_h8 *>(smraw);                           // [FL][wave][hi,lo][lane]
-    uint16_t *h16 = reinterpret_cast<uint16_t *>(smraw + DFX_G2_SMEM_W);      // [buf][hi,lo][16][HROW]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
-    // pair mapping: blocks b and b+8 (same XCD by the observed dispatch rule) serve row group grp
-    const int bid = blockIdx.x, xcd = bid & 7, jj = bid >> 3, half = jj & 1;
-    const int grp = (jj >> 1) * 8 + xcd;
-    if (grp >= A.groups) return;
-    const int64_t b0 = (int64_t)grp * DFX_GH_ROWS;
-    const bool valid = b0 + jl < A.B;
-    const int64_t brow = valid ? b0 + jl : A.B - 1;
-    const int ubase = HU * half + UW * wave;  // first hidden unit of this wave
-    const dfx_h8 *wg = A.whf + lane;
-    // fragment f = kc*6 + gate*2 + s  ->  global pair ((unit tile = ubase/16 + s)*8 + kc)*3 + gate
-#define DFX_G2_GIDX(f) (((((size_t)(ubase >> 4) + ((f) % TILES) % NS) * 8 + (f) / TILES) * 3 + ((f) % TILES) / NS) * 2 * 64)
-    dfx_h8 wr[DFX_G2_FR][2];
-    dfx_static_for<0, NF>([&](auto fc) {
-        constexpr int f = decltype(fc)::value;
-        if constexpr (SC.cls[f] == 0) {
-            wr[SC.idx[f]][0] = wg[DFX_G2_GIDX(f)];
-            wr[SC.idx[f]][1] = wg[DFX_G2_GIDX(f) + 64];
-        } else {
-            wl[((SC.idx[f] * 4 + wave) * 2 + 0) * 64 + lane] = wg[DFX_G2_GIDX(f)];
-            wl[((SC.idx[f] * 4 + wave) * 2 + 1) * 64 + lane] = wg[DFX_G2_GIDX(f) + 64];
-        }
-    });
-    // ---- state: this lane owns clip jl, units ubase + 16*s + 4*q + r
-    float hp[NS][4];
-    float4 bn[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int u0 = ubase + 16 * s + 4 * q;
-        bn[s] = *reinterpret_cast<const float4 *>(A.bhn + u0);
-        float4 h0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (A.h_in) h0 = *reinterpret_cast<const float4 *>(A.h_in + brow * H + u0);
-        hp[s][0] = h0.x, hp[s][1] = h0.y, hp[s][2] = h0.z, hp[s][3] = h0.w;
-    }
-    auto split = [](float v, uint16_t &hh, uint16_t &hl) {
-        hh = dfx_f32_to_f16_bits(v);
-        hl = dfx_f32_to_f16_bits(v - dfx_f16_bits_to_f32(hh));
-    };
-    // initial f16 copy of the FULL h (both halves) of the 16 clips: thread -> (row = tid/16, 16 units from (tid%16)*16)
-    {
-        const int row = tid >> 4, u0 = (tid & 15) * 16;
-        const int64_t br = (b0 + row < A.B) ? b0 + row : A.B - 1;
-#pragma unroll
-        for (int i = 0; i < 16; i += 4) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (A.h_in) v = *reinterpret_cast<const float4 *>(A.h_in + br * H + u0 + i);
-            const float vv[4] = {v.x, v.y, v.z, v.w};
-            uint16_t hh[4], hl[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) split(vv[r], hh[r], hl[r]);
-            *reinterpret_cast<uint2 *>(h16 + ((size_t)0 * DFX_GH_ROWS + row) * HROW + u0 + i) =
-                make_uint2((uint32_t)hh[0] | ((uint32_t)hh[1] << 16), (uint32_t)hh[2] | ((uint32_t)hh[3] << 16));
-            *reinterpret_cast<uint2 *>(h16 + ((size_t)1 * DFX_GH_ROWS + row) * HROW + u0 + i) =
-                make_uint2((uint32_t)hl[0] | ((uint32_t)hl[1] << 16), (uint32_t)hl[2] | ((uint32_t)hl[3] << 16));
-        }
-    }
-    __syncthreads();
-    const float *gp = A.gi + brow * A.T * (3 * H) + ubase + 4 * q;
-    float *yp = A.y + brow * A.T * H + ubase + 4 * q;
-    unsigned long long *xg = A.xbuf + (size_t)grp * 2 * 2 * DFX_GH_ROWS * HU;   // [parity][half][row][unit]
-    int cur = 0;
-    bool dead = false;  // a spin timed out: stop waiting, finish the loop
-    float4 gv[3][NS];
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-            gv[g][s] = (A.t1 > A.t0) ? *reinterpret_cast<const float4 *>(gp + A.t0 * (3 * H) + g * H + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int64_t t = A.t0; t < A.t1; ++t) {
-        const int64_t tn = t + 1 < A.t1 ? t + 1 : t;
-        const uint16_t *hb = h16 + (size_t)(cur * 2) * DFX_GH_ROWS * HROW + (size_t)jl * HROW + 8 * q;
-        f32x4 acc[TILES];
-#pragma unroll
-        for (int i = 0; i < TILES; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dfx_h8 bh[2], bl[2];
-        bh[0] = *reinterpret_cast<const dfx_h8 *>(hb);
-        bl[0] = *reinterpret_cast<const dfx_h8 *>(hb + (size_t)DFX_GH_ROWS * HROW);
-        dfx_static_for<0, NF / 3>([&](auto gc) {
-            constexpr int f0 = 3 * decltype(gc)::value;
-            constexpr int kc = f0 / TILES, tile0 = f0 % TILES;
-            if constexpr (tile0 == 3 && kc + 1 < 8) {
-                bh[(kc + 1) & 1] = *reinterpret_cast<const dfx_h8 *>(hb + 32 * (kc + 1));
-                bl[(kc + 1) & 1] = *reinterpret_cast<const dfx_h8 *>(hb + (size_t)DFX_GH_ROWS * HROW + 32 * (kc + 1));
-            }
-            dfx_h8 whi[3], wlo[3];
-            dfx_static_for<0, 3>([&](auto ic) {
-                constexpr int i = decltype(ic)::value, f = f0 + i;
-                if constexpr (SC.cls[f] == 0) {
-                    whi[i] = wr[SC.idx[f]][0];
-                    wlo[i] = wr[SC.idx[f]][1];
-                } else {
-                    whi[i] = wl[((SC.idx[f] * 4 + wave) * 2 + 0) * 64 + lane];
-                    wlo[i] = wl[((SC.idx[f] * 4 + wave) * 2 + 1) * 64 + lane];
-                }
-            });
-#pragma unroll
-            for (int i = 0; i < 3; ++i) acc[tile0 + i] = dfx_mfma_16x16x32_f16(wlo[i], bh[kc & 1], acc[tile0 + i]);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) acc[tile0 + i] = dfx_mfma_16x16x32_f16(whi[i], bl[kc & 1], acc[tile0 + i]);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) acc[tile0 + i] = dfx_mfma_16x16x32_f16(whi[i], bh[kc & 1], acc[tile0 + i]);
-        });
-        const unsigned int tag = (A.epoch << 20) | (unsigned int)((t + 1) & 0xFFFFF);
-        const int par = (int)(t & 1);
-        // ---- gates, new state; publish this workgroup's half (granules) and keep a copy in its own LDS
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const float gr[4] = {gv[0][s].x, gv[0][s].y, gv[0][s].z, gv[0][s].w};
-            const float gz[4] = {gv[1][s].x, gv[1][s].y, gv[1][s].z, gv[1][s].w};
-            const float gn[4] = {gv[2][s].x, gv[2][s].y, gv[2][s].z, gv[2][s].w};
-            const float bb[4] = {bn[s].x, bn[s].y, bn[s].z, bn[s].w};
-            uint16_t hh[4], hl[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float rg = dfx_fast_rcp(1.f + dfx_fast_exp(-(gr[r] + acc[0 * NS + s][r] * A.unscale)));
-                const float zg = dfx_fast_rcp(1.f + dfx_fast_exp(-(gz[r] + acc[1 * NS + s][r] * A.unscale)));
-                const float pre = gn[r] + rg * (acc[2 * NS + s][r] * A.unscale + bb[r]);
-                const float ng = 2.f * dfx_fast_rcp(1.f + dfx_fast_exp(-2.f * pre)) - 1.f;
-                hp[s][r] = (1.f - zg) * ng + zg * hp[s][r];
-                split(hp[s][r], hh[r], hl[r]);
-            }
-            unsigned long long *px = xg + ((size_t)(par * 2 + half) * DFX_GH_ROWS + jl) * HU + (UW * wave + 16 * s + 4 * q);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                __hip_atomic_store(px + r, ((unsigned long long)tag << 32) | (unsigned long long)((uint32_t)hh[r] | ((uint32_t)hl[r] << 16)),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int g = 0; g < 3; ++g) gv[g][s] = *reinterpret_cast<const float4 *>(gp + tn * (3 * H) + g * H + 16 * s);
-            if (valid) *reinterpret_cast<float4 *>(yp + t * H + 16 * s) = make_float4(hp[s][0], hp[s][1], hp[s][2], hp[s][3]);
-            const int col = ubase + 16 * s + 4 * q;
-            *reinterpret_cast<uint2 *>(h16 + ((size_t)((cur ^ 1) * 2 + 0) * DFX_GH_ROWS + jl) * HROW + col) =
-                make_uint2((uint32_t)hh[0] | ((uint32_t)hh[1] << 16), (uint32_t)hh[2] | ((uint32_t)hh[3] << 16));
-            *reinterpret_cast<uint2 *>(h16 + ((size_t)((cur ^ 1) * 2 + 1) * DFX_GH_ROWS + jl) * HROW + col) =
-                make_uint2((uint32_t)hl[0] | ((uint32_t)hl[1] << 16), (uint32_t)hl[2] | ((uint32_t)hl[3] << 16));
-        }
-        // ---- the partner's half: thread -> 8 consecutive granules (row = tid/16, units 8*(tid%16) ..), poll until tagged
-        {
-            const int row = tid >> 4, u0 = (tid & 15) * 8;
-            const unsigned long long *pp = xg + ((size_t)(par * 2 + (half ^ 1)) * DFX_GH_ROWS + row) * HU + u0;
-            unsigned long long g8[8];
-            int spins = 0;
-            bool ok;
-            do {
-                ok = true;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    g8[i] = __hip_atomic_load(pp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = ok && ((unsigned int)(g8[i] >> 32) == tag);
-                }
-                if (!ok) {
-                    if (dead || ++spins > DFX_G2_SPIN_LIMIT) {
-                        if (!dead) dfx_raise(A.err);
-                        dead = true;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            } while (!ok);
-            uint32_t wh[4], wlw[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t a = (uint32_t)g8[2 * i], b2 = (uint32_t)g8[2 * i + 1];
-                wh[i] = (a & 0xFFFFu) | (b2 << 16);
-                wlw[i] = (a >> 16) | (b2 & 0xFFFF0000u);
-            }
-            const int col = HU * (half ^ 1) + u0;
-            uint32_t *dh = reinterpret_cast<uint32_t *>(h16 + ((size_t)((cur ^ 1) * 2 + 0) * DFX_GH_ROWS + row) * HROW + col);
-            uint32_t *dl = reinterpret_cast<uint32_t *>(h16 + ((size_t)((cur ^ 1) * 2 + 1) * DFX_GH_ROWS + row) * HROW + col);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                dh[i] = wh[i];
-                dl[i] = wlw[i];
-            }
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-    if (A.h_out && valid) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-            *reinterpret_cast<float4 *>(A.h_out + brow * H + ubase + 16 * s + 4 * q) = make_float4(hp[s][0], hp[s][1], hp[s][2], hp[s][3]);
-    }
-}
-#undef DFX_G2_GIDX
-#endif  // !DFX_HIPEMU

@@ -107,17 +107,20 @@ def _norm_alpha(df: DF, tau: float = 1.0) -> float:
     return p.norm_alpha()
 
 
-def _workspace_cap(model: DfNet) -> Optional[int]:
+def _workspace_cap(model: DfNet, need: int) -> Optional[int]:
     """Bytes the enhance() workspace may take: DFX_WORKSPACE_CAP_GB if set, else 90 % of what the device has free plus the workspace this
-    model already holds (None when that cannot be asked, e.g. on the CPU interpreter build)."""
+    model already holds (None when that cannot be asked, e.g. on the CPU interpreter build).  The device is only asked when the answer can
+    matter: a request that fits into the workspace the model already holds needs no allocation at all."""
     env = os.environ.get("DFX_WORKSPACE_CAP_GB")
     if env:
         return int(float(env) * (1 << 30))
     if _lib.device().type != "cuda":
         return None
-    free, _ = torch.cuda.mem_get_info(_lib.device())
     # the workspace this model already holds counts as available: DfNet.workspace() releases it before it allocates a larger one
     held = model._ws.numel() if getattr(model, "_ws", None) is not None else 0
+    if need <= held:
+        return held
+    free, _ = torch.cuda.mem_get_info(_lib.device())
     return int(0.9 * (free + held))
 
 
@@ -126,21 +129,27 @@ def enhance(model: DfNet, df_state: DF, audio: torch.Tensor, pad: bool = True, a
             ) -> torch.Tensor:
     """enhance.py:206-250.  audio [C, T] float32 (host or device) -> enhanced audio, same shape when ``pad``.
 
-    The result lives on the device the input came from (a CPU tensor in -> CPU tensor out, like the reference)."""
+    The result lives on the device the input came from (a CPU tensor in -> CPU tensor out, like the reference).
+
+    Extension: an ``int16`` tensor is taken as 16-bit PCM — the sample format the reference's file loop decodes and encodes around this
+    call (enhance.py:73-89 -> io.py:25-84) — and comes back as ``int16``: torchaudio's ``x / 32768`` and save_audio's
+    ``(audio * (1 << 15)).to(torch.int16)`` run inside the STFT kernel's loads and the ISTFT kernel's stores (``dfx_enhance_pcm16``): the same
+    samples as ``float_to_pcm16(enhance(pcm16_to_float(audio)))``, half the bytes over PCIe and no conversion passes."""
     if not isinstance(model, DfNet):
         raise TypeError("enhance() of deepfilternet_amd needs a deepfilternet_amd.DfNet (see init_df)")
     src_dev = audio.device
+    pcm16 = audio.dtype == torch.int16
     # a page-locked host batch moves by DMA without the driver's staging copies (and comes back into page-locked memory): the
     # transfer is then asynchronous on the launch stream, ~55 GB/s over PCIe Gen5 instead of ~10 for pageable memory
     pinned = src_dev.type == "cpu" and audio.is_pinned() and _lib.device().type == "cuda"
-    x = audio.to(_lib.device(), torch.float32, non_blocking=pinned).contiguous()
+    x = audio.to(_lib.device(), torch.int16 if pcm16 else torch.float32, non_blocking=pinned).contiguous()
     if x.dim() != 2:
         raise ValueError("audio must have shape [C, T]")
     B, T = x.shape
     hop = df_state.hop_size()
     n_fft = df_state.fft_size()
     out_len = T if pad else ((T // hop) * hop)
-    y = torch.empty((B, out_len), dtype=torch.float32, device=x.device)
+    y = torch.empty((B, out_len), dtype=x.dtype, device=x.device)
     if B == 0 or out_len == 0:
         return y.to(src_dev)
     nbytes = C.c_int64()
@@ -154,9 +163,10 @@ def enhance(model: DfNet, df_state: DF, audio: torch.Tensor, pad: bool = True, a
     # The engine's scratch is ~82 MB per 10 s clip: a batch whose workspace does not fit what the device has free is
     # enhanced in sub-batches of whole clips, one after the other in the same workspace (clips are independent: same samples).
     # DFX_WORKSPACE_CAP_GB bounds the workspace explicitly (tests; shared devices).
-    cap = _workspace_cap(model)
+    need = ws_bytes(B)
+    cap = _workspace_cap(model, need)
     sub = B
-    if cap is not None and ws_bytes(B) > cap:
+    if cap is not None and need > cap:
         lo, hi = 1, B                      # largest sub-batch whose workspace fits (the requirement grows with the batch)
         if ws_bytes(1) > cap:
             raise MemoryError(f"enhance(): a single clip of {T} samples needs {ws_bytes(1)} bytes of workspace, {cap} available")
@@ -167,11 +177,11 @@ def enhance(model: DfNet, df_state: DF, audio: torch.Tensor, pad: bool = True, a
             else:
                 hi = mid - 1
         sub = lo if lo < 16 else lo - lo % 16   # whole groups of 16 clips (one GRU workgroup each) when there are that many
-    ws = model.workspace(ws_bytes(sub))
+    ws = model.workspace(need if sub == B else ws_bytes(sub))
     for b0 in range(0, B, sub):
         n = min(sub, B - b0)
-        _lib.check(L.dfx_enhance(model.handle, df_state.handle, _lib.ptr(x[b0:b0 + n]), n, T, int(bool(pad)), lim_db, _lib.ptr(y[b0:b0 + n]),
-                                 _lib.ptr(ws), ws.numel(), _lib.stream()))
+        _lib.check((L.dfx_enhance_pcm16 if pcm16 else L.dfx_enhance)(model.handle, df_state.handle, _lib.ptr(x[b0:b0 + n]), n, T, int(bool(pad)), lim_db,
+                                                                     _lib.ptr(y[b0:b0 + n]), _lib.ptr(ws), ws.numel(), _lib.stream()))
     # No silent garbage: a kernel that found a fault (fp16-split range, flag-wait timeout) raised an error word of the model.  A host
     # result is only handed back after the device has finished, so its own pass is checked; a device result is asynchronous, and the
     # words are looked at without waiting — the C entry points do the same before they start the next pass, so a fault surfaces in the
@@ -191,15 +201,18 @@ def enhance_files(model: DfNet, df_state: DF, input_files, output_dir: Optional[
                   compensate_delay: bool = True, atten_lim_db: Optional[float] = None, method: str = "sinc_fast"):
     """The body of the reference's file loop, ``df.enhance.main`` (enhance.py:73-89), without its argument parser: every file is
     decoded, brought to the model's sampling rate, enhanced, brought back to its own rate and written next to the input (or into
-    ``output_dir``) as ``<name>_<suffix>.wav``.  The audio stays on the device from the int16 -> float conversion to the float ->
-    int16 one (deepfilternet_amd.io); channels of a file are the batch, as in the reference.  Returns the written paths."""
+    ``output_dir``) as ``<name>_<suffix>.wav``.  A file that already has the model's rate moves as 16-bit PCM all the way (the two
+    conversions of df/io.py run inside the STFT / ISTFT kernels: ``enhance()`` on an int16 tensor); one that has to be resampled takes the
+    float path (int16 -> float, resample, enhance, resample, float -> int16, all on the device).  Channels of a file are the batch, as in
+    the reference.  Returns the written paths."""
     from .io import load_audio, resample, save_audio
 
     sr = df_state.sr()
     out = []
     for file in input_files:
-        audio, meta = load_audio(file, sr=sr, verbose=False, method=method)
+        audio, meta = load_audio(file, sr=sr, verbose=False, method=method, pcm16=True)   # int16 when no resampling is needed
         enhanced = enhance(model, df_state, audio, pad=compensate_delay, atten_lim_db=atten_lim_db)
-        enhanced = resample(enhanced, sr, meta.sample_rate, method=method)
+        if enhanced.dtype != torch.int16:
+            enhanced = resample(enhanced, sr, meta.sample_rate, method=method)
         out.append(save_audio(file, enhanced, sr=meta.sample_rate, output_dir=output_dir, suffix=suffix))
     return out

@@ -106,8 +106,11 @@ def float_to_pcm16(audio: torch.Tensor) -> torch.Tensor:
 
 
 def load_audio(file: str, sr: Optional[int] = None, verbose: bool = True, **kwargs) -> Tuple[torch.Tensor, AudioMetaData]:
-    """io.py:25-57: audio [C, T] float32 (on the device), resampled to ``sr`` when given; ``method=`` selects the resampler set."""
+    """io.py:25-57: audio [C, T] float32 (on the device), resampled to ``sr`` when given; ``method=`` selects the resampler set.
+    ``pcm16=True`` (extension): a file that needs no resampling is handed back as its int16 samples (on the device) — ``enhance()`` takes
+    them as they are."""
     method = kwargs.pop("method", "sinc_fast")
+    want_pcm = bool(kwargs.pop("pcm16", False))
     with wave.open(file, "rb") as w:
         if w.getsampwidth() != 2 or w.getcomptype() != "NONE":
             raise RuntimeError(f"{file}: only 16-bit PCM RIFF/WAVE files are decoded here")
@@ -121,6 +124,8 @@ def load_audio(file: str, sr: Optional[int] = None, verbose: bool = True, **kwar
         raw = w.readframes(n - off if frames is None or frames <= 0 else min(frames, n - off))
     info = AudioMetaData(sample_rate=orig_sr, num_frames=n, num_channels=ch)
     pcm = torch.from_numpy(np.frombuffer(raw, dtype="<i2").reshape(-1, ch).T.copy())   # interleaved -> [C, T]
+    if want_pcm and (sr is None or orig_sr == sr):
+        return pcm.to(_lib.device()).contiguous(), info
     audio = pcm16_to_float(pcm)
     if sr is not None and orig_sr != sr:
         if verbose:

@@ -20,24 +20,9 @@ from . import _lib
 from .config import ModelParams
 from .libdf import DF
 
-_SKIP = {"none": 0, "identity": 1, "groupedlinear": 2}
-
-
 def make_cfg(p: ModelParams) -> _lib.ModelCfg:
     p.check_supported()
-    c = _lib.ModelCfg()
-    c.sr, c.fft_size, c.hop_size, c.nb_erb, c.nb_df = p.sr, p.fft_size, p.hop_size, p.nb_erb, p.nb_df
-    c.min_nb_freqs, c.df_order, c.df_lookahead = p.min_nb_freqs, p.df_order, p.df_lookahead
-    c.lsnr_min, c.lsnr_max = int(p.lsnr_min), int(p.lsnr_max)
-    c.conv_lookahead, c.conv_ch = p.conv_lookahead, p.conv_ch
-    c.emb_hidden_dim, c.emb_num_layers = p.emb_hidden_dim, p.emb_num_layers
-    c.df_hidden_dim, c.df_num_layers = p.df_hidden_dim, p.df_num_layers
-    c.df_gru_skip = _SKIP[p.df_gru_skip]
-    c.df_pathway_kernel_size_t = p.df_pathway_kernel_size_t
-    c.lin_groups, c.enc_lin_groups = p.lin_groups, p.enc_lin_groups
-    c.mask_pf, c.pf_beta, c.norm_alpha = int(p.mask_pf), float(p.pf_beta), float(p.norm_alpha())
-    c.emb_gru_skip_enc, c.emb_gru_skip, c.enc_concat = _SKIP[p.emb_gru_skip_enc], _SKIP[p.emb_gru_skip], int(bool(p.enc_concat))
-    return c
+    return p.to_cfg()
 
 
 def tensor_manifest(cfg: _lib.ModelCfg):
@@ -257,7 +242,7 @@ def read_onnx_targz(path: str) -> Tuple[ModelParams, Dict[str, np.ndarray]]:
     _lib.check(L.dfx_onnx_targz_read(os.fsencode(path), C.byref(cfg), None, 0, C.byref(n)))
     blob = np.empty(n.value, dtype=np.float32)
     _lib.check(L.dfx_onnx_targz_read(os.fsencode(path), C.byref(cfg), blob.ctypes.data_as(C.POINTER(C.c_float)), n.value, C.byref(n)))
-    skip = {v: k for k, v in _SKIP.items()}
+    skip = {0: "none", 1: "identity", 2: "groupedlinear"}
     p = ModelParams(sr=cfg.sr, fft_size=cfg.fft_size, hop_size=cfg.hop_size, nb_erb=cfg.nb_erb, nb_df=cfg.nb_df,
                     min_nb_freqs=cfg.min_nb_freqs, df_order=cfg.df_order, df_lookahead=cfg.df_lookahead, lsnr_min=cfg.lsnr_min,
                     lsnr_max=cfg.lsnr_max, conv_lookahead=cfg.conv_lookahead, conv_ch=cfg.conv_ch, emb_hidden_dim=cfg.emb_hidden_dim,

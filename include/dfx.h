@@ -201,12 +201,14 @@ int dfx_model_set_run_df(dfx_model *m, int enable);
  * starved flag wait then ends as a reported DFX_ERR_HIP (see dfx_model_check), never as silent garbage or a hang. */
 int dfx_model_set_pipeline(dfx_model *m, int time_chunks, int min_chunk_frames, int batch_chunks);
 /* Faults a kernel can find while it runs — an activation that left the range of the fp16-split matrix kernels (|x| >= 6e4 at a
- * split: DFX_ERR_UNSUPPORTED; DFX_EXACT_FP32=1 selects the exact fp32 kernels), a flag wait of the persistent GRU phase or a workgroup
- * pair of the two-CU GRU kernel that timed out (bounded spins, the engine never hangs: DFX_ERR_HIP) — are raised in three error words
+ * split: DFX_ERR_UNSUPPORTED; DFX_EXACT_FP32=1 selects the exact fp32 kernels), a flag wait of the persistent GRU phase that timed out
+ * (bounded spins, the engine never hangs: DFX_ERR_HIP) — are raised in error words
  * of the model that the device writes and the host reads.  The results of the pass that raised one are INVALID, and no call hides
  * that: every entry point that starts work on the model (dfx_enhance, dfx_model_forward, dfx_stream_process[_raw]) first looks at
- * the words and returns the error of the PREVIOUS pass instead of starting (the words are cleared by being reported; a big pass
- * waits for its predecessor anyway, see dfx_enhance).  So a fault is reported by the next call at the latest;
+ * the words and returns the error of the PREVIOUS pass instead of starting (each word is cleared, atomically, by being reported; a big pass
+ * waits for its predecessor anyway, see dfx_enhance).  So a fault of a BIG pass (>= 16384 frames) is reported by the next call at the
+ * latest; small passes are not waited for, so a fault of small pass N may only have been raised when call N + 2 looks — a hard
+ * guarantee for the last results of a sequence takes dfx_model_check (or DFX_CHECK_EVERY_PASS=1);
  *   dfx_model_poll   looks now, without waiting (faults of work that has completed);
  *   dfx_model_check  waits for the device, then looks: call it before trusting the LAST results of a sequence of calls;
  *   DFX_CHECK_EVERY_PASS=1 (environment, read at dfx_model_create): every call waits for its own pass and reports its own faults.
@@ -245,6 +247,12 @@ int dfx_model_forward(const dfx_model *m, const dfx_bands *bands, const float *s
 int dfx_enhance_workspace_bytes(const dfx_model *m, const dfx_state *st, int64_t B, int64_t T, int pad, int64_t *bytes);
 int dfx_enhance(const dfx_model *m, const dfx_state *st, const float *x, int64_t B, int64_t T, int pad,
                 float atten_lim_db, float *y, void *workspace, int64_t workspace_bytes, void *stream);
+/* The same pass from and to 16-bit PCM, the sample format the reference's file loop moves (df/enhance.py:73-89 -> df/io.py:25-57 load_audio:
+ * torchaudio's int16 normalisation x / 32768; df/io.py:60-84 save_audio: (audio * (1 << 15)).to(torch.int16), truncation toward zero).  Both
+ * conversions run inside the STFT kernel's loads and the ISTFT kernel's stores: half the bytes at the boundary (and over PCIe), no conversion
+ * launches, and bit-identical samples to dfx_pcm16_to_f32 -> dfx_enhance -> dfx_f32_to_pcm16.  Same workspace, same asynchrony. */
+int dfx_enhance_pcm16(const dfx_model *m, const dfx_state *st, const int16_t *x, int64_t B, int64_t T, int pad,
+                      float atten_lim_db, int16_t *y, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Streaming: the frame loop of the reference's real-time runtime, libDF/src/tract.rs `DfTract::process` (:509-642), exported by

@@ -138,3 +138,40 @@ def test_enhance_files_loop(backend, tmp_path):
     ref = IO.resample(O.enhance(p, torch_sd(p, 5), x48), 48000, sr)[0]
     assert got.shape == ref.shape
     assert np.abs(got - ref).max() <= 1.5 / 32768          # one quantisation step of the 16-bit output
+
+
+@pytest.mark.parametrize("pad", [True, False])
+def test_enhance_pcm16_equals_the_three_kernel_form(backend, tmp_path, pad):
+    """dfx_enhance_pcm16 (16-bit PCM in and out, the conversions of df/io.py:48,79-80 inside the STFT kernel's loads and the ISTFT kernel's
+    stores) gives exactly the samples of pcm16 -> float, enhance(), float -> pcm16; and the file loop takes that path for a file at the
+    model's rate (enhance.py:73-89)."""
+    from deepfilternet_amd import io as dio
+    from deepfilternet_amd.enhance import enhance, enhance_files, init_df
+    from tests.helpers import named_params
+
+    p = named_params("pf32" if backend == "emu" else "df3")
+    model, df_state, suffix, _ = init_df(params=p, epoch="none", seed=4)
+    rng = np.random.default_rng(8)
+    T = 480 * 7 + 123 if backend == "emu" else 48000 + 77      # odd lengths: ragged last frame, unaligned second row
+    pcm = torch.from_numpy((0.3 * rng.standard_normal((3, T)) * 32768).clip(-32768, 32767).astype(np.int16))
+    pcm[0, 5:9] = torch.tensor([32767, -32768, 0, 1], dtype=torch.int16)
+    got = enhance(model, df_state, pcm, pad=pad, atten_lim_db=None)
+    assert got.dtype == torch.int16 and got.device == pcm.device
+    want = dio.float_to_pcm16(enhance(model, df_state, dio.pcm16_to_float(pcm), pad=pad)).cpu()
+    assert got.shape == want.shape and torch.equal(got, want)
+    assert int(got.abs().max()) > 100
+    # a row handed over with a stride (a slice of a wider buffer) and an odd start
+    wide = torch.zeros((3, T + 6), dtype=torch.int16)
+    wide[:, 3:3 + T] = pcm
+    assert torch.equal(enhance(model, df_state, wide[:, 3:3 + T], pad=pad), want)
+    if pad:
+        path = str(tmp_path / "at_rate.wav")
+        with wave.open(path, "wb") as w:
+            w.setnchannels(3), w.setsampwidth(2), w.setframerate(p.sr)
+            w.writeframes(np.ascontiguousarray(pcm.numpy().T.astype("<i2")).tobytes())
+        audio, _ = dio.load_audio(path, sr=p.sr, pcm16=True)
+        assert audio.dtype == torch.int16
+        (out,) = enhance_files(model, df_state, [path], output_dir=str(tmp_path), suffix=suffix)
+        with wave.open(out, "rb") as w:
+            back = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").reshape(-1, 3).T
+        assert np.array_equal(back, want.numpy())

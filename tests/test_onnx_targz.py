@@ -183,6 +183,35 @@ def test_bad_archives_are_refused_with_the_reason(backend, tmp_path):
     assert abs(read_onnx_targz(str(f))[0].norm_alpha() - 0.985) < 1e-7
 
 
+def test_simplified_archive_reads_the_same(backend, tmp_path):
+    """An archive whose three graphs went through a simplifier (export.py --simplify: onnxsim) reads like the plain export: the reader
+    matches the weight-bearing nodes by structure, not by name.  onnxsim is not installed here; tests/onnx_rewrite.py does to the fixture's
+    graphs what its passes leave visible to a weight reader — every value and initializer renamed, node names dropped, Constant nodes turned
+    into initializers, Identity nodes and the Pad nodes in front of convolutions folded away, initializers re-ordered."""
+    from deepfilternet_amd.model import read_onnx_targz
+
+    from tests import onnx_rewrite
+
+    if backend != "emu":
+        pytest.skip("host-side reader: one backend is enough")
+    edit, changed = {}, 0
+    with tarfile.open(TARGZ, "r:gz") as t:
+        for m in t.getmembers():
+            if m.name.endswith(".onnx"):
+                data = t.extractfile(m).read()
+                edit[os.path.basename(m.name)] = onnx_rewrite.simplify(data)
+                changed += edit[os.path.basename(m.name)] != data
+    assert changed == 3
+    f = tmp_path / "simplified.tar.gz"
+    f.write_bytes(_repack(edit))
+    p0, sd0 = read_onnx_targz(TARGZ)
+    p1, sd1 = read_onnx_targz(str(f))
+    assert p0.to_ini() == p1.to_ini()
+    assert sd0.keys() == sd1.keys()
+    for k in sd0:
+        assert np.array_equal(np.asarray(sd0[k]), np.asarray(sd1[k])), k
+
+
 @pytest.mark.needs_reference
 @pytest.mark.parametrize("case", ["df3_opset14", "skip_id_gl", "skip_gl_id", "concat", "defaults_order3"])
 def test_exports_of_other_configurations(backend, case, tmp_path):
