@@ -58,6 +58,30 @@ def synth_audio(B: int, T: int, seed: int, device) -> torch.Tensor:
     return x.clamp_(-1, 1).contiguous()
 
 
+def macs_per_frame(p) -> dict:
+    """Multiply-accumulates of ONE frame through the reference's arithmetic (what `DfNet.forward` + the deep filter compute, not what the
+    fused kernels recompute), term by term (deepfilternet3.py:100-330, modules.py:18-126,702-780, multiframe.py:126-180)."""
+    C, E, Fd, O, H = p.conv_ch, p.nb_erb, p.nb_df, p.df_order, p.emb_hidden_dim
+    emb = C * E // 4
+    g, ge = p.lin_groups, p.enc_lin_groups
+    sep = lambda fout, k=3: fout * C * k + fout * C * C           # depthwise taps + pointwise C x C at fout positions
+    gru = lambda layers: layers * 2 * H * 3 * H                    # W_ih + W_hh per layer
+    m = {
+        "erb_conv0": 9 * C * E, "erb_conv1": sep(E // 2), "erb_conv2": sep(E // 4), "erb_conv3": sep(E // 4),
+        "df_conv0": 9 * 2 * (C // 2) * Fd // 1 + C * C * Fd,       # grouped 3x3 (2 -> C, groups 2) + pointwise
+        "df_conv1": sep(Fd // 2),
+        "df_fc_emb": (C * Fd // 2) * emb // ge, "enc_linear_in": emb * H // g, "enc_gru": gru(1), "enc_linear_out": H * emb // g, "lsnr": emb,
+        "dec_linear_in": emb * H // g, "dec_gru": gru(p.emb_num_layers - 1), "dec_linear_out": H * emb // g,
+        "convt3": sep(E // 4), "convt2": sep(E // 2), "convt1": sep(E), "conv0_out": 3 * C * E, "pathways": C * (E // 4 + E // 4 + E // 2 + E),
+        "df_linear_in": emb * H // 8, "df_gru": gru(p.df_num_layers), "df_skip": (emb * H // g) if p.df_gru_skip == "groupedlinear" else 0,
+        "df_out": H * (2 * O * Fd) // g,
+        "df_convp": (C // 2) * p.df_pathway_kernel_size_t * 2 * O * Fd + (2 * O) * (2 * O) * Fd,   # groups = gcd(C, 2O) = 2, then 1x1
+        "deep_filter": 4 * O * Fd + 2 * (p.fft_size // 2 + 1 - Fd),                                  # complex MACs as 4 real ones, gains as 2
+    }
+    m["total"] = sum(m.values())
+    return m
+
+
 def cpu_baseline(p, sd, clips: int, seconds: float) -> dict:
     """The oracle's enhance() (C port of libDF, sequential over channels like pyDF, + torch-CPU DeepFilterNet3) on a bounded
     sample of the same workload."""
@@ -225,7 +249,8 @@ def main() -> None:
         frames = world * B * (T // HOP) * args.steps
         print(json.dumps({"metric": "48 kHz audio frames/sec (hop=480), DeepFilterNet3 enhance()", "value": frames / dt, "unit": "frames/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-                          "dfa_in_loop_ms": (dfa_ms / dfa_n) if dfa_n else None, "finish_in_loop_ms": (syn_ms / syn_n) if syn_n else None}), flush=True)
+                          "dfa_in_loop_ms": (dfa_ms / dfa_n) if dfa_n else None, "finish_in_loop_ms": (syn_ms / syn_n) if syn_n else None,
+                          "gru_phase_form": "persistent" if gru_persistent else "events", "exact_fp32": bool(model.query(model.Q_EXACT_FP32))}), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -259,22 +284,29 @@ def main() -> None:
     # dfx_df_apply / dfx_model_forward).  enhance() no longer launches it (the same arithmetic runs inside the ISTFT kernel, see
     # rooflines.dfx_k_synthesis_rows), so it is timed here on this workload's own buffers: stand-alone launches on the launch stream with
     # the library's hipEvents around each (dfx_prof_*), in this process, right after the timed loop.
-    traffic, traffic_src = None, None
-    tpath = os.path.join(REPO, "profiles", "df_apply_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get("batch") == B and tj.get("frames_per_clip") == Tf and tj.get("model") == args.model:
-                traffic = tj.get("hbm_bytes_per_launch")
-                traffic_src = ("static: profiles/df_apply_traffic.json — rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_pmc_dfa.sh) over this kernel at "
-                               "this size, calibrated on pure-stream dispatches of the same kernel; not measured in this run (PMC needs rocprofv3)")
-        except Exception:  # noqa: BLE001
-            traffic = None
+    def pmc_traffic(fname, tool):
+        """HBM bytes per launch from the newest committed PMC measurement of this kernel at this size (PMC passes need rocprofv3 around the
+        process: tools/gpu_pmc_*.sh; separate --pmc passes for FETCH_SIZE and WRITE_SIZE, calibrated on pure-stream dispatches)."""
+        for rnd in ("r04_", "r03_", ""):
+            tpath = os.path.join(REPO, "profiles", rnd + fname)
+            if not os.path.exists(tpath):
+                continue
+            try:
+                with open(tpath) as f:
+                    tj = json.load(f)
+                if tj.get("batch") == B and tj.get("frames_per_clip") == Tf and tj.get("model") == args.model:
+                    return tj.get("hbm_bytes_per_launch"), (f"static: profiles/{rnd}{fname} — rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes ({tool}) over this kernel "
+                                                            "at this size, calibrated on pure-stream dispatches of the same kernel; not measured in this run "
+                                                            "(PMC needs rocprofv3 around the process)")
+            except Exception:  # noqa: BLE001
+                pass
+        return None, None
+
+    traffic, traffic_src = pmc_traffic("df_apply_traffic.json", "tools/gpu_pmc_dfa.sh")
     roofline = None
     try:
         sa_ms, sa_n = bench_df_apply_rows(dev, df_state, B, Tf, F, p.nb_df, O, p.df_lookahead, E)
-        roofline = hbm_record("dfx_k_df_apply", sa_ms / sa_n, alg_bytes,
+        roofline = hbm_record("dfx_k_df_apply_rows (stand-alone)", sa_ms / sa_n, alg_bytes,
                               {"traffic": traffic, "traffic_source": traffic_src, "launches": sa_n,
                                "where": "stand-alone launches of dfx_df_apply_strided at this workload's size (engine layout: 488-bin rows, tap-major coefficients), "
                                         "library hipEvents on the launch stream, inside bench.py after the timed loop"})
@@ -303,6 +335,8 @@ def main() -> None:
                                           "frac": round(fin_bpf * nfr / (syn_ms / syn_n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                           "where": "inside the timed loop (hipEvents on the launch stream, one launch per step)"}
     if fused_finish and fin_name in rooflines:
+        ft, fts = pmc_traffic("finish_traffic.json", "tools/gpu_pmc_finish.sh")
+        rooflines[fin_name]["traffic"], rooflines[fin_name]["traffic_source"] = ft, fts
         rooflines[fin_name]["algorithmic_bytes_per_frame"] = fin_bpf
         rooflines[fin_name]["note"] = ("read X 3848 + coefficients 3840 + gains 128, write 1920 bytes of audio per frame; the enhanced spectrum "
                                        "(7696 B per frame written + read back by the two-kernel form) never exists in HBM")
@@ -342,6 +376,24 @@ def main() -> None:
                              "where": "3 extra steps of the normal pipeline (layers concurrent, projections / decoder tails beside them)"}
         gru["achieved"], gru["frac"] = gru["under_load"]["achieved"], gru["under_load"]["frac"]
     rooflines["dfx_k_gru_rec_h3"] = gru
+    # ---- the parsed `roofline` object describes the loop as well: the north-star kernel stand-alone (above), the kernel that does its
+    # arithmetic INSIDE the timed loop, and the whole step against the matrix peaks
+    if isinstance(roofline, dict) and "error" not in roofline:
+        if syn_n and fin_name in rooflines:
+            il = dict(rooflines[fin_name]["in_loop"])
+            il.update({"kernel": fin_name, "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "algorithmic_bytes_per_frame": fin_bpf,
+                       "algorithmic_bytes_per_launch": fin_bpf * nfr, "achieved": round(fin_bpf * nfr / (syn_ms / syn_n * 1e-3) / 1e9, 1),
+                       "traffic": rooflines[fin_name].get("traffic"), "traffic_source": rooflines[fin_name].get("traffic_source"),
+                       "note": "deep filter + ERB gains + ISTFT in one kernel: what enhance() launches where the stand-alone kernel above used to run"})
+            roofline["in_loop"] = il
+        mm = macs_per_frame(p)
+        step_flop = 2.0 * mm["total"] * nfr
+        step_s = dt / args.steps
+        roofline["step"] = {"flop": step_flop, "macs_per_frame": mm, "frames": nfr, "achieved_tflops": round(step_flop / step_s / 1e12, 2),
+                            "frac_fp32_matrix": round(step_flop / step_s / 1e12 / FP32_MATRIX_PEAK_TF, 4),
+                            "frac_f16_mfma": round(3.0 * step_flop / step_s / 1e12 / F16_MFMA_PEAK_TF, 4),
+                            "note": "reference arithmetic of DfNet.forward + the deep filter (fp32-equivalent flops, STFT / ISTFT not counted) over the timed "
+                                    "step; frac_f16_mfma prices the three f16 matrix flops the fp16-split kernels issue per flop"}
 
     # ---- exact fp32: the same step with every contraction on the exact fp32 MFMA / VALU kernels
     exact_ms, exact_diff = None, None
@@ -352,13 +404,8 @@ def main() -> None:
         os.environ["DFX_EXACT_FP32"] = "1"
         m_exact, _, _, _ = init_df(params=p, state_dict=sd, epoch="none")
         del os.environ["DFX_EXACT_FP32"]
-        enhance(m_exact, df_state, x)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(3):
-            ye = enhance(m_exact, df_state, x)
-        torch.cuda.synchronize()
-        exact_ms = (time.perf_counter() - t1) / 3 * 1e3
+        ye = enhance(m_exact, df_state, x)   # (the output only: this process holds two model handles by now, whose ~40 streams share hardware
+        torch.cuda.synchronize()             #  queues — the exact step is timed in a process of its own below)
         exact_diff = float((ye - y).pow(2).mean().sqrt())
         del m_exact, ye
     except Exception as e:  # noqa: BLE001
@@ -383,6 +430,21 @@ def main() -> None:
     # can): what the engine's one-pass-in-flight / staged-phase enqueue policy is worth.  A process of its own, like the streaming
     # configuration below: this one has created three model handles by now (~40 streams; their hardware queues would be shared).
     ahead_ms = None
+    exact_form = None
+    try:
+        import subprocess
+
+        if not extras:
+            raise RuntimeError("N > 1: reported by the N = 1 run")
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                                                 "TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT")}
+        env["DFX_EXACT_FP32"] = "1"
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--main-only", "--steps", "5", "--warmup", "2", "--batch", str(B), "--seconds",
+                            str(args.seconds), "--model", args.model], env=env, capture_output=True, text=True, timeout=600)
+        je = json.loads(r.stdout.strip().splitlines()[-1])
+        exact_ms, exact_form = je["ms_per_step"], je.get("gru_phase_form")
+    except Exception as e:  # noqa: BLE001
+        exact_ms = repr(e)
     try:
         import subprocess
 
@@ -431,7 +493,7 @@ def main() -> None:
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (storage and accumulation; GRU projections / recurrences, the fused DF-encoder convolutions and the pointwise halves of the ERB separable convolutions as fp16-split MFMAs: "
                  "x = hi + lo in f16, hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16, ~2^-21 relative; see exact_fp32_ms_per_step)",
-        "exact_fp32_ms_per_step": exact_ms, "exact_fp32_rms_diff_of_output": exact_diff,
+        "exact_fp32_ms_per_step": exact_ms, "exact_fp32_rms_diff_of_output": exact_diff, "exact_fp32_gru_phase_form": exact_form,
         "data": "synthetic (seeded harmonic+noise 48 kHz audio, seeded random DeepFilterNet3 weights)",
         "config": {"workload": f"DeepFilterNet3 ({'recalled shipped shape, conv_ch=64' if args.model == 'df3' else 'code defaults'}) "
                                f"enhance(pad=True), batch={B} clips x {args.seconds:g} s @48 kHz per GPU, {Tf} STFT frames per clip",
@@ -515,47 +577,70 @@ def bench_host_io(model, df_state, x, steps: int) -> dict:
     compute queues and nothing waits on them on the device: the host waits for the device at the top of every iteration (pass k-1, the
     download of k-2 and the upload of k are over — it would wait for pass k-1 inside enhance() anyway) and then enqueues the two copies and
     the pass.  (Copies that have to wait for a kernel's signal, or that are enqueued in the middle of a pass, were measured at 20-35 ms
-    per step instead of 16-18: tools/dev/hostio_probe.py --variants, profiles/r03_hostio_probe.log.)"""
+    per step instead of 16-18: tools/dev/hostio_probe.py --variants, profiles/r03_hostio_probe.log.)
+    Twice: float32 samples (what df.enhance.enhance() is handed) and 16-bit PCM (what the reference's file loop decodes and encodes around
+    it, enhance.py:73-89 / io.py:25-84: dfx_enhance_pcm16 converts inside the STFT / ISTFT kernels, half the bytes over the link)."""
     from deepfilternet_amd.enhance import enhance
+    from deepfilternet_amd.io import float_to_pcm16
 
     B, T = x.shape
-    nbytes = B * T * 4
-    xh = torch.empty((B, T), dtype=torch.float32, pin_memory=True)
-    xh.copy_(x)
-    yh = [torch.empty((B, T), dtype=torch.float32, pin_memory=True) for _ in range(2)]
-    xd = [torch.empty_like(x) for _ in range(2)]
-    ys = [None, None]
-    s_in, s_out = torch.cuda.Stream(), torch.cuda.Stream()
 
-    def run(n):
-        torch.cuda.synchronize()
-        with torch.cuda.stream(s_in):
-            xd[0].copy_(xh, non_blocking=True)
-        for k in range(n):
-            torch.cuda.synchronize()                # pass k-1, the download of batch k-2 and the upload of batch k are over
-            if k >= 1:
-                with torch.cuda.stream(s_out):      # batch k-1 leaves under the compute of batch k (a consumer would take yh[(k-2) & 1] here)
-                    yh[(k - 1) & 1].copy_(ys[(k - 1) & 1], non_blocking=True)
-            if k + 1 < n:
-                with torch.cuda.stream(s_in):       # batch k+1 arrives under the compute of batch k
-                    xd[(k + 1) & 1].copy_(xh, non_blocking=True)
-            ys[k & 1] = enhance(model, df_state, xd[k & 1])
-        torch.cuda.synchronize()
-        with torch.cuda.stream(s_out):
-            yh[(n - 1) & 1].copy_(ys[(n - 1) & 1], non_blocking=True)
-        torch.cuda.synchronize()
+    def pipeline(xsrc):
+        nbytes = xsrc.numel() * xsrc.element_size()
+        xh = torch.empty(xsrc.shape, dtype=xsrc.dtype, pin_memory=True)
+        xh.copy_(xsrc)
+        yh = [torch.empty(xsrc.shape, dtype=xsrc.dtype, pin_memory=True) for _ in range(2)]
+        xd = [torch.empty_like(xsrc) for _ in range(2)]
+        ys = [None, None]
+        s_in, s_out = torch.cuda.Stream(), torch.cuda.Stream()
 
-    run(3)
+        def run(n):
+            torch.cuda.synchronize()
+            with torch.cuda.stream(s_in):
+                xd[0].copy_(xh, non_blocking=True)
+            for k in range(n):
+                torch.cuda.synchronize()                # pass k-1, the download of batch k-2 and the upload of batch k are over
+                if k >= 1:
+                    with torch.cuda.stream(s_out):      # batch k-1 leaves under the compute of batch k (a consumer would take yh[(k-2) & 1] here)
+                        yh[(k - 1) & 1].copy_(ys[(k - 1) & 1], non_blocking=True)
+                if k + 1 < n:
+                    with torch.cuda.stream(s_in):       # batch k+1 arrives under the compute of batch k
+                        xd[(k + 1) & 1].copy_(xh, non_blocking=True)
+                ys[k & 1] = enhance(model, df_state, xd[k & 1])
+            torch.cuda.synchronize()
+            with torch.cuda.stream(s_out):
+                yh[(n - 1) & 1].copy_(ys[(n - 1) & 1], non_blocking=True)
+            torch.cuda.synchronize()
+
+        run(3)
+        t0 = time.perf_counter()
+        run(steps)
+        dt = (time.perf_counter() - t0) / steps
+        out = yh[(steps - 1) & 1]
+        ok = bool(torch.isfinite(out).all()) if out.dtype.is_floating_point else bool(int(out.abs().max()) > 0)
+        return dt, nbytes, ok
+
+    dt, nbytes, ok = pipeline(x)
+    dt16, nbytes16, ok16 = pipeline(float_to_pcm16(x))
+    # the resident step of this process, for the ratio (same loop as the headline, inputs in HBM)
+    for _ in range(2):
+        enhance(model, df_state, x)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(steps)
-    dt = (time.perf_counter() - t0) / steps
-    ok = bool(torch.isfinite(yh[(steps - 1) & 1]).all())
+    for _ in range(steps):
+        enhance(model, df_state, x)
+    torch.cuda.synchronize()
+    dt_res = (time.perf_counter() - t0) / steps
     return {"ms_per_step_host_to_host": dt * 1e3, "frames_per_s_host_to_host": B * (T // HOP) / dt,
             "pcie_gb_per_s_each_way": nbytes / dt / 1e9, "bytes_each_way_per_step": nbytes, "steps": steps, "finite": ok,
-            "how": "page-locked [B, T] f32 input and output; H2D of batch k+1 and D2H of batch k-1 on their own HIP streams under the compute of "
+            "ms_per_step_host_to_host_pcm16": dt16 * 1e3, "frames_per_s_host_to_host_pcm16": B * (T // HOP) / dt16,
+            "bytes_each_way_per_step_pcm16": nbytes16, "pcm16_nonzero": ok16,
+            "ms_per_step_resident_same_process": dt_res * 1e3, "pcm16_over_resident": dt16 / dt_res, "f32_over_resident": dt / dt_res,
+            "how": "page-locked [B, T] input and output; H2D of batch k+1 and D2H of batch k-1 on their own HIP streams under the compute of "
                    "batch k (device input and output double-buffered, copies without device-side dependencies so that the DMA engines take them; the "
-                   "last batch's download is inside the timed region); a process of its own; not part of `value`, which keeps its inputs resident in "
-                   "HBM.  This box moves 57 GB/s in one direction and 2 x 28.7 GB/s in both at once (tools/dev/hostio_probe.py)"}
+                   "last batch's download is inside the timed region); f32 samples, then 16-bit PCM samples (dfx_enhance_pcm16: the int16 <-> float "
+                   "conversions of df/io.py inside the STFT loads / ISTFT stores); a process of its own; not part of `value`, which keeps its inputs "
+                   "resident in HBM.  This box moves 57 GB/s in one direction and 2 x 28.7 GB/s in both at once (tools/dev/hostio_probe.py)"}
 
 
 def bench_df_apply_o10(dev, df_state, B: int, Tf: int, iters: int = 20) -> dict:

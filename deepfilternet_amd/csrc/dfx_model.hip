@@ -82,6 +82,7 @@ struct GruW {
     size_t whh_h3 = 0;      // W_hh as pre-scaled f16 hi/lo MFMA fragments (dfx_k_gru_rec_h3)
     float whh_unscale = 1.f;
     size_t whh_pj = 0;      // W_hh in the projection kernel's fragment order (dfx_k_gru_step_h3: one time step of many streams), same scale
+    size_t whh_x32 = 0;     // W_hh as fp32 fragments in dfx_k_gru_rec_h3's order (dfx_k_gru_rec_x32: the exact recurrence of the layer-pipelined phase)
 };
 struct GlinW {
     size_t w = 0;
@@ -423,6 +424,9 @@ struct dfx_model {
     // version (8 waves per CU) 2.19 ms alone against 1.5 ms for the three launches and +0.37 ms per step; the second (12 waves per CU, 8.5 KB
     // of strips per wave, fragments read from LDS per k-chunk) 1.32 ms alone and -0.25 ... -0.45 ms per step.
     bool fuse_tail = true;
+    // e0 = erb_conv0's output (8 KB per frame) is not stored: the fused decoder tail recomputes it from the three feature rows it depends on
+    // (DFX_E0_RECOMPUTE=0: written by dfx_k_erb_enc, read back by dfx_k_erb_tail)
+    bool e0_recompute = true;
     size_t cp_w1 = 0, cp_w2 = 0, cp_b = 0;   // df_convp, tiled form (kt > 5)
     size_t cp_weff = 0, cp_b16 = 0;          // df_convp, folded sliding-window form (kt <= 5)
     size_t cin_weff = 0, cin_b = 0;          // enc.df_conv0 folded into a dense 3x3 conv 2 -> C
@@ -764,6 +768,20 @@ bool prep_gru(Prep &P, const std::string &name, int layers, std::vector<GruW> &o
                                 dst[((frag + 1) * 64 + l) * 8 + i] = lb;
                             }
         }
+        {   // the same fragment order in fp32: [16-unit tile][k-chunk][gate][half][lane][4], half h = weights 32 kc + 8 q + 4 h + 0..3 of the lane's unit
+            g.whh_x32 = P.alloc((size_t)3 * H * H);
+            float *dst = &P.out[g.whh_x32];
+            for (int ut = 0; ut < 16; ++ut)
+                for (int kc = 0; kc < 8; ++kc)
+                    for (int gate = 0; gate < 3; ++gate)
+                        for (int half = 0; half < 2; ++half)
+                            for (int l = 0; l < 64; ++l)
+                                for (int i = 0; i < 4; ++i) {
+                                    const int unit = 16 * ut + (l & 15), k = 32 * kc + 8 * (l >> 4) + 4 * half + i;
+                                    const size_t frag = (((size_t)ut * 8 + kc) * 3 + gate) * 2 + half;
+                                    dst[(frag * 64 + l) * 4 + i] = whh[(size_t)(gate * H + unit) * H + k];
+                                }
+        }
         out.push_back(g);
     }
     return true;
@@ -975,6 +993,8 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         m->fuse_dfa = !(fdf && fdf[0] == '0');
         const char *ftl = getenv("DFX_FUSE_TAIL");
         m->fuse_tail = !(ftl && ftl[0] == '0');
+        const char *e0r = getenv("DFX_E0_RECOMPUTE");
+        m->e0_recompute = !(e0r && e0r[0] == '0');
         const char *cep = getenv("DFX_CHECK_EVERY_PASS"), *spl = getenv("DFX_SYNC_SPIN_LIMIT");
         m->check_every_pass = cep && cep[0] == '1';
         if (spl && atoi(spl) > 0) m->spin_limit = atoi(spl);
@@ -1023,7 +1043,7 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         // every layer and the two decoder-tail streams must make progress independently.  Streams that share a hardware queue
         // (GPU_MAX_HW_QUEUES left at ROCm's default of 4, or set after HIP had initialised) would put a spinning wait in front of the
         // launch it waits for — a timeout and an invalid pass.  Checked once, here, with a handshake between exactly those streams.
-        if (m->gru_seq && m->concurrent && !m->exact_fp32 && !dfx_env_is_emulator()) {
+        if (m->gru_seq && m->concurrent && !dfx_env_is_emulator()) {
             const DfxLane &ln = m->lanes[0];
             const int nl = 1 + (m->cfg.emb_num_layers - 1) + m->cfg.df_num_layers;
             std::vector<hipStream_t> ss;
@@ -1145,7 +1165,7 @@ extern "C" int dfx_model_check(const dfx_model *m) {
 extern "C" int dfx_model_query(const dfx_model *m, int what, int64_t *value) {
     if (!m || !value) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_query: null");
     switch (what) {
-        case DFX_Q_GRU_PERSISTENT: *value = m->gru_seq && !m->exact_fp32 && m->concurrent ? 1 : 0; return DFX_OK;
+        case DFX_Q_GRU_PERSISTENT: *value = m->gru_seq && m->concurrent ? 1 : 0; return DFX_OK;
         case DFX_Q_HWQ_PROBE: *value = m->hwq_probe; return DFX_OK;
         case DFX_Q_EXACT_FP32: *value = m->exact_fp32 ? 1 : 0; return DFX_OK;
         case DFX_Q_SPIN_LIMIT: *value = m->spin_limit; return DFX_OK;
@@ -1516,8 +1536,10 @@ static bool erb_tail_ok(const dfx_model *m, int E) {
     return m->fuse_tail && m->fuse_erb && !m->exact_fp32 && m->ct3.wt_h3 && m->ct2.wt_h3 && m->ct1.wt_h3 && dfx_tail_ok(C, E);
 }
 template <int C>
+// e0 == null: recomputed in the kernel from feat_erb (rows of T frames per clip, feat_T frames per clip in feat_erb, lookahead L)
 static int launch_erb_tail(const dfx_model *m, const float *demb, const float *e3, const float *e2, const float *e1, const float *e0,
-                           float *mask, int64_t R, int E, hipStream_t s, DfxRowMap rm) {
+                           float *mask, int64_t R, int E, hipStream_t s, DfxRowMap rm, const float *feat_erb = nullptr, int64_t T = 0,
+                           int64_t feat_T = 0, int L = 0) {
     if constexpr (C % 32 != 0) {
         DFX_FAIL(DFX_ERR_UNSUPPORTED, "erb tail: conv_ch");
     } else {
@@ -1541,10 +1563,16 @@ static int launch_erb_tail(const dfx_model *m, const float *demb, const float *e
         A.E = E;
         A.rm = rm;
         A.err = m->d_err;
+        if (!e0) {
+            if (!feat_erb || T <= 0) DFX_FAIL(DFX_ERR_INVALID_ARG, "erb tail: e0 or the features it is recomputed from");
+            A.feat = feat_erb, A.w0 = m->p(m->erb0_w), A.b0 = m->p(m->erb0_b), A.T = T, A.feat_T = feat_T, A.L = L;
+        }
         const size_t smem = DFX_TAIL_SMEM(C);
-        DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_erb_tail<C>, smem));
+        DFX_HIP(dfx_env_set_max_dyn_smem(e0 ? (const void *)dfx_k_erb_tail<C, false> : (const void *)dfx_k_erb_tail<C, true>, smem));
         DfxKScope ks(DFX_K_ERB_TAIL, s);
-        dfx_launch(dfx_k_erb_tail<C>, dim3((unsigned)nn_grid(dfx_ceil_div(R, DFX_TAIL_WAVES), 1)), dim3(64 * DFX_TAIL_WAVES), smem, s, A);
+        const dim3 grid((unsigned)nn_grid(dfx_ceil_div(R, DFX_TAIL_WAVES), 1));
+        if (e0) dfx_launch((dfx_k_erb_tail<C, false>), grid, dim3(64 * DFX_TAIL_WAVES), smem, s, A);
+        else dfx_launch((dfx_k_erb_tail<C, true>), grid, dim3(64 * DFX_TAIL_WAVES), smem, s, A);
         DFX_LAUNCH_CHECK();
         return DFX_OK;
     }
@@ -1655,10 +1683,12 @@ static int launch_ggemm(const float *a, int lda, const float *w, int G, int Kg, 
     return DFX_OK;
 }
 // GRU input projection [M,256] x [256,N] + bias on the weight-stationary kernel (N % 128 == 0), else the generic GEMM
-static int launch_proj(const float *a, const float *w, const float *bias, float *out, int64_t M, int N, hipStream_t s) {
+static int launch_proj(const float *a, const float *w, const float *bias, float *out, int64_t M, int N, hipStream_t s,
+                       DfxRowMap rm = DfxRowMap{0, 0, 0}) {
     if (M <= 0) return DFX_OK;
-    if (N % DFX_PJ_BN) return launch_ggemm(a, 256, w, 1, 256, N, bias, DFX_ACT_NONE, nullptr, out, N, M, s);
+    if (N % DFX_PJ_BN) return launch_ggemm(a, 256, w, 1, 256, N, bias, DFX_ACT_NONE, nullptr, out, N, M, s, 0, 0, 1, rm);
     DfxPjArgs A;
+    A.rm = rm;
     A.a = a;
     A.w = w;
     A.bias = bias;
@@ -1827,6 +1857,8 @@ static int launch_gru_h3(const dfx_model *m, const GruW &g, const float *gi, flo
     A.t0 = t0;
     A.t1 = t1;
     A.unscale = g.whh_unscale;
+    const bool x32 = m->exact_fp32;   // exact fp32 matrix ops over fp32 fragments (dfx_k_gru_rec_x32)
+    if (x32) A.whf = reinterpret_cast<const dfx_h8 *>(m->p(g.whh_x32)), A.unscale = 1.f;
     // XCDs a layer's workgroups are confined to (1, 2 or 4; 0 = plain grid).  Measured at batch 256 inside the pipeline: 4 -> -0.7 ms
     // per step (the W_hh lines a layer streams every step are shared by more workgroups per L2), 1 and 2 -> +1.3 ms (L2 bandwidth).
     static const int xw = [] { const char *e = getenv("DFX_GRU_XCDS"); return e ? atoi(e) : 4; }();
@@ -1834,9 +1866,10 @@ static int launch_gru_h3(const dfx_model *m, const GruW &g, const float *gi, flo
     A.xcd_mask = 0;
     if (layer >= 0 && (xw == 1 || xw == 2 || xw == 4) && groups <= 32 * xw) A.xcd_mask = (((1 << xw) - 1) << ((layer * xw) % 8)) & 0xff;
     const int64_t nblk = A.xcd_mask ? dfx_ceil_div(groups, xw) * 8 : groups;
-    DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_rec_h3, DFX_GH_SMEM));
+    DFX_HIP(dfx_env_set_max_dyn_smem(x32 ? (const void *)dfx_k_gru_rec_x32 : (const void *)dfx_k_gru_rec_h3, DFX_GH_SMEM));
     DfxKScope ks(DFX_K_GRU_REC, s);
-    dfx_launch(dfx_k_gru_rec_h3, dim3((unsigned)nblk), dim3(DFX_GH_THREADS), DFX_GH_SMEM, s, A);
+    if (x32) dfx_launch(dfx_k_gru_rec_x32, dim3((unsigned)nblk), dim3(DFX_GH_THREADS), DFX_GH_SMEM, s, A);
+    else dfx_launch(dfx_k_gru_rec_h3, dim3((unsigned)nblk), dim3(DFX_GH_THREADS), DFX_GH_SMEM, s, A);
     DFX_LAUNCH_CHECK();
     return DFX_OK;
 }
@@ -1971,7 +2004,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     // dfx_k_emb_fan: emb = enc_out_skip(y) and its consumers in one pass.  emb itself is only written when something outside the kernel
     // still reads it (the ERB decoder's skip connection, an identity skip around the DF GRU).  df_skip(emb) lands in xdf WITHOUT the
     // DF GRU's output (which does not exist yet): df_out then takes its operand as the sum y_df + xdf (DfxGgArgs::a2).
-    const bool fan = m->fuse_emb && m->fan_chunks > 0 && !c.enc_concat && emb == 64 * m->fan_chunks && !m->exact_fp32;
+    const bool fan = m->fuse_emb && m->fan_chunks > 0 && !c.enc_concat && emb == 64 * m->fan_chunks;   // (exact fp32 matrix ops: also with DFX_EXACT_FP32=1)
     const bool fan_skp = fan && run_df && c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR && m->fan_kind[2] == 1;
     auto emb_fan = [&](const float *y, float *dec_x, int64_t M, hipStream_t st, DfxRowMap rm) -> int {
         const float *res = nullptr;
@@ -2016,6 +2049,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     const bool fuse_dec = E % 2 == 0 && m->fuse_erb && 2 * DFX_DEC10_SMEM(C, E) <= (size_t)160 * 1024;
     const bool fuse_tail = fuse_dec && erb_tail_ok<C>(m, E);
     const bool fuse_enc = E % 2 == 0 && 3 * (E + 2) <= 192 && m->fuse_erb && 2 * DFX_ENC_SMEM(C, E) <= (size_t)160 * 1024;
+    const bool no_e0 = fuse_tail && fuse_enc && m->e0_recompute && R < ((int64_t)1 << 31);   // e0 never exists in HBM
+    const float *e0r = no_e0 ? nullptr : e0;   // what the decoder tail is handed
     if (sc && !fuse_enc) DFX_FAIL(DFX_ERR_UNSUPPORTED, "streaming needs the fused ERB encoder head (DFX_FUSE_ERB unset)");
     const DfxGate *gate = sc ? sc->gate : nullptr;
     if (gate && T - t_begin != 1) DFX_FAIL(DFX_ERR_INVALID_ARG, "gated streaming passes carry exactly one new frame");
@@ -2027,7 +2062,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     int K = m->tchunks;
     if (T / K < m->tchunk_min) K = (int)(T / m->tchunk_min);
     const int nenc = (int)m->enc_gru.size(), ndec = (int)m->dec_gru.size(), ndf = run_df ? (int)m->df_gru.size() : 0;
-    const bool pipe = par && !sc && !m->exact_fp32 && K > 1 && nenc == 1 && 1 + ndec + ndf <= DFX_MAX_GRU_LAYERS && ln == &m->lanes[0];
+    // (DFX_EXACT_FP32=1: the same pipeline on dfx_k_gru_rec_x32 / dfx_k_proj256 — 16 CUs per layer instead of the VALU kernel's 128)
+    const bool pipe = par && !sc && K > 1 && nenc == 1 && 1 + ndec + ndf <= DFX_MAX_GRU_LAYERS && ln == &m->lanes[0];
     const int nl = 1 + ndec + ndf;
     // persistent form (default on the GPU): ONE launch runs the recurrences of all layers for the whole sequence
     // (dfx_k_gru_seq); needs every (layer, group) workgroup resident at once (each owns a CU)
@@ -2042,8 +2078,10 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // measured at batch 256 x 1002 frames (ms per step): 8 body chunks + ramp from 32: 21.28; 12 + 16: 21.91; 12, no ramp: 21.47;
         // 6 + 32: 21.35; 4 + 32: 22.45; 16 + 16: 22.69 (the event-based form: 22.07); after the decoder convolutions went to the
         // staged fp16-split kernels (lighter background): 8 + 32: 20.1; 10 + 32: 19.85; 12 + 32: 19.99; 12 + 16: 20.27; 16 + 32: 21.0
-        static const int ramp0 = [] { const char *e = getenv("DFX_SEQ_RAMP"); return e ? atoi(e) : 32; }();
-        static const int kbody = [] { const char *e = getenv("DFX_SEQ_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 10; }();
+        // (exact fp32: a step of the recurrence takes 14 us instead of 8, so the three-layer pipeline fills and drains in shorter chunks)
+        static const int ramp_env = [] { const char *e = getenv("DFX_SEQ_RAMP"); return e ? atoi(e) : -1; }();
+        static const int kbody_env = [] { const char *e = getenv("DFX_SEQ_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
+        const int ramp0 = ramp_env >= 0 ? ramp_env : (m->exact_fp32 ? 16 : 32), kbody = kbody_env > 0 ? kbody_env : (m->exact_fp32 ? 18 : 10);
         const int64_t body = T / kbody > m->tchunk_min ? T / kbody : m->tchunk_min;   // uniform chunk length
         std::vector<int> sizes;
         int64_t left = T;
@@ -2158,7 +2196,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     auto erb_range = [&](int64_t t0, int64_t t1, int64_t Rk, DfxRowMap rm, hipStream_t st) -> int {
         int r;
         if (fuse_enc) {
-            if ((r = launch_erb_enc<C>(m, feat_erb, e0, e1, B, T, st, t0, Lk, t1, featT))) return r;
+            if ((r = launch_erb_enc<C>(m, feat_erb, no_e0 ? nullptr : e0, e1, B, T, st, t0, Lk, t1, featT))) return r;
         } else {
             {
                 const int64_t total = R * E * (C / 4);
@@ -2174,7 +2212,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     };
     // cemb = relu(df_fc_emb(c1.flatten)); emb_in = e3.flatten + cemb (:179-182), then enc.emb_gru's linear_in (SqueezedGRU_S :149-158).
     // (DFX_FUSE_EMB=0 also restores the two grouped GEMMs of the front)
-    const bool enc_fan = m->fuse_emb && m->fuse_encfan && m->efan_groups > 0 && !c.enc_concat && !m->exact_fp32 && emb == 16 * m->efan_groups;
+    const bool enc_fan = m->fuse_emb && m->fuse_encfan && m->efan_groups > 0 && !c.enc_concat && emb == 16 * m->efan_groups;
     auto emb_range = [&](int64_t Rk, DfxRowMap rm, hipStream_t st) -> int {
         int r;
         if (enc_fan) return launch_enc_fan(m, c1, e3, c.emb_gru_skip_enc != DFX_SKIP_NONE ? emb_in : nullptr, xa, Rk, st, rm);
@@ -2214,6 +2252,9 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // (releasing it later — behind df_conv1, or behind the whole front — measured the same within noise, profiles/r01_gru_phase_ablation.log;
         // per time chunk inside the GRU phase: slower, profiles/r04_gru_floor_and_convp_phase.log)
         if (run_df) {
+            // (exact fp32: df_conv0->1 and df_convp are both bound by the fp32 matrix pipe — side by side each takes twice as long and the
+            // front's critical path, c1, with it: df_convp then starts when df_conv1 is through and runs under the head of the GRU phase)
+            if (m->exact_fp32 && par && (rc = wait(EV_C1, x2))) return rc;
             if ((rc = convp_range(t_begin, T, x2))) return rc;
             if (post_behind_convp && (rc = sc->df_post(x2))) return rc;
             if ((rc = signal(EV_C0P, x2))) return rc;
@@ -2282,7 +2323,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         if ((rc = run_gru_stack(m, m->dec_gru, dec_x, xa, xb, gi, B, T, &y, s, hs_dec, t_begin, rmw, hn_dec, par && run_df))) return rc;
         if ((rc = dec_out_skip(y, Rn, s, rmw))) return rc;
         if (fuse_tail) {
-            if ((rc = launch_erb_tail<C>(m, demb, e3, e2, e1, e0, mask, Rn, E, s, rmw))) return rc;
+            if ((rc = launch_erb_tail<C>(m, demb, e3, e2, e1, e0r, mask, Rn, E, s, rmw, feat_erb, T, featT, Lk))) return rc;
         } else if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, Rn, E / 4, E / 4, 1, s, rmw)) ||
                    (rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, Rn, E / 4, E / 2, 2, s, rmw))) {
             return rc;
@@ -2317,6 +2358,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         auto proj_chunk = [&](const GruW &g, int l, int k, const float *xin, hipStream_t st) -> int {
             static const int dev_skip3 = [] { const char *e = getenv("DFX_DEV_SKIP"); return e ? atoi(e) : 0; }();
             if ((dev_skip3 & 4) && l > 0) return DFX_OK;  // dev timing ablation: no input projections for layers > 0
+            if (m->exact_fp32) return launch_proj(xin, m->p(g.wih_t), m->p(g.bias_i), ws + w.pgi[l], Mk(k), 768, st, rmk(k));
             return launch_proj_h3(m, g, xin, ws + w.pgi[l], Mk(k), 768, st, rmk(k));
         };
         // ---- persistent form (default on the GPU): ONE launch runs the recurrences of all layers for the whole sequence
@@ -2330,6 +2372,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             auto rmk = [&](int k) { return DfxRowMap{T, tb(k + 1) - tb(k), tb(k)}; };
             auto Mk = [&](int k) { return B * (tb(k + 1) - tb(k)); };
             auto proj_chunk = [&](const GruW &g, int l, int k, const float *xin, hipStream_t st) -> int {
+                if (m->exact_fp32) return launch_proj(xin, m->p(g.wih_t), m->p(g.bias_i), ws + w.pgi[l], Mk(k), 768, st, rmk(k));
                 return launch_proj_h3(m, g, xin, ws + w.pgi[l], Mk(k), 768, st, rmk(k));
             };
             const unsigned int base = m->seq_base;
@@ -2356,9 +2399,9 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                     const GruW &g = l == 0 ? m->enc_gru[0] : (l <= ndec ? m->dec_gru[l - 1] : m->df_gru[l - 1 - ndec]);
                     S.gi[l] = ws + w.pgi[l];
                     S.y[l] = ws + w.py[l];
-                    S.whf[l] = reinterpret_cast<const dfx_h8 *>(m->p(g.whh_h3));
+                    S.whf[l] = reinterpret_cast<const dfx_h8 *>(m->p(m->exact_fp32 ? g.whh_x32 : g.whh_h3));
                     S.bhn[l] = m->p(g.bhn);
-                    S.unscale[l] = g.whh_unscale;
+                    S.unscale[l] = m->exact_fp32 ? 1.f : g.whh_unscale;
                 }
                 S.B = B, S.T = T, S.nlayers = nl, S.groups = groups, S.K = K;
                 for (int i = 0; i <= K; ++i) S.tb[i] = sb[i];
@@ -2366,9 +2409,10 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 S.trace = m->d_trace;
                 S.spin_limit = m->spin_limit;
                 m->trace_dims[0] = nl, m->trace_dims[1] = groups, m->trace_dims[2] = K;
-                DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_seq, DFX_GH_SMEM));
+                DFX_HIP(dfx_env_set_max_dyn_smem(m->exact_fp32 ? (const void *)dfx_k_gru_seq_x32 : (const void *)dfx_k_gru_seq, DFX_GH_SMEM));
                 DfxKScope ks(DFX_K_GRU_REC, G);
-                dfx_launch(dfx_k_gru_seq, dim3((unsigned)(nl * groups)), dim3(DFX_GH_THREADS), DFX_GH_SMEM, G, S);
+                if (m->exact_fp32) dfx_launch(dfx_k_gru_seq_x32, dim3((unsigned)(nl * groups)), dim3(DFX_GH_THREADS), DFX_GH_SMEM, G, S);
+                else dfx_launch(dfx_k_gru_seq, dim3((unsigned)(nl * groups)), dim3(DFX_GH_THREADS), DFX_GH_SMEM, G, S);
                 DFX_LAUNCH_CHECK();
             }
             {
@@ -2419,7 +2463,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 if ((r = launch_wait_ge(m, donep(ndec), groups, tgt(k), Eq))) return r;
                 if (dev_skip_seq & 1) return DFX_OK;
                 if ((r = dec_out_skip(ws + w.py[ndec], Rk, Eq, rm))) return r;
-                if (fuse_tail) return launch_erb_tail<C>(m, demb, e3, e2, e1, e0, mask, Rk, E, Eq, rm);
+                if (fuse_tail) return launch_erb_tail<C>(m, demb, e3, e2, e1, e0r, mask, Rk, E, Eq, rm, feat_erb, T, featT, Lk);
                 if ((r = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, Rk, E / 4, E / 4, 1, Eq, rm))) return r;
                 if ((r = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, Rk, E / 4, E / 2, 2, Eq, rm))) return r;
                 if (fuse_dec) return launch_erb_dec10<C>(m, d2, e1, e0, mask, Rk, E, Eq, rm);
@@ -2551,7 +2595,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 if (dev_skip & 1) continue;
                 if ((rc = dec_out_skip(ws + w.py[ndec], Rk, st, rm))) return rc;
                 if (fuse_tail) {
-                    if ((rc = launch_erb_tail<C>(m, demb, e3, e2, e1, e0, mask, Rk, E, st, rm))) return rc;
+                    if ((rc = launch_erb_tail<C>(m, demb, e3, e2, e1, e0r, mask, Rk, E, st, rm, feat_erb, T, featT, Lk))) return rc;
                 } else if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, Rk, E / 4, E / 4, 1, st, rm)) ||
                            (rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, Rk, E / 4, E / 2, 2, st, rm))) {
                     return rc;

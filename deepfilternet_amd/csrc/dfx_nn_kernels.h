@@ -1305,7 +1305,7 @@ __global__ void __launch_bounds__(256, 2) dfx_k_erb_enc(DfxEncArgs A) {
                     acc.w += ww.w * x;
                 }
             const float4 o = make_float4(fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f));
-            reinterpret_cast<float4 *>(A.e0 + (r * E + p) * C)[c4] = o;
+            if (A.e0) reinterpret_cast<float4 *>(A.e0 + (r * E + p) * C)[c4] = o;   // (null: the decoder tail recomputes e0 from the features, dfx_k_erb_tail)
             *reinterpret_cast<float4 *>(s0 + p * LD + 4 * c4) = o;
         }
         DFX_WAVE_SYNC();
@@ -1664,7 +1664,8 @@ __global__ void __launch_bounds__(256, 2) dfx_k_erb_dec10_f(DfxDec10fArgs AA) {
 #define DFX_TAIL_WAVE_FLOATS(C) (32 * ((C) + 4))
 #define DFX_TAIL_TAB4(C) (3 * 3 * (C) / 4 + 4 * 2 * (C) / 4 + 3 * (C) / 4 + 3 * (C) / 4)   /* float4s: dw x3, pathway a/b x4, wo, bias x3 */
 #define DFX_TAIL_WFRAG(C) ((size_t)((C) / 16) * ((C) / 32) * 2 * 64)                     /* dfx_h8 per layer */
-#define DFX_TAIL_SMEM(C) ((size_t)DFX_TAIL_TAB4(C) * 16 + 3 * DFX_TAIL_WFRAG(C) * 16 + (size_t)DFX_TAIL_WAVES * DFX_TAIL_WAVE_FLOATS(C) * 4)
+#define DFX_TAIL_W0_4(C) (10 * (C) / 4)   /* float4s: erb_conv0's folded weights [3][3][C] + bias [C] (e0 recomputed in the kernel) */
+#define DFX_TAIL_SMEM(C) ((size_t)(DFX_TAIL_TAB4(C) + DFX_TAIL_W0_4(C)) * 16 + 3 * DFX_TAIL_WFRAG(C) * 16 + (size_t)DFX_TAIL_WAVES * DFX_TAIL_WAVE_FLOATS(C) * 4)
 static __host__ __device__ __forceinline__ bool dfx_tail_ok(int C, int E) {
     return (C == 32 || C == 64) && E == 32 && DFX_TAIL_SMEM(C) <= (size_t)160 * 1024;
 }
@@ -1681,6 +1682,13 @@ struct DfxTailArgs {
     int E;
     DfxRowMap rm;
     unsigned int *err;
+    // e0 == null: e0 = relu(erb_conv0(feat_erb)) is recomputed per frame from the three feature rows it depends on (384 bytes instead of
+    // E * C * 4 = 8 KB per frame read beside the GRU chain — and the encoder does not write it): deepfilternet3.py:106,168, the
+    // arithmetic of dfx_k_erb_enc in the same order
+    const float *feat = nullptr;             // [B, feat_T or T, E]
+    const float *w0 = nullptr, *b0 = nullptr;   // erb_conv0 folded [3][3][C], [C]
+    int64_t T = 0, feat_T = 0;               // frames per clip of the row space / of feat (0: T)
+    int L = 0;                               // conv lookahead
 };
 // one 16-position tile of a separable stage on the fp16-split path, fragments and bias read from LDS (dfx_chain_stage_h3's tile body: same
 // operand roles, same k order, same bits); positions [p0, p0 + 16) of npos, input rows in `in`
@@ -1748,7 +1756,7 @@ static __device__ __forceinline__ void dfx_chain_tile_h3_lds(const float *in, in
                         fmaxf(acc[nt][3] * unscale + bz.w, 0.f)));
     }
 }
-template <int C>
+template <int C, bool RE0 = false>
 __global__ void __launch_bounds__(64 * DFX_TAIL_WAVES, 1) dfx_k_erb_tail(DfxTailArgs A) {
     constexpr int LD = C + 4, C4 = C / 4, NTH = 64 * DFX_TAIL_WAVES;
     constexpr int E = 32, E1 = 16, E4 = 8;
@@ -1760,7 +1768,8 @@ __global__ void __launch_bounds__(64 * DFX_TAIL_WAVES, 1) dfx_k_erb_tail(DfxTail
     float4 *sks = dws + 9 * C4;         // [4 pathways][a, b][C4]
     float4 *wos = sks + 8 * C4;         // [3][C4]
     float4 *bis = wos + 3 * C4;         // [3 layers][C4]
-    dfx_h8 *wfr = reinterpret_cast<dfx_h8 *>(bis + 3 * C4);   // [3 layers][NT * KC * 2 * 64]
+    float4 *w0s = bis + 3 * C4;         // [9 taps + bias][C4] (e0 recomputed)
+    dfx_h8 *wfr = reinterpret_cast<dfx_h8 *>(w0s + DFX_TAIL_W0_4(C));   // [3 layers][NT * KC * 2 * 64]
     float *X = reinterpret_cast<float *>(wfr + 3 * DFX_TAIL_WFRAG(C)) + (size_t)wave * DFX_TAIL_WAVE_FLOATS(C);
     float *Y = X + 16 * LD;
 #pragma unroll
@@ -1776,6 +1785,11 @@ __global__ void __launch_bounds__(64 * DFX_TAIL_WAVES, 1) dfx_k_erb_tail(DfxTail
             sks[pth * 2 * C4 + C4 + i] = reinterpret_cast<const float4 *>(A.skb[pth])[i];
         }
     for (int i = tid; i < 3 * C4; i += NTH) wos[i] = reinterpret_cast<const float4 *>(A.wo)[i];
+    constexpr bool re0 = RE0;   // (a template parameter: the e0 loads and their registers do not exist in this form)
+    if (re0) {
+        for (int i = tid; i < 9 * C4; i += NTH) w0s[i] = reinterpret_cast<const float4 *>(A.w0)[i];
+        for (int i = tid; i < C4; i += NTH) w0s[9 * C4 + i] = reinterpret_cast<const float4 *>(A.b0)[i];
+    }
     __syncthreads();
     const float4 *pd = reinterpret_cast<const float4 *>(A.demb), *p3 = reinterpret_cast<const float4 *>(A.e3), *p2 = reinterpret_cast<const float4 *>(A.e2),
                  *p1 = reinterpret_cast<const float4 *>(A.e1), *p0 = reinterpret_cast<const float4 *>(A.e0);
@@ -1816,6 +1830,18 @@ __global__ void __launch_bounds__(64 * DFX_TAIL_WAVES, 1) dfx_k_erb_tail(DfxTail
             const int idx = lane + 64 * i;
             r1[i] = idx < N1 ? p1[r * N1 + idx] : z4;
         }
+        // e0 recomputed: lane fp of fxr[kt] = element fp of the zero-bordered tap row kt of this frame, [E + 2] (dfx_k_erb_enc's `fs`: zero =
+        // border, causal pad after the lookahead shift, beyond T); requested here, used after convt2
+        float fxr[3] = {0.f, 0.f, 0.f};
+        if (re0) {
+            const uint32_t cb = (uint32_t)r / (uint32_t)A.T;
+            const int64_t ct = r - (int64_t)cb * A.T, fT = A.feat_T > 0 ? A.feat_T : A.T;
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) {
+                const int64_t tau = ct - 2 + kt, tin = tau + A.L;
+                if (lane >= 1 && lane <= E && tau >= 0 && tin < A.T) fxr[kt] = A.feat[((int64_t)cb * fT + tin) * E + lane - 1];
+            }
+        }
         {   // convt3's input and conv2p(e2) into X
             const float4 a3 = sks[lq], b3 = sks[C4 + lq], a2 = sks[2 * C4 + lq], b2 = sks[3 * C4 + lq];
 #pragma unroll
@@ -1845,6 +1871,7 @@ __global__ void __launch_bounds__(64 * DFX_TAIL_WAVES, 1) dfx_k_erb_tail(DfxTail
         }
         float4 r0[NV0];   // e0, one 16-position tile at a time: tile 0 requested here (needed after convt2), tile 1 when tile 0 has been stored
         auto issue_e0 = [&](int t) {
+            if (re0) return;   // (computed where it is stored: nothing to wait for)
 #pragma unroll
             for (int i = 0; i < NV0; ++i) {
                 const int idx = lane + 64 * i;
@@ -1861,12 +1888,35 @@ __global__ void __launch_bounds__(64 * DFX_TAIL_WAVES, 1) dfx_k_erb_tail(DfxTail
         const float4 a0 = sks[6 * C4 + lq], b0 = sks[7 * C4 + lq];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
+            if constexpr (re0) {
+                // e0 of (position 16 t + row, channel quad lq) from the three feature rows: bias, then the nine taps in dfx_k_erb_enc's order.  One
+                // float4 at a time (not unrolled: the unrolled form keeps 36 weight registers and a dozen shuffles in flight and spills)
+#pragma unroll 1
+                for (int i = 0; i < NV0; ++i) {
+                    const int row = (lane + 64 * i) / C4;
+                    float4 ev = w0s[9 * C4 + lq];
 #pragma unroll
-            for (int i = 0; i < NV0; ++i) {
-                const int idx = lane + 64 * i;
-                if (idx < N0T) {
-                    const int row = idx / C4, c4 = idx - row * C4;
-                    *reinterpret_cast<float4 *>(X + row * LD + 4 * c4) = path(r0[i], a0, b0);
+                    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+                        for (int kf = 0; kf < 3; ++kf) {
+                            const float4 ww = w0s[(kt * 3 + kf) * C4 + lq];
+                            const float x = __shfl(fxr[kt], 16 * t + row + kf);   // bin (16 t + row) - 1 + kf, border included
+                            ev.x += ww.x * x;
+                            ev.y += ww.y * x;
+                            ev.z += ww.z * x;
+                            ev.w += ww.w * x;
+                        }
+                    ev = make_float4(fmaxf(ev.x, 0.f), fmaxf(ev.y, 0.f), fmaxf(ev.z, 0.f), fmaxf(ev.w, 0.f));
+                    *reinterpret_cast<float4 *>(X + row * LD + 4 * lq) = path(ev, a0, b0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NV0; ++i) {
+                    const int idx = lane + 64 * i;
+                    if (idx < N0T) {
+                        const int row = idx / C4, c4 = idx - row * C4;
+                        *reinterpret_cast<float4 *>(X + row * LD + 4 * c4) = path(r0[i], a0, b0);
+                    }
                 }
             }
             if (t == 0) {
@@ -2281,6 +2331,7 @@ struct DfxPjArgs {
     float *out;         // [M, N]
     int64_t M;
     int N, ncol, rgroups;  // ncol = N/128 column tiles, rgroups = row groups (grid = 8 * ceil(rgroups/8) * ncol)
+    DfxRowMap rm = DfxRowMap{0, 0, 0};   // logical row -> physical row of a and out (time-chunked launches of the layer-pipelined phase)
 };
 
 // MODE (dev ablations, tools/dev/proj_bench.hip): 0 = product; 1 = no activation loads; 2 = no LDS fragment re-reads
@@ -2309,7 +2360,7 @@ __global__ void __launch_bounds__(DFX_PJ_THREADS, 2) dfx_k_proj256(DfxPjArgs A) 
     auto load_tile = [&](float4 *dst, int64_t tl) {
         const int64_t m = tl * 16 + jl;
         if (MODE != 1 && tl < ntiles && m < A.M) {
-            const float4 *p = reinterpret_cast<const float4 *>(A.a + m * K + 64 * q);
+            const float4 *p = reinterpret_cast<const float4 *>(A.a + dfx_row(A.rm, m) * K + 64 * q);
 #pragma unroll
             for (int v = 0; v < 16; ++v) dst[v] = p[v];
         } else {
@@ -2339,7 +2390,7 @@ __global__ void __launch_bounds__(DFX_PJ_THREADS, 2) dfx_k_proj256(DfxPjArgs A) 
         });
         const int64_t m = tl * 16 + jl;
         if (m < A.M) {
-            float4 *op = reinterpret_cast<float4 *>(A.out + m * A.N + n0 + 4 * q);
+            float4 *op = reinterpret_cast<float4 *>(A.out + dfx_row(A.rm, m) * A.N + n0 + 4 * q);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const float4 bz = bias4[4 * nt];
@@ -3253,6 +3304,7 @@ __global__ void __launch_bounds__(DFX_GRU_THREADS, 2) dfx_k_gru_rec(const float 
 #define DFX_GH_D 6       /* ring slots for the streamed pairs */
 #endif
 #define DFX_GH_HROW 264  /* halves per row of the f16 copy of h (256 + 8 pad) */
+#define DFX_GH_HROW32 260 /* floats per row of the fp32 copy of h of the exact form (X32): 260 = 4 mod 64 words, so the 16 rows a ds_read_b128 pass touches hit 64 different banks */
 // Consumption order of the fragments: position f -> (k-chunk, gate, sub-tile), kc-major over all 3*NS tiles.  (Walking the sub-tiles in two
 // halves with the first half's gate math issued between the second half's matrix ops — one matrix op : three VALU through
 // sched_group_barrier — was built and measured +0.2 ms per step: one wave per SIMD does not overlap the two pipes that way.)
@@ -3325,7 +3377,12 @@ struct DfxGhSync {
 };
 #define DFX_SYNC_SPIN_LIMIT (1 << 22)   /* default bound of every flag wait: polls with s_sleep, ~2 s (dfx_model::spin_limit, DFX_SYNC_SPIN_LIMIT) */
 
-template <bool SEQ>
+// X32 (DFX_EXACT_FP32=1): the same kernel on exact fp32 matrix ops.  A fragment "pair" holds the same 32 bytes per lane — the eight weights
+// W[unit][32 kc + 8 q + 0..7] as fp32 instead of their f16 hi / lo halves — and feeds eight v_mfma_f32_16x16x4_f32 (op j contracts the
+// k-set {32 kc + 8 q + j}: A = the lane's j-th weight, B = the j-th of the eight consecutive h values the lane reads from an fp32 copy of h
+// in LDS); same residency plan, same ring, same accumulator layout.  768 matrix ops of 32 cycles per step and wave: 10.2 us per step —
+// twice the VALU kernel dfx_k_gru_rec's 5.0, but on 16 CUs per layer instead of 128, so all layers fit the persistent, layer-pipelined phase.
+template <bool SEQ, bool X32 = false>
 static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_t grp, const DfxGhSync &Y) {
     constexpr int H = 256, FR = DFX_GH_FR, FS = DFX_GH_FS, NF = DFX_GH_NF, D = DFX_GH_D, HROW = DFX_GH_HROW;
     constexpr int NW = DFX_GH_NW, NS = DFX_GH_NS, TILES = DFX_GH_TILES, UW = 16 * NS;  // UW = units per wave
@@ -3334,6 +3391,10 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
     DFX_DYN_SMEM(unsigned char, smraw);
     dfx_h8 *wl = reinterpret_cast<dfx_h8 *>(smraw);                           // [FL][wave][hi,lo][lane]
     uint16_t *h16 = reinterpret_cast<uint16_t *>(smraw + DFX_GH_SMEM_W);      // [buf][hi,lo][16][HROW]
+    float *h32 = reinterpret_cast<float *>(smraw + DFX_GH_SMEM_W);            // X32: [buf][16][HROW32]
+    static_assert((size_t)2 * DFX_GH_ROWS * DFX_GH_HROW32 * 4 <= (size_t)2 * 2 * DFX_GH_ROWS * DFX_GH_HROW * 2, "the fp32 copy of h fits where the f16 copies live");
+    // byte geometry of the B-operand reads: a k-chunk's 16 bytes for the `hi` slot, the partner 16 bytes for the `lo` slot
+    constexpr size_t HB_KSTEP = X32 ? 32 * 4 : 32 * 2, HB_LO = X32 ? 16 : (size_t)DFX_GH_ROWS * HROW * 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
     const int64_t b0 = grp * DFX_GH_ROWS;
     const bool valid = b0 + jl < A.B;
@@ -3364,7 +3425,12 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
         if (A.h_in) h0 = *reinterpret_cast<const float4 *>(A.h_in + brow * H + u0);
         hp[s][0] = h0.x, hp[s][1] = h0.y, hp[s][2] = h0.z, hp[s][3] = h0.w;
     }
-    auto put_h16 = [&](int buf, int s) {  // f16 hi/lo of hp[s][0..3] -> LDS (8 bytes each)
+    auto put_h16 = [&](int buf, int s) {  // f16 hi/lo of hp[s][0..3] -> LDS (8 bytes each); X32: the four fp32 values
+        if constexpr (X32) {
+            *reinterpret_cast<float4 *>(h32 + ((size_t)buf * DFX_GH_ROWS + jl) * DFX_GH_HROW32 + UW * wave + 16 * s + 4 * q) =
+                make_float4(hp[s][0], hp[s][1], hp[s][2], hp[s][3]);
+            return;
+        }
         uint16_t hh[4], hl[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -3428,13 +3494,14 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
         DFX_OPAQUE(zoff);  // keeps the (loop-invariant) streamed weight loads inside the time loop
         const dfx_h8 *wst = wg + zoff;
         const int64_t tn = t + 1 < c1 ? t + 1 : t;
-        const uint16_t *hb = h16 + (size_t)(cur * 2) * DFX_GH_ROWS * HROW + (size_t)jl * HROW + 8 * q;
+        const unsigned char *hb = X32 ? reinterpret_cast<const unsigned char *>(h32 + ((size_t)cur * DFX_GH_ROWS + jl) * DFX_GH_HROW32 + 8 * q)
+                                      : reinterpret_cast<const unsigned char *>(h16 + (size_t)(cur * 2) * DFX_GH_ROWS * HROW + (size_t)jl * HROW + 8 * q);
         f32x4 acc[TILES];
 #pragma unroll
         for (int i = 0; i < TILES; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         dfx_h8 bh[2], bl[2];
         bh[0] = *reinterpret_cast<const dfx_h8 *>(hb);
-        bl[0] = *reinterpret_cast<const dfx_h8 *>(hb + (size_t)DFX_GH_ROWS * HROW);
+        bl[0] = *reinterpret_cast<const dfx_h8 *>(hb + HB_LO);
         // ---- gates, new state (lane: clip jl, units UW*w + 16s + 4q + r)
         auto gate_unit = [&](int s, int r) {
             const float gr = r == 0 ? gv[0][s].x : r == 1 ? gv[0][s].y : r == 2 ? gv[0][s].z : gv[0][s].w;
@@ -3467,8 +3534,8 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
             // next k-chunk of h, half a chunk ahead
             if constexpr (tt0 == (DFX_GH_TILES / 6) * 3 && kc + 1 < 8) {
                 constexpr int kn = kc + 1;
-                bh[kn & 1] = *reinterpret_cast<const dfx_h8 *>(hb + 32 * kn);
-                bl[kn & 1] = *reinterpret_cast<const dfx_h8 *>(hb + (size_t)DFX_GH_ROWS * HROW + 32 * kn);
+                bh[kn & 1] = *reinterpret_cast<const dfx_h8 *>(hb + HB_KSTEP * kn);
+                bl[kn & 1] = *reinterpret_cast<const dfx_h8 *>(hb + HB_LO + HB_KSTEP * kn);
             }
             dfx_h8 whi[3], wlo[3];
             dfx_static_for<0, 3>([&](auto ic) {
@@ -3485,7 +3552,23 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
                 }
             });
             constexpr int ta = DFX_GH_POS_TILE(f0), tb_ = DFX_GH_POS_TILE(f0 + 1), tc = DFX_GH_POS_TILE(f0 + 2);
-            if (!(DFX_GH_ABLATE & 4)) {
+            if constexpr (X32) {
+                const f32x4 b0 = __builtin_bit_cast(f32x4, bh[kc & 1]), b1 = __builtin_bit_cast(f32x4, bl[kc & 1]);
+                const f32x4 a0[3] = {__builtin_bit_cast(f32x4, whi[0]), __builtin_bit_cast(f32x4, whi[1]), __builtin_bit_cast(f32x4, whi[2])};
+                const f32x4 a1[3] = {__builtin_bit_cast(f32x4, wlo[0]), __builtin_bit_cast(f32x4, wlo[1]), __builtin_bit_cast(f32x4, wlo[2])};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {   // k ascending inside the chunk; the three accumulators alternate
+                    acc[ta] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[0][j], b0[j], acc[ta], 0, 0, 0);
+                    acc[tb_] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[1][j], b0[j], acc[tb_], 0, 0, 0);
+                    acc[tc] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[2][j], b0[j], acc[tc], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[ta] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[0][j], b1[j], acc[ta], 0, 0, 0);
+                    acc[tb_] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[1][j], b1[j], acc[tb_], 0, 0, 0);
+                    acc[tc] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[2][j], b1[j], acc[tc], 0, 0, 0);
+                }
+            } else if (!(DFX_GH_ABLATE & 4)) {
                 acc[ta] = dfx_mfma_16x16x32_f16(wlo[0], bh[kc & 1], acc[ta]);
                 acc[tb_] = dfx_mfma_16x16x32_f16(wlo[1], bh[kc & 1], acc[tb_]);
                 acc[tc] = dfx_mfma_16x16x32_f16(wlo[2], bh[kc & 1], acc[tc]);
@@ -3535,7 +3618,8 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
 }
 #undef DFX_GH_GIDX
 
-__global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_rec_h3(DfxGhArgs A) {
+template <bool X32>
+static __device__ __forceinline__ void dfx_gru_rec_body(const DfxGhArgs &A) {
     int64_t grp = blockIdx.x;
     if (A.xcd_mask) {
         const int x = dfx_xcc_id();   // the XCD itself, not blockIdx % 8 (equal only up to a per-launch rotation)
@@ -3543,8 +3627,11 @@ __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_rec_h
         grp = (int64_t)(blockIdx.x >> 3) * __builtin_popcount(A.xcd_mask) + __builtin_popcount(A.xcd_mask & ((1 << x) - 1));
         if (grp * DFX_GH_ROWS >= A.B) return;
     }
-    dfx_gru_h3_run<false>(A, grp, DfxGhSync{nullptr, nullptr, 0u, 1, nullptr, nullptr, nullptr, 0});
+    dfx_gru_h3_run<false, X32>(A, grp, DfxGhSync{nullptr, nullptr, 0u, 1, nullptr, nullptr, nullptr, 0});
 }
+__global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_rec_h3(DfxGhArgs A) { dfx_gru_rec_body<false>(A); }
+// whf: fp32 fragments [16 unit tiles][8 k-chunks][3 gates][2 halves][64 lanes] float4 (pack_whh_x32), unscale = 1
+__global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_rec_x32(DfxGhArgs A) { dfx_gru_rec_body<true>(A); }
 
 // All GRU layers of a forward pass in ONE persistent launch: workgroup (layer l, group g) keeps its share of W_hh on the CU for the
 // whole sequence and walks the K time chunks, synchronised with the kernels around it through DfxGhSync flags instead of kernel
@@ -3569,7 +3656,8 @@ struct DfxGsArgs {
     unsigned long long *trace;   // dev aid: [layers][groups][K][3] or null
     int spin_limit;
 };
-__global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_seq(DfxGsArgs S) {
+template <bool X32>
+static __device__ __forceinline__ void dfx_gru_seq_body(const DfxGsArgs &S) {
     // block -> (layer, group): consecutive blocks of a layer are dealt round-robin over the XCDs, so every L2 holds a part of every
     // layer's streamed weights (16 groups of a layer = 2 per XCD; confining layers to XCD subsets measured the same: 17.96 vs 18.02 ms)
     const int l = (int)(blockIdx.x / (unsigned)S.groups), g = (int)(blockIdx.x % (unsigned)S.groups);
@@ -3587,9 +3675,11 @@ __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_seq(D
     A.t1 = S.T;
     A.unscale = S.unscale[l];
     A.xcd_mask = 0;
-    dfx_gru_h3_run<true>(A, g, DfxGhSync{S.ready + l, S.done + (size_t)l * S.done_stride, S.base, S.K, S.tb, S.err,
-                                         S.trace ? S.trace + ((size_t)l * S.groups + g) * S.K * 3 : nullptr, S.spin_limit});
+    dfx_gru_h3_run<true, X32>(A, g, DfxGhSync{S.ready + l, S.done + (size_t)l * S.done_stride, S.base, S.K, S.tb, S.err,
+                                              S.trace ? S.trace + ((size_t)l * S.groups + g) * S.K * 3 : nullptr, S.spin_limit});
 }
+__global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_seq(DfxGsArgs S) { dfx_gru_seq_body<false>(S); }
+__global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_seq_x32(DfxGsArgs S) { dfx_gru_seq_body<true>(S); }
 
 // flag kernels of the persistent GRU phase: dfx_k_flag_set runs behind a producer on its stream (the kernel boundary in front of it
 // has made the producer's writes visible), dfx_k_wait_ge holds its stream until all n flags have reached the target
