@@ -1399,6 +1399,8 @@ static int launch_convp_h3(const dfx_model *m, const float *feat_spec, float *ou
         A.tseg = (int)tseg;
         A.nseg = (int)dfx_ceil_div(Tn, tseg);
         const int64_t nruns = B * A.nfb * A.nseg;
+        // (capping the launch at 64 ... 192 resident workgroups, so that the rest of the chip is free for the front's critical path, measured
+        // +0.1 ... +0.5 ms per step: profiles/r04_exact_and_convp_cap.log)
         const int grid = nn_grid(dfx_ceil_div(nruns, 4), 2 * m->front_grain_p);
         DfxKScope ks(DFX_K_DF_CONVP, s);
         dfx_launch((dfx_k_df_convp_h3<C, KT>), dim3(grid), dim3(256), 0, s, A);
@@ -2078,10 +2080,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // measured at batch 256 x 1002 frames (ms per step): 8 body chunks + ramp from 32: 21.28; 12 + 16: 21.91; 12, no ramp: 21.47;
         // 6 + 32: 21.35; 4 + 32: 22.45; 16 + 16: 22.69 (the event-based form: 22.07); after the decoder convolutions went to the
         // staged fp16-split kernels (lighter background): 8 + 32: 20.1; 10 + 32: 19.85; 12 + 32: 19.99; 12 + 16: 20.27; 16 + 32: 21.0
-        // (exact fp32: a step of the recurrence takes 14 us instead of 8, so the three-layer pipeline fills and drains in shorter chunks)
-        static const int ramp_env = [] { const char *e = getenv("DFX_SEQ_RAMP"); return e ? atoi(e) : -1; }();
-        static const int kbody_env = [] { const char *e = getenv("DFX_SEQ_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
-        const int ramp0 = ramp_env >= 0 ? ramp_env : (m->exact_fp32 ? 16 : 32), kbody = kbody_env > 0 ? kbody_env : (m->exact_fp32 ? 18 : 10);
+        static const int ramp0 = [] { const char *e = getenv("DFX_SEQ_RAMP"); return e ? atoi(e) : 32; }();
+        static const int kbody = [] { const char *e = getenv("DFX_SEQ_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 10; }();
         const int64_t body = T / kbody > m->tchunk_min ? T / kbody : m->tchunk_min;   // uniform chunk length
         std::vector<int> sizes;
         int64_t left = T;
@@ -2252,9 +2252,6 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // (releasing it later — behind df_conv1, or behind the whole front — measured the same within noise, profiles/r01_gru_phase_ablation.log;
         // per time chunk inside the GRU phase: slower, profiles/r04_gru_floor_and_convp_phase.log)
         if (run_df) {
-            // (exact fp32: df_conv0->1 and df_convp are both bound by the fp32 matrix pipe — side by side each takes twice as long and the
-            // front's critical path, c1, with it: df_convp then starts when df_conv1 is through and runs under the head of the GRU phase)
-            if (m->exact_fp32 && par && (rc = wait(EV_C1, x2))) return rc;
             if ((rc = convp_range(t_begin, T, x2))) return rc;
             if (post_behind_convp && (rc = sc->df_post(x2))) return rc;
             if ((rc = signal(EV_C0P, x2))) return rc;
