@@ -294,7 +294,7 @@ def main() -> None:
             try:
                 with open(tpath) as f:
                     tj = json.load(f)
-                if tj.get("batch") == B and tj.get("frames_per_clip") == Tf and tj.get("model") == args.model:
+                if tj.get("batch") == B and tj.get("frames_per_clip") == Tf and tj.get("model", args.model) == args.model:
                     return tj.get("hbm_bytes_per_launch"), (f"static: profiles/{rnd}{fname} — rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes ({tool}) over this kernel "
                                                             "at this size, calibrated on pure-stream dispatches of the same kernel; not measured in this run "
                                                             "(PMC needs rocprofv3 around the process)")

@@ -417,6 +417,12 @@ struct dfx_model {
     // dfx_k_enc_fan (df_fc_emb + the encoder GRU's linear_in in one pass over c1): fragment offsets, 0 groups = shapes do not nest
     size_t efan_w1 = 0, efan_w2 = 0;
     int efan_groups = 0;
+    // dfx_k_df_enc_h3 (df_conv0 -> df_conv1 -> df_fc_emb -> linear_in in one kernel, c1 never stored): fc / linear_in fragments; 0 chunks = the
+    // shapes do not fit (then dfx_k_df_conv01_h3 + dfx_k_enc_fan run); DFX_FUSE_DFENC=0: off
+    size_t dfenc_fc = 0, dfenc_in = 0;
+    int dfenc_chunks = 0;
+    float dfenc_fc_unscale = 1.f, dfenc_in_unscale = 1.f;
+    bool fuse_dfenc = true;
     bool fuse_encfan = true;       // DFX_FUSE_ENCFAN=0 (dev A/B): df_fc_emb and linear_in as two grouped GEMMs while the rest of DFX_FUSE_EMB stays on
     bool fuse_dfa = true;          // DFX_FUSE_DFA=0: deep filter and ISTFT of enhance() as two kernels with spec_e between them
     // The ERB decoder's convolutions as ONE launch (dfx_k_erb_tail: d3 / d2 / d1 stay in LDS, -12 KB per frame beside the GRU chain);
@@ -962,6 +968,25 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
     ok = ok && prep_glin(P, "df_dec.df_out.0.weight", m->df_out);
     if (ok) pack_fan(P, m);
     if (ok) pack_encfan(P, m);
+    if (ok && C % 32 == 0 && m->c0_h3 && m->dfc1_h3) {   // fragments of the fused DF branch of the encoder (dfx_k_df_enc_h3)
+        const GlinW a = m->fc_emb, b = m->enc_in;
+        const int Fout = c.nb_df / 2, KC = C / 32;
+        if (a.Kg % 32 == 0 && a.Ng == 16 && b.Kg == 32 && b.Ng == 16 && b.G * 2 == a.G && (int64_t)a.G * a.Kg == (int64_t)Fout * C) {
+            const std::vector<float> src(P.out.begin(), P.out.end());   // pack_h3 may reallocate P.out
+            // chunk ci = fo * KC + kc; lane (o = l & 15, q = l >> 4), element i <-> channel 16 ((8 kc + i) >> 2) + 4 q + (i & 3) of bin fo (the order
+            // in which dfx_k_df_conv01_h3's D fragments hold df_conv1's output)
+            m->dfenc_fc = pack_h3(P, Fout * KC, [&](int ci, int l, int i) {
+                const int fo = ci / KC, kc = ci % KC, ch = 16 * ((8 * kc + i) >> 2) + 4 * (l >> 4) + (i & 3);
+                const int idx = fo * C + ch, g = idx / a.Kg, kin = idx % a.Kg;
+                return src[a.w + ((size_t)g * a.Kg + kin) * 16 + (l & 15)];
+            }, &m->dfenc_fc_unscale);
+            // linear_in group j: element i <-> feature 16 (i >> 2) + 4 q + (i & 3) of its 32 inputs (two finished fc groups)
+            m->dfenc_in = pack_h3(P, b.G, [&](int j, int l, int i) {
+                return src[b.w + ((size_t)j * 32 + 16 * (i >> 2) + 4 * (l >> 4) + (i & 3)) * 16 + (l & 15)];
+            }, &m->dfenc_in_unscale);
+            m->dfenc_chunks = Fout * KC;
+        }
+    }
     if (!ok) {
         delete m;
         DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_create: %s", P.err.empty() ? "weight preparation failed" : P.err.c_str());
@@ -995,6 +1020,8 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         m->fuse_tail = !(ftl && ftl[0] == '0');
         const char *e0r = getenv("DFX_E0_RECOMPUTE");
         m->e0_recompute = !(e0r && e0r[0] == '0');
+        const char *fde = getenv("DFX_FUSE_DFENC");
+        m->fuse_dfenc = !(fde && fde[0] == '0');
         const char *cep = getenv("DFX_CHECK_EVERY_PASS"), *spl = getenv("DFX_SYNC_SPIN_LIMIT");
         m->check_every_pass = cep && cep[0] == '1';
         if (spl && atoi(spl) > 0) m->spin_limit = atoi(spl);
@@ -1791,6 +1818,38 @@ static int launch_enc_fan(const dfx_model *m, const float *c1, const float *e3, 
     DFX_LAUNCH_CHECK();
     return DFX_OK;
 }
+// The DF branch of the encoder in one kernel: feat_spec -> (c0 -> c1 -> df_fc_emb + e3 -> linear_in) -> xa (dfx_k_df_enc_h3); frames [t_begin, t_end)
+template <int C>
+static int launch_df_enc(const dfx_model *m, const float *feat_spec, const float *e3, float *emb_in, float *xa, int64_t B, int64_t T, int Fin,
+                         hipStream_t s, int64_t t_begin, int L, int64_t t_end, int64_t feat_T) {
+    if constexpr (C % 32 != 0) {
+        DFX_FAIL(DFX_ERR_UNSUPPORTED, "fused DF encoder needs conv_ch %% 32 == 0");
+    } else {
+        if (B * T >= ((int64_t)1 << 31) || T * Fin >= ((int64_t)1 << 30)) DFX_FAIL(DFX_ERR_UNSUPPORTED, "fused DF encoder: batch too large for one launch (32-bit frame index)");
+        DfxDfEncArgs A;
+        A.feat = feat_spec;
+        A.w0f = reinterpret_cast<const dfx_h8 *>(m->p(m->c0_h3));
+        A.bias0 = m->p(m->cin_b);
+        A.dw = m->p(m->dfc1.dw);
+        A.wpf = reinterpret_cast<const dfx_h8 *>(m->p(m->dfc1_h3));
+        A.bias = m->p(m->dfc1.bias);
+        A.wfc = reinterpret_cast<const dfx_h8 *>(m->p(m->dfenc_fc));
+        A.win = reinterpret_cast<const dfx_h8 *>(m->p(m->dfenc_in));
+        A.e3 = e3, A.emb_in = emb_in, A.xa = xa;
+        A.B = B, A.T = T;
+        A.Fin = Fin, A.Fout = Fin / 2, A.stride = 2, A.L = L;
+        A.cpg = m->fc_emb.Kg / 32;
+        A.unscale0 = m->c0_unscale, A.unscale = m->dfc1_unscale, A.unscale_fc = m->dfenc_fc_unscale, A.unscale_in = m->dfenc_in_unscale;
+        A.t_begin = t_begin, A.t_end = t_end;
+        A.err = m->d_err;
+        A.feat_T = feat_T;
+        const int64_t tiles = B * dfx_ceil_div(t_end - t_begin, 16);
+        DfxKScope ks(DFX_K_PWCONV, s);
+        dfx_launch(dfx_k_df_enc_h3<C>, dim3((unsigned)nn_grid(dfx_ceil_div(tiles, 4), 3)), dim3(DFX_PW_THREADS), 0, s, A);
+        DFX_LAUNCH_CHECK();
+        return DFX_OK;
+    }
+}
 // emb and everything that reads it, in one pass over the encoder GRU's output (dfx_k_emb_fan); outs[c] null = consumer not wanted
 static int launch_emb_fan(const dfx_model *m, const float *y, const float *res, float *emb_out, float *dec_x, float *dfg_x, float *skp,
                           float *lsnr, int64_t M, hipStream_t s, DfxRowMap rm, float *embv_for_split = nullptr) {
@@ -2224,10 +2283,13 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         } else if ((r = launch_glin(m, m->fc_emb, c1, DFX_ACT_RELU, e3, emb_in, Rk, st, rm))) return r;
         return launch_glin(m, m->enc_in, emb_in, DFX_ACT_RELU, nullptr, xa, Rk, st, rm);
     };
+    // the DF branch of the encoder as one kernel behind the ERB convolutions (it adds e3), c1 never stored: whole clips only (a block of 16
+    // frames per matrix-op tile: the frame-by-frame streaming runtime keeps the two kernels)
+    const bool dfenc = m->fuse_dfenc && fuse_h3 && enc_fan && m->dfenc_chunks > 0 && !sc;
     {   // ---- the front: the frames [t_begin, T) that this pass computes
         if (fuse_c0) {
             if ((rc = signal(EV_C0, x1)) || (rc = wait(EV_C0, x2))) return rc;  // df_convp only needs feat_spec
-            if ((rc = df1_range(t_begin, T, x1))) return rc;
+            if (!dfenc && (rc = df1_range(t_begin, T, x1))) return rc;
         } else {
             DfxCinArgs A;
             A.feat = feat_spec;
@@ -2258,7 +2320,9 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         }
         if ((rc = erb_range(t_begin, T, Rn, rmw, s))) return rc;
         if ((rc = wait(EV_C1, s))) return rc;
-        if ((rc = emb_range(Rn, rmw, s))) return rc;
+        if (dfenc) {
+            if ((rc = launch_df_enc<C>(m, feat_spec, e3, c.emb_gru_skip_enc != DFX_SKIP_NONE ? emb_in : nullptr, xa, B, T, Fd, s, t_begin, Lk, T, featT))) return rc;
+        } else if ((rc = emb_range(Rn, rmw, s))) return rc;
         // the chip-filling front of this chunk is enqueued: the next chunk of a pipelined dfx_enhance may start its own front
         // (it then overlaps this chunk's GRU chain, which occupies only a few CUs)
         if (signal_front && (rc = signal(EV_FRONT, s))) return rc;

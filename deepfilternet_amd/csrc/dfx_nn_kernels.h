@@ -734,6 +734,196 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, DFX_C01_MINB) dfx_k_df_conv01_
     if (amax >= DFX_H3_LIMIT && A.err) dfx_raise(A.err + 1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The DF branch of the encoder in ONE kernel (round 4): df_conv0 -> df_conv1 -> df_fc_emb (+ e3) -> linear_in of the encoder GRU
+// (deepfilternet3.py:115-123,176-182, modules.py:702-738,741-780).  c1 = df_conv1's output (12 KB per frame: written by dfx_k_df_conv01_h3,
+// read back by dfx_k_enc_fan = 6.3 GB per pass at config 2) never exists: the 16 lanes of a matrix-op column are 16 consecutive FRAMES of
+// one clip at ONE output bin instead of 16 bins of one frame, so the D fragments of df_conv1 — lane (frame, q): channels 16 nt + 4 q + r of
+// that bin — are, after a split, the B operand of df_fc_emb's contraction over (bin, channel) with the frames as columns, exactly like the
+// chained products inside dfx_k_df_conv01_h3.  df_fc_emb's groups are 96 = 3 x 32 consecutive inputs of the flattened [bin][channel]
+// vector: a k-chunk (32 channels of one bin) lies in exactly one group at offset 0 / 32 / 64, so walking the bins in order finishes a
+// group every 1.5 bins; two finished groups (32 features of emb_in = relu(fc) + e3) are one group of linear_in.  Per bin and 16 frames:
+// 36 (c0, three taps) + 24 (df_conv1 pointwise) + 6 (fc) + 1 (linear_in) matrix ops against 60 + the c1 store + dfx_k_enc_fan before.
+// The tile body up to c1 is dfx_k_df_conv01_h3's, expression for expression (same c1 bits); the feat_spec patches are gathered per frame
+// (rows 768 B apart: L1 / L2 hits, feat_spec is 197 MB per pass), the fc fragments stream from L2 (196 KB per tile and wave).
+// Needs Kg(fc) % 32 == 0, C % 32 == 0, Ng(fc) == 16 and linear_in in groups of 32 -> 16 (the released shapes; else the two kernels run).
+// ---------------------------------------------------------------------------------------------------------------------
+struct DfxDfEncArgs {
+    const float *feat;   // [B, T, Fin, 2]
+    const dfx_h8 *w0f;   // [C/16][hi,lo][64]        folded df_conv0
+    const float *bias0;  // [C]
+    const float *dw;     // [3][C]
+    const dfx_h8 *wpf;   // [C/16][C/32][hi,lo][64]  df_conv1 pointwise (BN-scaled)
+    const float *bias;   // [C]
+    const dfx_h8 *wfc;   // [Fout * C/32 chunks][hi,lo][64]: chunk ci = fo * C/32 + kc of df_fc_emb (group (32 ci) / Kg, offset (32 ci) % Kg)
+    const dfx_h8 *win;   // [emb/32][hi,lo][64]      linear_in, group j = features [32 j, 32 j + 32)
+    const float *e3;     // [B*T, emb]
+    float *emb_in;       // [B*T, emb] or null (only a skip connection around the encoder GRU reads it)
+    float *xa;           // [B*T, emb/2]: relu(linear_in(emb_in))
+    int64_t B, T;
+    int Fin, Fout, stride, L;
+    int cpg;             // k-chunks per fc group (Kg / 32)
+    float unscale0, unscale, unscale_fc, unscale_in;
+    int64_t t_begin, t_end;
+    unsigned int *err;
+    int64_t feat_T = 0;
+};
+
+template <int C>
+__global__ void __launch_bounds__(DFX_PW_THREADS, 3) dfx_k_df_enc_h3(DfxDfEncArgs A) {
+    constexpr int CPL = C / 4, NT = C / 16, KC = C / 32, C4 = C / 4;
+    static_assert(C % 32 == 0, "one k-chunk is 32 channels");
+    __shared__ float4 dws[3 * C4];
+    __shared__ float4 b0s[C4], b1s[C4];
+    __shared__ dfx_h8 wps[NT * KC * 2 * 64];
+    __shared__ dfx_h8 w0s[NT * 2 * 64];   // df_conv0's fragments: read where they are used (in registers they are 32 of the 168 a wave may have)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
+    for (int i = tid; i < 3 * C4; i += DFX_PW_THREADS) dws[i] = reinterpret_cast<const float4 *>(A.dw)[i];
+    for (int i = tid; i < C4; i += DFX_PW_THREADS) {
+        b0s[i] = reinterpret_cast<const float4 *>(A.bias0)[i];
+        b1s[i] = reinterpret_cast<const float4 *>(A.bias)[i];
+    }
+    for (int i = tid; i < NT * KC * 2 * 64; i += DFX_PW_THREADS) wps[i] = A.wpf[i];
+    for (int i = tid; i < NT * 2 * 64; i += DFX_PW_THREADS) w0s[i] = A.w0f[i];
+    __syncthreads();
+    // tile = (clip, block of 16 consecutive frames to produce); wave-uniform (clip, first frame), a lane adds its frame jl
+    const unsigned Tn = (unsigned)(A.t_end - A.t_begin), TB = (Tn + 15) >> 4, ntiles = (unsigned)A.B * TB;
+    const unsigned nwaves = gridDim.x * 4;
+    const int T32 = (int)A.T, Fin = A.Fin, Lk = A.L, Fout = A.Fout, emb = Fout * C / A.cpg / 2;   // emb = groups * 16 = Fout * KC / cpg * 16
+    const int64_t fT = A.feat_T > 0 ? A.feat_T : (int64_t)T32;
+    int tdt[4], tdf[4];
+    bool tok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int tap = 4 * q + i, kt = tap / 3;
+        tok[i] = tap < 9;
+        tdt[i] = kt - 2 + Lk;
+        tdf[i] = tap - 3 * kt - 1;
+    }
+    float amax = 0.f;
+    for (unsigned tile = (unsigned)blockIdx.x * 4 + (unsigned)dfx_wave_uniform(wave); tile < ntiles; tile += nwaves) {
+        const int b = (int)(tile / TB), t = (int)A.t_begin + (int)((tile - (unsigned)b * TB) << 4) + jl;   // this lane's frame
+        const bool live = t < (int)A.t_end;
+        const float2 *clip = reinterpret_cast<const float2 *>(A.feat) + (int64_t)b * fT * Fin;
+        const int64_t row = (int64_t)b * T32 + t;
+        float2 raw[3][4];
+        auto issue = [&](int j, int fo) {   // patch j (input bin fo * stride + j - 1) of this lane's frame
+            const int fi = fo * A.stride + j - 1;
+            const bool ok = live && fo < Fout && fi >= 0 && fi < Fin;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int tin = t + tdt[i], fin = fi + tdf[i];
+                float2 v = make_float2(0.f, 0.f);
+                if (ok && tok[i] && tin - Lk >= 0 && tin < T32 && fin >= 0 && fin < Fin) v = clip[(int64_t)tin * Fin + fin];
+                raw[j][i] = v;
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < 3; ++j) issue(j, 0);
+        f32x4 accg = f32x4{0.f, 0.f, 0.f, 0.f};   // the fc group in progress: lane (frame, q) holds its outputs 4 q + r
+        float ev[8];                              // emb_in features 16 (g & 1) + 4 q + r of the two groups of a linear_in group
+        int ci = 0;                               // k-chunk of the flattened (bin, channel) vector (wave-uniform)
+        for (int fo = 0; fo < Fout; ++fo) {
+            float u[CPL];
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) u[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float x[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[2 * i] = raw[j][i].x, x[2 * i + 1] = raw[j][i].y;
+                const int fi = fo * A.stride + j - 1;
+                const bool keep = live && fi >= 0 && fi < Fin;
+                dfx_h8 ph, pl;
+                dfx_split8_g(x, ph, pl, amax);
+                issue(j, fo + 1);   // raw[j] is free again: the same patch of the next bin (beyond the last: zeros, no loads)
+                int z0 = 0;
+                DFX_OPAQUE(z0);     // (loop-invariant LDS reads: not to be hoisted back into registers)
+                dfx_h8 w0h[NT], w0l[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) w0h[nt] = w0s[(nt * 2 + 0) * 64 + lane + z0], w0l[nt] = w0s[(nt * 2 + 1) * 64 + lane + z0];
+                f32x4 acc[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(w0l[nt], ph, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(w0h[nt], pl, acc[nt]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(w0h[nt], ph, acc[nt]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float4 bz = b0s[4 * nt + q], w = dws[j * C4 + 4 * nt + q];
+                    u[4 * nt + 0] += w.x * (keep ? fmaxf(acc[nt][0] * A.unscale0 + bz.x, 0.f) : 0.f);
+                    u[4 * nt + 1] += w.y * (keep ? fmaxf(acc[nt][1] * A.unscale0 + bz.y, 0.f) : 0.f);
+                    u[4 * nt + 2] += w.z * (keep ? fmaxf(acc[nt][2] * A.unscale0 + bz.z, 0.f) : 0.f);
+                    u[4 * nt + 3] += w.w * (keep ? fmaxf(acc[nt][3] * A.unscale0 + bz.w, 0.f) : 0.f);
+                }
+            }
+            dfx_h8 uh[KC], ul[KC];
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) dfx_split8_g(u + 8 * kc, uh[kc], ul[kc], amax);
+            int zoff = 0;
+            DFX_OPAQUE(zoff);  // the fragment reads are loop invariant: keep the compiler from hoisting them into 64 registers
+            const dfx_h8 *wpl_ = wps + lane + zoff;
+            // df_conv1's output of this bin, 32 channels (two 16-channel tiles = one k-chunk of df_fc_emb) at a time: element 4 (nt & 1) + r of
+            // c1v = channel 16 nt + 4 q + r of this lane's frame
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc, ++ci) {
+                float c1v[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int nt = 2 * kc + h;
+                    f32x4 aa = f32x4{0.f, 0.f, 0.f, 0.f}, ab = aa, ac = aa;  // independent chains per product term
+#pragma unroll
+                    for (int k2 = 0; k2 < KC; ++k2) {
+                        const dfx_h8 wh = wpl_[((nt * KC + k2) * 2 + 0) * 64], wl = wpl_[((nt * KC + k2) * 2 + 1) * 64];
+                        aa = dfx_mfma_16x16x32_f16(wl, uh[k2], aa);
+                        ab = dfx_mfma_16x16x32_f16(wh, ul[k2], ab);
+                        ac = dfx_mfma_16x16x32_f16(wh, uh[k2], ac);
+                    }
+                    const float4 bz = b1s[4 * nt + q];
+                    c1v[4 * h + 0] = fmaxf(((aa[0] + ab[0]) + ac[0]) * A.unscale + bz.x, 0.f);
+                    c1v[4 * h + 1] = fmaxf(((aa[1] + ab[1]) + ac[1]) * A.unscale + bz.y, 0.f);
+                    c1v[4 * h + 2] = fmaxf(((aa[2] + ab[2]) + ac[2]) * A.unscale + bz.z, 0.f);
+                    c1v[4 * h + 3] = fmaxf(((aa[3] + ab[3]) + ac[3]) * A.unscale + bz.w, 0.f);
+                }
+                // ---- df_fc_emb over these 32 channels
+                const dfx_h8 fh = A.wfc[((size_t)ci * 2 + 0) * 64 + lane], fl = A.wfc[((size_t)ci * 2 + 1) * 64 + lane];
+                dfx_h8 ch, cl;
+                dfx_split8_g(c1v, ch, cl, amax);
+                accg = dfx_mfma_16x16x32_f16(fl, ch, accg);
+                accg = dfx_mfma_16x16x32_f16(fh, cl, accg);
+                accg = dfx_mfma_16x16x32_f16(fh, ch, accg);
+                if ((ci + 1) % A.cpg == 0) {   // group g = ci / cpg is complete (wave-uniform)
+                    const int g = ci / A.cpg;
+                    float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (live) e = *reinterpret_cast<const float4 *>(A.e3 + row * emb + 16 * g + 4 * q);
+                    const float4 v = make_float4(fmaxf(accg[0] * A.unscale_fc, 0.f) + e.x, fmaxf(accg[1] * A.unscale_fc, 0.f) + e.y,
+                                                 fmaxf(accg[2] * A.unscale_fc, 0.f) + e.z, fmaxf(accg[3] * A.unscale_fc, 0.f) + e.w);
+                    if (A.emb_in && live) *reinterpret_cast<float4 *>(A.emb_in + row * emb + 16 * g + 4 * q) = v;
+                    accg = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (g & 1) {   // with the previous group: one group of linear_in, k-index (q, i) <-> feature 16 (i >> 2) + 4 q + (i & 3)
+                        ev[4] = v.x, ev[5] = v.y, ev[6] = v.z, ev[7] = v.w;
+                        const int jg = g >> 1;
+                        const dfx_h8 ih = A.win[((size_t)jg * 2 + 0) * 64 + lane], il = A.win[((size_t)jg * 2 + 1) * 64 + lane];
+                        dfx_h8 eh, el;
+                        dfx_split8_g(ev, eh, el, amax);
+                        f32x4 o = dfx_mfma_16x16x32_f16(il, eh, f32x4{0.f, 0.f, 0.f, 0.f});
+                        o = dfx_mfma_16x16x32_f16(ih, el, o);
+                        o = dfx_mfma_16x16x32_f16(ih, eh, o);
+                        if (live)
+                            *reinterpret_cast<float4 *>(A.xa + row * (emb / 2) + 16 * jg + 4 * q) =
+                                make_float4(fmaxf(o[0] * A.unscale_in, 0.f), fmaxf(o[1] * A.unscale_in, 0.f), fmaxf(o[2] * A.unscale_in, 0.f),
+                                            fmaxf(o[3] * A.unscale_in, 0.f));
+                    } else {
+                        ev[0] = v.x, ev[1] = v.y, ev[2] = v.z, ev[3] = v.w;
+                    }
+                }
+            }
+        }
+    }
+    if (amax >= DFX_H3_LIMIT && A.err) dfx_raise(A.err + 1);
+}
+
 // df_dec.df_convp with df_conv0 recomputed, fp16-split form of dfx_k_df_convp2<C, KT, true> (same run decomposition: a wave walks a
 // segment of frames for 16 bins of one clip).  The window holds the hi/lo halves of the last KT c0 frames (the B operands), the
 // A fragments [KT][C/32][hi,lo] are persistent: 3*KT*C/32 + 3*C/16 MFMAs per 16 bins and frame.
