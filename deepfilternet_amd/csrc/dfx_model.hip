@@ -1843,7 +1843,11 @@ static int launch_df_enc(const dfx_model *m, const float *feat_spec, const float
         A.t_begin = t_begin, A.t_end = t_end;
         A.err = m->d_err;
         A.feat_T = feat_T;
-        const int64_t tiles = B * dfx_ceil_div(t_end - t_begin, 16);
+        int64_t tiles = dfx_ceil_div(B * (t_end - t_begin), 16);
+        // few frames (a streaming hop): deal the bins of a tile to several waves — parts of whole linear_in groups = (2 cpg / KC) bins each
+        const int KC = C / 32, unit = 2 * A.cpg / KC > 0 && (2 * A.cpg) % KC == 0 ? 2 * A.cpg / KC : A.Fout;
+        while (tiles * A.nsplit < (int64_t)dfx_env_num_cus() * 4 * 3 && A.Fout % (2 * A.nsplit) == 0 && (A.Fout / (2 * A.nsplit)) % unit == 0) A.nsplit *= 2;
+        tiles *= A.nsplit;
         DfxKScope ks(DFX_K_PWCONV, s);
         dfx_launch(dfx_k_df_enc_h3<C>, dim3((unsigned)nn_grid(dfx_ceil_div(tiles, 4), 3)), dim3(DFX_PW_THREADS), 0, s, A);
         DFX_LAUNCH_CHECK();
@@ -2283,9 +2287,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         } else if ((r = launch_glin(m, m->fc_emb, c1, DFX_ACT_RELU, e3, emb_in, Rk, st, rm))) return r;
         return launch_glin(m, m->enc_in, emb_in, DFX_ACT_RELU, nullptr, xa, Rk, st, rm);
     };
-    // the DF branch of the encoder as one kernel behind the ERB convolutions (it adds e3), c1 never stored: whole clips only (a block of 16
-    // frames per matrix-op tile: the frame-by-frame streaming runtime keeps the two kernels)
-    const bool dfenc = m->fuse_dfenc && fuse_h3 && enc_fan && m->dfenc_chunks > 0 && !sc;
+    // the DF branch of the encoder as one kernel behind the ERB convolutions (it adds e3), c1 never stored
+    const bool dfenc = m->fuse_dfenc && fuse_h3 && enc_fan && m->dfenc_chunks > 0;
     {   // ---- the front: the frames [t_begin, T) that this pass computes
         if (fuse_c0) {
             if ((rc = signal(EV_C0, x1)) || (rc = wait(EV_C0, x2))) return rc;  // df_convp only needs feat_spec

@@ -763,6 +763,9 @@ struct DfxDfEncArgs {
     int64_t B, T;
     int Fin, Fout, stride, L;
     int cpg;             // k-chunks per fc group (Kg / 32)
+    int nsplit = 1;      // the bins of a tile's frames are dealt to nsplit waves, Fout / nsplit consecutive bins each — whole pairs of fc groups (=
+                         // whole linear_in groups), which are independent of each other: a pass of few frames (a streaming hop: 4096 frames = 256
+                         // tiles) then runs on nsplit x as many waves
     float unscale0, unscale, unscale_fc, unscale_in;
     int64_t t_begin, t_end;
     unsigned int *err;
@@ -777,6 +780,7 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 3) dfx_k_df_enc_h3(DfxDfEncArg
     __shared__ float4 b0s[C4], b1s[C4];
     __shared__ dfx_h8 wps[NT * KC * 2 * 64];
     __shared__ dfx_h8 w0s[NT * 2 * 64];   // df_conv0's fragments: read where they are used (in registers they are 32 of the 168 a wave may have)
+    __shared__ __attribute__((aligned(16))) int tis[4 * DFX_PW_THREADS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
     for (int i = tid; i < 3 * C4; i += DFX_PW_THREADS) dws[i] = reinterpret_cast<const float4 *>(A.dw)[i];
     for (int i = tid; i < C4; i += DFX_PW_THREADS) {
@@ -786,44 +790,55 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 3) dfx_k_df_enc_h3(DfxDfEncArg
     for (int i = tid; i < NT * KC * 2 * 64; i += DFX_PW_THREADS) wps[i] = A.wpf[i];
     for (int i = tid; i < NT * 2 * 64; i += DFX_PW_THREADS) w0s[i] = A.w0f[i];
     __syncthreads();
-    // tile = (clip, block of 16 consecutive frames to produce); wave-uniform (clip, first frame), a lane adds its frame jl
-    const unsigned Tn = (unsigned)(A.t_end - A.t_begin), TB = (Tn + 15) >> 4, ntiles = (unsigned)A.B * TB;
+    // tile = 16 consecutive (clip, frame) pairs of the B * Tn frames to produce, one per lane of a matrix-op column: 16 consecutive frames of
+    // a clip in a batch pass, the newest frame of 16 consecutive streams in a frame-by-frame pass (Tn = 1)
+    const unsigned Tn = (unsigned)(A.t_end - A.t_begin), NFR = (unsigned)A.B * Tn, nsp = (unsigned)A.nsplit, ntiles = ((NFR + 15) >> 4) * nsp;
+    const int bpp = A.Fout / A.nsplit;   // bins per part
     const unsigned nwaves = gridDim.x * 4;
     const int T32 = (int)A.T, Fin = A.Fin, Lk = A.L, Fout = A.Fout, emb = Fout * C / A.cpg / 2;   // emb = groups * 16 = Fout * KC / cpg * 16
     const int64_t fT = A.feat_T > 0 ? A.feat_T : (int64_t)T32;
-    int tdt[4], tdf[4];
-    bool tok[4];
+    // the four taps (of the 3x3 window over (t, f), padded to 16) this lane feeds into the k index of the matrix op, packed (dt + 64 |
+    // (df + 1) << 8 | ok << 16) and parked in LDS: the kernel sits at the 168-register edge of three waves per SIMD
+    {
+        int ti[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int tap = 4 * q + i, kt = tap / 3;
-        tok[i] = tap < 9;
-        tdt[i] = kt - 2 + Lk;
-        tdf[i] = tap - 3 * kt - 1;
+        for (int i = 0; i < 4; ++i) {
+            const int tap = 4 * q + i, kt = tap / 3;
+            ti[i] = (kt - 2 + Lk + 64) | ((tap - 3 * kt) << 8) | ((tap < 9 ? 1 : 0) << 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tis[4 * tid + i] = ti[i];
     }
     float amax = 0.f;
     for (unsigned tile = (unsigned)blockIdx.x * 4 + (unsigned)dfx_wave_uniform(wave); tile < ntiles; tile += nwaves) {
-        const int b = (int)(tile / TB), t = (int)A.t_begin + (int)((tile - (unsigned)b * TB) << 4) + jl;   // this lane's frame
-        const bool live = t < (int)A.t_end;
+        const unsigned ftile = tile / nsp, part = tile - ftile * nsp;
+        const int fo0 = (int)part * bpp, fo1 = fo0 + bpp;
+        const unsigned rl = (ftile << 4) + (unsigned)jl, b = rl / Tn;
+        const int t = (int)A.t_begin + (int)(rl - b * Tn);   // this lane's frame
+        const bool live = rl < NFR;
         const float2 *clip = reinterpret_cast<const float2 *>(A.feat) + (int64_t)b * fT * Fin;
         const int64_t row = (int64_t)b * T32 + t;
         float2 raw[3][4];
         auto issue = [&](int j, int fo) {   // patch j (input bin fo * stride + j - 1) of this lane's frame
             const int fi = fo * A.stride + j - 1;
-            const bool ok = live && fo < Fout && fi >= 0 && fi < Fin;
+            const bool ok = live && fo < fo1 && fi >= 0 && fi < Fin;
+            int zt = tid;
+            DFX_OPAQUE(zt);   // (a read per use, not a value carried in registers)
+            const int tinfo[4] = {tis[4 * zt], tis[4 * zt + 1], tis[4 * zt + 2], tis[4 * zt + 3]};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int tin = t + tdt[i], fin = fi + tdf[i];
+                const int tin = t + (tinfo[i] & 0xff) - 64, fin = fi + ((tinfo[i] >> 8) & 0xff) - 1;
                 float2 v = make_float2(0.f, 0.f);
-                if (ok && tok[i] && tin - Lk >= 0 && tin < T32 && fin >= 0 && fin < Fin) v = clip[(int64_t)tin * Fin + fin];
+                if (ok && (tinfo[i] >> 16) && tin - Lk >= 0 && tin < T32 && fin >= 0 && fin < Fin) v = clip[(int64_t)tin * Fin + fin];
                 raw[j][i] = v;
             }
         };
 #pragma unroll
-        for (int j = 0; j < 3; ++j) issue(j, 0);
+        for (int j = 0; j < 3; ++j) issue(j, fo0);
         f32x4 accg = f32x4{0.f, 0.f, 0.f, 0.f};   // the fc group in progress: lane (frame, q) holds its outputs 4 q + r
         float ev[8];                              // emb_in features 16 (g & 1) + 4 q + r of the two groups of a linear_in group
-        int ci = 0;                               // k-chunk of the flattened (bin, channel) vector (wave-uniform)
-        for (int fo = 0; fo < Fout; ++fo) {
+        int ci = fo0 * KC;                        // k-chunk of the flattened (bin, channel) vector (wave-uniform)
+        for (int fo = fo0; fo < fo1; ++fo) {
             float u[CPL];
 #pragma unroll
             for (int i = 0; i < CPL; ++i) u[i] = 0.f;
@@ -868,6 +883,8 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 3) dfx_k_df_enc_h3(DfxDfEncArg
             // c1v = channel 16 nt + 4 q + r of this lane's frame
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc, ++ci) {
+                // (this chunk's fc fragments are requested before the twelve matrix ops of the pointwise conv that produce its operand)
+                const dfx_h8 fh = A.wfc[((size_t)ci * 2 + 0) * 64 + lane], fl = A.wfc[((size_t)ci * 2 + 1) * 64 + lane];
                 float c1v[8];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -887,7 +904,6 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 3) dfx_k_df_enc_h3(DfxDfEncArg
                     c1v[4 * h + 3] = fmaxf(((aa[3] + ab[3]) + ac[3]) * A.unscale + bz.w, 0.f);
                 }
                 // ---- df_fc_emb over these 32 channels
-                const dfx_h8 fh = A.wfc[((size_t)ci * 2 + 0) * 64 + lane], fl = A.wfc[((size_t)ci * 2 + 1) * 64 + lane];
                 dfx_h8 ch, cl;
                 dfx_split8_g(c1v, ch, cl, amax);
                 accg = dfx_mfma_16x16x32_f16(fl, ch, accg);
@@ -1051,7 +1067,7 @@ __global__ void __launch_bounds__(256, 1) dfx_k_df_convp_h3(DfxCphArgs A) {
 // dfx_k_gate_pend_commit flips par[b] and counts the frame where the decoder ran — elsewhere the new frame is simply dropped, as the
 // reference's pulsed model drops it (tract.rs: a sub-model that is not run does not advance).
 template <int C, int KT, bool REBUILD>
-__global__ void __launch_bounds__(256, 2) dfx_k_df_convp_step(DfxCphArgs A, f32x4 *pend, int slot_new, const unsigned char *par = nullptr,
+__global__ void __launch_bounds__(256, REBUILD ? 1 : 2) dfx_k_df_convp_step(DfxCphArgs A, f32x4 *pend, int slot_new, const unsigned char *par = nullptr,
                                                              const int *cnt = nullptr) {
     constexpr int CPL = C / 4, NT = C / 16, KC = C / 32, NS = KT - 1;
     static_assert(C % 32 == 0 && KT >= 2, "one k-chunk is 32 channels; kt = 1 has no history");
