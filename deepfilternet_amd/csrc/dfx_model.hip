@@ -423,6 +423,12 @@ struct dfx_model {
     int dfenc_chunks = 0;
     float dfenc_fc_unscale = 1.f, dfenc_in_unscale = 1.f;
     bool fuse_dfenc = true;
+    // dfx_k_df_out_h3 (df_out + tanh + c0p as a row-streaming kernel of its own): fragments [G][ceil(Ng / 16)]; 0 = shapes do not fit
+    // (dfx_k_ggemm then); DFX_DFOUT_LEAN=0: off
+    size_t dfo_h3 = 0;
+    int dfo_nu = 0;
+    float dfo_unscale = 1.f;
+    bool dfout_lean = true;
     bool fuse_encfan = true;       // DFX_FUSE_ENCFAN=0 (dev A/B): df_fc_emb and linear_in as two grouped GEMMs while the rest of DFX_FUSE_EMB stays on
     bool fuse_dfa = true;          // DFX_FUSE_DFA=0: deep filter and ISTFT of enhance() as two kernels with spec_e between them
     // The ERB decoder's convolutions as ONE launch (dfx_k_erb_tail: d3 / d2 / d1 stay in LDS, -12 KB per frame beside the GRU chain);
@@ -968,6 +974,20 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
     ok = ok && prep_glin(P, "df_dec.df_out.0.weight", m->df_out);
     if (ok) pack_fan(P, m);
     if (ok) pack_encfan(P, m);
+    if (ok) {   // fragments of dfx_k_df_out_h3
+        const GlinW a = m->df_out;
+        const int NO = 2 * O, Fd = c.nb_df;
+        if (a.Kg <= 32 && a.Kg % 8 == 0 && a.Ng % 2 == 0 && NO % 2 == 0 && Fd % 2 == 0 && (int64_t)a.G * a.Ng == (int64_t)NO * Fd &&
+            DFX_DFO_SMEM(NO, Fd) <= (size_t)64 * 1024) {
+            const std::vector<float> src(P.out.begin(), P.out.end());   // pack_h3 may reallocate P.out
+            const int NU = (a.Ng + 15) / 16;
+            m->dfo_h3 = pack_h3(P, a.G * NU, [&](int fr, int l, int i) {
+                const int g = fr / NU, u = fr % NU, o = 16 * u + (l & 15), k = 8 * (l >> 4) + i;
+                return o < a.Ng && k < a.Kg ? src[a.w + ((size_t)g * a.Kg + k) * a.Ng + o] : 0.f;
+            }, &m->dfo_unscale);
+            m->dfo_nu = NU;
+        }
+    }
     if (ok && C % 32 == 0 && m->c0_h3 && m->dfc1_h3) {   // fragments of the fused DF branch of the encoder (dfx_k_df_enc_h3)
         const GlinW a = m->fc_emb, b = m->enc_in;
         const int Fout = c.nb_df / 2, KC = C / 32;
@@ -1022,6 +1042,8 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         m->e0_recompute = !(e0r && e0r[0] == '0');
         const char *fde = getenv("DFX_FUSE_DFENC");
         m->fuse_dfenc = !(fde && fde[0] == '0');
+        const char *dfl = getenv("DFX_DFOUT_LEAN");
+        m->dfout_lean = !(dfl && dfl[0] == '0');
         const char *cep = getenv("DFX_CHECK_EVERY_PASS"), *spl = getenv("DFX_SYNC_SPIN_LIMIT");
         m->check_every_pass = cep && cep[0] == '1';
         if (spl && atoi(spl) > 0) m->spin_limit = atoi(spl);
@@ -1825,7 +1847,8 @@ static int launch_df_enc(const dfx_model *m, const float *feat_spec, const float
     if constexpr (C % 32 != 0) {
         DFX_FAIL(DFX_ERR_UNSUPPORTED, "fused DF encoder needs conv_ch %% 32 == 0");
     } else {
-        if (B * T >= ((int64_t)1 << 31) || T * Fin >= ((int64_t)1 << 30)) DFX_FAIL(DFX_ERR_UNSUPPORTED, "fused DF encoder: batch too large for one launch (32-bit frame index)");
+        if (B * T * (int64_t)m->fc_emb.G * 16 >= ((int64_t)1 << 31) || B * (feat_T > 0 ? feat_T : T) * Fin >= ((int64_t)1 << 29))
+            DFX_FAIL(DFX_ERR_UNSUPPORTED, "fused DF encoder: batch too large for one launch (32-bit element offsets)");
         DfxDfEncArgs A;
         A.feat = feat_spec;
         A.w0f = reinterpret_cast<const dfx_h8 *>(m->p(m->c0_h3));
@@ -2083,6 +2106,23 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     };
     // c = tanh(df_out(c)).view(b,t,F',2O) + c0p   (:329-330) of M rows; cfeat (+ cfeat2) is df_out's operand
     auto df_out_rows = [&](const float *cfeat, const float *cfeat2, int64_t M, hipStream_t st, DfxRowMap rm) -> int {
+        if (m->dfout_lean && m->dfo_nu > 0 && !m->exact_fp32 && M > 0 && R < ((int64_t)1 << 31)) {   // row-streaming form (dfx_k_df_out_h3)
+            DfxDfOutArgs A;
+            A.a = cfeat, A.a2 = cfeat2;
+            A.wf = reinterpret_cast<const dfx_h8 *>(m->p(m->dfo_h3));
+            A.c0p = c0p, A.out = coefs;
+            A.R = M, A.T = T;
+            A.G = m->df_out.G, A.Kg = m->df_out.Kg, A.Ng = m->df_out.Ng, A.NO = NO, A.Fd = Fd;
+            A.unscale = m->dfo_unscale;
+            A.rm = rm;
+            A.err = m->d_err;
+            const size_t smem = DFX_DFO_SMEM(NO, Fd);
+            DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_df_out_h3, smem));
+            DfxKScope ks(DFX_K_GGEMM, st);
+            dfx_launch(dfx_k_df_out_h3, dim3((unsigned)nn_grid(dfx_ceil_div(M, 16), 2)), dim3(DFX_DFO_THREADS), smem, st, A);
+            DFX_LAUNCH_CHECK();
+            return DFX_OK;
+        }
         return launch_ggemm(cfeat, m->df_out.G * m->df_out.Kg, m->p(m->df_out.w), m->df_out.G, m->df_out.Kg, m->df_out.Ng, nullptr, DFX_ACT_TANH,
                             c0p, coefs, m->df_out.G * m->df_out.Ng, M, st, NO, Fd, T, rm, cfeat2);
     };
@@ -2288,7 +2328,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         return launch_glin(m, m->enc_in, emb_in, DFX_ACT_RELU, nullptr, xa, Rk, st, rm);
     };
     // the DF branch of the encoder as one kernel behind the ERB convolutions (it adds e3), c1 never stored
-    const bool dfenc = m->fuse_dfenc && fuse_h3 && enc_fan && m->dfenc_chunks > 0;
+    const bool dfenc = m->fuse_dfenc && fuse_h3 && enc_fan && m->dfenc_chunks > 0 && B * T * (int64_t)emb < ((int64_t)1 << 31) &&
+                       B * (featT > 0 ? featT : T) * Fd < ((int64_t)1 << 29);   // (32-bit element offsets inside the kernel; beyond: the two kernels)
     {   // ---- the front: the frames [t_begin, T) that this pass computes
         if (fuse_c0) {
             if ((rc = signal(EV_C0, x1)) || (rc = wait(EV_C0, x2))) return rc;  // df_convp only needs feat_spec

@@ -816,8 +816,10 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 3) dfx_k_df_enc_h3(DfxDfEncArg
         const unsigned rl = (ftile << 4) + (unsigned)jl, b = rl / Tn;
         const int t = (int)A.t_begin + (int)(rl - b * Tn);   // this lane's frame
         const bool live = rl < NFR;
-        const float2 *clip = reinterpret_cast<const float2 *>(A.feat) + (int64_t)b * fT * Fin;
-        const int64_t row = (int64_t)b * T32 + t;
+        // 32-bit element offsets from the (scalar) array bases: B * feat_T * Fin < 2^29 and B * T * emb < 2^31 are checked by the host
+        const float2 *feat2 = reinterpret_cast<const float2 *>(A.feat);
+        const unsigned cbase = b * (unsigned)fT * (unsigned)Fin;
+        const unsigned row = b * (unsigned)T32 + (unsigned)t;
         float2 raw[3][4];
         auto issue = [&](int j, int fo) {   // patch j (input bin fo * stride + j - 1) of this lane's frame
             const int fi = fo * A.stride + j - 1;
@@ -829,7 +831,7 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 3) dfx_k_df_enc_h3(DfxDfEncArg
             for (int i = 0; i < 4; ++i) {
                 const int tin = t + (tinfo[i] & 0xff) - 64, fin = fi + ((tinfo[i] >> 8) & 0xff) - 1;
                 float2 v = make_float2(0.f, 0.f);
-                if (ok && (tinfo[i] >> 16) && tin - Lk >= 0 && tin < T32 && fin >= 0 && fin < Fin) v = clip[(int64_t)tin * Fin + fin];
+                if (ok && (tinfo[i] >> 16) && tin - Lk >= 0 && tin < T32 && fin >= 0 && fin < Fin) v = feat2[cbase + (unsigned)(tin * Fin + fin)];
                 raw[j][i] = v;
             }
         };
@@ -856,7 +858,10 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 3) dfx_k_df_enc_h3(DfxDfEncArg
                 DFX_OPAQUE(z0);     // (loop-invariant LDS reads: not to be hoisted back into registers)
                 dfx_h8 w0h[NT], w0l[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) w0h[nt] = w0s[(nt * 2 + 0) * 64 + lane + z0], w0l[nt] = w0s[(nt * 2 + 1) * 64 + lane + z0];
+                for (int nt = 0; nt < NT; ++nt) {
+                    w0h[nt] = w0s[(nt * 2 + 0) * 64 + lane + z0];
+                    w0l[nt] = w0s[(nt * 2 + 1) * 64 + lane + z0];
+                }
                 f32x4 acc[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(w0l[nt], ph, f32x4{0.f, 0.f, 0.f, 0.f});
@@ -912,10 +917,10 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 3) dfx_k_df_enc_h3(DfxDfEncArg
                 if ((ci + 1) % A.cpg == 0) {   // group g = ci / cpg is complete (wave-uniform)
                     const int g = ci / A.cpg;
                     float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (live) e = *reinterpret_cast<const float4 *>(A.e3 + row * emb + 16 * g + 4 * q);
+                    if (live) e = *reinterpret_cast<const float4 *>(A.e3 + (row * (unsigned)emb + (unsigned)(16 * g + 4 * q)));
                     const float4 v = make_float4(fmaxf(accg[0] * A.unscale_fc, 0.f) + e.x, fmaxf(accg[1] * A.unscale_fc, 0.f) + e.y,
                                                  fmaxf(accg[2] * A.unscale_fc, 0.f) + e.z, fmaxf(accg[3] * A.unscale_fc, 0.f) + e.w);
-                    if (A.emb_in && live) *reinterpret_cast<float4 *>(A.emb_in + row * emb + 16 * g + 4 * q) = v;
+                    if (A.emb_in && live) *reinterpret_cast<float4 *>(A.emb_in + (row * (unsigned)emb + (unsigned)(16 * g + 4 * q))) = v;
                     accg = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (g & 1) {   // with the previous group: one group of linear_in, k-index (q, i) <-> feature 16 (i >> 2) + 4 q + (i & 3)
                         ev[4] = v.x, ev[5] = v.y, ev[6] = v.z, ev[7] = v.w;
@@ -927,7 +932,7 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 3) dfx_k_df_enc_h3(DfxDfEncArg
                         o = dfx_mfma_16x16x32_f16(ih, el, o);
                         o = dfx_mfma_16x16x32_f16(ih, eh, o);
                         if (live)
-                            *reinterpret_cast<float4 *>(A.xa + row * (emb / 2) + 16 * jg + 4 * q) =
+                            *reinterpret_cast<float4 *>(A.xa + (row * (unsigned)(emb / 2) + (unsigned)(16 * jg + 4 * q))) =
                                 make_float4(fmaxf(o[0] * A.unscale_in, 0.f), fmaxf(o[1] * A.unscale_in, 0.f), fmaxf(o[2] * A.unscale_in, 0.f),
                                             fmaxf(o[3] * A.unscale_in, 0.f));
                     } else {
@@ -2514,6 +2519,97 @@ __global__ void __launch_bounds__(DFX_GG_THREADS) dfx_k_ggemm(DfxGgArgs A) {
             A.out[idx] = v;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// df_dec.df_out as a kernel of its own (round 4): coefs = tanh(df_out(y [+ skip])).view(b, t, F', 2 O) + c0p, stored tap-major
+// [B, O, T, F'][2] (deepfilternet3.py:326-330, modules.py:741-780).  The grouped linear is 15 k MACs per frame against 9.7 KB of traffic:
+// HBM-bound — as dfx_k_ggemm (exact fp32 matrix ops, K through LDS, a tap-major permutation per output value) it was instruction-bound,
+// 1.23 ms per pass at config 2.  Here a workgroup owns 16 frames: the frames are the columns of fp16-split matrix ops (A = the group's
+// weights, 16 outputs x K = Kg <= 32 per fragment, B = the frames' 16 inputs of the group), tanh on the D fragments, which are parked in an
+// LDS image of the 16 frames' output rows [O][16 frames][F' x 2] (row stride + 4 floats: the 16 lanes of a column write 16 different bank
+// pairs); then every row leaves as coalesced 16-byte stores with c0p added on the way.  Wave w computes groups w, w + 4, ...
+// ---------------------------------------------------------------------------------------------------------------------
+#define DFX_DFO_THREADS 256
+struct DfxDfOutArgs {
+    const float *a, *a2;   // [R, G * Kg] operand (+ second addend or null)
+    const dfx_h8 *wf;      // [G][ceil(Ng / 16)][hi,lo][64]: fragment (g, u): lane (o = l & 15, q = l >> 4), element i = W[g][8 q + i][16 u + o], zero beyond Kg / Ng
+    const float *c0p;      // [B, O, T, Fd][2]
+    float *out;            // [B, O, T, Fd][2]
+    int64_t R, T;          // logical rows of this launch, frames per clip
+    int G, Kg, Ng, NO, Fd; // NO = 2 * O values per bin
+    float unscale;
+    DfxRowMap rm;
+    unsigned int *err;
+};
+#define DFX_DFO_SMEM(NO, Fd) ((size_t)((NO) / 2) * 16 * (2 * (Fd) + 4) * 4 + 16 * 8)
+
+__global__ void __launch_bounds__(DFX_DFO_THREADS, 2) dfx_k_df_out_h3(DfxDfOutArgs A) {
+    DFX_DYN_SMEM(float, img);   // [O][16][RS] then the 16 rows' (clip, frame)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
+    const int O = A.NO / 2, RS = 2 * A.Fd + 4, NU = (A.Ng + 15) >> 4, K = A.G * A.Kg;
+    int *rows = reinterpret_cast<int *>(img + (size_t)O * 16 * RS);   // [16][2]: clip, frame (-1: beyond R)
+    float amax = 0.f;
+    const int64_t ntiles = (A.R + 15) >> 4;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t m = tile * 16 + jl;
+        const bool live = m < A.R;
+        const int64_t r = live ? dfx_row(A.rm, m) : 0;
+        if (tid < 16) {
+            const uint32_t cb = (uint32_t)r / (uint32_t)A.T;
+            rows[2 * tid] = live ? (int)cb : -1;
+            rows[2 * tid + 1] = (int)((uint32_t)r - cb * (uint32_t)A.T);
+        }
+        // ---- compute: groups wave, wave + 4, ...; lane (frame jl, q) feeds k = 8 q .. 8 q + 7 of the group's Kg inputs
+        for (int g = wave; g < A.G; g += DFX_DFO_THREADS / 64) {
+            float x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = 0.f;
+            if (live && 8 * q < A.Kg) {   // (Kg % 8 == 0: host)
+                const float4 *p = reinterpret_cast<const float4 *>(A.a + r * K + g * A.Kg + 8 * q);
+                float4 v0 = p[0], v1 = p[1];
+                if (A.a2) {
+                    const float4 *p2 = reinterpret_cast<const float4 *>(A.a2 + r * K + g * A.Kg + 8 * q);
+                    const float4 w0 = p2[0], w1 = p2[1];
+                    v0 = make_float4(v0.x + w0.x, v0.y + w0.y, v0.z + w0.z, v0.w + w0.w);
+                    v1 = make_float4(v1.x + w1.x, v1.y + w1.y, v1.z + w1.z, v1.w + w1.w);
+                }
+                x[0] = v0.x, x[1] = v0.y, x[2] = v0.z, x[3] = v0.w, x[4] = v1.x, x[5] = v1.y, x[6] = v1.z, x[7] = v1.w;
+            }
+            dfx_h8 xh, xl;
+            dfx_split8_g(x, xh, xl, amax);
+            for (int u = 0; u < NU; ++u) {
+                const dfx_h8 wh = A.wf[(((size_t)g * NU + u) * 2 + 0) * 64 + lane], wl = A.wf[(((size_t)g * NU + u) * 2 + 1) * 64 + lane];
+                f32x4 d = dfx_mfma_16x16x32_f16(wl, xh, f32x4{0.f, 0.f, 0.f, 0.f});
+                d = dfx_mfma_16x16x32_f16(wh, xl, d);
+                d = dfx_mfma_16x16x32_f16(wh, xh, d);
+                // D: lane (frame jl, q) holds outputs 16 u + 4 q + r of the group = flat index o = g Ng + 16 u + 4 q + r -> (bin o / NO, value o % NO)
+#pragma unroll
+                for (int r2 = 0; r2 < 4; r2 += 2) {
+                    const int ol = 16 * u + 4 * q + r2;
+                    if (ol < A.Ng) {   // (Ng and NO even: a pair (re, im) never straddles)
+                        const int o = g * A.Ng + ol, f = o / A.NO, i = o - f * A.NO;
+                        *reinterpret_cast<float2 *>(img + ((size_t)(i >> 1) * 16 + jl) * RS + 2 * f) =
+                            make_float2(dfx_act(d[r2] * A.unscale, DFX_ACT_TANH), dfx_act(d[r2 + 1] * A.unscale, DFX_ACT_TANH));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- write-out: row (tap n, frame i) = 2 Fd floats, + c0p, coalesced 16-byte accesses (Fd even: rows are 16-byte multiples when Fd % 2 == 0)
+        const int F4 = A.Fd / 2;   // float4s per row
+        for (int idx = tid; idx < O * 16 * F4; idx += DFX_DFO_THREADS) {
+            const int row = idx / F4, c4 = idx - row * F4, n = row >> 4, i = row & 15;
+            const int cb = rows[2 * i];
+            if (cb < 0) continue;
+            const int64_t off = (((int64_t)cb * O + n) * A.T + rows[2 * i + 1]) * (2 * A.Fd) + 4 * c4;
+            const float4 v = *reinterpret_cast<const float4 *>(img + ((size_t)n * 16 + i) * RS + 4 * c4);
+            const float4 c = *reinterpret_cast<const float4 *>(A.c0p + off);
+            *reinterpret_cast<float4 *>(A.out + off) = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
+        }
+        __syncthreads();   // the image is rewritten by the next tile
+    }
+    if (amax >= DFX_H3_LIMIT && A.err) dfx_raise(A.err + 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
