@@ -2106,7 +2106,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     };
     // c = tanh(df_out(c)).view(b,t,F',2O) + c0p   (:329-330) of M rows; cfeat (+ cfeat2) is df_out's operand
     auto df_out_rows = [&](const float *cfeat, const float *cfeat2, int64_t M, hipStream_t st, DfxRowMap rm) -> int {
-        if (m->dfout_lean && m->dfo_nu > 0 && !m->exact_fp32 && M > 0 && R < ((int64_t)1 << 31)) {   // row-streaming form (dfx_k_df_out_h3)
+        if (m->dfout_lean && m->dfo_nu > 0 && !m->exact_fp32 && M > 0 && R * (int64_t)NO * Fd < ((int64_t)1 << 31)) {   // row-streaming form (dfx_k_df_out_h3)
             DfxDfOutArgs A;
             A.a = cfeat, A.a2 = cfeat2;
             A.wf = reinterpret_cast<const dfx_h8 *>(m->p(m->dfo_h3));

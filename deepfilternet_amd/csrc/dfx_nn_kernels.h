@@ -963,18 +963,23 @@ struct DfxCphArgs {
     int64_t feat_T = 0;       // as in DfxC01hArgs
 };
 
+// (Round 4: the fragments in LDS instead — 28 KB per workgroup, read where they are used — so that the kernel fits two waves per SIMD and one
+// wave's VALU work, ~310 instructions per tile, runs under the other's 42 matrix ops, was built again on the current tree and measured:
+// 256 registers + 94 spilled, 2.19 instead of 2.01 ms alone, the step +0.7 ms: profiles/r04_df_out_and_convp_lds.log.  Everything in registers,
+// one wave per SIMD, stays.)
 template <int C, int KT>
 __global__ void __launch_bounds__(256, 1) dfx_k_df_convp_h3(DfxCphArgs A) {
     constexpr int CPL = C / 4, NT = C / 16, KC = C >= 32 ? C / 32 : 1;
     static_assert(C % 32 == 0, "one k-chunk is 32 channels");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
-    dfx_h8 w0h[NT], w0l[NT], wh[KT][KC], wl[KT][KC];
     float4 bias0[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bias0[nt] = reinterpret_cast<const float4 *>(A.bias0)[4 * nt + q];
+    dfx_h8 w0h[NT], w0l[NT], wh[KT][KC], wl[KT][KC];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         w0h[nt] = A.w0f[(nt * 2 + 0) * 64 + lane];
         w0l[nt] = A.w0f[(nt * 2 + 1) * 64 + lane];
-        bias0[nt] = reinterpret_cast<const float4 *>(A.bias0)[4 * nt + q];
     }
 #pragma unroll
     for (int k = 0; k < KT; ++k)
@@ -1030,9 +1035,10 @@ __global__ void __launch_bounds__(256, 1) dfx_k_df_convp_h3(DfxCphArgs A) {
                         constexpr int sl = (ph + 1 + k) % KT;  // tap k reads frame t - (KT-1) + k
 #pragma unroll
                         for (int kc = 0; kc < KC; ++kc) {
-                            aa = dfx_mfma_16x16x32_f16(wl[k][kc], xh[sl][kc], aa);
-                            ab = dfx_mfma_16x16x32_f16(wh[k][kc], xl[sl][kc], ab);
-                            ac = dfx_mfma_16x16x32_f16(wh[k][kc], xh[sl][kc], ac);
+                            const dfx_h8 whk = wh[k][kc], wlk = wl[k][kc];
+                            aa = dfx_mfma_16x16x32_f16(wlk, xh[sl][kc], aa);
+                            ab = dfx_mfma_16x16x32_f16(whk, xl[sl][kc], ab);
+                            ac = dfx_mfma_16x16x32_f16(whk, xh[sl][kc], ac);
                         }
                     });
                     f32x4 acc;
@@ -2531,6 +2537,7 @@ __global__ void __launch_bounds__(DFX_GG_THREADS) dfx_k_ggemm(DfxGgArgs A) {
 // pairs); then every row leaves as coalesced 16-byte stores with c0p added on the way.  Wave w computes groups w, w + 4, ...
 // ---------------------------------------------------------------------------------------------------------------------
 #define DFX_DFO_THREADS 256
+#define DFX_DFO_NPT 16   /* most float4s of the tile's output rows a thread moves with the c0p values prefetched (more: loaded in the write-out loop) */
 struct DfxDfOutArgs {
     const float *a, *a2;   // [R, G * Kg] operand (+ second addend or null)
     const dfx_h8 *wf;      // [G][ceil(Ng / 16)][hi,lo][64]: fragment (g, u): lane (o = l & 15, q = l >> 4), element i = W[g][8 q + i][16 u + o], zero beyond Kg / Ng
@@ -2551,6 +2558,8 @@ __global__ void __launch_bounds__(DFX_DFO_THREADS, 2) dfx_k_df_out_h3(DfxDfOutAr
     int *rows = reinterpret_cast<int *>(img + (size_t)O * 16 * RS);   // [16][2]: clip, frame (-1: beyond R)
     float amax = 0.f;
     const int64_t ntiles = (A.R + 15) >> 4;
+    const int F4 = A.Fd / 2, NP4 = O * 16 * F4;   // float4s per output row, float4s of a tile's output rows
+    const bool pre = NP4 <= DFX_DFO_NPT * DFX_DFO_THREADS;   // the c0p values of a tile are requested before its compute phase
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t m = tile * 16 + jl;
         const bool live = m < A.R;
@@ -2559,6 +2568,24 @@ __global__ void __launch_bounds__(DFX_DFO_THREADS, 2) dfx_k_df_out_h3(DfxDfOutAr
             const uint32_t cb = (uint32_t)r / (uint32_t)A.T;
             rows[2 * tid] = live ? (int)cb : -1;
             rows[2 * tid + 1] = (int)((uint32_t)r - cb * (uint32_t)A.T);
+        }
+        __syncthreads();
+        // ---- this thread's pieces of the write-out: element offsets (B * O * T * 2 Fd < 2^31: host) and, ahead of the compute phase, c0p
+        float4 cv[DFX_DFO_NPT];
+        unsigned off[DFX_DFO_NPT];
+#pragma unroll
+        for (int k = 0; k < DFX_DFO_NPT; ++k) {
+            const int idx = tid + DFX_DFO_THREADS * k;
+            off[k] = 0xffffffffu;
+            cv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pre && idx < NP4) {
+                const int row = idx / F4, c4 = idx - row * F4, n = row >> 4, i = row & 15;
+                const int cb = rows[2 * i];
+                if (cb >= 0) {
+                    off[k] = (((unsigned)cb * (unsigned)O + (unsigned)n) * (unsigned)A.T + (unsigned)rows[2 * i + 1]) * (unsigned)(2 * A.Fd) + 4u * (unsigned)c4;
+                    cv[k] = *reinterpret_cast<const float4 *>(A.c0p + off[k]);
+                }
+            }
         }
         // ---- compute: groups wave, wave + 4, ...; lane (frame jl, q) feeds k = 8 q .. 8 q + 7 of the group's Kg inputs
         for (int g = wave; g < A.G; g += DFX_DFO_THREADS / 64) {
@@ -2578,11 +2605,16 @@ __global__ void __launch_bounds__(DFX_DFO_THREADS, 2) dfx_k_df_out_h3(DfxDfOutAr
             }
             dfx_h8 xh, xl;
             dfx_split8_g(x, xh, xl, amax);
+            dfx_h8 wh = A.wf[(((size_t)g * NU) * 2 + 0) * 64 + lane], wl = A.wf[(((size_t)g * NU) * 2 + 1) * 64 + lane];
             for (int u = 0; u < NU; ++u) {
-                const dfx_h8 wh = A.wf[(((size_t)g * NU + u) * 2 + 0) * 64 + lane], wl = A.wf[(((size_t)g * NU + u) * 2 + 1) * 64 + lane];
-                f32x4 d = dfx_mfma_16x16x32_f16(wl, xh, f32x4{0.f, 0.f, 0.f, 0.f});
-                d = dfx_mfma_16x16x32_f16(wh, xl, d);
-                d = dfx_mfma_16x16x32_f16(wh, xh, d);
+                const dfx_h8 ch = wh, cl = wl;
+                if (u + 1 < NU) {   // the next tile's fragments are requested before this one's matrix ops
+                    wh = A.wf[(((size_t)g * NU + u + 1) * 2 + 0) * 64 + lane];
+                    wl = A.wf[(((size_t)g * NU + u + 1) * 2 + 1) * 64 + lane];
+                }
+                f32x4 d = dfx_mfma_16x16x32_f16(cl, xh, f32x4{0.f, 0.f, 0.f, 0.f});
+                d = dfx_mfma_16x16x32_f16(ch, xl, d);
+                d = dfx_mfma_16x16x32_f16(ch, xh, d);
                 // D: lane (frame jl, q) holds outputs 16 u + 4 q + r of the group = flat index o = g Ng + 16 u + 4 q + r -> (bin o / NO, value o % NO)
 #pragma unroll
                 for (int r2 = 0; r2 < 4; r2 += 2) {
@@ -2596,18 +2628,28 @@ __global__ void __launch_bounds__(DFX_DFO_THREADS, 2) dfx_k_df_out_h3(DfxDfOutAr
             }
         }
         __syncthreads();
-        // ---- write-out: row (tap n, frame i) = 2 Fd floats, + c0p, coalesced 16-byte accesses (Fd even: rows are 16-byte multiples when Fd % 2 == 0)
-        const int F4 = A.Fd / 2;   // float4s per row
-        for (int idx = tid; idx < O * 16 * F4; idx += DFX_DFO_THREADS) {
-            const int row = idx / F4, c4 = idx - row * F4, n = row >> 4, i = row & 15;
-            const int cb = rows[2 * i];
-            if (cb < 0) continue;
-            const int64_t off = (((int64_t)cb * O + n) * A.T + rows[2 * i + 1]) * (2 * A.Fd) + 4 * c4;
-            const float4 v = *reinterpret_cast<const float4 *>(img + ((size_t)n * 16 + i) * RS + 4 * c4);
-            const float4 c = *reinterpret_cast<const float4 *>(A.c0p + off);
-            *reinterpret_cast<float4 *>(A.out + off) = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
+        // ---- write-out: row (tap n, frame i) = 2 Fd floats, + c0p, coalesced 16-byte accesses
+        if (pre) {
+#pragma unroll
+            for (int k = 0; k < DFX_DFO_NPT; ++k) {
+                if (off[k] != 0xffffffffu) {
+                    const int idx = tid + DFX_DFO_THREADS * k, row = idx / F4, c4 = idx - row * F4;
+                    const float4 v = *reinterpret_cast<const float4 *>(img + (size_t)row * RS + 4 * c4);
+                    *reinterpret_cast<float4 *>(A.out + off[k]) = make_float4(v.x + cv[k].x, v.y + cv[k].y, v.z + cv[k].z, v.w + cv[k].w);
+                }
+            }
+        } else {
+            for (int idx = tid; idx < NP4; idx += DFX_DFO_THREADS) {
+                const int row = idx / F4, c4 = idx - row * F4, n = row >> 4, i = row & 15;
+                const int cb = rows[2 * i];
+                if (cb < 0) continue;
+                const int64_t o64 = (((int64_t)cb * O + n) * A.T + rows[2 * i + 1]) * (2 * A.Fd) + 4 * c4;
+                const float4 v = *reinterpret_cast<const float4 *>(img + (size_t)row * RS + 4 * c4);
+                const float4 c = *reinterpret_cast<const float4 *>(A.c0p + o64);
+                *reinterpret_cast<float4 *>(A.out + o64) = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
+            }
         }
-        __syncthreads();   // the image is rewritten by the next tile
+        __syncthreads();   // the image and the row table are rewritten by the next tile
     }
     if (amax >= DFX_H3_LIMIT && A.err) dfx_raise(A.err + 1);
 }
