@@ -3114,7 +3114,7 @@ extern "C" int dfx_stream_create(const dfx_model *m, const dfx_state *st, int64_
     s->model_ws = take((size_t)s->model_ws_bytes);
     {
         const char *ge = getenv("DFX_STREAM_GRAPH");
-        s->use_graph = !dfx_env_is_emulator() && ge && ge[0] == '1';  // opt-in: measured slower than plain launches
+        s->use_graph = !dfx_env_is_emulator() && ge && ge[0] == '1';  // opt-in: measured slower than plain launches (docs/measurements.md §9)
         if (s->use_graph)
             s->use_graph = hipStreamCreateWithFlags(&s->cs, hipStreamNonBlocking) == hipSuccess &&
                            hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming) == hipSuccess &&

@@ -1232,7 +1232,7 @@ static __device__ __forceinline__ void dfx_chain_load_w(const float *wt, const f
     }
 }
 
-// The same stage on the fp16-split matrix path: the pointwise C x C contraction runs as hi*hi + hi*lo + lo*hi on
+// The same stage on the fp16-split matrix path (docs/measurements.md §5a): the pointwise C x C contraction runs as hi*hi + hi*lo + lo*hi on
 // v_mfma_f32_16x16x32_f16 (3 * C/32 matrix ops of 16 cycles per 16 output channels instead of C/4 fp32 ops of 32 cycles: the fp32
 // form keeps the matrix pipe busy for more than half of these kernels' run time).  The depthwise taps stay fp32 on the VALU; u is
 // split on the fly; lane (pos, q) feeds channels (C/4)q + 8kc + i as element i of k-chunk kc, the host packs W accordingly (pack_pw_h3).

@@ -242,7 +242,7 @@ int dfx_model_forward(const dfx_model *m, const dfx_bands *bands, const float *s
  * Asynchronous: the call returns before the pass has run (y is valid once `stream` has caught up).  For passes of >= 16384 frames the
  * engine paces its own enqueue (DFX_ENQUEUE_AHEAD=1: off): the call first waits, on the host, until the previous pass of this handle
  * (dfx_enhance or dfx_model_forward) has drained, and it returns only when the encoder front of its own pass has run and the rest is
- * enqueued — packets queued ahead on the pass's hardware queues slow the kernels that are running.  One pass at a time
+ * enqueued — packets queued ahead on the pass's hardware queues slow the kernels that are running (docs/measurements.md §5e).  One pass at a time
  * per handle, as before; use one handle per concurrent caller. */
 int dfx_enhance_workspace_bytes(const dfx_model *m, const dfx_state *st, int64_t B, int64_t T, int pad, int64_t *bytes);
 int dfx_enhance(const dfx_model *m, const dfx_state *st, const float *x, int64_t B, int64_t T, int pad,

@@ -1,5 +1,5 @@
 """Range of the fp16-split ("fp16x3") matrix kernels — the default arithmetic of the GRU projections / recurrences and of the fused
-DF-encoder convolutions (x = hi + lo in f16, three f16 MFMA products, fp32 accumulation).
+DF-encoder convolutions (x = hi + lo in f16, three f16 MFMA products, fp32 accumulation; DESIGN.md §4, docs/measurements.md §5a).
 
 f16 covers 6e-5 .. 65504: inputs far outside O(1) must either keep fp32-like accuracy or fail loudly, never return garbage quietly:
   * the GRU input projections scale every activation row by a power of two before the split (any finite row is safe);

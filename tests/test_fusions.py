@@ -1,4 +1,4 @@
-"""Round-3 fusions of the GRU phase's side work: each fused kernel against the separate kernels it replaces (the switch
+"""Round-3 fusions of the GRU phase's side work (docs/measurements.md §5f): each fused kernel against the separate kernels it replaces (the switch
 DFX_FUSE_*=0 restores them) and against the oracle, on the DeepFilterNet3 shape whose group structure the fusions are written for, in the
 serial, the event-pipelined and (on the GPU) the persistent form of the GRU phase, with the skip connections that change what is fused."""
 import numpy as np
