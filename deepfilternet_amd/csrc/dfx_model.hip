@@ -1621,7 +1621,7 @@ static int launch_erb_tail(const dfx_model *m, const float *demb, const float *e
         const size_t smem = DFX_TAIL_SMEM(C);
         DFX_HIP(dfx_env_set_max_dyn_smem(e0 ? (const void *)dfx_k_erb_tail<C, false> : (const void *)dfx_k_erb_tail<C, true>, smem));
         DfxKScope ks(DFX_K_ERB_TAIL, s);
-        const dim3 grid((unsigned)nn_grid(dfx_ceil_div(R, DFX_TAIL_WAVES), 1));
+        const dim3 grid((unsigned)nn_grid(dfx_ceil_div(R, DFX_TAIL_WAVES), 1));   // (capped at 64 ... 128 workgroups: +0.1 ... +0.5 ms per step)
         if (e0) dfx_launch((dfx_k_erb_tail<C, false>), grid, dim3(64 * DFX_TAIL_WAVES), smem, s, A);
         else dfx_launch((dfx_k_erb_tail<C, true>), grid, dim3(64 * DFX_TAIL_WAVES), smem, s, A);
         DFX_LAUNCH_CHECK();
@@ -2183,8 +2183,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // measured at batch 256 x 1002 frames (ms per step): 8 body chunks + ramp from 32: 21.28; 12 + 16: 21.91; 12, no ramp: 21.47;
         // 6 + 32: 21.35; 4 + 32: 22.45; 16 + 16: 22.69 (the event-based form: 22.07); after the decoder convolutions went to the
         // staged fp16-split kernels (lighter background): 8 + 32: 20.1; 10 + 32: 19.85; 12 + 32: 19.99; 12 + 16: 20.27; 16 + 32: 21.0
-        static const int ramp0 = [] { const char *e = getenv("DFX_SEQ_RAMP"); return e ? atoi(e) : 32; }();
-        static const int kbody = [] { const char *e = getenv("DFX_SEQ_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 10; }();
+        // round 4, after e0 / c1 / the grouped-GEMM df_out left the phase (lighter side work, shorter hand-overs), same-box A/B: 10 + ramp 32: 14.47;
+        // 12 uniform chunks, no ramp: 14.12; 13: 14.17; 14: 14.14; 12 + ramp 48: 14.20; 15 + 48: 14.27; 16: 15.1 (chunks of < 16384 rows take the
+        // small-launch forms of the fan-out kernels) -> 12 uniform chunks
+        static const int ramp0 = [] { const char *e = getenv("DFX_SEQ_RAMP"); return e ? atoi(e) : 0; }();
+        static const int kbody = [] { const char *e = getenv("DFX_SEQ_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 12; }();
         const int64_t body = T / kbody > m->tchunk_min ? T / kbody : m->tchunk_min;   // uniform chunk length
         std::vector<int> sizes;
         int64_t left = T;
