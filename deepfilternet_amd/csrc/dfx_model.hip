@@ -1418,6 +1418,7 @@ static int launch_convp_h3(const dfx_model *m, const float *feat_spec, float *ou
         DFX_FAIL(DFX_ERR_UNSUPPORTED, "fp16-split df_convp needs conv_ch %% 32 == 0");
     } else {
         if (t_end < 0) t_end = T;
+        if (B * (feat_T > 0 ? feat_T : T) * Fd >= ((int64_t)1 << 29)) DFX_FAIL(DFX_ERR_UNSUPPORTED, "df_convp: batch too large for one launch (32-bit element offsets)");
         DfxCphArgs A;
         A.t_end = t_end;
         A.feat = feat_spec;

@@ -993,15 +993,44 @@ __global__ void __launch_bounds__(256, 1) dfx_k_df_convp_h3(DfxCphArgs A) {
     for (int r = 0; r < 4; ++r) biasr[r] = A.bias[4 * q + r];
     const int64_t nruns = A.B * A.nfb * A.nseg;
     float amax = 0.f;   // range guard of the f16 splits
-    for (int64_t run = (int64_t)blockIdx.x * 4 + wave; run < nruns; run += (int64_t)gridDim.x * 4) {
+    // Round 4: the run decomposition is WAVE-UNIFORM (clip, bin block, segment and every frame index live in scalar registers; the wave index
+    // goes through readfirstlane) and a lane adds its bin and its taps as 32-bit element offsets from the scalar base of its clip's frame — the
+    // per-lane 64-bit (clip, frame, bin) arithmetic and the division of the tap index by 3 at every patch load were ~40 % of the kernel's
+    // non-matrix instructions.  B * feat_T * Fd < 2^29 (checked by the host: 32-bit offsets).
+    const int Fd = A.Fd, T32 = (int)A.T, Lk = A.L;
+    const int fT = (int)(A.feat_T > 0 ? A.feat_T : A.T);
+    int toff[4], tdt[4], tdf[4];   // per lane and tap i: element offset (dt * Fd + df) from (frame, bin), dt, df; taps >= 9 are the padding of K = 16
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int tap = 4 * q + i, kt = tap / 3;
+        tdt[i] = tap < 9 ? kt - 2 + Lk : (1 << 20);   // (padding taps: a frame index that is never inside the clip)
+        tdf[i] = tap - 3 * kt - 1;
+        toff[i] = (kt - 2 + Lk) * Fd + tdf[i];
+    }
+    const float2 *feat2 = reinterpret_cast<const float2 *>(A.feat);
+    for (int64_t run = (int64_t)blockIdx.x * 4 + dfx_wave_uniform(wave); run < nruns; run += (int64_t)gridDim.x * 4) {
         const int seg = (int)(run % A.nseg);
         const int64_t rest = run / A.nseg;
         const int fb = (int)(rest % A.nfb);
         const int64_t b = rest / A.nfb;
         const int f = fb * 16 + jl;
-        const bool fvalid = f < A.Fd;
+        const bool fvalid = f < Fd;
         const int64_t t0 = A.t_begin + (int64_t)seg * A.tseg;
         const int64_t t1 = (t0 + A.tseg < A.t_end) ? t0 + A.tseg : A.t_end;
+        const unsigned cbase = (unsigned)b * (unsigned)fT * (unsigned)Fd;   // scalar
+        // the patch of frame t (scalar) and this lane's bin: four taps, zero outside the clip / the bins / the causal padding
+        auto patch = [&](int t, bool ok, float2 (&rw)[4]) {
+            const unsigned pbase = cbase + (unsigned)(t * Fd + f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int tin = t + tdt[i], fin = f + tdf[i];
+                // branch-free: a tap outside reads the clip's first element (always there) and is zeroed by a select — an exec-masked load is a
+                // save / branch / restore sequence per tap
+                const bool in = ok && tin - Lk >= 0 && tin < T32 && fin >= 0 && fin < Fd;
+                const float2 v = feat2[in ? pbase + (unsigned)toff[i] : cbase];
+                rw[i] = make_float2(in ? v.x : 0.f, in ? v.y : 0.f);
+            }
+        };
         dfx_h8 xh[KT][KC], xl[KT][KC];  // frame tau lives in slot (tau - t0) mod KT
         float2 raw[4];
         auto make_frame = [&](dfx_h8 (&dh)[KC], dfx_h8 (&dl)[KC], int64_t tau, const float2 (&rw)[4]) {
@@ -1014,10 +1043,10 @@ __global__ void __launch_bounds__(256, 1) dfx_k_df_convp_h3(DfxCphArgs A) {
         dfx_static_for<1, KT>([&](auto sc) {
             constexpr int sl = decltype(sc)::value;
             const int64_t tau = t0 - KT + sl;
-            dfx_c0_patch_load(A.feat, b, tau, f, fvalid && tau >= 0, A.T, A.Fd, A.L, q, raw, A.feat_T);
+            patch((int)tau, fvalid && tau >= 0, raw);
             make_frame(xh[sl], xl[sl], tau, raw);
         });
-        dfx_c0_patch_load(A.feat, b, t0, f, fvalid, A.T, A.Fd, A.L, q, raw, A.feat_T);
+        patch((int)t0, fvalid, raw);
         for (int64_t tb = t0; tb < t1; tb += KT) {
             dfx_static_for<0, KT>([&](auto pc) {
                 constexpr int ph = decltype(pc)::value;
@@ -1026,7 +1055,7 @@ __global__ void __launch_bounds__(256, 1) dfx_k_df_convp_h3(DfxCphArgs A) {
                     float2 cur[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) cur[i] = raw[i];
-                    dfx_c0_patch_load(A.feat, b, t + 1, f, fvalid && t + 1 < t1, A.T, A.Fd, A.L, q, raw, A.feat_T);
+                    patch((int)t + 1, fvalid && t + 1 < t1, raw);
                     make_frame(xh[ph], xl[ph], t, cur);
                     // three independent accumulation chains (one per product term), summed small-to-large at the end
                     f32x4 aa = f32x4{0.f, 0.f, 0.f, 0.f}, ab = aa, ac = aa;
