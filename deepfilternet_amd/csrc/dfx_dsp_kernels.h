@@ -1649,7 +1649,7 @@ struct DfxSynRowsArgs {
 #define DFX_SYNR_SMEM ((size_t)960 * 12 + (size_t)DFX_DSP_TEAMS * 482 * 8 + (size_t)2 * 480 * 4 + 512)
 
 template <int O, bool PF, bool I16 = false>
-__global__ void __launch_bounds__(DFX_DSP_THREADS, 6) dfx_k_synthesis_rows(DfxSynRowsArgs A) {
+__global__ void __launch_bounds__(DFX_DSP_THREADS, (PF && I16) ? 5 : 6) dfx_k_synthesis_rows(DfxSynRowsArgs A) {   // (post-filter + 16-bit output: two registers over the budget of six waves per SIMD)
     constexpr int M = 480, N = 960, HOP = 480, NTM = DFX_DSP_TEAMS, BUF = M + 2;
     DFX_DYN_SMEM(unsigned char, smem);
     float2 *tw = reinterpret_cast<float2 *>(smem);

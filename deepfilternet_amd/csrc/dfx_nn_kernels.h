@@ -1154,12 +1154,15 @@ __global__ void __launch_bounds__(256, REBUILD ? 1 : 2) dfx_k_df_convp_step(DfxC
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) dfx_split8_g(c0v + 8 * kc, xh[kc], xl[kc], amax);
             // consecutive matrix ops go to different sums (an op that waits for its predecessor's accumulator stalls for that op's latency)
+            int zoff = 0;
+            DFX_OPAQUE(zoff);   // the fragment loads are loop invariant: hoisted out of the run loop they are 80 registers (28 bytes of scratch at two waves per SIMD)
+            const dfx_h8 *wfl = A.wf + lane + zoff;
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
                 dfx_h8 wl[KT], wh[KT];
                 dfx_static_for<0, d + 1>([&](auto kcn) {
                     constexpr int k = decltype(kcn)::value;
-                    wl[k] = A.wf[((k * KC + kc) * 2 + 1) * 64 + lane], wh[k] = A.wf[((k * KC + kc) * 2 + 0) * 64 + lane];
+                    wl[k] = wfl[((k * KC + kc) * 2 + 1) * 64], wh[k] = wfl[((k * KC + kc) * 2 + 0) * 64];
                 });
                 dfx_static_for<0, d + 1>([&](auto kcn) { constexpr int k = decltype(kcn)::value; sa[d - k] = dfx_mfma_16x16x32_f16(wl[k], xh[kc], sa[d - k]); });
                 dfx_static_for<0, d + 1>([&](auto kcn) { constexpr int k = decltype(kcn)::value; sb[d - k] = dfx_mfma_16x16x32_f16(wh[k], xl[kc], sb[d - k]); });
@@ -1372,7 +1375,7 @@ static __host__ __device__ __forceinline__ bool dfx_pwf_ok(int C, int Fin, int F
 }
 
 template <int C, int MODE, bool SKIP, int NVI /* input float4s per lane and item: 4 or DFX_PWF_MAXV */, bool H3 = false>
-__global__ void __launch_bounds__(DFX_PW_THREADS, 2) dfx_k_pwconv_f(DfxPwArgs A) {
+__global__ void __launch_bounds__(DFX_PW_THREADS, (SKIP && NVI == DFX_PWF_MAXV) ? 1 : 2) dfx_k_pwconv_f(DfxPwArgs A) {   // (pathway + 8 loads in flight: 44 registers over the budget of two waves per SIMD; only the unfused decoder tail, DFX_FUSE_TAIL=0, runs that form)
     constexpr int NT = C / 16, CPL = C / 4, LD = C + 4, C4 = C / 4, KC = H3 ? C / 32 : 1;
     DFX_DYN_SMEM(float4, dfx_pwf_smem4);
     float4 *dws = dfx_pwf_smem4, *sks = dfx_pwf_smem4 + 3 * C4;
@@ -1404,9 +1407,15 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 2) dfx_k_pwconv_f(DfxPwArgs A)
     auto issue = [&](int64_t item) {
         const int64_t base = item * G;
         const DfxRowBase rb = dfx_row_base(A.rm, base);
+        // (the per-piece parts of an address — frame of the piece, its offset inside the frame — are loop invariant: hoisted as 64-bit values
+        // per piece they left the widest form of the kernel one register pair short: a scratch reload and a full vmcnt(0) in the middle of
+        // every item's loads.  Recomputed per item from an opaque copy of the lane index: a dozen instructions.)
+        int ln = lane;
+        DFX_OPAQUE(ln);
+        const float4 *xq = x4, *sq = s4;
 #pragma unroll
         for (int i = 0; i < NVI; ++i) {
-            const int idx = lane + 64 * i;
+            const int idx = ln + 64 * i;
             xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (SKIP) sr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (idx < nin4) {
@@ -1414,8 +1423,8 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 2) dfx_k_pwconv_f(DfxPwArgs A)
                 const int64_t rl = base + fr;
                 if (rl < A.R) {
                     const int64_t off = dfx_row_at(A.rm, base, rb, fr) * fin4 + (idx - fr * fin4);
-                    xr[i] = x4[off];
-                    if (SKIP) sr[i] = s4[off];
+                    xr[i] = xq[off];
+                    if (SKIP) sr[i] = sq[off];
                 }
             }
         }
@@ -2115,16 +2124,6 @@ __global__ void __launch_bounds__(64 * DFX_TAIL_WAVES, 1) dfx_k_erb_tail(DfxTail
                 }
             }
         }
-        float4 r0[NV0];   // e0, one 16-position tile at a time: tile 0 requested here (needed after convt2), tile 1 when tile 0 has been stored
-        auto issue_e0 = [&](int t) {
-            if (re0) return;   // (computed where it is stored: nothing to wait for)
-#pragma unroll
-            for (int i = 0; i < NV0; ++i) {
-                const int idx = lane + 64 * i;
-                r0[i] = idx < N0T ? p0[(r * 2 + t) * N0T + idx] : z4;
-            }
-        };
-        issue_e0(0);
         DFX_WAVE_SYNC();
         // ---- convt2: X[8, 16) -> += into Y[0, 16)
         dfx_chain_tile_h3_lds<C, DFX_PW_MODE_DWT3>(X + E4 * LD, E4, 2, 0, E1, dws + 3 * C4, wfr + DFX_TAIL_WFRAG(C), bis + C4, A.unscale[1], amax, lane,
@@ -2161,13 +2160,13 @@ __global__ void __launch_bounds__(64 * DFX_TAIL_WAVES, 1) dfx_k_erb_tail(DfxTail
                     const int idx = lane + 64 * i;
                     if (idx < N0T) {
                         const int row = idx / C4, c4 = idx - row * C4;
-                        *reinterpret_cast<float4 *>(X + row * LD + 4 * c4) = path(r0[i], a0, b0);
+                        // (e0 from HBM — DFX_E0_RECOMPUTE=0 or an encoder that is not fused — is read where it is used: requested a stage
+                        // ahead, its 16 registers were 48 bytes of scratch per lane at this kernel's three waves per SIMD)
+                        *reinterpret_cast<float4 *>(X + row * LD + 4 * c4) = path(p0[(r * 2 + t) * N0T + idx], a0, b0);
                     }
                 }
             }
-            if (t == 0) {
-                issue_e0(1);
-            } else {   // the next frame's first operands: in flight during this frame's last tile
+            if (t == 1) {   // the next frame's first operands: in flight during this frame's last tile
                 const int64_t next = rl + (int64_t)gridDim.x * DFX_TAIL_WAVES;
                 if (next < A.R) issue(dfx_row(A.rm, next));
             }
@@ -2198,7 +2197,8 @@ __global__ void __launch_bounds__(64 * DFX_TAIL_WAVES, 1) dfx_k_erb_tail(DfxTail
                 const int i = (p & 15) * 3 + j;
                 return (p < 16 ? Y : X)[(i >> 2) * LD + C + (i & 3)];
             };
-            const int f = lane;
+            int f = lane;
+            DFX_OPAQUE(f);   // (the three strip addresses below are loop invariant: recomputed per frame instead of held — or spilled — across the frame loop)
             float acc = A.bias_o + V(f, 1);
             if (f > 0) acc += V(f - 1, 0);
             if (f < E - 1) acc += V(f + 1, 2);
@@ -2730,19 +2730,28 @@ __global__ void __launch_bounds__(DFX_PJ_THREADS, 2) dfx_k_proj256(DfxPjArgs A) 
     const int64_t tstride = (int64_t)A.rgroups * NW;
     const float *wfrag = wl + q * LDW + jl;  // + (ks*4)*LDW + 16*nt
     const float4 *bias4 = reinterpret_cast<const float4 *>(A.bias + n0) + q;
-    auto load_tile = [&](float4 *dst, int64_t tl) {
+    // half h of a tile's rows (8 float4 per lane): the second half of the k range and the first are refilled separately (below)
+    auto load_half = [&](float4 *dst, int64_t tl, int h) {
         const int64_t m = tl * 16 + jl;
         if (MODE != 1 && tl < ntiles && m < A.M) {
-            const float4 *p = reinterpret_cast<const float4 *>(A.a + dfx_row(A.rm, m) * K + 64 * q);
+            const float4 *p = reinterpret_cast<const float4 *>(A.a + dfx_row(A.rm, m) * K + 64 * q) + 8 * h;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) dst[v] = p[v];
+            for (int v = 0; v < 8; ++v) dst[8 * h + v] = p[v];
         } else {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) dst[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int v = 0; v < 8; ++v) dst[8 * h + v] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
+    // One register buffer, refilled in halves while the matrix core works: the next tile's first 32 k values go into xv[0..8) as soon as
+    // k-step 31 has read them (8192 matrix cycles before they are needed), its last 32 after k-step 63.  (Two whole buffers — 128 registers —
+    // left the kernel 44 registers short of its two waves per SIMD: 176 bytes of scratch per lane.)
+    float4 xv[16];
+    int64_t tile = rg * NW + wave;
+    load_half(xv, tile, 0);
+    load_half(xv, tile, 1);
     // one 16-row tile: 64 k-steps x NT MFMAs; the W^T fragments of k-step ks+1 are read from LDS while k-step ks computes
-    auto do_tile = [&](const float4 *xv, int64_t tl) {
+    while (tile < ntiles) {
+        const int64_t next = tile + tstride;
         f32x4 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -2760,8 +2769,10 @@ __global__ void __launch_bounds__(DFX_PJ_THREADS, 2) dfx_k_proj256(DfxPjArgs A) 
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[MODE == 2 ? 0 : (ks & 1)][nt], xk, acc[nt], 0, 0, 0);
             DFX_SCHED_BARRIER();
+            if constexpr (ks == 31) load_half(xv, next, 0);
         });
-        const int64_t m = tl * 16 + jl;
+        load_half(xv, next, 1);
+        const int64_t m = tile * 16 + jl;
         if (m < A.M) {
             float4 *op = reinterpret_cast<float4 *>(A.out + dfx_row(A.rm, m) * A.N + n0 + 4 * q);
 #pragma unroll
@@ -2770,19 +2781,7 @@ __global__ void __launch_bounds__(DFX_PJ_THREADS, 2) dfx_k_proj256(DfxPjArgs A) 
                 op[4 * nt] = make_float4(acc[nt][0] + bz.x, acc[nt][1] + bz.y, acc[nt][2] + bz.z, acc[nt][3] + bz.w);
             }
         }
-    };
-    // two register buffers: the next tile's rows are in flight while the matrix core works on the current one
-    float4 xa[16], xb[16];
-    int64_t tile = rg * NW + wave;
-    load_tile(xa, tile);
-    while (tile < ntiles) {
-        load_tile(xb, tile + tstride);
-        do_tile(xa, tile);
-        tile += tstride;
-        if (tile >= ntiles) break;
-        load_tile(xa, tile + tstride);
-        do_tile(xb, tile);
-        tile += tstride;
+        tile = next;
     }
 }
 

@@ -106,3 +106,17 @@ def test_headers_are_plain_c_and_the_example_links(tmp_path):
     assert r.returncode == 2 and "usage" in r.stderr
     r = subprocess.run([str(exe), str(tmp_path / "missing.dfx")], capture_output=True, text=True, input="")
     assert r.returncode == 1 and "df_create failed" in r.stderr and "missing.dfx" in r.stderr
+
+
+def test_no_kernel_spills_registers():
+    """No kernel of the library uses scratch memory on gfx950: a spill in a hot loop is a memory round trip per iteration — and a `s_waitcnt vmcnt(0)`
+    in the middle of whatever loads are in flight (tools/dev/scratch_report.py reads the compiler's resource-usage remarks; hipcc cross-compiles)."""
+    import shutil
+    import subprocess
+    import sys
+
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dev", "scratch_report.py")
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
