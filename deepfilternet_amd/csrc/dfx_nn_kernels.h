@@ -963,6 +963,8 @@ struct DfxCphArgs {
     int64_t feat_T = 0;       // as in DfxC01hArgs
 };
 
+// (Two 16-bin blocks per wave side by side — two independent tiles in one instruction stream, df_conv0's fragments in LDS to make room for the
+// second window — was built and measured the same: 2.07 ms alone, 14.13 / 14.07 vs 14.10 / 14.17 ms per step.)
 // (Round 4: the fragments in LDS instead — 28 KB per workgroup, read where they are used — so that the kernel fits two waves per SIMD and one
 // wave's VALU work, ~310 instructions per tile, runs under the other's 42 matrix ops, was built again on the current tree and measured:
 // 256 registers + 94 spilled, 2.19 instead of 2.01 ms alone, the step +0.7 ms: profiles/r04_df_out_and_convp_lds.log.  Everything in registers,
@@ -987,6 +989,11 @@ __global__ void __launch_bounds__(256, 1) dfx_k_df_convp_h3(DfxCphArgs A) {
         for (int kc = 0; kc < KC; ++kc) {
             wh[k][kc] = A.wf[((k * KC + kc) * 2 + 0) * 64 + lane];
             wl[k][kc] = A.wf[((k * KC + kc) * 2 + 1) * 64 + lane];
+            // The 80 registers of df_convp's fragments are pinned in the accumulation half of the register file, where the matrix ops read them
+            // directly.  Left to the allocator they moved between the halves: 468 v_accvgpr copies among the 2605 vector instructions of the
+            // unrolled frame loop (32 of 2176 with the pin; the step 14.16-14.20 -> 13.93-14.06 ms).
+            DFX_PIN_AGPR(wh[k][kc]);
+            DFX_PIN_AGPR(wl[k][kc]);
         }
     float biasr[4];
 #pragma unroll
@@ -3658,6 +3665,9 @@ __global__ void __launch_bounds__(DFX_GRU_THREADS, 2) dfx_k_gru_rec(const float 
 #ifndef DFX_GH_ABLATE
 #define DFX_GH_ABLATE 0  /* dev ablations (tools/dev/gru_h3_bench.hip): 1 no stream refill, 2 no gi loads, 4 no matrix ops, 8 no gate math, 16 no y stores */
 #endif
+#ifndef DFX_GH_PIN
+#define DFX_GH_PIN 1
+#endif
 #ifndef DFX_GH_NW
 #define DFX_GH_NW 4      /* waves per workgroup: 4 (one per SIMD, 512 registers each) or 8 */
 #endif
@@ -3781,6 +3791,13 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
         if constexpr (SC.cls[f] == 0) {
             wr[SC.idx[f]][0] = wg[DFX_GH_GIDX(f)];
             wr[SC.idx[f]][1] = wg[DFX_GH_GIDX(f) + 64];
+            // The resident fragments live in the accumulation half of the register file, where the matrix ops read them directly: left to the
+            // allocator they were parked there anyway and copied back before every use — 190 v_accvgpr_read among the 619 vector instructions
+            // of a step (0 of 428 with the pin).  (Not the exact form: its matrix ops take single registers of a fragment and the pin spills.)
+            if constexpr (DFX_GH_PIN && !X32) {
+                DFX_PIN_AGPR(wr[SC.idx[f]][0]);
+                DFX_PIN_AGPR(wr[SC.idx[f]][1]);
+            }
         } else if constexpr (SC.cls[f] == 1) {
             wl[((SC.idx[f] * NW + wave) * 2 + 0) * 64 + lane] = wg[DFX_GH_GIDX(f)];
             wl[((SC.idx[f] * NW + wave) * 2 + 1) * 64 + lane] = wg[DFX_GH_GIDX(f) + 64];

@@ -125,6 +125,7 @@ static __device__ __forceinline__ f32x4 dfx_mfma_16x16x32_f16(dfx_h8 a, dfx_h8 b
 
 // compiler fences used by the hand-scheduled kernels
 #define DFX_OPAQUE(x) asm volatile("" : "+v"(x))
+#define DFX_PIN_AGPR(x) asm volatile("" : "+a"(x))   /* the value lives in an AGPR from here on (matrix-op operands of kernels with one wave per SIMD) */
 #define DFX_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #define DFX_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)   /* ask for n instructions of a class next (0x008 MFMA, 0x002 VALU) */
 // barrier + LDS visibility among the 64 lanes of ONE wave (LDS operations of a wave complete in order; the fences only pin the
