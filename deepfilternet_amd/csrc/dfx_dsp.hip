@@ -412,10 +412,8 @@ int dfx_launch_norm_scan(const float *erb_in, float *erb_out, int E, const float
     if (n <= 0) return DFX_OK;
     if ((erb_out_cs > 0 || spec_out_cs > 0) && T >= 16) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_launch_norm_scan: strided outputs are for calls of < 16 frames");
     DfxKScope ks(DFX_K_NORM_SCAN, s);
-    // four lanes per (row, channel) when there are frames to share (the frame-by-frame streaming runtime keeps one lane per channel);
-    // DFX_NORM_SCAN4=0: always one lane
-    const char *q4 = getenv("DFX_NORM_SCAN4");
-    if (T >= 16 && !(q4 && q4[0] == '0')) {
+    // four lanes per (row, channel) when there are frames to share (the frame-by-frame streaming runtime keeps one lane per channel)
+    if (T >= 16) {
         dfx_launch(dfx_k_norm_scan4, dim3((unsigned)dfx_ceil_div(4 * n, 256)), dim3(256), 0, s, erb_in, erb_out, E,
                    reinterpret_cast<const float2 *>(spec_in), spec_frame_stride, reinterpret_cast<float2 *>(spec_out), Fn, C,
                    T, alpha, erb_state, unit_state);
@@ -643,10 +641,8 @@ int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, 
     const int nbands = (gains && bands) ? bands->nb : 0;
     {
         const int64_t nd = nb_df, O = order, Tc = coef_T < 0 ? T : coef_T;
-        static const int force_flat = [] { const char *e = getenv("DFX_DFA_FLAT"); return e && e[0] == '1' ? 1 : 0; }();
         const bool rows_ok = spec_stride % 2 == 0 && out_stride % 2 == 0 && coef_layout != DFX_COEF_BTFO && nd % 2 == 0 && nd / 2 <= 64 &&
-                             nbands <= 64 && O <= 16 && !((uintptr_t)spec & 15) && !((uintptr_t)out & 15) && !((uintptr_t)coefs & 15) &&
-                             !(force_flat && spec_stride == F && out_stride == F);
+                             nbands <= 64 && O <= 16 && !((uintptr_t)spec & 15) && !((uintptr_t)out & 15) && !((uintptr_t)coefs & 15);
         if (rows_ok) {
             DfxDfrArgs R;
             R.spec = spec;
@@ -672,8 +668,7 @@ int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, 
             R.pf_ch = pf_rs_channels > 0 ? pf_rs_channels : 0;
             R.t_begin = (int)t_begin;
             R.t_end = (int)t_end;
-            static const int rpw_env = [] { const char *e = getenv("DFX_DFA_RPW"); return e ? atoi(e) : 0; }();
-            R.rpw = rpw_env > 0 ? rpw_env : 1;   // one frame per wave measured fastest (the O-1 extra rows a wave reads are L2 hits)
+            R.rpw = 1;   // one frame per wave measured fastest (6.2 TB/s vs 5.9 at 4 and 5.4 at 16: the O-1 extra rows a wave reads are L2 hits)
             R.chunks = (int)dfx_ceil_div(t_end - t_begin, R.rpw);
             R.zcols = (F + 1) / 2;
             if ((out_stride * 8) % 64 == 0) {   // 64-byte aligned output rows: complete the last sector of every row with zeros
@@ -681,11 +676,9 @@ int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, 
                 R.zcols = (int)(z < out_stride / 2 ? z : out_stride / 2);
             }
             R.items = dfx_ceil_div(B, 8) * 8 * dfx_ceil_div(R.chunks, 4);
-            // one workgroup per work item by default (DFX_DFA_WGS=n: a persistent grid of n workgroups per CU walking the items, measured
-            // slower: 0.54 vs 0.47 ms stand-alone, profiles/r02_dfa_bench.log)
-            static const int wg_per_cu = [] { const char *e = getenv("DFX_DFA_WGS"); return e ? atoi(e) : 0; }();
-            int64_t nblk = R.items;
-            if (wg_per_cu > 0 && nblk > (int64_t)dfx_env_num_cus() * wg_per_cu) nblk = (int64_t)dfx_env_num_cus() * wg_per_cu;
+            // one workgroup per work item (a persistent grid of n workgroups per CU walking the items measured slower: 0.54 vs 0.47 ms
+            // stand-alone, profiles/r02_dfa_bench.log)
+            const int64_t nblk = R.items;
             if (nblk > 0x7fffffff) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_df_apply: batch too large for one launch");
             const int np = ((F + 1) / 2 + 63) / 64;
             DfxKScope ks(DFX_K_DF_APPLY, s);
@@ -726,12 +719,7 @@ int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, 
     A.pf_beta = pf_beta;
     A.atten_lim = atten_lim;
     A.pf_ch = pf_rs_channels > 0 ? pf_rs_channels : 0;
-    static int rows_sel = 0;
-    if (!rows_sel) {
-        const char *e = getenv("DFX_DFA_ROWS");
-        rows_sel = (e && atoi(e) == 32) ? 32 : DFX_DFA_ROWS;
-    }
-    const int ROWS = rows_sel;
+    const int ROWS = DFX_DFA_ROWS;
     A.t_begin = (int)t_begin;
     A.t_end = (int)t_end;
     A.chunks = (int)dfx_ceil_div(t_end - t_begin, ROWS);
@@ -742,13 +730,8 @@ int dfx_launch_df_apply(const float *spec, const float *coefs, int coef_layout, 
     const size_t smem = al((size_t)(ROWS + order - 1) * nb_df * 8) + al((size_t)ROWS * (A.nb > 0 ? A.nb : 1) * 4) + al((size_t)F);
     if (smem > 160 * 1024) DFX_FAIL(DFX_ERR_UNSUPPORTED, "dfx_df_apply: nb_df*order too large for LDS staging (%zu B)", smem);
     DfxKScope ks(DFX_K_DF_APPLY, s);
-    if (ROWS == 32) {
-        if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_df_apply<32>, smem));
-        dfx_launch(dfx_k_df_apply<32>, dim3((unsigned)nblk), dim3(DFX_DFA_THREADS), smem, s, A);
-    } else {
-        if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_df_apply<16>, smem));
-        dfx_launch(dfx_k_df_apply<16>, dim3((unsigned)nblk), dim3(DFX_DFA_THREADS), smem, s, A);
-    }
+    if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_df_apply<DFX_DFA_ROWS>, smem));
+    dfx_launch(dfx_k_df_apply<DFX_DFA_ROWS>, dim3((unsigned)nblk), dim3(DFX_DFA_THREADS), smem, s, A);
     DFX_LAUNCH_CHECK();
     return DFX_OK;
 }

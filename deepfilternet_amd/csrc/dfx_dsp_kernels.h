@@ -1229,7 +1229,7 @@ __global__ void __launch_bounds__(256) dfx_k_norm_scan4(const float *erb_in, flo
 //                  coefficients, and the tap rows of X are L2 hits: the clip -> XCD mapping keeps a clip on one L2)
 // The coefficient layout is described by four strides (complex elements): BOTF, BTFO and the engine's own BTOF.
 // ---------------------------------------------------------------------------------------------------------------------
-#define DFX_DFA_ROWS 16  // default rows per workgroup (DFX_DFA_ROWS=32 in the environment selects the 32-row instantiation)
+#define DFX_DFA_ROWS 16  // rows per workgroup
 #define DFX_DFA_THREADS 256
 
 struct DfxDfaArgs {

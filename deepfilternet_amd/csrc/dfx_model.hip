@@ -139,7 +139,6 @@ struct DfxStreamCtx {
     float pf_beta;     // < 0: the model's setting
     float *out;        // [B, out_T, F][2]: local frame t of clip b is stored at frame t - out_toff
     int64_t out_T, out_toff;
-    bool serial;       // every kernel on the caller's stream (graph capture records a single-stream chain)
     const struct DfxGate *gate = nullptr;  // per-stream stage gating (one new frame per pass); null: every frame runs every stage
     int channels = 1;                      // > 1: consecutive streams are the channels of one multi-channel stream ...
     int reduce_mask = 0;                   // ... whose ERB masks are reduced over the channels: 0 none, 1 max, 2 mean (tract.rs:96-118,868-902)
@@ -385,14 +384,6 @@ __global__ void dfx_k_gate_finish(const unsigned char *flags, int *skip_counter,
     }
 }
 
-#ifndef DFX_HIPEMU
-__global__ void dfx_k_dev_spin(long long ticks) {
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-}
-#else
-__global__ void dfx_k_dev_spin(long long) {}
-#endif
 enum { EV_START = 0, EV_C0, EV_C1, EV_C0P, EV_EMB, EV_COEFS, EV_FRONT, EV_DONE, EV_XA, EV_MASK, EV_FIN };
 
 struct dfx_model {
@@ -1483,8 +1474,7 @@ static int launch_convp_step(const dfx_model *m, const float *feat_spec, float *
         A.err = m->d_err;
         A.nfb = (Fd + 15) / 16;
         A.nseg = 1, A.tseg = 1;
-        static const int per_cu = [] { const char *e = getenv("DFX_CONVP_STEP_WGS"); return e && atoi(e) > 0 ? atoi(e) : 8; }();
-        const int grid = nn_grid(dfx_ceil_div(B * A.nfb, 4), per_cu);
+        const int grid = nn_grid(dfx_ceil_div(B * A.nfb, 4), 8);
         DfxKScope ks(DFX_K_DF_CONVP, s);
         if (rebuild) dfx_launch((dfx_k_df_convp_step<C, KT, true>), dim3(grid), dim3(256), 0, s, A, reinterpret_cast<f32x4 *>(ring), slot, par, cnt);
         else dfx_launch((dfx_k_df_convp_step<C, KT, false>), dim3(grid), dim3(256), 0, s, A, reinterpret_cast<f32x4 *>(ring), slot, par, cnt);
@@ -1521,8 +1511,7 @@ static int launch_conv01_h3(const dfx_model *m, const PwW &w, const float *feat_
         A.unscale0 = m->c0_unscale;
         A.unscale = m->dfc1_unscale;
         A.err = m->d_err;
-        static const int c01_wgs = [] { const char *e = getenv("DFX_C01_WGS"); return e && atoi(e) > 0 ? atoi(e) : 3; }();   // dev: resident workgroups per CU
-        const int grid = nn_grid(dfx_ceil_div(B * (t_end - t_begin) * Fout, 64), c01_wgs * m->front_grain);
+        const int grid = nn_grid(dfx_ceil_div(B * (t_end - t_begin) * Fout, 64), 3 * m->front_grain);   // three resident workgroups per CU
         DfxKScope ks(DFX_K_PWCONV, s);
         dfx_launch(dfx_k_df_conv01_h3<C>, dim3(grid), dim3(DFX_PW_THREADS), 0, s, A);
         DFX_LAUNCH_CHECK();
@@ -1796,14 +1785,12 @@ static int launch_proj_h3(const dfx_model *m, const GruW &g, const float *a, flo
         return DFX_OK;
     }
     // few row blocks (a streaming hop): the 64-column chunks of W are dealt to `parts` workgroups per row block — one workgroup per CU
-    // (128 KB of LDS each) — so that the launch covers the chip instead of nblk CUs streaming all of W each (DFX_PROJ_PARTS=n: dev)
+    // (128 KB of LDS each) — so that the launch covers the chip instead of nblk CUs streaming all of W each
     {
-        static const int parts_env = [] { const char *e = getenv("DFX_PROJ_PARTS"); return e ? atoi(e) : 0; }();
         const int nch = N / DFX_PH_NC;
         int parts = 1;
         for (int d = 1; d <= nch; ++d)
             if (nch % d == 0 && nblk * d <= dfx_env_num_cus()) parts = d;
-        if (parts_env > 0 && nch % parts_env == 0) parts = parts_env;
         A.parts = parts;
     }
     DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_proj256_h3, DFX_PH_SMEM));
@@ -1948,12 +1935,12 @@ static int launch_gru_h3(const dfx_model *m, const GruW &g, const float *gi, flo
     A.unscale = g.whh_unscale;
     const bool x32 = m->exact_fp32;   // exact fp32 matrix ops over fp32 fragments (dfx_k_gru_rec_x32)
     if (x32) A.whf = reinterpret_cast<const dfx_h8 *>(m->p(g.whh_x32)), A.unscale = 1.f;
-    // XCDs a layer's workgroups are confined to (1, 2 or 4; 0 = plain grid).  Measured at batch 256 inside the pipeline: 4 -> -0.7 ms
-    // per step (the W_hh lines a layer streams every step are shared by more workgroups per L2), 1 and 2 -> +1.3 ms (L2 bandwidth).
-    static const int xw = [] { const char *e = getenv("DFX_GRU_XCDS"); return e ? atoi(e) : 4; }();
+    // A layer's workgroups are confined to 4 XCDs.  Measured at batch 256 inside the event-based pipeline: -0.7 ms per step against a plain grid
+    // (the W_hh lines a layer streams every step are shared by more workgroups per L2); 1 and 2 XCDs +1.3 ms (L2 bandwidth).
+    constexpr int xw = 4;
     const int64_t groups = dfx_ceil_div(B, DFX_GH_ROWS);
     A.xcd_mask = 0;
-    if (layer >= 0 && (xw == 1 || xw == 2 || xw == 4) && groups <= 32 * xw) A.xcd_mask = (((1 << xw) - 1) << ((layer * xw) % 8)) & 0xff;
+    if (layer >= 0 && groups <= 32 * xw) A.xcd_mask = (((1 << xw) - 1) << ((layer * xw) % 8)) & 0xff;
     const int64_t nblk = A.xcd_mask ? dfx_ceil_div(groups, xw) * 8 : groups;
     DFX_HIP(dfx_env_set_max_dyn_smem(x32 ? (const void *)dfx_k_gru_rec_x32 : (const void *)dfx_k_gru_rec_h3, DFX_GH_SMEM));
     DfxKScope ks(DFX_K_GRU_REC, s);
@@ -2131,7 +2118,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     //   s : e0..e3 ----------------(join c1)-- fc_emb, enc GRU, emb, lsnr --+-- ERB decoder: GRU stack, convt3..conv0_out --(join coefs)-- df_apply
     //   x1: c0 -+- c1 ------------------------------------------------------+-- DF decoder: GRU stack, skip, (join c0p) df_out -> coefs
     //   x2:     +- df_convp -> c0p
-    const bool par = m->concurrent && !(sc && sc->serial);
+    const bool par = m->concurrent;
     hipStream_t x1 = par ? ln->aux[0] : s, x2 = par ? ln->aux[1] : s;
     auto signal = [&](int e, hipStream_t from) -> int {
         if (par) DFX_HIP(hipEventRecord(ln->ev[e], from));
@@ -2807,22 +2794,6 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                                    atten_lim, sc->out, s, t_begin, T, T, sc->out_T, sc->out_toff, sc->spec_stride, sc->spec_stride,
                                    sc->channels > 0 ? sc->channels : 1);
     }
-    {   // dev experiment: DFX_DEV_SPIN="<blocks>,<microseconds>" launches a spinning kernel in front of the deep filter
-        static const char *sp = getenv("DFX_DEV_SPIN");
-        if (sp && sp[0] == 'd') {  // "d": the deep filter twice in a row (is the second launch as slow as the first?)
-            if ((rc = dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, Fd, O, c.df_lookahead,
-                                          c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, fin_s, 0, -1, -1, -1, 0, sstride, sstride)))
-                return rc;
-        } else if (sp && sp[0] == 'c') {  // "c<MB>": a device copy spec -> spec_e of that many MB first (spec_e is overwritten afterwards anyway)
-            const size_t mb = (size_t)atoi(sp + 1);
-            const char *xr = strchr(sp, 'x');
-            for (int r = 0; r < (xr ? atoi(xr + 1) : 1); ++r) (void)hipMemcpyAsync(spec_e, spec, mb << 20, hipMemcpyDeviceToDevice, fin_s);
-        } else if (sp) {
-            int blocks = 1, us = 0;
-            sscanf(sp, "%d,%d", &blocks, &us);
-            dfx_launch(dfx_k_dev_spin, dim3((unsigned)blocks), dim3(64), 0, fin_s, (long long)us * 100);  // wall_clock64 ticks at 100 MHz
-        }
-    }
     // enhance(): the deep filter + gains are applied on the way into the inverse transform (dfx_k_synthesis_rows): spec_e never exists.
     // DFX_FUSE_DFA=0: dfx_k_df_apply_rows -> spec_e -> dfx_k_synthesis (the stand-alone deep-filter kernel stays the API of
     // dfx_model_forward / dfx_df_apply and the roofline kernel of bench.py)
@@ -2905,11 +2876,10 @@ extern "C" int dfx_model_forward(const dfx_model *m, const dfx_bands *bands, con
 // row stride (complex elements) of enhance()'s spec / spec_e buffers: F rounded up to a multiple of 8 = rows that start on a
 // 64-byte boundary (F = 481 -> 488): every access of the row-streaming deep-filter kernel is then a 16-byte access inside whole
 // 64-byte sectors.  Measured (tools/dev/dfa_bench.hip, profiles/r02_dfa_bench.log): stride 481 (flat-stream kernel) 4.9 TB/s,
-// 482 -> 6.0, 488 / 496 / 512 -> 6.2 TB/s.  (DFX_SPEC_PAD=0: dense rows and the flat-stream kernel, for A/B measurements)
+// 482 -> 6.0, 488 / 496 / 512 -> 6.2 TB/s.
 static inline int64_t enh_spec_stride(const dfx_state *st) {
-    static const bool pad = [] { const char *e = getenv("DFX_SPEC_PAD"); return !(e && e[0] == '0'); }();
     const int64_t F = (int64_t)st->N / 2 + 1;
-    return pad ? (F + 7) & ~(int64_t)7 : F;
+    return (F + 7) & ~(int64_t)7;
 }
 namespace {
 struct EnhWs {
@@ -3013,19 +2983,8 @@ struct dfx_stream_state {
     size_t g_flags = 0, g_counter = 0, g_sh_erb = 0, g_sh_unit = 0, g_sh_h = 0, g_c0_win = 0, g_mask = 0, g_coefs = 0, gate_bytes = 0;
     size_t g_pend2 = 0, g_par = 0, g_cnt = 0;   // pending-sum form of the gated df_convp (g_pend2_ok; then g_c0_win is not allocated)
     bool g_pend2_ok = false;
-    // DFX_STREAM_GRAPH=1: steady-state calls are replayed from a hipGraph (one per memory parity) captured as a single-stream chain on
-    // handle-owned I/O buffers (x / y are copied in and out around it).  Off by default: on ROCm 7.2 the replay of the ~35 kernel
-    // nodes takes 2.0-2.2 ms per call where the plain three-stream launches take 1.4-1.6 ms.
-    struct Graph {
-        hipGraphExec_t exec = nullptr;
-        int64_t n = 0;
-        float lim = 0.f, pf_beta = 0.f;
-    } graph[2];
-    size_t x_in = 0, y_out = 0, lsnr_out = 0;
-    bool use_graph = false;
-    hipStream_t cs = nullptr;          // capture / replay stream (the caller's stream may be the legacy default stream, which cannot capture)
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    bool capturing = false;
+    // (Replaying a steady-state call from a hipGraph was built in round 1 and removed in round 4: on ROCm 7.2 the replay of the hop's kernel nodes
+    // took 2.0-2.2 ms per call where plain launches take 0.4.)
 };
 
 static int stream_copy_rows(const float *src, int64_t src_stride, int64_t src_len, int64_t src_off, float *dst, int64_t dst_stride,
@@ -3111,19 +3070,8 @@ extern "C" int dfx_stream_create(const dfx_model *m, const dfx_state *st, int64_
         }
     }
     s->lsnr = take((size_t)B * (H + n) * 4);
-    s->x_in = take((size_t)B * n * st->hop * 4);
-    s->y_out = take((size_t)B * n * st->hop * 4);
-    s->lsnr_out = take((size_t)B * n * 4);
     dfx_model_workspace_bytes(m, B, H + n, &s->model_ws_bytes);
     s->model_ws = take((size_t)s->model_ws_bytes);
-    {
-        const char *ge = getenv("DFX_STREAM_GRAPH");
-        s->use_graph = !dfx_env_is_emulator() && ge && ge[0] == '1';  // opt-in: measured slower than plain launches (docs/measurements.md §9)
-        if (s->use_graph)
-            s->use_graph = hipStreamCreateWithFlags(&s->cs, hipStreamNonBlocking) == hipSuccess &&
-                           hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming) == hipSuccess &&
-                           hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming) == hipSuccess;
-    }
     s->bytes = off;
     if (hipMalloc(reinterpret_cast<void **>(&s->buf), s->bytes) != hipSuccess) {
         delete s;
@@ -3139,11 +3087,6 @@ extern "C" int dfx_stream_create(const dfx_model *m, const dfx_state *st, int64_
 
 extern "C" void dfx_stream_free(dfx_stream_state *s) {
     if (!s) return;
-    for (auto &g : s->graph)
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    if (s->cs) (void)hipStreamDestroy(s->cs);
-    if (s->ev_in) (void)hipEventDestroy(s->ev_in);
-    if (s->ev_out) (void)hipEventDestroy(s->ev_out);
     if (s->buf) (void)hipFree(s->buf);
     if (s->gate_buf) (void)hipFree(s->gate_buf);
     delete s;
@@ -3227,8 +3170,7 @@ extern "C" int dfx_stream_set_gating(dfx_stream_state *s, int enable) {
         s->g_sh_h = take((size_t)s->layers * B * 256 * 4);
         {   // df_convp's state of a gated handle: pending sums (fp16-split models; 2 x what the ungated handle keeps) or the window of c0 frames
             const int kt = c.df_pathway_kernel_size_t;
-            static const bool pend_env = [] { const char *e = getenv("DFX_GATE_PEND"); return !(e && e[0] == '0'); }();
-            s->g_pend2_ok = pend_env && kt >= 2 && kt <= 5 && c.conv_ch % 32 == 0 && s->m->fuse_c0 && !s->m->exact_fp32 && s->m->cp_h3;
+            s->g_pend2_ok = kt >= 2 && kt <= 5 && c.conv_ch % 32 == 0 && s->m->fuse_c0 && !s->m->exact_fp32 && s->m->cp_h3;
             if (s->g_pend2_ok) {
                 s->g_pend2 = take((size_t)B * 2 * (kt - 1) * ((c.nb_df + 15) / 16) * 64 * 16);
                 s->g_par = take((size_t)B);
@@ -3286,8 +3228,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     // ---- rolling spectra: linear (sliding window, see dfx_stream_state::spec_lin) or ring.  spec_window() brings the form this call uses
     // up to date with the other one if that one holds the state, appends the call's new frames and returns the window [Hs + n frames]
     // and the clip stride (in frames) the deep filter has to use.
-    static const bool gate_lin_env = [] { const char *e = getenv("DFX_GATE_LINEAR"); return !(e && e[0] == '0'); }();
-    const bool lin = S->lin_cap > 0 && !(gated && !gate_lin_env) && !S->use_graph && !S->capturing;
+    const bool lin = S->lin_cap > 0;
     const int64_t Fp = S->Fp, F2 = Fp * 2;   // the handle's spectra have rows of Fp >= F bins
     // The feature windows of the encoder take the same form when the kernels that read them accept a clip stride (the fp16-split DF
     // encoder: DfxC01hArgs::feat_T): [B, feat_cap, E] and [B, feat_cap, Fd, 2] with the same slack as the spectra, so that all three
@@ -3414,7 +3355,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     // other buffer (DFX_STREAM_STEP=0: the projection and the recurrence kernel of the batch path, in place)
     static const bool step_env = [] { const char *e = getenv("DFX_STREAM_STEP"); return !(e && e[0] == '0'); }();
     const int64_t skip_early = S->frames < L ? ((L - S->frames) < n ? (L - S->frames) : n) : 0;
-    const bool step_all = step_env && n - skip_early == 1 && !S->capturing && !S->use_graph;
+    const bool step_all = step_env && n - skip_early == 1;
     if (gated) {
         // silent-input shortcut (tract.rs:513-525) + a copy of the in-place state, so that the streams that turn out not to advance
         // (frozen, or a decoder stage skipped) can be given their state back after the pass
@@ -3432,7 +3373,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
     // only the final deep filter or the NEXT call needs (the spectrum window, the analysis memory) behind df_convp on its stream
     // (DfxStreamCtx::df_post) — in front of the encoder these four small launches were 40 us of a 520 us hop at 4096 streams
     static const bool side_env = [] { const char *e = getenv("DFX_STREAM_SIDE"); return !(e && e[0] == '0'); }();
-    const bool side = side_env && !S->capturing && !S->use_graph;   // (either form of the windows: the ring steps are deferred like the copies)
+    const bool side = side_env;   // (either form of the windows: the ring steps are deferred like the copies)
     if ((rc = dfx_launch_analysis(st, x, B, n * hop, xs, am_in, side ? nullptr : am_out, new_spec, new_fe, s, -1, Fp))) return rc;
     // ---- windows: [history ; new].  Net position p uses the features of hop p + L, so the hops of this call are the positions
     // a0 - L .. a0 + n - 1 - L; positions < 0 do not exist: their features are zero for the taps of later positions (the causal
@@ -3468,8 +3409,7 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         }
         fe_win = Lfe + S->lin_pos * E1, fs_win = Lfs + S->lin_pos * D2;
         feat_T = capf;
-        static const bool direct_env = [] { const char *e = getenv("DFX_STREAM_NORM_DIRECT"); return !(e && e[0] == '0'); }();
-        if (n < 16 && direct_env) {   // the norms write the new frames straight into the windows (no append copies)
+        if (n < 16) {   // the norms write the new frames straight into the windows (no append copies)
             norm_fe = Lfe + (S->lin_pos + H) * E1, norm_fs = Lfs + (S->lin_pos + H) * D2;
             norm_fe_cs = capf * E1, norm_fs_cs = capf * D2;
         } else {
@@ -3533,7 +3473,6 @@ static int stream_body(dfx_stream_state *S, const float *x, int64_t n, float *y,
         sc.out = out_spec;  // local frame t of clip b lands at out_spec[(b*n + t - H) * Fp]
         sc.out_T = n;
         sc.out_toff = H;
-        sc.serial = S->capturing;
         sc.channels = S->channels;
         sc.reduce_mask = S->reduce_mask;
         DfxGate gate;
@@ -3628,7 +3567,7 @@ extern "C" int dfx_stream_process(dfx_stream_state *S, const float *x, int64_t n
 }
 static int stream_process_impl(dfx_stream_state *S, const float *x, int64_t n, float *y, float *lsnr_out, hipStream_t s) {
     const bool advances = S->lim != 1.f;  // the pass-through case (tract.rs:540-543) moves the STFT memory and the rolling spectra only
-    const int64_t hop = S->st->hop, B = S->B;
+    const int64_t hop = S->st->hop;
     if (S->gated && S->gate_buf) {  // one hop per pass: the stage decisions of hop i shape the state hop i+1 starts from
         for (int64_t i = 0; i < n; ++i) {
             if (int rc = stream_body(S, x + i * hop, 1, y + i * hop, lsnr_out ? lsnr_out + i : nullptr, s, n * hop, n * hop, n)) return rc;
@@ -3636,52 +3575,6 @@ static int stream_process_impl(dfx_stream_state *S, const float *x, int64_t n, f
             S->flip ^= 1;
         }
         return DFX_OK;
-    }
-    // steady state (every history frame is a real frame): replay the call from a graph
-    if (S->use_graph && advances && S->channels == 1 && S->frames >= S->H + S->L) {
-        auto fp = [&](size_t o) { return reinterpret_cast<float *>(S->buf + o); };
-        dfx_stream_state::Graph &g = S->graph[S->flip];
-        const float beta = S->pf_beta;
-        if (g.exec && (g.n != n || g.lim != S->lim || g.pf_beta != beta)) {
-            (void)hipGraphExecDestroy(g.exec);
-            g.exec = nullptr;
-        }
-        if (!g.exec) {
-            hipGraph_t graph = nullptr;
-            const hipError_t eb = hipStreamBeginCapture(S->cs, hipStreamCaptureModeRelaxed);
-            if (eb == hipSuccess) {
-                S->capturing = true;
-                const int rc = stream_body(S, fp(S->x_in), n, fp(S->y_out), fp(S->lsnr_out), S->cs);
-                S->capturing = false;
-                const hipError_t e = hipStreamEndCapture(S->cs, &graph);
-                if (rc == DFX_OK && e == hipSuccess && graph && hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-                    g.n = n;
-                    g.lim = S->lim;
-                    g.pf_beta = beta;
-                } else {
-                    g.exec = nullptr;
-                    S->use_graph = false;  // capture is not available here: plain launches from now on
-                }
-                if (graph) (void)hipGraphDestroy(graph);
-                (void)hipGetLastError();
-            } else {
-                S->use_graph = false;
-                (void)hipGetLastError();
-            }
-        }
-        if (g.exec) {
-            DFX_HIP(hipEventRecord(S->ev_in, s));  // fork from the caller's stream ...
-            DFX_HIP(hipStreamWaitEvent(S->cs, S->ev_in, 0));
-            DFX_HIP(hipMemcpyAsync(fp(S->x_in), x, (size_t)B * n * hop * 4, hipMemcpyDeviceToDevice, S->cs));
-            DFX_HIP(hipGraphLaunch(g.exec, S->cs));
-            DFX_HIP(hipMemcpyAsync(y, fp(S->y_out), (size_t)B * n * hop * 4, hipMemcpyDeviceToDevice, S->cs));
-            if (lsnr_out) DFX_HIP(hipMemcpyAsync(lsnr_out, fp(S->lsnr_out), (size_t)B * n * 4, hipMemcpyDeviceToDevice, S->cs));
-            DFX_HIP(hipEventRecord(S->ev_out, S->cs));  // ... and join it again
-            DFX_HIP(hipStreamWaitEvent(s, S->ev_out, 0));
-            S->frames += n;
-            S->flip ^= 1;
-            return DFX_OK;
-        }
     }
     if (int rc = stream_body(S, x, n, y, lsnr_out, s)) return rc;
     if (advances) S->frames += n;
@@ -3763,7 +3656,6 @@ extern "C" int dfx_stream_process_raw(dfx_stream_state *S, const float *spec, fl
         sc.out = fp(S->out_spec);  // the deep-filter kernel still runs (on whatever the spectrum window holds); its output is not used
         sc.out_T = n;
         sc.out_toff = H;
-        sc.serial = false;
         sc.channels = S->channels;
         sc.reduce_mask = S->reduce_mask;
         DfxGate gate;
