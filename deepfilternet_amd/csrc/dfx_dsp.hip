@@ -351,7 +351,6 @@ int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t 
                         int64_t spec_stride, bool x_i16) {
     if (x_i16 && (mem_in || mem_out)) DFX_FAIL(DFX_ERR_INVALID_ARG, "analysis of 16-bit PCM input carries no memories (whole rows only)");
     const int64_t Tf = T / st->hop;
-    const int ML = st->N - st->hop;
     if (B > 0 && Tf > 0) {
         DfxAnaArgs A;
         A.x = x;
