@@ -105,8 +105,8 @@ def cpu_baseline(p, sd, clips: int, seconds: float) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
     ap.add_argument("--seconds", type=float, default=10.0, help="clip length")
     ap.add_argument("--model", default="df3", choices=["df3", "defaults"])
