@@ -781,6 +781,7 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 3) dfx_k_df_enc_h3(DfxDfEncArg
     __shared__ dfx_h8 wps[NT * KC * 2 * 64];
     __shared__ dfx_h8 w0s[NT * 2 * 64];   // df_conv0's fragments: read where they are used (in registers they are 32 of the 168 a wave may have)
     __shared__ __attribute__((aligned(16))) int tis[4 * DFX_PW_THREADS];
+    __shared__ float4 uns[NT * DFX_PW_THREADS];   // lane-private: the carried first term of the next bin's depthwise sum (below)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
     for (int i = tid; i < 3 * C4; i += DFX_PW_THREADS) dws[i] = reinterpret_cast<const float4 *>(A.dw)[i];
     for (int i = tid; i < C4; i += DFX_PW_THREADS) {
@@ -820,8 +821,8 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 3) dfx_k_df_enc_h3(DfxDfEncArg
         const float2 *feat2 = reinterpret_cast<const float2 *>(A.feat);
         const unsigned cbase = b * (unsigned)fT * (unsigned)Fin;
         const unsigned row = b * (unsigned)T32 + (unsigned)t;
-        float2 raw[3][4];
-        auto issue = [&](int j, int fo) {   // patch j (input bin fo * stride + j - 1) of this lane's frame
+        float2 raw[2][4];   // taps 1 and 2 (and, before the first bin, tap 0 in raw[0])
+        auto issue_to = [&](float2 (&dst)[4], int j, int fo) {   // patch j (input bin fo * stride + j - 1) of this lane's frame
             const int fi = fo * A.stride + j - 1;
             const bool ok = live && fo < fo1 && fi >= 0 && fi < Fin;
             int zt = tid;
@@ -832,52 +833,81 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 3) dfx_k_df_enc_h3(DfxDfEncArg
                 const int tin = t + (tinfo[i] & 0xff) - 64, fin = fi + ((tinfo[i] >> 8) & 0xff) - 1;
                 float2 v = make_float2(0.f, 0.f);
                 if (ok && (tinfo[i] >> 16) && tin - Lk >= 0 && tin < T32 && fin >= 0 && fin < Fin) v = feat2[cbase + (unsigned)(tin * Fin + fin)];
-                raw[j][i] = v;
+                dst[i] = v;
             }
         };
+        // One c0 tile (input bin fo * stride + j - 1 of this lane's frame): its patch -> split -> three products per 16 channels -> ReLU, added
+        // to the depthwise sum u with tap j's weight (ADD) and / or parked with tap 0's weight as the first term of the NEXT bin's sum (NEXT).
+        // With stride 2 (the host launches nothing else) the last tap of output bin fo and the first tap of fo + 1 read the SAME c0 tile (input bin
+        // 2 fo + 1): it is computed once — two tiles per bin instead of three (24 instead of 36 of the bin's 67 matrix ops, a third of the patch loads, splits and
+        // epilogues).  The parked term is w0 * v = what `0 + w0 * v` is in the three-tile form: the same bits.  It waits in LDS, lane-private
+        // (16 registers the kernel does not have at three waves per SIMD).
+        auto c0_tile = [&](auto jc, auto addc, auto nextc, int fo, float2 (&rw)[4], float (&u)[CPL], bool refill) {
+            constexpr int j = decltype(jc)::value;
+            constexpr bool ADD = decltype(addc)::value, NEXT = decltype(nextc)::value;
+            float x[8];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) issue(j, fo0);
+            for (int i = 0; i < 4; ++i) x[2 * i] = rw[i].x, x[2 * i + 1] = rw[i].y;
+            const int fi = fo * A.stride + j - 1;
+            const bool keep = live && fi >= 0 && fi < Fin;
+            dfx_h8 ph, pl;
+            dfx_split8_g(x, ph, pl, amax);
+            if (refill) issue_to(rw, j, fo + 1);   // the patch registers are free again: the same patch of the next bin (beyond the last: zeros, no loads)
+            int z0 = 0;
+            DFX_OPAQUE(z0);     // (loop-invariant LDS reads: not to be hoisted back into registers)
+            dfx_h8 w0h[NT], w0l[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                w0h[nt] = w0s[(nt * 2 + 0) * 64 + lane + z0];
+                w0l[nt] = w0s[(nt * 2 + 1) * 64 + lane + z0];
+            }
+            f32x4 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(w0l[nt], ph, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(w0h[nt], pl, acc[nt]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(w0h[nt], ph, acc[nt]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 bz = b0s[4 * nt + q];
+                const float v0 = keep ? fmaxf(acc[nt][0] * A.unscale0 + bz.x, 0.f) : 0.f, v1 = keep ? fmaxf(acc[nt][1] * A.unscale0 + bz.y, 0.f) : 0.f;
+                const float v2 = keep ? fmaxf(acc[nt][2] * A.unscale0 + bz.z, 0.f) : 0.f, v3 = keep ? fmaxf(acc[nt][3] * A.unscale0 + bz.w, 0.f) : 0.f;
+                if constexpr (ADD) {
+                    const float4 w = dws[j * C4 + 4 * nt + q];
+                    u[4 * nt + 0] += w.x * v0;
+                    u[4 * nt + 1] += w.y * v1;
+                    u[4 * nt + 2] += w.z * v2;
+                    u[4 * nt + 3] += w.w * v3;
+                }
+                if constexpr (NEXT) {
+                    const float4 wn = dws[4 * nt + q];
+                    uns[nt * DFX_PW_THREADS + tid] = make_float4(0.f + wn.x * v0, 0.f + wn.y * v1, 0.f + wn.z * v2, 0.f + wn.w * v3);
+                }
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
         f32x4 accg = f32x4{0.f, 0.f, 0.f, 0.f};   // the fc group in progress: lane (frame, q) holds its outputs 4 q + r
         float ev[8];                              // emb_in features 16 (g & 1) + 4 q + r of the two groups of a linear_in group
         int ci = fo0 * KC;                        // k-chunk of the flattened (bin, channel) vector (wave-uniform)
+        {   // tap 0 of the part's first bin: the one tile nothing before it has computed
+            float none[CPL];
+            issue_to(raw[0], 0, fo0);
+            c0_tile(I0{}, std::false_type{}, std::true_type{}, fo0, raw[0], none, false);
+            issue_to(raw[0], 1, fo0);   // raw[0] / raw[1] carry taps 1 / 2 from here on
+            issue_to(raw[1], 2, fo0);
+        }
         for (int fo = fo0; fo < fo1; ++fo) {
             float u[CPL];
 #pragma unroll
-            for (int i = 0; i < CPL; ++i) u[i] = 0.f;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                float x[8];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) x[2 * i] = raw[j][i].x, x[2 * i + 1] = raw[j][i].y;
-                const int fi = fo * A.stride + j - 1;
-                const bool keep = live && fi >= 0 && fi < Fin;
-                dfx_h8 ph, pl;
-                dfx_split8_g(x, ph, pl, amax);
-                issue(j, fo + 1);   // raw[j] is free again: the same patch of the next bin (beyond the last: zeros, no loads)
-                int z0 = 0;
-                DFX_OPAQUE(z0);     // (loop-invariant LDS reads: not to be hoisted back into registers)
-                dfx_h8 w0h[NT], w0l[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    w0h[nt] = w0s[(nt * 2 + 0) * 64 + lane + z0];
-                    w0l[nt] = w0s[(nt * 2 + 1) * 64 + lane + z0];
-                }
-                f32x4 acc[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(w0l[nt], ph, f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(w0h[nt], pl, acc[nt]);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = dfx_mfma_16x16x32_f16(w0h[nt], ph, acc[nt]);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float4 bz = b0s[4 * nt + q], w = dws[j * C4 + 4 * nt + q];
-                    u[4 * nt + 0] += w.x * (keep ? fmaxf(acc[nt][0] * A.unscale0 + bz.x, 0.f) : 0.f);
-                    u[4 * nt + 1] += w.y * (keep ? fmaxf(acc[nt][1] * A.unscale0 + bz.y, 0.f) : 0.f);
-                    u[4 * nt + 2] += w.z * (keep ? fmaxf(acc[nt][2] * A.unscale0 + bz.z, 0.f) : 0.f);
-                    u[4 * nt + 3] += w.w * (keep ? fmaxf(acc[nt][3] * A.unscale0 + bz.w, 0.f) : 0.f);
-                }
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 c = uns[nt * DFX_PW_THREADS + tid];
+                u[4 * nt + 0] = c.x, u[4 * nt + 1] = c.y, u[4 * nt + 2] = c.z, u[4 * nt + 3] = c.w;
             }
+            c0_tile(I1{}, std::true_type{}, std::false_type{}, fo, raw[0], u, true);
+            c0_tile(I2{}, std::true_type{}, std::true_type{}, fo, raw[1], u, true);
             dfx_h8 uh[KC], ul[KC];
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) dfx_split8_g(u + 8 * kc, uh[kc], ul[kc], amax);
@@ -889,7 +919,10 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 3) dfx_k_df_enc_h3(DfxDfEncArg
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc, ++ci) {
                 // (this chunk's fc fragments are requested before the twelve matrix ops of the pointwise conv that produce its operand)
-                const dfx_h8 fh = A.wfc[((size_t)ci * 2 + 0) * 64 + lane], fl = A.wfc[((size_t)ci * 2 + 1) * 64 + lane];
+                int lz = lane;
+                DFX_OPAQUE(lz);   // (the lane's part of the address per chunk, not a pair of 64-bit lane pointers held across the tile loop)
+                const dfx_h8 *wfl_ = A.wfc + lz;
+                const dfx_h8 fh = wfl_[((size_t)ci * 2 + 0) * 64], fl = wfl_[((size_t)ci * 2 + 1) * 64];
                 float c1v[8];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -925,7 +958,8 @@ __global__ void __launch_bounds__(DFX_PW_THREADS, 3) dfx_k_df_enc_h3(DfxDfEncArg
                     if (g & 1) {   // with the previous group: one group of linear_in, k-index (q, i) <-> feature 16 (i >> 2) + 4 q + (i & 3)
                         ev[4] = v.x, ev[5] = v.y, ev[6] = v.z, ev[7] = v.w;
                         const int jg = g >> 1;
-                        const dfx_h8 ih = A.win[((size_t)jg * 2 + 0) * 64 + lane], il = A.win[((size_t)jg * 2 + 1) * 64 + lane];
+                        const dfx_h8 *wil_ = A.win + lane + zoff;
+                        const dfx_h8 ih = wil_[((size_t)jg * 2 + 0) * 64], il = wil_[((size_t)jg * 2 + 1) * 64];
                         dfx_h8 eh, el;
                         dfx_split8_g(ev, eh, el, amax);
                         f32x4 o = dfx_mfma_16x16x32_f16(il, eh, f32x4{0.f, 0.f, 0.f, 0.f});
