@@ -459,6 +459,7 @@ struct dfx_model {
     // df_conv0's output c0 is recomputed by its consumers instead of being stored when the pathway conv has the sliding-window kernel
     // (kt <= 5); DFX_FUSE_C0=0 restores the materialised c0 (dfx_k_conv_in_df -> dfx_k_pwconv / dfx_k_df_convp2).
     bool fuse_c0 = true;
+    bool c0_batch_unfused = false;   // exact mode: batch passes materialise c0 (below)
     // frame-resident ERB encoder head / decoder tail (dfx_k_erb_enc, dfx_k_erb_dec10); DFX_FUSE_ERB=0: layer-by-layer kernels
     bool fuse_erb = true;
     // persistent GRU phase (dfx_k_gru_seq): flag words [ready: 8][emb: 1][pad][done: 8 * DFX_SEQ_GMAX], monotonic over the model's life
@@ -1018,6 +1019,10 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         m->exact_fp32 = x && x[0] == '1';
         const char *f0 = getenv("DFX_FUSE_C0"), *fe = getenv("DFX_FUSE_ERB");
         m->fuse_c0 = !(f0 && f0[0] == '0') && m->cfg.df_pathway_kernel_size_t <= 5 && 2 * m->cfg.df_order <= 16;
+        // Exact mode, batch passes: c0 is written once and read by its two consumers instead of being recomputed by both — on fp32 matrix ops a c0
+        // tile is 20 ops of 32 cycles (3 of 16 on the fp16-split path), and the two recomputing kernels side by side are the exact front's 10 ms:
+        // 28.65 vs 29.45 ms per step (DFX_FUSE_C0=1 keeps the recomputing forms; the frame-by-frame runtime always uses them)
+        m->c0_batch_unfused = m->exact_fp32 && m->fuse_c0 && !f0;
         m->fuse_erb = !(fe && fe[0] == '0');
         const char *gq = getenv("DFX_GRU_SEQ");
         m->gru_seq = !(gq && gq[0] == '0') && !dfx_env_is_emulator();
@@ -1282,7 +1287,7 @@ Ws plan_ws(const dfx_model_cfg &c, bool fuse_c0, int64_t R, int64_t B = 0) {
 
 extern "C" int dfx_model_workspace_bytes(const dfx_model *m, int64_t B, int64_t T, int64_t *bytes) {
     if (!m || !bytes || B < 0 || T < 0) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_workspace_bytes: bad arguments");
-    *bytes = (int64_t)(plan_ws(m->cfg, m->fuse_c0, B * T, B).total * sizeof(float)) + 256;
+    *bytes = (int64_t)(plan_ws(m->cfg, m->fuse_c0 && !m->c0_batch_unfused, B * T, B).total * sizeof(float)) + 256;
     return DFX_OK;
 }
 
@@ -2043,7 +2048,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     const DfxRowMap rmw = sc ? DfxRowMap{T, T - t_begin, t_begin} : DfxRowMap{0, 0, 0};
     const int Lk = sc ? 0 : c.conv_lookahead;
     const int64_t t_zero = sc ? sc->t_zero : 0;
-    const Ws w = plan_ws(c, m->fuse_c0, R, B);
+    const Ws w = plan_ws(c, m->fuse_c0 && !m->c0_batch_unfused, R, B);
     const int64_t sstride = fin ? fin->spec_stride : 0;  // 0: dense rows of F bins
     hipStream_t fin_s = s;                               // stream of the finishing kernels (deep filter, synthesis)
     const int E = c.nb_erb, Fd = c.nb_df, O = c.df_order, NO = 2 * O, emb = C * E / 4, L = c.conv_lookahead;
@@ -2135,7 +2140,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     if (sc && sc->df_post && !post_behind_convp && (rc = sc->df_post(x1))) return rc;
     // ---- Encoder, DF branch on x1 (deepfilternet3.py:176-179).  By default c0 = df_conv0(feat_spec) never exists in HBM: its two
     // consumers (df_conv1 here, df_convp below) recompute the tiles they need from feat_spec on the matrix core.
-    const bool fuse_c0 = m->fuse_c0;
+    const bool fuse_c0 = m->fuse_c0 && !(m->c0_batch_unfused && !sc);
     if (sc && !fuse_c0) DFX_FAIL(DFX_ERR_UNSUPPORTED, "streaming needs the fused DF encoder (df_pathway_kernel_size_t <= 5, df_order <= 8, DFX_FUSE_C0 unset)");
     const float *cp_feat = fuse_c0 ? feat_spec : nullptr;
     const bool fuse_h3 = fuse_c0 && !m->exact_fp32 && C % 32 == 0 && m->cp_h3;  // fp16-split matrix ops (default)
