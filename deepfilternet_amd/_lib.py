@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.environ.get("DFX_LIBRARY") or os.path.join(_HERE, "csrc", "libdfx.so")
 
 DFX_OK = 0
+DFX_ERR_INVALID_ARG, DFX_ERR_UNSUPPORTED, DFX_ERR_HIP, DFX_ERR_NO_DEVICE, DFX_ERR_ALLOC = 1, 2, 3, 4, 5   # include/dfx.h:31-35
 _ERRNAMES = {1: "invalid argument", 2: "unsupported configuration", 3: "HIP runtime error", 4: "no HIP device",
              5: "allocation failed"}
 

@@ -238,10 +238,17 @@ class ModelParams:
 
         from . import _lib
 
+        try:
+            L = _lib.lib()
+        except Exception as e:  # noqa: BLE001  (no built / loadable libdfx.so on this host: say so instead of a bare loader error)
+            raise RuntimeError("deepfilternet_amd: cannot validate the configuration's kernel shapes without the native library "
+                               f"(csrc/libdfx.so; build it with `python -m deepfilternet_amd.build`): {e}") from e
         cfg, n = self.to_cfg(), ctypes.c_int64()
-        rc = _lib.lib().dfx_model_blob_floats(ctypes.byref(cfg), ctypes.byref(n))
+        rc = L.dfx_model_blob_floats(ctypes.byref(cfg), ctypes.byref(n))
+        if rc == _lib.DFX_ERR_INVALID_ARG:   # contradictory options (e.g. enc_concat with emb_gru_skip_enc): an invalid value, not a missing kernel
+            raise ValueError(f"deepfilternet_amd: invalid configuration: {L.dfx_last_error().decode()}")
         if rc != _lib.DFX_OK:
-            raise NotImplementedError(f"deepfilternet_amd: unsupported configuration: {_lib.lib().dfx_last_error().decode()}")
+            raise NotImplementedError(f"deepfilternet_amd: unsupported configuration: {L.dfx_last_error().decode()}")
 
 
 def _fix_legacy_sections(parser: ConfigParser) -> None:

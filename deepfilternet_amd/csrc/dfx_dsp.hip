@@ -338,7 +338,7 @@ static bool ana_in_place(const dfx_state *st) {
     return !off && pl.M == 480 && pl.nstage == 5 && pl.radix[0] == 4 && pl.radix[1] == 4 && pl.radix[2] == 2 && pl.radix[3] == 3 && pl.radix[4] == 5;
 }
 static size_t ana_smem_bytes(const dfx_state *st) {
-    return (size_t)st->N * 12 + (size_t)DFX_DSP_TEAMS * (ana_in_place(st) ? 1 : 2) * (size_t)(st->plan.M + 2) * 8 +
+    return (size_t)st->N * 12 + (size_t)DFX_DSP_TEAMS * (ana_in_place(st) ? (size_t)DFX_FFT480_BUF : 2 * (size_t)(st->plan.M + 2)) * 8 +   // (in place: one buffer per frame, with room for the transform's padded layout)
            (((size_t)(2 * st->nb + 1 + 3 * 64 + st->nb + 1 + DFX_DSP_TEAMS * 64) * 4 + 15) & ~(size_t)15);   // + the ERB band tables and segment sums (analysis)
 }
 static int grid_for(int64_t work_groups, int per_cu = 8) {

@@ -180,7 +180,21 @@ static __device__ __forceinline__ void dfx_dft5(float2 x0, float2 x1, float2 x2,
 // sync between the two halves costs nothing on the GPU and is what the CPU interpreter needs).  Same butterflies, same twiddles, same
 // order of operations as dfx_fft_pass_c — same bits — with half the LDS per frame: 3 workgroups per CU instead of 2 (the STFT kernels
 // wait on LDS / memory latencies for more than half of their wave-cycles; profiles/r02_pmc_stft_kernels.txt).
-template <int R, int SG, int M, int NCUR, int S>
+// PIN / POUT (round 5): the pass reads / writes the PADDED layout, element i at slot i + (i >> 3) (one float2 of padding per eight).  The autosort
+// passes write with a stride of S * R... elements: 8 float2 = 64 bytes in the first pass of the 8 x 6 x 10 plan — every lane of a ds_write_b64 in one
+// of two banks, a 32-way conflict — and 48 float2 in the second (8-way).  The counters of the round-4 kernels (profiles/
+// r05_pmc_side_kernels_start_of_round.txt) show the STFT kernels' LDS pipe 82 % busy with half of its active cycles bank conflicts.  Since a pass
+// reads everything before it writes anything, the layout may change inside a pass: the first pass reads the natural layout and writes the padded
+// one, the last reads padded and writes natural (unit stride either way) — nothing outside the transform sees the padding; the frame buffer is
+// DFX_FFT480_BUF slots long.  Every slot index stays `lane-dependent base + compile-time offset` (the j-dependent parts are multiples of 8 or are
+// folded into one base per residue), so the passes cost no extra address arithmetic per access.
+#define DFX_FFT480_BUF 544   /* float2 slots per in-place frame buffer: 480 + 59 of padding, rounded up to a multiple of 4 (16-byte carve) */
+template <int C>
+static __device__ __forceinline__ int dfx_pad_idx(int i0, int j) {   // slot of element i0 + C * j (C * j known after unrolling)
+    const int cj = C * j, rem = cj & 7;
+    return i0 + ((i0 + rem) >> 3) + cj + ((cj - rem) >> 3);
+}
+template <int R, int SG, int M, int NCUR, int S, bool PIN = false, bool POUT = false>
 static __device__ __forceinline__ void dfx_fft_pass_ip(float2 *x, const float2 *tw, int lane, bool active) {
     constexpr int m = NCUR / R, nbf = M / R, tws = (2 * M) / NCUR, NR = (nbf + DFX_DSP_TEAM - 1) / DFX_DSP_TEAM;
     float2 a[NR][R];
@@ -197,7 +211,7 @@ static __device__ __forceinline__ void dfx_fft_pass_ip(float2 *x, const float2 *
             const int b0 = lane + r * DFX_DSP_TEAM, b = full || b0 < nbf ? b0 : 0;
             const int p = b / S, q = b - p * S;
 #pragma unroll
-            for (int j = 0; j < R; ++j) a[r][j] = x[q + S * (p + m * j)];
+            for (int j = 0; j < R; ++j) a[r][j] = PIN ? x[dfx_pad_idx<S * m>(q + S * p, j)] : x[q + S * (p + m * j)];
             if constexpr (NCUR != R) {   // (the last pass has p = 0: every twiddle is 1)
 #pragma unroll
                 for (int j = 1; j < R; ++j) w[r][j - 1] = tw[j * p * tws];
@@ -282,15 +296,16 @@ static __device__ __forceinline__ void dfx_fft_pass_ip(float2 *x, const float2 *
                 o[2] = dfx_cadd(m2, n2);
                 o[3] = dfx_csub(m2, n2);
             }
-            x[q + S * (R * p)] = o[0];
+            auto slot = [&](int j) { return POUT ? dfx_pad_idx<S>(q + S * (R * p), j) : q + S * (R * p + j); };
+            x[slot(0)] = o[0];
 #pragma unroll
             for (int j = 1; j < R; ++j) {
                 if constexpr (NCUR != R) {
                     float2 wj = w[r][j - 1];
                     if (SG > 0) wj.y = -wj.y;
-                    x[q + S * (R * p + j)] = dfx_cmul(o[j], wj);
+                    x[slot(j)] = dfx_cmul(o[j], wj);
                 } else {
-                    x[q + S * (R * p + j)] = o[j];
+                    x[slot(j)] = o[j];
                 }
             }
         }
@@ -311,11 +326,15 @@ static __device__ __forceinline__ void dfx_fft480_ip(float2 *x, const float2 *tw
     int l = lane;
     DFX_OPAQUE(l);
 #if DFX_FFT480_PASSES == 3     /* 480 = 8 * 6 * 10: 60 + 80 + 48 butterflies, the 6- and 10-point ones without inner twiddles (coprime factors) */
-    dfx_fft_pass_ip<8, SG, 480, 480, 1>(x, tw, l, active);
+#ifndef DFX_FFT480_PAD
+#define DFX_FFT480_PAD 1   /* 0: the unpadded passes (dev A/B) */
+#endif
+    constexpr bool PD = DFX_FFT480_PAD != 0;
+    dfx_fft_pass_ip<8, SG, 480, 480, 1, false, PD>(x, tw, l, active);
     DFX_OPAQUE(l);
-    dfx_fft_pass_ip<6, SG, 480, 60, 8>(x, tw, l, active);
+    dfx_fft_pass_ip<6, SG, 480, 60, 8, PD, PD>(x, tw, l, active);
     DFX_OPAQUE(l);
-    dfx_fft_pass_ip<10, SG, 480, 10, 48>(x, tw, l, active);
+    dfx_fft_pass_ip<10, SG, 480, 10, 48, PD, false>(x, tw, l, active);
 #else
     dfx_fft_pass_ip<4, SG, 480, 480, 1>(x, tw, l, active);
     DFX_OPAQUE(l);
@@ -440,7 +459,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_analysis(Df
     float2 *tw = reinterpret_cast<float2 *>(smem);                       // [N]
     float *win = reinterpret_cast<float *>(smem + (size_t)N * 8);        // [N]
     const size_t team_off = (size_t)N * 12;
-    const size_t buf_elems = (size_t)(M + 2);                            // M+1 used, padded to keep 16-byte carve
+    const size_t buf_elems = IP ? (size_t)DFX_FFT480_BUF : (size_t)(M + 2);   // M+1 used, padded to keep 16-byte carve (in place: room for the transform's padded layout)
     // (the team = wave index is uniform across the wave: frame index, clip / frame split — a 64-bit division — and the row bases stay scalar)
     const int team = dfx_wave_uniform(threadIdx.x / DFX_DSP_TEAM), lane = threadIdx.x % DFX_DSP_TEAM;
     // the 480-point plan transforms in place: one buffer per frame (the host sizes the dynamic LDS accordingly, dfx_dsp.hip)
@@ -714,7 +733,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_synthesis(D
     float2 *tw = reinterpret_cast<float2 *>(smem);
     float *win = reinterpret_cast<float *>(smem + (size_t)N * 8);
     const size_t team_off = (size_t)N * 12;
-    const size_t buf_elems = (size_t)(M + 2);
+    const size_t buf_elems = IP ? (size_t)DFX_FFT480_BUF : (size_t)(M + 2);
     constexpr int NBUF = IP ? 1 : 2;   // buffers per frame
     const int team = dfx_wave_uniform(threadIdx.x / DFX_DSP_TEAM), lane = threadIdx.x % DFX_DSP_TEAM;   // (wave-uniform: scalar frame / row arithmetic)
     float2 *bufs = reinterpret_cast<float2 *>(smem + team_off);
@@ -1646,11 +1665,11 @@ struct DfxSynRowsArgs {
     float pf_beta, atten_lim;
     int segs, seg_chunks;     // segments per row, 8-frame chunks per segment
 };
-#define DFX_SYNR_SMEM ((size_t)960 * 12 + (size_t)DFX_DSP_TEAMS * 482 * 8 + (size_t)2 * 480 * 4 + 512)
+#define DFX_SYNR_SMEM ((size_t)960 * 12 + (size_t)DFX_DSP_TEAMS * DFX_FFT480_BUF * 8 + (size_t)2 * 480 * 4 + 512)
 
 template <int O, bool PF, bool I16 = false>
 __global__ void __launch_bounds__(DFX_DSP_THREADS, (PF && I16) ? 5 : 6) dfx_k_synthesis_rows(DfxSynRowsArgs A) {   // (post-filter + 16-bit output: two registers over the budget of six waves per SIMD)
-    constexpr int M = 480, N = 960, HOP = 480, NTM = DFX_DSP_TEAMS, BUF = M + 2;
+    constexpr int M = 480, N = 960, HOP = 480, NTM = DFX_DSP_TEAMS, BUF = DFX_FFT480_BUF;
     DFX_DYN_SMEM(unsigned char, smem);
     float2 *tw = reinterpret_cast<float2 *>(smem);
     float *win = reinterpret_cast<float *>(smem + (size_t)N * 8);

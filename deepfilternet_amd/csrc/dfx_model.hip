@@ -395,6 +395,8 @@ struct dfx_model {
     PwW erb1, erb2, erb3, dfc0, dfc1, ct3, ct2, ct1;
     size_t co_w = 0, co_ska = 0, co_skb = 0;
     float co_bias = 0.f;
+    size_t tail_w0h3 = 0, tail_woh3 = 0;    // dfx_k_erb_tail's fp16-split fragments of erb_conv0 (e0 recomputed, bias in a constant-1 slot) and of conv0_out
+    float tail_w0_unscale = 1.f, tail_wo_unscale = 1.f;
     GlinW fc_emb, enc_in, enc_out, dec_in, dec_out, dfg_in, df_skip, df_out, enc_skip, dec_skip;
     std::vector<GruW> enc_gru, dec_gru, df_gru;
     size_t lsnr_w = 0;
@@ -486,6 +488,7 @@ struct dfx_model {
     unsigned int *h_err = nullptr;      // host address of the same words
     bool check_every_pass = false;
     int spin_limit = DFX_SYNC_SPIN_LIMIT;   // DFX_SYNC_SPIN_LIMIT=n (tests: force the timeouts)
+    bool hwq_probe_pending = false;     // the handshake of the persistent phase's streams has not run yet (hwq_probe_run)
     int hwq_probe = -1;                 // -1 not run, 1: the phase's streams run concurrently, 0: they do not (event-based GRU phase instead)
     const float *p(size_t off) const { return d_w + off; }
 };
@@ -814,6 +817,48 @@ static bool dfx_create_lane(dfx_model *m, int l) {
     return good;
 }
 
+// The persistent GRU phase synchronises through device flags: the stream of the persistent launch, the preparation stream of
+// every layer and the two decoder-tail streams must make progress independently.  Streams that share a hardware queue
+// (GPU_MAX_HW_QUEUES left at ROCm's default of 4, or set after HIP had initialised) would put a spinning wait in front of the
+// launch it waits for — a timeout and an invalid pass.  Checked once per handle with a handshake between exactly those streams, the
+// first time it matters (hwq_probe_pending).
+static void hwq_probe_fallback(dfx_model *m) {   // the event-synchronised form (DFX_GRU_SEQ=0) needs no concurrency to be correct
+    m->gru_seq = false;
+    if (!(getenv("DFX_QUIET") && getenv("DFX_QUIET")[0] == '1'))
+        fprintf(stderr, "dfx: the streams of the persistent GRU phase do not run concurrently (GPU_MAX_HW_QUEUES >= 16 must be in the environment "
+                        "before HIP initialises): this model uses the slower event-synchronised GRU phase (dfx_model_query DFX_Q_HWQ_PROBE = 0)\n");
+}
+static void hwq_probe_run(dfx_model *m) {
+    if (!m->hwq_probe_pending) return;
+    m->hwq_probe_pending = false;
+    const DfxLane &ln = m->lanes[0];
+    const int nl = 1 + (m->cfg.emb_num_layers - 1) + m->cfg.df_num_layers;
+    std::vector<hipStream_t> ss;
+    if (ln.gs[1]) ss.push_back(ln.gs[1]);
+    for (int i = 0; i < nl && i < DFX_MAX_GRU_LAYERS; ++i)
+        if (ln.ps[i]) ss.push_back(ln.ps[i]);
+    for (int i = 0; i < 2; ++i)
+        if (ln.ts[i]) ss.push_back(ln.ts[i]);
+    unsigned int *cnt = m->d_sync + 13;   // (a spare word of the flag block: ready 0-7 | emb 8 | probe 13 | done 16-)
+    // warm-up: the kernel's code object is loaded and every stream's queue exists before the bounded handshake starts (a slow first
+    // launch must not look like a shared queue); a failed handshake is tried once more with a longer bound before it counts
+    for (hipStream_t st : ss) dfx_launch(dfx_k_probe_meet, dim3(1), dim3(64), 0, st, cnt, 0u, 1, m->d_err + 9);
+    bool okp = hipGetLastError() == hipSuccess;
+    for (hipStream_t st : ss) okp = hipStreamSynchronize(st) == hipSuccess && okp;
+    m->hwq_probe = 0;
+    for (int attempt = 0; attempt < 2 && okp && m->hwq_probe == 0; ++attempt) {
+        (void)hipMemset(cnt, 0, sizeof(unsigned int));
+        m->h_err[8] = 0u;
+        for (hipStream_t st : ss) dfx_launch(dfx_k_probe_meet, dim3(1), dim3(64), 0, st, cnt, (unsigned int)ss.size(), 1 << (16 + 3 * attempt), m->d_err + 8);
+        okp = hipGetLastError() == hipSuccess;
+        for (hipStream_t st : ss) okp = hipStreamSynchronize(st) == hipSuccess && okp;
+        m->hwq_probe = okp && ((volatile unsigned int *)m->h_err)[8] == 0u ? 1 : 0;
+    }
+    m->h_err[8] = 0u, m->h_err[9] = 0u;
+    (void)hipMemset(cnt, 0, sizeof(unsigned int));
+    if (m->hwq_probe == 0) hwq_probe_fallback(m);
+}
+
 extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx_model **out) {
     if (int rc = check_cfg(cfg)) return rc;
     if (!blob || !out) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_create: null");
@@ -892,6 +937,22 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
                 for (int j = 0; j < 3; ++j) P.out[m->co_w + j * C + ch] = w[ch * 3 + j] * sc[0];
             m->co_bias = sh[0];
         }
+    }
+    if (ok && C % 32 == 0) {   // matrix-op forms of the two small contractions inside dfx_k_erb_tail (round 5)
+        const int KC = C / 32;
+        const std::vector<float> src(P.out.begin(), P.out.end());   // pack_h3 may reallocate P.out
+        const size_t w0 = m->erb0_w, b0 = m->erb0_b, wo = m->co_w;
+        // erb_conv0 as [C x 32] fragments per 16 channels: k-slot 8 (l >> 4) + i = tap 3 kt + kf for k < 9, the bias (against a constant 1) at k = 9
+        m->tail_w0h3 = pack_h3(P, C / 16, [&](int nt, int l, int i) {
+            const int k = 8 * (l >> 4) + i, ch = 16 * nt + (l & 15);
+            return k < 9 ? src[w0 + (size_t)k * C + ch] : (k == 9 ? src[b0 + ch] : 0.f);
+        }, &m->tail_w0_unscale);
+        // conv0_out's three taps as the rows 0..2 of one 16-row tile; the contraction index is enumerated the way a D fragment leaves it (lane
+        // (position, q): element 8 kc + i <-> channel 16 ((8 kc + i) >> 2) + 4 q + ((8 kc + i) & 3))
+        m->tail_woh3 = pack_h3(P, KC, [&](int kc, int l, int i) {
+            const int j = l & 15, e = 8 * kc + i, ch = 16 * (e >> 2) + 4 * (l >> 4) + (e & 3);
+            return j < 3 ? src[wo + (size_t)j * C + ch] : 0.f;
+        }, &m->tail_wo_unscale);
     }
     if (ok) {   // df_dec.df_convp
         const int kt = c.df_pathway_kernel_size_t, NO = 2 * O, G = dfx_gcd(C, NO), CG = C / G, OG = NO / G;
@@ -1084,47 +1145,18 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
             }
             m->have_streams = true;
         }
-        // The persistent GRU phase synchronises through device flags: the stream of the persistent launch, the preparation stream of
-        // every layer and the two decoder-tail streams must make progress independently.  Streams that share a hardware queue
-        // (GPU_MAX_HW_QUEUES left at ROCm's default of 4, or set after HIP had initialised) would put a spinning wait in front of the
-        // launch it waits for — a timeout and an invalid pass.  Checked once, here, with a handshake between exactly those streams.
+        // The persistent GRU phase synchronises through device flags and needs its streams to run concurrently: checked with a handshake
+        // (hwq_probe_run) — not here but before the first pass that would use the persistent form, or when DFX_Q_HWQ_PROBE /
+        // DFX_Q_GRU_PERSISTENT is asked for: a process that creates many handles it only streams through (df_create: one state per
+        // stream, never a persistent phase) pays nothing for it.
         if (m->gru_seq && m->concurrent && !dfx_env_is_emulator()) {
-            const DfxLane &ln = m->lanes[0];
-            const int nl = 1 + (m->cfg.emb_num_layers - 1) + m->cfg.df_num_layers;
-            std::vector<hipStream_t> ss;
-            if (ln.gs[1]) ss.push_back(ln.gs[1]);
-            for (int i = 0; i < nl && i < DFX_MAX_GRU_LAYERS; ++i)
-                if (ln.ps[i]) ss.push_back(ln.ps[i]);
-            for (int i = 0; i < 2; ++i)
-                if (ln.ts[i]) ss.push_back(ln.ts[i]);
             const char *pe = getenv("DFX_HWQ_PROBE");   // "0": skip the probe (trust the environment); "fail": dev / test hook
             if (pe && pe[0] == '0') {
             } else if (pe && pe[0] == 'f') {
                 m->hwq_probe = 0;
+                hwq_probe_fallback(m);
             } else {
-                unsigned int *cnt = m->d_sync + 13;   // (a spare word of the flag block: ready 0-7 | emb 8 | probe 13 | done 16-)
-                // warm-up: the kernel's code object is loaded and every stream's queue exists before the bounded handshake starts (a slow first
-                // launch must not look like a shared queue); a failed handshake is tried once more with a longer bound before it counts
-                for (hipStream_t st : ss) dfx_launch(dfx_k_probe_meet, dim3(1), dim3(64), 0, st, cnt, 0u, 1, m->d_err + 9);
-                bool okp = hipGetLastError() == hipSuccess;
-                for (hipStream_t st : ss) okp = hipStreamSynchronize(st) == hipSuccess && okp;
-                m->hwq_probe = 0;
-                for (int attempt = 0; attempt < 2 && okp && m->hwq_probe == 0; ++attempt) {
-                    (void)hipMemset(cnt, 0, sizeof(unsigned int));
-                    m->h_err[8] = 0u;
-                    for (hipStream_t st : ss) dfx_launch(dfx_k_probe_meet, dim3(1), dim3(64), 0, st, cnt, (unsigned int)ss.size(), 1 << (16 + 3 * attempt), m->d_err + 8);
-                    okp = hipGetLastError() == hipSuccess;
-                    for (hipStream_t st : ss) okp = hipStreamSynchronize(st) == hipSuccess && okp;
-                    m->hwq_probe = okp && ((volatile unsigned int *)m->h_err)[8] == 0u ? 1 : 0;
-                }
-                m->h_err[8] = 0u, m->h_err[9] = 0u;
-                (void)hipMemset(cnt, 0, sizeof(unsigned int));
-            }
-            if (m->hwq_probe == 0) {   // the event-synchronised form (DFX_GRU_SEQ=0) needs no concurrency to be correct
-                m->gru_seq = false;
-                if (!(getenv("DFX_QUIET") && getenv("DFX_QUIET")[0] == '1'))
-                    fprintf(stderr, "dfx: the streams of the persistent GRU phase do not run concurrently (GPU_MAX_HW_QUEUES >= 16 must be in the environment "
-                                    "before HIP initialises): this model uses the slower event-synchronised GRU phase (dfx_model_query DFX_Q_HWQ_PROBE = 0)\n");
+                m->hwq_probe_pending = true;
             }
         }
     }
@@ -1210,8 +1242,8 @@ extern "C" int dfx_model_check(const dfx_model *m) {
 extern "C" int dfx_model_query(const dfx_model *m, int what, int64_t *value) {
     if (!m || !value) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_query: null");
     switch (what) {
-        case DFX_Q_GRU_PERSISTENT: *value = m->gru_seq && m->concurrent ? 1 : 0; return DFX_OK;
-        case DFX_Q_HWQ_PROBE: *value = m->hwq_probe; return DFX_OK;
+        case DFX_Q_GRU_PERSISTENT: hwq_probe_run(const_cast<dfx_model *>(m)); *value = m->gru_seq && m->concurrent ? 1 : 0; return DFX_OK;
+        case DFX_Q_HWQ_PROBE: hwq_probe_run(const_cast<dfx_model *>(m)); *value = m->hwq_probe; return DFX_OK;
         case DFX_Q_EXACT_FP32: *value = m->exact_fp32 ? 1 : 0; return DFX_OK;
         case DFX_Q_SPIN_LIMIT: *value = m->spin_limit; return DFX_OK;
     }
@@ -1414,7 +1446,21 @@ static int launch_convp_h3(const dfx_model *m, const float *feat_spec, float *ou
         DFX_FAIL(DFX_ERR_UNSUPPORTED, "fp16-split df_convp needs conv_ch %% 32 == 0");
     } else {
         if (t_end < 0) t_end = T;
-        if (B * (feat_T > 0 ? feat_T : T) * Fd >= ((int64_t)1 << 29)) DFX_FAIL(DFX_ERR_UNSUPPORTED, "df_convp: batch too large for one launch (32-bit element offsets)");
+        {   // 32-bit element offsets inside the kernel (B * feat_T * Fd < 2^29 per launch): a larger batch runs as several launches over whole clips
+            const int64_t per_clip = (feat_T > 0 ? feat_T : T) * Fd;
+            static const int64_t lim = [] { const char *e = getenv("DFX_CONVP_ELEMS"); return e && atoll(e) > 0 ? (int64_t)atoll(e) : (int64_t)1 << 29; }();   // (test hook: the split at small sizes)
+            if (per_clip >= lim) DFX_FAIL(DFX_ERR_UNSUPPORTED, "df_convp: clip too long for 32-bit element offsets");
+            const int64_t bmax = (lim - 1) / per_clip;
+            if (B > bmax) {
+                for (int64_t b0 = 0; b0 < B; b0 += bmax) {
+                    const int64_t nb = B - b0 < bmax ? B - b0 : bmax;
+                    if (int r = launch_convp_h3<C, KT>(m, feat_spec + b0 * per_clip * 2, out + b0 * (int64_t)(NO / 2) * T * Fd * 2, nb, T, Fd, NO, s, t_begin, t_zero, L,
+                                                       t_end, feat_T))
+                        return r;
+                }
+                return DFX_OK;
+            }
+        }
         DfxCphArgs A;
         A.t_end = t_end;
         A.feat = feat_spec;
@@ -1579,7 +1625,7 @@ static int launch_erb_dec10(const dfx_model *m, const float *d2, const float *e1
 template <int C>
 static bool erb_tail_ok(const dfx_model *m, int E) {
     if constexpr (C % 32 != 0) return false;
-    return m->fuse_tail && m->fuse_erb && !m->exact_fp32 && m->ct3.wt_h3 && m->ct2.wt_h3 && m->ct1.wt_h3 && dfx_tail_ok(C, E);
+    return m->fuse_tail && m->fuse_erb && !m->exact_fp32 && m->ct3.wt_h3 && m->ct2.wt_h3 && m->ct1.wt_h3 && m->tail_w0h3 && m->tail_woh3 && dfx_tail_ok(C, E);
 }
 template <int C>
 // e0 == null: recomputed in the kernel from feat_erb (rows of T frames per clip, feat_T frames per clip in feat_erb, lookahead L)
@@ -1603,6 +1649,8 @@ static int launch_erb_tail(const dfx_model *m, const float *demb, const float *e
         A.ska[3] = m->p(m->co_ska);
         A.skb[3] = m->p(m->co_skb);
         A.wo = m->p(m->co_w);
+        A.woh3 = reinterpret_cast<const dfx_h8 *>(m->p(m->tail_woh3)), A.unscale_wo = m->tail_wo_unscale;
+        A.w0h3 = reinterpret_cast<const dfx_h8 *>(m->p(m->tail_w0h3)), A.unscale_w0 = m->tail_w0_unscale;
         A.bias_o = m->co_bias;
         A.out = mask;
         A.R = R;
@@ -1809,6 +1857,13 @@ static int launch_glin(const dfx_model *m, const GlinW &g, const float *a, int a
     return launch_ggemm(a, g.G * g.Kg, m->p(g.w), g.G, g.Kg, g.Ng, nullptr, act, res, out, g.G * g.Ng, M, s, 0, 0, 1, rm, a2);
 }
 
+// Row count up to which the fan-out kernels take their few-rows forms (one row tile per wave, a tile's chunks dealt to separate waves): made
+// for a streaming hop (4096 rows).  Round 5: the time chunks of the persistent GRU phase (10-20 k rows at 16-24 chunks) take the large-launch
+// forms — at the old bound of 16384 rows every chunking finer than 15 chunks fell onto the hop's forms (15.1 vs 14.1 ms per step).
+static int64_t fan_few_rows() {
+    static const int64_t v = [] { const char *e = getenv("DFX_FAN_FEW_ROWS"); return e && atoll(e) > 0 ? (int64_t)atoll(e) : (int64_t)4096; }();
+    return v;
+}
 // df_fc_emb (+ e3) and the encoder GRU's linear_in in one pass over c1 (dfx_k_enc_fan)
 static int launch_enc_fan(const dfx_model *m, const float *c1, const float *e3, float *emb_out, float *xa, int64_t M, hipStream_t s, DfxRowMap rm) {
     DfxEncFanArgs A;
@@ -1822,7 +1877,7 @@ static int launch_enc_fan(const dfx_model *m, const float *c1, const float *e3, 
     A.ng = m->efan_groups;
     A.rm = rm;
     DfxKScope ks(DFX_K_GGEMM, s);
-    if (M > 16384) {
+    if (M > fan_few_rows()) {
         constexpr int RT = 2;
         A.parts = 1;
         dfx_launch(dfx_k_enc_fan<RT>, dim3((unsigned)nn_grid(dfx_ceil_div(dfx_ceil_div(M, 16 * RT), 4), 8)), dim3(256), 0, s, A);
@@ -1890,7 +1945,7 @@ static int launch_emb_fan(const dfx_model *m, const float *y, const float *res, 
     A.parts = 1;
     // few rows (a streaming hop): one wave per (16 rows, super-chunk) instead of a wave walking all super-chunks — emb is then written out
     // (embv: 2 KB per row of a few thousand rows) and lsnr, the one consumer that needs all of a row's features, is a launch of its own
-    const bool split = M <= 16384 && lsnr && embv_for_split;
+    const bool split = M <= fan_few_rows() && lsnr && embv_for_split;
     if (split) {
         A.parts = A.nj;
         A.emb_out = embv_for_split;
@@ -1899,7 +1954,7 @@ static int launch_emb_fan(const dfx_model *m, const float *y, const float *res, 
     {
     DfxKScope ks(DFX_K_EMB_FAN, s);
     // (the kinds are what pack_fan accepted: dec_in narrow, dfg_in wide, df_skip narrow; a consumer that is not wanted drops out)
-    if (M > 16384) {
+    if (M > fan_few_rows()) {
         constexpr int RT = 2;
         const dim3 grid((unsigned)nn_grid(dfx_ceil_div(dfx_ceil_div(M, 16 * RT), 4), 8));
         if (dfg_x && skp) dfx_launch((dfx_k_emb_fan<RT, 1, 2, 1>), grid, dim3(256), 0, s, A);
@@ -2166,6 +2221,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     // persistent form (default on the GPU): ONE launch runs the recurrences of all layers for the whole sequence
     // (dfx_k_gru_seq); needs every (layer, group) workgroup resident at once (each owns a CU)
     const int groups = (int)dfx_ceil_div(B, DFX_GH_ROWS);
+    if (pipe && m->gru_seq && m->hwq_probe_pending && groups <= DFX_SEQ_GMAX && nl * groups + 8 <= dfx_env_num_cus())
+        hwq_probe_run(const_cast<dfx_model *>(m));   // first pass that would use the persistent form: do its streams run concurrently?
     const bool use_seq = pipe && m->gru_seq && groups <= DFX_SEQ_GMAX && nl * groups + 8 <= dfx_env_num_cus();
     int sb[DFX_GS_MAX_CHUNKS + 1];   // chunk boundaries of the persistent form
     int Ks = 0;
@@ -2181,7 +2238,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // small-launch forms of the fan-out kernels) -> 12 uniform chunks
         static const int ramp0 = [] { const char *e = getenv("DFX_SEQ_RAMP"); return e ? atoi(e) : 0; }();
         static const int kbody = [] { const char *e = getenv("DFX_SEQ_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 12; }();
-        const int64_t body = T / kbody > m->tchunk_min ? T / kbody : m->tchunk_min;   // uniform chunk length
+        const int64_t body = std::max<int64_t>(dfx_ceil_div(T, (int64_t)kbody), m->tchunk_min);   // uniform chunk length: DFX_SEQ_CHUNKS=n gives n chunks (ceil: 1002 / 12 -> 84, not 83 and a 13th chunk)
         std::vector<int> sizes;
         int64_t left = T;
         for (int64_t r = ramp0; ramp0 > 0 && r < body && left > 4 * body; r *= 2) sizes.push_back((int)r), left -= r;   // up
@@ -2521,7 +2578,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 // (stays two chunks ahead of the recurrence instead of flooding the chip with all K projections while the decoders'
                 // first chunks are being prepared)
                 for (int k = 0; k < K; ++k) {
-                    if (k >= 3 && (rc = launch_wait_ge(m, donep(0), groups, tgt(k - 3), Pq))) return rc;
+                    static const int p0_ahead = [] { const char *e = getenv("DFX_SEQ_P0_AHEAD"); return e && atoi(e) > 0 ? atoi(e) : 3; }();
+                    if (k >= p0_ahead && (rc = launch_wait_ge(m, donep(0), groups, tgt(k - p0_ahead), Pq))) return rc;
                     if ((rc = proj_chunk(m->enc_gru[0], 0, k, xa, Pq)) || (rc = launch_flag_set(ready + 0, tgt(k), Pq))) return rc;
                 }
             }
@@ -2557,9 +2615,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 return DFX_OK;
             };
             // ---- ERB tail, chunk k
-            auto erb_tail = [&](int k) -> int {
-                const int64_t Rk = Mk(k);
-                const DfxRowMap rm = rmk(k);
+            // (tails consume: they may take several hand-over chunks [k0, k1] in one launch — DFX_SEQ_TAIL_EVERY — when the chain is cut finer
+            // than a decoder tail's launch is worth)
+            auto erb_tail = [&](int k0, int k) -> int {
+                const int64_t Rk = B * (tb(k + 1) - tb(k0));
+                const DfxRowMap rm = DfxRowMap{T, tb(k + 1) - tb(k0), tb(k0)};
                 int r;
                 if ((r = launch_wait_ge(m, donep(ndec), groups, tgt(k), Eq))) return r;
                 if (dev_skip_seq & 1) return DFX_OK;
@@ -2591,8 +2651,10 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 return DFX_OK;
             };
             // ---- DF tail, chunk k
-            auto df_tail = [&](int k) -> int {
+            auto df_tail = [&](int k0, int k) -> int {
                 const int l = ndec + ndf;
+                const int64_t Rk = B * (tb(k + 1) - tb(k0));
+                const DfxRowMap rm = DfxRowMap{T, tb(k + 1) - tb(k0), tb(k0)};
                 int r;
                 if ((r = launch_wait_ge(m, donep(l), groups, tgt(k), Dq))) return r;
                 if (dev_skip_seq & 2) return DFX_OK;
@@ -2611,10 +2673,10 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 if (fan_skp) {
                     cfeat2 = xdf;
                 } else if (c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR) {
-                    if ((r = launch_glin(m, m->df_skip, embv, DFX_ACT_NONE, ws + w.py[l], xdf, Mk(k), Dq, rmk(k)))) return r;
+                    if ((r = launch_glin(m, m->df_skip, embv, DFX_ACT_NONE, ws + w.py[l], xdf, Rk, Dq, rm))) return r;
                     cfeat = xdf;
                 }
-                return df_out_rows(cfeat, cfeat2, Mk(k), Dq, rmk(k));
+                return df_out_rows(cfeat, cfeat2, Rk, Dq, rm);
             };
             if (run_df && (rc = wait(EV_C0P, Dq))) return rc;
             for (int k = 0; k < K; ++k) {
@@ -2622,8 +2684,12 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                     if (j < ndec && (rc = prep_dec(j, k))) return rc;
                     if (j < ndf && (rc = prep_df(j, k))) return rc;
                 }
-                if ((rc = erb_tail(k))) return rc;
-                if (run_df && (rc = df_tail(k))) return rc;
+                static const int tail_every = [] { const char *e = getenv("DFX_SEQ_TAIL_EVERY"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
+                if ((k + 1) % tail_every == 0 || k == K - 1) {
+                    const int k0 = k - (k % tail_every);
+                    if ((rc = erb_tail(k0, k))) return rc;
+                    if (run_df && (rc = df_tail(k0, k))) return rc;
+                }
             }
             if ((rc = signal(EV_MASK, Eq))) return rc;
             // ---- lsnr on the caller's stream once the whole embedding exists (:163-165,184); dfx_k_emb_fan has written it per chunk

@@ -1958,9 +1958,9 @@ __global__ void __launch_bounds__(256, 2) dfx_k_erb_dec10_f(DfxDec10fArgs AA) {
 // ---------------------------------------------------------------------------------------------------------------------
 #define DFX_TAIL_WAVES 12
 #define DFX_TAIL_WAVE_FLOATS(C) (32 * ((C) + 4))
-#define DFX_TAIL_TAB4(C) (3 * 3 * (C) / 4 + 4 * 2 * (C) / 4 + 3 * (C) / 4 + 3 * (C) / 4)   /* float4s: dw x3, pathway a/b x4, wo, bias x3 */
+#define DFX_TAIL_TAB4(C) (3 * 3 * (C) / 4 + 4 * 2 * (C) / 4 + 3 * (C) / 4)   /* float4s: dw x3, pathway a/b x4, bias x3 */
 #define DFX_TAIL_WFRAG(C) ((size_t)((C) / 16) * ((C) / 32) * 2 * 64)                     /* dfx_h8 per layer */
-#define DFX_TAIL_W0_4(C) (10 * (C) / 4)   /* float4s: erb_conv0's folded weights [3][3][C] + bias [C] (e0 recomputed in the kernel) */
+#define DFX_TAIL_W0_4(C) (((C) / 16) * 2 * 32 + ((C) / 32) * 2 * 16)   /* dfx_h8 (16 bytes each): erb_conv0's fragments [C/16][hi, lo], the 32 lanes that carry k-slots < 16 (e0 recomputed in the kernel); conv0_out's [C/32][hi, lo], the lanes of rows 0..3 */
 #define DFX_TAIL_SMEM(C) ((size_t)(DFX_TAIL_TAB4(C) + DFX_TAIL_W0_4(C)) * 16 + 3 * DFX_TAIL_WFRAG(C) * 16 + (size_t)DFX_TAIL_WAVES * DFX_TAIL_WAVE_FLOATS(C) * 4)
 static __host__ __device__ __forceinline__ bool dfx_tail_ok(int C, int E) {
     return (C == 32 || C == 64) && E == 32 && DFX_TAIL_SMEM(C) <= (size_t)160 * 1024;
@@ -1972,6 +1972,9 @@ struct DfxTailArgs {
     float unscale[3];
     const float *ska[4], *skb[4];            // pathway scale / shift of conv3p, conv2p, conv1p, conv0p
     const float *wo;                         // conv0_out [3][C]
+    const dfx_h8 *woh3;                      // the same as fp16-split fragments [C/32][hi, lo][64] (rows 0..2 of a 16-row tile)
+    const dfx_h8 *w0h3;                      // erb_conv0 (+ bias) as fragments [C/16][hi, lo][64] (e0 recomputed)
+    float unscale_wo, unscale_w0;
     float bias_o;
     float *out;                              // mask [R, E]
     int64_t R;
@@ -1988,7 +1991,9 @@ struct DfxTailArgs {
 };
 // one 16-position tile of a separable stage on the fp16-split path, fragments and bias read from LDS (dfx_chain_stage_h3's tile body: same
 // operand roles, same k order, same bits); positions [p0, p0 + 16) of npos, input rows in `in`
-template <int C, int MODE, typename Epi>
+// FB: channel tiles whose fragments are read per batch (NT: one k-chunk at a time, 32 registers at C = 64; NT / 2: half of that, for a caller
+// whose epilogue needs the registers)
+template <int C, int MODE, int FB = C / 16, typename Epi>
 static __device__ __forceinline__ void dfx_chain_tile_h3_lds(const float *in, int Fin, int stride, int p0, int npos, const float4 *dws,
                                                              const dfx_h8 *wfr, const float4 *bias4, float unscale, float &amax, int lane, Epi &&epi) {
     constexpr int CPL = C / 4, NT = C / 16, KC = C / 32, V4 = CPL / 4, LD = C + 4;
@@ -2029,19 +2034,23 @@ static __device__ __forceinline__ void dfx_chain_tile_h3_lds(const float *in, in
     f32x4 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    static_assert(NT % FB == 0, "whole batches of channel tiles");
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
-        dfx_h8 ahi[NT], alo[NT];   // one k-chunk of fragments at a time
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            ahi[nt] = wfr[((size_t)(nt * KC + kc) * 2 + 0) * 64 + lane];
-            alo[nt] = wfr[((size_t)(nt * KC + kc) * 2 + 1) * 64 + lane];
-        }
+        for (int n0 = 0; n0 < NT; n0 += FB) {
+            dfx_h8 ahi[FB], alo[FB];   // one batch of a k-chunk's fragments at a time (per accumulator the same order of terms for any FB: same bits)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            acc[nt] = dfx_mfma_16x16x32_f16(alo[nt], bhi[kc], acc[nt]);
-            acc[nt] = dfx_mfma_16x16x32_f16(ahi[nt], blo[kc], acc[nt]);
-            acc[nt] = dfx_mfma_16x16x32_f16(ahi[nt], bhi[kc], acc[nt]);
+            for (int d = 0; d < FB; ++d) {
+                ahi[d] = wfr[((size_t)((n0 + d) * KC + kc) * 2 + 0) * 64 + lane];
+                alo[d] = wfr[((size_t)((n0 + d) * KC + kc) * 2 + 1) * 64 + lane];
+            }
+#pragma unroll
+            for (int d = 0; d < FB; ++d) {
+                acc[n0 + d] = dfx_mfma_16x16x32_f16(alo[d], bhi[kc], acc[n0 + d]);
+                acc[n0 + d] = dfx_mfma_16x16x32_f16(ahi[d], blo[kc], acc[n0 + d]);
+                acc[n0 + d] = dfx_mfma_16x16x32_f16(ahi[d], bhi[kc], acc[n0 + d]);
+            }
         }
     }
 #pragma unroll
@@ -2060,12 +2069,13 @@ __global__ void __launch_bounds__(64 * DFX_TAIL_WAVES, 1) dfx_k_erb_tail(DfxTail
     constexpr int NV3 = (N3 + 63) / 64, NV1 = (N1 + 63) / 64, NV0 = (N0T + 63) / 64;
     DFX_DYN_SMEM(float4, sm4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4;
+    constexpr int NT = C / 16, KC = C / 32;
     float4 *dws = sm4;                  // [3 layers][3][C4]
     float4 *sks = dws + 9 * C4;         // [4 pathways][a, b][C4]
-    float4 *wos = sks + 8 * C4;         // [3][C4]
-    float4 *bis = wos + 3 * C4;         // [3 layers][C4]
-    float4 *w0s = bis + 3 * C4;         // [9 taps + bias][C4] (e0 recomputed)
-    dfx_h8 *wfr = reinterpret_cast<dfx_h8 *>(w0s + DFX_TAIL_W0_4(C));   // [3 layers][NT * KC * 2 * 64]
+    float4 *bis = sks + 8 * C4;         // [3 layers][C4]
+    dfx_h8 *w0f = reinterpret_cast<dfx_h8 *>(bis + 3 * C4);   // [NT][hi, lo][32]: erb_conv0's fragments, the lanes of k-slots 0..15 (e0 recomputed)
+    dfx_h8 *wof = w0f + NT * 2 * 32;                           // [KC][hi, lo][4 q][4 rows]: conv0_out's fragments, rows 0..3 (only rows 0..2 of the tile are read back)
+    dfx_h8 *wfr = w0f + DFX_TAIL_W0_4(C);                      // [3 layers][NT * KC * 2 * 64]
     float *X = reinterpret_cast<float *>(wfr + 3 * DFX_TAIL_WFRAG(C)) + (size_t)wave * DFX_TAIL_WAVE_FLOATS(C);
     float *Y = X + 16 * LD;
 #pragma unroll
@@ -2080,12 +2090,11 @@ __global__ void __launch_bounds__(64 * DFX_TAIL_WAVES, 1) dfx_k_erb_tail(DfxTail
             sks[pth * 2 * C4 + i] = reinterpret_cast<const float4 *>(A.ska[pth])[i];
             sks[pth * 2 * C4 + C4 + i] = reinterpret_cast<const float4 *>(A.skb[pth])[i];
         }
-    for (int i = tid; i < 3 * C4; i += NTH) wos[i] = reinterpret_cast<const float4 *>(A.wo)[i];
     constexpr bool re0 = RE0;   // (a template parameter: the e0 loads and their registers do not exist in this form)
     if (re0) {
-        for (int i = tid; i < 9 * C4; i += NTH) w0s[i] = reinterpret_cast<const float4 *>(A.w0)[i];
-        for (int i = tid; i < C4; i += NTH) w0s[9 * C4 + i] = reinterpret_cast<const float4 *>(A.b0)[i];
+        for (int i = tid; i < NT * 2 * 32; i += NTH) w0f[i] = A.w0h3[(i >> 5) * 64 + (i & 31)];
     }
+    for (int i = tid; i < KC * 2 * 16; i += NTH) wof[i] = A.woh3[(i >> 4) * 64 + 16 * ((i & 15) >> 2) + (i & 3)];
     __syncthreads();
     const float4 *pd = reinterpret_cast<const float4 *>(A.demb), *p3 = reinterpret_cast<const float4 *>(A.e3), *p2 = reinterpret_cast<const float4 *>(A.e2),
                  *p1 = reinterpret_cast<const float4 *>(A.e1), *p0 = reinterpret_cast<const float4 *>(A.e0);
@@ -2175,25 +2184,38 @@ __global__ void __launch_bounds__(64 * DFX_TAIL_WAVES, 1) dfx_k_erb_tail(DfxTail
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if constexpr (re0) {
-                // e0 of (position 16 t + row, channel quad lq) from the three feature rows: bias, then the nine taps in dfx_k_erb_enc's order.  One
-                // float4 at a time (not unrolled: the unrolled form keeps 36 weight registers and a dozen shuffles in flight and spills)
-#pragma unroll 1
-                for (int i = 0; i < NV0; ++i) {
-                    const int row = (lane + 64 * i) / C4;
-                    float4 ev = w0s[9 * C4 + lq];
+                // e0 of the tile's 16 positions on the matrix pipe (round 5; on the VALU this stage was 72 ds_bpermute + 72 weight reads per frame, a
+                // third of the LDS time of an LDS-bound kernel): D[channel][position] = W0[channel][k] P[k][position], k-slot 8 q + i = tap
+                // 3 kt + kf for k < 9, a constant 1 against the bias at k = 9.  Lane (position jl, q = 0) gathers its eight taps from the three
+                // feature rows (lane fp of fxr[kt] = element fp of the zero-bordered row), q = 1 the ninth; the fragments' lanes 32..63 multiply
+                // zeros and re-read lanes 0..31.
+                int jl = lane & 15;
+                DFX_OPAQUE(jl);   // (addresses / shuffle indices recomputed per tile instead of held across the frame loop)
+                float xk[8];
 #pragma unroll
-                    for (int kt = 0; kt < 3; ++kt)
+                for (int i = 0; i < 8; ++i) xk[i] = __shfl(fxr[i / 3], 16 * t + jl + i % 3);
+                const float x8 = __shfl(fxr[2], 16 * t + jl + 2);
 #pragma unroll
-                        for (int kf = 0; kf < 3; ++kf) {
-                            const float4 ww = w0s[(kt * 3 + kf) * C4 + lq];
-                            const float x = __shfl(fxr[kt], 16 * t + row + kf);   // bin (16 t + row) - 1 + kf, border included
-                            ev.x += ww.x * x;
-                            ev.y += ww.y * x;
-                            ev.z += ww.z * x;
-                            ev.w += ww.w * x;
-                        }
-                    ev = make_float4(fmaxf(ev.x, 0.f), fmaxf(ev.y, 0.f), fmaxf(ev.z, 0.f), fmaxf(ev.w, 0.f));
-                    *reinterpret_cast<float4 *>(X + row * LD + 4 * lq) = path(ev, a0, b0);
+                for (int i = 0; i < 8; ++i) xk[i] = q == 0 ? xk[i] : 0.f;
+                if (q == 1) xk[0] = x8, xk[1] = 1.f;
+                dfx_h8 ph, pl;
+                dfx_split8_g(xk, ph, pl, amax);
+                int l32 = lane & 31;
+                DFX_OPAQUE(l32);
+                f32x4 acc0[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const dfx_h8 wh = w0f[(nt * 2 + 0) * 32 + l32], wl = w0f[(nt * 2 + 1) * 32 + l32];
+                    acc0[nt] = dfx_mfma_16x16x32_f16(wl, ph, f32x4{0.f, 0.f, 0.f, 0.f});
+                    acc0[nt] = dfx_mfma_16x16x32_f16(wh, pl, acc0[nt]);
+                    acc0[nt] = dfx_mfma_16x16x32_f16(wh, ph, acc0[nt]);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {   // lane (position jl, q): channels 16 nt + 4 q + r = channel quad 4 nt + q
+                    const float4 a0q = sks[6 * C4 + 4 * nt + q], b0q = sks[7 * C4 + 4 * nt + q];
+                    const float4 ev = make_float4(fmaxf(acc0[nt][0] * A.unscale_w0, 0.f), fmaxf(acc0[nt][1] * A.unscale_w0, 0.f),
+                                                  fmaxf(acc0[nt][2] * A.unscale_w0, 0.f), fmaxf(acc0[nt][3] * A.unscale_w0, 0.f));
+                    *reinterpret_cast<float4 *>(X + jl * LD + 16 * nt + 4 * q) = path(ev, a0q, b0q);
                 }
             } else {
 #pragma unroll
@@ -2212,25 +2234,41 @@ __global__ void __launch_bounds__(64 * DFX_TAIL_WAVES, 1) dfx_k_erb_tail(DfxTail
                 if (next < A.R) issue(dfx_row(A.rm, next));
             }
             DFX_WAVE_SYNC();
-            dfx_chain_tile_h3_lds<C, DFX_PW_MODE_DWT3>(Y, E1, 2, 16 * t, E, dws + 6 * C4, wfr + 2 * DFX_TAIL_WFRAG(C), bis + 2 * C4, A.unscale[2], amax, lane,
-                                                       add_into(X, 16 * t));
-            DFX_WAVE_SYNC();
-            // V[p][j] = sum_c wo[j][c] * xin[p][c] for the tile's 16 positions: 48 values, parked in the pad columns of Y (tile 0) / X (tile 1)
-            float vacc = 0.f;
-            if (lane < 48) {
-                const int p = lane / 3, j = lane - 3 * p;
-                const float4 *xrow = reinterpret_cast<const float4 *>(X + p * LD);
-#pragma unroll 4
-                for (int c = 0; c < C4; ++c) {
-                    const float4 x = xrow[c], w = wos[j * C4 + c];
-                    vacc += w.x * x.x;
-                    vacc += w.y * x.y;
-                    vacc += w.z * x.z;
-                    vacc += w.w * x.w;
+            // convt1's tile; its epilogue adds the pathway term parked in X and hands the sums — conv0_out's operand — to the matrix pipe two channel
+            // tiles (= one k-chunk) at a time: element 4 (nt & 1) + r of sv = channel 16 nt + 4 q + r of this lane's position, the k order conv0_out's
+            // fragments were packed in.  V[j][p] = sum_c wo[j][c] * xin[p][c] for the tile's 16 positions (round 5; on the VALU: 32 row / weight reads
+            // of 16 bytes per tile by 48 lanes): rows j = 0..2 of one tile, the lanes q = 0 hold them.  The fragments' rows 3..15 multiply into rows of
+            // the result nobody reads: those lanes re-read row 3 (1 KB of LDS instead of 4).
+            float sv[8];
+            f32x4 vj = f32x4{0.f, 0.f, 0.f, 0.f};
+            int lw = 4 * q + ((lane & 15) < 3 ? (lane & 15) : 3);
+            DFX_OPAQUE(lw);
+            dfx_chain_tile_h3_lds<C, DFX_PW_MODE_DWT3, (C >= 64 ? C / 32 : C / 16)>(Y, E1, 2, 16 * t, E, dws + 6 * C4, wfr + 2 * DFX_TAIL_WFRAG(C), bis + 2 * C4, A.unscale[2], amax, lane,
+                                                       [&](int p, bool, int nt, float4 d) {
+                                                           const float4 e = *reinterpret_cast<const float4 *>(X + (p - 16 * t) * LD + 16 * nt + 4 * q);
+                                                           const int o = 4 * (nt & 1);
+                                                           sv[o + 0] = d.x + e.x, sv[o + 1] = d.y + e.y, sv[o + 2] = d.z + e.z, sv[o + 3] = d.w + e.w;
+                                                           if (nt & 1) {
+                                                               const int kc = nt >> 1;
+                                                               dfx_h8 sh, sl;
+                                                               dfx_split8_g(sv, sh, sl, amax);
+                                                               const dfx_h8 woh = wof[(kc * 2 + 0) * 16 + lw], wol = wof[(kc * 2 + 1) * 16 + lw];
+                                                               vj = dfx_mfma_16x16x32_f16(wol, sh, vj);
+                                                               vj = dfx_mfma_16x16x32_f16(woh, sl, vj);
+                                                               vj = dfx_mfma_16x16x32_f16(woh, sh, vj);
+                                                           }
+                                                       });
+            DFX_WAVE_SYNC();   // (the reads of X above are done before a pad column of X is written — and before the next tile's e0 rows are)
+            if (lane < 16) {
+                float *Vp = t == 0 ? Y : X;
+                int lv = lane;
+                DFX_OPAQUE(lv);   // (six loop-invariant strip addresses otherwise: recomputed per tile instead of held — or spilled — across the frame loop)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int i = lv * 3 + j;
+                    Vp[(i >> 2) * LD + C + (i & 3)] = vj[j] * A.unscale_wo;
                 }
             }
-            DFX_WAVE_SYNC();   // (the row reads above are done before a pad column of X is written)
-            if (lane < 48) (t == 0 ? Y : X)[(lane >> 2) * LD + C + (lane & 3)] = vacc;
         }
         DFX_WAVE_SYNC();
         if (lane < E) {
@@ -3695,7 +3733,7 @@ __global__ void __launch_bounds__(DFX_GRU_THREADS, 2) dfx_k_gru_rec(const float 
 // ---------------------------------------------------------------------------------------------------------------------
 #define DFX_GH_ROWS 16
 #define DFX_GS_MAX_LAYERS 8   /* layers one persistent dfx_k_gru_seq launch can carry */
-#define DFX_GS_MAX_CHUNKS 24  /* time chunks of the persistent GRU phase */
+#define DFX_GS_MAX_CHUNKS 96  /* time chunks of the persistent GRU phase (the default is 12: finer cuts lose to the hand-overs, profiles/r05_gru_chain.log) */
 #ifndef DFX_GH_ABLATE
 #define DFX_GH_ABLATE 0  /* dev ablations (tools/dev/gru_h3_bench.hip): 1 no stream refill, 2 no gi loads, 4 no matrix ops, 8 no gate math, 16 no y stores */
 #endif
@@ -3737,7 +3775,14 @@ struct DfxGhSched {
     int idx[DFX_GH_NF];   // index inside its class
     int spos[DFX_GH_FS];  // fragment position of streamed fragment i
 };
-// uniform interleave: the resident fragments consumed between two streamed ones cover the stream's latency
+// uniform interleave: the resident fragments consumed between two streamed ones cover the stream's latency.
+// Round 5, three forms aimed at the recurrence's first-touch gi reads (7.4 us per step under load, 5.7 when they hit in L2: profiles/r04_gi_warm.log),
+// built, measured and not kept (profiles/r05_gru_chain.log): (1) a step that OPENS with a run of 12 / 20 / 28 resident fragments, so that the ring
+// refills queued behind the gi loads are not needed before those have returned (vector loads return in order): 5.15 -> 5.6-5.8 us per step alone,
+// 7.4 -> 7.7-7.9 under load — the streamed part gets denser than the CU's vector-memory path delivers; (2) the gi rows of TWO steps requested
+// together every other step (a second register set: 256 + 254 registers, no scratch): 5.5 alone, 7.6-7.7 under load; (3) non-temporal gi loads /
+// y stores here and non-temporal gi stores / x loads in the input projection: 6.0 alone, 7.8 under load.  The cost of those reads is not an
+// in-order bubble a schedule can hide: it is the L2 capacity they and the side traffic take from the streamed W_hh ring.
 static constexpr DfxGhSched dfx_gh_make_sched() {
     DfxGhSched sc{};
     constexpr int R = DFX_GH_FR + DFX_GH_FL, FS = DFX_GH_FS;

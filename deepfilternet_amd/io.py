@@ -1,8 +1,9 @@
 """Host-side mirror of ``df/io.py`` (load_audio :25-57, save_audio :60-84, get_resample_params :92-111, resample :114-116) with
-the sample work on the MI355X: the file is parsed on the host (RIFF/WAVE PCM16 via the standard library — the reference goes
-through torchaudio, which is not a dependency here), the int16 -> float scaling, the sample-rate conversion and the float -> int16
-encoding run as HIP kernels (csrc/dfx_io.hip), so a file -> file loop like ``enhance.main`` (enhance.py:73-89) keeps its audio on the
-device between decode and encode:
+the sample work on the MI355X: the file is parsed on the host (a RIFF/WAVE reader / writer of its own, below — the reference goes
+through torchaudio, which is not a dependency here; 8 / 16 / 24 / 32-bit integer PCM and 32 / 64-bit IEEE float, plain or
+WAVE_FORMAT_EXTENSIBLE), the int16 -> float scaling, the sample-rate conversion and the float -> int16 encoding run as HIP kernels
+(csrc/dfx_io.hip), so a file -> file loop like ``enhance.main`` (enhance.py:73-89) keeps its audio on the device between decode and
+encode (the rarer sample formats are scaled with torch ops on the device):
 
     audio, meta = load_audio("noisy.wav", sr=48000)          # [C, T] float32 on the GPU, resampled if the file is not 48 kHz
     enhanced = enhance(model, df_state, audio)
@@ -12,7 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-import wave
+import struct
 from dataclasses import dataclass
 from functools import lru_cache
 from typing import Any, Dict, Optional, Tuple, Union
@@ -105,28 +106,111 @@ def float_to_pcm16(audio: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_WAVE_PCM, _WAVE_FLOAT, _WAVE_EXTENSIBLE = 1, 3, 0xFFFE
+
+
+def _read_riff(file: str, frame_offset: int = 0, num_frames: int = -1):
+    """-> (samples [T, C] numpy array in the file's own sample type (24-bit: int32, sign-extended), sample_rate, total frames, bits, float?).
+    RIFF/WAVE with a 'fmt ' chunk of tag 1 (integer PCM), 3 (IEEE float) or 0xFFFE (extensible: the sub-format's first two bytes)."""
+    with open(file, "rb") as f:
+        head = f.read(12)
+        if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+            raise RuntimeError(f"{file}: not a RIFF/WAVE file")
+        fmt = None
+        while True:
+            ch = f.read(8)
+            if len(ch) < 8:
+                raise RuntimeError(f"{file}: no 'data' chunk")
+            cid, size = ch[:4], struct.unpack("<I", ch[4:])[0]
+            if cid == b"fmt ":
+                body = f.read(size + (size & 1))
+                tag, nch, rate, _, align, bits = struct.unpack("<HHIIHH", body[:16])
+                if tag == _WAVE_EXTENSIBLE and size >= 26:
+                    tag = struct.unpack("<H", body[24:26])[0]
+                fmt = (tag, nch, rate, align, bits)
+            elif cid == b"data":
+                if fmt is None:
+                    raise RuntimeError(f"{file}: 'data' chunk before 'fmt '")
+                tag, nch, rate, align, bits = fmt
+                if tag not in (_WAVE_PCM, _WAVE_FLOAT) or (tag == _WAVE_PCM and bits not in (8, 16, 24, 32)) or (tag == _WAVE_FLOAT and bits not in (32, 64)):
+                    raise RuntimeError(f"{file}: unsupported WAVE sample format (tag {tag}, {bits} bits); integer PCM 8/16/24/32 and IEEE float 32/64 are decoded")
+                bps = bits // 8
+                if align != nch * bps or nch < 1:
+                    raise RuntimeError(f"{file}: inconsistent 'fmt ' chunk (block align {align}, {nch} channels x {bps} bytes)")
+                here = f.tell()
+                f.seek(0, 2)
+                size = min(size, f.tell() - here)      # (a streamed file may carry 0xFFFFFFFF / a stale size)
+                total = size // align
+                off = min(max(int(frame_offset or 0), 0), total)
+                n = total - off if num_frames is None or num_frames <= 0 else min(int(num_frames), total - off)
+                f.seek(here + off * align)
+                raw = f.read(n * align)
+                n = len(raw) // align
+                raw = raw[: n * align]
+                if tag == _WAVE_FLOAT:
+                    x = np.frombuffer(raw, dtype="<f4" if bits == 32 else "<f8")
+                elif bits == 8:
+                    x = np.frombuffer(raw, dtype=np.uint8)
+                elif bits == 16:
+                    x = np.frombuffer(raw, dtype="<i2")
+                elif bits == 32:
+                    x = np.frombuffer(raw, dtype="<i4")
+                else:   # 24-bit little endian -> int32 with the sign extended
+                    b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+                    x = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+                    x = (x ^ 0x800000) - 0x800000
+                return x.reshape(n, nch), rate, total, bits, tag == _WAVE_FLOAT
+            else:
+                f.seek(size + (size & 1), 1)
+
+
+def _write_riff(file: str, data: np.ndarray, sr: int, is_float: bool) -> None:
+    """data [T, C]: int16 -> 16-bit PCM (tag 1), float32 -> 32-bit IEEE float (tag 3, with the 'fact' chunk non-PCM formats carry)."""
+    T, nch = data.shape
+    bps = 4 if is_float else 2
+    payload = np.ascontiguousarray(data.astype("<f4" if is_float else "<i2", copy=False)).tobytes()
+    pad = b"\x00" if len(payload) & 1 else b""
+    if is_float:
+        fmt = struct.pack("<HHIIHHH", _WAVE_FLOAT, nch, int(sr), int(sr) * nch * bps, nch * bps, 8 * bps, 0)
+        extra = b"fact" + struct.pack("<II", 4, T)
+    else:
+        fmt = struct.pack("<HHIIHH", _WAVE_PCM, nch, int(sr), int(sr) * nch * bps, nch * bps, 8 * bps)
+        extra = b""
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + extra + b"data" + struct.pack("<I", len(payload)) + payload + pad
+    with open(file, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
 def load_audio(file: str, sr: Optional[int] = None, verbose: bool = True, **kwargs) -> Tuple[torch.Tensor, AudioMetaData]:
     """io.py:25-57: audio [C, T] float32 (on the device), resampled to ``sr`` when given; ``method=`` selects the resampler set.
-    ``pcm16=True`` (extension): a file that needs no resampling is handed back as its int16 samples (on the device) — ``enhance()`` takes
-    them as they are."""
+    Sample formats as torchaudio.load(normalize=True) scales them: int16 / 32768 (a HIP kernel), 24-bit / 2^23, int32 / 2^31,
+    uint8 (x - 128) / 128, float32 as stored, float64 rounded to float32.
+    ``pcm16=True`` (extension): a 16-bit file that needs no resampling is handed back as its int16 samples (on the device) — ``enhance()``
+    takes them as they are."""
     method = kwargs.pop("method", "sinc_fast")
     want_pcm = bool(kwargs.pop("pcm16", False))
-    with wave.open(file, "rb") as w:
-        if w.getsampwidth() != 2 or w.getcomptype() != "NONE":
-            raise RuntimeError(f"{file}: only 16-bit PCM RIFF/WAVE files are decoded here")
-        ch, n, orig_sr = w.getnchannels(), w.getnframes(), w.getframerate()
-        frames = kwargs.get("num_frames", -1)
-        if frames is not None and frames > 0 and sr is not None:
-            frames *= orig_sr // sr                       # io.py:46-47
-        off = kwargs.get("frame_offset", 0)
-        if off:
-            w.setpos(min(off, n))
-        raw = w.readframes(n - off if frames is None or frames <= 0 else min(frames, n - off))
-    info = AudioMetaData(sample_rate=orig_sr, num_frames=n, num_channels=ch)
-    pcm = torch.from_numpy(np.frombuffer(raw, dtype="<i2").reshape(-1, ch).T.copy())   # interleaved -> [C, T]
-    if want_pcm and (sr is None or orig_sr == sr):
-        return pcm.to(_lib.device()).contiguous(), info
-    audio = pcm16_to_float(pcm)
+    frames = kwargs.get("num_frames", -1)
+    off = kwargs.get("frame_offset", 0)
+    if frames is not None and frames > 0 and sr is not None:
+        _, rate0, _, _, _ = _read_riff(file, 0, 1)        # io.py:46-47 scales num_frames by the file's own rate: read it first
+        frames *= rate0 // sr
+    x, orig_sr, n, bits, is_float = _read_riff(file, off, frames)
+    ch = x.shape[1]
+    info = AudioMetaData(sample_rate=orig_sr, num_frames=n, num_channels=ch, bits_per_sample=bits,
+                         encoding="PCM_F" if is_float else ("PCM_U" if bits == 8 else "PCM_S"))
+    xt = torch.from_numpy(np.array(x.T, order="C"))       # interleaved -> [C, T] (a writable copy)
+    if x.dtype == np.dtype("<i2"):
+        if want_pcm and (sr is None or orig_sr == sr):
+            return xt.to(_lib.device()).contiguous(), info
+        audio = pcm16_to_float(xt)
+    else:
+        xd = xt.to(_lib.device())
+        if is_float:
+            audio = xd.to(torch.float32)
+        elif bits == 8:
+            audio = (xd.to(torch.float32) - 128.0) / 128.0
+        else:
+            audio = xd.to(torch.float32) / float(1 << (bits - 1))
     if sr is not None and orig_sr != sr:
         if verbose:
             import warnings
@@ -138,23 +222,25 @@ def load_audio(file: str, sr: Optional[int] = None, verbose: bool = True, **kwar
 
 def save_audio(file: str, audio: Union[torch.Tensor, np.ndarray], sr: int, output_dir: Optional[str] = None,
                suffix: Optional[str] = None, log: bool = False, dtype=torch.int16) -> str:
-    """io.py:60-84 (16-bit PCM only: the reference's float32 option needs torchaudio's encoder)."""
+    """io.py:60-84: ``dtype=torch.int16`` (default) writes 16-bit PCM (float input scaled by 2^15 and truncated, io.py:79-80, on the
+    device), ``dtype=torch.float32`` a 32-bit IEEE-float WAVE (int16 input divided by 2^15, io.py:81-82) — the two files torchaudio.save
+    writes for an int16 / a float32 tensor."""
     outpath = file
     if suffix is not None:
         base, ext = os.path.splitext(file)
         outpath = base + f"_{suffix}" + ext
     if output_dir is not None:
         outpath = os.path.join(output_dir, os.path.basename(outpath))
-    if dtype != torch.int16:
-        raise NotImplementedError("save_audio: only 16-bit PCM output")
+    if dtype not in (torch.int16, torch.float32):
+        raise ValueError(f"save_audio: dtype must be torch.int16 or torch.float32, not {dtype}")
     audio = torch.as_tensor(audio)
     if audio.ndim == 1:
         audio = audio.unsqueeze(0)
-    pcm = audio if audio.dtype == torch.int16 else float_to_pcm16(audio)
-    data = pcm.cpu().numpy().T.astype("<i2", copy=False)  # [T, C] interleaved
-    with wave.open(outpath, "wb") as w:
-        w.setnchannels(data.shape[1])
-        w.setsampwidth(2)
-        w.setframerate(int(sr))
-        w.writeframes(np.ascontiguousarray(data).tobytes())
+    if dtype == torch.int16 and audio.dtype != torch.int16:
+        audio = float_to_pcm16(audio)
+    if dtype == torch.float32 and audio.dtype != torch.float32:
+        audio = audio.to(torch.float32) / (1 << 15)
+    if audio.dtype not in (torch.int16, torch.float32):   # (torchaudio.save takes what it is given: only these two reach it from the branches above)
+        audio = audio.to(torch.float32)
+    _write_riff(outpath, audio.cpu().numpy().T, int(sr), audio.dtype == torch.float32)
     return outpath

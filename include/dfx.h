@@ -196,7 +196,8 @@ int dfx_model_set_run_df(dfx_model *m, int enable);
  *   batch_chunks     dfx_enhance additionally pipelines this many batch chunks (multiples of 16 clips) on separate stream sets.
  * The streams need their own hardware queues: export GPU_MAX_HW_QUEUES=24 before HIP initialises (ROCm maps streams onto 4 queues by
  * default; the Python package sets it on import if it is unset).  The persistent, flag-synchronised GRU phase REQUIRES that its ~8
- * streams make progress independently; dfx_model_create checks that with a handshake between them (DFX_Q_HWQ_PROBE) and selects the
+ * streams make progress independently; the engine checks that with a handshake between them (DFX_Q_HWQ_PROBE) — once per handle, before the
+ * first pass that would use the persistent form (handles that are only streamed through never pay for it) — and selects the
  * event-synchronised form when they do not.  Co-residency with another process's kernels is not under the engine's control: a
  * starved flag wait then ends as a reported DFX_ERR_HIP (see dfx_model_check), never as silent garbage or a hang. */
 int dfx_model_set_pipeline(dfx_model *m, int time_chunks, int min_chunk_frames, int batch_chunks);
@@ -218,7 +219,7 @@ int dfx_model_poll(const dfx_model *m);
 int dfx_model_check(const dfx_model *m);
 /* Read-only facts about a model handle (what = DFX_Q_*). */
 #define DFX_Q_GRU_PERSISTENT 1 /* 1: big multi-stream passes run the GRU phase as ONE persistent, flag-synchronised launch (default on the GPU) */
-#define DFX_Q_HWQ_PROBE 2      /* 1: the streams of that phase were seen to run concurrently at dfx_model_create; 0: they were not (hardware
+#define DFX_Q_HWQ_PROBE 2      /* 1: the streams of that phase were seen to run concurrently (the handshake runs at the first use or at this query); 0: they were not (hardware
                                 * queues shared: GPU_MAX_HW_QUEUES too small or HIP initialised before it was set) and the event-synchronised
                                 * form is used instead; -1: not probed (no streams, exact fp32, CPU interpreter) */
 #define DFX_Q_EXACT_FP32 3     /* 1: DFX_EXACT_FP32=1 was set at creation */

@@ -1,7 +1,9 @@
 """CPU restatement of the steps either side of enhance() in the reference's file loop — TEST INFRASTRUCTURE ONLY.
 
-  * df/io.py:114-116 ``resample`` -> ``torchaudio.functional.resample`` with the parameter sets of io.py:92-111.  torchaudio (2.x;
-    the reference's pyproject pins ``torchaudio >= 0.8, < 2.2``-era APIs, io.py:10-19) is a third-party dependency that is absent from
+  * df/io.py:114-116 ``resample`` -> ``torchaudio.functional.resample`` with the parameter sets of io.py:92-111.  torchaudio (the
+    2.0 - 2.2 releases: the ones whose ``resampling_method`` names are ``sinc_interp_hann`` / ``sinc_interp_kaiser``, the branch io.py:10-14
+    takes when ``from torchaudio import AudioMetaData`` succeeds; ``torchaudio/functional/functional.py`` of v2.1.0 is the text restated here:
+    float64 index grid when no dtype is passed, kernel rounded to float32 at the end) is a third-party dependency that is absent from
     this image, so its published algorithm is restated here (functional.py ``_get_sinc_resample_kernel`` /
     ``_apply_sinc_resample_kernel``): polyphase windowed-sinc bank built in float64 and rounded to float32, zero padding
     (width, width + orig), strided correlation, output trimmed to ceil(new * length / orig).  **Parity unpinned**: no torchaudio

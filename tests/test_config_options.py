@@ -102,7 +102,7 @@ def test_options_that_are_accepted_or_refused(backend):
     DfNet(p, random_state_dict(p, 0))
     p = ModelParams.defaults()
     p.enc_concat, p.emb_gru_skip_enc = True, "identity"      # the reference's own assert (deepfilternet3.py:141)
-    with pytest.raises(NotImplementedError, match="enc_concat"):
+    with pytest.raises(ValueError, match="enc_concat"):       # contradictory options are an invalid value, not a missing kernel
         DfNet(p, {})
     p = ModelParams.defaults()
     p.emb_gru_skip = "conv"

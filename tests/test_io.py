@@ -112,6 +112,88 @@ def test_pcm16_roundtrip_and_wav_files(backend, tmp_path):
     assert rms((back[:, 300:n - 300] - raw[:, 300:n - 300]).cpu().numpy()) < 2e-3   # 44.1k -> 48k -> 44.1k reproduces the tones
 
 
+def _riff(path, fmt_body, payload, extra=b""):
+    import struct
+
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt_body)) + fmt_body + extra + b"data" + struct.pack("<I", len(payload)) + payload
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+def test_wav_sample_formats(backend, tmp_path):
+    """load_audio decodes what torchaudio.load(normalize=True) decodes from RIFF/WAVE (io.py:25-57): integer PCM of 8 / 16 / 24 / 32 bits, IEEE
+    float 32 / 64, plain and WAVE_FORMAT_EXTENSIBLE headers, unknown chunks skipped; save_audio(dtype=torch.float32) writes the 32-bit float
+    file torchaudio.save writes for a float tensor (io.py:60-84) and divides int16 input by 2^15 (io.py:81-82)."""
+    import struct
+
+    from deepfilternet_amd import io as dio
+
+    sr, C = 48000, 2
+    rng = np.random.default_rng(0)
+    x = np.clip(0.5 * rng.standard_normal((257, C)), -0.999, 0.999)
+
+    def fmt(tag, bits, ext=False):
+        bps = bits // 8
+        base = struct.pack("<HHIIHH", 0xFFFE if ext else tag, C, sr, sr * C * bps, C * bps, bits)
+        if not ext:
+            return base
+        guid_tail = bytes.fromhex("000000001000800000aa00389b71")
+        return base + struct.pack("<HHI", 22, bits, 3) + struct.pack("<H", tag) + guid_tail
+
+    # 24-bit, with a LIST chunk in front of the data and an extensible header
+    i24 = np.round(x * (1 << 23)).astype(np.int32)
+    b = np.zeros((i24.size, 3), np.uint8)
+    flat = i24.reshape(-1) & 0xFFFFFF
+    b[:, 0], b[:, 1], b[:, 2] = flat & 255, (flat >> 8) & 255, (flat >> 16) & 255
+    p24 = str(tmp_path / "s24.wav")
+    _riff(p24, fmt(1, 24, ext=True), b.tobytes(), extra=b"LIST" + struct.pack("<I", 5) + b"hello\x00")
+    a, meta = dio.load_audio(p24)
+    assert (meta.sample_rate, meta.num_frames, meta.num_channels, meta.bits_per_sample, meta.encoding) == (sr, 257, C, 24, "PCM_S")
+    assert np.array_equal(a.cpu().numpy(), (i24.T.astype(np.float32) / np.float32(1 << 23)))
+    # 32-bit integers, 8-bit unsigned
+    i32 = np.round(x * (2.0 ** 31 - 1)).astype("<i4")
+    p32 = str(tmp_path / "s32.wav")
+    _riff(p32, fmt(1, 32), i32.tobytes())
+    assert np.array_equal(dio.load_audio(p32)[0].cpu().numpy(), i32.T.astype(np.float32) / np.float32(2.0 ** 31))
+    u8 = np.round(x * 127 + 128).astype(np.uint8)
+    p8 = str(tmp_path / "u8.wav")
+    _riff(p8, fmt(1, 8), u8.tobytes())
+    a8, m8 = dio.load_audio(p8)
+    assert m8.encoding == "PCM_U" and np.array_equal(a8.cpu().numpy(), (u8.T.astype(np.float32) - 128) / 128)
+    # IEEE float 32 / 64; frame_offset / num_frames
+    f32 = x.astype("<f4")
+    pf = str(tmp_path / "f32.wav")
+    _riff(pf, fmt(3, 32) + struct.pack("<H", 0), f32.tobytes(), extra=b"fact" + struct.pack("<II", 4, 257))
+    af, mf = dio.load_audio(pf)
+    assert mf.encoding == "PCM_F" and mf.bits_per_sample == 32 and np.array_equal(af.cpu().numpy(), f32.T)
+    assert np.array_equal(dio.load_audio(pf, frame_offset=7, num_frames=100)[0].cpu().numpy(), f32.T[:, 7:107])
+    pd = str(tmp_path / "f64.wav")
+    _riff(pd, fmt(3, 64, ext=True), x.astype("<f8").tobytes())
+    assert np.array_equal(dio.load_audio(pd)[0].cpu().numpy(), x.T.astype(np.float32))
+    # refused loudly: A-law, a file that is not RIFF
+    pa = str(tmp_path / "alaw.wav")
+    _riff(pa, fmt(6, 8), u8.tobytes())
+    with pytest.raises(RuntimeError, match="unsupported WAVE sample format"):
+        dio.load_audio(pa)
+    (tmp_path / "x.wav").write_bytes(b"OggS" + bytes(40))
+    with pytest.raises(RuntimeError, match="not a RIFF/WAVE"):
+        dio.load_audio(str(tmp_path / "x.wav"))
+    # save_audio(dtype=torch.float32): float tensor as it is, int16 tensor / 2^15
+    out = dio.save_audio(str(tmp_path / "o.wav"), torch.from_numpy(f32.T.copy()), sr, suffix="f", dtype=torch.float32)
+    back, mb = dio.load_audio(out)
+    assert mb.encoding == "PCM_F" and mb.bits_per_sample == 32 and np.array_equal(back.cpu().numpy(), f32.T)
+    pcm = torch.from_numpy((x.T * 32767).astype(np.int16))
+    out = dio.save_audio(str(tmp_path / "o.wav"), pcm, sr, suffix="i2f", dtype=torch.float32)
+    assert np.array_equal(dio.load_audio(out)[0].cpu().numpy(), pcm.numpy().astype(np.float32) / 32768)
+    out = dio.save_audio(str(tmp_path / "o.wav"), pcm, sr, suffix="i", dtype=torch.int16)       # int16 in, int16 file: unchanged samples
+    assert torch.equal(dio.load_audio(out, pcm16=True)[0].cpu(), pcm)
+    with pytest.raises(ValueError):
+        dio.save_audio(str(tmp_path / "o.wav"), pcm, sr, dtype=torch.float64)
+    # the stdlib reader agrees about the 16-bit file this writer produced
+    with wave.open(out, "rb") as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (C, 2, sr, 257)
+
+
 def test_enhance_files_loop(backend, tmp_path):
     """df.enhance.main's loop (enhance.py:73-89): file -> load/resample -> enhance -> resample back -> save, against the same chain
     on the oracles."""

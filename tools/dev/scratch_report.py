@@ -15,15 +15,28 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-fun
 
 
 def remarks(src):
-    return src, subprocess.run(["hipcc"] + FLAGS + [os.path.join(CSRC, src)], capture_output=True, text=True).stderr
+    r = subprocess.run(["hipcc"] + FLAGS + [os.path.join(CSRC, src)], capture_output=True, text=True)
+    return src, r.returncode, r.stderr
 
 
 def main():
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     bad = 0
     with ThreadPoolExecutor(len(srcs)) as ex:
-        for src, err in ex.map(remarks, srcs):
+        for src, rc, err in ex.map(remarks, srcs):
             name, vg = None, "?"
+            if rc != 0:   # a source that does not compile has no remarks: that is a failure, not "no spills"
+                print(f"{src}: hipcc failed (rc {rc})\n{err[-2000:]}")
+                bad += 1
+                continue
+            with open(os.path.join(CSRC, src)) as f:
+                text = f.read()
+            defines_kernels = "__global__" in text or any(
+                "__global__" in open(os.path.join(CSRC, h)).read() for h in re.findall(r'#include "(dfx_\w+\.h)"', text) if os.path.exists(os.path.join(CSRC, h)))
+            if defines_kernels and "Function Name:" not in err:
+                print(f"{src}: no kernel-resource-usage remarks although the source defines kernels (toolchain without the remark pass?)")
+                bad += 1
+                continue
             for line in err.splitlines():
                 m = re.search(r"Function Name: (\S+)", line)
                 if m:
