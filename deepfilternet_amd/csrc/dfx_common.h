@@ -56,6 +56,7 @@ struct dfx_state {
     std::vector<float> window_host;
     float *d_window = nullptr;  // [N]
     float2 *d_tw = nullptr;     // [N] exp(-2*pi*i*k/N)
+    unsigned char *d_mfft = nullptr;   // N == 960 only: tables of the matrix-pipe 480-point transform, forward then inverse (DFX_MFFT_TABLE_BYTES each)
     dfx_bands *bands = nullptr;
 };
 

@@ -248,6 +248,47 @@ static int make_plan(int N, DfxFftPlan *pl) {
     return rem == 1 ? 0 : -1;
 }
 
+// Tables of dfx_fft480_mfma for one direction (sg = -1 forward, +1 inverse): see dfx_dsp_kernels.h.  Built in double precision; matrix
+// entries scaled by 2^13 and split into f16 hi / lo, the twiddle factors carry 2^-17.
+static void build_mfft_table(int sg, unsigned char *dst) {
+    uint16_t *fr = reinterpret_cast<uint16_t *>(dst);
+    const double s13 = 8192.0;
+    auto put = [&](int frag, int lane, int i, double v) {   // fragment pair (frag, frag + 1) = (hi, lo)
+        const float w = (float)(v * s13);
+        const uint16_t hb = dfx_f32_to_f16_bits(w);
+        const uint16_t lb = dfx_f32_to_f16_bits(w - dfx_f16_bits_to_f32(hb));
+        fr[((size_t)frag * 64 + lane) * 8 + i] = hb;
+        fr[((size_t)(frag + 1) * 64 + lane) * 8 + i] = lb;
+    };
+    for (int l = 0; l < 64; ++l) {
+        const int jl = l & 15, q = l >> 4;
+        for (int i = 0; i < 8; ++i) {
+            // first product, B operand: column k1 = jl, k-slot 8 q + i = (re | im) of n1
+            const int k = 8 * q + i, n1 = k & 15;
+            const double th = 2.0 * M_PI * (double)((n1 * jl) % 16) / 16.0, wr = cos(th), wi = sg * sin(th);
+            put(0, l, i, k < 16 ? wr : -wi);   // -> Yr
+            put(2, l, i, k < 16 ? wi : wr);    // -> Yi
+            // second product, A operand: row k2 = 16 t2 + jl, k-slot i <-> n2 = 16 (i >> 2) + 4 q + (i & 3)
+            const int n2 = 16 * (i >> 2) + 4 * q + (i & 3);
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const int k2 = 16 * t2 + jl;
+                const bool ok = n2 < 30 && k2 < 30;
+                const double ph = 2.0 * M_PI * (double)((n2 * k2) % 30) / 30.0;
+                put(DFX_MFFT_FRAG1 + (0 * 2 + t2) * 2, l, i, ok ? cos(ph) : 0.0);
+                put(DFX_MFFT_FRAG1 + (1 * 2 + t2) * 2, l, i, ok ? sg * sin(ph) : 0.0);
+            }
+        }
+        // twiddle factors of the lane's eight values: n2 = 16 mt + 4 q + r, k1 = jl
+        float2 *tw = reinterpret_cast<float2 *>(dst + (size_t)(DFX_MFFT_FRAG1 + DFX_MFFT_FRAG3) * 64 * 16) + l * 8;
+        for (int mt = 0; mt < 2; ++mt)
+            for (int r = 0; r < 4; ++r) {
+                const int n2 = 16 * mt + 4 * q + r;
+                const double a = 2.0 * M_PI * (double)((n2 * jl) % 480) / 480.0, sc = n2 < 30 ? 1.0 / 131072.0 : 0.0;
+                tw[4 * mt + r] = make_float2((float)(cos(a) * sc), (float)(sg * sin(a) * sc));
+            }
+    }
+}
+
 extern "C" int dfx_state_create(int sr, int fft_size, int hop_size, int nb_bands, int min_nb_erb_freqs, dfx_state **out) {
     if (!out || sr <= 0 || fft_size <= 0 || hop_size <= 0 || nb_bands <= 0)
         DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_state_create: bad arguments");
@@ -284,6 +325,12 @@ extern "C" int dfx_state_create(int sr, int fft_size, int hop_size, int nb_bands
     dfx_erb_fb(sr, fft_size, nb_bands, min_nb_erb_freqs, widths.data());
     int rc = upload(&st->d_window, st->window_host.data(), st->window_host.size());
     if (!rc) rc = upload(&st->d_tw, tw.data(), tw.size());
+    if (!rc && dfx_plan_is_480(st->plan)) {
+        std::vector<unsigned char> mt(2 * DFX_MFFT_TABLE_BYTES);
+        build_mfft_table(-1, mt.data());
+        build_mfft_table(+1, mt.data() + DFX_MFFT_TABLE_BYTES);
+        rc = upload(&st->d_mfft, mt.data(), mt.size());
+    }
     if (!rc) rc = dfx_bands_create(widths.data(), nb_bands, &st->bands);
     if (!rc && st->bands->F != fft_size / 2 + 1) {
         dfx_set_error("ERB widths sum to %d, expected %d", st->bands->F, fft_size / 2 + 1);
@@ -300,6 +347,7 @@ extern "C" void dfx_state_free(dfx_state *st) {
     if (!st) return;
     if (st->d_window) (void)hipFree(st->d_window);
     if (st->d_tw) (void)hipFree(st->d_tw);
+    if (st->d_mfft) (void)hipFree(st->d_mfft);
     dfx_bands_free(st->bands);
     delete st;
 }
@@ -337,8 +385,14 @@ static bool ana_in_place(const dfx_state *st) {
     const DfxFftPlan &pl = st->plan;
     return !off && pl.M == 480 && pl.nstage == 5 && pl.radix[0] == 4 && pl.radix[1] == 4 && pl.radix[2] == 2 && pl.radix[3] == 3 && pl.radix[4] == 5;
 }
-static size_t ana_smem_bytes(const dfx_state *st) {
-    return (size_t)st->N * 12 + (size_t)DFX_DSP_TEAMS * (ana_in_place(st) ? (size_t)DFX_FFT480_BUF : 2 * (size_t)(st->plan.M + 2)) * 8 +   // (in place: one buffer per frame, with room for the transform's padded layout)
+// the 480-point transform on the matrix pipe (dfx_fft480_mfma) instead of the radix passes: DFX_FFT_MFMA=1.  Not the default: built, validated
+// and measured in round 5 — analysis 0.535 vs 0.478 ms, the finishing kernel 0.74 vs 0.63 (profiles/r05_dft_mfma.log)
+static bool fft_mfma(const dfx_state *st) {
+    const char *e = getenv("DFX_FFT_MFMA");   // read per launch, like DFX_FFT_IN_PLACE
+    return st->d_mfft && e && e[0] == '1';
+}
+static size_t ana_smem_bytes(const dfx_state *st, bool mf = false) {
+    return (mf ? (size_t)DFX_MFFT_FRAG3 * 64 * 16 : 0) + (size_t)st->N * 12 + (size_t)DFX_DSP_TEAMS * (ana_in_place(st) ? (size_t)DFX_FFT480_BUF : 2 * (size_t)(st->plan.M + 2)) * 8 +   // (in place: one buffer per frame, with room for the transform's padded layout)
            (((size_t)(2 * st->nb + 1 + 3 * 64 + st->nb + 1 + DFX_DSP_TEAMS * 64) * 4 + 15) & ~(size_t)15);   // + the ERB band tables and segment sums (analysis)
 }
 static int grid_for(int64_t work_groups, int per_cu = 8) {
@@ -372,16 +426,18 @@ int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t 
         A.nb = st->nb;
         A.wnorm = st->wnorm;
         A.plan = st->plan;
-        const bool ip = ana_in_place(st);
-        const size_t smem = ana_smem_bytes(st);
-        const int grid = grid_for(dfx_ceil_div(B * Tf, DFX_DSP_TEAMS), ip ? 9 : 8);   // (three resident workgroups per CU in place: whole rounds)
+        const bool ip = ana_in_place(st), mf = ip && fft_mfma(st);
+        const size_t smem = ana_smem_bytes(st, mf);
+        A.mfft = mf ? st->d_mfft : nullptr;
+        const int grid = grid_for(dfx_ceil_div(B * Tf, DFX_DSP_TEAMS), ip ? (mf ? 8 : 9) : 8);   // (three resident workgroups per CU in place, two on the matrix pipe: whole rounds)
         DfxKScope ks(DFX_K_ANALYSIS, s);
         auto go = [&](auto kern) -> int {
             if (smem > 64 * 1024) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)kern, smem));
             dfx_launch(kern, dim3(grid), dim3(DFX_DSP_THREADS), smem, s, A);
             return DFX_OK;
         };
-        if (int rc = ip ? (x_i16 ? go(dfx_k_analysis<true, true>) : go(dfx_k_analysis<true, false>))
+        if (int rc = mf ? (x_i16 ? go(dfx_k_analysis<true, true, true>) : go(dfx_k_analysis<true, false, true>))
+                   : ip ? (x_i16 ? go(dfx_k_analysis<true, true>) : go(dfx_k_analysis<true, false>))
                         : (x_i16 ? go(dfx_k_analysis<false, true>) : go(dfx_k_analysis<false, false>)))
             return rc;
         DFX_LAUNCH_CHECK();
@@ -472,11 +528,12 @@ int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int6
     // in place like the analysis (one buffer per frame, six waves per SIMD; without the register prefetch of the next frame, which would spill
     // there): 1.07-1.13 -> 0.93-1.03 ms alone; DFX_FFT_IN_PLACE=2 keeps two buffers here, =0 in both kernels
     const char *ipe = getenv("DFX_FFT_IN_PLACE");
-    const bool ip = ana_in_place(st) && !(ipe && ipe[0] == '2');
-    const size_t smem = ip ? ana_smem_bytes(st) : dsp_smem_bytes(st);
+    const bool ip = ana_in_place(st) && !(ipe && ipe[0] == '2'), mf = ip && fft_mfma(st);
+    const size_t smem = ip ? ana_smem_bytes(st, mf) : dsp_smem_bytes(st);
+    A.mfft = mf ? st->d_mfft + DFX_MFFT_TABLE_BYTES : nullptr;   // (the inverse tables)
     int64_t nblk = B * A.chunks;
     // persistent workgroups (the twiddle / window tables are staged once per workgroup): a few per CU, grid-stride over the work items
-    const int64_t cap = (int64_t)dfx_env_num_cus() * (ip ? 9 : 8);   // (three resident workgroups per CU in place: whole rounds)
+    const int64_t cap = (int64_t)dfx_env_num_cus() * (ip ? (mf ? 8 : 9) : 8);   // (three resident workgroups per CU in place, two on the matrix pipe: whole rounds)
     if (nblk > cap) nblk = cap;
     DfxKScope ks(DFX_K_SYNTHESIS, stream);
     auto go = [&](auto kern) -> int {
@@ -484,7 +541,8 @@ int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int6
         dfx_launch(kern, dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, stream, A);
         return DFX_OK;
     };
-    if (int rc = ip ? (out_i16 ? go(dfx_k_synthesis<true, true>) : go(dfx_k_synthesis<true, false>))
+    if (int rc = mf ? (out_i16 ? go(dfx_k_synthesis<true, true, true>) : go(dfx_k_synthesis<true, false, true>))
+               : ip ? (out_i16 ? go(dfx_k_synthesis<true, true>) : go(dfx_k_synthesis<true, false>))
                     : (out_i16 ? go(dfx_k_synthesis<false, true>) : go(dfx_k_synthesis<false, false>)))
         return rc;
     DFX_LAUNCH_CHECK();
@@ -529,18 +587,23 @@ int dfx_launch_synthesis_rows(const dfx_state *st, const float *spec, int64_t sp
     A.seg_chunks = (int)dfx_ceil_div(chunks, segs);
     A.segs = (int)dfx_ceil_div(chunks, A.seg_chunks);
     int64_t nblk = B * A.segs;
-    const int64_t cap = (int64_t)dfx_env_num_cus() * 3;
+    const bool mf = fft_mfma(st);
+    A.mfft = mf ? st->d_mfft + DFX_MFFT_TABLE_BYTES : nullptr;   // (the inverse tables)
+    const int64_t cap = (int64_t)dfx_env_num_cus() * (mf ? 2 : 3);
     if (nblk > cap) nblk = cap;
-    const size_t smem = DFX_SYNR_SMEM;
+    const size_t smem = mf ? DFX_SYNR_SMEM_MF : DFX_SYNR_SMEM;
     const bool pf = pf_beta > 0.f || atten_lim > 0.f;
     DfxKScope ks(DFX_K_SYNTHESIS, s);
     auto go = [&](auto kern) { dfx_launch(kern, dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, s, A); };
     if (!with_df) {
-        out_i16 ? go(dfx_k_synthesis_rows<0, false, true>) : go(dfx_k_synthesis_rows<0, false, false>);
+        mf ? (out_i16 ? go(dfx_k_synthesis_rows<0, false, true, true>) : go(dfx_k_synthesis_rows<0, false, false, true>))
+           : (out_i16 ? go(dfx_k_synthesis_rows<0, false, true>) : go(dfx_k_synthesis_rows<0, false, false>));
     } else if (pf) {
-        out_i16 ? go(dfx_k_synthesis_rows<5, true, true>) : go(dfx_k_synthesis_rows<5, true, false>);
+        mf ? (out_i16 ? go(dfx_k_synthesis_rows<5, true, true, true>) : go(dfx_k_synthesis_rows<5, true, false, true>))
+           : (out_i16 ? go(dfx_k_synthesis_rows<5, true, true>) : go(dfx_k_synthesis_rows<5, true, false>));
     } else {
-        out_i16 ? go(dfx_k_synthesis_rows<5, false, true>) : go(dfx_k_synthesis_rows<5, false, false>);
+        mf ? (out_i16 ? go(dfx_k_synthesis_rows<5, false, true, true>) : go(dfx_k_synthesis_rows<5, false, false, true>))
+           : (out_i16 ? go(dfx_k_synthesis_rows<5, false, true>) : go(dfx_k_synthesis_rows<5, false, false>));
     }
     DFX_LAUNCH_CHECK();
     return DFX_OK;

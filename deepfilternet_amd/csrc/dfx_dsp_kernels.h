@@ -313,7 +313,7 @@ static __device__ __forceinline__ void dfx_fft_pass_ip(float2 *x, const float2 *
     DFX_WAVE_SYNC();
 }
 // the 48 kHz / 20 ms configuration of every shipped model: N = 960, M = 480 = 4*4*2*3*5 (make_plan's order)
-static __device__ __forceinline__ bool dfx_plan_is_480(const DfxFftPlan &pl) {
+static __host__ __device__ __forceinline__ bool dfx_plan_is_480(const DfxFftPlan &pl) {
     return pl.M == 480 && pl.nstage == 5 && pl.radix[0] == 4 && pl.radix[1] == 4 && pl.radix[2] == 2 && pl.radix[3] == 3 && pl.radix[4] == 5;
 }
 // (the lane index is made opaque before every pass: the passes' LDS addresses depend on nothing but the lane, and a compiler that hoists
@@ -350,6 +350,141 @@ static __device__ __forceinline__ void dfx_fft480_ip(float2 *x, const float2 *tw
     DFX_OPAQUE(l);
     dfx_fft_pass_ip<5, SG, 480, 5, 96>(x, tw, l, active);
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The 480-point transform on the matrix pipe (round 5).  The counters of the VALU form (profiles/r05_pmc_side_kernels_start_of_round.txt)
+// show the STFT kernels co-bound by the LDS pipe (82 % busy, half of it bank conflicts of the strided autosort passes) and the VALU
+// (66 %: ~480 of a frame's ~830 vector instructions are the three passes, most of them index arithmetic and moves, not flops).  Here the
+// transform of ONE frame (one wave, as before: a drop-in for dfx_fft480_ip between the same LDS layouts) is two chained matrix products
+// with 16 columns, 480 = 16 x 30, input n = 30 n1 + n2, output k = k1 + 16 k2:
+//     Y[n2][k1]  = sum_n1 z[30 n1 + n2] W16^(n1 k1)          A = the frame's data (rows n2, k = (re | im, n1)), B = the 16-point matrix
+//     Y'[n2][k1] = Y[n2][k1] W480^(n2 k1)                    eight complex products per lane, the factors lane constants in registers
+//     X[k2][k1]  = sum_n2 W30^(n2 k2) Y'[n2][k1]             A = the 30-point matrix (rows k2), B = Y' exactly as the first product's D
+//                                                             fragments leave it (lane (k1, q): n2 = 16 (i >> 2) + 4 q + (i & 3))
+// 12 + 24 matrix ops of the fp16-split kind (hi hi + hi lo + lo hi, fp32 accumulate) per frame instead of 480 vector instructions and 77
+// LDS operations.  Block floating point: the frame is scaled by the power of two that puts its largest component just below 2^14 before
+// the first split (any finite input keeps ~22 bits relative to its own peak; no range guard, no fallback), the scales of the constant
+// matrices (2^13) and of the twiddle factors (2^-17) are fixed, the result is unscaled on its way back to LDS.  Measured against the
+// double-precision transform: 1.5e-7 of the frame's peak (the radix passes in fp32: 3e-8..1e-7) — tools/dev/dft_mfma_check.py.
+// Tables (dfx_state::d_mfft, one set per direction): 4 fragments of the 16-point matrix [Br hi, Br lo, Bi hi, Bi lo][64] (registers), 8 of the
+// 30-point matrix [Wr | Wi][rows 0..15 | 16..29][hi, lo][64] (staged in LDS by the kernel), 8 complex twiddle factors per lane (registers).
+// ---------------------------------------------------------------------------------------------------------------------
+#define DFX_MFFT_FRAG1 4
+#define DFX_MFFT_FRAG3 8
+#define DFX_MFFT_TABLE_BYTES ((size_t)(DFX_MFFT_FRAG1 + DFX_MFFT_FRAG3) * 64 * 16 + (size_t)64 * 8 * 8)   /* per direction */
+struct DfxMfftRegs {
+    dfx_h8 b1[DFX_MFFT_FRAG1];
+    float2 tw[8];
+};
+static __device__ __forceinline__ void dfx_mfft_load(DfxMfftRegs &R, const unsigned char *table, int lane) {
+    const dfx_h8 *fr = reinterpret_cast<const dfx_h8 *>(table);
+#pragma unroll
+    for (int i = 0; i < DFX_MFFT_FRAG1; ++i) R.b1[i] = fr[i * 64 + lane];
+    const float2 *tw = reinterpret_cast<const float2 *>(table + (size_t)(DFX_MFFT_FRAG1 + DFX_MFFT_FRAG3) * 64 * 16);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) R.tw[i] = tw[lane * 8 + i];
+}
+// x: the frame's 480 complex values in LDS (natural order), transformed in place; a3: the 30-point fragments in LDS [8][64]
+static __device__ __forceinline__ void dfx_fft480_mfma(float2 *x, const DfxMfftRegs &R, const dfx_h8 *a3, int lane, bool active) {
+    int l = lane;
+    DFX_OPAQUE(l);   // (addresses recomputed per frame instead of living in registers across the frame loop, as in dfx_fft480_ip)
+    const int jl = l & 15, q = l >> 4;
+    float av[2][8];
+    if (active) {
+        // A operand of the first product: row n2 = 16 mt + jl (rows 30, 31 re-read row 29: their results meet zero weights), k-slot 8 q + i =
+        // (re | im)(z[30 n1 + n2]), n1 = 8 (q & 1) + i, the imaginary parts in the upper half of k
+        const float *xf = reinterpret_cast<const float *>(x);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int n2 = 16 * mt + jl < 30 ? 16 * mt + jl : 29;
+            const float *p = xf + 2 * n2 + (q >> 1) + 480 * (q & 1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) av[mt][i] = p[60 * i];
+        }
+    }
+    DFX_WAVE_SYNC();   // every read of the frame precedes the first write of the result (in place)
+    if (active) {
+        float m = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) m = fmaxf(m, fabsf(av[mt][i]));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        int e = 0;
+        if (m > 0.f && m < 3.0e38f) {
+            int ex;
+            (void)frexpf(m, &ex);   // m = f * 2^ex, f in [0.5, 1)
+            e = 14 - ex;
+            e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        }
+        const float sc = ldexpf(1.f, e), us = ldexpf(1.f, -e - 9);
+        dfx_h8 ah[2], al[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) av[mt][i] *= sc;
+            dfx_split8(av[mt], ah[mt], al[mt]);
+        }
+        // Y (scaled 2^(e + 13)): lane (k1 = jl, q) holds rows n2 = 16 mt + 4 q + r of (Yr | Yi)
+        f32x4 y[2][2];
+        // (term-major over the four accumulators: a dependent op is four ops behind its predecessor)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) y[mt][c] = dfx_mfma_16x16x32_f16(al[mt], R.b1[2 * c], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) y[mt][c] = dfx_mfma_16x16x32_f16(ah[mt], R.b1[2 * c + 1], y[mt][c]);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) y[mt][c] = dfx_mfma_16x16x32_f16(ah[mt], R.b1[2 * c], y[mt][c]);
+        DFX_MFMA_GUARD();
+        // twiddle: element 4 mt + r of (yr8 | yi8) = Y'[n2 = 16 mt + 4 q + r][k1] scaled 2^(e - 4): the k order of the second product's B operand
+        float yr8[8], yi8[8];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float2 w = R.tw[4 * mt + r];
+                const float a = y[mt][0][r], b = y[mt][1][r];
+                yr8[4 * mt + r] = a * w.x - b * w.y;
+                yi8[4 * mt + r] = a * w.y + b * w.x;
+            }
+        dfx_h8 rh, rl, ih, il;
+        dfx_split8(yr8, rh, rl);
+        dfx_split8(yi8, ih, il);
+        // X[k2][k1] (scaled 2^(e + 9)): Xr = Wr Yr' - Wi Yi', Xi = Wi Yr' + Wr Yi'; fragments [Wr | Wi][tile][hi, lo]
+        const dfx_h8 *fl = a3 + l;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const dfx_h8 wrh = fl[((0 * 2 + t2) * 2 + 0) * 64], wrl = fl[((0 * 2 + t2) * 2 + 1) * 64];
+            const dfx_h8 wih = fl[((1 * 2 + t2) * 2 + 0) * 64], wil = fl[((1 * 2 + t2) * 2 + 1) * 64];
+            // four independent chains of three, term-major: a dependent op is three ops behind its predecessor
+            f32x4 pa = dfx_mfma_16x16x32_f16(wrl, rh, f32x4{0.f, 0.f, 0.f, 0.f});   // Wr Yr'
+            f32x4 pb = dfx_mfma_16x16x32_f16(wil, ih, f32x4{0.f, 0.f, 0.f, 0.f});   // Wi Yi'
+            f32x4 pc = dfx_mfma_16x16x32_f16(wil, rh, f32x4{0.f, 0.f, 0.f, 0.f});   // Wi Yr'
+            f32x4 pd = dfx_mfma_16x16x32_f16(wrl, ih, f32x4{0.f, 0.f, 0.f, 0.f});   // Wr Yi'
+            pa = dfx_mfma_16x16x32_f16(wrh, rl, pa);
+            pb = dfx_mfma_16x16x32_f16(wih, il, pb);
+            pc = dfx_mfma_16x16x32_f16(wih, rl, pc);
+            pd = dfx_mfma_16x16x32_f16(wrh, il, pd);
+            pa = dfx_mfma_16x16x32_f16(wrh, rh, pa);
+            pb = dfx_mfma_16x16x32_f16(wih, ih, pb);
+            pc = dfx_mfma_16x16x32_f16(wih, rh, pc);
+            pd = dfx_mfma_16x16x32_f16(wrh, ih, pd);
+        DFX_MFMA_GUARD();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k2 = 16 * t2 + 4 * q + r;
+                if (k2 < 30) x[jl + 16 * k2] = make_float2((pa[r] - pb[r]) * us, (pc[r] + pd[r]) * us);
+            }
+        }
+    }
+    DFX_WAVE_SYNC();
 }
 
 // Complex FFT of length pl.M by one 64-lane team.  Data starts in `a`; returns the buffer that holds the result.
@@ -445,6 +580,7 @@ struct DfxAnaArgs {
     int hop, nb;
     float wnorm;
     DfxFftPlan plan;
+    const unsigned char *mfft = nullptr;   // MF instances: the forward tables of dfx_fft480_mfma
 };
 
 // STFT analysis: frame (b,t) = rfft_N( window * stream[(t+1)*hop-N : (t+1)*hop] ) * wnorm   (lib.rs:356-394),
@@ -452,13 +588,16 @@ struct DfxAnaArgs {
 // Optional fused ERB band energies in dB (lib.rs:206-212 without the norm; transforms.rs:236-253).
 // IP: the 480-point plan, transformed in place (one LDS buffer per frame; a kernel of its own so that the generic plan's run-time loops
 // do not cost it registers: three workgroups = six waves per SIMD have to fit)
-template <bool IP, bool I16 = false>
-__global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_analysis(DfxAnaArgs A) {
+// MF: the transform on the matrix pipe (dfx_fft480_mfma; its 30-point fragments, 8 KB, sit behind the window table; four waves per SIMD)
+template <bool IP, bool I16 = false, bool MF = false>
+__global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? (MF ? 4 : 6) : 4) dfx_k_analysis(DfxAnaArgs A) {
+    static_assert(!MF || IP, "the matrix-pipe transform replaces the in-place 480-point plan");
     DFX_DYN_SMEM(unsigned char, smem);
     const int N = A.plan.N, M = A.plan.M, F = M + 1;
     float2 *tw = reinterpret_cast<float2 *>(smem);                       // [N]
     float *win = reinterpret_cast<float *>(smem + (size_t)N * 8);        // [N]
-    const size_t team_off = (size_t)N * 12;
+    dfx_h8 *a3s = reinterpret_cast<dfx_h8 *>(smem + (size_t)N * 12);    // [8][64] (MF)
+    const size_t team_off = (size_t)N * 12 + (MF ? (size_t)DFX_MFFT_FRAG3 * 64 * 16 : 0);
     const size_t buf_elems = IP ? (size_t)DFX_FFT480_BUF : (size_t)(M + 2);   // M+1 used, padded to keep 16-byte carve (in place: room for the transform's padded layout)
     // (the team = wave index is uniform across the wave: frame index, clip / frame split — a 64-bit division — and the row bases stay scalar)
     const int team = dfx_wave_uniform(threadIdx.x / DFX_DSP_TEAM), lane = threadIdx.x % DFX_DSP_TEAM;
@@ -498,6 +637,11 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_analysis(Df
                 win[i] = wv[u];
             }
         }
+    }
+    DfxMfftRegs mfr;
+    if constexpr (MF) {
+        for (int i = threadIdx.x; i < DFX_MFFT_FRAG3 * 64; i += DFX_DSP_THREADS) a3s[i] = reinterpret_cast<const dfx_h8 *>(A.mfft)[DFX_MFFT_FRAG1 * 64 + i];
+        dfx_mfft_load(mfr, A.mfft, lane);
     }
     __syncthreads();
     const int64_t nframes = A.B * A.Tf;
@@ -559,7 +703,8 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_analysis(Df
         float *pw = nullptr;    // |X|^2 per bin for the ERB feature (float array)
         int pws = 1;            // stride of pw in floats
         if constexpr (IP) {
-            dfx_fft480_ip<-1>(bufA, tw, lane, active);
+            if constexpr (MF) dfx_fft480_mfma(bufA, mfr, a3s, lane, active);
+            else dfx_fft480_ip<-1>(bufA, tw, lane, active);
             // real post-pass on the pairs (k, M-k): both bins of a pair need Z[k] and Z[M-k] and nothing else, so a lane that owns the pair
             // can put |X|^2 of the two bins back into the .x halves of the two slots it has just read (pw stride 2 floats; slot M takes
             // the Nyquist bin)
@@ -720,19 +865,27 @@ struct DfxSynArgs {
     int hop, R /* N/hop rounded up: frames overlapping one output hop */, outf /* output frames per chunk */;
     int chunks;           // chunks per row (including the tail chunk that produces mem_out)
     DfxFftPlan plan;
+    const unsigned char *mfft = nullptr;   // MF instances: the inverse tables of dfx_fft480_mfma
 };
 
 // ISTFT + window + overlap-add (lib.rs:396-427).  A workgroup produces `outf` consecutive output hops of one row from
 // DFX_DSP_TEAMS = outf + R - 1 frames (the first R-1 are halo frames recomputed instead of carried through memory).
 // Sum order per output sample follows the reference: oldest contribution first, the current frame last.
 // IP: the 480-point plan in place, one LDS buffer per frame (see dfx_k_analysis<IP>).
-template <bool IP, bool I16 = false>
-__global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_synthesis(DfxSynArgs A) {
+template <bool IP, bool I16 = false, bool MF = false>
+__global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? (MF ? 4 : 6) : 4) dfx_k_synthesis(DfxSynArgs A) {
+    static_assert(!MF || IP, "the matrix-pipe transform replaces the in-place 480-point plan");
     DFX_DYN_SMEM(unsigned char, smem);
     const int N = A.plan.N, M = A.plan.M;
     float2 *tw = reinterpret_cast<float2 *>(smem);
     float *win = reinterpret_cast<float *>(smem + (size_t)N * 8);
-    const size_t team_off = (size_t)N * 12;
+    dfx_h8 *a3s = reinterpret_cast<dfx_h8 *>(smem + (size_t)N * 12);    // [8][64] (MF)
+    const size_t team_off = (size_t)N * 12 + (MF ? (size_t)DFX_MFFT_FRAG3 * 64 * 16 : 0);
+    DfxMfftRegs mfr;
+    if constexpr (MF) {
+        for (int i = threadIdx.x; i < DFX_MFFT_FRAG3 * 64; i += DFX_DSP_THREADS) a3s[i] = reinterpret_cast<const dfx_h8 *>(A.mfft)[DFX_MFFT_FRAG1 * 64 + i];
+        dfx_mfft_load(mfr, A.mfft, (int)(threadIdx.x % DFX_DSP_TEAM));
+    }
     const size_t buf_elems = IP ? (size_t)DFX_FFT480_BUF : (size_t)(M + 2);
     constexpr int NBUF = IP ? 1 : 2;   // buffers per frame
     const int team = dfx_wave_uniform(threadIdx.x / DFX_DSP_TEAM), lane = threadIdx.x % DFX_DSP_TEAM;   // (wave-uniform: scalar frame / row arithmetic)
@@ -860,7 +1013,8 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? 6 : 4) dfx_k_synthesis(D
             }
         }
         DFX_WAVE_SYNC();
-        dfx_fft480_ip<+1>(bufA, tw, lane, active);
+        if constexpr (MF) dfx_fft480_mfma(bufA, mfr, a3s, lane, active);
+        else dfx_fft480_ip<+1>(bufA, tw, lane, active);
     } else {
         if (active)
             for (int k = lane; k < M; k += DFX_DSP_TEAM) bufA[k] = zbin(k, bufB[k], bufB[M - k]);
@@ -1664,16 +1818,24 @@ struct DfxSynRowsArgs {
     int nbdf, lookahead, nb;
     float pf_beta, atten_lim;
     int segs, seg_chunks;     // segments per row, 8-frame chunks per segment
+    const unsigned char *mfft = nullptr;   // MF instances: the inverse tables of dfx_fft480_mfma
 };
 #define DFX_SYNR_SMEM ((size_t)960 * 12 + (size_t)DFX_DSP_TEAMS * DFX_FFT480_BUF * 8 + (size_t)2 * 480 * 4 + 512)
+#define DFX_SYNR_SMEM_MF (DFX_SYNR_SMEM + (size_t)DFX_MFFT_FRAG3 * 64 * 16)
 
-template <int O, bool PF, bool I16 = false>
-__global__ void __launch_bounds__(DFX_DSP_THREADS, (PF && I16) ? 5 : 6) dfx_k_synthesis_rows(DfxSynRowsArgs A) {   // (post-filter + 16-bit output: two registers over the budget of six waves per SIMD)
+template <int O, bool PF, bool I16 = false, bool MF = false>
+__global__ void __launch_bounds__(DFX_DSP_THREADS, MF ? 4 : ((PF && I16) ? 5 : 6)) dfx_k_synthesis_rows(DfxSynRowsArgs A) {   // (post-filter + 16-bit output: two registers over the budget of six waves per SIMD)
     constexpr int M = 480, N = 960, HOP = 480, NTM = DFX_DSP_TEAMS, BUF = DFX_FFT480_BUF;
     DFX_DYN_SMEM(unsigned char, smem);
     float2 *tw = reinterpret_cast<float2 *>(smem);
     float *win = reinterpret_cast<float *>(smem + (size_t)N * 8);
-    float2 *bufs = reinterpret_cast<float2 *>(smem + (size_t)N * 12);
+    dfx_h8 *a3s = reinterpret_cast<dfx_h8 *>(smem + (size_t)N * 12);    // [8][64] (MF)
+    float2 *bufs = reinterpret_cast<float2 *>(smem + (size_t)N * 12 + (MF ? (size_t)DFX_MFFT_FRAG3 * 64 * 16 : 0));
+    DfxMfftRegs mfr;
+    if constexpr (MF) {
+        for (int i = threadIdx.x; i < DFX_MFFT_FRAG3 * 64; i += DFX_DSP_THREADS) a3s[i] = reinterpret_cast<const dfx_h8 *>(A.mfft)[DFX_MFFT_FRAG1 * 64 + i];
+        dfx_mfft_load(mfr, A.mfft, (int)(threadIdx.x % DFX_DSP_TEAM));
+    }
     float *carry = reinterpret_cast<float *>(bufs + (size_t)NTM * BUF);   // [2][HOP]
     unsigned char *b2b = reinterpret_cast<unsigned char *>(carry + 2 * HOP);   // [M + 1] (+ pad)
     const int team = dfx_wave_uniform(threadIdx.x / DFX_DSP_TEAM), lane = threadIdx.x % DFX_DSP_TEAM;
@@ -1815,7 +1977,8 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, (PF && I16) ? 5 : 6) dfx_k_sy
         }
     }
     DFX_WAVE_SYNC();
-    dfx_fft480_ip<+1>(bufA, tw, lane, active);
+    if constexpr (MF) dfx_fft480_mfma(bufA, mfr, a3s, lane, active);
+    else dfx_fft480_ip<+1>(bufA, tw, lane, active);
     {   // apply_window_in_place (lib.rs:406): the interleaved (re, im) pairs of z ARE the time samples
         constexpr int NQ = N / 4, NR4 = (NQ + DFX_DSP_TEAM - 1) / DFX_DSP_TEAM;
         f32x4 *xq = reinterpret_cast<f32x4 *>(bufA);

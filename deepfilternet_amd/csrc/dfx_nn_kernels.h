@@ -2130,9 +2130,11 @@ __global__ void __launch_bounds__(64 * DFX_TAIL_WAVES, 1) dfx_k_erb_tail(DfxTail
         int lq = lane % C4;
         DFX_OPAQUE(lq);
         float4 r1[NV1];
+        int l1 = lane;
+        DFX_OPAQUE(l1);   // (the lane's share of the address per frame, not a 64-bit lane pointer held — spilled — across the frame loop)
 #pragma unroll
         for (int i = 0; i < NV1; ++i) {
-            const int idx = lane + 64 * i;
+            const int idx = l1 + 64 * i;
             r1[i] = idx < N1 ? p1[r * N1 + idx] : z4;
         }
         // e0 recomputed: lane fp of fxr[kt] = element fp of the zero-bordered tap row kt of this frame, [E + 2] (dfx_k_erb_enc's `fs`: zero =
@@ -2202,14 +2204,17 @@ __global__ void __launch_bounds__(64 * DFX_TAIL_WAVES, 1) dfx_k_erb_tail(DfxTail
                 dfx_split8_g(xk, ph, pl, amax);
                 int l32 = lane & 31;
                 DFX_OPAQUE(l32);
+                // (term-major over the NT accumulators: dependent matrix ops NT issues apart; a guard before the epilogue reads them — DFX_MFMA_GUARD)
+                // (the hi fragments are read once per term: the kernel has LDS reads to spare here, registers it has not)
                 f32x4 acc0[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const dfx_h8 wh = w0f[(nt * 2 + 0) * 32 + l32], wl = w0f[(nt * 2 + 1) * 32 + l32];
-                    acc0[nt] = dfx_mfma_16x16x32_f16(wl, ph, f32x4{0.f, 0.f, 0.f, 0.f});
-                    acc0[nt] = dfx_mfma_16x16x32_f16(wh, pl, acc0[nt]);
-                    acc0[nt] = dfx_mfma_16x16x32_f16(wh, ph, acc0[nt]);
-                }
+                for (int nt = 0; nt < NT; ++nt) acc0[nt] = dfx_mfma_16x16x32_f16(w0f[(nt * 2 + 1) * 32 + l32], ph, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc0[nt] = dfx_mfma_16x16x32_f16(w0f[(nt * 2 + 0) * 32 + l32], pl, acc0[nt]);
+                DFX_OPAQUE(l32);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc0[nt] = dfx_mfma_16x16x32_f16(w0f[(nt * 2 + 0) * 32 + l32], ph, acc0[nt]);
+                DFX_MFMA_GUARD();
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {   // lane (position jl, q): channels 16 nt + 4 q + r = channel quad 4 nt + q
                     const float4 a0q = sks[6 * C4 + 4 * nt + q], b0q = sks[7 * C4 + 4 * nt + q];
@@ -2240,7 +2245,7 @@ __global__ void __launch_bounds__(64 * DFX_TAIL_WAVES, 1) dfx_k_erb_tail(DfxTail
             // of 16 bytes per tile by 48 lanes): rows j = 0..2 of one tile, the lanes q = 0 hold them.  The fragments' rows 3..15 multiply into rows of
             // the result nobody reads: those lanes re-read row 3 (1 KB of LDS instead of 4).
             float sv[8];
-            f32x4 vj = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 va = f32x4{0.f, 0.f, 0.f, 0.f}, vb = va, vc = va;   // one chain per product term (dependent ops three issues apart)
             int lw = 4 * q + ((lane & 15) < 3 ? (lane & 15) : 3);
             DFX_OPAQUE(lw);
             dfx_chain_tile_h3_lds<C, DFX_PW_MODE_DWT3, (C >= 64 ? C / 32 : C / 16)>(Y, E1, 2, 16 * t, E, dws + 6 * C4, wfr + 2 * DFX_TAIL_WFRAG(C), bis + 2 * C4, A.unscale[2], amax, lane,
@@ -2253,11 +2258,13 @@ __global__ void __launch_bounds__(64 * DFX_TAIL_WAVES, 1) dfx_k_erb_tail(DfxTail
                                                                dfx_h8 sh, sl;
                                                                dfx_split8_g(sv, sh, sl, amax);
                                                                const dfx_h8 woh = wof[(kc * 2 + 0) * 16 + lw], wol = wof[(kc * 2 + 1) * 16 + lw];
-                                                               vj = dfx_mfma_16x16x32_f16(wol, sh, vj);
-                                                               vj = dfx_mfma_16x16x32_f16(woh, sl, vj);
-                                                               vj = dfx_mfma_16x16x32_f16(woh, sh, vj);
+                                                               va = dfx_mfma_16x16x32_f16(wol, sh, va);
+                                                               vb = dfx_mfma_16x16x32_f16(woh, sl, vb);
+                                                               vc = dfx_mfma_16x16x32_f16(woh, sh, vc);
                                                            }
                                                        });
+            DFX_MFMA_GUARD();
+            const f32x4 vj = (va + vb) + vc;
             DFX_WAVE_SYNC();   // (the reads of X above are done before a pad column of X is written — and before the next tile's e0 rows are)
             if (lane < 16) {
                 float *Vp = t == 0 ? Y : X;

@@ -127,6 +127,17 @@ static __device__ __forceinline__ f32x4 dfx_mfma_16x16x32_f16(dfx_h8 a, dfx_h8 b
 #define DFX_OPAQUE(x) asm volatile("" : "+v"(x))
 #define DFX_PIN_AGPR(x) asm volatile("" : "+a"(x))   /* the value lives in an AGPR from here on (matrix-op operands of kernels with one wave per SIMD) */
 #define DFX_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// Between the last matrix op of a group and the first vector instruction that reads its result when that reader may land in the NEXT basic
+// block (an `if (valid)` epilogue: s_and_saveexec, then the read).  Round 5: dfx_fft480_mfma returned one wrong bin in ~10 % of its runs on the
+// GPU (never on the interpreter) where the compiler had left 8 wait states between a chain of back-to-back DEPENDENT matrix ops and such a
+// read; four more — or just keeping the scheduler from sinking the ops to the end of their block — and 450 of 450 runs were right
+// (tools/dev/dbg_mf.py, tools/dev/scan_mfma_reads.py).  Chains are also kept three ops apart (term-major order), as everywhere else here.
+#define DFX_MFMA_GUARD()                         \
+    do {                                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+        asm volatile("s_nop 7");                 \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
 #define DFX_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)   /* ask for n instructions of a class next (0x008 MFMA, 0x002 VALU) */
 // barrier + LDS visibility among the 64 lanes of ONE wave (LDS operations of a wave complete in order; the fences only pin the
 // compiler's ordering) — costs nothing compared with s_barrier across the workgroup

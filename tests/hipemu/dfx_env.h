@@ -565,6 +565,7 @@ static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
 #define DFX_OPAQUE(x) asm volatile("" : "+r"(x))
 #define DFX_PIN_AGPR(x) ((void)0)
 #define DFX_SCHED_BARRIER() ((void)0)
+#define DFX_MFMA_GUARD() do { } while (0)
 #define DFX_SCHED_GROUP(mask, n) ((void)0)
 #define DFX_WAVE_SYNC() ((void)hipemu::wave_exchange(0, 0))  // all live lanes of the wave rendezvous
 #define DFX_DYN_SMEM(T, name) T *name = reinterpret_cast<T *>(hipemu::dyn_smem_ptr())

@@ -30,6 +30,26 @@ def test_analysis_matches_oracle(backend, N, H, nb):
     assert np.abs(S - R).max() < 3e-7 * max(1.0, np.abs(R).max() / 0.02)
 
 
+@pytest.mark.parametrize("hop", [480, 240])
+def test_matrix_pipe_transform_matches_the_radix_passes(backend, hop, monkeypatch):
+    """DFX_FFT_MFMA=1: the 480-point transform as chained fp16-split matrix products with block floating point per frame (dfx_fft480_mfma) — the
+    same spectra / waveforms as the radix passes within a few 1e-7 of the frame's peak, for small and large inputs (no range guard, no fallback),
+    repeatedly (its first form returned a wrong bin in one run of ten on the GPU: profiles/r05_dft_mfma.log)."""
+    D = _libdf()
+    rng = np.random.default_rng(hop)
+    x = rng.standard_normal((3, hop * 13)).astype(np.float32)
+    x[1] *= 3.0e4    # int16-scale samples
+    x[2] *= 1.0e-6   # near silence
+    Y = (rng.standard_normal((2, 11, 481)) + 1j * rng.standard_normal((2, 11, 481))).astype(np.complex64)
+    S0, y0 = D.DF(48000, 960, hop, 32, 1).analysis(x), D.DF(48000, 960, hop, 32, 1).synthesis(Y)
+    monkeypatch.setenv("DFX_FFT_MFMA", "1")
+    for _ in range(8):
+        S1, y1 = D.DF(48000, 960, hop, 32, 1).analysis(x), D.DF(48000, 960, hop, 32, 1).synthesis(Y)
+        for b in range(3):
+            assert np.abs(S1[b] - S0[b]).max() < 1e-6 * np.abs(S0[b]).max()
+        assert np.abs(y1 - y0).max() < 1e-6 * np.abs(y0).max()
+
+
 def test_analysis_many_frames_gridstride(backend):
     D = _libdf()
     rng = np.random.default_rng(1)
