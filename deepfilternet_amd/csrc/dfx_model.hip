@@ -1493,9 +1493,8 @@ static int launch_convp_h3(const dfx_model *m, const float *feat_spec, float *ou
         const int64_t nruns = B * A.nfb * A.nseg;
         // (capping the launch at 64 ... 192 resident workgroups, so that the rest of the chip is free for the front's critical path, measured
         // +0.1 ... +0.5 ms per step: profiles/r04_exact_and_convp_cap.log)
-        const int grid = nn_grid(dfx_ceil_div(nruns, 4), 2 * m->front_grain_p);
         DfxKScope ks(DFX_K_DF_CONVP, s);
-        dfx_launch((dfx_k_df_convp_h3<C, KT>), dim3(grid), dim3(256), 0, s, A);
+        dfx_launch((dfx_k_df_convp_h3<C, KT>), dim3(nn_grid(dfx_ceil_div(nruns, 4), 2 * m->front_grain_p)), dim3(256), 0, s, A);
         DFX_LAUNCH_CHECK();
         return DFX_OK;
     }
@@ -2252,6 +2251,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         for (int i = 0; i < Ks; ++i) sb[i + 1] = sb[i] + sizes[i];
     }
     const int kt = c.df_pathway_kernel_size_t;
+    int64_t convp_split = T;   // frames [convp_split, T) of df_convp are enqueued under the GRU phase (DFX_CONVP_LATE)
     // df_conv0 -> df_conv1 of frames [t0, t1) (fuse_c0)
     auto df1_range = [&](int64_t t0, int64_t t1, hipStream_t st) -> int {
         if (fuse_h3) return launch_conv01_h3<C>(m, m->dfc1, feat_spec, c1, B, T, Fd, Fd / 2, 2, st, t0, Lk, t1, featT);
@@ -2411,9 +2411,15 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // (releasing it later — behind df_conv1, or behind the whole front — measured the same within noise, profiles/r01_gru_phase_ablation.log;
         // per time chunk inside the GRU phase: slower, profiles/r04_gru_floor_and_convp_phase.log)
         if (run_df) {
-            if ((rc = convp_range(t_begin, T, x2))) return rc;
+            // Round 5: with the persistent GRU phase the pathway conv is released only when the front has run, i.e. it runs UNDER the phase: the
+            // front's critical path (ERB convolutions -> DF encoder) has the chip to itself, and since the decoder tail got 0.4 ms lighter the
+            // phase has the room: 13.50 / 13.54 -> 13.18 / 13.22 ms per step (same box; 30 / 50 / 70 % of the frames deferred: 13.41 / 13.41 /
+            // 13.48; in round 4, with the heavier tail, the same move measured as noise).  DFX_CONVP_LATE=p defers the last p percent (0: as before).
+            static const int late_pct = [] { const char *e = getenv("DFX_CONVP_LATE"); const int v = e ? atoi(e) : 100; return v < 0 ? 0 : (v > 100 ? 100 : v); }();
+            convp_split = use_seq && late_pct > 0 ? T - (T - t_begin) * late_pct / 100 : T;
+            if (convp_split > t_begin && (rc = convp_range(t_begin, convp_split, x2))) return rc;
             if (post_behind_convp && (rc = sc->df_post(x2))) return rc;
-            if ((rc = signal(EV_C0P, x2))) return rc;
+            if (convp_split >= T && (rc = signal(EV_C0P, x2))) return rc;
         }
         if ((rc = erb_range(t_begin, T, Rn, rmw, s))) return rc;
         if ((rc = wait(EV_C1, s))) return rc;
@@ -2572,6 +2578,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 if (m->exact_fp32) dfx_launch(dfx_k_gru_seq_x32, dim3((unsigned)(nl * groups)), dim3(DFX_GH_THREADS), DFX_GH_SMEM, G, S);
                 else dfx_launch(dfx_k_gru_seq, dim3((unsigned)(nl * groups)), dim3(DFX_GH_THREADS), DFX_GH_SMEM, G, S);
                 DFX_LAUNCH_CHECK();
+            }
+            if (run_df && convp_split < T) {   // the deferred part of the pathway conv: behind the front, beside the chain
+                // (held back further, until the layer pipeline has filled — a flag wait on the last layer's first chunk in front of it — the fill is
+                // 0.3 ms shorter and the layers then wait as long for the inputs of their next chunks: 13.20-13.23 vs 13.21 ms, not kept)
+                if ((rc = wait(ev_go, x2)) || (rc = convp_range(convp_split, T, x2)) || (rc = signal(EV_C0P, x2))) return rc;
             }
             {
                 // layer 0 (encoder GRU): its input xa is complete; one projection + flag per chunk

@@ -1003,6 +1003,11 @@ struct DfxCphArgs {
 // wave's VALU work, ~310 instructions per tile, runs under the other's 42 matrix ops, was built again on the current tree and measured:
 // 256 registers + 94 spilled, 2.19 instead of 2.01 ms alone, the step +0.7 ms: profiles/r04_df_out_and_convp_lds.log.  Everything in registers,
 // one wave per SIMD, stays.)
+// (Round 5: a form with PENDING SUMS instead of the window of c0 frames — a frame's c0 tile, split once, times all KT taps into the sums of the
+// outputs t .. t + KT - 1, as dfx_k_df_convp_step does — with df_conv0's and the lo fragments in LDS fits two waves per SIMD and is faster ALONE,
+// 1.56 instead of 1.90 ms, one wave's matrix ops under the other's vector work; but beside the GRU phase or beside the front the step got 0.7-1.4 ms
+// SLOWER (14.0-14.8 vs 13.3 ms, every placement): two 256-register waves per SIMD leave no room for another kernel's wave, where this kernel's
+// single 352-register wave leaves 160 registers per SIMD to the kernels it runs beside.  Removed; profiles/r05_convp_pending_sums.log.)
 template <int C, int KT>
 __global__ void __launch_bounds__(256, 1) dfx_k_df_convp_h3(DfxCphArgs A) {
     constexpr int CPL = C / 4, NT = C / 16, KC = C >= 32 ? C / 32 : 1;
