@@ -2421,6 +2421,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             if (post_behind_convp && (rc = sc->df_post(x2))) return rc;
             if (convp_split >= T && (rc = signal(EV_C0P, x2))) return rc;
         }
+        // (Round 5, timing only: the fused DF encoder on x1 BESIDE the ERB convolutions, its e3 dependency ignored — one VALU-bound, the others
+        // HBM-bound — 13.68 / 13.71 vs 13.36 / 13.31 ms per step: slower; the encoder stays behind them.)
         if ((rc = erb_range(t_begin, T, Rn, rmw, s))) return rc;
         if ((rc = wait(EV_C1, s))) return rc;
         if (dfenc) {
