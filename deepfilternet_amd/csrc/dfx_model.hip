@@ -1117,7 +1117,7 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
             const char *tq = getenv("DFX_SEQ_TRACE");
             if (tq && tq[0] == '1') (void)hipMalloc(reinterpret_cast<void **>(&m->d_trace), (size_t)DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX * DFX_GS_MAX_CHUNKS * 3 * 8);
         }
-        const size_t sync_bytes = (size_t)(16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX) * sizeof(unsigned int);   // ready 0-7 | emb 8 | probe 13 | done 16-
+        const size_t sync_bytes = (size_t)(16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX + 16) * sizeof(unsigned int);   // ready 0-7 | emb 8 | probe 13 | done 16- | producers' completion counters (DfxPublish): 9 words
         if (hipMalloc(reinterpret_cast<void **>(&m->d_sync), sync_bytes) != hipSuccess || hipMemset(m->d_sync, 0, sync_bytes) != hipSuccess ||
             dfx_env_err_words_alloc(&m->h_err, &m->d_err, 256) != hipSuccess) {
             dfx_model_free(m);
@@ -1805,9 +1805,10 @@ static int launch_proj(const float *a, const float *w, const float *bias, float 
 }
 
 // GRU input projection on the fp16-split matrix path (K = 256, N % 64 == 0)
+static int launch_flag_set(unsigned int *flag, unsigned int value, hipStream_t s);
 static int launch_proj_h3(const dfx_model *m, const GruW &g, const float *a, float *out, int64_t M, int N, hipStream_t s,
-                          DfxRowMap rm = DfxRowMap{0, 0, 0}) {
-    if (M <= 0) return DFX_OK;
+                          DfxRowMap rm = DfxRowMap{0, 0, 0}, const DfxPublish *pub = nullptr) {
+    if (M <= 0) return pub ? launch_flag_set(pub->flag, pub->value, s) : DFX_OK;
     DfxPhArgs A;
     A.a = a;
     A.wf = reinterpret_cast<const dfx_h8 *>(m->p(g.wih_h3));
@@ -1826,12 +1827,14 @@ static int launch_proj_h3(const dfx_model *m, const GruW &g, const float *a, flo
     const int row_tiles = m->proj_rt;
     if (row_tiles == 3) {   // two workgroups of 4 waves per CU on 32-column chunks (measured 0.375 vs 0.363 ms: not the default)
         DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_proj256_h3x2<4, 2>, DFX_PH_SMEM / 2));
+        if (pub) A.pub = *pub, A.pub.nblocks = (unsigned)dfx_ceil_div(M, 128);
         dfx_launch((dfx_k_proj256_h3x2<4, 2>), dim3((unsigned)dfx_ceil_div(M, 128)), dim3(256), DFX_PH_SMEM / 2, s, A);
         DFX_LAUNCH_CHECK();
         return DFX_OK;
     }
     if (row_tiles == 2 || (row_tiles == 0 && M > 8192)) {
         DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_proj256_h3x2<8, 4>, DFX_PH_SMEM));
+        if (pub) A.pub = *pub, A.pub.nblocks = (unsigned)dfx_ceil_div(M, 256);
         dfx_launch((dfx_k_proj256_h3x2<8, 4>), dim3((unsigned)dfx_ceil_div(M, 256)), dim3(512), DFX_PH_SMEM, s, A);
         DFX_LAUNCH_CHECK();
         return DFX_OK;
@@ -1846,6 +1849,7 @@ static int launch_proj_h3(const dfx_model *m, const GruW &g, const float *a, flo
         A.parts = parts;
     }
     DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_proj256_h3, DFX_PH_SMEM));
+    if (pub) A.pub = *pub, A.pub.nblocks = (unsigned)(nblk * A.parts);
     dfx_launch(dfx_k_proj256_h3, dim3((unsigned)(nblk * A.parts)), dim3(DFX_PH_THREADS), DFX_PH_SMEM, s, A);
     DFX_LAUNCH_CHECK();
     return DFX_OK;
@@ -1926,7 +1930,7 @@ static int launch_df_enc(const dfx_model *m, const float *feat_spec, const float
 }
 // emb and everything that reads it, in one pass over the encoder GRU's output (dfx_k_emb_fan); outs[c] null = consumer not wanted
 static int launch_emb_fan(const dfx_model *m, const float *y, const float *res, float *emb_out, float *dec_x, float *dfg_x, float *skp,
-                          float *lsnr, int64_t M, hipStream_t s, DfxRowMap rm, float *embv_for_split = nullptr) {
+                          float *lsnr, int64_t M, hipStream_t s, DfxRowMap rm, float *embv_for_split = nullptr, const DfxPublish *pub = nullptr) {
     const dfx_model_cfg &c = m->cfg;
     DfxFanArgs A;
     A.y = y;
@@ -1956,12 +1960,14 @@ static int launch_emb_fan(const dfx_model *m, const float *y, const float *res, 
     if (M > fan_few_rows()) {
         constexpr int RT = 2;
         const dim3 grid((unsigned)nn_grid(dfx_ceil_div(dfx_ceil_div(M, 16 * RT), 4), 8));
+        if (pub) A.pub = *pub, A.pub.nblocks = grid.x;
         if (dfg_x && skp) dfx_launch((dfx_k_emb_fan<RT, 1, 2, 1>), grid, dim3(256), 0, s, A);
         else if (dfg_x) dfx_launch((dfx_k_emb_fan<RT, 1, 2, 0>), grid, dim3(256), 0, s, A);
         else dfx_launch((dfx_k_emb_fan<RT, 1, 0, 0>), grid, dim3(256), 0, s, A);
     } else {   // few rows (a streaming hop): one row tile per wave — twice the waves, half the serial matrix work per wave
         constexpr int RT = 1;
         const dim3 grid((unsigned)nn_grid(dfx_ceil_div(dfx_ceil_div(M, 16 * RT) * A.parts, 4), 8));
+        if (pub && !split) A.pub = *pub, A.pub.nblocks = grid.x;
         if (dfg_x && skp) dfx_launch((dfx_k_emb_fan<RT, 1, 2, 1>), grid, dim3(256), 0, s, A);
         else if (dfg_x) dfx_launch((dfx_k_emb_fan<RT, 1, 2, 0>), grid, dim3(256), 0, s, A);
         else dfx_launch((dfx_k_emb_fan<RT, 1, 0, 0>), grid, dim3(256), 0, s, A);
@@ -1973,6 +1979,7 @@ static int launch_emb_fan(const dfx_model *m, const float *y, const float *res, 
         dfx_launch(dfx_k_lsnr_rows, dim3((unsigned)dfx_ceil_div(M * 64, 256)), dim3(256), 0, s, (const float *)embv_for_split, m->p(m->lsnr_w), m->lsnr_b,
                    (float)(c.lsnr_max - c.lsnr_min), (float)c.lsnr_min, lsnr, M, 64 * A.nj, rm);
         DFX_LAUNCH_CHECK();
+        if (pub) return launch_flag_set(pub->flag, pub->value, s);   // (two launches: the flag follows the second)
     }
     return DFX_OK;
 }
@@ -2141,7 +2148,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     // DF GRU's output (which does not exist yet): df_out then takes its operand as the sum y_df + xdf (DfxGgArgs::a2).
     const bool fan = m->fuse_emb && m->fan_chunks > 0 && !c.enc_concat && emb == 64 * m->fan_chunks;   // (exact fp32 matrix ops: also with DFX_EXACT_FP32=1)
     const bool fan_skp = fan && run_df && c.df_gru_skip == DFX_SKIP_GROUPEDLINEAR && m->fan_kind[2] == 1;
-    auto emb_fan = [&](const float *y, float *dec_x, int64_t M, hipStream_t st, DfxRowMap rm) -> int {
+    auto emb_fan = [&](const float *y, float *dec_x, int64_t M, hipStream_t st, DfxRowMap rm, const DfxPublish *pub = nullptr) -> int {
         const float *res = nullptr;
         if (c.emb_gru_skip_enc == DFX_SKIP_IDENTITY) res = emb_in;
         else if (c.emb_gru_skip_enc == DFX_SKIP_GROUPEDLINEAR) {
@@ -2149,7 +2156,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             res = skp_e;
         }
         const bool need_emb = c.emb_gru_skip != DFX_SKIP_NONE || (run_df && c.df_gru_skip == DFX_SKIP_IDENTITY);
-        return launch_emb_fan(m, y, res, need_emb ? embv : nullptr, dec_x, run_df ? xa2 : nullptr, fan_skp ? xdf : nullptr, lsnr, M, st, rm, embv);
+        return launch_emb_fan(m, y, res, need_emb ? embv : nullptr, dec_x, run_df ? xa2 : nullptr, fan_skp ? xdf : nullptr, lsnr, M, st, rm, embv, pub);
     };
     // c = tanh(df_out(c)).view(b,t,F',2O) + c0p   (:329-330) of M rows; cfeat (+ cfeat2) is df_out's operand
     auto df_out_rows = [&](const float *cfeat, const float *cfeat2, int64_t M, hipStream_t st, DfxRowMap rm) -> int {
@@ -2236,7 +2243,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // 12 uniform chunks, no ramp: 14.12; 13: 14.17; 14: 14.14; 12 + ramp 48: 14.20; 15 + 48: 14.27; 16: 15.1 (chunks of < 16384 rows take the
         // small-launch forms of the fan-out kernels) -> 12 uniform chunks
         static const int ramp0 = [] { const char *e = getenv("DFX_SEQ_RAMP"); return e ? atoi(e) : 0; }();
-        static const int kbody = [] { const char *e = getenv("DFX_SEQ_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 12; }();
+        // 16 chunks where the producers raise their flags themselves (DfxPublish: 17 launches per chunk), 12 where a one-thread launch does
+        // (22 per chunk: the exact mode, DFX_SEQ_PUBLISH=0) — measured 13.24-13.28 (16) vs 13.37-13.49 (12) ms per step, measurements R5.10
+        static const int kenv = [] { const char *e = getenv("DFX_SEQ_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
+        static const bool kpub = [] { const char *e = getenv("DFX_SEQ_PUBLISH"); return !(e && e[0] == '0'); }();
+        const int kbody = kenv > 0 ? kenv : (kpub && !m->exact_fp32 ? 16 : 12);
         const int64_t body = std::max<int64_t>(dfx_ceil_div(T, (int64_t)kbody), m->tchunk_min);   // uniform chunk length: DFX_SEQ_CHUNKS=n gives n chunks (ceil: 1002 / 12 -> 84, not 83 and a 13th chunk)
         std::vector<int> sizes;
         int64_t left = T;
@@ -2537,13 +2548,24 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             auto tb = [&](int k) { return (int64_t)sb[k]; };
             auto rmk = [&](int k) { return DfxRowMap{T, tb(k + 1) - tb(k), tb(k)}; };
             auto Mk = [&](int k) { return B * (tb(k + 1) - tb(k)); };
-            auto proj_chunk = [&](const GruW &g, int l, int k, const float *xin, hipStream_t st) -> int {
-                if (m->exact_fp32) return launch_proj(xin, m->p(g.wih_t), m->p(g.bias_i), ws + w.pgi[l], Mk(k), 768, st, rmk(k));
-                return launch_proj_h3(m, g, xin, ws + w.pgi[l], Mk(k), 768, st, rmk(k));
-            };
             const unsigned int base = m->seq_base;
             m->seq_base += (unsigned int)K + 1u;
             unsigned int *ready = m->d_sync, *embf = m->d_sync + 8, *done = m->d_sync + 16;
+            unsigned int *pcnt = m->d_sync + 16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX;   // one completion counter per producing stream (layer), [8] = emb
+            // a layer's input projection of chunk k, and ready[l] = chunk k + 1 behind it: raised by the projection kernel's last workgroup
+            // (DfxPublish; DFX_SEQ_PUBLISH=0 or the exact mode: by a one-thread launch behind it, as before round 5)
+            static const bool publish = [] { const char *e = getenv("DFX_SEQ_PUBLISH"); return !(e && e[0] == '0'); }();
+            auto proj_chunk = [&](const GruW &g, int l, int k, const float *xin, hipStream_t st) -> int {
+                const unsigned int val = base + (unsigned int)k + 1u;
+                if (m->exact_fp32 || !publish) {
+                    const int r = m->exact_fp32 ? launch_proj(xin, m->p(g.wih_t), m->p(g.bias_i), ws + w.pgi[l], Mk(k), 768, st, rmk(k))
+                                                : launch_proj_h3(m, g, xin, ws + w.pgi[l], Mk(k), 768, st, rmk(k));
+                    return r ? r : launch_flag_set(ready + l, val, st);
+                }
+                DfxPublish pub;
+                pub.cnt = pcnt + l, pub.flag = ready + l, pub.value = val;
+                return launch_proj_h3(m, g, xin, ws + w.pgi[l], Mk(k), 768, st, rmk(k), &pub);
+            };
             // (Finishing — deep filter + ISTFT — per time chunk behind the DF tail was built here and in the event-based form and measured:
             // 21.7 vs 20.2 ms per step; the chunks' traffic beside the chain costs more than the 1.2 ms it takes off the end.)
             static const int dev_skip_seq = [] { const char *e = getenv("DFX_DEV_SKIP"); return e ? atoi(e) : 0; }();   // dev timing ablations (results invalid)
@@ -2593,7 +2615,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 for (int k = 0; k < K; ++k) {
                     static const int p0_ahead = [] { const char *e = getenv("DFX_SEQ_P0_AHEAD"); return e && atoi(e) > 0 ? atoi(e) : 3; }();
                     if (k >= p0_ahead && (rc = launch_wait_ge(m, donep(0), groups, tgt(k - p0_ahead), Pq))) return rc;
-                    if ((rc = proj_chunk(m->enc_gru[0], 0, k, xa, Pq)) || (rc = launch_flag_set(ready + 0, tgt(k), Pq))) return rc;
+                    if ((rc = proj_chunk(m->enc_gru[0], 0, k, xa, Pq))) return rc;
                 }
             }
             const int fpt = 64 / E > 0 ? 64 / E : 1;
@@ -2615,7 +2637,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 if ((r = launch_wait_ge(m, donep(l - 1), groups, tgt(k), st))) return r;
                 const float *xin = ws + w.py[l - 1];
                 if (j == 0 && fan) {   // emb, lsnr and the inputs of both decoders' GRU stacks in one pass over the encoder GRU's chunk
-                    if ((r = emb_fan(ws + w.py[0], xb, Mk(k), st, rmk(k))) || (r = launch_flag_set(embf, tgt(k), st))) return r;
+                    if (publish && !m->exact_fp32) {
+                        DfxPublish pub;
+                        pub.cnt = pcnt + 8, pub.flag = embf, pub.value = tgt(k);
+                        if ((r = emb_fan(ws + w.py[0], xb, Mk(k), st, rmk(k), &pub))) return r;
+                    } else if ((r = emb_fan(ws + w.py[0], xb, Mk(k), st, rmk(k))) || (r = launch_flag_set(embf, tgt(k), st))) return r;
                     if (k == K - 1 && (r = signal(EV_EMB, st))) return r;
                     xin = xb;
                 } else if (j == 0) {
@@ -2624,7 +2650,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                     if ((r = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, xb, Mk(k), st, rmk(k)))) return r;
                     xin = xb;
                 }
-                if ((r = proj_chunk(m->dec_gru[j], l, k, xin, st)) || (r = launch_flag_set(ready + l, tgt(k), st))) return r;
+                if ((r = proj_chunk(m->dec_gru[j], l, k, xin, st))) return r;
                 return DFX_OK;
             };
             // ---- ERB tail, chunk k
@@ -2660,7 +2686,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                     if (!fan && (r = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, Mk(k), st, rmk(k)))) return r;
                     xin = xa2;
                 } else if ((r = launch_wait_ge(m, donep(l - 1), groups, tgt(k), st))) return r;
-                if ((r = proj_chunk(m->df_gru[j], l, k, xin, st)) || (r = launch_flag_set(ready + l, tgt(k), st))) return r;
+                if ((r = proj_chunk(m->df_gru[j], l, k, xin, st))) return r;
                 return DFX_OK;
             };
             // ---- DF tail, chunk k

@@ -2892,6 +2892,26 @@ __global__ void __launch_bounds__(DFX_PJ_THREADS, 2) dfx_k_proj256(DfxPjArgs A) 
 #define DFX_PH_NC 64
 #define DFX_PH_CHUNK_H8 (8 * 4 * 2 * 64)                 /* dfx_h8 per column chunk: [kc][ct][hi,lo][lane] */
 #define DFX_PH_SMEM ((size_t)2 * DFX_PH_CHUNK_H8 * 16)
+// A producer kernel of the persistent GRU phase announces its own completion (round 5): every workgroup, when its rows are stored, adds itself to a
+// counter; the last one resets the counter and raises the flag the consumers poll — the dfx_k_flag_set launch behind the producer (and the ~8 us of
+// host enqueue and dispatch it costs per layer and chunk) is gone.  cnt == nullptr: nothing (every launch outside that phase).
+struct DfxPublish {
+    unsigned int *cnt = nullptr;   // completion counter of this producer (one word per stream: launches on a stream do not overlap)
+    unsigned int *flag = nullptr;
+    unsigned int value = 0, nblocks = 0;
+};
+static __device__ __forceinline__ void dfx_publish(const DfxPublish &P) {
+    if (!P.cnt) return;
+    __syncthreads();   // the workgroup's stores happen before thread 0's release below (one L2 write-back per workgroup; a release fence in
+                       // every thread in front of the barrier is one per WAVE and costs the step 1.6 ms, measurements R5.10)
+    if (threadIdx.x == 0) {
+        const unsigned int old = __hip_atomic_fetch_add(P.cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == P.nblocks) {
+            __hip_atomic_store(P.cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(P.flag, P.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 struct DfxPhArgs {
     const float *a;      // [M, 256]
     const dfx_h8 *wf;    // [N/64][8][4][2][64] fragment-ordered, pre-scaled f16 hi/lo of W[k][n]
@@ -2903,6 +2923,7 @@ struct DfxPhArgs {
     DfxRowMap rm;        // logical row -> physical row of a and out
     int parts = 1;       // dfx_k_proj256_h3 only: the column chunks of a row block are dealt to this many workgroups (divides N / 64).  A launch of
                          // few rows (a streaming hop: 4096 rows = 32 row blocks) then runs on parts x 32 CUs and each workgroup streams 1 / parts of W
+    DfxPublish pub;      // persistent GRU phase: the kernel raises its consumers' flag itself
 };
 
 __global__ void __launch_bounds__(DFX_PH_THREADS, 2) dfx_k_proj256_h3(DfxPhArgs A) {
@@ -2999,6 +3020,7 @@ __global__ void __launch_bounds__(DFX_PH_THREADS, 2) dfx_k_proj256_h3(DfxPhArgs 
         }
         __syncthreads();
     }
+    dfx_publish(A.pub);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -3297,6 +3319,7 @@ __global__ void __launch_bounds__(64 * NW, CT == 2 ? 2 : 1) dfx_k_proj256_h3x2(D
         }
         __syncthreads();
     }
+    dfx_publish(A.pub);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -3330,6 +3353,7 @@ struct DfxFanArgs {
     int nj;                     // super-chunks: hidden / 32
     int parts;                  // a row tile's super-chunks are dealt to this many waves (divides nj; > 1 only without lsnr: few rows, a streaming hop)
     DfxRowMap rm;
+    DfxPublish pub;             // persistent GRU phase: the kernel raises its consumers' flag itself
 };
 template <int RT, int K0, int K1, int K2>
 __global__ void __launch_bounds__(256, 2) dfx_k_emb_fan(DfxFanArgs A) {
@@ -3441,6 +3465,7 @@ __global__ void __launch_bounds__(256, 2) dfx_k_emb_fan(DfxFanArgs A) {
             }
         }
     }
+    dfx_publish(A.pub);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
