@@ -466,6 +466,7 @@ struct dfx_model {
     bool fuse_erb = true;
     // persistent GRU phase (dfx_k_gru_seq): flag words [ready: 8][emb: 1][pad][done: 8 * DFX_SEQ_GMAX], monotonic over the model's life
     unsigned int *d_sync = nullptr;
+    mutable unsigned int seq_pbase = 0;       // step counter base of the follower hand-overs (yprog / giprog), monotonic like seq_base
     mutable unsigned int seq_base = 0;  // flag value of "nothing of the current forward pass yet"
     unsigned long long *d_trace = nullptr;   // dev aid (DFX_SEQ_TRACE=1): chunk timestamps of the last persistent GRU launch
     mutable int trace_dims[3] = {0, 0, 0};
@@ -1117,7 +1118,8 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
             const char *tq = getenv("DFX_SEQ_TRACE");
             if (tq && tq[0] == '1') (void)hipMalloc(reinterpret_cast<void **>(&m->d_trace), (size_t)DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX * DFX_GS_MAX_CHUNKS * 3 * 8);
         }
-        const size_t sync_bytes = (size_t)(16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX + 16) * sizeof(unsigned int);   // ready 0-7 | emb 8 | probe 13 | done 16- | producers' completion counters (DfxPublish): 9 words
+        // ready 0-7 | emb 8 | probe 13 | done 16- | producers' completion counters (DfxPublish): 9 words (16) | yprog, giprog: steps per (layer, group)
+        const size_t sync_bytes = (size_t)(16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX + 16 + 2 * DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX) * sizeof(unsigned int);
         if (hipMalloc(reinterpret_cast<void **>(&m->d_sync), sync_bytes) != hipSuccess || hipMemset(m->d_sync, 0, sync_bytes) != hipSuccess ||
             dfx_env_err_words_alloc(&m->h_err, &m->d_err, 256) != hipSuccess) {
             dfx_model_free(m);
@@ -1928,9 +1930,7 @@ static int launch_df_enc(const dfx_model *m, const float *feat_spec, const float
         return DFX_OK;
     }
 }
-// emb and everything that reads it, in one pass over the encoder GRU's output (dfx_k_emb_fan); outs[c] null = consumer not wanted
-static int launch_emb_fan(const dfx_model *m, const float *y, const float *res, float *emb_out, float *dec_x, float *dfg_x, float *skp,
-                          float *lsnr, int64_t M, hipStream_t s, DfxRowMap rm, float *embv_for_split = nullptr, const DfxPublish *pub = nullptr) {
+static DfxFanArgs emb_fan_args(const dfx_model *m, const float *y, const float *res, float *emb_out, float *dec_x, float *dfg_x, float *skp, float *lsnr) {
     const dfx_model_cfg &c = m->cfg;
     DfxFanArgs A;
     A.y = y;
@@ -1942,10 +1942,19 @@ static int launch_emb_fan(const dfx_model *m, const float *y, const float *res, 
     A.lsnr_w = lsnr ? m->p(m->lsnr_w) : nullptr;
     A.lsnr_b = m->lsnr_b, A.lsnr_scale = (float)(c.lsnr_max - c.lsnr_min), A.lsnr_off = (float)c.lsnr_min;
     A.lsnr = lsnr;
-    A.R = M;
+    A.R = 0;
     A.nj = m->fan_chunks;
-    A.rm = rm;
+    A.rm = DfxRowMap{0, 0, 0};
     A.parts = 1;
+    return A;
+}
+// emb and everything that reads it, in one pass over the encoder GRU's output (dfx_k_emb_fan); outs[c] null = consumer not wanted
+static int launch_emb_fan(const dfx_model *m, const float *y, const float *res, float *emb_out, float *dec_x, float *dfg_x, float *skp,
+                          float *lsnr, int64_t M, hipStream_t s, DfxRowMap rm, float *embv_for_split = nullptr, const DfxPublish *pub = nullptr) {
+    const dfx_model_cfg &c = m->cfg;
+    DfxFanArgs A = emb_fan_args(m, y, res, emb_out, dec_x, dfg_x, skp, lsnr);
+    A.R = M;
+    A.rm = rm;
     // few rows (a streaming hop): one wave per (16 rows, super-chunk) instead of a wave walking all super-chunks — emb is then written out
     // (embv: 2 KB per row of a few thousand rows) and lsnr, the one consumer that needs all of a row's features, is a launch of its own
     const bool split = M <= fan_few_rows() && lsnr && embv_for_split;
@@ -2555,6 +2564,30 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             // a layer's input projection of chunk k, and ready[l] = chunk k + 1 behind it: raised by the projection kernel's last workgroup
             // (DfxPublish; DFX_SEQ_PUBLISH=0 or the exact mode: by a one-thread launch behind it, as before round 5)
             static const bool publish = [] { const char *e = getenv("DFX_SEQ_PUBLISH"); return !(e && e[0] == '0'); }();
+            // Follower workgroups (dfx_k_proj_follow) feed the layers whose input is the output of the layer below — the second (third ...)
+            // layers of the decoder stacks — in blocks of 16 steps instead of time chunks.  DFX_SEQ_FOLLOW=0: a projection launch per chunk.
+            // DFX_SEQ_FOLLOW=2: the stacks' first layers too — a follower of the encoder GRU (dfx_k_emb_follow) runs dfx_k_emb_fan's arithmetic
+            // per block of 8 steps and the first layers' projection followers read what it wrote.
+            static const int follow_env = [] { const char *e = getenv("DFX_SEQ_FOLLOW"); return e ? atoi(e) : 0; }();
+            unsigned int *yprog = pcnt + 16, *giprog = yprog + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX;
+            unsigned int *embprog = yprog + (size_t)(DFX_MAX_GRU_LAYERS - 1) * DFX_SEQ_GMAX;   // (the row of a layer that cannot exist: nl < 8 below)
+            const unsigned int pbase = m->seq_pbase;
+            bool followed[DFX_MAX_GRU_LAYERS] = {};
+            int nfollow = 0;
+            const int lfirst_df = 1 + ndec;
+            const bool follow_emb = follow_env >= 2 && !m->exact_fp32 && fan && c.emb_gru_skip_enc != DFX_SKIP_GROUPEDLINEAR && nl < DFX_MAX_GRU_LAYERS &&
+                                    (nl + nl) * groups <= dfx_env_num_cus() * 3 / 4 && nl - 1 <= DFX_PF_MAX;
+            if (follow_env >= 1 && !m->exact_fp32) {
+                for (int l = 1; l < nl; ++l) {
+                    const bool first = l == 1 || l == lfirst_df;   // a stack's first layer reads a grouped linear of emb, the others the layer below
+                    if (first ? follow_emb : follow_env != 3) followed[l] = true, ++nfollow;   // (3: the first layers only)
+                }
+                if (nfollow > DFX_PF_MAX || (nl + nfollow + 1) * groups > dfx_env_num_cus() * 3 / 4) {   // all of them or none (every workgroup must be resident)
+                    nfollow = 0;
+                    for (int l = 0; l < nl; ++l) followed[l] = false;
+                }
+            }
+            if (nfollow) m->seq_pbase += (unsigned int)T + 1u;
             auto proj_chunk = [&](const GruW &g, int l, int k, const float *xin, hipStream_t st) -> int {
                 const unsigned int val = base + (unsigned int)k + 1u;
                 if (m->exact_fp32 || !publish) {
@@ -2596,12 +2629,64 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 S.ready = ready, S.done = done, S.done_stride = DFX_SEQ_GMAX, S.base = base, S.err = m->d_err;
                 S.trace = m->d_trace;
                 S.spin_limit = m->spin_limit;
+                S.pbase = pbase, S.sblk = 16;
+                for (int l = 1; l < nl; ++l) {
+                    if (!followed[l]) continue;
+                    S.giprog[l] = giprog + (size_t)l * DFX_SEQ_GMAX;
+                    const bool first = l == 1 || l == lfirst_df;
+                    const int src = first ? 0 : l - 1;   // the recurrence whose output feeds the follower chain of layer l
+                    S.yprog[src] = yprog + (size_t)src * DFX_SEQ_GMAX;
+                    S.yblk[src] = first ? DFX_EF_STEPS : 16;
+                }
                 m->trace_dims[0] = nl, m->trace_dims[1] = groups, m->trace_dims[2] = K;
                 DFX_HIP(dfx_env_set_max_dyn_smem(m->exact_fp32 ? (const void *)dfx_k_gru_seq_x32 : (const void *)dfx_k_gru_seq, DFX_GH_SMEM));
                 DfxKScope ks(DFX_K_GRU_REC, G);
                 if (m->exact_fp32) dfx_launch(dfx_k_gru_seq_x32, dim3((unsigned)(nl * groups)), dim3(DFX_GH_THREADS), DFX_GH_SMEM, G, S);
                 else dfx_launch(dfx_k_gru_seq, dim3((unsigned)(nl * groups)), dim3(DFX_GH_THREADS), DFX_GH_SMEM, G, S);
                 DFX_LAUNCH_CHECK();
+            }
+            if (nfollow) {   // the followers: right behind the recurrences, while the chip is still empty (each needs a CU's LDS)
+                DfxPfArgs F;
+                int f = 0;
+                for (int l = 1; l < nl; ++l) {
+                    if (!followed[l]) continue;
+                    const GruW &g = l <= ndec ? m->dec_gru[l - 1] : m->df_gru[l - 1 - ndec];
+                    const bool first = l == 1 || l == lfirst_df;
+                    F.x[f] = first ? (l == 1 ? xb : xa2) : ws + w.py[l - 1], F.gi[f] = ws + w.pgi[l];
+                    F.wf[f] = reinterpret_cast<const dfx_h8 *>(m->p(g.wih_h3)), F.bias[f] = m->p(g.bias_i), F.unscale[f] = g.wih_unscale;
+                    F.yprog[f] = first ? embprog : yprog + (size_t)(l - 1) * DFX_SEQ_GMAX, F.giprog[f] = giprog + (size_t)l * DFX_SEQ_GMAX;
+                    ++f;
+                }
+                for (; f < DFX_PF_MAX; ++f) F.x[f] = nullptr, F.gi[f] = nullptr, F.wf[f] = nullptr, F.bias[f] = nullptr, F.unscale[f] = 1.f, F.yprog[f] = nullptr, F.giprog[f] = nullptr;
+                F.B = B, F.T = T, F.nf = nfollow, F.groups = groups, F.pbase = pbase, F.err = m->d_err, F.spin_limit = m->spin_limit;
+                int lq = -1;
+                for (int l = nl - 1; l >= 2 && lq < 0; --l)
+                    if (followed[l]) lq = l;
+                // the stream of a followed layer's projections has nothing else to carry (ps[1]: the emb follower); only layer 1 followed = no DF stack: its tail stream is free
+                hipStream_t Fq = lq > 0 ? ln->ps[lq] : Dq;
+                DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_proj_follow, DFX_PH_SMEM));
+                if ((rc = wait(ev_go, Fq))) return rc;
+                DfxKScope ks(DFX_K_PROJ, Fq);
+                dfx_launch(dfx_k_proj_follow, dim3((unsigned)(nfollow * groups)), dim3(512), DFX_PH_SMEM, Fq, F);
+                DFX_LAUNCH_CHECK();
+            }
+            if (followed[1]) {   // the follower of the encoder GRU: emb, lsnr and the inputs of both decoders' stacks per block of 8 steps
+                const float *res = c.emb_gru_skip_enc == DFX_SKIP_IDENTITY ? emb_in : nullptr;
+                const bool need_emb = c.emb_gru_skip != DFX_SKIP_NONE || (run_df && c.df_gru_skip == DFX_SKIP_IDENTITY);
+                float *dfg_x = run_df ? xa2 : nullptr, *skp = fan_skp ? xdf : nullptr;
+                DfxFanArgs EA = emb_fan_args(m, ws + w.py[0], res, need_emb ? embv : nullptr, xb, dfg_x, skp, lsnr);
+                DfxFollowSync EY;
+                EY.src = yprog, EY.dst = embprog, EY.pbase = pbase, EY.err = m->d_err, EY.spin_limit = m->spin_limit, EY.B = B, EY.T = T;
+                hipStream_t Eq2 = ln->ps[1];
+                if ((rc = wait(ev_go, Eq2))) return rc;
+                {
+                    DfxKScope ks(DFX_K_EMB_FAN, Eq2);
+                    if (dfg_x && skp) dfx_launch((dfx_k_emb_follow<1, 2, 1>), dim3((unsigned)groups), dim3(512), 0, Eq2, EA, EY);
+                    else if (dfg_x) dfx_launch((dfx_k_emb_follow<1, 2, 0>), dim3((unsigned)groups), dim3(512), 0, Eq2, EA, EY);
+                    else dfx_launch((dfx_k_emb_follow<1, 0, 0>), dim3((unsigned)groups), dim3(512), 0, Eq2, EA, EY);
+                    DFX_LAUNCH_CHECK();
+                }
+                if ((rc = signal(EV_EMB, Eq2))) return rc;   // the whole embedding exists (lsnr)
             }
             if (run_df && convp_split < T) {   // the deferred part of the pathway conv: behind the front, beside the chain
                 // (held back further, until the layer pipeline has filled — a flag wait on the last layer's first chunk in front of it — the fill is
@@ -2634,6 +2719,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 const int l = 1 + j;
                 hipStream_t st = ln->ps[l];
                 int r;
+                if (followed[l]) return DFX_OK;
                 if ((r = launch_wait_ge(m, donep(l - 1), groups, tgt(k), st))) return r;
                 const float *xin = ws + w.py[l - 1];
                 if (j == 0 && fan) {   // emb, lsnr and the inputs of both decoders' GRU stacks in one pass over the encoder GRU's chunk
@@ -2680,6 +2766,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 const int l = lf + j;
                 hipStream_t st = ln->ps[l];
                 int r;
+                if (followed[l]) return DFX_OK;
                 const float *xin = ws + w.py[l - 1];
                 if (j == 0) {
                     if ((r = launch_wait_ge(m, embf, 1, tgt(k), st))) return r;

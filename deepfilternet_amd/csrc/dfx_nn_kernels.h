@@ -3355,117 +3355,173 @@ struct DfxFanArgs {
     DfxRowMap rm;
     DfxPublish pub;             // persistent GRU phase: the kernel raises its consumers' flag itself
 };
+// one item of dfx_k_emb_fan: row tile `tile` (16 * RT logical rows), super-chunks [J0, J1)
 template <int RT, int K0, int K1, int K2>
-__global__ void __launch_bounds__(256, 2) dfx_k_emb_fan(DfxFanArgs A) {
+static __device__ __forceinline__ void dfx_emb_fan_item(const DfxFanArgs &A, int64_t tile, int J0, int J1) {
     const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
     const int H = 32 * A.nj, EMB = 64 * A.nj;
+    int64_t prow[RT];
+    bool ok[RT];
+    float ls[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int64_t lr = tile * (16 * RT) + 16 * rt + n;
+        ok[rt] = lr < A.R;
+        prow[rt] = ok[rt] ? dfx_row(A.rm, lr) : 0;
+        ls[rt] = 0.f;
+    }
+    // stage-1 fragments and the y columns of the NEXT super-chunk are requested before the current one's matrix ops; the consumers'
+    // fragments of a super-chunk are requested at its top and first used after its stage 1
+    float4 w1n[4], yn[RT][2];
+    auto request = [&](int J) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w1n[i] = A.wfrag[((size_t)J * DFX_FAN_WPJ + i) * 64 + lane];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch)
+                yn[rt][ch] = ok[rt] ? *reinterpret_cast<const float4 *>(A.y + prow[rt] * H + 32 * J + 16 * ch + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    request(J0);
+    for (int J = J0; J < J1; ++J) {
+        float4 w1[4], yc[RT][2], wc[DFX_FAN_NC][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w1[i] = w1n[i];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) yc[rt][0] = yn[rt][0], yc[rt][1] = yn[rt][1];
+        dfx_static_for<0, DFX_FAN_NC>([&](auto CI) {
+            constexpr int c = decltype(CI)::value;
+            constexpr int kind = c == 0 ? K0 : (c == 1 ? K1 : K2);
+#pragma unroll
+            for (int i = 0; i < (kind == 2 ? 8 : (kind == 1 ? 4 : 0)); ++i) wc[c][i] = A.wfrag[((size_t)J * DFX_FAN_WPJ + 4 + 8 * c + i) * 64 + lane];
+        });
+        if (J + 1 < J1) request(J + 1);
+        float4 lw[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+            lw[tt] = A.lsnr_w ? *reinterpret_cast<const float4 *>(A.lsnr_w + 64 * J + 16 * tt + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float e[4][4];   // [feature tile tt = 2 ch + t][r]: feature 64 J + 16 tt + 4 q + r of row n
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                const float ys[4] = {yc[rt][ch].x, yc[rt][ch].y, yc[rt][ch].z, yc[rt][ch].w};
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int tt = 2 * ch + t;
+                    const float ws[4] = {w1[tt].x, w1[tt].y, w1[tt].z, w1[tt].w};
+                    f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) d = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[k], ys[k], d, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) e[tt][r] = fmaxf(d[r], 0.f);
+                    const int64_t eoff = prow[rt] * EMB + 64 * J + 16 * tt + 4 * q;
+                    if (A.res && ok[rt]) {
+                        const float4 rv = *reinterpret_cast<const float4 *>(A.res + eoff);
+                        e[tt][0] += rv.x, e[tt][1] += rv.y, e[tt][2] += rv.z, e[tt][3] += rv.w;
+                    }
+                    if (A.emb_out && ok[rt]) *reinterpret_cast<float4 *>(A.emb_out + eoff) = make_float4(e[tt][0], e[tt][1], e[tt][2], e[tt][3]);
+                    ls[rt] += e[tt][0] * lw[tt].x;
+                    ls[rt] += e[tt][1] * lw[tt].y;
+                    ls[rt] += e[tt][2] * lw[tt].z;
+                    ls[rt] += e[tt][3] * lw[tt].w;
+                }
+            }
+            dfx_static_for<0, DFX_FAN_NC>([&](auto CI) {
+                constexpr int c = decltype(CI)::value;
+                constexpr int kind = c == 0 ? K0 : (c == 1 ? K1 : K2);
+                if constexpr (kind != 0) {
+                    constexpr int NTT = kind == 2 ? 4 : 2;   // feature tiles an output tile contracts over
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {   // output columns 32 J + 16 u + 4 q + r
+                        f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int i = 0; i < NTT; ++i) {
+                            const int tt = kind == 2 ? i : 2 * u + i;
+                            const float4 wv = wc[c][NTT * u + i];
+                            const float ws[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) d = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[r], e[tt][r], d, 0, 0, 0);
+                        }
+                        if (ok[rt])
+                            *reinterpret_cast<float4 *>(A.out[c] + prow[rt] * H + 32 * J + 16 * u + 4 * q) =
+                                make_float4(dfx_act(d[0], A.act[c]), dfx_act(d[1], A.act[c]), dfx_act(d[2], A.act[c]), dfx_act(d[3], A.act[c]));
+                    }
+                }
+            });
+        }
+    }
+    if (A.lsnr) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float v = ls[rt];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (q == 0 && ok[rt]) A.lsnr[prow[rt]] = dfx_sigmoid(v + A.lsnr_b) * A.lsnr_scale + A.lsnr_off;
+        }
+    }
+}
+template <int RT, int K0, int K1, int K2>
+__global__ void __launch_bounds__(256, 2) dfx_k_emb_fan(DfxFanArgs A) {
     const int64_t ntile = (A.R + 16 * RT - 1) / (16 * RT);
     const int jper = A.nj / A.parts;
     for (int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); item < ntile * A.parts; item += (int64_t)gridDim.x * 4) {
         const int64_t tile = item / A.parts;
-        const int J0 = (int)(item - tile * A.parts) * jper, J1 = J0 + jper;
-        int64_t prow[RT];
-        bool ok[RT];
-        float ls[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const int64_t lr = tile * (16 * RT) + 16 * rt + n;
-            ok[rt] = lr < A.R;
-            prow[rt] = ok[rt] ? dfx_row(A.rm, lr) : 0;
-            ls[rt] = 0.f;
-        }
-        // stage-1 fragments and the y columns of the NEXT super-chunk are requested before the current one's matrix ops; the consumers'
-        // fragments of a super-chunk are requested at its top and first used after its stage 1
-        float4 w1n[4], yn[RT][2];
-        auto request = [&](int J) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) w1n[i] = A.wfrag[((size_t)J * DFX_FAN_WPJ + i) * 64 + lane];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int ch = 0; ch < 2; ++ch)
-                    yn[rt][ch] = ok[rt] ? *reinterpret_cast<const float4 *>(A.y + prow[rt] * H + 32 * J + 16 * ch + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-        };
-        request(J0);
-        for (int J = J0; J < J1; ++J) {
-            float4 w1[4], yc[RT][2], wc[DFX_FAN_NC][8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) w1[i] = w1n[i];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) yc[rt][0] = yn[rt][0], yc[rt][1] = yn[rt][1];
-            dfx_static_for<0, DFX_FAN_NC>([&](auto CI) {
-                constexpr int c = decltype(CI)::value;
-                constexpr int kind = c == 0 ? K0 : (c == 1 ? K1 : K2);
-#pragma unroll
-                for (int i = 0; i < (kind == 2 ? 8 : (kind == 1 ? 4 : 0)); ++i) wc[c][i] = A.wfrag[((size_t)J * DFX_FAN_WPJ + 4 + 8 * c + i) * 64 + lane];
-            });
-            if (J + 1 < J1) request(J + 1);
-            float4 lw[4];
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-                lw[tt] = A.lsnr_w ? *reinterpret_cast<const float4 *>(A.lsnr_w + 64 * J + 16 * tt + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                float e[4][4];   // [feature tile tt = 2 ch + t][r]: feature 64 J + 16 tt + 4 q + r of row n
-#pragma unroll
-                for (int ch = 0; ch < 2; ++ch) {
-                    const float ys[4] = {yc[rt][ch].x, yc[rt][ch].y, yc[rt][ch].z, yc[rt][ch].w};
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int tt = 2 * ch + t;
-                        const float ws[4] = {w1[tt].x, w1[tt].y, w1[tt].z, w1[tt].w};
-                        f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) d = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[k], ys[k], d, 0, 0, 0);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) e[tt][r] = fmaxf(d[r], 0.f);
-                        const int64_t eoff = prow[rt] * EMB + 64 * J + 16 * tt + 4 * q;
-                        if (A.res && ok[rt]) {
-                            const float4 rv = *reinterpret_cast<const float4 *>(A.res + eoff);
-                            e[tt][0] += rv.x, e[tt][1] += rv.y, e[tt][2] += rv.z, e[tt][3] += rv.w;
-                        }
-                        if (A.emb_out && ok[rt]) *reinterpret_cast<float4 *>(A.emb_out + eoff) = make_float4(e[tt][0], e[tt][1], e[tt][2], e[tt][3]);
-                        ls[rt] += e[tt][0] * lw[tt].x;
-                        ls[rt] += e[tt][1] * lw[tt].y;
-                        ls[rt] += e[tt][2] * lw[tt].z;
-                        ls[rt] += e[tt][3] * lw[tt].w;
-                    }
-                }
-                dfx_static_for<0, DFX_FAN_NC>([&](auto CI) {
-                    constexpr int c = decltype(CI)::value;
-                    constexpr int kind = c == 0 ? K0 : (c == 1 ? K1 : K2);
-                    if constexpr (kind != 0) {
-                        constexpr int NTT = kind == 2 ? 4 : 2;   // feature tiles an output tile contracts over
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {   // output columns 32 J + 16 u + 4 q + r
-                            f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                            for (int i = 0; i < NTT; ++i) {
-                                const int tt = kind == 2 ? i : 2 * u + i;
-                                const float4 wv = wc[c][NTT * u + i];
-                                const float ws[4] = {wv.x, wv.y, wv.z, wv.w};
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) d = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[r], e[tt][r], d, 0, 0, 0);
-                            }
-                            if (ok[rt])
-                                *reinterpret_cast<float4 *>(A.out[c] + prow[rt] * H + 32 * J + 16 * u + 4 * q) =
-                                    make_float4(dfx_act(d[0], A.act[c]), dfx_act(d[1], A.act[c]), dfx_act(d[2], A.act[c]), dfx_act(d[3], A.act[c]));
-                        }
-                    }
-                });
-            }
-        }
-        if (A.lsnr) {
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                float v = ls[rt];
-                v += __shfl_xor(v, 16);
-                v += __shfl_xor(v, 32);
-                if (q == 0 && ok[rt]) A.lsnr[prow[rt]] = dfx_sigmoid(v + A.lsnr_b) * A.lsnr_scale + A.lsnr_off;
-            }
-        }
+        const int J0 = (int)(item - tile * A.parts) * jper;
+        dfx_emb_fan_item<RT, K0, K1, K2>(A, tile, J0, J0 + jper);
     }
     dfx_publish(A.pub);
+}
+// The same arithmetic as a persistent FOLLOWER of the encoder GRU's recurrence (round 5, see dfx_k_proj_follow): workgroup g serves the 16
+// clips of group g; per block of DFX_EF_STEPS steps it waits for the recurrence's yprog word, runs one item per wave (16 rows, all
+// super-chunks: RT = 1) and raises embprog.  A's pointers are those of the whole pass; rm is ignored.
+#define DFX_EF_STEPS 8
+struct DfxFollowSync {
+    const unsigned int *src;   // [groups]: steps the producer has completed (pbase + steps)
+    unsigned int *dst;         // [groups]: steps this follower has completed
+    unsigned int pbase;
+    unsigned int *err;
+    int spin_limit;
+    int64_t B, T;
+};
+template <int K0, int K1, int K2>
+__global__ void __launch_bounds__(512, 1) dfx_k_emb_follow(DfxFanArgs A, DfxFollowSync Y) {
+    const int g = (int)blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+    const int64_t b0 = (int64_t)g * 16;
+    const int nclip = (int)(Y.B - b0 < 16 ? Y.B - b0 : 16);
+    if (nclip <= 0) return;
+    const int H = 32 * A.nj, EMB = 64 * A.nj;
+    // this group's rows: every array starts at clip b0 (a logical row of a block is (clip, step) through rm)
+    A.y += b0 * Y.T * H;
+    if (A.res) A.res += b0 * Y.T * EMB;
+    if (A.emb_out) A.emb_out += b0 * Y.T * EMB;
+#pragma unroll
+    for (int c = 0; c < DFX_FAN_NC; ++c)
+        if (A.out[c]) A.out[c] += b0 * Y.T * H;
+    if (A.lsnr) A.lsnr += b0 * Y.T;
+    A.parts = 1;
+    for (int64_t t0 = 0; t0 < Y.T; t0 += DFX_EF_STEPS) {
+        const int64_t t1 = t0 + DFX_EF_STEPS < Y.T ? t0 + DFX_EF_STEPS : Y.T;
+        if (tid == 0) {
+            const unsigned int want = Y.pbase + (unsigned int)t1;
+            int spins = 0;
+            while ((int)(__hip_atomic_load(Y.src + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+                if (++spins > Y.spin_limit) {
+                    dfx_raise(Y.err + 2);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        A.rm = DfxRowMap{Y.T, t1 - t0, t0};
+        A.R = (int64_t)nclip * (t1 - t0);
+        const int ntile = (int)((A.R + 15) / 16);
+        for (int tile = wave; tile < ntile; tile += 8) dfx_emb_fan_item<1, K0, K1, K2>(A, tile, 0, A.nj);
+        __syncthreads();   // the block's rows are stored
+        if (tid == 0) __hip_atomic_store(Y.dst + g, Y.pbase + (unsigned int)t1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -3872,6 +3928,14 @@ struct DfxGhSync {
     unsigned int *err;
     unsigned long long *trace;   // dev aid (DFX_SEQ_TRACE=1): [K][3] wall-clock ticks of this workgroup: wait begin, compute begin, chunk end
     int spin_limit;              // polls before a wait gives up and raises err[2]
+    // block-granular hand-over to / from a follower workgroup (dfx_k_proj_follow), null = none.  Both words count STEPS of this 16-clip group
+    // (pbase + steps): yprog is raised by this workgroup every `sblk` steps (and at the end of the sequence) for the follower of the layer above;
+    // giprog is raised by this layer's own follower — this workgroup then does not wait for `ready` (no host-launched projection feeds it).
+    unsigned int *yprog = nullptr;
+    const unsigned int *giprog = nullptr;
+    unsigned int pbase = 0;
+    int sblk = 16;               // steps per block of this layer's follower (a power of two)
+    int yblk = 16;               // steps between two yprog announcements (= the block of the consumer's follower)
 };
 #define DFX_SYNC_SPIN_LIMIT (1 << 22)   /* default bound of every flag wait: polls with s_sleep, ~2 s (dfx_model::spin_limit, DFX_SYNC_SPIN_LIMIT) */
 
@@ -3968,13 +4032,29 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
     for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int s = 0; s < NS; ++s) gv[g][s] = make_float4(0.1f, 0.2f, 0.3f, 0.4f);
+    // (follower-fed layer) the gi rows of steps < upto must exist before they are requested
+    auto wait_gi = [&](int64_t upto) {
+        if (tid == 0) {
+            const unsigned int want = Y.pbase + (unsigned int)(upto < A.T ? upto : A.T);
+            int spins = 0;
+            while ((int)(__hip_atomic_load(Y.giprog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+                if (++spins > Y.spin_limit) {
+                    dfx_raise(Y.err + 2);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    };
     const int nchunk = SEQ ? Y.K : 1;
     const bool dead = false;
     for (int ck = 0; ck < nchunk; ++ck) {
     const int64_t c0 = SEQ ? (int64_t)Y.tb[ck] : A.t0, c1 = SEQ ? (int64_t)Y.tb[ck + 1] : A.t1;
     if (SEQ) {   // the input projection of this chunk must exist
         if (tid == 0 && Y.trace) Y.trace[ck * 3 + 0] = wall_clock64();
-        if (tid == 0 && !dead) {
+        if (tid == 0 && !dead && !Y.giprog) {
             const unsigned int want = Y.base + (unsigned int)ck + 1u;
             int spins = 0;
             while ((int)(__hip_atomic_load(Y.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
@@ -3987,6 +4067,7 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
         }
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (Y.giprog && ck == 0) wait_gi(Y.sblk);   // (later blocks: one step before their first row is requested, below)
         if (tid == 0 && Y.trace) Y.trace[ck * 3 + 1] = wall_clock64();
     }
 #pragma unroll
@@ -3995,6 +4076,7 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
         for (int s = 0; s < NS; ++s)
             if (c1 > c0 && !(DFX_GH_ABLATE & 2)) gv[g][s] = *reinterpret_cast<const float4 *>(gp + c0 * (3 * H) + g * H + 16 * s);
     for (int64_t t = c0; t < c1; ++t) {
+        if (SEQ && Y.giprog && ((t + 1) & (Y.sblk - 1)) == 0 && t + 1 < A.T) wait_gi(t + 1 + Y.sblk);   // this step requests the first row of the next block
         int zoff = 0;
         DFX_OPAQUE(zoff);  // keeps the (loop-invariant) streamed weight loads inside the time loop
         const dfx_h8 *wst = wg + zoff;
@@ -4107,6 +4189,8 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
         }
         __syncthreads();
         cur ^= 1;
+        if (SEQ && Y.yprog && (((t + 1) & (Y.yblk - 1)) == 0 || t + 1 == A.T) && tid == 0)   // a block of y rows is complete (stored in front of the barrier)
+            __hip_atomic_store(Y.yprog, Y.pbase + (unsigned int)(t + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (SEQ) {   // this workgroup's rows of chunk ck are complete: make them visible device-wide, then say so
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -4160,6 +4244,11 @@ struct DfxGsArgs {
     unsigned int *err;
     unsigned long long *trace;   // dev aid: [layers][groups][K][3] or null
     int spin_limit;
+    unsigned int *yprog[DFX_GS_MAX_LAYERS] = {};         // [groups] each or null (DfxGhSync)
+    unsigned int *giprog[DFX_GS_MAX_LAYERS] = {};        // [groups] each or null
+    unsigned int pbase = 0;
+    int sblk = 16;
+    int yblk[DFX_GS_MAX_LAYERS] = {};
 };
 template <bool X32>
 static __device__ __forceinline__ void dfx_gru_seq_body(const DfxGsArgs &S) {
@@ -4180,11 +4269,180 @@ static __device__ __forceinline__ void dfx_gru_seq_body(const DfxGsArgs &S) {
     A.t1 = S.T;
     A.unscale = S.unscale[l];
     A.xcd_mask = 0;
-    dfx_gru_h3_run<true, X32>(A, g, DfxGhSync{S.ready + l, S.done + (size_t)l * S.done_stride, S.base, S.K, S.tb, S.err,
-                                              S.trace ? S.trace + ((size_t)l * S.groups + g) * S.K * 3 : nullptr, S.spin_limit});
+    DfxGhSync Y{S.ready + l, S.done + (size_t)l * S.done_stride, S.base, S.K, S.tb, S.err,
+                S.trace ? S.trace + ((size_t)l * S.groups + g) * S.K * 3 : nullptr, S.spin_limit};
+    Y.yprog = S.yprog[l] ? S.yprog[l] + g : nullptr;
+    Y.giprog = S.giprog[l] ? S.giprog[l] + g : nullptr;
+    Y.pbase = S.pbase, Y.sblk = S.sblk, Y.yblk = S.yblk[l] > 0 ? S.yblk[l] : 16;
+    dfx_gru_h3_run<true, X32>(A, g, Y);
 }
 __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_seq(DfxGsArgs S) { dfx_gru_seq_body<false>(S); }
 __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_seq_x32(DfxGsArgs S) { dfx_gru_seq_body<true>(S); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dfx_k_proj_follow: the input projection of a GRU layer whose input IS the output of the layer below (the second layers of the decoder
+// stacks), as persistent FOLLOWER workgroups of the recurrences instead of one launch per time chunk (round 5).  Workgroup (f, g) serves
+// the 16 clips of group g of layer lay[f]: it waits until the recurrence of the layer below has completed the next block of 16 steps of
+// those clips (its yprog word), runs dfx_k_proj256_h3x2<8, 4>'s arithmetic on the block's 256 rows (wave w, tile t: step 2 w + t of the
+// block; lane: clip — the same bits, a row's result does not depend on the tiling) and raises the layer's giprog word.  The layer above
+// therefore starts 16 steps + one block (~45 us) behind the layer below instead of one time chunk (63-84 steps) + a wait kernel + a
+// projection launch (~0.6 ms), and its projections no longer travel through the side streams.  W_ih is streamed from L2 once per block
+// through LDS (2 x 64 KB), like the launch form.
+// ---------------------------------------------------------------------------------------------------------------------
+#define DFX_PF_MAX 4
+struct DfxPfArgs {
+    const float *x[DFX_PF_MAX];        // [B, T, 256]: y of the layer below
+    float *gi[DFX_PF_MAX];             // [B, T, 768]
+    const dfx_h8 *wf[DFX_PF_MAX];      // as DfxPhArgs::wf
+    const float *bias[DFX_PF_MAX];
+    float unscale[DFX_PF_MAX];
+    const unsigned int *yprog[DFX_PF_MAX];   // [groups]: steps the layer below has completed (pbase + steps)
+    unsigned int *giprog[DFX_PF_MAX];        // [groups]: steps of gi this follower has completed
+    int64_t B, T;
+    int nf, groups;
+    unsigned int pbase;
+    unsigned int *err;
+    int spin_limit;
+};
+__global__ void __launch_bounds__(512, 1) dfx_k_proj_follow(DfxPfArgs A) {
+    constexpr int NW = 8, CT = 4, NTH = 64 * NW, SB = 2 * NW, N = 768;   // SB steps per block
+    constexpr int CH8 = 8 * CT * 2 * 64;
+    constexpr int PER_T = CH8 / NTH;
+    DFX_DYN_SMEM(dfx_h8, ws);  // [2][CH8]
+    const int f = (int)(blockIdx.x / (unsigned)A.groups), g = (int)(blockIdx.x % (unsigned)A.groups);
+    if (f >= A.nf) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
+    constexpr int nchunks = N / (16 * CT);
+    const int T = (int)A.T;
+    for (int t0 = 0; t0 < T; t0 += SB) {
+        const int t1 = t0 + SB < T ? t0 + SB : T;
+        int zoff = 0, jz = jl;
+        DFX_OPAQUE(zoff);   // (keeps the block-invariant addresses out of registers held across the block loop: no scratch)
+        DFX_OPAQUE(jz);
+        const dfx_h8 *wf = A.wf[f] + zoff;
+        const float *bias = A.bias[f] + zoff;
+        const int64_t clip = (int64_t)g * 16 + jz;
+        const bool okc = clip < A.B;
+        const float *xrow = A.x[f] + (okc ? clip : 0) * A.T * 256 + 8 * q;
+        float *orow = A.gi[f] + (okc ? clip : 0) * A.T * N;
+        // the first chunk of W does not depend on the producer: stage it in front of the wait (buffer 0 is free: nchunks is even)
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) ws[i * NTH + tid] = wf[i * NTH + tid];
+        if (tid == 0) {
+            const unsigned int want = A.pbase + (unsigned int)t1;
+            int spins = 0;
+            while ((int)(__hip_atomic_load(A.yprog[f] + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+                if (++spins > A.spin_limit) {
+                    dfx_raise(A.err + 2);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        dfx_h8 xh[2][8], xl[2][8];
+        float unscale[2];
+        int trow[2];
+        bool okr[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            trow[t] = t0 + 2 * wave + t;
+            okr[t] = okc && trow[t] < t1;
+            if (!okr[t]) trow[t] = t0;
+            const float4 *p = reinterpret_cast<const float4 *>(xrow + trow[t] * 256);
+            float4 xu[8], xv[8];
+            float mx = 0.f;
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                xu[kc] = okr[t] ? p[8 * kc] : make_float4(0.f, 0.f, 0.f, 0.f);
+                xv[kc] = okr[t] ? p[8 * kc + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(xu[kc].x), fabsf(xu[kc].y)), fmaxf(fabsf(xu[kc].z), fabsf(xu[kc].w))));
+                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(xv[kc].x), fabsf(xv[kc].y)), fmaxf(fabsf(xv[kc].z), fabsf(xv[kc].w))));
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));   // the four lanes (q) that share a row
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            int e = 0;
+            if (mx > 0.f && mx < 3.0e38f) {       // per-row power-of-two scale, exactly as in dfx_k_proj256_h3
+                int ex;
+                (void)frexpf(mx, &ex);
+                e = 14 - ex;
+                e = e > 100 ? 100 : (e < -100 ? -100 : e);
+            }
+            const float sc = ldexpf(1.f, e);
+            unscale[t] = A.unscale[f] * ldexpf(1.f, -e);
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                float x[8];
+                x[0] = xu[kc].x * sc, x[1] = xu[kc].y * sc, x[2] = xu[kc].z * sc, x[3] = xu[kc].w * sc;
+                x[4] = xv[kc].x * sc, x[5] = xv[kc].y * sc, x[6] = xv[kc].z * sc, x[7] = xv[kc].w * sc;
+                dfx_split8(x, xh[t][kc], xl[t][kc]);
+            }
+        }
+        for (int c = 0; c < nchunks; ++c) {
+            const dfx_h8 *wc = ws + (size_t)(c & 1) * CH8;
+            // the next chunk travels to the other LDS buffer in two halves (16 registers in flight instead of 32: the kernel's 256 are full)
+            constexpr int HP = PER_T / 2;
+            dfx_h8 pre[HP];
+            const dfx_h8 *src = wf + (size_t)(c + 1) * CH8;   // (CT = 4: a chunk is one of the host's 64-column blocks)
+            dfx_h8 *dst = ws + (size_t)((c + 1) & 1) * CH8;
+            if (c + 1 < nchunks) {
+#pragma unroll
+                for (int i = 0; i < HP; ++i) pre[i] = src[i * NTH + tid];
+            }
+            f32x4 acc[2][CT];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[t][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                dfx_h8 whi[CT], wlo[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    whi[ct] = wc[((kc * CT + ct) * 2 + 0) * 64 + lane];
+                    wlo[ct] = wc[((kc * CT + ct) * 2 + 1) * 64 + lane];
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[t][ct] = dfx_mfma_16x16x32_f16(wlo[ct], xh[t][kc], acc[t][ct]);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[t][ct] = dfx_mfma_16x16x32_f16(whi[ct], xl[t][kc], acc[t][ct]);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[t][ct] = dfx_mfma_16x16x32_f16(whi[ct], xh[t][kc], acc[t][ct]);
+                if (kc == 3 && c + 1 < nchunks) {
+#pragma unroll
+                    for (int i = 0; i < HP; ++i) dst[i * NTH + tid] = pre[i];
+#pragma unroll
+                    for (int i = 0; i < HP; ++i) pre[i] = src[(HP + i) * NTH + tid];
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int n = c * (16 * CT) + 16 * ct + 4 * q;
+                const float4 bz = *reinterpret_cast<const float4 *>(bias + n);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    if (okr[t])
+                        *reinterpret_cast<float4 *>(orow + trow[t] * N + n) =
+                            make_float4(acc[t][ct][0] * unscale[t] + bz.x, acc[t][ct][1] * unscale[t] + bz.y, acc[t][ct][2] * unscale[t] + bz.z,
+                                        acc[t][ct][3] * unscale[t] + bz.w);
+            }
+            if (c + 1 < nchunks) {
+#pragma unroll
+                for (int i = 0; i < HP; ++i) dst[(HP + i) * NTH + tid] = pre[i];
+            }
+            __syncthreads();
+        }
+        // the block's gi rows are stored (in front of the last barrier): say so
+        if (tid == 0) __hip_atomic_store(A.giprog[f] + g, A.pbase + (unsigned int)t1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 // flag kernels of the persistent GRU phase: dfx_k_flag_set runs behind a producer on its stream (the kernel boundary in front of it
 // has made the producer's writes visible), dfx_k_wait_ge holds its stream until all n flags have reached the target
