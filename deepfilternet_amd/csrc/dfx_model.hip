@@ -6,6 +6,7 @@
 #include <cmath>
 #include <functional>
 #include <map>
+#include <mutex>
 
 // ------------------------------------------------------------------------------------------------ cfg validation
 static int check_cfg(const dfx_model_cfg *c) {
@@ -1119,7 +1120,8 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
             if (tq && tq[0] == '1') (void)hipMalloc(reinterpret_cast<void **>(&m->d_trace), (size_t)DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX * DFX_GS_MAX_CHUNKS * 3 * 8);
         }
         // ready 0-7 | emb 8 | probe 13 | done 16- | producers' completion counters (DfxPublish): 9 words (16) | yprog, giprog: steps per (layer, group)
-        const size_t sync_bytes = (size_t)(16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX + 16 + 2 * DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX) * sizeof(unsigned int);
+        // | XCD registrations [3 kinds][layers][groups] (DfxXcd) | 64 words: [0] light hand-overs counted (dev aid), [8..48) the followers' claim counters
+        const size_t sync_bytes = (size_t)(16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX + 16 + 2 * DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX + 3 * DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX + 64) * sizeof(unsigned int);
         if (hipMalloc(reinterpret_cast<void **>(&m->d_sync), sync_bytes) != hipSuccess || hipMemset(m->d_sync, 0, sync_bytes) != hipSuccess ||
             dfx_env_err_words_alloc(&m->h_err, &m->d_err, 256) != hipSuccess) {
             dfx_model_free(m);
@@ -1166,6 +1168,7 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
     return DFX_OK;
 }
 
+static void follow_forget(const dfx_model *m);
 extern "C" void dfx_model_free(dfx_model *m) {
     if (!m) return;
     for (int l = 0; l < DFX_MAX_LANES; ++l) {
@@ -1191,6 +1194,12 @@ extern "C" void dfx_model_free(dfx_model *m) {
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_pass) (void)hipEventDestroy(m->ev_pass);
     dfx_env_err_words_free(m->h_err);
+    follow_forget(m);
+    if (m->d_sync && m->d_trace) {   // dev aid (DFX_SEQ_TRACE=1): how many block hand-overs of the followers took the same-XCD form
+        unsigned int n = 0;
+        const size_t off = 16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX + 16 + 2 * DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX + 3 * DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX;
+        if (hipMemcpy(&n, m->d_sync + off, sizeof(n), hipMemcpyDeviceToHost) == hipSuccess) fprintf(stderr, "[dfx] same-XCD (light) block hand-overs over the model's life: %u\n", n);
+    }
     if (m->d_sync) (void)hipFree(m->d_sync);
     if (m->d_trace) (void)hipFree(m->d_trace);
     if (m->d_w) (void)hipFree(m->d_w);
@@ -1862,6 +1871,42 @@ static int launch_glin(const dfx_model *m, const GlinW &g, const float *a, int a
     return launch_ggemm(a, g.G * g.Kg, m->p(g.w), g.G, g.Kg, g.Ng, nullptr, act, res, out, g.G * g.Ng, M, s, 0, 0, 1, rm, a2);
 }
 
+// DFX_SEQ_FOLLOW (persistent GRU phase): 0 = every input projection a launch per time chunk; 1 = follower workgroups for the stacks' second layers;
+// 2 (default since the same-XCD hand-over, M§R5.12) = followers for every decoder layer + the emb fan-out; 3 = the first layers + emb only.
+static int seq_follow_mode() {
+    static const int v = [] { const char *e = getenv("DFX_SEQ_FOLLOW"); return e ? atoi(e) : 2; }();
+    return v;
+}
+// Followers double the workgroups that must be resident at once (160 at batch 256).  Two model handles driven from two host threads could put two
+// such phases on the chip together, and then neither might fit: a pass takes followers only if no OTHER handle's follower pass can still be running
+// (checked and claimed under a process-wide lock; the other handle's pass then runs the launch form, which needs 80).
+struct FollowGuard {
+    std::mutex mu;
+    const dfx_model *owner = nullptr;
+    hipEvent_t done = nullptr;   // recorded behind the owner's last follower pass (the owner's event)
+    bool pending = false;        // the owner is between claiming and recording
+};
+static FollowGuard &follow_guard() {
+    static FollowGuard g;
+    return g;
+}
+static bool follow_claim(const dfx_model *m) {
+    FollowGuard &g = follow_guard();
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (g.owner && g.owner != m && (g.pending || (g.done && hipEventQuery(g.done) == hipErrorNotReady))) return false;
+    g.owner = m, g.pending = true, g.done = nullptr;
+    return true;
+}
+static void follow_recorded(const dfx_model *m, hipEvent_t ev) {
+    FollowGuard &g = follow_guard();
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (g.owner == m) g.done = ev, g.pending = false;
+}
+static void follow_forget(const dfx_model *m) {   // dfx_model_free
+    FollowGuard &g = follow_guard();
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (g.owner == m) g.owner = nullptr, g.done = nullptr, g.pending = false;
+}
 // Row count up to which the fan-out kernels take their few-rows forms (one row tile per wave, a tile's chunks dealt to separate waves): made
 // for a streaming hop (4096 rows).  Round 5: the time chunks of the persistent GRU phase (10-20 k rows at 16-24 chunks) take the large-launch
 // forms — at the old bound of 16384 rows every chunking finer than 15 chunks fell onto the hop's forms (15.1 vs 14.1 ms per step).
@@ -2256,7 +2301,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // (22 per chunk: the exact mode, DFX_SEQ_PUBLISH=0) — measured 13.24-13.28 (16) vs 13.37-13.49 (12) ms per step, measurements R5.10
         static const int kenv = [] { const char *e = getenv("DFX_SEQ_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
         static const bool kpub = [] { const char *e = getenv("DFX_SEQ_PUBLISH"); return !(e && e[0] == '0'); }();
-        const int kbody = kenv > 0 ? kenv : (kpub && !m->exact_fp32 ? 16 : 12);
+        // (with followers only the encoder layer's projections and the decoder tails are still per chunk: 12 again, 12.98 vs 13.12 ms at 16)
+        const int kbody = kenv > 0 ? kenv : (kpub && !m->exact_fp32 && seq_follow_mode() <= 0 ? 16 : 12);
         const int64_t body = std::max<int64_t>(dfx_ceil_div(T, (int64_t)kbody), m->tchunk_min);   // uniform chunk length: DFX_SEQ_CHUNKS=n gives n chunks (ceil: 1002 / 12 -> 84, not 83 and a 13th chunk)
         std::vector<int> sizes;
         int64_t left = T;
@@ -2435,7 +2481,10 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             // front's critical path (ERB convolutions -> DF encoder) has the chip to itself, and since the decoder tail got 0.4 ms lighter the
             // phase has the room: 13.50 / 13.54 -> 13.18 / 13.22 ms per step (same box; 30 / 50 / 70 % of the frames deferred: 13.41 / 13.41 /
             // 13.48; in round 4, with the heavier tail, the same move measured as noise).  DFX_CONVP_LATE=p defers the last p percent (0: as before).
-            static const int late_pct = [] { const char *e = getenv("DFX_CONVP_LATE"); const int v = e ? atoi(e) : 100; return v < 0 ? 0 : (v > 100 ? 100 : v); }();
+            // Exact mode with followers: in front of the phase, beside the (long) exact front — under the phase it starves the encoder layer's first
+            // projections on the CUs the followers leave (25.9 vs 30.3 ms per step).
+            static const int late_env = [] { const char *e = getenv("DFX_CONVP_LATE"); const int v = e ? atoi(e) : -1; return v > 100 ? 100 : v; }();
+            const int late_pct = late_env >= 0 ? late_env : (m->exact_fp32 && seq_follow_mode() >= 2 ? 0 : 100);
             convp_split = use_seq && late_pct > 0 ? T - (T - t_begin) * late_pct / 100 : T;
             if (convp_split > t_begin && (rc = convp_range(t_begin, convp_split, x2))) return rc;
             if (post_behind_convp && (rc = sc->df_post(x2))) return rc;
@@ -2568,21 +2617,27 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             // layers of the decoder stacks — in blocks of 16 steps instead of time chunks.  DFX_SEQ_FOLLOW=0: a projection launch per chunk.
             // DFX_SEQ_FOLLOW=2: the stacks' first layers too — a follower of the encoder GRU (dfx_k_emb_follow) runs dfx_k_emb_fan's arithmetic
             // per block of 8 steps and the first layers' projection followers read what it wrote.
-            static const int follow_env = [] { const char *e = getenv("DFX_SEQ_FOLLOW"); return e ? atoi(e) : 0; }();
+            const int follow_env = seq_follow_mode();
             unsigned int *yprog = pcnt + 16, *giprog = yprog + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX;
             unsigned int *embprog = yprog + (size_t)(DFX_MAX_GRU_LAYERS - 1) * DFX_SEQ_GMAX;   // (the row of a layer that cannot exist: nl < 8 below)
+            // same-XCD hand-overs (DfxXcd; DFX_SEQ_XCD_LIGHT=0: every block hand-over with the agent-scope release / acquire)
+            static const bool xcd_light = [] { const char *e = getenv("DFX_SEQ_XCD_LIGHT"); return !(e && e[0] == '0'); }();
+            unsigned int *xtab = xcd_light ? giprog + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX : nullptr;
+            unsigned int *xstat = xtab ? xtab + 3 * DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX : nullptr;
+            const unsigned int xtag = (m->seq_pbase & 0x0fffffffu) << 4;
+            auto xword = [&](int kind, int layer) { return xtab + ((size_t)kind * DFX_MAX_GRU_LAYERS + layer) * DFX_SEQ_GMAX; };
             const unsigned int pbase = m->seq_pbase;
             bool followed[DFX_MAX_GRU_LAYERS] = {};
             int nfollow = 0;
             const int lfirst_df = 1 + ndec;
-            const bool follow_emb = follow_env >= 2 && !m->exact_fp32 && fan && c.emb_gru_skip_enc != DFX_SKIP_GROUPEDLINEAR && nl < DFX_MAX_GRU_LAYERS &&
+            const bool follow_emb = follow_env >= 2 && fan && c.emb_gru_skip_enc != DFX_SKIP_GROUPEDLINEAR && nl < DFX_MAX_GRU_LAYERS &&
                                     (nl + nl) * groups <= dfx_env_num_cus() * 3 / 4 && nl - 1 <= DFX_PF_MAX;
-            if (follow_env >= 1 && !m->exact_fp32) {
+            if (follow_env >= 1) {
                 for (int l = 1; l < nl; ++l) {
                     const bool first = l == 1 || l == lfirst_df;   // a stack's first layer reads a grouped linear of emb, the others the layer below
                     if (first ? follow_emb : follow_env != 3) followed[l] = true, ++nfollow;   // (3: the first layers only)
                 }
-                if (nfollow > DFX_PF_MAX || (nl + nfollow + 1) * groups > dfx_env_num_cus() * 3 / 4) {   // all of them or none (every workgroup must be resident)
+                if (nfollow > DFX_PF_MAX || (nl + nfollow + 1) * groups > dfx_env_num_cus() * 3 / 4 || (nfollow && !follow_claim(m))) {   // all of them or none (every workgroup must be resident)
                     nfollow = 0;
                     for (int l = 0; l < nl; ++l) followed[l] = false;
                 }
@@ -2613,6 +2668,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             // and the rest follows chunk-major, faster than the chain consumes it.
             if (m->phase_late && !m->enqueue_ahead && R >= DFX_THROTTLE_MIN_FRAMES) DFX_HIP(hipEventSynchronize(ln->ev[EV_XA]));
             if ((rc = wait(ev_go, G)) || (rc = wait(ev_go, Eq)) || (rc = wait(ev_go, Dq)) || (rc = wait(ev_go, Pq))) return rc;
+            // (the followers' claim counters, dfx_xcd_claim: zeroed in front of the recurrences, whose registrations every follower waits for)
+            if (nfollow && xtab) DFX_HIP(hipMemsetAsync(xstat + 8, 0, (size_t)(DFX_PF_MAX + 1) * 8 * sizeof(unsigned int), G));
             {   // the recurrences
                 DfxGsArgs S;
                 for (int l = 0; l < DFX_GS_MAX_LAYERS; ++l) S.gi[l] = nullptr, S.y[l] = nullptr, S.whf[l] = nullptr, S.bhn[l] = nullptr, S.unscale[l] = 1.f;
@@ -2630,6 +2687,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 S.trace = m->d_trace;
                 S.spin_limit = m->spin_limit;
                 S.pbase = pbase, S.sblk = 16;
+                if (xtab) S.xtab = xtab, S.xstride = DFX_SEQ_GMAX, S.xtag = xtag, S.xstat = xstat;
                 for (int l = 1; l < nl; ++l) {
                     if (!followed[l]) continue;
                     S.giprog[l] = giprog + (size_t)l * DFX_SEQ_GMAX;
@@ -2637,6 +2695,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                     const int src = first ? 0 : l - 1;   // the recurrence whose output feeds the follower chain of layer l
                     S.yprog[src] = yprog + (size_t)src * DFX_SEQ_GMAX;
                     S.yblk[src] = first ? DFX_EF_STEPS : 16;
+                    S.xcons_kind[src] = first ? 2 : 1, S.xcons_layer[src] = first ? 0 : l;
                 }
                 m->trace_dims[0] = nl, m->trace_dims[1] = groups, m->trace_dims[2] = K;
                 DFX_HIP(dfx_env_set_max_dyn_smem(m->exact_fp32 ? (const void *)dfx_k_gru_seq_x32 : (const void *)dfx_k_gru_seq, DFX_GH_SMEM));
@@ -2653,21 +2712,27 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                     const GruW &g = l <= ndec ? m->dec_gru[l - 1] : m->df_gru[l - 1 - ndec];
                     const bool first = l == 1 || l == lfirst_df;
                     F.x[f] = first ? (l == 1 ? xb : xa2) : ws + w.py[l - 1], F.gi[f] = ws + w.pgi[l];
-                    F.wf[f] = reinterpret_cast<const dfx_h8 *>(m->p(g.wih_h3)), F.bias[f] = m->p(g.bias_i), F.unscale[f] = g.wih_unscale;
+                    F.wf[f] = reinterpret_cast<const dfx_h8 *>(m->p(m->exact_fp32 ? g.wih_t : g.wih_h3)), F.bias[f] = m->p(g.bias_i), F.unscale[f] = g.wih_unscale;
                     F.yprog[f] = first ? embprog : yprog + (size_t)(l - 1) * DFX_SEQ_GMAX, F.giprog[f] = giprog + (size_t)l * DFX_SEQ_GMAX;
+                    if (xtab) F.xme[f] = xword(1, l), F.xprod[f] = first ? xword(2, 0) : xword(0, l - 1), F.xcons[f] = xword(0, l);
                     ++f;
                 }
                 for (; f < DFX_PF_MAX; ++f) F.x[f] = nullptr, F.gi[f] = nullptr, F.wf[f] = nullptr, F.bias[f] = nullptr, F.unscale[f] = 1.f, F.yprog[f] = nullptr, F.giprog[f] = nullptr;
+                F.xtag = xtag, F.xstat = xstat;
+                if (xtab) {   // the followers choose their groups by XCD (dfx_xcd_claim): counters zeroed in front of the launches
+                    F.xrec = xword(0, 0), F.xclaim = xstat + 8;
+                }
                 F.B = B, F.T = T, F.nf = nfollow, F.groups = groups, F.pbase = pbase, F.err = m->d_err, F.spin_limit = m->spin_limit;
                 int lq = -1;
                 for (int l = nl - 1; l >= 2 && lq < 0; --l)
                     if (followed[l]) lq = l;
                 // the stream of a followed layer's projections has nothing else to carry (ps[1]: the emb follower); only layer 1 followed = no DF stack: its tail stream is free
                 hipStream_t Fq = lq > 0 ? ln->ps[lq] : Dq;
-                DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_proj_follow, DFX_PH_SMEM));
+                DFX_HIP(dfx_env_set_max_dyn_smem(m->exact_fp32 ? (const void *)dfx_k_proj_follow_x32 : (const void *)dfx_k_proj_follow, DFX_PH_SMEM));
                 if ((rc = wait(ev_go, Fq))) return rc;
                 DfxKScope ks(DFX_K_PROJ, Fq);
-                dfx_launch(dfx_k_proj_follow, dim3((unsigned)(nfollow * groups)), dim3(512), DFX_PH_SMEM, Fq, F);
+                if (m->exact_fp32) dfx_launch(dfx_k_proj_follow_x32, dim3((unsigned)(nfollow * groups)), dim3(512), DFX_PH_SMEM, Fq, F);
+                else dfx_launch(dfx_k_proj_follow, dim3((unsigned)(nfollow * groups)), dim3(512), DFX_PH_SMEM, Fq, F);
                 DFX_LAUNCH_CHECK();
             }
             if (followed[1]) {   // the follower of the encoder GRU: emb, lsnr and the inputs of both decoders' stacks per block of 8 steps
@@ -2676,6 +2741,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 float *dfg_x = run_df ? xa2 : nullptr, *skp = fan_skp ? xdf : nullptr;
                 DfxFanArgs EA = emb_fan_args(m, ws + w.py[0], res, need_emb ? embv : nullptr, xb, dfg_x, skp, lsnr);
                 DfxFollowSync EY;
+                if (xtab) {
+                    EY.x.me = xword(2, 0), EY.x.prod = xword(0, 0), EY.x.cons = xword(1, 1), EY.x.cons2 = followed[lfirst_df] ? xword(1, lfirst_df) : nullptr;
+                    EY.x.tag = xtag, EY.x.stat = xstat;
+                    EY.xclaim = xstat + 8 + 8 * DFX_PF_MAX, EY.groups = groups;
+                }
                 EY.src = yprog, EY.dst = embprog, EY.pbase = pbase, EY.err = m->d_err, EY.spin_limit = m->spin_limit, EY.B = B, EY.T = T;
                 hipStream_t Eq2 = ln->ps[1];
                 if ((rc = wait(ev_go, Eq2))) return rc;
@@ -2688,11 +2758,20 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 }
                 if ((rc = signal(EV_EMB, Eq2))) return rc;   // the whole embedding exists (lsnr)
             }
-            if (run_df && convp_split < T) {   // the deferred part of the pathway conv: behind the front, beside the chain
-                // (held back further, until the layer pipeline has filled — a flag wait on the last layer's first chunk in front of it — the fill is
-                // 0.3 ms shorter and the layers then wait as long for the inputs of their next chunks: 13.20-13.23 vs 13.21 ms, not kept)
-                if ((rc = wait(ev_go, x2)) || (rc = convp_range(convp_split, T, x2)) || (rc = signal(EV_C0P, x2))) return rc;
-            }
+            // the deferred part of the pathway conv: behind the front, beside the chain
+            // (held back further, until the layer pipeline has filled — a flag wait on the last layer's first chunk in front of it — the fill is
+            // 0.3 ms shorter and the layers then wait as long for the inputs of their next chunks: 13.20-13.23 vs 13.21 ms, not kept)
+            // With followers the encoder layer's first projections go out in front of it: on the CUs the followers leave, a kernel that is enqueued
+            // behind df_convp waits for it (exact mode: 6.4 ms for the first chunk's projection).
+            static const int convp_order = [] { const char *e = getenv("DFX_CONVP_AFTER_P0"); return e ? atoi(e) : -1; }();
+            const bool convp_after_p0 = convp_order >= 0 ? convp_order != 0 : nfollow > 0;
+            auto convp_late = [&]() -> int {
+                if (!(run_df && convp_split < T)) return DFX_OK;
+                int r;
+                if ((r = wait(ev_go, x2)) || (r = convp_range(convp_split, T, x2)) || (r = signal(EV_C0P, x2))) return r;
+                return DFX_OK;
+            };
+            if (!convp_after_p0 && (rc = convp_late())) return rc;
             {
                 // layer 0 (encoder GRU): its input xa is complete; one projection + flag per chunk
                 // (stays two chunks ahead of the recurrence instead of flooding the chip with all K projections while the decoders'
@@ -2701,6 +2780,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                     static const int p0_ahead = [] { const char *e = getenv("DFX_SEQ_P0_AHEAD"); return e && atoi(e) > 0 ? atoi(e) : 3; }();
                     if (k >= p0_ahead && (rc = launch_wait_ge(m, donep(0), groups, tgt(k - p0_ahead), Pq))) return rc;
                     if ((rc = proj_chunk(m->enc_gru[0], 0, k, xa, Pq))) return rc;
+                    if (convp_after_p0 && k == (K < p0_ahead ? K : p0_ahead) - 1 && (rc = convp_late())) return rc;
                 }
             }
             const int fpt = 64 / E > 0 ? 64 / E : 1;
@@ -2833,6 +2913,10 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             for (int l = 0; l < nl; ++l) {
                 DFX_HIP(hipEventRecord(ln->pev[l][0], ln->ps[l]));
                 DFX_HIP(hipStreamWaitEvent(s, ln->pev[l][0], 0));
+            }
+            if (nfollow) {   // every persistent workgroup of this pass is over when s gets here
+                DFX_HIP(hipEventRecord(ln->gev[0][1], s));
+                follow_recorded(m, ln->gev[0][1]);
             }
         } else {
         auto gru_chunk = [&](const GruW &g, int l, int k, hipStream_t st) -> int {

@@ -2892,9 +2892,80 @@ __global__ void __launch_bounds__(DFX_PJ_THREADS, 2) dfx_k_proj256(DfxPjArgs A) 
 #define DFX_PH_NC 64
 #define DFX_PH_CHUNK_H8 (8 * 4 * 2 * 64)                 /* dfx_h8 per column chunk: [kc][ct][hi,lo][lane] */
 #define DFX_PH_SMEM ((size_t)2 * DFX_PH_CHUNK_H8 * 16)
+// Same-XCD hand-overs of the persistent GRU phase's followers (round 5, see DfxGhSync::x).
+struct DfxXcd {
+    unsigned int *me = nullptr;            // this party's registration word: tag | (xcd + 1)
+    const unsigned int *prod = nullptr;    // the registration word of the party whose output this one consumes, or null
+    const unsigned int *cons = nullptr;    // ... of the party that consumes this one's output, or null
+    const unsigned int *cons2 = nullptr;   // a second consumer (the emb follower feeds two projection followers), or null
+    unsigned int tag = 0;                  // of this pass (low four bits zero)
+    unsigned int *stat = nullptr;          // dev aid: counts light releases
+};
+static __device__ __forceinline__ void dfx_xcd_register(const DfxXcd &X) {
+    if (X.me && threadIdx.x == 0) __hip_atomic_store(X.me, X.tag | (unsigned int)(dfx_xcc_id() + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __device__ __forceinline__ bool dfx_xcd_same(const DfxXcd &X, const unsigned int *other) {
+    return other && __hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (X.tag | (unsigned int)(dfx_xcc_id() + 1));
+}
+// the consumer's side of a block hand-over, behind the barrier that follows the poll (every thread)
+static __device__ __forceinline__ void dfx_xcd_acquire(const DfxXcd &X) {
+    if (dfx_xcd_same(X, X.prod)) DFX_L1_INV();
+    else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// the producer's side: thread 0, behind a barrier in front of which EVERY wave has drained its stores (DFX_VMEM_DRAIN)
+static __device__ __forceinline__ void dfx_xcd_release(const DfxXcd &X, unsigned int *flag, unsigned int value) {
+    if (dfx_xcd_same(X, X.cons) && (!X.cons2 || dfx_xcd_same(X, X.cons2))) {
+        __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (X.stat) __hip_atomic_fetch_add(X.stat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 // A producer kernel of the persistent GRU phase announces its own completion (round 5): every workgroup, when its rows are stored, adds itself to a
 // counter; the last one resets the counter and raises the flag the consumers poll — the dfx_k_flag_set launch behind the producer (and the ~8 us of
 // host enqueue and dispatch it costs per layer and chunk) is gone.  cnt == nullptr: nothing (every launch outside that phase).
+// A follower workgroup picks the 16-clip group it serves: one whose RECURRENCE runs on this workgroup's XCD (workgroups go round-robin over the 8
+// XCDs with a rotation that differs from launch to launch, so block index g of the follower launch is usually NOT next to group g's recurrence).
+// rec[g] = registration words of the recurrences of one layer (all layers of a launch share the mapping), claim[8] = slots handed out per XCD
+// (zeroed by the host before the launch).  Own XCD first, then the others in turn: as many workgroups as groups, so everyone finds exactly one —
+// also if the dispatch was not an exact round robin.  Thread 0 decides, the result travels through *slot (LDS).  rec == nullptr: group = fallback.
+static __device__ __forceinline__ int dfx_xcd_claim(const unsigned int *rec, unsigned int tag, int groups, unsigned int *claim, int fallback, int spin_limit,
+                                                    unsigned int *err, int *slot) {
+    if (!rec || groups > 64) return fallback;
+    if (threadIdx.x == 0) {
+        auto xcd_of = [&](int g) { return (int)(__hip_atomic_load(rec + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 15u) - 1; };   // (re-read: no array in scratch)
+        bool ok = true;
+        for (int g = 0; g < groups && ok; ++g) {   // every recurrence of this pass has registered (they start first)
+            unsigned int v;
+            int spins = 0;
+            while (((v = __hip_atomic_load(rec + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & ~15u) != tag || (v & 15u) == 0u) {
+                if (++spins > spin_limit) {
+                    dfx_raise(err + 2);
+                    ok = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        int got = -1;
+        const int x0 = dfx_xcc_id();
+        for (int d = 0; d < 8 && got < 0 && ok; ++d) {
+            const int x = (x0 + d) & 7;
+            int cnt = 0;
+            for (int g = 0; g < groups; ++g) cnt += xcd_of(g) == x;
+            if (!cnt) continue;
+            const unsigned int k = __hip_atomic_fetch_add(claim + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int)k >= cnt) continue;
+            for (int g = 0, j = 0; g < groups; ++g)
+                if (xcd_of(g) == x && j++ == (int)k) got = g;
+        }
+        *slot = got < 0 ? fallback : got;   // (got < 0: registrations timed out; err is raised)
+    }
+    __syncthreads();
+    const int r = *slot;
+    __syncthreads();
+    return r;
+}
 struct DfxPublish {
     unsigned int *cnt = nullptr;   // completion counter of this producer (one word per stream: launches on a stream do not overlap)
     unsigned int *flag = nullptr;
@@ -3483,10 +3554,15 @@ struct DfxFollowSync {
     unsigned int *err;
     int spin_limit;
     int64_t B, T;
+    DfxXcd x;   // same-XCD hand-overs: the words of group 0 (the kernel adds its group)
+    unsigned int *xclaim = nullptr;   // [8], zeroed before the launch (dfx_xcd_claim over x.prod: the encoder layer's recurrences), or null
+    int groups = 0;
 };
 template <int K0, int K1, int K2>
 __global__ void __launch_bounds__(512, 1) dfx_k_emb_follow(DfxFanArgs A, DfxFollowSync Y) {
-    const int g = (int)blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+    __shared__ int gslot;
+    const int g = dfx_xcd_claim(Y.xclaim ? Y.x.prod : nullptr, Y.x.tag, Y.groups, Y.xclaim, (int)blockIdx.x, Y.spin_limit, Y.err, &gslot);
+    const int tid = threadIdx.x, wave = tid >> 6;
     const int64_t b0 = (int64_t)g * 16;
     const int nclip = (int)(Y.B - b0 < 16 ? Y.B - b0 : 16);
     if (nclip <= 0) return;
@@ -3500,6 +3576,9 @@ __global__ void __launch_bounds__(512, 1) dfx_k_emb_follow(DfxFanArgs A, DfxFoll
         if (A.out[c]) A.out[c] += b0 * Y.T * H;
     if (A.lsnr) A.lsnr += b0 * Y.T;
     A.parts = 1;
+    DfxXcd X = Y.x;
+    if (X.me) X.me += g, X.prod = X.prod ? X.prod + g : nullptr, X.cons = X.cons ? X.cons + g : nullptr, X.cons2 = X.cons2 ? X.cons2 + g : nullptr;
+    dfx_xcd_register(X);
     for (int64_t t0 = 0; t0 < Y.T; t0 += DFX_EF_STEPS) {
         const int64_t t1 = t0 + DFX_EF_STEPS < Y.T ? t0 + DFX_EF_STEPS : Y.T;
         if (tid == 0) {
@@ -3514,13 +3593,14 @@ __global__ void __launch_bounds__(512, 1) dfx_k_emb_follow(DfxFanArgs A, DfxFoll
             }
         }
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        dfx_xcd_acquire(X);
         A.rm = DfxRowMap{Y.T, t1 - t0, t0};
         A.R = (int64_t)nclip * (t1 - t0);
         const int ntile = (int)((A.R + 15) / 16);
         for (int tile = wave; tile < ntile; tile += 8) dfx_emb_fan_item<1, K0, K1, K2>(A, tile, 0, A.nj);
-        __syncthreads();   // the block's rows are stored
-        if (tid == 0) __hip_atomic_store(Y.dst + g, Y.pbase + (unsigned int)t1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        DFX_VMEM_DRAIN();
+        __syncthreads();   // the block's rows are stored, and have reached the L2
+        if (tid == 0) dfx_xcd_release(X, Y.dst + g, Y.pbase + (unsigned int)t1);
     }
 }
 
@@ -3936,6 +4016,12 @@ struct DfxGhSync {
     unsigned int pbase = 0;
     int sblk = 16;               // steps per block of this layer's follower (a power of two)
     int yblk = 16;               // steps between two yprog announcements (= the block of the consumer's follower)
+    // Same-XCD hand-overs (DfxXcd): a producer and a consumer that share an L2 need neither the L2 write-back of an agent-scope release nor the L2
+    // invalidate of an agent-scope acquire — the invalidate alone throws the XCD's share of the streamed W_hh out of the L2 every 16 steps of every
+    // recurrence on it (measured with both left out: 7.9 -> 7.3 us per step).  Every party registers the XCD it runs on; a hand-over whose partner
+    // is registered on the same XCD drains its stores (s_waitcnt vmcnt(0) in every wave in front of the barrier), raises the flag with a plain
+    // device-scope store, and the consumer invalidates its L1 only.  Anything else — partner elsewhere, or not registered yet — takes the full form.
+    DfxXcd x;
 };
 #define DFX_SYNC_SPIN_LIMIT (1 << 22)   /* default bound of every flag wait: polls with s_sleep, ~2 s (dfx_model::spin_limit, DFX_SYNC_SPIN_LIMIT) */
 
@@ -4046,8 +4132,9 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
             }
         }
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        dfx_xcd_acquire(Y.x);
     };
+    if (SEQ) dfx_xcd_register(Y.x);
     const int nchunk = SEQ ? Y.K : 1;
     const bool dead = false;
     for (int ck = 0; ck < nchunk; ++ck) {
@@ -4187,10 +4274,11 @@ static __device__ __forceinline__ void dfx_gru_h3_run(const DfxGhArgs &A, int64_
             for (int r = 0; r < 4; ++r) gate_unit(s, r);
             gate_finish(s);
         }
+        const bool ypub = SEQ && Y.yprog && (((t + 1) & (Y.yblk - 1)) == 0 || t + 1 == A.T);   // a block of y rows is complete with this step
+        if (ypub) DFX_VMEM_DRAIN();
         __syncthreads();
         cur ^= 1;
-        if (SEQ && Y.yprog && (((t + 1) & (Y.yblk - 1)) == 0 || t + 1 == A.T) && tid == 0)   // a block of y rows is complete (stored in front of the barrier)
-            __hip_atomic_store(Y.yprog, Y.pbase + (unsigned int)(t + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (ypub && tid == 0) dfx_xcd_release(Y.x, Y.yprog, Y.pbase + (unsigned int)(t + 1));
     }
     if (SEQ) {   // this workgroup's rows of chunk ck are complete: make them visible device-wide, then say so
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -4249,6 +4337,12 @@ struct DfxGsArgs {
     unsigned int pbase = 0;
     int sblk = 16;
     int yblk[DFX_GS_MAX_LAYERS] = {};
+    // same-XCD hand-overs: the registration words [kind][layer][xstride]: kind 0 recurrences, 1 projection followers, 2 the emb follower (row 0)
+    unsigned int *xtab = nullptr;
+    int xstride = 0;
+    int xcons_kind[DFX_GS_MAX_LAYERS] = {}, xcons_layer[DFX_GS_MAX_LAYERS] = {};   // who consumes layer l's yprog blocks
+    unsigned int xtag = 0;
+    unsigned int *xstat = nullptr;
 };
 template <bool X32>
 static __device__ __forceinline__ void dfx_gru_seq_body(const DfxGsArgs &S) {
@@ -4274,6 +4368,13 @@ static __device__ __forceinline__ void dfx_gru_seq_body(const DfxGsArgs &S) {
     Y.yprog = S.yprog[l] ? S.yprog[l] + g : nullptr;
     Y.giprog = S.giprog[l] ? S.giprog[l] + g : nullptr;
     Y.pbase = S.pbase, Y.sblk = S.sblk, Y.yblk = S.yblk[l] > 0 ? S.yblk[l] : 16;
+    if (S.xtab) {   // (every layer registers: the followers' claims read the encoder layer's row)
+        auto word = [&](int kind, int layer) { return S.xtab + ((size_t)kind * DFX_GS_MAX_LAYERS + layer) * S.xstride + g; };
+        Y.x.me = word(0, l);
+        Y.x.prod = Y.giprog ? word(1, l) : nullptr;
+        Y.x.cons = Y.yprog ? word(S.xcons_kind[l], S.xcons_layer[l]) : nullptr;
+        Y.x.tag = S.xtag, Y.x.stat = S.xstat;
+    }
     dfx_gru_h3_run<true, X32>(A, g, Y);
 }
 __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_seq(DfxGsArgs S) { dfx_gru_seq_body<false>(S); }
@@ -4303,17 +4404,33 @@ struct DfxPfArgs {
     unsigned int pbase;
     unsigned int *err;
     int spin_limit;
+    // same-XCD hand-overs (DfxXcd): registration words of this follower's producer / itself / its consumer, [groups] each, or null
+    const unsigned int *xprod[DFX_PF_MAX] = {};
+    unsigned int *xme[DFX_PF_MAX] = {};
+    const unsigned int *xcons[DFX_PF_MAX] = {};
+    unsigned int xtag = 0;
+    unsigned int *xstat = nullptr;
+    const unsigned int *xrec = nullptr;   // registration words of one layer's recurrences [groups] (dfx_xcd_claim) or null: group = block index
+    unsigned int *xclaim = nullptr;       // [DFX_PF_MAX][8], zeroed before the launch
 };
+static __device__ __forceinline__ DfxXcd dfx_pf_xcd(const DfxPfArgs &A, int f, int g) {
+    DfxXcd X;
+    if (A.xme[f]) X.me = A.xme[f] + g, X.prod = A.xprod[f] ? A.xprod[f] + g : nullptr, X.cons = A.xcons[f] ? A.xcons[f] + g : nullptr, X.tag = A.xtag, X.stat = A.xstat;
+    return X;
+}
 __global__ void __launch_bounds__(512, 1) dfx_k_proj_follow(DfxPfArgs A) {
     constexpr int NW = 8, CT = 4, NTH = 64 * NW, SB = 2 * NW, N = 768;   // SB steps per block
     constexpr int CH8 = 8 * CT * 2 * 64;
     constexpr int PER_T = CH8 / NTH;
     DFX_DYN_SMEM(dfx_h8, ws);  // [2][CH8]
-    const int f = (int)(blockIdx.x / (unsigned)A.groups), g = (int)(blockIdx.x % (unsigned)A.groups);
+    const int f = (int)(blockIdx.x / (unsigned)A.groups);
     if (f >= A.nf) return;
+    const int g = dfx_xcd_claim(A.xrec, A.xtag, A.groups, A.xclaim ? A.xclaim + 8 * f : nullptr, (int)(blockIdx.x % (unsigned)A.groups), A.spin_limit, A.err,
+                                reinterpret_cast<int *>(ws));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
     constexpr int nchunks = N / (16 * CT);
     const int T = (int)A.T;
+    dfx_xcd_register(dfx_pf_xcd(A, f, g));
     for (int t0 = 0; t0 < T; t0 += SB) {
         const int t1 = t0 + SB < T ? t0 + SB : T;
         int zoff = 0, jz = jl;
@@ -4340,7 +4457,7 @@ __global__ void __launch_bounds__(512, 1) dfx_k_proj_follow(DfxPfArgs A) {
             }
         }
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        dfx_xcd_acquire(dfx_pf_xcd(A, f, g));
         dfx_h8 xh[2][8], xl[2][8];
         float unscale[2];
         int trow[2];
@@ -4436,11 +4553,143 @@ __global__ void __launch_bounds__(512, 1) dfx_k_proj_follow(DfxPfArgs A) {
             if (c + 1 < nchunks) {
 #pragma unroll
                 for (int i = 0; i < HP; ++i) dst[(HP + i) * NTH + tid] = pre[i];
+            } else {
+                DFX_VMEM_DRAIN();   // the block's gi rows have reached the L2 (same-XCD hand-over)
             }
             __syncthreads();
         }
         // the block's gi rows are stored (in front of the last barrier): say so
-        if (tid == 0) __hip_atomic_store(A.giprog[f] + g, A.pbase + (unsigned int)t1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) dfx_xcd_release(dfx_pf_xcd(A, f, g), A.giprog[f] + g, A.pbase + (unsigned int)t1);
+    }
+}
+
+// The exact form (DFX_EXACT_FP32=1): the same follower on v_mfma_f32_16x16x4_f32.  A.wf is W_ih^T as plain fp32 [256][768] (GruW::wih_t); a 64-column
+// chunk of it (64 KB) is staged per chunk in the k order of dfx_k_proj256 — LDS row 4 ks + q holds W[64 q + ks][.], so that matrix op ks contracts
+// the k-set {64 q + ks} and a lane's B operands are the 64 CONTIGUOUS values [64 q, 64 q + 64) of its row (float4 loads) — with bit 4 of the
+// column index flipped in odd rows: the 2 x 16 lanes a ds_read_b32 serves per cycle (q = 0 / 1, then 2 / 3) then hit 32 different banks.
+// 6144 matrix ops of 32 cycles per wave and block, two waves per SIMD: ~165 us per 16 steps of a recurrence that takes 14 us per step.
+__global__ void __launch_bounds__(512, 1) dfx_k_proj_follow_x32(DfxPfArgs A) {
+    constexpr int NW = 8, CT = 4, NTH = 64 * NW, SB = 2 * NW, N = 768, K = 256;
+    constexpr int CHF = K * 16 * CT;          // floats per chunk
+    constexpr int PER_T = CHF / 4 / NTH;      // float4 pieces per thread and chunk (8)
+    constexpr int HP = PER_T / 2;
+    DFX_DYN_SMEM(float, wsf);  // [2][CHF]
+    const int f = (int)(blockIdx.x / (unsigned)A.groups);
+    if (f >= A.nf) return;
+    const int g = dfx_xcd_claim(A.xrec, A.xtag, A.groups, A.xclaim ? A.xclaim + 8 * f : nullptr, (int)(blockIdx.x % (unsigned)A.groups), A.spin_limit, A.err,
+                                reinterpret_cast<int *>(wsf));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
+    constexpr int nchunks = N / (16 * CT);
+    const int T = (int)A.T;
+    dfx_xcd_register(dfx_pf_xcd(A, f, g));
+    // piece i of a chunk (i compile-time): k = 32 i + kt, kt = tid / 16, columns 4 n4 .. + 3 of the chunk, n4 = tid % 16; its LDS row is
+    // 4 (k % 64) + k / 64 = 4 kt + 128 (i % 2) + i / 2, whose parity — the column flip — is that of i / 2: one source and two destination bases per thread
+    const int kt = tid >> 4, n4 = tid & 15;
+    const int src_off = kt * N + 4 * n4;                                       // + 32 i N + 64 c
+    const int dst_off0 = 4 * kt * 64 + 4 * n4, dst_off1 = 4 * kt * 64 + ((4 * n4) ^ 16);   // + (128 (i % 2) + i / 2) * 64
+    auto piece_src = [&](const float *w, int c, int i) -> const f32x4 * {
+        return reinterpret_cast<const f32x4 *>(w + src_off + 32 * i * N + 64 * c);
+    };
+    auto piece_dst = [&](float *buf, int i) -> f32x4 * {
+        return reinterpret_cast<f32x4 *>(buf + (((i >> 1) & 1) ? dst_off1 : dst_off0) + (128 * (i & 1) + (i >> 1)) * 64);
+    };
+    for (int t0 = 0; t0 < T; t0 += SB) {
+        const int t1 = t0 + SB < T ? t0 + SB : T;
+        int zoff = 0, jz = jl;
+        DFX_OPAQUE(zoff);   // (keeps the block-invariant addresses out of registers held across the block loop)
+        DFX_OPAQUE(jz);
+        const float *w = reinterpret_cast<const float *>(A.wf[f]) + zoff;
+        const float *bias = A.bias[f] + zoff;
+        const int64_t clip = (int64_t)g * 16 + jz;
+        const bool okc = clip < A.B;
+        const float *xrow = A.x[f] + (okc ? clip : 0) * A.T * K + 64 * q;
+        float *orow = A.gi[f] + (okc ? clip : 0) * A.T * N;
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) *piece_dst(wsf, i) = *piece_src(w, 0, i);
+        if (tid == 0) {
+            const unsigned int want = A.pbase + (unsigned int)t1;
+            int spins = 0;
+            while ((int)(__hip_atomic_load(A.yprog[f] + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+                if (++spins > A.spin_limit) {
+                    dfx_raise(A.err + 2);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        __syncthreads();
+        dfx_xcd_acquire(dfx_pf_xcd(A, f, g));
+        float4 xv[2][16];
+        int trow[2];
+        bool okr[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            trow[t] = t0 + 2 * wave + t;
+            okr[t] = okc && trow[t] < t1;
+            if (!okr[t]) trow[t] = t0;
+            const float4 *p = reinterpret_cast<const float4 *>(xrow + trow[t] * K);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) xv[t][v] = okr[t] ? p[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int c = 0; c < nchunks; ++c) {
+            const float *wc = wsf + (size_t)(c & 1) * CHF + q * 64 + jl;   // element (row 4 ks + q, column 16 ct + jl) sits at + ks * 256 + 16 * (ct ^ (q & 1))
+            float *dstb = wsf + (size_t)((c + 1) & 1) * CHF;
+            f32x4 pre[HP];   // (the ext-vector type: a HIP float4 array with a conditional first write stays in scratch)
+            if (c + 1 < nchunks) {
+#pragma unroll
+                for (int i = 0; i < HP; ++i) pre[i] = *piece_src(w, c + 1, i);
+            }
+            f32x4 acc[2][CT];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[t][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float fa[2][CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) fa[0][ct] = wc[16 * (ct ^ (q & 1))];
+            auto ksteps = [&](auto kc) {
+                constexpr int ks = decltype(kc)::value;
+                if constexpr (ks + 1 < 64) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) fa[(ks + 1) & 1][ct] = wc[(ks + 1) * 256 + 16 * (ct ^ (q & 1))];
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float4 x4 = xv[t][ks >> 2];
+                    const float xk = (ks & 3) == 0 ? x4.x : (ks & 3) == 1 ? x4.y : (ks & 3) == 2 ? x4.z : x4.w;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks & 1][ct], xk, acc[t][ct], 0, 0, 0);
+                }
+                DFX_SCHED_BARRIER();
+            };
+            dfx_static_for<0, 32>(ksteps);
+            if (c + 1 < nchunks) {   // the next chunk's first half lands in the other buffer, its second half is requested
+#pragma unroll
+                for (int i = 0; i < HP; ++i) *piece_dst(dstb, i) = pre[i];
+#pragma unroll
+                for (int i = 0; i < HP; ++i) pre[i] = *piece_src(w, c + 1, HP + i);
+            }
+            dfx_static_for<32, 64>(ksteps);
+            DFX_MFMA_GUARD();
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int n = c * (16 * CT) + 16 * ct + 4 * q;
+                const float4 bz = *reinterpret_cast<const float4 *>(bias + n);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    if (okr[t])
+                        *reinterpret_cast<float4 *>(orow + trow[t] * N + n) =
+                            make_float4(acc[t][ct][0] + bz.x, acc[t][ct][1] + bz.y, acc[t][ct][2] + bz.z, acc[t][ct][3] + bz.w);
+            }
+            if (c + 1 < nchunks) {
+#pragma unroll
+                for (int i = 0; i < HP; ++i) *piece_dst(dstb, HP + i) = pre[i];
+            } else {
+                DFX_VMEM_DRAIN();
+            }
+            __syncthreads();
+        }
+        if (tid == 0) dfx_xcd_release(dfx_pf_xcd(A, f, g), A.giprog[f] + g, A.pbase + (unsigned int)t1);
     }
 }
 

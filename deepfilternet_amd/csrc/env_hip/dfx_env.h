@@ -138,6 +138,10 @@ static __device__ __forceinline__ f32x4 dfx_mfma_16x16x32_f16(dfx_h8 a, dfx_h8 b
         asm volatile("s_nop 7");                 \
         __builtin_amdgcn_sched_barrier(0);       \
     } while (0)
+// same-XCD hand-overs (DfxXcd): every outstanding vector-memory operation of the wave has completed (stores: acknowledged by the L2) / this CU's
+// L1 holds nothing stale (group-scope invalidate: the L2, shared by the XCD's CUs, is left alone)
+#define DFX_VMEM_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define DFX_L1_INV() asm volatile("buffer_inv sc0" ::: "memory")
 #define DFX_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)   /* ask for n instructions of a class next (0x008 MFMA, 0x002 VALU) */
 // barrier + LDS visibility among the 64 lanes of ONE wave (LDS operations of a wave complete in order; the fences only pin the
 // compiler's ordering) — costs nothing compared with s_barrier across the workgroup

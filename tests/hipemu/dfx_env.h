@@ -71,6 +71,7 @@ typedef float f32x16 __attribute__((vector_size(64)));
 typedef int hipError_t;
 typedef void *hipStream_t;
 #define hipSuccess 0
+#define hipErrorNotReady 600
 #define hipMemcpyHostToDevice 1
 #define hipMemcpyDeviceToHost 2
 #define hipMemcpyDeviceToDevice 3
@@ -142,6 +143,7 @@ static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }   // (launches are synchronous: every event has passed)
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) {
     *ms = 0.f;
     return hipSuccess;
@@ -566,6 +568,8 @@ static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
 #define DFX_PIN_AGPR(x) ((void)0)
 #define DFX_SCHED_BARRIER() ((void)0)
 #define DFX_MFMA_GUARD() do { } while (0)
+#define DFX_VMEM_DRAIN() ((void)0)
+#define DFX_L1_INV() ((void)0)
 #define DFX_SCHED_GROUP(mask, n) ((void)0)
 #define DFX_WAVE_SYNC() ((void)hipemu::wave_exchange(0, 0))  // all live lanes of the wave rendezvous
 #define DFX_DYN_SMEM(T, name) T *name = reinterpret_cast<T *>(hipemu::dyn_smem_ptr())
