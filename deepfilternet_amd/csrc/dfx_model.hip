@@ -2613,10 +2613,9 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             // a layer's input projection of chunk k, and ready[l] = chunk k + 1 behind it: raised by the projection kernel's last workgroup
             // (DfxPublish; DFX_SEQ_PUBLISH=0 or the exact mode: by a one-thread launch behind it, as before round 5)
             static const bool publish = [] { const char *e = getenv("DFX_SEQ_PUBLISH"); return !(e && e[0] == '0'); }();
-            // Follower workgroups (dfx_k_proj_follow) feed the layers whose input is the output of the layer below — the second (third ...)
-            // layers of the decoder stacks — in blocks of 16 steps instead of time chunks.  DFX_SEQ_FOLLOW=0: a projection launch per chunk.
-            // DFX_SEQ_FOLLOW=2: the stacks' first layers too — a follower of the encoder GRU (dfx_k_emb_follow) runs dfx_k_emb_fan's arithmetic
-            // per block of 8 steps and the first layers' projection followers read what it wrote.
+            // Follower workgroups (dfx_k_proj_follow) feed the decoder layers in blocks of 16 steps instead of time chunks (seq_follow_mode; default 2:
+            // all of them — a follower of the encoder GRU, dfx_k_emb_follow, runs dfx_k_emb_fan's arithmetic per block of 8 steps and the stacks' first
+            // layers' projection followers read what it wrote; 1: only the layers whose input is the output of the layer below; 0: launches per chunk).
             const int follow_env = seq_follow_mode();
             unsigned int *yprog = pcnt + 16, *giprog = yprog + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX;
             unsigned int *embprog = yprog + (size_t)(DFX_MAX_GRU_LAYERS - 1) * DFX_SEQ_GMAX;   // (the row of a layer that cannot exist: nl < 8 below)

@@ -3906,7 +3906,7 @@ __global__ void __launch_bounds__(DFX_GRU_THREADS, 2) dfx_k_gru_rec(const float 
 // ---------------------------------------------------------------------------------------------------------------------
 #define DFX_GH_ROWS 16
 #define DFX_GS_MAX_LAYERS 8   /* layers one persistent dfx_k_gru_seq launch can carry */
-#define DFX_GS_MAX_CHUNKS 96  /* time chunks of the persistent GRU phase (the default is 12: finer cuts lose to the hand-overs, profiles/r05_gru_chain.log) */
+#define DFX_GS_MAX_CHUNKS 96  /* time chunks of the persistent GRU phase (the default is 12; without followers 16: finer cuts lose to the hand-overs, profiles/r05_gru_chain.log) */
 #ifndef DFX_GH_ABLATE
 #define DFX_GH_ABLATE 0  /* dev ablations (tools/dev/gru_h3_bench.hip): 1 no stream refill, 2 no gi loads, 4 no matrix ops, 8 no gate math, 16 no y stores */
 #endif
@@ -4381,10 +4381,11 @@ __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_seq(D
 __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_seq_x32(DfxGsArgs S) { dfx_gru_seq_body<true>(S); }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// dfx_k_proj_follow: the input projection of a GRU layer whose input IS the output of the layer below (the second layers of the decoder
-// stacks), as persistent FOLLOWER workgroups of the recurrences instead of one launch per time chunk (round 5).  Workgroup (f, g) serves
-// the 16 clips of group g of layer lay[f]: it waits until the recurrence of the layer below has completed the next block of 16 steps of
-// those clips (its yprog word), runs dfx_k_proj256_h3x2<8, 4>'s arithmetic on the block's 256 rows (wave w, tile t: step 2 w + t of the
+// dfx_k_proj_follow: the input projection of a decoder GRU layer as persistent FOLLOWER workgroups of the recurrences instead of one launch
+// per time chunk (round 5; the default, DFX_SEQ_FOLLOW).  The layer's input is the output of the layer below (the stacks' second layers) or what the
+// emb follower wrote behind the encoder GRU (their first layers: dfx_k_emb_follow).  Workgroup (f, g) serves 16 clips of layer f — the group whose
+// recurrence runs on ITS XCD (dfx_xcd_claim), with L2-local hand-overs (DfxXcd) — : it waits until its producer has completed the next block of 16
+// steps of those clips (a step counter: yprog / embprog), runs dfx_k_proj256_h3x2<8, 4>'s arithmetic on the block's 256 rows (wave w, tile t: step 2 w + t of the
 // block; lane: clip — the same bits, a row's result does not depend on the tiling) and raises the layer's giprog word.  The layer above
 // therefore starts 16 steps + one block (~45 us) behind the layer below instead of one time chunk (63-84 steps) + a wait kernel + a
 // projection launch (~0.6 ms), and its projections no longer travel through the side streams.  W_ih is streamed from L2 once per block
