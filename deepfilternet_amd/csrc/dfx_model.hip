@@ -474,6 +474,20 @@ struct dfx_model {
     bool gru_seq = true;                // DFX_GRU_SEQ=0: one launch per (layer, time chunk) synchronised with events (round-1 form)
     bool phase_late = true;             // DFX_PHASE_LATE=0: the GRU phase is enqueued right behind the front (no staged enqueue)
     int proj_rt = 0;                    // DFX_PROJ_RT=1|2|3: one form of the projection kernel for every launch size
+    // switches of the persistent GRU phase and its side work, read when the handle is created like the rest; -1 = "the default"
+    struct {
+        int follow = 2;                 // DFX_SEQ_FOLLOW (see seq_follow_mode)
+        int chunks = 0, ramp = 0;       // DFX_SEQ_CHUNKS (0: 12, or 16 without followers), DFX_SEQ_RAMP
+        bool publish = true;            // DFX_SEQ_PUBLISH
+        bool xcd_light = true;          // DFX_SEQ_XCD_LIGHT
+        int convp_late = -1;            // DFX_CONVP_LATE (percent)
+        int convp_after_p0 = -1;        // DFX_CONVP_AFTER_P0
+        int p0_ahead = 3;               // DFX_SEQ_P0_AHEAD
+        int tail_every = 1;             // DFX_SEQ_TAIL_EVERY
+        int dftail_every = 0;           // DFX_SEQ_DFTAIL_EVERY (0: the rule in forward_impl)
+        int64_t fan_few_rows = 4096;    // DFX_FAN_FEW_ROWS
+        int64_t convp_elems = (int64_t)1 << 29;   // DFX_CONVP_ELEMS (test hook)
+    } sw;
     // DFX_FRONT_GRAIN=k[,kp]: k (kp) times as many, shorter workgroups for df_conv0->1 (df_convp).  df_convp owns whole SIMDs (one wave of
     // 512 registers each) and is needed last (by df_out, deep in the GRU phase): as a persistent grid of long workgroups it held every SIMD
     // for 4.7 ms while the kernels on the front's critical path (ERB encoder convs -> embedding GEMMs) waited for slots (erb_conv2: 1.8 ms
@@ -1109,6 +1123,25 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         const char *pl = getenv("DFX_PHASE_LATE"), *prt = getenv("DFX_PROJ_RT");
         m->phase_late = !(pl && pl[0] == '0');
         m->proj_rt = prt ? atoi(prt) : 0;
+        {
+            auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+            auto env_pos = [](const char *name, int dflt) { const char *e = getenv(name); return e && atoi(e) > 0 ? atoi(e) : dflt; };
+            auto env_on = [](const char *name) { const char *e = getenv(name); return !(e && e[0] == '0'); };
+            m->sw.follow = env_int("DFX_SEQ_FOLLOW", 2);
+            m->sw.chunks = env_pos("DFX_SEQ_CHUNKS", 0);
+            m->sw.ramp = env_int("DFX_SEQ_RAMP", 0);
+            m->sw.publish = env_on("DFX_SEQ_PUBLISH");
+            m->sw.xcd_light = env_on("DFX_SEQ_XCD_LIGHT");
+            m->sw.convp_late = env_int("DFX_CONVP_LATE", -1);
+            if (m->sw.convp_late > 100) m->sw.convp_late = 100;
+            m->sw.convp_after_p0 = env_int("DFX_CONVP_AFTER_P0", -1);
+            m->sw.p0_ahead = env_pos("DFX_SEQ_P0_AHEAD", 3);
+            m->sw.tail_every = env_pos("DFX_SEQ_TAIL_EVERY", 1);
+            m->sw.dftail_every = env_pos("DFX_SEQ_DFTAIL_EVERY", 0);
+            const char *ffr = getenv("DFX_FAN_FEW_ROWS"), *cel = getenv("DFX_CONVP_ELEMS");
+            if (ffr && atoll(ffr) > 0) m->sw.fan_few_rows = atoll(ffr);
+            if (cel && atoll(cel) > 0) m->sw.convp_elems = atoll(cel);
+        }
         const char *fg = getenv("DFX_FRONT_GRAIN");
         if (fg) {
             m->front_grain = atoi(fg) > 1 ? atoi(fg) : 1;
@@ -1459,7 +1492,7 @@ static int launch_convp_h3(const dfx_model *m, const float *feat_spec, float *ou
         if (t_end < 0) t_end = T;
         {   // 32-bit element offsets inside the kernel (B * feat_T * Fd < 2^29 per launch): a larger batch runs as several launches over whole clips
             const int64_t per_clip = (feat_T > 0 ? feat_T : T) * Fd;
-            static const int64_t lim = [] { const char *e = getenv("DFX_CONVP_ELEMS"); return e && atoll(e) > 0 ? (int64_t)atoll(e) : (int64_t)1 << 29; }();   // (test hook: the split at small sizes)
+            const int64_t lim = m->sw.convp_elems;   // (DFX_CONVP_ELEMS, test hook: the split at small sizes)
             if (per_clip >= lim) DFX_FAIL(DFX_ERR_UNSUPPORTED, "df_convp: clip too long for 32-bit element offsets");
             const int64_t bmax = (lim - 1) / per_clip;
             if (B > bmax) {
@@ -1873,10 +1906,7 @@ static int launch_glin(const dfx_model *m, const GlinW &g, const float *a, int a
 
 // DFX_SEQ_FOLLOW (persistent GRU phase): 0 = every input projection a launch per time chunk; 1 = follower workgroups for the stacks' second layers;
 // 2 (default since the same-XCD hand-over, M§R5.12) = followers for every decoder layer + the emb fan-out; 3 = the first layers + emb only.
-static int seq_follow_mode() {
-    static const int v = [] { const char *e = getenv("DFX_SEQ_FOLLOW"); return e ? atoi(e) : 2; }();
-    return v;
-}
+static int seq_follow_mode(const dfx_model *m) { return m->sw.follow; }
 // Followers double the workgroups that must be resident at once (160 at batch 256).  Two model handles driven from two host threads could put two
 // such phases on the chip together, and then neither might fit: a pass takes followers only if no OTHER handle's follower pass can still be running
 // (checked and claimed under a process-wide lock; the other handle's pass then runs the launch form, which needs 80).
@@ -1910,10 +1940,7 @@ static void follow_forget(const dfx_model *m) {   // dfx_model_free
 // Row count up to which the fan-out kernels take their few-rows forms (one row tile per wave, a tile's chunks dealt to separate waves): made
 // for a streaming hop (4096 rows).  Round 5: the time chunks of the persistent GRU phase (10-20 k rows at 16-24 chunks) take the large-launch
 // forms — at the old bound of 16384 rows every chunking finer than 15 chunks fell onto the hop's forms (15.1 vs 14.1 ms per step).
-static int64_t fan_few_rows() {
-    static const int64_t v = [] { const char *e = getenv("DFX_FAN_FEW_ROWS"); return e && atoll(e) > 0 ? (int64_t)atoll(e) : (int64_t)4096; }();
-    return v;
-}
+static int64_t fan_few_rows(const dfx_model *m) { return m->sw.fan_few_rows; }
 // df_fc_emb (+ e3) and the encoder GRU's linear_in in one pass over c1 (dfx_k_enc_fan)
 static int launch_enc_fan(const dfx_model *m, const float *c1, const float *e3, float *emb_out, float *xa, int64_t M, hipStream_t s, DfxRowMap rm) {
     DfxEncFanArgs A;
@@ -1927,7 +1954,7 @@ static int launch_enc_fan(const dfx_model *m, const float *c1, const float *e3, 
     A.ng = m->efan_groups;
     A.rm = rm;
     DfxKScope ks(DFX_K_GGEMM, s);
-    if (M > fan_few_rows()) {
+    if (M > fan_few_rows(m)) {
         constexpr int RT = 2;
         A.parts = 1;
         dfx_launch(dfx_k_enc_fan<RT>, dim3((unsigned)nn_grid(dfx_ceil_div(dfx_ceil_div(M, 16 * RT), 4), 8)), dim3(256), 0, s, A);
@@ -2002,7 +2029,7 @@ static int launch_emb_fan(const dfx_model *m, const float *y, const float *res, 
     A.rm = rm;
     // few rows (a streaming hop): one wave per (16 rows, super-chunk) instead of a wave walking all super-chunks — emb is then written out
     // (embv: 2 KB per row of a few thousand rows) and lsnr, the one consumer that needs all of a row's features, is a launch of its own
-    const bool split = M <= fan_few_rows() && lsnr && embv_for_split;
+    const bool split = M <= fan_few_rows(m) && lsnr && embv_for_split;
     if (split) {
         A.parts = A.nj;
         A.emb_out = embv_for_split;
@@ -2011,7 +2038,7 @@ static int launch_emb_fan(const dfx_model *m, const float *y, const float *res, 
     {
     DfxKScope ks(DFX_K_EMB_FAN, s);
     // (the kinds are what pack_fan accepted: dec_in narrow, dfg_in wide, df_skip narrow; a consumer that is not wanted drops out)
-    if (M > fan_few_rows()) {
+    if (M > fan_few_rows(m)) {
         constexpr int RT = 2;
         const dim3 grid((unsigned)nn_grid(dfx_ceil_div(dfx_ceil_div(M, 16 * RT), 4), 8));
         if (pub) A.pub = *pub, A.pub.nblocks = grid.x;
@@ -2296,13 +2323,13 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // round 4, after e0 / c1 / the grouped-GEMM df_out left the phase (lighter side work, shorter hand-overs), same-box A/B: 10 + ramp 32: 14.47;
         // 12 uniform chunks, no ramp: 14.12; 13: 14.17; 14: 14.14; 12 + ramp 48: 14.20; 15 + 48: 14.27; 16: 15.1 (chunks of < 16384 rows take the
         // small-launch forms of the fan-out kernels) -> 12 uniform chunks
-        static const int ramp0 = [] { const char *e = getenv("DFX_SEQ_RAMP"); return e ? atoi(e) : 0; }();
+        const int ramp0 = m->sw.ramp;
         // 16 chunks where the producers raise their flags themselves (DfxPublish: 17 launches per chunk), 12 where a one-thread launch does
         // (22 per chunk: the exact mode, DFX_SEQ_PUBLISH=0) — measured 13.24-13.28 (16) vs 13.37-13.49 (12) ms per step, measurements R5.10
-        static const int kenv = [] { const char *e = getenv("DFX_SEQ_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
-        static const bool kpub = [] { const char *e = getenv("DFX_SEQ_PUBLISH"); return !(e && e[0] == '0'); }();
+        const int kenv = m->sw.chunks;
+        const bool kpub = m->sw.publish;
         // (with followers only the encoder layer's projections and the decoder tails are still per chunk: 12 again, 12.98 vs 13.12 ms at 16)
-        const int kbody = kenv > 0 ? kenv : (kpub && !m->exact_fp32 && seq_follow_mode() <= 0 ? 16 : 12);
+        const int kbody = kenv > 0 ? kenv : (kpub && !m->exact_fp32 && seq_follow_mode(m) <= 0 ? 16 : 12);
         const int64_t body = std::max<int64_t>(dfx_ceil_div(T, (int64_t)kbody), m->tchunk_min);   // uniform chunk length: DFX_SEQ_CHUNKS=n gives n chunks (ceil: 1002 / 12 -> 84, not 83 and a 13th chunk)
         std::vector<int> sizes;
         int64_t left = T;
@@ -2483,8 +2510,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             // 13.48; in round 4, with the heavier tail, the same move measured as noise).  DFX_CONVP_LATE=p defers the last p percent (0: as before).
             // Exact mode with followers: in front of the phase, beside the (long) exact front — under the phase it starves the encoder layer's first
             // projections on the CUs the followers leave (25.9 vs 30.3 ms per step).
-            static const int late_env = [] { const char *e = getenv("DFX_CONVP_LATE"); const int v = e ? atoi(e) : -1; return v > 100 ? 100 : v; }();
-            const int late_pct = late_env >= 0 ? late_env : (m->exact_fp32 && seq_follow_mode() >= 2 ? 0 : 100);
+            const int late_env = m->sw.convp_late;
+            const int late_pct = late_env >= 0 ? late_env : (m->exact_fp32 && seq_follow_mode(m) >= 2 ? 0 : 100);
             convp_split = use_seq && late_pct > 0 ? T - (T - t_begin) * late_pct / 100 : T;
             if (convp_split > t_begin && (rc = convp_range(t_begin, convp_split, x2))) return rc;
             if (post_behind_convp && (rc = sc->df_post(x2))) return rc;
@@ -2612,15 +2639,15 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             unsigned int *pcnt = m->d_sync + 16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX;   // one completion counter per producing stream (layer), [8] = emb
             // a layer's input projection of chunk k, and ready[l] = chunk k + 1 behind it: raised by the projection kernel's last workgroup
             // (DfxPublish; DFX_SEQ_PUBLISH=0 or the exact mode: by a one-thread launch behind it, as before round 5)
-            static const bool publish = [] { const char *e = getenv("DFX_SEQ_PUBLISH"); return !(e && e[0] == '0'); }();
+            const bool publish = m->sw.publish;
             // Follower workgroups (dfx_k_proj_follow) feed the decoder layers in blocks of 16 steps instead of time chunks (seq_follow_mode; default 2:
             // all of them — a follower of the encoder GRU, dfx_k_emb_follow, runs dfx_k_emb_fan's arithmetic per block of 8 steps and the stacks' first
             // layers' projection followers read what it wrote; 1: only the layers whose input is the output of the layer below; 0: launches per chunk).
-            const int follow_env = seq_follow_mode();
+            const int follow_env = seq_follow_mode(m);
             unsigned int *yprog = pcnt + 16, *giprog = yprog + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX;
             unsigned int *embprog = yprog + (size_t)(DFX_MAX_GRU_LAYERS - 1) * DFX_SEQ_GMAX;   // (the row of a layer that cannot exist: nl < 8 below)
             // same-XCD hand-overs (DfxXcd; DFX_SEQ_XCD_LIGHT=0: every block hand-over with the agent-scope release / acquire)
-            static const bool xcd_light = [] { const char *e = getenv("DFX_SEQ_XCD_LIGHT"); return !(e && e[0] == '0'); }();
+            const bool xcd_light = m->sw.xcd_light;
             unsigned int *xtab = xcd_light ? giprog + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX : nullptr;
             unsigned int *xstat = xtab ? xtab + 3 * DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX : nullptr;
             const unsigned int xtag = (m->seq_pbase & 0x0fffffffu) << 4;
@@ -2762,7 +2789,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             // 0.3 ms shorter and the layers then wait as long for the inputs of their next chunks: 13.20-13.23 vs 13.21 ms, not kept)
             // With followers the encoder layer's first projections go out in front of it: on the CUs the followers leave, a kernel that is enqueued
             // behind df_convp waits for it (exact mode: 6.4 ms for the first chunk's projection).
-            static const int convp_order = [] { const char *e = getenv("DFX_CONVP_AFTER_P0"); return e ? atoi(e) : -1; }();
+            const int convp_order = m->sw.convp_after_p0;
             const bool convp_after_p0 = convp_order >= 0 ? convp_order != 0 : nfollow > 0;
             auto convp_late = [&]() -> int {
                 if (!(run_df && convp_split < T)) return DFX_OK;
@@ -2776,7 +2803,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 // (stays two chunks ahead of the recurrence instead of flooding the chip with all K projections while the decoders'
                 // first chunks are being prepared)
                 for (int k = 0; k < K; ++k) {
-                    static const int p0_ahead = [] { const char *e = getenv("DFX_SEQ_P0_AHEAD"); return e && atoi(e) > 0 ? atoi(e) : 3; }();
+                    const int p0_ahead = m->sw.p0_ahead;
                     if (k >= p0_ahead && (rc = launch_wait_ge(m, donep(0), groups, tgt(k - p0_ahead), Pq))) return rc;
                     if ((rc = proj_chunk(m->enc_gru[0], 0, k, xa, Pq))) return rc;
                     if (convp_after_p0 && k == (K < p0_ahead ? K : p0_ahead) - 1 && (rc = convp_late())) return rc;
@@ -2889,14 +2916,14 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                     if (j < ndec && (rc = prep_dec(j, k))) return rc;
                     if (j < ndf && (rc = prep_df(j, k))) return rc;
                 }
-                static const int tail_every = [] { const char *e = getenv("DFX_SEQ_TAIL_EVERY"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
+                const int tail_every = m->sw.tail_every;
                 if ((k + 1) % tail_every == 0 || k == K - 1) {
                     const int k0 = k - (k % tail_every);
                     if ((rc = erb_tail(k0, k))) return rc;
                 }
                 // the DF tail waits for ALL of df_convp, which — deferred under the phase, beside followers — ends with the phase: its launches then run
                 // behind the chain anyway, and few large ones are through sooner than twelve small ones (DFX_SEQ_DFTAIL_EVERY=n chunks per launch)
-                static const int dft_env = [] { const char *e = getenv("DFX_SEQ_DFTAIL_EVERY"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
+                const int dft_env = m->sw.dftail_every;
                 // (12.47-12.52 ms per step at 4 chunks per launch against 12.69-12.83 at 1, same box; 6: 12.49-12.57)
                 const int dft_every = dft_env > 0 ? dft_env : (nfollow > 0 && convp_split < T && tail_every < 4 ? 4 : tail_every);
                 if (run_df && ((k + 1) % dft_every == 0 || k == K - 1)) {

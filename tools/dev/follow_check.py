@@ -1,5 +1,6 @@
-"""Dev: the bits of enhance() at the bench size under the engine switches of the environment — one digest per call.
-    DFX_SEQ_FOLLOW=2 python tools/dev/follow_check.py [calls]     (compare the digests with those of a run without the switch)"""
+"""Dev: the bits of enhance() under the engine switches of the environment — one digest per call.
+    DFX_SEQ_FOLLOW=0 python tools/dev/follow_check.py [calls [clips [samples]]]     (compare the digests with those of a run without the switch;
+    default: the bench size, 256 clips x 480000 samples)"""
 import hashlib
 import os
 import sys
@@ -14,7 +15,9 @@ from deepfilternet_amd.state_dict import random_state_dict
 calls = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 p = ModelParams.deepfilternet3()
 model, df_state, _, _ = init_df(params=p, state_dict=random_state_dict(p, 0), epoch="none")
-x = synth_audio(256, 480000, 100, torch.device("cuda"))
+clips = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+samples = int(sys.argv[3]) if len(sys.argv) > 3 else 480000
+x = synth_audio(clips, samples, 100, torch.device("cuda"))
 digests = []
 for i in range(calls):
     y = enhance(model, df_state, x)
