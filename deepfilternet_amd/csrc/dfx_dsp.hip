@@ -582,7 +582,8 @@ int dfx_launch_synthesis_rows(const dfx_state *st, const float *spec, int64_t sp
     const int64_t want = dfx_ceil_div((int64_t)dfx_env_num_cus() * 3, B);
     int64_t segs = want < 1 ? 1 : want;
     if (segs > chunks / 4) segs = chunks / 4 > 0 ? chunks / 4 : 1;
-    static const int seg_env = [] { const char *e = getenv("DFX_SYN_SEGS"); return e ? atoi(e) : 0; }();   // dev: segments per row
+    const char *seg_e = getenv("DFX_SYN_SEGS");   // dev / variant test: segments per row (read per launch, like DFX_FFT_IN_PLACE)
+    const int seg_env = seg_e ? atoi(seg_e) : 0;
     if (seg_env > 0) segs = seg_env < chunks ? seg_env : chunks;
     A.seg_chunks = (int)dfx_ceil_div(chunks, segs);
     A.segs = (int)dfx_ceil_div(chunks, A.seg_chunks);
