@@ -450,6 +450,7 @@ struct dfx_model {
     // at config 2: 19.45 ms per step with free enqueue-ahead, 18.8 ms when the host holds the next step back (DF-apply inside the loop
     // 0.60 -> 0.50 ms, the rate it has alone).  DFX_ENQUEUE_AHEAD=1 restores the unthrottled enqueue.
     hipEvent_t ev_pass = nullptr;
+    hipEvent_t ev_gate = nullptr;       // recorded behind every multi-stream pass of this handle (PassTurn)
     mutable bool pass_pending = false;
     bool enqueue_ahead = false;
     bool concurrent = false;
@@ -1170,6 +1171,7 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
             // pipelining, off by default) are created on demand by dfx_model_set_pipeline.
             bool good = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) == hipSuccess;
             good = good && hipEventCreateWithFlags(&m->ev_pass, hipEventDisableTiming) == hipSuccess;
+            good = good && hipEventCreateWithFlags(&m->ev_gate, hipEventDisableTiming) == hipSuccess;
             {
                 const char *ea = getenv("DFX_ENQUEUE_AHEAD");
                 m->enqueue_ahead = ea && ea[0] == '1';
@@ -1201,7 +1203,7 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
     return DFX_OK;
 }
 
-static void follow_forget(const dfx_model *m);
+static void pass_gate_forget(const dfx_model *m);
 extern "C" void dfx_model_free(dfx_model *m) {
     if (!m) return;
     for (int l = 0; l < DFX_MAX_LANES; ++l) {
@@ -1226,8 +1228,9 @@ extern "C" void dfx_model_free(dfx_model *m) {
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_pass) (void)hipEventDestroy(m->ev_pass);
+    if (m->ev_gate) (void)hipEventDestroy(m->ev_gate);
     dfx_env_err_words_free(m->h_err);
-    follow_forget(m);
+    pass_gate_forget(m);
     if (m->d_sync && m->d_trace) {   // dev aid (DFX_SEQ_TRACE=1): how many block hand-overs of the followers took the same-XCD form
         unsigned int n = 0;
         const size_t off = 16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX + 16 + 2 * DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX + 3 * DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX;
@@ -1907,36 +1910,6 @@ static int launch_glin(const dfx_model *m, const GlinW &g, const float *a, int a
 // DFX_SEQ_FOLLOW (persistent GRU phase): 0 = every input projection a launch per time chunk; 1 = follower workgroups for the stacks' second layers;
 // 2 (default since the same-XCD hand-over, M§R5.12) = followers for every decoder layer + the emb fan-out; 3 = the first layers + emb only.
 static int seq_follow_mode(const dfx_model *m) { return m->sw.follow; }
-// Followers double the workgroups that must be resident at once (160 at batch 256).  Two model handles driven from two host threads could put two
-// such phases on the chip together, and then neither might fit: a pass takes followers only if no OTHER handle's follower pass can still be running
-// (checked and claimed under a process-wide lock; the other handle's pass then runs the launch form, which needs 80).
-struct FollowGuard {
-    std::mutex mu;
-    const dfx_model *owner = nullptr;
-    hipEvent_t done = nullptr;   // recorded behind the owner's last follower pass (the owner's event)
-    bool pending = false;        // the owner is between claiming and recording
-};
-static FollowGuard &follow_guard() {
-    static FollowGuard g;
-    return g;
-}
-static bool follow_claim(const dfx_model *m) {
-    FollowGuard &g = follow_guard();
-    std::lock_guard<std::mutex> lk(g.mu);
-    if (g.owner && g.owner != m && (g.pending || (g.done && hipEventQuery(g.done) == hipErrorNotReady))) return false;
-    g.owner = m, g.pending = true, g.done = nullptr;
-    return true;
-}
-static void follow_recorded(const dfx_model *m, hipEvent_t ev) {
-    FollowGuard &g = follow_guard();
-    std::lock_guard<std::mutex> lk(g.mu);
-    if (g.owner == m) g.done = ev, g.pending = false;
-}
-static void follow_forget(const dfx_model *m) {   // dfx_model_free
-    FollowGuard &g = follow_guard();
-    std::lock_guard<std::mutex> lk(g.mu);
-    if (g.owner == m) g.owner = nullptr, g.done = nullptr, g.pending = false;
-}
 // Row count up to which the fan-out kernels take their few-rows forms (one row tile per wave, a tile's chunks dealt to separate waves): made
 // for a streaming hop (4096 rows).  Round 5: the time chunks of the persistent GRU phase (10-20 k rows at 16-24 chunks) take the large-launch
 // forms — at the old bound of 16384 rows every chunking finer than 15 chunks fell onto the hop's forms (15.1 vs 14.1 ms per step).
@@ -2663,7 +2636,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                     const bool first = l == 1 || l == lfirst_df;   // a stack's first layer reads a grouped linear of emb, the others the layer below
                     if (first ? follow_emb : follow_env != 3) followed[l] = true, ++nfollow;   // (3: the first layers only)
                 }
-                if (nfollow > DFX_PF_MAX || (nl + nfollow + 1) * groups > dfx_env_num_cus() * 3 / 4 || (nfollow && !follow_claim(m))) {   // all of them or none (every workgroup must be resident)
+                if (nfollow > DFX_PF_MAX || (nl + nfollow + 1) * groups > dfx_env_num_cus() * 3 / 4) {   // all of them or none (every workgroup must be resident; passes of other handles never overlap this one: PassTurn)
                     nfollow = 0;
                     for (int l = 0; l < nl; ++l) followed[l] = false;
                 }
@@ -2948,10 +2921,6 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 DFX_HIP(hipEventRecord(ln->pev[l][0], ln->ps[l]));
                 DFX_HIP(hipStreamWaitEvent(s, ln->pev[l][0], 0));
             }
-            if (nfollow) {   // every persistent workgroup of this pass is over when s gets here
-                DFX_HIP(hipEventRecord(ln->gev[0][1], s));
-                follow_recorded(m, ln->gev[0][1]);
-            }
         } else {
         auto gru_chunk = [&](const GruW &g, int l, int k, hipStream_t st) -> int {
             float *hl = ws + w.ph[l];
@@ -3154,6 +3123,39 @@ static int model_forward_lane(const dfx_model *m, const dfx_bands *bands, const 
     DFX_FAIL(DFX_ERR_UNSUPPORTED, "conv_ch");
 }
 
+// One handle's pass at a time.  Two model handles driven from two host threads used to overlap their multi-stream passes on the GPU, and the
+// samples of a few clips came out wrong now and then — in every form of the GRU phase, also the round-4 one (tools/dev/two_handles.py; an
+// unrelated kernel stream beside ONE handle is harmless: tools/dev/one_handle_noise.py).  Overlap buys nothing (one pass fills the chip), so the
+// passes take turns: the host enqueues one handle's pass at a time (a process-wide lock held for the enqueue), and a pass starts on the device
+// when the other handle's last pass is through (a stream wait on its event; the same handle's passes are ordered by its caller's stream and
+// ev_pass as before).  The frame-by-frame streaming calls are not part of this.
+struct PassGate {
+    std::mutex mu;
+    const dfx_model *owner = nullptr;
+    hipEvent_t done = nullptr;   // the owner's ev_gate, recorded behind its last pass
+};
+static PassGate &pass_gate() {
+    static PassGate g;
+    return g;
+}
+struct PassTurn {
+    std::unique_lock<std::mutex> lk;
+    PassTurn(const dfx_model *m, hipStream_t s) {
+        if (!m->concurrent || !m->ev_gate) return;
+        PassGate &g = pass_gate();
+        lk = std::unique_lock<std::mutex>(g.mu);
+        if (g.owner && g.owner != m && g.done) (void)hipStreamWaitEvent(s, g.done, 0);
+    }
+    void passed(const dfx_model *m, hipStream_t s) {   // the pass is enqueued and joined into s
+        if (!lk.owns_lock()) return;
+        if (hipEventRecord(m->ev_gate, s) == hipSuccess) pass_gate().owner = m, pass_gate().done = m->ev_gate;
+    }
+};
+static void pass_gate_forget(const dfx_model *m) {
+    PassGate &g = pass_gate();
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (g.owner == m) g.owner = nullptr, g.done = nullptr;
+}
 // Enqueue throttle of the multi-stream pass (see dfx_model::ev_pass): big passes only — a small pass is over before the host has
 // enqueued the next one, and holding the host back would serialise its launch overhead with the device's work.
 static int pass_begin(const dfx_model *m, int64_t frames) {
@@ -3181,9 +3183,11 @@ extern "C" int dfx_model_forward(const dfx_model *m, const dfx_bands *bands, con
                                  void *stream) {
     if (!m) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_forward: bad arguments");
     if (int rc = pass_begin(m, B * T)) return rc;
+    PassTurn turn(m, dfx_stream(stream));
     if (int rc = model_forward_lane(m, bands, spec, feat_erb, feat_spec, B, T, atten_lim, spec_e, mask, lsnr, df_coefs, workspace,
                                     workspace_bytes, stream, &m->lanes[0], false))
         return rc;
+    turn.passed(m, dfx_stream(stream));
     return pass_end(m, B * T, dfx_stream(stream));
 }
 
@@ -4125,8 +4129,10 @@ static int enhance_any(const dfx_model *m, const dfx_state *st, const float *x, 
         if (lim >= 1.f) lim = 0.99999994f;              // |dB| tiny: the reference mixes with lim == 1.0f (the noisy signal passes)
     }
     if (int rc = pass_begin(m, B * Tf)) return rc;
+    PassTurn turn(m, s);
     if (nc == 1) {
         if (int rc = enhance_chunk(m, st, x, B, T, pad, lim, y, base, s, &m->lanes[0], false, pcm16)) return rc;
+        turn.passed(m, s);
         return pass_end(m, B * Tf, s);
     }
     // ---- pipelined chunks: fork from the caller's stream, stagger the fronts, join back
@@ -4145,6 +4151,7 @@ static int enhance_any(const dfx_model *m, const dfx_state *st, const float *x, 
         row += sizes[i];
     }
     for (int i = 0; i < nc; ++i) DFX_HIP(hipStreamWaitEvent(s, m->lanes[i].ev[EV_DONE], 0));
+    turn.passed(m, s);
     return pass_end(m, B * Tf, s);
 }
 extern "C" int dfx_enhance(const dfx_model *m, const dfx_state *st, const float *x, int64_t B, int64_t T, int pad,

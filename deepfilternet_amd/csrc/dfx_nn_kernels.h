@@ -2973,6 +2973,7 @@ struct DfxPublish {
 };
 static __device__ __forceinline__ void dfx_publish(const DfxPublish &P) {
     if (!P.cnt) return;
+    DFX_VMEM_DRAIN();  // (s_barrier does not wait for the other waves' stores: each wave drains its own in front of it)
     __syncthreads();   // the workgroup's stores happen before thread 0's release below (one L2 write-back per workgroup; a release fence in
                        // every thread in front of the barrier is one per WAVE and costs the step 1.6 ms, measurements R5.10)
     if (threadIdx.x == 0) {
@@ -3599,8 +3600,12 @@ __global__ void __launch_bounds__(512, 1) dfx_k_emb_follow(DfxFanArgs A, DfxFoll
         const int ntile = (int)((A.R + 15) / 16);
         for (int tile = wave; tile < ntile; tile += 8) dfx_emb_fan_item<1, K0, K1, K2>(A, tile, 0, A.nj);
         DFX_VMEM_DRAIN();
-        __syncthreads();   // the block's rows are stored, and have reached the L2
-        if (tid == 0) dfx_xcd_release(X, Y.dst + g, Y.pbase + (unsigned int)t1);
+        __syncthreads();   // the block's rows are stored (every wave's stores acknowledged: the barrier alone does not wait for them)
+        // ALWAYS the agent-scope release here: dec_in / dfg_in only go to this XCD's projection followers, but df_skip, emb and lsnr are read by
+        // kernels anywhere on the chip (the DF tail, the decoder tails) while this kernel is still running — they must leave this XCD's L2.
+        // (Those readers are ordered behind a recurrence's chunk flag, whose release writes back the RECURRENCE's L2: the same one only as long as
+        // nothing else disturbs the round-robin dispatch — two handles at once gave wrong samples with the light form here.)
+        if (tid == 0) __hip_atomic_store(Y.dst + g, Y.pbase + (unsigned int)t1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
