@@ -31,7 +31,7 @@ nl, ng, K = dims[0], dims[1], dims[2]
 t = buf[: nl * ng * K * 3].reshape(nl, ng, K, 3).astype(np.float64) / 100.0   # microseconds
 t0 = t[..., 0].min()
 t -= t0
-def bounds(T=1002, K0=int(os.environ.get("DFX_SEQ_CHUNKS", "16")), ramp0=int(os.environ.get("DFX_SEQ_RAMP", "0"))):
+def bounds(T=1002, K0=int(os.environ.get("DFX_SEQ_CHUNKS", "16" if os.environ.get("DFX_SEQ_FOLLOW", "2") == "0" else "12")), ramp0=int(os.environ.get("DFX_SEQ_RAMP", "0"))):
     body, sizes, down, left = max(-(-T // K0), 32), [], [], T
     r = ramp0
     while ramp0 > 0 and r < body and left > 4 * body:
