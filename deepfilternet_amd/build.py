@@ -14,6 +14,7 @@ REPO = os.path.dirname(HERE)
 LIB = os.path.join(CSRC, "libdfx.so")
 SOURCES = ["dfx_dsp.hip", "dfx_model.hip", "dfx_capi.hip", "dfx_io.hip", "dfx_mf.hip", "dfx_onnx.hip"]
 ARCH = "gfx950"
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def _hipcc() -> str:
@@ -33,6 +34,7 @@ def _deps() -> List[str]:
         out += [os.path.join(root, f) for f in files if f.endswith((".h", ".hip"))]
     out.append(os.path.join(REPO, "include", "dfx.h"))
     out.append(os.path.join(REPO, "include", "df_capi.h"))
+    out.append(os.path.abspath(__file__))   # the compiler flags live here
     return out
 
 
@@ -60,8 +62,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # -amdgpu-mfma-vgpr-form: matrix-op results in VGPRs instead of AGPRs where registers allow (the epilogues read every accumulator on
     # the VALU: one v_accvgpr_read per value otherwise — 682 of the 4344 instructions of df_convp, 20 % of the persistent GRU kernel's);
     # measured -0.1 ms per step
+    # -target-feature -packed-fp32-ops (round 6): no v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32 anywhere in the library.  On the
+    # MI355X of this pool a wave's packed fp32 operations with operand swizzles (op_sel: what complex arithmetic compiles to) return wrong
+    # values for groups of 16 lanes while ANOTHER wave on the same SIMD — any kernel, any process — executes the double-rate matrix
+    # operations (v_mfma_f32_16x16x32_f16 / _bf16, v_mfma_f32_32x32x16_f16).  That was the "two handles return wrong samples" failure of
+    # round 5: one handle's STFT kernels beside the other handle's fp16-split kernels; rocFFT is hit the same way (tools/dev/xkern_probe.hip,
+    # docs/measurements.md R6.1).  The scalar forms are as fast here (analysis 0.48 -> 0.45 ms) and tests/test_isa.py keeps the packed ones out.
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
-             f"-I{os.path.join(REPO, 'include')}", f"-I{os.path.join(CSRC, 'env_hip')}", f"-I{CSRC}"]
+             *NO_PACKED_FP32, f"-I{os.path.join(REPO, 'include')}", f"-I{os.path.join(CSRC, 'env_hip')}", f"-I{CSRC}"]
     objs = []
     procs = []
     for src in sources():

@@ -392,6 +392,8 @@ static bool fft_mfma(const dfx_state *st) {
     return st->d_mfft && e && e[0] == '1';
 }
 static size_t ana_smem_bytes(const dfx_state *st, bool mf = false) {
+    static const bool whole_cu = [] { const char *e = getenv("DFX_DEV_STFT_WHOLE_CU"); return e && e[0] == '1'; }();   // dev (round 6): no other workgroup beside an STFT workgroup
+    if (whole_cu) return (size_t)160 * 1024;
     return (mf ? (size_t)DFX_MFFT_FRAG3 * 64 * 16 : 0) + (size_t)st->N * 12 + (size_t)DFX_DSP_TEAMS * (ana_in_place(st) ? (size_t)DFX_FFT480_BUF : 2 * (size_t)(st->plan.M + 2)) * 8 +   // (in place: one buffer per frame, with room for the transform's padded layout)
            (((size_t)(2 * st->nb + 1 + 3 * 64 + st->nb + 1 + DFX_DSP_TEAMS * 64) * 4 + 15) & ~(size_t)15);   // + the ERB band tables and segment sums (analysis)
 }

@@ -2147,6 +2147,24 @@ static int run_gru_stack(const dfx_model *m, const std::vector<GruW> &layers, co
 static int stream_copy_rows(const float *src, int64_t src_stride, int64_t src_len, int64_t src_off, float *dst, int64_t dst_stride,
                             int64_t dst_len, int64_t B, hipStream_t s);
 
+// Work-skipping ablations exist only in dev builds (tools/dev/build_variant.sh <tag> -DDFX_DEV): the product library has no switch that leaves
+// work out of a pass.  DFX_DEV_SKIP=bits: no ERB tail (1), DF tail (2), projections of layers > 0 (4), df_convp (8) — timing only, results
+// invalid.  DFX_DEV_STAGE_LO / _HI: only the stages [lo, hi] of the serial forward (DFX_STREAMS=0) are enqueued (which kernel disturbs a neighbour).
+#ifdef DFX_DEV
+static int dfx_dev_skip() {
+    static const int v = [] { const char *e = getenv("DFX_DEV_SKIP"); return e ? atoi(e) : 0; }();
+    return v;
+}
+static bool dfx_dev_stage(int n) {
+    static const int lo = [] { const char *e = getenv("DFX_DEV_STAGE_LO"); return e ? atoi(e) : 0; }();
+    static const int hi = [] { const char *e = getenv("DFX_DEV_STAGE_HI"); return e ? atoi(e) : 99; }();
+    return n >= lo && n <= hi;
+}
+#else
+static constexpr int dfx_dev_skip() { return 0; }
+static constexpr bool dfx_dev_stage(int) { return true; }
+#endif
+
 template <int C>
 static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float *spec, const float *feat_erb,
                         const float *feat_spec, int64_t B, int64_t T, float atten_lim, float *spec_e, float *mask_out,
@@ -2325,8 +2343,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     };
     // df_dec.df_convp of frames [t0, t1) (only needs c0 / feat_spec; :328)
     auto convp_range = [&](int64_t t0, int64_t t1, hipStream_t st) -> int {
-        static const int dev_skip_cp = [] { const char *e = getenv("DFX_DEV_SKIP"); return e ? atoi(e) : 0; }();   // dev timing ablation (results invalid)
-        if (dev_skip_cp & 8) return DFX_OK;
+        if (dfx_dev_skip() & 8) return DFX_OK;
         if (gate && kt > 1 && gate->pend2 && fuse_h3 && t1 - t0 == 1 && t1 == T) {   // gated, fp16-split: pending sums, two halves per stream
             switch (kt) {
                 case 2: return launch_convp_step<C, 2>(m, feat_spec, c0p, B, T, Fd, NO, st, t_zero, Lk, gate->pend2, 0, false, featT, gate->par, gate->cnt);
@@ -2452,7 +2469,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     {   // ---- the front: the frames [t_begin, T) that this pass computes
         if (fuse_c0) {
             if ((rc = signal(EV_C0, x1)) || (rc = wait(EV_C0, x2))) return rc;  // df_convp only needs feat_spec
-            if (!dfenc && (rc = df1_range(t_begin, T, x1))) return rc;
+            if (!dfenc && dfx_dev_stage(3) && (rc = df1_range(t_begin, T, x1))) return rc;
         } else {
             DfxCinArgs A;
             A.feat = feat_spec;
@@ -2486,17 +2503,17 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             const int late_env = m->sw.convp_late;
             const int late_pct = late_env >= 0 ? late_env : (m->exact_fp32 && seq_follow_mode(m) >= 2 ? 0 : 100);
             convp_split = use_seq && late_pct > 0 ? T - (T - t_begin) * late_pct / 100 : T;
-            if (convp_split > t_begin && (rc = convp_range(t_begin, convp_split, x2))) return rc;
+            if (convp_split > t_begin && dfx_dev_stage(1) && (rc = convp_range(t_begin, convp_split, x2))) return rc;
             if (post_behind_convp && (rc = sc->df_post(x2))) return rc;
             if (convp_split >= T && (rc = signal(EV_C0P, x2))) return rc;
         }
         // (Round 5, timing only: the fused DF encoder on x1 BESIDE the ERB convolutions, its e3 dependency ignored — one VALU-bound, the others
         // HBM-bound — 13.68 / 13.71 vs 13.36 / 13.31 ms per step: slower; the encoder stays behind them.)
-        if ((rc = erb_range(t_begin, T, Rn, rmw, s))) return rc;
+        if (dfx_dev_stage(2) && (rc = erb_range(t_begin, T, Rn, rmw, s))) return rc;
         if ((rc = wait(EV_C1, s))) return rc;
         if (dfenc) {
-            if ((rc = launch_df_enc<C>(m, feat_spec, e3, c.emb_gru_skip_enc != DFX_SKIP_NONE ? emb_in : nullptr, xa, B, T, Fd, s, t_begin, Lk, T, featT))) return rc;
-        } else if ((rc = emb_range(Rn, rmw, s))) return rc;
+            if (dfx_dev_stage(3) && (rc = launch_df_enc<C>(m, feat_spec, e3, c.emb_gru_skip_enc != DFX_SKIP_NONE ? emb_in : nullptr, xa, B, T, Fd, s, t_begin, Lk, T, featT))) return rc;
+        } else if (dfx_dev_stage(3) && (rc = emb_range(Rn, rmw, s))) return rc;
         // the chip-filling front of this chunk is enqueued: the next chunk of a pipelined dfx_enhance may start its own front
         // (it then overlaps this chunk's GRU chain, which occupies only a few CUs)
         if (signal_front && (rc = signal(EV_FRONT, s))) return rc;
@@ -2507,11 +2524,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     float *hn_enc = sc && sc->h_next ? sc->h_next : nullptr, *hn_dec = hn_enc ? hn_enc + (int64_t)nenc * B * 256 : nullptr;
     float *hn_df = hn_enc ? hn_enc + (int64_t)(nenc + ndec) * B * 256 : nullptr;
     if (!pipe) {
-        const float *y = nullptr;
-        if ((rc = run_gru_stack(m, m->enc_gru, xa, xa, xb, gi, B, T, &y, s, hs_enc, t_begin, rmw, hn_enc))) return rc;
+        const float *y = xa;
+        if (dfx_dev_stage(4) && (rc = run_gru_stack(m, m->enc_gru, xa, xa, xb, gi, B, T, &y, s, hs_enc, t_begin, rmw, hn_enc))) return rc;
         float *dec_x = y == xa ? xb : xa;   // input of the ERB decoder's GRU stack
         if (fan) {
-            if ((rc = emb_fan(y, dec_x, Rn, s, rmw))) return rc;
+            if (dfx_dev_stage(5) && (rc = emb_fan(y, dec_x, Rn, s, rmw))) return rc;
             if ((rc = signal(EV_EMB, s)) || (rc = wait(EV_EMB, x1))) return rc;
         } else {
             if ((rc = enc_out_skip(y, Rn, s, rmw))) return rc;
@@ -2529,7 +2546,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             DFX_LAUNCH_CHECK();
         }
         // ---- DfDecoder on x1 (:323-331)
-        if (run_df) {
+        if (run_df && dfx_dev_stage(6)) {
             const float *y2 = nullptr;
             if (!fan && (rc = launch_glin(m, m->dfg_in, embv, DFX_ACT_RELU, nullptr, xa2, Rn, x1, rmw))) return rc;
             if ((rc = run_gru_stack(m, m->df_gru, xa2, xa2, xb2, gi2, B, T, &y2, x1, hs_df, t_begin, rmw, hn_df, par))) return rc;
@@ -2555,10 +2572,10 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         }
         // ---- ErbDecoder on s (:245-254)
         if (!fan && (rc = launch_glin(m, m->dec_in, embv, DFX_ACT_RELU, nullptr, dec_x, Rn, s, rmw))) return rc;
-        if ((rc = run_gru_stack(m, m->dec_gru, dec_x, xa, xb, gi, B, T, &y, s, hs_dec, t_begin, rmw, hn_dec, par && run_df))) return rc;
-        if ((rc = dec_out_skip(y, Rn, s, rmw))) return rc;
+        if (dfx_dev_stage(7) && (rc = run_gru_stack(m, m->dec_gru, dec_x, xa, xb, gi, B, T, &y, s, hs_dec, t_begin, rmw, hn_dec, par && run_df))) return rc;
+        if (dfx_dev_stage(8) && (rc = dec_out_skip(y, Rn, s, rmw))) return rc;
         if (fuse_tail) {
-            if ((rc = launch_erb_tail<C>(m, demb, e3, e2, e1, e0r, mask, Rn, E, s, rmw, feat_erb, T, featT, Lk))) return rc;
+            if (dfx_dev_stage(9) && (rc = launch_erb_tail<C>(m, demb, e3, e2, e1, e0r, mask, Rn, E, s, rmw, feat_erb, T, featT, Lk))) return rc;
         } else if ((rc = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, Rn, E / 4, E / 4, 1, s, rmw)) ||
                    (rc = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, Rn, E / 4, E / 2, 2, s, rmw))) {
             return rc;
@@ -2591,8 +2608,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
         // signals gev[l][k].  Two tail streams consume the last layers' chunks (linear_out / skip / df_out) and then run the
         // rest of their decoder.  The latency chain is therefore K+2 recurrence chunks and nothing else.
         auto proj_chunk = [&](const GruW &g, int l, int k, const float *xin, hipStream_t st) -> int {
-            static const int dev_skip3 = [] { const char *e = getenv("DFX_DEV_SKIP"); return e ? atoi(e) : 0; }();
-            if ((dev_skip3 & 4) && l > 0) return DFX_OK;  // dev timing ablation: no input projections for layers > 0
+            if ((dfx_dev_skip() & 4) && l > 0) return DFX_OK;
             if (m->exact_fp32) return launch_proj(xin, m->p(g.wih_t), m->p(g.bias_i), ws + w.pgi[l], Mk(k), 768, st, rmk(k));
             return launch_proj_h3(m, g, xin, ws + w.pgi[l], Mk(k), 768, st, rmk(k));
         };
@@ -2655,7 +2671,6 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             };
             // (Finishing — deep filter + ISTFT — per time chunk behind the DF tail was built here and in the event-based form and measured:
             // 21.7 vs 20.2 ms per step; the chunks' traffic beside the chain costs more than the 1.2 ms it takes off the end.)
-            static const int dev_skip_seq = [] { const char *e = getenv("DFX_DEV_SKIP"); return e ? atoi(e) : 0; }();   // dev timing ablations (results invalid)
             auto donep = [&](int l) { return done + (size_t)l * DFX_SEQ_GMAX; };
             auto tgt = [&](int k) { return base + (unsigned int)k + 1u; };
             hipStream_t G = ln->gs[1], Eq = ln->ts[0], Dq = ln->ts[1], Pq = ln->ps[0];
@@ -2826,7 +2841,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 const DfxRowMap rm = DfxRowMap{T, tb(k + 1) - tb(k0), tb(k0)};
                 int r;
                 if ((r = launch_wait_ge(m, donep(ndec), groups, tgt(k), Eq))) return r;
-                if (dev_skip_seq & 1) return DFX_OK;
+                if (dfx_dev_skip() & 1) return DFX_OK;
                 if ((r = dec_out_skip(ws + w.py[ndec], Rk, Eq, rm))) return r;
                 if (fuse_tail) return launch_erb_tail<C>(m, demb, e3, e2, e1, e0r, mask, Rk, E, Eq, rm, feat_erb, T, featT, Lk);
                 if ((r = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, Rk, E / 4, E / 4, 1, Eq, rm))) return r;
@@ -2862,7 +2877,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 const DfxRowMap rm = DfxRowMap{T, tb(k + 1) - tb(k0), tb(k0)};
                 int r;
                 if ((r = launch_wait_ge(m, donep(l), groups, tgt(k), Dq))) return r;
-                if (dev_skip_seq & 2) return DFX_OK;
+                if (dfx_dev_skip() & 2) return DFX_OK;
                 if (c.df_gru_skip == DFX_SKIP_IDENTITY) {
                     if (k < K - 1) return DFX_OK;   // the identity-skip form is not chunked: one add + df_out over all frames at the end
                     {
@@ -2967,12 +2982,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             hipStream_t st = ln->ts[0];
             const int fpt = 64 / E > 0 ? 64 / E : 1;
             const size_t smem = ((size_t)fpt * E * (C + 1) + (size_t)fpt * E * 3 + 3 * C) * sizeof(float);
-            static const int dev_skip = [] { const char *e = getenv("DFX_DEV_SKIP"); return e ? atoi(e) : 0; }();
             for (int k = 0; k < K; ++k) {
                 const int64_t Rk = Mk(k);
                 const DfxRowMap rm = rmk(k);
                 if ((rc = ewait(ln->gev[ndec][k], st))) return rc;
-                if (dev_skip & 1) continue;
+                if (dfx_dev_skip() & 1) continue;
                 if ((rc = dec_out_skip(ws + w.py[ndec], Rk, st, rm))) return rc;
                 if (fuse_tail) {
                     if ((rc = launch_erb_tail<C>(m, demb, e3, e2, e1, e0r, mask, Rk, E, st, rm, feat_erb, T, featT, Lk))) return rc;
@@ -3014,10 +3028,9 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             const int l = ndec + ndf;
             if ((rc = wait(EV_C0P, st))) return rc;
             if (c.df_gru_skip != DFX_SKIP_IDENTITY) {
-                static const int dev_skip2 = [] { const char *e = getenv("DFX_DEV_SKIP"); return e ? atoi(e) : 0; }();
                 for (int k = 0; k < K; ++k) {
                     if ((rc = ewait(ln->gev[l][k], st))) return rc;
-                    if (dev_skip2 & 2) continue;
+                    if (dfx_dev_skip() & 2) continue;
                     const float *cfeat = ws + w.py[l], *cfeat2 = nullptr;
                     if (fan_skp) {
                         cfeat2 = xdf;
@@ -3086,7 +3099,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                                             c.mask_pf ? c.pf_beta : 0.f, atten_lim, B, T, fin->y, fin->out_stride, fin->out_skip, fin->out_len, fin_s, fin->out_i16)))
             return rc;
     } else {
-        if ((rc = dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, run_df ? Fd : 0, O, c.df_lookahead,
+        if (dfx_dev_stage(10) && (rc = dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, run_df ? Fd : 0, O, c.df_lookahead,
                                       c.mask_pf ? c.pf_beta : 0.f, atten_lim, spec_e, fin_s, 0, -1, -1, -1, 0, sstride, sstride)))
             return rc;
         if (fin && (rc = dfx_launch_synthesis(fin->st, spec_e, B, T, nullptr, nullptr, fin->y, fin->out_stride, fin->out_skip, fin->out_len,
@@ -3142,6 +3155,8 @@ struct PassTurn {
     std::unique_lock<std::mutex> lk;
     PassTurn(const dfx_model *m, hipStream_t s) {
         if (!m->concurrent || !m->ev_gate) return;
+        static const bool off = [] { const char *e = getenv("DFX_PASS_TURN"); return e && e[0] == '0'; }();   // dev: two_handles_diag.py
+        if (off) return;
         PassGate &g = pass_gate();
         lk = std::unique_lock<std::mutex>(g.mu);
         if (g.owner && g.owner != m && g.done) (void)hipStreamWaitEvent(s, g.done, 0);

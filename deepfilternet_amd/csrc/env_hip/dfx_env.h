@@ -145,12 +145,22 @@ static __device__ __forceinline__ f32x4 dfx_mfma_16x16x32_f16(dfx_h8 a, dfx_h8 b
 #define DFX_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)   /* ask for n instructions of a class next (0x008 MFMA, 0x002 VALU) */
 // barrier + LDS visibility among the 64 lanes of ONE wave (LDS operations of a wave complete in order; the fences only pin the
 // compiler's ordering) — costs nothing compared with s_barrier across the workgroup
+#ifdef DFX_WAVE_SYNC_WAIT   /* dev (round 6): the wave's LDS operations have completed before it goes on */
+#define DFX_WAVE_SYNC()                                          \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+        __builtin_amdgcn_wave_barrier();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+    } while (0)
+#else
 #define DFX_WAVE_SYNC()                                          \
     do {                                                         \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
         __builtin_amdgcn_wave_barrier();                         \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
     } while (0)
+#endif
 
 static __device__ __forceinline__ float dfx_fast_exp(float x) { return __expf(x); }
 // v_rcp_f32: one instruction, 1 ulp.  (__frcp_rn — the correctly rounded reciprocal — is a ten-instruction sequence: v_div_scale, v_rcp,

@@ -10,6 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(REPO, "deepfilternet_amd", "csrc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+         "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",   # (the product flags: deepfilternet_amd/build.py)
          "-I" + os.path.join(REPO, "include"), "-I" + os.path.join(CSRC, "env_hip"), "-I" + CSRC, "-Rpass-analysis=kernel-resource-usage",
          "--cuda-device-only", "-c", "-o", "/dev/null"]
 
