@@ -83,7 +83,7 @@ def macs_per_frame(p) -> dict:
     return m
 
 
-def cpu_baseline(p, sd, clips: int, seconds: float) -> dict:
+def cpu_baseline(p, sd, clips: int, seconds: float, keep=None) -> dict:
     """The oracle's enhance() (C port of libDF, sequential over channels like pyDF, + torch-CPU DeepFilterNet3) on a bounded
     sample of the same workload."""
     from oracle import dfnet_oracle as O
@@ -96,6 +96,8 @@ def cpu_baseline(p, sd, clips: int, seconds: float) -> dict:
     y = O.enhance(p, sdt, x)
     dt = time.perf_counter() - t0
     assert y.shape == x.shape
+    if keep is not None:   # the sample and the oracle's samples: the line's `parity` compares the engine with them
+        keep["x"], keep["y"] = x, y
     frames = clips * (T // HOP)
     return {"value": frames / dt, "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
             "sample": f"{clips} clips x {seconds:g} s ({frames} frames, {dt:.2f} s wall): oracle/ C port of libDF "
@@ -139,6 +141,13 @@ def main() -> None:
 
         init_world("nccl", world, rank, dev)
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        # one process per GPU, checked on what the ranks really hold (a launcher that did not apply LOCAL_RANK puts every rank on device 0)
+        from deepfilternet_amd.distributed import check_distinct_devices, gather_device_ids
+
+        try:
+            check_distinct_devices(gather_device_ids(dev))
+        except WorldError as e:
+            raise SystemExit(f"bench.py: {e}")
 
     from deepfilternet_amd import _lib
     from deepfilternet_amd.config import ModelParams
@@ -234,6 +243,30 @@ def main() -> None:
         dt2 = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
         dist.all_reduce(dt2, op=dist.ReduceOp.MAX)
         no_gather_ms = float(dt2.item()) / args.steps * 1e3
+    # ---- multi-GPU, the consumer is the host: no collective at all, every rank copies its own slice to page-locked host memory on
+    # its stream (overlapping the next step like the gather does)
+    host_consumer_ms = None
+    if world > 1:
+        hp = [None, None]
+        for i in range(2 + args.steps):
+            if i == 2:
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+            k = i & 1
+            if hp[k] is not None:
+                hp[k].wait()
+            hp[k] = enhance_sharded(model, df_state, x, presharded=True, counts=[B] * world, gather="host")
+        for h in hp:
+            if h is not None:
+                h.wait()
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt3 = torch.tensor([time.perf_counter() - t2], device=dev, dtype=torch.float64)
+        dist.all_reduce(dt3, op=dist.ReduceOp.MAX)
+        host_consumer_ms = float(dt3.item()) / args.steps * 1e3
+        del hp
 
     if rank != 0:
         if dist is not None:
@@ -433,6 +466,31 @@ def main() -> None:
     if extras:
         host_io = "pending"   # run below in a process of its own (this one has created three model handles and ~40 streams by then)
 
+    # ---- the CPU baseline (the oracle on a bounded sample) and, on the same clips, the parity of the timed handle
+    cpu, parity = None, None
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            keep = {}
+            cpu = cpu_baseline(p, sd, args.cpu_clips, args.seconds, keep)
+            # parity in the run that is timed: the engine (the timed handle, the timed arithmetic) on the clips the oracle has just enhanced.
+            # The bar of the north star is 1e-4 RMS on the waveform; the reference's own habit is a quality pin beside every run (df/scripts/test_df.py:67-77).
+            yo = torch.from_numpy(keep["y"])
+            yh = enhance(model, df_state, torch.from_numpy(keep["x"]).to(dev)).cpu()
+            model.check()
+            d = (yh - yo).double()
+            row = d.pow(2).mean(dim=1).sqrt()
+            parity = {"rms": float(d.pow(2).mean().sqrt()), "max_row_rms": float(row.max()), "max_abs": float(d.abs().max()),
+                      "signal_rms": float(yo.double().pow(2).mean().sqrt()), "clips": int(yo.shape[0]), "bar": 1e-4,
+                      "against": "oracle/ (C port of libDF + torch-fp32 DfNet3) on the cpu_baseline sample, the timed handle and arithmetic"}
+            if not parity["rms"] < 1e-4:
+                raise SystemExit(f"bench.py: parity {parity['rms']:.3e} RMS against the oracle (bar 1e-4): the timed numbers would be meaningless")
+        except SystemExit:
+            raise
+        except Exception as e:  # noqa: BLE001
+            cpu = cpu if cpu is not None else {"error": repr(e)}
+            parity = {"error": repr(e)}
+
+
     # ---- BASELINE.json configs[3] and configs[4] (the batch model's streams are released first: a process with more streams than
     # hardware queues makes them share queues, which serialises the streaming runtime's three branches)
     import gc
@@ -493,13 +551,6 @@ def main() -> None:
         configs["df_apply_o10"] = cfg_o10
     torch.cuda.empty_cache()
 
-    cpu = None
-    if world == 1 and not args.no_cpu_baseline:
-        try:
-            cpu = cpu_baseline(p, sd, args.cpu_clips, args.seconds)
-        except Exception as e:  # noqa: BLE001
-            cpu = {"error": repr(e)}
-
     frames = world * B * (T // HOP) * args.steps
     out = {
         "metric": "48 kHz audio frames/sec (hop=480), DeepFilterNet3 enhance()",
@@ -514,7 +565,7 @@ def main() -> None:
                    "batch_per_gpu": B, "clip_seconds": args.seconds, "global_batch": B * world,
                    "parallelism": f"clips sharded over {world} GPU(s); " + ("async RCCL gather of waveforms to rank 0" if gather else "no collective"),
                    "inputs_resident_in_hbm": True},
-        "ms_per_step_without_gather": no_gather_ms, "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
+        "ms_per_step_without_gather": no_gather_ms, "ms_per_step_host_consumer": host_consumer_ms, "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
         "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
         "enqueue": {"policy": "one big pass in flight per model handle (a call first waits, on the host, for the previous pass to drain) and the GRU phase "
                               "of a pass is enqueued once its encoder front has run: packets waiting at the head of the pass's ~13 hardware queues slow "
@@ -522,7 +573,7 @@ def main() -> None:
                     "ms_per_step_with_free_enqueue_ahead": ahead_ms, "switch": "DFX_ENQUEUE_AHEAD=1"},
         "host_io": host_io,
         "gru_phase_form": ("persistent flag-synchronised launch (dfx_k_gru_seq)" if gru_persistent else "event-synchronised launches per (layer, time chunk)"),
-        "roofline": roofline, "rooflines": rooflines, "configs": configs, "cpu_baseline": cpu, "kernels": kern,
+        "roofline": roofline, "rooflines": rooflines, "configs": configs, "cpu_baseline": cpu, "parity": parity, "kernels": kern,
         "realtime_factor": frames / dt / 100.0,
     }
     # the numbers a reader of the line's tail looks for, once more at the very end
@@ -531,7 +582,9 @@ def main() -> None:
             d = d.get(k) if isinstance(d, dict) else None
         return d
     out["summary"] = {
-        "ms_per_step": round(dt / args.steps * 1e3, 3), "exact_fp32_ms_per_step": exact_ms, "exact_fp32_gru_phase_form": exact_form,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "frames_per_s_fp16_split": round(frames / dt, 1),
+        "exact_fp32_ms_per_step": exact_ms, "frames_per_s_exact_fp32": (round(world * B * (T // HOP) / (exact_ms * 1e-3), 1) if exact_ms else None),
+        "exact_fp32_gru_phase_form": exact_form, "parity_rms_vs_oracle": _g(parity, "rms"),
         "roofline_kernel": _g(roofline, "kernel"), "roofline_frac": _g(roofline, "frac"),
         "standalone_df_apply_frac": _g(roofline, "standalone_df_apply_frac"),
         "analysis_frac": _g(rooflines, "dfx_k_analysis", "frac"),

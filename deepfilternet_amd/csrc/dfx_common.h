@@ -109,7 +109,9 @@ int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int6
 bool dfx_synthesis_rows_ok(const dfx_state *st, bool with_df, int order, int nb_df, int nbands);
 int dfx_launch_synthesis_rows(const dfx_state *st, const float *spec, int64_t spec_stride, const float *coefs, int nb_df, int order, int lookahead,
                               const float *gains, float pf_beta, float atten_lim, int64_t B, int64_t Tf, float *out, int64_t out_stride,
-                              int64_t out_skip, int64_t out_len, hipStream_t s, bool out_i16 = false);
+                              int64_t out_skip, int64_t out_len, hipStream_t s, bool out_i16 = false,
+                              const unsigned int *err = nullptr,    // the model's error words (host memory) and a device word for their verdict: a pass in
+                              unsigned int *poison = nullptr);      // which a kernel raised a fault stores NaN (dfx_k_fault_mirror)
 int dfx_launch_norm_scan(const float *erb_in, float *erb_out, int E, const float *spec_in, int64_t spec_frame_stride,
                          float *spec_out, int Fn, int64_t C, int64_t T, float alpha, float *erb_state,
                          float *unit_state, hipStream_t s, int64_t erb_out_cs = 0,   // > 0: floats between the clips of erb_out / spec_out (< 16 frames)

@@ -558,7 +558,7 @@ bool dfx_synthesis_rows_ok(const dfx_state *st, bool with_df, int order, int nb_
 }
 int dfx_launch_synthesis_rows(const dfx_state *st, const float *spec, int64_t spec_stride, const float *coefs, int nb_df, int order, int lookahead,
                               const float *gains, float pf_beta, float atten_lim, int64_t B, int64_t Tf, float *out, int64_t out_stride,
-                              int64_t out_skip, int64_t out_len, hipStream_t s, bool out_i16) {
+                              int64_t out_skip, int64_t out_len, hipStream_t s, bool out_i16, const unsigned int *err, unsigned int *poison) {
     if (B <= 0 || Tf <= 0) return DFX_OK;
     const bool with_df = coefs != nullptr || gains != nullptr;
     if (!dfx_synthesis_rows_ok(st, with_df, order, coefs ? nb_df : 0, gains ? st->bands->nb : 0))
@@ -587,6 +587,12 @@ int dfx_launch_synthesis_rows(const dfx_state *st, const float *spec, int64_t sp
     const char *seg_e = getenv("DFX_SYN_SEGS");   // dev / variant test: segments per row (read per launch, like DFX_FFT_IN_PLACE)
     const int seg_env = seg_e ? atoi(seg_e) : 0;
     if (seg_env > 0) segs = seg_env < chunks ? seg_env : chunks;
+    A.poison = nullptr;
+    if (err && poison) {   // the pass's faults so far (every one that can reach this kernel's inputs), as a device word
+        dfx_launch(dfx_k_fault_mirror, dim3(1), dim3(1), 0, s, err, poison);
+        DFX_LAUNCH_CHECK();
+        A.poison = poison;
+    }
     A.seg_chunks = (int)dfx_ceil_div(chunks, segs);
     A.segs = (int)dfx_ceil_div(chunks, A.seg_chunks);
     int64_t nblk = B * A.segs;

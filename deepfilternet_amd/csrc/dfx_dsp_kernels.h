@@ -1618,6 +1618,15 @@ struct DfxDfrArgs {
     int64_t items;        // work items = ceil(B / 8) * 8 * ceil(chunks / 4)
     int pf_ch = 0;        // > 0: the real-time runtime's post filter (see DfxDfaArgs::pf_ch): pf_ch consecutive clips are the channels of one stream
 };
+// A pass of enhance() whose kernels raised a fault (err[1]: fp16-split range, err[2]: a flag wait timed out and its workgroup ran on without its data)
+// must not hand back plausible samples: the finishing kernel looks at the words when it starts — every fault that can reach its inputs has been
+// raised by then, it runs behind everything else of the pass — and stores NaN (16-bit PCM: zeros) instead.  The host still gets the error from the
+// words.  The words live in host memory — a read over PCIe each: every thread reading them cost the kernel 1.7 ms, one lane per workgroup still
+// 0.12 ms — so a one-thread launch in front of the finishing kernel copies their verdict into a word of device memory (dfx_k_fault_mirror), and
+// that is what the finishing kernel reads.
+__global__ void dfx_k_fault_mirror(const unsigned int *err, unsigned int *poison) {
+    *poison = (__hip_atomic_load(err + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) | __hip_atomic_load(err + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0u ? 1u : 0u;
+}
 
 // NPC > 0: the number of 64-lane passes over a row (ceil(ceil(F/2) / 64)) as a compile-time constant (all row loads of a frame are
 // then issued together and the band indices live in registers); NPC == 0: any F, one pass at a time.  PF: post filter / attenuation
@@ -1819,6 +1828,7 @@ struct DfxSynRowsArgs {
     float pf_beta, atten_lim;
     int segs, seg_chunks;     // segments per row, 8-frame chunks per segment
     const unsigned char *mfft = nullptr;   // MF instances: the inverse tables of dfx_fft480_mfma
+    const unsigned int *poison = nullptr;  // device word, non-zero: a kernel of this pass raised a fault — store NaN (16-bit PCM: zeros); dfx_k_fault_mirror
 };
 #define DFX_SYNR_SMEM ((size_t)960 * 12 + (size_t)DFX_DSP_TEAMS * DFX_FFT480_BUF * 8 + (size_t)2 * 480 * 4 + 512)
 #define DFX_SYNR_SMEM_MF (DFX_SYNR_SMEM + (size_t)DFX_MFFT_FRAG3 * 64 * 16)
@@ -1840,6 +1850,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, MF ? 4 : ((PF && I16) ? 5 : 6
     unsigned char *b2b = reinterpret_cast<unsigned char *>(carry + 2 * HOP);   // [M + 1] (+ pad)
     const int team = dfx_wave_uniform(threadIdx.x / DFX_DSP_TEAM), lane = threadIdx.x % DFX_DSP_TEAM;
     float2 *bufA = bufs + (size_t)team * BUF;
+    const bool poisoned = A.poison && *A.poison != 0u;   // (a faulted pass: the window table carries NaN, so every sample of the pass does)
     for (int i0 = threadIdx.x; i0 < N; i0 += 4 * DFX_DSP_THREADS) {   // all loads of a pass before its first LDS store
         float2 tv[4];
         float wv[4];
@@ -1847,7 +1858,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, MF ? 4 : ((PF && I16) ? 5 : 6
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + u * DFX_DSP_THREADS;
             tv[u] = i < N ? A.tw[i] : make_float2(0.f, 0.f);
-            wv[u] = i < N ? A.window[i] : 0.f;
+            wv[u] = i < N ? (poisoned ? __builtin_nanf("") : A.window[i]) : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {

@@ -5,8 +5,13 @@
 
 #include <cmath>
 #include <functional>
+#include <atomic>
 #include <map>
 #include <mutex>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 // ------------------------------------------------------------------------------------------------ cfg validation
 static int check_cfg(const dfx_model_cfg *c) {
@@ -96,6 +101,7 @@ struct GlinW {
 #define DFX_MAX_GRU_LAYERS 8   /* all GRU layers of the three stacks */
 #define DFX_MAX_TCHUNKS 16     /* time chunks of the layer-pipelined GRU phase */
 #define DFX_SEQ_GMAX 64        /* most 16-clip groups per layer the persistent GRU phase is used for (all workgroups must be co-resident) */
+struct DfxLane;
 struct DfxLane {
     hipStream_t main = nullptr;
     hipStream_t aux[2] = {nullptr, nullptr};
@@ -106,6 +112,12 @@ struct DfxLane {
     hipEvent_t gev[DFX_MAX_GRU_LAYERS][DFX_MAX_TCHUNKS] = {};     // layer l has produced time chunk k
     hipEvent_t pev[DFX_MAX_GRU_LAYERS][DFX_MAX_TCHUNKS] = {};     // gi of layer l, chunk k is ready
     hipEvent_t eev[DFX_MAX_TCHUNKS] = {};                         // emb chunk k is ready
+};
+// The internal streams and events of a process on one device (created on demand, kept for the life of the process) and what the handshake of
+// the persistent GRU phase found about them (hwq_probe: -1 not run, 1 concurrent, 0 not).
+struct DfxLaneSet {
+    DfxLane lanes[DFX_MAX_LANES];
+    int hwq_probe = -1;
 };
 // enhance() hands the synthesis to the model forward so that it runs behind the deep filter on the stream that carries the last coefficients
 struct DfxFinish {
@@ -385,7 +397,7 @@ __global__ void dfx_k_gate_finish(const unsigned char *flags, int *skip_counter,
     }
 }
 
-enum { EV_START = 0, EV_C0, EV_C1, EV_C0P, EV_EMB, EV_COEFS, EV_FRONT, EV_DONE, EV_XA, EV_MASK, EV_FIN };
+enum { EV_START = 0, EV_C0, EV_C1, EV_C0P, EV_EMB, EV_COEFS, EV_FRONT, EV_DONE, EV_XA, EV_MASK, EV_FIN, EV_TICKET };
 
 struct dfx_model {
     dfx_model_cfg cfg{};
@@ -443,14 +455,19 @@ struct dfx_model {
     // concurrency (created once; one forward / enhance at a time per handle):
     //   a lane = the streams of one batch chunk: `main` (only used when dfx_enhance pipelines chunks; otherwise the caller's
     //   stream plays that role) + two auxiliary streams for the independent branches of the forward pass + fork/join events
-    DfxLane lanes[DFX_MAX_LANES];
+    //   Round 6: the lanes belong to the PROCESS (one set per device, DfxLaneSet), not to the handle: every handle of a process enqueues on the
+    //   same ~14 internal streams.  Handles used to bring 14 streams each, the second handle's streams shared hardware queues with the first
+    //   one's (GPU_MAX_HW_QUEUES = 24) and its handshake put it on the event-synchronised form for good; passes of different handles take turns
+    //   anyway (DfxTurn), so nothing is lost.
+    DfxLane *lanes = nullptr;
+    struct DfxLaneSet *laneset = nullptr;
     hipEvent_t ev_fork = nullptr;
     // One big pass in flight per handle: a call that would enqueue a multi-stream pass while the previous one is still running first
     // waits (on the host) for that one to drain.  Packets queued ahead on the pass's ~13 hardware queues slow the running pass — measured
     // at config 2: 19.45 ms per step with free enqueue-ahead, 18.8 ms when the host holds the next step back (DF-apply inside the loop
     // 0.60 -> 0.50 ms, the rate it has alone).  DFX_ENQUEUE_AHEAD=1 restores the unthrottled enqueue.
     hipEvent_t ev_pass = nullptr;
-    hipEvent_t ev_gate = nullptr;       // recorded behind every multi-stream pass of this handle (PassTurn)
+    hipEvent_t ev_gate = nullptr;       // recorded behind every multi-stream pass of this handle (DfxTurn)
     mutable bool pass_pending = false;
     bool enqueue_ahead = false;
     bool concurrent = false;
@@ -469,6 +486,7 @@ struct dfx_model {
     // persistent GRU phase (dfx_k_gru_seq): flag words [ready: 8][emb: 1][pad][done: 8 * DFX_SEQ_GMAX], monotonic over the model's life
     unsigned int *d_sync = nullptr;
     mutable unsigned int seq_pbase = 0;       // step counter base of the follower hand-overs (yprog / giprog), monotonic like seq_base
+    mutable int64_t passes_seq = 0, passes_ev = 0;   // passes that ran the persistent phase / that gave it up because another process held the device's ticket (DFX_Q_TICKET_*)
     mutable unsigned int seq_base = 0;  // flag value of "nothing of the current forward pass yet"
     unsigned long long *d_trace = nullptr;   // dev aid (DFX_SEQ_TRACE=1): chunk timestamps of the last persistent GRU launch
     mutable int trace_dims[3] = {0, 0, 0};
@@ -812,24 +830,99 @@ bool prep_gru(Prep &P, const std::string &name, int layers, std::vector<GruW> &o
 }
 }  // namespace
 
-static bool dfx_create_lane(dfx_model *m, int l) {
-    DfxLane &ln = m->lanes[l];
-    if (ln.main) return true;
-    bool good = hipStreamCreateWithFlags(&ln.main, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i < 2; ++i) good = good && hipStreamCreateWithFlags(&ln.aux[i], hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i < DFX_LANE_EVENTS; ++i) good = good && hipEventCreateWithFlags(&ln.ev[i], hipEventDisableTiming) == hipSuccess;
-    if (l == 0) {  // the layer-pipelined GRU phase runs on lane 0 only
-        const int nl = 1 + (m->cfg.emb_num_layers - 1) + m->cfg.df_num_layers;
-        for (int i = 0; i < nl && i < DFX_MAX_GRU_LAYERS; ++i) {
-            if (i > 0) good = good && hipStreamCreateWithFlags(&ln.gs[i], hipStreamNonBlocking) == hipSuccess;  // layer 0 recurs on the caller's stream
-            good = good && hipStreamCreateWithFlags(&ln.ps[i], hipStreamNonBlocking) == hipSuccess;   // (highest priority for these was measured: the spinning wait kernels then starve every other queue, seconds per step)
-            for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) {
-                good = good && hipEventCreateWithFlags(&ln.gev[i][k], hipEventDisableTiming) == hipSuccess;
-                good = good && hipEventCreateWithFlags(&ln.pev[i][k], hipEventDisableTiming) == hipSuccess;
-            }
+static std::mutex &dfx_laneset_mu() {
+    static std::mutex mu;
+    return mu;
+}
+static DfxLaneSet *dfx_laneset_of_device() {   // (never freed: streams of a process live as long as it does)
+    static std::map<int, DfxLaneSet *> sets;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(dfx_laneset_mu());
+    DfxLaneSet *&ls = sets[dev];
+    if (!ls) ls = new DfxLaneSet();
+    return ls;
+}
+// The persistent GRU phase across PROCESSES.  Its ~160 workgroups must all be resident (each owns a CU); two such passes of two processes on one
+// GPU can each hold the CUs the other's missing workgroups wait for, and both end in flag-wait timeouts (a fault the host is told about, but two
+// seconds late and with both passes lost).  Inside a process the passes take turns (DfxTurn); between processes there is a ticket per device: an
+// advisory lock on /dev/shm/dfx_persistent_<PCI bus id>.lock, taken without waiting in front of a persistent phase and given back by a host callback
+// behind the pass (on a side stream: the caller's stream does not wait for the callback).  A pass that does not get the ticket runs the
+// event-synchronised form of the phase (no residency requirement; ~1.4 x slower), so nobody ever waits for another process.  DFX_DEVICE_TICKET=0:
+// off (one process per GPU is guaranteed by the deployment); processes that do not share /dev/shm do not see each other.
+struct DfxTicket {
+    int fd = -2;                    // -2 not opened yet, -1 unavailable
+    std::atomic<int> holds{0};      // passes of this process that hold it
+};
+static DfxTicket &dfx_ticket() {
+    static DfxTicket t;
+    return t;
+}
+static bool dfx_ticket_try() {   // (under the enqueue lock)
+    DfxTicket &t = dfx_ticket();
+    if (t.fd == -2) {
+        const char *e = getenv("DFX_DEVICE_TICKET");
+        t.fd = -1;
+        if (!(e && e[0] == '0')) {
+            int dev = 0;
+            char bus[64] = "gpu";
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev);
+            for (char *c = bus; *c; ++c)
+                if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+            char path[160];
+            snprintf(path, sizeof(path), "/dev/shm/dfx_persistent_%s.lock", bus);
+            t.fd = open(path, O_RDWR | O_CREAT | O_CLOEXEC, 0666);
+            if (t.fd >= 0) (void)fchmod(t.fd, 0666);
         }
-        for (int i = 0; i < 2; ++i) good = good && hipStreamCreateWithFlags(&ln.ts[i], hipStreamNonBlocking) == hipSuccess;
-        for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) good = good && hipEventCreateWithFlags(&ln.eev[k], hipEventDisableTiming) == hipSuccess;
+    }
+    if (t.fd < 0) return true;                      // no ticket office: as before
+    if (t.holds.load() > 0) {                       // this process already holds it (an earlier pass still in flight)
+        t.holds.fetch_add(1);
+        return true;
+    }
+    if (flock(t.fd, LOCK_EX | LOCK_NB) != 0) return false;
+    t.holds.fetch_add(1);
+    return true;
+}
+static void dfx_ticket_release_cb(void *) {
+    DfxTicket &t = dfx_ticket();
+    if (t.fd >= 0 && t.holds.fetch_sub(1) == 1) (void)flock(t.fd, LOCK_UN);
+}
+// One enqueue at a time per process: every entry point that puts work on the process's internal streams holds this lock while it does
+// (forward, enhance, the streaming calls); see DfxTurn.
+static std::mutex &dfx_enqueue_mu() {
+    static std::mutex mu;
+    return mu;
+}
+static bool dfx_create_lane(dfx_model *m, int l) {
+    if (!m->laneset) {
+        m->laneset = dfx_laneset_of_device();
+        if (!m->laneset) return false;
+        m->lanes = m->laneset->lanes;
+    }
+    // idempotent: whatever of the lane does not exist yet is created (a second handle finds the first one's streams; a deeper model adds its layers')
+    std::lock_guard<std::mutex> lk(dfx_laneset_mu());
+    DfxLane &ln = m->lanes[l];
+    bool good = true;
+    auto stream = [&](hipStream_t &st) {
+        if (!st) good = good && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    };
+    auto event = [&](hipEvent_t &e) {
+        if (!e) good = good && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    };
+    stream(ln.main);
+    for (int i = 0; i < 2; ++i) stream(ln.aux[i]);
+    for (int i = 0; i < DFX_LANE_EVENTS; ++i) event(ln.ev[i]);
+    if (l == 0) {  // the layer-pipelined GRU phase runs on lane 0 only
+        const int nl_model = 1 + (m->cfg.emb_num_layers - 1) + m->cfg.df_num_layers;
+        const int nl = nl_model > 5 ? nl_model : 5;   // (at least the five layers of the shipped shapes: the handshake then covers what later handles use)
+        for (int i = 0; i < nl && i < DFX_MAX_GRU_LAYERS; ++i) {
+            if (i > 0) stream(ln.gs[i]);  // layer 0 recurs on the caller's stream
+            stream(ln.ps[i]);             // (highest priority for these was measured: the spinning wait kernels then starve every other queue, seconds per step)
+            for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) event(ln.gev[i][k]), event(ln.pev[i][k]);
+        }
+        for (int i = 0; i < 2; ++i) stream(ln.ts[i]);
+        for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) event(ln.eev[k]);
     }
     return good;
 }
@@ -845,14 +938,21 @@ static void hwq_probe_fallback(dfx_model *m) {   // the event-synchronised form 
         fprintf(stderr, "dfx: the streams of the persistent GRU phase do not run concurrently (GPU_MAX_HW_QUEUES >= 16 must be in the environment "
                         "before HIP initialises): this model uses the slower event-synchronised GRU phase (dfx_model_query DFX_Q_HWQ_PROBE = 0)\n");
 }
+// (the caller holds the enqueue lock, DfxTurn: the handshake synchronises the process's internal streams, so whatever another handle has in flight
+// on them is over before it starts; its result belongs to the lane set — one handshake per process and device)
 static void hwq_probe_run(dfx_model *m) {
     if (!m->hwq_probe_pending) return;
     m->hwq_probe_pending = false;
+    DfxLaneSet *ls = m->laneset;
+    if (ls && ls->hwq_probe >= 0) {
+        m->hwq_probe = ls->hwq_probe;
+        if (m->hwq_probe == 0) hwq_probe_fallback(m);
+        return;
+    }
     const DfxLane &ln = m->lanes[0];
-    const int nl = 1 + (m->cfg.emb_num_layers - 1) + m->cfg.df_num_layers;
     std::vector<hipStream_t> ss;
     if (ln.gs[1]) ss.push_back(ln.gs[1]);
-    for (int i = 0; i < nl && i < DFX_MAX_GRU_LAYERS; ++i)
+    for (int i = 0; i < DFX_MAX_GRU_LAYERS; ++i)
         if (ln.ps[i]) ss.push_back(ln.ps[i]);
     for (int i = 0; i < 2; ++i)
         if (ln.ts[i]) ss.push_back(ln.ts[i]);
@@ -873,6 +973,7 @@ static void hwq_probe_run(dfx_model *m) {
     }
     m->h_err[8] = 0u, m->h_err[9] = 0u;
     (void)hipMemset(cnt, 0, sizeof(unsigned int));
+    if (ls) ls->hwq_probe = m->hwq_probe;
     if (m->hwq_probe == 0) hwq_probe_fallback(m);
 }
 
@@ -1206,31 +1307,11 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
 static void pass_gate_forget(const dfx_model *m);
 extern "C" void dfx_model_free(dfx_model *m) {
     if (!m) return;
-    for (int l = 0; l < DFX_MAX_LANES; ++l) {
-        DfxLane &ln = m->lanes[l];
-        if (ln.main) (void)hipStreamDestroy(ln.main);
-        for (int i = 0; i < 2; ++i)
-            if (ln.aux[i]) (void)hipStreamDestroy(ln.aux[i]);
-        for (int i = 0; i < DFX_LANE_EVENTS; ++i)
-            if (ln.ev[i]) (void)hipEventDestroy(ln.ev[i]);
-        for (int i = 0; i < DFX_MAX_GRU_LAYERS; ++i) {
-            if (ln.gs[i]) (void)hipStreamDestroy(ln.gs[i]);
-            if (ln.ps[i]) (void)hipStreamDestroy(ln.ps[i]);
-            for (int k = 0; k < DFX_MAX_TCHUNKS; ++k) {
-                if (ln.gev[i][k]) (void)hipEventDestroy(ln.gev[i][k]);
-                if (ln.pev[i][k]) (void)hipEventDestroy(ln.pev[i][k]);
-            }
-        }
-        for (int i = 0; i < 2; ++i)
-            if (ln.ts[i]) (void)hipStreamDestroy(ln.ts[i]);
-        for (int k = 0; k < DFX_MAX_TCHUNKS; ++k)
-            if (ln.eev[k]) (void)hipEventDestroy(ln.eev[k]);
-    }
+    pass_gate_forget(m);   // (first: nobody may wait on ev_gate once it is destroyed; the lanes are the process's and stay)
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_pass) (void)hipEventDestroy(m->ev_pass);
     if (m->ev_gate) (void)hipEventDestroy(m->ev_gate);
     dfx_env_err_words_free(m->h_err);
-    pass_gate_forget(m);
     if (m->d_sync && m->d_trace) {   // dev aid (DFX_SEQ_TRACE=1): how many block hand-overs of the followers took the same-XCD form
         unsigned int n = 0;
         const size_t off = 16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX + 16 + 2 * DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX + 3 * DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX;
@@ -1289,9 +1370,16 @@ extern "C" int dfx_model_check(const dfx_model *m) {
 extern "C" int dfx_model_query(const dfx_model *m, int what, int64_t *value) {
     if (!m || !value) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_query: null");
     switch (what) {
-        case DFX_Q_GRU_PERSISTENT: hwq_probe_run(const_cast<dfx_model *>(m)); *value = m->gru_seq && m->concurrent ? 1 : 0; return DFX_OK;
-        case DFX_Q_HWQ_PROBE: hwq_probe_run(const_cast<dfx_model *>(m)); *value = m->hwq_probe; return DFX_OK;
+        case DFX_Q_GRU_PERSISTENT:
+        case DFX_Q_HWQ_PROBE: {
+            std::lock_guard<std::mutex> lk(dfx_enqueue_mu());
+            hwq_probe_run(const_cast<dfx_model *>(m));
+            *value = what == DFX_Q_HWQ_PROBE ? m->hwq_probe : (m->gru_seq && m->concurrent ? 1 : 0);
+            return DFX_OK;
+        }
         case DFX_Q_EXACT_FP32: *value = m->exact_fp32 ? 1 : 0; return DFX_OK;
+        case DFX_Q_PASSES_PERSISTENT: *value = m->passes_seq; return DFX_OK;
+        case DFX_Q_PASSES_TICKET_BUSY: *value = m->passes_ev; return DFX_OK;
         case DFX_Q_SPIN_LIMIT: *value = m->spin_limit; return DFX_OK;
     }
     DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_query: unknown item %d", what);
@@ -2301,7 +2389,16 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     const int groups = (int)dfx_ceil_div(B, DFX_GH_ROWS);
     if (pipe && m->gru_seq && m->hwq_probe_pending && groups <= DFX_SEQ_GMAX && nl * groups + 8 <= dfx_env_num_cus())
         hwq_probe_run(const_cast<dfx_model *>(m));   // first pass that would use the persistent form: do its streams run concurrently?
-    const bool use_seq = pipe && m->gru_seq && groups <= DFX_SEQ_GMAX && nl * groups + 8 <= dfx_env_num_cus();
+    const bool want_seq = pipe && m->gru_seq && groups <= DFX_SEQ_GMAX && nl * groups + 8 <= dfx_env_num_cus();
+    // (another process in its persistent phase on this device: this pass takes the event-synchronised form, DfxTicket)
+    const bool use_seq = want_seq && dfx_ticket_try();
+    m->passes_seq += use_seq ? 1 : 0, m->passes_ev += (want_seq && !use_seq) ? 1 : 0;
+    struct TicketGuard {   // an enqueue that fails half-way gives the ticket back at once
+        bool armed;
+        ~TicketGuard() {
+            if (armed) dfx_ticket_release_cb(nullptr);
+        }
+    } ticket_guard{use_seq && dfx_ticket().fd >= 0};
     int sb[DFX_GS_MAX_CHUNKS + 1];   // chunk boundaries of the persistent form
     int Ks = 0;
     if (use_seq) {
@@ -3096,7 +3193,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     // dfx_model_forward / dfx_df_apply and the roofline kernel of bench.py)
     if (fin && m->fuse_dfa && dfx_synthesis_rows_ok(fin->st, true, O, run_df ? Fd : 0, E) && bands == fin->st->bands) {
         if ((rc = dfx_launch_synthesis_rows(fin->st, spec, sstride, run_df ? coefs : nullptr, run_df ? Fd : 0, O, c.df_lookahead, mask,
-                                            c.mask_pf ? c.pf_beta : 0.f, atten_lim, B, T, fin->y, fin->out_stride, fin->out_skip, fin->out_len, fin_s, fin->out_i16)))
+                                            c.mask_pf ? c.pf_beta : 0.f, atten_lim, B, T, fin->y, fin->out_stride, fin->out_skip, fin->out_len, fin_s, fin->out_i16, m->d_err, m->d_sync ? m->d_sync + 14 : nullptr)))   // (d_sync[14]: a spare word of the flag block)
             return rc;
     } else {
         if (dfx_dev_stage(10) && (rc = dfx_launch_df_apply(spec, coefs, DFX_COEF_BOTF, mask, bands, B, T, c.fft_size / 2 + 1, run_df ? Fd : 0, O, c.df_lookahead,
@@ -3107,6 +3204,15 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             return rc;
     }
     if (fin_s != s && ((rc = signal(EV_FIN, fin_s)) || (rc = wait(EV_FIN, s)))) return rc;
+    if (use_seq && dfx_ticket().fd >= 0) {   // give the device's ticket back when this pass is through (side stream: s does not wait for the callback)
+        hipStream_t ts = ln->main ? ln->main : s;
+        if (ts != s) {
+            DFX_HIP(hipEventRecord(ln->ev[EV_TICKET], s));
+            DFX_HIP(hipStreamWaitEvent(ts, ln->ev[EV_TICKET], 0));
+        }
+        DFX_HIP(hipLaunchHostFunc(ts, dfx_ticket_release_cb, nullptr));
+        ticket_guard.armed = false;
+    }
     return DFX_OK;
 }
 
@@ -3136,14 +3242,15 @@ static int model_forward_lane(const dfx_model *m, const dfx_bands *bands, const 
     DFX_FAIL(DFX_ERR_UNSUPPORTED, "conv_ch");
 }
 
-// One handle's pass at a time.  Two model handles driven from two host threads used to overlap their multi-stream passes on the GPU, and the
-// samples of a few clips came out wrong now and then — in every form of the GRU phase, also the round-4 one (tools/dev/two_handles.py; an
-// unrelated kernel stream beside ONE handle is harmless: tools/dev/one_handle_noise.py).  Overlap buys nothing (one pass fills the chip), so the
-// passes take turns: the host enqueues one handle's pass at a time (a process-wide lock held for the enqueue), and a pass starts on the device
-// when the other handle's last pass is through (a stream wait on its event; the same handle's passes are ordered by its caller's stream and
-// ev_pass as before).  The frame-by-frame streaming calls are not part of this.
+// Whose turn it is.  The internal streams and events belong to the process (DfxLaneSet), so the enqueue of every entry point is serialised by
+// one lock (a stream's event pairs must not interleave with another thread's), and the multi-stream passes of DIFFERENT handles also take
+// turns on the device: a pass starts when the other handle's last pass is through (a stream wait on its event; passes of one handle are ordered
+// by their caller's stream and ev_pass as before).  Why on the device too: a persistent GRU phase needs every one of its ~160 workgroups
+// resident (each owns a CU) — two of them at once are 320 on 256 CUs, each can hold the CUs the other's missing workgroups wait for, and both
+// end in flag-wait timeouts (seen with two handles on the persistent form, profiles/r06_two_handles.log).  Overlap buys nothing either: one
+// pass fills the chip.  (Round 5 blamed the overlap for wrong samples; that was the packed-fp32 fault, measurements R6.1, and is gone with it.)
+// The frame-by-frame streaming calls only take the lock: they start no persistent phase.
 struct PassGate {
-    std::mutex mu;
     const dfx_model *owner = nullptr;
     hipEvent_t done = nullptr;   // the owner's ev_gate, recorded behind its last pass
 };
@@ -3151,25 +3258,31 @@ static PassGate &pass_gate() {
     static PassGate g;
     return g;
 }
-struct PassTurn {
+struct DfxTurn {
     std::unique_lock<std::mutex> lk;
-    PassTurn(const dfx_model *m, hipStream_t s) {
-        if (!m->concurrent || !m->ev_gate) return;
-        static const bool off = [] { const char *e = getenv("DFX_PASS_TURN"); return e && e[0] == '0'; }();   // dev: two_handles_diag.py
-        if (off) return;
+    const dfx_model *m;
+    hipStream_t s;
+    bool big, recorded = false;
+    DfxTurn(const dfx_model *m_, hipStream_t s_, bool big_pass) : m(m_), s(s_), big(big_pass && m_->concurrent && m_->ev_gate) {
+        if (!m->have_streams) return;
+        lk = std::unique_lock<std::mutex>(dfx_enqueue_mu());
         PassGate &g = pass_gate();
-        lk = std::unique_lock<std::mutex>(g.mu);
-        if (g.owner && g.owner != m && g.done) (void)hipStreamWaitEvent(s, g.done, 0);
+        if (big && g.owner && g.owner != m && g.done) (void)hipStreamWaitEvent(s, g.done, 0);
     }
-    void passed(const dfx_model *m, hipStream_t s) {   // the pass is enqueued and joined into s
-        if (!lk.owns_lock()) return;
+    void passed() {   // the pass is enqueued and joined into s
+        if (!big || !lk.owns_lock() || recorded) return;
+        recorded = true;
         if (hipEventRecord(m->ev_gate, s) == hipSuccess) pass_gate().owner = m, pass_gate().done = m->ev_gate;
     }
+    ~DfxTurn() { passed(); }   // also behind a pass that failed half-way: whatever it did enqueue is ordered in front of the next handle's pass
 };
 static void pass_gate_forget(const dfx_model *m) {
+    std::lock_guard<std::mutex> lk(dfx_enqueue_mu());
     PassGate &g = pass_gate();
-    std::lock_guard<std::mutex> lk(g.mu);
-    if (g.owner == m) g.owner = nullptr, g.done = nullptr;
+    if (g.owner == m) {
+        if (g.done) (void)hipEventSynchronize(g.done);
+        g.owner = nullptr, g.done = nullptr;
+    }
 }
 // Enqueue throttle of the multi-stream pass (see dfx_model::ev_pass): big passes only — a small pass is over before the host has
 // enqueued the next one, and holding the host back would serialise its launch overhead with the device's work.
@@ -3198,11 +3311,11 @@ extern "C" int dfx_model_forward(const dfx_model *m, const dfx_bands *bands, con
                                  void *stream) {
     if (!m) DFX_FAIL(DFX_ERR_INVALID_ARG, "dfx_model_forward: bad arguments");
     if (int rc = pass_begin(m, B * T)) return rc;
-    PassTurn turn(m, dfx_stream(stream));
+    DfxTurn turn(m, dfx_stream(stream), true);
     if (int rc = model_forward_lane(m, bands, spec, feat_erb, feat_spec, B, T, atten_lim, spec_e, mask, lsnr, df_coefs, workspace,
                                     workspace_bytes, stream, &m->lanes[0], false))
         return rc;
-    turn.passed(m, dfx_stream(stream));
+    turn.passed();
     return pass_end(m, B * T, dfx_stream(stream));
 }
 
@@ -3896,7 +4009,10 @@ extern "C" int dfx_stream_process(dfx_stream_state *S, const float *x, int64_t n
     if (int rc = dfx_require_device()) return rc;
     if (int rc = model_poll(S->m)) return rc;
     hipStream_t s = dfx_stream(stream);
-    if (int rc = stream_process_impl(S, x, n, y, lsnr_out, s)) return rc;
+    {
+        DfxTurn turn(S->m, s, false);   // (the enqueue lock only: a hop starts no persistent phase)
+        if (int rc = stream_process_impl(S, x, n, y, lsnr_out, s)) return rc;
+    }
     return stream_call_end(S->m, s);
 }
 static int stream_process_impl(dfx_stream_state *S, const float *x, int64_t n, float *y, float *lsnr_out, hipStream_t s) {
@@ -3930,6 +4046,7 @@ extern "C" int dfx_stream_process_raw(dfx_stream_state *S, const float *spec, fl
     if (int rc = dfx_require_device()) return rc;
     if (int rc = model_poll(S->m)) return rc;
     hipStream_t s = dfx_stream(stream);
+    DfxTurn turn(S->m, s, false);   // (the enqueue lock)
     const dfx_model *m = S->m;
     const dfx_state *st = S->st;
     const dfx_model_cfg &c = m->cfg;
@@ -4144,10 +4261,10 @@ static int enhance_any(const dfx_model *m, const dfx_state *st, const float *x, 
         if (lim >= 1.f) lim = 0.99999994f;              // |dB| tiny: the reference mixes with lim == 1.0f (the noisy signal passes)
     }
     if (int rc = pass_begin(m, B * Tf)) return rc;
-    PassTurn turn(m, s);
+    DfxTurn turn(m, s, true);
     if (nc == 1) {
         if (int rc = enhance_chunk(m, st, x, B, T, pad, lim, y, base, s, &m->lanes[0], false, pcm16)) return rc;
-        turn.passed(m, s);
+        turn.passed();
         return pass_end(m, B * Tf, s);
     }
     // ---- pipelined chunks: fork from the caller's stream, stagger the fronts, join back
@@ -4166,7 +4283,7 @@ static int enhance_any(const dfx_model *m, const dfx_state *st, const float *x, 
         row += sizes[i];
     }
     for (int i = 0; i < nc; ++i) DFX_HIP(hipStreamWaitEvent(s, m->lanes[i].ev[EV_DONE], 0));
-    turn.passed(m, s);
+    turn.passed();
     return pass_end(m, B * Tf, s);
 }
 extern "C" int dfx_enhance(const dfx_model *m, const dfx_state *st, const float *x, int64_t B, int64_t T, int pad,

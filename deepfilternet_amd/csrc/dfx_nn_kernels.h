@@ -2128,7 +2128,10 @@ __global__ void __launch_bounds__(64 * DFX_TAIL_WAVES, 1) dfx_k_erb_tail(DfxTail
     };
     static_assert(64 % C4 == 0, "channel quad of a lane must not depend on the load index");
     float amax = 0.f;
-    int64_t rl = (int64_t)blockIdx.x * DFX_TAIL_WAVES + wave;
+    // (the frame index is wave-uniform: said so, its row-map divisions run on the scalar unit and their reciprocals live in scalar registers — as
+    // vector values hoisted out of the frame loop they were the three registers this kernel does not have: 12 bytes of scratch per lane once the
+    // library was built without packed fp32 operations)
+    int64_t rl = (int64_t)blockIdx.x * DFX_TAIL_WAVES + dfx_wave_uniform(wave);
     if (rl < A.R) issue(dfx_row(A.rm, rl));
     for (; rl < A.R; rl += (int64_t)gridDim.x * DFX_TAIL_WAVES) {
         const int64_t r = dfx_row(A.rm, rl);

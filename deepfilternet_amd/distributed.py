@@ -39,15 +39,60 @@ class GatherHandle:
         return torch.cat([p[:n] for p, n in zip(self._parts, self._sizes)], dim=0)
 
 
+class HostHandle:
+    """Result of ``enhance_sharded(..., gather="host")``: the consumer is the host, so nothing crosses xGMI — every rank copies its own slice
+    to page-locked host memory on its own stream ("if the consumer is the host, skip the gather").  ``wait()`` returns this rank's
+    ``[n, T]`` host tensor; ``local`` is the device result."""
+
+    def __init__(self, host: torch.Tensor, event, local: torch.Tensor):
+        self._host, self._event, self.local = host, event, local
+
+    def wait(self) -> torch.Tensor:
+        if self._event is not None:
+            self._event.synchronize()
+            self._event = None
+        return self._host
+
+
+def check_distinct_devices(ids: List[str]) -> None:
+    """Every rank of a node must sit on a GPU of its own.  Two ranks on one device would run two passes of the persistent GRU phase side by
+    side — each needs all its ~160 workgroups resident, so they fall back to taking turns through the device's ticket at best (half the
+    throughput, reported as scaling) — and is always a launcher mistake (LOCAL_RANK not applied, HIP_VISIBLE_DEVICES narrowed).  ``ids`` = one
+    device identity per rank (PCI bus id / uuid)."""
+    seen = {}
+    for r, d in enumerate(ids):
+        if d in seen:
+            raise WorldError(f"ranks {seen[d]} and {r} are both on device {d}: one process per GPU (check LOCAL_RANK / HIP_VISIBLE_DEVICES of the "
+                             "launcher); two ranks on one device would share its CUs between two persistent GRU phases (docs/measurements.md R6.1)")
+        seen[d] = r
+
+
+def gather_device_ids(device=None, group=None) -> List[str]:
+    """The device identity of every rank (all_gather_object; a CPU run reports ``cpu:<rank>``)."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if device is not None and torch.cuda.is_available():
+        p = torch.cuda.get_device_properties(device)
+        mine = str(getattr(p, "uuid", None) or getattr(p, "pci_bus_id", None) or f"{p.name}:{torch.device(device).index}")
+        mine = f"{mine}:{getattr(p, 'pci_bus_id', '')}:{getattr(p, 'pci_device_id', '')}"
+    else:
+        mine = f"cpu:{rank}"
+    if not dist.is_initialized():
+        return [mine]
+    out: List[Optional[str]] = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, mine, group=group)
+    return [str(o) for o in out]
+
+
 def enhance_sharded(model, df_state, audio: torch.Tensor, pad: bool = True, atten_lim_db: Optional[float] = None, *,
-                    group=None, presharded: bool = False, counts: Optional[List[int]] = None, gather: bool = True,
+                    group=None, presharded: bool = False, counts: Optional[List[int]] = None, gather=True,
                     dst: int = 0, enhance_fn=None):
     """Enhance this rank's clips of ``audio`` and (optionally) gather every rank's output to ``dst``.
 
     audio       full batch ``[C, T]`` (every rank passes the same tensor; only its own slice is touched) or, with
                 ``presharded=True``, this rank's slice only.
     counts      with ``presharded``: clips held by every rank, if known (saves the size exchange, which synchronises the host).
-    gather      True: returns a :class:`GatherHandle` (asynchronous ``dist.gather``); False: returns the local output.
+    gather      True: returns a :class:`GatherHandle` (asynchronous ``dist.gather`` to ``dst``); "host": no collective, every rank copies its slice to
+                page-locked host memory (:class:`HostHandle`); False: returns the local output.
     enhance_fn  defaults to :func:`deepfilternet_amd.enhance.enhance` (hook for tests).
     """
     if enhance_fn is None:
@@ -70,6 +115,14 @@ def enhance_sharded(model, df_state, audio: torch.Tensor, pad: bool = True, atte
             mine = mine.pin_memory()
         sizes = [b - a for a, b in (shard_range(audio.shape[0], r, world) for r in range(world))]
     y = enhance_fn(model, df_state, mine, pad=pad, atten_lim_db=atten_lim_db)
+    if gather == "host":
+        if y.device.type != "cuda":
+            return HostHandle(y, None, y)
+        host = torch.empty(y.shape, dtype=y.dtype, pin_memory=True)
+        host.copy_(y, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(y.device))
+        return HostHandle(host, ev, y)
     if not gather or world == 1:
         return GatherHandle(None, [y], [y.shape[0]], y) if gather else y
     if sizes is None:  # ranks may hold different numbers of clips: exchange the counts first (tiny; blocks the host once)

@@ -136,7 +136,7 @@ class DfNet:
         is raised by the next call on the model at the latest (``DFX_CHECK_EVERY_PASS=1``: by the call that caused it)."""
         _lib.check(_lib.lib().dfx_model_poll(self._h))
 
-    Q_GRU_PERSISTENT, Q_HWQ_PROBE, Q_EXACT_FP32, Q_SPIN_LIMIT = 1, 2, 3, 4
+    Q_GRU_PERSISTENT, Q_HWQ_PROBE, Q_EXACT_FP32, Q_SPIN_LIMIT, Q_PASSES_PERSISTENT, Q_PASSES_TICKET_BUSY = 1, 2, 3, 4, 5, 6
 
     def query(self, what: int) -> int:
         """dfx_model_query (include/dfx.h DFX_Q_*)."""

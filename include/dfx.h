@@ -224,6 +224,9 @@ int dfx_model_check(const dfx_model *m);
                                 * form is used instead; -1: not probed (no streams, exact fp32, CPU interpreter) */
 #define DFX_Q_EXACT_FP32 3     /* 1: DFX_EXACT_FP32=1 was set at creation */
 #define DFX_Q_SPIN_LIMIT 4     /* polls a flag wait makes before it gives up (DFX_SYNC_SPIN_LIMIT, default 2^22 ~ 2 s) */
+#define DFX_Q_PASSES_PERSISTENT 5   /* big passes of this handle that ran the persistent GRU phase */
+#define DFX_Q_PASSES_TICKET_BUSY 6  /* big passes that took the event-synchronised form because another PROCESS held the device's ticket for its own
+                                       persistent phase (/dev/shm/dfx_persistent_<PCI bus id>.lock, DFX_DEVICE_TICKET=0: no ticket) */
 int dfx_model_query(const dfx_model *m, int what, int64_t *value);
 
 /* Scratch memory the caller must provide (device bytes) for a [B, T-frames] batch. */

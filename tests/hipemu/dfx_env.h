@@ -141,6 +141,9 @@ static inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) {
 }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+typedef void (*hipHostFn_t)(void *);
+static inline hipError_t hipLaunchHostFunc(hipStream_t, hipHostFn_t fn, void *arg) { fn(arg); return hipSuccess; }   // (everything is synchronous here)
+static inline hipError_t hipDeviceGetPCIBusId(char *buf, int len, int) { snprintf(buf, (size_t)len, "emu"); return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }   // (launches are synchronous: every event has passed)
@@ -547,6 +550,7 @@ static inline int dfx_wave_uniform(int v) { return v; }
 // agent-scope atomics / fences / sleep of the flag-synchronised kernels (dfx_k_gru_seq, dfx_k_wait_ge): plain accesses here — the
 // interpreter runs one launch at a time to completion, so the host never selects the persistent GRU phase on it (dfx_env_is_emulator)
 #define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
 template <typename T>
 static inline T __hip_atomic_load(const T *p, int, int) { return *p; }
 template <typename T, typename V>

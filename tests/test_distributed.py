@@ -55,6 +55,16 @@ def _worker(rank, world, port, x, out_path):
         else:
             assert full is None and full2 is None
         assert h.local.shape[0] == hi - lo
+        # the host-consumer form (no collective, every rank hands its own slice to the host): the same rows
+        from deepfilternet_amd.distributed import check_distinct_devices, gather_device_ids
+
+        hh = enhance_sharded(model, df_state, xt, gather="host")
+        mine = hh.wait()
+        assert torch.equal(mine, h.local) and mine.shape[0] == hi - lo
+        np.save(out_path + f".host{rank}.npy", mine.numpy())
+        ids = gather_device_ids()
+        assert ids == [f"cpu:{r}" for r in range(world)]
+        check_distinct_devices(ids)
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -76,6 +86,16 @@ def test_two_rank_sharded_enhance_matches_single_process(tmp_path):
     model, df_state, _, _ = init_df(params=named_params("defaults"), epoch="none", seed=3)
     ref = enhance(model, df_state, torch.from_numpy(x)).numpy()
     assert got.shape == ref.shape and np.array_equal(got, ref)  # rows are independent: sharding must not change a bit
+    host = np.concatenate([np.load(out_path + f".host{r}.npy") for r in range(2)])
+    assert np.array_equal(host, ref)                             # the host-consumer form: the ranks' own slices, no gather
+
+
+def test_two_ranks_on_one_device_are_refused():
+    from deepfilternet_amd.distributed import WorldError, check_distinct_devices
+
+    check_distinct_devices(["GPU-a", "GPU-b", "GPU-c"])
+    with pytest.raises(WorldError, match="ranks 0 and 2 are both on device GPU-a: one process per GPU"):
+        check_distinct_devices(["GPU-a", "GPU-b", "GPU-a"])
 
 
 # ---- the launcher bench.py --gpus N uses (deepfilternet_amd.distributed.check_world / launch_ranks / init_world)

@@ -1,6 +1,8 @@
 """Dev: which buffer of a pass goes wrong first when two model handles run their passes at the same time (round-5 review, item 1).
 
-Two handles (same weights), one host thread each, every round started together from a barrier with the pass gate off (DFX_PASS_TURN=0).
+Two handles (same weights), one host thread each, every round started together from a barrier.  (Written against the round-5 library, where
+DFX_PASS_TURN=0 switched the pass gate off; since the handles share the process's streams the enqueue lock cannot be switched off any more — the
+tool still shows which buffer differs first should a pass ever come back wrong.)
 After a round whose output differs from the solo run, every buffer of the failing handle's workspace is compared with the snapshot of its
 solo run: name, differing elements, clips, frames.  The earliest buffer in the dependency order that differs names the kernel.
 
