@@ -380,20 +380,15 @@ static size_t dsp_smem_bytes(const dfx_state *st) {
 }
 // analysis: the 480-point plan transforms in place — one buffer per frame (dfx_plan_is_480, dfx_k_analysis)
 static bool ana_in_place(const dfx_state *st) {
-    const char *e = getenv("DFX_FFT_IN_PLACE");   // read per launch (one STFT launch per call): =0 two buffers per frame, =2 only in the ISTFT
-    const bool off = e && e[0] == '0';
-    const DfxFftPlan &pl = st->plan;
-    return !off && pl.M == 480 && pl.nstage == 5 && pl.radix[0] == 4 && pl.radix[1] == 4 && pl.radix[2] == 2 && pl.radix[3] == 3 && pl.radix[4] == 5;
+    const DfxFftPlan &pl = st->plan;   // (the 48 kHz / 20 ms plan transforms in place; any other plan takes the two-buffer passes)
+    return pl.M == 480 && pl.nstage == 5 && pl.radix[0] == 4 && pl.radix[1] == 4 && pl.radix[2] == 2 && pl.radix[3] == 3 && pl.radix[4] == 5;
 }
 // the 480-point transform on the matrix pipe (dfx_fft480_mfma) instead of the radix passes: DFX_FFT_MFMA=1.  Not the default: built, validated
 // and measured in round 5 — analysis 0.535 vs 0.478 ms, the finishing kernel 0.74 vs 0.63 (profiles/r05_dft_mfma.log)
-static bool fft_mfma(const dfx_state *st) {
-    const char *e = getenv("DFX_FFT_MFMA");   // read per launch, like DFX_FFT_IN_PLACE
-    return st->d_mfft && e && e[0] == '1';
-}
+// (round 6: no switch any more and no instance of the MF forms in the library; dfx_fft480_mfma stays in dfx_dsp_kernels.h as the record of the
+// experiment, with its tables)
+static constexpr bool fft_mfma(const dfx_state *) { return false; }
 static size_t ana_smem_bytes(const dfx_state *st, bool mf = false) {
-    static const bool whole_cu = [] { const char *e = getenv("DFX_DEV_STFT_WHOLE_CU"); return e && e[0] == '1'; }();   // dev (round 6): no other workgroup beside an STFT workgroup
-    if (whole_cu) return (size_t)160 * 1024;
     return (mf ? (size_t)DFX_MFFT_FRAG3 * 64 * 16 : 0) + (size_t)st->N * 12 + (size_t)DFX_DSP_TEAMS * (ana_in_place(st) ? (size_t)DFX_FFT480_BUF : 2 * (size_t)(st->plan.M + 2)) * 8 +   // (in place: one buffer per frame, with room for the transform's padded layout)
            (((size_t)(2 * st->nb + 1 + 3 * 64 + st->nb + 1 + DFX_DSP_TEAMS * 64) * 4 + 15) & ~(size_t)15);   // + the ERB band tables and segment sums (analysis)
 }
@@ -418,7 +413,7 @@ int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t 
         A.band_start = st->bands->d_start;
         A.band_invw = st->bands->d_invw;
         A.seg_tab = st->bands->d_segtab;
-        A.nseg = getenv("DFX_ERB_SEGMENTS") && getenv("DFX_ERB_SEGMENTS")[0] == '0' ? 0 : st->bands->nseg;   // (=0: one lane per band)
+        A.nseg = st->bands->nseg;   // (0: more than 64 bands, one lane per band)
         A.B = B;
         A.Tf = Tf;
         A.x_stride = x_stride;
@@ -438,8 +433,7 @@ int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t 
             dfx_launch(kern, dim3(grid), dim3(DFX_DSP_THREADS), smem, s, A);
             return DFX_OK;
         };
-        if (int rc = mf ? (x_i16 ? go(dfx_k_analysis<true, true, true>) : go(dfx_k_analysis<true, false, true>))
-                   : ip ? (x_i16 ? go(dfx_k_analysis<true, true>) : go(dfx_k_analysis<true, false>))
+        if (int rc = ip ? (x_i16 ? go(dfx_k_analysis<true, true>) : go(dfx_k_analysis<true, false>))
                         : (x_i16 ? go(dfx_k_analysis<false, true>) : go(dfx_k_analysis<false, false>)))
             return rc;
         DFX_LAUNCH_CHECK();
@@ -528,9 +522,8 @@ int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int6
     A.plan = st->plan;
     if (A.chunks <= 0) return DFX_OK;
     // in place like the analysis (one buffer per frame, six waves per SIMD; without the register prefetch of the next frame, which would spill
-    // there): 1.07-1.13 -> 0.93-1.03 ms alone; DFX_FFT_IN_PLACE=2 keeps two buffers here, =0 in both kernels
-    const char *ipe = getenv("DFX_FFT_IN_PLACE");
-    const bool ip = ana_in_place(st) && !(ipe && ipe[0] == '2'), mf = ip && fft_mfma(st);
+    // there): 1.07-1.13 -> 0.93-1.03 ms alone
+    const bool ip = ana_in_place(st), mf = ip && fft_mfma(st);
     const size_t smem = ip ? ana_smem_bytes(st, mf) : dsp_smem_bytes(st);
     A.mfft = mf ? st->d_mfft + DFX_MFFT_TABLE_BYTES : nullptr;   // (the inverse tables)
     int64_t nblk = B * A.chunks;
@@ -543,8 +536,7 @@ int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int6
         dfx_launch(kern, dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, stream, A);
         return DFX_OK;
     };
-    if (int rc = mf ? (out_i16 ? go(dfx_k_synthesis<true, true, true>) : go(dfx_k_synthesis<true, false, true>))
-               : ip ? (out_i16 ? go(dfx_k_synthesis<true, true>) : go(dfx_k_synthesis<true, false>))
+    if (int rc = ip ? (out_i16 ? go(dfx_k_synthesis<true, true>) : go(dfx_k_synthesis<true, false>))
                     : (out_i16 ? go(dfx_k_synthesis<false, true>) : go(dfx_k_synthesis<false, false>)))
         return rc;
     DFX_LAUNCH_CHECK();
@@ -584,9 +576,6 @@ int dfx_launch_synthesis_rows(const dfx_state *st, const float *spec, int64_t sp
     const int64_t want = dfx_ceil_div((int64_t)dfx_env_num_cus() * 3, B);
     int64_t segs = want < 1 ? 1 : want;
     if (segs > chunks / 4) segs = chunks / 4 > 0 ? chunks / 4 : 1;
-    const char *seg_e = getenv("DFX_SYN_SEGS");   // dev / variant test: segments per row (read per launch, like DFX_FFT_IN_PLACE)
-    const int seg_env = seg_e ? atoi(seg_e) : 0;
-    if (seg_env > 0) segs = seg_env < chunks ? seg_env : chunks;
     A.poison = nullptr;
     if (err && poison) {   // the pass's faults so far (every one that can reach this kernel's inputs), as a device word
         dfx_launch(dfx_k_fault_mirror, dim3(1), dim3(1), 0, s, err, poison);
@@ -605,14 +594,11 @@ int dfx_launch_synthesis_rows(const dfx_state *st, const float *spec, int64_t sp
     DfxKScope ks(DFX_K_SYNTHESIS, s);
     auto go = [&](auto kern) { dfx_launch(kern, dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, s, A); };
     if (!with_df) {
-        mf ? (out_i16 ? go(dfx_k_synthesis_rows<0, false, true, true>) : go(dfx_k_synthesis_rows<0, false, false, true>))
-           : (out_i16 ? go(dfx_k_synthesis_rows<0, false, true>) : go(dfx_k_synthesis_rows<0, false, false>));
+        (out_i16 ? go(dfx_k_synthesis_rows<0, false, true>) : go(dfx_k_synthesis_rows<0, false, false>));
     } else if (pf) {
-        mf ? (out_i16 ? go(dfx_k_synthesis_rows<5, true, true, true>) : go(dfx_k_synthesis_rows<5, true, false, true>))
-           : (out_i16 ? go(dfx_k_synthesis_rows<5, true, true>) : go(dfx_k_synthesis_rows<5, true, false>));
+        (out_i16 ? go(dfx_k_synthesis_rows<5, true, true>) : go(dfx_k_synthesis_rows<5, true, false>));
     } else {
-        mf ? (out_i16 ? go(dfx_k_synthesis_rows<5, false, true, true>) : go(dfx_k_synthesis_rows<5, false, false, true>))
-           : (out_i16 ? go(dfx_k_synthesis_rows<5, false, true>) : go(dfx_k_synthesis_rows<5, false, false>));
+        (out_i16 ? go(dfx_k_synthesis_rows<5, false, true>) : go(dfx_k_synthesis_rows<5, false, false>));
     }
     DFX_LAUNCH_CHECK();
     return DFX_OK;

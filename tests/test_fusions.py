@@ -1,6 +1,7 @@
-"""Round-3 fusions of the GRU phase's side work (docs/measurements.md §5f): each fused kernel against the separate kernels it replaces (the switch
-DFX_FUSE_*=0 restores them) and against the oracle, on the DeepFilterNet3 shape whose group structure the fusions are written for, in the
-serial, the event-pipelined and (on the GPU) the persistent form of the GRU phase, with the skip connections that change what is fused."""
+"""The fused kernels of the GRU phase's side work (docs/measurements.md §5f: the fan-outs around the embedding, the ERB decoder tail) against the
+oracle, on the DeepFilterNet3 shape whose group structure the fusions are written for, in the serial, the event-pipelined and (on the GPU) the
+persistent form of the GRU phase, with the skip connections that change what is fused.  (Up to round 5 every fusion also had a switch that
+restored the separate kernels; round 6 removed those switches.)"""
 import numpy as np
 import pytest
 import torch
@@ -27,7 +28,7 @@ def _params(variant: str) -> ModelParams:
 def _run(p, sd, x, env, monkeypatch, pipeline, mask_only=False):
     from deepfilternet_amd.enhance import enhance, init_df
 
-    for k in ("DFX_FUSE_EMB", "DFX_FUSE_TAIL", "DFX_STREAMS", "DFX_GRU_SEQ"):
+    for k in ("DFX_STREAMS", "DFX_GRU_SEQ"):
         monkeypatch.delenv(k, raising=False)
     for kv in env:
         k, v = kv.split("=")
@@ -42,8 +43,7 @@ def _run(p, sd, x, env, monkeypatch, pipeline, mask_only=False):
 
 @pytest.mark.parametrize("form", ["serial", "pipelined", "persistent"])
 @pytest.mark.parametrize("variant", ["df3", "skips", "idskip", "noskip_df", "mask_only"])
-@pytest.mark.parametrize("switch", ["DFX_FUSE_EMB", "DFX_FUSE_TAIL"])
-def test_fused_side_kernels_match_the_separate_ones(backend, switch, variant, form, monkeypatch):
+def test_fused_side_kernels_match_the_oracle_in_every_form_of_the_phase(backend, variant, form, monkeypatch):
     if backend == "emu" and form == "persistent":
         pytest.skip("the persistent GRU launch needs the GPU (the interpreter runs the event form)")
     if emu_subset(backend) and (variant in ("idskip", "noskip_df") or (form == "serial" and variant != "df3")):
@@ -55,11 +55,10 @@ def test_fused_side_kernels_match_the_separate_ones(backend, switch, variant, fo
     B, T = (2, 480 * 9 + 5) if backend == "emu" else ((33, 480 * 70 + 11) if form == "persistent" else (3, 480 * 23 + 5))
     x = torch.from_numpy((0.1 * rng.standard_normal((B, T))).astype(np.float32))
     base = {"serial": ["DFX_STREAMS=0"], "pipelined": ["DFX_GRU_SEQ=0"], "persistent": []}[form]
-    pipe = form == "pipelined" or (form == "persistent" and False)
-    y_fused = _run(p, sd, x, base + [switch + "=1"], monkeypatch, pipe, mask_only)
-    y_sep = _run(p, sd, x, base + [switch + "=0"], monkeypatch, pipe, mask_only)
-    assert rms((y_fused - y_sep).numpy()) < 1e-6, (switch, variant, form)
+    y = _run(p, sd, x, base, monkeypatch, form == "pipelined", mask_only)
+    y_serial = y if form == "serial" else _run(p, sd, x, ["DFX_STREAMS=0"], monkeypatch, False, mask_only)
+    assert rms((y - y_serial).numpy()) < 1e-6, (variant, form)
     if not mask_only:   # (the mask-only oracle comparison lives in tests/test_config_options.py)
         rows = slice(0, 2)
         ref = O.enhance(p, {k: torch.as_tensor(v) for k, v in sd.items()}, x[rows].numpy())
-        assert rms(y_fused[rows].numpy() - ref) < 2e-6, (switch, variant, form)
+        assert rms(y[rows].numpy() - ref) < 2e-6, (variant, form)

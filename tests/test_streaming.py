@@ -163,57 +163,33 @@ def test_linear_rolling_spectra_equal_the_ring_form(backend, monkeypatch):
             assert torch.equal(run(env, toggle), ref), (env, toggle)
 
 
-_SWITCH_CHILD = r"""
-import hashlib, sys
-sys.path.insert(0, {repo!r})
-import numpy as np, torch
-from tests.helpers import named_params
-from deepfilternet_amd.enhance import init_df
-from deepfilternet_amd.streaming import DfStream
-p = named_params("df3")
-model, df_state, _, _ = init_df(params=p, epoch="none", seed=11)
-hop, T = 480, 40
-rng = np.random.default_rng(3)
-x = torch.from_numpy((0.1 * rng.standard_normal((3, hop * T))).astype(np.float32)).cuda()
-rt = DfStream(model, df_state, streams=3, max_frames=3)
-cuts = [1] * 9 + [2, 3, 1, 1, 1, 2] + [1] * (T - 19)      # one hop per call (the step kernels), several (their states are rebuilt), one again
-out, pos = [], 0
-for n in cuts:
-    out.append(rt.process(x[:, pos * hop:(pos + n) * hop]).cpu())
-    pos += n
-y = torch.cat(out, dim=1).numpy()
-assert np.isfinite(y).all() and float(np.abs(y).max()) > 1e-4
-np.save({out!r}, y)
-"""
-
-
 @pytest.mark.gpu
-def test_one_hop_kernels_agree_with_the_general_path(tmp_path):
+def test_one_hop_kernels_agree_with_the_general_path(hip_backend):
     """A call of ONE hop takes kernels of its own (dfx_k_gru_step_h3, dfx_k_df_convp_step with its pending sums, window updates on the DF
-    branch's streams, feature windows in linear buffers).  Each can be switched off by an environment variable that is read once per
-    process: the same stream — one hop per call, then calls of several hops (after which the one-hop state is rebuilt), then one hop
-    again — run in child processes agrees with the default to rounding (df_convp's sums are taken in a different order) or to the bit
-    (pure data movement)."""
-    import os
-    import subprocess
-    import sys
+    branch's streams, feature windows in linear buffers); calls of several hops take the general windowed forward pass (and rebuild the one-hop
+    state behind them).  The same streams cut into single hops, into calls of three hops, and mixed agree to rounding (df_convp's sums are taken
+    in a different order).  (Up to round 5 each one-hop form also had an environment switch; removed in round 6.)"""
+    from deepfilternet_amd.enhance import init_df
+    from deepfilternet_amd.streaming import DfStream
 
-    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = named_params("df3")
+    model, df_state, _, _ = init_df(params=p, epoch="none", seed=12)
+    hop, T = 480, 48
+    x = torch.from_numpy((0.1 * np.random.default_rng(3).standard_normal((3, hop * T))).astype(np.float32)).cuda()
 
-    def run(tag, env):
-        out = str(tmp_path / f"{tag}.npy")
-        e = dict(os.environ, **env)
-        r = subprocess.run([sys.executable, "-c", _SWITCH_CHILD.format(repo=repo, out=out)], env=e, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        return np.load(out)
+    def run(cuts):
+        rt = DfStream(model, df_state, streams=3, max_frames=3)
+        out, pos = [], 0
+        for n in cuts:
+            out.append(rt.process(x[:, pos * hop:(pos + n) * hop]).cpu())
+            pos += n
+        assert pos == T
+        return torch.cat(out, dim=1).numpy()
 
-    ref = run("default", {})
-    scale = float(np.sqrt((ref ** 2).mean()))
-    for tag, env, exact in (("side", {"DFX_STREAM_SIDE": "0"}, True), ("linfeat", {"DFX_STREAM_LINEAR_FEAT": "0"}, True),
-                            ("ct4", {"DFX_GRU_STEP_CT": "4"}, True), ("ct2", {"DFX_GRU_STEP_CT": "2"}, True),
-                            ("pend", {"DFX_STREAM_C0RING": "0"}, False), ("step", {"DFX_STREAM_STEP": "0"}, False)):
-        y = run(tag, env)
-        if exact:
-            assert np.array_equal(y, ref), tag
-        else:
-            assert rms(y - ref) < 2e-6 * max(scale, 1e-3) + 1e-7, (tag, rms(y - ref), scale)
+    ones = run([1] * T)
+    threes = run([3] * (T // 3))
+    mixed = run([1] * 9 + [2, 3, 1, 1, 1, 2] + [1] * (T - 19))
+    scale = float(np.sqrt((ones ** 2).mean()))
+    assert np.isfinite(ones).all() and float(np.abs(ones).max()) > 1e-4
+    for tag, y in (("threes", threes), ("mixed", mixed)):
+        assert rms(y - ones) < 2e-6 * max(scale, 1e-3) + 1e-7, (tag, rms(y - ones), scale)
