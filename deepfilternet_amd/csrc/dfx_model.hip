@@ -99,6 +99,7 @@ struct GlinW {
 #define DFX_LANE_EVENTS 12
 #define DFX_THROTTLE_MIN_FRAMES 16384   /* passes of at least this many frames are enqueued one at a time (dfx_model::ev_pass) */
 #define DFX_MAX_GRU_LAYERS 8   /* all GRU layers of the three stacks */
+static_assert(DFX_MAX_GRU_LAYERS == DFX_GS_MAX_LAYERS, "the host lays the XCD / progress tables out with the stride the kernels index them with");
 #define DFX_MAX_TCHUNKS 16     /* time chunks of the layer-pipelined GRU phase */
 #define DFX_SEQ_GMAX 64        /* most 16-clip groups per layer the persistent GRU phase is used for (all workgroups must be co-resident) */
 struct DfxLane;

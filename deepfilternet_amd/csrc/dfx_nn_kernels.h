@@ -4434,7 +4434,8 @@ __global__ void __launch_bounds__(512, 1) dfx_k_proj_follow(DfxPfArgs A) {
     DFX_DYN_SMEM(dfx_h8, ws);  // [2][CH8]
     const int f = (int)(blockIdx.x / (unsigned)A.groups);
     if (f >= A.nf) return;
-    const int g = dfx_xcd_claim(A.xrec, A.xtag, A.groups, A.xclaim ? A.xclaim + 8 * f : nullptr, (int)(blockIdx.x % (unsigned)A.groups), A.spin_limit, A.err,
+    const int g = dfx_xcd_claim(A.xrec ? (A.xcons[f] ? A.xcons[f] : A.xrec) : nullptr, A.xtag, A.groups,   // (the registrations of the layer this follower FEEDS: with groups % 8 != 0 the layers sit on different XCDs)
+                                A.xclaim ? A.xclaim + 8 * f : nullptr, (int)(blockIdx.x % (unsigned)A.groups), A.spin_limit, A.err,
                                 reinterpret_cast<int *>(ws));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
     constexpr int nchunks = N / (16 * CT);
@@ -4585,7 +4586,8 @@ __global__ void __launch_bounds__(512, 1) dfx_k_proj_follow_x32(DfxPfArgs A) {
     DFX_DYN_SMEM(float, wsf);  // [2][CHF]
     const int f = (int)(blockIdx.x / (unsigned)A.groups);
     if (f >= A.nf) return;
-    const int g = dfx_xcd_claim(A.xrec, A.xtag, A.groups, A.xclaim ? A.xclaim + 8 * f : nullptr, (int)(blockIdx.x % (unsigned)A.groups), A.spin_limit, A.err,
+    const int g = dfx_xcd_claim(A.xrec ? (A.xcons[f] ? A.xcons[f] : A.xrec) : nullptr, A.xtag, A.groups,   // (the registrations of the layer this follower FEEDS: with groups % 8 != 0 the layers sit on different XCDs)
+                                A.xclaim ? A.xclaim + 8 * f : nullptr, (int)(blockIdx.x % (unsigned)A.groups), A.spin_limit, A.err,
                                 reinterpret_cast<int *>(wsf));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, jl = lane & 15;
     constexpr int nchunks = N / (16 * CT);

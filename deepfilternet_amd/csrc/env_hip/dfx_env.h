@@ -119,8 +119,19 @@ static __device__ __forceinline__ void dfx_split8_g(const float *x, dfx_h8 &hi, 
     dfx_split8(x, hi, lo);
 }
 // D[i][j] += sum_k A[i][k] B[k][j]; lane l: A row i = l&15, B col j = l&15, both hold k = 8*(l>>4) .. +7; D: col = l&15, row = 4*(l>>4)+r
+// DFX_MFMA_K16 (build option, tools/dev/build_variant.sh k16 -DDFX_MFMA_K16=1): the same contraction as two v_mfma_f32_16x16x16_f16 (the gfx90a
+// operation: k-slots 0..3 of every lane group, then 4..7).  Why one would want it: on the MI355X this was developed on the double-rate operation
+// disturbs the packed fp32 arithmetic of OTHER kernels that run on the GPU at the same time (docs/measurements.md R6.1); the
+// gfx90a operation does not.  Twice the matrix-op count; the results differ from the default build's in the last bits (order of the fp32 sums).
 static __device__ __forceinline__ f32x4 dfx_mfma_16x16x32_f16(dfx_h8 a, dfx_h8 b, f32x4 c) {
+#ifdef DFX_MFMA_K16
+    typedef _Float16 dfx_h4v __attribute__((ext_vector_type(4)));
+    const dfx_h4v a0 = {a[0], a[1], a[2], a[3]}, a1 = {a[4], a[5], a[6], a[7]}, b0 = {b[0], b[1], b[2], b[3]}, b1 = {b[4], b[5], b[6], b[7]};
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, b0, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a1, b1, c, 0, 0, 0);
+#else
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
 }
 
 // compiler fences used by the hand-scheduled kernels

@@ -124,8 +124,13 @@ def _read_riff(file: str, frame_offset: int = 0, num_frames: int = -1):
             cid, size = ch[:4], struct.unpack("<I", ch[4:])[0]
             if cid == b"fmt ":
                 body = f.read(size + (size & 1))
+                if size < 16 or len(body) < 16:
+                    raise RuntimeError(f"{file}: 'fmt ' chunk of {size} bytes (16 at least)")
                 tag, nch, rate, _, align, bits = struct.unpack("<HHIIHH", body[:16])
                 if tag == _WAVE_EXTENSIBLE and size >= 26:
+                    valid = struct.unpack("<H", body[18:20])[0]   # wValidBitsPerSample: fewer than the container (24 in 32) would need their own scale
+                    if valid not in (0, bits):
+                        raise RuntimeError(f"{file}: extensible WAVE with {valid} valid bits in {bits}-bit containers is not decoded")
                     tag = struct.unpack("<H", body[24:26])[0]
                 fmt = (tag, nch, rate, align, bits)
             elif cid == b"data":
@@ -193,6 +198,8 @@ def load_audio(file: str, sr: Optional[int] = None, verbose: bool = True, **kwar
     off = kwargs.get("frame_offset", 0)
     if frames is not None and frames > 0 and sr is not None:
         _, rate0, _, _, _ = _read_riff(file, 0, 1)        # io.py:46-47 scales num_frames by the file's own rate: read it first
+        if rate0 < sr:   # (the reference's `num_frames *= rate0 // sr` is 0 there, which torchaudio reads as "nothing": say so instead of loading the whole file)
+            raise RuntimeError(f"{file}: num_frames with a file rate ({rate0}) below the requested rate ({sr}) selects no frames (df/io.py:46-47)")
         frames *= rate0 // sr
     x, orig_sr, n, bits, is_float = _read_riff(file, off, frames)
     ch = x.shape[1]

@@ -51,19 +51,26 @@ def test_stft_kernels_beside_another_handles_passes(hip_backend):
         except Exception as e:   # noqa: BLE001
             errs.append(repr(e))
 
+    import time
+
     t = threading.Thread(target=other)
     t.start()
-    wrong = 0
+    t0 = time.time()
+    while passes[0] < 2 and not errs and time.time() - t0 < 120:   # (the other handle's first pass carries its handshake and allocations)
+        time.sleep(0.01)
+    wrong = n = 0
+    p0 = passes[0]
     with torch.cuda.stream(torch.cuda.Stream()):
-        for _ in range(300):
+        while (n < 300 or passes[0] - p0 < 8) and n < 5000 and not errs:
             got = df_features(x, st, p.nb_df)
             wrong += int(not all(torch.equal(a, b) for a, b in zip(got, ref)))
+            n += 1
     stop.set()
     t.join()
     torch.cuda.synchronize()
     assert not errs, errs
-    assert passes[0] >= 8, passes   # the other handle really ran beside the loop
-    assert wrong == 0, f"{wrong} of 300 STFT results differ from the result computed alone"
+    assert passes[0] - p0 >= 8, (passes, n)   # the other handle really ran beside the loop
+    assert wrong == 0, f"{wrong} of {n} STFT results differ from the result computed alone"
 
 
 def test_two_handles_share_the_process_streams_and_both_run_the_persistent_phase(hip_backend):
