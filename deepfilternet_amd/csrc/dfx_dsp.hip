@@ -546,7 +546,7 @@ int dfx_launch_synthesis(const dfx_state *st, const float *spec, int64_t B, int6
 bool dfx_synthesis_rows_ok(const dfx_state *st, bool with_df, int order, int nb_df, int nbands) {
     if (!st || st->N != 960 || st->hop != 480 || !ana_in_place(st)) return false;
     if (!with_df) return true;
-    return (order == 5 || nb_df == 0) && nb_df >= 0 && nb_df <= 128 && nbands <= 64 && st->bands && st->bands->F == 481;
+    return (order == 5 || nb_df == 0) && nb_df >= 0 && nb_df <= 128 && nb_df % 2 == 0 && nbands <= 64 && st->bands && st->bands->F == 481;   // (bins in pairs: 16-byte accesses)
 }
 int dfx_launch_synthesis_rows(const dfx_state *st, const float *spec, int64_t spec_stride, const float *coefs, int nb_df, int order, int lookahead,
                               const float *gains, float pf_beta, float atten_lim, int64_t B, int64_t Tf, float *out, int64_t out_stride,
@@ -565,6 +565,8 @@ int dfx_launch_synthesis_rows(const dfx_state *st, const float *spec, int64_t sp
     A.tw = st->d_tw;
     A.B = B, A.Tf = Tf;
     A.spec_stride = spec_stride > 0 ? spec_stride : st->N / 2 + 1;
+    if (with_df && ((A.spec_stride & 1) || ((uintptr_t)spec & 15) || ((uintptr_t)coefs & 15)))
+        DFX_FAIL(DFX_ERR_UNSUPPORTED, "synthesis_rows: the deep-filter form reads bins in pairs (rows of an even stride, 16-byte aligned arrays)");
     A.out_stride = out_stride, A.out_skip = out_skip, A.out_len = out_len;
     const int64_t nd = coefs ? nb_df : 0;
     A.cs_b = (int64_t)order * Tf * nd, A.cs_n = Tf * nd, A.cs_t = nd;   // [B, O, Tf, nd] (DFX_COEF_BOTF)

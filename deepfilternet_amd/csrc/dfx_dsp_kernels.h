@@ -1899,59 +1899,63 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, MF ? 4 : ((PF && I16) ? 5 : 6
                 if (k <= M) bufA[k] = v[u];
             }
         } else {
-            // ---- the deep-filter bins (k < nb_df <= 128: passes 0 and 1): taps n read frame t + n - toff, zero outside the clip
+            // ---- two neighbouring bins per lane, 16-byte accesses (round 6: was one bin per lane and round, twice the vector-memory and LDS
+            // instructions; the arithmetic per bin is the same expression: same bits).  Round 0 = bins 2 l, 2 l + 1 < 128: the deep-filter bins
+            // (k < nb_df <= 128, an even count): taps n read frame t + n - toff, zero outside the clip; the rest of the round and rounds 1-3: band gains only.
+            const f32x4 *Xr4 = reinterpret_cast<const f32x4 *>(Xr);
             const float2 *Cr = A.coefs + b * A.cs_b + t * A.cs_t;
-            float2 x01[2], cf[2][O], xt[2][O];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int k = lr + u * DFX_DSP_TEAM;
+            float gv = 1.f;
+            if (A.gains) gv = A.gains[(b * A.Tf + t) * A.nb + (lr < A.nb ? lr : 0)];
+            auto gain2 = [&](int k, float &g0, float &g1) {   // (every lane takes part in the shuffles)
+                g0 = g1 = 1.f;
+                if (A.gains) g0 = __shfl(gv, (int)b2b[k <= M ? k : 0]), g1 = __shfl(gv, (int)b2b[k + 1 <= M ? k + 1 : 0]);
+            };
+            {
+                const int k = 2 * lr;
                 const bool df = k < A.nbdf;
-                x01[u] = Xr[k];
+                const f32x4 x01 = Xr4[lr];
+                f32x4 cf[O], xt[O];
+                const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int n = 0; n < O; ++n) {
                     const int64_t tt = t + n - toff;
-                    cf[u][n] = df ? Cr[n * A.cs_n + k] : make_float2(0.f, 0.f);
-                    xt[u][n] = (df && tt >= 0 && tt < A.Tf) ? A.spec[(b * A.Tf + tt) * A.spec_stride + k] : make_float2(0.f, 0.f);
+                    cf[n] = df ? *reinterpret_cast<const f32x4 *>(Cr + n * A.cs_n + k) : z4;
+                    xt[n] = (df && tt >= 0 && tt < A.Tf) ? *reinterpret_cast<const f32x4 *>(A.spec + (b * A.Tf + tt) * A.spec_stride + k) : z4;
                 }
-            }
-            float gv = 1.f;
-            if (A.gains) gv = A.gains[(b * A.Tf + t) * A.nb + (lr < A.nb ? lr : 0)];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int k = lr + u * DFX_DSP_TEAM;
-                float g = 1.f;
-                if (A.gains) g = __shfl(gv, (int)b2b[k]);   // (every lane takes part)
-                float2 y;
-                if (k < A.nbdf) {
-                    float re = 0.f, im = 0.f;
+                float g0, g1;
+                gain2(k, g0, g1);
+                float2 y0, y1;
+                if (df) {
+                    float re0 = 0.f, im0 = 0.f, re1 = 0.f, im1 = 0.f;
 #pragma unroll
                     for (int n = 0; n < O; ++n) {
-                        const float2 c = cf[u][n], xx = xt[u][n];
-                        re += xx.x * c.x - xx.y * c.y;
-                        im += xx.x * c.y + xx.y * c.x;
+                        re0 += xt[n][0] * cf[n][0] - xt[n][1] * cf[n][1];
+                        im0 += xt[n][0] * cf[n][1] + xt[n][1] * cf[n][0];
+                        re1 += xt[n][2] * cf[n][2] - xt[n][3] * cf[n][3];
+                        im1 += xt[n][2] * cf[n][3] + xt[n][3] * cf[n][2];
                     }
-                    y = make_float2(re, im);
+                    y0 = make_float2(re0, im0), y1 = make_float2(re1, im1);
                 } else {
-                    y = make_float2(x01[u].x * g, x01[u].y * g);
+                    y0 = make_float2(x01[0] * g0, x01[1] * g0), y1 = make_float2(x01[2] * g1, x01[3] * g1);
                 }
-                if (PF) y = dfx_dfa_finish(y, x01[u], A.pf_beta, A.atten_lim);
-                bufA[k] = y;
+                if (PF) y0 = dfx_dfa_finish(y0, make_float2(x01[0], x01[1]), A.pf_beta, A.atten_lim), y1 = dfx_dfa_finish(y1, make_float2(x01[2], x01[3]), A.pf_beta, A.atten_lim);
+                *reinterpret_cast<f32x4 *>(bufA + k) = f32x4{y0.x, y0.y, y1.x, y1.y};
             }
-            // ---- the other bins: band gains only
-            float2 v[6];
+            f32x4 v[3];
 #pragma unroll
-            for (int u = 2; u < 8; ++u) {
-                const int k = lr + u * DFX_DSP_TEAM;
-                v[u - 2] = Xr[k <= M ? k : lr];
+            for (int u = 1; u < 4; ++u) {
+                const int k = 2 * lr + 128 * u;
+                v[u - 1] = Xr4[k <= M ? lr + 64 * u : lr];
             }
 #pragma unroll
-            for (int u = 2; u < 8; ++u) {
-                const int k = lr + u * DFX_DSP_TEAM, kk = k <= M ? k : lr;
-                float g = 1.f;
-                if (A.gains) g = __shfl(gv, (int)b2b[kk]);
-                float2 y = make_float2(v[u - 2].x * g, v[u - 2].y * g);
-                if (PF) y = dfx_dfa_finish(y, v[u - 2], A.pf_beta, A.atten_lim);
-                if (k <= M) bufA[k] = y;
+            for (int u = 1; u < 4; ++u) {
+                const int k = 2 * lr + 128 * u;
+                float g0, g1;
+                gain2(k, g0, g1);
+                const f32x4 x = v[u - 1];
+                float2 y0 = make_float2(x[0] * g0, x[1] * g0), y1 = make_float2(x[2] * g1, x[3] * g1);
+                if (PF) y0 = dfx_dfa_finish(y0, make_float2(x[0], x[1]), A.pf_beta, A.atten_lim), y1 = dfx_dfa_finish(y1, make_float2(x[2], x[3]), A.pf_beta, A.atten_lim);
+                if (k <= M) *reinterpret_cast<f32x4 *>(bufA + k) = f32x4{y0.x, y0.y, y1.x, y1.y};   // (k = M: the slot behind the Nyquist bin takes the row's pad bin; nobody reads it)
             }
         }
     }
@@ -1990,50 +1994,35 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, MF ? 4 : ((PF && I16) ? 5 : 6
     DFX_WAVE_SYNC();
     if constexpr (MF) dfx_fft480_mfma(bufA, mfr, a3s, lane, active);
     else dfx_fft480_ip<+1>(bufA, tw, lane, active);
-    {   // apply_window_in_place (lib.rs:406): the interleaved (re, im) pairs of z ARE the time samples
-        constexpr int NQ = N / 4, NR4 = (NQ + DFX_DSP_TEAM - 1) / DFX_DSP_TEAM;
-        f32x4 *xq = reinterpret_cast<f32x4 *>(bufA);
-        const f32x4 *wq = reinterpret_cast<const f32x4 *>(win);
-        f32x4 xv[NR4], wv[NR4];
-        int lw = lane;
-        DFX_OPAQUE(lw);
-        if (active) {
-#pragma unroll
-            for (int r = 0; r < NR4; ++r) {
-                const int i = lw + r * DFX_DSP_TEAM, ii = i < NQ ? i : 0;
-                xv[r] = xq[ii], wv[r] = wq[ii];
-            }
-#pragma unroll
-            for (int r = 0; r < NR4; ++r) {
-                const int i = lw + r * DFX_DSP_TEAM;
-                if (i < NQ) xq[i] = xv[r] * wv[r];
-            }
-        }
-    }
     __syncthreads();
-    // overlap-add: output frame tf = t0 + j gets the second half of frame tf - 1 (the previous wave's buffer, or the carry) + the first
-    // half of frame tf; the second half of the chunk's last frame becomes the next item's carry
+    // apply_window_in_place (lib.rs:406: the interleaved (re, im) pairs of z ARE the time samples) and the overlap-add in one pass over the LDS:
+    // output frame tf = t0 + j gets the windowed second half of frame tf - 1 (the previous wave's buffer, or the carry, which is stored windowed) +
+    // the windowed first half of frame tf; the second half of the chunk's last frame becomes the next item's carry.  (Round 6: the window was a
+    // pass of its own over every frame buffer — 8 LDS reads + 4 writes of 16 bytes per lane and frame; the products are the same roundings:
+    // __fmul_rn / __fadd_rn, never contracted.)
     constexpr int HQ = HOP / 4;
     const float *cin = carry + par * HOP;
     float *cout = carry + (par ^ 1) * HOP;
+    auto wmul = [](const f32x4 x, const f32x4 w) -> f32x4 { return f32x4{__fmul_rn(x[0], w[0]), __fmul_rn(x[1], w[1]), __fmul_rn(x[2], w[2]), __fmul_rn(x[3], w[3])}; };
     if (!pro) {
         for (int q = threadIdx.x; q < NTM * HQ; q += DFX_DSP_THREADS) {
             const int j = q / HQ, i = (q - j * HQ) << 2;
             const int64_t tf = t0 + j;
             if (tf >= A.Tf) break;
             const float *fr = reinterpret_cast<const float *>(bufs + (size_t)j * BUF);
-            const f32x4 cur = *reinterpret_cast<const f32x4 *>(fr + i);
+            const f32x4 cur = wmul(*reinterpret_cast<const f32x4 *>(fr + i), *reinterpret_cast<const f32x4 *>(win + i));
             f32x4 v = cur;
             if (tf > 0) {
-                const f32x4 old = j > 0 ? *reinterpret_cast<const f32x4 *>(fr - 2 * BUF + HOP + i) : *reinterpret_cast<const f32x4 *>(cin + i);
-                v = cur + old;
+                const f32x4 old = j > 0 ? wmul(*reinterpret_cast<const f32x4 *>(fr - 2 * BUF + HOP + i), *reinterpret_cast<const f32x4 *>(win + HOP + i))
+                                        : *reinterpret_cast<const f32x4 *>(cin + i);
+                v = f32x4{__fadd_rn(cur[0], old[0]), __fadd_rn(cur[1], old[1]), __fadd_rn(cur[2], old[2]), __fadd_rn(cur[3], old[3])};
             }
             dfx_store_out4<I16>(A.out, b * A.out_stride, tf * HOP + i - A.out_skip, A.out_len, v);
         }
     }
     if (threadIdx.x < HQ && t0 + NTM - 1 < A.Tf) {
         const float *fr = reinterpret_cast<const float *>(bufs + (size_t)(NTM - 1) * BUF);
-        *reinterpret_cast<f32x4 *>(cout + 4 * threadIdx.x) = *reinterpret_cast<const f32x4 *>(fr + HOP + 4 * threadIdx.x);
+        *reinterpret_cast<f32x4 *>(cout + 4 * threadIdx.x) = wmul(*reinterpret_cast<const f32x4 *>(fr + HOP + 4 * threadIdx.x), *reinterpret_cast<const f32x4 *>(win + HOP + 4 * threadIdx.x));
     }
     par ^= 1;
     __syncthreads();  // the frame buffers are rewritten by the next item, which also reads the carry just stored

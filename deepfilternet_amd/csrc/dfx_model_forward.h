@@ -959,7 +959,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
     // enhance(): the deep filter + gains are applied on the way into the inverse transform (dfx_k_synthesis_rows): spec_e never exists.
     // DFX_FUSE_DFA=0: dfx_k_df_apply_rows -> spec_e -> dfx_k_synthesis (the stand-alone deep-filter kernel stays the API of
     // dfx_model_forward / dfx_df_apply and the roofline kernel of bench.py)
-    if (fin && m->fuse_dfa && dfx_synthesis_rows_ok(fin->st, true, O, run_df ? Fd : 0, E) && bands == fin->st->bands) {
+    if (fin && m->fuse_dfa && dfx_synthesis_rows_ok(fin->st, true, O, run_df ? Fd : 0, E) && bands == fin->st->bands && sstride % 2 == 0 && sstride > 0) {
         if ((rc = dfx_launch_synthesis_rows(fin->st, spec, sstride, run_df ? coefs : nullptr, run_df ? Fd : 0, O, c.df_lookahead, mask,
                                             c.mask_pf ? c.pf_beta : 0.f, atten_lim, B, T, fin->y, fin->out_stride, fin->out_skip, fin->out_len, fin_s, fin->out_i16, m->d_err, m->d_sync ? m->d_sync + 14 : nullptr)))   // (d_sync[14]: a spare word of the flag block)
             return rc;
