@@ -321,7 +321,7 @@ def main() -> None:
     def pmc_traffic(fname, tool):
         """HBM bytes per launch from the newest committed PMC measurement of this kernel at this size (PMC passes need rocprofv3 around the
         process: tools/gpu_pmc_*.sh; separate --pmc passes for FETCH_SIZE and WRITE_SIZE, calibrated on pure-stream dispatches)."""
-        for rnd in ("r05_", "r04_", "r03_", ""):
+        for rnd in ("r06_", "r05_", "r04_", "r03_", ""):
             tpath = os.path.join(REPO, "profiles", rnd + fname)
             if not os.path.exists(tpath):
                 continue
