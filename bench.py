@@ -195,7 +195,10 @@ def main() -> None:
     # two hipEventRecords per step on the launch stream around the finishing kernel; everything else untouched.  (Since round 3 enhance()
     # applies the deep filter + gains INSIDE the ISTFT kernel, dfx_k_synthesis_rows; with DFX_FUSE_DFA=0 the separate deep-filter kernel is
     # timed in the loop as before.)
-    _lib.prof_enable(["dfx_k_df_apply", "dfx_k_synthesis"])
+    loop_kernels = ["dfx_k_df_apply", "dfx_k_synthesis"]
+    if os.environ.get("DFX_BENCH_PROF_ANALYSIS") == "1":   # dev (tools/gpu_ab.sh): the STFT kernel of the loop too
+        loop_kernels.append("dfx_k_analysis")
+    _lib.prof_enable(loop_kernels)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -214,6 +217,7 @@ def main() -> None:
     loop_prof = _lib.prof_read()
     dfa_ms, dfa_n = loop_prof.get("dfx_k_df_apply", (0.0, 0))
     syn_ms, syn_n = loop_prof.get("dfx_k_synthesis", (0.0, 0))
+    ana_ms, ana_n = loop_prof.get("dfx_k_analysis", (0.0, 0))
     _lib.prof_enable(None)
     per_rank_ms = [dt / args.steps * 1e3]
     if dist is not None:
@@ -284,6 +288,7 @@ def main() -> None:
         print(json.dumps({"metric": "48 kHz audio frames/sec (hop=480), DeepFilterNet3 enhance()", "value": frames / dt, "unit": "frames/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                           "dfa_in_loop_ms": (dfa_ms / dfa_n) if dfa_n else None, "finish_in_loop_ms": (syn_ms / syn_n) if syn_n else None,
+                          "analysis_in_loop_ms": (ana_ms / ana_n) if ana_n else None,
                           "gru_phase_form": "persistent" if gru_persistent else "events", "exact_fp32": bool(model.query(model.Q_EXACT_FP32))}), flush=True)
         if dist is not None:
             dist.barrier()
