@@ -47,6 +47,7 @@ struct dfx_bands {
     unsigned char *d_bin2band = nullptr;  // [F]
     int *d_segtab = nullptr;              // [3*64 + nb + 1] the bands cut into <= 64 near-equal segments (dfx_k_analysis), nseg > 0
     int nseg = 0;
+    int segcap = 0, segparts = 0;         // longest segment in bins, most segments of one band
 };
 
 struct dfx_state {

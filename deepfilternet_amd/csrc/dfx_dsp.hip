@@ -177,6 +177,8 @@ extern "C" int dfx_bands_create(const uint64_t *widths, int nb, dfx_bands **out)
         }
         segtab[3 * 64 + nb] = ns;
         b->nseg = ns;
+        b->segcap = (int)cap;
+        for (int i = 0; i < nb; ++i) b->segparts = std::max(b->segparts, (int)((widths[i] + cap - 1) / cap));
     }
     int rc = upload(&b->d_start, start.data(), start.size());
     if (!rc) rc = upload(&b->d_invw, invw.data(), invw.size());
@@ -390,7 +392,7 @@ static bool ana_in_place(const dfx_state *st) {
 static constexpr bool fft_mfma(const dfx_state *) { return false; }
 static size_t ana_smem_bytes(const dfx_state *st, bool mf = false) {
     return (mf ? (size_t)DFX_MFFT_FRAG3 * 64 * 16 : 0) + (size_t)st->N * 12 + (size_t)DFX_DSP_TEAMS * (ana_in_place(st) ? (size_t)DFX_FFT480_BUF : 2 * (size_t)(st->plan.M + 2)) * 8 +   // (in place: one buffer per frame, with room for the transform's padded layout)
-           (((size_t)(2 * st->nb + 1 + 3 * 64 + st->nb + 1 + DFX_DSP_TEAMS * 64) * 4 + 15) & ~(size_t)15);   // + the ERB band tables and segment sums (analysis)
+           (((size_t)(2 * st->nb + 1 + 3 * 64 + st->nb + 1 + DFX_DSP_TEAMS * 64) * 4 + 15) & ~(size_t)15) + 64;   // + the ERB band tables and segment sums (analysis), and slack behind the last frame's sums (fixed-trip reads)
 }
 static int grid_for(int64_t work_groups, int per_cu = 8) {
     const int64_t cap = (int64_t)dfx_env_num_cus() * per_cu;  // memory-bound: ~8 workgroups per CU, grid-stride the rest
@@ -414,6 +416,10 @@ int dfx_launch_analysis(const dfx_state *st, const float *x, int64_t B, int64_t 
         A.band_invw = st->bands->d_invw;
         A.seg_tab = st->bands->d_segtab;
         A.nseg = st->bands->nseg;   // (0: more than 64 bands, one lane per band)
+        // fixed-trip band sums: a lane reads up to segcap (rounded up to 6) power values from its segment's start, `part` up to segparts (rounded up
+        // to 4) from its band's first segment — inside the frame buffer / the slack behind `part` for the shipped band layouts
+        A.segcap = st->bands->segcap <= 24 && st->bands->segparts <= 12 ? st->bands->segcap : 0;
+        A.segparts = st->bands->segparts;
         A.B = B;
         A.Tf = Tf;
         A.x_stride = x_stride;
@@ -574,8 +580,8 @@ int dfx_launch_synthesis_rows(const dfx_state *st, const float *spec, int64_t sp
     A.pf_beta = pf_beta, A.atten_lim = atten_lim;
     // segments: enough (row, segment) items to fill three workgroups per CU, but at least 4 chunks each (a segment that does not start a
     // row costs one extra single-wave item)
-    const int64_t chunks = dfx_ceil_div(Tf, DFX_DSP_TEAMS);
-    const int64_t want = dfx_ceil_div((int64_t)dfx_env_num_cus() * 3, B);
+    const int64_t chunks = dfx_ceil_div(Tf, DFX_SYNR_TEAMS);
+    const int64_t want = dfx_ceil_div((int64_t)dfx_env_num_cus() * DFX_SYNR_WGS, B);
     int64_t segs = want < 1 ? 1 : want;
     if (segs > chunks / 4) segs = chunks / 4 > 0 ? chunks / 4 : 1;
     A.poison = nullptr;
@@ -589,12 +595,12 @@ int dfx_launch_synthesis_rows(const dfx_state *st, const float *spec, int64_t sp
     int64_t nblk = B * A.segs;
     const bool mf = fft_mfma(st);
     A.mfft = mf ? st->d_mfft + DFX_MFFT_TABLE_BYTES : nullptr;   // (the inverse tables)
-    const int64_t cap = (int64_t)dfx_env_num_cus() * (mf ? 2 : 3);
+    const int64_t cap = (int64_t)dfx_env_num_cus() * (mf ? 2 : DFX_SYNR_WGS);
     if (nblk > cap) nblk = cap;
     const size_t smem = mf ? DFX_SYNR_SMEM_MF : DFX_SYNR_SMEM;
     const bool pf = pf_beta > 0.f || atten_lim > 0.f;
     DfxKScope ks(DFX_K_SYNTHESIS, s);
-    auto go = [&](auto kern) { dfx_launch(kern, dim3((unsigned)nblk), dim3(DFX_DSP_THREADS), smem, s, A); };
+    auto go = [&](auto kern) { dfx_launch(kern, dim3((unsigned)nblk), dim3(DFX_SYNR_THREADS), smem, s, A); };
     if (!with_df) {
         (out_i16 ? go(dfx_k_synthesis_rows<0, false, true>) : go(dfx_k_synthesis_rows<0, false, false>));
     } else if (pf) {

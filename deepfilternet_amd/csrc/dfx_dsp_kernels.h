@@ -175,6 +175,48 @@ static __device__ __forceinline__ void dfx_dft5(float2 x0, float2 x1, float2 x2,
     y3 = dfx_csub(m2, n2);
 }
 
+// 8-, 6- and 10-point transforms on values: the butterflies of the 8 x 6 x 10 plan (dfx_fft_pass_ip, dfx_fft480_t)
+template <int SG>
+static __device__ __forceinline__ void dfx_bfly8(const float2 *a, float2 *o) {
+    // even / odd inputs through two 4-point transforms, then o[k] = E[k] + W8^k O[k], o[k + 4] = E[k] - W8^k O[k]
+    float2 e0, e1, e2, e3, q0, q1, q2, q3;
+    dfx_dft4<SG>(a[0], a[2], a[4], a[6], e0, e1, e2, e3);
+    dfx_dft4<SG>(a[1], a[3], a[5], a[7], q0, q1, q2, q3);
+    q1 = dfx_mul_w8<SG, 1>(q1);
+    q2 = dfx_mul_sgi<SG>(q2);
+    q3 = dfx_mul_w8<SG, 3>(q3);
+    o[0] = dfx_cadd(e0, q0), o[4] = dfx_csub(e0, q0);
+    o[1] = dfx_cadd(e1, q1), o[5] = dfx_csub(e1, q1);
+    o[2] = dfx_cadd(e2, q2), o[6] = dfx_csub(e2, q2);
+    o[3] = dfx_cadd(e3, q3), o[7] = dfx_csub(e3, q3);
+}
+template <int SG>
+static __device__ __forceinline__ void dfx_bfly10(const float2 *a, float2 *o) {
+    // 10 = 2 x 5 with coprime factors: input n = 5 n1 + 2 n2, output k = 5 k1 + 6 k2 (mod 10), no twiddles in between
+    dfx_dft5<SG>(dfx_cadd(a[0], a[5]), dfx_cadd(a[2], a[7]), dfx_cadd(a[4], a[9]), dfx_cadd(a[6], a[1]), dfx_cadd(a[8], a[3]), o[0], o[6], o[2], o[8], o[4]);
+    dfx_dft5<SG>(dfx_csub(a[0], a[5]), dfx_csub(a[2], a[7]), dfx_csub(a[4], a[9]), dfx_csub(a[6], a[1]), dfx_csub(a[8], a[3]), o[5], o[1], o[7], o[3], o[9]);
+}
+template <int SG>
+static __device__ __forceinline__ void dfx_bfly6(const float2 *a, float2 *o) {
+    // 6 = 2 x 3 with coprime factors: input n = 3 n1 + 2 n2, output k = 3 k1 + 4 k2 (mod 6) need no twiddles between the
+    // three 2-point and the two 3-point transforms
+    const float2 s0 = dfx_cadd(a[0], a[3]), t0 = dfx_csub(a[0], a[3]);
+    const float2 s1 = dfx_cadd(a[2], a[5]), t1 = dfx_csub(a[2], a[5]);
+    const float2 s2 = dfx_cadd(a[4], a[1]), t2 = dfx_csub(a[4], a[1]);
+    auto dft3 = [](float2 x0, float2 x1, float2 x2, float2 &y0, float2 &y1, float2 &y2) {
+        const float2 sm = dfx_cadd(x1, x2), d = dfx_csub(x1, x2);
+        const float2 mm = make_float2(x0.x - 0.5f * sm.x, x0.y - 0.5f * sm.y);
+        float2 jd = dfx_mul_sgi<SG>(d);
+        jd.x *= 0.86602540378443864676f;
+        jd.y *= 0.86602540378443864676f;
+        y0 = dfx_cadd(x0, sm);
+        y1 = dfx_cadd(mm, jd);
+        y2 = dfx_csub(mm, jd);
+    };
+    dft3(s0, s1, s2, o[0], o[4], o[2]);   // k1 = 0: k = 4 k2 mod 6
+    dft3(t0, t1, t2, o[3], o[1], o[5]);   // k1 = 1: k = 3 + 4 k2 mod 6
+}
+
 // The same pass IN PLACE: a lane first reads the inputs of all its butterflies, then writes their outputs.  One team is one wave, whose
 // lanes run in lockstep and whose LDS accesses complete in program order, so every read of the pass precedes every write (the wave-level
 // sync between the two halves costs nothing on the GPU and is what the CPU interpreter needs).  Same butterflies, same twiddles, same
@@ -246,41 +288,11 @@ static __device__ __forceinline__ void dfx_fft_pass_ip(float2 *x, const float2 *
                 o[2] = dfx_csub(t0, t2);
                 o[3] = dfx_csub(t1, t3);
             } else if constexpr (R == 8) {
-                // even / odd inputs through two 4-point transforms, then o[k] = E[k] + W8^k O[k], o[k + 4] = E[k] - W8^k O[k]
-                float2 e0, e1, e2, e3, q0, q1, q2, q3;
-                dfx_dft4<SG>(a[r][0], a[r][2], a[r][4], a[r][6], e0, e1, e2, e3);
-                dfx_dft4<SG>(a[r][1], a[r][3], a[r][5], a[r][7], q0, q1, q2, q3);
-                q1 = dfx_mul_w8<SG, 1>(q1);
-                q2 = dfx_mul_sgi<SG>(q2);
-                q3 = dfx_mul_w8<SG, 3>(q3);
-                o[0] = dfx_cadd(e0, q0), o[4] = dfx_csub(e0, q0);
-                o[1] = dfx_cadd(e1, q1), o[5] = dfx_csub(e1, q1);
-                o[2] = dfx_cadd(e2, q2), o[6] = dfx_csub(e2, q2);
-                o[3] = dfx_cadd(e3, q3), o[7] = dfx_csub(e3, q3);
+                dfx_bfly8<SG>(a[r], o);
             } else if constexpr (R == 10) {
-                // 10 = 2 x 5 with coprime factors: input n = 5 n1 + 2 n2, output k = 5 k1 + 6 k2 (mod 10), no twiddles in between
-                dfx_dft5<SG>(dfx_cadd(a[r][0], a[r][5]), dfx_cadd(a[r][2], a[r][7]), dfx_cadd(a[r][4], a[r][9]), dfx_cadd(a[r][6], a[r][1]),
-                             dfx_cadd(a[r][8], a[r][3]), o[0], o[6], o[2], o[8], o[4]);
-                dfx_dft5<SG>(dfx_csub(a[r][0], a[r][5]), dfx_csub(a[r][2], a[r][7]), dfx_csub(a[r][4], a[r][9]), dfx_csub(a[r][6], a[r][1]),
-                             dfx_csub(a[r][8], a[r][3]), o[5], o[1], o[7], o[3], o[9]);
+                dfx_bfly10<SG>(a[r], o);
             } else if constexpr (R == 6) {
-                // 6 = 2 x 3 with coprime factors: input n = 3 n1 + 2 n2, output k = 3 k1 + 4 k2 (mod 6) need no twiddles between the
-                // three 2-point and the two 3-point transforms
-                const float2 s0 = dfx_cadd(a[r][0], a[r][3]), t0 = dfx_csub(a[r][0], a[r][3]);
-                const float2 s1 = dfx_cadd(a[r][2], a[r][5]), t1 = dfx_csub(a[r][2], a[r][5]);
-                const float2 s2 = dfx_cadd(a[r][4], a[r][1]), t2 = dfx_csub(a[r][4], a[r][1]);
-                auto dft3 = [](float2 x0, float2 x1, float2 x2, float2 &y0, float2 &y1, float2 &y2) {
-                    const float2 sm = dfx_cadd(x1, x2), d = dfx_csub(x1, x2);
-                    const float2 mm = make_float2(x0.x - 0.5f * sm.x, x0.y - 0.5f * sm.y);
-                    float2 jd = dfx_mul_sgi<SG>(d);
-                    jd.x *= 0.86602540378443864676f;
-                    jd.y *= 0.86602540378443864676f;
-                    y0 = dfx_cadd(x0, sm);
-                    y1 = dfx_cadd(mm, jd);
-                    y2 = dfx_csub(mm, jd);
-                };
-                dft3(s0, s1, s2, o[0], o[4], o[2]);   // k1 = 0: k = 4 k2 mod 6
-                dft3(t0, t1, t2, o[3], o[1], o[5]);   // k1 = 1: k = 3 + 4 k2 mod 6
+                dfx_bfly6<SG>(a[r], o);
             } else {  // R == 5
                 const float c1 = 0.30901699437494742410f, s1 = 0.95105651629515357212f;
                 const float c2 = -0.80901699437494742410f, s2 = 0.58778525229247312917f;
@@ -350,6 +362,117 @@ static __device__ __forceinline__ void dfx_fft480_ip(float2 *x, const float2 *tw
     DFX_OPAQUE(l);
     dfx_fft_pass_ip<5, SG, 480, 5, 96>(x, tw, l, active);
 #endif
+}
+
+// dfx_fft480_t (round 6): the 8 x 6 x 10 plan of dfx_fft480_ip written out for the two kernels of enhance()'s batch path — same butterflies,
+// same passes, same padded layout — with everything a pass needs besides its data at `lane-dependent base + constant`:
+//   * the twiddles of a pass come from tables laid out FOR that pass (DfxTw480: t1[jj][lane] = the factors of outputs 2 jj + 1, 2 jj + 2 of lane's
+//     butterfly in the first pass, t2[jj][p] those of the second), read with conflict-free 16-byte accesses — the generic pass computes seven and
+//     ten table indices j * p * stride per frame, each a quarter-rate 32-bit multiply (the counters of round 6, profiles/r06_pmc_stft_before.txt:
+//     the STFT kernels are bound by the VALU, ~890 instructions per frame of which barely half are arithmetic);
+//   * element and slot indices are shifts and adds of the lane index (9 l, l + (l >> 3), q + 54 p).
+// Lanes beyond a pass's last butterfly read in-range slots and drop them.  tw480_fill builds the tables from the length-960 table.
+#define DFX_TW480_T1 256                      /* f32x4 entries: [4][64] */
+#define DFX_TW480_T2 32                       /* f32x4 entries: [3][10] (+ 2 pad) */
+#define DFX_TW480_BYTES ((DFX_TW480_T1 + DFX_TW480_T2) * 16)
+static __device__ __forceinline__ void dfx_tw480_fill(f32x4 *t1, f32x4 *t2, const float2 *tw_global, int tid, int nthreads) {
+    for (int i = tid; i < DFX_TW480_T1 + 30; i += nthreads) {
+        int k0, k1;
+        if (i < DFX_TW480_T1) {
+            const int jj = i >> 6, l = i & 63;
+            k0 = (2 * (2 * jj + 1) * l) % 960, k1 = jj < 3 ? (2 * (2 * jj + 2) * l) % 960 : 0;
+        } else {
+            const int e = i - DFX_TW480_T1, jj = e / 10, p = e - jj * 10;
+            k0 = 16 * (2 * jj + 1) * p, k1 = 16 * (2 * jj + 2) * p;
+        }
+        const float2 a = tw_global[k0], b = tw_global[k1];
+        (i < DFX_TW480_T1 ? t1[i] : t2[i - DFX_TW480_T1]) = f32x4{a.x, a.y, b.x, b.y};
+    }
+}
+template <int SG>
+static __device__ __forceinline__ float2 dfx_tw_mul(float2 o, const f32x4 w, int half) {   // o * w (forward) or o * conj(w) (inverse)
+    float2 wj = half ? make_float2(w[2], w[3]) : make_float2(w[0], w[1]);
+    if (SG > 0) wj.y = -wj.y;
+    return dfx_cmul(o, wj);
+}
+template <int SG>
+static __device__ __forceinline__ void dfx_fft480_t(float2 *x, const f32x4 *t1, const f32x4 *t2, int lane, bool active) {
+    {   // ---- pass 1: 60 butterflies of radix 8, element l + 60 j (natural layout) -> slot 9 l + j (padded)
+        int l = lane;
+        DFX_OPAQUE(l);
+        float2 a[8];
+        f32x4 w[4];
+        {   // (an idle wave reads its own buffer too: values that are defined on one path only would be zero-filled on the other)
+            const float2 *rp = x + l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = rp[60 * j];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) w[jj] = t1[jj * 64 + l];
+        }
+        DFX_WAVE_SYNC();
+        if (active && l < 60) {
+            float2 o[8];
+            dfx_bfly8<SG>(a, o);
+            float2 *wp = x + ((l << 3) + l);
+            wp[0] = o[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) wp[j] = dfx_tw_mul<SG>(o[j], w[(j - 1) >> 1], (j - 1) & 1);
+        }
+        DFX_WAVE_SYNC();
+    }
+    {   // ---- pass 2: 80 butterflies of radix 6 (b = 8 p + q; the second round: b = 64 + l for l < 16), slot b + (b >> 3) + 90 j -> slot q + 54 p + 9 j
+        int l = lane;
+        DFX_OPAQUE(l);
+        float2 a[2][6];
+        f32x4 w[2][3];
+        const int l1 = l & 15, p0 = l >> 3, p1 = l1 >> 3;
+        {
+            const float2 *r0 = x + l + p0, *r1 = x + 72 + l1 + p1;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) a[0][j] = r0[90 * j];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) a[1][j] = r1[90 * j];
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) w[0][jj] = t2[jj * 10 + p0], w[1][jj] = t2[jj * 10 + 8 + p1];
+        }
+        DFX_WAVE_SYNC();
+        if (active) {
+            float2 o[6];
+            dfx_bfly6<SG>(a[0], o);
+            float2 *wp = x + (l & 7) + DFX_MUL24(p0, 54);
+            wp[0] = o[0];
+#pragma unroll
+            for (int j = 1; j < 6; ++j) wp[9 * j] = dfx_tw_mul<SG>(o[j], w[0][(j - 1) >> 1], (j - 1) & 1);
+            if (l < 16) {
+                dfx_bfly6<SG>(a[1], o);
+                wp = x + 432 + (l & 7) + DFX_MUL24(p1, 54);
+                wp[0] = o[0];
+#pragma unroll
+                for (int j = 1; j < 6; ++j) wp[9 * j] = dfx_tw_mul<SG>(o[j], w[1][(j - 1) >> 1], (j - 1) & 1);
+            }
+        }
+        DFX_WAVE_SYNC();
+    }
+    {   // ---- pass 3: 48 butterflies of radix 10, slot q + (q >> 3) + 54 j (padded) -> element q + 48 j (natural layout), no twiddles
+        int l = lane;
+        DFX_OPAQUE(l);
+        float2 a[10];
+        {
+            const int q = l < 48 ? l : 47;
+            const float2 *rp = x + q + (q >> 3);
+#pragma unroll
+            for (int j = 0; j < 10; ++j) a[j] = rp[54 * j];
+        }
+        DFX_WAVE_SYNC();
+        if (active && l < 48) {
+            float2 o[10];
+            dfx_bfly10<SG>(a, o);
+            float2 *wp = x + l;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) wp[48 * j] = o[j];
+        }
+        DFX_WAVE_SYNC();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -574,6 +697,7 @@ struct DfxAnaArgs {
     const int *seg_tab;     // [3*64 + nb + 1] band sums on all 64 lanes (dfx_bands_create): start bin, bins, 1/width (float bits) of each
                             // segment, then the first segment of every band; used when nseg > 0
     int nseg;
+    int segcap = 0, segparts = 0;   // longest segment / most segments of a band when the fixed-trip band sums may be used (dfx_launch_analysis), else 0
     int64_t B, Tf, x_stride;
     int64_t x_len;        // samples that exist per row; positions >= x_len read as 0 (enhance()'s F.pad(audio, (0, n_fft)) without a copy)
     int64_t spec_stride;  // row stride of spec in complex elements (>= F; the engine pads odd F to even so rows are 16-byte aligned)
@@ -620,24 +744,35 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? (MF ? 4 : 6) : 4) dfx_k_
     }
     // twiddles + window: every load of a pass is issued before the first LDS store (a load -> store loop waits out one memory
     // latency per iteration; the compiler does not batch across a runtime trip count)
+    // T480 (the 480-point plan on the vector pipe): the table area holds the per-pass tables of dfx_fft480_t and, behind them, the post-pass
+    // factors tp[k] = exp(-2 pi i k / N) * wnorm / 2 for k <= M / 2 (6.5 of the 7.5 KB of the plain table)
+    constexpr bool T480 = IP && !MF;
+    f32x4 *t1 = reinterpret_cast<f32x4 *>(smem), *t2 = t1 + DFX_TW480_T1;
+    float2 *tp = reinterpret_cast<float2 *>(smem + DFX_TW480_BYTES);   // [M / 2 + 1] (T480)
+    const float hnorm = 0.5f * A.wnorm;
     for (int i0 = threadIdx.x; i0 < N; i0 += 4 * DFX_DSP_THREADS) {
         float2 tv[4];
         float wv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + u * DFX_DSP_THREADS;
-            tv[u] = i < N ? A.tw[i] : make_float2(0.f, 0.f);
+            tv[u] = i < N && (!T480 || i <= 240) ? A.tw[i] : make_float2(0.f, 0.f);
             wv[u] = i < N ? A.window[i] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + u * DFX_DSP_THREADS;
             if (i < N) {
-                tw[i] = tv[u];
+                if constexpr (T480) {
+                    if (i <= 240) tp[i] = make_float2(tv[u].x * hnorm, tv[u].y * hnorm);
+                } else {
+                    tw[i] = tv[u];
+                }
                 win[i] = wv[u];
             }
         }
     }
+    if constexpr (T480) dfx_tw480_fill(t1, t2, A.tw, (int)threadIdx.x, DFX_DSP_THREADS);
     DfxMfftRegs mfr;
     if constexpr (MF) {
         for (int i = threadIdx.x; i < DFX_MFFT_FRAG3 * 64; i += DFX_DSP_THREADS) a3s[i] = reinterpret_cast<const dfx_h8 *>(A.mfft)[DFX_MFFT_FRAG1 * 64 + i];
@@ -704,7 +839,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? (MF ? 4 : 6) : 4) dfx_k_
         int pws = 1;            // stride of pw in floats
         if constexpr (IP) {
             if constexpr (MF) dfx_fft480_mfma(bufA, mfr, a3s, lane, active);
-            else dfx_fft480_ip<-1>(bufA, tw, lane, active);
+            else dfx_fft480_t<-1>(bufA, t1, t2, lane, active);
             // real post-pass on the pairs (k, M-k): both bins of a pair need Z[k] and Z[M-k] and nothing else, so a lane that owns the pair
             // can put |X|^2 of the two bins back into the .x halves of the two slots it has just read (pw stride 2 floats; slot M takes
             // the Nyquist bin)
@@ -713,33 +848,34 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? (MF ? 4 : 6) : 4) dfx_k_
             if (active) {
                 float2 *out = A.spec + (b * A.Tf + t) * A.spec_stride;
                 if (lane == 0 && A.spec_stride > F) out[F] = make_float2(0.f, 0.f);  // the pad bin of an aligned row
-                auto bin = [&](float2 zk, float2 zc, float2 twk) -> float2 {
-                    // E = (Z[k] + conj(Z[M-k]))/2 ; O = (Z[k] - conj(Z[M-k]))/(2i) ; X[k] = E + exp(-2*pi*i*k/N) * O
-                    const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);
-                    const float dr = 0.5f * (zk.x - zc.x), di = 0.5f * (zk.y + zc.y);
-                    const float2 tt = dfx_cmul(make_float2(di, -dr), twk);
-                    return make_float2((er + tt.x) * A.wnorm, (ei + tt.y) * A.wnorm);
-                };
+                // E = (Z[k] + conj(Z[M-k]))/2 ; O = (Z[k] - conj(Z[M-k]))/(2i) ; X[k] = (E + exp(-2*pi*i*k/N) * O) * wnorm.  The two bins of a pair share
+                // E and O up to signs and exp(-2 pi i (M - k) / N) = -conj(exp(-2 pi i k / N)): with tt = (Z[k].y + Z[M-k].y, Z[M-k].x - Z[k].x) * tp[k],
+                // X[k] = ((er, ei) * wnorm / 2) + tt and X[M-k] = ((er, -ei) * wnorm / 2) + (-tt.x, tt.y) — 12 operations per pair where the two
+                // separate evaluations took 28 (the halves are exact: only the scaled factor and the fused multiply-adds round differently)
                 // (every LDS read of the pass before its first LDS store, as in the transform's passes)
                 constexpr int MI = 480, NPR = (MI / 2 + DFX_DSP_TEAM) / DFX_DSP_TEAM;
-                float2 za[NPR], zb[NPR], ta[NPR], tb[NPR];
+                float2 za[NPR], zb[NPR], ta[NPR];
                 int lp = lane;
                 DFX_OPAQUE(lp);
 #pragma unroll
                 for (int i = 0; i < NPR; ++i) {
                     const int k = lp + i * DFX_DSP_TEAM, kk = k <= MI / 2 ? k : 0, kc = MI - kk;
                     za[i] = Z[kk], zb[i] = Z[kk == 0 ? 0 : kc];   // partner bin (k = 0: the Nyquist bin M, both from Z[0])
-                    ta[i] = tw[kk], tb[i] = tw[kc];
+                    if constexpr (T480) ta[i] = tp[kk];
+                    else ta[i] = make_float2(tw[kk].x * hnorm, tw[kk].y * hnorm);
                 }
 #pragma unroll
                 for (int i = 0; i < NPR; ++i) {
                     const int k = lp + i * DFX_DSP_TEAM, kc = MI - k;
                     if (k > MI / 2) continue;
-                    const float2 Xa = bin(za[i], zb[i], ta[i]);
+                    const float er = za[i].x + zb[i].x, ei = za[i].y - zb[i].y;
+                    const float dr = za[i].x - zb[i].x, di = za[i].y + zb[i].y;
+                    const float2 tt = dfx_cmul(make_float2(di, -dr), ta[i]);
+                    const float2 Xa = make_float2(fmaf(er, hnorm, tt.x), fmaf(ei, hnorm, tt.y));
                     out[k] = Xa;
                     float pa = __fadd_rn(__fmul_rn(Xa.x, Xa.x), __fmul_rn(Xa.y, Xa.y)), pb = 0.f;
                     if (kc != k) {
-                        const float2 Xb = bin(zb[i], za[i], tb[i]);
+                        const float2 Xb = make_float2(fmaf(er, hnorm, -tt.x), fmaf(-ei, hnorm, tt.y));
                         out[kc] = Xb;
                         pb = __fadd_rn(__fmul_rn(Xb.x, Xb.x), __fmul_rn(Xb.y, Xb.y));
                     }
@@ -771,7 +907,44 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? (MF ? 4 : 6) : 4) dfx_k_
         }
         if (A.erb_db) {
             DFX_WAVE_SYNC();
-            if (A.nseg > 0) {
+            if (A.nseg > 0 && A.segcap > 0) {
+                // The same segment sums with FIXED trip counts (round 6): every lane reads segcap values from `segment start + constant` and adds
+                // the ones inside its segment (the rest are in-range slots of the frame buffer), the 1/width factor once per segment; the band's lane
+                // then adds at most segparts segment sums the same way.  No per-element index clamps, predicated reads or loop-carried
+                // addresses: ~90 vector instructions per frame where the loops below take ~230 (a quarter of the kernel, which is VALU-bound).
+                int le = lane;
+                DFX_OPAQUE(le);
+                const int n = segs[DFX_DSP_TEAM + le];   // (0 for lanes beyond the last segment: the table is zero-filled)
+                const float kk = __int_as_float(segs[2 * DFX_DSP_TEAM + le]);
+                const float *pp = pw + pws * segs[le];
+                float acc = 0.f;
+                for (int j0 = 0; j0 < A.segcap; j0 += 6) {
+                    float pv[6];
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) pv[u] = pp[pws * u];
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) acc = __fadd_rn(acc, j0 + u < n ? pv[u] : 0.f);
+                    pp += 6 * pws;
+                }
+                if (active) part[le] = __fmul_rn(acc, kk);
+                DFX_WAVE_SYNC();
+                {
+                    const int *bseg = segs + 3 * DFX_DSP_TEAM;
+                    const int lb = le < A.nb ? le : 0;
+                    const int g0 = bseg[lb], cnt = bseg[lb + 1] - g0;
+                    const float *qq = part + g0;
+                    float tot = 0.f;
+                    for (int u0 = 0; u0 < A.segparts; u0 += 4) {
+                        float pv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) pv[u] = qq[u];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) tot = __fadd_rn(tot, u0 + u < cnt ? pv[u] : 0.f);
+                        qq += 4;
+                    }
+                    if (active && le < A.nb) A.erb_db[(b * A.Tf + t) * A.nb + le] = log10f(tot + 1e-10f) * 10.f;
+                }
+            } else if (A.nseg > 0) {
                 // compute_band_corr (lib.rs:280-295): acc += |X|^2 * (1/width) over the bins of a band.  The bands are cut into at most 64
                 // segments of near-equal length (11 bins at 48 kHz, where the widest band has 67): every lane sums one segment, bins in
                 // ascending order, then the lane of a band adds its segments in ascending order.  (One lane per band, as below, makes the
@@ -1830,20 +2003,29 @@ struct DfxSynRowsArgs {
     const unsigned char *mfft = nullptr;   // MF instances: the inverse tables of dfx_fft480_mfma
     const unsigned int *poison = nullptr;  // device word, non-zero: a kernel of this pass raised a fault — store NaN (16-bit PCM: zeros); dfx_k_fault_mirror
 };
-#define DFX_SYNR_SMEM ((size_t)960 * 12 + (size_t)DFX_DSP_TEAMS * DFX_FFT480_BUF * 8 + (size_t)2 * 480 * 4 + 512)
-#define DFX_SYNR_SMEM_MF (DFX_SYNR_SMEM + (size_t)DFX_MFFT_FRAG3 * 64 * 16)
+// eight frames per chunk = eight waves per workgroup, three workgroups per CU (six waves per SIMD).  Round 6 measured the other shapes the LDS admits
+// (same bits): 4 waves x 5 workgroups 0.66 ms, 6 x 4 0.61, 4 x 4 0.54 against 0.52 — the kernel wants FEW, LONG streams (a chunk reads 31 KB of
+// spectrum rows and 6 KB of each tap's coefficients in one piece); profiles/r06_stft_variants.log
+#define DFX_SYNR_TEAMS 8
+#define DFX_SYNR_WPS 6
+#define DFX_SYNR_WGS 3
+#define DFX_SYNR_THREADS (DFX_DSP_TEAM * DFX_SYNR_TEAMS)
+#define DFX_SYNR_TAB 6560  /* per-pass twiddle tables (DFX_TW480_BYTES) + the pre-pass factors [241] */
+#define DFX_SYNR_SMEM ((size_t)DFX_SYNR_TAB + 960 * 4 + (size_t)DFX_SYNR_TEAMS * DFX_FFT480_BUF * 8 + (size_t)2 * 480 * 4 + 496)
+#define DFX_SYNR_SMEM_MF ((size_t)960 * 12 + (size_t)DFX_SYNR_TEAMS * DFX_FFT480_BUF * 8 + (size_t)2 * 480 * 4 + 496 + (size_t)DFX_MFFT_FRAG3 * 64 * 16)
 
 template <int O, bool PF, bool I16 = false, bool MF = false>
-__global__ void __launch_bounds__(DFX_DSP_THREADS, MF ? 4 : ((PF && I16) ? 5 : 6)) dfx_k_synthesis_rows(DfxSynRowsArgs A) {   // (post-filter + 16-bit output: two registers over the budget of six waves per SIMD)
-    constexpr int M = 480, N = 960, HOP = 480, NTM = DFX_DSP_TEAMS, BUF = DFX_FFT480_BUF;
+__global__ void __launch_bounds__(DFX_SYNR_THREADS, MF ? 4 : ((PF && I16 && DFX_SYNR_WPS == 6) ? 5 : DFX_SYNR_WPS)) dfx_k_synthesis_rows(DfxSynRowsArgs A) {   // (post-filter + 16-bit output: two registers over the budget of six waves per SIMD)
+    constexpr int M = 480, N = 960, HOP = 480, NTM = DFX_SYNR_TEAMS, BUF = DFX_FFT480_BUF;
+    constexpr size_t TAB = MF ? (size_t)N * 8 : (size_t)DFX_SYNR_TAB;
     DFX_DYN_SMEM(unsigned char, smem);
     float2 *tw = reinterpret_cast<float2 *>(smem);
-    float *win = reinterpret_cast<float *>(smem + (size_t)N * 8);
-    dfx_h8 *a3s = reinterpret_cast<dfx_h8 *>(smem + (size_t)N * 12);    // [8][64] (MF)
-    float2 *bufs = reinterpret_cast<float2 *>(smem + (size_t)N * 12 + (MF ? (size_t)DFX_MFFT_FRAG3 * 64 * 16 : 0));
+    float *win = reinterpret_cast<float *>(smem + TAB);
+    dfx_h8 *a3s = reinterpret_cast<dfx_h8 *>(smem + TAB + (size_t)N * 4);    // [8][64] (MF)
+    float2 *bufs = reinterpret_cast<float2 *>(smem + TAB + (size_t)N * 4 + (MF ? (size_t)DFX_MFFT_FRAG3 * 64 * 16 : 0));
     DfxMfftRegs mfr;
     if constexpr (MF) {
-        for (int i = threadIdx.x; i < DFX_MFFT_FRAG3 * 64; i += DFX_DSP_THREADS) a3s[i] = reinterpret_cast<const dfx_h8 *>(A.mfft)[DFX_MFFT_FRAG1 * 64 + i];
+        for (int i = threadIdx.x; i < DFX_MFFT_FRAG3 * 64; i += DFX_SYNR_THREADS) a3s[i] = reinterpret_cast<const dfx_h8 *>(A.mfft)[DFX_MFFT_FRAG1 * 64 + i];
         dfx_mfft_load(mfr, A.mfft, (int)(threadIdx.x % DFX_DSP_TEAM));
     }
     float *carry = reinterpret_cast<float *>(bufs + (size_t)NTM * BUF);   // [2][HOP]
@@ -1851,25 +2033,31 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, MF ? 4 : ((PF && I16) ? 5 : 6
     const int team = dfx_wave_uniform(threadIdx.x / DFX_DSP_TEAM), lane = threadIdx.x % DFX_DSP_TEAM;
     float2 *bufA = bufs + (size_t)team * BUF;
     const bool poisoned = A.poison && *A.poison != 0u;   // (a faulted pass: the window table carries NaN, so every sample of the pass does)
-    for (int i0 = threadIdx.x; i0 < N; i0 += 4 * DFX_DSP_THREADS) {   // all loads of a pass before its first LDS store
+    // T480: the table area holds the per-pass tables of dfx_fft480_t and, behind them, the pre-pass factors tp[k] = exp(-2 pi i k / N), k <= M / 2
+    constexpr bool T480 = !MF;
+    f32x4 *t1 = reinterpret_cast<f32x4 *>(smem), *t2 = t1 + DFX_TW480_T1;
+    float2 *tp = T480 ? reinterpret_cast<float2 *>(smem + DFX_TW480_BYTES) : tw;   // [M / 2 + 1]
+    for (int i0 = threadIdx.x; i0 < N; i0 += 4 * DFX_SYNR_THREADS) {   // all loads of a pass before its first LDS store
         float2 tv[4];
         float wv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * DFX_DSP_THREADS;
-            tv[u] = i < N ? A.tw[i] : make_float2(0.f, 0.f);
+            const int i = i0 + u * DFX_SYNR_THREADS;
+            tv[u] = i < N && (!T480 || i <= M / 2) ? A.tw[i] : make_float2(0.f, 0.f);
             wv[u] = i < N ? (poisoned ? __builtin_nanf("") : A.window[i]) : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * DFX_DSP_THREADS;
+            const int i = i0 + u * DFX_SYNR_THREADS;
             if (i < N) {
-                tw[i] = tv[u];
+                if (!T480 || i <= M / 2) tp[i] = tv[u];
                 win[i] = wv[u];
             }
         }
     }
-    if (O > 0 && A.gains && threadIdx.x <= M) b2b[threadIdx.x] = A.bin2band[threadIdx.x];
+    if constexpr (T480) dfx_tw480_fill(t1, t2, A.tw, (int)threadIdx.x, DFX_SYNR_THREADS);
+    if (O > 0 && A.gains)
+        for (int i = threadIdx.x; i <= M; i += DFX_SYNR_THREADS) b2b[i] = A.bin2band[i];
     __syncthreads();
     const int toff = O - 1 - A.lookahead;
     const int64_t chunks = (A.Tf + NTM - 1) / NTM;
@@ -1960,40 +2148,36 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, MF ? 4 : ((PF && I16) ? 5 : 6
         }
     }
     DFX_WAVE_SYNC();
-    // E' = X[k] + conj(X[M-k]) ; O' = conj(w^k) * (X[k] - conj(X[M-k])) ; Z[k] = E' + i*O'   (in place on the pairs (k, M-k), see dfx_k_synthesis)
-    auto zbin_w = [&](int k, float2 xk, float2 xm, float2 w) -> float2 {
-        if (k == 0) {  // C2R ignores imag(DC) and imag(Nyquist)
-            xk.y = 0.f;
-            xm.y = 0.f;
-        }
-        const float er = xk.x + xm.x, ei = xk.y - xm.y;
-        w.y = -w.y;
-        const float2 o = dfx_cmul(make_float2(xk.x - xm.x, xk.y + xm.y), w);
-        return make_float2(er - o.y, ei + o.x);
-    };
+    // E' = X[k] + conj(X[M-k]) ; O' = conj(w^k) * (X[k] - conj(X[M-k])) ; Z[k] = E' + i*O'   (in place on the pairs (k, M-k), see dfx_k_synthesis).
+    // The two bins of a pair share E' and O' up to signs, and w^(M-k) = -conj(w^k): with o = (X[k] - conj(X[M-k])) * conj(w^k),
+    // Z[k] = (er - o.y, ei + o.x) and Z[M-k] = (er + o.y, -ei + o.x) — 12 operations per pair instead of 20 (round 6; the sums are the same, only
+    // the partner's factor is no longer a table entry of its own)
     if (active) {
         constexpr int NPR = (M / 2 + DFX_DSP_TEAM) / DFX_DSP_TEAM;
-        float2 xa[NPR], xb[NPR], wa[NPR], wb[NPR];
+        float2 xa[NPR], xb[NPR], wa[NPR];
         int lp = lane;
         DFX_OPAQUE(lp);
 #pragma unroll
         for (int i = 0; i < NPR; ++i) {
             const int k = lp + i * DFX_DSP_TEAM, kk = k <= M / 2 ? k : 0, kc = M - kk;
             xa[i] = bufA[kk], xb[i] = bufA[kc];
-            wa[i] = tw[kk], wb[i] = tw[kc];
+            wa[i] = tp[kk];
         }
 #pragma unroll
         for (int i = 0; i < NPR; ++i) {
             const int k = lp + i * DFX_DSP_TEAM, kc = M - k;
             if (k > M / 2) continue;
-            const float2 za = zbin_w(k, xa[i], xb[i], wa[i]);
-            if (k != 0 && kc != k) bufA[kc] = zbin_w(kc, xb[i], xa[i], wb[i]);
-            bufA[k] = za;
+            float2 xk = xa[i], xm = xb[i];
+            if (k == 0) xk.y = 0.f, xm.y = 0.f;   // C2R ignores imag(DC) and imag(Nyquist)
+            const float er = xk.x + xm.x, ei = xk.y - xm.y;
+            const float2 o = dfx_cmul(make_float2(xk.x - xm.x, xk.y + xm.y), make_float2(wa[i].x, -wa[i].y));
+            if (k != 0 && kc != k) bufA[kc] = make_float2(er + o.y, o.x - ei);
+            bufA[k] = make_float2(er - o.y, ei + o.x);
         }
     }
     DFX_WAVE_SYNC();
     if constexpr (MF) dfx_fft480_mfma(bufA, mfr, a3s, lane, active);
-    else dfx_fft480_ip<+1>(bufA, tw, lane, active);
+    else dfx_fft480_t<+1>(bufA, t1, t2, lane, active);
     __syncthreads();
     // apply_window_in_place (lib.rs:406: the interleaved (re, im) pairs of z ARE the time samples) and the overlap-add in one pass over the LDS:
     // output frame tf = t0 + j gets the windowed second half of frame tf - 1 (the previous wave's buffer, or the carry, which is stored windowed) +
@@ -2005,7 +2189,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, MF ? 4 : ((PF && I16) ? 5 : 6
     float *cout = carry + (par ^ 1) * HOP;
     auto wmul = [](const f32x4 x, const f32x4 w) -> f32x4 { return f32x4{__fmul_rn(x[0], w[0]), __fmul_rn(x[1], w[1]), __fmul_rn(x[2], w[2]), __fmul_rn(x[3], w[3])}; };
     if (!pro) {
-        for (int q = threadIdx.x; q < NTM * HQ; q += DFX_DSP_THREADS) {
+        for (int q = threadIdx.x; q < NTM * HQ; q += DFX_SYNR_THREADS) {
             const int j = q / HQ, i = (q - j * HQ) << 2;
             const int64_t tf = t0 + j;
             if (tf >= A.Tf) break;

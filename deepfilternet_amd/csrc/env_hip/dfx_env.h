@@ -134,6 +134,8 @@ static __device__ __forceinline__ f32x4 dfx_mfma_16x16x32_f16(dfx_h8 a, dfx_h8 b
 #endif
 }
 
+// small index products at the full VALU rate (v_mul_i32_i24; v_mul_lo_u32 issues at a quarter of it)
+#define DFX_MUL24(a, b) __mul24((a), (b))
 // compiler fences used by the hand-scheduled kernels
 #define DFX_OPAQUE(x) asm volatile("" : "+v"(x))
 #define DFX_PIN_AGPR(x) asm volatile("" : "+a"(x))   /* the value lives in an AGPR from here on (matrix-op operands of kernels with one wave per SIMD) */

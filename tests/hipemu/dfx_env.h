@@ -568,6 +568,7 @@ static inline int __all(int pred) { return __ballot(!pred) == 0ull; }
 #define dfx_xcc_id() ((int)(blockIdx.x & 7))
 static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
 
+#define DFX_MUL24(a, b) ((a) * (b))
 #define DFX_OPAQUE(x) asm volatile("" : "+r"(x))
 #define DFX_PIN_AGPR(x) ((void)0)
 #define DFX_SCHED_BARRIER() ((void)0)
