@@ -505,6 +505,7 @@ struct dfx_model {
         int p0_ahead = 3;               // DFX_SEQ_P0_AHEAD
         int tail_every = 1;             // DFX_SEQ_TAIL_EVERY
         int dftail_every = 0;           // DFX_SEQ_DFTAIL_EVERY (0: the rule in forward_impl)
+        bool tail_split = true;         // the ERB decoder's linear_out on a stream of its own beside the decoder tail (round 6; DFX_TAIL_SPLIT=0 in -DDFX_DEV builds)
         int64_t fan_few_rows = 4096;    // DFX_FAN_FEW_ROWS
         int64_t convp_elems = (int64_t)1 << 29;   // DFX_CONVP_ELEMS (test hook)
     } sw;
@@ -1217,6 +1218,16 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
             const char *cel = getenv("DFX_CONVP_ELEMS");   // test hook: the 32-bit-offset split of df_convp at small sizes
             if (cel && atoll(cel) > 0) m->sw.convp_elems = atoll(cel);
         }
+#ifdef DFX_DEV
+        {   // dev A/Bs of the phase's side work (product builds have no such switches)
+            const char *v;
+            if ((v = getenv("DFX_TAIL_SPLIT"))) m->sw.tail_split = v[0] != '0';
+            if ((v = getenv("DFX_SEQ_P0_AHEAD")) && atoi(v) > 0) m->sw.p0_ahead = atoi(v);
+            if ((v = getenv("DFX_SEQ_DFTAIL_EVERY")) && atoi(v) > 0) m->sw.dftail_every = atoi(v);
+            if ((v = getenv("DFX_SEQ_TAIL_EVERY")) && atoi(v) > 0) m->sw.tail_every = atoi(v);
+            if ((v = getenv("DFX_SEQ_CHUNKS")) && atoi(v) > 0) m->sw.chunks = atoi(v);
+        }
+#endif
         {
             const char *tq = getenv("DFX_SEQ_TRACE");
             if (tq && tq[0] == '1') (void)hipMalloc(reinterpret_cast<void **>(&m->d_trace), (size_t)DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX * DFX_GS_MAX_CHUNKS * 3 * 8);

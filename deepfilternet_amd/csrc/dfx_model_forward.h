@@ -705,9 +705,16 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 const int64_t Rk = B * (tb(k + 1) - tb(k0));
                 const DfxRowMap rm = DfxRowMap{T, tb(k + 1) - tb(k0), tb(k0)};
                 int r;
-                if ((r = launch_wait_ge(m, donep(ndec), groups, tgt(k), Eq))) return r;
+                // Round 6: linear_out of chunk k + 1 runs beside the decoder tail of chunk k.  On one stream (wait -> linear_out -> tail: 0.8 ms per
+                // chunk under the phase's load against a chunk every 0.67 ms) the ERB tail fell two chunks behind the chain and ended 1.0 ms after it
+                // (profiles/r06_timeline.txt).  With followers the projection stream of the decoder's second layer has nothing to carry: it takes the
+                // flag wait and linear_out, an event per chunk hands demb's rows over (12.34 -> 12.22 ms per step, same box; the ERB tail now ends
+                // 0.37 ms behind the chain, the three df_out launches that wait for all of df_convp 0.8 ms: profiles/r06_tail_split.log).
+                hipStream_t Gq = (m->sw.tail_split && ndec >= 2 && followed[2]) ? ln->ps[2] : Eq;
+                if ((r = launch_wait_ge(m, donep(ndec), groups, tgt(k), Gq))) return r;
                 if (dfx_dev_skip() & 1) return DFX_OK;
-                if ((r = dec_out_skip(ws + w.py[ndec], Rk, Eq, rm))) return r;
+                if ((r = dec_out_skip(ws + w.py[ndec], Rk, Gq, rm))) return r;
+                if (Gq != Eq && ((r = esig(ln->pev[2][k], Gq)) || (r = ewait(ln->pev[2][k], Eq)))) return r;
                 if (fuse_tail) return launch_erb_tail<C>(m, demb, e3, e2, e1, e0r, mask, Rk, E, Eq, rm, feat_erb, T, featT, Lk);
                 if ((r = launch_pw<C>(DFX_PW_MODE_DW3, m, m->ct3, demb, e3, d3, Rk, E / 4, E / 4, 1, Eq, rm))) return r;
                 if ((r = launch_pw<C>(DFX_PW_MODE_DWT3, m, m->ct2, d3, e2, d2, Rk, E / 4, E / 2, 2, Eq, rm))) return r;
