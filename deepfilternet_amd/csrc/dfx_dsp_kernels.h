@@ -792,6 +792,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? (MF ? 4 : 6) : 4) dfx_k_
             const float *xf = xb + pos0;
             int ll = lane;
             DFX_OPAQUE(ll);   // (addresses recomputed per frame instead of living in registers across the loop: see dfx_fft480_ip)
+            DFX_ASSUME(ll >= 0 && ll < DFX_DSP_TEAM);
             if (pos0 >= 0 && pos0 + N <= A.x_len && (I16 ? (reinterpret_cast<uintptr_t>(xs + pos0) & 3) == 0 : (reinterpret_cast<uintptr_t>(xf) & 7) == 0)) {
                 // interior frame (wave-uniform test; all but the first of a clip and the ones reaching into the implicit zero padding):
                 // 8-byte loads, 8 per lane in flight before the first LDS store (M = 480: one pass) — a load -> store loop would
@@ -857,31 +858,32 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? (MF ? 4 : 6) : 4) dfx_k_
                 float2 za[NPR], zb[NPR], ta[NPR];
                 int lp = lane;
                 DFX_OPAQUE(lp);
+                DFX_ASSUME(lp >= 0 && lp < DFX_DSP_TEAM);
+                // pairs k = lane + 64 i: i < 3 always exist (k <= 191), i = 3 for the lanes with k <= MI / 2 (the others read pair 0 and store nothing);
+                // only the last pair of lane 48 is its own partner (round 6: was a clamp, a k <= MI / 2 test and a partner test in every iteration)
+                const bool last = lp + (NPR - 1) * DFX_DSP_TEAM <= MI / 2;
 #pragma unroll
                 for (int i = 0; i < NPR; ++i) {
-                    const int k = lp + i * DFX_DSP_TEAM, kk = k <= MI / 2 ? k : 0, kc = MI - kk;
-                    za[i] = Z[kk], zb[i] = Z[kk == 0 ? 0 : kc];   // partner bin (k = 0: the Nyquist bin M, both from Z[0])
+                    const int kk = (i < NPR - 1 || last) ? lp + i * DFX_DSP_TEAM : 0, kc = MI - kk;
+                    za[i] = Z[kk], zb[i] = Z[(i == 0 && kk == 0) ? 0 : kc];   // partner bin (k = 0: the Nyquist bin M, both from Z[0])
                     if constexpr (T480) ta[i] = tp[kk];
                     else ta[i] = make_float2(tw[kk].x * hnorm, tw[kk].y * hnorm);
                 }
 #pragma unroll
                 for (int i = 0; i < NPR; ++i) {
                     const int k = lp + i * DFX_DSP_TEAM, kc = MI - k;
-                    if (k > MI / 2) continue;
+                    if (i == NPR - 1 && !last) continue;
                     const float er = za[i].x + zb[i].x, ei = za[i].y - zb[i].y;
                     const float dr = za[i].x - zb[i].x, di = za[i].y + zb[i].y;
                     const float2 tt = dfx_cmul(make_float2(di, -dr), ta[i]);
                     const float2 Xa = make_float2(fmaf(er, hnorm, tt.x), fmaf(ei, hnorm, tt.y));
+                    const float2 Xb = make_float2(fmaf(er, hnorm, -tt.x), fmaf(-ei, hnorm, tt.y));
+                    const float pa = __fadd_rn(__fmul_rn(Xa.x, Xa.x), __fmul_rn(Xa.y, Xa.y)), pb = __fadd_rn(__fmul_rn(Xb.x, Xb.x), __fmul_rn(Xb.y, Xb.y));
+                    if (i < NPR - 1 || kc != k) out[kc] = Xb;
                     out[k] = Xa;
-                    float pa = __fadd_rn(__fmul_rn(Xa.x, Xa.x), __fmul_rn(Xa.y, Xa.y)), pb = 0.f;
-                    if (kc != k) {
-                        const float2 Xb = make_float2(fmaf(er, hnorm, -tt.x), fmaf(-ei, hnorm, tt.y));
-                        out[kc] = Xb;
-                        pb = __fadd_rn(__fmul_rn(Xb.x, Xb.x), __fmul_rn(Xb.y, Xb.y));
-                    }
-                    if (A.erb_db) {
+                    if (A.erb_db) {   // (LDS operations of a wave complete in order: where a pair is its own partner the second store stays)
+                        pw[2 * kc] = pb;
                         pw[2 * k] = pa;
-                        if (kc != k) pw[2 * kc] = pb;
                     }
                 }
             }
@@ -914,6 +916,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? (MF ? 4 : 6) : 4) dfx_k_
                 // addresses: ~90 vector instructions per frame where the loops below take ~230 (a quarter of the kernel, which is VALU-bound).
                 int le = lane;
                 DFX_OPAQUE(le);
+                DFX_ASSUME(le >= 0 && le < DFX_DSP_TEAM);
                 const int n = segs[DFX_DSP_TEAM + le];   // (0 for lanes beyond the last segment: the table is zero-filled)
                 const float kk = __int_as_float(segs[2 * DFX_DSP_TEAM + le]);
                 const float *pp = pw + pws * segs[le];
@@ -951,6 +954,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? (MF ? 4 : 6) : 4) dfx_k_
                 // widest band the length of the whole stage — a third of this kernel's instructions with half of the lanes idle.)
                 int le = lane;
                 DFX_OPAQUE(le);
+                DFX_ASSUME(le >= 0 && le < DFX_DSP_TEAM);
                 const bool mine = active && le < A.nseg;
                 const int s0 = segs[mine ? le : 0], n = mine ? segs[DFX_DSP_TEAM + le] : 0;
                 const float kk = __int_as_float(segs[2 * DFX_DSP_TEAM + (mine ? le : 0)]);
@@ -985,6 +989,7 @@ __global__ void __launch_bounds__(DFX_DSP_THREADS, IP ? (MF ? 4 : 6) : 4) dfx_k_
                 // trips, more than the five passes of the transform together
                 int le = lane;
                 DFX_OPAQUE(le);
+                DFX_ASSUME(le >= 0 && le < DFX_DSP_TEAM);
                 const int s0 = bstart[le], s1 = bstart[le + 1];
                 const float kk = binvw[le];
                 float acc = 0.f;
@@ -2015,7 +2020,7 @@ struct DfxSynRowsArgs {
 #define DFX_SYNR_SMEM_MF ((size_t)960 * 12 + (size_t)DFX_SYNR_TEAMS * DFX_FFT480_BUF * 8 + (size_t)2 * 480 * 4 + 496 + (size_t)DFX_MFFT_FRAG3 * 64 * 16)
 
 template <int O, bool PF, bool I16 = false, bool MF = false>
-__global__ void __launch_bounds__(DFX_SYNR_THREADS, MF ? 4 : ((PF && I16 && DFX_SYNR_WPS == 6) ? 5 : DFX_SYNR_WPS)) dfx_k_synthesis_rows(DfxSynRowsArgs A) {   // (post-filter + 16-bit output: two registers over the budget of six waves per SIMD)
+__global__ void __launch_bounds__(DFX_SYNR_THREADS, (MF || PF) ? 4 : DFX_SYNR_WPS) dfx_k_synthesis_rows(DfxSynRowsArgs A) {   // (post filter: its frames need ~100 registers with all fifteen loads of a frame in flight)
     constexpr int M = 480, N = 960, HOP = 480, NTM = DFX_SYNR_TEAMS, BUF = DFX_FFT480_BUF;
     constexpr size_t TAB = MF ? (size_t)N * 8 : (size_t)DFX_SYNR_TAB;
     DFX_DYN_SMEM(unsigned char, smem);
@@ -2056,8 +2061,18 @@ __global__ void __launch_bounds__(DFX_SYNR_THREADS, MF ? 4 : ((PF && I16 && DFX_
         }
     }
     if constexpr (T480) dfx_tw480_fill(t1, t2, A.tw, (int)threadIdx.x, DFX_SYNR_THREADS);
-    if (O > 0 && A.gains)
-        for (int i = threadIdx.x; i <= M; i += DFX_SYNR_THREADS) b2b[i] = A.bin2band[i];
+    // the bands of this lane's eight bins 2 l + 128 u (+ 1), each as the byte address 4 * band of the lane that holds the band's gain: they depend
+    // on nothing but the lane (round 6: were two LDS byte reads + mask + shift in front of every gather)
+    unsigned bandq[2] = {0u, 0u};
+    if (O > 0 && A.gains) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = 2 * lane + 128 * u;
+            const unsigned b0 = A.bin2band[k <= M ? k : 0], b1 = A.bin2band[k + 1 <= M ? k + 1 : 0];
+            bandq[u >> 1] |= (((b0 & 63u) << 2) | ((b1 & 63u) << 10)) << (16 * (u & 1));
+        }
+    }
+    (void)b2b;
     __syncthreads();
     const int toff = O - 1 - A.lookahead;
     const int64_t chunks = (A.Tf + NTM - 1) / NTM;
@@ -2074,6 +2089,7 @@ __global__ void __launch_bounds__(DFX_SYNR_THREADS, MF ? 4 : ((PF && I16 && DFX_
         const float2 *Xr = A.spec + (b * A.Tf + t) * A.spec_stride;
         int lr = lane;
         DFX_OPAQUE(lr);
+        DFX_ASSUME(lr >= 0 && lr < DFX_DSP_TEAM);
         if constexpr (O == 0) {
             float2 v[8];
 #pragma unroll
@@ -2094,24 +2110,60 @@ __global__ void __launch_bounds__(DFX_SYNR_THREADS, MF ? 4 : ((PF && I16 && DFX_
             const float2 *Cr = A.coefs + b * A.cs_b + t * A.cs_t;
             float gv = 1.f;
             if (A.gains) gv = A.gains[(b * A.Tf + t) * A.nb + (lr < A.nb ? lr : 0)];
-            auto gain2 = [&](int k, float &g0, float &g1) {   // (every lane takes part in the shuffles)
+            auto gain2 = [&](int u, float &g0, float &g1) {   // (every lane takes part in the gathers)
                 g0 = g1 = 1.f;
-                if (A.gains) g0 = __shfl(gv, (int)b2b[k <= M ? k : 0]), g1 = __shfl(gv, (int)b2b[k + 1 <= M ? k + 1 : 0]);
+                if (A.gains) {
+                    const unsigned q = bandq[u >> 1] >> (16 * (u & 1));
+                    g0 = dfx_lane_gather4(gv, q & 0xffu), g1 = dfx_lane_gather4(gv, (q >> 8) & 0xffu);
+                }
             };
+            // rounds 1-3 are requested first and finished while the taps of round 0 are on their way: one memory latency per frame instead of two
+            f32x4 v[3];
+#pragma unroll
+            for (int u = 1; u < 4; ++u) {
+                const int k = 2 * lr + 128 * u;
+                v[u - 1] = Xr4[k <= M ? lr + 64 * u : lr];
+            }
             {
                 const int k = 2 * lr;
                 const bool df = k < A.nbdf;
+                const int kd = df ? k : 0;   // lanes behind the deep-filter bins load column 0 and drop it (a predicated load: zeroed destination + save / narrow / restore of exec)
                 const f32x4 x01 = Xr4[lr];
                 f32x4 cf[O], xt[O];
-                const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                // Every tap is loaded by every lane, without a predicate (round 6: was each of the 2 O loads of every frame predicated).  Taps whose
+                // frame lies outside the clip contribute nothing: their row index is clamped and their COEFFICIENT zeroed, under a wave-uniform
+                // branch that only the first / last frames of a clip take.  Gains only (no coefficients): the loads read the frame's own row.
+                const bool edge = t - toff < 0 || t + (O - 1) - toff >= A.Tf;
+                const bool anydf = A.nbdf > 0;
+                const float2 *Xd = Xr + kd, *Cd = anydf ? Cr + kd : Xd;
+                const int64_t csn = anydf ? A.cs_n : 0;
+                const int sstr = (int)A.spec_stride;
 #pragma unroll
                 for (int n = 0; n < O; ++n) {
                     const int64_t tt = t + n - toff;
-                    cf[n] = df ? *reinterpret_cast<const f32x4 *>(Cr + n * A.cs_n + k) : z4;
-                    xt[n] = (df && tt >= 0 && tt < A.Tf) ? *reinterpret_cast<const f32x4 *>(A.spec + (b * A.Tf + tt) * A.spec_stride + k) : z4;
+                    const int dr = edge ? (int)((tt < 0 ? 0 : (tt >= A.Tf ? A.Tf - 1 : tt)) - t) : n - toff;
+                    cf[n] = *reinterpret_cast<const f32x4 *>(Cd + n * csn);
+                    xt[n] = *reinterpret_cast<const f32x4 *>(Xd + dr * sstr);
+                }
+#pragma unroll
+                for (int u = 1; u < 4; ++u) {   // rounds 1-3: band gains only
+                    const int ku = 2 * lr + 128 * u;
+                    float gu0, gu1;
+                    gain2(u, gu0, gu1);
+                    const f32x4 x = v[u - 1];
+                    float2 yu0 = make_float2(x[0] * gu0, x[1] * gu0), yu1 = make_float2(x[2] * gu1, x[3] * gu1);
+                    if (PF) yu0 = dfx_dfa_finish(yu0, make_float2(x[0], x[1]), A.pf_beta, A.atten_lim), yu1 = dfx_dfa_finish(yu1, make_float2(x[2], x[3]), A.pf_beta, A.atten_lim);
+                    if (ku <= M) *reinterpret_cast<f32x4 *>(bufA + ku) = f32x4{yu0.x, yu0.y, yu1.x, yu1.y};   // (ku = M: the slot behind the Nyquist bin takes the row's pad bin; nobody reads it)
+                }
+                if (edge) {
+#pragma unroll
+                    for (int n = 0; n < O; ++n) {
+                        const int64_t tt = t + n - toff;
+                        if (tt < 0 || tt >= A.Tf) cf[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
                 }
                 float g0, g1;
-                gain2(k, g0, g1);
+                gain2(0, g0, g1);
                 float2 y0, y1;
                 if (df) {
                     float re0 = 0.f, im0 = 0.f, re1 = 0.f, im1 = 0.f;
@@ -2129,22 +2181,6 @@ __global__ void __launch_bounds__(DFX_SYNR_THREADS, MF ? 4 : ((PF && I16 && DFX_
                 if (PF) y0 = dfx_dfa_finish(y0, make_float2(x01[0], x01[1]), A.pf_beta, A.atten_lim), y1 = dfx_dfa_finish(y1, make_float2(x01[2], x01[3]), A.pf_beta, A.atten_lim);
                 *reinterpret_cast<f32x4 *>(bufA + k) = f32x4{y0.x, y0.y, y1.x, y1.y};
             }
-            f32x4 v[3];
-#pragma unroll
-            for (int u = 1; u < 4; ++u) {
-                const int k = 2 * lr + 128 * u;
-                v[u - 1] = Xr4[k <= M ? lr + 64 * u : lr];
-            }
-#pragma unroll
-            for (int u = 1; u < 4; ++u) {
-                const int k = 2 * lr + 128 * u;
-                float g0, g1;
-                gain2(k, g0, g1);
-                const f32x4 x = v[u - 1];
-                float2 y0 = make_float2(x[0] * g0, x[1] * g0), y1 = make_float2(x[2] * g1, x[3] * g1);
-                if (PF) y0 = dfx_dfa_finish(y0, make_float2(x[0], x[1]), A.pf_beta, A.atten_lim), y1 = dfx_dfa_finish(y1, make_float2(x[2], x[3]), A.pf_beta, A.atten_lim);
-                if (k <= M) *reinterpret_cast<f32x4 *>(bufA + k) = f32x4{y0.x, y0.y, y1.x, y1.y};   // (k = M: the slot behind the Nyquist bin takes the row's pad bin; nobody reads it)
-            }
         }
     }
     DFX_WAVE_SYNC();
@@ -2153,26 +2189,34 @@ __global__ void __launch_bounds__(DFX_SYNR_THREADS, MF ? 4 : ((PF && I16 && DFX_
     // Z[k] = (er - o.y, ei + o.x) and Z[M-k] = (er + o.y, -ei + o.x) — 12 operations per pair instead of 20 (round 6; the sums are the same, only
     // the partner's factor is no longer a table entry of its own)
     if (active) {
+        // pairs (k, M - k), k = lane + 64 i: i < 3 always exist (k <= 191), i = 3 for the lanes with k <= M / 2 = 240 (the others read pair 0 and drop
+        // it).  Only k = 0 (lane 0 of i = 0) is special: C2R ignores imag(DC) and imag(Nyquist), and its partner slot M is not part of the transform's
+        // input — so every pair stores both bins, partner first: lane 0 then leaves a value nobody reads in slot M, and for k = M / 2 = M - k the
+        // lane's own second store (LDS operations of a wave complete in order) is the one that stays.  (Round 6: was four predicated iterations
+        // with a k == 0 test and a partner test each.)
         constexpr int NPR = (M / 2 + DFX_DSP_TEAM) / DFX_DSP_TEAM;
         float2 xa[NPR], xb[NPR], wa[NPR];
         int lp = lane;
         DFX_OPAQUE(lp);
+        DFX_ASSUME(lp >= 0 && lp < DFX_DSP_TEAM);
+        const bool last = lp + (NPR - 1) * DFX_DSP_TEAM <= M / 2;
 #pragma unroll
         for (int i = 0; i < NPR; ++i) {
-            const int k = lp + i * DFX_DSP_TEAM, kk = k <= M / 2 ? k : 0, kc = M - kk;
-            xa[i] = bufA[kk], xb[i] = bufA[kc];
-            wa[i] = tp[kk];
+            const int k = (i < NPR - 1 || last) ? lp + i * DFX_DSP_TEAM : 0, kc = M - k;
+            xa[i] = bufA[k], xb[i] = bufA[kc];
+            wa[i] = tp[k];
         }
+        if (lp == 0) xa[0].y = 0.f, xb[0].y = 0.f;
 #pragma unroll
         for (int i = 0; i < NPR; ++i) {
             const int k = lp + i * DFX_DSP_TEAM, kc = M - k;
-            if (k > M / 2) continue;
-            float2 xk = xa[i], xm = xb[i];
-            if (k == 0) xk.y = 0.f, xm.y = 0.f;   // C2R ignores imag(DC) and imag(Nyquist)
+            const float2 xk = xa[i], xm = xb[i];
             const float er = xk.x + xm.x, ei = xk.y - xm.y;
             const float2 o = dfx_cmul(make_float2(xk.x - xm.x, xk.y + xm.y), make_float2(wa[i].x, -wa[i].y));
-            if (k != 0 && kc != k) bufA[kc] = make_float2(er + o.y, o.x - ei);
-            bufA[k] = make_float2(er - o.y, ei + o.x);
+            if (i < NPR - 1 || last) {
+                bufA[kc] = make_float2(er + o.y, o.x - ei);
+                bufA[k] = make_float2(er - o.y, ei + o.x);
+            }
         }
     }
     DFX_WAVE_SYNC();
@@ -2188,20 +2232,29 @@ __global__ void __launch_bounds__(DFX_SYNR_THREADS, MF ? 4 : ((PF && I16 && DFX_
     const float *cin = carry + par * HOP;
     float *cout = carry + (par ^ 1) * HOP;
     auto wmul = [](const f32x4 x, const f32x4 w) -> f32x4 { return f32x4{__fmul_rn(x[0], w[0]), __fmul_rn(x[1], w[1]), __fmul_rn(x[2], w[2]), __fmul_rn(x[3], w[3])}; };
+    // Wave j stores output frame t0 + j (round 6: was a flat loop over the chunk's 960 float4 with a division per item): frame, row and the source of the
+    // overlap are wave-uniform, a lane's two float4 (lane, lane + 64 < 120) differ by a constant.
     if (!pro) {
-        for (int q = threadIdx.x; q < NTM * HQ; q += DFX_SYNR_THREADS) {
-            const int j = q / HQ, i = (q - j * HQ) << 2;
-            const int64_t tf = t0 + j;
-            if (tf >= A.Tf) break;
-            const float *fr = reinterpret_cast<const float *>(bufs + (size_t)j * BUF);
-            const f32x4 cur = wmul(*reinterpret_cast<const f32x4 *>(fr + i), *reinterpret_cast<const f32x4 *>(win + i));
-            f32x4 v = cur;
-            if (tf > 0) {
-                const f32x4 old = j > 0 ? wmul(*reinterpret_cast<const f32x4 *>(fr - 2 * BUF + HOP + i), *reinterpret_cast<const f32x4 *>(win + HOP + i))
-                                        : *reinterpret_cast<const f32x4 *>(cin + i);
-                v = f32x4{__fadd_rn(cur[0], old[0]), __fadd_rn(cur[1], old[1]), __fadd_rn(cur[2], old[2]), __fadd_rn(cur[3], old[3])};
+        const int64_t tf = t0 + team;
+        if (tf < A.Tf) {
+            const float *fr = reinterpret_cast<const float *>(bufA);
+            int lq = lane;
+            DFX_OPAQUE(lq);   // (keeps the lane's share of the addresses out of registers held across the chunk loop)
+            DFX_ASSUME(lq >= 0 && lq < DFX_DSP_TEAM);
+#pragma unroll
+            for (int it = 0; it < (HQ + DFX_DSP_TEAM - 1) / DFX_DSP_TEAM; ++it) {
+                const int i = (lq + it * DFX_DSP_TEAM) << 2;
+                if (i < HOP) {
+                    const f32x4 cur = wmul(*reinterpret_cast<const f32x4 *>(fr + i), *reinterpret_cast<const f32x4 *>(win + i));
+                    f32x4 v = cur;
+                    if (tf > 0) {
+                        const f32x4 old = team > 0 ? wmul(*reinterpret_cast<const f32x4 *>(fr - 2 * BUF + HOP + i), *reinterpret_cast<const f32x4 *>(win + HOP + i))
+                                                   : *reinterpret_cast<const f32x4 *>(cin + i);
+                        v = f32x4{__fadd_rn(cur[0], old[0]), __fadd_rn(cur[1], old[1]), __fadd_rn(cur[2], old[2]), __fadd_rn(cur[3], old[3])};
+                    }
+                    dfx_store_out4<I16>(A.out, b * A.out_stride, tf * HOP + i - A.out_skip, A.out_len, v);
+                }
             }
-            dfx_store_out4<I16>(A.out, b * A.out_stride, tf * HOP + i - A.out_skip, A.out_len, v);
         }
     }
     if (threadIdx.x < HQ && t0 + NTM - 1 < A.Tf) {

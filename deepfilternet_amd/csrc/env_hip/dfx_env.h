@@ -134,10 +134,15 @@ static __device__ __forceinline__ f32x4 dfx_mfma_16x16x32_f16(dfx_h8 a, dfx_h8 b
 #endif
 }
 
+// lane gather with a ready-made byte address (4 * source lane, < 256): one ds_bpermute_b32, where __shfl() first masks and shifts the index
+static __device__ __forceinline__ float dfx_lane_gather4(float v, unsigned byte_addr) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)byte_addr, __builtin_bit_cast(int, v)));
+}
 // small index products at the full VALU rate (v_mul_i32_i24; v_mul_lo_u32 issues at a quarter of it)
 #define DFX_MUL24(a, b) __mul24((a), (b))
 // compiler fences used by the hand-scheduled kernels
 #define DFX_OPAQUE(x) asm volatile("" : "+v"(x))
+#define DFX_ASSUME(c) __builtin_assume(c)   /* what an opaque value is known to be, e.g. a lane index: 0 <= x < 64 (lets the compiler drop clamps that never bind) */
 #define DFX_PIN_AGPR(x) asm volatile("" : "+a"(x))   /* the value lives in an AGPR from here on (matrix-op operands of kernels with one wave per SIMD) */
 #define DFX_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 // Between the last matrix op of a group and the first vector instruction that reads its result when that reader may land in the NEXT basic

@@ -547,6 +547,7 @@ static inline float __int_as_float(int v) {
 }
 // wave-uniform values: identity on the interpreter (callers only pass values that are uniform across the wave by construction)
 static inline int dfx_wave_uniform(int v) { return v; }
+static inline float dfx_lane_gather4(float v, unsigned byte_addr) { return __shfl(v, (int)(byte_addr >> 2)); }
 // agent-scope atomics / fences / sleep of the flag-synchronised kernels (dfx_k_gru_seq, dfx_k_wait_ge): plain accesses here — the
 // interpreter runs one launch at a time to completion, so the host never selects the persistent GRU phase on it (dfx_env_is_emulator)
 #define __HIP_MEMORY_SCOPE_AGENT 4
@@ -570,6 +571,7 @@ static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
 
 #define DFX_MUL24(a, b) ((a) * (b))
 #define DFX_OPAQUE(x) asm volatile("" : "+r"(x))
+#define DFX_ASSUME(c) do { if (!(c)) __builtin_trap(); } while (0)   /* the interpreter CHECKS what the GPU build assumes */
 #define DFX_PIN_AGPR(x) ((void)0)
 #define DFX_SCHED_BARRIER() ((void)0)
 #define DFX_MFMA_GUARD() do { } while (0)
