@@ -578,10 +578,13 @@ int dfx_launch_synthesis_rows(const dfx_state *st, const float *spec, int64_t sp
     A.cs_b = (int64_t)order * Tf * nd, A.cs_n = Tf * nd, A.cs_t = nd;   // [B, O, Tf, nd] (DFX_COEF_BOTF)
     A.nbdf = (int)nd, A.lookahead = lookahead, A.nb = gains ? st->bands->nb : 0;
     A.pf_beta = pf_beta, A.atten_lim = atten_lim;
-    // segments: enough (row, segment) items to fill three workgroups per CU, but at least 4 chunks each (a segment that does not start a
-    // row costs one extra single-wave item)
+    // segments: enough (row, segment) items to fill the workgroups a CU holds — three of the plain ISTFT; two with the deep filter, whose next
+    // frame stays in flight in ~60 registers (four waves per SIMD); one with the post filter on top (three) —, but at least 4 chunks each (a
+    // segment that does not start a row costs one extra single-wave item)
+    const bool pf = pf_beta > 0.f || atten_lim > 0.f;
+    const int wgs = !with_df ? DFX_SYNR_WGS : (pf ? 1 : 2);
     const int64_t chunks = dfx_ceil_div(Tf, DFX_SYNR_TEAMS);
-    const int64_t want = dfx_ceil_div((int64_t)dfx_env_num_cus() * DFX_SYNR_WGS, B);
+    const int64_t want = dfx_ceil_div((int64_t)dfx_env_num_cus() * wgs, B);
     int64_t segs = want < 1 ? 1 : want;
     if (segs > chunks / 4) segs = chunks / 4 > 0 ? chunks / 4 : 1;
     A.poison = nullptr;
@@ -595,10 +598,9 @@ int dfx_launch_synthesis_rows(const dfx_state *st, const float *spec, int64_t sp
     int64_t nblk = B * A.segs;
     const bool mf = fft_mfma(st);
     A.mfft = mf ? st->d_mfft + DFX_MFFT_TABLE_BYTES : nullptr;   // (the inverse tables)
-    const int64_t cap = (int64_t)dfx_env_num_cus() * (mf ? 2 : DFX_SYNR_WGS);
+    const int64_t cap = (int64_t)dfx_env_num_cus() * (mf ? (wgs < 2 ? wgs : 2) : wgs);
     if (nblk > cap) nblk = cap;
     const size_t smem = mf ? DFX_SYNR_SMEM_MF : DFX_SYNR_SMEM;
-    const bool pf = pf_beta > 0.f || atten_lim > 0.f;
     DfxKScope ks(DFX_K_SYNTHESIS, s);
     auto go = [&](auto kern) { dfx_launch(kern, dim3((unsigned)nblk), dim3(DFX_SYNR_THREADS), smem, s, A); };
     if (!with_df) {

@@ -2020,7 +2020,7 @@ struct DfxSynRowsArgs {
 #define DFX_SYNR_SMEM_MF ((size_t)960 * 12 + (size_t)DFX_SYNR_TEAMS * DFX_FFT480_BUF * 8 + (size_t)2 * 480 * 4 + 496 + (size_t)DFX_MFFT_FRAG3 * 64 * 16)
 
 template <int O, bool PF, bool I16 = false, bool MF = false>
-__global__ void __launch_bounds__(DFX_SYNR_THREADS, (MF || PF) ? 4 : DFX_SYNR_WPS) dfx_k_synthesis_rows(DfxSynRowsArgs A) {   // (post filter: its frames need ~100 registers with all fifteen loads of a frame in flight)
+__global__ void __launch_bounds__(DFX_SYNR_THREADS, MF ? 4 : (O > 0 ? (PF ? 3 : 4) : DFX_SYNR_WPS)) dfx_k_synthesis_rows(DfxSynRowsArgs A) {   // (O > 0: the next frame's fifteen loads stay in flight across the item: ~60 registers more)
     constexpr int M = 480, N = 960, HOP = 480, NTM = DFX_SYNR_TEAMS, BUF = DFX_FFT480_BUF;
     constexpr size_t TAB = MF ? (size_t)N * 8 : (size_t)DFX_SYNR_TAB;
     DFX_DYN_SMEM(unsigned char, smem);
@@ -2077,112 +2077,155 @@ __global__ void __launch_bounds__(DFX_SYNR_THREADS, (MF || PF) ? 4 : DFX_SYNR_WP
     const int toff = O - 1 - A.lookahead;
     const int64_t chunks = (A.Tf + NTM - 1) / NTM;
     int par = 0;   // carry buffer the current item reads
-    for (int64_t seg = blockIdx.x; seg < A.B * A.segs; seg += gridDim.x) {
-    const int64_t b = seg / A.segs;
-    const int64_t c0 = (seg - b * A.segs) * A.seg_chunks;
-    const int64_t c1 = c0 + A.seg_chunks < chunks ? c0 + A.seg_chunks : chunks;
-    for (int64_t ch = c0 > 0 ? c0 - 1 : c0; ch < c1; ++ch) {
-    const bool pro = ch < c0;                  // prologue item: only the frame in front of the segment, nothing stored
-    const int64_t t0 = ch * NTM, t = t0 + team;
-    const bool active = t < A.Tf && (!pro || team == NTM - 1);
-    if (active) {
-        const float2 *Xr = A.spec + (b * A.Tf + t) * A.spec_stride;
+    // ---- The items of this workgroup — for every (row, segment) it is dealt: [one prologue item,] the segment's chunks — as ONE software-pipelined loop
+    // (round 6): the loads of item i + 1 are requested as soon as item i's values have left their registers for the LDS, and are on their way while
+    // item i goes through pre-pass, transform, overlap-add and stores.  Round-6 ablations (profiles/r06_finish_ablation.log): without the transform
+    // the kernel took 7 % less, without its stores 18 %, with a fifth of its loads 25 % — bound by the bytes it has in flight (fifteen 16-byte loads
+    // per lane, but only for the quarter of a frame's time that its wave waited for them), not by its instructions.  The frame in flight lives in
+    // ~60 registers across the whole item: four waves per SIMD (two workgroups per CU) instead of six.
+    struct Item {
+        int64_t seg, b, c0, c1, ch;
+    };
+    const int64_t nseg = A.B * A.segs;
+    auto start_seg = [&](Item &I) {
+        I.b = I.seg / A.segs;
+        I.c0 = (I.seg - I.b * A.segs) * A.seg_chunks;
+        I.c1 = I.c0 + A.seg_chunks < chunks ? I.c0 + A.seg_chunks : chunks;
+        I.ch = I.c0 > 0 ? I.c0 - 1 : I.c0;
+    };
+    auto item_active = [&](const Item &I) -> bool {   // prologue item: only the frame in front of the segment, nothing stored
+        const int64_t t = I.ch * NTM + team;
+        return t < A.Tf && (I.ch >= I.c0 || team == NTM - 1);
+    };
+    // the frame in flight
+    constexpr int OT = O > 0 ? O : 1;
+    f32x4 rv[3], rx01, rcf[OT], rxt[OT];
+    float2 r0[8];
+    float rgv = 1.f;
+    auto issue = [&](const Item &I) {
+        if (!item_active(I)) return;
+        const int64_t t = I.ch * NTM + team;
+        const float2 *Xr = A.spec + (I.b * A.Tf + t) * A.spec_stride;
         int lr = lane;
         DFX_OPAQUE(lr);
         DFX_ASSUME(lr >= 0 && lr < DFX_DSP_TEAM);
         if constexpr (O == 0) {
-            float2 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int k = lr + u * DFX_DSP_TEAM;
-                v[u] = Xr[k <= M ? k : lr];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = lr + u * DFX_DSP_TEAM;
-                if (k <= M) bufA[k] = v[u];
+                r0[u] = Xr[k <= M ? k : lr];
             }
         } else {
-            // ---- two neighbouring bins per lane, 16-byte accesses (round 6: was one bin per lane and round, twice the vector-memory and LDS
-            // instructions; the arithmetic per bin is the same expression: same bits).  Round 0 = bins 2 l, 2 l + 1 < 128: the deep-filter bins
-            // (k < nb_df <= 128, an even count): taps n read frame t + n - toff, zero outside the clip; the rest of the round and rounds 1-3: band gains only.
+            // ---- two neighbouring bins per lane, 16-byte accesses.  Round 0 = bins 2 l, 2 l + 1 < 128: the deep-filter bins (k < nb_df <= 128, an even
+            // count): taps n read frame t + n - toff; the rest of the round and rounds 1-3: band gains only.
             const f32x4 *Xr4 = reinterpret_cast<const f32x4 *>(Xr);
-            const float2 *Cr = A.coefs + b * A.cs_b + t * A.cs_t;
-            float gv = 1.f;
-            if (A.gains) gv = A.gains[(b * A.Tf + t) * A.nb + (lr < A.nb ? lr : 0)];
+            const float2 *Cr = A.coefs + I.b * A.cs_b + t * A.cs_t;
+            if (A.gains) rgv = A.gains[(I.b * A.Tf + t) * A.nb + (lr < A.nb ? lr : 0)];
+#pragma unroll
+            for (int u = 1; u < 4; ++u) {
+                const int k = 2 * lr + 128 * u;
+                rv[u - 1] = Xr4[k <= M ? lr + 64 * u : lr];
+            }
+            const int k = 2 * lr;
+            const int kd = k < A.nbdf ? k : 0;   // lanes behind the deep-filter bins load column 0 and drop it (a predicated load: zeroed destination + save / narrow / restore of exec)
+            rx01 = Xr4[lr];
+            // Every tap is loaded by every lane, without a predicate.  Taps whose frame lies outside the clip contribute nothing: their row index is
+            // clamped here and their COEFFICIENT zeroed when the frame is finished, under a wave-uniform branch that only the first / last frames of a
+            // clip take.  Gains only (no coefficients): the loads read the frame's own row.
+            const bool edge = t - toff < 0 || t + (O - 1) - toff >= A.Tf;
+            const bool anydf = A.nbdf > 0;
+            const float2 *Xd = Xr + kd, *Cd = anydf ? Cr + kd : Xd;
+            const int64_t csn = anydf ? A.cs_n : 0;
+            const int sstr = (int)A.spec_stride;
+#pragma unroll
+            for (int n = 0; n < O; ++n) {
+                const int64_t tt = t + n - toff;
+                const int dr = edge ? (int)((tt < 0 ? 0 : (tt >= A.Tf ? A.Tf - 1 : tt)) - t) : n - toff;
+                rcf[n] = *reinterpret_cast<const f32x4 *>(Cd + n * csn);
+                rxt[n] = *reinterpret_cast<const f32x4 *>(Xd + dr * sstr);
+            }
+        }
+    };
+    // the frame's values -> gains / deep filter / post filter -> its LDS buffer (same expressions, same order as dfx_k_df_apply_rows: same bits)
+    auto finish_frame = [&](int64_t t) {
+        int lr = lane;
+        DFX_OPAQUE(lr);
+        DFX_ASSUME(lr >= 0 && lr < DFX_DSP_TEAM);
+        if constexpr (O == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = lr + u * DFX_DSP_TEAM;
+                if (k <= M) bufA[k] = r0[u];
+            }
+        } else {
             auto gain2 = [&](int u, float &g0, float &g1) {   // (every lane takes part in the gathers)
                 g0 = g1 = 1.f;
                 if (A.gains) {
                     const unsigned q = bandq[u >> 1] >> (16 * (u & 1));
-                    g0 = dfx_lane_gather4(gv, q & 0xffu), g1 = dfx_lane_gather4(gv, (q >> 8) & 0xffu);
+                    g0 = dfx_lane_gather4(rgv, q & 0xffu), g1 = dfx_lane_gather4(rgv, (q >> 8) & 0xffu);
                 }
             };
-            // rounds 1-3 are requested first and finished while the taps of round 0 are on their way: one memory latency per frame instead of two
-            f32x4 v[3];
 #pragma unroll
-            for (int u = 1; u < 4; ++u) {
-                const int k = 2 * lr + 128 * u;
-                v[u - 1] = Xr4[k <= M ? lr + 64 * u : lr];
+            for (int u = 1; u < 4; ++u) {   // rounds 1-3: band gains only
+                const int ku = 2 * lr + 128 * u;
+                float gu0, gu1;
+                gain2(u, gu0, gu1);
+                const f32x4 x = rv[u - 1];
+                float2 yu0 = make_float2(x[0] * gu0, x[1] * gu0), yu1 = make_float2(x[2] * gu1, x[3] * gu1);
+                if (PF) yu0 = dfx_dfa_finish(yu0, make_float2(x[0], x[1]), A.pf_beta, A.atten_lim), yu1 = dfx_dfa_finish(yu1, make_float2(x[2], x[3]), A.pf_beta, A.atten_lim);
+                if (ku <= M) *reinterpret_cast<f32x4 *>(bufA + ku) = f32x4{yu0.x, yu0.y, yu1.x, yu1.y};   // (ku = M: the slot behind the Nyquist bin takes the row's pad bin; nobody reads it)
             }
-            {
-                const int k = 2 * lr;
-                const bool df = k < A.nbdf;
-                const int kd = df ? k : 0;   // lanes behind the deep-filter bins load column 0 and drop it (a predicated load: zeroed destination + save / narrow / restore of exec)
-                const f32x4 x01 = Xr4[lr];
-                f32x4 cf[O], xt[O];
-                // Every tap is loaded by every lane, without a predicate (round 6: was each of the 2 O loads of every frame predicated).  Taps whose
-                // frame lies outside the clip contribute nothing: their row index is clamped and their COEFFICIENT zeroed, under a wave-uniform
-                // branch that only the first / last frames of a clip take.  Gains only (no coefficients): the loads read the frame's own row.
-                const bool edge = t - toff < 0 || t + (O - 1) - toff >= A.Tf;
-                const bool anydf = A.nbdf > 0;
-                const float2 *Xd = Xr + kd, *Cd = anydf ? Cr + kd : Xd;
-                const int64_t csn = anydf ? A.cs_n : 0;
-                const int sstr = (int)A.spec_stride;
+            const int k = 2 * lr;
+            const bool df = k < A.nbdf;
+            const f32x4 x01 = rx01;
+            if (t - toff < 0 || t + (O - 1) - toff >= A.Tf) {
 #pragma unroll
                 for (int n = 0; n < O; ++n) {
                     const int64_t tt = t + n - toff;
-                    const int dr = edge ? (int)((tt < 0 ? 0 : (tt >= A.Tf ? A.Tf - 1 : tt)) - t) : n - toff;
-                    cf[n] = *reinterpret_cast<const f32x4 *>(Cd + n * csn);
-                    xt[n] = *reinterpret_cast<const f32x4 *>(Xd + dr * sstr);
+                    if (tt < 0 || tt >= A.Tf) rcf[n] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-#pragma unroll
-                for (int u = 1; u < 4; ++u) {   // rounds 1-3: band gains only
-                    const int ku = 2 * lr + 128 * u;
-                    float gu0, gu1;
-                    gain2(u, gu0, gu1);
-                    const f32x4 x = v[u - 1];
-                    float2 yu0 = make_float2(x[0] * gu0, x[1] * gu0), yu1 = make_float2(x[2] * gu1, x[3] * gu1);
-                    if (PF) yu0 = dfx_dfa_finish(yu0, make_float2(x[0], x[1]), A.pf_beta, A.atten_lim), yu1 = dfx_dfa_finish(yu1, make_float2(x[2], x[3]), A.pf_beta, A.atten_lim);
-                    if (ku <= M) *reinterpret_cast<f32x4 *>(bufA + ku) = f32x4{yu0.x, yu0.y, yu1.x, yu1.y};   // (ku = M: the slot behind the Nyquist bin takes the row's pad bin; nobody reads it)
-                }
-                if (edge) {
-#pragma unroll
-                    for (int n = 0; n < O; ++n) {
-                        const int64_t tt = t + n - toff;
-                        if (tt < 0 || tt >= A.Tf) cf[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                }
-                float g0, g1;
-                gain2(0, g0, g1);
-                float2 y0, y1;
-                if (df) {
-                    float re0 = 0.f, im0 = 0.f, re1 = 0.f, im1 = 0.f;
-#pragma unroll
-                    for (int n = 0; n < O; ++n) {
-                        re0 += xt[n][0] * cf[n][0] - xt[n][1] * cf[n][1];
-                        im0 += xt[n][0] * cf[n][1] + xt[n][1] * cf[n][0];
-                        re1 += xt[n][2] * cf[n][2] - xt[n][3] * cf[n][3];
-                        im1 += xt[n][2] * cf[n][3] + xt[n][3] * cf[n][2];
-                    }
-                    y0 = make_float2(re0, im0), y1 = make_float2(re1, im1);
-                } else {
-                    y0 = make_float2(x01[0] * g0, x01[1] * g0), y1 = make_float2(x01[2] * g1, x01[3] * g1);
-                }
-                if (PF) y0 = dfx_dfa_finish(y0, make_float2(x01[0], x01[1]), A.pf_beta, A.atten_lim), y1 = dfx_dfa_finish(y1, make_float2(x01[2], x01[3]), A.pf_beta, A.atten_lim);
-                *reinterpret_cast<f32x4 *>(bufA + k) = f32x4{y0.x, y0.y, y1.x, y1.y};
             }
+            float g0, g1;
+            gain2(0, g0, g1);
+            float2 y0, y1;
+            if (df) {
+                float re0 = 0.f, im0 = 0.f, re1 = 0.f, im1 = 0.f;
+#pragma unroll
+                for (int n = 0; n < O; ++n) {
+                    re0 += rxt[n][0] * rcf[n][0] - rxt[n][1] * rcf[n][1];
+                    im0 += rxt[n][0] * rcf[n][1] + rxt[n][1] * rcf[n][0];
+                    re1 += rxt[n][2] * rcf[n][2] - rxt[n][3] * rcf[n][3];
+                    im1 += rxt[n][2] * rcf[n][3] + rxt[n][3] * rcf[n][2];
+                }
+                y0 = make_float2(re0, im0), y1 = make_float2(re1, im1);
+            } else {
+                y0 = make_float2(x01[0] * g0, x01[1] * g0), y1 = make_float2(x01[2] * g1, x01[3] * g1);
+            }
+            if (PF) y0 = dfx_dfa_finish(y0, make_float2(x01[0], x01[1]), A.pf_beta, A.atten_lim), y1 = dfx_dfa_finish(y1, make_float2(x01[2], x01[3]), A.pf_beta, A.atten_lim);
+            *reinterpret_cast<f32x4 *>(bufA + k) = f32x4{y0.x, y0.y, y1.x, y1.y};
         }
+    };
+    Item cur;
+    cur.seg = blockIdx.x;
+    bool have = cur.seg < nseg;
+    if (have) {
+        start_seg(cur);
+        issue(cur);
     }
+    while (have) {
+    const int64_t b = cur.b;
+    const bool pro = cur.ch < cur.c0;
+    const int64_t t0 = cur.ch * NTM, t = t0 + team;
+    const bool active = item_active(cur);
+    if (active) finish_frame(t);
+    Item nxt = cur;
+    bool have_next = true;
+    if (++nxt.ch >= nxt.c1) {
+        nxt.seg += gridDim.x;
+        have_next = nxt.seg < nseg;
+        if (have_next) start_seg(nxt);
+    }
+    if (have_next) issue(nxt);
     DFX_WAVE_SYNC();
     // E' = X[k] + conj(X[M-k]) ; O' = conj(w^k) * (X[k] - conj(X[M-k])) ; Z[k] = E' + i*O'   (in place on the pairs (k, M-k), see dfx_k_synthesis).
     // The two bins of a pair share E' and O' up to signs, and w^(M-k) = -conj(w^k): with o = (X[k] - conj(X[M-k])) * conj(w^k),
@@ -2263,7 +2306,8 @@ __global__ void __launch_bounds__(DFX_SYNR_THREADS, (MF || PF) ? 4 : DFX_SYNR_WP
     }
     par ^= 1;
     __syncthreads();  // the frame buffers are rewritten by the next item, which also reads the carry just stored
-    }
+    cur = nxt;
+    have = have_next;
     }
 }
 
