@@ -579,10 +579,10 @@ int dfx_launch_synthesis_rows(const dfx_state *st, const float *spec, int64_t sp
     A.nbdf = (int)nd, A.lookahead = lookahead, A.nb = gains ? st->bands->nb : 0;
     A.pf_beta = pf_beta, A.atten_lim = atten_lim;
     // segments: enough (row, segment) items to fill the workgroups a CU holds — three of the plain ISTFT; two with the deep filter, whose next
-    // frame stays in flight in ~60 registers (four waves per SIMD); one with the post filter on top (three) —, but at least 4 chunks each (a
+    // frame stays in flight in ~60 registers (four waves per SIMD) —, but at least 4 chunks each (a
     // segment that does not start a row costs one extra single-wave item)
     const bool pf = pf_beta > 0.f || atten_lim > 0.f;
-    const int wgs = !with_df ? DFX_SYNR_WGS : (pf ? 1 : 2);
+    const int wgs = !with_df ? DFX_SYNR_WGS : 2;
     const int64_t chunks = dfx_ceil_div(Tf, DFX_SYNR_TEAMS);
     const int64_t want = dfx_ceil_div((int64_t)dfx_env_num_cus() * wgs, B);
     int64_t segs = want < 1 ? 1 : want;

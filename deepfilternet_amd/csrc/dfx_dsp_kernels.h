@@ -2020,7 +2020,7 @@ struct DfxSynRowsArgs {
 #define DFX_SYNR_SMEM_MF ((size_t)960 * 12 + (size_t)DFX_SYNR_TEAMS * DFX_FFT480_BUF * 8 + (size_t)2 * 480 * 4 + 496 + (size_t)DFX_MFFT_FRAG3 * 64 * 16)
 
 template <int O, bool PF, bool I16 = false, bool MF = false>
-__global__ void __launch_bounds__(DFX_SYNR_THREADS, MF ? 4 : (O > 0 ? (PF ? 3 : 4) : DFX_SYNR_WPS)) dfx_k_synthesis_rows(DfxSynRowsArgs A) {   // (O > 0: the next frame's fifteen loads stay in flight across the item: ~60 registers more)
+__global__ void __launch_bounds__(DFX_SYNR_THREADS, MF ? 4 : (O > 0 ? 4 : DFX_SYNR_WPS)) dfx_k_synthesis_rows(DfxSynRowsArgs A) {   // (O > 0: the next frame's fifteen loads stay in flight across the item: ~60 registers more)
     constexpr int M = 480, N = 960, HOP = 480, NTM = DFX_SYNR_TEAMS, BUF = DFX_FFT480_BUF;
     constexpr size_t TAB = MF ? (size_t)N * 8 : (size_t)DFX_SYNR_TAB;
     DFX_DYN_SMEM(unsigned char, smem);
@@ -2099,6 +2099,7 @@ __global__ void __launch_bounds__(DFX_SYNR_THREADS, MF ? 4 : (O > 0 ? (PF ? 3 : 
     };
     // the frame in flight
     constexpr int OT = O > 0 ? O : 1;
+    constexpr bool LATE3 = PF;   // post filter: rounds 1-3 (12 registers) are requested when the frame is finished — with them in flight too the kernel needs 132 registers, four more than four waves per SIMD have
     f32x4 rv[3], rx01, rcf[OT], rxt[OT];
     float2 r0[8];
     float rgv = 1.f;
@@ -2121,10 +2122,12 @@ __global__ void __launch_bounds__(DFX_SYNR_THREADS, MF ? 4 : (O > 0 ? (PF ? 3 : 
             const f32x4 *Xr4 = reinterpret_cast<const f32x4 *>(Xr);
             const float2 *Cr = A.coefs + I.b * A.cs_b + t * A.cs_t;
             if (A.gains) rgv = A.gains[(I.b * A.Tf + t) * A.nb + (lr < A.nb ? lr : 0)];
+            if constexpr (!LATE3) {
 #pragma unroll
-            for (int u = 1; u < 4; ++u) {
-                const int k = 2 * lr + 128 * u;
-                rv[u - 1] = Xr4[k <= M ? lr + 64 * u : lr];
+                for (int u = 1; u < 4; ++u) {
+                    const int k = 2 * lr + 128 * u;
+                    rv[u - 1] = Xr4[k <= M ? lr + 64 * u : lr];
+                }
             }
             const int k = 2 * lr;
             const int kd = k < A.nbdf ? k : 0;   // lanes behind the deep-filter bins load column 0 and drop it (a predicated load: zeroed destination + save / narrow / restore of exec)
@@ -2147,10 +2150,18 @@ __global__ void __launch_bounds__(DFX_SYNR_THREADS, MF ? 4 : (O > 0 ? (PF ? 3 : 
         }
     };
     // the frame's values -> gains / deep filter / post filter -> its LDS buffer (same expressions, same order as dfx_k_df_apply_rows: same bits)
-    auto finish_frame = [&](int64_t t) {
+    auto finish_frame = [&](int64_t b, int64_t t) {
         int lr = lane;
         DFX_OPAQUE(lr);
         DFX_ASSUME(lr >= 0 && lr < DFX_DSP_TEAM);
+        if constexpr (O > 0 && LATE3) {
+            const f32x4 *Xr4 = reinterpret_cast<const f32x4 *>(A.spec + (b * A.Tf + t) * A.spec_stride);
+#pragma unroll
+            for (int u = 1; u < 4; ++u) {
+                const int k = 2 * lr + 128 * u;
+                rv[u - 1] = Xr4[k <= M ? lr + 64 * u : lr];
+            }
+        }
         if constexpr (O == 0) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -2217,7 +2228,7 @@ __global__ void __launch_bounds__(DFX_SYNR_THREADS, MF ? 4 : (O > 0 ? (PF ? 3 : 
     const bool pro = cur.ch < cur.c0;
     const int64_t t0 = cur.ch * NTM, t = t0 + team;
     const bool active = item_active(cur);
-    if (active) finish_frame(t);
+    if (active) finish_frame(b, t);
     Item nxt = cur;
     bool have_next = true;
     if (++nxt.ch >= nxt.c1) {
