@@ -99,9 +99,16 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
             A.rm = rm;
             A.err = m->d_err;
             const size_t smem = DFX_DFO_SMEM(NO, Fd);
-            DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_df_out_h3, smem));
             DfxKScope ks(DFX_K_GGEMM, st);
-            dfx_launch(dfx_k_df_out_h3, dim3((unsigned)nn_grid(dfx_ceil_div(M, 16), 2)), dim3(DFX_DFO_THREADS), smem, st, A);
+            // (weight fragments resident in registers when a wave's share fits: <= 16 groups of <= 4 tiles — every shipped shape)
+            const bool resident = m->dfo_nu == 4 && A.G <= 16 && (int64_t)(NO / 2) * 16 * (Fd / 2) <= (int64_t)DFX_DFO_NPT * DFX_DFO_THREADS;
+            if (resident) {
+                DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_df_out_h3r<4>, smem));
+                dfx_launch(dfx_k_df_out_h3r<4>, dim3((unsigned)nn_grid(dfx_ceil_div(M, 16), 2)), dim3(DFX_DFO_THREADS), smem, st, A);
+            } else {
+                DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_df_out_h3, smem));
+                dfx_launch(dfx_k_df_out_h3, dim3((unsigned)nn_grid(dfx_ceil_div(M, 16), 2)), dim3(DFX_DFO_THREADS), smem, st, A);
+            }
             DFX_LAUNCH_CHECK();
             return DFX_OK;
         }

@@ -2777,6 +2777,131 @@ __global__ void __launch_bounds__(DFX_DFO_THREADS, 2) dfx_k_df_out_h3(DfxDfOutAr
     if (amax >= DFX_H3_LIMIT && A.err) dfx_raise(A.err + 1);
 }
 
+// dfx_k_df_out_h3r<NU> (round 6): the same kernel with the wave's weight fragments RESIDENT in registers (<= 4 groups per wave x NU tiles x hi / lo =
+// 128 registers at NU = 4: two waves per SIMD have 256 each) and a tile's operand rows requested in one batch.  dfx_k_df_out_h3 asks for a group's rows when
+// it reaches the group and for every tile's fragments one tile ahead: per 16-frame tile a wave waited out four row latencies and sixteen L2 latencies — ~24 us
+// per tile for ~2 us of arithmetic, 3.6 of the 8 TB/s.  Here the operand rows of all four groups are in flight at once, the prior c0p values are requested in one batch
+// behind the arithmetic (into the registers the rows have left), and the loop over the tile's fragments reads registers only.  Same expressions, same order: same bits.
+template <int NU>
+__global__ void __launch_bounds__(DFX_DFO_THREADS, 2) dfx_k_df_out_h3r(DfxDfOutArgs A) {
+    constexpr int GW = 4;   // groups per wave (G <= 4 GW: host)
+    DFX_DYN_SMEM(float, img);   // [O][16][RS] then the 16 rows' (clip, frame)
+    const int tid = threadIdx.x, lane = tid & 63, wave = dfx_wave_uniform(tid >> 6), q = lane >> 4, jl = lane & 15;
+    const int O = A.NO / 2, RS = 2 * A.Fd + 4, K = A.G * A.Kg;
+    int *rows = reinterpret_cast<int *>(img + (size_t)O * 16 * RS);   // [16][2]: clip, frame (-1: beyond R)
+    float amax = 0.f;
+    const int64_t ntiles = (A.R + 15) >> 4;
+    const int F4 = A.Fd / 2, NP4 = O * 16 * F4;   // float4s per output row, float4s of a tile's output rows (<= DFX_DFO_NPT * DFX_DFO_THREADS: host)
+    dfx_h8 wr[GW][NU][2];
+#pragma unroll
+    for (int gi = 0; gi < GW; ++gi) {
+        const int g = wave + 4 * gi, gc = g < A.G ? g : 0;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            wr[gi][u][0] = A.wf[(((size_t)gc * NU + u) * 2 + 0) * 64 + lane];
+            wr[gi][u][1] = A.wf[(((size_t)gc * NU + u) * 2 + 1) * 64 + lane];
+        }
+    }
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t m = tile * 16 + jl;
+        const bool live = m < A.R;
+        const int64_t r = live ? dfx_row(A.rm, m) : 0;
+        // ---- the operand rows of the wave's groups: lane (frame jl, q) feeds k = 8 q .. 8 q + 7 of a group's Kg inputs (Kg % 8 == 0: host)
+        float4 xa[GW][2], xb[GW][2];
+        const bool feeds = live && 8 * q < A.Kg;
+#pragma unroll
+        for (int gi = 0; gi < GW; ++gi) {
+            const int g = wave + 4 * gi;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            xa[gi][0] = xa[gi][1] = xb[gi][0] = xb[gi][1] = z;
+            if (feeds && g < A.G) {
+                const float4 *p = reinterpret_cast<const float4 *>(A.a + r * K + g * A.Kg + 8 * q);
+                xa[gi][0] = p[0], xa[gi][1] = p[1];
+                if (A.a2) {
+                    const float4 *p2 = reinterpret_cast<const float4 *>(A.a2 + r * K + g * A.Kg + 8 * q);
+                    xb[gi][0] = p2[0], xb[gi][1] = p2[1];
+                }
+            }
+        }
+        if (tid < 16) {
+            const uint32_t cb = (uint32_t)r / (uint32_t)A.T;
+            rows[2 * tid] = live ? (int)cb : -1;
+            rows[2 * tid + 1] = (int)((uint32_t)r - cb * (uint32_t)A.T);
+        }
+        __syncthreads();
+        // this thread's pieces of the write-out: element offsets (B * O * T * 2 Fd < 2^31: host)
+        int tq = tid, qq = q, jq = jl;   // (opaque per tile: the ~50 tile-invariant LDS / row addresses derived from them are recomputed, not held across the tile loop — no scratch)
+        DFX_OPAQUE(tq);
+        DFX_OPAQUE(qq);
+        DFX_OPAQUE(jq);
+        auto piece_off = [&](int k) -> unsigned {
+            const int idx = tq + DFX_DFO_THREADS * k;
+            if (idx >= NP4) return 0xffffffffu;
+            const int row = idx / F4, c4 = idx - row * F4, n = row >> 4, i = row & 15;
+            const int cb = rows[2 * i];
+            if (cb < 0) return 0xffffffffu;
+            return (((unsigned)cb * (unsigned)O + (unsigned)n) * (unsigned)A.T + (unsigned)rows[2 * i + 1]) * (unsigned)(2 * A.Fd) + 4u * (unsigned)c4;
+        };
+#pragma unroll
+        for (int gi = 0; gi < GW; ++gi) {
+            const int g = wave + 4 * gi;
+            if (g < A.G) {
+                float x[8];
+                float4 v0 = xa[gi][0], v1 = xa[gi][1];
+                if (A.a2) {
+                    const float4 w0 = xb[gi][0], w1 = xb[gi][1];
+                    v0 = make_float4(v0.x + w0.x, v0.y + w0.y, v0.z + w0.z, v0.w + w0.w);
+                    v1 = make_float4(v1.x + w1.x, v1.y + w1.y, v1.z + w1.z, v1.w + w1.w);
+                }
+                x[0] = v0.x, x[1] = v0.y, x[2] = v0.z, x[3] = v0.w, x[4] = v1.x, x[5] = v1.y, x[6] = v1.z, x[7] = v1.w;
+                dfx_h8 xh, xl;
+                dfx_split8_g(x, xh, xl, amax);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const dfx_h8 ch = wr[gi][u][0], cl = wr[gi][u][1];
+                    f32x4 d = dfx_mfma_16x16x32_f16(cl, xh, f32x4{0.f, 0.f, 0.f, 0.f});
+                    d = dfx_mfma_16x16x32_f16(ch, xl, d);
+                    d = dfx_mfma_16x16x32_f16(ch, xh, d);
+                    // D: lane (frame jl, q) holds outputs 16 u + 4 q + r of the group = flat index o = g Ng + 16 u + 4 q + r -> (bin o / NO, value o % NO)
+#pragma unroll
+                    for (int r2 = 0; r2 < 4; r2 += 2) {
+                        const int ol = 16 * u + 4 * qq + r2;
+                        if (ol < A.Ng) {   // (Ng and NO even: a pair (re, im) never straddles)
+                            const int o = g * A.Ng + ol, f = o / A.NO, i = o - f * A.NO;
+                            *reinterpret_cast<float2 *>(img + ((size_t)(i >> 1) * 16 + jq) * RS + 2 * f) =
+                                make_float2(dfx_act(d[r2] * A.unscale, DFX_ACT_TANH), dfx_act(d[r2 + 1] * A.unscale, DFX_ACT_TANH));
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- write-out: row (tap n, frame i) = 2 Fd floats, + c0p, coalesced 16-byte accesses; c0p in two batches of DFX_DFO_NPT / 2 loads behind the
+        // tile's arithmetic (a whole tile's values in flight beside the operand rows and the resident fragments do not fit 256 registers)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float4 cv[DFX_DFO_NPT / 2];
+#pragma unroll
+            for (int k = 0; k < DFX_DFO_NPT / 2; ++k) {
+                const unsigned off = piece_off(h * (DFX_DFO_NPT / 2) + k);
+                cv[k] = *reinterpret_cast<const float4 *>(A.c0p + (off != 0xffffffffu ? off : 0u));
+            }
+#pragma unroll
+            for (int k = 0; k < DFX_DFO_NPT / 2; ++k) {
+                const int kk = h * (DFX_DFO_NPT / 2) + k;
+                const unsigned off = piece_off(kk);
+                if (off != 0xffffffffu) {
+                    const int idx = tq + DFX_DFO_THREADS * kk, row = idx / F4, c4 = idx - row * F4;
+                    const float4 v = *reinterpret_cast<const float4 *>(img + (size_t)row * RS + 4 * c4);
+                    *reinterpret_cast<float4 *>(A.out + off) = make_float4(v.x + cv[k].x, v.y + cv[k].y, v.z + cv[k].z, v.w + cv[k].w);
+                }
+            }
+        }
+        __syncthreads();   // the image and the row table are rewritten by the next tile
+    }
+    if (amax >= DFX_H3_LIMIT && A.err) dfx_raise(A.err + 1);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Dense projection with a weight-stationary LDS tile:  out[m, n] = sum_k a[m, k] * w[k, n] + bias[n]   (K = 256).
 // Used for the GRU input projections W_ih x + b (5 launches of [B*T, 256] x [256, 768] — 60 % of all GEMM flops).
