@@ -2802,6 +2802,10 @@ __global__ void __launch_bounds__(DFX_DFO_THREADS, 2) dfx_k_df_out_h3r(DfxDfOutA
             wr[gi][u][1] = A.wf[(((size_t)gc * NU + u) * 2 + 1) * 64 + lane];
         }
     }
+    // this thread's pieces of a tile's write-out, idx = tid + 256 k -> (output row idx / F4, float4 column idx % F4): the first one by division, once; piece
+    // k + 1 from piece k by adding 256 = da * F4 + db (the divisions by the run-time row length were a quarter of the kernel's vector instructions when every
+    // piece of every tile repeated them: the kernel is VALU-bound, ~800 vector instructions per frame)
+    const int row0 = tid / F4, col0 = tid - row0 * F4, da = DFX_DFO_THREADS / F4, db = DFX_DFO_THREADS - da * F4;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t m = tile * 16 + jl;
         const bool live = m < A.R;
@@ -2830,17 +2834,18 @@ __global__ void __launch_bounds__(DFX_DFO_THREADS, 2) dfx_k_df_out_h3r(DfxDfOutA
         }
         __syncthreads();
         // this thread's pieces of the write-out: element offsets (B * O * T * 2 Fd < 2^31: host)
-        int tq = tid, qq = q, jq = jl;   // (opaque per tile: the ~50 tile-invariant LDS / row addresses derived from them are recomputed, not held across the tile loop — no scratch)
-        DFX_OPAQUE(tq);
+        int qq = q, jq = jl;   // (opaque per tile: the ~50 tile-invariant LDS / row addresses derived from them are recomputed, not held across the tile loop — no scratch)
         DFX_OPAQUE(qq);
         DFX_OPAQUE(jq);
-        auto piece_off = [&](int k) -> unsigned {
-            const int idx = tq + DFX_DFO_THREADS * k;
-            if (idx >= NP4) return 0xffffffffu;
-            const int row = idx / F4, c4 = idx - row * F4, n = row >> 4, i = row & 15;
+        auto piece_off = [&](int row, int c4) -> unsigned {   // element offset of (tap n = row / 16, frame i = row % 16, column c4) in c0p / out
+            const int n = row >> 4, i = row & 15;
             const int cb = rows[2 * i];
-            if (cb < 0) return 0xffffffffu;
+            if (row >= 16 * O || cb < 0) return 0xffffffffu;
             return (((unsigned)cb * (unsigned)O + (unsigned)n) * (unsigned)A.T + (unsigned)rows[2 * i + 1]) * (unsigned)(2 * A.Fd) + 4u * (unsigned)c4;
+        };
+        auto piece_next = [&](int &row, int &c4) {
+            row += da, c4 += db;
+            if (c4 >= F4) c4 -= F4, row += 1;
         };
 #pragma unroll
         for (int gi = 0; gi < GW; ++gi) {
@@ -2878,22 +2883,26 @@ __global__ void __launch_bounds__(DFX_DFO_THREADS, 2) dfx_k_df_out_h3r(DfxDfOutA
         __syncthreads();
         // ---- write-out: row (tap n, frame i) = 2 Fd floats, + c0p, coalesced 16-byte accesses; c0p in two batches of DFX_DFO_NPT / 2 loads behind the
         // tile's arithmetic (a whole tile's values in flight beside the operand rows and the resident fragments do not fit 256 registers)
+        int prow = row0, pcol = col0;
+        DFX_OPAQUE(prow);
+        DFX_OPAQUE(pcol);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             float4 cv[DFX_DFO_NPT / 2];
+            unsigned off[DFX_DFO_NPT / 2];
+            int lrow[DFX_DFO_NPT / 2];   // (row << 8 | column: where the piece sits in the LDS image)
 #pragma unroll
             for (int k = 0; k < DFX_DFO_NPT / 2; ++k) {
-                const unsigned off = piece_off(h * (DFX_DFO_NPT / 2) + k);
-                cv[k] = *reinterpret_cast<const float4 *>(A.c0p + (off != 0xffffffffu ? off : 0u));
+                off[k] = piece_off(prow, pcol);
+                lrow[k] = (prow << 8) | pcol;
+                piece_next(prow, pcol);
+                cv[k] = *reinterpret_cast<const float4 *>(A.c0p + (off[k] != 0xffffffffu ? off[k] : 0u));
             }
 #pragma unroll
             for (int k = 0; k < DFX_DFO_NPT / 2; ++k) {
-                const int kk = h * (DFX_DFO_NPT / 2) + k;
-                const unsigned off = piece_off(kk);
-                if (off != 0xffffffffu) {
-                    const int idx = tq + DFX_DFO_THREADS * kk, row = idx / F4, c4 = idx - row * F4;
-                    const float4 v = *reinterpret_cast<const float4 *>(img + (size_t)row * RS + 4 * c4);
-                    *reinterpret_cast<float4 *>(A.out + off) = make_float4(v.x + cv[k].x, v.y + cv[k].y, v.z + cv[k].z, v.w + cv[k].w);
+                if (off[k] != 0xffffffffu) {
+                    const float4 v = *reinterpret_cast<const float4 *>(img + (size_t)(lrow[k] >> 8) * RS + 4 * (lrow[k] & 255));
+                    *reinterpret_cast<float4 *>(A.out + off[k]) = make_float4(v.x + cv[k].x, v.y + cv[k].y, v.z + cv[k].z, v.w + cv[k].w);
                 }
             }
         }

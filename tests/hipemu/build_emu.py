@@ -2,6 +2,7 @@
 the fiber-based SIMT interpreter in tests/hipemu/dfx_env.h.  Test infrastructure only — the package never loads it."""
 from __future__ import annotations
 
+import fcntl
 import os
 import subprocess
 import sys
@@ -22,6 +23,15 @@ def _deps():
 
 
 def build(force: bool = False) -> str:
+    # one builder at a time (pytest-xdist workers import this side by side; two of them compiling into the same object files, or one renaming the
+    # library the other has just linked, failed a worker now and then): whoever comes second finds the library up to date
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    with open(OUT + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build_locked(force)
+
+
+def _build_locked(force: bool) -> str:
     stamp = OUT + ".sources"
     try:
         with open(stamp) as f:
