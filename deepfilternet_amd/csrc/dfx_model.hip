@@ -486,6 +486,7 @@ struct dfx_model {
     bool fuse_erb = true;
     // persistent GRU phase (dfx_k_gru_seq): flag words [ready: 8][emb: 1][pad][done: 8 * DFX_SEQ_GMAX], monotonic over the model's life
     unsigned int *d_sync = nullptr;
+    unsigned int *d_psync = nullptr;    // pair form of the persistent GRU phase: [DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX / 2][48] words
     mutable unsigned int seq_pbase = 0;       // step counter base of the follower hand-overs (yprog / giprog), monotonic like seq_base
     mutable int64_t passes_seq = 0, passes_ev = 0;   // passes that ran the persistent phase / that gave it up because another process held the device's ticket (DFX_Q_TICKET_*)
     mutable unsigned int seq_base = 0;  // flag value of "nothing of the current forward pass yet"
@@ -500,6 +501,7 @@ struct dfx_model {
         int chunks = 0, ramp = 0;       // DFX_SEQ_CHUNKS (0: 12, or 16 without followers), DFX_SEQ_RAMP
         bool publish = true;            // DFX_SEQ_PUBLISH
         bool xcd_light = true;          // DFX_SEQ_XCD_LIGHT
+        bool gru_pair = true;           // DFX_GRU_PAIR=0: every 16-clip group's recurrence on one CU (W_hh streamed from the L2) instead of 32 clips on a pair of CUs (dfx_gru_pair.h)
         int convp_late = -1;            // DFX_CONVP_LATE (percent)
         int convp_after_p0 = -1;        // DFX_CONVP_AFTER_P0
         int p0_ahead = 3;               // DFX_SEQ_P0_AHEAD
@@ -1207,6 +1209,10 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         m->c0_batch_unfused = m->exact_fp32 && m->fuse_c0;
         m->fuse_erb = true;
         const char *gq = getenv("DFX_GRU_SEQ");
+        {
+            const char *gp = getenv("DFX_GRU_PAIR");
+            if (gp) m->sw.gru_pair = gp[0] != '0';
+        }
         m->gru_seq = !(gq && gq[0] == '0') && !dfx_env_is_emulator();
         m->fuse_emb = m->fuse_encfan = m->fuse_dfa = m->fuse_tail = m->e0_recompute = m->fuse_dfenc = m->dfout_lean = true;
         const char *cep = getenv("DFX_CHECK_EVERY_PASS"), *spl = getenv("DFX_SYNC_SPIN_LIMIT");
@@ -1235,7 +1241,9 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         // ready 0-7 | emb 8 | probe 13 | done 16- | producers' completion counters (DfxPublish): 9 words (16) | yprog, giprog: steps per (layer, group)
         // | XCD registrations [3 kinds][layers][groups] (DfxXcd) | 64 words: [0] light hand-overs counted (dev aid), [8..48) the followers' claim counters
         const size_t sync_bytes = (size_t)(16 + DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX + 16 + 2 * DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX + 3 * DFX_MAX_GRU_LAYERS * DFX_SEQ_GMAX + 64) * sizeof(unsigned int);
-        if (hipMalloc(reinterpret_cast<void **>(&m->d_sync), sync_bytes) != hipSuccess || hipMemset(m->d_sync, 0, sync_bytes) != hipSuccess ||
+        const size_t psync_bytes = (size_t)DFX_MAX_GRU_LAYERS * (DFX_SEQ_GMAX / 2) * 48 * sizeof(unsigned int);
+        if (hipMalloc(reinterpret_cast<void **>(&m->d_psync), psync_bytes) != hipSuccess || hipMemset(m->d_psync, 0, psync_bytes) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&m->d_sync), sync_bytes) != hipSuccess || hipMemset(m->d_sync, 0, sync_bytes) != hipSuccess ||
             dfx_env_err_words_alloc(&m->h_err, &m->d_err, 256) != hipSuccess) {
             dfx_model_free(m);
             DFX_FAIL(DFX_ERR_ALLOC, "dfx_model_create: device allocation failed");
@@ -1294,6 +1302,7 @@ extern "C" void dfx_model_free(dfx_model *m) {
         if (hipMemcpy(&n, m->d_sync + off, sizeof(n), hipMemcpyDeviceToHost) == hipSuccess) fprintf(stderr, "[dfx] same-XCD (light) block hand-overs over the model's life: %u\n", n);
     }
     if (m->d_sync) (void)hipFree(m->d_sync);
+    if (m->d_psync) (void)hipFree(m->d_psync);
     if (m->d_trace) (void)hipFree(m->d_trace);
     if (m->d_w) (void)hipFree(m->d_w);
     delete m;

@@ -529,7 +529,9 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                     for (int l = 0; l < nl; ++l) followed[l] = false;
                 }
             }
-            if (nfollow) m->seq_pbase += (unsigned int)T + 1u;
+            // the recurrences on pairs of CUs (dfx_gru_pair.h): 32 clips per pair, W_hh resident; fp16-split arithmetic only (the exact form's fragments are the same bytes, its matrix ops are not)
+            const bool use_pair = m->sw.gru_pair && !m->exact_fp32 && groups >= 2 && m->d_psync;
+            if (nfollow || use_pair) m->seq_pbase += (unsigned int)T + 1u;
             auto proj_chunk = [&](const GruW &g, int l, int k, const float *xin, hipStream_t st) -> int {
                 const unsigned int val = base + (unsigned int)k + 1u;
                 if (m->exact_fp32 || !publish) {
@@ -573,7 +575,8 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 S.trace = m->d_trace;
                 S.spin_limit = m->spin_limit;
                 S.pbase = pbase, S.sblk = 16;
-                if (xtab) S.xtab = xtab, S.xstride = DFX_SEQ_GMAX, S.xtag = xtag, S.xstat = xstat;
+                if (xtab) S.xtab = xtab, S.xstride = DFX_SEQ_GMAX, S.xstat = xstat;
+                S.xtag = xtag, S.psync = m->d_psync;
                 for (int l = 1; l < nl; ++l) {
                     if (!followed[l]) continue;
                     S.giprog[l] = giprog + (size_t)l * DFX_SEQ_GMAX;
@@ -584,9 +587,11 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                     S.xcons_kind[src] = first ? 2 : 1, S.xcons_layer[src] = first ? 0 : l;
                 }
                 m->trace_dims[0] = nl, m->trace_dims[1] = groups, m->trace_dims[2] = K;
-                DFX_HIP(dfx_env_set_max_dyn_smem(m->exact_fp32 ? (const void *)dfx_k_gru_seq_x32 : (const void *)dfx_k_gru_seq, DFX_GH_SMEM));
+                if (use_pair) DFX_HIP(dfx_env_set_max_dyn_smem((const void *)dfx_k_gru_seq_p2, DFX_GP_SMEM));
+                else DFX_HIP(dfx_env_set_max_dyn_smem(m->exact_fp32 ? (const void *)dfx_k_gru_seq_x32 : (const void *)dfx_k_gru_seq, DFX_GH_SMEM));
                 DfxKScope ks(DFX_K_GRU_REC, G);
-                if (m->exact_fp32) dfx_launch(dfx_k_gru_seq_x32, dim3((unsigned)(nl * groups)), dim3(DFX_GH_THREADS), DFX_GH_SMEM, G, S);
+                if (use_pair) dfx_launch(dfx_k_gru_seq_p2, dim3(dfx_gp_grid(nl * (int)((groups + 1) / 2))), dim3(DFX_GP_THREADS), DFX_GP_SMEM, G, S);
+                else if (m->exact_fp32) dfx_launch(dfx_k_gru_seq_x32, dim3((unsigned)(nl * groups)), dim3(DFX_GH_THREADS), DFX_GH_SMEM, G, S);
                 else dfx_launch(dfx_k_gru_seq, dim3((unsigned)(nl * groups)), dim3(DFX_GH_THREADS), DFX_GH_SMEM, G, S);
                 DFX_LAUNCH_CHECK();
             }

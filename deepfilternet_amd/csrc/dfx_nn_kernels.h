@@ -4485,6 +4485,7 @@ struct DfxGsArgs {
     int xcons_kind[DFX_GS_MAX_LAYERS] = {}, xcons_layer[DFX_GS_MAX_LAYERS] = {};   // who consumes layer l's yprog blocks
     unsigned int xtag = 0;
     unsigned int *xstat = nullptr;
+    unsigned int *psync = nullptr;   // pair form (dfx_k_gru_seq_p2, dfx_gru_pair.h): [nlayers * pairs per layer][48] step flags and XCD words of the pairs' halves
 };
 template <bool X32>
 static __device__ __forceinline__ void dfx_gru_seq_body(const DfxGsArgs &S) {
@@ -4521,6 +4522,8 @@ static __device__ __forceinline__ void dfx_gru_seq_body(const DfxGsArgs &S) {
 }
 __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_seq(DfxGsArgs S) { dfx_gru_seq_body<false>(S); }
 __global__ void __launch_bounds__(DFX_GH_THREADS, DFX_GH_NW / 4) dfx_k_gru_seq_x32(DfxGsArgs S) { dfx_gru_seq_body<true>(S); }
+
+#include "dfx_gru_pair.h"   // the recurrence on a pair of CUs (W_hh fully resident, h exchanged per step through the XCD's L2)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // dfx_k_proj_follow: the input projection of a decoder GRU layer as persistent FOLLOWER workgroups of the recurrences instead of one launch
