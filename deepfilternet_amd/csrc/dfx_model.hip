@@ -1232,6 +1232,7 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
             if ((v = getenv("DFX_SEQ_DFTAIL_EVERY")) && atoi(v) > 0) m->sw.dftail_every = atoi(v);
             if ((v = getenv("DFX_SEQ_TAIL_EVERY")) && atoi(v) > 0) m->sw.tail_every = atoi(v);
             if ((v = getenv("DFX_SEQ_CHUNKS")) && atoi(v) > 0) m->sw.chunks = atoi(v);
+            if ((v = getenv("DFX_CONVP_LATE")) && atoi(v) >= 0) m->sw.convp_late = atoi(v);
         }
 #endif
         {
