@@ -388,11 +388,15 @@ def main() -> None:
         rooflines[fin_name]["note"] = ("read X 3848 + coefficients 3840 + gains 128, write 1920 bytes of audio per frame; the enhanced spectrum "
                                        "(7696 B per frame written + read back by the two-kernel form) never exists in HBM")
     nlayers = 1 + (p.emb_num_layers - 1) + p.df_num_layers
+    pair_form = os.environ.get("DFX_GRU_PAIR", "1")[:1] != "0" and B > 16 and os.environ.get("DFX_EXACT_FP32", "0")[:1] != "1"
     flop_step = 2.0 * B * 256 * 768          # h[B,256] x W_hh^T[256,768] per time step and layer (fp32-equivalent flops)
     gru = {"kernel": "dfx_k_gru_rec_h3", "bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MATRIX_PEAK_TF, "peak_f16_mfma": F16_MFMA_PEAK_TF,
            "flop_per_step_and_layer": flop_step, "layers": nlayers, "steps_per_layer": Tf,
            "note": "fp32-equivalent flops; the kernel issues 3 f16 MFMA flops per flop (fp16-split). One layer = B/16 workgroups (16 CUs at B=256): "
-                   "a sequential chain, latency-bound by construction; 'frac' prices one layer-kernel against the whole chip's fp32 matrix peak"}
+                   "a sequential chain, latency-bound by construction; 'frac' prices one layer-kernel against the whole chip's fp32 matrix peak. "
+                   "'alone' is the one-CU-per-16-clips launch form of the serialised step (W_hh streamed from the L2); 'under_load' is the persistent "
+                   "launch of the timed path: " + ("dfx_k_gru_seq_p2, pairs of CUs per 32 clips with W_hh resident and h exchanged every step (csrc/dfx_gru_pair.h)"
+                                                   if pair_form else "dfx_k_gru_seq, one CU per 16 clips")}
     if "dfx_k_gru_rec" in serial and serial["dfx_k_gru_rec"][1]:
         us_alone = serial["dfx_k_gru_rec"][0] * 1e3 / (nlayers * Tf)
         gru["alone"] = {"us_per_step": round(us_alone, 3), "achieved": round(flop_step / us_alone / 1e6, 2),
@@ -585,7 +589,7 @@ def main() -> None:
                               "the kernels that are running; every step of the timed loop still runs to completion inside the timed region",
                     "ms_per_step_with_free_enqueue_ahead": ahead_ms, "switch": "DFX_ENQUEUE_AHEAD=1"},
         "host_io": host_io,
-        "gru_phase_form": ("persistent flag-synchronised launch (dfx_k_gru_seq)" if gru_persistent else "event-synchronised launches per (layer, time chunk)"),
+        "gru_phase_form": (("persistent flag-synchronised launch (dfx_k_gru_seq_p2: recurrences on pairs of CUs)" if os.environ.get("DFX_GRU_PAIR", "1")[:1] != "0" and B > 16 else "persistent flag-synchronised launch (dfx_k_gru_seq)") if gru_persistent else "event-synchronised launches per (layer, time chunk)"),
         "roofline": roofline, "rooflines": rooflines, "configs": configs, "cpu_baseline": cpu, "parity": parity, "kernels": kern,
         "realtime_factor": frames / dt / 100.0,
     }

@@ -34,9 +34,6 @@
 #ifndef DFX_GP_ABLATE
 #define DFX_GP_ABLATE 0   /* dev (tools/dev/gru_p2_bench.hip): 1 no partner wait / load, 2 no gate math, 4 no matrix ops, 8 no drain */
 #endif
-#ifndef DFX_GP_OWN_FIRST
-#define DFX_GP_OWN_FIRST 0   /* a half contracts its OWN units' k-chunks first, while the partner's half of h travels (half 1: k-chunks 4-7, then 0-3) */
-#endif
 #ifndef DFX_GP_TRACE
 #define DFX_GP_TRACE 0    /* dev: thread 0 of every workgroup sums the shader-clock ticks between the phases of a step into DfxGpSync::ptrace[block][8] */
 #endif
@@ -99,6 +96,7 @@ struct DfxGpSync {
     const unsigned int *xprod[2] = {nullptr, nullptr};    // ... of the followers that feed the two groups
     const unsigned int *xcons = nullptr;                  // ... of the follower that consumes group 2 pg + p's rows
     unsigned long long *ptrace = nullptr;                 // dev (DFX_GP_TRACE)
+    int far = 0;                                          // test hook (DFX_GRU_PAIR_FAR=1): treat every partner / follower as if it sat on another XCD (the agent-scope forms)
 };
 
 template <bool SEQ>
@@ -121,8 +119,7 @@ static __device__ __forceinline__ void dfx_gru_p2_run(const DfxGhArgs &A, int64_
     const int ubase = 128 * half + 32 * wave;   // this wave's first unit
     // fragment f = kc*TILES + gate*NS + s of this wave is global pair ((unit tile = 8 half + 2 wave + s)*8 + kc)*3 + gate  (DfxGhArgs::whf)
     const dfx_h8 *wg = A.whf + lane;
-    // (DFX_GP_OWN_FIRST: position p of the consumption order is k-chunk (p + 4 half) mod 8)
-#define DFX_GP_GIDX(f) (((((size_t)(8 * half + NS * wave + DFX_GP_POS_S(f))) * 8 + ((DFX_GP_POS_KC(f) + (DFX_GP_OWN_FIRST ? 4 * half : 0)) & 7)) * 3 + DFX_GP_POS_GATE(f)) * 2 * 64)
+#define DFX_GP_GIDX(f) (((((size_t)(8 * half + NS * wave + DFX_GP_POS_S(f))) * 8 + DFX_GP_POS_KC(f)) * 3 + DFX_GP_POS_GATE(f)) * 2 * 64)
     dfx_h8 wr[DFX_GP_FR][2];
     dfx_static_for<0, NF>([&](auto fc) {
         constexpr int f = decltype(fc)::value;
@@ -177,7 +174,7 @@ static __device__ __forceinline__ void dfx_gru_p2_run(const DfxGhArgs &A, int64_
             }
             __builtin_amdgcn_s_sleep(2);
         }
-        sflag[0] = (!dead && v == me) ? 1 : 0;
+        sflag[0] = (!dead && v == me && !Y.far) ? 1 : 0;
         sflag[1] = 0;
         if (Y.stat && half == 0 && v != me) __hip_atomic_fetch_add(Y.stat + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -230,230 +227,12 @@ static __device__ __forceinline__ void dfx_gru_p2_run(const DfxGhArgs &A, int64_
             }
             same = same && Y.xprod[i] && __hip_atomic_load(Y.xprod[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (Y.tag | (unsigned int)(dfx_xcc_id() + 1));
         }
-        sflag[1] = same ? 1 : 0;
+        sflag[1] = same && !Y.far ? 1 : 0;
     };
 #if DFX_GP_TRACE
     unsigned long long tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
 #endif
-#if DFX_GP_OWN_FIRST
-    const int nchunk = SEQ ? Y.K : 1;
-    // ---- own units first: while the partner's half of h(t) travels, this half already contracts the k-chunks of its own units
-    const unsigned char *const hb = reinterpret_cast<const unsigned char *>(h16 + (size_t)jl * HROW + 8 * q);
-    constexpr size_t HB_N = (size_t)16 * HROW * 2, HB_LO = (size_t)ROWS * HROW * 2, HB_KSTEP = 32 * 2;
-    const unsigned char *const hb_own = hb + 4 * HB_KSTEP * half, *const hb_par = hb + 4 * HB_KSTEP * (half ^ 1);
-    f32x4 acc[2][TILES];
-    dfx_h8 bh[2][2], bl[2][2];     // [position parity][clip tile]
-    dfx_h8 lhi[2][3], llo[2][3];   // LDS-resident fragments of the current / next group
-    auto load_b = [&](auto pc) {   // the B fragments of position p
-        constexpr int p = decltype(pc)::value;
-        const unsigned char *src = (p < 4 ? hb_own : hb_par) + HB_KSTEP * (p & 3);
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            bh[p & 1][n] = *reinterpret_cast<const dfx_h8 *>(src + HB_N * n);
-            bl[p & 1][n] = *reinterpret_cast<const dfx_h8 *>(src + HB_N * n + HB_LO);
-        }
-    };
-    auto load_l = [&](auto gc) {   // the LDS-resident weight fragments of group grp
-        constexpr int grp = decltype(gc)::value;
-        dfx_static_for<0, 3>([&](auto ic) {
-            constexpr int i = decltype(ic)::value, f = 3 * grp + i;
-            if constexpr (SC.cls[f] == 1) {
-                lhi[grp & 1][i] = wl[((SC.idx[f] * NW + wave) * 2 + 0) * 64 + lane];
-                llo[grp & 1][i] = wl[((SC.idx[f] * NW + wave) * 2 + 1) * 64 + lane];
-            }
-        });
-    };
-    // positions [P0, P1) of the consumption order: per position two groups of three fragments x two clip tiles = 18 matrix ops each, consecutive ones on
-    // different accumulators; the B fragments of the next position are requested a position ahead unless it is the partner's first (not there yet)
-    auto mfma_range = [&](auto p0c, auto p1c) {
-        constexpr int P0 = decltype(p0c)::value, P1 = decltype(p1c)::value;
-        dfx_static_for<2 * P0, 2 * P1>([&](auto gc) {
-            constexpr int grp = decltype(gc)::value, f0 = 3 * grp, p = grp / 2;
-            if constexpr ((grp & 1) == 0 && p + 1 < 8 && p + 1 != 4) load_b(std::integral_constant<int, p + 1>{});
-            if constexpr (grp + 1 < NF / 3) load_l(std::integral_constant<int, grp + 1>{});
-            dfx_h8 whi[3], wlo[3];
-            dfx_static_for<0, 3>([&](auto ic) {
-                constexpr int i = decltype(ic)::value, f = f0 + i;
-                if constexpr (SC.cls[f] == 0) {
-                    whi[i] = wr[SC.idx[f]][0];
-                    wlo[i] = wr[SC.idx[f]][1];
-                } else {
-                    whi[i] = lhi[grp & 1][i];
-                    wlo[i] = llo[grp & 1][i];
-                }
-            });
-            constexpr int ta = DFX_GP_POS_TILE(f0), tb_ = DFX_GP_POS_TILE(f0 + 1), tc = DFX_GP_POS_TILE(f0 + 2);
-            if constexpr (DFX_GP_ABLATE & 4) {
-                acc[0][ta][0] += (float)whi[0][0] + (float)wlo[1][1] + (float)whi[2][0] + (float)bh[p & 1][0][0] + (float)bl[p & 1][1][0];
-                acc[1][tb_][0] += (float)wlo[0][0] + (float)whi[1][1] + (float)wlo[2][0] + (float)bh[p & 1][1][0] + (float)bl[p & 1][0][0];
-            } else {
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    acc[n][ta] = dfx_mfma_16x16x32_f16(wlo[0], bh[p & 1][n], acc[n][ta]);
-                    acc[n][tb_] = dfx_mfma_16x16x32_f16(wlo[1], bh[p & 1][n], acc[n][tb_]);
-                    acc[n][tc] = dfx_mfma_16x16x32_f16(wlo[2], bh[p & 1][n], acc[n][tc]);
-                }
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    acc[n][ta] = dfx_mfma_16x16x32_f16(whi[0], bl[p & 1][n], acc[n][ta]);
-                    acc[n][tb_] = dfx_mfma_16x16x32_f16(whi[1], bl[p & 1][n], acc[n][tb_]);
-                    acc[n][tc] = dfx_mfma_16x16x32_f16(whi[2], bl[p & 1][n], acc[n][tc]);
-                }
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    acc[n][ta] = dfx_mfma_16x16x32_f16(whi[0], bh[p & 1][n], acc[n][ta]);
-                    acc[n][tb_] = dfx_mfma_16x16x32_f16(whi[1], bh[p & 1][n], acc[n][tb_]);
-                    acc[n][tc] = dfx_mfma_16x16x32_f16(whi[2], bh[p & 1][n], acc[n][tc]);
-                }
-            }
-            DFX_SCHED_BARRIER();
-        });
-    };
-    // the partner's half of row t (four 16-byte pieces per thread) -> f16 hi / lo in the LDS
-    auto partner_row = [&](int64_t t, bool with_gi, int64_t tg) {
-        float4 o[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = *reinterpret_cast<const float4 *>(ypo[i] + t * H);
-        DFX_SCHED_BARRIER();
-        if (with_gi) load_gi(tg);   // (behind the partner's pieces: vector loads return in order, and the gi rows may come from HBM)
-        DFX_SCHED_BARRIER();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) put4(prow, pcol + 32 * i, o[i].x, o[i].y, o[i].z, o[i].w);
-    };
-    auto publish_y = [&](int64_t rows) {   // (thread 0) `rows` rows of group 2 pg + p are complete, both halves' units
-        const bool cons_same = Y.xcons && __hip_atomic_load(Y.xcons, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (Y.tag | (unsigned int)(dfx_xcc_id() + 1));
-        if (cons_same) __hip_atomic_store(Y.yprog, Y.pbase + (unsigned int)rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else __hip_atomic_store(Y.yprog, Y.pbase + (unsigned int)rows, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    auto raise_flag = [&](int64_t rows) {   // (thread 0, behind the drain and the barrier) my units of `rows` rows are stored
-        if (light) __hip_atomic_store(fmine, Y.pbase + (unsigned int)rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else __hip_atomic_store(fmine, Y.pbase + (unsigned int)rows, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    auto poll_partner = [&](int64_t rows) {   // (thread 0)
-        const unsigned int want = Y.pbase + (unsigned int)rows;
-        int spins = 0;
-        while (!(DFX_GP_ABLATE & 1) && !dead && (int)(__hip_atomic_load(ftheirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
-            if (++spins > Y.spin_limit) {
-                dfx_raise(Y.err + 2);
-                dead = true;
-                break;
-            }
-        }
-    };
-    for (int ck = 0; ck < nchunk; ++ck) {
-        const int64_t c0 = SEQ ? (int64_t)Y.tb[ck] : A.t0, c1 = SEQ ? (int64_t)Y.tb[ck + 1] : A.t1;
-        if (c1 <= c0) continue;
-        if (SEQ) {   // the input projection of this chunk (layer 0) / of the block that starts here (followed layers) must exist
-            if (tid == 0 && Y.trace) Y.trace[ck * 3 + 0] = wall_clock64();
-            if (tid == 0 && !Y.giprog[0] && Y.ready) {
-                const unsigned int want = Y.base + (unsigned int)ck + 1u;
-                int spins = 0;
-                while (!dead && (int)(__hip_atomic_load(Y.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
-                    if (++spins > Y.spin_limit) {
-                        dfx_raise(Y.err + 2);
-                        dead = true;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(8);
-                }
-            }
-            if (tid == 0 && Y.giprog[0] && (c0 & (Y.sblk - 1)) == 0) poll_gi(c0 + Y.sblk);
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (tid == 0 && Y.trace) Y.trace[ck * 3 + 1] = wall_clock64();
-        }
-        load_gi(c0);
-        for (int64_t t = c0; t < c1; ++t) {
-            const bool first = t == c0;   // both halves of h(t) are in the LDS already (h(0) = 0, or the chunk hand-over below)
-            const bool gi_now = SEQ && !first && Y.giprog[0] && (t & (Y.sblk - 1)) == 0;   // row t opens a block of the followers: wait before it is requested
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int i = 0; i < TILES; ++i) acc[n][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            load_b(std::integral_constant<int, 0>{});
-            load_l(std::integral_constant<int, 0>{});
-            mfma_range(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-            DFX_GP_TICK(0);   // own k-chunk 0
-            if (!first) {     // row t - 1: my units are in the L2 (or released) by now
-                if (!(DFX_GP_ABLATE & 8)) DFX_VMEM_DRAIN();
-                __syncthreads();
-                if (tid == 0) raise_flag(t);
-                if (!gi_now) load_gi(t);
-            }
-            DFX_GP_TICK(1);   // drain, barrier, flag
-            mfma_range(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{});
-            DFX_GP_TICK(2);   // own k-chunks 1-3
-            if (!first) {
-                if (tid == 0) {
-                    poll_partner(t);
-                    if (gi_now) poll_gi(t + Y.sblk);
-                }
-                DFX_GP_TICK(3);   // partner's flag seen
-                __syncthreads();
-                DFX_GP_TICK(4);   // barrier
-                if (light && !(gi_now && sflag[1] == 0)) DFX_L1_INV();
-                else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                if (!(DFX_GP_ABLATE & 1)) partner_row(t - 1, gi_now, t);
-                else if (gi_now) load_gi(t);
-                DFX_GP_TICK(5);   // partner's half loaded, in LDS
-                if (SEQ && tid == 0 && Y.yprog && (t & (Y.yblk - 1)) == 0) publish_y(t);
-            }
-            __syncthreads();
-            DFX_GP_TICK(6);   // barrier
-            load_b(std::integral_constant<int, 4>{});
-            mfma_range(std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{});
-            DFX_GP_TICK(7);   // partner's k-chunks
-            // ---- gates, new state (dfx_gru_h3_run's gate_unit), y
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float gr = r == 0 ? gv[n][0][s].x : r == 1 ? gv[n][0][s].y : r == 2 ? gv[n][0][s].z : gv[n][0][s].w;
-                        const float gz = r == 0 ? gv[n][1][s].x : r == 1 ? gv[n][1][s].y : r == 2 ? gv[n][1][s].z : gv[n][1][s].w;
-                        const float gn = r == 0 ? gv[n][2][s].x : r == 1 ? gv[n][2][s].y : r == 2 ? gv[n][2][s].z : gv[n][2][s].w;
-                        const float bb = r == 0 ? bn[s].x : r == 1 ? bn[s].y : r == 2 ? bn[s].z : bn[s].w;
-                        if (DFX_GP_ABLATE & 2) {
-                            hp[n][s][r] = 0.5f * hp[n][s][r] + 1e-3f * (gr + gz + gn + bb + acc[n][s][r] + acc[n][NS + s][r] + acc[n][2 * NS + s][r]);
-                            continue;
-                        }
-                        const float rg = dfx_fast_rcp(1.f + dfx_fast_exp(-(gr + acc[n][0 * NS + s][r] * A.unscale)));
-                        const float zg = dfx_fast_rcp(1.f + dfx_fast_exp(-(gz + acc[n][1 * NS + s][r] * A.unscale)));
-                        const float pre = gn + rg * (acc[n][2 * NS + s][r] * A.unscale + bb);
-                        const float ng = 2.f * dfx_fast_rcp(1.f + dfx_fast_exp(-2.f * pre)) - 1.f;
-                        hp[n][s][r] = (1.f - zg) * ng + zg * hp[n][s][r];
-                    }
-                    if (valid[n]) *reinterpret_cast<float4 *>(yp[n] + t * H + 16 * s) = make_float4(hp[n][s][0], hp[n][s][1], hp[n][s][2], hp[n][s][3]);
-                    put4(16 * n + jl, ubase + 16 * s + 4 * q, hp[n][s][0], hp[n][s][1], hp[n][s][2], hp[n][s][3]);   // (own region: last read in front of the barriers above)
-                }
-            DFX_GP_TICK(8);   // gates, y stores issued, own half in LDS
-            __syncthreads();
-            DFX_GP_TICK(9);   // barrier
-        }
-        // ---- the chunk's hand-over: rows < c1 complete on both halves (flag, partner's flag), the partner's half of h(c1) in the LDS
-        DFX_VMEM_DRAIN();
-        __syncthreads();
-        if (tid == 0) {
-            raise_flag(c1);
-            poll_partner(c1);
-        }
-        __syncthreads();
-        if (light) DFX_L1_INV();
-        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (c1 < A.T && !(DFX_GP_ABLATE & 1)) partner_row(c1 - 1, false, 0);
-        if (SEQ && tid == 0 && Y.yprog && ((c1 & (Y.yblk - 1)) == 0 || c1 == A.T)) publish_y(c1);
-        if (SEQ) {   // make the pair's rows visible device-wide, then say so
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __syncthreads();
-            if (tid == 0 && Y.done) __hip_atomic_store(Y.done, Y.base + (unsigned int)ck + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            if (tid == 0 && Y.trace) Y.trace[ck * 3 + 2] = wall_clock64();
-        } else {
-            __syncthreads();
-        }
-    }
-#else
     const int nchunk = SEQ ? Y.K : 1;
     for (int ck = 0; ck < nchunk; ++ck) {
         const int64_t c0 = SEQ ? (int64_t)Y.tb[ck] : A.t0, c1 = SEQ ? (int64_t)Y.tb[ck + 1] : A.t1;
@@ -631,7 +410,7 @@ static __device__ __forceinline__ void dfx_gru_p2_run(const DfxGhArgs &A, int64_
             }
             DFX_GP_TICK(6);   // partner's half loaded and in LDS
             if (SEQ && tid == 0 && Y.yprog && (((t + 1) & (Y.yblk - 1)) == 0 || t + 1 == A.T)) {   // a block of group 2 pg + p's rows is complete (both halves' units)
-                const bool cons_same = Y.xcons && __hip_atomic_load(Y.xcons, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (Y.tag | (unsigned int)(dfx_xcc_id() + 1));
+                const bool cons_same = !Y.far && Y.xcons && __hip_atomic_load(Y.xcons, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (Y.tag | (unsigned int)(dfx_xcc_id() + 1));
                 if (cons_same) __hip_atomic_store(Y.yprog, Y.pbase + (unsigned int)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else __hip_atomic_store(Y.yprog, Y.pbase + (unsigned int)(t + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -645,7 +424,6 @@ static __device__ __forceinline__ void dfx_gru_p2_run(const DfxGhArgs &A, int64_
             if (tid == 0 && Y.trace) Y.trace[ck * 3 + 2] = wall_clock64();
         }
     }
-#endif
 #if DFX_GP_TRACE
     if (tid == 0 && Y.ptrace)
         for (int i = 0; i < 12; ++i) Y.ptrace[(size_t)blockIdx.x * 12 + i] = tk[i];
@@ -711,6 +489,7 @@ __global__ void __launch_bounds__(DFX_GP_THREADS, 1) dfx_k_gru_seq_p2(DfxGsArgs 
     Y.trace = S.trace && has ? S.trace + ((size_t)l * S.groups + g) * S.K * 3 : nullptr;
     Y.yprog = S.yprog[l] && has ? S.yprog[l] + g : nullptr;
     Y.sblk = S.sblk, Y.yblk = S.yblk[l] > 0 ? S.yblk[l] : 16;
+    Y.far = S.pair_far;
     for (int i = 0; i < 2; ++i) Y.giprog[i] = S.giprog[l] && 2 * pg + i < S.groups ? S.giprog[l] + 2 * pg + i : nullptr;
     if (S.xtab) {
         auto word = [&](int kind, int layer, int grp) { return S.xtab + ((size_t)kind * DFX_GS_MAX_LAYERS + layer) * S.xstride + grp; };

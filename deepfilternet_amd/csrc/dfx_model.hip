@@ -501,6 +501,7 @@ struct dfx_model {
         int chunks = 0, ramp = 0;       // DFX_SEQ_CHUNKS (0: 12, or 16 without followers), DFX_SEQ_RAMP
         bool publish = true;            // DFX_SEQ_PUBLISH
         bool xcd_light = true;          // DFX_SEQ_XCD_LIGHT
+        bool gru_pair_far = false;      // DFX_GRU_PAIR_FAR=1 (test hook): the pairs' hand-overs in their agent-scope form, as if the halves sat on different XCDs
         bool gru_pair = true;           // DFX_GRU_PAIR=0: every 16-clip group's recurrence on one CU (W_hh streamed from the L2) instead of 32 clips on a pair of CUs (dfx_gru_pair.h)
         int convp_late = -1;            // DFX_CONVP_LATE (percent)
         int convp_after_p0 = -1;        // DFX_CONVP_AFTER_P0
@@ -1212,6 +1213,8 @@ extern "C" int dfx_model_create(const dfx_model_cfg *cfg, const float *blob, dfx
         {
             const char *gp = getenv("DFX_GRU_PAIR");
             if (gp) m->sw.gru_pair = gp[0] != '0';
+            const char *gf = getenv("DFX_GRU_PAIR_FAR");
+            m->sw.gru_pair_far = gf && gf[0] == '1';
         }
         m->gru_seq = !(gq && gq[0] == '0') && !dfx_env_is_emulator();
         m->fuse_emb = m->fuse_encfan = m->fuse_dfa = m->fuse_tail = m->e0_recompute = m->fuse_dfenc = m->dfout_lean = true;

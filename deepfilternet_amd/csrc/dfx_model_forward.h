@@ -576,7 +576,7 @@ static int forward_impl(const dfx_model *m, const dfx_bands *bands, const float 
                 S.spin_limit = m->spin_limit;
                 S.pbase = pbase, S.sblk = 16;
                 if (xtab) S.xtab = xtab, S.xstride = DFX_SEQ_GMAX, S.xstat = xstat;
-                S.xtag = xtag, S.psync = m->d_psync;
+                S.xtag = xtag, S.psync = m->d_psync, S.pair_far = m->sw.gru_pair_far ? 1 : 0;
                 for (int l = 1; l < nl; ++l) {
                     if (!followed[l]) continue;
                     S.giprog[l] = giprog + (size_t)l * DFX_SEQ_GMAX;

@@ -4485,6 +4485,7 @@ struct DfxGsArgs {
     int xcons_kind[DFX_GS_MAX_LAYERS] = {}, xcons_layer[DFX_GS_MAX_LAYERS] = {};   // who consumes layer l's yprog blocks
     unsigned int xtag = 0;
     unsigned int *xstat = nullptr;
+    int pair_far = 0;                // test hook of the pair form: agent-scope hand-overs everywhere
     unsigned int *psync = nullptr;   // pair form (dfx_k_gru_seq_p2, dfx_gru_pair.h): [nlayers * pairs per layer][48] step flags and XCD words of the pairs' halves
 };
 template <bool X32>
